@@ -1,0 +1,331 @@
+"""CPU oracle for the RUMpy convolutional SR hot path (EDSR / RCAN train + eval step).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``rumpy_amd/`` may import this module; only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` do, and
+only as the checker / the reported CPU baseline - never as the thing shipped.
+
+What it is: a plain PyTorch-CPU fp32 restatement of the reference arithmetic.  The reference
+(um-dsrg/RUMpy v1.0) is 100 % Python on PyTorch, so the arithmetic itself lives in the
+third-party dependency ``pytorch>=1.10.0`` (unpinned, reference ``requirements.txt:1``); the
+restatement therefore uses the same ATen CPU ops (conv2d, pixel_shuffle, adaptive mean,
+sigmoid, l1, Adam, cosine warm restarts) wired exactly like the reference modules.
+
+Parity pinning: PINNED.  ``tests/golden/make_golden.py`` imports the real reference from
+``/root/reference`` in the build container (torch 2.10.0 CPU) and stores inputs/outputs of
+its own modules and handlers as fixtures under ``tests/golden/``; ``tests/test_oracle_golden.py``
+checks every function below against them (bit-exact for forward, <=1e-6 for the train step).
+The reference's own tests pin shapes only (automated_testing/sisr_tests/test_model_cpu_execute.py:33-49)
+plus the parameter counts in rumpy/sr_tools/stats.py:238, which are asserted too.
+
+Every builder cites the reference file:line it restates (paths relative to /root/reference).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+# --------------------------------------------------------------------------------------
+# functional building blocks
+# --------------------------------------------------------------------------------------
+def conv3x3(cin, cout, k=3):
+    """rumpy/SISR/models/advanced/common.py:6-9 (default_conv): same-padding conv + bias."""
+    return nn.Conv2d(cin, cout, k, padding=k // 2, bias=True)
+
+
+class ScaledResidualBlock(nn.Module):
+    """rumpy/SISR/models/advanced/common.py:51-75 (ResBlock): x + res_scale * conv(relu(conv(x))).
+
+    state_dict keys ``body.0.*`` / ``body.2.*`` (index 1 is the shared in-place ReLU).
+    """
+
+    def __init__(self, feats, res_scale):
+        super().__init__()
+        self.body = nn.Sequential(conv3x3(feats, feats), nn.ReLU(), conv3x3(feats, feats))
+        self.res_scale = res_scale
+
+    def forward(self, x):
+        return self.body(x) * self.res_scale + x
+
+
+def make_upsampler(scale, feats):
+    """rumpy/SISR/models/advanced/common.py:23-48 (Upsampler, act=False, bn=False).
+
+    scale = 2^n: n x [conv feats->4*feats, PixelShuffle(2)]; scale = 3: conv feats->9*feats, PixelShuffle(3).
+    """
+    layers = []
+    if scale & (scale - 1) == 0:
+        for _ in range(int(round(math.log2(scale)))):
+            layers += [conv3x3(feats, 4 * feats), nn.PixelShuffle(2)]
+    elif scale == 3:
+        layers += [conv3x3(feats, 9 * feats), nn.PixelShuffle(3)]
+    else:
+        raise NotImplementedError
+    return nn.Sequential(*layers)
+
+
+class ChannelAttention(nn.Module):
+    """rumpy/SISR/models/advanced/architectures.py:24-44 (CALayer).
+
+    x * sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2); keys ``conv_du.0.*`` / ``conv_du.2.*``.
+    """
+
+    def __init__(self, feats, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = nn.Sequential(
+            nn.Conv2d(feats, feats // reduction, 1), nn.ReLU(),
+            nn.Conv2d(feats // reduction, feats, 1), nn.Sigmoid())
+
+    def forward(self, x):
+        return x * self.conv_du(self.avg_pool(x))
+
+
+class AttentionResidualBlock(nn.Module):
+    """rumpy/SISR/models/advanced/architectures.py:60-84 (RCAB).
+
+    x + CA(conv(relu(conv(x)))).  NOTE: the reference stores ``res_scale`` but never applies it
+    (architectures.py:79-84) - reproduced here.
+    """
+
+    def __init__(self, feats, reduction, res_scale=1):
+        super().__init__()
+        self.body = nn.Sequential(conv3x3(feats, feats), nn.ReLU(), conv3x3(feats, feats),
+                                  ChannelAttention(feats, reduction))
+        self.res_scale = res_scale  # unused, as in the reference
+
+    def forward(self, x):
+        return self.body(x) + x
+
+
+class AttentionGroup(nn.Module):
+    """rumpy/SISR/models/advanced/architectures.py:107-124 (ResidualGroup): n RCAB + conv, + skip."""
+
+    def __init__(self, feats, reduction, res_scale, n_blocks):
+        super().__init__()
+        mods = [AttentionResidualBlock(feats, reduction, res_scale) for _ in range(n_blocks)]
+        mods.append(conv3x3(feats, feats))
+        self.body = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.body(x) + x
+
+
+class OracleEDSR(nn.Module):
+    """rumpy/SISR/models/advanced/architectures.py:198-241 (EDSR).
+
+    head conv -> num_blocks x ResBlock -> conv -> + head output -> Upsampler -> conv.
+    Keys: head.0, body.{i}.body.{0,2}, body.{num_blocks}, tail.0.{0,2,..}, tail.1
+    """
+
+    def __init__(self, in_features=3, out_features=3, net_features=64, num_blocks=16, scale=4, res_scale=0.1):
+        super().__init__()
+        f = net_features
+        self.head = nn.Sequential(conv3x3(in_features, f))
+        self.body = nn.Sequential(*([ScaledResidualBlock(f, res_scale) for _ in range(num_blocks)]
+                                    + [conv3x3(f, f)]))
+        self.tail = nn.Sequential(make_upsampler(scale, f), conv3x3(f, out_features))
+
+    def forward(self, x):
+        x = self.head(x)
+        return self.tail(self.body(x) + x)
+
+
+class OracleRCAN(nn.Module):
+    """rumpy/SISR/models/advanced/architectures.py:140-176 (RCAN).
+
+    head conv -> n_resgroups x ResidualGroup -> conv -> + head output -> Upsampler -> conv.
+    Keys: head.0, body.{g}.body.{b}.body.{0,2}, body.{g}.body.{b}.body.3.conv_du.{0,2},
+    body.{g}.body.{n_resblocks}, body.{n_resgroups}, tail.0.{0,2}, tail.1
+    """
+
+    def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4,
+                 reduction=16, res_scale=1.0, **_ignored):
+        super().__init__()
+        f = n_feats
+        self.head = nn.Sequential(conv3x3(in_feats, f))
+        self.body = nn.Sequential(*([AttentionGroup(f, reduction, res_scale, n_resblocks)
+                                     for _ in range(n_resgroups)] + [conv3x3(f, f)]))
+        self.tail = nn.Sequential(make_upsampler(scale, f), conv3x3(f, out_feats))
+
+    def forward(self, x):
+        x = self.head(x)
+        return self.tail(self.body(x) + x)
+
+
+# --------------------------------------------------------------------------------------
+# handler-level restatement: one train step / one eval step
+# --------------------------------------------------------------------------------------
+class OracleHandler:
+    """Restates BaseModel for the L1 + Adam (+ optional per-batch scheduler) configuration.
+
+    rumpy/shared_framework/models/base_architecture.py:
+      :40        criterion = nn.L1Loss()
+      :79-99     define_optimizer: Adam(lr, betas default (0.9, .999) / optimizer_params beta_1,beta_2)
+      :101-117   define_scheduler 'cosine_annealing_warm_restarts' (T_0=restart_period, T_mult=t_mult,
+                 eta_min=lr_min); also multi_step_lr / step_lr restated below
+      :425-440   standard_update: zero_grad, backward, [clip_grad_norm_], optimizer.step, scheduler.step (PER BATCH)
+      :457-485   run_train  -> (loss ndarray, out tensor)
+      :488-520   run_eval   -> (out tensor, loss ndarray | None, None)
+    """
+
+    def __init__(self, net, lr=1e-4, scheduler=None, scheduler_params=None, optimizer_params=None,
+                 grad_clip=None, eval_mode=False):
+        self.net = net
+        self.eval_mode = eval_mode
+        self.grad_clip = None if grad_clip == 0 else grad_clip
+        self.criterion = nn.L1Loss()
+        self.optimizer = None
+        self.learning_rate_scheduler = None
+        if not eval_mode:
+            params = [p for p in net.parameters() if p.requires_grad]
+            if optimizer_params is not None:
+                self.optimizer = torch.optim.Adam(params, lr=lr, betas=(optimizer_params['beta_1'],
+                                                                         optimizer_params['beta_2']))
+            else:
+                self.optimizer = torch.optim.Adam(params, lr=lr)
+            if scheduler == 'cosine_annealing_warm_restarts':
+                self.learning_rate_scheduler = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(
+                    self.optimizer, T_0=scheduler_params['restart_period'], T_mult=scheduler_params['t_mult'],
+                    eta_min=scheduler_params['lr_min'])
+            elif scheduler == 'multi_step_lr':
+                self.learning_rate_scheduler = torch.optim.lr_scheduler.MultiStepLR(
+                    self.optimizer, milestones=scheduler_params['milestones'], gamma=scheduler_params['gamma'])
+            elif scheduler == 'step_lr':
+                self.learning_rate_scheduler = torch.optim.lr_scheduler.StepLR(
+                    self.optimizer, step_size=scheduler_params['step_size'], gamma=scheduler_params['gamma'])
+            elif scheduler is not None:
+                raise RuntimeError('%s scheduler not implemented' % scheduler)
+
+    def run_train(self, x, y, scheduler_skip=False):
+        if self.eval_mode:
+            raise RuntimeError('Model initialized in eval mode, training not possible.')
+        self.net.train()
+        out = self.net(x)
+        loss = self.criterion(out, y)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.grad_clip is not None:
+            nn.utils.clip_grad_norm_(self.net.parameters(), self.grad_clip)
+        self.optimizer.step()
+        if self.learning_rate_scheduler is not None and not scheduler_skip:
+            self.learning_rate_scheduler.step()
+        return loss.detach().cpu().numpy(), out.detach().cpu()
+
+    def run_eval(self, x, y=None, request_loss=False):
+        self.net.eval()
+        with torch.no_grad():
+            out = self.net(x)
+            loss = self.criterion(out, y).detach().cpu().numpy() if (request_loss and y is not None) else None
+        return out.detach().cpu(), loss, None
+
+    def get_learning_rate(self):
+        return self.optimizer.param_groups[0]['lr']
+
+
+def build_oracle(name, **internal_params):
+    """Handler kwargs -> architecture kwargs, as the reference handlers map them.
+
+    EDSRHandler rumpy/SISR/models/advanced/handlers.py:13-25: scale, in_features, num_features->net_features,
+    num_blocks, res_scale (defaults 4, 3, 64, 16, 0.1).
+    RCANHandler :33-42: scale, in_features->in_feats, remaining kwargs forwarded to RCAN(**kwargs).
+    """
+    p = dict(internal_params)
+    if name == 'edsr':
+        return OracleEDSR(in_features=p.get('in_features', 3), net_features=p.get('num_features', 64),
+                          num_blocks=p.get('num_blocks', 16), scale=p.get('scale', 4),
+                          res_scale=p.get('res_scale', 0.1))
+    if name == 'rcan':
+        fwd = {k: p[k] for k in ('n_resblocks', 'n_resgroups', 'n_feats', 'out_feats', 'reduction', 'res_scale')
+               if k in p}
+        return OracleRCAN(scale=p.get('scale', 4), in_feats=p.get('in_features', 3), **fwd)
+    raise KeyError(name)
+
+
+# --------------------------------------------------------------------------------------
+# eval post-processing and metric (defines "eval PSNR")
+# --------------------------------------------------------------------------------------
+def clip01(im):
+    """rumpy/shared_framework/models/base_interface.py:216-222 (_standard_image_formatting)."""
+    return np.clip(np.copy(im), 0, 1)
+
+
+def rgb_to_ycbcr_jpg(img, max_val=1):
+    """rumpy/image_tools/image_manipulation/image_functions.py:81-96 ('jpg' matrix, y_only=False).
+
+    img: C,H,W array.  Returns 3,H,W [Y, Cb, Cr].
+    """
+    bias_c = 128. * (max_val / 255)
+    y = 0.299 * img[0] + 0.587 * img[1] + 0.114 * img[2]
+    cb = bias_c + (-0.168736 * img[0] - 0.331264 * img[1] + 0.5 * img[2])
+    cr = bias_c + (0.5 * img[0] - 0.418688 * img[1] - 0.081312 * img[2])
+    return np.array([y, cb, cr])
+
+
+def net_run_and_process(handler, lr, hr=None, request_loss=False):
+    """rumpy/SISR/models/interface.py:103-124, 'rgb' colourspace branch.
+
+    -> (rgb clipped [B,3,H,W] ndarray, ycbcr [B,3,H,W] ndarray of the clipped rgb, loss, timing)
+    """
+    out_rgb, loss, timing = handler.run_eval(lr, hr, request_loss=request_loss)
+    clipped = clip01(out_rgb.numpy())
+    ycbcr = np.copy(clipped)
+    for i in range(ycbcr.shape[0]):
+        ycbcr[i] = rgb_to_ycbcr_jpg(ycbcr[i])
+    return clipped, ycbcr, loss, timing
+
+
+def psnr(img1, img2, max_value=1.0):
+    """rumpy/sr_tools/metrics.py:33-44: float32 mse, 100 if identical, 20 log10(max/sqrt(mse))."""
+    mse = np.mean((np.array(img1, dtype=np.float32) - np.array(img2, dtype=np.float32)) ** 2)
+    if mse == 0:
+        return 100
+    return 20 * np.log10(max_value / (np.sqrt(mse)))
+
+
+def y_psnr(ycbcr_a, ycbcr_ref):
+    """rumpy/sr_tools/metrics.py:109-121 (run_psnr, multichannel=False): PSNR over channel 0 of the whole batch,
+    max_value=1, no border shave."""
+    return psnr(ycbcr_a[:, 0, :, :], ycbcr_ref[:, 0, :, :], max_value=1)
+
+
+# --------------------------------------------------------------------------------------
+# deterministic synthetic tensors (regenerable on the GPU box without the reference)
+# --------------------------------------------------------------------------------------
+def seeded_state_dict(module, seed, scale=None):
+    """Fill every parameter from numpy.random.default_rng(seed) in state_dict order.
+
+    Weights ~ U(-b, b) with b = 1/sqrt(fan_in) (the magnitude of torch's default conv init, so deep stacks
+    stay well-conditioned); biases likewise.  ``scale`` optionally overrides b.
+    """
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for k, v in module.state_dict().items():
+        shape = tuple(v.shape)
+        if k.endswith('weight') and len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+        elif k.endswith('bias'):
+            w = module.state_dict()[k[:-4] + 'weight']
+            fan_in = w.shape[1] * w.shape[2] * w.shape[3]
+        else:
+            fan_in = 1
+        b = scale if scale is not None else 1.0 / math.sqrt(fan_in)
+        sd[k] = torch.from_numpy(rng.uniform(-b, b, size=shape).astype(np.float32))
+    return sd
+
+
+def synthetic_batch(seed, n, lr_hw=48, scale=4, channels=3):
+    """x uniform[0,1) fp32 [n,C,h,w], y uniform[0,1) fp32 [n,C,s*h,s*w], default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    h, w = (lr_hw, lr_hw) if isinstance(lr_hw, int) else lr_hw
+    x = torch.from_numpy(rng.random((n, channels, h, w), dtype=np.float32))
+    y = torch.from_numpy(rng.random((n, channels, h * scale, w * scale), dtype=np.float32))
+    return x, y
+
+
+def bf16_round(t):
+    """Round-to-nearest-even to bf16 and back to fp32 (what the MFMA operands see)."""
+    return t.to(torch.bfloat16).to(torch.float32)

@@ -1,0 +1,160 @@
+"""Pin the CPU oracle (oracle/sr_oracle.py) against the golden vectors the REAL reference produced
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import sr_oracle as O
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _t(a, grad=False):
+    t = torch.from_numpy(np.array(a))
+    return t.requires_grad_(True) if grad else t
+
+
+def _check_block(mod, g, seed, fwd_tol=0.0, bwd_tol=1e-6):
+    mod.load_state_dict(O.seeded_state_dict(mod, seed))
+    x = _t(g['x'], grad=True)
+    y = mod(x)
+    y.backward(_t(g['gy']))
+    assert np.abs(y.detach().numpy() - g['y']).max() <= fwd_tol
+    np.testing.assert_allclose(x.grad.numpy(), g['gx'], rtol=0, atol=bwd_tol)
+    for k, p in mod.named_parameters():
+        ref = g['g.' + k] if ('g.' + k) in g else None
+        if ref is not None:
+            np.testing.assert_allclose(p.grad.numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_g1_default_conv(golden_dir):
+    g = _load(golden_dir, 'g1_conv.npz')
+    conv = O.conv3x3(64, 64)
+    conv.load_state_dict(O.seeded_state_dict(conv, 101))
+    x = _t(g['x'], grad=True)
+    y = conv(x)
+    y.backward(_t(g['gy']))
+    assert np.array_equal(y.detach().numpy(), g['y'])
+    np.testing.assert_allclose(x.grad.numpy(), g['gx'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(conv.weight.grad.numpy(), g['gw'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(conv.bias.grad.numpy(), g['gb'], rtol=1e-5, atol=1e-5)
+
+
+def test_g2_resblock(golden_dir):
+    _check_block(O.ScaledResidualBlock(64, 0.1), _load(golden_dir, 'g2_resblock.npz'), 102)
+
+
+def test_g3_calayer(golden_dir):
+    _check_block(O.ChannelAttention(64, 16), _load(golden_dir, 'g3_calayer.npz'), 103)
+
+
+def test_g3_rcab_ignores_res_scale(golden_dir):
+    # the reference RCAB was built with res_scale=0.5 and must ignore it (architectures.py:79-84)
+    _check_block(O.AttentionResidualBlock(64, 16, res_scale=0.5), _load(golden_dir, 'g3_rcab.npz'), 104)
+
+
+def test_g4_upsampler_and_pixel_shuffle_order(golden_dir):
+    g = _load(golden_dir, 'g4_upsampler.npz')
+    _check_block(O.make_upsampler(4, 16), g, 105)
+    # out[c, 2h+i, 2w+j] = in[4c+2i+j, h, w]
+    pin, pout = g['ps_in'], g['ps_out']
+    n, c4, h, w = pin.shape
+    for c in range(c4 // 4):
+        for i in range(2):
+            for j in range(2):
+                assert np.array_equal(pout[:, c, i::2, j::2], pin[:, 4 * c + 2 * i + j])
+
+
+def _train_case(golden_dir, name, kw, wseed):
+    g = _load(golden_dir, 'g5_%s_small_train.npz' % name)
+    net = O.build_oracle(name, **kw)
+    net.load_state_dict(O.seeded_state_dict(net, wseed))
+    h = O.OracleHandler(net, lr=1e-3, scheduler='cosine_annealing_warm_restarts',
+                        scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+    for step in range(3):
+        xb, yb = O.synthetic_batch(300 + step, 2, lr_hw=12, scale=4)
+        loss, out = h.run_train(xb, yb)
+        np.testing.assert_allclose(loss, g['loss%d' % step], rtol=1e-6)
+        np.testing.assert_allclose(h.get_learning_rate(), g['lr_after%d' % step], rtol=1e-12)
+        if step == 0:
+            np.testing.assert_allclose(out.numpy(), g['out0'], rtol=0, atol=1e-6)
+            for k, p in net.named_parameters():
+                np.testing.assert_allclose(p.grad.numpy(), g['grad0.' + k], rtol=1e-5, atol=1e-7)
+            for k, v in net.state_dict().items():
+                np.testing.assert_allclose(v.numpy(), g['w1.' + k], rtol=0, atol=1e-6)
+    for k, v in net.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g['w3.' + k], rtol=0, atol=2e-6)
+    ev, evl, _ = h.run_eval(xb, yb, request_loss=True)
+    np.testing.assert_allclose(ev.numpy(), g['eval_out'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(evl, g['eval_loss'], rtol=1e-5)
+
+
+def test_g5_edsr_small_train_steps(golden_dir):
+    _train_case(golden_dir, 'edsr', dict(scale=4, num_features=16, num_blocks=2, res_scale=0.1), 201)
+
+
+def test_g5_rcan_small_train_steps(golden_dir):
+    _train_case(golden_dir, 'rcan', dict(scale=4, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=4), 202)
+
+
+def test_g6_edsr_baseline_full_forward(golden_dir):
+    g = _load(golden_dir, 'g6_edsr_full_fwd.npz')
+    net = O.build_oracle('edsr', scale=4)
+    net.load_state_dict(O.seeded_state_dict(net, 401))
+    xb, _ = O.synthetic_batch(1234, 2, lr_hw=48, scale=4)
+    out, _, _ = O.OracleHandler(net, eval_mode=True).run_eval(xb)
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=0, atol=1e-6)
+
+
+def test_g6_rcan_full_forward(golden_dir):
+    g = _load(golden_dir, 'g6_rcan_full_fwd.npz')
+    net = O.build_oracle('rcan', scale=4)
+    net.load_state_dict(O.seeded_state_dict(net, 402))
+    xb, _ = O.synthetic_batch(1235, 1, lr_hw=24, scale=4)
+    out, _, _ = O.OracleHandler(net, eval_mode=True).run_eval(xb)
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=0, atol=2e-6)
+
+
+def test_g7_eval_postprocess_and_y_psnr(golden_dir):
+    g = _load(golden_dir, 'g7_eval_set5.npz')
+    lr_t = torch.from_numpy(g['lr'].transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
+    hr_t = torch.from_numpy(g['hr'].transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
+    net = O.build_oracle('edsr', scale=4, num_blocks=4)
+    net.load_state_dict(O.seeded_state_dict(net, 403))
+    h = O.OracleHandler(net, eval_mode=True)
+    rgb, ycbcr, loss, _ = O.net_run_and_process(h, lr_t, hr_t, request_loss=True)
+    np.testing.assert_allclose(rgb, g['rgb'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ycbcr, g['ycbcr'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-5)
+    hr_ycbcr = O.clip01(hr_t.numpy())
+    hr_ycbcr[0] = O.rgb_to_ycbcr_jpg(hr_ycbcr[0])
+    np.testing.assert_allclose(hr_ycbcr, g['hr_ycbcr'], rtol=0, atol=1e-7)
+    assert abs(O.y_psnr(ycbcr, hr_ycbcr) - float(g['psnr'])) < 1e-4
+    # conversion itself is exact on the golden rgb
+    yc = np.copy(g['rgb'])
+    yc[0] = O.rgb_to_ycbcr_jpg(yc[0])
+    assert np.array_equal(yc, g['ycbcr'])
+    assert O.psnr(g['ycbcr'][:, 0], g['hr_ycbcr'][:, 0], 1) == float(g['psnr'])
+    assert O.psnr(np.zeros((4, 4)), np.zeros((4, 4))) == 100
+
+
+def test_g8_parameter_counts_and_keys(golden_dir):
+    with open(os.path.join(golden_dir, 'g8_params.json')) as f:
+        g = json.load(f)
+    assert g['edsr_baseline_count'] == 1517571
+    assert g['rcan_count'] == g['stats_py_238']['rcan'] == 15592355
+    assert g['edsr_full_count'] == g['stats_py_238']['edsr'] == 43089923
+    e = O.build_oracle('edsr', scale=4)
+    assert [(k, list(v.shape)) for k, v in e.state_dict().items()] == [tuple(x) for x in map(tuple, g['edsr_keys'])]
+    assert sum(p.numel() for p in e.parameters()) == 1517571
+    r = O.build_oracle('rcan', scale=4)
+    assert [(k, list(v.shape)) for k, v in r.state_dict().items()] == [tuple(x) for x in map(tuple, g['rcan_keys'])]
+    assert sum(p.numel() for p in r.parameters()) == 15592355
+    big = O.OracleEDSR(net_features=256, num_blocks=32)
+    assert sum(p.numel() for p in big.parameters()) == 43089923
