@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 48x48 LR patches/sec for a full EDSR-baseline x4 training step (forward + L1 + backward +
+Adam + per-batch LR schedule) on N MI355X, bf16 MFMA operands / fp32 accumulate, through the handler API.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): EDSR-baseline (64 feats x 16 blocks) x4, per-GPU batch 32 of
+uniform[0,1) synthetic [32,3,48,48] / [32,3,192,192] pairs (numpy default_rng(1234+i), pool of 8 device-resident
+batches), weights = handler default init under torch.manual_seed(8), Adam lr 1e-4, cosine warm restarts (T_0 40000).
+One JSON line on rank 0; `roofline` prices the dominant kernel (3x3 conv 64->64, forward and data-gradient launches)
+from HIP-event timings taken in this process; `cpu_baseline` times the CPU oracle on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, fwd + wgrad + dgrad
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
+SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=32, help='LR patches per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--probe-steps', type=int, default=5)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    elif args.gpus != 1:
+        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from oracle import sr_oracle as O                      # synthetic-batch generator + cpu_baseline leg only
+    from rumpy_amd import _lib as L
+    from rumpy_amd.parallel import broadcast_parameters
+    from rumpy_amd.shared_framework.models import define_model
+
+    N = args.batch
+    torch.manual_seed(8)                                    # reference default seed (net_train.py:20)
+    h = define_model('edsr', model_save_dir=tempfile.mkdtemp(), device=local_rank, eval_mode=False, checkpoint_load=False,
+                     loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
+    if world > 1:
+        broadcast_parameters(h.net)
+        h.set_multi_gpu()
+    pool = []
+    for i in range(8):
+        x, y = O.synthetic_batch(1234 + i + 100 * rank, N, lr_hw=48, scale=4)
+        pool.append((x.to(dev), y.to(dev)))
+
+    def step(i):
+        x, y = pool[i % len(pool)]
+        return h.run_train(x=x, y=y, keep_on_device=True)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = N * world * args.steps / elapsed
+
+    # ---- dominant-kernel timing with HIP events (same process, same steps, right after the timed region) ----
+    roofline = None
+    if rank == 0:
+        import ctypes
+        lib = L.lib()
+        per_step = 4 * 16 + 2          # 64->64 launches per step: 33 forward + 33 data-gradient (body convs)
+        lib.rumpy_probe_begin(1, per_step * args.probe_steps + 8)
+        for i in range(args.probe_steps):
+            step(i)
+        torch.cuda.synchronize(dev)
+        tot = ctypes.c_double(0.0)
+        n_launch = lib.rumpy_probe_end(ctypes.byref(tot))
+        if n_launch > 0:
+            avg_s = tot.value * 1e-3 / n_launch
+            flop = 2.0 * N * 48 * 48 * 64 * 576            # algorithmic FLOPs of one 64->64 3x3 launch
+            achieved = flop / avg_s / 1e12
+            roofline = {'bound': 'mfma', 'kernel': 'conv3x3_kernel<1> (3x3 conv 64->64, fwd + dgrad launches)',
+                        'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                        'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch,
+                        'algorithmic_gflop_per_launch': round(flop / 1e9, 3),
+                        'algorithmic_mb_per_launch': round(2 * N * 48 * 48 * 64 * 2 / 1e6, 3),
+                        'hbm_equiv_gbps': round(2 * N * 48 * 48 * 64 * 2 / avg_s / 1e9, 1)}
+
+    # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.manual_seed(8)
+        onet = O.build_oracle('edsr', scale=4)
+        oh = O.OracleHandler(onet, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        xb, yb = O.synthetic_batch(1234, N, lr_hw=48, scale=4)
+        oh.run_train(xb, yb)
+        best = 1e30
+        for _ in range(2):
+            t1 = time.perf_counter()
+            oh.run_train(xb, yb)
+            best = min(best, time.perf_counter() - t1)
+        cpu = {'value': round(N / best, 3), 'unit': 'LR patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '1 warm-up + 2 timed EDSR-baseline x4 train steps of %d 48x48 patches (best of 2), torch CPU fp32 oracle' % N,
+               's_per_step': round(best, 3)}
+
+    if rank == 0:
+        line = {'metric': '48px LR patches/sec (train step) EDSR x4 bf16', 'value': round(value, 2), 'unit': 'LR patches/s',
+                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+                'data': 'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
+                'config': {'workload': 'EDSR-baseline x4 (64 feats x 16 blocks) train step, 48x48 LR patches, batch %d per GPU' % N,
+                           'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
+                           'loss': float(loss), 'train_tflops': round(value * FLOP_PER_PATCH_TRAIN / 1e12, 2),
+                           'train_mfma_frac': round(value * FLOP_PER_PATCH_TRAIN / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4)},
+                'roofline': roofline, 'cpu_baseline': cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,286 @@
+/*
+ * rumpy_amd.h - C ABI of the MI355X (gfx950) kernels behind the RUMpy SISR model-handler hot path.
+ *
+ * Boundary: the reference has NO native layer - below its Python handlers
+ * (rumpy/shared_framework/models/base_architecture.py:442-485) sits ATen.  Each entry point here
+ * replaces the ATen op(s) one reference call site dispatches; the call site is cited per function.
+ * Conventions: every function is `int fn(const <args>* a, void* stream)`; returns 0 or a negative
+ * RUMPY_E_* code (text via rumpy_last_error()); all pointers are DEVICE pointers owned by the caller
+ * (PyTorch tensors); nothing is allocated; everything is asynchronous on `stream` (a hipStream_t);
+ * re-entrant across streams; no global mutable state except the thread-local error string.
+ *
+ * Data layout: activations are NHWC bf16 (raw uint16), 64 channels per pixel = one 128-byte line
+ * (tensors with 64*k channels are k such chunks per pixel).  Master weights stay fp32 OIHW (the
+ * reference state_dict layout); rumpy_pack_weights produces the bf16 MFMA-fragment-ordered copies.
+ */
+#ifndef RUMPY_AMD_H
+#define RUMPY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RUMPY_OK 0
+#define RUMPY_E_ARG (-1)     /* invalid argument / unsupported shape */
+#define RUMPY_E_LAUNCH (-2)  /* HIP launch error */
+
+#define RUMPY_TILE_H 8
+#define RUMPY_TILE_W 16
+
+const char* rumpy_last_error(void);
+int rumpy_abi_version(void);
+/* number of persistent workgroups the conv kernels want for `tiles` pixel tiles (host sizes workspaces with it) */
+int rumpy_device_cus(void);
+
+/* ---- 3x3 same-padding convolution, Cin = 64*cin_chunks, Cout = 64*cout_tiles, bf16 MFMA, fp32 accumulate ----
+ * Replaces nn.Conv2d(k=3,p=1) + the elementwise ops fused around it:
+ *   forward : common.py:6-9 (default_conv), common.py:62-73 (ReLU / .mul(res_scale) / res += x),
+ *             architectures.py:72-83,118-123,238-239 (RCAB / group / global skips), common.py:30-33 (PixelShuffle)
+ *   backward: the autograd dgrad of the same layers (base_architecture.py:432 loss.backward()) - call with the
+ *             dgrad-packed filter; `mask` applies the ReLU derivative, in_mode=1 applies PixelShuffle^T.
+ * v = acc + bias; if relu v = max(v,0); v *= scale; if mask v = mask>0 ? v : 0;
+ * pool[n][tile][c] = sum over the tile of v (optional); v += res1 + res2; out = bf16(v)
+ */
+typedef struct {
+  const void* x;        /* in_mode 0: [N,H,W,64*cin_chunks] ; in_mode 1: [N,2H,2W,64], chunk q=2i+j read at (2h+i,2w+j) */
+  const void* w;        /* packed filter from rumpy_pack_weights (fwd or dgrad image) */
+  const float* bias;    /* packed-order bias [64*cout_tiles] or NULL */
+  void* out;            /* out_mode 0: [N,H,W,64*cout_tiles] ; out_mode 1: [N,2H,2W,64], tile q=2i+j stored at (2h+i,2w+j) */
+  const void* mask;     /* bf16, layout of out (out_mode 0 only) or NULL */
+  const void* res1;     /* bf16, layout of out, or NULL */
+  const void* res2;     /* bf16, layout of out, or NULL */
+  float* pool;          /* [N][tiles_y*tiles_x][64*cout_tiles] per-tile channel sums, or NULL */
+  int32_t N, H, W;
+  int32_t cin_chunks;   /* 1 or 4 */
+  int32_t cout_tiles;
+  int32_t in_mode, out_mode;
+  int32_t relu;
+  float scale;
+  int32_t grid_x;       /* persistent workgroups per cout tile; 0 = library default */
+} rumpy_conv_args;
+int rumpy_conv3x3(const rumpy_conv_args* a, void* stream);
+
+/* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
+ * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */
+typedef struct {
+  const float* x;   /* [N,C,H,W] fp32 */
+  const float* w;   /* [64*cout_tiles, C, 3, 3] fp32 OIHW master weights */
+  const float* b;   /* [64*cout_tiles] */
+  void* out;        /* [N,H,W,64*cout_tiles] bf16 */
+  int32_t N, C, H, W, cout;
+} rumpy_head_fwd_args;
+int rumpy_head_fwd(const rumpy_head_fwd_args* a, void* stream);
+
+/* weight/bias gradient of the head conv (no data gradient: the image needs none).
+ * Two launches inside: persistent partial sums into `slab` (>= rumpy_head_wgrad_slab_floats floats), then a
+ * deterministic reduction into gw [cout,C,3,3] / gb [cout], multiplied by `scale`. */
+typedef struct {
+  const float* x;   /* [N,C,H,W] fp32 */
+  const void* dy;   /* [N,H,W,cout] bf16 */
+  float* slab;
+  float* gw;
+  float* gb;
+  int32_t N, C, H, W, cout;
+  float scale;
+} rumpy_head_wgrad_args;
+int rumpy_head_wgrad(const rumpy_head_wgrad_args* a, void* stream);
+int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout);
+
+/* ---- tail conv: 64 ch NHWC bf16 -> C (<=4) fp32 NCHW, optionally fused with nn.L1Loss and its derivative ----
+ * Replaces nn.Conv2d(n_feats, out_features, 3, p=1) (architectures.py:229,165), BaseModel.find_loss with
+ * nn.L1Loss (base_architecture.py:40,448-449) and d|o-y|/do = sign(o-y) (the 1/numel factor is applied by
+ * rumpy_wgrad_reduce / rumpy_head_wgrad through `scale`, so the stored gradient is exactly +-1 or 0). */
+typedef struct {
+  const void* x;         /* [N,H,W,64] bf16 */
+  const void* w;         /* packed tail filter (rumpy_pack_weights kind 2, fwd image) */
+  const float* bias;     /* [C] */
+  float* out;            /* [N,C,H,W] fp32 */
+  const float* target;   /* [N,C,H,W] fp32 or NULL */
+  void* dy4;             /* [N,H,W,4] bf16 sign(out-target) or NULL */
+  float* loss_partial;   /* [grid] per-workgroup sums of |out-target| (needs target) */
+  float* loss;           /* scalar: sum(loss_partial)/numel, written by a second tiny launch (needs target) */
+  int32_t N, C, H, W;
+  int32_t grid_x;        /* persistent workgroups (<= capacity of loss_partial); 0 = default */
+} rumpy_tail_fwd_args;
+int rumpy_tail_fwd(const rumpy_tail_fwd_args* a, void* stream);
+
+/* data gradient of the tail conv: dy4 [N,H,W,4] bf16 -> dx [N,H,W,64] bf16 */
+typedef struct {
+  const void* dy4;
+  const void* w;    /* packed tail filter, dgrad image */
+  void* dx;
+  int32_t N, H, W;
+} rumpy_tail_dgrad_args;
+int rumpy_tail_dgrad(const rumpy_tail_dgrad_args* a, void* stream);
+
+/* fp32 NCHW [N,C<=4,H,W] -> bf16 [N,H,W,4] (zero padded): an upstream gradient entering the backward pass */
+typedef struct {
+  const float* src;
+  void* dst;
+  int32_t N, C, H, W;
+} rumpy_nchw_to_nhwc4_args;
+int rumpy_nchw_to_nhwc4(const rumpy_nchw_to_nhwc4_args* a, void* stream);
+
+/* ---- weight gradient of the 3x3 convs: grouped launch over a job table + deterministic slab reduction ----
+ * Replaces the wgrad/bias-grad half of loss.backward() (base_architecture.py:432) for every nn.Conv2d(k=3)
+ * with 64-multiple input channels.  One job = one (layer, cin chunk, cout tile, image range); it leaves
+ * fp32 partial sums [16*mt][9][64] (+ [16*mt] bias sums) in its slab. */
+typedef struct {
+  const void* x;     /* [N,H,W,x_cstride] bf16, channels x_coff..x_coff+63 used */
+  const void* dy;    /* dy_mode 0: [N,H,W,dy_cstride] bf16 at channel offset dy_coff ;
+                        dy_mode 1: [N,2H,2W,64], sub-pixel q = dy_coff ; dy_mode 2: [N,H,W,4] (mt must be 1) */
+  float* slab;       /* rumpy_wgrad_slab_floats(mt) floats */
+  int32_t n0, n1;    /* image range */
+  int32_t H, W;
+  int32_t x_cstride, x_coff;
+  int32_t dy_mode, dy_cstride, dy_coff;
+  int32_t mt;        /* 4: 64 output channels ; 1: <=4 output channels (tail) */
+} rumpy_wgrad_job;
+int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t njobs, int32_t mt, void* stream);
+int64_t rumpy_wgrad_slab_floats(int32_t mt);
+
+typedef struct {
+  const float* slab;    /* first slab of this item's jobs */
+  int64_t slab_stride;  /* floats between consecutive jobs' slabs */
+  int32_t njobs;
+  int32_t mt;
+  int32_t co_count;     /* real output channels in the slab (64, or C for the tail) */
+  int32_t co_mode;      /* 0: co = co_off + c ; 1: co = 4*c + co_off (PixelShuffle order) */
+  int32_t co_off;
+  int32_t ci_total;     /* Cin of the layer */
+  int32_t ci_off;       /* channel offset of this item's cin chunk */
+  int32_t write_bias;   /* 1: also reduce the bias sums into gb */
+  float scale;
+  float* gw;            /* [Cout,Cin,3,3] fp32 (OIHW) */
+  float* gb;            /* [Cout] */
+} rumpy_reduce_item;
+int rumpy_wgrad_reduce(const rumpy_reduce_item* items_device, int32_t nitems, void* stream);
+
+/* ---- filter packing: fp32 OIHW master weights -> bf16 MFMA-fragment images (run after every optimizer step) ---- */
+typedef struct {
+  const float* w;      /* [Cout,Cin,3,3] */
+  const float* b;      /* [Cout] */
+  void* w_fwd;         /* kind 0: [cout_tiles][cin_chunks][4][18][64][8] bf16 ; kind 2: [18][64][8] */
+  void* w_dgrad;       /* kind 0: [cin_chunks][cout_tiles][4][18][64][8] ; kind 2: [4][2][64][8] ; may be NULL */
+  float* b_packed;     /* kind 0: [Cout] in packed channel order ; else NULL */
+  int32_t cout, cin;
+  int32_t kind;        /* 0: 64-multiple conv ; 2: tail conv (cout<=4, cin=64) */
+  int32_t shuffle;     /* kind 0: 1 = output channels grouped by PixelShuffle sub-pixel (co = 4c+q -> tile q, channel c) */
+} rumpy_pack_item;
+int rumpy_pack_weights(const rumpy_pack_item* items_device, int32_t nitems, void* stream);
+
+/* ---- channel attention (RCAN CALayer, architectures.py:24-44) ---- */
+typedef struct {
+  const float* pool;   /* [N][ntiles][C] per-tile sums from rumpy_conv3x3 */
+  const float* w1;     /* [Cr,C,1,1] */
+  const float* b1;     /* [Cr] */
+  const float* w2;     /* [C,Cr,1,1] */
+  const float* b2;     /* [C] */
+  float* mean;         /* [N][C]  out: pooled mean */
+  float* hidden;       /* [N][Cr] out: relu(W1 mean + b1) */
+  float* gate;         /* [N][C]  out: sigmoid(W2 hidden + b2) */
+  int32_t N, C, Cr, ntiles;
+  float inv_hw;
+} rumpy_ca_mlp_fwd_args;
+int rumpy_ca_mlp_fwd(const rumpy_ca_mlp_fwd_args* a, void* stream);
+
+/* out = res + t * gate[n][c]  (x*y at architectures.py:44 fused with `res += x` at :83) */
+typedef struct {
+  const void* t;       /* [N,HW,C] bf16 */
+  const void* res;     /* [N,HW,C] bf16 or NULL */
+  const float* gate;   /* [N][C] */
+  void* out;
+  int32_t N, HW, C;
+} rumpy_ca_scale_args;
+int rumpy_ca_scale_res_fwd(const rumpy_ca_scale_args* a, void* stream);
+
+/* dgate_partial[n][chunk][c] = sum over 128-pixel chunks of dy * t */
+typedef struct {
+  const void* dy;
+  const void* t;
+  float* partial;      /* [N][nchunks][C], nchunks = ceil(HW/128) */
+  int32_t N, HW, C;
+} rumpy_ca_bwd_reduce_args;
+int rumpy_ca_bwd_reduce(const rumpy_ca_bwd_reduce_args* a, void* stream);
+
+typedef struct {
+  const float* partial;  /* from rumpy_ca_bwd_reduce */
+  const float* mean;
+  const float* hidden;
+  const float* gate;
+  const float* w1;
+  const float* w2;
+  float* dpool;          /* [N][C] out: d(mean)/HW, to be broadcast-added by rumpy_ca_bwd_apply */
+  float* gw1;
+  float* gb1;
+  float* gw2;
+  float* gb2;            /* parameter gradients (overwritten), multiplied by scale */
+  int32_t N, C, Cr, nchunks;
+  float inv_hw;
+  float scale;
+} rumpy_ca_mlp_bwd_args;
+int rumpy_ca_mlp_bwd(const rumpy_ca_mlp_bwd_args* a, void* stream);
+
+/* dt = dy * gate[n][c] + dpool[n][c] */
+typedef struct {
+  const void* dy;
+  const float* gate;
+  const float* dpool;
+  void* dt;
+  int32_t N, HW, C;
+} rumpy_ca_bwd_apply_args;
+int rumpy_ca_bwd_apply(const rumpy_ca_bwd_apply_args* a, void* stream);
+
+/* ---- optimizer: torch.optim.Adam semantics (base_architecture.py:93-95,437), flat fp32 buffers ---- */
+typedef struct {
+  float lr, beta1, beta2, eps;
+  float bias_c1;        /* 1 - beta1^t */
+  float sqrt_bias_c2;   /* sqrt(1 - beta2^t) */
+  float grad_mult;      /* multiplies every gradient first (1, 1/world, or a clipping coefficient) */
+  float max_norm;       /* > 0: clip_grad_norm_ semantics using *sumsq (base_architecture.py:434-435) */
+} rumpy_adam_hyper;
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  const rumpy_adam_hyper* hyper;  /* DEVICE pointer: lets a captured graph replay with new hyper-parameters */
+  const float* sumsq;             /* device scalar (sum of g^2) when hyper->max_norm > 0, else NULL */
+} rumpy_adam_args;
+int rumpy_adam_step(const rumpy_adam_args* a, void* stream);
+
+/* out[0] = sum(g[i]^2) (deterministic two-pass; `partial` >= 1024 floats) */
+typedef struct {
+  const float* g;
+  int64_t n;
+  float* partial;
+  float* out;
+} rumpy_sumsq_args;
+int rumpy_sumsq(const rumpy_sumsq_args* a, void* stream);
+
+/* ---- eval post-processing (SISR/models/interface.py:103-124 + sr_tools/metrics.py:33-44,109-121) ----
+ * rgb = clip(out,0,1); ycbcr = 'jpg' matrix of rgb; if ref (RGB in [0,1]): sse += (Y(rgb) - Y(clip(ref)))^2 */
+typedef struct {
+  const float* out;     /* [N,3,H,W] fp32 */
+  const float* ref;     /* [N,3,H,W] fp32 or NULL */
+  float* rgb;           /* [N,3,H,W] */
+  float* ycbcr;         /* [N,3,H,W] */
+  float* sse_partial;   /* >= 1024 floats or NULL */
+  float* sse;           /* scalar: sum of squared Y error, or NULL */
+  int32_t N, H, W;
+} rumpy_eval_post_args;
+int rumpy_eval_post(const rumpy_eval_post_args* a, void* stream);
+
+/* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
+ * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 */
+int rumpy_probe_begin(int kernel_id, int max_records);
+/* synchronises the recorded events; returns launches seen; *total_ms = summed duration */
+int rumpy_probe_end(double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,265 @@
+"""EDSR / RCAN for the MI355X HIP path - drop-in for rumpy/SISR/models/advanced/architectures.py (EDSR :198-241,
+RCAN :140-176, RCAB :60-84, ResidualGroup :107-124, CALayer :24-44) and common.py (ResBlock :51-75, Upsampler :23-48).
+
+The nn.Module tree exists to own the parameters under the reference's exact ``state_dict`` keys and OIHW fp32
+layout (checkpoints interchange) and to consume the RNG like the reference's constructors do (same seed -> same
+initial weights).  It does NOT compute: ``forward`` hands the whole network to the hand-written HIP kernels
+through ``rumpy_amd.engine.SREngine``.  There is no CPU / eager fallback - calling the net without a GPU or
+without the built extension raises.
+
+All parameters live in ONE flat fp32 HBM buffer (``flat_p``; gradients in ``flat_g``): each ``nn.Parameter`` is a
+view, so the fused Adam kernel and the gradient all-reduce see one contiguous tensor.
+"""
+import math
+
+import torch
+from torch import nn
+
+from rumpy_amd.engine import CALayerParams, ConvLayer, NetSpec, SREngine
+
+
+def _conv(cin, cout, k=3):
+    # default_conv, common.py:6-9 (parameter container; same default init / RNG use as nn.Conv2d there)
+    return nn.Conv2d(cin, cout, k, padding=k // 2, bias=True)
+
+
+class _Holder(nn.Module):
+    """A module whose children only hold parameters (``body`` Sequential naming as in the reference)."""
+
+    def __init__(self, mods):
+        super().__init__()
+        self.body = nn.Sequential(*mods)
+
+
+class _ResBlockParams(_Holder):
+    # common.py:51-75: body = [conv, ReLU, conv] -> keys body.0.*, body.2.*
+    def __init__(self, feats, res_scale):
+        super().__init__([_conv(feats, feats), nn.ReLU(True), _conv(feats, feats)])
+        self.res_scale = res_scale
+
+
+class _CAParams(nn.Module):
+    # architectures.py:24-44: conv_du = [conv1x1, ReLU, conv1x1, Sigmoid] -> keys conv_du.0.*, conv_du.2.*
+    def __init__(self, feats, reduction):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = nn.Sequential(nn.Conv2d(feats, feats // reduction, 1, padding=0, bias=True), nn.ReLU(inplace=True),
+                                     nn.Conv2d(feats // reduction, feats, 1, padding=0, bias=True), nn.Sigmoid())
+
+
+class _RCABParams(_Holder):
+    # architectures.py:60-84: body = [conv, ReLU, conv, CALayer]; res_scale is stored and IGNORED (:79-84)
+    def __init__(self, feats, reduction, res_scale):
+        super().__init__([_conv(feats, feats), nn.ReLU(True), _conv(feats, feats), _CAParams(feats, reduction)])
+        self.res_scale = res_scale
+
+
+class _GroupParams(_Holder):
+    # architectures.py:107-124: body = n x RCAB + conv
+    def __init__(self, feats, reduction, res_scale, n_resblocks):
+        super().__init__([_RCABParams(feats, reduction, res_scale) for _ in range(n_resblocks)] + [_conv(feats, feats)])
+
+
+def _upsampler(scale, feats):
+    # common.py:23-48, act=False, bn=False
+    mods = []
+    if (scale & (scale - 1)) == 0:
+        for _ in range(int(math.log(scale, 2))):
+            mods += [_conv(feats, 4 * feats), nn.PixelShuffle(2)]
+    elif scale == 3:
+        mods += [_conv(feats, 9 * feats), nn.PixelShuffle(3)]
+    else:
+        raise NotImplementedError
+    return nn.Sequential(*mods)
+
+
+class _NetFn(torch.autograd.Function):
+    """Whole-network autograd node for the generic (non-fused-loss) path: forward/backward both run the HIP engine;
+    parameter gradients are deposited straight into the flat gradient buffer (``p.grad`` views, overwritten)."""
+
+    @staticmethod
+    def forward(ctx, x, net, train, *params):
+        out, _, plan = net.engine_forward(x, train=train)
+        ctx.net, ctx.plan = net, plan
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        net.engine.backward(ctx.plan, 1.0, gout=gout.contiguous().float())
+        net.attach_grads()
+        return (None, None, None) + tuple(None for _ in net.param_list)
+
+
+class HipSRNet(nn.Module):
+    """Common machinery of the HIP-backed SR nets."""
+
+    def _finalize(self):
+        self.param_list = list(self.parameters())
+        self.flat_p = self.flat_g = None
+        self.engine = None
+        self._packed_version = None
+        self._flatten()
+
+    # ---- flat parameter storage ----
+    def _flatten(self):
+        dev = self.param_list[0].device
+        total = sum(p.numel() for p in self.param_list)
+        flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.offsets = []
+        with torch.no_grad():
+            for p in self.param_list:
+                n = p.numel()
+                flat_p[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = flat_p[off:off + n].view(p.shape)
+                self.offsets.append(off)
+                off += n
+        self.flat_p, self.flat_g = flat_p, flat_g
+        self.grad_views = [flat_g[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.param_list)]
+        self.attach_grads()
+        self.engine = None
+        self._packed_version = None
+
+    def attach_grads(self):
+        for p, g in zip(self.param_list, self.grad_views):
+            if p.requires_grad:
+                p.grad = g
+
+    def _apply(self, fn, recurse=True):
+        had = getattr(self, 'param_list', None) is not None
+        super()._apply(fn)
+        if had:
+            self.param_list = list(self.parameters())   # Parameter objects may have been replaced
+            if self.flat_p is None or self.param_list[0].data_ptr() != self.flat_p.data_ptr():
+                self._flatten()
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._packed_version = None
+        return res
+
+    # ---- engine ----
+    def _spec(self):
+        raise NotImplementedError
+
+    def _conv_layer(self, name, mod, kind='main', shuffle=False):
+        cv = ConvLayer(name, mod.weight.data, mod.bias.data, kind, shuffle)
+        idx = {id(p): i for i, p in enumerate(self.param_list)}
+        cv.gw, cv.gb = self.grad_views[idx[id(mod.weight)]], self.grad_views[idx[id(mod.bias)]]
+        return cv
+
+    def _ca_layer(self, name, ca):
+        c0, c2 = ca.conv_du[0], ca.conv_du[2]
+        lp = CALayerParams(name, c0.weight.data, c0.bias.data, c2.weight.data, c2.bias.data)
+        idx = {id(p): i for i, p in enumerate(self.param_list)}
+        lp.gw1, lp.gb1 = self.grad_views[idx[id(c0.weight)]], self.grad_views[idx[id(c0.bias)]]
+        lp.gw2, lp.gb2 = self.grad_views[idx[id(c2.weight)]], self.grad_views[idx[id(c2.bias)]]
+        return lp
+
+    def _ensure_engine(self):
+        if not self.flat_p.is_cuda:
+            raise RuntimeError('rumpy_amd: this network only runs on an MI355X through the HIP extension; '
+                               'there is no CPU path (parameters are on %s)' % self.flat_p.device)
+        if self.engine is None:
+            self.engine = SREngine(self._spec(), self.flat_p.device)
+        v = self._weights_version()
+        if self._packed_version != v:
+            self.engine.repack()
+            self._packed_version = v
+
+    def _weights_version(self):
+        # torch-side in-place writes (load_state_dict, a stock optimizer, manual edits) bump these counters
+        return sum(p._version for p in self.param_list)
+
+    def mark_weights_updated(self):
+        """Called by the fused optimizer after it rewrote flat_p behind torch's back."""
+        self._ensure_engine()
+        self.engine.repack()
+        self._packed_version = self._weights_version()
+
+    def engine_forward(self, x, train, target=None):
+        self._ensure_engine()
+        if not x.is_cuda:
+            raise RuntimeError('rumpy_amd: input must be on the GPU')
+        return self.engine.forward(x.float().contiguous(), train=train, target=target)
+
+    def forward(self, x):
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list)
+        if train:
+            return _NetFn.apply(x, self, True, *self.param_list)
+        out, _, _ = self.engine_forward(x, train=False)
+        return out.clone()
+
+    def fused_l1_forward_backward(self, x, y):
+        """forward + nn.L1Loss + full backward in one pass (base_architecture.py:474-480 minus the optimizer).
+        Returns (loss device scalar, out).  Gradients land in flat_g / p.grad."""
+        out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous())
+        self.engine.backward(plan, 1.0 / out.numel())
+        return loss, out
+
+    def l1_eval(self, x, y):
+        out, loss, _ = self.engine_forward(x, train=False, target=y.float().contiguous())
+        return out, loss
+
+
+class EDSR(HipSRNet):
+    """architectures.py:198-241.  Keys: head.0, body.{i}.body.{0,2}, body.{num_blocks}, tail.0.{0,2..}, tail.1"""
+
+    def __init__(self, in_features=3, out_features=3, net_features=64, num_blocks=16, scale=4, res_scale=0.1):
+        super().__init__()
+        f = net_features
+        self.scale, self.res_scale = scale, res_scale
+        self.head = nn.Sequential(_conv(in_features, f))
+        self.body = nn.Sequential(*([_ResBlockParams(f, res_scale) for _ in range(num_blocks)] + [_conv(f, f)]))
+        self.tail = nn.Sequential(_upsampler(scale, f), _conv(f, out_features))
+        self._finalize()
+
+    def _spec(self):
+        if self.scale not in (1, 2, 4, 8):
+            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path (PixelShuffle(3) not implemented)' % self.scale)
+        body = []
+        blocks = list(self.body)[:-1]
+        for i, b in enumerate(blocks):
+            body.append(('resblock', self._conv_layer('body.%d.body.0' % i, b.body[0]),
+                         self._conv_layer('body.%d.body.2' % i, b.body[2]), float(b.res_scale)))
+        ups = [self._conv_layer('tail.0.%d' % i, m, shuffle=True) for i, m in enumerate(self.tail[0]) if isinstance(m, nn.Conv2d)]
+        return NetSpec(self._conv_layer('head.0', self.head[0], kind='head'), body,
+                       self._conv_layer('body.%d' % len(blocks), self.body[-1]), ups,
+                       self._conv_layer('tail.1', self.tail[1], kind='tail'), self.scale)
+
+
+class RCAN(HipSRNet):
+    """architectures.py:140-176.  Keys: head.0, body.{g}.body.{b}.body.{0,2}, body.{g}.body.{b}.body.3.conv_du.{0,2},
+    body.{g}.body.{n_resblocks}, body.{n_resgroups}, tail.0.{0,2}, tail.1"""
+
+    def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4, reduction=16,
+                 res_scale=1.0, **kwargs):
+        super().__init__()
+        f = n_feats
+        self.scale = scale
+        self.head = nn.Sequential(_conv(in_feats, f))
+        self.body = nn.Sequential(*([_GroupParams(f, reduction, res_scale, n_resblocks) for _ in range(n_resgroups)]
+                                    + [_conv(f, f)]))
+        self.tail = nn.Sequential(_upsampler(scale, f), _conv(f, out_feats))
+        self._finalize()
+
+    def _spec(self):
+        if self.scale not in (1, 2, 4, 8):
+            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path (PixelShuffle(3) not implemented)' % self.scale)
+        body = []
+        groups = list(self.body)[:-1]
+        for gi, grp in enumerate(groups):
+            mods = list(grp.body)
+            items = []
+            for bi, rb in enumerate(mods[:-1]):
+                pre = 'body.%d.body.%d.body' % (gi, bi)
+                items.append(('rcab', self._conv_layer(pre + '.0', rb.body[0]), self._conv_layer(pre + '.2', rb.body[2]),
+                              self._ca_layer(pre + '.3', rb.body[3])))
+            body.append(('group', items, self._conv_layer('body.%d.body.%d' % (gi, len(mods) - 1), mods[-1])))
+        ups = [self._conv_layer('tail.0.%d' % i, m, shuffle=True) for i, m in enumerate(self.tail[0]) if isinstance(m, nn.Conv2d)]
+        return NetSpec(self._conv_layer('head.0', self.head[0], kind='head'), body,
+                       self._conv_layer('body.%d' % len(groups), self.body[-1]), ups,
+                       self._conv_layer('tail.1', self.tail[1], kind='tail'), self.scale)

@@ -1,0 +1,180 @@
+"""ctypes binding of the C-ABI kernel library (include/rumpy_amd.h -> rumpy_amd/librumpy_amd.so).
+
+The library is the product: there is NO fallback.  ``lib()`` raises ``RuntimeError`` when the shared object
+is missing or an entry point fails, so a GPU box without the HIP extension fails loudly instead of silently
+running something else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librumpy_amd.so')
+
+c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+TILE_H, TILE_W = 8, 16
+
+
+class _S(C.Structure):
+    def __init__(self, **kw):
+        super().__init__()
+        names = {f[0] for f in self._fields_}
+        for k, v in kw.items():
+            if k not in names:
+                raise AttributeError('%s has no field %s' % (type(self).__name__, k))
+            setattr(self, k, v)
+
+
+class ConvArgs(_S):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('mask', c_void_p),
+                ('res1', c_void_p), ('res2', c_void_p), ('pool', c_void_p),
+                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cin_chunks', c_int32), ('cout_tiles', c_int32),
+                ('in_mode', c_int32), ('out_mode', c_int32), ('relu', c_int32), ('scale', c_float),
+                ('grid_x', c_int32)]
+
+
+class HeadFwdArgs(_S):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('b', c_void_p), ('out', c_void_p),
+                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32)]
+
+
+class HeadWgradArgs(_S):
+    _fields_ = [('x', c_void_p), ('dy', c_void_p), ('slab', c_void_p), ('gw', c_void_p), ('gb', c_void_p),
+                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32),
+                ('scale', c_float)]
+
+
+class TailFwdArgs(_S):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('target', c_void_p),
+                ('dy4', c_void_p), ('loss_partial', c_void_p), ('loss', c_void_p),
+                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('grid_x', c_int32)]
+
+
+class TailDgradArgs(_S):
+    _fields_ = [('dy4', c_void_p), ('w', c_void_p), ('dx', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32)]
+
+
+class NchwToNhwc4Args(_S):
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32)]
+
+
+class WgradJob(_S):
+    _fields_ = [('x', c_void_p), ('dy', c_void_p), ('slab', c_void_p), ('n0', c_int32), ('n1', c_int32),
+                ('H', c_int32), ('W', c_int32), ('x_cstride', c_int32), ('x_coff', c_int32),
+                ('dy_mode', c_int32), ('dy_cstride', c_int32), ('dy_coff', c_int32), ('mt', c_int32)]
+
+
+class ReduceItem(_S):
+    _fields_ = [('slab', c_void_p), ('slab_stride', c_int64), ('njobs', c_int32), ('mt', c_int32),
+                ('co_count', c_int32), ('co_mode', c_int32), ('co_off', c_int32), ('ci_total', c_int32),
+                ('ci_off', c_int32), ('write_bias', c_int32), ('scale', c_float), ('gw', c_void_p), ('gb', c_void_p)]
+
+
+class PackItem(_S):
+    _fields_ = [('w', c_void_p), ('b', c_void_p), ('w_fwd', c_void_p), ('w_dgrad', c_void_p), ('b_packed', c_void_p),
+                ('cout', c_int32), ('cin', c_int32), ('kind', c_int32), ('shuffle', c_int32)]
+
+
+class CaMlpFwdArgs(_S):
+    _fields_ = [('pool', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p),
+                ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p),
+                ('N', c_int32), ('C', c_int32), ('Cr', c_int32), ('ntiles', c_int32), ('inv_hw', c_float)]
+
+
+class CaScaleArgs(_S):
+    _fields_ = [('t', c_void_p), ('res', c_void_p), ('gate', c_void_p), ('out', c_void_p),
+                ('N', c_int32), ('HW', c_int32), ('C', c_int32)]
+
+
+class CaBwdReduceArgs(_S):
+    _fields_ = [('dy', c_void_p), ('t', c_void_p), ('partial', c_void_p), ('N', c_int32), ('HW', c_int32), ('C', c_int32)]
+
+
+class CaMlpBwdArgs(_S):
+    _fields_ = [('partial', c_void_p), ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('w1', c_void_p),
+                ('w2', c_void_p), ('dpool', c_void_p), ('gw1', c_void_p), ('gb1', c_void_p), ('gw2', c_void_p),
+                ('gb2', c_void_p), ('N', c_int32), ('C', c_int32), ('Cr', c_int32), ('nchunks', c_int32),
+                ('inv_hw', c_float), ('scale', c_float)]
+
+
+class CaBwdApplyArgs(_S):
+    _fields_ = [('dy', c_void_p), ('gate', c_void_p), ('dpool', c_void_p), ('dt', c_void_p),
+                ('N', c_int32), ('HW', c_int32), ('C', c_int32)]
+
+
+class AdamHyper(_S):
+    _fields_ = [('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float), ('bias_c1', c_float),
+                ('sqrt_bias_c2', c_float), ('grad_mult', c_float), ('max_norm', c_float)]
+
+
+class AdamArgs(_S):
+    _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_int64),
+                ('hyper', c_void_p), ('sumsq', c_void_p)]
+
+
+class SumsqArgs(_S):
+    _fields_ = [('g', c_void_p), ('n', c_int64), ('partial', c_void_p), ('out', c_void_p)]
+
+
+class EvalPostArgs(_S):
+    _fields_ = [('out', c_void_p), ('ref', c_void_p), ('rgb', c_void_p), ('ycbcr', c_void_p),
+                ('sse_partial', c_void_p), ('sse', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32)]
+
+
+# every symbol include/rumpy_amd.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    'rumpy_last_error': (C.c_char_p, []),
+    'rumpy_abi_version': (C.c_int, []),
+    'rumpy_device_cus': (C.c_int, []),
+    'rumpy_conv3x3': (C.c_int, [_P(ConvArgs), c_void_p]),
+    'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
+    'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
+    'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),
+    'rumpy_tail_fwd': (C.c_int, [_P(TailFwdArgs), c_void_p]),
+    'rumpy_tail_dgrad': (C.c_int, [_P(TailDgradArgs), c_void_p]),
+    'rumpy_nchw_to_nhwc4': (C.c_int, [_P(NchwToNhwc4Args), c_void_p]),
+    'rumpy_wgrad_grouped': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_wgrad_slab_floats': (c_int64, [c_int32]),
+    'rumpy_wgrad_reduce': (C.c_int, [c_void_p, c_int32, c_void_p]),
+    'rumpy_pack_weights': (C.c_int, [c_void_p, c_int32, c_void_p]),
+    'rumpy_ca_mlp_fwd': (C.c_int, [_P(CaMlpFwdArgs), c_void_p]),
+    'rumpy_ca_scale_res_fwd': (C.c_int, [_P(CaScaleArgs), c_void_p]),
+    'rumpy_ca_bwd_reduce': (C.c_int, [_P(CaBwdReduceArgs), c_void_p]),
+    'rumpy_ca_mlp_bwd': (C.c_int, [_P(CaMlpBwdArgs), c_void_p]),
+    'rumpy_ca_bwd_apply': (C.c_int, [_P(CaBwdApplyArgs), c_void_p]),
+    'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),
+    'rumpy_sumsq': (C.c_int, [_P(SumsqArgs), c_void_p]),
+    'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
+    'rumpy_probe_begin': (C.c_int, [C.c_int, C.c_int]),
+    'rumpy_probe_end': (C.c_int, [_P(C.c_double)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError('rumpy_amd: %s is missing - build it with `python -c "import __graft_entry__ as g; '
+                               'g.build()"` (or make -C rumpy_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().rumpy_last_error()
+        raise RuntimeError('rumpy_amd %s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+
+
+def call(name, args, stream):
+    """Invoke ``int name(const args*, stream)``."""
+    check(getattr(lib(), name)(C.byref(args), stream), name)

@@ -1,0 +1,78 @@
+// Error reporting, device query and the timing probe of the C ABI.
+#include "common.hpp"
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void rumpy_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int rumpy_check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    rumpy_set_error("%s: %s", what, hipGetErrorString(e));
+    return RUMPY_E_LAUNCH;
+  }
+  return RUMPY_OK;
+}
+extern "C" const char* rumpy_last_error(void) { return g_err; }
+extern "C" int rumpy_abi_version(void) { return 1; }
+extern "C" int rumpy_device_cus(void) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;  // MI355X
+  }
+  return cus;
+}
+
+// ---- timing probe ---------------------------------------------------------------------------------------
+static int g_probe_id = 0;
+static int g_probe_max = 0;
+static std::vector<hipEvent_t> g_probe_ev;   // start/stop pairs
+static int g_probe_n = 0;
+
+void rumpy_probe_pre(int kernel_id, hipStream_t s) {
+  if (g_probe_id == 0) return;
+  if (kernel_id != g_probe_id && !(g_probe_id == 3 && kernel_id == 1)) return;
+  if (g_probe_n >= g_probe_max) return;
+  (void)hipEventRecord(g_probe_ev[2 * g_probe_n], s);
+}
+void rumpy_probe_post(int kernel_id, hipStream_t s) {
+  if (g_probe_id == 0) return;
+  if (kernel_id != g_probe_id && !(g_probe_id == 3 && kernel_id == 1)) return;
+  if (g_probe_n >= g_probe_max) return;
+  (void)hipEventRecord(g_probe_ev[2 * g_probe_n + 1], s);
+  ++g_probe_n;
+}
+extern "C" int rumpy_probe_begin(int kernel_id, int max_records) {
+  if (kernel_id < 1 || kernel_id > 3 || max_records <= 0) { rumpy_set_error("rumpy_probe_begin: bad argument"); return RUMPY_E_ARG; }
+  while ((int)g_probe_ev.size() < 2 * max_records) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { rumpy_set_error("rumpy_probe_begin: hipEventCreate failed"); return RUMPY_E_LAUNCH; }
+    g_probe_ev.push_back(e);
+  }
+  g_probe_max = max_records;
+  g_probe_n = 0;
+  g_probe_id = kernel_id;
+  return RUMPY_OK;
+}
+extern "C" int rumpy_probe_end(double* total_ms) {
+  double tot = 0.0;
+  const int n = g_probe_n;
+  for (int i = 0; i < n; ++i) {
+    (void)hipEventSynchronize(g_probe_ev[2 * i + 1]);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_probe_ev[2 * i], g_probe_ev[2 * i + 1]) == hipSuccess) tot += ms;
+  }
+  g_probe_id = 0;
+  g_probe_n = 0;
+  if (total_ms) *total_ms = tot;
+  return n;
+}

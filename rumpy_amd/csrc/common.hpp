@@ -1,0 +1,93 @@
+// Shared device helpers for the gfx950 kernels (CDNA4: wave64, MFMA 16x16x32 bf16, 160 KiB LDS/CU).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rumpy_amd.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Tile geometry shared by conv / wgrad: 8 rows x 16 columns of output pixels per stage, 1-pixel halo.
+constexpr int TH = RUMPY_TILE_H;       // 8
+constexpr int TW = RUMPY_TILE_W;       // 16
+constexpr int HALO_H = TH + 2;         // 10
+constexpr int HALO_W = TW + 2;         // 18
+constexpr int HALO_PIX = HALO_H * HALO_W;  // 180
+// One pixel = 64 bf16 = 128 B, stored at a 160-B stride in LDS: an odd multiple of 32 B makes both the
+// 16-lane ds_read_b128 fragment reads (conv) and the 8-consecutive-pixel ds_read_b64_tr_b16 reads (wgrad)
+// bank-conflict free (64 banks x 4 B; checked by brute force over the gfx950 lane groups).
+constexpr int PIX_STRIDE = 160;
+constexpr int X_STAGE_BYTES = HALO_PIX * PIX_STRIDE;  // 28800
+constexpr int DY_STAGE_BYTES = TH * TW * PIX_STRIDE;  // 20480
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
+  union { uint4 u; bf16x8 b; } c; c.u = v; return c.b;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  union { __bf16 b; uint16_t u; } c; c.b = b; return c.u;
+}
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = (uint32_t)f32_to_bf16_bits(a) | ((uint32_t)f32_to_bf16_bits(b) << 16);
+  r.y = (uint32_t)f32_to_bf16_bits(c) | ((uint32_t)f32_to_bf16_bits(d) << 16);
+  return r;
+}
+__device__ __forceinline__ void unpack4_bf16(uint2 v, float (&o)[4]) {
+  o[0] = bf16_bits_to_f32(v.x & 0xffffu); o[1] = bf16_bits_to_f32(v.x >> 16);
+  o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
+}
+
+struct TileCoord { int n, ty, tx; };
+__device__ __forceinline__ TileCoord decode_tile(int tile, int tiles_x, int tiles_y) {
+  TileCoord t;
+  t.tx = tile % tiles_x;
+  const int r = tile / tiles_x;
+  t.ty = r % tiles_y;
+  t.n = r / tiles_y;
+  return t;
+}
+
+// Issue the global loads of one 10x18-pixel x 64-channel halo tile into registers (6 x 16 B per thread).
+// mode 0: src is [N,H,W,cstride] bf16, channels coff..coff+63.  mode 1: src is [N,2H,2W,64], sub-pixel q = coff
+// (PixelShuffle^T gather: logical pixel (y,x) lives at (2y + q/2, 2x + q%2)).  Out-of-image pixels read as zero.
+__device__ __forceinline__ void halo_issue(uint4 (&R)[6], const uint16_t* __restrict__ src, int mode, int cstride,
+                                           int coff, int n, int ty, int tx, int H, int W, int tid) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int p = tid + 256 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p < HALO_PIX * 8) {
+      const int pix = p >> 3, part = p & 7;
+      const int r = pix / HALO_W, c = pix - r * HALO_W;
+      const int y = ty * TH + r - 1, x = tx * TW + c - 1;
+      if (y >= 0 && y < H && x >= 0 && x < W) {
+        size_t e;
+        if (mode == 0) e = ((size_t)(n * H + y) * W + x) * cstride + coff + part * 8;
+        else e = ((size_t)(n * 2 * H + 2 * y + (coff >> 1)) * (2 * W) + 2 * x + (coff & 1)) * 64 + part * 8;
+        v = *reinterpret_cast<const uint4*>(src + e);
+      }
+    }
+    R[i] = v;
+  }
+}
+__device__ __forceinline__ void halo_write(const uint4 (&R)[6], unsigned char* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int p = tid + 256 * i;
+    if (p < HALO_PIX * 8) {
+      const int pix = p >> 3, part = p & 7;
+      *reinterpret_cast<uint4*>(lds + pix * PIX_STRIDE + part * 16) = R[i];
+    }
+  }
+}
+
+// host side
+void rumpy_set_error(const char* fmt, ...);
+int rumpy_check_launch(const char* what);
+void rumpy_probe_pre(int kernel_id, hipStream_t s);
+void rumpy_probe_post(int kernel_id, hipStream_t s);

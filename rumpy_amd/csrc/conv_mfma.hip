@@ -1,0 +1,384 @@
+// 3x3 same-padding convolution as an implicit GEMM on bf16 MFMA (gfx950), filter-stationary.
+//
+// One workgroup = 4 waves = one 64-output-channel tile; wave w owns output channels 16w..16w+15 and keeps
+// its slice of the filter (16 co x 576 k = 18 MFMA A-fragments = 72 VGPRs per 64-channel input chunk) in
+// registers for the whole kernel.  The workgroup is persistent: it walks 8x16-pixel tiles; each stage's
+// 10x18-pixel x 64-channel halo tile is staged HBM -> registers -> LDS one stage ahead (two LDS buffers, one
+// barrier per stage), and every wave reads it as MFMA B-fragments (ds_read_b128, conflict-free at the
+// 160-B pixel stride).  One B-fragment (input row r, tap column kx, channel half) feeds the three output
+// rows r-2..r (ky = 2,1,0), so LDS traffic is 10 reads per 24 MFMAs.
+//   D[co][px] (16x16 f32) += A[co][k = 32 input channels of one tap] * B[k][px]
+// The epilogue works on 4 consecutive channels per lane (8-byte accesses): bias, ReLU, scale, ReLU-mask
+// (backward), per-tile channel sums (channel attention), two residual adds, PixelShuffle scatter.
+#include "common.hpp"
+
+struct ConvDev {
+  const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
+  const uint16_t* mask; const uint16_t* res1; const uint16_t* res2; float* pool;
+  int N, H, W, cout_tiles, in_mode, out_mode, relu; float scale; int tiles_x, tiles_y;
+};
+
+template <int CHUNKS>
+__global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(ConvDev a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int ct = blockIdx.y;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const int cstride = 64 * CHUNKS;
+
+  // stationary filter fragments: packed [ct][chunk][wave][s = tap*2 + half][lane] x 16 B
+  bf16x8 F[CHUNKS][18];
+  {
+    const uint4* wp = a.w + (size_t)ct * CHUNKS * (4 * 18 * 64);
+#pragma unroll
+    for (int ch = 0; ch < CHUNKS; ++ch)
+#pragma unroll
+      for (int s = 0; s < 18; ++s) F[ch][s] = as_bf16x8(wp[((ch * 4 + wave) * 18 + s) * 64 + lane]);
+  }
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + ct * 64 + 16 * wave + 4 * g);
+    bj[0] = b4.x; bj[1] = b4.y; bj[2] = b4.z; bj[3] = b4.w;
+  }
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  uint4 R[6];
+  {
+    const TileCoord t = decode_tile(tile, a.tiles_x, a.tiles_y);
+    halo_issue(R, a.x, a.in_mode, cstride, 0, t.n, t.ty, t.tx, a.H, a.W, tid);
+    halo_write(R, lds, tid);
+  }
+  __syncthreads();
+  int buf = 0;
+
+  for (; tile < ntiles; tile += gridDim.x) {
+    const TileCoord tc = decode_tile(tile, a.tiles_x, a.tiles_y);
+    f32x4 acc[TH];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ch = 0; ch < CHUNKS; ++ch) {
+      // prefetch the next stage (next chunk of this tile, or chunk 0 of the next tile)
+      const int ntile = (ch + 1 < CHUNKS) ? tile : tile + (int)gridDim.x;
+      const int nch = (ch + 1 < CHUNKS) ? ch + 1 : 0;
+      const bool has_next = ntile < ntiles;
+      if (has_next) {
+        const TileCoord tn = decode_tile(ntile, a.tiles_x, a.tiles_y);
+        halo_issue(R, a.x, a.in_mode, cstride, a.in_mode == 0 ? nch * 64 : nch, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
+      }
+      const unsigned char* cur = lds + buf * X_STAGE_BYTES;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          bf16x8 I[HALO_H];
+#pragma unroll
+          for (int r = 0; r < HALO_H; ++r)
+            I[r] = *reinterpret_cast<const bf16x8*>(cur + (r * HALO_W + px + kx) * PIX_STRIDE + half * 64 + g * 16);
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int r = 0; r < TH; ++r)
+              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[r + ky], acc[r], 0, 0, 0);
+        }
+      }
+      if (ch == CHUNKS - 1) {
+        // ---- epilogue: lane holds channels c0..c0+3 of pixel (row r, column px) ----
+        const int c0 = 16 * wave + 4 * g;
+        const int xx = tc.tx * TW + px;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < TH; ++r) {
+          const int y = tc.ty * TH + r;
+          if (y < a.H && xx < a.W) {
+            size_t o;
+            if (a.out_mode == 0) o = ((size_t)(tc.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + c0;
+            else o = ((size_t)(tc.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + c0;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = acc[r][j] + bj[j];
+              if (a.relu) v[j] = fmaxf(v[j], 0.f);
+              v[j] *= a.scale;
+            }
+            if (a.mask) {
+              float m[4];
+              unpack4_bf16(*reinterpret_cast<const uint2*>(a.mask + o), m);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ps[j] += v[j];
+            if (a.res1) {
+              float m[4];
+              unpack4_bf16(*reinterpret_cast<const uint2*>(a.res1 + o), m);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += m[j];
+            }
+            if (a.res2) {
+              float m[4];
+              unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + o), m);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] += m[j];
+            }
+            *reinterpret_cast<uint2*>(a.out + o) = pack4_bf16(v[0], v[1], v[2], v[3]);
+          }
+        }
+        if (a.pool) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float s = ps[j];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            ps[j] = s;
+          }
+          if (px == 0) {
+            float* pp = a.pool + ((size_t)(tc.n * a.tiles_y + tc.ty) * a.tiles_x + tc.tx) * (64 * a.cout_tiles) + ct * 64 + c0;
+            *reinterpret_cast<float4*>(pp) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+          }
+        }
+      }
+      if (has_next) halo_write(R, lds + (buf ^ 1) * X_STAGE_BYTES, tid);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tail conv 64 -> C (<=4): every wave holds the same 16-row filter block (rows >= C are zero) and takes two
+// of the tile's eight rows; output fp32 NCHW, optional fused L1 loss + sign gradient.  HBM-bound (reads the
+// largest activation), so MFMA row waste is irrelevant.
+// ------------------------------------------------------------------------------------------------------
+struct TailDev {
+  const uint16_t* x; const uint4* w; const float* bias; float* out; const float* target; uint16_t* dy4;
+  float* loss_partial; int N, C, H, W, tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  bf16x8 F[18];
+#pragma unroll
+  for (int s = 0; s < 18; ++s) F[s] = as_bf16x8(a.w[s * 64 + lane]);
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < a.C; ++j) bj[j] = a.bias[j];
+  float lsum = 0.f;
+
+  int tile = blockIdx.x;
+  uint4 R[6];
+  if (tile < ntiles) {
+    const TileCoord t = decode_tile(tile, a.tiles_x, a.tiles_y);
+    halo_issue(R, a.x, 0, 64, 0, t.n, t.ty, t.tx, a.H, a.W, tid);
+    halo_write(R, lds, tid);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const TileCoord tc = decode_tile(tile, a.tiles_x, a.tiles_y);
+    const int ntile = tile + (int)gridDim.x;
+    const bool has_next = ntile < ntiles;
+    if (has_next) {
+      const TileCoord tn = decode_tile(ntile, a.tiles_x, a.tiles_y);
+      halo_issue(R, a.x, 0, 64, 0, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
+    }
+    const unsigned char* cur = lds + buf * X_STAGE_BYTES;
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        bf16x8 I[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          I[r] = *reinterpret_cast<const bf16x8*>(cur + ((2 * wave + r) * HALO_W + px + kx) * PIX_STRIDE + half * 64 + g * 16);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r], 0, 0, 0);
+      }
+    if (g == 0) {  // D rows 0..3 (= output channels) live in lanes 0..15
+      const int xx = tc.tx * TW + px;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int y = tc.ty * TH + 2 * wave + r;
+        if (y < a.H && xx < a.W) {
+          float sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < a.C) {
+              const size_t o = ((size_t)(tc.n * a.C + j) * a.H + y) * a.W + xx;
+              const float v = acc[r][j] + bj[j];
+              a.out[o] = v;
+              if (a.target) {
+                const float d = v - a.target[o];
+                lsum += fabsf(d);
+                sg[j] = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+              }
+            }
+          }
+          if (a.dy4)
+            *reinterpret_cast<uint2*>(a.dy4 + ((size_t)(tc.n * a.H + y) * a.W + xx) * 4) = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
+        }
+      }
+    }
+    if (has_next) halo_write(R, lds + (buf ^ 1) * X_STAGE_BYTES, tid);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (a.loss_partial) {
+    float s = lsum;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) a.loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+__global__ void loss_finalize_kernel(const float* partial, int n, float inv_numel, float* loss) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] * inv_numel;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// tail dgrad: dy4 [N,H,W,4] bf16 -> dx [N,H,W,64] bf16.  K = 9 taps x 4 channels = 36, padded to 64 (two MFMA
+// k-steps); B-fragment element e of lane group g is (tap = 8*ks + 2g + e/4, channel e%4), i.e. two 8-byte LDS
+// reads per k-step.  Write-bound (the output is the largest gradient tensor).
+// ------------------------------------------------------------------------------------------------------
+struct TailDgradDev { const uint16_t* dy4; const uint4* w; uint16_t* dx; int N, H, W, tiles_x, tiles_y; };
+
+__global__ void __launch_bounds__(256, 2) tail_dgrad_kernel(TailDgradDev a) {
+  __shared__ __attribute__((aligned(16))) uint2 sdy[HALO_PIX + 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const TileCoord tc = decode_tile(blockIdx.x, a.tiles_x, a.tiles_y);
+  if (tid < HALO_PIX) {
+    const int r = tid / HALO_W, c = tid - r * HALO_W;
+    const int y = tc.ty * TH + r - 1, x = tc.tx * TW + c - 1;
+    uint2 v = make_uint2(0, 0);
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+      v = *reinterpret_cast<const uint2*>(a.dy4 + ((size_t)(tc.n * a.H + y) * a.W + x) * 4);
+    sdy[tid] = v;
+  }
+  const bf16x8 F0 = as_bf16x8(a.w[(wave * 2 + 0) * 64 + lane]);
+  const bf16x8 F1 = as_bf16x8(a.w[(wave * 2 + 1) * 64 + lane]);
+  __syncthreads();
+  const int c0 = 16 * wave + 4 * g;
+  const int xx = tc.tx * TW + px;
+  // taps of this lane group: ks=0 -> 2g, 2g+1 ; ks=1 -> 8+2g (only g==0 real), 9+2g (never)
+  const int ta = 2 * g, tb = 2 * g + 1;
+  const int kya = ta / 3, kxa = ta - 3 * kya, kyb = tb / 3, kxb = tb - 3 * kyb;
+#pragma unroll
+  for (int r = 0; r < TH; ++r) {
+    union { uint2 u[2]; bf16x8 b; } B0, B1;
+    B0.u[0] = sdy[(r + kya) * HALO_W + px + kxa];
+    B0.u[1] = sdy[(r + kyb) * HALO_W + px + kxb];
+    B1.u[0] = (g == 0) ? sdy[(r + 2) * HALO_W + px + 2] : make_uint2(0, 0);
+    B1.u[1] = make_uint2(0, 0);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F0, B0.b, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1, B1.b, acc, 0, 0, 0);
+    const int y = tc.ty * TH + r;
+    if (y < a.H && xx < a.W)
+      *reinterpret_cast<uint2*>(a.dx + ((size_t)(tc.n * a.H + y) * a.W + xx) * 64 + c0) = pack4_bf16(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+
+__global__ void nchw_to_nhwc4_kernel(const float* src, uint16_t* dst, int N, int C, int H, int W) {
+  const size_t total = (size_t)N * H * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t hw = i % ((size_t)H * W);
+    const size_t n = i / ((size_t)H * W);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) v[c] = src[(n * C + c) * (size_t)H * W + hw];
+    *reinterpret_cast<uint2*>(dst + i * 4) = pack4_bf16(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host entry points
+// ------------------------------------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
+  if (!p || !p->x || !p->w || !p->out) { rumpy_set_error("rumpy_conv3x3: null pointer"); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cout_tiles <= 0) { rumpy_set_error("rumpy_conv3x3: bad shape"); return RUMPY_E_ARG; }
+  if (p->cin_chunks != 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 or 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
+  if (p->in_mode == 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: in_mode 1 needs cin_chunks 4"); return RUMPY_E_ARG; }
+  if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || p->res1 || p->res2)) { rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4 and no mask/residual"); return RUMPY_E_ARG; }
+  ConvDev d;
+  d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = (uint16_t*)p->out;
+  d.mask = (const uint16_t*)p->mask; d.res1 = (const uint16_t*)p->res1; d.res2 = (const uint16_t*)p->res2; d.pool = p->pool;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.cout_tiles = p->cout_tiles; d.in_mode = p->in_mode; d.out_mode = p->out_mode;
+  d.relu = p->relu; d.scale = p->scale; d.tiles_x = cdiv(p->W, TW); d.tiles_y = cdiv(p->H, TH);
+  const int ntiles = d.N * d.tiles_x * d.tiles_y;
+  int gx = p->grid_x;
+  if (gx <= 0) {
+    const int slots = (p->cin_chunks == 1 ? 2 : 1) * rumpy_device_cus();
+    const int per_ct = slots / p->cout_tiles > 0 ? slots / p->cout_tiles : 1;
+    const int rounds = cdiv(ntiles, per_ct);       // balance: every workgroup gets `rounds` or rounds-1 tiles
+    gx = cdiv(ntiles, rounds);
+  }
+  if (gx > ntiles) gx = ntiles;
+  hipStream_t s = (hipStream_t)stream;
+  const int kid = (p->cin_chunks == 1 && p->cout_tiles == 1) ? 1 : 3;
+  rumpy_probe_pre(kid, s);
+  dim3 grid(gx, p->cout_tiles);
+  if (p->cin_chunks == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
+  rumpy_probe_post(kid, s);
+  return rumpy_check_launch("rumpy_conv3x3");
+}
+
+extern "C" int rumpy_tail_fwd(const rumpy_tail_fwd_args* p, void* stream) {
+  if (!p || !p->x || !p->w || !p->bias || !p->out) { rumpy_set_error("rumpy_tail_fwd: null pointer"); return RUMPY_E_ARG; }
+  if (p->C < 1 || p->C > 4 || p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("rumpy_tail_fwd: bad shape"); return RUMPY_E_ARG; }
+  if ((p->dy4 || p->loss_partial || p->loss) && !p->target) { rumpy_set_error("rumpy_tail_fwd: loss outputs need target"); return RUMPY_E_ARG; }
+  if (p->target && (!p->loss_partial || !p->loss)) { rumpy_set_error("rumpy_tail_fwd: target needs loss_partial and loss"); return RUMPY_E_ARG; }
+  TailDev d;
+  d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = p->out; d.target = p->target;
+  d.dy4 = (uint16_t*)p->dy4; d.loss_partial = p->loss_partial; d.N = p->N; d.C = p->C; d.H = p->H; d.W = p->W;
+  d.tiles_x = cdiv(p->W, TW); d.tiles_y = cdiv(p->H, TH);
+  const int ntiles = d.N * d.tiles_x * d.tiles_y;
+  int gx = p->grid_x > 0 ? p->grid_x : 2 * rumpy_device_cus();
+  if (gx > ntiles) gx = ntiles;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tail_fwd_kernel, dim3(gx), dim3(256), 0, s, d);
+  if (p->target) {
+    const float inv = 1.0f / ((float)p->N * p->C * p->H * p->W);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, p->loss_partial, gx, inv, p->loss);
+  }
+  return rumpy_check_launch("rumpy_tail_fwd");
+}
+
+extern "C" int rumpy_tail_dgrad(const rumpy_tail_dgrad_args* p, void* stream) {
+  if (!p || !p->dy4 || !p->w || !p->dx || p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("rumpy_tail_dgrad: bad argument"); return RUMPY_E_ARG; }
+  TailDgradDev d;
+  d.dy4 = (const uint16_t*)p->dy4; d.w = (const uint4*)p->w; d.dx = (uint16_t*)p->dx; d.N = p->N; d.H = p->H; d.W = p->W;
+  d.tiles_x = cdiv(p->W, TW); d.tiles_y = cdiv(p->H, TH);
+  hipLaunchKernelGGL(tail_dgrad_kernel, dim3(d.N * d.tiles_x * d.tiles_y), dim3(256), 0, (hipStream_t)stream, d);
+  return rumpy_check_launch("rumpy_tail_dgrad");
+}
+
+extern "C" int rumpy_nchw_to_nhwc4(const rumpy_nchw_to_nhwc4_args* p, void* stream) {
+  if (!p || !p->src || !p->dst || p->C < 1 || p->C > 4 || p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("rumpy_nchw_to_nhwc4: bad argument"); return RUMPY_E_ARG; }
+  const size_t total = (size_t)p->N * p->H * p->W;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p->src, (uint16_t*)p->dst, p->N, p->C, p->H, p->W);
+  return rumpy_check_launch("rumpy_nchw_to_nhwc4");
+}

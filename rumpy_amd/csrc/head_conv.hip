@@ -1,0 +1,163 @@
+// Head convolution (image, C <= 4 channels, fp32 NCHW -> 64*k channels NHWC bf16) and its weight gradient.
+// K = 9*C <= 36 is far too small for MFMA to matter (0.09 % of the network's FLOPs), so both run on the fp32
+// VALU and are exact fp32 like the reference; the image is read straight from the caller's NCHW tensor.
+#include "common.hpp"
+
+constexpr int HEAD_MAXC = 4;
+
+// one thread = one pixel x 64 output channels; weights transposed to [k = (c,ky,kx)][co] in LDS (broadcast reads)
+template <int C>
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, uint16_t* __restrict__ out,
+                                                       int N, int H, int W, int cout) {
+  __shared__ __attribute__((aligned(16))) float sw[9 * HEAD_MAXC * 64];
+  __shared__ float sb[64];
+  const int ct = blockIdx.y;
+  constexpr int K = 9 * C;
+  for (int i = threadIdx.x; i < K * 64; i += 256) {
+    const int k = i >> 6, co = i & 63;
+    sw[i] = w[(size_t)(ct * 64 + co) * K + k];  // OIHW: [co][c][ky][kx] -> k = c*9 + ky*3 + kx
+  }
+  if (threadIdx.x < 64) sb[threadIdx.x] = b[ct * 64 + threadIdx.x];
+  __syncthreads();
+  const size_t total = (size_t)N * H * W;
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= total) return;
+  const int xx = (int)(p % W);
+  const int y = (int)((p / W) % H);
+  const int n = (int)(p / ((size_t)W * H));
+  float in[K];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xc = xx + kx - 1;
+        in[c * 9 + ky * 3 + kx] = (yy >= 0 && yy < H && xc >= 0 && xc < W) ? x[((size_t)(n * C + c) * H + yy) * W + xc] : 0.f;
+      }
+  uint16_t* op = out + p * cout + ct * 64;
+#pragma unroll
+  for (int cb = 0; cb < 64; cb += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = sb[cb + j];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float4 w0 = *reinterpret_cast<const float4*>(&sw[k * 64 + cb]);
+      const float4 w1 = *reinterpret_cast<const float4*>(&sw[k * 64 + cb + 4]);
+      const float v = in[k];
+      acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]); acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
+      acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]); acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+    }
+    const uint2 lo = pack4_bf16(acc[0], acc[1], acc[2], acc[3]);
+    const uint2 hi = pack4_bf16(acc[4], acc[5], acc[6], acc[7]);
+    *reinterpret_cast<uint4*>(op + cb) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+}
+
+// weight gradient: persistent workgroups over 8x16-pixel tiles.  Thread (co = tid & 63, part = tid >> 6) owns
+// k = part, part+4, ... (<= 9 of the 9*C taps) and accumulates dy[p][co] * x[p + tap][c] over the tile pixels.
+// slab per workgroup: [cout_tiles][64][9*C + 1] (last column = bias sum).
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                         float* __restrict__ slab, int N, int C, int H, int W, int cout) {
+  __shared__ float sx[HEAD_MAXC * HALO_PIX];
+  __shared__ __attribute__((aligned(16))) uint16_t sdy[TH * TW * 64];
+  const int tid = threadIdx.x, co = tid & 63, part = tid >> 6;
+  const int ct = blockIdx.y;
+  const int K = 9 * C;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int ntiles = N * tiles_y * tiles_x;
+  float acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+  float bsum = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const TileCoord tc = decode_tile(tile, tiles_x, tiles_y);
+    __syncthreads();
+    for (int i = tid; i < C * HALO_PIX; i += 256) {
+      const int c = i / HALO_PIX, pix = i - c * HALO_PIX;
+      const int r = pix / HALO_W, cc = pix - r * HALO_W;
+      const int y = tc.ty * TH + r - 1, xx = tc.tx * TW + cc - 1;
+      sx[i] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[((size_t)(tc.n * C + c) * H + y) * W + xx] : 0.f;
+    }
+    for (int i = tid; i < TH * TW * 8; i += 256) {
+      const int pix = i >> 3, part8 = i & 7;
+      const int y = tc.ty * TH + (pix >> 4), xx = tc.tx * TW + (pix & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y < H && xx < W) v = *reinterpret_cast<const uint4*>(dy + ((size_t)(tc.n * H + y) * W + xx) * cout + ct * 64 + part8 * 8);
+      *reinterpret_cast<uint4*>(&sdy[pix * 64 + part8 * 8]) = v;
+    }
+    __syncthreads();
+    for (int pix = 0; pix < TH * TW; ++pix) {
+      const float d = bf16_bits_to_f32(sdy[pix * 64 + co]);
+      const int r = pix >> 4, cc = pix & 15;
+      if (part == 0) bsum += d;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const int k = part + 4 * i;
+        if (k < K) {
+          const int c = k / 9, t = k - 9 * c, ky = t / 3, kx = t - 3 * ky;
+          acc[i] = fmaf(d, sx[c * HALO_PIX + (r + ky) * HALO_W + cc + kx], acc[i]);
+        }
+      }
+    }
+  }
+  float* s = slab + ((size_t)blockIdx.x * gridDim.y + ct) * 64 * (K + 1) + (size_t)co * (K + 1);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int k = part + 4 * i;
+    if (k < K) s[k] = acc[i];
+  }
+  if (part == 0) s[K] = bsum;
+}
+
+__global__ void head_wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int C, int cout, float scale,
+                                         float* __restrict__ gw, float* __restrict__ gb) {
+  const int K = 9 * C;
+  const int total = cout * (K + 1);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  float s = 0.f;
+  for (int g = 0; g < nwg; ++g) s += slab[(size_t)g * total + e];
+  const int co = e / (K + 1), k = e - co * (K + 1);
+  if (k < K) gw[(size_t)co * K + k] = s * scale;
+  else gb[co] = s * scale;
+}
+
+static int head_wgrad_grid() { return rumpy_device_cus(); }
+
+extern "C" int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout) {
+  return (int64_t)head_wgrad_grid() * cout * (9 * C + 1);
+}
+
+extern "C" int rumpy_head_fwd(const rumpy_head_fwd_args* p, void* stream) {
+  if (!p || !p->x || !p->w || !p->b || !p->out) { rumpy_set_error("rumpy_head_fwd: null pointer"); return RUMPY_E_ARG; }
+  if (p->C < 1 || p->C > HEAD_MAXC || p->cout <= 0 || p->cout % 64 || p->N <= 0 || p->H <= 0 || p->W <= 0) {
+    rumpy_set_error("rumpy_head_fwd: unsupported shape (C=%d cout=%d)", p->C, p->cout); return RUMPY_E_ARG; }
+  const size_t total = (size_t)p->N * p->H * p->W;
+  dim3 grid((unsigned)((total + 255) / 256), p->cout / 64);
+  hipStream_t s = (hipStream_t)stream;
+  uint16_t* o = (uint16_t*)p->out;
+  switch (p->C) {
+    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    default: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+  }
+  return rumpy_check_launch("rumpy_head_fwd");
+}
+
+extern "C" int rumpy_head_wgrad(const rumpy_head_wgrad_args* p, void* stream) {
+  if (!p || !p->x || !p->dy || !p->slab || !p->gw || !p->gb) { rumpy_set_error("rumpy_head_wgrad: null pointer"); return RUMPY_E_ARG; }
+  if (p->C < 1 || p->C > HEAD_MAXC || p->cout <= 0 || p->cout % 64 || p->N <= 0 || p->H <= 0 || p->W <= 0) {
+    rumpy_set_error("rumpy_head_wgrad: unsupported shape"); return RUMPY_E_ARG; }
+  const int nwg = head_wgrad_grid();
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(head_wgrad_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
+                     p->N, p->C, p->H, p->W, p->cout);
+  const int total = p->cout * (9 * p->C + 1);
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p->slab, nwg, p->C, p->cout,
+                     p->scale, p->gw, p->gb);
+  return rumpy_check_launch("rumpy_head_wgrad");
+}

@@ -1,0 +1,469 @@
+"""Host-side executor of the SR conv hot path on MI355X: turns an EDSR / RCAN module tree into a static list of
+C-ABI kernel launches (forward, backward, weight gradients, optimizer) over preallocated NHWC-bf16 HBM buffers.
+
+PyTorch is used only for device memory, streams and (elsewhere) torch.distributed; every arithmetic step is a
+hand-written HIP kernel reached through ``rumpy_amd._lib`` (include/rumpy_amd.h).  Reference behaviour being
+reproduced (paths relative to /root/reference/rumpy):
+  SISR/models/advanced/architectures.py:198-241 (EDSR.forward), :140-176 (RCAN.forward), :60-84 (RCAB),
+  :107-124 (ResidualGroup), :24-44 (CALayer); SISR/models/advanced/common.py:23-75 (Upsampler, ResBlock);
+  shared_framework/models/base_architecture.py:425-485 (loss.backward + Adam step).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class ConvLayer:
+    """One nn.Conv2d(k=3, p=1) of the net: fp32 OIHW master parameters + packed bf16 images."""
+
+    def __init__(self, name, weight, bias, kind, shuffle=False):
+        self.name, self.weight, self.bias, self.kind, self.shuffle = name, weight, bias, kind, shuffle
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.w_fwd = self.w_dgrad = self.b_packed = None
+        self.gw = self.gb = None  # views into the flat gradient buffer
+
+
+class CALayerParams:
+    """RCAN CALayer 1x1 convs (architectures.py:34-39)."""
+
+    def __init__(self, name, w1, b1, w2, b2):
+        self.name, self.w1, self.b1, self.w2, self.b2 = name, w1, b1, w2, b2
+        self.C, self.Cr = w2.shape[0], w1.shape[0]
+        self.gw1 = self.gb1 = self.gw2 = self.gb2 = None
+
+
+class NetSpec:
+    """Topology handed over by the architecture module.
+
+    body items: ('resblock', conv1, conv2, res_scale) | ('rcab', conv1, conv2, ca) | ('group', [items], conv)
+    """
+
+    def __init__(self, head, body, body_conv, ups, tail, scale):
+        self.head, self.body, self.body_conv, self.ups, self.tail, self.scale = head, body, body_conv, ups, tail, scale
+
+    def convs(self):
+        out = [self.head]
+
+        def walk(items):
+            for it in items:
+                if it[0] in ('resblock', 'rcab'):
+                    out.extend([it[1], it[2]])
+                else:
+                    walk(it[1])
+                    out.append(it[2])
+        walk(self.body)
+        out.append(self.body_conv)
+        out.extend(self.ups)
+        out.append(self.tail)
+        return out
+
+    def cas(self):
+        out = []
+
+        def walk(items):
+            for it in items:
+                if it[0] == 'rcab':
+                    out.append(it[3])
+                elif it[0] == 'group':
+                    walk(it[1])
+        walk(self.body)
+        return out
+
+
+class _Plan:
+    """Static launch lists + buffers for one (N, H, W, train) shape."""
+
+    def __init__(self):
+        self.fwd, self.bwd, self.keep = [], [], []
+        self.x_in = self.target = self.out = self.loss = self.dy4 = None
+        self.gout_stage = None
+
+
+class SREngine:
+    def __init__(self, spec, device, wgrad_pixels_per_job=9216):
+        self.spec, self.device = spec, device
+        self.lib = L.lib()
+        self.cus = self.lib.rumpy_device_cus()
+        self.plans = {}
+        self.wgrad_pixels_per_job = wgrad_pixels_per_job
+        self.feats = spec.head.cout
+        if self.feats != 64:
+            raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 (got %d); other widths are not '
+                               'implemented yet and there is no fallback' % self.feats)
+        if spec.head.cin > 4 or spec.tail.cout > 4:
+            raise RuntimeError('rumpy_amd: image channels must be <= 4')
+        if spec.tail.cin != 64:
+            raise RuntimeError('rumpy_amd: tail conv needs 64 input features (got %d)' % spec.tail.cin)
+        for cv in spec.convs():
+            if cv.kind == 'main' and (cv.cin not in (64, 256) or cv.cout % 64):
+                raise RuntimeError('rumpy_amd: conv %s %d->%d unsupported (Cin must be 64 or 256, Cout a multiple of 64)'
+                                   % (cv.name, cv.cin, cv.cout))
+        self._alloc_packed()
+        self.packed_version = None
+
+    # ------------------------------------------------------------------ packed filters
+    def _alloc_packed(self):
+        dev = self.device
+        items = []
+        for cv in self.spec.convs():
+            if cv.kind == 'head':
+                continue
+            if cv.kind == 'main':
+                n = cv.cout * cv.cin * 9
+                cv.w_fwd = torch.empty(n, dtype=BF16, device=dev)
+                cv.w_dgrad = torch.empty(n, dtype=BF16, device=dev)
+                cv.b_packed = torch.empty(cv.cout, dtype=torch.float32, device=dev)
+                items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd), w_dgrad=_ptr(cv.w_dgrad),
+                                        b_packed=_ptr(cv.b_packed), cout=cv.cout, cin=cv.cin, kind=0,
+                                        shuffle=1 if cv.shuffle else 0))
+            else:  # tail
+                cv.w_fwd = torch.empty(18 * 64 * 8, dtype=BF16, device=dev)
+                cv.w_dgrad = torch.empty(4 * 2 * 64 * 8, dtype=BF16, device=dev)
+                items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd), w_dgrad=_ptr(cv.w_dgrad),
+                                        b_packed=None, cout=cv.cout, cin=cv.cin, kind=2, shuffle=0))
+        self._pack_items_host = (L.PackItem * len(items))(*items)
+        self._pack_items = self._to_device_bytes(self._pack_items_host)
+        self._n_pack = len(items)
+
+    def _to_device_bytes(self, ctypes_array):
+        raw = np.frombuffer(bytes(ctypes_array), dtype=np.uint8).copy()
+        return torch.from_numpy(raw).to(self.device)
+
+    def repack(self, stream=None):
+        """fp32 OIHW master weights -> bf16 MFMA-fragment images (after every optimizer step / weight load)."""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.rumpy_pack_weights(_ptr(self._pack_items), self._n_pack, s), 'rumpy_pack_weights')
+
+    # ------------------------------------------------------------------ plan construction
+    def _new(self, plan, *shape, dtype=BF16):
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        plan.keep.append(t)
+        return t
+
+    def _conv(self, ops, x, cv, N, H, W, out, dgrad=False, relu=False, scale=1.0, mask=None, res1=None, res2=None,
+              pool=None, in_mode=0, out_mode=0, bias=True):
+        if dgrad:
+            w, cin_chunks, cout_tiles, b = cv.w_dgrad, cv.cout // 64, cv.cin // 64, None
+        else:
+            w, cin_chunks, cout_tiles, b = cv.w_fwd, cv.cin // 64, cv.cout // 64, (cv.b_packed if bias else None)
+        a = L.ConvArgs(x=_ptr(x), w=_ptr(w), bias=_ptr(b), out=_ptr(out), mask=_ptr(mask), res1=_ptr(res1), res2=_ptr(res2),
+                       pool=_ptr(pool), N=N, H=H, W=W, cin_chunks=cin_chunks, cout_tiles=cout_tiles, in_mode=in_mode,
+                       out_mode=out_mode, relu=1 if relu else 0, scale=float(scale), grid_x=0)
+        ops.append(('rumpy_conv3x3', a))
+
+    def _build(self, N, H, W, train):
+        spec, lib = self.spec, self.lib
+        F = self.feats
+        plan = _Plan()
+        plan.N, plan.H, plan.W, plan.train = N, H, W, train
+        Cin, Cout = spec.head.cin, spec.tail.cout
+        plan.x_in = self._new(plan, N, Cin, H, W, dtype=torch.float32)
+        fwd, bwd = plan.fwd, plan.bwd
+        tiles = ((H + L.TILE_H - 1) // L.TILE_H) * ((W + L.TILE_W - 1) // L.TILE_W)
+        wjobs = []      # (layer, x, dy, H, W, dy_mode, scale, mt)
+
+        free_pool = []
+        protected = []          # data_ptrs of live skip sources (eval-mode buffer reuse must not recycle them)
+        plan.scaled = []
+
+        def act():
+            if not train and free_pool:
+                return free_pool.pop()
+            return self._new(plan, N, H, W, F)
+
+        def release(t):
+            if not train and t.data_ptr() not in protected:
+                free_pool.append(t)
+
+        # ---- head ----
+        a0 = act()
+        protected.append(a0.data_ptr())
+        fwd.append(('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(plan.x_in), w=_ptr(spec.head.weight), b=_ptr(spec.head.bias),
+                                                    out=_ptr(a0), N=N, C=Cin, H=H, W=W, cout=F)))
+
+        def emit_items(items, cur):
+            """Emit forward ops for a chain of body items; returns (output buffer, backward node list).
+            A backward node is a callable(g_out, extra) -> g_in for a residual unit, or
+            ('group', conv, inner_out, sub_nodes) for a ResidualGroup."""
+            nodes = []
+            for it in items:
+                if it[0] == 'resblock':
+                    _, c1, c2, rs = it
+                    t1, y = act(), act()
+                    self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
+                    self._conv(fwd, t1, c2, N, H, W, y, scale=rs, res1=cur)
+
+                    def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs):
+                        # y = x + rs*conv2(relu(conv1 x)):  dt1 = rs*dgrad2(g) masked ; dx = g + dgrad1(dt1) (+ extra)
+                        dt1, dx = self._new(plan, N, H, W, F), self._new(plan, N, H, W, F)
+                        self._conv(bwd, g_out, c2, N, H, W, dt1, dgrad=True, scale=rs, mask=t1)
+                        wjobs.append((c2, t1, g_out, H, W, 0, rs, 4))
+                        self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
+                        wjobs.append((c1, x_in, dt1, H, W, 0, 1.0, 4))
+                        return dx
+                    nodes.append(node)
+                    release(t1)
+                    release(cur)
+                    cur = y
+                elif it[0] == 'rcab':
+                    _, c1, c2, ca = it
+                    t1, t2, y = act(), act(), act()
+                    pool = self._new(plan, N, tiles, F, dtype=torch.float32)
+                    mean = self._new(plan, N, F, dtype=torch.float32)
+                    hid = self._new(plan, N, ca.Cr, dtype=torch.float32)
+                    gate = self._new(plan, N, F, dtype=torch.float32)
+                    self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
+                    self._conv(fwd, t1, c2, N, H, W, t2, pool=pool)
+                    fwd.append(('rumpy_ca_mlp_fwd', L.CaMlpFwdArgs(pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2),
+                                                                    b2=_ptr(ca.b2), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate),
+                                                                    N=N, C=F, Cr=ca.Cr, ntiles=tiles, inv_hw=1.0 / (H * W))))
+                    fwd.append(('rumpy_ca_scale_res_fwd', L.CaScaleArgs(t=_ptr(t2), res=_ptr(cur), gate=_ptr(gate), out=_ptr(y),
+                                                                         N=N, HW=H * W, C=F)))
+
+                    def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate):
+                        # y = x + t2*gate:  dgate = sum(g*t2) -> MLP backward -> dpool ; dt2 = g*gate + dpool
+                        nchunks = (H * W + 127) // 128
+                        part = self._new(plan, N, nchunks, F, dtype=torch.float32)
+                        dpool = self._new(plan, N, F, dtype=torch.float32)
+                        dt2, dt1, dx = (self._new(plan, N, H, W, F) for _ in range(3))
+                        bwd.append(('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=_ptr(g_out), t=_ptr(t2), partial=_ptr(part),
+                                                                              N=N, HW=H * W, C=F)))
+                        a = L.CaMlpBwdArgs(partial=_ptr(part), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1),
+                                           w2=_ptr(ca.w2), dpool=_ptr(dpool), gw1=_ptr(ca.gw1), gb1=_ptr(ca.gb1),
+                                           gw2=_ptr(ca.gw2), gb2=_ptr(ca.gb2), N=N, C=F, Cr=ca.Cr, nchunks=nchunks,
+                                           inv_hw=1.0 / (H * W), scale=1.0)
+                        bwd.append(('rumpy_ca_mlp_bwd', a))
+                        plan.scaled.append(a)
+                        bwd.append(('rumpy_ca_bwd_apply', L.CaBwdApplyArgs(dy=_ptr(g_out), gate=_ptr(gate), dpool=_ptr(dpool),
+                                                                            dt=_ptr(dt2), N=N, HW=H * W, C=F)))
+                        self._conv(bwd, dt2, c2, N, H, W, dt1, dgrad=True, mask=t1)
+                        wjobs.append((c2, t1, dt2, H, W, 0, 1.0, 4))
+                        self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
+                        wjobs.append((c1, x_in, dt1, H, W, 0, 1.0, 4))
+                        return dx
+                    nodes.append(node)
+                    release(t1)
+                    release(t2)
+                    release(cur)
+                    cur = y
+                else:  # ('group', items, conv): y = conv(chain(x)) + x
+                    _, sub, gconv = it
+                    x_in = cur
+                    protected.append(x_in.data_ptr())
+                    inner, sub_nodes = emit_items(sub, x_in)
+                    y = act()
+                    self._conv(fwd, inner, gconv, N, H, W, y, res1=x_in)
+                    protected.pop()
+                    nodes.append(('group', gconv, inner, sub_nodes))
+                    if inner is not x_in:
+                        release(inner)
+                    release(x_in)
+                    cur = y
+            return cur, nodes
+
+        last, tree = emit_items(spec.body, a0)
+        r = act()
+        self._conv(fwd, last, spec.body_conv, N, H, W, r, res1=a0)
+        # ---- upsampler ----
+        ups_in = []
+        u, h, w = r, H, W
+        for cv in spec.ups:
+            nxt = self._new(plan, N, 2 * h, 2 * w, F)
+            self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1)
+            ups_in.append((cv, u, h, w))
+            u, h, w = nxt, 2 * h, 2 * w
+        # ---- tail (+ fused L1) ----
+        plan.out = self._new(plan, N, Cout, h, w, dtype=torch.float32)
+        plan.HR = (h, w)
+        tail_grid = min(2 * self.cus, N * ((h + L.TILE_H - 1) // L.TILE_H) * ((w + L.TILE_W - 1) // L.TILE_W))
+        plan.loss = self._new(plan, 1, dtype=torch.float32)
+        plan.loss_partial = self._new(plan, max(tail_grid, 1), dtype=torch.float32)
+        plan.target = self._new(plan, N, Cout, h, w, dtype=torch.float32)
+        plan.dy4 = self._new(plan, N, h, w, 4) if train else None
+        plan.tail_plain = L.TailFwdArgs(x=_ptr(u), w=_ptr(spec.tail.w_fwd), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
+                                        target=None, dy4=None, loss_partial=None, loss=None, N=N, C=Cout, H=h, W=w, grid_x=tail_grid)
+        plan.tail_loss = L.TailFwdArgs(x=_ptr(u), w=_ptr(spec.tail.w_fwd), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
+                                       target=_ptr(plan.target), dy4=_ptr(plan.dy4), loss_partial=_ptr(plan.loss_partial),
+                                       loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid)
+        if not train:
+            return plan
+
+        # =============================== backward ===============================
+        plan.gout_stage = None
+        g = self._new(plan, N, h, w, F)
+        bwd.append(('rumpy_tail_dgrad', L.TailDgradArgs(dy4=_ptr(plan.dy4), w=_ptr(spec.tail.w_dgrad), dx=_ptr(g), N=N, H=h, W=w)))
+        wjobs.append((spec.tail, u, plan.dy4, h, w, 2, 1.0, 1))
+        for cv, uin, uh, uw in reversed(ups_in):
+            gin = self._new(plan, N, uh, uw, F)
+            self._conv(bwd, g, cv, N, uh, uw, gin, dgrad=True, in_mode=1)
+            wjobs.append((cv, uin, g, uh, uw, 1, 1.0, 4))
+            g = gin
+        g_r = g                                      # grad wrt r = body_conv(last) + a0
+        g_last = self._new(plan, N, H, W, F)
+        self._conv(bwd, g_r, spec.body_conv, N, H, W, g_last, dgrad=True)
+        wjobs.append((spec.body_conv, last, g_r, H, W, 0, 1.0, 4))
+
+        def run_tree(nodes, g_out, extra_first):
+            for idx in range(len(nodes) - 1, -1, -1):
+                nd = nodes[idx]
+                extra = extra_first if idx == 0 else None
+                if callable(nd):
+                    g_out = nd(g_out, extra)
+                else:
+                    _, gconv, inner_out, sub = nd
+                    # y = gconv(inner_out) + x_in ; g_out = dL/dy
+                    g_inner = self._new(plan, N, H, W, F)
+                    self._conv(bwd, g_out, gconv, N, H, W, g_inner, dgrad=True)
+                    wjobs.append((gconv, inner_out, g_out, H, W, 0, 1.0, 4))
+                    if sub:
+                        g_in = run_tree(sub, g_inner, g_out)      # skip gradient joins at the group's first block
+                        if extra is not None:
+                            g_in = self._add_extra(plan, bwd, g_in, extra, N, H, W)
+                    else:
+                        g_in = self._add_extra(plan, bwd, g_inner, g_out, N, H, W)
+                        if extra is not None:
+                            g_in = self._add_extra(plan, bwd, g_in, extra, N, H, W)
+                    g_out = g_in
+            return g_out
+
+        if tree:
+            g_a0 = run_tree(tree, g_last, g_r)       # global skip gradient g_r joins at the first body block
+        else:
+            g_a0 = self._add_extra(plan, bwd, g_last, g_r, N, H, W)
+
+        # ---- head weight gradient ----
+        slab = self._new(plan, int(lib.rumpy_head_wgrad_slab_floats(Cin, F)), dtype=torch.float32)
+        a = L.HeadWgradArgs(x=_ptr(plan.x_in), dy=_ptr(g_a0), slab=_ptr(slab), gw=_ptr(spec.head.gw), gb=_ptr(spec.head.gb),
+                            N=N, C=Cin, H=H, W=W, cout=F, scale=1.0)
+        bwd.append(('rumpy_head_wgrad', a))
+        plan.scaled.append(a)
+
+        # ---- grouped weight gradients ----
+        self._emit_wgrad(plan, wjobs, N)
+        return plan
+
+    def _add_extra(self, plan, ops, g, extra, N, H, W):
+        """g + extra through the CA scale kernel with a unit gate (rare path: group without residual units)."""
+        F = self.feats
+        if not hasattr(plan, 'ones_gate'):
+            plan.ones_gate = torch.ones(N, F, dtype=torch.float32, device=self.device)
+        out = self._new(plan, N, H, W, F)
+        ops.append(('rumpy_ca_scale_res_fwd', L.CaScaleArgs(t=_ptr(g), res=_ptr(extra), gate=_ptr(plan.ones_gate), out=_ptr(out),
+                                                             N=N, HW=H * W, C=F)))
+        return out
+
+    def _emit_wgrad(self, plan, wjobs, N):
+        lib = self.lib
+        jobs = {4: [], 1: []}
+        items = []
+        slab_floats = {4: int(lib.rumpy_wgrad_slab_floats(4)), 1: int(lib.rumpy_wgrad_slab_floats(1))}
+        # first pass: count slabs
+        layout = []
+        total = 0
+        for (cv, x, dy, H, W, dy_mode, scale, mt) in wjobs:
+            imgs = max(1, min(N, self.wgrad_pixels_per_job // (H * W)))
+            ranges = [(n0, min(N, n0 + imgs)) for n0 in range(0, N, imgs)]
+            cin_chunks = cv.cin // 64
+            cout_tiles = cv.cout // 64 if mt == 4 else 1
+            for ch in range(cin_chunks):
+                for ct in range(cout_tiles):
+                    layout.append((cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, total))
+                    total += len(ranges) * slab_floats[mt]
+        slabs = self._new(plan, max(total, 1), dtype=torch.float32)
+        base = slabs.data_ptr()
+        for (cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, off) in layout:
+            sf = slab_floats[mt]
+            for k, (n0, n1) in enumerate(ranges):
+                if dy_mode == 0:
+                    dcs, dco = cv.cout, ct * 64
+                elif dy_mode == 1:
+                    dcs, dco = 64, ct
+                else:
+                    dcs, dco = 4, 0
+                jobs[mt].append(L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=n0, n1=n1, H=H, W=W,
+                                           x_cstride=cv.cin, x_coff=ch * 64, dy_mode=dy_mode, dy_cstride=dcs, dy_coff=dco, mt=mt))
+            items.append(L.ReduceItem(slab=base + 4 * off, slab_stride=sf, njobs=len(ranges), mt=mt,
+                                      co_count=(64 if mt == 4 else cv.cout), co_mode=1 if (mt == 4 and cv.shuffle) else 0,
+                                      co_off=(ct if (mt == 4 and cv.shuffle) else ct * 64), ci_total=cv.cin, ci_off=ch * 64,
+                                      write_bias=1 if ch == 0 else 0, scale=float(scale), gw=_ptr(cv.gw), gb=_ptr(cv.gb)))
+        plan.reduce_scales = [it.scale for it in items]
+        plan.reduce_host = (L.ReduceItem * len(items))(*items)
+        plan.reduce_dev = torch.empty(C.sizeof(plan.reduce_host), dtype=torch.uint8, device=self.device)
+        plan.keep.append(plan.reduce_dev)
+        plan.n_reduce = len(items)
+        plan.job_dev = {}
+        for mt in (4, 1):
+            if jobs[mt]:
+                arr = (L.WgradJob * len(jobs[mt]))(*jobs[mt])
+                dev = self._to_device_bytes(arr)
+                plan.keep.append(dev)
+                plan.job_dev[mt] = (dev, len(jobs[mt]))
+        plan.grad_scale = None
+
+    def _set_grad_scale(self, plan, gs):
+        """The stored activation gradients are unscaled (+-1 at the loss); 1/numel enters once, in fp32, where the
+        parameter gradients are written."""
+        if plan.grad_scale == gs:
+            return
+        for it, s in zip(plan.reduce_host, plan.reduce_scales):
+            it.scale = s * gs
+        raw = np.frombuffer(bytes(plan.reduce_host), dtype=np.uint8).copy()
+        plan.reduce_dev.copy_(torch.from_numpy(raw), non_blocking=False)
+        for a in plan.scaled:
+            a.scale = gs
+        plan.grad_scale = gs
+
+    # ------------------------------------------------------------------ execution
+    def plan_for(self, N, H, W, train):
+        key = (N, H, W, bool(train))
+        p = self.plans.get(key)
+        if p is None:
+            p = self._build(N, H, W, bool(train))
+            self.plans[key] = p
+        return p
+
+    def _run(self, ops, stream):
+        lib = self.lib
+        for name, a in ops:
+            rc = getattr(lib, name)(C.byref(a), stream)
+            if rc != 0:
+                L.check(rc, name)
+
+    def forward(self, x, train=False, target=None):
+        """x: [N,C,H,W] fp32 on the device.  Returns (out fp32 [N,C,sH,sW] (engine-owned buffer), loss tensor | None)."""
+        N, _, H, W = x.shape
+        plan = self.plan_for(N, H, W, train)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        plan.x_in.copy_(x, non_blocking=True)
+        self._run(plan.fwd, stream)
+        if target is not None:
+            plan.target.copy_(target, non_blocking=True)
+            L.call('rumpy_tail_fwd', plan.tail_loss, stream)
+            return plan.out, plan.loss, plan
+        L.call('rumpy_tail_fwd', plan.tail_plain, stream)
+        return plan.out, None, plan
+
+    def backward(self, plan, grad_scale, gout=None):
+        """Run the backward pass of the last training forward of `plan`.  gout: optional upstream gradient
+        [N,C,sH,sW] fp32 (replaces the fused sign gradient)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if gout is not None:
+            h, w = plan.HR
+            L.call('rumpy_nchw_to_nhwc4', L.NchwToNhwc4Args(src=_ptr(gout), dst=_ptr(plan.dy4), N=plan.N, C=gout.shape[1], H=h, W=w), stream)
+        self._set_grad_scale(plan, float(grad_scale))
+        self._run(plan.bwd, stream)
+        for mt in (4, 1):
+            if mt in plan.job_dev:
+                dev, n = plan.job_dev[mt]
+                L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, stream), 'rumpy_wgrad_grouped')
+        L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')

@@ -1,0 +1,96 @@
+"""Fused Adam over the flat parameter buffer of a HipSRNet.
+
+Semantics: torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0, amsgrad=False) as the reference builds it
+(rumpy/shared_framework/models/base_architecture.py:79-99); one HIP kernel updates every parameter, then the
+bf16 filter images are re-packed.  It subclasses torch.optim.Adam only so that ``param_groups`` /
+``state_dict()`` / ``load_state_dict()`` keep the reference checkpoint layout (``optimizer`` entry of
+``train_model_<epoch>``, base_architecture.py:247-249) and torch LR schedulers can drive it.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+
+
+class FlatAdam(torch.optim.Adam):
+    def __init__(self, net, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.net = net
+        params = [p for p in net.param_list if p.requires_grad]
+        if len(params) != len(net.param_list):
+            raise RuntimeError('FlatAdam: frozen parameters are not supported by the fused update')
+        super().__init__(params, lr=lr, betas=betas, eps=eps)
+        dev = net.flat_p.device
+        self.flat_m = torch.zeros_like(net.flat_p)
+        self.flat_v = torch.zeros_like(net.flat_p)
+        self._step_t = torch.tensor(0.0)
+        self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(8, dtype=torch.float32)
+        if dev.type == 'cuda':
+            self._hyper_host = self._hyper_host.pin_memory()
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._sumsq_partial = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self._bind_state()
+
+    def _bind_state(self):
+        net = self.net
+        for p, off in zip(net.param_list, net.offsets):
+            n = p.numel()
+            self.state[p] = {'step': self._step_t,
+                             'exp_avg': self.flat_m[off:off + n].view(p.shape),
+                             'exp_avg_sq': self.flat_v[off:off + n].view(p.shape)}
+
+    @property
+    def step_count(self):
+        return int(self._step_t.item())
+
+    def zero_grad(self, set_to_none=True):
+        # gradients are overwritten (not accumulated) by every backward pass of the engine
+        self.net.attach_grads()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # torch deep-copied the loaded state: pull it back into the flat buffers
+        net = self.net
+        step = 0.0
+        with torch.no_grad():
+            for p, off in zip(net.param_list, net.offsets):
+                st = self.state.get(p, None)
+                n = p.numel()
+                if st and 'exp_avg' in st:
+                    self.flat_m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                    self.flat_v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    step = float(st['step'])
+                else:
+                    self.flat_m[off:off + n].zero_()
+                    self.flat_v[off:off + n].zero_()
+        self._step_t = torch.tensor(step)
+        self._bind_state()
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_mult=1.0, max_norm=None):
+        net = self.net
+        if not net.flat_p.is_cuda:
+            raise RuntimeError('rumpy_amd FlatAdam: parameters are not on the GPU; there is no CPU path')
+        group = self.param_groups[0]
+        beta1, beta2 = group['betas']
+        self._step_t += 1
+        t = float(self._step_t)
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3] = group['lr'], beta1, beta2, group['eps']
+        h[4] = 1.0 - beta1 ** t
+        h[5] = math.sqrt(1.0 - beta2 ** t)
+        h[6] = grad_mult
+        h[7] = float(max_norm) if max_norm else 0.0
+        self._hyper_dev.copy_(h, non_blocking=True)
+        stream = torch.cuda.current_stream(net.flat_p.device).cuda_stream
+        n = net.flat_p.numel()
+        sumsq = None
+        if max_norm:
+            L.call('rumpy_sumsq', L.SumsqArgs(g=net.flat_g.data_ptr(), n=n, partial=self._sumsq_partial.data_ptr(),
+                                              out=self._sumsq.data_ptr()), stream)
+            sumsq = self._sumsq.data_ptr()
+        L.call('rumpy_adam_step', L.AdamArgs(p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(), m=self.flat_m.data_ptr(),
+                                             v=self.flat_v.data_ptr(), n=n, hyper=self._hyper_dev.data_ptr(), sumsq=sumsq), stream)
+        net.mark_weights_updated()
+        return None

@@ -1,0 +1,67 @@
+"""Data parallelism for the SR hot path: one process per GPU, replicas hold identical fp32 master weights and Adam
+state, and the ONLY exchange per step is a mean all-reduce of the flat gradient buffer over RCCL/xGMI
+(torch.distributed backend "nccl" on ROCm), issued in buckets on a side HIP stream.
+
+Replaces nn.DataParallel (rumpy/shared_framework/models/base_architecture.py:70-77), which re-broadcasts every
+parameter each step from one Python process.  Equal per-rank shards + mean of per-rank mean-L1 gradients equals the
+reference's global-batch mean-L1 gradient.  Works with any backend (tests use gloo on CPU tensors).
+"""
+import torch
+import torch.distributed as dist
+
+
+def bucket_bounds(n, bucket_elems):
+    """Split [0, n) into contiguous buckets, LAST parameters first (tail/upsampler gradients are ready first)."""
+    bounds = []
+    hi = n
+    while hi > 0:
+        lo = max(0, hi - bucket_elems)
+        bounds.append((lo, hi))
+        hi = lo
+    return bounds
+
+
+class GradientAverager:
+    def __init__(self, net=None, flat_grad=None, bucket_elems=1 << 20, group=None):
+        self.flat_g = flat_grad if flat_grad is not None else net.flat_g
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.buckets = bucket_bounds(self.flat_g.numel(), bucket_elems)
+        self.side = torch.cuda.Stream(self.flat_g.device) if self.flat_g.is_cuda else None
+        self.pending = []
+
+    def launch_bucket(self, idx):
+        """All-reduce bucket idx asynchronously (call as soon as its gradients are final)."""
+        if self.world_size == 1:
+            return
+        lo, hi = self.buckets[idx]
+        view = self.flat_g[lo:hi]
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.flat_g.device))
+            with torch.cuda.stream(self.side):
+                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.side is not None:
+            torch.cuda.current_stream(self.flat_g.device).wait_stream(self.side)
+
+    def average(self):
+        """Sum over ranks of every bucket; the 1/world factor is applied here so the optimizer sees the mean."""
+        if self.world_size == 1:
+            return
+        for i in range(len(self.buckets)):
+            self.launch_bucket(i)
+        self.finish()
+        self.flat_g.mul_(1.0 / self.world_size)
+
+
+def broadcast_parameters(net, src=0, group=None):
+    """Make every replica start from rank src's weights (one flat broadcast)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(net.flat_p, src=src, group=group)
+        net._packed_version = None

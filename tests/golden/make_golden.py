@@ -191,6 +191,20 @@ def main():
     rcan_keys = [(k, list(v.shape)) for k, v in h.net.state_dict().items()]
     rcan_count = int(h.print_parameters())
 
+    # default initialisation under the reference's default seed (net_train.py:20): pins constructor RNG order
+    init = {}
+    for name, kw in (('edsr', dict(scale=4)), ('rcan', dict(scale=4, n_resgroups=2, n_resblocks=2))):
+        torch.manual_seed(8)
+        hh = define_model(name, model_save_dir=tmp, device=torch.device('cpu'), eval_mode=True, checkpoint_load=False,
+                          loss_masking=False, **kw)
+        sd = hh.net.state_dict()
+        keys = list(sd.keys())
+        for k in (keys[0], keys[1], keys[len(keys) // 2], keys[-2], keys[-1]):
+            init[name + '/' + k] = npy(sd[k])
+        init[name + '/checksum'] = np.asarray(sum(float(v.double().sum()) for v in sd.values()))
+    np.savez(os.path.join(HERE, 'g8_init_seed8.npz'), **init)
+    torch.manual_seed(0)
+
     big = rarch.EDSR(net_features=256, num_blocks=32, scale=4, res_scale=0.1)
     big_count = int(sum(p.numel() for p in big.parameters()))
 

@@ -1,0 +1,235 @@
+"""CPU-only tests (-m "not gpu"): host logic of the drop-in boundary, the C-ABI library surface, data-parallel
+gradient averaging over gloo.  No kernel is executed here (there is no GPU and no CPU fallback)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'rumpy_amd.h')
+
+
+def _lib_or_skip():
+    from rumpy_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib
+
+
+def _handler(name, eval_mode=False, **kw):
+    from rumpy_amd.shared_framework.models import define_model
+    return define_model(name, model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=eval_mode,
+                        checkpoint_load=False, loss_masking=False, metadata_list=None, **kw)
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    _lib = _lib_or_skip()
+    with open(HEADER) as f:
+        src = f.read()
+    declared = set(re.findall(r'\b(rumpy_[a-z0-9_]+)\s*\(', src))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared:
+        assert hasattr(h, s), s
+    lib = _lib.lib()
+    assert lib.rumpy_abi_version() == 1
+    assert lib.rumpy_wgrad_slab_floats(4) == 64 * 576 + 64 and lib.rumpy_wgrad_slab_floats(1) == 16 * 576 + 16
+
+
+def test_ctypes_structs_match_the_header_layout():
+    """compile a C probe against include/rumpy_amd.h and compare sizeof / offsetof with the ctypes mirrors"""
+    _lib = _lib_or_skip()
+    pairs = {'rumpy_conv_args': _lib.ConvArgs, 'rumpy_head_fwd_args': _lib.HeadFwdArgs, 'rumpy_head_wgrad_args': _lib.HeadWgradArgs,
+             'rumpy_tail_fwd_args': _lib.TailFwdArgs, 'rumpy_tail_dgrad_args': _lib.TailDgradArgs,
+             'rumpy_nchw_to_nhwc4_args': _lib.NchwToNhwc4Args, 'rumpy_wgrad_job': _lib.WgradJob, 'rumpy_reduce_item': _lib.ReduceItem,
+             'rumpy_pack_item': _lib.PackItem, 'rumpy_ca_mlp_fwd_args': _lib.CaMlpFwdArgs, 'rumpy_ca_scale_args': _lib.CaScaleArgs,
+             'rumpy_ca_bwd_reduce_args': _lib.CaBwdReduceArgs, 'rumpy_ca_mlp_bwd_args': _lib.CaMlpBwdArgs,
+             'rumpy_ca_bwd_apply_args': _lib.CaBwdApplyArgs, 'rumpy_adam_hyper': _lib.AdamHyper, 'rumpy_adam_args': _lib.AdamArgs,
+             'rumpy_sumsq_args': _lib.SumsqArgs, 'rumpy_eval_post_args': _lib.EvalPostArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rumpy_amd.h"', 'int main(void){']
+    for cname, st in pairs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
+        for fname, _ in st._fields_:
+            lines.append('printf(" %%zu", offsetof(%s, %s));' % (cname, fname))
+        lines.append('printf("\\n");')
+    lines.append('return 0;}')
+    d = tempfile.mkdtemp()
+    with open(os.path.join(d, 'p.c'), 'w') as f:
+        f.write('\n'.join(lines))
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 'p.c'), '-o', os.path.join(d, 'p')])
+    out = subprocess.check_output([os.path.join(d, 'p')]).decode().strip().splitlines()
+    for line in out:
+        parts = line.split()
+        st = pairs[parts[0]]
+        assert int(parts[1]) == ctypes.sizeof(st), parts[0]
+        for (fname, _), off in zip(st._fields_, parts[2:]):
+            assert getattr(st, fname).offset == int(off), (parts[0], fname)
+
+
+def test_argument_validation_runs_without_a_gpu():
+    _lib = _lib_or_skip()
+    lib = _lib.lib()
+    assert lib.rumpy_conv3x3(_lib.ConvArgs(), None) == -1 and b'null' in lib.rumpy_last_error()
+    assert lib.rumpy_adam_step(_lib.AdamArgs(), None) == -1
+    assert lib.rumpy_wgrad_grouped(None, 0, 4, None) == -1
+    assert lib.rumpy_probe_begin(9, 1) == -1
+
+
+# ------------------------------------------------------------------ plugin boundary
+def test_registry_scans_handlers_like_the_reference():
+    from rumpy_amd.shared_framework.models import available_models, define_model
+    assert available_models['edsr'].endswith('SISR.models.advanced.handlers.EDSRHandler')
+    assert available_models['rcan'].endswith('SISR.models.advanced.handlers.RCANHandler')
+    with pytest.raises(KeyError):
+        define_model('nonexistent')
+
+
+def test_handlers_expose_the_reference_contract(golden_dir):
+    with open(os.path.join(golden_dir, 'g8_params.json')) as f:
+        g = json.load(f)
+    h = _handler('edsr', scale=4, lr=2e-4, some_unknown_kwarg=1, scheduler='multi_step_lr',
+                 scheduler_params={'milestones': [2, 4], 'gamma': 0.5})
+    assert h.model_name == 'edsr' and h.colorspace == 'rgb' and h.im_input == 'unmodified'
+    assert isinstance(h.criterion, torch.nn.L1Loss) and h.legacy_load and h.curr_epoch == 0 and h.eval_request_loss
+    assert [(k, list(v.shape)) for k, v in h.net.state_dict().items()] == [tuple(x) for x in map(tuple, g['edsr_keys'])]
+    assert h.print_parameters() == g['edsr_baseline_count'] == 1517571
+    assert h.get_learning_rate() == 2e-4 and h.verify_eval() is True
+    for _ in range(2):
+        h.learning_rate_scheduler.step()
+    assert abs(h.get_learning_rate() - 1e-4) < 1e-12
+    r = _handler('rcan', eval_mode=True, scale=4)
+    assert [(k, list(v.shape)) for k, v in r.net.state_dict().items()] == [tuple(x) for x in map(tuple, g['rcan_keys'])]
+    assert r.print_parameters() == g['rcan_count'] == 15592355
+    assert r.optimizer is None and r.model_name == 'rcan'
+    with pytest.raises(RuntimeError, match='eval mode'):
+        r.run_train(x=torch.zeros(1, 3, 8, 8), y=torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match='scheduler not implemented'):
+        _handler('edsr', scheduler='bogus', scheduler_params={})
+
+
+def test_default_init_consumes_rng_like_the_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g8_init_seed8.npz'))
+    for name, kw in (('edsr', dict(scale=4)), ('rcan', dict(scale=4, n_resgroups=2, n_resblocks=2))):
+        torch.manual_seed(8)
+        h = _handler(name, eval_mode=True, **kw)
+        sd = h.net.state_dict()
+        for k in g.files:
+            if k.startswith(name + '/') and not k.endswith('checksum'):
+                assert np.array_equal(sd[k.split('/', 1)[1]].numpy(), g[k]), k
+        chk = sum(float(v.double().sum()) for v in sd.values())
+        assert abs(chk - float(g[name + '/checksum'])) < 1e-9
+
+
+def test_compute_without_gpu_fails_loudly():
+    h = _handler('edsr', scale=4, num_blocks=1)
+    x, y = O.synthetic_batch(1, 1, lr_hw=8, scale=4)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        h.run_train(x=x, y=y)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        h.run_eval(x=x)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        h.optimizer.step()
+    with pytest.raises(RuntimeError, match='multiple of 64|n_feats = 64'):
+        from rumpy_amd.engine import SREngine
+        hh = _handler('edsr', scale=4, num_blocks=1, num_features=16)
+        SREngine(hh.net._spec(), torch.device('cpu'))
+
+
+def test_checkpoint_layout_matches_reference(golden_dir):
+    sched = dict(scheduler='cosine_annealing_warm_restarts', scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+    for name, kw in (('edsr', dict(scale=4, num_blocks=2)), ('rcan', dict(scale=4, n_resgroups=1, n_resblocks=2))):
+        with open(os.path.join(golden_dir, 'g9_checkpoint_%s.json' % name)) as f:
+            g = json.load(f)
+        h = _handler(name, lr=1e-3, **kw, **sched)
+        st = h.save_model('train_model', extract_state_only=True)
+        assert sorted(st.keys()) == g['top_keys']
+        assert sorted(st['optimizer'].keys()) == g['optimizer_keys']
+        assert sorted(st['optimizer']['param_groups'][0].keys()) == g['optimizer_param_group_keys']
+        assert sorted(st['optimizer']['state'][0].keys()) == g['optimizer_state_entry_keys']
+        assert sorted(st['scheduler_G'].keys()) == g['scheduler_keys']
+        assert st['model_name'] == g['model_name'] and st['model_epoch'] == 0
+        # file round trip + a reference-shaped (oracle) net and a stock Adam accept it
+        h.set_epoch(2)
+        h.save_model('train_model')
+        loaded = torch.load(os.path.join(h.model_save_dir, 'train_model_2'), map_location='cpu', weights_only=False)
+        onet = O.build_oracle(name, **kw)
+        onet.load_state_dict(loaded['network'])
+        torch.optim.Adam(onet.parameters(), lr=1.0).load_state_dict(loaded['optimizer'])
+        h2 = _handler(name, lr=5e-4, **kw, **sched)
+        h2.model_save_dir = h.model_save_dir
+        h2.load_model('train_model', 2, config_changes={'values_changed': {"root['internal_params']['lr']": {'new_value': 7e-4}}})
+        assert h2.curr_epoch == 2 and abs(h2.get_learning_rate() - 7e-4) < 1e-12
+        for a, b in zip(h.net.parameters(), h2.net.parameters()):
+            assert torch.equal(a, b)
+        # legacy prefixes are stripped
+        legacy = {('model.module.' + k): v for k, v in loaded['network'].items()}
+        assert list(h.legacy_switch(legacy).keys()) == list(loaded['network'].keys())
+
+
+def test_reference_checkpoint_with_empty_optimizer_state_loads():
+    """a reference checkpoint saved before the first step has an empty Adam state"""
+    h = _handler('edsr', scale=4, num_blocks=1, lr=1e-3)
+    onet = O.build_oracle('edsr', scale=4, num_blocks=1)
+    ref_opt = torch.optim.Adam(onet.parameters(), lr=3e-4)
+    state = {'network': onet.state_dict(), 'model_name': 'edsr', 'model_epoch': 5, 'optimizer': ref_opt.state_dict(), 'steps': None}
+    h.load_model('train_model', 5, preloaded_state=state)
+    assert h.curr_epoch == 5 and h.optimizer.step_count == 0 and abs(h.get_learning_rate() - 3e-4) < 1e-12
+    assert float(h.optimizer.flat_m.abs().sum()) == 0.0
+
+
+def test_flat_parameter_views_survive_module_moves():
+    h = _handler('edsr', scale=4, num_blocks=1)
+    net = h.net
+    assert net.head[0].weight.data_ptr() == net.flat_p.data_ptr()
+    assert sum(p.numel() for p in net.parameters()) == net.flat_p.numel()
+    before = net.flat_p.clone()
+    net.double().float()          # goes through nn.Module._apply -> re-flattened
+    assert net.head[0].weight.data_ptr() == net.flat_p.data_ptr() and torch.equal(before, net.flat_p)
+    assert net.tail[1].bias.grad.data_ptr() == net.flat_g[-3:].data_ptr()
+
+
+# ------------------------------------------------------------------ data parallel (gloo, world size 2)
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from rumpy_amd.parallel import GradientAverager, broadcast_parameters, bucket_bounds
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo')
+g = torch.arange(10007, dtype=torch.float32) * (rank + 1)
+avg = GradientAverager(flat_grad=g, bucket_elems=1000)
+assert avg.world_size == 2 and len(avg.buckets) == 11 and avg.buckets[0] == (9007, 10007) and avg.buckets[-1] == (0, 7)
+avg.average()
+assert torch.equal(g, torch.arange(10007, dtype=torch.float32) * 1.5), rank
+class Net: pass
+n = Net(); n.flat_p = torch.full((5,), float(rank)); n._packed_version = 1
+broadcast_parameters(n, src=0)
+assert float(n.flat_p.sum()) == 0.0 and n._packed_version is None
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_gradient_averager_gloo_world_size_2():
+    from rumpy_amd.parallel import bucket_bounds
+    assert bucket_bounds(10, 4) == [(6, 10), (2, 6), (0, 2)]
+    d = tempfile.mkdtemp()
+    script = os.path.join(d, 'w.py')
+    with open(script, 'w') as f:
+        f.write(_DP_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

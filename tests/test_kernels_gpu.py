@@ -1,0 +1,363 @@
+"""-m gpu parity tests of the individual C-ABI kernels against the CPU oracle arithmetic (torch fp32 on the same
+bf16-rounded operands).  Tolerances: outputs stored as bf16 -> one bf16 rounding (relative Frobenius error < 4e-3,
+max error < 2^-6 of the tensor's max); fp32 outputs from bf16 operands -> summation order only (< 2e-3 relative,
+typically 1e-6)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+try:
+    from tests.gpu_utils import (BF16, DEV, PackedConv, assert_bf16_close, assert_f32_close, bf16r, hip_conv, hip_wgrad,
+                                 nchw, nhwc, pack_bias_ref, pack_ref, stream, to_dev_bytes)
+except ImportError:  # pytest rootdir import mode
+    from gpu_utils import (BF16, DEV, PackedConv, assert_bf16_close, assert_f32_close, bf16r, hip_conv, hip_wgrad,
+                           nchw, nhwc, pack_bias_ref, pack_ref, stream, to_dev_bytes)
+from rumpy_amd import _lib as L
+
+
+def _rand(gen, *shape, scale=1.0):
+    return torch.from_numpy(gen.standard_normal(shape).astype(np.float32) * scale)
+
+
+def _wb(gen, co, ci):
+    b = 1.0 / np.sqrt(ci * 9)
+    return (torch.from_numpy(gen.uniform(-b, b, (co, ci, 3, 3)).astype(np.float32)),
+            torch.from_numpy(gen.uniform(-b, b, (co,)).astype(np.float32)))
+
+
+@pytest.mark.parametrize('co,ci,shuffle', [(64, 64, False), (256, 64, True), (64, 256, False)])
+def test_pack_weights_layout(co, ci, shuffle):
+    gen = np.random.default_rng(1)
+    w, b = _wb(gen, co, ci)
+    pc = PackedConv(w, b, 0, shuffle)
+    fwd, dgr = pack_ref(w.numpy(), shuffle)
+    assert torch.equal(pc.w_fwd.float().cpu(), bf16r(torch.from_numpy(fwd.reshape(-1))))
+    assert torch.equal(pc.w_dgrad.float().cpu(), bf16r(torch.from_numpy(dgr.reshape(-1))))
+    assert np.array_equal(pc.b_packed.cpu().numpy(), pack_bias_ref(b.numpy(), shuffle))
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 12, 12), (1, 48, 48), (3, 10, 21), (1, 8, 16), (2, 5, 3)])
+def test_conv3x3_forward_plain(N, H, W):
+    gen = np.random.default_rng(10 + H)
+    w, b = _wb(gen, 64, 64)
+    x = _rand(gen, N, 64, H, W)
+    pc = PackedConv(w, b)
+    out, _ = hip_conv(nhwc(x), pc, N, H, W)
+    ref = F.conv2d(bf16r(x), bf16r(w), b, padding=1)
+    assert_bf16_close(nchw(out), ref, 'conv fwd %dx%dx%d' % (N, H, W))
+
+
+def test_conv3x3_forward_persistent_grid_variants():
+    """every grid size must give the same bits (tiles are independent)"""
+    gen = np.random.default_rng(11)
+    w, b = _wb(gen, 64, 64)
+    x = _rand(gen, 4, 64, 24, 40)
+    pc = PackedConv(w, b)
+    xd = nhwc(x)
+    base, _ = hip_conv(xd, pc, 4, 24, 40)
+    for gx in (1, 3, 7, 36):
+        o, _ = hip_conv(xd, pc, 4, 24, 40, grid_x=gx)
+        assert torch.equal(o, base), gx
+
+
+def test_conv3x3_epilogue_relu_scale_residuals_mask_pool():
+    gen = np.random.default_rng(12)
+    N, H, W = 2, 20, 18
+    w, b = _wb(gen, 64, 64)
+    x, r1, r2, m = (_rand(gen, N, 64, H, W) for _ in range(4))
+    pc = PackedConv(w, b)
+    conv = F.conv2d(bf16r(x), bf16r(w), b, padding=1)
+    # ResBlock conv1: relu
+    o, _ = hip_conv(nhwc(x), pc, N, H, W, relu=True)
+    assert_bf16_close(nchw(o), conv.clamp_min(0), 'relu')
+    # ResBlock conv2: *0.1 + residual
+    o, _ = hip_conv(nhwc(x), pc, N, H, W, scale=0.1, res1=nhwc(r1))
+    assert_bf16_close(nchw(o), conv * 0.1 + bf16r(r1), 'scale+res')
+    # two residuals
+    o, _ = hip_conv(nhwc(x), pc, N, H, W, res1=nhwc(r1), res2=nhwc(r2))
+    assert_bf16_close(nchw(o), conv + bf16r(r1) + bf16r(r2), 'res1+res2')
+    # backward style: no bias, scale, relu mask
+    o, _ = hip_conv(nhwc(x), pc, N, H, W, use_bias=False, scale=0.1, mask=nhwc(m))
+    ref = F.conv2d(bf16r(x), bf16r(w), None, padding=1) * 0.1 * (bf16r(m) > 0).float()
+    assert_bf16_close(nchw(o), ref, 'mask')
+    # per-tile channel sums (global average pool partials), taken before the residual add
+    o, pl = hip_conv(nhwc(x), pc, N, H, W, res1=nhwc(r1), pool=True)
+    tiles_y, tiles_x = (H + 7) // 8, (W + 15) // 16
+    refp = torch.zeros(N, tiles_y * tiles_x, 64)
+    for ty in range(tiles_y):
+        for tx in range(tiles_x):
+            refp[:, ty * tiles_x + tx] = conv[:, :, ty * 8:ty * 8 + 8, tx * 16:tx * 16 + 16].sum(dim=(2, 3))
+    assert_f32_close(pl, refp, 'pool partials', rel=1e-4)
+    assert_bf16_close(nchw(o), conv + bf16r(r1), 'pool+res output')
+
+
+def test_conv3x3_upsampler_forward_pixel_shuffle_fused():
+    gen = np.random.default_rng(13)
+    N, H, W = 2, 11, 19
+    w, b = _wb(gen, 256, 64)
+    x = _rand(gen, N, 64, H, W)
+    pc = PackedConv(w, b, 0, True)
+    o, _ = hip_conv(nhwc(x), pc, N, H, W, out_mode=1)
+    ref = F.pixel_shuffle(F.conv2d(bf16r(x), bf16r(w), b, padding=1), 2)
+    assert_bf16_close(nchw(o), ref, 'conv 64->256 + PixelShuffle(2)')
+
+
+def test_conv3x3_dgrad_plain_and_unshuffle():
+    gen = np.random.default_rng(14)
+    N, H, W = 2, 13, 17
+    # plain 64->64: dgrad == autograd grad wrt input
+    w, b = _wb(gen, 64, 64)
+    gy = _rand(gen, N, 64, H, W)
+    x = torch.zeros(N, 64, H, W, requires_grad=True)
+    F.conv2d(x, bf16r(w), None, padding=1).backward(bf16r(gy))
+    pc = PackedConv(w, b)
+    o, _ = hip_conv(nhwc(gy), pc, N, H, W, dgrad=True)
+    assert_bf16_close(nchw(o), x.grad, 'dgrad 64->64')
+    # upsampler: grad wrt conv input of PixelShuffle(conv 64->256)
+    w, b = _wb(gen, 256, 64)
+    gy = _rand(gen, N, 64, 2 * H, 2 * W)
+    x = torch.zeros(N, 64, H, W, requires_grad=True)
+    F.pixel_shuffle(F.conv2d(x, bf16r(w), None, padding=1), 2).backward(bf16r(gy))
+    pc = PackedConv(w, b, 0, True)
+    o, _ = hip_conv(nhwc(gy), pc, N, H, W, dgrad=True, in_mode=1)
+    assert_bf16_close(nchw(o), x.grad, 'dgrad upsampler (PixelShuffle^T gather)')
+
+
+def test_conv3x3_rejects_bad_arguments():
+    a = L.ConvArgs(x=None, w=None, out=None, N=1, H=1, W=1, cin_chunks=1, cout_tiles=1)
+    assert L.lib().rumpy_conv3x3(a, None) == -1
+    assert b'null' in L.lib().rumpy_last_error()
+    t = torch.zeros(64, dtype=BF16, device=DEV)
+    a = L.ConvArgs(x=t.data_ptr(), w=t.data_ptr(), out=t.data_ptr(), N=1, H=1, W=1, cin_chunks=3, cout_tiles=1)
+    assert L.lib().rumpy_conv3x3(a, None) == -1
+
+
+@pytest.mark.parametrize('C', [1, 3])
+def test_head_forward_and_wgrad(C):
+    gen = np.random.default_rng(15)
+    N, H, W = 3, 14, 22
+    b_ = 1.0 / np.sqrt(C * 9)
+    w = torch.from_numpy(gen.uniform(-b_, b_, (64, C, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(gen.uniform(-b_, b_, (64,)).astype(np.float32))
+    x = torch.from_numpy(gen.random((N, C, H, W), dtype=np.float32))
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    out = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    L.call('rumpy_head_fwd', L.HeadFwdArgs(x=xd.data_ptr(), w=wd.data_ptr(), b=bd.data_ptr(), out=out.data_ptr(), N=N, C=C, H=H, W=W, cout=64), stream())
+    ref = F.conv2d(x, w, b, padding=1)
+    assert_bf16_close(nchw(out), ref, 'head fwd')
+    # weight gradient
+    gy = _rand(gen, N, 64, H, W)
+    wp = w.clone().requires_grad_(True)
+    bp = b.clone().requires_grad_(True)
+    F.conv2d(x, wp, bp, padding=1).backward(bf16r(gy) * 0.25)
+    slab = torch.zeros(int(L.lib().rumpy_head_wgrad_slab_floats(C, 64)), dtype=torch.float32, device=DEV)
+    gw = torch.full((64, C, 3, 3), float('nan'), device=DEV)
+    gb = torch.full((64,), float('nan'), device=DEV)
+    L.call('rumpy_head_wgrad', L.HeadWgradArgs(x=xd.data_ptr(), dy=nhwc(gy).data_ptr(), slab=slab.data_ptr(), gw=gw.data_ptr(),
+                                               gb=gb.data_ptr(), N=N, C=C, H=H, W=W, cout=64, scale=0.25), stream())
+    torch.cuda.synchronize()
+    assert_f32_close(gw, wp.grad, 'head wgrad', rel=1e-4)
+    assert_f32_close(gb, bp.grad, 'head bgrad', rel=1e-4)
+
+
+@pytest.mark.parametrize('C', [3, 1])
+def test_tail_forward_l1_and_dgrad(C):
+    gen = np.random.default_rng(16)
+    N, H, W = 2, 21, 35
+    b_ = 1.0 / np.sqrt(64 * 9)
+    w = torch.from_numpy(gen.uniform(-b_, b_, (C, 64, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(gen.uniform(-b_, b_, (C,)).astype(np.float32))
+    x = _rand(gen, N, 64, H, W)
+    y = torch.from_numpy(gen.random((N, C, H, W), dtype=np.float32))
+    pc = PackedConv(w, b, 2)
+    out = torch.full((N, C, H, W), float('nan'), device=DEV)
+    dy4 = torch.full((N, H, W, 4), float('nan'), dtype=BF16, device=DEV)
+    part = torch.zeros(2048, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    yd, xd = y.to(DEV), nhwc(x)
+    a = L.TailFwdArgs(x=xd.data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b.data_ptr(), out=out.data_ptr(), target=yd.data_ptr(),
+                      dy4=dy4.data_ptr(), loss_partial=part.data_ptr(), loss=loss.data_ptr(), N=N, C=C, H=H, W=W, grid_x=0)
+    L.call('rumpy_tail_fwd', a, stream())
+    torch.cuda.synchronize()
+    ref = F.conv2d(bf16r(x), bf16r(w), b, padding=1)
+    assert_f32_close(out, ref, 'tail fwd', rel=1e-5)
+    got = out.cpu()
+    assert abs(float(loss.item()) - float((got - y).abs().mean())) < 1e-6 * max(1.0, float(loss.item()))
+    sg = torch.sign(got - y)
+    d4 = dy4.float().cpu()
+    assert torch.equal(d4[..., :C].permute(0, 3, 1, 2), sg)
+    assert float(d4[..., C:].abs().sum()) == 0.0
+    # plain variant (eval): no target
+    out2 = torch.full((N, C, H, W), float('nan'), device=DEV)
+    a2 = L.TailFwdArgs(x=xd.data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b.data_ptr(), out=out2.data_ptr(), N=N, C=C, H=H, W=W)
+    L.call('rumpy_tail_fwd', a2, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
+    # dgrad of the tail conv from an arbitrary 4-channel gradient
+    gy = _rand(gen, N, C, H, W)
+    g4 = torch.zeros(N, H, W, 4, dtype=BF16, device=DEV)
+    gyd = gy.to(DEV)
+    L.call('rumpy_nchw_to_nhwc4', L.NchwToNhwc4Args(src=gyd.data_ptr(), dst=g4.data_ptr(), N=N, C=C, H=H, W=W), stream())
+    dx = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    L.call('rumpy_tail_dgrad', L.TailDgradArgs(dy4=g4.data_ptr(), w=pc.w_dgrad.data_ptr(), dx=dx.data_ptr(), N=N, H=H, W=W), stream())
+    torch.cuda.synchronize()
+    xin = torch.zeros(N, 64, H, W, requires_grad=True)
+    F.conv2d(xin, bf16r(w), None, padding=1).backward(bf16r(gy))
+    assert_bf16_close(nchw(dx), xin.grad, 'tail dgrad')
+
+
+def _wgrad_ref(x, gy, co, scale=1.0):
+    w = torch.zeros(co, 64, 3, 3, requires_grad=True)
+    b = torch.zeros(co, requires_grad=True)
+    F.conv2d(bf16r(x), w, b, padding=1).backward(bf16r(gy) * scale)
+    return w.grad, b.grad
+
+
+@pytest.mark.parametrize('N,H,W,split', [(2, 12, 12, 1), (4, 16, 32, 2), (3, 9, 21, 3), (1, 48, 48, 1)])
+def test_wgrad_grouped_plain(N, H, W, split):
+    gen = np.random.default_rng(17 + H)
+    x, gy = _rand(gen, N, 64, H, W), _rand(gen, N, 64, H, W)
+    xd, gd = nhwc(x), nhwc(gy)
+    per = (N + split - 1) // split
+    jobs = [dict(x=xd, dy=gd, n0=n0, n1=min(N, n0 + per), H=H, W=W, x_cstride=64, x_coff=0, dy_mode=0, dy_cstride=64, dy_coff=0)
+            for n0 in range(0, N, per)]
+    gw = torch.full((64, 64, 3, 3), float('nan'), device=DEV)
+    gb = torch.full((64,), float('nan'), device=DEV)
+    hip_wgrad(jobs, 4, [dict(first_job=0, njobs=len(jobs), co_count=64, co_mode=0, co_off=0, ci_total=64, ci_off=0,
+                             write_bias=1, scale=0.5)], gw, gb)
+    rw, rb = _wgrad_ref(x, gy, 64, 0.5)
+    assert_f32_close(gw, rw, 'wgrad 64x64', rel=1e-4)
+    assert_f32_close(gb, rb, 'bgrad', rel=1e-4)
+
+
+def test_wgrad_upsampler_unshuffle_view():
+    gen = np.random.default_rng(18)
+    N, H, W = 2, 10, 18
+    x = _rand(gen, N, 64, H, W)
+    gy = _rand(gen, N, 64, 2 * H, 2 * W)            # gradient of the shuffled output
+    w = torch.zeros(256, 64, 3, 3, requires_grad=True)
+    b = torch.zeros(256, requires_grad=True)
+    F.pixel_shuffle(F.conv2d(bf16r(x), w, b, padding=1), 2).backward(bf16r(gy))
+    xd, gd = nhwc(x), nhwc(gy)
+    jobs, red = [], []
+    for q in range(4):
+        jobs.append(dict(x=xd, dy=gd, n0=0, n1=N, H=H, W=W, x_cstride=64, x_coff=0, dy_mode=1, dy_cstride=64, dy_coff=q))
+        red.append(dict(first_job=q, njobs=1, co_count=64, co_mode=1, co_off=q, ci_total=64, ci_off=0, write_bias=1, scale=1.0))
+    gw = torch.full((256, 64, 3, 3), float('nan'), device=DEV)
+    gb = torch.full((256,), float('nan'), device=DEV)
+    hip_wgrad(jobs, 4, red, gw, gb)
+    assert_f32_close(gw, w.grad, 'wgrad upsampler', rel=1e-4)
+    assert_f32_close(gb, b.grad, 'bgrad upsampler', rel=1e-4)
+
+
+def test_wgrad_tail_dy4():
+    gen = np.random.default_rng(19)
+    N, H, W, C = 2, 24, 20, 3
+    x = _rand(gen, N, 64, H, W)
+    gy = torch.sign(_rand(gen, N, C, H, W))
+    g4 = torch.zeros(N, H, W, 4, dtype=BF16)
+    g4[..., :C] = gy.permute(0, 2, 3, 1).to(BF16)
+    xd, gd = nhwc(x), g4.to(DEV)
+    jobs = [dict(x=xd, dy=gd, n0=n, n1=n + 1, H=H, W=W, x_cstride=64, x_coff=0, dy_mode=2, dy_cstride=4, dy_coff=0) for n in range(N)]
+    gw = torch.full((C, 64, 3, 3), float('nan'), device=DEV)
+    gb = torch.full((C,), float('nan'), device=DEV)
+    hip_wgrad(jobs, 1, [dict(first_job=0, njobs=N, co_count=C, co_mode=0, co_off=0, ci_total=64, ci_off=0, write_bias=1, scale=1.0 / 7)], gw, gb)
+    rw, rb = _wgrad_ref(x, gy, C, 1.0 / 7)
+    assert_f32_close(gw, rw, 'tail wgrad', rel=1e-4)
+    assert_f32_close(gb, rb, 'tail bgrad', rel=1e-4)
+
+
+def test_channel_attention_forward_backward():
+    gen = np.random.default_rng(20)
+    N, H, W, Cc, Cr = 3, 10, 23, 64, 4
+    t2, xres, gy = _rand(gen, N, Cc, H, W), _rand(gen, N, Cc, H, W), _rand(gen, N, Cc, H, W)
+    w1 = torch.from_numpy(gen.uniform(-0.3, 0.3, (Cr, Cc, 1, 1)).astype(np.float32)).requires_grad_(True)
+    b1 = torch.from_numpy(gen.uniform(-0.3, 0.3, (Cr,)).astype(np.float32)).requires_grad_(True)
+    w2 = torch.from_numpy(gen.uniform(-0.3, 0.3, (Cc, Cr, 1, 1)).astype(np.float32)).requires_grad_(True)
+    b2 = torch.from_numpy(gen.uniform(-0.3, 0.3, (Cc,)).astype(np.float32)).requires_grad_(True)
+    tt = bf16r(t2).requires_grad_(True)
+    gate_ref = torch.sigmoid(F.conv2d(F.relu(F.conv2d(tt.mean(dim=(2, 3), keepdim=True), w1, b1)), w2, b2))
+    y_ref = bf16r(xres) + tt * gate_ref
+    y_ref.backward(bf16r(gy))
+    # device: pool partials as the conv epilogue would leave them (one "tile" = whole image here)
+    pool = bf16r(t2).sum(dim=(2, 3)).reshape(N, 1, Cc).contiguous().to(DEV)
+    d = lambda t: t.detach().contiguous().to(DEV)
+    w1d, b1d, w2d, b2d = d(w1), d(b1), d(w2), d(b2)
+    mean, hid, gate = (torch.zeros(N, k, device=DEV) for k in (Cc, Cr, Cc))
+    L.call('rumpy_ca_mlp_fwd', L.CaMlpFwdArgs(pool=pool.data_ptr(), w1=w1d.data_ptr(), b1=b1d.data_ptr(), w2=w2d.data_ptr(), b2=b2d.data_ptr(),
+                                              mean=mean.data_ptr(), hidden=hid.data_ptr(), gate=gate.data_ptr(), N=N, C=Cc, Cr=Cr, ntiles=1,
+                                              inv_hw=1.0 / (H * W)), stream())
+    torch.cuda.synchronize()
+    assert_f32_close(gate, gate_ref.reshape(N, Cc), 'CA gate', rel=1e-5)
+    t2d, xd, gd = nhwc(t2), nhwc(xres), nhwc(gy)
+    y = torch.zeros(N, H, W, Cc, dtype=BF16, device=DEV)
+    L.call('rumpy_ca_scale_res_fwd', L.CaScaleArgs(t=t2d.data_ptr(), res=xd.data_ptr(), gate=gate.data_ptr(), out=y.data_ptr(), N=N, HW=H * W, C=Cc), stream())
+    torch.cuda.synchronize()
+    assert_bf16_close(nchw(y), y_ref, 'CA scale+res')
+    # backward
+    nchunks = (H * W + 127) // 128
+    part = torch.zeros(N, nchunks, Cc, device=DEV)
+    L.call('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=gd.data_ptr(), t=t2d.data_ptr(), partial=part.data_ptr(), N=N, HW=H * W, C=Cc), stream())
+    dpool = torch.zeros(N, Cc, device=DEV)
+    gw1, gb1, gw2, gb2 = (torch.full(s, float('nan'), device=DEV) for s in ((Cr, Cc, 1, 1), (Cr,), (Cc, Cr, 1, 1), (Cc,)))
+    L.call('rumpy_ca_mlp_bwd', L.CaMlpBwdArgs(partial=part.data_ptr(), mean=mean.data_ptr(), hidden=hid.data_ptr(), gate=gate.data_ptr(),
+                                              w1=w1d.data_ptr(), w2=w2d.data_ptr(), dpool=dpool.data_ptr(), gw1=gw1.data_ptr(), gb1=gb1.data_ptr(),
+                                              gw2=gw2.data_ptr(), gb2=gb2.data_ptr(), N=N, C=Cc, Cr=Cr, nchunks=nchunks, inv_hw=1.0 / (H * W),
+                                              scale=1.0), stream())
+    dt = torch.zeros(N, H, W, Cc, dtype=BF16, device=DEV)
+    L.call('rumpy_ca_bwd_apply', L.CaBwdApplyArgs(dy=gd.data_ptr(), gate=gate.data_ptr(), dpool=dpool.data_ptr(), dt=dt.data_ptr(), N=N, HW=H * W, C=Cc), stream())
+    torch.cuda.synchronize()
+    assert_bf16_close(nchw(dt), tt.grad, 'CA d(t2)')
+    assert_f32_close(gw1, w1.grad, 'CA gW1', rel=1e-4)
+    assert_f32_close(gb1, b1.grad, 'CA gb1', rel=1e-4)
+    assert_f32_close(gw2, w2.grad, 'CA gW2', rel=1e-4)
+    assert_f32_close(gb2, b2.grad, 'CA gb2', rel=1e-4)
+
+
+def test_adam_matches_torch_and_clips():
+    gen = np.random.default_rng(21)
+    n = 100003
+    p0 = torch.from_numpy(gen.standard_normal(n).astype(np.float32))
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    hyper = torch.zeros(8, device=DEV)
+    sumsq, part = torch.zeros(1, device=DEV), torch.zeros(1024, device=DEV)
+    for t in range(1, 4):
+        g = torch.from_numpy(gen.standard_normal(n).astype(np.float32) * 10 ** (-t))
+        max_norm = 0.5 if t == 2 else 0.0
+        ref_p.grad = g.clone()
+        if max_norm:
+            torch.nn.utils.clip_grad_norm_([ref_p], max_norm)
+        opt.step()
+        gd = g.to(DEV)
+        hyper.copy_(torch.tensor([1e-3, 0.9, 0.999, 1e-8, 1 - 0.9 ** t, float(np.sqrt(1 - 0.999 ** t)), 1.0, max_norm]))
+        if max_norm:
+            L.call('rumpy_sumsq', L.SumsqArgs(g=gd.data_ptr(), n=n, partial=part.data_ptr(), out=sumsq.data_ptr()), stream())
+            torch.cuda.synchronize()
+            assert abs(float(sumsq.item()) - float((g.double() ** 2).sum())) < 1e-4 * float((g.double() ** 2).sum())
+        L.call('rumpy_adam_step', L.AdamArgs(p=p.data_ptr(), g=gd.data_ptr(), m=m.data_ptr(), v=v.data_ptr(), n=n, hyper=hyper.data_ptr(),
+                                             sumsq=sumsq.data_ptr() if max_norm else None), stream())
+        torch.cuda.synchronize()
+        assert float((p.cpu() - ref_p.detach()).abs().max()) < 2e-6, t
+
+
+def test_eval_post_clip_ycbcr_psnr():
+    from oracle import sr_oracle as O
+    gen = np.random.default_rng(22)
+    out = torch.from_numpy(gen.uniform(-0.2, 1.2, (2, 3, 31, 17)).astype(np.float32))
+    ref = torch.from_numpy(gen.random((2, 3, 31, 17), dtype=np.float32))
+    from rumpy_amd.SISR.models.interface import SISRInterface
+    rgb, ycbcr, p = SISRInterface.postprocess(out.to(DEV), ref.to(DEV))
+    rgb_ref = O.clip01(out.numpy())
+    yc_ref = np.copy(rgb_ref)
+    hr_ref = O.clip01(ref.numpy())
+    for i in range(2):
+        yc_ref[i] = O.rgb_to_ycbcr_jpg(yc_ref[i])
+        hr_ref[i] = O.rgb_to_ycbcr_jpg(hr_ref[i])
+    assert np.array_equal(rgb.cpu().numpy(), rgb_ref)
+    np.testing.assert_allclose(ycbcr.cpu().numpy(), yc_ref, rtol=0, atol=2e-7)
+    assert abs(p - O.y_psnr(yc_ref, hr_ref)) < 1e-3
