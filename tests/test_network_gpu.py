@@ -47,6 +47,9 @@ def _grad_check(h, oh, tol=3e-2):
         assert k == k2
         g, r = p.grad.detach().float().cpu().double().reshape(-1), q.grad.double().reshape(-1)
         assert torch.isfinite(g).all(), k
+        if float(r.norm()) == 0.0:      # e.g. a dead ReLU in the squeeze-excite MLP: both must be exactly zero
+            assert float(g.norm()) == 0.0, k
+            continue
         rel = float((g - r).norm() / (r.norm() + 1e-30))
         cos = float((g @ r) / (g.norm() * r.norm() + 1e-30))
         if rel > worst[0]:
