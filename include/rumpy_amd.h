@@ -51,7 +51,7 @@ typedef struct {
   const void* mask;     /* bf16, layout of out (out_mode 0 only) or NULL */
   const void* res1;     /* bf16, layout of out, or NULL */
   const void* res2;     /* bf16, layout of out, or NULL */
-  float* pool;          /* [N][tiles_y*tiles_x][64*cout_tiles] per-tile channel sums, or NULL */
+  float* pool;          /* [N][rumpy_conv_pool_tiles()][64*cout_tiles] per-tile channel sums, or NULL */
   int32_t N, H, W;
   int32_t cin_chunks;   /* 1 or 4 */
   int32_t cout_tiles;
@@ -61,6 +61,11 @@ typedef struct {
   int32_t grid_x;       /* persistent workgroups per cout tile; 0 = library default */
 } rumpy_conv_args;
 int rumpy_conv3x3(const rumpy_conv_args* a, void* stream);
+/* number of per-image pool partial rows ("tiles") rumpy_conv3x3 writes for an H x W image */
+int rumpy_conv_pool_tiles(int32_t H, int32_t W, int32_t cin_chunks);
+/* diagnostic (never on the product path): stamped build of the Cin=64 kernel; a->pool receives grid_x*4*8 u64 of
+ * s_memrealtime (100 MHz) phase stamps of each wave's first strip */
+int rumpy_debug_conv_stamps(const rumpy_conv_args* a, void* stream);
 
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
  * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */
@@ -133,6 +138,7 @@ typedef struct {
                         dy_mode 1: [N,2H,2W,64], sub-pixel q = dy_coff ; dy_mode 2: [N,H,W,4] (mt must be 1) */
   float* slab;       /* rumpy_wgrad_slab_floats(mt) floats */
   int32_t n0, n1;    /* image range */
+  int32_t t0, t1;    /* tile sub-range inside that image range: tiles [t0, t1) of (n1-n0)*tiles_y*tiles_x, row-major */
   int32_t H, W;
   int32_t x_cstride, x_coff;
   int32_t dy_mode, dy_cstride, dy_coff;
@@ -162,8 +168,9 @@ int rumpy_wgrad_reduce(const rumpy_reduce_item* items_device, int32_t nitems, vo
 typedef struct {
   const float* w;      /* [Cout,Cin,3,3] */
   const float* b;      /* [Cout] */
-  void* w_fwd;         /* kind 0: [cout_tiles][cin_chunks][4][18][64][8] bf16 ; kind 2: [18][64][8] */
-  void* w_dgrad;       /* kind 0: [cin_chunks][cout_tiles][4][18][64][8] ; kind 2: [4][2][64][8] ; may be NULL */
+  void* w_fwd;         /* kind 0: Cout*Cin*9 bf16 in MFMA A-fragment order [cout_tile][cin_chunk][co quarter 4][s = tap*2 +
+                          ci half, 18][lane 64][8] ; kind 2: [18][64][8] */
+  void* w_dgrad;       /* kind 0: same for the transposed, flipped filter ; kind 2: [4][2][64][8] ; may be NULL */
   float* b_packed;     /* kind 0: [Cout] in packed channel order ; else NULL */
   int32_t cout, cin;
   int32_t kind;        /* 0: 64-multiple conv ; 2: tail conv (cout<=4, cin=64) */

@@ -59,7 +59,7 @@ class NchwToNhwc4Args(_S):
 
 
 class WgradJob(_S):
-    _fields_ = [('x', c_void_p), ('dy', c_void_p), ('slab', c_void_p), ('n0', c_int32), ('n1', c_int32),
+    _fields_ = [('x', c_void_p), ('dy', c_void_p), ('slab', c_void_p), ('n0', c_int32), ('n1', c_int32), ('t0', c_int32), ('t1', c_int32),
                 ('H', c_int32), ('W', c_int32), ('x_cstride', c_int32), ('x_coff', c_int32),
                 ('dy_mode', c_int32), ('dy_cstride', c_int32), ('dy_coff', c_int32), ('mt', c_int32)]
 
@@ -128,6 +128,8 @@ SYMBOLS = {
     'rumpy_abi_version': (C.c_int, []),
     'rumpy_device_cus': (C.c_int, []),
     'rumpy_conv3x3': (C.c_int, [_P(ConvArgs), c_void_p]),
+    'rumpy_conv_pool_tiles': (C.c_int, [c_int32, c_int32, c_int32]),
+    'rumpy_debug_conv_stamps': (C.c_int, [_P(ConvArgs), c_void_p]),
     'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
     'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),

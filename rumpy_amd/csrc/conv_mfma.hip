@@ -314,6 +314,7 @@ __global__ void nchw_to_nhwc4_kernel(const float* src, uint16_t* dst, int N, int
 // host entry points
 // ------------------------------------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s);   // conv_strip.hip
 
 extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->out) { rumpy_set_error("rumpy_conv3x3: null pointer"); return RUMPY_E_ARG; }
@@ -321,6 +322,14 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (p->cin_chunks != 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 or 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
   if (p->in_mode == 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: in_mode 1 needs cin_chunks 4"); return RUMPY_E_ARG; }
   if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || p->res1 || p->res2)) { rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4 and no mask/residual"); return RUMPY_E_ARG; }
+  if (p->cin_chunks == 1) {   // Cin = 64: strip kernel (conv_strip.hip)
+    hipStream_t s1 = (hipStream_t)stream;
+    const int kid1 = (p->cout_tiles == 1) ? 1 : 3;
+    rumpy_probe_pre(kid1, s1);
+    rumpy_conv3x3_strip_launch(p, s1);
+    rumpy_probe_post(kid1, s1);
+    return rumpy_check_launch("rumpy_conv3x3");
+  }
   ConvDev d;
   d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = (uint16_t*)p->out;
   d.mask = (const uint16_t*)p->mask; d.res1 = (const uint16_t*)p->res1; d.res2 = (const uint16_t*)p->res2; d.pool = p->pool;
@@ -336,11 +345,10 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   }
   if (gx > ntiles) gx = ntiles;
   hipStream_t s = (hipStream_t)stream;
-  const int kid = (p->cin_chunks == 1 && p->cout_tiles == 1) ? 1 : 3;
+  const int kid = 3;
   rumpy_probe_pre(kid, s);
   dim3 grid(gx, p->cout_tiles);
-  if (p->cin_chunks == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, grid, dim3(256), 0, s, d);
-  else hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
+  hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
   rumpy_probe_post(kid, s);
   return rumpy_check_launch("rumpy_conv3x3");
 }

@@ -56,22 +56,30 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
   }
 }
 
-// weight gradient: persistent workgroups over 8x16-pixel tiles.  Thread (co = tid & 63, part = tid >> 6) owns
-// k = part, part+4, ... (<= 9 of the 9*C taps) and accumulates dy[p][co] * x[p + tap][c] over the tile pixels.
-// slab per workgroup: [cout_tiles][64][9*C + 1] (last column = bias sum).
+// weight gradient: persistent workgroups over 8x16-pixel tiles.  Thread = (pixel quarter q = tid >> 6,
+// channel quad c4 = (tid >> 2) & 15 -> co 4*c4..4*c4+3, tap part kp = tid & 3 -> k = kp, kp+4, ... < 9*C):
+// per pixel one 8-byte LDS read of dy feeds up to 36 FMAs.  The four pixel quarters are added through LDS in a
+// fixed order; slab per workgroup: [cout_tiles][64][9*C + 1] (last column = bias sum).
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
                                                          float* __restrict__ slab, int N, int C, int H, int W, int cout) {
   __shared__ float sx[HEAD_MAXC * HALO_PIX];
   __shared__ __attribute__((aligned(16))) uint16_t sdy[TH * TW * 64];
-  const int tid = threadIdx.x, co = tid & 63, part = tid >> 6;
+  __shared__ float red[4 * 64 * (9 * HEAD_MAXC + 1)];
+  const int tid = threadIdx.x, q = tid >> 6, c4 = (tid >> 2) & 15, kp = tid & 3;
   const int ct = blockIdx.y;
   const int K = 9 * C;
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int ntiles = N * tiles_y * tiles_x;
-  float acc[9];
+  float acc[9][4];
+  int xoff[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-  float bsum = 0.f;
+  for (int i = 0; i < 9; ++i) {
+    acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.f;
+    const int k = kp + 4 * i;
+    const int c = k / 9, t = k - 9 * c, ky = t / 3, kx = t - 3 * ky;
+    xoff[i] = (k < K) ? c * HALO_PIX + ky * HALO_W + kx : -1;
+  }
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const TileCoord tc = decode_tile(tile, tiles_x, tiles_y);
     __syncthreads();
@@ -89,27 +97,41 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict
       *reinterpret_cast<uint4*>(&sdy[pix * 64 + part8 * 8]) = v;
     }
     __syncthreads();
-    for (int pix = 0; pix < TH * TW; ++pix) {
-      const float d = bf16_bits_to_f32(sdy[pix * 64 + co]);
-      const int r = pix >> 4, cc = pix & 15;
-      if (part == 0) bsum += d;
+#pragma unroll 4
+    for (int p = 0; p < 32; ++p) {
+      const int pix = q * 32 + p;
+      float d[4];
+      unpack4_bf16(*reinterpret_cast<const uint2*>(&sdy[pix * 64 + 4 * c4]), d);
+      const int base = (pix >> 4) * HALO_W + (pix & 15);
+      if (kp == 0) { bs[0] += d[0]; bs[1] += d[1]; bs[2] += d[2]; bs[3] += d[3]; }
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        const int k = part + 4 * i;
-        if (k < K) {
-          const int c = k / 9, t = k - 9 * c, ky = t / 3, kx = t - 3 * ky;
-          acc[i] = fmaf(d, sx[c * HALO_PIX + (r + ky) * HALO_W + cc + kx], acc[i]);
+        if (xoff[i] >= 0) {
+          const float xv = sx[xoff[i] + base];
+          acc[i][0] = fmaf(d[0], xv, acc[i][0]); acc[i][1] = fmaf(d[1], xv, acc[i][1]);
+          acc[i][2] = fmaf(d[2], xv, acc[i][2]); acc[i][3] = fmaf(d[3], xv, acc[i][3]);
         }
       }
     }
   }
-  float* s = slab + ((size_t)blockIdx.x * gridDim.y + ct) * 64 * (K + 1) + (size_t)co * (K + 1);
+  // cross-quarter reduction in a fixed order
+  const int KS = K + 1;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    const int k = part + 4 * i;
-    if (k < K) s[k] = acc[i];
+    const int k = kp + 4 * i;
+    if (k < K) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(q * 64 + 4 * c4 + j) * KS + k] = acc[i][j];
+    }
   }
-  if (part == 0) s[K] = bsum;
+  if (kp == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(q * 64 + 4 * c4 + j) * KS + K] = bs[j];
+  }
+  __syncthreads();
+  float* s = slab + ((size_t)blockIdx.x * gridDim.y + ct) * 64 * KS;
+  for (int e = tid; e < 64 * KS; e += 256)
+    s[e] = (red[e] + red[64 * KS + e]) + (red[2 * 64 * KS + e] + red[3 * 64 * KS + e]);
 }
 
 __global__ void head_wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int C, int cout, float scale,
@@ -118,14 +140,22 @@ __global__ void head_wgrad_reduce_kernel(const float* __restrict__ slab, int nwg
   const int total = cout * (K + 1);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
-  float s = 0.f;
-  for (int g = 0; g < nwg; ++g) s += slab[(size_t)g * total + e];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int g = 0;
+  for (; g + 4 <= nwg; g += 4) {
+    s0 += slab[(size_t)g * total + e];
+    s1 += slab[(size_t)(g + 1) * total + e];
+    s2 += slab[(size_t)(g + 2) * total + e];
+    s3 += slab[(size_t)(g + 3) * total + e];
+  }
+  for (; g < nwg; ++g) s0 += slab[(size_t)g * total + e];
+  const float s = (s0 + s1) + (s2 + s3);
   const int co = e / (K + 1), k = e - co * (K + 1);
   if (k < K) gw[(size_t)co * K + k] = s * scale;
   else gb[co] = s * scale;
 }
 
-static int head_wgrad_grid() { return rumpy_device_cus(); }
+static int head_wgrad_grid() { return 128; }
 
 extern "C" int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout) {
   return (int64_t)head_wgrad_grid() * cout * (9 * C + 1);

@@ -78,15 +78,15 @@ template <int MT>
 __global__ void __launch_bounds__(256, 1) wgrad_kernel(const rumpy_wgrad_job* __restrict__ jobs) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * WG_STAGE_BYTES];
   const rumpy_wgrad_job* jp = jobs + blockIdx.x;
-  struct { const uint16_t* x; float* slab; int n0, n1, H, W, x_cstride, x_coff, dy_mode; } j;
-  j.x = (const uint16_t*)jp->x; j.slab = jp->slab; j.n0 = jp->n0; j.n1 = jp->n1; j.H = jp->H; j.W = jp->W;
+  struct { const uint16_t* x; float* slab; int n0, n1, t0, t1, H, W, x_cstride, x_coff, dy_mode; } j;
+  j.x = (const uint16_t*)jp->x; j.slab = jp->slab; j.n0 = jp->n0; j.n1 = jp->n1; j.t0 = jp->t0; j.t1 = jp->t1; j.H = jp->H; j.W = jp->W;
   j.x_cstride = jp->x_cstride; j.x_coff = jp->x_coff; j.dy_mode = jp->dy_mode;
   DyView dv;
   dv.dy = (const uint16_t*)jp->dy; dv.H = j.H; dv.W = j.W; dv.dy_mode = j.dy_mode; dv.dy_cstride = jp->dy_cstride; dv.dy_coff = jp->dy_coff;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
   const int tiles_x = (j.W + TW - 1) / TW, tiles_y = (j.H + TH - 1) / TH;
-  const int ntiles = (j.n1 - j.n0) * tiles_y * tiles_x;
+  const int ntiles = j.t1 - j.t0;   // tiles [t0, t1) of the image range
 
   if (MT == 1) {  // channels 4..15 of the dy image are never written: clear both dy buffers once
     for (int i = tid; i < 2 * (DY_STAGE_BYTES / 16); i += 256) {
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const rumpy_wgrad_job* __
 
   uint4 RX[6], RD[4];
   if (ntiles > 0) {
-    const TileCoord t = decode_tile(0, tiles_x, tiles_y);
+    const TileCoord t = decode_tile(j.t0, tiles_x, tiles_y);
     halo_issue(RX, j.x, 0, j.x_cstride, j.x_coff, j.n0 + t.n, t.ty, t.tx, j.H, j.W, tid);
     dy_issue<MT == 1>(RD, dv, j.n0 + t.n, t.ty, t.tx, tid);
     halo_write(RX, lds, tid);
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_kernel(const rumpy_wgrad_job* __
   for (int tile = 0; tile < ntiles; ++tile) {
     const bool has_next = tile + 1 < ntiles;
     if (has_next) {
-      const TileCoord tn = decode_tile(tile + 1, tiles_x, tiles_y);
+      const TileCoord tn = decode_tile(j.t0 + tile + 1, tiles_x, tiles_y);
       halo_issue(RX, j.x, 0, j.x_cstride, j.x_coff, j.n0 + tn.n, tn.ty, tn.tx, j.H, j.W, tid);
       dy_issue<MT == 1>(RD, dv, j.n0 + tn.n, tn.ty, tn.tx, tid);
     }
@@ -215,6 +215,6 @@ extern "C" int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t n
 
 extern "C" int rumpy_wgrad_reduce(const rumpy_reduce_item* items_device, int32_t nitems, void* stream) {
   if (!items_device || nitems <= 0) { rumpy_set_error("rumpy_wgrad_reduce: bad argument"); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(36, nitems), dim3(256), 0, (hipStream_t)stream, items_device);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(145, nitems), dim3(256), 0, (hipStream_t)stream, items_device);
   return rumpy_check_launch("rumpy_wgrad_reduce");
 }

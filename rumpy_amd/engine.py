@@ -169,7 +169,7 @@ class SREngine:
         Cin, Cout = spec.head.cin, spec.tail.cout
         plan.x_in = self._new(plan, N, Cin, H, W, dtype=torch.float32)
         fwd, bwd = plan.fwd, plan.bwd
-        tiles = ((H + L.TILE_H - 1) // L.TILE_H) * ((W + L.TILE_W - 1) // L.TILE_W)
+        tiles = int(lib.rumpy_conv_pool_tiles(H, W, 1))     # per-image pool partial rows written by the 64->64 conv
         wjobs = []      # (layer, x, dy, H, W, dy_mode, scale, mt)
 
         free_pool = []
@@ -371,8 +371,12 @@ class SREngine:
         layout = []
         total = 0
         for (cv, x, dy, H, W, dy_mode, scale, mt) in wjobs:
-            imgs = max(1, min(N, self.wgrad_pixels_per_job // (H * W)))
-            ranges = [(n0, min(N, n0 + imgs)) for n0 in range(0, N, imgs)]
+            # split the layer's N*tiles_y*tiles_x pixel tiles into jobs of about wgrad_pixels_per_job pixels
+            ntile = N * ((H + L.TILE_H - 1) // L.TILE_H) * ((W + L.TILE_W - 1) // L.TILE_W)
+            per = max(1, self.wgrad_pixels_per_job // (L.TILE_H * L.TILE_W))
+            njob = max(1, (ntile + per - 1) // per)
+            per = (ntile + njob - 1) // njob
+            ranges = [(t0, min(ntile, t0 + per)) for t0 in range(0, ntile, per)]
             cin_chunks = cv.cin // 64
             cout_tiles = cv.cout // 64 if mt == 4 else 1
             for ch in range(cin_chunks):
@@ -383,14 +387,14 @@ class SREngine:
         base = slabs.data_ptr()
         for (cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, off) in layout:
             sf = slab_floats[mt]
-            for k, (n0, n1) in enumerate(ranges):
+            for k, (t0, t1) in enumerate(ranges):
                 if dy_mode == 0:
                     dcs, dco = cv.cout, ct * 64
                 elif dy_mode == 1:
                     dcs, dco = 64, ct
                 else:
                     dcs, dco = 4, 0
-                jobs[mt].append(L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=n0, n1=n1, H=H, W=W,
+                jobs[mt].append(L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=0, n1=N, t0=t0, t1=t1, H=H, W=W,
                                            x_cstride=cv.cin, x_coff=ch * 64, dy_mode=dy_mode, dy_cstride=dcs, dy_coff=dco, mt=mt))
             items.append(L.ReduceItem(slab=base + 4 * off, slab_stride=sf, njobs=len(ranges), mt=mt,
                                       co_count=(64 if mt == 4 else cv.cout), co_mode=1 if (mt == 4 and cv.shuffle) else 0,

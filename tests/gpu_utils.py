@@ -77,7 +77,7 @@ def pack_ref(w, shuffle):
         half, tap = s & 1, s >> 1
         ky, kx = tap // 3, tap % 3
         for wave in range(4):
-            c = 16 * wave + r                                    # [64]
+            c = 16 * wave + r                                    # channel quarter `wave`, MFMA row r: [64]
             cc = (32 * half + 8 * g)[:, None] + e[None, :]       # [64,8]
             for ct in range(ctn):
                 co = (4 * c + ct) if shuffle else (64 * ct + c)
@@ -133,7 +133,7 @@ def hip_conv(x, pc, N, H, W, dgrad=False, relu=False, scale=1.0, mask=None, res1
         out = torch.full((N, 2 * H, 2 * W, 64), float('nan'), dtype=BF16, device=DEV)
     else:
         out = torch.full((N, H, W, 64 * cout_tiles), float('nan'), dtype=BF16, device=DEV)
-    tiles = ((H + 7) // 8) * ((W + 15) // 16)
+    tiles = int(L.lib().rumpy_conv_pool_tiles(H, W, cin_chunks))
     pl = torch.full((N, tiles, 64 * cout_tiles), float('nan'), dtype=torch.float32, device=DEV) if pool else None
     p = lambda t: None if t is None else t.data_ptr()
     a = L.ConvArgs(x=x.data_ptr(), w=w.data_ptr(), bias=p(b), out=out.data_ptr(), mask=p(mask), res1=p(res1), res2=p(res2),
@@ -152,7 +152,9 @@ def hip_wgrad(jobs_spec, mt, reduce_spec, gw, gb):
     slabs = torch.full((len(jobs_spec) * sf,), float('nan'), dtype=torch.float32, device=DEV)
     jobs = []
     for k, j in enumerate(jobs_spec):
+        tiles = (j['n1'] - j['n0']) * ((j['H'] + 7) // 8) * ((j['W'] + 15) // 16)
         jobs.append(L.WgradJob(x=j['x'].data_ptr(), dy=j['dy'].data_ptr(), slab=slabs.data_ptr() + 4 * k * sf, n0=j['n0'], n1=j['n1'],
+                               t0=j.get('t0', 0), t1=j.get('t1', tiles),
                                H=j['H'], W=j['W'], x_cstride=j['x_cstride'], x_coff=j['x_coff'], dy_mode=j['dy_mode'],
                                dy_cstride=j['dy_cstride'], dy_coff=j['dy_coff'], mt=mt))
     jd = to_dev_bytes((L.WgradJob * len(jobs))(*jobs))

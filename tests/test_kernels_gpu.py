@@ -85,11 +85,13 @@ def test_conv3x3_epilogue_relu_scale_residuals_mask_pool():
     assert_bf16_close(nchw(o), ref, 'mask')
     # per-tile channel sums (global average pool partials), taken before the residual add
     o, pl = hip_conv(nhwc(x), pc, N, H, W, res1=nhwc(r1), pool=True)
-    tiles_y, tiles_x = (H + 7) // 8, (W + 15) // 16
-    refp = torch.zeros(N, tiles_y * tiles_x, 64)
-    for ty in range(tiles_y):
-        for tx in range(tiles_x):
-            refp[:, ty * tiles_x + tx] = conv[:, :, ty * 8:ty * 8 + 8, tx * 16:tx * 16 + 16].sum(dim=(2, 3))
+    # strip kernel: one partial row per (6-row strip, 3-row group, 48-column strip)
+    rows_n, cols_n = 2 * ((H + 5) // 6), (W + 47) // 48
+    assert pl.shape[1] == rows_n * cols_n
+    refp = torch.zeros(N, rows_n * cols_n, 64)
+    for ry in range(rows_n):
+        for tx in range(cols_n):
+            refp[:, ry * cols_n + tx] = conv[:, :, ry * 3:ry * 3 + 3, tx * 48:tx * 48 + 48].sum(dim=(2, 3))
     assert_f32_close(pl, refp, 'pool partials', rel=1e-4)
     assert_bf16_close(nchw(o), conv + bf16r(r1), 'pool+res output')
 
@@ -361,3 +363,21 @@ def test_eval_post_clip_ycbcr_psnr():
     assert np.array_equal(rgb.cpu().numpy(), rgb_ref)
     np.testing.assert_allclose(ycbcr.cpu().numpy(), yc_ref, rtol=0, atol=2e-7)
     assert abs(p - O.y_psnr(yc_ref, hr_ref)) < 1e-3
+
+
+def test_wgrad_jobs_split_by_tile_subranges():
+    """jobs may cover any contiguous tile sub-range of the image range; the reduction adds them up"""
+    gen = np.random.default_rng(23)
+    N, H, W = 3, 20, 40          # 3 x 3 x 3 = 27 tiles
+    x, gy = _rand(gen, N, 64, H, W), _rand(gen, N, 64, H, W)
+    xd, gd = nhwc(x), nhwc(gy)
+    cuts = [0, 1, 8, 20, 27]
+    jobs = [dict(x=xd, dy=gd, n0=0, n1=N, t0=a, t1=b, H=H, W=W, x_cstride=64, x_coff=0, dy_mode=0, dy_cstride=64, dy_coff=0)
+            for a, b in zip(cuts[:-1], cuts[1:])]
+    gw = torch.full((64, 64, 3, 3), float('nan'), device=DEV)
+    gb = torch.full((64,), float('nan'), device=DEV)
+    hip_wgrad(jobs, 4, [dict(first_job=0, njobs=len(jobs), co_count=64, co_mode=0, co_off=0, ci_total=64, ci_off=0,
+                             write_bias=1, scale=1.0)], gw, gb)
+    rw, rb = _wgrad_ref(x, gy, 64, 1.0)
+    assert_f32_close(gw, rw, 'wgrad tile sub-ranges', rel=1e-4)
+    assert_f32_close(gb, rb, 'bgrad tile sub-ranges', rel=1e-4)

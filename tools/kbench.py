@@ -1,0 +1,81 @@
+"""Micro-benchmarks of single kernels on the bench shapes (GPU box only): python tools/kbench.py [conv|wgrad|all]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from gpu_utils import BF16, DEV, PackedConv, hip_wgrad, stream, to_dev_bytes  # noqa: E402
+from rumpy_amd import _lib as L  # noqa: E402
+
+
+def time_fn(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / iters  # us
+
+
+def conv_bench(N=32, H=48, W=48):
+    gen = np.random.default_rng(0)
+    w = torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32))
+    b = torch.zeros(64)
+    pc = PackedConv(w, b)
+    xs = [torch.randn(N, H, W, 64, device=DEV).to(BF16) for _ in range(4)]
+    out = torch.empty(N, H, W, 64, dtype=BF16, device=DEV)
+    res = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    flop = 2.0 * N * H * W * 64 * 576
+    for gx in (0, 128, 192, 256, 288, 384, 512, 576):
+        k = [0]
+
+        def fn():
+            a = L.ConvArgs(x=xs[k[0] % 4].data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b_packed.data_ptr(), out=out.data_ptr(),
+                           res1=res.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1, in_mode=0, out_mode=0, relu=0,
+                           scale=0.1, grid_x=gx)
+            L.call('rumpy_conv3x3', a, stream())
+            k[0] += 1
+        us = time_fn(fn)
+        print('conv 64->64 %dx%dx%d grid_x=%3d: %7.2f us  %6.1f TFLOP/s' % (N, H, W, gx, us, flop / us / 1e6))
+
+
+if __name__ == '__main__':
+    which = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    if which in ('conv', 'all'):
+        conv_bench()
+        conv_bench(32, 96, 96)
+
+
+def conv_stamps(N=32, H=48, W=48):
+    gen = np.random.default_rng(0)
+    w = torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32))
+    pc = PackedConv(w, torch.zeros(64))
+    x = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    out = torch.empty(N, H, W, 64, dtype=BF16, device=DEV)
+    res = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    gx = 256
+    dbg = torch.zeros(gx * 8 * 8, dtype=torch.int64, device=DEV)
+    a = L.ConvArgs(x=x.data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b_packed.data_ptr(), out=out.data_ptr(), res1=res.data_ptr(),
+                   pool=dbg.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1, scale=0.1, grid_x=gx)
+    for _ in range(3):
+        L.call('rumpy_debug_conv_stamps', a, stream())
+    torch.cuda.synchronize()
+    d = dbg.cpu().numpy().reshape(gx, 8, 8).astype(np.float64)
+    t0 = d[:, :, 0].min()
+    rel = (d - t0) * 10.0 / 1000.0    # us
+    names = ['start', 'loads issued', 'stage in LDS', 'mfma issued', 'K halves exchanged', 'epilogue+barrier', '-', '-']
+    for i in range(6):
+        v = rel[:, :, i]
+        print('stamp %d %-18s median %6.2f us  min %6.2f  max %6.2f' % (i, names[i], np.median(v), v.min(), v.max()))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stamps':
+    conv_stamps()
