@@ -115,7 +115,7 @@ def main():
             avg_s = tot.value * 1e-3 / n_launch
             flop = 2.0 * N * 48 * 48 * 64 * 576            # algorithmic FLOPs of one 64->64 3x3 launch
             achieved = flop / avg_s / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'conv3x3_kernel<1> (3x3 conv 64->64, fwd + dgrad launches)',
+            roofline = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel (3x3 conv 64->64, fwd + dgrad launches)',
                         'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                         'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch,

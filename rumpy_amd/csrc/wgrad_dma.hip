@@ -1,0 +1,197 @@
+// Weight gradient of the 64-channel 3x3 convolutions, streaming version: LDS-DMA ring + K-split over 8 waves.
+//
+// Same math and slab format as wgrad_kernel<4> (wgrad_mfma.hip) - dW[co][tap][ci] = sum_p dy[p][co] * x[p+tap][ci],
+// pixels are the MFMA K dimension, both operands come out of LDS through ds_read_b64_tr_b16 - but built as a
+// streaming kernel, because this op moves 2 bytes per 288 flops less than the forward conv and is fed from HBM:
+//   * 512 threads: wave (w4, kh) accumulates D[all 64 co][ci 16*w4..] for the 9 taps (36 f32 16x16 tiles) over the
+//     k-steps {2kh, 2kh+1} of every 8x16-pixel tile; the two K halves are added through LDS once, at the end.
+//   * tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a 3-slot ring, two tiles
+//     ahead of the MFMAs, ordered by a counted s_waitcnt vmcnt + one raw s_barrier per tile.
+//   * LDS image: 128-byte pixels, unpadded (an LDS-DMA wave-instruction writes 1 KiB contiguously), with the 16-byte
+//     chunk index XOR-swizzled by (pixel index & 7) - applied to the per-lane SOURCE address, so the DMA stays
+//     lane-linear - which makes every transposed read (8 consecutive pixels x 32 B per 32-lane half) conflict free.
+//   * out-of-image pixels are fetched from a zero page; the bias gradient is one extra MFMA against a ones fragment.
+#include "common.hpp"
+
+typedef __attribute__((address_space(3))) short4v* lds_s4_ptr2;
+typedef __attribute__((address_space(3))) unsigned char* lds_u8;
+
+__device__ __attribute__((aligned(256))) uint4 g_zero_page[16];   // zero-initialised; source of out-of-image pixels
+
+constexpr int DX_PIX = 192;                        // 10x18 = 180 halo pixels, rounded up to 24 DMA pieces of 8 pixels
+constexpr int DD_PIX = 128;                        // 8x16 dy pixels = 16 pieces
+constexpr int DSTAGE = (DX_PIX + DD_PIX) * 128;    // 40960
+constexpr int DNSTAGE = 3;
+constexpr int DPIECES = 40, DPER_WAVE = 5;         // 40 pieces over 8 waves
+constexpr int DLDS = 4 * 36 * 1024;                // final K-half exchange: 4 waves x 36 tiles x 1 KiB (>= 3 stages)
+
+__device__ __forceinline__ short4v tr_read2(unsigned addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr2)(size_t)addr);
+}
+__device__ __forceinline__ bf16x8 join8b(short4v a, short4v b) {
+  union { short8v s; bf16x8 h; } c;
+  c.s = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return c.h;
+}
+// one LDS-DMA wave-instruction: lane l copies 16 B from its own global address to LDS byte (lds_dst + 16*l).
+// M0 is compiler-reserved: save, set, use and restore it inside ONE statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+struct DmaJob { const uint16_t* x; const uint16_t* dy; int n0, H, W, x_cstride, x_coff, dy_mode, dy_cstride, dy_coff, tiles_x, tiles_y; };
+
+// issue this wave's 5 pieces of one tile into ring slot `stage_addr` (LDS byte address, wave-uniform)
+__device__ __forceinline__ void tile_issue(const DmaJob& j, int tile, unsigned stage_addr, int wave, int lane) {
+  const TileCoord tc = decode_tile(tile, j.tiles_x, j.tiles_y);
+  const int n = j.n0 + tc.n;
+  const int sub = lane >> 3, slot = lane & 7;
+#pragma unroll
+  for (int k = 0; k < DPER_WAVE; ++k) {
+    const int piece = wave + 8 * k;                       // wave-uniform
+    const void* src = g_zero_page;
+    if (piece < 24) {                                     // x halo: pixels 8*piece .. 8*piece+7 of the 10x18 tile
+      const int pix = piece * 8 + sub;
+      const int r = pix / HALO_W, c = pix - r * HALO_W;
+      const int y = tc.ty * TH + r - 1, x = tc.tx * TW + c - 1;
+      const int chunk = slot ^ (pix & 7);
+      if (pix < HALO_PIX && (unsigned)y < (unsigned)j.H && (unsigned)x < (unsigned)j.W)
+        src = j.x + ((size_t)(n * j.H + y) * j.W + x) * j.x_cstride + j.x_coff + chunk * 8;
+    } else {                                              // dy: pixels 8*(piece-24) .. of the 8x16 tile
+      const int pix = (piece - 24) * 8 + sub;
+      const int y = tc.ty * TH + (pix >> 4), x = tc.tx * TW + (pix & 15);
+      const int chunk = slot ^ (pix & 7);
+      if (y < j.H && x < j.W) {
+        if (j.dy_mode == 0) src = j.dy + ((size_t)(n * j.H + y) * j.W + x) * j.dy_cstride + j.dy_coff + chunk * 8;
+        else src = j.dy + ((size_t)(n * 2 * j.H + 2 * y + (j.dy_coff >> 1)) * (2 * j.W) + 2 * x + (j.dy_coff & 1)) * 64 + chunk * 8;
+      }
+    }
+    dma16(src, __builtin_amdgcn_readfirstlane(stage_addr + piece * 1024));
+  }
+}
+
+__global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job* __restrict__ jobs) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[DLDS];
+  const rumpy_wgrad_job* jp = jobs + blockIdx.x;
+  DmaJob j;
+  j.x = (const uint16_t*)jp->x; j.dy = (const uint16_t*)jp->dy; j.n0 = jp->n0; j.H = jp->H; j.W = jp->W;
+  j.x_cstride = jp->x_cstride; j.x_coff = jp->x_coff; j.dy_mode = jp->dy_mode; j.dy_cstride = jp->dy_cstride; j.dy_coff = jp->dy_coff;
+  j.tiles_x = (j.W + TW - 1) / TW; j.tiles_y = (j.H + TH - 1) / TH;
+  const int t0 = jp->t0, ntiles = jp->t1 - jp->t0;
+  float* slab = jp->slab;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w4 = wave & 3, kh = wave >> 2;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
+  const unsigned lds0 = (unsigned)(size_t)(lds_u8)lds;
+
+  // per-lane transposed-read offsets inside a stage, for k-step 0 of this wave (rows 4kh, 4kh+1):
+  //   pixel (row, col) of the first read: row = 4kh + g/2, col = 4*(g%2) + q; second read: col + 8 (same swizzle)
+  const int rsel = 4 * kh + (g >> 1), col0 = 4 * (g & 1) + q;
+  unsigned offA[4], offB[9];
+  {
+    const int idx = rsel * TW + col0;                    // dy tile pixel index
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      offA[ct] = DX_PIX * 128 + idx * 128 + (((2 * ct + (p4 >> 1)) ^ (idx & 7)) << 4) + (p4 & 1) * 8;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int ix = (rsel + ky) * HALO_W + col0 + kx;   // x halo pixel index
+      offB[tap] = ix * 128 + (((2 * w4 + (p4 >> 1)) ^ (ix & 7)) << 4) + (p4 & 1) * 8;
+    }
+  }
+  // second k-step of this wave: rows +2 -> dy index +32 (same swizzle), x index +36 (swizzle ^ 4 -> byte 64 flips)
+
+  f32x4 acc[4][9];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[ct][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) bacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  if (ntiles > 0) tile_issue(j, t0, lds0, wave, lane);
+  if (ntiles > 1) tile_issue(j, t0 + 1, lds0 + DSTAGE, wave, lane);
+  int slot = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed once at most the 5 pieces of tile t+1 are still in flight (per wave), then all waves meet
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < ntiles) {
+      const int s2 = (slot + 2 >= DNSTAGE) ? slot + 2 - DNSTAGE : slot + 2;
+      tile_issue(j, t0 + t + 2, lds0 + s2 * DSTAGE, wave, lane);
+    }
+    const unsigned sb = lds0 + slot * DSTAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 A[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const unsigned pa = sb + offA[ct] + ks * (32 * 128);
+        A[ct] = join8b(tr_read2(pa), tr_read2(pa + 8 * 128));
+      }
+      if (w4 == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) bacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], ones, bacc[ct], 0, 0, 0);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const unsigned pb = sb + (ks ? (offB[tap] ^ 64u) + 36 * 128 : offB[tap]);
+        const bf16x8 B = join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
+      }
+    }
+    slot = (slot + 1 >= DNSTAGE) ? 0 : slot + 1;
+  }
+  // ---- add the two K halves through LDS, then write the slab: [co 64][tap 9][ci 64] + [64] bias sums ----
+  __syncthreads();
+  f32x4* xch = reinterpret_cast<f32x4*>(lds) + (size_t)w4 * (36 * 64) + lane;
+  if (kh == 1) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) xch[(ct * 9 + tap) * 64] = acc[ct][tap];
+  }
+  __syncthreads();
+  if (kh == 0) {
+    const int ci = 16 * w4 + (lane & 15);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const f32x4 o = acc[ct][tap] + xch[(ct * 9 + tap) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) slab[((16 * ct + 4 * g + e) * 9 + tap) * 64 + ci] = o[e];
+      }
+  }
+  // bias sums: waves (w4 = 0, kh = 0/1) hold D[co][*] (all 16 columns equal); add the halves through LDS too
+  __syncthreads();
+  float* bx = reinterpret_cast<float*>(lds);
+  if (w4 == 0 && kh == 1 && (lane & 15) == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bx[16 * ct + 4 * g + e] = bacc[ct][e];
+  }
+  __syncthreads();
+  if (w4 == 0 && kh == 0 && (lane & 15) == 0) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) slab[64 * 576 + 16 * ct + 4 * g + e] = bacc[ct][e] + bx[16 * ct + 4 * g + e];
+  }
+}
+
+int rumpy_wgrad_dma_launch(const rumpy_wgrad_job* jobs_device, int njobs, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_dma_kernel, dim3(njobs), dim3(512), 0, s, jobs_device);
+  return 0;
+}

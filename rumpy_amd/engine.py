@@ -90,7 +90,7 @@ class _Plan:
 
 
 class SREngine:
-    def __init__(self, spec, device, wgrad_pixels_per_job=9216):
+    def __init__(self, spec, device, wgrad_pixels_per_job=8192):
         self.spec, self.device = spec, device
         self.lib = L.lib()
         self.cus = self.lib.rumpy_device_cus()
@@ -385,7 +385,8 @@ class SREngine:
                     total += len(ranges) * slab_floats[mt]
         slabs = self._new(plan, max(total, 1), dtype=torch.float32)
         base = slabs.data_ptr()
-        for (cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, off) in layout:
+        keyed = {4: [], 1: []}
+        for li, (cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, off) in enumerate(layout):
             sf = slab_floats[mt]
             for k, (t0, t1) in enumerate(ranges):
                 if dy_mode == 0:
@@ -394,12 +395,20 @@ class SREngine:
                     dcs, dco = 64, ct
                 else:
                     dcs, dco = 4, 0
-                jobs[mt].append(L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=0, n1=N, t0=t0, t1=t1, H=H, W=W,
-                                           x_cstride=cv.cin, x_coff=ch * 64, dy_mode=dy_mode, dy_cstride=dcs, dy_coff=dco, mt=mt))
+                # launch order: jobs that read the same x tiles (the cout tiles of one tile range) sit next to each other,
+                # so the x halo re-reads of an upsampler conv hit L2; slab addresses do not depend on the order
+                keyed[mt].append(((id(x), k, li), L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=0, n1=N,
+                                                              t0=t0, t1=t1, H=H, W=W, x_cstride=cv.cin, x_coff=ch * 64, dy_mode=dy_mode,
+                                                              dy_cstride=dcs, dy_coff=dco, mt=mt)))
             items.append(L.ReduceItem(slab=base + 4 * off, slab_stride=sf, njobs=len(ranges), mt=mt,
                                       co_count=(64 if mt == 4 else cv.cout), co_mode=1 if (mt == 4 and cv.shuffle) else 0,
                                       co_off=(ct if (mt == 4 and cv.shuffle) else ct * 64), ci_total=cv.cin, ci_off=ch * 64,
                                       write_bias=1 if ch == 0 else 0, scale=float(scale), gw=_ptr(cv.gw), gb=_ptr(cv.gb)))
+        first_seen = {}
+        for mt in (4, 1):
+            for key, _ in keyed[mt]:
+                first_seen.setdefault(key[0], len(first_seen))
+            jobs[mt] = [jb for _, jb in sorted(keyed[mt], key=lambda kj: (first_seen[kj[0][0]], kj[0][1], kj[0][2]))]
         plan.reduce_scales = [it.scale for it in items]
         plan.reduce_host = (L.ReduceItem * len(items))(*items)
         plan.reduce_dev = torch.empty(C.sizeof(plan.reduce_host), dtype=torch.uint8, device=self.device)
