@@ -144,7 +144,9 @@ typedef struct {
   int32_t dy_mode, dy_cstride, dy_coff;
   int32_t mt;        /* 4: 64 output channels ; 1: <=4 output channels (tail) */
 } rumpy_wgrad_job;
-int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t njobs, int32_t mt, void* stream);
+/* variant 0 = streaming LDS-DMA kernel (mt == 1 needs an even image width: its dy pieces are pixel pairs);
+ * variant 1 = register-staged kernel (any width; also the A/B reference) */
+int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t njobs, int32_t mt, int32_t variant, void* stream);
 int64_t rumpy_wgrad_slab_floats(int32_t mt);
 
 typedef struct {

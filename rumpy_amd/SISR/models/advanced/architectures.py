@@ -81,7 +81,7 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, x, net, train, *params):
         out, _, plan = net.engine_forward(x, train=train)
         ctx.net, ctx.plan = net, plan
-        return out.clone()
+        return out
 
     @staticmethod
     def backward(ctx, gout):
@@ -191,7 +191,7 @@ class HipSRNet(nn.Module):
         if train:
             return _NetFn.apply(x, self, True, *self.param_list)
         out, _, _ = self.engine_forward(x, train=False)
-        return out.clone()
+        return out
 
     def fused_l1_forward_backward(self, x, y):
         """forward + nn.L1Loss + full backward in one pass (base_architecture.py:474-480 minus the optimizer).

@@ -11,6 +11,7 @@
 // The epilogue works on 4 consecutive channels per lane (8-byte accesses): bias, ReLU, scale, ReLU-mask
 // (backward), per-tile channel sums (channel attention), two residual adds, PixelShuffle scatter.
 #include "common.hpp"
+#include <cstdlib>
 
 struct ConvDev {
   const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
@@ -322,9 +323,12 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (p->cin_chunks != 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 or 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
   if (p->in_mode == 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: in_mode 1 needs cin_chunks 4"); return RUMPY_E_ARG; }
   if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || p->res1 || p->res2)) { rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4 and no mask/residual"); return RUMPY_E_ARG; }
-  if (p->cin_chunks == 1) {   // Cin = 64: strip kernel (conv_strip.hip)
+  // Cin = 256 (upsampler data gradients): the 8x16-tile kernel below measures faster than the 4-chunk strip build
+  // (which spills at 256 VGPRs); RUMPY_CONV4_STRIP=1 selects the strip build for A/B runs.
+  static const bool strip4 = getenv("RUMPY_CONV4_STRIP") != nullptr;
+  if (p->cin_chunks == 1 || strip4) {   // strip kernel (conv_strip.hip)
     hipStream_t s1 = (hipStream_t)stream;
-    const int kid1 = (p->cout_tiles == 1) ? 1 : 3;
+    const int kid1 = (p->cout_tiles == 1 && p->cin_chunks == 1) ? 1 : 3;
     rumpy_probe_pre(kid1, s1);
     rumpy_conv3x3_strip_launch(p, s1);
     rumpy_probe_post(kid1, s1);

@@ -1,20 +1,18 @@
-// 3x3 same-padding convolution, Cin = 64, on bf16 MFMA: strip kernel (the dominant kernel of the hot path).
+// 3x3 same-padding convolution, Cin = 64 (x chunks), on bf16 MFMA: strip kernel (the dominant kernel of the hot path).
 //
 // Work unit = a strip of 6 output rows x 48 output columns of one image (288 pixels: exactly one strip per CU
-// for the headline shape 32 x 48 x 48).  One 512-thread workgroup per CU; its 8 waves partition the FILTER, not the
-// pixels: wave (q, kh) owns output channels 16q..16q+15 and input channels 32kh..32kh+31, i.e. 9 MFMA A-fragments
-// (36 VGPRs) that stay in registers for the whole kernel and are fetched exactly once per CU (73.7 KB, no
-// redundancy between waves).  Every wave sweeps all 288 pixels for its (channel quarter, K half):
+// for the headline shape 32 x 48 x 48).  One 512-thread workgroup per CU; wave (q, rh) owns output channels
+// 16q..16q+15 of output rows 3rh..3rh+2 and keeps its filter slice (16 co x 576 k = 18 MFMA A-fragments = 72 VGPRs)
+// in registers for the whole kernel; waves never exchange data, so each runs at its own pace and stores as soon as
+// its 162 MFMAs are done (one barrier per strip, only to recycle the LDS buffers).
 //   D[co 16][px 16] += A[co][k = 32 input channels of one tap] * B[k][px]          (v_mfma_f32_16x16x32_bf16)
 // The 8 x 50-pixel input halo of a strip is staged HBM -> registers -> LDS as two 32-channel halves (64-byte pixel
-// halves at a 96-byte stride: conflict-free ds_read_b128 B-fragments); wave (q, kh) reads only half kh, so the two
-// K halves run concurrently on the two waves of a SIMD with no barrier between them.  One B-fragment (input row,
-// column tile, tap column) feeds up to 3 output rows: 72 LDS reads per 162 MFMAs per wave.
-// The two K-half partial accumulators are exchanged through LDS (the dead input buffer): wave (q,0) finishes rows
-// 0-2, wave (q,1) rows 3-5.  Epilogue (per lane 4 consecutive channels of a pixel, 8-byte vectors): bias enters as
-// the accumulator's initial value, then ReLU, scale, ReLU mask, per-strip channel sums, two residual adds,
-// PixelShuffle scatter, bf16 store; mask / residual vectors are prefetched under the MFMAs.
-// Persistent over strips with the next strip's halo prefetched into the other LDS buffer.
+// halves at a 96-byte stride: conflict-free ds_read_b128 B-fragments).  One B-fragment (input row, column tile, tap
+// column, channel half) feeds up to 3 output rows: 90 LDS reads per 162 MFMAs per wave.
+// Epilogue (per lane 4 consecutive channels of a pixel, 8-byte vectors): bias enters as the accumulator's initial
+// value, then ReLU, scale, ReLU mask, per-strip channel sums, two residual adds, PixelShuffle scatter, bf16 store;
+// mask / residual vectors are prefetched under the MFMAs.  Persistent over strips with the next strip's halo
+// prefetched into the other LDS buffer.
 #include "common.hpp"
 
 constexpr int SH = 6, SW = 48;
@@ -29,7 +27,7 @@ constexpr int SREGS = (SPIECES + STHREADS - 1) / STHREADS;            // 7 per t
 struct StripDev {
   const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
   const uint16_t* mask; const uint16_t* res1; const uint16_t* res2; float* pool;
-  int N, H, W, cout_tiles, out_mode, relu; float scale; int sx_n, sy_n;
+  int N, H, W, cout_tiles, in_mode, out_mode, relu; float scale; int sx_n, sy_n;
 };
 
 struct StripCoord { int n, sy, sx; };
@@ -42,47 +40,49 @@ __device__ __forceinline__ StripCoord decode_strip(int s, int sx_n, int sy_n) {
   return c;
 }
 
-// Per-thread staging geometry, loop invariant: piece i of this thread = 16 B = channels 8*part..8*part+7 of halo pixel
-// (lrow, lcol); it lands in K half part/4 of the stage.
-struct StripGeom { int lrow[SREGS], lcol[SREGS], goff[SREGS], loff[SREGS]; };
-__device__ __forceinline__ void strip_geom(StripGeom& gm, int tid) {
+// Staging: piece p (16 B) = channels 8*part..8*part+7 of halo pixel pix = p/8 (row pix/50, column pix%50); it lands in K
+// half part/4 of the stage.  The geometry is recomputed at each use (a few VALU ops) instead of living in registers
+// across the MFMA loop.  Branch-free: every lane loads from a clamped in-bounds address and the result is zeroed
+// afterwards, so the loads of a stage issue back to back (no exec-mask regions; 32-bit element offsets).
+// mode 0: src is [N,H,W,64*chunks], input chunk `ch` = channels 64ch..64ch+63.
+// mode 1: src is [N,2H,2W,64] (a pixel-shuffled gradient); chunk ch = sub-pixel (ch/2, ch%2): PixelShuffle^T gather.
+template <int CHUNKS>
+__device__ __forceinline__ void strip_issue(uint4 (&R)[SREGS], const uint16_t* __restrict__ src, int mode, int ch, StripCoord c,
+                                            int H, int W, int tid) {
+  const int y0 = c.sy * SH - 1, x0 = c.sx * SW - 1;
+  int base, rstep, cstep;
+  if (CHUNKS == 1 || mode == 0) {
+    base = ((c.n * H + y0) * W + x0) * (64 * CHUNKS) + ch * 64;
+    rstep = W * 64 * CHUNKS; cstep = 64 * CHUNKS;
+  } else {
+    base = ((c.n * 2 * H + 2 * y0 + (ch >> 1)) * (2 * W) + 2 * x0 + (ch & 1)) * 64;
+    rstep = 4 * W * 64; cstep = 128;
+  }
 #pragma unroll
   for (int i = 0; i < SREGS; ++i) {
     const int p = tid + STHREADS * i;
-    const bool in = p < SPIECES;
-    const int pix = in ? (p >> 3) : 0, part = p & 7;
-    const int r = pix / SCOLS;
-    gm.lrow[i] = in ? r : -100000;                 // pieces beyond the halo never validate
-    gm.lcol[i] = pix - r * SCOLS;
-    gm.goff[i] = part * 8;
-    gm.loff[i] = in ? (part >> 2) * HHALF + pix * HSTRIDE + (part & 3) * 16 : -1;
-  }
-}
-// Branch-free: every lane loads from a clamped in-bounds address and the result is zeroed afterwards, so the loads
-// of a stage issue back to back (no exec-mask regions; 32-bit element offsets).
-__device__ __forceinline__ void strip_issue(uint4 (&R)[SREGS], const uint16_t* __restrict__ src, StripCoord c, int H, int W,
-                                            const StripGeom& gm) {
-  const int y0 = c.sy * SH - 1, x0 = c.sx * SW - 1;
-  const int base = ((c.n * H + y0) * W + x0) * 64;
-#pragma unroll
-  for (int i = 0; i < SREGS; ++i) {
-    const int y = y0 + gm.lrow[i], x = x0 + gm.lcol[i];
-    const bool ok = ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
-    const int e = ok ? base + (gm.lrow[i] * W + gm.lcol[i]) * 64 + gm.goff[i] : 0;
+    const int pix = p >> 3, part = p & 7;
+    const int lr = pix / SCOLS, lc = pix - lr * SCOLS;
+    const int y = y0 + lr, x = x0 + lc;
+    const bool ok = (p < SPIECES) & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+    const int e = ok ? base + lr * rstep + lc * cstep + part * 8 : 0;
     uint4 v = *reinterpret_cast<const uint4*>(src + (unsigned)e);
     if (!ok) v = make_uint4(0, 0, 0, 0);
     R[i] = v;
   }
 }
-__device__ __forceinline__ void strip_write(const uint4 (&R)[SREGS], unsigned char* lds, const StripGeom& gm) {
+__device__ __forceinline__ void strip_write(const uint4 (&R)[SREGS], unsigned char* lds, int tid) {
 #pragma unroll
-  for (int i = 0; i < SREGS; ++i)
-    if (gm.loff[i] >= 0) *reinterpret_cast<uint4*>(lds + gm.loff[i]) = R[i];
+  for (int i = 0; i < SREGS; ++i) {
+    const int p = tid + STHREADS * i;
+    const int pix = p >> 3, part = p & 7;
+    if (p < SPIECES) *reinterpret_cast<uint4*>(lds + (part >> 2) * HHALF + pix * HSTRIDE + (part & 3) * 16) = R[i];
+  }
 }
 
 // STAMP = true is a diagnostic build: lane 0 of every wave writes s_memrealtime (100 MHz) stamps at the phase
 // boundaries of its FIRST strip into a.pool (reinterpreted as u64 [workgroup][wave][8]); never used by the product.
-template <bool STAMP>
+template <int CHUNKS, bool STAMP>
 __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SSTAGE];
   unsigned long long stamps[8];
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
   STAMP_HERE();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
-  const int q = wave & 3, kh = wave >> 2;
+  const int q = wave & 3, rh = wave >> 2;
   const int ct = blockIdx.y;
   const int nstrips = a.N * a.sy_n * a.sx_n;
 
@@ -99,25 +99,22 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
   if (strip >= nstrips) return;
   // the input loads go out first (longest latency); the filter comes from L2 behind them
   uint4 R[SREGS];
-  StripGeom gm;
-  strip_geom(gm, tid);
-  strip_issue(R, a.x, decode_strip(strip, a.sx_n, a.sy_n), a.H, a.W, gm);
+  strip_issue<CHUNKS>(R, a.x, a.in_mode, 0, decode_strip(strip, a.sx_n, a.sy_n), a.H, a.W, tid);
 
-  // stationary filter slice: packed [ct][q][s = tap*2 + kh][lane] x 16 B  -> this wave keeps s = 2*tap + kh
-  bf16x8 F[9];
-  {
-    const uint4* wp = a.w + ((size_t)(ct * 4 + q) * 18) * 64;
+  // stationary filter slice: packed [ct][chunk][q][s = tap*2 + ci half][lane] x 16 B
+  //   (CHUNKS > 1: the 18 fragments are re-fetched from L2 for every input chunk)
+  bf16x8 F[18];
+  const uint4* wbase = a.w + ((size_t)(ct * CHUNKS * 4 + q) * 18) * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) F[t] = as_bf16x8(wp[(t * 2 + kh) * 64 + lane]);
-  }
+  for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wbase[t * 64]);
   const int c0 = 16 * q + 4 * g;   // this lane's 4 consecutive channels inside the 64-channel tile
   f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (a.bias && kh == 0) {          // the bias rides in the K-half-0 accumulator
+  if (a.bias) {                     // the bias is the accumulator's initial value
     const float4 b4 = *reinterpret_cast<const float4*>(a.bias + ct * 64 + c0);
     bias4 = (f32x4){b4.x, b4.y, b4.z, b4.w};
   }
   STAMP_HERE();                         // 1: all prologue loads issued
-  strip_write(R, lds, gm);
+  strip_write(R, lds, tid);
   __syncthreads();
   STAMP_HERE();                         // 2: first stage in LDS
 
@@ -129,96 +126,83 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
 
   for (; strip < nstrips; strip += gridDim.x) {
     const StripCoord sc = decode_strip(strip, a.sx_n, a.sy_n);
-    const int nstrip = strip + (int)gridDim.x;
-    const bool has_next = nstrip < nstrips;
-    if (has_next) strip_issue(R, a.x, decode_strip(nstrip, a.sx_n, a.sy_n), a.H, a.W, gm);
-
-    // this wave finishes output rows 3*kh .. 3*kh+2: element offsets of its 9 output vectors
     unsigned off[3][3];
     uint2 P0[3][3], P1[3][3];
+    f32x4 acc[3][3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int y = sc.sy * SH + 3 * kh + r;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int xx = sc.sx * SW + 16 * c + px;
-        unsigned o = 0xffffffffu;
-        if (y < a.H && xx < a.W) {
-          if (a.out_mode == 0) o = (unsigned)(((sc.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + c0);
-          else o = (unsigned)(((sc.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + c0);
-        }
-        off[r][c] = o;
-        const unsigned oc = (o != 0xffffffffu) ? o : 0u;   // clamped: the prefetch loads are unconditional
-        P0[r][c] = make_uint2(0, 0); P1[r][c] = make_uint2(0, 0);
-        if (p0) P0[r][c] = *reinterpret_cast<const uint2*>(p0 + oc);
-        if (p1) P1[r][c] = *reinterpret_cast<const uint2*>(p1 + oc);
-      }
-    }
-
-    f32x4 acc[6][3];
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[r][c] = bias4;
 
-    unsigned char* stage = lds + buf * SSTAGE;
-    const unsigned char* cur = stage + kh * HHALF;
+    unsigned char* stage = lds;
+    bool has_next = false;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int ch = 0; ch < CHUNKS; ++ch) {
+      // prefetch the next stage: next input chunk of this strip, or chunk 0 of the next strip
+      const int nstrip = (ch + 1 < CHUNKS) ? strip : strip + (int)gridDim.x;
+      const int nch = (ch + 1 < CHUNKS) ? ch + 1 : 0;
+      has_next = nstrip < nstrips;
+      if (has_next) strip_issue<CHUNKS>(R, a.x, a.in_mode, nch, decode_strip(nstrip, a.sx_n, a.sy_n), a.H, a.W, tid);
+      if (ch == CHUNKS - 1) {
+        // element offsets of this lane's 9 output vectors (rows 3*rh .. 3*rh+2) + epilogue operands
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        bf16x8 I[8];
+        for (int r = 0; r < 3; ++r) {
+          const int y = sc.sy * SH + 3 * rh + r;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-          I[r] = *reinterpret_cast<const bf16x8*>(cur + (r * SCOLS + 16 * c + px + kx) * HSTRIDE + g * 16);
+          for (int c = 0; c < 3; ++c) {
+            const int xx = sc.sx * SW + 16 * c + px;
+            unsigned o = 0xffffffffu;
+            if (y < a.H && xx < a.W) {
+              if (a.out_mode == 0) o = (unsigned)(((sc.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + c0);
+              else o = (unsigned)(((sc.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + c0);
+            }
+            off[r][c] = o;
+            const unsigned oc = (o != 0xffffffffu) ? o : 0u;   // clamped: the prefetch loads are unconditional
+            P0[r][c] = make_uint2(0, 0); P1[r][c] = make_uint2(0, 0);
+            if (p0) P0[r][c] = *reinterpret_cast<const uint2*>(p0 + oc);
+            if (p1) P1[r][c] = *reinterpret_cast<const uint2*>(p1 + oc);
+          }
+        }
+      }
+      stage = lds + buf * SSTAGE;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+      for (int half = 0; half < 2; ++half) {
+        const unsigned char* cur = stage + half * HHALF + (3 * rh * SCOLS + px) * HSTRIDE + g * 16;
 #pragma unroll
-          for (int r = 0; r < 6; ++r)
-            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ky * 3 + kx], I[r + ky], acc[r][c], 0, 0, 0);
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            bf16x8 I[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+              I[r] = *reinterpret_cast<const bf16x8*>(cur + (r * SCOLS + 16 * c + kx) * HSTRIDE);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int r = 0; r < 3; ++r)
+                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r][c], 0, 0, 0);
+          }
+        }
+      }
+      if (CHUNKS > 1 && has_next) {     // filter fragments of the next stage (L2 hits) land under the hand-over below
+#pragma unroll
+        for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wbase[(size_t)nch * (4 * 18 * 64) + t * 64]);
+      }
+      if (ch + 1 < CHUNKS) {            // not the last chunk: hand the LDS buffers over and continue accumulating
+        if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
+        __syncthreads();
+        buf ^= 1;
       }
     }
     STAMP_HERE();                       // 3: MFMAs issued
-    __syncthreads();                    // every wave is done reading the input stage: reuse it for the exchange
-    // ---- K-half exchange: hand the partner the rows it finishes, take ours ----
-    {
-      f32x4* xw = reinterpret_cast<f32x4*>(stage) + (size_t)(q * 2 + kh) * (9 * 64) + lane;
-      if (kh == 0) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) xw[(r * 3 + c) * 64] = acc[3 + r][c];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) xw[(r * 3 + c) * 64] = acc[r][c];
-      }
-    }
-    __syncthreads();
-    f32x4 fin[3][3];
-    {
-      const f32x4* xr = reinterpret_cast<const f32x4*>(stage) + (size_t)(q * 2 + (kh ^ 1)) * (9 * 64) + lane;
-      if (kh == 0) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) fin[r][c] = acc[r][c] + xr[(r * 3 + c) * 64];
-      } else {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) fin[r][c] = acc[3 + r][c] + xr[(r * 3 + c) * 64];
-      }
-    }
-    STAMP_HERE();                       // 4: partial sums exchanged
-    // ---- epilogue: lane holds channels c0..c0+3 of pixel (row 3kh + r, column 16c + px) ----
+    STAMP_HERE();                       // 4: (unused)
+    // ---- epilogue: lane holds channels c0..c0+3 of pixel (row 3rh + r, column 16c + px) ----
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float v[4] = {fin[r][c][0], fin[r][c][1], fin[r][c][2], fin[r][c][3]};
+        float v[4] = {acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]};
         if (a.relu) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -259,7 +243,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
       }
     }
     if (a.pool && !STAMP) {
-      // per-(strip, row half) channel sums: pool[n][(2*sy + kh) * sx_n + sx][channel]
+      // per-(strip, row half) channel sums: pool[n][(2*sy + rh) * sx_n + sx][channel]
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float s = ps[j];
@@ -267,11 +251,11 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
         ps[j] = s;
       }
       if (px == 0) {
-        float* pp = a.pool + ((size_t)(sc.n * a.sy_n * 2 + 2 * sc.sy + kh) * a.sx_n + sc.sx) * (64 * a.cout_tiles) + ct * 64 + c0;
+        float* pp = a.pool + ((size_t)(sc.n * a.sy_n * 2 + 2 * sc.sy + rh) * a.sx_n + sc.sx) * (64 * a.cout_tiles) + ct * 64 + c0;
         *reinterpret_cast<float4*>(pp) = make_float4(ps[0], ps[1], ps[2], ps[3]);
       }
     }
-    if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, gm);
+    if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
     __syncthreads();
     STAMP_HERE();                       // 5: epilogue done
     buf ^= 1;
@@ -295,7 +279,7 @@ int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s) {
   StripDev d;
   d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = (uint16_t*)p->out;
   d.mask = (const uint16_t*)p->mask; d.res1 = (const uint16_t*)p->res1; d.res2 = (const uint16_t*)p->res2; d.pool = p->pool;
-  d.N = p->N; d.H = p->H; d.W = p->W; d.cout_tiles = p->cout_tiles; d.out_mode = p->out_mode;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.cout_tiles = p->cout_tiles; d.in_mode = p->in_mode; d.out_mode = p->out_mode;
   d.relu = p->relu; d.scale = p->scale; d.sx_n = cdiv(p->W, SW); d.sy_n = cdiv(p->H, SH);
   const int nstrips = d.N * d.sx_n * d.sy_n;
   int gx = p->grid_x;
@@ -307,9 +291,11 @@ int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s) {
   if (gx > nstrips) gx = nstrips;
   if (p->relu == 0x5754) {   // diagnostic stamp build (rumpy_debug_conv_stamps)
     d.relu = 0;
-    hipLaunchKernelGGL(conv3x3_strip_kernel<true>, dim3(gx, 1), dim3(STHREADS), 0, s, d);
+    hipLaunchKernelGGL((conv3x3_strip_kernel<1, true>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
+  } else if (p->cin_chunks == 1) {
+    hipLaunchKernelGGL((conv3x3_strip_kernel<1, false>), dim3(gx, p->cout_tiles), dim3(STHREADS), 0, s, d);
   } else {
-    hipLaunchKernelGGL(conv3x3_strip_kernel<false>, dim3(gx, p->cout_tiles), dim3(STHREADS), 0, s, d);
+    hipLaunchKernelGGL((conv3x3_strip_kernel<4, false>), dim3(gx, p->cout_tiles), dim3(STHREADS), 0, s, d);
   }
   return 0;
 }

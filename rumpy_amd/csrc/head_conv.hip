@@ -155,7 +155,7 @@ __global__ void head_wgrad_reduce_kernel(const float* __restrict__ slab, int nwg
   else gb[co] = s * scale;
 }
 
-static int head_wgrad_grid() { return 128; }
+static int head_wgrad_grid() { return 256; }
 
 extern "C" int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout) {
   return (int64_t)head_wgrad_grid() * cout * (9 * C + 1);

@@ -19,11 +19,17 @@ typedef __attribute__((address_space(3))) unsigned char* lds_u8;
 __device__ __attribute__((aligned(256))) uint4 g_zero_page[16];   // zero-initialised; source of out-of-image pixels
 
 constexpr int DX_PIX = 192;                        // 10x18 = 180 halo pixels, rounded up to 24 DMA pieces of 8 pixels
-constexpr int DD_PIX = 128;                        // 8x16 dy pixels = 16 pieces
-constexpr int DSTAGE = (DX_PIX + DD_PIX) * 128;    // 40960
+constexpr int DD_PIX = 128;                        // 8x16 dy pixels = 16 pieces (MT = 4)
 constexpr int DNSTAGE = 3;
-constexpr int DPIECES = 40, DPER_WAVE = 5;         // 40 pieces over 8 waves
-constexpr int DLDS = 4 * 36 * 1024;                // final K-half exchange: 4 waves x 36 tiles x 1 KiB (>= 3 stages)
+// MT = 4 (64 output channels): 24 x pieces + 16 dy pieces = 40 pieces, 5 per wave.
+// MT = 1 (tail conv, dy = [N,H,W,4]): 24 x pieces + 1 dy piece (128 px x 8 B) + 7 pieces of zeros = 32, 4 per wave; the zero
+// pieces double as the all-zero channels 4..15 of the transposed dy reads.
+template <int MT> struct DmaCfg {
+  static constexpr int PIECES = (MT == 4) ? 40 : 32;
+  static constexpr int PER_WAVE = PIECES / 8;
+  static constexpr int STAGE = PIECES * 1024;
+  static constexpr int LDS = (MT == 4) ? 4 * 36 * 1024 : 3 * STAGE;   // >= 3 stages and >= the final K-half exchange
+};
 
 __device__ __forceinline__ short4v tr_read2(unsigned addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr2)(size_t)addr);
@@ -43,13 +49,14 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 
 struct DmaJob { const uint16_t* x; const uint16_t* dy; int n0, H, W, x_cstride, x_coff, dy_mode, dy_cstride, dy_coff, tiles_x, tiles_y; };
 
-// issue this wave's 5 pieces of one tile into ring slot `stage_addr` (LDS byte address, wave-uniform)
+// issue this wave's pieces of one tile into ring slot `stage_addr` (LDS byte address, wave-uniform)
+template <int MT>
 __device__ __forceinline__ void tile_issue(const DmaJob& j, int tile, unsigned stage_addr, int wave, int lane) {
   const TileCoord tc = decode_tile(tile, j.tiles_x, j.tiles_y);
   const int n = j.n0 + tc.n;
   const int sub = lane >> 3, slot = lane & 7;
 #pragma unroll
-  for (int k = 0; k < DPER_WAVE; ++k) {
+  for (int k = 0; k < DmaCfg<MT>::PER_WAVE; ++k) {
     const int piece = wave + 8 * k;                       // wave-uniform
     const void* src = g_zero_page;
     if (piece < 24) {                                     // x halo: pixels 8*piece .. 8*piece+7 of the 10x18 tile
@@ -59,6 +66,12 @@ __device__ __forceinline__ void tile_issue(const DmaJob& j, int tile, unsigned s
       const int chunk = slot ^ (pix & 7);
       if (pix < HALO_PIX && (unsigned)y < (unsigned)j.H && (unsigned)x < (unsigned)j.W)
         src = j.x + ((size_t)(n * j.H + y) * j.W + x) * j.x_cstride + j.x_coff + chunk * 8;
+    } else if (MT == 1) {                                 // dy4: lane l carries pixels 2l, 2l+1 (8 B each) of piece 24
+      if (piece == 24) {
+        const int pix = 2 * lane;
+        const int y = tc.ty * TH + (pix >> 4), x = tc.tx * TW + (pix & 15);
+        if (y < j.H && x < j.W) src = j.dy + ((size_t)(n * j.H + y) * j.W + x) * 4;   // W is even: x+1 is in the image too
+      }
     } else {                                              // dy: pixels 8*(piece-24) .. of the 8x16 tile
       const int pix = (piece - 24) * 8 + sub;
       const int y = tc.ty * TH + (pix >> 4), x = tc.tx * TW + (pix & 15);
@@ -72,8 +85,10 @@ __device__ __forceinline__ void tile_issue(const DmaJob& j, int tile, unsigned s
   }
 }
 
+template <int MT>
 __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job* __restrict__ jobs) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[DLDS];
+  constexpr int DSTAGE = DmaCfg<MT>::STAGE;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[DmaCfg<MT>::LDS];
   const rumpy_wgrad_job* jp = jobs + blockIdx.x;
   DmaJob j;
   j.x = (const uint16_t*)jp->x; j.dy = (const uint16_t*)jp->dy; j.n0 = jp->n0; j.H = jp->H; j.W = jp->W;
@@ -89,12 +104,14 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
   // per-lane transposed-read offsets inside a stage, for k-step 0 of this wave (rows 4kh, 4kh+1):
   //   pixel (row, col) of the first read: row = 4kh + g/2, col = 4*(g%2) + q; second read: col + 8 (same swizzle)
   const int rsel = 4 * kh + (g >> 1), col0 = 4 * (g & 1) + q;
-  unsigned offA[4], offB[9];
+  unsigned offA[MT], offB[9];
   {
     const int idx = rsel * TW + col0;                    // dy tile pixel index
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-      offA[ct] = DX_PIX * 128 + idx * 128 + (((2 * ct + (p4 >> 1)) ^ (idx & 7)) << 4) + (p4 & 1) * 8;
+    for (int ct = 0; ct < MT; ++ct) {
+      if (MT == 4) offA[ct] = DX_PIX * 128 + idx * 128 + (((2 * ct + (p4 >> 1)) ^ (idx & 7)) << 4) + (p4 & 1) * 8;
+      else offA[ct] = (p4 == 0) ? DX_PIX * 128 + idx * 8 : DX_PIX * 128 + 1024;   // channels 0..3, else the zero piece
+    }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int ky = tap / 3, kx = tap - 3 * ky;
@@ -104,49 +121,56 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
   }
   // second k-step of this wave: rows +2 -> dy index +32 (same swizzle), x index +36 (swizzle ^ 4 -> byte 64 flips)
 
-  f32x4 acc[4][9];
+  f32x4 acc[MT][9];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < MT; ++ct)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[ct][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 bacc[4];
+  f32x4 bacc[MT];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct) bacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ct = 0; ct < MT; ++ct) bacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-  if (ntiles > 0) tile_issue(j, t0, lds0, wave, lane);
-  if (ntiles > 1) tile_issue(j, t0 + 1, lds0 + DSTAGE, wave, lane);
+  if (ntiles > 0) tile_issue<MT>(j, t0, lds0, wave, lane);
+  if (ntiles > 1) tile_issue<MT>(j, t0 + 1, lds0 + DSTAGE, wave, lane);
   int slot = 0;
   for (int t = 0; t < ntiles; ++t) {
-    // tile t has landed once at most the 5 pieces of tile t+1 are still in flight (per wave), then all waves meet
-    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile t has landed once at most the pieces of tile t+1 are still in flight (per wave), then all waves meet
+    if (t + 1 < ntiles) {
+      if (MT == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + 2 < ntiles) {
       const int s2 = (slot + 2 >= DNSTAGE) ? slot + 2 - DNSTAGE : slot + 2;
-      tile_issue(j, t0 + t + 2, lds0 + s2 * DSTAGE, wave, lane);
+      tile_issue<MT>(j, t0 + t + 2, lds0 + s2 * DSTAGE, wave, lane);
     }
     const unsigned sb = lds0 + slot * DSTAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 A[4];
+      bf16x8 A[MT];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const unsigned pa = sb + offA[ct] + ks * (32 * 128);
-        A[ct] = join8b(tr_read2(pa), tr_read2(pa + 8 * 128));
+      for (int ct = 0; ct < MT; ++ct) {
+        if (MT == 4) {
+          const unsigned pa = sb + offA[ct] + ks * (32 * 128);
+          A[ct] = join8b(tr_read2(pa), tr_read2(pa + 8 * 128));
+        } else {   // dy4: 8 B per pixel; lanes p4 > 0 read the zero piece (same address for both reads)
+          const unsigned pa = sb + offA[ct] + ((p4 == 0) ? ks * (32 * 8) : 0);
+          A[ct] = join8b(tr_read2(pa), tr_read2(pa + ((p4 == 0) ? 8 * 8 : 0)));
+        }
       }
       if (w4 == 0) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) bacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], ones, bacc[ct], 0, 0, 0);
+        for (int ct = 0; ct < MT; ++ct) bacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], ones, bacc[ct], 0, 0, 0);
       }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const unsigned pb = sb + (ks ? (offB[tap] ^ 64u) + 36 * 128 : offB[tap]);
         const bf16x8 B = join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+        for (int ct = 0; ct < MT; ++ct)
           acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
       }
     }
@@ -154,10 +178,10 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
   }
   // ---- add the two K halves through LDS, then write the slab: [co 64][tap 9][ci 64] + [64] bias sums ----
   __syncthreads();
-  f32x4* xch = reinterpret_cast<f32x4*>(lds) + (size_t)w4 * (36 * 64) + lane;
+  f32x4* xch = reinterpret_cast<f32x4*>(lds) + (size_t)w4 * (MT * 9 * 64) + lane;
   if (kh == 1) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < MT; ++ct)
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) xch[(ct * 9 + tap) * 64] = acc[ct][tap];
   }
@@ -165,7 +189,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
   if (kh == 0) {
     const int ci = 16 * w4 + (lane & 15);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < MT; ++ct)
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const f32x4 o = acc[ct][tap] + xch[(ct * 9 + tap) * 64];
@@ -178,20 +202,21 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
   float* bx = reinterpret_cast<float*>(lds);
   if (w4 == 0 && kh == 1 && (lane & 15) == 0) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < MT; ++ct)
 #pragma unroll
       for (int e = 0; e < 4; ++e) bx[16 * ct + 4 * g + e] = bacc[ct][e];
   }
   __syncthreads();
   if (w4 == 0 && kh == 0 && (lane & 15) == 0) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < MT; ++ct)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) slab[64 * 576 + 16 * ct + 4 * g + e] = bacc[ct][e] + bx[16 * ct + 4 * g + e];
+      for (int e = 0; e < 4; ++e) slab[16 * MT * 576 + 16 * ct + 4 * g + e] = bacc[ct][e] + bx[16 * ct + 4 * g + e];
   }
 }
 
-int rumpy_wgrad_dma_launch(const rumpy_wgrad_job* jobs_device, int njobs, hipStream_t s) {
-  hipLaunchKernelGGL(wgrad_dma_kernel, dim3(njobs), dim3(512), 0, s, jobs_device);
+int rumpy_wgrad_dma_launch(const rumpy_wgrad_job* jobs_device, int njobs, int mt, hipStream_t s) {
+  if (mt == 4) hipLaunchKernelGGL(wgrad_dma_kernel<4>, dim3(njobs), dim3(512), 0, s, jobs_device);
+  else hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(njobs), dim3(512), 0, s, jobs_device);
   return 0;
 }

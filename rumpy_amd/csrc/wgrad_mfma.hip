@@ -204,14 +204,14 @@ __global__ void wgrad_reduce_kernel(const rumpy_reduce_item* __restrict__ items)
 
 extern "C" int64_t rumpy_wgrad_slab_floats(int32_t mt) { return (int64_t)16 * mt * 576 + 16 * mt; }
 
-int rumpy_wgrad_dma_launch(const rumpy_wgrad_job* jobs_device, int njobs, hipStream_t s);   // wgrad_dma.hip
+int rumpy_wgrad_dma_launch(const rumpy_wgrad_job* jobs_device, int njobs, int mt, hipStream_t s);   // wgrad_dma.hip
 
-extern "C" int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t njobs, int32_t mt, void* stream) {
+extern "C" int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t njobs, int32_t mt, int32_t variant, void* stream) {
   if (!jobs_device || njobs <= 0 || (mt != 1 && mt != 4)) { rumpy_set_error("rumpy_wgrad_grouped: bad argument"); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   rumpy_probe_pre(2, s);
   static const bool use_old = getenv("RUMPY_WGRAD_OLD") != nullptr;   // A/B switch for the register-staged kernel
-  if (mt == 4 && !use_old) rumpy_wgrad_dma_launch(jobs_device, njobs, s);
+  if (variant == 0 && !use_old) rumpy_wgrad_dma_launch(jobs_device, njobs, mt, s);
   else if (mt == 4) hipLaunchKernelGGL(wgrad_kernel<4>, dim3(njobs), dim3(256), 0, s, jobs_device);
   else hipLaunchKernelGGL(wgrad_kernel<1>, dim3(njobs), dim3(256), 0, s, jobs_device);
   rumpy_probe_post(2, s);

@@ -188,8 +188,9 @@ class SREngine:
         # ---- head ----
         a0 = act()
         protected.append(a0.data_ptr())
-        fwd.append(('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(plan.x_in), w=_ptr(spec.head.weight), b=_ptr(spec.head.bias),
-                                                    out=_ptr(a0), N=N, C=Cin, H=H, W=W, cout=F)))
+        plan.head_args = L.HeadFwdArgs(x=_ptr(plan.x_in), w=_ptr(spec.head.weight), b=_ptr(spec.head.bias),
+                                       out=_ptr(a0), N=N, C=Cin, H=H, W=W, cout=F)
+        fwd.append(('rumpy_head_fwd', plan.head_args))
 
         def emit_items(items, cur):
             """Emit forward ops for a chain of body items; returns (output buffer, backward node list).
@@ -347,6 +348,7 @@ class SREngine:
                             N=N, C=Cin, H=H, W=W, cout=F, scale=1.0)
         bwd.append(('rumpy_head_wgrad', a))
         plan.scaled.append(a)
+        plan.head_wgrad_args = a
 
         # ---- grouped weight gradients ----
         self._emit_wgrad(plan, wjobs, N)
@@ -453,18 +455,25 @@ class SREngine:
                 L.check(rc, name)
 
     def forward(self, x, train=False, target=None):
-        """x: [N,C,H,W] fp32 on the device.  Returns (out fp32 [N,C,sH,sW] (engine-owned buffer), loss tensor | None)."""
+        """x (and target): contiguous fp32 [N,C,H,W] on the device.  Returns (out fp32 [N,C,sH,sW], loss tensor | None, plan)."""
         N, _, H, W = x.shape
         plan = self.plan_for(N, H, W, train)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        plan.x_in.copy_(x, non_blocking=True)
+        # the head / tail kernels read the caller's fp32 NCHW tensors in place and write a fresh output tensor: no copies
+        plan.x_ref, plan.target_ref = x, target           # keep them alive until the backward pass has consumed them
+        plan.head_args.x = x.data_ptr()
+        if train:
+            plan.head_wgrad_args.x = x.data_ptr()
+        out = torch.empty_like(plan.out)
         self._run(plan.fwd, stream)
         if target is not None:
-            plan.target.copy_(target, non_blocking=True)
+            plan.tail_loss.out = out.data_ptr()
+            plan.tail_loss.target = target.data_ptr()
             L.call('rumpy_tail_fwd', plan.tail_loss, stream)
-            return plan.out, plan.loss, plan
+            return out, plan.loss, plan
+        plan.tail_plain.out = out.data_ptr()
         L.call('rumpy_tail_fwd', plan.tail_plain, stream)
-        return plan.out, None, plan
+        return out, None, plan
 
     def backward(self, plan, grad_scale, gout=None):
         """Run the backward pass of the last training forward of `plan`.  gout: optional upstream gradient
@@ -478,5 +487,6 @@ class SREngine:
         for mt in (4, 1):
             if mt in plan.job_dev:
                 dev, n = plan.job_dev[mt]
-                L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, stream), 'rumpy_wgrad_grouped')
+                variant = 1 if (mt == 1 and plan.HR[1] % 2) else 0     # dy4 pixel-pair DMA needs an even width
+                L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, variant, stream), 'rumpy_wgrad_grouped')
         L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')

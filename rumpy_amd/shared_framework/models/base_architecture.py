@@ -234,7 +234,7 @@ class BaseModel(nn.Module):
             loss = self.find_loss(out, y)
             self.standard_update(loss, scheduler_skip=scheduler_skip)
         if keep_on_device:
-            return loss.detach().reshape(()).cpu().numpy(), out.detach().clone()
+            return loss.detach().reshape(()).cpu().numpy(), out.detach()
         return loss.detach().reshape(()).cpu().numpy(), out.detach().cpu()
 
     def run_eval(self, x, y=None, request_loss=False, tag=None, timing=False, keep_on_device=False, *args, **kwargs):
@@ -250,7 +250,6 @@ class BaseModel(nn.Module):
                 tic = time.perf_counter()
             if want_loss and self._fused_l1():
                 out, loss_t = self.net.l1_eval(x, y.to(device=dev))
-                out = out.clone()
             else:
                 out = self.run_model(x, image_names=tag, **kwargs)
                 loss_t = self.find_loss(out, y.to(device=dev)) if want_loss else None

@@ -82,7 +82,7 @@ def test_argument_validation_runs_without_a_gpu():
     lib = _lib.lib()
     assert lib.rumpy_conv3x3(_lib.ConvArgs(), None) == -1 and b'null' in lib.rumpy_last_error()
     assert lib.rumpy_adam_step(_lib.AdamArgs(), None) == -1
-    assert lib.rumpy_wgrad_grouped(None, 0, 4, None) == -1
+    assert lib.rumpy_wgrad_grouped(None, 0, 4, 0, None) == -1
     assert lib.rumpy_probe_begin(9, 1) == -1
 
 

@@ -218,8 +218,9 @@ def _wgrad_ref(x, gy, co, scale=1.0):
     return w.grad, b.grad
 
 
+@pytest.mark.parametrize('variant', [0, 1])
 @pytest.mark.parametrize('N,H,W,split', [(2, 12, 12, 1), (4, 16, 32, 2), (3, 9, 21, 3), (1, 48, 48, 1)])
-def test_wgrad_grouped_plain(N, H, W, split):
+def test_wgrad_grouped_plain(N, H, W, split, variant):
     gen = np.random.default_rng(17 + H)
     x, gy = _rand(gen, N, 64, H, W), _rand(gen, N, 64, H, W)
     xd, gd = nhwc(x), nhwc(gy)
@@ -229,7 +230,7 @@ def test_wgrad_grouped_plain(N, H, W, split):
     gw = torch.full((64, 64, 3, 3), float('nan'), device=DEV)
     gb = torch.full((64,), float('nan'), device=DEV)
     hip_wgrad(jobs, 4, [dict(first_job=0, njobs=len(jobs), co_count=64, co_mode=0, co_off=0, ci_total=64, ci_off=0,
-                             write_bias=1, scale=0.5)], gw, gb)
+                             write_bias=1, scale=0.5)], gw, gb, variant)
     rw, rb = _wgrad_ref(x, gy, 64, 0.5)
     assert_f32_close(gw, rw, 'wgrad 64x64', rel=1e-4)
     assert_f32_close(gb, rb, 'bgrad', rel=1e-4)
@@ -255,9 +256,10 @@ def test_wgrad_upsampler_unshuffle_view():
     assert_f32_close(gb, b.grad, 'bgrad upsampler', rel=1e-4)
 
 
-def test_wgrad_tail_dy4():
+@pytest.mark.parametrize('W,variant', [(20, 0), (20, 1), (23, 1), (34, 0)])
+def test_wgrad_tail_dy4(W, variant):
     gen = np.random.default_rng(19)
-    N, H, W, C = 2, 24, 20, 3
+    N, H, C = 2, 24, 3
     x = _rand(gen, N, 64, H, W)
     gy = torch.sign(_rand(gen, N, C, H, W))
     g4 = torch.zeros(N, H, W, 4, dtype=BF16)
@@ -266,7 +268,7 @@ def test_wgrad_tail_dy4():
     jobs = [dict(x=xd, dy=gd, n0=n, n1=n + 1, H=H, W=W, x_cstride=64, x_coff=0, dy_mode=2, dy_cstride=4, dy_coff=0) for n in range(N)]
     gw = torch.full((C, 64, 3, 3), float('nan'), device=DEV)
     gb = torch.full((C,), float('nan'), device=DEV)
-    hip_wgrad(jobs, 1, [dict(first_job=0, njobs=N, co_count=C, co_mode=0, co_off=0, ci_total=64, ci_off=0, write_bias=1, scale=1.0 / 7)], gw, gb)
+    hip_wgrad(jobs, 1, [dict(first_job=0, njobs=N, co_count=C, co_mode=0, co_off=0, ci_total=64, ci_off=0, write_bias=1, scale=1.0 / 7)], gw, gb, variant)
     rw, rb = _wgrad_ref(x, gy, C, 1.0 / 7)
     assert_f32_close(gw, rw, 'tail wgrad', rel=1e-4)
     assert_f32_close(gb, rb, 'tail bgrad', rel=1e-4)
