@@ -33,6 +33,16 @@ class ConvArgs(_S):
                 ('grid_x', c_int32)]
 
 
+class ChainLayer(_S):
+    _fields_ = [('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('mask', c_void_p), ('res1', c_void_p),
+                ('res2', c_void_p), ('relu', c_int32), ('scale', c_float)]
+
+
+class ChainArgs(_S):
+    _fields_ = [('x', c_void_p), ('layers', c_void_p), ('nlayers', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32),
+                ('xchg', c_void_p), ('flags', c_void_p), ('status', c_void_p), ('stamps', c_void_p)]
+
+
 class HeadFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('b', c_void_p), ('out', c_void_p),
                 ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32)]
@@ -130,6 +140,8 @@ SYMBOLS = {
     'rumpy_conv3x3': (C.c_int, [_P(ConvArgs), c_void_p]),
     'rumpy_conv_pool_tiles': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_debug_conv_stamps': (C.c_int, [_P(ConvArgs), c_void_p]),
+    'rumpy_conv_chain': (C.c_int, [_P(ChainArgs), c_void_p]),
+    'rumpy_conv_chain_xchg_elems': (c_int64, [c_int32]),
     'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
     'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),

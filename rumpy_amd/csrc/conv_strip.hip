@@ -82,7 +82,8 @@ __device__ __forceinline__ void strip_write(const uint4 (&R)[SREGS], unsigned ch
 
 // STAMP = true is a diagnostic build: lane 0 of every wave writes s_memrealtime (100 MHz) stamps at the phase
 // boundaries of its FIRST strip into a.pool (reinterpreted as u64 [workgroup][wave][8]); never used by the product.
-template <int CHUNKS, bool STAMP>
+// DBG (diagnostic builds only): 1 = MFMAs without the LDS fragment reads, 2 = LDS fragment reads without the MFMAs
+template <int CHUNKS, bool STAMP, int DBG = 0>
 __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SSTAGE];
   unsigned long long stamps[8];
@@ -126,8 +127,14 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
 
   for (; strip < nstrips; strip += gridDim.x) {
     const StripCoord sc = decode_strip(strip, a.sx_n, a.sy_n);
-    unsigned off[3][3];
-    uint2 P0[3][3], P1[3][3];
+    // Epilogue geometry.  The MFMA leaves 4 channels x 1 pixel per lane (8 B); stores that narrow are issue-bound, so tiles
+    // are processed in PAIRS (X, Y): lanes with even g trade their Y values for the neighbour lane's (g+1) X values
+    // (one __shfl_xor(.,16) per dword) and end up with 8 consecutive channels of X's pixel, odd-g lanes with 8 channels
+    // of Y's pixel -> every global access of the epilogue is a 16-byte vector.  4 pairs + 1 single tile per wave:
+    //   pair k<3: X = (row k, col tile 0), Y = (row k, col tile 1); pair 3: X = (0, 2), Y = (1, 2); single: (2, 2).
+    unsigned poff[4], soff;
+    uint4 P0p[4], P1p[4];
+    uint2 P0s, P1s;
     f32x4 acc[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -144,43 +151,65 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
       has_next = nstrip < nstrips;
       if (has_next) strip_issue<CHUNKS>(R, a.x, a.in_mode, nch, decode_strip(nstrip, a.sx_n, a.sy_n), a.H, a.W, tid);
       if (ch == CHUNKS - 1) {
-        // element offsets of this lane's 9 output vectors (rows 3*rh .. 3*rh+2) + epilogue operands
+        // element offsets (0xffffffff = outside the image) + prefetch of the mask / residual vectors
+        auto pix_off = [&](int r, int c) -> unsigned {
+          const int y = sc.sy * SH + 3 * rh + r, xx = sc.sx * SW + 16 * c + px;
+          if (y >= a.H || xx >= a.W) return 0xffffffffu;
+          if (a.out_mode == 0) return (unsigned)(((sc.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + 16 * q);
+          return (unsigned)(((sc.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + 16 * q);
+        };
+        const int gpair = 4 * (g & ~1);                    // first of this lane's 8 channels inside the wave's 16
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int y = sc.sy * SH + 3 * rh + r;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const int xx = sc.sx * SW + 16 * c + px;
-            unsigned o = 0xffffffffu;
-            if (y < a.H && xx < a.W) {
-              if (a.out_mode == 0) o = (unsigned)(((sc.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + c0);
-              else o = (unsigned)(((sc.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + c0);
-            }
-            off[r][c] = o;
-            const unsigned oc = (o != 0xffffffffu) ? o : 0u;   // clamped: the prefetch loads are unconditional
-            P0[r][c] = make_uint2(0, 0); P1[r][c] = make_uint2(0, 0);
-            if (p0) P0[r][c] = *reinterpret_cast<const uint2*>(p0 + oc);
-            if (p1) P1[r][c] = *reinterpret_cast<const uint2*>(p1 + oc);
-          }
+        for (int k = 0; k < 4; ++k) {
+          const unsigned ox = (k < 3) ? pix_off(k, 0) : pix_off(0, 2);
+          const unsigned oy = (k < 3) ? pix_off(k, 1) : pix_off(1, 2);
+          const unsigned o = (g & 1) ? oy : ox;
+          poff[k] = (o != 0xffffffffu) ? o + gpair : 0xffffffffu;
+          const unsigned oc = (o != 0xffffffffu) ? o + gpair : 0u;   // clamped: the prefetch loads are unconditional
+          P0p[k] = make_uint4(0, 0, 0, 0); P1p[k] = make_uint4(0, 0, 0, 0);
+          if (p0) P0p[k] = *reinterpret_cast<const uint4*>(p0 + oc);
+          if (p1) P1p[k] = *reinterpret_cast<const uint4*>(p1 + oc);
+        }
+        {
+          const unsigned o = pix_off(2, 2);
+          soff = (o != 0xffffffffu) ? o + 4 * g : 0xffffffffu;
+          const unsigned oc = (o != 0xffffffffu) ? o + 4 * g : 0u;
+          P0s = make_uint2(0, 0); P1s = make_uint2(0, 0);
+          if (p0) P0s = *reinterpret_cast<const uint2*>(p0 + oc);
+          if (p1) P1s = *reinterpret_cast<const uint2*>(p1 + oc);
         }
       }
       stage = lds + buf * SSTAGE;
+      {
+        // 18 groups (channel half, tap column, column tile) of 5 B-fragment reads + 9 MFMAs, software pipelined: the
+        // reads of group i+1 are issued before the MFMAs of group i (two fragment sets), so LDS and the matrix pipe
+        // overlap inside one wave instead of alternating (measured: 2.1 us of reads + 2.3 us of MFMAs otherwise add up)
+        const unsigned char* wbase = stage + (3 * rh * SCOLS + px) * HSTRIDE + g * 16;
+        bf16x8 I[2][5];
+        auto load_group = [&](int grp, bf16x8 (&dst)[5]) {
+          const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+          const unsigned char* cur = wbase + half * HHALF + (16 * c + kx) * HSTRIDE;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const unsigned char* cur = stage + half * HHALF + (3 * rh * SCOLS + px) * HSTRIDE + g * 16;
+          for (int r = 0; r < 5; ++r) {
+            if (DBG == 1) dst[r] = F[r];
+            else dst[r] = *reinterpret_cast<const bf16x8*>(cur + r * SCOLS * HSTRIDE);
+          }
+        };
+        load_group(0, I[0]);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int grp = 0; grp < 18; ++grp) {
+          if (grp + 1 < 18) load_group(grp + 1, I[(grp + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads AHEAD of this group's MFMAs (hipcc sinks them otherwise)
+          const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+          if (DBG == 2) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            bf16x8 I[5];
-#pragma unroll
-            for (int r = 0; r < 5; ++r)
-              I[r] = *reinterpret_cast<const bf16x8*>(cur + (r * SCOLS + 16 * c + kx) * HSTRIDE);
+            for (int r = 0; r < 5; ++r) asm volatile("" :: "v"(I[grp & 1][r]));
+          } else {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
               for (int r = 0; r < 3; ++r)
-                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r][c], 0, 0, 0);
+                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
           }
         }
       }
@@ -196,63 +225,122 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
     }
     STAMP_HERE();                       // 3: MFMAs issued
     STAMP_HERE();                       // 4: (unused)
-    // ---- epilogue: lane holds channels c0..c0+3 of pixel (row 3rh + r, column 16c + px) ----
-    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- epilogue ----
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};              // single tile: channels 4g .. 4g+3 of this wave's 16
+    float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // paired tiles: channels 4(g&~1) .. +7
+    // per-value math on this lane's OWN 4 channels (bias is already in the accumulator)
+    auto own = [&](f32x4 t) -> f32x4 {
+      if (a.relu) {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+        for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], 0.f);
+      }
+      if (a.scale != 1.0f) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float v[4] = {acc[r][c][0], acc[r][c][1], acc[r][c][2], acc[r][c][3]};
-        if (a.relu) {
+        for (int j = 0; j < 4; ++j) t[j] *= a.scale;
+      }
+      return t;
+    };
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = own((k < 3) ? acc[k][0] : acc[0][2]);
+      const f32x4 ty = own((k < 3) ? acc[k][1] : acc[1][2]);
+      float v[8], m[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float send = (g & 1) ? tx[j] : ty[j];        // what the partner lane (g ^ 1) needs from me
+        const float recv = __shfl_xor(send, 16);
+        v[j] = (g & 1) ? recv : tx[j];                      // channels gpair .. gpair+3
+        v[4 + j] = (g & 1) ? ty[j] : recv;                  // channels gpair+4 .. gpair+7
+      }
+      const bool in = poff[k] != 0xffffffffu;
+      if (a.mask) {
+        unpack4_bf16(make_uint2(P0p[k].x, P0p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
+        unpack4_bf16(make_uint2(P0p[k].z, P0p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
+      }
+      if (a.pool && in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ps8[j] += v[j];
+      }
+      if (!a.mask && p0) {
+        unpack4_bf16(make_uint2(P0p[k].x, P0p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
+        unpack4_bf16(make_uint2(P0p[k].z, P0p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += m[j];
+      }
+      if (p1) {
+        unpack4_bf16(make_uint2(P1p[k].x, P1p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
+        unpack4_bf16(make_uint2(P1p[k].z, P1p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += m[j];
+      }
+      if (in) {
+        if (p2) {
+          const uint4 t = *reinterpret_cast<const uint4*>(p2 + poff[k]);
+          unpack4_bf16(make_uint2(t.x, t.y), *reinterpret_cast<float(*)[4]>(&m[0]));
+          unpack4_bf16(make_uint2(t.z, t.w), *reinterpret_cast<float(*)[4]>(&m[4]));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
-        if (a.scale != 1.0f) {
+        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<uint4*>(a.out + poff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
+    {   // the single unpaired tile (row 2, column tile 2): 8-byte path
+      const f32x4 t = own(acc[2][2]);
+      float v[4] = {t[0], t[1], t[2], t[3]};
+      float m[4];
+      if (a.mask) {
+        unpack4_bf16(P0s, m);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= a.scale;
-        }
-        float m[4];
-        if (a.mask) {
-          unpack4_bf16(P0[r][c], m);
+        for (int j = 0; j < 4; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
+      }
+      if (a.pool && soff != 0xffffffffu) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
-        }
-        if (a.pool) {
-          const bool in = off[r][c] != 0xffffffffu;
+        for (int j = 0; j < 4; ++j) ps[j] += v[j];
+      }
+      if (!a.mask && p0) {
+        unpack4_bf16(P0s, m);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) ps[j] += in ? v[j] : 0.f;
-        }
-        if (!a.mask && p0) {   // P0 = res1
-          unpack4_bf16(P0[r][c], m);
+        for (int j = 0; j < 4; ++j) v[j] += m[j];
+      }
+      if (p1) {
+        unpack4_bf16(P1s, m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += m[j];
+      }
+      if (soff != 0xffffffffu) {
+        if (p2) {
+          unpack4_bf16(*reinterpret_cast<const uint2*>(p2 + soff), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
-        if (p1) {              // P1 = res1 (with mask) or res2
-          unpack4_bf16(P1[r][c], m);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += m[j];
-        }
-        if (off[r][c] != 0xffffffffu) {
-          if (p2) {
-            unpack4_bf16(*reinterpret_cast<const uint2*>(p2 + off[r][c]), m);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += m[j];
-          }
-          *reinterpret_cast<uint2*>(a.out + off[r][c]) = pack4_bf16(v[0], v[1], v[2], v[3]);
-        }
+        *reinterpret_cast<uint2*>(a.out + soff) = pack4_bf16(v[0], v[1], v[2], v[3]);
       }
     }
     if (a.pool && !STAMP) {
-      // per-(strip, row half) channel sums: pool[n][(2*sy + rh) * sx_n + sx][channel]
+      // per-(strip, row half) channel sums: pool[n][(2*sy + rh) * sx_n + sx][channel]; reduce over the 16 pixel lanes,
+      // fold the odd-g lanes (other pixels, same 8 channels) into the even ones, add the single tile's 4+4 channels
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = ps8[j];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        t += __shfl_xor(t, 16);
+        ps8[j] = t;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float s = ps[j];
-        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        ps[j] = s;
+        float t = ps[j];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        const float up = __shfl_xor(t, 16);             // the same sums of lane group g ^ 1
+        ps8[j] += (g & 1) ? up : t;                      // channels 4(g&~1) + j     belong to the even group
+        ps8[4 + j] += (g & 1) ? t : up;                  // channels 4(g&~1) + 4 + j belong to the odd group
       }
-      if (px == 0) {
-        float* pp = a.pool + ((size_t)(sc.n * a.sy_n * 2 + 2 * sc.sy + rh) * a.sx_n + sc.sx) * (64 * a.cout_tiles) + ct * 64 + c0;
-        *reinterpret_cast<float4*>(pp) = make_float4(ps[0], ps[1], ps[2], ps[3]);
+      if (px == 0 && !(g & 1)) {
+        float* pp = a.pool + ((size_t)(sc.n * a.sy_n * 2 + 2 * sc.sy + rh) * a.sx_n + sc.sx) * (64 * a.cout_tiles) + ct * 64 + 16 * q + 4 * g;
+        *reinterpret_cast<float4*>(pp) = make_float4(ps8[0], ps8[1], ps8[2], ps8[3]);
+        *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
       }
     }
     if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
@@ -289,9 +377,12 @@ int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s) {
     gx = cdiv(nstrips, rounds);
   }
   if (gx > nstrips) gx = nstrips;
-  if (p->relu == 0x5754) {   // diagnostic stamp build (rumpy_debug_conv_stamps)
+  if (p->relu >= 0x5754 && p->relu <= 0x5756) {   // diagnostic stamp builds (rumpy_debug_conv_stamps)
+    const int dbg = p->relu - 0x5754;
     d.relu = 0;
-    hipLaunchKernelGGL((conv3x3_strip_kernel<1, true>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
+    if (dbg == 0) hipLaunchKernelGGL((conv3x3_strip_kernel<1, true, 0>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
+    else if (dbg == 1) hipLaunchKernelGGL((conv3x3_strip_kernel<1, true, 1>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
+    else hipLaunchKernelGGL((conv3x3_strip_kernel<1, true, 2>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
   } else if (p->cin_chunks == 1) {
     hipLaunchKernelGGL((conv3x3_strip_kernel<1, false>), dim3(gx, p->cout_tiles), dim3(STHREADS), 0, s, d);
   } else {
@@ -304,7 +395,7 @@ int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s) {
 extern "C" int rumpy_debug_conv_stamps(const rumpy_conv_args* p, void* stream) {
   if (!p || !p->pool || p->cin_chunks != 1 || p->cout_tiles != 1 || p->grid_x <= 0) { rumpy_set_error("rumpy_debug_conv_stamps: bad argument"); return RUMPY_E_ARG; }
   rumpy_conv_args q = *p;
-  q.relu = 0x5754;
+  q.relu = 0x5754 + ((p->relu >= 1 && p->relu <= 2) ? p->relu : 0);   // relu field selects the ablation (0, 1, 2)
   rumpy_conv3x3_strip_launch(&q, (hipStream_t)stream);
   return rumpy_check_launch("rumpy_debug_conv_stamps");
 }

@@ -383,3 +383,74 @@ def test_wgrad_jobs_split_by_tile_subranges():
     rw, rb = _wgrad_ref(x, gy, 64, 1.0)
     assert_f32_close(gw, rw, 'wgrad tile sub-ranges', rel=1e-4)
     assert_f32_close(gb, rb, 'bgrad tile sub-ranges', rel=1e-4)
+
+
+def _chain_reference_and_run(N, H, W, nlayers, seed):
+    """Run a chain of 64->64 convs (alternating ResBlock-style epilogues) once through rumpy_conv_chain and once layer by
+    layer through rumpy_conv3x3; returns the two lists of outputs."""
+    gen = np.random.default_rng(seed)
+    x = nhwc(_rand(gen, N, 64, H, W))
+    extra_res = nhwc(_rand(gen, N, 64, H, W))
+    mask_t = nhwc(_rand(gen, N, 64, H, W))
+    pcs = [PackedConv(*_wb(gen, 64, 64)) for _ in range(nlayers)]
+    outs_ref, cfgs = [], []
+    cur = x
+    for l in range(nlayers):
+        kind = l % 4
+        if kind == 0:
+            cfg = dict(relu=True)                                   # ResBlock conv1
+        elif kind == 1:
+            cfg = dict(scale=0.1, res1=(outs_ref[l - 2] if l >= 2 else x))   # ResBlock conv2: + block input
+        elif kind == 2:
+            cfg = dict(use_bias=False, scale=0.1, mask=mask_t)      # data-gradient style
+        else:
+            cfg = dict(use_bias=False, res1=outs_ref[l - 2], res2=extra_res)
+        o, _ = hip_conv(cur, pcs[l], N, H, W, **cfg)
+        outs_ref.append(o)
+        cfgs.append(cfg)
+        cur = o
+    # chain launch writing into fresh buffers; residual sources must be the CHAIN's own earlier outputs
+    outs = [torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(nlayers)]
+    layers = []
+    p = lambda t: None if t is None else t.data_ptr()
+    for l, cfg in enumerate(cfgs):
+        def remap(t):
+            if t is None:
+                return None
+            for k, r in enumerate(outs_ref):
+                if t is r:
+                    return outs[k]
+            return t
+        use_bias = cfg.get('use_bias', True)
+        layers.append(L.ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=(pcs[l].b_packed.data_ptr() if use_bias else None),
+                                   out=outs[l].data_ptr(), mask=p(remap(cfg.get('mask'))), res1=p(remap(cfg.get('res1'))),
+                                   res2=p(remap(cfg.get('res2'))), relu=1 if cfg.get('relu') else 0, scale=float(cfg.get('scale', 1.0))))
+    ldev = to_dev_bytes((L.ChainLayer * nlayers)(*layers))
+    nstrips = N * ((H + 5) // 6)
+    xchg = torch.zeros(int(L.lib().rumpy_conv_chain_xchg_elems(nstrips)), dtype=BF16, device=DEV)
+    flags = torch.full((nstrips,), 12345, dtype=torch.int32, device=DEV)     # the call must re-initialise them
+    status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W, xchg=xchg.data_ptr(),
+                    flags=flags.data_ptr(), status=status.data_ptr())
+    for _ in range(2):                                                       # twice: state is re-initialised per call
+        L.call('rumpy_conv_chain', a, stream())
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
+    return outs_ref, outs
+
+
+@pytest.mark.parametrize('N,H,W,nlayers', [(1, 6, 16, 2), (2, 12, 48, 5), (3, 20, 37, 8), (32, 48, 48, 33)])
+def test_conv_chain_matches_layer_by_layer(N, H, W, nlayers):
+    ref, got = _chain_reference_and_run(N, H, W, nlayers, 31 + H)
+    for l, (r, g) in enumerate(zip(ref, got)):
+        assert torch.isfinite(g.float()).all(), l
+        # same bf16 operands, same fp32 products; only the order of the halo-row term in the sum differs
+        assert_bf16_close(g.float(), r.float(), 'chain layer %d' % l, rel=2e-3 * (1 + l), amax=2.0 ** -6 * (1 + l))
+
+
+def test_conv_chain_rejects_shapes_that_cannot_be_resident():
+    t = torch.zeros(64, dtype=BF16, device=DEV)
+    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=1, H=6, W=49, xchg=t.data_ptr(), flags=t.data_ptr(), status=t.data_ptr())
+    assert L.lib().rumpy_conv_chain(a, None) == -1
+    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, xchg=t.data_ptr(), flags=t.data_ptr(), status=t.data_ptr())
+    assert L.lib().rumpy_conv_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()

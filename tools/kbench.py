@@ -65,17 +65,73 @@ def conv_stamps(N=32, H=48, W=48):
     dbg = torch.zeros(gx * 8 * 8, dtype=torch.int64, device=DEV)
     a = L.ConvArgs(x=x.data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b_packed.data_ptr(), out=out.data_ptr(), res1=res.data_ptr(),
                    pool=dbg.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1, scale=0.1, grid_x=gx)
-    for _ in range(3):
-        L.call('rumpy_debug_conv_stamps', a, stream())
-    torch.cuda.synchronize()
-    d = dbg.cpu().numpy().reshape(gx, 8, 8).astype(np.float64)
-    t0 = d[:, :, 0].min()
-    rel = (d - t0) * 10.0 / 1000.0    # us
-    names = ['start', 'loads issued', 'stage in LDS', 'mfma issued', 'K halves exchanged', 'epilogue+barrier', '-', '-']
-    for i in range(6):
-        v = rel[:, :, i]
-        print('stamp %d %-18s median %6.2f us  min %6.2f  max %6.2f' % (i, names[i], np.median(v), v.min(), v.max()))
+    for variant in (0, 1, 2):
+        a.relu = variant
+        for _ in range(3):
+            L.call('rumpy_debug_conv_stamps', a, stream())
+        torch.cuda.synchronize()
+        d = dbg.cpu().numpy().reshape(gx, 8, 8).astype(np.float64)
+        t0 = d[:, :, 0].min()
+        rel = (d - t0) * 10.0 / 1000.0    # us
+        names = ['start', 'loads issued', 'stage in LDS', 'mfma issued', '-', 'epilogue+barrier', '-', '-']
+        print('variant %d (0 = product code, 1 = MFMAs without LDS reads, 2 = LDS reads without MFMAs)' % variant)
+        for i in (2, 3, 5):
+            v = rel[:, :, i]
+            print('  stamp %d %-18s median %6.2f us  min %6.2f  max %6.2f' % (i, names[i], np.median(v), v.min(), v.max()))
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'stamps':
     conv_stamps()
+
+
+def chain_bench(N=32, H=48, W=48, nlayers=33):
+    gen = np.random.default_rng(0)
+    x = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    pcs = [PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32)), torch.zeros(64)) for _ in range(nlayers)]
+    outs = [torch.empty(N, H, W, 64, dtype=BF16, device=DEV) for _ in range(nlayers)]
+    layers = []
+    for l in range(nlayers):
+        res = (outs[l - 2] if l >= 2 else x) if (l % 2 == 1) else None
+        layers.append(L.ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=pcs[l].b_packed.data_ptr(), out=outs[l].data_ptr(),
+                                   res1=(res.data_ptr() if res is not None else None), relu=1 if l % 2 == 0 else 0,
+                                   scale=1.0 if l % 2 == 0 else 0.1))
+    ldev = to_dev_bytes((L.ChainLayer * nlayers)(*layers))
+    nstrips = N * ((H + 5) // 6)
+    xchg = torch.zeros(int(L.lib().rumpy_conv_chain_xchg_elems(nstrips)), dtype=BF16, device=DEV)
+    flags = torch.zeros(nstrips, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W, xchg=xchg.data_ptr(),
+                    flags=flags.data_ptr(), status=status.data_ptr())
+    us = time_fn(lambda: L.call('rumpy_conv_chain', a, stream()), iters=20)
+    st = torch.zeros(nstrips * 8 * 8 * 8, dtype=torch.int64, device=DEV)
+    a.stamps = st.data_ptr()
+    L.call('rumpy_conv_chain', a, stream())
+    torch.cuda.synchronize()
+    a.stamps = None
+    d = st.cpu().numpy().reshape(nstrips, 8, 8, 8).astype(np.float64)
+    t0 = d[:, :, 0, 0].min()
+    names = ['layer start', 'A1 + publish', 'A2 done', 'halo in regs', 'mid barrier', 'B done', 'epilogue issued', 'end barrier']
+    for l in (0, 1, 2, 5):
+        for kk in range(8):
+            v = (d[:, :, l, kk] - t0) / 100.0
+            v = v[d[:, :, l, kk] > 0]
+            if v.size:
+                print('layer %d %-16s median %7.2f us  min %7.2f  max %7.2f' % (l, names[kk], np.median(v), v.min(), v.max()))
+    flop = 2.0 * N * H * W * 64 * 576 * nlayers
+    print('chain of %d layers: %8.1f us  = %6.2f us/layer  %6.1f TFLOP/s  status %d' % (nlayers, us, us / nlayers, flop / us / 1e6, int(status.item())))
+
+    def per_layer():
+        cur = x
+        for l in range(nlayers):
+            res = (outs[l - 2] if l >= 2 else x) if (l % 2 == 1) else None
+            aa = L.ConvArgs(x=cur.data_ptr(), w=pcs[l].w_fwd.data_ptr(), bias=pcs[l].b_packed.data_ptr(), out=outs[l].data_ptr(),
+                            res1=(res.data_ptr() if res is not None else None), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1,
+                            relu=1 if l % 2 == 0 else 0, scale=1.0 if l % 2 == 0 else 0.1, grid_x=0)
+            L.call('rumpy_conv3x3', aa, stream())
+            cur = outs[l]
+    us2 = time_fn(per_layer, iters=20)
+    print('same %d layers, one launch each: %8.1f us = %6.2f us/layer' % (nlayers, us2, us2 / nlayers))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'chain':
+    chain_bench()
