@@ -105,6 +105,7 @@ def main():
         import ctypes
         lib = L.lib()
         per_step = 4 * 16 + 2          # 64->64 launches per step: 33 forward + 33 data-gradient (body convs)
+        h.net.use_graph = False          # the probe records events around eager launches (a graph replay has none)
         lib.rumpy_probe_begin(1, per_step * args.probe_steps + 8)
         for i in range(args.probe_steps):
             step(i)

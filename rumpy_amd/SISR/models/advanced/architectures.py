@@ -11,6 +11,7 @@ All parameters live in ONE flat fp32 HBM buffer (``flat_p``; gradients in ``flat
 view, so the fused Adam kernel and the gradient all-reduce see one contiguous tensor.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -97,6 +98,9 @@ class HipSRNet(nn.Module):
     def _finalize(self):
         self.param_list = list(self.parameters())
         self.flat_p = self.flat_g = None
+        # RUMPY_GRAPH=1 replays the fused training pass as a captured hipGraph.  Off by default: measured on MI355X the
+        # step is GPU-bound (dependent kernel boundaries), eager launches keep up and a replay gains nothing (1.99 vs 2.03 ms)
+        self.use_graph = os.environ.get('RUMPY_GRAPH') == '1'
         self.engine = None
         self._packed_version = None
         self._flatten()
@@ -175,9 +179,13 @@ class HipSRNet(nn.Module):
         return sum(p._version for p in self.param_list)
 
     def mark_weights_updated(self):
-        """Called by the fused optimizer after it rewrote flat_p behind torch's back."""
+        """Called after flat_p was rewritten behind torch's back: re-pack the bf16 filter images."""
         self._ensure_engine()
         self.engine.repack()
+        self._packed_version = self._weights_version()
+
+    def mark_weights_clean(self):
+        """The fused optimizer has already re-packed (inside its own launch list / graph)."""
         self._packed_version = self._weights_version()
 
     def engine_forward(self, x, train, target=None):
@@ -196,6 +204,10 @@ class HipSRNet(nn.Module):
     def fused_l1_forward_backward(self, x, y):
         """forward + nn.L1Loss + full backward in one pass (base_architecture.py:474-480 minus the optimizer).
         Returns (loss device scalar, out).  Gradients land in flat_g / p.grad."""
+        if self.use_graph:
+            self._ensure_engine()
+            out, loss, _ = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous())
+            return loss, out
         out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous())
         self.engine.backward(plan, 1.0 / out.numel())
         return loss, out

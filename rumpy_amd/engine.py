@@ -490,3 +490,49 @@ class SREngine:
                 variant = 1 if (mt == 1 and plan.HR[1] % 2) else 0     # dy4 pixel-pair DMA needs an even width
                 L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, variant, stream), 'rumpy_wgrad_grouped')
         L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')
+
+    # ------------------------------------------------------------------ hipGraph replay of the fused L1 training pass
+    def train_pass_graphed(self, x, target):
+        """forward + L1 + full backward of one batch as ONE captured hipGraph (the per-step launch list is static):
+        ~150 kernel launches collapse into a graph replay, which removes the host launch gaps between the short
+        per-layer kernels.  Inputs are copied into the plan's static buffers; the returned `out` / `loss` tensors are
+        the plan's static buffers (valid until the next call).  Returns (out, loss, plan)."""
+        N, _, H, W = x.shape
+        plan = self.plan_for(N, H, W, True)
+        cur = torch.cuda.current_stream(self.device)
+        if getattr(plan, 'graph', None) is None:
+            self._set_grad_scale(plan, 1.0 / plan.out.numel())
+            plan.head_args.x = plan.x_in.data_ptr()
+            plan.head_wgrad_args.x = plan.x_in.data_ptr()
+            plan.tail_loss.out = plan.out.data_ptr()
+            plan.tail_loss.target = plan.target.data_ptr()
+            plan.x_in.copy_(x)
+            plan.target.copy_(target)
+
+            def body(stream):
+                self._run(plan.fwd, stream)
+                L.call('rumpy_tail_fwd', plan.tail_loss, stream)
+                self._backward_launches(plan, stream)
+            side = torch.cuda.Stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):           # warm-up run outside capture (lazy initialisation, allocator)
+                body(side.cuda_stream)
+            cur.wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body(torch.cuda.current_stream(self.device).cuda_stream)
+            plan.graph = g
+        plan.x_in.copy_(x, non_blocking=True)
+        plan.target.copy_(target, non_blocking=True)
+        plan.graph.replay()
+        return plan.out, plan.loss, plan
+
+    def _backward_launches(self, plan, stream):
+        self._run(plan.bwd, stream)
+        for mt in (4, 1):
+            if mt in plan.job_dev:
+                dev, n = plan.job_dev[mt]
+                variant = 1 if (mt == 1 and plan.HR[1] % 2) else 0
+                L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, variant, stream), 'rumpy_wgrad_grouped')
+        L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')

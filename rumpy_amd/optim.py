@@ -30,6 +30,7 @@ class FlatAdam(torch.optim.Adam):
             self._hyper_host = self._hyper_host.pin_memory()
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sumsq_partial = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self._graphs = {}
         self._bind_state()
 
     def _bind_state(self):
@@ -83,14 +84,33 @@ class FlatAdam(torch.optim.Adam):
         h[6] = grad_mult
         h[7] = float(max_norm) if max_norm else 0.0
         self._hyper_dev.copy_(h, non_blocking=True)
-        stream = torch.cuda.current_stream(net.flat_p.device).cuda_stream
+        dev = net.flat_p.device
         n = net.flat_p.numel()
-        sumsq = None
-        if max_norm:
-            L.call('rumpy_sumsq', L.SumsqArgs(g=net.flat_g.data_ptr(), n=n, partial=self._sumsq_partial.data_ptr(),
-                                              out=self._sumsq.data_ptr()), stream)
-            sumsq = self._sumsq.data_ptr()
-        L.call('rumpy_adam_step', L.AdamArgs(p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(), m=self.flat_m.data_ptr(),
-                                             v=self.flat_v.data_ptr(), n=n, hyper=self._hyper_dev.data_ptr(), sumsq=sumsq), stream)
-        net.mark_weights_updated()
+
+        def launches(stream):
+            sumsq = None
+            if max_norm:
+                L.call('rumpy_sumsq', L.SumsqArgs(g=net.flat_g.data_ptr(), n=n, partial=self._sumsq_partial.data_ptr(),
+                                                  out=self._sumsq.data_ptr()), stream)
+                sumsq = self._sumsq.data_ptr()
+            L.call('rumpy_adam_step', L.AdamArgs(p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(), m=self.flat_m.data_ptr(),
+                                                 v=self.flat_v.data_ptr(), n=n, hyper=self._hyper_dev.data_ptr(), sumsq=sumsq), stream)
+            net.engine.repack(stream)
+
+        net._ensure_engine()
+        if not getattr(net, 'use_graph', False):
+            launches(torch.cuda.current_stream(dev).cuda_stream)
+            net.mark_weights_clean()
+            return None
+        # hyper-parameters live in device memory, so ONE captured graph (per clipping mode) serves every step
+        key = bool(max_norm)
+        if key not in self._graphs:
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launches(torch.cuda.current_stream(dev).cuda_stream)
+            self._graphs[key] = g
+            # capture does not execute: fall through to the replay below
+        self._graphs[key].replay()
+        net.mark_weights_clean()
         return None

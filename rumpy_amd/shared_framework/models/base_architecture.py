@@ -234,7 +234,9 @@ class BaseModel(nn.Module):
             loss = self.find_loss(out, y)
             self.standard_update(loss, scheduler_skip=scheduler_skip)
         if keep_on_device:
-            return loss.detach().reshape(()).cpu().numpy(), out.detach()
+            # in graph mode `out` is the plan's static buffer (rewritten by the next step): hand out a copy
+            keep = out.detach().clone() if getattr(self.net, 'use_graph', False) else out.detach()
+            return loss.detach().reshape(()).cpu().numpy(), keep
         return loss.detach().reshape(()).cpu().numpy(), out.detach().cpu()
 
     def run_eval(self, x, y=None, request_loss=False, tag=None, timing=False, keep_on_device=False, *args, **kwargs):

@@ -213,3 +213,16 @@ def test_full_size_properties_determinism_and_loss_directional_derivative():
     l2, _, = h.run_eval(x=x, y=y, request_loss=True)[1], None
     pred = l0 + d * float(gb.sum())
     assert abs(float(l2) - pred) < 0.02 * abs(d * float(gb.sum())) + 1e-6, (float(l2), pred, l0)
+
+
+def test_hipgraph_replay_gives_the_same_step_as_eager_launches():
+    h1, _ = _pair('edsr', 506, scale=4, num_blocks=2)
+    h2, _ = _pair('edsr', 506, scale=4, num_blocks=2)
+    h2.net.use_graph = True
+    for s in (650, 651, 652):
+        x, y = O.synthetic_batch(s, 2, lr_hw=24, scale=4)
+        l1, o1 = h1.run_train(x=x, y=y)
+        l2, o2 = h2.run_train(x=x, y=y)
+        assert float(l1) == float(l2) and torch.equal(o1, o2), s
+    for p, q in zip(h1.net.parameters(), h2.net.parameters()):
+        assert torch.equal(p.detach(), q.detach())
