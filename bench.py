@@ -22,6 +22,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, fwd + wgrad + dgrad
+HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+PMC_TRAFFIC_BYTES = 35.2e6           # FETCH_SIZE 21.9 MB + WRITE_SIZE 13.3 MB per launch
+PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv3x3_strip.md (separate rocprofv3 --pmc passes; launch with one residual operand)'
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
 
@@ -115,14 +118,33 @@ def main():
         if n_launch > 0:
             avg_s = tot.value * 1e-3 / n_launch
             flop = 2.0 * N * 48 * 48 * 64 * 576            # algorithmic FLOPs of one 64->64 3x3 launch
-            achieved = flop / avg_s / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'conv3x3_strip_kernel (3x3 conv 64->64, fwd + dgrad launches)',
-                        'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
-                        'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch,
-                        'algorithmic_gflop_per_launch': round(flop / 1e9, 3),
-                        'algorithmic_mb_per_launch': round(2 * N * 48 * 48 * 64 * 2 / 1e6, 3),
-                        'hbm_equiv_gbps': round(2 * N * 48 * 48 * 64 * 2 / avg_s / 1e9, 1)}
+            # algorithmic bytes of the same launches: every [N,48,48,64] bf16 tensor a launch must touch once (input, output,
+            # ReLU mask, residual operands), averaged over the step's 64->64 launches as the engine planned them
+            plan = h.net.engine.plan_for(N, 48, 48, True)
+            tensors = [2 + sum(1 for f in ('mask', 'res1', 'res2') if getattr(a, f))
+                       for name, a in plan.fwd + plan.bwd
+                       if name == 'rumpy_conv3x3' and a.cin_chunks == 1 and a.cout_tiles == 1 and a.out_mode == 0]
+            tensor_bytes = N * 48 * 48 * 64 * 2
+            alg_bytes = tensor_bytes * sum(tensors) / max(1, len(tensors))
+            t_mfma, t_hbm = flop / (MFMA_BF16_PEAK_TFLOPS * 1e12), alg_bytes / (HBM_PEAK_GBPS * 1e9)
+            tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
+            common = {'kernel': 'conv3x3_strip_kernel (3x3 conv 64->64, fwd + dgrad launches)',
+                      'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch, 'launches_per_step': len(tensors),
+                      'algorithmic_gflop_per_launch': round(flop / 1e9, 3), 'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
+                      'mfma': {'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)},
+                      'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}
+            # the launch sits at the ridge (C = 64): the binding roof is whichever limit takes longer for one launch
+            if t_hbm >= t_mfma:
+                roofline = {'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                            'frac': round(gbps / HBM_PEAK_GBPS, 4), 'traffic': None}
+            else:
+                roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None}
+            roofline.update(common)
+            # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
+            roofline['traffic'] = PMC_TRAFFIC_BYTES
+            roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
 
     # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1 only ----
     cpu = None

@@ -97,10 +97,9 @@ def chain_bench(N=32, H=48, W=48, nlayers=33):
                                    scale=1.0 if l % 2 == 0 else 0.1))
     ldev = to_dev_bytes((L.ChainLayer * nlayers)(*layers))
     nstrips = N * ((H + 5) // 6)
-    xchg = torch.zeros(int(L.lib().rumpy_conv_chain_xchg_elems(nstrips)), dtype=BF16, device=DEV)
     flags = torch.zeros(nstrips, dtype=torch.int32, device=DEV)
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
-    a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W, xchg=xchg.data_ptr(),
+    a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
                     flags=flags.data_ptr(), status=status.data_ptr())
     us = time_fn(lambda: L.call('rumpy_conv_chain', a, stream()), iters=20)
     st = torch.zeros(nstrips * 8 * 8 * 8, dtype=torch.int64, device=DEV)
