@@ -69,8 +69,8 @@ int rumpy_debug_conv_stamps(const rumpy_conv_args* a, void* stream);
 
 /* ---- layer-resident chain of 64->64 3x3 convs (EDSR body, forward or data-gradient direction) in one launch ----
  * Every layer has rumpy_conv3x3 semantics with cin_chunks = cout_tiles = 1; layer l+1's input is layer l's output, kept
- * in LDS by the workgroup that owns the strip; halo rows travel between vertical neighbours through the output tensors
- * themselves (edge rows are stored write-through).
+ * in LDS by the workgroup that owns the strip; halo rows travel between vertical neighbours through `xchg` as
+ * epoch-tagged 8-byte records (see conv_chain.hip).
  * Requirements: W <= 48 and N * ceil(H/6) <= rumpy_device_cus() (all strips co-resident), nothing else running on the GPU.
  * *status != 0 afterwards means a hand-off timed out (results invalid). */
 typedef struct {
@@ -88,11 +88,13 @@ typedef struct {
   const rumpy_chain_layer* layers;  /* DEVICE array */
   int32_t nlayers;
   int32_t N, H, W;
-  uint32_t* flags;                  /* N*ceil(H/6) words (zeroed by the call) */
+  void* xchg;                       /* rumpy_conv_chain_xchg_bytes(N*ceil(H/6)) bytes: zeroed ONCE by the caller when
+                                       allocated, then owned by the library (halo-row records + epoch header) */
   uint32_t* status;                 /* 1 word (zeroed by the call) */
   uint64_t* stamps;                 /* NULL, or diagnostics: [strip][wave 8][layer < 8][8] s_memrealtime stamps */
 } rumpy_chain_args;
 int rumpy_conv_chain(const rumpy_chain_args* a, void* stream);
+int64_t rumpy_conv_chain_xchg_bytes(int32_t nstrips);
 
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
  * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */

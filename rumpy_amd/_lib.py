@@ -40,7 +40,7 @@ class ChainLayer(_S):
 
 class ChainArgs(_S):
     _fields_ = [('x', c_void_p), ('layers', c_void_p), ('nlayers', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32),
-                ('flags', c_void_p), ('status', c_void_p), ('stamps', c_void_p)]
+                ('xchg', c_void_p), ('status', c_void_p), ('stamps', c_void_p)]
 
 
 class HeadFwdArgs(_S):
@@ -140,6 +140,7 @@ SYMBOLS = {
     'rumpy_conv3x3': (C.c_int, [_P(ConvArgs), c_void_p]),
     'rumpy_conv_pool_tiles': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_debug_conv_stamps': (C.c_int, [_P(ConvArgs), c_void_p]),
+    'rumpy_conv_chain_xchg_bytes': (c_int64, [c_int32]),
     'rumpy_conv_chain': (C.c_int, [_P(ChainArgs), c_void_p]),
     'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),

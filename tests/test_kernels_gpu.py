@@ -427,11 +427,13 @@ def _chain_reference_and_run(N, H, W, nlayers, seed):
                                    res2=p(remap(cfg.get('res2'))), relu=1 if cfg.get('relu') else 0, scale=float(cfg.get('scale', 1.0))))
     ldev = to_dev_bytes((L.ChainLayer * nlayers)(*layers))
     nstrips = N * ((H + 5) // 6)
-    flags = torch.full((nstrips,), 12345, dtype=torch.int32, device=DEV)     # the call must re-initialise them
+    xchg = torch.zeros(int(L.lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
     status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
     a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
-                    flags=flags.data_ptr(), status=status.data_ptr())
-    for _ in range(2):                                                       # twice: state is re-initialised per call
+                    xchg=xchg.data_ptr(), status=status.data_ptr())
+    for _ in range(3):                 # repeated launches on the same exchange buffer: the epoch base moves on every call
+        for o in outs:
+            o.fill_(float('nan'))
         L.call('rumpy_conv_chain', a, stream())
     torch.cuda.synchronize()
     assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
@@ -449,7 +451,7 @@ def test_conv_chain_matches_layer_by_layer(N, H, W, nlayers):
 
 def test_conv_chain_rejects_shapes_that_cannot_be_resident():
     t = torch.zeros(64, dtype=BF16, device=DEV)
-    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=1, H=6, W=49, flags=t.data_ptr(), status=t.data_ptr())
+    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
     assert L.lib().rumpy_conv_chain(a, None) == -1
-    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, flags=t.data_ptr(), status=t.data_ptr())
+    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
     assert L.lib().rumpy_conv_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()

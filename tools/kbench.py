@@ -97,10 +97,10 @@ def chain_bench(N=32, H=48, W=48, nlayers=33):
                                    scale=1.0 if l % 2 == 0 else 0.1))
     ldev = to_dev_bytes((L.ChainLayer * nlayers)(*layers))
     nstrips = N * ((H + 5) // 6)
-    flags = torch.zeros(nstrips, dtype=torch.int32, device=DEV)
+    xchg = torch.zeros(int(L.lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
-                    flags=flags.data_ptr(), status=status.data_ptr())
+                    xchg=xchg.data_ptr(), status=status.data_ptr())
     us = time_fn(lambda: L.call('rumpy_conv_chain', a, stream()), iters=20)
     st = torch.zeros(nstrips * 8 * 8 * 8, dtype=torch.int64, device=DEV)
     a.stamps = st.data_ptr()
@@ -109,7 +109,7 @@ def chain_bench(N=32, H=48, W=48, nlayers=33):
     a.stamps = None
     d = st.cpu().numpy().reshape(nstrips, 8, 8, 8).astype(np.float64)
     t0 = d[:, :, 0, 0].min()
-    names = ['layer start', 'A1 + publish', 'A2 done', 'halo in regs', 'mid barrier', 'B done', 'epilogue issued', 'end barrier']
+    names = ['layer start', 'A done', 'early epilogue', 'halo in LDS', 'mid barrier', 'B done', 'late epilogue', 'end barrier']
     for l in (0, 1, 2, 5):
         for kk in range(8):
             v = (d[:, :, l, kk] - t0) / 100.0
