@@ -57,21 +57,20 @@ __device__ __forceinline__ TileCoord decode_tile(int tile, int tiles_x, int tile
 // (PixelShuffle^T gather: logical pixel (y,x) lives at (2y + q/2, 2x + q%2)).  Out-of-image pixels read as zero.
 __device__ __forceinline__ void halo_issue(uint4 (&R)[6], const uint16_t* __restrict__ src, int mode, int cstride,
                                            int coff, int n, int ty, int tx, int H, int W, int tid) {
+  // Branch-free: every lane loads from a clamped in-bounds address and the result is zeroed afterwards, so the six loads
+  // issue back to back on every path (no exec-mask regions) and callers' s_waitcnt values stay counted.
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int p = tid + 256 * i;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (p < HALO_PIX * 8) {
-      const int pix = p >> 3, part = p & 7;
-      const int r = pix / HALO_W, c = pix - r * HALO_W;
-      const int y = ty * TH + r - 1, x = tx * TW + c - 1;
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        size_t e;
-        if (mode == 0) e = ((size_t)(n * H + y) * W + x) * cstride + coff + part * 8;
-        else e = ((size_t)(n * 2 * H + 2 * y + (coff >> 1)) * (2 * W) + 2 * x + (coff & 1)) * 64 + part * 8;
-        v = *reinterpret_cast<const uint4*>(src + e);
-      }
-    }
+    const int pix = p >> 3, part = p & 7;
+    const int r = pix / HALO_W, c = pix - r * HALO_W;
+    const int y = ty * TH + r - 1, x = tx * TW + c - 1;
+    const bool ok = (p < HALO_PIX * 8) & ((unsigned)y < (unsigned)H) & ((unsigned)x < (unsigned)W);
+    size_t e = 0;
+    if (mode == 0) e = ((size_t)(n * H + y) * W + x) * cstride + coff + part * 8;
+    else e = ((size_t)(n * 2 * H + 2 * y + (coff >> 1)) * (2 * W) + 2 * x + (coff & 1)) * 64 + part * 8;
+    uint4 v = *reinterpret_cast<const uint4*>(src + (ok ? e : (size_t)0));
+    if (!ok) v = make_uint4(0, 0, 0, 0);
     R[i] = v;
   }
 }

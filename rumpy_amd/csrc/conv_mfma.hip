@@ -19,6 +19,9 @@ struct ConvDev {
   int N, H, W, cout_tiles, in_mode, out_mode, relu; float scale; int tiles_x, tiles_y;
 };
 
+#ifndef CONV4_ABL
+#define CONV4_ABL 0     // timing experiments only (tools/build_abl.sh): results are wrong for any value but 0
+#endif
 template <int CHUNKS>
 __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(ConvDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
@@ -43,8 +46,13 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
     bj[0] = b4.x; bj[1] = b4.y; bj[2] = b4.z; bj[3] = b4.w;
   }
 
+  // Register-staged input pipeline (a stage = one 64-channel input chunk of one tile): while stage s is multiplied out of
+  // LDS, stage s+1 is in flight into registers.  The request is issued on every path (past the end: the current tile
+  // again, unused) so that the waits stay counted.  (Two stages deep measured no faster here and spills: with the whole
+  // 256-channel filter in registers - 288 of them - this kernel runs one wave per SIMD.)
   int tile = blockIdx.x;
   if (tile >= ntiles) return;
+  const int gstride = (int)gridDim.x;
   uint4 R[6];
   {
     const TileCoord t = decode_tile(tile, a.tiles_x, a.tiles_y);
@@ -54,7 +62,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
   __syncthreads();
   int buf = 0;
 
-  for (; tile < ntiles; tile += gridDim.x) {
+  for (; tile < ntiles; tile += gstride) {
     const TileCoord tc = decode_tile(tile, a.tiles_x, a.tiles_y);
     f32x4 acc[TH];
 #pragma unroll
@@ -62,30 +70,42 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
 
 #pragma unroll
     for (int ch = 0; ch < CHUNKS; ++ch) {
-      // prefetch the next stage (next chunk of this tile, or chunk 0 of the next tile)
-      const int ntile = (ch + 1 < CHUNKS) ? tile : tile + (int)gridDim.x;
-      const int nch = (ch + 1 < CHUNKS) ? ch + 1 : 0;
-      const bool has_next = ntile < ntiles;
-      if (has_next) {
+      {
+        const int ntile0 = (ch + 1 < CHUNKS) ? tile : tile + gstride;
+        const int nch = (ch + 1 < CHUNKS) ? ch + 1 : 0;
+        const int ntile = (ntile0 < ntiles) ? ntile0 : tile;
         const TileCoord tn = decode_tile(ntile, a.tiles_x, a.tiles_y);
-        halo_issue(R, a.x, a.in_mode, cstride, a.in_mode == 0 ? nch * 64 : nch, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
+        if (CONV4_ABL != 2) halo_issue(R, a.x, a.in_mode, cstride, a.in_mode == 0 ? nch * 64 : nch, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
       }
+      const bool has_next = (ch + 1 < CHUNKS) || (tile + gstride < ntiles);
       const unsigned char* cur = lds + buf * X_STAGE_BYTES;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          bf16x8 I[HALO_H];
+      {
+        // 6 groups (tap column, channel half) of 10 B-fragment reads + 24 MFMAs, software pipelined as in conv_strip.hip:
+        // the reads of group i+1 are issued before the MFMAs of group i (one wave per SIMD here: nothing else hides them)
+        bf16x8 I[2][HALO_H];
+        auto load_group = [&](int grp, bf16x8 (&dst)[HALO_H]) {
+          const int kx = grp >> 1, half = grp & 1;
 #pragma unroll
           for (int r = 0; r < HALO_H; ++r)
-            I[r] = *reinterpret_cast<const bf16x8*>(cur + (r * HALO_W + px + kx) * PIX_STRIDE + half * 64 + g * 16);
+            dst[r] = *reinterpret_cast<const bf16x8*>(cur + (r * HALO_W + px + kx) * PIX_STRIDE + half * 64 + g * 16);
+        };
+        load_group(0, I[0]);
+#pragma unroll
+        for (int grp = 0; grp < 6; ++grp) {
+          if (grp + 1 < 6) load_group(grp + 1, I[(grp + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          const int kx = grp >> 1, half = grp & 1;
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int r = 0; r < TH; ++r)
-              acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[r + ky], acc[r], 0, 0, 0);
+              if (CONV4_ABL != 1) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r], 0, 0, 0);
+              else asm volatile("" :: "v"(I[grp & 1][r + ky]));
         }
       }
+      // stage s+1 goes to the other LDS buffer BEFORE the epilogue's stores (a wait issued behind them would drain them)
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) halo_write(R, lds + (buf ^ 1) * X_STAGE_BYTES, tid);
       if (ch == CHUNKS - 1) {
         // ---- epilogue: lane holds channels c0..c0+3 of pixel (row r, column px) ----
         const int c0 = 16 * wave + 4 * g;
@@ -125,7 +145,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] += m[j];
             }
-            *reinterpret_cast<uint2*>(a.out + o) = pack4_bf16(v[0], v[1], v[2], v[3]);
+            if (CONV4_ABL != 3) *reinterpret_cast<uint2*>(a.out + o) = pack4_bf16(v[0], v[1], v[2], v[3]);
           }
         }
         if (a.pool) {
@@ -141,7 +161,6 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
           }
         }
       }
-      if (has_next) halo_write(R, lds + (buf ^ 1) * X_STAGE_BYTES, tid);
       __syncthreads();
       buf ^= 1;
     }
@@ -171,24 +190,47 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   for (int j = 0; j < a.C; ++j) bj[j] = a.bias[j];
   float lsum = 0.f;
 
+  // Register-staged input pipeline, TWO tiles deep: while tile t is multiplied out of LDS, tile t+1 sits in registers (its
+  // loads were issued one iteration ago) and the loads of tile t+2 are issued - every load has two iterations to land, so
+  // the kernel is no longer one HBM latency per tile (it reads 151 MB on the headline shape: a bandwidth kernel).
+  const int stride = (int)gridDim.x;
   int tile = blockIdx.x;
-  uint4 R[6];
+  uint4 R[2][6];
   if (tile < ntiles) {
     const TileCoord t = decode_tile(tile, a.tiles_x, a.tiles_y);
-    halo_issue(R, a.x, 0, 64, 0, t.n, t.ty, t.tx, a.H, a.W, tid);
-    halo_write(R, lds, tid);
+    halo_issue(R[0], a.x, 0, 64, 0, t.n, t.ty, t.tx, a.H, a.W, tid);
+    halo_write(R[0], lds, tid);
+  }
+  if (tile < ntiles) {
+    const TileCoord t = decode_tile((tile + stride < ntiles) ? tile + stride : tile, a.tiles_x, a.tiles_y);
+    halo_issue(R[1], a.x, 0, 64, 0, t.n, t.ty, t.tx, a.H, a.W, tid);
   }
   __syncthreads();
-  int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
-    const TileCoord tc = decode_tile(tile, a.tiles_x, a.tiles_y);
-    const int ntile = tile + (int)gridDim.x;
-    const bool has_next = ntile < ntiles;
-    if (has_next) {
-      const TileCoord tn = decode_tile(ntile, a.tiles_x, a.tiles_y);
-      halo_issue(R, a.x, 0, 64, 0, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
+  auto step = [&](int cur_tile, const unsigned char* cur, uint4 (&Rnext)[6], uint4 (&Rfar)[6], unsigned char* other) {
+    const TileCoord tc = decode_tile(cur_tile, a.tiles_x, a.tiles_y);
+    // Target values of this tile first (lanes 0..15 own the pixels; 4 bytes per channel plane), then the far tile's halo.
+    // Both groups are issued on EVERY path with clamped addresses (no target / outside the image / past the last tile:
+    // some valid address, value unused): a fixed number of loads per iteration lets the compiler wait with counted
+    // vmcnt values - the epilogue below used to drain the whole queue once per channel.
+    const int xx = tc.tx * TW + px;
+    const float* tsrc = a.target ? a.target : a.out;
+    float tg[2][4];
+    size_t obase[2];
+    bool inimg[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int y = tc.ty * TH + 2 * wave + r;
+      inimg[r] = (g == 0) && y < a.H && xx < a.W;
+      obase[r] = inimg[r] ? ((size_t)tc.n * a.C * a.H + y) * a.W + xx : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tg[r][j] = tsrc[(j < a.C) ? obase[r] + (size_t)j * a.H * a.W : 0];
     }
-    const unsigned char* cur = lds + buf * X_STAGE_BYTES;
+    __builtin_amdgcn_sched_barrier(0);      // targets first in the queue: they are waited for with vmcnt(6), under the far loads
+    const int far = (cur_tile + 2 * stride < ntiles) ? cur_tile + 2 * stride : cur_tile;
+    {
+      const TileCoord tn = decode_tile(far, a.tiles_x, a.tiles_y);
+      halo_issue(Rfar, a.x, 0, 64, 0, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
+    }
     f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
@@ -204,34 +246,48 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
           for (int r = 0; r < 2; ++r)
             acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r], 0, 0, 0);
       }
-    if (g == 0) {  // D rows 0..3 (= output channels) live in lanes 0..15
-      const int xx = tc.tx * TW + px;
+    // all target values are consumed BEFORE the first store: with loads and stores pending together the compiler's
+    // s_waitcnt bookkeeping (gfx9: one vmcnt, loads and stores may retire out of order) falls back to draining everything
+    float vout[2][4], dif[2][4];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int y = tc.ty * TH + 2 * wave + r;
-        if (y < a.H && xx < a.W) {
-          float sg[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < a.C) {
-              const size_t o = ((size_t)(tc.n * a.C + j) * a.H + y) * a.W + xx;
-              const float v = acc[r][j] + bj[j];
-              a.out[o] = v;
-              if (a.target) {
-                const float d = v - a.target[o];
-                lsum += fabsf(d);
-                sg[j] = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-              }
+      for (int j = 0; j < 4; ++j) {
+        vout[r][j] = acc[r][j] + bj[j];
+        dif[r][j] = vout[r][j] - tg[r][j];
+        asm volatile("" : "+v"(dif[r][j]));     // materialise here (the optimiser would sink it below the stores)
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile's registers go to the other LDS buffer here - after the MFMAs (its loads had the whole step to land)
+    // and before the stores (a wait issued behind them would have to drain them)
+    if (cur_tile + stride < ntiles) halo_write(Rnext, other, tid);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {   // D rows 0..3 (= output channels) live in lanes 0..15
+      if (inimg[r]) {
+        float sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < a.C) {
+            a.out[obase[r] + (size_t)j * a.H * a.W] = vout[r][j];
+            if (a.target) {
+              const float d = dif[r][j];
+              lsum += fabsf(d);
+              sg[j] = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
             }
           }
-          if (a.dy4)
-            *reinterpret_cast<uint2*>(a.dy4 + ((size_t)(tc.n * a.H + y) * a.W + xx) * 4) = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
+        }
+        if (a.dy4) {
+          const int y = tc.ty * TH + 2 * wave + r;
+          *reinterpret_cast<uint2*>(a.dy4 + ((size_t)(tc.n * a.H + y) * a.W + xx) * 4) = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
         }
       }
     }
-    if (has_next) halo_write(R, lds + (buf ^ 1) * X_STAGE_BYTES, tid);
     __syncthreads();
-    buf ^= 1;
+  };
+  for (; tile < ntiles; tile += 2 * stride) {
+    step(tile, lds, R[1], R[0], lds + X_STAGE_BYTES);
+    if (tile + stride < ntiles) step(tile + stride, lds + X_STAGE_BYTES, R[0], R[1], lds);
   }
   if (a.loss_partial) {
     float s = lsum;

@@ -4,24 +4,27 @@
 #include "common.hpp"
 
 constexpr int HEAD_MAXC = 4;
+// forward: one wave per workgroup - the headline shape has 73,728 pixels = 1152 waves = 4.5 per CU, which 256-thread
+// workgroups would hand out as 288 workgroups on 256 CUs (two rounds, the second almost empty)
+constexpr int HEAD_FWD_THREADS = 64;
 
 // one thread = one pixel x 64 output channels; weights transposed to [k = (c,ky,kx)][co] in LDS (broadcast reads)
 template <int C>
-__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, uint16_t* __restrict__ out,
                                                        int N, int H, int W, int cout) {
   __shared__ __attribute__((aligned(16))) float sw[9 * HEAD_MAXC * 64];
   __shared__ float sb[64];
   const int ct = blockIdx.y;
   constexpr int K = 9 * C;
-  for (int i = threadIdx.x; i < K * 64; i += 256) {
+  for (int i = threadIdx.x; i < K * 64; i += HEAD_FWD_THREADS) {
     const int k = i >> 6, co = i & 63;
     sw[i] = w[(size_t)(ct * 64 + co) * K + k];  // OIHW: [co][c][ky][kx] -> k = c*9 + ky*3 + kx
   }
   if (threadIdx.x < 64) sb[threadIdx.x] = b[ct * 64 + threadIdx.x];
   __syncthreads();
   const size_t total = (size_t)N * H * W;
-  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t p = (size_t)blockIdx.x * HEAD_FWD_THREADS + threadIdx.x;
   if (p >= total) return;
   const int xx = (int)(p % W);
   const int y = (int)((p / W) % H);
@@ -134,28 +137,38 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict
     s[e] = (red[e] + red[64 * KS + e]) + (red[2 * 64 * KS + e] + red[3 * 64 * KS + e]);
 }
 
-__global__ void head_wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int C, int cout, float scale,
-                                         float* __restrict__ gw, float* __restrict__ gb) {
+// Deterministic reduction of the per-workgroup slabs: 16 outputs x 16 slab parts per 256-thread block; part p adds slabs
+// p, p+16, p+32, .. in order (independent loads, in flight together), the 16 parts are added in a fixed order through LDS.
+__global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int C, int cout, float scale,
+                                                                float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float part[16][17];
   const int K = 9 * C;
   const int total = cout * (K + 1);
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int g = 0;
-  for (; g + 4 <= nwg; g += 4) {
-    s0 += slab[(size_t)g * total + e];
-    s1 += slab[(size_t)(g + 1) * total + e];
-    s2 += slab[(size_t)(g + 2) * total + e];
-    s3 += slab[(size_t)(g + 3) * total + e];
+  const int el = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + el;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < total) {
+    int g = p;
+    for (; g + 16 < nwg; g += 32) {
+      s0 += slab[(size_t)g * total + e];
+      s1 += slab[(size_t)(g + 16) * total + e];
+    }
+    if (g < nwg) s0 += slab[(size_t)g * total + e];
   }
-  for (; g < nwg; ++g) s0 += slab[(size_t)g * total + e];
-  const float s = (s0 + s1) + (s2 + s3);
-  const int co = e / (K + 1), k = e - co * (K + 1);
-  if (k < K) gw[(size_t)co * K + k] = s * scale;
-  else gb[co] = s * scale;
+  part[p][el] = s0 + s1;
+  __syncthreads();
+  if (p == 0 && e < total) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += part[i][el];
+    const int co = e / (K + 1), k = e - co * (K + 1);
+    if (k < K) gw[(size_t)co * K + k] = s * scale;
+    else gb[co] = s * scale;
+  }
 }
 
-static int head_wgrad_grid() { return 256; }
+// up to three workgroups per CU (46 KB of LDS each): their load / barrier / FMA phases overlap
+static int head_wgrad_grid() { return 3 * rumpy_device_cus(); }
 
 extern "C" int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout) {
   return (int64_t)head_wgrad_grid() * cout * (9 * C + 1);
@@ -166,14 +179,14 @@ extern "C" int rumpy_head_fwd(const rumpy_head_fwd_args* p, void* stream) {
   if (p->C < 1 || p->C > HEAD_MAXC || p->cout <= 0 || p->cout % 64 || p->N <= 0 || p->H <= 0 || p->W <= 0) {
     rumpy_set_error("rumpy_head_fwd: unsupported shape (C=%d cout=%d)", p->C, p->cout); return RUMPY_E_ARG; }
   const size_t total = (size_t)p->N * p->H * p->W;
-  dim3 grid((unsigned)((total + 255) / 256), p->cout / 64);
+  dim3 grid((unsigned)((total + HEAD_FWD_THREADS - 1) / HEAD_FWD_THREADS), p->cout / 64);
   hipStream_t s = (hipStream_t)stream;
   uint16_t* o = (uint16_t*)p->out;
   switch (p->C) {
-    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
-    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
-    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
-    default: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(256), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    default: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
   }
   return rumpy_check_launch("rumpy_head_fwd");
 }
@@ -182,12 +195,13 @@ extern "C" int rumpy_head_wgrad(const rumpy_head_wgrad_args* p, void* stream) {
   if (!p || !p->x || !p->dy || !p->slab || !p->gw || !p->gb) { rumpy_set_error("rumpy_head_wgrad: null pointer"); return RUMPY_E_ARG; }
   if (p->C < 1 || p->C > HEAD_MAXC || p->cout <= 0 || p->cout % 64 || p->N <= 0 || p->H <= 0 || p->W <= 0) {
     rumpy_set_error("rumpy_head_wgrad: unsupported shape"); return RUMPY_E_ARG; }
-  const int nwg = head_wgrad_grid();
+  const int ntiles = p->N * ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW);
+  const int nwg = ntiles < head_wgrad_grid() ? ntiles : head_wgrad_grid();
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(head_wgrad_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
                      p->N, p->C, p->H, p->W, p->cout);
   const int total = p->cout * (9 * p->C + 1);
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, p->slab, nwg, p->C, p->cout,
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, s, p->slab, nwg, p->C, p->cout,
                      p->scale, p->gw, p->gb);
   return rumpy_check_launch("rumpy_head_wgrad");
 }

@@ -67,28 +67,32 @@ __global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
   const int Co = it.cout, Ci = it.cin;
   if (it.kind == 0) {
     const int ctn = Co / 64, chn = Ci / 64;
-    const size_t total = (size_t)Co * Ci * 9;  // elements of each image
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-      const int e = (int)(i & 7);
-      const int lane = (int)((i >> 3) & 63);
-      size_t r2 = i >> 9;
+    const size_t total8 = (size_t)Co * Ci * 9 / 8;  // 16-byte vectors (8 consecutive K elements of one lane) of each image
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < total8; v += (size_t)gridDim.x * blockDim.x) {
+      const int lane = (int)(v & 63);
+      size_t r2 = v >> 6;
       const int s = (int)(r2 % 18); r2 /= 18;
       const int wave = (int)(r2 & 3); r2 >>= 2;
       const int r = lane & 15, g = lane >> 4;
       const int half = s & 1, tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
-      {  // forward: r2 = ct*chn + ch
+      {  // forward: r2 = ct*chn + ch; the 8 elements are 8 consecutive input channels (stride 9 floats in the master copy)
         const int ch = (int)(r2 % chn), ct = (int)(r2 / chn);
         const int c = 16 * wave + r;
         const int co = it.shuffle ? 4 * c + ct : 64 * ct + c;
-        const int ci = 64 * ch + 32 * half + 8 * g + e;
-        wf[i] = f32_to_bf16_bits(it.w[((size_t)co * Ci + ci) * 9 + ky * 3 + kx]);
+        const float* src = it.w + ((size_t)co * Ci + 64 * ch + 32 * half + 8 * g) * 9 + ky * 3 + kx;
+        const uint2 lo = pack4_bf16(src[0], src[9], src[18], src[27]), hi = pack4_bf16(src[36], src[45], src[54], src[63]);
+        reinterpret_cast<uint4*>(wf)[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
-      if (wd) {  // dgrad: r2 = ct'*ctn + ch'
+      if (wd) {  // dgrad: r2 = ct'*ctn + ch'; the 8 elements are 8 output channels (stride Ci*9, or 4*Ci*9 when shuffled)
         const int chp = (int)(r2 % ctn), ctp = (int)(r2 / ctn);
-        const int cc = 32 * half + 8 * g + e;
-        const int co = it.shuffle ? 4 * cc + chp : 64 * chp + cc;
+        const int cc0 = 32 * half + 8 * g;
         const int ci = 64 * ctp + 16 * wave + r;
-        wd[i] = f32_to_bf16_bits(it.w[((size_t)co * Ci + ci) * 9 + (2 - ky) * 3 + (2 - kx)]);
+        const size_t co0 = it.shuffle ? (size_t)4 * cc0 + chp : (size_t)64 * chp + cc0;
+        const size_t cstep = (size_t)(it.shuffle ? 4 : 1) * Ci * 9;
+        const float* src = it.w + (co0 * Ci + ci) * 9 + (2 - ky) * 3 + (2 - kx);
+        const uint2 lo = pack4_bf16(src[0], src[cstep], src[2 * cstep], src[3 * cstep]);
+        const uint2 hi = pack4_bf16(src[4 * cstep], src[5 * cstep], src[6 * cstep], src[7 * cstep]);
+        reinterpret_cast<uint4*>(wd)[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
     if (it.b_packed) {

@@ -5,8 +5,8 @@
 // streaming kernel, because this op moves 2 bytes per 288 flops less than the forward conv and is fed from HBM:
 //   * 512 threads: wave (w4, kh) accumulates D[all 64 co][ci 16*w4..] for the 9 taps (36 f32 16x16 tiles) over the
 //     k-steps {2kh, 2kh+1} of every 8x16-pixel tile; the two K halves are added through LDS once, at the end.
-//   * tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a 3-slot ring, two tiles
-//     ahead of the MFMAs, ordered by a counted s_waitcnt vmcnt + one raw s_barrier per tile.
+//   * tiles arrive by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring of 3 (4 for the tail conv) slots, two (three)
+//     tiles ahead of the MFMAs, ordered by a counted s_waitcnt vmcnt + one raw s_barrier per tile.
 //   * LDS image: 128-byte pixels, unpadded (an LDS-DMA wave-instruction writes 1 KiB contiguously), with the 16-byte
 //     chunk index XOR-swizzled by (pixel index & 7) - applied to the per-lane SOURCE address, so the DMA stays
 //     lane-linear - which makes every transposed read (8 consecutive pixels x 32 B per 32-lane half) conflict free.
@@ -20,7 +20,6 @@ __device__ __attribute__((aligned(256))) uint4 g_zero_page[16];   // zero-initia
 
 constexpr int DX_PIX = 192;                        // 10x18 = 180 halo pixels, rounded up to 24 DMA pieces of 8 pixels
 constexpr int DD_PIX = 128;                        // 8x16 dy pixels = 16 pieces (MT = 4)
-constexpr int DNSTAGE = 3;
 // MT = 4 (64 output channels): 24 x pieces + 16 dy pieces = 40 pieces, 5 per wave.
 // MT = 1 (tail conv, dy = [N,H,W,4]): 24 x pieces + 1 dy piece (128 px x 8 B) + 7 pieces of zeros = 32, 4 per wave; the zero
 // pieces double as the all-zero channels 4..15 of the transposed dy reads.
@@ -28,7 +27,10 @@ template <int MT> struct DmaCfg {
   static constexpr int PIECES = (MT == 4) ? 40 : 32;
   static constexpr int PER_WAVE = PIECES / 8;
   static constexpr int STAGE = PIECES * 1024;
-  static constexpr int LDS = (MT == 4) ? 4 * 36 * 1024 : 3 * STAGE;   // >= 3 stages and >= the final K-half exchange
+  // ring depth: MT = 4 has room for 3 slots of 40 KB (two tiles in flight); the tail conv's 32 KB slots fit 4 (three tiles in
+  // flight per CU) - that kernel only streams the largest activation of the network, bytes in flight are its throughput
+  static constexpr int NSTAGE = (MT == 4) ? 3 : 4;
+  static constexpr int LDS = (MT == 4) ? 4 * 36 * 1024 : NSTAGE * STAGE;   // >= the ring and >= the final K-half exchange
 };
 
 __device__ __forceinline__ short4v tr_read2(unsigned addr) {
@@ -133,19 +135,22 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-  if (ntiles > 0) tile_issue<MT>(j, t0, lds0, wave, lane);
-  if (ntiles > 1) tile_issue<MT>(j, t0 + 1, lds0 + DSTAGE, wave, lane);
+  constexpr int NST = DmaCfg<MT>::NSTAGE, AHEAD = NST - 1, PW = DmaCfg<MT>::PER_WAVE;
+#pragma unroll
+  for (int k = 0; k < AHEAD; ++k)
+    if (k < ntiles) tile_issue<MT>(j, t0 + k, lds0 + k * DSTAGE, wave, lane);
   int slot = 0;
   for (int t = 0; t < ntiles; ++t) {
-    // tile t has landed once at most the pieces of tile t+1 are still in flight (per wave), then all waves meet
-    if (t + 1 < ntiles) {
-      if (MT == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile t has landed once at most the pieces of the tiles issued after it are still in flight (per wave; counted
+    // s_waitcnt immediates), then all waves meet
+    const int younger = (ntiles - 1 - t < AHEAD - 1) ? ntiles - 1 - t : AHEAD - 1;
+    if (younger >= 2) { if (PW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+    else if (younger == 1) { if (PW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < ntiles) {
-      const int s2 = (slot + 2 >= DNSTAGE) ? slot + 2 - DNSTAGE : slot + 2;
-      tile_issue<MT>(j, t0 + t + 2, lds0 + s2 * DSTAGE, wave, lane);
+    if (t + AHEAD < ntiles) {
+      const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
+      tile_issue<MT>(j, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave, lane);
     }
     const unsigned sb = lds0 + slot * DSTAGE;
 #pragma unroll
@@ -174,7 +179,7 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
           acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
       }
     }
-    slot = (slot + 1 >= DNSTAGE) ? 0 : slot + 1;
+    slot = (slot + 1 >= NST) ? 0 : slot + 1;
   }
   // ---- add the two K halves through LDS, then write the slab: [co 64][tap 9][ci 64] + [64] bias sums ----
   __syncthreads();

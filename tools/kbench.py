@@ -134,3 +134,21 @@ def chain_bench(N=32, H=48, W=48, nlayers=33):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'chain':
     chain_bench()
+
+
+def conv4_bench(N=32, H=96, W=96):
+    """data gradient of the second upsampler conv (64 -> 256 + PixelShuffle): 256 -> 64 gathered from [N,2H,2W,64]"""
+    gen = np.random.default_rng(0)
+    pc = PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (256, 64, 3, 3)).astype(np.float32)), torch.zeros(256), shuffle=True)
+    dy = torch.randn(N, 2 * H, 2 * W, 64, device=DEV).to(BF16)
+    out = torch.empty(N, H, W, 64, dtype=BF16, device=DEV)
+    a = L.ConvArgs(x=dy.data_ptr(), w=pc.w_dgrad.data_ptr(), out=out.data_ptr(), N=N, H=H, W=W, cin_chunks=4, cout_tiles=1,
+                   in_mode=1, out_mode=0, relu=0, scale=1.0, grid_x=0)
+    us = time_fn(lambda: L.call('rumpy_conv3x3', a, stream()), iters=20)
+    flop = 2.0 * N * H * W * 64 * 256 * 9
+    print('conv 256->64 (PixelShuffle^T gather) %dx%dx%d: %7.2f us  %6.1f TFLOP/s  %5.2f TB/s input' % (N, H, W, us, flop / us / 1e6, dy.numel() * 2 / us / 1e6))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'conv4':
+    conv4_bench()
+    conv4_bench(32, 48, 48)
