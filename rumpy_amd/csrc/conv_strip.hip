@@ -224,7 +224,11 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
       }
     }
     STAMP_HERE();                       // 3: MFMAs issued
-    STAMP_HERE();                       // 4: (unused)
+    // The next strip's registers go to the other LDS buffer HERE, before the epilogue: a wait for them issued behind the
+    // epilogue's stores would have to drain those stores first (the persistent upsampler launches run 16 strips per
+    // workgroup; the single-strip 64 -> 64 launches have no next strip).
+    if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
+    STAMP_HERE();                       // 4: next strip staged
     // ---- epilogue ----
     float ps[4] = {0.f, 0.f, 0.f, 0.f};              // single tile: channels 4g .. 4g+3 of this wave's 16
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // paired tiles: channels 4(g&~1) .. +7
@@ -343,7 +347,6 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
         *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
       }
     }
-    if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
     __syncthreads();
     STAMP_HERE();                       // 5: epilogue done
     buf ^= 1;
