@@ -39,6 +39,8 @@ def main():
     ap.add_argument('--probe-steps', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--device-patches', action='store_true',
+                    help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
     args = ap.parse_args()
 
     import numpy as np
@@ -77,8 +79,22 @@ def main():
         x, y = O.synthetic_batch(1234 + i + 100 * rank, N, lr_hw=48, scale=4)
         pool.append((x.to(dev), y.to(dev)))
 
+    src = None
+    if args.device_patches:
+        # random crop + flips + transpose + uint8 -> float/255 on the GPU, random numbers drawn like the reference
+        import random
+        from rumpy_amd.sr_tools.device_patches import DevicePatchSource
+        gen = np.random.default_rng(99 + rank)
+        lrs = [gen.integers(0, 256, (192, 256, 3), dtype=np.uint8) for _ in range(64)]
+        hrs = [gen.integers(0, 256, (768, 1024, 3), dtype=np.uint8) for _ in range(64)]
+        src = DevicePatchSource(lrs, hrs, 4, 48, device=dev)
+        random.seed(8 + rank)
+
     def step(i):
-        x, y = pool[i % len(pool)]
+        if src is not None:
+            x, y = src.sample([(i * N + k) % len(src) for k in range(N)], rng=random)
+        else:
+            x, y = pool[i % len(pool)]
         return h.run_train(x=x, y=y, keep_on_device=True)
 
     def fence():
@@ -184,7 +200,9 @@ def main():
         line = {'metric': '48px LR patches/sec (train step) EDSR x4 bf16', 'value': round(value, 2), 'unit': 'LR patches/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
-                'data': 'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
+                'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
+                         'random-init weights (seed 8)') if args.device_patches else
+                        'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
                 'config': {'workload': 'EDSR-baseline x4 (64 feats x 16 blocks) train step, 48x48 LR patches, batch %d per GPU' % N,
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * FLOP_PER_PATCH_TRAIN / 1e12, 2),

@@ -312,6 +312,29 @@ typedef struct {
 } rumpy_eval_post_args;
 int rumpy_eval_post(const rumpy_eval_post_args* a, void* stream);
 
+/* ---- device-side training-patch pipeline: crop + flips + transpose + uint8 -> float/255 ----
+ * Replaces SuperResImages.__getitem__ / image_augment_crop (rumpy/sr_tools/data_handler.py:570-645),
+ * random_flip_rotate / image_patch_selection / extract_image_patch (rumpy/image_tools/image_manipulation/
+ * image_functions.py:245-362) and torchvision ToTensor (data_handler.py:472-486) for a batch of patches.
+ * `images`: one device buffer of uint8 HWC images; an item names its LR / HR image by byte offset (HR = scale x LR size).
+ * Augmentation order as the reference: A = transpose(vflip(hflip(I))) when the flags are set, patch = A[:, y:y+crop, x:x+crop];
+ * the HR patch is A_hr[:, y*scale : (y+crop)*scale, x*scale : ...].  (y, x) index the AUGMENTED LR image. */
+typedef struct {
+  int64_t lr_off, hr_off;       /* byte offsets into `images` */
+  int32_t lr_h, lr_w;           /* size of the stored (un-augmented) LR image */
+  int32_t hflip, vflip, rot;    /* 0 / 1 */
+  int32_t y, x;                 /* top-left corner of the LR patch in the augmented image */
+  int32_t pad_;
+} rumpy_patch_item;
+typedef struct {
+  const uint8_t* images;
+  const rumpy_patch_item* items;   /* DEVICE array, N entries */
+  float* out_lr;                   /* [N,C,crop,crop] fp32 */
+  float* out_hr;                   /* [N,C,crop*scale,crop*scale] fp32, or NULL */
+  int32_t N, C, crop, scale;
+} rumpy_patch_args;
+int rumpy_patch_gather(const rumpy_patch_args* a, void* stream);
+
 /* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
  * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
  * 4 = rumpy_conv_chain */

@@ -132,6 +132,16 @@ class EvalPostArgs(_S):
                 ('sse_partial', c_void_p), ('sse', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32)]
 
 
+class PatchItem(_S):
+    _fields_ = [('lr_off', c_int64), ('hr_off', c_int64), ('lr_h', c_int32), ('lr_w', c_int32), ('hflip', c_int32),
+                ('vflip', c_int32), ('rot', c_int32), ('y', c_int32), ('x', c_int32), ('pad_', c_int32)]
+
+
+class PatchArgs(_S):
+    _fields_ = [('images', c_void_p), ('items', c_void_p), ('out_lr', c_void_p), ('out_hr', c_void_p),
+                ('N', c_int32), ('C', c_int32), ('crop', c_int32), ('scale', c_int32)]
+
+
 # every symbol include/rumpy_amd.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 SYMBOLS = {
@@ -161,6 +171,7 @@ SYMBOLS = {
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),
     'rumpy_sumsq': (C.c_int, [_P(SumsqArgs), c_void_p]),
     'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
+    'rumpy_patch_gather': (C.c_int, [_P(PatchArgs), c_void_p]),
     'rumpy_probe_begin': (C.c_int, [C.c_int, C.c_int]),
     'rumpy_probe_end': (C.c_int, [_P(C.c_double)]),
 }

@@ -233,3 +233,27 @@ def test_gradient_averager_gloo_world_size_2():
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_device_patch_source_needs_a_gpu():
+    """SURVEY.md 8f.1 path: no CPU fallback either."""
+    import numpy as np
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from rumpy_amd.sr_tools.device_patches import DevicePatchSource
+    lr = np.zeros((8, 8, 3), np.uint8)
+    hr = np.zeros((16, 16, 3), np.uint8)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        DevicePatchSource([lr], [hr], 2, 4)
+
+
+def test_patch_item_numpy_mirror_matches_the_c_struct():
+    import ctypes as C
+
+    from rumpy_amd import _lib as L
+    from rumpy_amd.sr_tools import device_patches as DP
+    assert DP.ITEM_BYTES == C.sizeof(L.PatchItem)
+    for name, _ in L.PatchItem._fields_:
+        assert DP.ITEM_DTYPE.fields[name][1] == getattr(L.PatchItem, name).offset, name

@@ -158,3 +158,27 @@ def test_g8_parameter_counts_and_keys(golden_dir):
     assert sum(p.numel() for p in r.parameters()) == 15592355
     big = O.OracleEDSR(net_features=256, num_blocks=32)
     assert sum(p.numel() for p in big.parameters()) == 43089923
+
+
+def test_g10_patch_pipeline_oracle_matches_reference_functions(golden_dir):
+    """oracle/patch_oracle.py (ToTensor + random_flip_rotate + random patch selection) against the patches the imported
+    reference functions returned for the same seeded images and random.seed values: bit for bit, locations included."""
+    import random
+
+    import numpy as np
+
+    from oracle import patch_oracle as PO
+    g = np.load(os.path.join(golden_dir, 'g10_patches.npz'))
+    crop, scale, seed_img, cases = [int(v) for v in g['meta']]
+    sizes = [tuple(int(v) for v in s) for s in g['sizes']]
+    lrs, hrs = PO.synthetic_images(seed_img, sizes, scale)
+    seen = set()
+    for case in range(cases):
+        random.seed(1000 + case)
+        k = case % len(sizes)
+        lp, hp, (h, v, r, y, x) = PO.sample_patch(lrs[k], hrs[k], crop, scale, random)
+        assert (y, x) == tuple(int(t) for t in g['loc_%d' % case])
+        assert np.array_equal(lp.numpy(), g['lr_%d' % case]), case
+        assert np.array_equal(hp.numpy(), g['hr_%d' % case]), case
+        seen.add((h, v, r))
+    assert len(seen) == 8, 'the fixture should exercise every flip / transpose combination'

@@ -152,3 +152,36 @@ def conv4_bench(N=32, H=96, W=96):
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'conv4':
     conv4_bench()
     conv4_bench(32, 48, 48)
+
+
+def patches_bench(N=32, crop=48, scale=4):
+    """device-side patch pipeline against the CPU oracle doing the reference's per-item work"""
+    import random
+    import time
+    from oracle import patch_oracle as PO
+    from rumpy_amd.sr_tools.device_patches import DevicePatchSource
+    lrs, hrs = PO.synthetic_images(3, [(192, 256)] * 16, scale)
+    src = DevicePatchSource(lrs, hrs, scale, crop, device=DEV)
+    order = [i % len(src) for i in range(N)]
+    random.seed(1)
+    params = [src.draw(i, random) for i in order]
+    us_kernel = time_fn(lambda: src.gather(order, params), iters=50)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        src.sample(order, random)
+    torch.cuda.synchronize()
+    us_total = (time.perf_counter() - t0) / 50 * 1e6
+    t0 = time.perf_counter()
+    for _ in range(5):
+        for i in order:
+            PO.sample_patch(lrs[i], hrs[i], crop, scale, random)
+    us_cpu = (time.perf_counter() - t0) / 5 * 1e6
+    out_mb = N * 3 * (crop * crop + (crop * scale) ** 2) * 4 / 1e6
+    print('patch batch N=%d: gather (host item table + 2 launches) %7.1f us  incl. random draws %7.1f us  = %6.0f k patches/s; '
+          'output %.1f MB; CPU oracle (ToTensor of the whole image + flips + crop, 1 thread) %9.1f us = %5.2f k patches/s'
+          % (N, us_kernel, us_total, N / us_total * 1e3, out_mb, us_cpu, N / us_cpu * 1e3))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'patches':
+    patches_bench()
