@@ -25,6 +25,8 @@ FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, 
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_BYTES = 35.2e6           # FETCH_SIZE 21.9 MB + WRITE_SIZE 13.3 MB per launch
 PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv3x3_strip.md (separate rocprofv3 --pmc passes; launch with one residual operand)'
+BLOCK_PMC_TRAFFIC_BYTES = 40.8e6     # conv_block_kernel, mean of forward (34.9 MB) and data-gradient (46.8 MB) launches
+BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv_block.md (separate rocprofv3 --pmc passes, FETCH_SIZE + WRITE_SIZE)'
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
 
@@ -123,9 +125,14 @@ def main():
     if rank == 0:
         import ctypes
         lib = L.lib()
-        per_step = 4 * 16 + 2          # 64->64 launches per step: 33 forward + 33 data-gradient (body convs)
+        # dominant kernel: the residual-block kernel (two 64->64 convs per launch, conv_block.hip) when the engine uses it,
+        # otherwise the single-layer strip kernel
+        plan = h.net.engine.plan_for(N, 48, 48, True)
+        ops = plan.fwd + plan.bwd
+        blocks = [a for name, a in ops if name == 'rumpy_conv_block']
+        use_block = len(blocks) > 0
         h.net.use_graph = False          # the probe records events around eager launches (a graph replay has none)
-        lib.rumpy_probe_begin(1, per_step * args.probe_steps + 8)
+        lib.rumpy_probe_begin(5 if use_block else 1, 80 * args.probe_steps + 8)
         for i in range(args.probe_steps):
             step(i)
         torch.cuda.synchronize(dev)
@@ -133,18 +140,23 @@ def main():
         n_launch = lib.rumpy_probe_end(ctypes.byref(tot))
         if n_launch > 0:
             avg_s = tot.value * 1e-3 / n_launch
-            flop = 2.0 * N * 48 * 48 * 64 * 576            # algorithmic FLOPs of one 64->64 3x3 launch
-            # algorithmic bytes of the same launches: every [N,48,48,64] bf16 tensor a launch must touch once (input, output,
-            # ReLU mask, residual operands), averaged over the step's 64->64 launches as the engine planned them
-            plan = h.net.engine.plan_for(N, 48, 48, True)
-            tensors = [2 + sum(1 for f in ('mask', 'res1', 'res2') if getattr(a, f))
-                       for name, a in plan.fwd + plan.bwd
-                       if name == 'rumpy_conv3x3' and a.cin_chunks == 1 and a.cout_tiles == 1 and a.out_mode == 0]
+            layer_flop = 2.0 * N * 48 * 48 * 64 * 576      # algorithmic FLOPs of one 64->64 3x3 layer
             tensor_bytes = N * 48 * 48 * 64 * 2
+            # algorithmic bytes: every [N,48,48,64] bf16 tensor a launch must touch once, from the engine's launch plan
+            if use_block:
+                flop = 2 * layer_flop                      # the halo-row recompute of the first conv is overhead, not counted
+                tensors = [2 + sum(1 for f in ('t', 'mask', 'res2') if getattr(a, f)) for a in blocks]
+                kname = 'conv_block_kernel (residual block: two 3x3 convs 64->64 per launch, fwd + data-gradient launches)'
+            else:
+                flop = layer_flop
+                tensors = [2 + sum(1 for f in ('mask', 'res1', 'res2') if getattr(a, f))
+                           for name, a in ops
+                           if name == 'rumpy_conv3x3' and a.cin_chunks == 1 and a.cout_tiles == 1 and a.out_mode == 0]
+                kname = 'conv3x3_strip_kernel (3x3 conv 64->64, fwd + dgrad launches)'
             alg_bytes = tensor_bytes * sum(tensors) / max(1, len(tensors))
             t_mfma, t_hbm = flop / (MFMA_BF16_PEAK_TFLOPS * 1e12), alg_bytes / (HBM_PEAK_GBPS * 1e9)
             tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
-            common = {'kernel': 'conv3x3_strip_kernel (3x3 conv 64->64, fwd + dgrad launches)',
+            common = {'kernel': kname,
                       'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch, 'launches_per_step': len(tensors),
                       'algorithmic_gflop_per_launch': round(flop / 1e9, 3), 'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
                       'mfma': {'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -158,9 +170,13 @@ def main():
                 roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None}
             roofline.update(common)
-            # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
-            roofline['traffic'] = PMC_TRAFFIC_BYTES
-            roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
+            if not use_block:
+                # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
+                roofline['traffic'] = PMC_TRAFFIC_BYTES
+                roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
+            elif BLOCK_PMC_TRAFFIC_BYTES:
+                roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
+                roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
 
     # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1 only ----
     cpu = None

@@ -96,6 +96,27 @@ typedef struct {
 int rumpy_conv_chain(const rumpy_chain_args* a, void* stream);
 int64_t rumpy_conv_chain_xchg_bytes(int32_t nstrips);
 
+/* ---- residual block in one launch: two 3x3 convs 64 -> 64, the activation between them stays in LDS (conv_block.hip) ----
+ *   T = post1(convA(X)),  post1 = [+b1] [ReLU] [* scale1] [zero where mask <= 0];   OUT = X + scale2 * (convB(T) + b2) [+ res2]
+ * forward of ResBlock (rumpy/SISR/models/advanced/common.py ResBlock, used by EDSR architectures.py:196-241):
+ *   w1/b1 = conv1 forward image, relu1 = 1, scale1 = 1, mask = NULL, w2/b2 = conv2 forward image, scale2 = res_scale, T = saved activation
+ * its data gradient: X = dOUT, w1 = conv2's data-gradient image, b1 = NULL, relu1 = 0, scale1 = res_scale, mask = saved T,
+ *   w2 = conv1's data-gradient image, b2 = NULL, scale2 = 1, res2 = extra skip gradient or NULL; T = gradient w.r.t. the activation.
+ * All tensors [N,H,W,64] bf16, W <= 48 (a strip spans the image width); `t` may be NULL (inference: the activation is not stored). */
+typedef struct {
+  const void* x;
+  const void* w1; const float* b1;
+  const void* w2; const float* b2;
+  const void* mask;
+  const void* res2;
+  void* t;
+  void* out;
+  int32_t N, H, W;
+  int32_t relu1;
+  float scale1, scale2;
+} rumpy_block_args;
+int rumpy_conv_block(const rumpy_block_args* a, void* stream);
+
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
  * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */
 typedef struct {
@@ -337,7 +358,7 @@ int rumpy_patch_gather(const rumpy_patch_args* a, void* stream);
 
 /* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
  * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
- * 4 = rumpy_conv_chain */
+ * 4 = rumpy_conv_chain ; 5 = rumpy_conv_block */
 int rumpy_probe_begin(int kernel_id, int max_records);
 /* synchronises the recorded events; returns launches seen; *total_ms = summed duration */
 int rumpy_probe_end(double* total_ms);

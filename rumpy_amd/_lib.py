@@ -132,6 +132,12 @@ class EvalPostArgs(_S):
                 ('sse_partial', c_void_p), ('sse', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32)]
 
 
+class BlockArgs(_S):
+    _fields_ = [('x', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mask', c_void_p),
+                ('res2', c_void_p), ('t', c_void_p), ('out', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32),
+                ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float)]
+
+
 class PatchItem(_S):
     _fields_ = [('lr_off', c_int64), ('hr_off', c_int64), ('lr_h', c_int32), ('lr_w', c_int32), ('hflip', c_int32),
                 ('vflip', c_int32), ('rot', c_int32), ('y', c_int32), ('x', c_int32), ('pad_', c_int32)]
@@ -171,6 +177,7 @@ SYMBOLS = {
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),
     'rumpy_sumsq': (C.c_int, [_P(SumsqArgs), c_void_p]),
     'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
+    'rumpy_conv_block': (C.c_int, [_P(BlockArgs), c_void_p]),
     'rumpy_patch_gather': (C.c_int, [_P(PatchArgs), c_void_p]),
     'rumpy_probe_begin': (C.c_int, [C.c_int, C.c_int]),
     'rumpy_probe_end': (C.c_int, [_P(C.c_double)]),

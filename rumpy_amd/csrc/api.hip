@@ -52,7 +52,7 @@ void rumpy_probe_post(int kernel_id, hipStream_t s) {
   ++g_probe_n;
 }
 extern "C" int rumpy_probe_begin(int kernel_id, int max_records) {
-  if (kernel_id < 1 || kernel_id > 4 || max_records <= 0) { rumpy_set_error("rumpy_probe_begin: bad argument"); return RUMPY_E_ARG; }
+  if (kernel_id < 1 || kernel_id > 5 || max_records <= 0) { rumpy_set_error("rumpy_probe_begin: bad argument"); return RUMPY_E_ARG; }
   while ((int)g_probe_ev.size() < 2 * max_records) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) { rumpy_set_error("rumpy_probe_begin: hipEventCreate failed"); return RUMPY_E_LAUNCH; }

@@ -1,0 +1,273 @@
+// Two 3x3 convolutions 64 -> 64 with the activation between them kept in LDS: one residual block per launch.
+//
+//   forward  (EDSR ResBlock, architectures.py:24-44 / common.py ResBlock):  t = relu(conv1(x) + b1) ;  out = x + s * (conv2(t) + b2)
+//   backward (its data gradient):                                           gt = mask(t) . s * conv2^T(g) ;  gx = g + conv1^T(gt)
+// both are   T = post1(convA(X)) ,  OUT = X + scale2 * convB(T)   with post1 = [+bias] [ReLU] [* scale1] [ReLU mask].
+//
+// Why: at 288 pixels per CU a 64 -> 64 layer launched alone is bounded by what it pays once per launch (kernel boundary
+// incl. the 9.4 MB write-back, first HBM loads, store drain: DESIGN.md 4.1), not by its MFMAs.  A block in one launch pays
+// them once for two layers, never re-reads T from HBM and takes the residual operand from the input tile that is already in
+// LDS; the price is the halo recompute: T is needed on 8 rows (6 + one halo row each side) -> 4/3 of convA's MFMAs.
+// No inter-workgroup communication: a strip spans the image width (W <= 48), so T needs no column halo; rows outside the
+// image are the zero padding of convB and are forced to zero (convA evaluated there would not be).
+//
+// Geometry = conv_strip.hip: strip of 6 output rows x 48 columns per 512-thread workgroup, wave (q, rh) = output channels
+// 16q.. of one row half, filter slice stationary in 72 VGPRs (re-fetched between the phases), MFMA 16x16x32 bf16, reads of
+// group i+1 issued ahead of the MFMAs of group i, paired-tile 16-byte epilogues.  LDS holds the 10 x 50 input pixels and the
+// 8 x 50 T pixels UNPADDED (128 B per pixel, 115.2 KB together; the 96-byte-stride layout of conv_strip would need 172.8 KB)
+// with the 16-byte chunk index XOR-ed with (linear pixel index & 7): conflict-free for every ds_read_b128 fragment read
+// (checked by enumeration against the 4 x 16-lane groups of MI355X_MICROARCH.md, LDS table).  The XOR term of a read depends
+// on lane constants and on (2*row + tap column) & 7 only (50 = 2 mod 8, 16 = 0 mod 8): 8 x 2 per-lane base addresses are
+// prepared per phase and every read is base + immediate.
+#include "common.hpp"
+
+constexpr int BSH = 6, BSW = 48, BCOLS = BSW + 2;
+constexpr int BXROWS = BSH + 4, BTROWS = BSH + 2;
+constexpr int BXBYTES = BXROWS * BCOLS * 128;       // 64000
+constexpr int BTBYTES = BTROWS * BCOLS * 128;       // 51200
+constexpr int BTHREADS = 512;
+constexpr int BPIECES = BXROWS * BCOLS * 8;         // 4000 16-byte pieces of the input tile
+constexpr int BREGS = (BPIECES + BTHREADS - 1) / BTHREADS;   // 8
+
+struct BlockDev {
+  const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
+  const uint16_t* mask; const uint16_t* res2; uint16_t* t; uint16_t* out;
+  int N, H, W, sy_n, relu1; float scale1, scale2;
+};
+
+__device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p * 128 + ((chunk ^ (p & 7)) << 4)); }
+
+// MFMA sweep over the 18 (channel half, tap column, column tile) groups for ROWS output rows per wave (window = ROWS + 2
+// input rows).  off[d][half]: per-lane byte address of (window row 0, column px, chunk 4*half + g) for XOR class d.
+template <int ROWS>
+__device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2]) {
+  bf16x8 I[2][ROWS + 2];
+  auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
+    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+#pragma unroll
+    for (int r = 0; r < ROWS + 2; ++r)
+      dst[r] = *reinterpret_cast<const bf16x8*>(lds + off[(2 * r + kx) & 7][half] + (r * BCOLS + 16 * c + kx) * 128);
+  };
+  load_group(0, I[0]);
+#pragma unroll
+  for (int grp = 0; grp < 18; ++grp) {
+    if (grp + 1 < 18) load_group(grp + 1, I[(grp + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs
+    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
+  }
+}
+
+// per-lane read bases of a phase: window row 0 = row `row0` of the image at byte `buffer` of the LDS allocation (folded in here so
+// that every read is one register + a 16-bit immediate)
+__device__ __forceinline__ void sweep_bases(unsigned (&off)[8][2], unsigned buffer, int row0, int px, int g) {
+  const int p0 = row0 * BCOLS + px;
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) off[d][h] = buffer + (unsigned)(p0 * 128 + (((4 * h + g) ^ ((p0 + d) & 7)) << 4));
+}
+
+// exchange between lane g and g ^ 1 so that even-g lanes end up with 8 consecutive channels of tile X's pixel and odd-g lanes
+// with 8 channels of tile Y's pixel (conv_strip.hip)
+__device__ __forceinline__ void pair_up(const f32x4& tx, const f32x4& ty, int g, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float snd = (g & 1) ? tx[j] : ty[j];
+    const float rcv = __shfl_xor(snd, 16);
+    v[j] = (g & 1) ? rcv : tx[j];
+    v[4 + j] = (g & 1) ? ty[j] : rcv;
+  }
+}
+__device__ __forceinline__ void unpack8(uint4 u, float (&m)[8]) {
+  unpack4_bf16(make_uint2(u.x, u.y), *reinterpret_cast<float(*)[4]>(&m[0]));
+  unpack4_bf16(make_uint2(u.z, u.w), *reinterpret_cast<float(*)[4]>(&m[4]));
+}
+
+__global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  unsigned char* const ldx = lds;
+  unsigned char* const ldt = lds + BXBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int q = wave & 3, rh = wave >> 2;
+  const int strip = blockIdx.x;
+  const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+
+  // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
+  {
+    uint4 R[BREGS];
+    const int y0 = sy * BSH - 2;
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+      const int y = y0 + lr, x = lc - 1;
+      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
+      uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      R[i] = v;
+    }
+    // border columns of the T image are convB's zero padding and are never written by the epilogue
+    if (tid < BTROWS * 2 * 8) {
+      const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
+      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+    }
+  }
+  bf16x8 F[18];
+  {
+    const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+  }
+  const int c0 = 16 * q + 4 * g;
+  const int gpair = 4 * (g & ~1);
+  const int chunk8 = 2 * q + (gpair >> 3);          // 16-byte chunk of this lane's 8 channels in the paired layout
+  __syncthreads();
+
+  // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
+  // tile pairs: k < 4: X = (row k, col tile 0), Y = (row k, col tile 1); k = 4: X = (0, 2), Y = (1, 2); k = 5: X = (2, 2), Y = (3, 2)
+  unsigned moff[6];
+  uint4 M[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+    const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+    const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
+    moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
+    M[k] = make_uint4(0, 0, 0, 0);
+    if (a.mask) M[k] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
+  }
+  {
+    f32x4 acc[4][3];
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.b1) { const float4 t = *reinterpret_cast<const float4*>(a.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    unsigned off[8][2];
+    sweep_bases(off, 0u, 4 * rh, px, g);
+    block_sweep<4>(acc, F, lds, off);
+    // second filter: L2 hits that land under the epilogue
+    {
+      const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    }
+    auto post1 = [&](f32x4 t) -> f32x4 {
+      if (a.relu1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], 0.f);
+      }
+      if (a.scale1 != 1.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] *= a.scale1;
+      }
+      return t;
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const f32x4 tx = post1((k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2]);
+      const f32x4 ty = post1((k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2]);
+      float v[8];
+      pair_up(tx, ty, g, v);
+      if (a.mask) {
+        float m[8];
+        unpack8(M[k], m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
+      }
+      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+      const int j = 4 * rh + jr, xx = 16 * c + px;
+      uint4 o = make_uint4(0, 0, 0, 0);                      // outside the image: convB's zero padding
+      if (moff[k] != 0xffffffffu) {
+        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;     // the strip's own rows only
+      }
+      *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: output rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ; OUT = X + scale2 * (convB(T) + b2) [+ res2] ----
+  {
+    f32x4 acc[3][3];
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.b2) { const float4 t = *reinterpret_cast<const float4*>(a.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    unsigned off[8][2];
+    sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
+    block_sweep<3>(acc, F, lds, off);
+    // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][2];
+      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][2];
+      float v[8], m[8];
+      pair_up(tx, ty, g, v);
+      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+      const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
+      if (y < a.H && xx < a.W) {
+        unpack8(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);   // residual = the input tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+        const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair);
+        if (a.res2) {
+          unpack8(*reinterpret_cast<const uint4*>(a.res2 + o), m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += m[j];
+        }
+        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<uint4*>(a.out + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
+    {
+      const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px;
+      if (y < a.H && xx < a.W) {
+        float v[4] = {acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]};
+        float m[4];
+        unpack4_bf16(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+        const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
+        if (a.res2) {
+          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + o), m);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += m[j];
+        }
+        *reinterpret_cast<uint2*>(a.out + o) = pack4_bf16(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
+  if (!p || !p->x || !p->w1 || !p->w2 || !p->out) { rumpy_set_error("rumpy_conv_block: null pointer"); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW) { rumpy_set_error("rumpy_conv_block: needs 0 < W <= 48 (got %d)", p->W); return RUMPY_E_ARG; }
+  BlockDev d;
+  d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
+  d.mask = (const uint16_t*)p->mask; d.res2 = (const uint16_t*)p->res2; d.t = (uint16_t*)p->t; d.out = (uint16_t*)p->out;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = (p->H + BSH - 1) / BSH; d.relu1 = p->relu1; d.scale1 = p->scale1; d.scale2 = p->scale2;
+  hipStream_t s = (hipStream_t)stream;
+  rumpy_probe_pre(5, s);
+  hipLaunchKernelGGL(conv_block_kernel, dim3(d.N * d.sy_n), dim3(BTHREADS), 0, s, d);
+  rumpy_probe_post(5, s);
+  return rumpy_check_launch("rumpy_conv_block");
+}

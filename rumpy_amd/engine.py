@@ -10,6 +10,7 @@ reproduced (paths relative to /root/reference/rumpy):
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -96,6 +97,7 @@ class SREngine:
         self.cus = self.lib.rumpy_device_cus()
         self.plans = {}
         self.wgrad_pixels_per_job = wgrad_pixels_per_job
+        self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
         self.feats = spec.head.cout
         if self.feats != 64:
             raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 (got %d); other widths are not '
@@ -200,20 +202,36 @@ class SREngine:
             for it in items:
                 if it[0] == 'resblock':
                     _, c1, c2, rs = it
-                    t1, y = act(), act()
-                    self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
-                    self._conv(fwd, t1, c2, N, H, W, y, scale=rs, res1=cur)
+                    # one launch per block when a strip spans the image width (conv_block.hip): the activation between the two
+                    # convs stays in LDS (it is still stored when training: the backward pass masks with it and the weight
+                    # gradient of conv2 reads it); RUMPY_NO_BLOCK=1 keeps the two-launch path for A/B runs
+                    fused = self.use_block_kernel and W <= 48
+                    t1 = act() if (train or not fused) else None
+                    y = act()
+                    if fused:
+                        fwd.append(('rumpy_conv_block', L.BlockArgs(
+                            x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed), mask=None,
+                            res2=None, t=_ptr(t1), out=_ptr(y), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs))))
+                    else:
+                        self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
+                        self._conv(fwd, t1, c2, N, H, W, y, scale=rs, res1=cur)
 
-                    def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs):
+                    def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs, fused=fused):
                         # y = x + rs*conv2(relu(conv1 x)):  dt1 = rs*dgrad2(g) masked ; dx = g + dgrad1(dt1) (+ extra)
                         dt1, dx = self._new(plan, N, H, W, F), self._new(plan, N, H, W, F)
-                        self._conv(bwd, g_out, c2, N, H, W, dt1, dgrad=True, scale=rs, mask=t1)
+                        if fused:
+                            bwd.append(('rumpy_conv_block', L.BlockArgs(
+                                x=_ptr(g_out), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1),
+                                res2=_ptr(extra), t=_ptr(dt1), out=_ptr(dx), N=N, H=H, W=W, relu1=0, scale1=float(rs), scale2=1.0)))
+                        else:
+                            self._conv(bwd, g_out, c2, N, H, W, dt1, dgrad=True, scale=rs, mask=t1)
+                            self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
                         wjobs.append((c2, t1, g_out, H, W, 0, rs, 4))
-                        self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
                         wjobs.append((c1, x_in, dt1, H, W, 0, 1.0, 4))
                         return dx
                     nodes.append(node)
-                    release(t1)
+                    if t1 is not None:
+                        release(t1)
                     release(cur)
                     cur = y
                 elif it[0] == 'rcab':

@@ -455,3 +455,53 @@ def test_conv_chain_rejects_shapes_that_cannot_be_resident():
     assert L.lib().rumpy_conv_chain(a, None) == -1
     a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
     assert L.lib().rumpy_conv_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# residual block in one launch (conv_block.hip) against the same two layers through rumpy_conv3x3
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_block(x, pa, pb, N, H, W, fwd, rs, mask=None, extra=None, store_t=True):
+    t = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) if store_t else None
+    out = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    p = lambda z: None if z is None else z.data_ptr()
+    if fwd:
+        a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                        mask=None, res2=None, t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs))
+    else:   # data gradient: first through conv2 (pb) masked, then through conv1 (pa)
+        a = L.BlockArgs(x=x.data_ptr(), w1=pb.w_dgrad.data_ptr(), b1=None, w2=pa.w_dgrad.data_ptr(), b2=None, mask=p(mask), res2=p(extra),
+                        t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=float(rs), scale2=1.0)
+    L.call('rumpy_conv_block', a, stream())
+    torch.cuda.synchronize()
+    return t, out
+
+
+@pytest.mark.parametrize('N,H,W', [(1, 6, 16), (2, 13, 48), (3, 20, 37), (1, 5, 9), (32, 48, 48)])
+def test_conv_block_matches_two_layer_launches(N, H, W):
+    gen = np.random.default_rng(100 + H + W)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
+                            torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
+    pa, pb = mk(), mk()
+    x = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    rs = 0.1
+    # forward: t = relu(conv1 x + b1); y = x + rs * (conv2 t + b2)
+    t_ref, _ = hip_conv(x, pa, N, H, W, relu=True)
+    y_ref, _ = hip_conv(t_ref, pb, N, H, W, scale=rs, res1=x)
+    t, y = _run_block(x, pa, pb, N, H, W, True, rs)
+    assert torch.equal(t, t_ref), 'activation between the two convs'
+    assert_bf16_close(y.float(), y_ref.float(), 'block forward', rel=2e-3, amax=2.0 ** -7)
+    _, y2 = _run_block(x, pa, pb, N, H, W, True, rs, store_t=False)        # inference: activation not stored
+    assert torch.equal(y2, y)
+    # data gradient: gt = mask(t) . rs * conv2^T(g); gx = g + conv1^T(gt) + extra
+    g = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    extra = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    gt_ref, _ = hip_conv(g, pb, N, H, W, dgrad=True, scale=rs, mask=t_ref)
+    gx_ref, _ = hip_conv(gt_ref, pa, N, H, W, dgrad=True, res1=g, res2=extra)
+    gt, gx = _run_block(g, pa, pb, N, H, W, False, rs, mask=t_ref, extra=extra)
+    assert torch.equal(gt, gt_ref), 'gradient w.r.t. the activation'
+    assert_bf16_close(gx.float(), gx_ref.float(), 'block data gradient', rel=2e-3, amax=2.0 ** -7)
+
+
+def test_conv_block_rejects_wide_images():
+    t = torch.zeros(64, dtype=BF16, device=DEV)
+    a = L.BlockArgs(x=t.data_ptr(), w1=t.data_ptr(), w2=t.data_ptr(), out=t.data_ptr(), N=1, H=6, W=49, relu1=1, scale1=1.0, scale2=1.0)
+    assert L.lib().rumpy_conv_block(a, None) == -1 and b'W <= 48' in L.lib().rumpy_last_error()

@@ -185,3 +185,37 @@ def patches_bench(N=32, crop=48, scale=4):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'patches':
     patches_bench()
+
+
+def block_bench(N=32, H=48, W=48, nblocks=16):
+    """EDSR body as residual blocks: one launch per block (conv_block.hip) against two launches per block"""
+    gen = np.random.default_rng(0)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32)), torch.zeros(64))
+    pcs = [(mk(), mk()) for _ in range(nblocks)]
+    bufs = [torch.randn(N, H, W, 64, device=DEV).to(BF16) for _ in range(nblocks + 1)]
+    ts = [torch.empty(N, H, W, 64, dtype=BF16, device=DEV) for _ in range(nblocks)]
+
+    def fused():
+        for b, (pa, pb) in enumerate(pcs):
+            a = L.BlockArgs(x=bufs[b].data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
+                            b2=pb.b_packed.data_ptr(), t=ts[b].data_ptr(), out=bufs[b + 1].data_ptr(), N=N, H=H, W=W, relu1=1,
+                            scale1=1.0, scale2=0.1)
+            L.call('rumpy_conv_block', a, stream())
+
+    def separate():
+        for b, (pa, pb) in enumerate(pcs):
+            a1 = L.ConvArgs(x=bufs[b].data_ptr(), w=pa.w_fwd.data_ptr(), bias=pa.b_packed.data_ptr(), out=ts[b].data_ptr(), N=N, H=H, W=W,
+                            cin_chunks=1, cout_tiles=1, relu=1, scale=1.0, grid_x=0)
+            L.call('rumpy_conv3x3', a1, stream())
+            a2 = L.ConvArgs(x=ts[b].data_ptr(), w=pb.w_fwd.data_ptr(), bias=pb.b_packed.data_ptr(), out=bufs[b + 1].data_ptr(),
+                            res1=bufs[b].data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1, relu=0, scale=0.1, grid_x=0)
+            L.call('rumpy_conv3x3', a2, stream())
+    for _ in range(2):
+        us_f = time_fn(fused, iters=20)
+        us_s = time_fn(separate, iters=20)
+        print('%d residual blocks %dx%dx%d: one launch per block %8.1f us = %6.2f us/block ; two launches per block %8.1f us = %6.2f us/block'
+              % (nblocks, N, H, W, us_f, us_f / nblocks, us_s, us_s / nblocks))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'block':
+    block_bench()
