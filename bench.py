@@ -25,7 +25,7 @@ FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, 
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_BYTES = 35.2e6           # FETCH_SIZE 21.9 MB + WRITE_SIZE 13.3 MB per launch
 PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv3x3_strip.md (separate rocprofv3 --pmc passes; launch with one residual operand)'
-BLOCK_PMC_TRAFFIC_BYTES = 40.8e6     # conv_block_kernel, mean of forward (34.9 MB) and data-gradient (46.8 MB) launches
+BLOCK_PMC_TRAFFIC_BYTES = 41.4e6     # conv_block_kernel, mean of forward (35.3 MB) and data-gradient (47.5 MB) launches
 BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv_block.md (separate rocprofv3 --pmc passes, FETCH_SIZE + WRITE_SIZE)'
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
