@@ -102,6 +102,7 @@ class HipSRNet(nn.Module):
         # step is GPU-bound (dependent kernel boundaries), eager launches keep up and a replay gains nothing (1.99 vs 2.03 ms)
         self.use_graph = os.environ.get('RUMPY_GRAPH') == '1'
         self.engine = None
+        self._loss_host, self._loss_event, self.early_loss = None, None, False
         self._packed_version = None
         self._flatten()
 
@@ -209,8 +210,26 @@ class HipSRNet(nn.Module):
             out, loss, _ = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous())
             return loss, out
         out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous())
+        # The loss is final once the forward pass has run: its read-back is queued HERE (pinned buffer + event), ahead of the
+        # backward launches, so that run_train's `loss.cpu().numpy()` (the reference API returns the loss of every step,
+        # base_architecture.py:482-485) waits for the forward pass only and the host can queue the next step while the GPU
+        # still runs this step's backward pass and optimizer.
+        if self._loss_host is None:
+            self._loss_host = torch.empty(1, dtype=torch.float32).pin_memory()
+            self._loss_event = torch.cuda.Event()
+        self._loss_host.copy_(loss, non_blocking=True)
+        self._loss_event.record()
+        self.early_loss = True
         self.engine.backward(plan, 1.0 / out.numel())
         return loss, out
+
+    def take_early_loss(self):
+        """-> 0-d float32 ndarray of the last fused step's loss (waits for its forward pass only), or None."""
+        if not getattr(self, 'early_loss', False):
+            return None
+        self.early_loss = False
+        self._loss_event.synchronize()
+        return self._loss_host.numpy().copy().reshape(())
 
     def l1_eval(self, x, y):
         out, loss, _ = self.engine_forward(x, train=False, target=y.float().contiguous())

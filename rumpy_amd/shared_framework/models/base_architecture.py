@@ -233,11 +233,13 @@ class BaseModel(nn.Module):
                 y = y * binary_mask
             loss = self.find_loss(out, y)
             self.standard_update(loss, scheduler_skip=scheduler_skip)
+        early = self.net.take_early_loss() if hasattr(self.net, 'take_early_loss') else None   # read back after the forward pass
+        loss_np = early if early is not None else loss.detach().reshape(()).cpu().numpy()
         if keep_on_device:
             # in graph mode `out` is the plan's static buffer (rewritten by the next step): hand out a copy
             keep = out.detach().clone() if getattr(self.net, 'use_graph', False) else out.detach()
-            return loss.detach().reshape(()).cpu().numpy(), keep
-        return loss.detach().reshape(()).cpu().numpy(), out.detach().cpu()
+            return loss_np, keep
+        return loss_np, out.detach().cpu()
 
     def run_eval(self, x, y=None, request_loss=False, tag=None, timing=False, keep_on_device=False, *args, **kwargs):
         """-> (out, loss | None, seconds | None) as :488-520."""
