@@ -117,6 +117,22 @@ typedef struct {
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
 
+/* ---- a chain of residual blocks in one launch, the strip resident in LDS from block to block (conv_block_chain.hip) ----
+ * blocks: DEVICE array of rumpy_block_args, block b+1's input is block b's output (x is read from blocks[0] only; res2 must be
+ * NULL).  Needs N*ceil(H/6) <= CUs (every strip co-resident), W <= 48 and nothing else occupying CUs while it runs.
+ * xchg: rumpy_block_chain_xchg_bytes(N*ceil(H/6)) bytes, zeroed ONCE by the caller at allocation, then owned by the library.
+ * status: one device word, 0 after a clean run (a neighbour hand-off that timed out stores 0x200 + block index). */
+typedef struct {
+  const rumpy_block_args* blocks;
+  int32_t nblocks;
+  int32_t N, H, W;
+  int32_t masked;      /* 1: the blocks carry ReLU masks (data-gradient chains), 0: none does (the masks are not even loaded) */
+  void* xchg;
+  uint32_t* status;
+} rumpy_block_chain_args;
+int rumpy_block_chain(const rumpy_block_chain_args* a, void* stream);
+int64_t rumpy_block_chain_xchg_bytes(int32_t nstrips);
+
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
  * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */
 typedef struct {
@@ -358,7 +374,7 @@ int rumpy_patch_gather(const rumpy_patch_args* a, void* stream);
 
 /* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
  * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
- * 4 = rumpy_conv_chain ; 5 = rumpy_conv_block */
+ * 4 = rumpy_conv_chain ; 5 = rumpy_conv_block and rumpy_block_chain */
 int rumpy_probe_begin(int kernel_id, int max_records);
 /* synchronises the recorded events; returns launches seen; *total_ms = summed duration */
 int rumpy_probe_end(double* total_ms);

@@ -138,6 +138,11 @@ class BlockArgs(_S):
                 ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float)]
 
 
+class BlockChainArgs(_S):
+    _fields_ = [('blocks', c_void_p), ('nblocks', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('masked', c_int32),
+                ('xchg', c_void_p), ('status', c_void_p)]
+
+
 class PatchItem(_S):
     _fields_ = [('lr_off', c_int64), ('hr_off', c_int64), ('lr_h', c_int32), ('lr_w', c_int32), ('hflip', c_int32),
                 ('vflip', c_int32), ('rot', c_int32), ('y', c_int32), ('x', c_int32), ('pad_', c_int32)]
@@ -178,6 +183,8 @@ SYMBOLS = {
     'rumpy_sumsq': (C.c_int, [_P(SumsqArgs), c_void_p]),
     'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
     'rumpy_conv_block': (C.c_int, [_P(BlockArgs), c_void_p]),
+    'rumpy_block_chain': (C.c_int, [_P(BlockChainArgs), c_void_p]),
+    'rumpy_block_chain_xchg_bytes': (c_int64, [c_int32]),
     'rumpy_patch_gather': (C.c_int, [_P(PatchArgs), c_void_p]),
     'rumpy_probe_begin': (C.c_int, [C.c_int, C.c_int]),
     'rumpy_probe_end': (C.c_int, [_P(C.c_double)]),

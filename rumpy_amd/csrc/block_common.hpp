@@ -1,0 +1,72 @@
+// Shared by conv_block.hip (one residual block per launch) and conv_block_chain.hip (a chain of blocks per launch):
+// strip geometry, the XOR-swizzled unpadded LDS image, the software-pipelined MFMA sweep and the paired-tile helpers.
+#pragma once
+#include "common.hpp"
+
+constexpr int BSH = 6, BSW = 48, BCOLS = BSW + 2;
+constexpr int BXROWS = BSH + 4, BTROWS = BSH + 2;
+constexpr int BXBYTES = BXROWS * BCOLS * 128;       // 64000
+constexpr int BTBYTES = BTROWS * BCOLS * 128;       // 51200
+constexpr int BTHREADS = 512;
+constexpr int BPIECES = BXROWS * BCOLS * 8;         // 4000 16-byte pieces of the input tile
+constexpr int BREGS = (BPIECES + BTHREADS - 1) / BTHREADS;   // 8
+
+struct BlockDev {
+  const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
+  const uint16_t* mask; const uint16_t* res2; uint16_t* t; uint16_t* out;
+  int N, H, W, sy_n, relu1; float scale1, scale2;
+};
+
+__device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p * 128 + ((chunk ^ (p & 7)) << 4)); }
+
+// MFMA sweep over the 18 (channel half, tap column, column tile) groups for ROWS output rows per wave (window = ROWS + 2
+// input rows).  off[d][half]: per-lane byte address of (window row 0, column px, chunk 4*half + g) for XOR class d.
+template <int ROWS>
+__device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2]) {
+  bf16x8 I[2][ROWS + 2];
+  auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
+    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+#pragma unroll
+    for (int r = 0; r < ROWS + 2; ++r)
+      dst[r] = *reinterpret_cast<const bf16x8*>(lds + off[(2 * r + kx) & 7][half] + (r * BCOLS + 16 * c + kx) * 128);
+  };
+  load_group(0, I[0]);
+#pragma unroll
+  for (int grp = 0; grp < 18; ++grp) {
+    if (grp + 1 < 18) load_group(grp + 1, I[(grp + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs
+    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r)
+        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
+  }
+}
+
+// per-lane read bases of a phase: window row 0 = row `row0` of the image at byte `buffer` of the LDS allocation (folded in here so
+// that every read is one register + a 16-bit immediate)
+__device__ __forceinline__ void sweep_bases(unsigned (&off)[8][2], unsigned buffer, int row0, int px, int g) {
+  const int p0 = row0 * BCOLS + px;
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) off[d][h] = buffer + (unsigned)(p0 * 128 + (((4 * h + g) ^ ((p0 + d) & 7)) << 4));
+}
+
+// exchange between lane g and g ^ 1 so that even-g lanes end up with 8 consecutive channels of tile X's pixel and odd-g lanes
+// with 8 channels of tile Y's pixel (conv_strip.hip)
+__device__ __forceinline__ void pair_up(const f32x4& tx, const f32x4& ty, int g, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float snd = (g & 1) ? tx[j] : ty[j];
+    const float rcv = __shfl_xor(snd, 16);
+    v[j] = (g & 1) ? rcv : tx[j];
+    v[4 + j] = (g & 1) ? ty[j] : rcv;
+  }
+}
+__device__ __forceinline__ void unpack8(uint4 u, float (&m)[8]) {
+  unpack4_bf16(make_uint2(u.x, u.y), *reinterpret_cast<float(*)[4]>(&m[0]));
+  unpack4_bf16(make_uint2(u.z, u.w), *reinterpret_cast<float(*)[4]>(&m[4]));
+}
+

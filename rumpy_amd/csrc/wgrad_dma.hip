@@ -12,6 +12,9 @@
 //     lane-linear - which makes every transposed read (8 consecutive pixels x 32 B per 32-lane half) conflict free.
 //   * out-of-image pixels are fetched from a zero page; the bias gradient is one extra MFMA against a ones fragment.
 #include "common.hpp"
+#ifndef WGRAD_ABL
+#define WGRAD_ABL 0     // timing experiments only (tools/build_abl.sh): results are wrong for any value but 0
+#endif
 
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr2;
 typedef __attribute__((address_space(3))) unsigned char* lds_u8;
@@ -51,39 +54,62 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 
 struct DmaJob { const uint16_t* x; const uint16_t* dy; int n0, H, W, x_cstride, x_coff, dy_mode, dy_cstride, dy_coff, tiles_x, tiles_y; };
 
-// issue this wave's pieces of one tile into ring slot `stage_addr` (LDS byte address, wave-uniform)
+// Per-lane geometry of this wave's DMA pieces, computed once per job: piece k of the wave = piece index wave + 8k; k < 3 are x
+// halo pieces (8 pixels x 128 B of the 10x18 halo), k >= 3 dy pieces.  Per tile only the tile origin changes, so the source
+// address is a handful of 32-bit operations instead of the div/mod + 64-bit chain it replaces (the address generation of
+// 5 pieces used to cost as many issue cycles as the tile's MFMAs).
+struct PieceGeom { int r, c, coff; bool valid; };
 template <int MT>
-__device__ __forceinline__ void tile_issue(const DmaJob& j, int tile, unsigned stage_addr, int wave, int lane) {
-  const TileCoord tc = decode_tile(tile, j.tiles_x, j.tiles_y);
-  const int n = j.n0 + tc.n;
+__device__ __forceinline__ void piece_geometry(PieceGeom (&pg)[DmaCfg<MT>::PER_WAVE], const DmaJob& j, int wave, int lane) {
   const int sub = lane >> 3, slot = lane & 7;
 #pragma unroll
   for (int k = 0; k < DmaCfg<MT>::PER_WAVE; ++k) {
-    const int piece = wave + 8 * k;                       // wave-uniform
-    const void* src = g_zero_page;
-    if (piece < 24) {                                     // x halo: pixels 8*piece .. 8*piece+7 of the 10x18 tile
+    const int piece = wave + 8 * k;
+    if (k < 3) {                                          // x halo: pixels 8*piece .. 8*piece+7 of the 10x18 tile
       const int pix = piece * 8 + sub;
-      const int r = pix / HALO_W, c = pix - r * HALO_W;
-      const int y = tc.ty * TH + r - 1, x = tc.tx * TW + c - 1;
-      const int chunk = slot ^ (pix & 7);
-      if (pix < HALO_PIX && (unsigned)y < (unsigned)j.H && (unsigned)x < (unsigned)j.W)
-        src = j.x + ((size_t)(n * j.H + y) * j.W + x) * j.x_cstride + j.x_coff + chunk * 8;
-    } else if (MT == 1) {                                 // dy4: lane l carries pixels 2l, 2l+1 (8 B each) of piece 24
-      if (piece == 24) {
-        const int pix = 2 * lane;
-        const int y = tc.ty * TH + (pix >> 4), x = tc.tx * TW + (pix & 15);
-        if (y < j.H && x < j.W) src = j.dy + ((size_t)(n * j.H + y) * j.W + x) * 4;   // W is even: x+1 is in the image too
-      }
+      const int r = pix / HALO_W;
+      pg[k].r = r - 1; pg[k].c = pix - r * HALO_W - 1;
+      pg[k].coff = j.x_coff + (slot ^ (pix & 7)) * 8;
+      pg[k].valid = pix < HALO_PIX;
+    } else if (MT == 1) {                                 // dy4: lane l carries pixels 2l, 2l+1 (8 B each) of piece 24; others: zeros
+      const int pix = 2 * lane;
+      pg[k].r = pix >> 4; pg[k].c = pix & 15; pg[k].coff = 0; pg[k].valid = piece == 24;
     } else {                                              // dy: pixels 8*(piece-24) .. of the 8x16 tile
       const int pix = (piece - 24) * 8 + sub;
-      const int y = tc.ty * TH + (pix >> 4), x = tc.tx * TW + (pix & 15);
-      const int chunk = slot ^ (pix & 7);
-      if (y < j.H && x < j.W) {
-        if (j.dy_mode == 0) src = j.dy + ((size_t)(n * j.H + y) * j.W + x) * j.dy_cstride + j.dy_coff + chunk * 8;
-        else src = j.dy + ((size_t)(n * 2 * j.H + 2 * y + (j.dy_coff >> 1)) * (2 * j.W) + 2 * x + (j.dy_coff & 1)) * 64 + chunk * 8;
-      }
+      pg[k].r = pix >> 4; pg[k].c = pix & 15;
+      pg[k].coff = (slot ^ (pix & 7)) * 8 + (j.dy_mode == 0 ? j.dy_coff : 0);
+      pg[k].valid = true;
     }
-    dma16(src, __builtin_amdgcn_readfirstlane(stage_addr + piece * 1024));
+  }
+}
+
+// issue this wave's pieces of one tile into ring slot `stage_addr` (LDS byte address, wave-uniform)
+template <int MT>
+__device__ __forceinline__ void tile_issue(const DmaJob& j, const PieceGeom (&pg)[DmaCfg<MT>::PER_WAVE], int tile, unsigned stage_addr, int wave) {
+  const TileCoord tc = decode_tile(tile, j.tiles_x, j.tiles_y);
+  const int n = j.n0 + tc.n;
+  const int y0 = tc.ty * TH, x0 = tc.tx * TW;
+  const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_page;
+#pragma unroll
+  for (int k = 0; k < DmaCfg<MT>::PER_WAVE; ++k) {
+    const int piece = wave + 8 * k;                       // wave-uniform
+    const int y = y0 + pg[k].r, x = x0 + pg[k].c;
+    const bool ok = pg[k].valid & ((unsigned)y < (unsigned)j.H) & ((unsigned)x < (unsigned)j.W);
+    unsigned long long base;
+    unsigned e;                                           // element offset (every tensor of the path has < 2^31 elements)
+    if (k < 3) {
+      base = (unsigned long long)(uintptr_t)j.x;
+      e = (unsigned)(((n * j.H + y) * j.W + x) * j.x_cstride + pg[k].coff);
+    } else if (MT == 1) {
+      base = (unsigned long long)(uintptr_t)j.dy;
+      e = (unsigned)(((n * j.H + y) * j.W + x) * 4);      // W is even: x+1 is in the image too
+    } else {
+      base = (unsigned long long)(uintptr_t)j.dy;
+      if (j.dy_mode == 0) e = (unsigned)(((n * j.H + y) * j.W + x) * j.dy_cstride + pg[k].coff);
+      else e = (unsigned)(((n * 2 * j.H + 2 * y + (j.dy_coff >> 1)) * (2 * j.W) + 2 * x + (j.dy_coff & 1)) * 64 + pg[k].coff);
+    }
+    const unsigned long long src = ok ? base + 2ull * e : zero;
+    dma16((const void*)(uintptr_t)src, __builtin_amdgcn_readfirstlane(stage_addr + piece * 1024));
   }
 }
 
@@ -136,9 +162,11 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   constexpr int NST = DmaCfg<MT>::NSTAGE, AHEAD = NST - 1, PW = DmaCfg<MT>::PER_WAVE;
+  PieceGeom pg[PW];
+  piece_geometry<MT>(pg, j, wave, lane);
 #pragma unroll
   for (int k = 0; k < AHEAD; ++k)
-    if (k < ntiles) tile_issue<MT>(j, t0 + k, lds0 + k * DSTAGE, wave, lane);
+    if (k < ntiles) tile_issue<MT>(j, pg, t0 + k, lds0 + k * DSTAGE, wave);
   int slot = 0;
   for (int t = 0; t < ntiles; ++t) {
     // tile t has landed once at most the pieces of the tiles issued after it are still in flight (per wave; counted
@@ -148,9 +176,9 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
     else if (younger == 1) { if (PW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + AHEAD < ntiles) {
+    if (t + AHEAD < ntiles && WGRAD_ABL != 3) {
       const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
-      tile_issue<MT>(j, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave, lane);
+      tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
     }
     const unsigned sb = lds0 + slot * DSTAGE;
 #pragma unroll
@@ -173,10 +201,11 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const unsigned pb = sb + (ks ? (offB[tap] ^ 64u) + 36 * 128 : offB[tap]);
-        const bf16x8 B = join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
+        const bf16x8 B = (WGRAD_ABL == 2) ? ones : join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
 #pragma unroll
         for (int ct = 0; ct < MT; ++ct)
-          acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
+          if (WGRAD_ABL != 1) acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
+          else asm volatile("" :: "v"(B), "v"(A[ct]));
       }
     }
     slot = (slot + 1 >= NST) ? 0 : slot + 1;

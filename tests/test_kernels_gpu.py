@@ -505,3 +505,66 @@ def test_conv_block_rejects_wide_images():
     t = torch.zeros(64, dtype=BF16, device=DEV)
     a = L.BlockArgs(x=t.data_ptr(), w1=t.data_ptr(), w2=t.data_ptr(), out=t.data_ptr(), N=1, H=6, W=49, relu1=1, scale1=1.0, scale2=1.0)
     assert L.lib().rumpy_conv_block(a, None) == -1 and b'W <= 48' in L.lib().rumpy_last_error()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# chain of residual blocks in one launch (conv_block_chain.hip) against one rumpy_conv_block launch per block
+# ---------------------------------------------------------------------------------------------------------------------
+def _block_chain_case(N, H, W, nblocks, fwd, seed):
+    gen = np.random.default_rng(seed)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
+                            torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
+    pcs = [(mk(), mk()) for _ in range(nblocks)]
+    x = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    masks = [torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16) for _ in range(nblocks)]
+    rs = 0.1
+    p = lambda z: None if z is None else z.data_ptr()
+
+    def args(b, xin, t, out):
+        pa, pb = pcs[b]
+        if fwd:
+            return L.BlockArgs(x=p(xin), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                               t=p(t), out=p(out), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=rs)
+        return L.BlockArgs(x=p(xin), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=p(masks[b]), t=p(t), out=p(out), N=N, H=H, W=W,
+                           relu1=0, scale1=rs, scale2=1.0)
+    mkbuf = lambda: torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    # reference: one launch per block
+    ref_t, ref_o, cur = [], [], x
+    for b in range(nblocks):
+        t, o = mkbuf(), mkbuf()
+        L.call('rumpy_conv_block', args(b, cur, t, o), stream())
+        ref_t.append(t); ref_o.append(o); cur = o
+    # chain
+    ts, outs = [mkbuf() for _ in range(nblocks)], [mkbuf() for _ in range(nblocks)]
+    table = (L.BlockArgs * nblocks)(*[args(b, x if b == 0 else outs[b - 1], ts[b], outs[b]) for b in range(nblocks)])
+    tdev = to_dev_bytes(table)
+    nstrips = N * ((H + 5) // 6)
+    xchg = torch.zeros(int(L.lib().rumpy_block_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
+    status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    a = L.BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0 if fwd else 1, xchg=xchg.data_ptr(),
+                         status=status.data_ptr())
+    for _ in range(3):                 # repeated launches on the same exchange buffer: the tag base moves on every call
+        for o in outs + ts:
+            o.fill_(float('nan'))
+        L.call('rumpy_block_chain', a, stream())
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
+    return ref_t, ref_o, ts, outs
+
+
+@pytest.mark.parametrize('N,H,W,nblocks', [(1, 6, 16, 2), (2, 13, 48, 3), (3, 20, 37, 4), (1, 26, 9, 5), (32, 48, 48, 16)])
+@pytest.mark.parametrize('fwd', [True, False])
+def test_block_chain_matches_block_by_block(N, H, W, nblocks, fwd):
+    ref_t, ref_o, ts, outs = _block_chain_case(N, H, W, nblocks, fwd, 7 + H + nblocks)
+    for b in range(nblocks):
+        # same operands and the same operation order per pixel: bit-identical
+        assert torch.equal(ts[b], ref_t[b]), ('activation', b)
+        assert torch.equal(outs[b], ref_o[b]), ('output', b)
+
+
+def test_block_chain_rejects_shapes_that_cannot_be_resident():
+    t = torch.zeros(64, dtype=BF16, device=DEV)
+    a = L.BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
+    assert L.lib().rumpy_block_chain(a, None) == -1
+    a = L.BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
+    assert L.lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()

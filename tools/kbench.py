@@ -219,3 +219,33 @@ def block_bench(N=32, H=48, W=48, nblocks=16):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'block':
     block_bench()
+
+
+def bchain_bench(N=32, H=48, W=48, nblocks=16):
+    """EDSR body: one launch for the whole chain of residual blocks against one launch per block"""
+    gen = np.random.default_rng(0)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32)), torch.zeros(64))
+    pcs = [(mk(), mk()) for _ in range(nblocks)]
+    bufs = [torch.randn(N, H, W, 64, device=DEV).to(BF16) for _ in range(nblocks + 1)]
+    ts = [torch.empty(N, H, W, 64, dtype=BF16, device=DEV) for _ in range(nblocks)]
+    items = [L.BlockArgs(x=bufs[b].data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
+                         b2=pb.b_packed.data_ptr(), t=ts[b].data_ptr(), out=bufs[b + 1].data_ptr(), N=N, H=H, W=W, relu1=1,
+                         scale1=1.0, scale2=0.1) for b, (pa, pb) in enumerate(pcs)]
+    tdev = to_dev_bytes((L.BlockArgs * nblocks)(*items))
+    nstrips = N * ((H + 5) // 6)
+    xchg = torch.zeros(int(L.lib().rumpy_block_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    a = L.BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0, xchg=xchg.data_ptr(), status=status.data_ptr())
+
+    def per_block():
+        for it in items:
+            L.call('rumpy_conv_block', it, stream())
+    for _ in range(2):
+        us_c = time_fn(lambda: L.call('rumpy_block_chain', a, stream()), iters=20)
+        us_b = time_fn(per_block, iters=20)
+        print('%d residual blocks %dx%dx%d: one launch for the chain %8.1f us = %6.2f us/block (status %d); one launch per block %8.1f us = %6.2f us/block'
+              % (nblocks, N, H, W, us_c, us_c / nblocks, int(status.item()), us_b, us_b / nblocks))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'bchain':
+    bchain_bench()
