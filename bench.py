@@ -34,8 +34,8 @@ SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=40)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--batch', type=int, default=32, help='LR patches per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--probe-steps', type=int, default=5)
