@@ -226,3 +226,36 @@ def test_hipgraph_replay_gives_the_same_step_as_eager_launches():
         assert float(l1) == float(l2) and torch.equal(o1, o2), s
     for p, q in zip(h1.net.parameters(), h2.net.parameters()):
         assert torch.equal(p.detach(), q.detach())
+
+
+def test_reference_written_checkpoint_continues_identically_on_the_gpu(golden_dir):
+    """G11: the checkpoint FILE written by the real reference handler is loaded into the HIP handler; the
+    evaluation at the saved state and the NEXT training step (loss, learning rate, weights - i.e. the restored Adam moments
+    and scheduler position) reproduce what the reference computed after saving."""
+    import shutil
+    src = os.path.join(golden_dir, 'g11_ref_checkpoint')
+    tmp = tempfile.mkdtemp()
+    shutil.copy(os.path.join(src, 'train_model_2'), tmp)
+    exp = np.load(os.path.join(src, 'expected.npz'))
+    h = define_model('edsr', model_save_dir=tmp, device=0, eval_mode=False, checkpoint_load=False, loss_masking=False,
+                     metadata_list=None, scale=2, num_features=64, num_blocks=1, res_scale=0.1, lr=1e-3,
+                     scheduler='cosine_annealing_warm_restarts', scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+    h.load_model('train_model', 2)
+    saved = {k: v.detach().float().cpu().clone() for k, v in h.net.state_dict().items()}
+    xe, ye = O.synthetic_batch(600, 1, lr_hw=16, scale=2)
+    out, loss, _ = h.run_eval(x=xe, y=ye, request_loss=True)
+    assert self_psnr(out.float().cpu(), torch.from_numpy(exp['eval_out'])) > 50.0
+    assert abs(float(loss) - float(exp['eval_loss'])) < 2e-3 * abs(float(exp['eval_loss'])) + 1e-4
+    assert np.isclose(h.get_learning_rate(), float(exp['lr_at_save']), rtol=1e-9)
+    xb, yb = O.synthetic_batch(502, 2, lr_hw=12, scale=2)
+    loss2, _ = h.run_train(x=xb, y=yb, tag=None, mask=None)
+    assert abs(float(loss2) - float(exp['loss2'])) < 2e-3 * abs(float(exp['loss2'])) + 1e-4
+    assert np.isclose(h.get_learning_rate(), float(exp['lr_after2']), rtol=1e-9)
+    # the update itself: (w_after - w_saved) must point where the reference's did - with fresh Adam moments it would not
+    num = den_a = den_b = 0.0
+    for k, v in h.net.state_dict().items():
+        mine = v.detach().float().cpu() - saved[k]
+        ref = torch.from_numpy(exp['w3.' + k]) - saved[k]
+        num += float((mine * ref).sum()); den_a += float((mine * mine).sum()); den_b += float((ref * ref).sum())
+    cos = num / (np.sqrt(den_a * den_b) + 1e-30)
+    assert cos > 0.98 and 0.9 < np.sqrt(den_a / den_b) < 1.1, (cos, den_a, den_b)
