@@ -41,6 +41,8 @@ def main():
     ap.add_argument('--probe-steps', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--model', choices=('edsr', 'rcan'), default='edsr',
+                    help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), for information')
     ap.add_argument('--device-patches', action='store_true',
                     help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
     args = ap.parse_args()
@@ -70,8 +72,9 @@ def main():
     from rumpy_amd.shared_framework.models import define_model
 
     N = args.batch
+    flop_per_patch = FLOP_PER_PATCH_TRAIN if args.model == 'edsr' else 220.04e9
     torch.manual_seed(8)                                    # reference default seed (net_train.py:20)
-    h = define_model('edsr', model_save_dir=tempfile.mkdtemp(), device=local_rank, eval_mode=False, checkpoint_load=False,
+    h = define_model(args.model, model_save_dir=tempfile.mkdtemp(), device=local_rank, eval_mode=False, checkpoint_load=False,
                      loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
     if world > 1:
         broadcast_parameters(h.net)
@@ -182,7 +185,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.manual_seed(8)
-        onet = O.build_oracle('edsr', scale=4)
+        onet = O.build_oracle(args.model, scale=4)
         oh = O.OracleHandler(onet, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
         try:
             usable = len(os.sched_getaffinity(0))
@@ -213,16 +216,17 @@ def main():
                's_per_step': round(best, 3), 'warmup_s': round(warm, 3)}
 
     if rank == 0:
-        line = {'metric': '48px LR patches/sec (train step) EDSR x4 bf16', 'value': round(value, 2), 'unit': 'LR patches/s',
+        line = {'metric': '48px LR patches/sec (train step) EDSR x4 bf16' if args.model == 'edsr' else '48px LR patches/sec (train step) RCAN x4 bf16', 'value': round(value, 2), 'unit': 'LR patches/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
                 'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
                          'random-init weights (seed 8)') if args.device_patches else
                         'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
-                'config': {'workload': 'EDSR-baseline x4 (64 feats x 16 blocks) train step, 48x48 LR patches, batch %d per GPU' % N,
+                'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)') +
+                                       ' train step, 48x48 LR patches, batch %d per GPU' % N,
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
-                           'loss': float(loss), 'train_tflops': round(value * FLOP_PER_PATCH_TRAIN / 1e12, 2),
-                           'train_mfma_frac': round(value * FLOP_PER_PATCH_TRAIN / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4)},
+                           'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),
+                           'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4)},
                 'roofline': roofline, 'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

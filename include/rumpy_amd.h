@@ -102,6 +102,8 @@ int64_t rumpy_conv_chain_xchg_bytes(int32_t nstrips);
  *   w1/b1 = conv1 forward image, relu1 = 1, scale1 = 1, mask = NULL, w2/b2 = conv2 forward image, scale2 = res_scale, T = saved activation
  * its data gradient: X = dOUT, w1 = conv2's data-gradient image, b1 = NULL, relu1 = 0, scale1 = res_scale, mask = saved T,
  *   w2 = conv1's data-gradient image, b2 = NULL, scale2 = 1, res2 = extra skip gradient or NULL; T = gradient w.r.t. the activation.
+ * RCAB (architectures.py:60-84) forward: as ResBlock with res_mode = 1, scale2 = 1 and `pool` set (the channel-attention gate
+ * and the skip follow in rumpy_ca_*); its data gradient: X = gradient after the gate, res_mode = 2, res1 = dOUT of the RCAB.
  * All tensors [N,H,W,64] bf16, W <= 48 (a strip spans the image width); `t` may be NULL (inference: the activation is not stored). */
 typedef struct {
   const void* x;
@@ -114,6 +116,12 @@ typedef struct {
   int32_t N, H, W;
   int32_t relu1;
   float scale1, scale2;
+  /* RCAB form (CALayer between the second conv and the skip, architectures.py:60-84): */
+  int32_t res_mode;    /* 0: OUT = X + ..., the residual operand is the block input (taken from LDS) ; 1: no residual ;
+                          2: the residual operand is `res1` */
+  const void* res1;    /* [N,H,W,64] bf16, res_mode 2 */
+  float* pool;         /* NULL, or per-(strip, row half) channel sums of scale2*(convB(T)+b2): [N][2*ceil(H/6)][64] fp32, the
+                          partial sums rumpy_ca_mlp_fwd reduces (same layout as rumpy_conv3x3's `pool`) */
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
 

@@ -135,7 +135,8 @@ class EvalPostArgs(_S):
 class BlockArgs(_S):
     _fields_ = [('x', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mask', c_void_p),
                 ('res2', c_void_p), ('t', c_void_p), ('out', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32),
-                ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float)]
+                ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float), ('res_mode', c_int32), ('res1', c_void_p),
+                ('pool', c_void_p)]
 
 
 class BlockChainArgs(_S):

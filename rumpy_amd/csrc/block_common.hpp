@@ -15,6 +15,7 @@ struct BlockDev {
   const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
   const uint16_t* mask; const uint16_t* res2; uint16_t* t; uint16_t* out;
   int N, H, W, sy_n, relu1; float scale1, scale2;
+  int res_mode; const uint16_t* res1; float* pool;
 };
 
 __device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p * 128 + ((chunk ^ (p & 7)) << 4)); }

@@ -89,64 +89,105 @@ __global__ void ca_bwd_reduce_kernel(const uint4* __restrict__ dy, const uint4* 
   }
 }
 
-// single workgroup: fixed-order sums over images -> bitwise reproducible parameter gradients
-__global__ void ca_mlp_bwd_kernel(rumpy_ca_mlp_bwd_args a) {
+// Backward of the squeeze-excite MLP, two launches (a single workgroup walking over the images one by one - the first
+// version - spent 200 us per channel-attention layer in dependent global-load latencies: 70 % of an RCAN training step):
+//   image kernel, one workgroup per image n: ds = sum of the pooled-gradient partials, dz = ds * s * (1 - s) (sigmoid'),
+//     dh = relu'(hidden) * W2^T dz, dpool = W1^T dh / HW.  dz replaces partial[n][0][:] for the second kernel.
+//   parameter kernel, one workgroup: dh for all images into LDS (recomputed: 64-long dot products), then the sums over images
+//     of dz x hidden (gW2), dh x mean (gW1), dz (gb2), dh (gb1): 4 groups of 64 threads take every 4th image, their partial sums
+//     are added in a fixed order -> bitwise reproducible parameter gradients.
+__global__ void __launch_bounds__(CA_MAXC) ca_mlp_bwd_image_kernel(rumpy_ca_mlp_bwd_args a) {
   __shared__ float sdz[CA_MAXC];
   __shared__ float sdh[CA_MAXR];
-  const int c = threadIdx.x;
-  float gw2[CA_MAXR > 16 ? 16 : CA_MAXR];  // Cr <= 16 rows kept in registers per thread c
+  const int c = threadIdx.x, n = blockIdx.x;
+  float* part = const_cast<float*>(a.partial) + (size_t)n * a.nchunks * a.C;
+  if (c < a.C) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= a.nchunks; k += 4) {
+      s0 += part[(size_t)k * a.C + c]; s1 += part[(size_t)(k + 1) * a.C + c];
+      s2 += part[(size_t)(k + 2) * a.C + c]; s3 += part[(size_t)(k + 3) * a.C + c];
+    }
+    for (; k < a.nchunks; ++k) s0 += part[(size_t)k * a.C + c];
+    const float ds = (s0 + s1) + (s2 + s3);
+    const float s = a.gate[(size_t)n * a.C + c];
+    const float dz = ds * s * (1.f - s);
+    sdz[c] = dz;
+    part[c] = dz;                       // this thread was the only reader of column c
+  }
+  __syncthreads();
+  if (c < a.Cr) {
+    float dh = 0.f;
+    for (int k = 0; k < a.C; ++k) dh = fmaf(a.w2[(size_t)k * a.Cr + c], sdz[k], dh);
+    sdh[c] = (a.hidden[(size_t)n * a.Cr + c] > 0.f) ? dh : 0.f;
+  }
+  __syncthreads();
+  if (c < a.C) {
+    float dp = 0.f;
+    for (int r = 0; r < a.Cr; ++r) dp = fmaf(a.w1[(size_t)r * a.C + c], sdh[r], dp);
+    a.dpool[(size_t)n * a.C + c] = dp * a.inv_hw;
+  }
+}
+
+constexpr int CA_PGROUPS = 4;
+constexpr int CA_PR = 16;                               // rows of the squeeze layer kept in registers (Cr <= 16: ca_shape_ok)
+// blockDim = CA_PGROUPS * Cp (Cp = C rounded up to 64); dynamic LDS: sdh[N][Cr], red[groups][Cp][2*Cr+1], redb1[groups][Cr]
+__global__ void ca_mlp_bwd_params_kernel(rumpy_ca_mlp_bwd_args a, int Cp) {
+  extern __shared__ float dyn[];
+  float* sdh = dyn;
+  float* red = sdh + a.N * a.Cr;
+  const int RS = 2 * a.Cr + 1;
+  float* redb1 = red + CA_PGROUPS * Cp * RS;
+  const int tid = threadIdx.x, c = tid % Cp, grp = tid / Cp, nthreads = CA_PGROUPS * Cp;
+  const float* dzp = a.partial;                        // dz[n][c] = partial[n][0][c]
+  const size_t nstride = (size_t)a.nchunks * a.C;
+  for (int i = tid; i < a.N * a.Cr; i += nthreads) {
+    const int n = i / a.Cr, r = i - n * a.Cr;
+    float dh = 0.f;
+    for (int k = 0; k < a.C; ++k) dh = fmaf(a.w2[(size_t)k * a.Cr + r], dzp[n * nstride + k], dh);
+    sdh[i] = (a.hidden[(size_t)n * a.Cr + r] > 0.f) ? dh : 0.f;
+  }
+  __syncthreads();
+  float gw2[CA_PR], gw1c[CA_PR];
+#pragma unroll
+  for (int r = 0; r < CA_PR; ++r) { gw2[r] = 0.f; gw1c[r] = 0.f; }
   float gb2 = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) gw2[r] = 0.f;
-  float gw1c[16];  // thread c accumulates gW1[r][c] for r < Cr
-#pragma unroll
-  for (int r = 0; r < 16; ++r) gw1c[r] = 0.f;
-  float gb1 = 0.f;  // thread r < Cr
-  for (int n = 0; n < a.N; ++n) {
-    float dz = 0.f;
-    if (c < a.C) {
-      float ds = 0.f;
-      for (int k = 0; k < a.nchunks; ++k) ds += a.partial[((size_t)n * a.nchunks + k) * a.C + c];
-      const float s = a.gate[(size_t)n * a.C + c];
-      dz = ds * s * (1.f - s);
-      sdz[c] = dz;
-      gb2 += dz;
-    }
-    __syncthreads();
-    if (c < a.Cr) {
-      float dh = 0.f;
-      for (int k = 0; k < a.C; ++k) dh = fmaf(a.w2[(size_t)k * a.Cr + c], sdz[k], dh);
-      dh = (a.hidden[(size_t)n * a.Cr + c] > 0.f) ? dh : 0.f;
-      sdh[c] = dh;
-      gb1 += dh;
-    }
-    __syncthreads();
-    if (c < a.C) {
-      float dp = 0.f;
+  if (c < a.C) {
+    for (int n = grp; n < a.N; n += CA_PGROUPS) {
+      const float dz = dzp[n * nstride + c];
       const float pm = a.mean[(size_t)n * a.C + c];
+      gb2 += dz;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < CA_PR; ++r) {
         if (r < a.Cr) {
-          dp = fmaf(a.w1[(size_t)r * a.C + c], sdh[r], dp);
           gw2[r] = fmaf(dz, a.hidden[(size_t)n * a.Cr + r], gw2[r]);
-          gw1c[r] = fmaf(sdh[r], pm, gw1c[r]);
+          gw1c[r] = fmaf(sdh[n * a.Cr + r], pm, gw1c[r]);
         }
       }
-      a.dpool[(size_t)n * a.C + c] = dp * a.inv_hw;
     }
-    __syncthreads();
   }
-  if (c < a.C) {
+  float* mine = red + ((size_t)grp * Cp + c) * RS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r < a.Cr) {
-        a.gw2[(size_t)c * a.Cr + r] = gw2[r] * a.scale;
-        a.gw1[(size_t)r * a.C + c] = gw1c[r] * a.scale;
-      }
-    }
-    a.gb2[c] = gb2 * a.scale;
+  for (int r = 0; r < CA_PR; ++r) {
+    if (r < a.Cr) { mine[r] = gw2[r]; mine[a.Cr + r] = gw1c[r]; }
   }
-  if (c < a.Cr) a.gb1[c] = gb1 * a.scale;
+  mine[2 * a.Cr] = gb2;
+  if (c < a.Cr) {
+    float gb1 = 0.f;
+    for (int n = grp; n < a.N; n += CA_PGROUPS) gb1 += sdh[n * a.Cr + c];
+    redb1[grp * a.Cr + c] = gb1;
+  }
+  __syncthreads();
+  if (grp == 0 && c < a.C) {
+    auto sum4 = [&](int idx) { return (red[((size_t)0 * Cp + c) * RS + idx] + red[((size_t)1 * Cp + c) * RS + idx]) +
+                                      (red[((size_t)2 * Cp + c) * RS + idx] + red[((size_t)3 * Cp + c) * RS + idx]); };
+    for (int r = 0; r < a.Cr; ++r) {
+      a.gw2[(size_t)c * a.Cr + r] = sum4(r) * a.scale;
+      a.gw1[(size_t)r * a.C + c] = sum4(a.Cr + r) * a.scale;
+    }
+    a.gb2[c] = sum4(2 * a.Cr) * a.scale;
+    if (c < a.Cr) a.gb1[c] = ((redb1[c] + redb1[a.Cr + c]) + (redb1[2 * a.Cr + c] + redb1[3 * a.Cr + c])) * a.scale;
+  }
 }
 
 // dt = dy * gate + dpool
@@ -199,7 +240,11 @@ extern "C" int rumpy_ca_mlp_bwd(const rumpy_ca_mlp_bwd_args* p, void* stream) {
   if (!p || !p->partial || !p->mean || !p->hidden || !p->gate || !p->w1 || !p->w2 || !p->dpool || !p->gw1 || !p->gb1 || !p->gw2 || !p->gb2) {
     rumpy_set_error("rumpy_ca_mlp_bwd: null pointer"); return RUMPY_E_ARG; }
   if (!ca_shape_ok(p->C, p->Cr) || p->N <= 0 || p->nchunks <= 0) { rumpy_set_error("rumpy_ca_mlp_bwd: unsupported shape"); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(1), dim3(CA_MAXC), 0, (hipStream_t)stream, *p);
+  const int Cp = (p->C + 63) / 64 * 64;
+  const size_t dyn = ((size_t)p->N * p->Cr + (size_t)CA_PGROUPS * Cp * (2 * p->Cr + 1) + (size_t)CA_PGROUPS * p->Cr) * sizeof(float);
+  if (p->Cr > CA_PR || dyn > 60 * 1024) { rumpy_set_error("rumpy_ca_mlp_bwd: shape too large for the parameter kernel (N=%d C=%d Cr=%d)", p->N, p->C, p->Cr); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(ca_mlp_bwd_image_kernel, dim3(p->N), dim3(CA_MAXC), 0, (hipStream_t)stream, *p);
+  hipLaunchKernelGGL(ca_mlp_bwd_params_kernel, dim3(1), dim3(CA_PGROUPS * Cp), dyn, (hipStream_t)stream, *p, Cp);
   return rumpy_check_launch("rumpy_ca_mlp_bwd");
 }
 extern "C" int rumpy_ca_bwd_apply(const rumpy_ca_bwd_apply_args* p, void* stream) {

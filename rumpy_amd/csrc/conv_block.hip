@@ -21,6 +21,10 @@
 // prepared per phase and every read is base + immediate.
 #include "block_common.hpp"
 
+// GEN = false: the ResBlock form (residual operand = block input, read from LDS).  GEN = true: the general form used for
+// RCABs - res_mode 1 (no residual) or 2 (residual operand res1 from HBM, prefetched under the second sweep) and the
+// per-(strip, row half) channel sums of scale2 * (convB(T) + b2) for the channel-attention pool.
+template <bool GEN>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
   unsigned char* const ldx = lds;
@@ -145,9 +149,28 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    // GEN, res_mode 2: the residual vectors are requested before the sweep and land under it
+    unsigned roff[4], rsoff;
+    uint4 P1p[GEN ? 4 : 1];
+    uint2 P1s = make_uint2(0, 0);
+    if (GEN) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+        const int y = sy * BSH + 3 * rh + r, xx = 16 * c + px;
+        roff[k] = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
+        P1p[k] = make_uint4(0, 0, 0, 0);
+        if (a.res_mode == 2) P1p[k] = *reinterpret_cast<const uint4*>(a.res1 + (roff[k] != 0xffffffffu ? roff[k] : 0u));
+      }
+      const int y = sy * BSH + 3 * rh + 2, xx = 32 + px;
+      rsoff = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0) : 0xffffffffu;
+      if (a.res_mode == 2) P1s = *reinterpret_cast<const uint2*>(a.res1 + (rsoff != 0xffffffffu ? rsoff : 0u));
+    }
     unsigned off[8][2];
     sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
     block_sweep<3>(acc, F, lds, off);
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};                         // GEN pool sums: single tile, channels 4g .. 4g+3 of the wave's 16
+    float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    //                paired tiles, channels 4(g&~1) .. +7
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -158,9 +181,23 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
       const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
       if (y < a.H && xx < a.W) {
-        unpack8(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);   // residual = the input tile
+        if (!GEN) {
+          unpack8(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);   // residual = the input tile
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+          for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= a.scale2;
+          if (a.pool) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ps8[j] += v[j];
+          }
+          if (a.res_mode == 2) {
+            unpack8(P1p[GEN ? k : 0], m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += m[j];
+          }
+        }
         const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair);
         if (a.res2) {
           unpack8(*reinterpret_cast<const uint4*>(a.res2 + o), m);
@@ -176,9 +213,23 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       if (y < a.H && xx < a.W) {
         float v[4] = {acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]};
         float m[4];
-        unpack4_bf16(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
+        if (!GEN) {
+          unpack4_bf16(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+          for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= a.scale2;
+          if (a.pool) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ps[j] += v[j];
+          }
+          if (a.res_mode == 2) {
+            unpack4_bf16(P1s, m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += m[j];
+          }
+        }
         const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
         if (a.res2) {
           unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + o), m);
@@ -186,6 +237,30 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
         *reinterpret_cast<uint2*>(a.out + o) = pack4_bf16(v[0], v[1], v[2], v[3]);
+      }
+    }
+    if (GEN && a.pool) {
+      // per-(strip, row half) channel sums: pool[n][2*sy + rh][channel] (the layout of conv_strip.hip with one column strip):
+      // reduce over the 16 pixel lanes, fold the odd-g lanes into the even ones, add the single tile's 4+4 channels
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = ps8[j];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        t += __shfl_xor(t, 16);
+        ps8[j] = t;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = ps[j];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        const float up = __shfl_xor(t, 16);             // the same sums of lane group g ^ 1
+        ps8[j] += (g & 1) ? up : t;
+        ps8[4 + j] += (g & 1) ? t : up;
+      }
+      if (px == 0 && !(g & 1)) {
+        float* pp = a.pool + ((size_t)(n * a.sy_n * 2 + 2 * sy + rh)) * 64 + 16 * q + 4 * g;
+        *reinterpret_cast<float4*>(pp) = make_float4(ps8[0], ps8[1], ps8[2], ps8[3]);
+        *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
       }
     }
   }
@@ -198,9 +273,12 @@ extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
   d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
   d.mask = (const uint16_t*)p->mask; d.res2 = (const uint16_t*)p->res2; d.t = (uint16_t*)p->t; d.out = (uint16_t*)p->out;
   d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = (p->H + BSH - 1) / BSH; d.relu1 = p->relu1; d.scale1 = p->scale1; d.scale2 = p->scale2;
+  d.res_mode = p->res_mode; d.res1 = (const uint16_t*)p->res1; d.pool = p->pool;
+  if (p->res_mode < 0 || p->res_mode > 2 || (p->res_mode == 2 && !p->res1)) { rumpy_set_error("rumpy_conv_block: bad res_mode / res1"); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   rumpy_probe_pre(5, s);
-  hipLaunchKernelGGL(conv_block_kernel, dim3(d.N * d.sy_n), dim3(BTHREADS), 0, s, d);
+  if (p->res_mode == 0 && !p->pool) hipLaunchKernelGGL(conv_block_kernel<false>, dim3(d.N * d.sy_n), dim3(BTHREADS), 0, s, d);
+  else hipLaunchKernelGGL(conv_block_kernel<true>, dim3(d.N * d.sy_n), dim3(BTHREADS), 0, s, d);
   rumpy_probe_post(5, s);
   return rumpy_check_launch("rumpy_conv_block");
 }

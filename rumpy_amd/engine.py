@@ -241,15 +241,22 @@ class SREngine:
                     mean = self._new(plan, N, F, dtype=torch.float32)
                     hid = self._new(plan, N, ca.Cr, dtype=torch.float32)
                     gate = self._new(plan, N, F, dtype=torch.float32)
-                    self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
-                    self._conv(fwd, t1, c2, N, H, W, t2, pool=pool)
+                    fused = self.use_block_kernel and W <= 48
+                    if fused:   # conv -> ReLU -> conv (+ pool partial sums) in one launch, no residual yet (the gate comes first)
+                        fwd.append(('rumpy_conv_block', L.BlockArgs(
+                            x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed), mask=None,
+                            res2=None, t=_ptr(t1), out=_ptr(t2), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, res_mode=1,
+                            res1=None, pool=_ptr(pool))))
+                    else:
+                        self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
+                        self._conv(fwd, t1, c2, N, H, W, t2, pool=pool)
                     fwd.append(('rumpy_ca_mlp_fwd', L.CaMlpFwdArgs(pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2),
                                                                     b2=_ptr(ca.b2), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate),
                                                                     N=N, C=F, Cr=ca.Cr, ntiles=tiles, inv_hw=1.0 / (H * W))))
                     fwd.append(('rumpy_ca_scale_res_fwd', L.CaScaleArgs(t=_ptr(t2), res=_ptr(cur), gate=_ptr(gate), out=_ptr(y),
                                                                          N=N, HW=H * W, C=F)))
 
-                    def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate):
+                    def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused):
                         # y = x + t2*gate:  dgate = sum(g*t2) -> MLP backward -> dpool ; dt2 = g*gate + dpool
                         nchunks = (H * W + 127) // 128
                         part = self._new(plan, N, nchunks, F, dtype=torch.float32)
@@ -265,9 +272,15 @@ class SREngine:
                         plan.scaled.append(a)
                         bwd.append(('rumpy_ca_bwd_apply', L.CaBwdApplyArgs(dy=_ptr(g_out), gate=_ptr(gate), dpool=_ptr(dpool),
                                                                             dt=_ptr(dt2), N=N, HW=H * W, C=F)))
-                        self._conv(bwd, dt2, c2, N, H, W, dt1, dgrad=True, mask=t1)
+                        if fused:   # both data gradients in one launch; the skip operand is the RCAB's incoming gradient
+                            bwd.append(('rumpy_conv_block', L.BlockArgs(
+                                x=_ptr(dt2), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1), res2=_ptr(extra),
+                                t=_ptr(dt1), out=_ptr(dx), N=N, H=H, W=W, relu1=0, scale1=1.0, scale2=1.0, res_mode=2,
+                                res1=_ptr(g_out), pool=None)))
+                        else:
+                            self._conv(bwd, dt2, c2, N, H, W, dt1, dgrad=True, mask=t1)
+                            self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
                         wjobs.append((c2, t1, dt2, H, W, 0, 1.0, 4))
-                        self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
                         wjobs.append((c1, x_in, dt1, H, W, 0, 1.0, 4))
                         return dx
                     nodes.append(node)

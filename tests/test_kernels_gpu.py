@@ -568,3 +568,38 @@ def test_block_chain_rejects_shapes_that_cannot_be_resident():
     assert L.lib().rumpy_block_chain(a, None) == -1
     a = L.BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
     assert L.lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (8, 48, 48)])
+def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
+    """general form of the block kernel (RCAB): no residual + pool partial sums forward; external residual operand backward"""
+    gen = np.random.default_rng(300 + H + W)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
+                            torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
+    pa, pb = mk(), mk()
+    rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    x = rnd()
+    # forward: t1 = relu(conv1 x + b1); t2 = conv2 t1 + b2 with per-(strip, row half) channel sums
+    t_ref, _ = hip_conv(x, pa, N, H, W, relu=True)
+    y_ref, pool_ref = hip_conv(t_ref, pb, N, H, W, pool=True)
+    tiles = int(L.lib().rumpy_conv_pool_tiles(H, W, 1))
+    t = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    y = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    pool = torch.full((N, tiles, 64), float('nan'), dtype=torch.float32, device=DEV)
+    a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                    t=t.data_ptr(), out=y.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, res_mode=1, pool=pool.data_ptr())
+    L.call('rumpy_conv_block', a, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(t, t_ref) and torch.equal(y, y_ref)
+    assert_f32_close(pool, pool_ref, 'pool partial sums', rel=1e-5)
+    # data gradient: dt1 = mask(t1) . conv2^T(dt2); dx = conv1^T(dt1) + g + extra
+    dt2, g, extra = rnd(), rnd(), rnd()
+    d1_ref, _ = hip_conv(dt2, pb, N, H, W, dgrad=True, mask=t_ref)
+    dx_ref, _ = hip_conv(d1_ref, pa, N, H, W, dgrad=True, res1=g, res2=extra)
+    d1 = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    dx = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    a = L.BlockArgs(x=dt2.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=t_ref.data_ptr(), res2=extra.data_ptr(),
+                    t=d1.data_ptr(), out=dx.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=1.0, scale2=1.0, res_mode=2, res1=g.data_ptr())
+    L.call('rumpy_conv_block', a, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(d1, d1_ref) and torch.equal(dx, dx_ref)
