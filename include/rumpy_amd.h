@@ -304,7 +304,11 @@ typedef struct {
   float inv_hw;
   float scale;
 } rumpy_ca_mlp_bwd_args;
-int rumpy_ca_mlp_bwd(const rumpy_ca_mlp_bwd_args* a, void* stream);
+int rumpy_ca_mlp_bwd(const rumpy_ca_mlp_bwd_args* a, void* stream);   /* gw1 = gb1 = gw2 = gb2 = NULL: dpool only (parameter
+                                                                          gradients deferred to rumpy_ca_mlp_bwd_params) */
+/* the parameter gradients of `nitems` channel-attention layers in one launch; items: DEVICE array of the arguments the
+ * per-layer calls were made with (same N, C, Cr), now with the four gradient pointers set; run after all of them */
+int rumpy_ca_mlp_bwd_params(const rumpy_ca_mlp_bwd_args* items_device, int32_t nitems, int32_t N, int32_t C, int32_t Cr, void* stream);
 
 /* dt = dy * gate[n][c] + dpool[n][c] */
 typedef struct {

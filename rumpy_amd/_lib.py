@@ -179,6 +179,7 @@ SYMBOLS = {
     'rumpy_ca_scale_res_fwd': (C.c_int, [_P(CaScaleArgs), c_void_p]),
     'rumpy_ca_bwd_reduce': (C.c_int, [_P(CaBwdReduceArgs), c_void_p]),
     'rumpy_ca_mlp_bwd': (C.c_int, [_P(CaMlpBwdArgs), c_void_p]),
+    'rumpy_ca_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_ca_bwd_apply': (C.c_int, [_P(CaBwdApplyArgs), c_void_p]),
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),
     'rumpy_sumsq': (C.c_int, [_P(SumsqArgs), c_void_p]),

@@ -132,8 +132,7 @@ __global__ void __launch_bounds__(CA_MAXC) ca_mlp_bwd_image_kernel(rumpy_ca_mlp_
 constexpr int CA_PGROUPS = 4;
 constexpr int CA_PR = 16;                               // rows of the squeeze layer kept in registers (Cr <= 16: ca_shape_ok)
 // blockDim = CA_PGROUPS * Cp (Cp = C rounded up to 64); dynamic LDS: sdh[N][Cr], red[groups][Cp][2*Cr+1], redb1[groups][Cr]
-__global__ void ca_mlp_bwd_params_kernel(rumpy_ca_mlp_bwd_args a, int Cp) {
-  extern __shared__ float dyn[];
+__device__ __forceinline__ void ca_mlp_bwd_params_body(const rumpy_ca_mlp_bwd_args& a, int Cp, float* dyn) {
   float* sdh = dyn;
   float* red = sdh + a.N * a.Cr;
   const int RS = 2 * a.Cr + 1;
@@ -190,6 +189,15 @@ __global__ void ca_mlp_bwd_params_kernel(rumpy_ca_mlp_bwd_args a, int Cp) {
   }
 }
 
+extern __shared__ float ca_dyn_lds[];
+__global__ void ca_mlp_bwd_params_kernel(rumpy_ca_mlp_bwd_args a, int Cp) { ca_mlp_bwd_params_body(a, Cp, ca_dyn_lds); }
+// all channel-attention layers of a network in ONE launch (one workgroup per layer, arguments from a device table): the
+// parameter gradients are off the critical path of the backward pass, 200 launches of ~13 us each were 12 % of an RCAN step
+__global__ void ca_mlp_bwd_params_batch_kernel(const rumpy_ca_mlp_bwd_args* __restrict__ items, int Cp) {
+  const rumpy_ca_mlp_bwd_args a = items[blockIdx.x];
+  ca_mlp_bwd_params_body(a, Cp, ca_dyn_lds);
+}
+
 // dt = dy * gate + dpool
 __global__ void ca_bwd_apply_kernel(const uint4* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,
                                     uint4* __restrict__ dt, int HW, int C, size_t total_vec) {
@@ -236,16 +244,30 @@ extern "C" int rumpy_ca_bwd_reduce(const rumpy_ca_bwd_reduce_args* p, void* stre
                      (const uint4*)p->t, p->partial, p->HW, p->C, nchunks);
   return rumpy_check_launch("rumpy_ca_bwd_reduce");
 }
+static size_t ca_params_lds(int N, int C, int Cr, int* Cp) {
+  *Cp = (C + 63) / 64 * 64;
+  return ((size_t)N * Cr + (size_t)CA_PGROUPS * *Cp * (2 * Cr + 1) + (size_t)CA_PGROUPS * Cr) * sizeof(float);
+}
 extern "C" int rumpy_ca_mlp_bwd(const rumpy_ca_mlp_bwd_args* p, void* stream) {
-  if (!p || !p->partial || !p->mean || !p->hidden || !p->gate || !p->w1 || !p->w2 || !p->dpool || !p->gw1 || !p->gb1 || !p->gw2 || !p->gb2) {
+  if (!p || !p->partial || !p->mean || !p->hidden || !p->gate || !p->w1 || !p->w2 || !p->dpool) {
     rumpy_set_error("rumpy_ca_mlp_bwd: null pointer"); return RUMPY_E_ARG; }
+  const bool with_params = p->gw1 || p->gb1 || p->gw2 || p->gb2;
+  if (with_params && (!p->gw1 || !p->gb1 || !p->gw2 || !p->gb2)) { rumpy_set_error("rumpy_ca_mlp_bwd: give all four gradient pointers or none"); return RUMPY_E_ARG; }
   if (!ca_shape_ok(p->C, p->Cr) || p->N <= 0 || p->nchunks <= 0) { rumpy_set_error("rumpy_ca_mlp_bwd: unsupported shape"); return RUMPY_E_ARG; }
-  const int Cp = (p->C + 63) / 64 * 64;
-  const size_t dyn = ((size_t)p->N * p->Cr + (size_t)CA_PGROUPS * Cp * (2 * p->Cr + 1) + (size_t)CA_PGROUPS * p->Cr) * sizeof(float);
+  int Cp;
+  const size_t dyn = ca_params_lds(p->N, p->C, p->Cr, &Cp);
   if (p->Cr > CA_PR || dyn > 60 * 1024) { rumpy_set_error("rumpy_ca_mlp_bwd: shape too large for the parameter kernel (N=%d C=%d Cr=%d)", p->N, p->C, p->Cr); return RUMPY_E_ARG; }
   hipLaunchKernelGGL(ca_mlp_bwd_image_kernel, dim3(p->N), dim3(CA_MAXC), 0, (hipStream_t)stream, *p);
-  hipLaunchKernelGGL(ca_mlp_bwd_params_kernel, dim3(1), dim3(CA_PGROUPS * Cp), dyn, (hipStream_t)stream, *p, Cp);
+  if (with_params) hipLaunchKernelGGL(ca_mlp_bwd_params_kernel, dim3(1), dim3(CA_PGROUPS * Cp), dyn, (hipStream_t)stream, *p, Cp);
   return rumpy_check_launch("rumpy_ca_mlp_bwd");
+}
+extern "C" int rumpy_ca_mlp_bwd_params(const rumpy_ca_mlp_bwd_args* items_device, int32_t nitems, int32_t N, int32_t C, int32_t Cr, void* stream) {
+  if (!items_device || nitems <= 0 || N <= 0 || !ca_shape_ok(C, Cr)) { rumpy_set_error("rumpy_ca_mlp_bwd_params: bad argument"); return RUMPY_E_ARG; }
+  int Cp;
+  const size_t dyn = ca_params_lds(N, C, Cr, &Cp);
+  if (Cr > CA_PR || dyn > 60 * 1024) { rumpy_set_error("rumpy_ca_mlp_bwd_params: shape too large (N=%d C=%d Cr=%d)", N, C, Cr); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(ca_mlp_bwd_params_batch_kernel, dim3(nitems), dim3(CA_PGROUPS * Cp), dyn, (hipStream_t)stream, items_device, Cp);
+  return rumpy_check_launch("rumpy_ca_mlp_bwd_params");
 }
 extern "C" int rumpy_ca_bwd_apply(const rumpy_ca_bwd_apply_args* p, void* stream) {
   if (!p || !p->dy || !p->gate || !p->dpool || !p->dt || p->N <= 0 || p->HW <= 0 || p->C <= 0 || p->C % 8) { rumpy_set_error("rumpy_ca_bwd_apply: bad argument"); return RUMPY_E_ARG; }

@@ -22,7 +22,6 @@ typedef __attribute__((address_space(3))) unsigned char* lds_u8;
 __device__ __attribute__((aligned(256))) uint4 g_zero_page[16];   // zero-initialised; source of out-of-image pixels
 
 constexpr int DX_PIX = 192;                        // 10x18 = 180 halo pixels, rounded up to 24 DMA pieces of 8 pixels
-constexpr int DD_PIX = 128;                        // 8x16 dy pixels = 16 pieces (MT = 4)
 // MT = 4 (64 output channels): 24 x pieces + 16 dy pieces = 40 pieces, 5 per wave.
 // MT = 1 (tail conv, dy = [N,H,W,4]): 24 x pieces + 1 dy piece (128 px x 8 B) + 7 pieces of zeros = 32, 4 per wave; the zero
 // pieces double as the all-zero channels 4..15 of the transposed dy reads.

@@ -177,6 +177,7 @@ class SREngine:
         free_pool = []
         protected = []          # data_ptrs of live skip sources (eval-mode buffer reuse must not recycle them)
         plan.scaled = []
+        plan.ca_param_items = []
 
         def act():
             if not train and free_pool:
@@ -268,8 +269,12 @@ class SREngine:
                                            w2=_ptr(ca.w2), dpool=_ptr(dpool), gw1=_ptr(ca.gw1), gb1=_ptr(ca.gb1),
                                            gw2=_ptr(ca.gw2), gb2=_ptr(ca.gb2), N=N, C=F, Cr=ca.Cr, nchunks=nchunks,
                                            inv_hw=1.0 / (H * W), scale=1.0)
+                        # per layer only dpool (on the critical path); the parameter gradients of ALL channel-attention layers
+                        # come from one launch after the backward chain (rumpy_ca_mlp_bwd_params over a device table)
+                        full = L.CaMlpBwdArgs.from_buffer_copy(a)
+                        a.gw1 = a.gb1 = a.gw2 = a.gb2 = None
                         bwd.append(('rumpy_ca_mlp_bwd', a))
-                        plan.scaled.append(a)
+                        plan.ca_param_items.append(full)
                         bwd.append(('rumpy_ca_bwd_apply', L.CaBwdApplyArgs(dy=_ptr(g_out), gate=_ptr(gate), dpool=_ptr(dpool),
                                                                             dt=_ptr(dt2), N=N, HW=H * W, C=F)))
                         if fused:   # both data gradients in one launch; the skip operand is the RCAB's incoming gradient
@@ -467,6 +472,14 @@ class SREngine:
         plan.reduce_dev.copy_(torch.from_numpy(raw), non_blocking=False)
         for a in plan.scaled:
             a.scale = gs
+        if plan.ca_param_items:
+            for a in plan.ca_param_items:
+                a.scale = gs
+            arr = (L.CaMlpBwdArgs * len(plan.ca_param_items))(*plan.ca_param_items)
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            if getattr(plan, 'ca_params_dev', None) is None:
+                plan.ca_params_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
+            plan.ca_params_dev.copy_(torch.from_numpy(raw), non_blocking=False)
         plan.grad_scale = gs
 
     # ------------------------------------------------------------------ execution
@@ -515,6 +528,7 @@ class SREngine:
             L.call('rumpy_nchw_to_nhwc4', L.NchwToNhwc4Args(src=_ptr(gout), dst=_ptr(plan.dy4), N=plan.N, C=gout.shape[1], H=h, W=w), stream)
         self._set_grad_scale(plan, float(grad_scale))
         self._run(plan.bwd, stream)
+        self._ca_param_grads(plan, stream)
         for mt in (4, 1):
             if mt in plan.job_dev:
                 dev, n = plan.job_dev[mt]
@@ -559,8 +573,15 @@ class SREngine:
         plan.graph.replay()
         return plan.out, plan.loss, plan
 
+    def _ca_param_grads(self, plan, stream):
+        if plan.ca_param_items:
+            a0 = plan.ca_param_items[0]
+            L.check(self.lib.rumpy_ca_mlp_bwd_params(_ptr(plan.ca_params_dev), len(plan.ca_param_items), a0.N, a0.C, a0.Cr, stream),
+                    'rumpy_ca_mlp_bwd_params')
+
     def _backward_launches(self, plan, stream):
         self._run(plan.bwd, stream)
+        self._ca_param_grads(plan, stream)
         for mt in (4, 1):
             if mt in plan.job_dev:
                 dev, n = plan.job_dev[mt]
