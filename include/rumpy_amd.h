@@ -320,6 +320,27 @@ typedef struct {
 } rumpy_ca_bwd_apply_args;
 int rumpy_ca_bwd_apply(const rumpy_ca_bwd_apply_args* a, void* stream);
 
+/* ---- fused forms (what the engine launches): the MLP is recomputed per workgroup inside the streaming kernel ----
+ * forward: rumpy_ca_mlp_fwd + rumpy_ca_scale_res_fwd in one launch; backward: the dpool part of rumpy_ca_mlp_bwd +
+ * rumpy_ca_bwd_apply in one launch, dz[n][c] (gradient before the sigmoid) is stored for rumpy_ca_mlp_bwd_params
+ * (pass it there as `partial` with nchunks = 1).  Results are identical to the separate calls. */
+typedef struct {
+  const float* pool; const float* w1; const float* b1; const float* w2; const float* b2;
+  float* mean; float* hidden; float* gate;     /* [N,C], [N,Cr], [N,C]: saved for the backward pass */
+  const void* t; const void* res; void* out;   /* out = res + t * gate (res may be NULL) */
+  int32_t N, HW, C, Cr, ntiles;
+  float inv_hw;
+} rumpy_ca_fwd_fused_args;
+int rumpy_ca_fwd_fused(const rumpy_ca_fwd_fused_args* a, void* stream);
+typedef struct {
+  const void* dy; const float* partial; const float* hidden; const float* gate; const float* w1; const float* w2;
+  float* dz;                                   /* [N,C] out */
+  void* dt;                                    /* dt = dy * gate + dpool */
+  int32_t N, HW, C, Cr, nchunks;
+  float inv_hw;
+} rumpy_ca_bwd_fused_args;
+int rumpy_ca_bwd_fused(const rumpy_ca_bwd_fused_args* a, void* stream);
+
 /* ---- optimizer: torch.optim.Adam semantics (base_architecture.py:93-95,437), flat fp32 buffers ---- */
 typedef struct {
   float lr, beta1, beta2, eps;

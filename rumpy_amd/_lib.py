@@ -113,6 +113,18 @@ class CaBwdApplyArgs(_S):
                 ('N', c_int32), ('HW', c_int32), ('C', c_int32)]
 
 
+class CaFwdFusedArgs(_S):
+    _fields_ = [('pool', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mean', c_void_p),
+                ('hidden', c_void_p), ('gate', c_void_p), ('t', c_void_p), ('res', c_void_p), ('out', c_void_p),
+                ('N', c_int32), ('HW', c_int32), ('C', c_int32), ('Cr', c_int32), ('ntiles', c_int32), ('inv_hw', c_float)]
+
+
+class CaBwdFusedArgs(_S):
+    _fields_ = [('dy', c_void_p), ('partial', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('w1', c_void_p), ('w2', c_void_p),
+                ('dz', c_void_p), ('dt', c_void_p), ('N', c_int32), ('HW', c_int32), ('C', c_int32), ('Cr', c_int32),
+                ('nchunks', c_int32), ('inv_hw', c_float)]
+
+
 class AdamHyper(_S):
     _fields_ = [('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float), ('bias_c1', c_float),
                 ('sqrt_bias_c2', c_float), ('grad_mult', c_float), ('max_norm', c_float)]
@@ -179,6 +191,8 @@ SYMBOLS = {
     'rumpy_ca_scale_res_fwd': (C.c_int, [_P(CaScaleArgs), c_void_p]),
     'rumpy_ca_bwd_reduce': (C.c_int, [_P(CaBwdReduceArgs), c_void_p]),
     'rumpy_ca_mlp_bwd': (C.c_int, [_P(CaMlpBwdArgs), c_void_p]),
+    'rumpy_ca_fwd_fused': (C.c_int, [_P(CaFwdFusedArgs), c_void_p]),
+    'rumpy_ca_bwd_fused': (C.c_int, [_P(CaBwdFusedArgs), c_void_p]),
     'rumpy_ca_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_ca_bwd_apply': (C.c_int, [_P(CaBwdApplyArgs), c_void_p]),
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),

@@ -217,6 +217,121 @@ __global__ void ca_bwd_apply_kernel(const uint4* __restrict__ dy, const float* _
   }
 }
 
+// ---- fused forms used by the engine: the squeeze-excite MLP is ~600 flops per image, so every workgroup of the streaming
+// kernel recomputes it for its image (a few KB of L2 reads) instead of waiting for a separate launch; workgroup 0 of each
+// image also stores what the backward pass needs.  Same arithmetic, same order as the separate kernels: identical results.
+struct CaFwdFused {
+  const float* pool; const float* w1; const float* b1; const float* w2; const float* b2;
+  float* mean; float* hidden; float* gate;
+  const uint4* t; const uint4* res; uint4* out;
+  int N, HW, C, Cr, ntiles, per_image; float inv_hw;
+};
+__global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
+  __shared__ float sp[CA_MAXC];
+  __shared__ float sh[CA_MAXR];
+  __shared__ float sg[CA_MAXC];
+  const int n = blockIdx.x / a.per_image, j = blockIdx.x - n * a.per_image, c = threadIdx.x;
+  if (c < a.C) {
+    float s = 0.f;
+    for (int t = 0; t < a.ntiles; ++t) s += a.pool[((size_t)n * a.ntiles + t) * a.C + c];
+    s *= a.inv_hw;
+    sp[c] = s;
+    if (j == 0) a.mean[(size_t)n * a.C + c] = s;
+  }
+  __syncthreads();
+  if (c < a.Cr) {
+    float h = a.b1[c];
+    for (int k = 0; k < a.C; ++k) h = fmaf(a.w1[(size_t)c * a.C + k], sp[k], h);
+    h = fmaxf(h, 0.f);
+    sh[c] = h;
+    if (j == 0) a.hidden[(size_t)n * a.Cr + c] = h;
+  }
+  __syncthreads();
+  if (c < a.C) {
+    float z = a.b2[c];
+    for (int r = 0; r < a.Cr; ++r) z = fmaf(a.w2[(size_t)c * a.Cr + r], sh[r], z);
+    const float gt = 1.f / (1.f + expf(-z));
+    sg[c] = gt;
+    if (j == 0) a.gate[(size_t)n * a.C + c] = gt;
+  }
+  __syncthreads();
+  const int cv = a.C / 8;
+  const size_t img_vec = (size_t)a.HW * cv, base = (size_t)n * img_vec;
+  for (size_t v = (size_t)j * 256 + threadIdx.x; v < img_vec; v += (size_t)a.per_image * 256) {
+    const size_t i = base + v;
+    const float* gp = sg + (int)(v % cv) * 8;
+    const uint4 tv = a.t[i];
+    float x[4], y[4], ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+    unpack4_bf16(make_uint2(tv.x, tv.y), x);
+    unpack4_bf16(make_uint2(tv.z, tv.w), y);
+    if (a.res) {
+      const uint4 rv = a.res[i];
+      unpack4_bf16(make_uint2(rv.x, rv.y), ra);
+      unpack4_bf16(make_uint2(rv.z, rv.w), rb);
+    }
+    const uint2 lo = pack4_bf16(fmaf(x[0], gp[0], ra[0]), fmaf(x[1], gp[1], ra[1]), fmaf(x[2], gp[2], ra[2]), fmaf(x[3], gp[3], ra[3]));
+    const uint2 hi = pack4_bf16(fmaf(y[0], gp[4], rb[0]), fmaf(y[1], gp[5], rb[1]), fmaf(y[2], gp[6], rb[2]), fmaf(y[3], gp[7], rb[3]));
+    a.out[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+}
+
+struct CaBwdFused {
+  const uint4* dy; const float* partial; const float* hidden; const float* gate; const float* w1; const float* w2;
+  float* dz; uint4* dt;
+  int N, HW, C, Cr, nchunks, per_image; float inv_hw;
+};
+__global__ void __launch_bounds__(256) ca_bwd_fused_kernel(CaBwdFused a) {
+  __shared__ float sdz[CA_MAXC];
+  __shared__ float sdh[CA_MAXR];
+  __shared__ float sg[CA_MAXC];
+  __shared__ float sdp[CA_MAXC];
+  const int n = blockIdx.x / a.per_image, j = blockIdx.x - n * a.per_image, c = threadIdx.x;
+  const float* part = a.partial + (size_t)n * a.nchunks * a.C;
+  if (c < a.C) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= a.nchunks; k += 4) {
+      s0 += part[(size_t)k * a.C + c]; s1 += part[(size_t)(k + 1) * a.C + c];
+      s2 += part[(size_t)(k + 2) * a.C + c]; s3 += part[(size_t)(k + 3) * a.C + c];
+    }
+    for (; k < a.nchunks; ++k) s0 += part[(size_t)k * a.C + c];
+    const float ds = (s0 + s1) + (s2 + s3);
+    const float s = a.gate[(size_t)n * a.C + c];
+    const float dz = ds * s * (1.f - s);
+    sdz[c] = dz;
+    sg[c] = s;
+    if (j == 0) a.dz[(size_t)n * a.C + c] = dz;          // for the parameter-gradient launch (rumpy_ca_mlp_bwd_params, nchunks = 1)
+  }
+  __syncthreads();
+  if (c < a.Cr) {
+    float dh = 0.f;
+    for (int k = 0; k < a.C; ++k) dh = fmaf(a.w2[(size_t)k * a.Cr + c], sdz[k], dh);
+    sdh[c] = (a.hidden[(size_t)n * a.Cr + c] > 0.f) ? dh : 0.f;
+  }
+  __syncthreads();
+  if (c < a.C) {
+    float dp = 0.f;
+    for (int r = 0; r < a.Cr; ++r) dp = fmaf(a.w1[(size_t)r * a.C + c], sdh[r], dp);
+    sdp[c] = dp * a.inv_hw;
+  }
+  __syncthreads();
+  const int cv = a.C / 8;
+  const size_t img_vec = (size_t)a.HW * cv, base = (size_t)n * img_vec;
+  for (size_t v = (size_t)j * 256 + threadIdx.x; v < img_vec; v += (size_t)a.per_image * 256) {
+    const size_t i = base + v;
+    const int c8 = (int)(v % cv) * 8;
+    const float* gp = sg + c8;
+    const float* dp = sdp + c8;
+    const uint4 dv = a.dy[i];
+    float x[4], y[4];
+    unpack4_bf16(make_uint2(dv.x, dv.y), x);
+    unpack4_bf16(make_uint2(dv.z, dv.w), y);
+    const uint2 lo = pack4_bf16(fmaf(x[0], gp[0], dp[0]), fmaf(x[1], gp[1], dp[1]), fmaf(x[2], gp[2], dp[2]), fmaf(x[3], gp[3], dp[3]));
+    const uint2 hi = pack4_bf16(fmaf(y[0], gp[4], dp[4]), fmaf(y[1], gp[5], dp[5]), fmaf(y[2], gp[6], dp[6]), fmaf(y[3], gp[7], dp[7]));
+    a.dt[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+}
+
 static int stream_blocks(size_t total_vec) {
   size_t b = (total_vec + 255) / 256;
   const size_t cap = (size_t)rumpy_device_cus() * 8;
@@ -275,4 +390,34 @@ extern "C" int rumpy_ca_bwd_apply(const rumpy_ca_bwd_apply_args* p, void* stream
   hipLaunchKernelGGL(ca_bwd_apply_kernel, dim3(stream_blocks(tv)), dim3(256), 0, (hipStream_t)stream, (const uint4*)p->dy,
                      p->gate, p->dpool, (uint4*)p->dt, p->HW, p->C, tv);
   return rumpy_check_launch("rumpy_ca_bwd_apply");
+}
+
+static int ca_per_image(int N, int HW, int C) {        // workgroups per image: ~4 vectors per thread, at most 8 workgroups per CU overall
+  const size_t img_vec = (size_t)HW * (C / 8);
+  int per = (int)((img_vec + 1023) / 1024);
+  const int cap = (rumpy_device_cus() * 8 + N - 1) / N;
+  if (per > cap) per = cap;
+  return per < 1 ? 1 : per;
+}
+extern "C" int rumpy_ca_fwd_fused(const rumpy_ca_fwd_fused_args* p, void* stream) {
+  if (!p || !p->pool || !p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->mean || !p->hidden || !p->gate || !p->t || !p->out) {
+    rumpy_set_error("rumpy_ca_fwd_fused: null pointer"); return RUMPY_E_ARG; }
+  if (!ca_shape_ok(p->C, p->Cr) || p->N <= 0 || p->HW <= 0 || p->ntiles <= 0) { rumpy_set_error("rumpy_ca_fwd_fused: unsupported shape"); return RUMPY_E_ARG; }
+  CaFwdFused d;
+  d.pool = p->pool; d.w1 = p->w1; d.b1 = p->b1; d.w2 = p->w2; d.b2 = p->b2; d.mean = p->mean; d.hidden = p->hidden; d.gate = p->gate;
+  d.t = (const uint4*)p->t; d.res = (const uint4*)p->res; d.out = (uint4*)p->out;
+  d.N = p->N; d.HW = p->HW; d.C = p->C; d.Cr = p->Cr; d.ntiles = p->ntiles; d.inv_hw = p->inv_hw; d.per_image = ca_per_image(p->N, p->HW, p->C);
+  hipLaunchKernelGGL(ca_fwd_fused_kernel, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
+  return rumpy_check_launch("rumpy_ca_fwd_fused");
+}
+extern "C" int rumpy_ca_bwd_fused(const rumpy_ca_bwd_fused_args* p, void* stream) {
+  if (!p || !p->dy || !p->partial || !p->hidden || !p->gate || !p->w1 || !p->w2 || !p->dz || !p->dt) {
+    rumpy_set_error("rumpy_ca_bwd_fused: null pointer"); return RUMPY_E_ARG; }
+  if (!ca_shape_ok(p->C, p->Cr) || p->N <= 0 || p->HW <= 0 || p->nchunks <= 0) { rumpy_set_error("rumpy_ca_bwd_fused: unsupported shape"); return RUMPY_E_ARG; }
+  CaBwdFused d;
+  d.dy = (const uint4*)p->dy; d.partial = p->partial; d.hidden = p->hidden; d.gate = p->gate; d.w1 = p->w1; d.w2 = p->w2;
+  d.dz = p->dz; d.dt = (uint4*)p->dt;
+  d.N = p->N; d.HW = p->HW; d.C = p->C; d.Cr = p->Cr; d.nchunks = p->nchunks; d.inv_hw = p->inv_hw; d.per_image = ca_per_image(p->N, p->HW, p->C);
+  hipLaunchKernelGGL(ca_bwd_fused_kernel, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
+  return rumpy_check_launch("rumpy_ca_bwd_fused");
 }

@@ -251,32 +251,29 @@ class SREngine:
                     else:
                         self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
                         self._conv(fwd, t1, c2, N, H, W, t2, pool=pool)
-                    fwd.append(('rumpy_ca_mlp_fwd', L.CaMlpFwdArgs(pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2),
-                                                                    b2=_ptr(ca.b2), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate),
-                                                                    N=N, C=F, Cr=ca.Cr, ntiles=tiles, inv_hw=1.0 / (H * W))))
-                    fwd.append(('rumpy_ca_scale_res_fwd', L.CaScaleArgs(t=_ptr(t2), res=_ptr(cur), gate=_ptr(gate), out=_ptr(y),
-                                                                         N=N, HW=H * W, C=F)))
+                    # squeeze-excite MLP + gate * t2 + skip in one launch (the MLP is recomputed per workgroup)
+                    fwd.append(('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(
+                        pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2), b2=_ptr(ca.b2), mean=_ptr(mean),
+                        hidden=_ptr(hid), gate=_ptr(gate), t=_ptr(t2), res=_ptr(cur), out=_ptr(y), N=N, HW=H * W, C=F, Cr=ca.Cr,
+                        ntiles=tiles, inv_hw=1.0 / (H * W))))
 
                     def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused):
                         # y = x + t2*gate:  dgate = sum(g*t2) -> MLP backward -> dpool ; dt2 = g*gate + dpool
                         nchunks = (H * W + 127) // 128
                         part = self._new(plan, N, nchunks, F, dtype=torch.float32)
-                        dpool = self._new(plan, N, F, dtype=torch.float32)
+                        dz = self._new(plan, N, F, dtype=torch.float32)
                         dt2, dt1, dx = (self._new(plan, N, H, W, F) for _ in range(3))
                         bwd.append(('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=_ptr(g_out), t=_ptr(t2), partial=_ptr(part),
                                                                               N=N, HW=H * W, C=F)))
-                        a = L.CaMlpBwdArgs(partial=_ptr(part), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1),
-                                           w2=_ptr(ca.w2), dpool=_ptr(dpool), gw1=_ptr(ca.gw1), gb1=_ptr(ca.gb1),
-                                           gw2=_ptr(ca.gw2), gb2=_ptr(ca.gb2), N=N, C=F, Cr=ca.Cr, nchunks=nchunks,
-                                           inv_hw=1.0 / (H * W), scale=1.0)
-                        # per layer only dpool (on the critical path); the parameter gradients of ALL channel-attention layers
-                        # come from one launch after the backward chain (rumpy_ca_mlp_bwd_params over a device table)
-                        full = L.CaMlpBwdArgs.from_buffer_copy(a)
-                        a.gw1 = a.gb1 = a.gw2 = a.gb2 = None
-                        bwd.append(('rumpy_ca_mlp_bwd', a))
-                        plan.ca_param_items.append(full)
-                        bwd.append(('rumpy_ca_bwd_apply', L.CaBwdApplyArgs(dy=_ptr(g_out), gate=_ptr(gate), dpool=_ptr(dpool),
-                                                                            dt=_ptr(dt2), N=N, HW=H * W, C=F)))
+                        # MLP backward (dpool) + dt2 = g * gate + dpool in one launch; dz is kept for the parameter gradients
+                        # of ALL channel-attention layers, which come from one launch after the backward chain
+                        bwd.append(('rumpy_ca_bwd_fused', L.CaBwdFusedArgs(
+                            dy=_ptr(g_out), partial=_ptr(part), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
+                            dz=_ptr(dz), dt=_ptr(dt2), N=N, HW=H * W, C=F, Cr=ca.Cr, nchunks=nchunks, inv_hw=1.0 / (H * W))))
+                        plan.ca_param_items.append(L.CaMlpBwdArgs(
+                            partial=_ptr(dz), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
+                            dpool=_ptr(dz), gw1=_ptr(ca.gw1), gb1=_ptr(ca.gb1), gw2=_ptr(ca.gw2), gb2=_ptr(ca.gb2), N=N, C=F, Cr=ca.Cr,
+                            nchunks=1, inv_hw=1.0 / (H * W), scale=1.0))
                         if fused:   # both data gradients in one launch; the skip operand is the RCAB's incoming gradient
                             bwd.append(('rumpy_conv_block', L.BlockArgs(
                                 x=_ptr(dt2), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1), res2=_ptr(extra),

@@ -319,6 +319,35 @@ def test_channel_attention_forward_backward():
     assert_f32_close(gb1, b1.grad, 'CA gb1', rel=1e-4)
     assert_f32_close(gw2, w2.grad, 'CA gW2', rel=1e-4)
     assert_f32_close(gb2, b2.grad, 'CA gb2', rel=1e-4)
+    # ---- the fused forms the engine launches: identical results ----
+    mean2, hid2, gate2 = (torch.full((N, k), float('nan'), device=DEV) for k in (Cc, Cr, Cc))
+    y2 = torch.full((N, H, W, Cc), float('nan'), dtype=BF16, device=DEV)
+    L.call('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(pool=pool.data_ptr(), w1=w1d.data_ptr(), b1=b1d.data_ptr(), w2=w2d.data_ptr(), b2=b2d.data_ptr(),
+                                                  mean=mean2.data_ptr(), hidden=hid2.data_ptr(), gate=gate2.data_ptr(), t=t2d.data_ptr(),
+                                                  res=xd.data_ptr(), out=y2.data_ptr(), N=N, HW=H * W, C=Cc, Cr=Cr, ntiles=1,
+                                                  inv_hw=1.0 / (H * W)), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y) and torch.equal(mean2, mean) and torch.equal(hid2, hid) and torch.equal(gate2, gate)
+    L.call('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=gd.data_ptr(), t=t2d.data_ptr(), partial=part.data_ptr(), N=N, HW=H * W, C=Cc), stream())
+    dz = torch.full((N, Cc), float('nan'), device=DEV)
+    dt2 = torch.full((N, H, W, Cc), float('nan'), dtype=BF16, device=DEV)
+    L.call('rumpy_ca_bwd_fused', L.CaBwdFusedArgs(dy=gd.data_ptr(), partial=part.data_ptr(), hidden=hid.data_ptr(), gate=gate.data_ptr(),
+                                                  w1=w1d.data_ptr(), w2=w2d.data_ptr(), dz=dz.data_ptr(), dt=dt2.data_ptr(), N=N, HW=H * W, C=Cc,
+                                                  Cr=Cr, nchunks=nchunks, inv_hw=1.0 / (H * W)), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dt2, dt)
+    # parameter gradients of (here two copies of) the layer in one batched launch, from dz
+    g2 = [tuple(torch.full(sh, float('nan'), device=DEV) for sh in ((Cr, Cc, 1, 1), (Cr,), (Cc, Cr, 1, 1), (Cc,))) for _ in range(2)]
+    items = (L.CaMlpBwdArgs * 2)(*[L.CaMlpBwdArgs(partial=dz.data_ptr(), mean=mean.data_ptr(), hidden=hid.data_ptr(), gate=gate.data_ptr(),
+                                                  w1=w1d.data_ptr(), w2=w2d.data_ptr(), dpool=dz.data_ptr(), gw1=q[0].data_ptr(), gb1=q[1].data_ptr(),
+                                                  gw2=q[2].data_ptr(), gb2=q[3].data_ptr(), N=N, C=Cc, Cr=Cr, nchunks=1, inv_hw=1.0 / (H * W),
+                                                  scale=0.5 * (k + 1)) for k, q in enumerate(g2)])
+    idev = to_dev_bytes(items)
+    L.check(L.lib().rumpy_ca_mlp_bwd_params(idev.data_ptr(), 2, N, Cc, Cr, stream()), 'params')
+    torch.cuda.synchronize()
+    for k, q in enumerate(g2):
+        for got, ref in zip(q, (gw1, gb1, gw2, gb2)):
+            assert_f32_close(got, ref * (0.5 * (k + 1)), 'batched CA parameter gradients', rel=1e-6)
 
 
 def test_adam_matches_torch_and_clips():
