@@ -226,11 +226,23 @@ struct CaFwdFused {
   const uint4* t; const uint4* res; uint4* out;
   int N, HW, C, Cr, ntiles, per_image; float inv_hw;
 };
+constexpr int CA_PRE = 4;       // vectors per thread requested BEFORE the MLP is recomputed: their latency hides behind it
 __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
   __shared__ float sp[CA_MAXC];
   __shared__ float sh[CA_MAXR];
   __shared__ float sg[CA_MAXC];
   const int n = blockIdx.x / a.per_image, j = blockIdx.x - n * a.per_image, c = threadIdx.x;
+  const int cv = a.C / 8;
+  const size_t img_vec = (size_t)a.HW * cv, base = (size_t)n * img_vec, stride = (size_t)a.per_image * 256;
+  const size_t v0 = (size_t)j * 256 + threadIdx.x;
+  uint4 T[CA_PRE], R[CA_PRE];
+#pragma unroll
+  for (int k = 0; k < CA_PRE; ++k) {
+    const size_t v = v0 + k * stride;
+    const size_t i = base + (v < img_vec ? v : 0);
+    T[k] = a.t[i];
+    R[k] = a.res ? a.res[i] : make_uint4(0, 0, 0, 0);
+  }
   if (c < a.C) {
     float s = 0.f;
     for (int t = 0; t < a.ntiles; ++t) s += a.pool[((size_t)n * a.ntiles + t) * a.C + c];
@@ -255,24 +267,24 @@ __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
     if (j == 0) a.gate[(size_t)n * a.C + c] = gt;
   }
   __syncthreads();
-  const int cv = a.C / 8;
-  const size_t img_vec = (size_t)a.HW * cv, base = (size_t)n * img_vec;
-  for (size_t v = (size_t)j * 256 + threadIdx.x; v < img_vec; v += (size_t)a.per_image * 256) {
-    const size_t i = base + v;
+  auto apply = [&](size_t v, uint4 tv, uint4 rv) {
     const float* gp = sg + (int)(v % cv) * 8;
-    const uint4 tv = a.t[i];
-    float x[4], y[4], ra[4] = {0.f, 0.f, 0.f, 0.f}, rb[4] = {0.f, 0.f, 0.f, 0.f};
+    float x[4], y[4], ra[4], rb[4];
     unpack4_bf16(make_uint2(tv.x, tv.y), x);
     unpack4_bf16(make_uint2(tv.z, tv.w), y);
-    if (a.res) {
-      const uint4 rv = a.res[i];
-      unpack4_bf16(make_uint2(rv.x, rv.y), ra);
-      unpack4_bf16(make_uint2(rv.z, rv.w), rb);
-    }
+    unpack4_bf16(make_uint2(rv.x, rv.y), ra);
+    unpack4_bf16(make_uint2(rv.z, rv.w), rb);
     const uint2 lo = pack4_bf16(fmaf(x[0], gp[0], ra[0]), fmaf(x[1], gp[1], ra[1]), fmaf(x[2], gp[2], ra[2]), fmaf(x[3], gp[3], ra[3]));
     const uint2 hi = pack4_bf16(fmaf(y[0], gp[4], rb[0]), fmaf(y[1], gp[5], rb[1]), fmaf(y[2], gp[6], rb[2]), fmaf(y[3], gp[7], rb[3]));
-    a.out[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    a.out[base + v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+#pragma unroll
+  for (int k = 0; k < CA_PRE; ++k) {
+    const size_t v = v0 + k * stride;
+    if (v < img_vec) apply(v, T[k], R[k]);
   }
+  for (size_t v = v0 + CA_PRE * stride; v < img_vec; v += stride)
+    apply(v, a.t[base + v], a.res ? a.res[base + v] : make_uint4(0, 0, 0, 0));
 }
 
 struct CaBwdFused {
@@ -286,6 +298,15 @@ __global__ void __launch_bounds__(256) ca_bwd_fused_kernel(CaBwdFused a) {
   __shared__ float sg[CA_MAXC];
   __shared__ float sdp[CA_MAXC];
   const int n = blockIdx.x / a.per_image, j = blockIdx.x - n * a.per_image, c = threadIdx.x;
+  const int cv = a.C / 8;
+  const size_t img_vec = (size_t)a.HW * cv, base = (size_t)n * img_vec, stride = (size_t)a.per_image * 256;
+  const size_t v0 = (size_t)j * 256 + threadIdx.x;
+  uint4 D[CA_PRE];
+#pragma unroll
+  for (int k = 0; k < CA_PRE; ++k) {
+    const size_t v = v0 + k * stride;
+    D[k] = a.dy[base + (v < img_vec ? v : 0)];
+  }
   const float* part = a.partial + (size_t)n * a.nchunks * a.C;
   if (c < a.C) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -315,21 +336,23 @@ __global__ void __launch_bounds__(256) ca_bwd_fused_kernel(CaBwdFused a) {
     sdp[c] = dp * a.inv_hw;
   }
   __syncthreads();
-  const int cv = a.C / 8;
-  const size_t img_vec = (size_t)a.HW * cv, base = (size_t)n * img_vec;
-  for (size_t v = (size_t)j * 256 + threadIdx.x; v < img_vec; v += (size_t)a.per_image * 256) {
-    const size_t i = base + v;
+  auto apply = [&](size_t v, uint4 dv) {
     const int c8 = (int)(v % cv) * 8;
     const float* gp = sg + c8;
     const float* dp = sdp + c8;
-    const uint4 dv = a.dy[i];
     float x[4], y[4];
     unpack4_bf16(make_uint2(dv.x, dv.y), x);
     unpack4_bf16(make_uint2(dv.z, dv.w), y);
     const uint2 lo = pack4_bf16(fmaf(x[0], gp[0], dp[0]), fmaf(x[1], gp[1], dp[1]), fmaf(x[2], gp[2], dp[2]), fmaf(x[3], gp[3], dp[3]));
     const uint2 hi = pack4_bf16(fmaf(y[0], gp[4], dp[4]), fmaf(y[1], gp[5], dp[5]), fmaf(y[2], gp[6], dp[6]), fmaf(y[3], gp[7], dp[7]));
-    a.dt[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    a.dt[base + v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+#pragma unroll
+  for (int k = 0; k < CA_PRE; ++k) {
+    const size_t v = v0 + k * stride;
+    if (v < img_vec) apply(v, D[k]);
   }
+  for (size_t v = v0 + CA_PRE * stride; v < img_vec; v += stride) apply(v, a.dy[base + v]);
 }
 
 static int stream_blocks(size_t total_vec) {
