@@ -182,8 +182,14 @@ typedef struct {
   float* loss;           /* scalar: sum(loss_partial)/numel, written by a second tiny launch (needs target) */
   int32_t N, C, H, W;
   int32_t grid_x;        /* persistent workgroups (<= capacity of loss_partial); 0 = default */
+  float* wslab;          /* NULL, or (needs target) rumpy_tail_fwd_grid(..) * rumpy_wgrad_slab_floats(1) floats: the weight /
+                            bias gradient of this conv w.r.t. the L1 loss is accumulated in the same pass (one slab per
+                            workgroup; rumpy_tail_wgrad_reduce adds them up) instead of re-reading x in rumpy_wgrad_grouped */
 } rumpy_tail_fwd_args;
 int rumpy_tail_fwd(const rumpy_tail_fwd_args* a, void* stream);
+int rumpy_tail_fwd_grid(int32_t N, int32_t H, int32_t W, int32_t grid_x);   /* workgroups rumpy_tail_fwd launches = slabs written */
+/* gw [C,64,3,3] / gb [C] = scale * sum of the slabs (fixed order) */
+int rumpy_tail_wgrad_reduce(const float* wslab, int32_t nslabs, int32_t C, float scale, float* gw, float* gb, void* stream);
 
 /* data gradient of the tail conv: dy4 [N,H,W,4] bf16 -> dx [N,H,W,64] bf16 */
 typedef struct {

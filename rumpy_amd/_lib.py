@@ -58,7 +58,7 @@ class HeadWgradArgs(_S):
 class TailFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('target', c_void_p),
                 ('dy4', c_void_p), ('loss_partial', c_void_p), ('loss', c_void_p),
-                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('grid_x', c_int32)]
+                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('grid_x', c_int32), ('wslab', c_void_p)]
 
 
 class TailDgradArgs(_S):
@@ -181,6 +181,8 @@ SYMBOLS = {
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
     'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),
     'rumpy_tail_fwd': (C.c_int, [_P(TailFwdArgs), c_void_p]),
+    'rumpy_tail_fwd_grid': (C.c_int, [c_int32, c_int32, c_int32, c_int32]),
+    'rumpy_tail_wgrad_reduce': (C.c_int, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     'rumpy_tail_dgrad': (C.c_int, [_P(TailDgradArgs), c_void_p]),
     'rumpy_nchw_to_nhwc4': (C.c_int, [_P(NchwToNhwc4Args), c_void_p]),
     'rumpy_wgrad_grouped': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

@@ -174,21 +174,50 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
 // ------------------------------------------------------------------------------------------------------
 struct TailDev {
   const uint16_t* x; const uint4* w; const float* bias; float* out; const float* target; uint16_t* dy4;
-  float* loss_partial; int N, C, H, W, tiles_x, tiles_y;
+  float* loss_partial; float* wslab; int N, C, H, W, tiles_x, tiles_y;
 };
 
+typedef __attribute__((address_space(3))) short4v* tail_lds_s4;
+typedef __attribute__((address_space(3))) unsigned char* tail_lds_u8;
+__device__ __forceinline__ bf16x8 tail_tr8(unsigned addr, unsigned second) {      // two transposed 4x16 reads -> 8 K values
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tail_lds_s4)(size_t)addr);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tail_lds_s4)(size_t)(addr + second));
+  union { short8v s; bf16x8 h; } c;
+  c.s = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return c.h;
+}
+// WGRAD = true (training with the fused L1 loss): the weight gradient of this conv, dW[co][tap][ci] = sum_px dy[px][co] * x[px+tap][ci],
+// is accumulated here as well - the input tile is in LDS and the sign gradient has just been computed, so the separate
+// weight-gradient pass (which re-read the 151 MB activation: 71 us) disappears.  Pixels are the MFMA K axis: both operands
+// come out of LDS through transposed reads (ds_read_b64_tr_b16, as in wgrad_dma.hip); wave w owns input channels 16w..16w+15,
+// 9 accumulator tiles stay in registers for the whole kernel, each workgroup leaves one slab (format of rumpy_wgrad_slab_floats(1)).
+template <bool WGRAD>
 __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char ldy[TH * TW * 8 + 16];      // sign gradient of the tile [px][4 ch] bf16 + 16 zero bytes
   __shared__ float red[4];
+  __shared__ float redb[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  bf16x8 F[18];
+  // forward filter: stationary in 72 VGPRs, or - WGRAD, where 36 accumulator registers are needed on top - in 18 KB of LDS
+  // (18 extra fragment reads per tile)
+  __shared__ __attribute__((aligned(16))) uint4 ldf[WGRAD ? 18 * 64 : 1];
+  bf16x8 F[WGRAD ? 1 : 18];
+  if (WGRAD) {
+    for (int i = tid; i < 18 * 64; i += 256) ldf[i] = a.w[i];
+  } else {
 #pragma unroll
-  for (int s = 0; s < 18; ++s) F[s] = as_bf16x8(a.w[s * 64 + lane]);
+    for (int s = 0; s < 18; ++s) F[WGRAD ? 0 : s] = as_bf16x8(a.w[s * 64 + lane]);
+  }
   float bj[4] = {0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < a.C; ++j) bj[j] = a.bias[j];
   float lsum = 0.f;
+  f32x4 wacc[WGRAD ? 9 : 1];
+#pragma unroll
+  for (int t = 0; t < (WGRAD ? 9 : 1); ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  if (WGRAD && tid < 4) *reinterpret_cast<unsigned*>(ldy + TH * TW * 8 + tid * 4) = 0u;
 
   // Register-staged input pipeline, TWO tiles deep: while tile t is multiplied out of LDS, tile t+1 sits in registers (its
   // loads were issued one iteration ago) and the loads of tile t+2 are issued - every load has two iterations to land, so
@@ -244,7 +273,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < 2; ++r)
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r], 0, 0, 0);
+            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WGRAD ? as_bf16x8(ldf[WGRAD ? ((ky * 3 + kx) * 2 + half) * 64 + lane : 0]) : F[WGRAD ? 0 : (ky * 3 + kx) * 2 + half], I[r + ky], acc[r], 0, 0, 0);
       }
     // all target values are consumed BEFORE the first store: with loads and stores pending together the compiler's
     // s_waitcnt bookkeeping (gfx9: one vmcnt, loads and stores may retire out of order) falls back to draining everything
@@ -264,8 +293,8 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {   // D rows 0..3 (= output channels) live in lanes 0..15
+      float sg[4] = {0.f, 0.f, 0.f, 0.f};
       if (inimg[r]) {
-        float sg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (j < a.C) {
@@ -282,12 +311,54 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
           *reinterpret_cast<uint2*>(a.dy4 + ((size_t)(tc.n * a.H + y) * a.W + xx) * 4) = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
         }
       }
+      if (WGRAD && g == 0) {          // the tile's sign gradient in LDS (zero outside the image), and its per-channel sums (bias gradient)
+        *reinterpret_cast<uint2*>(ldy + ((2 * wave + r) * TW + px) * 8) = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bsum[j] += sg[j];
+      }
+    }
+    if (WGRAD) {
+      __syncthreads();                // the whole tile's sign gradient is in LDS
+      const unsigned xb = (unsigned)(size_t)(tail_lds_u8)cur, yb = (unsigned)(size_t)(tail_lds_u8)ldy;
+      const int qq = (lane >> 2) & 3, p4 = lane & 3;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {          // 32 pixels (2 rows x 16) per MFMA K step
+        const int rsel = 2 * ks + (g >> 1), col0 = 4 * (g & 1) + qq;
+        // A = dy^T: rows = output channels (only lanes p4 == 0 carry the 4 real ones, the others read zeros)
+        const bf16x8 A = tail_tr8(yb + ((p4 == 0) ? (unsigned)((rsel * TW + col0) * 8) : (unsigned)(TH * TW * 8)), (p4 == 0) ? 64u : 0u);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - 3 * ky;
+          const unsigned ix = (unsigned)((rsel + ky) * HALO_W + col0 + kx);
+          const bf16x8 B = tail_tr8(xb + ix * PIX_STRIDE + (unsigned)((2 * wave + (p4 >> 1)) * 16 + (p4 & 1) * 8), 8u * PIX_STRIDE);
+          wacc[WGRAD ? tap : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, wacc[WGRAD ? tap : 0], 0, 0, 0);
+          if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);    // at most three B fragments in flight: the register budget is full
+        }
+      }
     }
     __syncthreads();
   };
   for (; tile < ntiles; tile += 2 * stride) {
     step(tile, lds, R[1], R[0], lds + X_STAGE_BYTES);
     if (tile + stride < ntiles) step(tile + stride, lds + X_STAGE_BYTES, R[0], R[1], lds);
+  }
+  if (WGRAD) {
+    // slab of this workgroup: [co 16][tap 9][ci 64] + [16] bias sums; D rows 0..3 (the real output channels) live in lanes 0..15
+    float* slab = a.wslab + (size_t)blockIdx.x * (16 * 576 + 16);
+    if (g == 0) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) slab[(e * 9 + tap) * 64 + 16 * wave + px] = wacc[WGRAD ? tap : 0][e];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = bsum[j];
+      t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+      if (lane == 0) redb[wave][j] = t;
+    }
+    __syncthreads();
+    if (tid < 4) slab[16 * 576 + tid] = (redb[0][tid] + redb[1][tid]) + (redb[2][tid] + redb[3][tid]);
   }
   if (a.loss_partial) {
     float s = lsum;
@@ -413,6 +484,48 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   return rumpy_check_launch("rumpy_conv3x3");
 }
 
+// sum of the per-workgroup slabs of the fused tail weight gradient: block = 16 elements x 16 slab groups; group p adds slabs
+// p, p+16, .. (independent loads), the 16 partial sums are added in a fixed order
+__global__ void __launch_bounds__(256) tail_wgrad_reduce_kernel(const float* __restrict__ slabs, int nslabs, int C, float scale,
+                                                                float* __restrict__ gw, float* __restrict__ gb) {
+  __shared__ float part[16][17];
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int nelem = C * 576;
+  const int e = blockIdx.x * 16 + el;                    // e < nelem: weight (co, tap, ci); nelem <= e < nelem + C: bias co
+  const int stride = 16 * 576 + 16;
+  float s0 = 0.f, s1 = 0.f;
+  if (e < nelem + C) {
+    const int src = (e < nelem) ? e : 16 * 576 + (e - nelem);
+    int k = grp;
+    for (; k + 16 < nslabs; k += 32) { s0 += slabs[(size_t)k * stride + src]; s1 += slabs[(size_t)(k + 16) * stride + src]; }
+    if (k < nslabs) s0 += slabs[(size_t)k * stride + src];
+  }
+  part[grp][el] = s0 + s1;
+  __syncthreads();
+  if (grp == 0 && e < nelem + C) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += part[i][el];
+    s *= scale;
+    if (e < nelem) {
+      const int co = e / 576, rem = e - co * 576, tap = rem >> 6, ci = rem & 63;
+      gw[((size_t)co * 64 + ci) * 9 + tap] = s;
+    } else gb[e - nelem] = s;
+  }
+}
+
+extern "C" int rumpy_tail_wgrad_reduce(const float* wslab, int32_t nslabs, int32_t C, float scale, float* gw, float* gb, void* stream) {
+  if (!wslab || !gw || !gb || nslabs <= 0 || C < 1 || C > 4) { rumpy_set_error("rumpy_tail_wgrad_reduce: bad argument"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(tail_wgrad_reduce_kernel, dim3((C * 576 + C + 15) / 16), dim3(256), 0, (hipStream_t)stream, wslab, nslabs, C, scale, gw, gb);
+  return rumpy_check_launch("rumpy_tail_wgrad_reduce");
+}
+
+extern "C" int rumpy_tail_fwd_grid(int32_t N, int32_t H, int32_t W, int32_t grid_x) {
+  const int ntiles = N * cdiv(W, TW) * cdiv(H, TH);
+  int gx = grid_x > 0 ? grid_x : 2 * rumpy_device_cus();
+  return gx > ntiles ? ntiles : gx;
+}
+
 extern "C" int rumpy_tail_fwd(const rumpy_tail_fwd_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->bias || !p->out) { rumpy_set_error("rumpy_tail_fwd: null pointer"); return RUMPY_E_ARG; }
   if (p->C < 1 || p->C > 4 || p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("rumpy_tail_fwd: bad shape"); return RUMPY_E_ARG; }
@@ -420,13 +533,15 @@ extern "C" int rumpy_tail_fwd(const rumpy_tail_fwd_args* p, void* stream) {
   if (p->target && (!p->loss_partial || !p->loss)) { rumpy_set_error("rumpy_tail_fwd: target needs loss_partial and loss"); return RUMPY_E_ARG; }
   TailDev d;
   d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = p->out; d.target = p->target;
-  d.dy4 = (uint16_t*)p->dy4; d.loss_partial = p->loss_partial; d.N = p->N; d.C = p->C; d.H = p->H; d.W = p->W;
+  d.dy4 = (uint16_t*)p->dy4; d.loss_partial = p->loss_partial; d.wslab = p->wslab; d.N = p->N; d.C = p->C; d.H = p->H; d.W = p->W;
+  if (p->wslab && !p->target) { rumpy_set_error("rumpy_tail_fwd: wslab needs target"); return RUMPY_E_ARG; }
   d.tiles_x = cdiv(p->W, TW); d.tiles_y = cdiv(p->H, TH);
   const int ntiles = d.N * d.tiles_x * d.tiles_y;
   int gx = p->grid_x > 0 ? p->grid_x : 2 * rumpy_device_cus();
   if (gx > ntiles) gx = ntiles;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(tail_fwd_kernel, dim3(gx), dim3(256), 0, s, d);
+  if (p->wslab) hipLaunchKernelGGL(tail_fwd_kernel<true>, dim3(gx), dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(tail_fwd_kernel<false>, dim3(gx), dim3(256), 0, s, d);
   if (p->target) {
     const float inv = 1.0f / ((float)p->N * p->C * p->H * p->W);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, p->loss_partial, gx, inv, p->loss);

@@ -326,9 +326,13 @@ class SREngine:
         plan.dy4 = self._new(plan, N, h, w, 4) if train else None
         plan.tail_plain = L.TailFwdArgs(x=_ptr(u), w=_ptr(spec.tail.w_fwd), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
                                         target=None, dy4=None, loss_partial=None, loss=None, N=N, C=Cout, H=h, W=w, grid_x=tail_grid)
+        # fused L1 training path: the tail conv's weight gradient is accumulated inside the same pass (one slab per workgroup)
+        plan.tail_slabs = int(lib.rumpy_tail_fwd_grid(N, h, w, tail_grid))
+        plan.tail_wslab = self._new(plan, plan.tail_slabs * int(lib.rumpy_wgrad_slab_floats(1)), dtype=torch.float32) if train else None
+        plan.tail_fused = False
         plan.tail_loss = L.TailFwdArgs(x=_ptr(u), w=_ptr(spec.tail.w_fwd), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
                                        target=_ptr(plan.target), dy4=_ptr(plan.dy4), loss_partial=_ptr(plan.loss_partial),
-                                       loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid)
+                                       loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid, wslab=_ptr(plan.tail_wslab))
         if not train:
             return plan
 
@@ -449,6 +453,9 @@ class SREngine:
         plan.reduce_dev = torch.empty(C.sizeof(plan.reduce_host), dtype=torch.uint8, device=self.device)
         plan.keep.append(plan.reduce_dev)
         plan.n_reduce = len(items)
+        plan.reduce_keep = [i for i, it in enumerate(items) if it.mt != 1]      # items used when the tail gradient came from tail_fwd
+        plan.reduce_dev_notail = torch.empty(max(1, len(plan.reduce_keep)) * C.sizeof(L.ReduceItem), dtype=torch.uint8, device=self.device)
+        plan.keep.append(plan.reduce_dev_notail)
         plan.job_dev = {}
         for mt in (4, 1):
             if jobs[mt]:
@@ -467,6 +474,8 @@ class SREngine:
             it.scale = s * gs
         raw = np.frombuffer(bytes(plan.reduce_host), dtype=np.uint8).copy()
         plan.reduce_dev.copy_(torch.from_numpy(raw), non_blocking=False)
+        sub = (L.ReduceItem * max(1, len(plan.reduce_keep)))(*[plan.reduce_host[i] for i in plan.reduce_keep])
+        plan.reduce_dev_notail.copy_(torch.from_numpy(np.frombuffer(bytes(sub), dtype=np.uint8).copy()), non_blocking=False)
         for a in plan.scaled:
             a.scale = gs
         if plan.ca_param_items:
@@ -511,8 +520,10 @@ class SREngine:
             plan.tail_loss.out = out.data_ptr()
             plan.tail_loss.target = target.data_ptr()
             L.call('rumpy_tail_fwd', plan.tail_loss, stream)
+            plan.tail_fused = plan.tail_wslab is not None      # the tail weight gradient w.r.t. the L1 loss now sits in tail_wslab
             return out, plan.loss, plan
         plan.tail_plain.out = out.data_ptr()
+        plan.tail_fused = False
         L.call('rumpy_tail_fwd', plan.tail_plain, stream)
         return out, None, plan
 
@@ -524,14 +535,23 @@ class SREngine:
             h, w = plan.HR
             L.call('rumpy_nchw_to_nhwc4', L.NchwToNhwc4Args(src=_ptr(gout), dst=_ptr(plan.dy4), N=plan.N, C=gout.shape[1], H=h, W=w), stream)
         self._set_grad_scale(plan, float(grad_scale))
+        tail_done = plan.tail_fused and gout is None      # an upstream gradient replaces the sign gradient: separate pass then
+        plan.tail_fused = False
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
         for mt in (4, 1):
-            if mt in plan.job_dev:
+            if mt in plan.job_dev and not (mt == 1 and tail_done):
                 dev, n = plan.job_dev[mt]
                 variant = 1 if (mt == 1 and plan.HR[1] % 2) else 0     # dy4 pixel-pair DMA needs an even width
                 L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, variant, stream), 'rumpy_wgrad_grouped')
-        L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')
+        if tail_done:
+            if plan.reduce_keep:
+                L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev_notail), len(plan.reduce_keep), stream), 'rumpy_wgrad_reduce')
+            tl = self.spec.tail
+            L.check(self.lib.rumpy_tail_wgrad_reduce(_ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, float(grad_scale), _ptr(tl.gw),
+                                                     _ptr(tl.gb), stream), 'rumpy_tail_wgrad_reduce')
+        else:
+            L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')
 
     # ------------------------------------------------------------------ hipGraph replay of the fused L1 training pass
     def train_pass_graphed(self, x, target):
@@ -577,11 +597,14 @@ class SREngine:
                     'rumpy_ca_mlp_bwd_params')
 
     def _backward_launches(self, plan, stream):
+        """backward launch list of the fused L1 pass (captured into the hipGraph): the tail weight gradient came from tail_fwd"""
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
-        for mt in (4, 1):
-            if mt in plan.job_dev:
-                dev, n = plan.job_dev[mt]
-                variant = 1 if (mt == 1 and plan.HR[1] % 2) else 0
-                L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, variant, stream), 'rumpy_wgrad_grouped')
-        L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')
+        if 4 in plan.job_dev:
+            dev, n = plan.job_dev[4]
+            L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 4, 0, stream), 'rumpy_wgrad_grouped')
+        if plan.reduce_keep:
+            L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev_notail), len(plan.reduce_keep), stream), 'rumpy_wgrad_reduce')
+        tl = self.spec.tail
+        L.check(self.lib.rumpy_tail_wgrad_reduce(_ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, float(plan.grad_scale), _ptr(tl.gw),
+                                                 _ptr(tl.gb), stream), 'rumpy_tail_wgrad_reduce')
