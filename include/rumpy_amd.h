@@ -411,6 +411,19 @@ typedef struct {
 } rumpy_patch_args;
 int rumpy_patch_gather(const rumpy_patch_args* a, void* stream);
 
+/* ---- SSIM with the reference's settings: skimage.metrics.structural_similarity(data_range, gaussian_weights=True,
+ * use_sample_covariance=False, sigma=1.5) as called by Metrics.run_ssim (rumpy/sr_tools/metrics.py:123-149); per plane [H,W] fp32 */
+typedef struct {
+  const float* a;       /* [P,H,W] */
+  const float* b;       /* [P,H,W] reference planes */
+  float* partial;       /* rumpy_ssim_partial_floats(P,H,W) floats of scratch */
+  float* out;           /* [P] mean SSIM of each plane */
+  int32_t P, H, W;
+  float data_range;
+} rumpy_ssim_args;
+int rumpy_ssim(const rumpy_ssim_args* a, void* stream);
+int64_t rumpy_ssim_partial_floats(int32_t P, int32_t H, int32_t W);
+
 /* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
  * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
  * 4 = rumpy_conv_chain ; 5 = rumpy_conv_block and rumpy_block_chain */

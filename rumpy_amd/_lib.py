@@ -156,6 +156,11 @@ class BlockChainArgs(_S):
                 ('xchg', c_void_p), ('status', c_void_p)]
 
 
+class SsimArgs(_S):
+    _fields_ = [('a', c_void_p), ('b', c_void_p), ('partial', c_void_p), ('out', c_void_p), ('P', c_int32), ('H', c_int32),
+                ('W', c_int32), ('data_range', c_float)]
+
+
 class PatchItem(_S):
     _fields_ = [('lr_off', c_int64), ('hr_off', c_int64), ('lr_h', c_int32), ('lr_w', c_int32), ('hflip', c_int32),
                 ('vflip', c_int32), ('rot', c_int32), ('y', c_int32), ('x', c_int32), ('pad_', c_int32)]
@@ -203,6 +208,8 @@ SYMBOLS = {
     'rumpy_conv_block': (C.c_int, [_P(BlockArgs), c_void_p]),
     'rumpy_block_chain': (C.c_int, [_P(BlockChainArgs), c_void_p]),
     'rumpy_block_chain_xchg_bytes': (c_int64, [c_int32]),
+    'rumpy_ssim': (C.c_int, [_P(SsimArgs), c_void_p]),
+    'rumpy_ssim_partial_floats': (c_int64, [c_int32, c_int32, c_int32]),
     'rumpy_patch_gather': (C.c_int, [_P(PatchArgs), c_void_p]),
     'rumpy_probe_begin': (C.c_int, [C.c_int, C.c_int]),
     'rumpy_probe_end': (C.c_int, [_P(C.c_double)]),

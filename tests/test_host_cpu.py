@@ -300,3 +300,31 @@ def test_reference_written_checkpoint_loads_into_the_handler(golden_dir):
     assert sorted(again.keys()) == sorted(ref.keys())
     for k in ref['network']:
         assert torch.equal(again['network'][k], ref['network'][k])
+
+
+def test_ssim_oracle_properties_and_no_cpu_path():
+    """oracle/ssim_oracle.py: identical images give 1; the crop (5 px) equals the window radius, so the result cannot depend on
+    the filter's boundary mode (the HIP kernel relies on that and never evaluates padded pixels); the product has no CPU path."""
+    import numpy as np
+    import pytest
+    import torch
+    from scipy.ndimage import gaussian_filter
+
+    from oracle import ssim_oracle as SO
+    gen = np.random.default_rng(5)
+    a = gen.uniform(0, 1, (37, 52))
+    b = np.clip(a + gen.normal(0, 0.05, a.shape), 0, 1)
+    assert SO.ssim_plane(a, a) == 1.0
+    v = SO.ssim_plane(a, b)
+    assert 0.5 < v < 1.0
+
+    def with_mode(mode):
+        f = lambda z: gaussian_filter(z, sigma=1.5, truncate=3.5, mode=mode)
+        ux, uy, uxx, uyy, uxy = f(a), f(b), f(a * a), f(b * b), f(a * b)
+        S = ((2 * ux * uy + 1e-4) * (2 * (uxy - ux * uy) + 9e-4)) / ((ux ** 2 + uy ** 2 + 1e-4) * ((uxx - ux * ux) + (uyy - uy * uy) + 9e-4))
+        return S[5:-5, 5:-5].mean()
+    assert abs(with_mode('constant') - v) < 1e-12 and abs(with_mode('nearest') - v) < 1e-12
+    if not torch.cuda.is_available():
+        from rumpy_amd.sr_tools.metrics import Metrics
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            Metrics().run_ssim(a[None, None], b[None, None])

@@ -259,3 +259,25 @@ def test_reference_written_checkpoint_continues_identically_on_the_gpu(golden_di
         num += float((mine * ref).sum()); den_a += float((mine * mine).sum()); den_b += float((ref * ref).sum())
     cos = num / (np.sqrt(den_a * den_b) + 1e-30)
     assert cos > 0.98 and 0.9 < np.sqrt(den_a / den_b) < 1.1, (cos, den_a, den_b)
+
+
+def test_ssim_matches_the_restated_skimage_metric():
+    """rumpy_ssim behind Metrics.run_ssim against oracle/ssim_oracle.py (skimage's algorithm on scipy's
+    gaussian_filter; skimage itself is absent here: parity pinned to scipy only).  fp32 kernel vs float64 oracle: 2e-5."""
+    from oracle import ssim_oracle as SO
+    from rumpy_amd.sr_tools.metrics import Metrics
+    gen = np.random.default_rng(77)
+    for (n, c, h, w) in ((3, 1, 40, 57), (2, 3, 96, 64), (1, 1, 11 + 1, 11 + 3), (2, 1, 192, 192)):
+        ref = gen.uniform(0, 1, (n, c, h, w)).astype(np.float32)
+        # a degraded copy (blur-ish + noise), like an SR output against its ground truth
+        a = np.clip(0.6 * ref + 0.4 * np.roll(ref, 1, axis=3) + gen.normal(0, 0.03, ref.shape), 0, 1).astype(np.float32)
+        m = Metrics()
+        assert abs(m.run_ssim(a, ref) - SO.run_ssim(a, ref)) < 2e-5
+        got = m.run_ssim(a, ref, single_values=True)
+        exp = SO.run_ssim(a, ref, single_values=True)
+        assert len(got) == n and max(abs(x - y) for x, y in zip(got, exp)) < 2e-5
+        assert abs(m.run_ssim(a, ref, multichannel=True) - SO.run_ssim(a, ref, multichannel=True)) < 2e-5
+    same = gen.uniform(0, 1, (1, 1, 33, 33)).astype(np.float32)
+    assert abs(Metrics().run_ssim(same, same) - 1.0) < 1e-6            # identical images
+    with pytest.raises(RuntimeError):
+        Metrics().run_ssim(same[:, :, :8, :8], same[:, :, :8, :8])     # smaller than the window: refused like skimage does
