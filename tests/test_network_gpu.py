@@ -281,3 +281,28 @@ def test_ssim_matches_the_restated_skimage_metric():
     assert abs(Metrics().run_ssim(same, same) - 1.0) < 1e-6            # identical images
     with pytest.raises(RuntimeError):
         Metrics().run_ssim(same[:, :, :8, :8], same[:, :, :8, :8])     # smaller than the window: refused like skimage does
+
+
+@pytest.mark.parametrize('name,kw', [('edsr', dict(scale=2, num_blocks=2, res_scale=0.1)),
+                                     ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16))])
+def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
+    """RUMPY_NO_BLOCK=1 keeps residual blocks / RCABs on two rumpy_conv3x3 launches (also what images wider than 48 pixels use):
+    same operands, same per-pixel operation order up to one fused multiply-add -> the two engines agree to bf16 rounding."""
+    x, y = O.synthetic_batch(640, 2, lr_hw=20, scale=2)
+    res = []
+    for no_block in ('0', '1'):
+        monkeypatch.setenv('RUMPY_NO_BLOCK', no_block)
+        h, _ = _pair(name, 507, sched=False, **kw)
+        loss, out = h.run_train(x=x, y=y)
+        assert h.net.engine.use_block_kernel == (no_block == '0')
+        names = {op for op, _ in h.net.engine.plan_for(2, 20, 20, True).fwd}
+        assert ('rumpy_conv_block' in names) == (no_block == '0')
+        res.append((float(loss), out, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}))
+    assert abs(res[0][0] - res[1][0]) < 1e-4 * abs(res[1][0])
+    assert self_psnr(res[0][1], res[1][1]) > 60.0
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+        else:
+            assert float((a - b).norm() / b.norm()) < 2e-2, k
