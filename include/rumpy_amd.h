@@ -333,6 +333,7 @@ int rumpy_ca_bwd_apply(const rumpy_ca_bwd_apply_args* a, void* stream);
 typedef struct {
   const float* pool; const float* w1; const float* b1; const float* w2; const float* b2;
   float* mean; float* hidden; float* gate;     /* [N,C], [N,Cr], [N,C]: saved for the backward pass */
+  /* pool: [N,ntiles,C] partial sums from the conv epilogue; SCRATCH - with more than 32 rows per image they are folded in place */
   const void* t; const void* res; void* out;   /* out = res + t * gate (res may be NULL) */
   int32_t N, HW, C, Cr, ntiles;
   float inv_hw;

@@ -224,7 +224,7 @@ struct CaFwdFused {
   const float* pool; const float* w1; const float* b1; const float* w2; const float* b2;
   float* mean; float* hidden; float* gate;
   const uint4* t; const uint4* res; uint4* out;
-  int N, HW, C, Cr, ntiles, per_image; float inv_hw;
+  int N, HW, C, Cr, ntiles, per_image; float inv_hw; int image_stride;
 };
 constexpr int CA_PRE = 4;       // vectors per thread requested BEFORE the MLP is recomputed: their latency hides behind it
 __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
   }
   if (c < a.C) {
     float s = 0.f;
-    for (int t = 0; t < a.ntiles; ++t) s += a.pool[((size_t)n * a.ntiles + t) * a.C + c];
+    for (int t = 0; t < a.ntiles; ++t) s += a.pool[(size_t)n * a.image_stride + (size_t)t * a.C + c];
     s *= a.inv_hw;
     sp[c] = s;
     if (j == 0) a.mean[(size_t)n * a.C + c] = s;
@@ -285,6 +285,30 @@ __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
   }
   for (size_t v = v0 + CA_PRE * stride; v < img_vec; v += stride)
     apply(v, a.t[base + v], a.res ? a.res[base + v] : make_uint4(0, 0, 0, 0));
+}
+
+// Large images leave thousands of pool partial rows per image (two per 6 x 48 strip); every workgroup of the fused kernel walking
+// over all of them made a 2K-image RCAN inference spend 300 us per channel-attention layer.  They are first folded IN PLACE to
+// CA_FOLD rows: block (n, j) adds rows j, j + CA_FOLD, .. (four groups of threads, fixed order) and overwrites row j, the only
+// row of its residue class that anyone reads afterwards.
+constexpr int CA_FOLD = 16;
+__global__ void __launch_bounds__(256) ca_pool_fold_kernel(float* __restrict__ pool, int ntiles, int C) {
+  __shared__ float part[4][64];
+  const int n = blockIdx.y, j = blockIdx.x, grp = threadIdx.x >> 6, cl = threadIdx.x & 63;
+  float* img = pool + (size_t)n * ntiles * C;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+      int t = j + grp * CA_FOLD;
+      for (; t + 4 * CA_FOLD < ntiles; t += 8 * CA_FOLD) { s0 += img[(size_t)t * C + c]; s1 += img[(size_t)(t + 4 * CA_FOLD) * C + c]; }
+      if (t < ntiles) s0 += img[(size_t)t * C + c];
+    }
+    part[grp][cl] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && c < C) img[(size_t)j * C + c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
+    __syncthreads();
+  }
 }
 
 struct CaBwdFused {
@@ -430,6 +454,11 @@ extern "C" int rumpy_ca_fwd_fused(const rumpy_ca_fwd_fused_args* p, void* stream
   d.pool = p->pool; d.w1 = p->w1; d.b1 = p->b1; d.w2 = p->w2; d.b2 = p->b2; d.mean = p->mean; d.hidden = p->hidden; d.gate = p->gate;
   d.t = (const uint4*)p->t; d.res = (const uint4*)p->res; d.out = (uint4*)p->out;
   d.N = p->N; d.HW = p->HW; d.C = p->C; d.Cr = p->Cr; d.ntiles = p->ntiles; d.inv_hw = p->inv_hw; d.per_image = ca_per_image(p->N, p->HW, p->C);
+  d.image_stride = p->ntiles * p->C;
+  if (p->ntiles > 2 * CA_FOLD) {      // fold the partial rows in place first (pool is scratch of the producing conv)
+    hipLaunchKernelGGL(ca_pool_fold_kernel, dim3(CA_FOLD, p->N), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(p->pool), p->ntiles, p->C);
+    d.ntiles = CA_FOLD;
+  }
   hipLaunchKernelGGL(ca_fwd_fused_kernel, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
   return rumpy_check_launch("rumpy_ca_fwd_fused");
 }

@@ -249,3 +249,30 @@ def bchain_bench(N=32, H=48, W=48, nblocks=16):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'bchain':
     bchain_bench()
+
+
+def eval_bench():
+    """whole-image inference (run_eval) of EDSR-baseline x4 and RCAN x4 on DIV2K-sized and Set5-sized LR images"""
+    import tempfile
+    import time
+    from rumpy_amd.shared_framework.models import define_model
+    for name in ('edsr', 'rcan'):
+        h = define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, checkpoint_load=False, loss_masking=False,
+                         metadata_list=None, scale=4)
+        for (n, hh, ww) in ((1, 339, 510), (1, 128, 128), (8, 48, 48)):
+            x = torch.rand(n, 3, hh, ww, device=DEV)
+            for _ in range(3):
+                h.run_eval(x=x, keep_on_device=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            iters = 20
+            for _ in range(iters):
+                h.run_eval(x=x, keep_on_device=True)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            print('%s x4 eval %dx%dx%d LR -> %dx%d HR: %7.2f ms per batch = %6.1f images/s, %6.1f HR Mpixel/s'
+                  % (name, n, hh, ww, 4 * hh, 4 * ww, ms, n / ms * 1e3, n * 16 * hh * ww / ms / 1e3))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'eval':
+    eval_bench()
