@@ -337,6 +337,7 @@ typedef struct {
   const void* t; const void* res; void* out;   /* out = res + t * gate (res may be NULL) */
   int32_t N, HW, C, Cr, ntiles;
   float inv_hw;
+  const float* qgate;                          /* NULL, or the meta-attention gate [N,C] of a QRCAB: out = res + t * gate * qgate */
 } rumpy_ca_fwd_fused_args;
 int rumpy_ca_fwd_fused(const rumpy_ca_fwd_fused_args* a, void* stream);
 typedef struct {
@@ -345,8 +346,26 @@ typedef struct {
   void* dt;                                    /* dt = dy * gate + dpool */
   int32_t N, HW, C, Cr, nchunks;
   float inv_hw;
+  const float* qgate;                          /* NULL, or the meta-attention gate [N,C] used in the forward pass */
+  float* dzq;                                  /* with qgate: [N,C] out, gradient before the meta-attention sigmoid */
 } rumpy_ca_bwd_fused_args;
 int rumpy_ca_bwd_fused(const rumpy_ca_bwd_fused_args* a, void* stream);
+
+/* ---- meta-attention q-layers (ParaCALayer, rumpy/SISR/models/attention_manipulators/q_layer.py:5-45; QRCAB architectures.py:154-228):
+ * gate_q[n][c] = sigmoid(W2 relu(W1 m_n + b1) + b2), m_n = metadata vector [M] of image n.  All layers of a network in one launch
+ * (items: DEVICE array); the parameter gradients likewise, from dzq written by rumpy_ca_bwd_fused. */
+typedef struct {
+  const float* w1; const float* b1;     /* [Hq,M], [Hq]  (attribute_integrator.0) */
+  const float* w2; const float* b2;     /* [C,Hq], [C]   (attribute_integrator.2) */
+  float* hidden;                        /* [N,Hq] out of the forward launch */
+  float* gate;                          /* [N,C]  out of the forward launch */
+  const float* dzq;                     /* [N,C]  in of the backward launch */
+  float* gw1; float* gb1; float* gw2; float* gb2;
+  float scale;
+  int32_t pad_;
+} rumpy_q_mlp_item;
+int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
+int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
 
 /* ---- optimizer: torch.optim.Adam semantics (base_architecture.py:93-95,437), flat fp32 buffers ---- */
 typedef struct {

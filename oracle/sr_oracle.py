@@ -156,6 +156,99 @@ class OracleRCAN(nn.Module):
         return self.tail(self.body(x) + x)
 
 
+class MetaAttention(nn.Module):
+    """rumpy/SISR/models/attention_manipulators/q_layer.py:5-45 (ParaCALayer, the meta-attention block), nonlinearity=True:
+    x * sigmoid(FC_k(...relu(FC_1(metadata)))) with 1x1 convs on the [N,M,1,1] vector.  Unit sizes q_layer.py:27-31:
+    layer i of num_layers maps to channels // (num_layers - i) (or (channels - M) // (num_layers - i) + M when M > 15).
+    Keys ``attribute_integrator.{0,2,..}.*`` (ReLU after every layer but the last, then Sigmoid)."""
+
+    def __init__(self, feats, num_metadata, num_layers=2):
+        super().__init__()
+        layers, sizes, mult = [], [num_metadata], num_layers
+        for i in range(num_layers):
+            sizes.append((feats - num_metadata) // mult + num_metadata if num_metadata > 15 else feats // mult)
+            layers.append(nn.Conv2d(sizes[i], sizes[i + 1], 1))
+            if mult != 1:
+                layers.append(nn.ReLU())
+            mult -= 1
+        layers.append(nn.Sigmoid())
+        self.attribute_integrator = nn.Sequential(*layers)
+
+    def forward(self, x, attributes):
+        return x * self.attribute_integrator(attributes)
+
+
+class MetaAttentionResidualBlock(nn.Module):
+    """rumpy/SISR/models/attention_manipulators/architectures.py:154-228 (QRCAB) for style='standard', q_layer=True, no other
+    optional node: res = body(x); res = QCALayer_standard(res) (:113-136 -> plain channel attention, keys final_body.conv_du.*);
+    res = q_node(res, metadata); res += x.  ``res_scale`` is stored and unused, as in the reference."""
+
+    def __init__(self, feats, reduction, num_metadata, num_layers_in_q_layer=2, q_layer=True):
+        super().__init__()
+        # creation order as the reference (architectures.py:166-172: the two convs first - same seed, same initial weights);
+        # registration order as the reference (:173-195: final_body, q_node, body) - it is the order of the state_dict keys
+        # and of the optimizer's parameter indices in a checkpoint
+        convs = [conv3x3(feats, feats), nn.ReLU(), conv3x3(feats, feats)]
+        self.final_body = ChannelAttention(feats, reduction)
+        self.q_layer = q_layer
+        if q_layer:
+            self.q_node = MetaAttention(feats, num_metadata, num_layers_in_q_layer)
+        self.body = nn.Sequential(*convs)
+
+    def forward(self, xm):
+        x, meta = xm
+        res = self.final_body(self.body(x))
+        if self.q_layer:
+            res = self.q_node(res, meta)
+        return res + x, meta
+
+
+class MetaAttentionGroup(nn.Module):
+    """architectures.py:249-299 (QResidualGroup): n QRCABs (the first num_q_layers of them with a q-layer, all if None),
+    then ``final_body`` conv, + skip."""
+
+    def __init__(self, feats, reduction, n_blocks, num_metadata, q_layer, num_q_layers, num_layers_in_q_layer):
+        super().__init__()
+        blocks = [MetaAttentionResidualBlock(feats, reduction, num_metadata, num_layers_in_q_layer,
+                                             q_layer=q_layer and (num_q_layers is None or b < num_q_layers)) for b in range(n_blocks)]
+        self.final_body = conv3x3(feats, feats)          # registered before body (architectures.py:292-293)
+        self.body = nn.Sequential(*blocks)
+
+    def forward(self, xm):
+        res, _ = self.body(xm)
+        return self.final_body(res) + xm[0], xm[1]
+
+
+class OracleQRCAN(nn.Module):
+    """architectures.py:313-462 (QRCAN) for style='standard' with the meta-attention q-layers (include_q_layer=True;
+    selective_meta_blocks / num_q_layers_inner_residual honoured), no pixel attention / dgfmb / sft / da-conv nodes.
+    forward(x, metadata [N,M,1,1]).  Keys: head.0, body.{g}.body.{b}.body.{0,2}, body.{g}.body.{b}.final_body.conv_du.{0,2},
+    body.{g}.body.{b}.q_node.attribute_integrator.{0,2}, body.{g}.final_body, final_body, tail.0.{0,2}, tail.1"""
+
+    def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4, reduction=16,
+                 num_metadata=1, include_q_layer=True, selective_meta_blocks=None, num_q_layers_inner_residual=None,
+                 num_layers_in_q_layer=2, style='standard', **_ignored):
+        super().__init__()
+        if style != 'standard':
+            raise NotImplementedError('oracle restates QCALayer style "standard" only')
+        f = n_feats
+        head = conv3x3(in_feats, f)                      # creation order (random init) and registration order (keys) of
+        groups = [MetaAttentionGroup(                    # architectures.py:368-433: head, groups, final_body, tail created;
+            f, reduction, n_resblocks, num_metadata,     # final_body, head, body, tail registered
+            include_q_layer and (selective_meta_blocks is None or bool(selective_meta_blocks[g])),
+            num_q_layers_inner_residual, num_layers_in_q_layer) for g in range(n_resgroups)]
+        self.final_body = conv3x3(f, f)
+        tail = [make_upsampler(scale, f), conv3x3(f, out_feats)]
+        self.head = nn.Sequential(head)
+        self.body = nn.Sequential(*groups)
+        self.tail = nn.Sequential(*tail)
+
+    def forward(self, x, metadata):
+        x = self.head(x)
+        res, _ = self.body((x, metadata))
+        return self.tail(self.final_body(res) + x)
+
+
 # --------------------------------------------------------------------------------------
 # handler-level restatement: one train step / one eval step
 # --------------------------------------------------------------------------------------
@@ -200,11 +293,12 @@ class OracleHandler:
             elif scheduler is not None:
                 raise RuntimeError('%s scheduler not implemented' % scheduler)
 
-    def run_train(self, x, y, scheduler_skip=False):
+    def run_train(self, x, y, scheduler_skip=False, extra_channels=None):
+        """extra_channels: the [N,M,1,1] metadata tensor of the Q models (attention_manipulators/__init__.py:186-202)"""
         if self.eval_mode:
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
-        out = self.net(x)
+        out = self.net(x) if extra_channels is None else self.net(x, extra_channels)
         loss = self.criterion(out, y)
         self.optimizer.zero_grad()
         loss.backward()
@@ -215,10 +309,10 @@ class OracleHandler:
             self.learning_rate_scheduler.step()
         return loss.detach().cpu().numpy(), out.detach().cpu()
 
-    def run_eval(self, x, y=None, request_loss=False):
+    def run_eval(self, x, y=None, request_loss=False, extra_channels=None):
         self.net.eval()
         with torch.no_grad():
-            out = self.net(x)
+            out = self.net(x) if extra_channels is None else self.net(x, extra_channels)
             loss = self.criterion(out, y).detach().cpu().numpy() if (request_loss and y is not None) else None
         return out.detach().cpu(), loss, None
 
@@ -242,6 +336,13 @@ def build_oracle(name, **internal_params):
         fwd = {k: p[k] for k in ('n_resblocks', 'n_resgroups', 'n_feats', 'out_feats', 'reduction', 'res_scale')
                if k in p}
         return OracleRCAN(scale=p.get('scale', 4), in_feats=p.get('in_features', 3), **fwd)
+    if name == 'qrcan':
+        # QRCANHandler attention_manipulators/handlers.py:27-45: scale, in_features->in_feats, n_feats, style, num_metadata from
+        # the metadata list (QModel, attention_manipulators/__init__.py:23-58), remaining kwargs forwarded to QRCAN(**kwargs)
+        fwd = {k: p[k] for k in ('n_resblocks', 'n_resgroups', 'n_feats', 'out_feats', 'reduction', 'include_q_layer',
+                                 'selective_meta_blocks', 'num_q_layers_inner_residual', 'num_layers_in_q_layer') if k in p}
+        return OracleQRCAN(scale=p.get('scale', 4), in_feats=p.get('in_features', 3), style=p.get('style', 'standard'),
+                           num_metadata=p['num_metadata'], **fwd)
     raise KeyError(name)
 
 

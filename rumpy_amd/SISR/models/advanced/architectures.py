@@ -16,7 +16,7 @@ import os
 import torch
 from torch import nn
 
-from rumpy_amd.engine import CALayerParams, ConvLayer, NetSpec, SREngine
+from rumpy_amd.engine import CALayerParams, ConvLayer, NetSpec, QLayerParams, SREngine
 
 
 def _conv(cin, cout, k=3):
@@ -79,8 +79,8 @@ class _NetFn(torch.autograd.Function):
     parameter gradients are deposited straight into the flat gradient buffer (``p.grad`` views, overwritten)."""
 
     @staticmethod
-    def forward(ctx, x, net, train, *params):
-        out, _, plan = net.engine_forward(x, train=train)
+    def forward(ctx, x, net, train, meta, *params):
+        out, _, plan = net.engine_forward(x, train=train, meta=meta)
         ctx.net, ctx.plan = net, plan
         return out
 
@@ -89,7 +89,7 @@ class _NetFn(torch.autograd.Function):
         net = ctx.net
         net.engine.backward(ctx.plan, 1.0, gout=gout.contiguous().float())
         net.attach_grads()
-        return (None, None, None) + tuple(None for _ in net.param_list)
+        return (None, None, None, None) + tuple(None for _ in net.param_list)
 
 
 class HipSRNet(nn.Module):
@@ -164,6 +164,15 @@ class HipSRNet(nn.Module):
         lp.gw2, lp.gb2 = self.grad_views[idx[id(c2.weight)]], self.grad_views[idx[id(c2.bias)]]
         return lp
 
+    def _q_layer(self, name, qn):
+        c0, c2 = qn.attribute_integrator[0], qn.attribute_integrator[2]
+        lp = QLayerParams(name, c0.weight.data.reshape(c0.weight.shape[0], -1), c0.bias.data,
+                          c2.weight.data.reshape(c2.weight.shape[0], -1), c2.bias.data)
+        idx = {id(p): i for i, p in enumerate(self.param_list)}
+        lp.gw1, lp.gb1 = self.grad_views[idx[id(c0.weight)]], self.grad_views[idx[id(c0.bias)]]
+        lp.gw2, lp.gb2 = self.grad_views[idx[id(c2.weight)]], self.grad_views[idx[id(c2.bias)]]
+        return lp
+
     def _ensure_engine(self):
         if not self.flat_p.is_cuda:
             raise RuntimeError('rumpy_amd: this network only runs on an MI355X through the HIP extension; '
@@ -189,27 +198,34 @@ class HipSRNet(nn.Module):
         """The fused optimizer has already re-packed (inside its own launch list / graph)."""
         self._packed_version = self._weights_version()
 
-    def engine_forward(self, x, train, target=None):
+    def engine_forward(self, x, train, target=None, meta=None):
         self._ensure_engine()
         if not x.is_cuda:
             raise RuntimeError('rumpy_amd: input must be on the GPU')
-        return self.engine.forward(x.float().contiguous(), train=train, target=target)
+        return self.engine.forward(x.float().contiguous(), train=train, target=target, meta=self._meta_matrix(meta, x))
 
-    def forward(self, x):
+    @staticmethod
+    def _meta_matrix(meta, x):
+        """[N,M,1,1] / [N,M] metadata as the Q models receive it (attention_manipulators/__init__.py:84-103) -> fp32 [N,M] on x's device"""
+        if meta is None:
+            return None
+        return meta.reshape(meta.shape[0], -1).to(device=x.device, dtype=torch.float32).contiguous()
+
+    def forward(self, x, metadata=None):
         train = torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list)
         if train:
-            return _NetFn.apply(x, self, True, *self.param_list)
-        out, _, _ = self.engine_forward(x, train=False)
+            return _NetFn.apply(x, self, True, metadata, *self.param_list)
+        out, _, _ = self.engine_forward(x, train=False, meta=metadata)
         return out
 
-    def fused_l1_forward_backward(self, x, y):
+    def fused_l1_forward_backward(self, x, y, metadata=None):
         """forward + nn.L1Loss + full backward in one pass (base_architecture.py:474-480 minus the optimizer).
         Returns (loss device scalar, out).  Gradients land in flat_g / p.grad."""
         if self.use_graph:
             self._ensure_engine()
             out, loss, _ = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous())
             return loss, out
-        out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous())
+        out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous(), meta=metadata)
         # The loss is final once the forward pass has run: its read-back is queued HERE (pinned buffer + event), ahead of the
         # backward launches, so that run_train's `loss.cpu().numpy()` (the reference API returns the loss of every step,
         # base_architecture.py:482-485) waits for the forward pass only and the host can queue the next step while the GPU
@@ -231,8 +247,8 @@ class HipSRNet(nn.Module):
         self._loss_event.synchronize()
         return self._loss_host.numpy().copy().reshape(())
 
-    def l1_eval(self, x, y):
-        out, loss, _ = self.engine_forward(x, train=False, target=y.float().contiguous())
+    def l1_eval(self, x, y, metadata=None):
+        out, loss, _ = self.engine_forward(x, train=False, target=y.float().contiguous(), meta=metadata)
         return out, loss
 
 

@@ -1,0 +1,97 @@
+"""QRCAN with meta-attention for the MI355X HIP path - drop-in for rumpy/SISR/models/attention_manipulators/architectures.py
+(QRCAN :313-462, QResidualGroup :249-299, QRCAB :154-228, QCALayer :41-136) and q_layer.py (ParaCALayer :5-45).
+
+Supported configuration (the meta-attention setup of the reference's blind / non-blind QRCAN experiments):
+``style='standard'`` (plain channel attention in QCALayer) with ``include_q_layer=True`` - a ParaCALayer with two FC layers and
+ReLU after every residual block (or the subsets selected by ``selective_meta_blocks`` / ``num_q_layers_inner_residual``).
+Other QCALayer styles and the pixel-attention / dgfmb / SFT / DA-conv nodes raise.
+
+As in rumpy_amd/SISR/models/advanced/architectures.py the module tree only owns the parameters, under the reference's
+state_dict keys AND in the reference's registration order (final_body before head/body/tail, a block's final_body and q_node
+before its body: it fixes the order of the keys and of the optimizer's parameter indices in a checkpoint) and it creates the
+layers in the reference's creation order (same seed -> same initial weights).  All arithmetic runs in the HIP engine:
+gate = channel attention x meta attention inside the fused channel-attention kernels, the metadata MLPs of all blocks in one
+launch (rumpy_q_mlp_fwd / rumpy_q_mlp_bwd_params).
+"""
+from torch import nn
+
+from rumpy_amd.engine import NetSpec
+from rumpy_amd.SISR.models.advanced.architectures import HipSRNet, _CAParams, _conv, _upsampler
+
+
+class _QLayerParams(nn.Module):
+    # q_layer.py:22-45 with nonlinearity=True, num_layers=2: attribute_integrator = [conv1x1, ReLU, conv1x1, Sigmoid]
+    def __init__(self, feats, num_metadata, num_layers=2):
+        super().__init__()
+        if num_layers != 2:
+            raise RuntimeError('rumpy_amd: q-layers with %d FC layers are not implemented on the HIP path (2 only)' % num_layers)
+        hidden = (feats - num_metadata) // 2 + num_metadata if num_metadata > 15 else feats // 2
+        self.attribute_integrator = nn.Sequential(nn.Conv2d(num_metadata, hidden, 1, padding=0, bias=True), nn.ReLU(inplace=True),
+                                                  nn.Conv2d(hidden, feats, 1, padding=0, bias=True), nn.Sigmoid())
+
+
+class _QRCABParams(nn.Module):
+    # architectures.py:159-196: the two convs are created first, then QCALayer, then the q-node; registered: final_body, q_node, body
+    def __init__(self, feats, reduction, num_metadata, q_layer, num_layers_in_q_layer):
+        super().__init__()
+        convs = [_conv(feats, feats), nn.ReLU(True), _conv(feats, feats)]
+        self.final_body = _CAParams(feats, reduction)
+        self.q_layer = q_layer
+        if q_layer:
+            self.q_node = _QLayerParams(feats, num_metadata, num_layers_in_q_layer)
+        self.body = nn.Sequential(*convs)
+
+
+class _QGroupParams(nn.Module):
+    # architectures.py:254-294: blocks created, then the group conv; registered: final_body, body
+    def __init__(self, feats, reduction, n_resblocks, num_metadata, q_layer, num_q_layers, num_layers_in_q_layer):
+        super().__init__()
+        blocks = [_QRCABParams(feats, reduction, num_metadata, q_layer and (num_q_layers is None or b < num_q_layers), num_layers_in_q_layer)
+                  for b in range(n_resblocks)]
+        self.final_body = _conv(feats, feats)
+        self.body = nn.Sequential(*blocks)
+
+
+class QRCAN(HipSRNet):
+    def __init__(self, n_resblocks=20, n_resgroups=10, n_feats=64, in_feats=3, out_feats=3, scale=4, reduction=16, res_scale=1.0,
+                 style='modulate', num_metadata=1, include_pixel_attention=False, selective_meta_blocks=None, include_q_layer=False,
+                 num_q_layers_inner_residual=None, num_layers_in_q_layer=2, include_sft_layer=False, include_dgfmb_layer=False,
+                 use_dgfmb_outer_reduction=False, include_da_conv_layer=False, staggered_encoding=False, **kwargs):
+        super().__init__()
+        unsupported = [k for k, v in (('style=%r' % style, style != 'standard'), ('include_pixel_attention', include_pixel_attention),
+                                      ('include_sft_layer', include_sft_layer), ('include_dgfmb_layer', include_dgfmb_layer),
+                                      ('use_dgfmb_outer_reduction', use_dgfmb_outer_reduction), ('include_da_conv_layer', include_da_conv_layer),
+                                      ('staggered_encoding', staggered_encoding)) if v]
+        if unsupported:
+            raise RuntimeError('rumpy_amd: QRCAN option(s) %s are not implemented on the HIP path (style "standard" with q-layers only); '
+                               'there is no fallback' % ', '.join(unsupported))
+        f = n_feats
+        self.scale, self.num_metadata = scale, num_metadata
+        self.metadata_reduction = nn.Sequential(nn.Identity())
+        head = _conv(in_feats, f)
+        groups = [_QGroupParams(f, reduction, n_resblocks, num_metadata,
+                                include_q_layer and (selective_meta_blocks is None or bool(selective_meta_blocks[g])),
+                                num_q_layers_inner_residual, num_layers_in_q_layer) for g in range(n_resgroups)]
+        self.final_body = _conv(f, f)
+        tail = [_upsampler(scale, f), _conv(f, out_feats)]
+        self.head = nn.Sequential(head)
+        self.body = nn.Sequential(*groups)
+        self.tail = nn.Sequential(*tail)
+        self._finalize()
+
+    def _spec(self):
+        if self.scale not in (1, 2, 4, 8):
+            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path (PixelShuffle(3) not implemented)' % self.scale)
+        body, any_q = [], False
+        for gi, grp in enumerate(self.body):
+            items = []
+            for bi, rb in enumerate(grp.body):
+                pre = 'body.%d.body.%d' % (gi, bi)
+                q = self._q_layer(pre + '.q_node', rb.q_node) if rb.q_layer else None
+                any_q = any_q or q is not None
+                items.append(('rcab', self._conv_layer(pre + '.body.0', rb.body[0]), self._conv_layer(pre + '.body.2', rb.body[2]),
+                              self._ca_layer(pre + '.final_body', rb.final_body), q))
+            body.append(('group', items, self._conv_layer('body.%d.final_body' % gi, grp.final_body)))
+        ups = [self._conv_layer('tail.0.%d' % i, m, shuffle=True) for i, m in enumerate(self.tail[0]) if isinstance(m, nn.Conv2d)]
+        return NetSpec(self._conv_layer('head.0', self.head[0], kind='head'), body, self._conv_layer('final_body', self.final_body), ups,
+                       self._conv_layer('tail.1', self.tail[1], kind='tail'), self.scale, num_metadata=self.num_metadata if any_q else 0)

@@ -116,13 +116,20 @@ class CaBwdApplyArgs(_S):
 class CaFwdFusedArgs(_S):
     _fields_ = [('pool', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mean', c_void_p),
                 ('hidden', c_void_p), ('gate', c_void_p), ('t', c_void_p), ('res', c_void_p), ('out', c_void_p),
-                ('N', c_int32), ('HW', c_int32), ('C', c_int32), ('Cr', c_int32), ('ntiles', c_int32), ('inv_hw', c_float)]
+                ('N', c_int32), ('HW', c_int32), ('C', c_int32), ('Cr', c_int32), ('ntiles', c_int32), ('inv_hw', c_float),
+                ('qgate', c_void_p)]
 
 
 class CaBwdFusedArgs(_S):
     _fields_ = [('dy', c_void_p), ('partial', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('w1', c_void_p), ('w2', c_void_p),
                 ('dz', c_void_p), ('dt', c_void_p), ('N', c_int32), ('HW', c_int32), ('C', c_int32), ('Cr', c_int32),
-                ('nchunks', c_int32), ('inv_hw', c_float)]
+                ('nchunks', c_int32), ('inv_hw', c_float), ('qgate', c_void_p), ('dzq', c_void_p)]
+
+
+class QMlpItem(_S):
+    _fields_ = [('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('hidden', c_void_p), ('gate', c_void_p),
+                ('dzq', c_void_p), ('gw1', c_void_p), ('gb1', c_void_p), ('gw2', c_void_p), ('gb2', c_void_p), ('scale', c_float),
+                ('pad_', c_int32)]
 
 
 class AdamHyper(_S):
@@ -200,6 +207,8 @@ SYMBOLS = {
     'rumpy_ca_mlp_bwd': (C.c_int, [_P(CaMlpBwdArgs), c_void_p]),
     'rumpy_ca_fwd_fused': (C.c_int, [_P(CaFwdFusedArgs), c_void_p]),
     'rumpy_ca_bwd_fused': (C.c_int, [_P(CaBwdFusedArgs), c_void_p]),
+    'rumpy_q_mlp_fwd': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'rumpy_q_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_ca_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_ca_bwd_apply': (C.c_int, [_P(CaBwdApplyArgs), c_void_p]),
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),

@@ -225,6 +225,7 @@ struct CaFwdFused {
   float* mean; float* hidden; float* gate;
   const uint4* t; const uint4* res; uint4* out;
   int N, HW, C, Cr, ntiles, per_image; float inv_hw; int image_stride;
+  const float* qgate;      // [N,C] meta-attention gate (QRCAB q-layer) multiplied into the channel-attention gate, or NULL
 };
 constexpr int CA_PRE = 4;       // vectors per thread requested BEFORE the MLP is recomputed: their latency hides behind it
 __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
     float z = a.b2[c];
     for (int r = 0; r < a.Cr; ++r) z = fmaf(a.w2[(size_t)c * a.Cr + r], sh[r], z);
     const float gt = 1.f / (1.f + expf(-z));
-    sg[c] = gt;
+    sg[c] = a.qgate ? gt * a.qgate[(size_t)n * a.C + c] : gt;      // x * gate_ca, then * gate_q (QRCAB order)
     if (j == 0) a.gate[(size_t)n * a.C + c] = gt;
   }
   __syncthreads();
@@ -315,6 +316,7 @@ struct CaBwdFused {
   const uint4* dy; const float* partial; const float* hidden; const float* gate; const float* w1; const float* w2;
   float* dz; uint4* dt;
   int N, HW, C, Cr, nchunks, per_image; float inv_hw;
+  const float* qgate; float* dzq;      // meta-attention gate [N,C] and the gradient before ITS sigmoid (out), or NULL
 };
 __global__ void __launch_bounds__(256) ca_bwd_fused_kernel(CaBwdFused a) {
   __shared__ float sdz[CA_MAXC];
@@ -340,12 +342,16 @@ __global__ void __launch_bounds__(256) ca_bwd_fused_kernel(CaBwdFused a) {
       s2 += part[(size_t)(k + 2) * a.C + c]; s3 += part[(size_t)(k + 3) * a.C + c];
     }
     for (; k < a.nchunks; ++k) s0 += part[(size_t)k * a.C + c];
-    const float ds = (s0 + s1) + (s2 + s3);
+    const float ds = (s0 + s1) + (s2 + s3);                // d(loss)/d(total gate): the block output is t * (gate_ca * gate_q)
     const float s = a.gate[(size_t)n * a.C + c];
-    const float dz = ds * s * (1.f - s);
+    const float gq = a.qgate ? a.qgate[(size_t)n * a.C + c] : 1.f;
+    const float dz = (ds * gq) * s * (1.f - s);
     sdz[c] = dz;
-    sg[c] = s;
-    if (j == 0) a.dz[(size_t)n * a.C + c] = dz;          // for the parameter-gradient launch (rumpy_ca_mlp_bwd_params, nchunks = 1)
+    sg[c] = s * gq;
+    if (j == 0) {
+      a.dz[(size_t)n * a.C + c] = dz;                      // for the parameter-gradient launch (rumpy_ca_mlp_bwd_params, nchunks = 1)
+      if (a.dzq) a.dzq[(size_t)n * a.C + c] = (ds * s) * gq * (1.f - gq);
+    }
   }
   __syncthreads();
   if (c < a.Cr) {
@@ -455,6 +461,7 @@ extern "C" int rumpy_ca_fwd_fused(const rumpy_ca_fwd_fused_args* p, void* stream
   d.t = (const uint4*)p->t; d.res = (const uint4*)p->res; d.out = (uint4*)p->out;
   d.N = p->N; d.HW = p->HW; d.C = p->C; d.Cr = p->Cr; d.ntiles = p->ntiles; d.inv_hw = p->inv_hw; d.per_image = ca_per_image(p->N, p->HW, p->C);
   d.image_stride = p->ntiles * p->C;
+  d.qgate = p->qgate;
   if (p->ntiles > 2 * CA_FOLD) {      // fold the partial rows in place first (pool is scratch of the producing conv)
     hipLaunchKernelGGL(ca_pool_fold_kernel, dim3(CA_FOLD, p->N), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(p->pool), p->ntiles, p->C);
     d.ntiles = CA_FOLD;
@@ -468,8 +475,91 @@ extern "C" int rumpy_ca_bwd_fused(const rumpy_ca_bwd_fused_args* p, void* stream
   if (!ca_shape_ok(p->C, p->Cr) || p->N <= 0 || p->HW <= 0 || p->nchunks <= 0) { rumpy_set_error("rumpy_ca_bwd_fused: unsupported shape"); return RUMPY_E_ARG; }
   CaBwdFused d;
   d.dy = (const uint4*)p->dy; d.partial = p->partial; d.hidden = p->hidden; d.gate = p->gate; d.w1 = p->w1; d.w2 = p->w2;
-  d.dz = p->dz; d.dt = (uint4*)p->dt;
+  d.dz = p->dz; d.dt = (uint4*)p->dt; d.qgate = p->qgate; d.dzq = p->dzq;
+  if ((p->qgate == nullptr) != (p->dzq == nullptr)) { rumpy_set_error("rumpy_ca_bwd_fused: qgate and dzq go together"); return RUMPY_E_ARG; }
   d.N = p->N; d.HW = p->HW; d.C = p->C; d.Cr = p->Cr; d.nchunks = p->nchunks; d.inv_hw = p->inv_hw; d.per_image = ca_per_image(p->N, p->HW, p->C);
   hipLaunchKernelGGL(ca_bwd_fused_kernel, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
   return rumpy_check_launch("rumpy_ca_bwd_fused");
+}
+
+// ---- meta-attention (q-layer, rumpy/SISR/models/attention_manipulators/q_layer.py:5-45): gate_q = sigmoid(W2 relu(W1 m + b1) + b2) from
+// the per-image metadata vector m [M]; it depends on metadata and weights only, so all layers of a network are evaluated by ONE
+// launch before the forward pass and their parameter gradients by ONE launch after the backward pass.
+constexpr int Q_MAXN = 64, Q_MAXH = 64, Q_MAXM = 32, Q_MAXC = 64;
+__global__ void __launch_bounds__(64) q_mlp_fwd_kernel(const rumpy_q_mlp_item* __restrict__ items, const float* __restrict__ meta,
+                                                       int N, int M, int Hq, int C) {
+  __shared__ float sm[Q_MAXM], sh[Q_MAXH];
+  const rumpy_q_mlp_item it = items[blockIdx.x];
+  const int n = blockIdx.y, t = threadIdx.x;
+  if (t < M) sm[t] = meta[(size_t)n * M + t];
+  __syncthreads();
+  if (t < Hq) {
+    float h = it.b1[t];
+    for (int m = 0; m < M; ++m) h = fmaf(it.w1[(size_t)t * M + m], sm[m], h);
+    h = fmaxf(h, 0.f);
+    sh[t] = h;
+    it.hidden[(size_t)n * Hq + t] = h;
+  }
+  __syncthreads();
+  if (t < C) {
+    float z = it.b2[t];
+    for (int k = 0; k < Hq; ++k) z = fmaf(it.w2[(size_t)t * Hq + k], sh[k], z);
+    it.gate[(size_t)n * C + t] = 1.f / (1.f + expf(-z));
+  }
+}
+
+// one workgroup per layer; sums over images in a fixed order (deterministic)
+__global__ void __launch_bounds__(256) q_mlp_bwd_params_kernel(const rumpy_q_mlp_item* __restrict__ items, const float* __restrict__ meta,
+                                                               int N, int M, int Hq, int C) {
+  __shared__ float sdz[Q_MAXN * Q_MAXC];
+  __shared__ float shid[Q_MAXN * Q_MAXH];
+  __shared__ float sdh[Q_MAXN * Q_MAXH];
+  __shared__ float smeta[Q_MAXN * Q_MAXM];
+  const rumpy_q_mlp_item it = items[blockIdx.x];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < N * C; i += 256) sdz[i] = it.dzq[i];
+  for (int i = tid; i < N * Hq; i += 256) shid[i] = it.hidden[i];
+  for (int i = tid; i < N * M; i += 256) smeta[i] = meta[i];
+  __syncthreads();
+  for (int i = tid; i < N * Hq; i += 256) {           // dh[n][h] = relu'(hidden) * sum_c W2[c][h] dz[n][c]
+    const int n = i / Hq, h = i - n * Hq;
+    float d = 0.f;
+    for (int c = 0; c < C; ++c) d = fmaf(it.w2[(size_t)c * Hq + h], sdz[n * C + c], d);
+    sdh[i] = (shid[i] > 0.f) ? d : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < C * Hq; i += 256) {            // gW2[c][h] = sum_n dz[n][c] hidden[n][h]
+    const int c = i / Hq, h = i - c * Hq;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(sdz[n * C + c], shid[n * Hq + h], s);
+    it.gw2[i] = s * it.scale;
+  }
+  for (int i = tid; i < Hq * M; i += 256) {            // gW1[h][m] = sum_n dh[n][h] meta[n][m]
+    const int h = i / M, m = i - h * M;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(sdh[n * Hq + h], smeta[n * M + m], s);
+    it.gw1[i] = s * it.scale;
+  }
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += sdz[n * C + c];
+    it.gb2[c] = s * it.scale;
+  }
+  for (int h = tid; h < Hq; h += 256) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += sdh[n * Hq + h];
+    it.gb1[h] = s * it.scale;
+  }
+}
+
+static bool q_shape_ok(int N, int M, int Hq, int C) { return N > 0 && N <= Q_MAXN && M > 0 && M <= Q_MAXM && Hq > 0 && Hq <= Q_MAXH && C > 0 && C <= Q_MAXC; }
+extern "C" int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream) {
+  if (!items_device || !meta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_fwd: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(q_mlp_fwd_kernel, dim3(nitems, N), dim3(64), 0, (hipStream_t)stream, items_device, meta, N, M, Hq, C);
+  return rumpy_check_launch("rumpy_q_mlp_fwd");
+}
+extern "C" int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream) {
+  if (!items_device || !meta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_bwd_params: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(q_mlp_bwd_params_kernel, dim3(nitems), dim3(256), 0, (hipStream_t)stream, items_device, meta, N, M, Hq, C);
+  return rumpy_check_launch("rumpy_q_mlp_bwd_params");
 }

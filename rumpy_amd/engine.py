@@ -43,14 +43,24 @@ class CALayerParams:
         self.gw1 = self.gb1 = self.gw2 = self.gb2 = None
 
 
+class QLayerParams(CALayerParams):
+    """Meta-attention q-layer (ParaCALayer, attention_manipulators/q_layer.py:5-45, two FC layers): w1 [Hq,M], w2 [C,Hq]."""
+
+    def __init__(self, name, w1, b1, w2, b2):
+        super().__init__(name, w1, b1, w2, b2)
+        self.Hq, self.M = w1.shape[0], w1.shape[1]
+
+
 class NetSpec:
     """Topology handed over by the architecture module.
 
-    body items: ('resblock', conv1, conv2, res_scale) | ('rcab', conv1, conv2, ca) | ('group', [items], conv)
+    body items: ('resblock', conv1, conv2, res_scale) | ('rcab', conv1, conv2, ca[, q]) | ('group', [items], conv)
+    (q: QLayerParams of a QRCAB's meta-attention node or None; num_metadata > 0 makes forward() expect a metadata matrix)
     """
 
-    def __init__(self, head, body, body_conv, ups, tail, scale):
+    def __init__(self, head, body, body_conv, ups, tail, scale, num_metadata=0):
         self.head, self.body, self.body_conv, self.ups, self.tail, self.scale = head, body, body_conv, ups, tail, scale
+        self.num_metadata = num_metadata
 
     def convs(self):
         out = [self.head]
@@ -178,6 +188,8 @@ class SREngine:
         protected = []          # data_ptrs of live skip sources (eval-mode buffer reuse must not recycle them)
         plan.scaled = []
         plan.ca_param_items = []
+        plan.q_items, plan.q_shape, plan.q_dev = [], None, None
+        plan.meta = self._new(plan, N, max(1, spec.num_metadata), dtype=torch.float32) if spec.num_metadata else None
 
         def act():
             if not train and free_pool:
@@ -236,7 +248,17 @@ class SREngine:
                     release(cur)
                     cur = y
                 elif it[0] == 'rcab':
-                    _, c1, c2, ca = it
+                    _, c1, c2, ca = it[:4]
+                    q = it[4] if len(it) > 4 else None
+                    qh = qg = qdz = None
+                    if q is not None:      # meta-attention gate of this QRCAB: evaluated for all layers by one launch before the forward ops
+                        qh = self._new(plan, N, q.Hq, dtype=torch.float32)
+                        qg = self._new(plan, N, F, dtype=torch.float32)
+                        qdz = self._new(plan, N, F, dtype=torch.float32) if train else None
+                        plan.q_items.append(L.QMlpItem(w1=_ptr(q.w1), b1=_ptr(q.b1), w2=_ptr(q.w2), b2=_ptr(q.b2), hidden=_ptr(qh),
+                                                       gate=_ptr(qg), dzq=_ptr(qdz), gw1=_ptr(q.gw1), gb1=_ptr(q.gb1), gw2=_ptr(q.gw2),
+                                                       gb2=_ptr(q.gb2), scale=1.0))
+                        plan.q_shape = (q.M, q.Hq)
                     t1, t2, y = act(), act(), act()
                     pool = self._new(plan, N, tiles, F, dtype=torch.float32)
                     mean = self._new(plan, N, F, dtype=torch.float32)
@@ -255,9 +277,9 @@ class SREngine:
                     fwd.append(('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(
                         pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2), b2=_ptr(ca.b2), mean=_ptr(mean),
                         hidden=_ptr(hid), gate=_ptr(gate), t=_ptr(t2), res=_ptr(cur), out=_ptr(y), N=N, HW=H * W, C=F, Cr=ca.Cr,
-                        ntiles=tiles, inv_hw=1.0 / (H * W))))
+                        ntiles=tiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg))))
 
-                    def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused):
+                    def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused, qg=qg, qdz=qdz):
                         # y = x + t2*gate:  dgate = sum(g*t2) -> MLP backward -> dpool ; dt2 = g*gate + dpool
                         nchunks = (H * W + 127) // 128
                         part = self._new(plan, N, nchunks, F, dtype=torch.float32)
@@ -269,7 +291,8 @@ class SREngine:
                         # of ALL channel-attention layers, which come from one launch after the backward chain
                         bwd.append(('rumpy_ca_bwd_fused', L.CaBwdFusedArgs(
                             dy=_ptr(g_out), partial=_ptr(part), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
-                            dz=_ptr(dz), dt=_ptr(dt2), N=N, HW=H * W, C=F, Cr=ca.Cr, nchunks=nchunks, inv_hw=1.0 / (H * W))))
+                            dz=_ptr(dz), dt=_ptr(dt2), N=N, HW=H * W, C=F, Cr=ca.Cr, nchunks=nchunks, inv_hw=1.0 / (H * W),
+                            qgate=_ptr(qg), dzq=_ptr(qdz))))
                         plan.ca_param_items.append(L.CaMlpBwdArgs(
                             partial=_ptr(dz), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
                             dpool=_ptr(dz), gw1=_ptr(ca.gw1), gb1=_ptr(ca.gb1), gw2=_ptr(ca.gw2), gb2=_ptr(ca.gb2), N=N, C=F, Cr=ca.Cr,
@@ -486,7 +509,37 @@ class SREngine:
             if getattr(plan, 'ca_params_dev', None) is None:
                 plan.ca_params_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
             plan.ca_params_dev.copy_(torch.from_numpy(raw), non_blocking=False)
+        if plan.q_items:
+            for a in plan.q_items:
+                a.scale = gs
+            self._upload_q_items(plan)
         plan.grad_scale = gs
+
+    def _upload_q_items(self, plan):
+        arr = (L.QMlpItem * len(plan.q_items))(*plan.q_items)
+        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+        if plan.q_dev is None:
+            plan.q_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
+        plan.q_dev.copy_(torch.from_numpy(raw), non_blocking=False)
+
+    def _q_gates(self, plan, meta, stream):
+        """metadata [N,M] -> the meta-attention gates of every q-layer (one launch)"""
+        if not plan.q_items:
+            return
+        if meta is None or tuple(meta.shape) != tuple(plan.meta.shape):
+            raise RuntimeError('rumpy_amd: this network needs a metadata matrix of shape %s (got %s)'
+                               % (tuple(plan.meta.shape), None if meta is None else tuple(meta.shape)))
+        plan.meta.copy_(meta, non_blocking=True)
+        if plan.q_dev is None:
+            self._upload_q_items(plan)
+        M, Hq = plan.q_shape
+        L.check(self.lib.rumpy_q_mlp_fwd(_ptr(plan.q_dev), len(plan.q_items), _ptr(plan.meta), plan.N, M, Hq, self.feats, stream), 'rumpy_q_mlp_fwd')
+
+    def _q_param_grads(self, plan, stream):
+        if plan.q_items:
+            M, Hq = plan.q_shape
+            L.check(self.lib.rumpy_q_mlp_bwd_params(_ptr(plan.q_dev), len(plan.q_items), _ptr(plan.meta), plan.N, M, Hq, self.feats, stream),
+                    'rumpy_q_mlp_bwd_params')
 
     # ------------------------------------------------------------------ execution
     def plan_for(self, N, H, W, train):
@@ -504,11 +557,13 @@ class SREngine:
             if rc != 0:
                 L.check(rc, name)
 
-    def forward(self, x, train=False, target=None):
-        """x (and target): contiguous fp32 [N,C,H,W] on the device.  Returns (out fp32 [N,C,sH,sW], loss tensor | None, plan)."""
+    def forward(self, x, train=False, target=None, meta=None):
+        """x (and target): contiguous fp32 [N,C,H,W] on the device; meta: fp32 [N,M] metadata (meta-attention nets only).
+        Returns (out fp32 [N,C,sH,sW], loss tensor | None, plan)."""
         N, _, H, W = x.shape
         plan = self.plan_for(N, H, W, train)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._q_gates(plan, meta, stream)
         # the head / tail kernels read the caller's fp32 NCHW tensors in place and write a fresh output tensor: no copies
         plan.x_ref, plan.target_ref = x, target           # keep them alive until the backward pass has consumed them
         plan.head_args.x = x.data_ptr()
@@ -539,6 +594,7 @@ class SREngine:
         plan.tail_fused = False
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
+        self._q_param_grads(plan, stream)
         for mt in (4, 1):
             if mt in plan.job_dev and not (mt == 1 and tail_done):
                 dev, n = plan.job_dev[mt]
@@ -600,6 +656,7 @@ class SREngine:
         """backward launch list of the fused L1 pass (captured into the hipGraph): the tail weight gradient came from tail_fwd"""
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
+        self._q_param_grads(plan, stream)
         if 4 in plan.job_dev:
             dev, n = plan.job_dev[4]
             L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 4, 0, stream), 'rumpy_wgrad_grouped')

@@ -223,7 +223,7 @@ class BaseModel(nn.Module):
         dev = self._torch_device()
         x, y = x.to(device=dev, non_blocking=True), y.to(device=dev, non_blocking=True)
         if self._fused_l1():
-            loss, out = self.net.fused_l1_forward_backward(x, y)
+            loss, out = self.net.fused_l1_forward_backward(x, y, metadata=kwargs.get('extra_channels'))
             self._apply_update(scheduler_skip)
         else:
             out = self.run_model(x, image_names=tag, **kwargs)
@@ -253,7 +253,7 @@ class BaseModel(nn.Module):
                 torch.cuda.synchronize(dev)
                 tic = time.perf_counter()
             if want_loss and self._fused_l1():
-                out, loss_t = self.net.l1_eval(x, y.to(device=dev))
+                out, loss_t = self.net.l1_eval(x, y.to(device=dev), metadata=kwargs.get('extra_channels'))
             else:
                 out = self.run_model(x, image_names=tag, **kwargs)
                 loss_t = self.find_loss(out, y.to(device=dev)) if want_loss else None

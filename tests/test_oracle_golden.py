@@ -182,3 +182,41 @@ def test_g10_patch_pipeline_oracle_matches_reference_functions(golden_dir):
         assert np.array_equal(hp.numpy(), g['hr_%d' % case]), case
         seen.add((h, v, r))
     assert len(seen) == 8, 'the fixture should exercise every flip / transpose combination'
+
+
+def test_g12_qrcan_meta_attention_oracle_matches_reference_handler(golden_dir):
+    """oracle QRCAN (style 'standard' + meta-attention q-layers) and the handler-level step with metadata against three
+    training steps and one evaluation of the REAL reference QRCANHandler (tests/golden/make_golden_qrcan.py)."""
+    g = np.load(os.path.join(golden_dir, 'g12_qrcan_small_train.npz'))
+    M = int(g['num_metadata'])
+    net = O.build_oracle('qrcan', scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard',
+                         include_q_layer=True, num_metadata=M)
+    assert list(net.state_dict().keys()) == [str(k) for k in g['keys']]
+    torch.manual_seed(8)     # same seed -> same initial weights: the restatement creates its layers in the reference's order
+    net8 = O.build_oracle('qrcan', scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard',
+                          include_q_layer=True, num_metadata=M)
+    init8 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in net8.state_dict().values()])
+    assert np.allclose(init8, g['init8'], rtol=0, atol=1e-12)
+    net.load_state_dict(O.seeded_state_dict(net, 811))
+    h = O.OracleHandler(net, lr=1e-3, scheduler='cosine_annealing_warm_restarts',
+                        scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+
+    def meta(seed, n):    # QModel.generate_channels (attention_manipulators/__init__.py:84-103): [N,M] -> [N,M,1,1]
+        m = np.random.default_rng(seed).uniform(0, 1, (n, M)).astype(np.float32)
+        return torch.from_numpy(m).unsqueeze(2).unsqueeze(3)
+    for step in range(3):
+        xb, yb = O.synthetic_batch(700 + step, 2, lr_hw=12, scale=2)
+        loss, out = h.run_train(xb, yb, extra_channels=meta(750 + step, 2))
+        assert abs(float(loss) - float(g['loss%d' % step])) < 1e-6
+        assert abs(h.get_learning_rate() - float(g['lr_after%d' % step])) < 1e-12
+        if step == 0:
+            assert np.allclose(out.numpy(), g['out0'], atol=1e-6)
+            for k, p in net.named_parameters():
+                assert np.allclose(p.grad.numpy(), g['grad0.' + k], atol=1e-6, rtol=1e-4), k
+            for k, v in net.state_dict().items():
+                assert np.allclose(v.numpy(), g['w1.' + k], atol=1e-6), k
+    for k, v in net.state_dict().items():
+        assert np.allclose(v.numpy(), g['w3.' + k], atol=2e-6), k
+    xe, ye = O.synthetic_batch(790, 1, lr_hw=10, scale=2)
+    ev, evl, _ = h.run_eval(xe, ye, request_loss=True, extra_channels=meta(791, 1))
+    assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6

@@ -1,0 +1,161 @@
+"""-m gpu parity for the meta-attention row: the HIP QRCAN ('standard' style + q-layers) through the QModel
+handler API against the CPU oracle (pinned on the real reference handler by golden G12), and the two q-layer kernels against
+plain torch.  Tolerances as in test_network_gpu.py (bf16 operands / activations, fp32 master weights and gates)."""
+import ctypes
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sr_oracle as O
+from rumpy_amd import _lib as L
+from rumpy_amd.shared_framework.models import define_model
+from tests.test_network_gpu import _grad_check, self_psnr
+
+SCHED = {'scheduler': 'cosine_annealing_warm_restarts', 'scheduler_params': {'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7}}
+
+
+def _meta(seed, n, m):
+    return torch.from_numpy(np.random.default_rng(seed).uniform(0, 1, (n, m)).astype(np.float32))
+
+
+def _pair(names, wseed, eval_mode=False, lr=1e-3, **kw):
+    h = define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=eval_mode, checkpoint_load=False, loss_masking=False,
+                     metadata_list=None, metadata=list(names), style='standard', include_q_layer=True, lr=lr,
+                     **({} if eval_mode else SCHED), **kw)
+    onet = O.build_oracle('qrcan', style='standard', include_q_layer=True, num_metadata=h.num_metadata, **kw)
+    assert list(onet.state_dict().keys()) == list(h.net.state_dict().keys())
+    sd = O.seeded_state_dict(onet, wseed)
+    onet.load_state_dict(sd)
+    h.net.load_state_dict(sd)
+    oh = O.OracleHandler(onet, lr=lr, eval_mode=eval_mode, scheduler=None if eval_mode else SCHED['scheduler'],
+                         scheduler_params=SCHED['scheduler_params'])
+    return h, oh
+
+
+def test_q_mlp_kernels_against_torch():
+    dev = torch.device('cuda:0')
+    lib = L.load()
+    N, M, C = 7, 5, 64
+    Hq = C // 2
+    g = torch.Generator().manual_seed(5)
+    items, keep = [], []
+    for _ in range(3):
+        w1, b1 = torch.randn(Hq, M, generator=g) * 0.5, torch.randn(Hq, generator=g) * 0.2
+        w2, b2 = torch.randn(C, Hq, generator=g) * 0.3, torch.randn(C, generator=g) * 0.2
+        dz = torch.randn(N, C, generator=g)
+        d = [t.to(dev).contiguous() for t in (w1, b1, w2, b2, dz)]
+        outs = [torch.zeros(N, Hq, device=dev), torch.zeros(N, C, device=dev), torch.zeros(Hq, M, device=dev), torch.zeros(Hq, device=dev),
+                torch.zeros(C, Hq, device=dev), torch.zeros(C, device=dev)]
+        keep.append((w1, b1, w2, b2, dz, d, outs))
+        items.append(L.QMlpItem(w1=d[0].data_ptr(), b1=d[1].data_ptr(), w2=d[2].data_ptr(), b2=d[3].data_ptr(), hidden=outs[0].data_ptr(),
+                                gate=outs[1].data_ptr(), dzq=d[4].data_ptr(), gw1=outs[2].data_ptr(), gb1=outs[3].data_ptr(),
+                                gw2=outs[4].data_ptr(), gb2=outs[5].data_ptr(), scale=0.5))
+    arr = (L.QMlpItem * len(items))(*items)
+    tab = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+    meta = _meta(3, N, M)
+    md = meta.to(dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    L.check(lib.rumpy_q_mlp_fwd(tab.data_ptr(), len(items), md.data_ptr(), N, M, Hq, C, s), 'fwd')
+    L.check(lib.rumpy_q_mlp_bwd_params(tab.data_ptr(), len(items), md.data_ptr(), N, M, Hq, C, s), 'bwd')
+    torch.cuda.synchronize()
+    for w1, b1, w2, b2, dz, d, outs in keep:
+        p = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        hid = torch.relu(meta @ p[0].t() + p[1])
+        z = hid @ p[2].t() + p[3]
+        assert torch.allclose(outs[0].cpu(), hid.detach(), atol=1e-5)
+        assert torch.allclose(outs[1].cpu(), torch.sigmoid(z).detach(), atol=1e-5)
+        (z * dz).sum().backward()        # dz = gradient in front of the sigmoid
+        for got, ref in zip(outs[2:], (p[0].grad, p[1].grad, p[2].grad, p[3].grad)):
+            assert torch.allclose(got.cpu(), 0.5 * ref, atol=1e-4, rtol=1e-4)
+    # shapes beyond the kernel's tables are refused, not truncated
+    assert lib.rumpy_q_mlp_fwd(tab.data_ptr(), len(items), md.data_ptr(), 65, M, Hq, C, s) != 0
+    assert lib.rumpy_q_mlp_fwd(tab.data_ptr(), len(items), md.data_ptr(), N, 33, Hq, C, s) != 0
+
+
+@pytest.mark.parametrize('names,kw', [
+    (['blur_sigma', 'noise_level', 'jpeg_q', 'extra_a', 'extra_b'], dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16)),
+    (['qpi'], dict(scale=4, n_feats=64, n_resgroups=1, n_resblocks=2, reduction=16)),
+    (['m%02d' % i for i in range(18)], dict(scale=2, n_feats=64, n_resgroups=1, n_resblocks=1, reduction=16)),     # > 15 entries: wider hidden layer
+])
+def test_qrcan_train_steps_against_oracle(names, kw):
+    h, oh = _pair(names, 821, **kw)
+    M, sc = len(names), kw['scale']
+    keys = [(n, 'numeric') for n in names]
+    for step in range(3):
+        x, y = O.synthetic_batch(830 + step, 3, lr_hw=16, scale=sc)
+        m = _meta(840 + step, 3, M)
+        loss, out = h.run_train(x=x, y=y, metadata=m, metadata_keys=keys)
+        oloss, oout = oh.run_train(x, y, extra_channels=m.unsqueeze(2).unsqueeze(3))
+        assert abs(float(loss) - float(oloss)) < (2e-3 if step == 0 else 5e-3) * float(oloss)
+        assert abs(h.get_learning_rate() - oh.get_learning_rate()) < 1e-12
+        if step == 0:
+            assert self_psnr(out, oout) >= 50.0
+            worst = _grad_check(h, oh)
+            print('worst grad rel err', worst)
+            for k, p in h.net.named_parameters():
+                if 'q_node' in k:
+                    assert float(p.grad.abs().max()) > 0, k
+    assert h.metadata_keys_used_in_training == names
+
+
+def test_qrcan_metadata_is_selected_by_key_and_changes_the_output():
+    names = ['noise_level', 'blur_sigma']
+    h, oh = _pair(names, 822, eval_mode=True, scale=2, n_feats=64, n_resgroups=1, n_resblocks=2, reduction=16)
+    x, y = O.synthetic_batch(850, 2, lr_hw=20, scale=2)
+    # the dataset delivers more attributes than the model was built for: QModel keeps the columns whose key is in its list
+    keys = [('jpeg_q',), ('blur_sigma',), ('unused',), ('noise_level',)]
+    full = _meta(851, 2, 4)
+    out, loss, _ = h.run_eval(x=x, y=y, request_loss=True, metadata=full, metadata_keys=keys)
+    picked = full[:, [1, 3]].unsqueeze(2).unsqueeze(3)
+    oout, oloss, _ = oh.run_eval(x, y, request_loss=True, extra_channels=picked)
+    assert self_psnr(out, oout) >= 50.0 and abs(float(loss) - float(oloss)) < 2e-3 * float(oloss)
+    out2, _, _ = h.run_eval(x=x, extra_channels=(1.0 - picked))
+    assert not torch.equal(out, out2)
+    with pytest.raises(RuntimeError):
+        h.run_eval(x=x)                                       # no metadata at all
+    with pytest.raises(RuntimeError):
+        h.run_eval(x=x, extra_channels=torch.zeros(2, 3, 1, 1))   # wrong width
+
+
+def test_qrcan_checkpoint_roundtrip_and_oracle_interchange():
+    names = ['a', 'b', 'c']
+    kw = dict(scale=2, n_feats=64, n_resgroups=1, n_resblocks=2, reduction=16)
+    h, oh = _pair(names, 823, **kw)
+    keys = [(n,) for n in names]
+    x, y = O.synthetic_batch(860, 2, lr_hw=16, scale=2)
+    m = _meta(861, 2, 3)
+    h.run_train(x=x, y=y, metadata=m, metadata_keys=keys)
+    h.set_epoch(4)
+    h.save_model('train_model')
+    path = os.path.join(h.model_save_dir, 'train_model_4')
+    st = torch.load(path, map_location='cpu', weights_only=False)
+    assert st['model_name'] == 'qrcan' and st['metadata_keys_used_in_training'] == names
+    assert list(st['network'].keys()) == list(oh.net.state_dict().keys())
+    # optimizer state indices follow the reference's registration order: parameter 0 is final_body.weight
+    n_par = len(list(oh.net.parameters()))
+    assert sorted(st['optimizer']['state'].keys()) == list(range(n_par))
+    assert tuple(st['optimizer']['state'][0]['exp_avg'].shape) == tuple(oh.net.final_body.weight.shape)
+    h2, oh2 = _pair(names, 999, **kw)
+    h2.model_save_dir = h.model_save_dir
+    h2.load_model('train_model', 4)
+    oh2.net.load_state_dict(st['network'])
+    oh2.optimizer.load_state_dict(st['optimizer'])
+    x2, y2 = O.synthetic_batch(862, 2, lr_hw=16, scale=2)
+    m2 = _meta(863, 2, 3)
+    l_a, o_a = h.run_train(x=x2, y=y2, metadata=m2, metadata_keys=keys)
+    l_b, o_b = h2.run_train(x=x2, y=y2, metadata=m2, metadata_keys=keys)
+    assert torch.equal(o_a, o_b) and float(l_a) == float(l_b)
+    l_o, o_o = oh2.run_train(x2, y2, extra_channels=m2.unsqueeze(2).unsqueeze(3))
+    assert self_psnr(o_b, o_o) >= 50.0 and abs(float(l_b) - float(l_o)) < 3e-3 * float(l_o)
+
+
+def test_unsupported_qrcan_variants_are_refused():
+    for bad in (dict(style='modulate'), dict(style='standard', include_pixel_attention=True), dict(style='standard', include_sft_layer=True),
+                dict(style='standard', srmd_mode=True), dict(style='standard', use_moco=True)):
+        with pytest.raises(RuntimeError):
+            define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, n_resgroups=1, n_resblocks=1, **bad)
