@@ -41,8 +41,8 @@ def main():
     ap.add_argument('--probe-steps', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--model', choices=('edsr', 'rcan'), default='edsr',
-                    help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), for information')
+    ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan'), default='edsr',
+                    help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block; both for information')
     ap.add_argument('--device-patches', action='store_true',
                     help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
     args = ap.parse_args()
@@ -75,7 +75,9 @@ def main():
     flop_per_patch = FLOP_PER_PATCH_TRAIN if args.model == 'edsr' else 220.04e9
     torch.manual_seed(8)                                    # reference default seed (net_train.py:20)
     h = define_model(args.model, model_save_dir=tempfile.mkdtemp(), device=local_rank, eval_mode=False, checkpoint_load=False,
-                     loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
+                     loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED,
+                     **(dict(style='standard', include_q_layer=True, metadata=['m%d' % i for i in range(5)]) if args.model == 'qrcan' else {}))
+    meta_pool = [torch.rand(N, 5, 1, 1, generator=torch.Generator().manual_seed(77 + i)).to(dev) for i in range(8)] if args.model == 'qrcan' else None
     if world > 1:
         broadcast_parameters(h.net)
         h.set_multi_gpu()
@@ -100,6 +102,8 @@ def main():
             x, y = src.sample([(i * N + k) % len(src) for k in range(N)], rng=random)
         else:
             x, y = pool[i % len(pool)]
+        if meta_pool is not None:
+            return h.run_train(x=x, y=y, keep_on_device=True, extra_channels=meta_pool[i % len(meta_pool)])
         return h.run_train(x=x, y=y, keep_on_device=True)
 
     def fence():
@@ -185,7 +189,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.manual_seed(8)
-        onet = O.build_oracle(args.model, scale=4)
+        onet = O.build_oracle(args.model, scale=4, **(dict(style='standard', include_q_layer=True, num_metadata=5) if args.model == 'qrcan' else {}))
+        cpu_meta = torch.rand(args.cpu_batch, 5, 1, 1) if args.model == 'qrcan' else None
         oh = O.OracleHandler(onet, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
         try:
             usable = len(os.sched_getaffinity(0))
@@ -202,27 +207,27 @@ def main():
         nb = args.cpu_batch                              # bounded sample: a few patches, same per-patch work
         xb, yb = O.synthetic_batch(1234, nb, lr_hw=48, scale=4)
         t1 = time.perf_counter()
-        oh.run_train(xb, yb)
+        oh.run_train(xb, yb, extra_channels=cpu_meta)
         warm = time.perf_counter() - t1
         best, timed = 1e30, 0
         while timed < 3 and (timed == 0 or (time.perf_counter() - t1) < 20.0):
             t2 = time.perf_counter()
-            oh.run_train(xb, yb)
+            oh.run_train(xb, yb, extra_channels=cpu_meta)
             best = min(best, time.perf_counter() - t2)
             timed += 1
         cpu = {'value': round(nb / best, 3), 'unit': 'LR patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': '1 warm-up + %d timed EDSR-baseline x4 train steps of %d 48x48 patches (best), torch CPU fp32 oracle; '
-                         'host reports %d logical CPUs, %d usable under the cgroup quota' % (timed, nb, os.cpu_count() or 0, usable),
+               'sample': '1 warm-up + %d timed %s x4 train steps of %d 48x48 patches (best), torch CPU fp32 oracle; '
+                         'host reports %d logical CPUs, %d usable under the cgroup quota' % (timed, {'edsr': 'EDSR-baseline'}.get(args.model, args.model.upper()), nb, os.cpu_count() or 0, usable),
                's_per_step': round(best, 3), 'warmup_s': round(warm, 3)}
 
     if rank == 0:
-        line = {'metric': '48px LR patches/sec (train step) EDSR x4 bf16' if args.model == 'edsr' else '48px LR patches/sec (train step) RCAN x4 bf16', 'value': round(value, 2), 'unit': 'LR patches/s',
+        line = {'metric': '48px LR patches/sec (train step) %s x4 bf16' % args.model.upper(), 'value': round(value, 2), 'unit': 'LR patches/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
                 'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
                          'random-init weights (seed 8)') if args.device_patches else
                         'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
-                'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)') +
+                'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)' + (' + meta-attention q-layers, 5 metadata entries' if args.model == 'qrcan' else '')) +
                                        ' train step, 48x48 LR patches, batch %d per GPU' % N,
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),

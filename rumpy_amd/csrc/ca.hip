@@ -485,67 +485,92 @@ extern "C" int rumpy_ca_bwd_fused(const rumpy_ca_bwd_fused_args* p, void* stream
 // ---- meta-attention (q-layer, rumpy/SISR/models/attention_manipulators/q_layer.py:5-45): gate_q = sigmoid(W2 relu(W1 m + b1) + b2) from
 // the per-image metadata vector m [M]; it depends on metadata and weights only, so all layers of a network are evaluated by ONE
 // launch before the forward pass and their parameter gradients by ONE launch after the backward pass.
-constexpr int Q_MAXN = 64, Q_MAXH = 64, Q_MAXM = 32, Q_MAXC = 64;
-__global__ void __launch_bounds__(64) q_mlp_fwd_kernel(const rumpy_q_mlp_item* __restrict__ items, const float* __restrict__ meta,
-                                                       int N, int M, int Hq, int C) {
-  __shared__ float sm[Q_MAXM], sh[Q_MAXH];
+constexpr int Q_MAXN = 64, Q_MAXH = 160, Q_MAXM = 256, Q_MAXC = 64;     // 256 -> 160 -> 64 is the contrastive-embedding q-layer
+constexpr int Q_NB = 8;                                                  // images per forward workgroup
+// grid (layers, ceil(N / Q_NB)), 256 threads.  Thread h owns hidden unit h for Q_NB images: its W1 row streams through L1 once,
+// the metadata rows are broadcast reads from LDS.  Then thread c owns output channel c the same way.
+__global__ void __launch_bounds__(256) q_mlp_fwd_kernel(const rumpy_q_mlp_item* __restrict__ items, const float* __restrict__ meta,
+                                                        int N, int M, int Hq, int C) {
+  __shared__ float sm[Q_NB * Q_MAXM];
+  __shared__ float sh[Q_NB * Q_MAXH];
   const rumpy_q_mlp_item it = items[blockIdx.x];
-  const int n = blockIdx.y, t = threadIdx.x;
-  if (t < M) sm[t] = meta[(size_t)n * M + t];
+  const int n0 = blockIdx.y * Q_NB, t = threadIdx.x;
+  const int nb = min(Q_NB, N - n0);
+  for (int i = t; i < Q_NB * M; i += 256) sm[i] = (i < nb * M) ? meta[(size_t)n0 * M + i] : 0.f;
   __syncthreads();
   if (t < Hq) {
-    float h = it.b1[t];
-    for (int m = 0; m < M; ++m) h = fmaf(it.w1[(size_t)t * M + m], sm[m], h);
-    h = fmaxf(h, 0.f);
-    sh[t] = h;
-    it.hidden[(size_t)n * Hq + t] = h;
+    float acc[Q_NB];
+    const float b = it.b1[t];
+#pragma unroll
+    for (int k = 0; k < Q_NB; ++k) acc[k] = b;
+    const float* wr = it.w1 + (size_t)t * M;
+    for (int m = 0; m < M; ++m) {
+      const float w = wr[m];
+#pragma unroll
+      for (int k = 0; k < Q_NB; ++k) acc[k] = fmaf(w, sm[k * M + m], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < Q_NB; ++k) {
+      const float h = fmaxf(acc[k], 0.f);
+      sh[k * Hq + t] = h;
+      if (k < nb) it.hidden[(size_t)(n0 + k) * Hq + t] = h;
+    }
   }
   __syncthreads();
   if (t < C) {
-    float z = it.b2[t];
-    for (int k = 0; k < Hq; ++k) z = fmaf(it.w2[(size_t)t * Hq + k], sh[k], z);
-    it.gate[(size_t)n * C + t] = 1.f / (1.f + expf(-z));
+    float acc[Q_NB];
+    const float b = it.b2[t];
+#pragma unroll
+    for (int k = 0; k < Q_NB; ++k) acc[k] = b;
+    const float* wr = it.w2 + (size_t)t * Hq;
+    for (int h = 0; h < Hq; ++h) {
+      const float w = wr[h];
+#pragma unroll
+      for (int k = 0; k < Q_NB; ++k) acc[k] = fmaf(w, sh[k * Hq + h], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < Q_NB; ++k)
+      if (k < nb) it.gate[(size_t)(n0 + k) * C + t] = 1.f / (1.f + expf(-acc[k]));
   }
 }
 
-// one workgroup per layer; sums over images in a fixed order (deterministic)
+// grid (layers, Q_PARTS), 256 threads.  Every workgroup rebuilds dh = relu'(hidden) * (W2^T dz) for its layer in LDS (cheap), then
+// writes its 1/Q_PARTS slice of the gradient entries; sums over images run in a fixed order (deterministic).
+constexpr int Q_PARTS = 8;
 __global__ void __launch_bounds__(256) q_mlp_bwd_params_kernel(const rumpy_q_mlp_item* __restrict__ items, const float* __restrict__ meta,
                                                                int N, int M, int Hq, int C) {
   __shared__ float sdz[Q_MAXN * Q_MAXC];
-  __shared__ float shid[Q_MAXN * Q_MAXH];
   __shared__ float sdh[Q_MAXN * Q_MAXH];
-  __shared__ float smeta[Q_MAXN * Q_MAXM];
   const rumpy_q_mlp_item it = items[blockIdx.x];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, part = blockIdx.y;
   for (int i = tid; i < N * C; i += 256) sdz[i] = it.dzq[i];
-  for (int i = tid; i < N * Hq; i += 256) shid[i] = it.hidden[i];
-  for (int i = tid; i < N * M; i += 256) smeta[i] = meta[i];
   __syncthreads();
   for (int i = tid; i < N * Hq; i += 256) {           // dh[n][h] = relu'(hidden) * sum_c W2[c][h] dz[n][c]
     const int n = i / Hq, h = i - n * Hq;
     float d = 0.f;
     for (int c = 0; c < C; ++c) d = fmaf(it.w2[(size_t)c * Hq + h], sdz[n * C + c], d);
-    sdh[i] = (shid[i] > 0.f) ? d : 0.f;
+    sdh[i] = (it.hidden[i] > 0.f) ? d : 0.f;
   }
   __syncthreads();
-  for (int i = tid; i < C * Hq; i += 256) {            // gW2[c][h] = sum_n dz[n][c] hidden[n][h]
+  const int gt = part * 256 + tid, gstride = Q_PARTS * 256;
+  for (int i = gt; i < C * Hq; i += gstride) {         // gW2[c][h] = sum_n dz[n][c] hidden[n][h]
     const int c = i / Hq, h = i - c * Hq;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(sdz[n * C + c], shid[n * Hq + h], s);
+    for (int n = 0; n < N; ++n) s = fmaf(sdz[n * C + c], it.hidden[(size_t)n * Hq + h], s);
     it.gw2[i] = s * it.scale;
   }
-  for (int i = tid; i < Hq * M; i += 256) {            // gW1[h][m] = sum_n dh[n][h] meta[n][m]
+  for (int i = gt; i < Hq * M; i += gstride) {         // gW1[h][m] = sum_n dh[n][h] meta[n][m]
     const int h = i / M, m = i - h * M;
     float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(sdh[n * Hq + h], smeta[n * M + m], s);
+    for (int n = 0; n < N; ++n) s = fmaf(sdh[n * Hq + h], meta[(size_t)n * M + m], s);
     it.gw1[i] = s * it.scale;
   }
-  for (int c = tid; c < C; c += 256) {
+  for (int c = gt; c < C; c += gstride) {
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += sdz[n * C + c];
     it.gb2[c] = s * it.scale;
   }
-  for (int h = tid; h < Hq; h += 256) {
+  for (int h = gt; h < Hq; h += gstride) {
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += sdh[n * Hq + h];
     it.gb1[h] = s * it.scale;
@@ -555,11 +580,11 @@ __global__ void __launch_bounds__(256) q_mlp_bwd_params_kernel(const rumpy_q_mlp
 static bool q_shape_ok(int N, int M, int Hq, int C) { return N > 0 && N <= Q_MAXN && M > 0 && M <= Q_MAXM && Hq > 0 && Hq <= Q_MAXH && C > 0 && C <= Q_MAXC; }
 extern "C" int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream) {
   if (!items_device || !meta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_fwd: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(q_mlp_fwd_kernel, dim3(nitems, N), dim3(64), 0, (hipStream_t)stream, items_device, meta, N, M, Hq, C);
+  hipLaunchKernelGGL(q_mlp_fwd_kernel, dim3(nitems, (N + Q_NB - 1) / Q_NB), dim3(256), 0, (hipStream_t)stream, items_device, meta, N, M, Hq, C);
   return rumpy_check_launch("rumpy_q_mlp_fwd");
 }
 extern "C" int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream) {
   if (!items_device || !meta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_bwd_params: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(q_mlp_bwd_params_kernel, dim3(nitems), dim3(256), 0, (hipStream_t)stream, items_device, meta, N, M, Hq, C);
+  hipLaunchKernelGGL(q_mlp_bwd_params_kernel, dim3(nitems, Q_PARTS), dim3(256), 0, (hipStream_t)stream, items_device, meta, N, M, Hq, C);
   return rumpy_check_launch("rumpy_q_mlp_bwd_params");
 }
