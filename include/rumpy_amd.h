@@ -149,6 +149,8 @@ typedef struct {
   const float* b;   /* [64*cout_tiles] */
   void* out;        /* [N,H,W,64*cout_tiles] bf16 */
   int32_t N, C, H, W, cout;
+  float neg_slope_m1;  /* negative-side slope MINUS ONE of the activation applied to the output: 0 = none (SR head),
+                          -0.9f = LeakyReLU(0.1) (first conv of the degradation encoder), -1 = ReLU */
 } rumpy_head_fwd_args;
 int rumpy_head_fwd(const rumpy_head_fwd_args* a, void* stream);
 
@@ -366,6 +368,22 @@ typedef struct {
 } rumpy_q_mlp_item;
 int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
 int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
+
+/* ---- degradation encoder of the blind-SR pipeline (frozen; rumpy/regression/models/contrastive_learning/encoding_models.py:5-55,
+ * called by ContrastiveBlindSRPipeline.forward, rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:241-329):
+ * nn.Conv2d(cin, cout, 3, stride, padding=1) + eval-mode BatchNorm2d (folded into w / bias by the host) + LeakyReLU, NHWC bf16 in and
+ * out, cin and cout multiples of 64; and nn.AdaptiveAvgPool2d(1) -> fp32 [N, C]. */
+typedef struct {
+  const void* x;       /* [N,H,W,cin] bf16 */
+  const void* w;       /* packed by rumpy_pack_weights (kind 0, shuffle 0): w_fwd */
+  const float* bias;   /* [cout] */
+  void* out;           /* [N,Ho,Wo,cout] bf16, Ho = (H-1)/stride + 1 */
+  int32_t N, H, W, cin, cout, stride;
+  float neg_slope;     /* LeakyReLU slope (1 = no activation, 0 = ReLU) */
+  int32_t pad_;
+} rumpy_enc_conv_args;
+int rumpy_enc_conv(const rumpy_enc_conv_args* a, void* stream);
+int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
 
 /* ---- optimizer: torch.optim.Adam semantics (base_architecture.py:93-95,437), flat fp32 buffers ---- */
 typedef struct {

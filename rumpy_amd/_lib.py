@@ -46,7 +46,13 @@ class ChainArgs(_S):
 
 class HeadFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('b', c_void_p), ('out', c_void_p),
-                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32)]
+                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32), ('neg_slope_m1', c_float)]
+
+
+class EncConvArgs(_S):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p),
+                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cin', c_int32), ('cout', c_int32), ('stride', c_int32),
+                ('neg_slope', c_float), ('pad_', c_int32)]
 
 
 class HeadWgradArgs(_S):
@@ -191,6 +197,8 @@ SYMBOLS = {
     'rumpy_conv_chain': (C.c_int, [_P(ChainArgs), c_void_p]),
     'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
+    'rumpy_enc_conv': (C.c_int, [_P(EncConvArgs), c_void_p]),
+    'rumpy_enc_pool': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),
     'rumpy_tail_fwd': (C.c_int, [_P(TailFwdArgs), c_void_p]),
     'rumpy_tail_fwd_grid': (C.c_int, [c_int32, c_int32, c_int32, c_int32]),

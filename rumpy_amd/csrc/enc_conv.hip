@@ -1,0 +1,125 @@
+// Degradation-encoder convolutions (frozen, inference only): the DASR-style `Encoder` the blind-SR pipeline runs in front of QRCAN
+// (rumpy/regression/models/contrastive_learning/encoding_models.py:5-55; ContrastiveBlindSRPipeline.forward,
+// rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:241-329).  Five of its six 3x3 convs have 64-multiple channel counts
+// (64->64, 64->128 /2, 128->128, 128->256 /2, 256->256), each followed by an eval-mode BatchNorm (folded into filter and bias on the
+// host, once - the encoder is frozen) and LeakyReLU(0.1); the first conv (3->64) goes through rumpy_head_fwd.  0.3 % of a blind-QRCAN
+// step's FLOPs, so the kernel is the plain form of the implicit GEMM the SR body uses:
+//   D[co 16][px 16] += A[co][k = 32 input channels of one tap] * B[k][px]          (v_mfma_f32_16x16x32_bf16)
+// workgroup = 4 output rows x 16 output columns x 64 output channels; wave w owns channels 16w.. of all four rows; per 64-channel
+// input chunk the halo tile is staged in LDS (unpadded 128-B pixels, 16-B chunk index XOR (pixel & 7)) and the wave's 18 filter
+// fragments are read straight from the packed image (kind-0 layout of rumpy_pack_weights, 1 KB coalesced per fragment).
+#include "common.hpp"
+
+struct EncConv {
+  const uint4* x; const uint4* w; const float* bias; uint16_t* out;
+  int N, H, W, Ho, Wo, chn, ctn, tiles_x, tiles_y;
+  float neg_slope;
+};
+
+template <int S>
+__global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
+  constexpr int IR = 3 * S + 3, IC = 15 * S + 3;          // input rows / columns under a 4 x 16 output tile
+  __shared__ uint4 lds[IR * IC * 8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+  const int ct = blockIdx.y;
+  int t = blockIdx.x;
+  const int tx = t % a.tiles_x; t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int n = t / a.tiles_y;
+  const int oy0 = ty * 4, ox0 = tx * 16, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int cin8 = a.chn * 8;                              // 16-byte vectors per input pixel
+  f32x4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ch = 0; ch < a.chn; ++ch) {
+    __syncthreads();
+    for (int v = tid; v < IR * IC * 8; v += 256) {
+      const int p = v >> 3, c8 = v & 7;
+      const int r = p / IC, c = p - r * IC;
+      const int y = iy0 + r, xx = ix0 + c;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (y >= 0 && y < a.H && xx >= 0 && xx < a.W) val = a.x[((size_t)(n * a.H + y) * a.W + xx) * cin8 + ch * 8 + c8];
+      lds[p * 8 + (c8 ^ (p & 7))] = val;
+    }
+    const uint4* wp = a.w + ((size_t)((ct * a.chn + ch) * 4 + wave) * 18) * 64 + lane;
+    uint4 F[18];
+#pragma unroll
+    for (int s = 0; s < 18; ++s) F[s] = wp[s * 64];
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int chunk = half * 4 + g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = (r * S + ky) * IC + j * S + kx;
+          const uint4 b = lds[p * 8 + (chunk ^ (p & 7))];
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(F[tap * 2 + half]), as_bf16x8(b), acc[r], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int co = ct * 64 + wave * 16 + 4 * g;              // D[m = 4g + i][n = j]
+  const float4 bv = *reinterpret_cast<const float4*>(a.bias + co);
+  const int cout = a.ctn * 64;
+  const int ox = ox0 + j;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oy = oy0 + r;
+    if (oy < a.Ho && ox < a.Wo) {
+      float v0 = acc[r][0] + bv.x, v1 = acc[r][1] + bv.y, v2 = acc[r][2] + bv.z, v3 = acc[r][3] + bv.w;
+      v0 = v0 > 0.f ? v0 : v0 * a.neg_slope; v1 = v1 > 0.f ? v1 : v1 * a.neg_slope;
+      v2 = v2 > 0.f ? v2 : v2 * a.neg_slope; v3 = v3 > 0.f ? v3 : v3 * a.neg_slope;
+      *reinterpret_cast<uint2*>(a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * cout + co) = pack4_bf16(v0, v1, v2, v3);
+    }
+  }
+}
+
+// AdaptiveAvgPool2d(1) over an NHWC bf16 map -> fp32 [N, C]; grid (N, C/64), fixed summation order (deterministic).
+__global__ void __launch_bounds__(256) enc_pool_kernel(const uint4* __restrict__ x, float* __restrict__ out, int HW, int C) {
+  __shared__ float red[32][65];
+  const int n = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x, c8 = tid & 7, pr = tid >> 3;
+  const int cvec = C / 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int p = pr; p < HW; p += 32) {
+    const uint4 v = x[((size_t)n * HW + p) * cvec + cg * 8 + c8];
+    float lo[4], hi[4];
+    unpack4_bf16(make_uint2(v.x, v.y), lo);
+    unpack4_bf16(make_uint2(v.z, v.w), hi);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i] += lo[i]; s[4 + i] += hi[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[pr][c8 * 8 + i] = s[i];
+  __syncthreads();
+  if (tid < 64) {
+    float tot = 0.f;
+    for (int k = 0; k < 32; ++k) tot += red[k][tid];
+    out[(size_t)n * C + cg * 64 + tid] = tot / (float)HW;
+  }
+}
+
+extern "C" int rumpy_enc_conv(const rumpy_enc_conv_args* p, void* stream) {
+  if (!p || !p->x || !p->w || !p->bias || !p->out) { rumpy_set_error("rumpy_enc_conv: null pointer"); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cin <= 0 || p->cin % 64 || p->cout <= 0 || p->cout % 64 || (p->stride != 1 && p->stride != 2)) {
+    rumpy_set_error("rumpy_enc_conv: unsupported shape (cin=%d cout=%d stride=%d)", p->cin, p->cout, p->stride); return RUMPY_E_ARG; }
+  EncConv a;
+  a.x = (const uint4*)p->x; a.w = (const uint4*)p->w; a.bias = p->bias; a.out = (uint16_t*)p->out;
+  a.N = p->N; a.H = p->H; a.W = p->W;
+  a.Ho = (p->H - 1) / p->stride + 1; a.Wo = (p->W - 1) / p->stride + 1;      // 3x3, padding 1
+  a.chn = p->cin / 64; a.ctn = p->cout / 64;
+  a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + 3) / 4;
+  a.neg_slope = p->neg_slope;
+  const dim3 grid((unsigned)(p->N * a.tiles_x * a.tiles_y), (unsigned)a.ctn);
+  if (p->stride == 1) hipLaunchKernelGGL(enc_conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(enc_conv_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  return rumpy_check_launch("rumpy_enc_conv");
+}
+
+extern "C" int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
+  if (!x || !out || N <= 0 || HW <= 0 || C <= 0 || C % 64) { rumpy_set_error("rumpy_enc_pool: bad argument"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(enc_pool_kernel, dim3(N, C / 64), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, out, HW, C);
+  return rumpy_check_launch("rumpy_enc_pool");
+}

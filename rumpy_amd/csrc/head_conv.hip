@@ -12,7 +12,7 @@ constexpr int HEAD_FWD_THREADS = 64;
 template <int C>
 __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, uint16_t* __restrict__ out,
-                                                       int N, int H, int W, int cout) {
+                                                       int N, int H, int W, int cout, float slope_m1) {
   __shared__ __attribute__((aligned(16))) float sw[9 * HEAD_MAXC * 64];
   __shared__ float sb[64];
   const int ct = blockIdx.y;
@@ -52,6 +52,10 @@ __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float*
       const float v = in[k];
       acc[0] = fmaf(v, w0.x, acc[0]); acc[1] = fmaf(v, w0.y, acc[1]); acc[2] = fmaf(v, w0.z, acc[2]); acc[3] = fmaf(v, w0.w, acc[3]);
       acc[4] = fmaf(v, w1.x, acc[4]); acc[5] = fmaf(v, w1.y, acc[5]); acc[6] = fmaf(v, w1.z, acc[6]); acc[7] = fmaf(v, w1.w, acc[7]);
+    }
+    if (slope_m1 != 0.f) {                                 // v + (slope - 1) * min(v, 0)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(slope_m1, fminf(acc[j], 0.f), acc[j]);
     }
     const uint2 lo = pack4_bf16(acc[0], acc[1], acc[2], acc[3]);
     const uint2 hi = pack4_bf16(acc[4], acc[5], acc[6], acc[7]);
@@ -183,10 +187,10 @@ extern "C" int rumpy_head_fwd(const rumpy_head_fwd_args* p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   uint16_t* o = (uint16_t*)p->out;
   switch (p->C) {
-    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
-    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
-    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
-    default: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout); break;
+    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
+    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
+    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
+    default: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
   }
   return rumpy_check_launch("rumpy_head_fwd");
 }
