@@ -41,8 +41,8 @@ def main():
     ap.add_argument('--probe-steps', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan'), default='edsr',
-                    help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block; both for information')
+    ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan', 'blindqrcan'), default='edsr',
+                    help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block, blindqrcan = frozen contrastive degradation encoder + QRCAN (BASELINE config 5 in bf16; q-layers as in the reference test config); all for information')
     ap.add_argument('--device-patches', action='store_true',
                     help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
     args = ap.parse_args()
@@ -74,9 +74,12 @@ def main():
     N = args.batch
     flop_per_patch = FLOP_PER_PATCH_TRAIN if args.model == 'edsr' else 220.04e9
     torch.manual_seed(8)                                    # reference default seed (net_train.py:20)
-    h = define_model(args.model, model_save_dir=tempfile.mkdtemp(), device=local_rank, eval_mode=False, checkpoint_load=False,
-                     loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED,
-                     **(dict(style='standard', include_q_layer=True, metadata=['m%d' % i for i in range(5)]) if args.model == 'qrcan' else {}))
+    BLIND = dict(style='standard', include_q_layer=True, selective_meta_blocks=[True] + [False] * 9, num_q_layers_inner_residual=1)
+    extra = {'qrcan': dict(style='standard', include_q_layer=True, metadata=['m%d' % i for i in range(5)]),
+             'blindqrcan': dict(block_encoder_loading=True, **BLIND)}.get(args.model, {})      # encoder weights: random init (no checkpoint offline)
+    h = define_model({'blindqrcan': 'contrastiveblindqrcan'}.get(args.model, args.model), model_save_dir=tempfile.mkdtemp(), device=local_rank,
+                     eval_mode=False, checkpoint_load=False, loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
+                     scheduler_params=SCHED, **extra)
     meta_pool = [torch.rand(N, 5, 1, 1, generator=torch.Generator().manual_seed(77 + i)).to(dev) for i in range(8)] if args.model == 'qrcan' else None
     if world > 1:
         broadcast_parameters(h.net)
@@ -134,11 +137,12 @@ def main():
         lib = L.lib()
         # dominant kernel: the residual-block kernel (two 64->64 convs per launch, conv_block.hip) when the engine uses it,
         # otherwise the single-layer strip kernel
-        plan = h.net.engine.plan_for(N, 48, 48, True)
+        hipnet = getattr(h.net, 'hip_generator', h.net)
+        plan = hipnet.engine.plan_for(N, 48, 48, True)
         ops = plan.fwd + plan.bwd
         blocks = [a for name, a in ops if name == 'rumpy_conv_block']
         use_block = len(blocks) > 0
-        h.net.use_graph = False          # the probe records events around eager launches (a graph replay has none)
+        hipnet.use_graph = False          # the probe records events around eager launches (a graph replay has none)
         lib.rumpy_probe_begin(5 if use_block else 1, 80 * args.probe_steps + 8)
         for i in range(args.probe_steps):
             step(i)
@@ -189,7 +193,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         torch.manual_seed(8)
-        onet = O.build_oracle(args.model, scale=4, **(dict(style='standard', include_q_layer=True, num_metadata=5) if args.model == 'qrcan' else {}))
+        onet = O.build_oracle({'blindqrcan': 'contrastiveblindqrcan'}.get(args.model, args.model), scale=4,
+                              **{'qrcan': dict(style='standard', include_q_layer=True, num_metadata=5), 'blindqrcan': BLIND}.get(args.model, {}))
         cpu_meta = torch.rand(args.cpu_batch, 5, 1, 1) if args.model == 'qrcan' else None
         oh = O.OracleHandler(onet, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
         try:
@@ -227,7 +232,7 @@ def main():
                 'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
                          'random-init weights (seed 8)') if args.device_patches else
                         'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
-                'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)' + (' + meta-attention q-layers, 5 metadata entries' if args.model == 'qrcan' else '')) +
+                'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)' + {'qrcan': ' + meta-attention q-layers, 5 metadata entries', 'blindqrcan': ' + frozen contrastive degradation encoder (256-vector) driving q-layers in group 0 block 0'}.get(args.model, '')) +
                                        ' train step, 48x48 LR patches, batch %d per GPU' % N,
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),

@@ -384,6 +384,22 @@ typedef struct {
 } rumpy_enc_conv_args;
 int rumpy_enc_conv(const rumpy_enc_conv_args* a, void* stream);
 int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+/* training-mode nn.BatchNorm2d + LeakyReLU in place on a conv output (the reference runs its frozen encoder under net.train() inside
+ * run_train: base_architecture.py:472): batch statistics over P = N*H*W values per channel (biased variance), running statistics updated
+ * with `momentum` (unbiased variance) and the counter incremented, as torch does.  Deterministic. */
+typedef struct {
+  void* x;                       /* [P, C] bf16, in and out */
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;   /* [C], updated; both NULL = leave untouched */
+  int64_t* num_batches_tracked;  /* device scalar, += 1; may be NULL */
+  float* partial;                /* scratch, >= rumpy_enc_bn_partial_floats(P, C) floats */
+  float* scale_shift;            /* scratch [2, C] */
+  int32_t P, C;
+  float eps, momentum, neg_slope;
+  int32_t pad_;
+} rumpy_enc_bn_args;
+int rumpy_enc_bn_train(const rumpy_enc_bn_args* a, void* stream);
+int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C);
 
 /* ---- optimizer: torch.optim.Adam semantics (base_architecture.py:93-95,437), flat fp32 buffers ---- */
 typedef struct {

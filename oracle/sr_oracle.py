@@ -249,6 +249,78 @@ class OracleQRCAN(nn.Module):
         return self.tail(self.final_body(res) + x)
 
 
+class OracleEncoder(nn.Module):
+    """rumpy/regression/models/contrastive_learning/encoding_models.py:5-55 (Encoder, dropdown_q=None): six 3x3 convs
+    (3-64-64-128/2-128-256/2-256), each + BatchNorm2d + LeakyReLU(0.1), global average pool -> ``fea`` [N,256]; ``mlp`` 256-256-256
+    -> ``q``.  Returns (fea, {'q': q}).  Keys ``E.{0,1,3,4,...,16}.*`` and ``mlp.{0,2}.*``."""
+
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for cout, stride in ((64, 1), (64, 1), (128, 2), (128, 1), (256, 2), (256, 1)):
+            layers += [nn.Conv2d(cin, cout, 3, stride=stride, padding=1), nn.BatchNorm2d(cout), nn.LeakyReLU(0.1)]
+            cin = cout
+        layers.append(nn.AdaptiveAvgPool2d(1))
+        self.E = nn.Sequential(*layers)
+        self.mlp = nn.Sequential(nn.Linear(256, 256), nn.LeakyReLU(0.1), nn.Linear(256, 256))
+
+    def forward(self, x):
+        fea = self.E(x).squeeze(-1).squeeze(-1)
+        return fea, {'q': self.mlp(fea)}
+
+
+class OracleBlindPipeline(nn.Module):
+    """rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:90-329 (ContrastiveBlindSRPipeline) for the default
+    configuration: contrastive_encoder='default', embedding_type='pre-q' (embedding = E(x)[0], :244), encoder_freeze_mode='all'
+    (:46-48: every encoder parameter has requires_grad False), no auxiliary encoder / reducer / normalisation / SFT:
+    sr = G(x, embedding[:, :, None, None]) (:285,315).  Registration order G, E (:134,154).
+
+    NOTE on BatchNorm mode, reproduced because it is what the reference computes: ContrastiveBlindQRCANHandler.run_train
+    (blur_kernel_blind_sr/handlers.py:513-521) puts E in eval mode and then calls BaseModel.run_train, whose first statement is
+    ``self.net.train()`` (base_architecture.py:472) - so during training the frozen encoder normalises with BATCH statistics and
+    keeps updating its running statistics; run_eval (``self.net.eval()``, :503) uses those running statistics."""
+
+    def __init__(self, generator):
+        super().__init__()
+        self.G = generator
+        self.E = OracleEncoder()
+        for p in self.E.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        emb = self.E(x)[0]
+        return self.G(x, emb.unsqueeze(2).unsqueeze(3))
+
+
+def seeded_encoder_state(encoder, seed):
+    """Deterministic, well-conditioned encoder state in state_dict order: conv / linear weights and biases U(-b, b) with
+    b = sqrt(6 / fan_in) (He gain, so the six LeakyReLU stages keep O(1) activations), BN weight and running_var U(0.5, 1.5), BN bias and
+    running_mean U(-0.2, 0.2), num_batches_tracked 0."""
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    ref = encoder.state_dict()
+    for k, v in ref.items():
+        shape = tuple(v.shape)
+        if k.endswith('num_batches_tracked'):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+        elif len(shape) >= 2 or (k.endswith('bias') and ref[k[:-4] + 'weight'].dim() >= 2):
+            w = ref[k] if len(shape) >= 2 else ref[k[:-4] + 'weight']
+            b = math.sqrt(6.0 / (w[0].numel()))
+            sd[k] = torch.from_numpy(rng.uniform(-b, b, size=shape).astype(np.float32))
+        elif k.endswith('weight') or k.endswith('running_var'):
+            sd[k] = torch.from_numpy(rng.uniform(0.5, 1.5, size=shape).astype(np.float32))
+        else:
+            sd[k] = torch.from_numpy(rng.uniform(-0.2, 0.2, size=shape).astype(np.float32))
+    return sd
+
+
+def seeded_pipeline_state(pipe, seed):
+    """G from seeded_state_dict(seed), E from seeded_encoder_state(seed + 1); keys as the pipeline's state_dict."""
+    sd = OrderedDict(('G.' + k, v) for k, v in seeded_state_dict(pipe.G, seed).items())
+    sd.update(('E.' + k, v) for k, v in seeded_encoder_state(pipe.E, seed + 1).items())
+    return sd
+
+
 # --------------------------------------------------------------------------------------
 # handler-level restatement: one train step / one eval step
 # --------------------------------------------------------------------------------------
@@ -343,6 +415,12 @@ def build_oracle(name, **internal_params):
                                  'selective_meta_blocks', 'num_q_layers_inner_residual', 'num_layers_in_q_layer') if k in p}
         return OracleQRCAN(scale=p.get('scale', 4), in_feats=p.get('in_features', 3), style=p.get('style', 'standard'),
                            num_metadata=p['num_metadata'], **fwd)
+    if name == 'contrastiveblindqrcan':
+        # ContrastiveBlindQRCANHandler blur_kernel_blind_sr/handlers.py:455-510: QRCAN(num_metadata=encoder_output_size=256, ...) inside
+        # ContrastiveBlindSRPipeline
+        q = dict(p)
+        q['num_metadata'] = p.get('encoder_output_size', 256)
+        return OracleBlindPipeline(build_oracle('qrcan', **q))
     raise KeyError(name)
 
 

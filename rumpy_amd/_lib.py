@@ -55,6 +55,12 @@ class EncConvArgs(_S):
                 ('neg_slope', c_float), ('pad_', c_int32)]
 
 
+class EncBnArgs(_S):
+    _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
+                ('num_batches_tracked', c_void_p), ('partial', c_void_p), ('scale_shift', c_void_p),
+                ('P', c_int32), ('C', c_int32), ('eps', c_float), ('momentum', c_float), ('neg_slope', c_float), ('pad_', c_int32)]
+
+
 class HeadWgradArgs(_S):
     _fields_ = [('x', c_void_p), ('dy', c_void_p), ('slab', c_void_p), ('gw', c_void_p), ('gb', c_void_p),
                 ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32),
@@ -198,6 +204,8 @@ SYMBOLS = {
     'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
     'rumpy_enc_conv': (C.c_int, [_P(EncConvArgs), c_void_p]),
+    'rumpy_enc_bn_train': (C.c_int, [_P(EncBnArgs), c_void_p]),
+    'rumpy_enc_bn_partial_floats': (c_int64, [c_int32, c_int32]),
     'rumpy_enc_pool': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),
     'rumpy_tail_fwd': (C.c_int, [_P(TailFwdArgs), c_void_p]),

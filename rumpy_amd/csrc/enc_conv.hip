@@ -101,6 +101,103 @@ __global__ void __launch_bounds__(256) enc_pool_kernel(const uint4* __restrict__
   }
 }
 
+// ---- training-mode BatchNorm2d of the (frozen) encoder.  The reference runs the encoder under net.train() inside run_train
+// (base_architecture.py:472 after handlers.py:517), so its BatchNorms normalise with BATCH statistics and update their running
+// statistics even though no parameter of the encoder is trained.  Three launches on the conv's bf16 output [P = N*H*W, C]:
+// per-block partial sums (fixed order), finalize (fp64 combine -> scale/shift, running statistics, counter), apply + LeakyReLU in place.
+constexpr int BN_MAXBLK = 64;
+static int bn_blocks(int P) { int b = (P + 255) / 256; return b > BN_MAXBLK ? BN_MAXBLK : (b < 1 ? 1 : b); }
+
+__global__ void __launch_bounds__(256) enc_bn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ partial, int P, int C, int chunk) {
+  __shared__ float red[32][129];
+  const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x, c8 = tid & 7, pr = tid >> 3;
+  const int cvec = C / 8;
+  const int p0 = b * chunk, p1 = min(P, p0 + chunk);
+  float s[8], q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+  for (int p = p0 + pr; p < p1; p += 32) {
+    const uint4 v = x[(size_t)p * cvec + cg * 8 + c8];
+    float f[8];
+    { float lo[4], hi[4]; unpack4_bf16(make_uint2(v.x, v.y), lo); unpack4_bf16(make_uint2(v.z, v.w), hi);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; } }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] = fmaf(f[i], f[i], q[i]); }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[pr][c8 * 8 + i] = s[i]; red[pr][64 + c8 * 8 + i] = q[i]; }
+  __syncthreads();
+  if (tid < 128) {
+    float tot = 0.f;
+    for (int k = 0; k < 32; ++k) tot += red[k][tid];
+    const int which = tid >> 6, c = cg * 64 + (tid & 63);
+    partial[((size_t)b * 2 + which) * C + c] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(64) enc_bn_finalize_kernel(const float* __restrict__ partial, int nblk, int P, int C,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
+                                                             float* __restrict__ scale_shift, float eps, float momentum) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c < C) {
+    double s = 0.0, q = 0.0;
+#pragma unroll 8
+    for (int b = 0; b < nblk; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; q += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    const double mean = s / P;
+    double var = q / P - mean * mean;                      // biased variance: what the batch is normalised with
+    if (var < 0.0) var = 0.0;
+    const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+    scale_shift[c] = sc;
+    scale_shift[C + c] = beta[c] - (float)mean * sc;
+    if (rmean) {                                           // running statistics: unbiased variance (torch.nn.BatchNorm2d)
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * ((double)P / (double)(P - 1)));
+    }
+  }
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void __launch_bounds__(256) enc_bn_apply_kernel(uint4* __restrict__ x, const float* __restrict__ scale_shift, size_t total_vec, int C,
+                                                           float neg_slope) {
+  const int cvec = C / 8;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total_vec; v += (size_t)gridDim.x * 256) {
+    const int c0 = (int)(v % cvec) * 8;
+    const uint4 in = x[v];
+    float f[8];
+    { float lo[4], hi[4]; unpack4_bf16(make_uint2(in.x, in.y), lo); unpack4_bf16(make_uint2(in.z, in.w), hi);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; } }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float y = fmaf(f[i], scale_shift[c0 + i], scale_shift[C + c0 + i]);
+      f[i] = y > 0.f ? y : y * neg_slope;
+    }
+    const uint2 lo = pack4_bf16(f[0], f[1], f[2], f[3]), hi = pack4_bf16(f[4], f[5], f[6], f[7]);
+    x[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+}
+
+extern "C" int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C) { return (int64_t)bn_blocks(P) * 2 * C; }
+extern "C" int rumpy_enc_bn_train(const rumpy_enc_bn_args* p, void* stream) {
+  if (!p || !p->x || !p->gamma || !p->beta || !p->partial || !p->scale_shift) { rumpy_set_error("rumpy_enc_bn_train: null pointer"); return RUMPY_E_ARG; }
+  if ((p->running_mean == nullptr) != (p->running_var == nullptr)) { rumpy_set_error("rumpy_enc_bn_train: running_mean and running_var go together"); return RUMPY_E_ARG; }
+  if (p->P < 2 || p->C <= 0 || p->C % 64) {   // torch refuses a single value per channel in training mode, too
+    rumpy_set_error("rumpy_enc_bn_train: needs more than one value per channel and C %% 64 == 0 (P=%d C=%d)", p->P, p->C); return RUMPY_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = bn_blocks(p->P), chunk = (p->P + nblk - 1) / nblk;
+  hipLaunchKernelGGL(enc_bn_stats_kernel, dim3(nblk, p->C / 64), dim3(256), 0, s, (const uint4*)p->x, p->partial, p->P, p->C, chunk);
+  hipLaunchKernelGGL(enc_bn_finalize_kernel, dim3(p->C / 64), dim3(64), 0, s, p->partial, nblk, p->P, p->C, p->gamma, p->beta, p->running_mean,
+                     p->running_var, (long long*)p->num_batches_tracked, p->scale_shift, p->eps, p->momentum);
+  const size_t tv = (size_t)p->P * (p->C / 8);
+  size_t blocks = (tv + 255) / 256;
+  const size_t cap = (size_t)rumpy_device_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(enc_bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)p->x, p->scale_shift, tv, p->C, p->neg_slope);
+  return rumpy_check_launch("rumpy_enc_bn_train");
+}
+
 extern "C" int rumpy_enc_conv(const rumpy_enc_conv_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->bias || !p->out) { rumpy_set_error("rumpy_enc_conv: null pointer"); return RUMPY_E_ARG; }
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cin <= 0 || p->cin % 64 || p->cout <= 0 || p->cout % 64 || (p->stride != 1 && p->stride != 2)) {

@@ -63,5 +63,11 @@ class GradientAverager:
 def broadcast_parameters(net, src=0, group=None):
     """Make every replica start from rank src's weights (one flat broadcast)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(net.flat_p, src=src, group=group)
-        net._packed_version = None
+        hip = getattr(net, 'hip_generator', net)        # a pipeline trains its generator; its frozen encoder is replicated as well
+        dist.broadcast(hip.flat_p, src=src, group=group)
+        hip._packed_version = None
+        enc = getattr(net, 'E', None) if hip is not net else None
+        if enc is not None:
+            for t in enc.state_dict().values():
+                dist.broadcast(t, src=src, group=group)
+            enc._packed = enc._folded = None

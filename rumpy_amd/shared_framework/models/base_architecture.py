@@ -73,10 +73,11 @@ class BaseModel(nn.Module):
         kind = optimizer_type.lower()
         if kind == 'adam':
             betas = (optimizer_params['beta_1'], optimizer_params['beta_2']) if optimizer_params is not None else (0.9, 0.999)
-            whole_net = isinstance(self.net, HipSRNet) and len(optim_weights) == len(self.net.param_list) and \
-                all(a is b for a, b in zip(optim_weights, self.net.param_list))
+            hip = self._hip_net()        # the HIP network whose flat buffers the fused optimizer updates (a pipeline's generator)
+            trainable = [p for p in optim_weights if p.requires_grad]
+            whole_net = hip is not None and len(trainable) == len(hip.param_list) and all(a is b for a, b in zip(trainable, hip.param_list))
             if whole_net:
-                return FlatAdam(self.net, lr=lr, betas=betas)
+                return FlatAdam(hip, lr=lr, betas=betas)
             return optim.Adam([p for p in optim_weights if p.requires_grad], lr=lr, betas=betas)
         if kind == 'rmsprop':
             trainable = [p for p in optim_weights if p.requires_grad]
@@ -212,8 +213,14 @@ class BaseModel(nn.Module):
         new_masks[non_black.unsqueeze(1).expand(-1, 3, -1, -1)] = 1
         return new_masks
 
+    def _hip_net(self):
+        if isinstance(self.net, HipSRNet):
+            return self.net
+        gen = getattr(self.net, 'hip_generator', None)
+        return gen if isinstance(gen, HipSRNet) else None
+
     def _fused_l1(self):
-        return isinstance(self.net, HipSRNet) and type(self.criterion) is nn.L1Loss and not self.loss_masking
+        return self._hip_net() is not None and type(self.criterion) is nn.L1Loss and not self.loss_masking
 
     def run_train(self, x, y, tag=None, mask=None, keep_on_device=False, scheduler_skip=False, *args, **kwargs):
         """-> (loss ndarray, out tensor (CPU unless keep_on_device)) as :457-485."""

@@ -1,0 +1,171 @@
+"""-m gpu parity of the blind-SR pipeline: HIP degradation encoder + QRCAN behind
+define_model('contrastiveblindqrcan') against the CPU oracle (pinned on the real reference handler by golden G13) and, for the
+encoder (whose architecture has no size parameter), directly against the embedding the REAL reference computed (G13).
+Tolerances: the encoder runs bf16 operands / activations through six layers; its 256-vector agrees with fp32 to ~1e-2 of its scale."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sr_oracle as O
+from rumpy_amd.regression.models.contrastive_learning.encoding_models import Encoder
+from rumpy_amd.shared_framework.models import define_model
+from tests.test_network_gpu import _grad_check, self_psnr
+
+DEV = torch.device('cuda:0')
+SCHED = {'scheduler': 'cosine_annealing_warm_restarts', 'scheduler_params': {'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7}}
+KW = dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True,
+          selective_meta_blocks=[True, False], num_q_layers_inner_residual=1)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def _encoders(seed):
+    e = Encoder()
+    oe = O.OracleEncoder()
+    sd = O.seeded_encoder_state(oe, seed)
+    oe.load_state_dict(sd)
+    e.load_state_dict(sd)
+    for p in e.parameters():
+        p.requires_grad = False
+    return e.to(DEV), oe
+
+
+def test_encoder_eval_embedding_matches_the_real_reference(golden_dir):
+    """weights = the seeded state the fixture was generated with, running statistics = the ones the reference held after its three
+    training steps, input = the fixture's seeded batch: the HIP encoder must reproduce the reference's own embedding."""
+    g = np.load(os.path.join(golden_dir, 'g13_blind_qrcan_small_train.npz'))
+    e, oe = _encoders(901)
+    sd = e.state_dict()
+    for k in sd:
+        if 'w3.E.' + k in g.files:
+            sd[k] = torch.from_numpy(g['w3.E.' + k])
+    e.load_state_dict(sd)
+    e.eval()
+    xe, _ = O.synthetic_batch(990, 2, lr_hw=10, scale=2)
+    fea, _ = e(xe.to(DEV))
+    ref = torch.from_numpy(g['eval_embedding'])
+    assert fea.shape == (2, 256) and fea.dtype == torch.float32
+    assert _rel(fea.cpu(), ref) < 1.5e-2, _rel(fea.cpu(), ref)
+
+
+@pytest.mark.parametrize('N,hw', [(3, 48), (2, (37, 53)), (1, 16)])
+def test_encoder_both_batchnorm_modes_against_oracle(N, hw):
+    e, oe = _encoders(77)
+    x, _ = O.synthetic_batch(5 + N, N, lr_hw=hw, scale=2)
+    # training mode: batch statistics, running statistics updated (twice, to exercise the momentum update)
+    e.train(); oe.train()
+    for rep in range(2):
+        fea, _ = e(x.to(DEV))
+        with torch.no_grad():
+            ofea, _ = oe(x)
+        assert _rel(fea.cpu(), ofea) < 2e-2, (rep, _rel(fea.cpu(), ofea))
+    for (k, a), (k2, b) in zip(e.state_dict().items(), oe.state_dict().items()):
+        assert k == k2
+        if 'running_mean' in k:
+            assert float((a.cpu() - b).abs().max()) < 2e-2 * float(b.abs().max()) + 2e-3, k
+        elif 'running_var' in k:
+            assert _rel(a.cpu(), b) < 2e-2, k
+        elif 'num_batches' in k:
+            assert int(a) == int(b) == 2
+        else:
+            assert torch.equal(a.cpu(), b), k            # the frozen parameters are never written
+    # eval mode on the updated running statistics (of the HIP side, copied to the oracle so that only this pass is compared)
+    oe.load_state_dict({k: v.cpu() for k, v in e.state_dict().items()})
+    e.eval(); oe.eval()
+    fea, _ = e(x.to(DEV))
+    with torch.no_grad():
+        ofea, _ = oe(x)
+    assert _rel(fea.cpu(), ofea) < 1.5e-2, _rel(fea.cpu(), ofea)
+    fea2, _ = e(x.to(DEV))
+    assert torch.equal(fea, fea2)                        # deterministic, and eval leaves the statistics alone
+
+
+def test_encoder_refuses_cpu_and_trainable_parameters():
+    e, _ = _encoders(3)
+    with pytest.raises(RuntimeError):
+        e(torch.zeros(1, 3, 8, 8))
+    next(e.parameters()).requires_grad = True
+    with pytest.raises(RuntimeError):
+        e(torch.zeros(1, 3, 8, 8, device=DEV))
+
+
+def _pair(wseed, eval_mode=False, lr=1e-3):
+    h = define_model('contrastiveblindqrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=eval_mode, checkpoint_load=False,
+                     loss_masking=False, metadata_list=None, block_encoder_loading=True, lr=lr, **({} if eval_mode else SCHED), **KW)
+    onet = O.build_oracle('contrastiveblindqrcan', **KW)
+    assert list(onet.state_dict().keys()) == list(h.net.state_dict().keys())
+    sd = O.seeded_pipeline_state(onet, wseed)
+    onet.load_state_dict(sd)
+    h.net.load_state_dict(sd)
+    oh = O.OracleHandler(onet, lr=lr, eval_mode=eval_mode, scheduler=None if eval_mode else SCHED['scheduler'],
+                         scheduler_params=SCHED['scheduler_params'])
+    return h, oh
+
+
+def test_blind_qrcan_train_steps_and_eval_against_oracle():
+    h, oh = _pair(826)
+    for step in range(3):
+        x, y = O.synthetic_batch(930 + step, 3, lr_hw=16, scale=2)
+        loss, out = h.run_train(x=x, y=y)
+        oloss, oout = oh.run_train(x, y)
+        assert abs(float(loss) - float(oloss)) < (2e-3 if step == 0 else 1e-2) * float(oloss)
+        assert abs(h.get_learning_rate() - oh.get_learning_rate()) < 1e-12
+        if step == 0:
+            assert self_psnr(out, oout) >= 50.0
+            # generator gradients (the encoder has none): same check as every other network
+            class G:      # adapt the pipeline to _grad_check's (handler.net.named_parameters) view of the trainable part
+                pass
+            a, b = G(), G()
+            a.net, b.net = h.net.G, oh.net.G
+            print('worst grad rel err', _grad_check(a, b))
+            assert all(p.grad is None for p in h.net.E.parameters())
+    # the running statistics the two encoders accumulated while "frozen" agree, and so does the evaluation that uses them
+    for (k, a), (_, b) in zip(h.net.E.state_dict().items(), oh.net.E.state_dict().items()):
+        if 'running_var' in k:
+            assert _rel(a.cpu(), b) < 2e-2, k
+        if 'num_batches' in k:
+            assert int(a) == int(b) == 3
+    xe, ye = O.synthetic_batch(940, 2, lr_hw=(20, 28), scale=2)
+    out, loss, _ = h.run_eval(x=xe, y=ye, request_loss=True)
+    oout, oloss, _ = oh.run_eval(xe, ye, request_loss=True)
+    assert self_psnr(out, oout) >= 45.0 and abs(float(loss) - float(oloss)) < 1e-2 * float(oloss)
+
+
+def test_blind_qrcan_checkpoint_roundtrip():
+    h, oh = _pair(827)
+    x, y = O.synthetic_batch(950, 2, lr_hw=16, scale=2)
+    h.run_train(x=x, y=y)
+    h.set_epoch(2)
+    h.save_model('train_model')
+    st = torch.load(os.path.join(h.model_save_dir, 'train_model_2'), map_location='cpu', weights_only=False)
+    assert st['model_name'] == 'blind_qrcan'
+    assert list(st['network'].keys()) == list(oh.net.state_dict().keys())
+    assert int(st['network']['E.E.1.num_batches_tracked']) == 1
+    n_train = len([p for p in oh.net.parameters() if p.requires_grad])
+    assert sorted(st['optimizer']['state'].keys()) == list(range(n_train)) and len(st['optimizer']['param_groups'][0]['params']) == n_train
+    h2, _ = _pair(999)
+    h2.model_save_dir = h.model_save_dir
+    h2.load_model('train_model', 2)
+    x2, y2 = O.synthetic_batch(951, 2, lr_hw=16, scale=2)
+    l_a, o_a = h.run_train(x=x2, y=y2)
+    l_b, o_b = h2.run_train(x=x2, y=y2)
+    assert torch.equal(o_a, o_b) and float(l_a) == float(l_b)
+    e_a, _, _ = h.run_eval(x=x2)
+    e_b, _, _ = h2.run_eval(x=x2)
+    assert torch.equal(e_a, e_b)
+
+
+def test_unsupported_blind_variants_are_refused():
+    base = dict(model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, block_encoder_loading=True, n_resgroups=1, n_resblocks=1,
+                style='standard', include_q_layer=True)
+    for bad in (dict(embedding_type='q'), dict(encoder_freeze_mode='pre_q'), dict(combined_loss_mode='moco'), dict(srmd_mode=True),
+                dict(reducer_layer_sizes=[256, 64]), dict(crop_count=2), dict(style='modulate')):
+        with pytest.raises(RuntimeError):
+            define_model('contrastiveblindqrcan', **{**base, **bad})

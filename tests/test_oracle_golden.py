@@ -220,3 +220,39 @@ def test_g12_qrcan_meta_attention_oracle_matches_reference_handler(golden_dir):
     xe, ye = O.synthetic_batch(790, 1, lr_hw=10, scale=2)
     ev, evl, _ = h.run_eval(xe, ye, request_loss=True, extra_channels=meta(791, 1))
     assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
+
+
+def test_g13_blind_pipeline_oracle_matches_reference_handler(golden_dir):
+    """frozen contrastive encoder + QRCAN (OracleBlindPipeline) against three training steps and one evaluation of the REAL reference
+    ContrastiveBlindQRCANHandler (tests/golden/make_golden_blind.py) - including the BatchNorm mode the reference actually runs the
+    encoder in while training (batch statistics, running statistics updated) and the running statistics its evaluation then uses."""
+    g = np.load(os.path.join(golden_dir, 'g13_blind_qrcan_small_train.npz'))
+    kw = dict(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True,
+              selective_meta_blocks=[True, False], num_q_layers_inner_residual=1)
+    net = O.build_oracle('contrastiveblindqrcan', **kw)
+    assert list(net.state_dict().keys()) == [str(k) for k in g['keys']]
+    assert [k for k, p in net.named_parameters() if p.requires_grad] == [str(k) for k in g['trainable']]
+    assert bool(g['encoder_training_flag0']) and bool(g['encoder_training_flag2'])
+    net.load_state_dict(O.seeded_pipeline_state(net, 900))
+    h = O.OracleHandler(net, lr=1e-3, scheduler='cosine_annealing_warm_restarts',
+                        scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+    assert len(h.optimizer.param_groups[0]['params']) == int(g['optimizer_params'])
+    for step in range(3):
+        xb, yb = O.synthetic_batch(910 + step, 3, lr_hw=12, scale=2)
+        loss, out = h.run_train(xb, yb)
+        assert abs(float(loss) - float(g['loss%d' % step])) < 1e-6
+        assert abs(h.get_learning_rate() - float(g['lr_after%d' % step])) < 1e-12
+        if step == 0:
+            assert np.allclose(out.numpy(), g['out0'], atol=1e-6)
+            for k, p in net.named_parameters():
+                if p.requires_grad:
+                    assert np.allclose(p.grad.numpy(), g['grad0.' + k], atol=1e-6, rtol=1e-4), k
+    for k, v in net.state_dict().items():
+        if 'w3.' + k in g.files:
+            assert np.allclose(v.numpy(), g['w3.' + k], atol=2e-6), k
+    assert int(net.state_dict()['E.E.1.num_batches_tracked']) == 3
+    xe, ye = O.synthetic_batch(990, 2, lr_hw=10, scale=2)
+    ev, evl, _ = h.run_eval(xe, ye, request_loss=True)
+    assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
+    with torch.no_grad():
+        assert np.allclose(net.E(xe)[0].numpy(), g['eval_embedding'], atol=1e-6)
