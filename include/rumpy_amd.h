@@ -125,6 +125,34 @@ typedef struct {
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
 
+/* ---- a whole residual channel-attention block per launch (conv_rcab.hip): RCAB, rumpy/SISR/models/advanced/architectures.py:60-84, and
+ * QRCAB, rumpy/SISR/models/attention_manipulators/architectures.py:154-228 (gate_q = `qgate`).
+ *   rumpy_rcab_fwd:  t1 = relu(conv1(x)+b1) ; t2 = conv2(t1)+b2 ; gate = sigmoid(W2 relu(W1 mean_hw(t2) + b1c) + b2c) ; out = x + gate*[qgate*]t2
+ *                    w1 / w2 = forward filter images of conv1 / conv2; t, t2 = stores of t1, t2 (training) or NULL; mean, hidden, gate: out.
+ *   rumpy_rcab_bwd:  x = dy ; ds = sum_hw(dy*t2_in) -> dz [, dzq] ; d_t2 = dy*gate[*qgate] + dp/HW -> t2 ; t = [mask > 0] . conv2^T(d_t2) ;
+ *                    out = dy + conv1^T(t).  w1 / w2 = DATA-GRADIENT filter images of conv2 / conv1; hidden, gate: in (from the forward launch).
+ * The strips of an image (6 rows each) exchange 64 partial sums through `xchg` (rumpy_rcab_xchg_bytes(N, H) bytes, zeroed ONCE at
+ * allocation; one buffer can serve every block of a network, launches on one stream are serialised) as records tagged
+ * (*epoch << 12) + seq: `epoch` is a device word the caller advances between passes (rumpy_rcab_epoch_advance), `seq` < 4096 must differ
+ * between the launches of one pass.  Needs W <= 48 and ceil(H/6) <= CUs.  *status (device word, zero it once) becomes 0x300 + seq if an
+ * exchange timed out. */
+typedef struct {
+  const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
+  void* t; void* t2; const void* t2_in; const void* mask;
+  const void* res2;    /* backward only: one more gradient added into `out` (a skip connection joining here), or NULL */
+  void* out;
+  int32_t N, H, W, cr;
+  const float* ca_w1; const float* ca_b1; const float* ca_w2; const float* ca_b2;   /* conv_du.0 [cr,64],[cr] ; conv_du.2 [64,cr],[64] */
+  float* mean; float* hidden; float* gate;       /* [N,64], [N,cr], [N,64] */
+  const float* qgate; float* dz; float* dzq;     /* [N,64] each */
+  void* xchg; int64_t xchg_bytes; const void* epoch; void* status;
+  uint32_t seq; int32_t pad_;
+} rumpy_rcab_args;
+int rumpy_rcab_fwd(const rumpy_rcab_args* a, void* stream);
+int rumpy_rcab_bwd(const rumpy_rcab_args* a, void* stream);
+int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H);
+int rumpy_rcab_epoch_advance(void* epoch, void* stream);
+
 /* ---- a chain of residual blocks in one launch, the strip resident in LDS from block to block (conv_block_chain.hip) ----
  * blocks: DEVICE array of rumpy_block_args, block b+1's input is block b's output (x is read from blocks[0] only; res2 must be
  * NULL).  Needs N*ceil(H/6) <= CUs (every strip co-resident), W <= 48 and nothing else occupying CUs while it runs.

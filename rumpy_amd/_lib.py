@@ -55,6 +55,16 @@ class EncConvArgs(_S):
                 ('neg_slope', c_float), ('pad_', c_int32)]
 
 
+class RcabArgs(_S):
+    _fields_ = [('x', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p),
+                ('t', c_void_p), ('t2', c_void_p), ('t2_in', c_void_p), ('mask', c_void_p), ('res2', c_void_p), ('out', c_void_p),
+                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cr', c_int32),
+                ('ca_w1', c_void_p), ('ca_b1', c_void_p), ('ca_w2', c_void_p), ('ca_b2', c_void_p),
+                ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('qgate', c_void_p), ('dz', c_void_p), ('dzq', c_void_p),
+                ('xchg', c_void_p), ('xchg_bytes', c_int64), ('epoch', c_void_p), ('status', c_void_p),
+                ('seq', C.c_uint32), ('pad_', c_int32)]
+
+
 class EncBnArgs(_S):
     _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
                 ('num_batches_tracked', c_void_p), ('partial', c_void_p), ('scale_shift', c_void_p),
@@ -203,6 +213,10 @@ SYMBOLS = {
     'rumpy_conv_chain': (C.c_int, [_P(ChainArgs), c_void_p]),
     'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
+    'rumpy_rcab_fwd': (C.c_int, [_P(RcabArgs), c_void_p]),
+    'rumpy_rcab_bwd': (C.c_int, [_P(RcabArgs), c_void_p]),
+    'rumpy_rcab_xchg_bytes': (c_int64, [c_int32, c_int32]),
+    'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
     'rumpy_enc_conv': (C.c_int, [_P(EncConvArgs), c_void_p]),
     'rumpy_enc_bn_train': (C.c_int, [_P(EncBnArgs), c_void_p]),
     'rumpy_enc_bn_partial_floats': (c_int64, [c_int32, c_int32]),

@@ -1,0 +1,466 @@
+// A whole residual channel-attention block (RCAB, rumpy/SISR/models/advanced/architectures.py:60-84; QRCAB,
+// attention_manipulators/architectures.py:154-228) per launch, forward and backward:
+//
+//   forward :  t1 = relu(conv1(x) + b1) ; t2 = conv2(t1) + b2 ; gate = CA(mean_hw(t2)) [* gate_q] ; out = x + gate * t2
+//   backward:  ds = sum_hw(dy * t2) -> (dz, dh, dp) through the squeeze-excite MLP ; d_t2 = dy * gate + dp / HW ;
+//              gt1 = [t1 > 0] . conv2^T(d_t2) ; dx = dy + conv1^T(gt1)
+//
+// conv_block.hip already keeps the activation between the two convs in LDS but has to stop at the channel attention, because its gate
+// needs the mean over the WHOLE image: three more streaming launches per block (gate * t2 + x ; sum dy * t2 ; dy * gate + dp) that
+// re-read and re-write 9.4 MB tensors at 2-3 TB/s - 31 % of an RCAN step.  Here the strips of one image exchange their 64 partial sums
+// through HBM instead (one 8-byte record {fp32 value, tag} per channel and strip, written with write-through stores and polled with
+// system-coherent loads: the data is the signal, as in conv_block_chain.hip), every workgroup evaluates the 600-flop MLP itself, and the
+// gate is applied to the tile that is still on chip.  Tags are (epoch << 12) + launch sequence number, epoch read from device memory
+// and advanced once per pass by the host side, so a record of an earlier launch or step can never be taken for a current one and ONE
+// exchange buffer serves every block of the network.
+// Needs every strip of an image resident at the same time: strips of an image have consecutive workgroup ids and ids are dispatched
+// in order, so the oldest unfinished image always has all of its strips on the chip as long as ceil(H/6) <= CUs (checked by the host).
+// A poll that does not complete within ~0.1 s stores a code in *status and gives up (wrong numbers, reported by the host; no hang).
+// Sums over strips are taken in strip order by every workgroup: all strips of an image use bit-identical gates, run to run.
+#include "block_common.hpp"
+
+typedef unsigned int rc_u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rc_rsrc;
+constexpr int RC_SC1 = 16;
+constexpr unsigned RC_SPIN = 1u << 20;
+constexpr int RC_MAXR = 16;
+
+struct RcabDev {
+  const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
+  uint16_t* t; uint16_t* t2; const uint16_t* t2_in; const uint16_t* mask; const uint16_t* res2; uint16_t* out;
+  int N, H, W, sy_n;
+  const float* cw1; const float* cb1; const float* cw2; const float* cb2; int cr; float inv_hw;
+  float* mean; float* hidden; float* gate; const float* qgate; float* dz; float* dzq;
+  unsigned long long* xchg; unsigned xchg_bytes; const unsigned* epoch; unsigned seq; unsigned* status;
+};
+
+__device__ __forceinline__ float wave_sum(float t) {
+  t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
+  return t;
+}
+
+// all-gather of one fp32 per (strip, channel) among the strips of image n; returns (threads < 64: channel tid) the sum over strips
+// in strip order.  sx: LDS scratch of 8 * 64 floats.  Called by all 512 threads.
+__device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int n, int sy, int tid, unsigned tag, float* sx) {
+  const rc_rsrc rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, a.xchg_bytes, 0x00020000);
+  const int c = tid & 63, w = tid >> 6;
+  if (tid < 64) __builtin_amdgcn_raw_buffer_store_b64((rc_u32x2){__float_as_uint(mine), tag}, rr, (unsigned)(((n * a.sy_n + sy) * 64 + c) * 8), 0, RC_SC1);
+  float total = 0.f;
+  for (int s0 = 0; s0 < a.sy_n; s0 += 8) {
+    const int s = s0 + w;
+    float val = 0.f;
+    if (s < a.sy_n) {                                       // wave-uniform
+      const unsigned byte = (unsigned)(((n * a.sy_n + s) * 64 + c) * 8);
+      rc_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rr, byte, 0, RC_SC1);
+      unsigned spins = 0;
+      while (!__all(r.y == tag)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > RC_SPIN) { if (c == 0) atomicExch(a.status, 0x300u + a.seq); break; }
+        r = __builtin_amdgcn_raw_buffer_load_b64(rr, byte, 0, RC_SC1);
+      }
+      val = __uint_as_float(r.x);
+    }
+    __syncthreads();                                        // the previous round's sx has been consumed
+    sx[w * 64 + c] = val;
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) total += sx[k * 64 + c];  // strips beyond sy_n contributed zeros
+    }
+  }
+  return total;
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  __shared__ float sx[8 * 64];
+  __shared__ float spool[2 * 64];
+  __shared__ __attribute__((aligned(16))) float sgate[64];
+  __shared__ __attribute__((aligned(16))) float sdp[64];
+  unsigned char* const ldx = lds;
+  unsigned char* const ldt = lds + BXBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int q = wave & 3, rh = wave >> 2;
+  const int strip = blockIdx.x;
+  const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+  const unsigned tag = (*a.epoch << 12) + a.seq;
+
+  // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
+  uint4 T2[BWD ? 5 : 1];
+  {
+    uint4 R[BREGS];
+    const int y0 = sy * BSH - 2;
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+      const int y = y0 + lr, x = lc - 1;
+      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
+      uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      R[i] = v;
+    }
+    if (BWD) {   // the strip's own rows of the forward conv2 output: piece p = tid + 512 i -> (pixel p >> 3 of 6 x 48, chunk tid & 7)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int p = tid + BTHREADS * i;
+        const int pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+        const int y = sy * BSH + r;
+        const bool ok = (p < BSH * BSW * 8) & (y < a.H) & (col < a.W);
+        const int e = ok ? ((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8 : 0;
+        uint4 v = *reinterpret_cast<const uint4*>(a.t2_in + (unsigned)e);
+        if (!ok) v = make_uint4(0, 0, 0, 0);
+        T2[i] = v;
+      }
+    }
+    if (tid < BTROWS * 2 * 8) {
+      const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
+      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+    }
+  }
+  bf16x8 F[18];
+  {
+    const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+  }
+  const int c0 = 16 * q + 4 * g;
+  const int gpair = 4 * (g & ~1);
+  const int chunk8 = 2 * q + (gpair >> 3);
+  __syncthreads();
+
+  if (BWD) {
+    // ---- phase 0b: ds = sum over the strip of dy * t2 per channel -> all strips of the image -> MLP backward -> d_t2 in place ----
+    float part8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+      if (p < BSH * BSW * 8) {
+        float d[8], t[8];
+        unpack8(*reinterpret_cast<const uint4*>(ldx + swz((r + 2) * BCOLS + col + 1, tid & 7)), d);
+        unpack8(T2[i], t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part8[j] = fmaf(d[j], t[j], part8[j]);
+      }
+    }
+    // threads with the same chunk (tid & 7) hold partial sums of the same 8 channels: [k = tid >> 3][chunk][8] in the (still unused)
+    // T image, then 256 threads add 16 k's each, then 64 threads add the 4 parts - fixed order
+    float* red = reinterpret_cast<float*>(ldt);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(tid >> 3) * 64 + (tid & 7) * 8 + j] = part8[j];
+    __syncthreads();
+    if (tid < 256) {
+      const int c = tid & 63, part = tid >> 6;
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += red[(part * 16 + k) * 64 + c];
+      red[64 * 64 + part * 64 + c] = s;
+    }
+    __syncthreads();
+    float mine = 0.f;
+    if (tid < 64) mine = (red[64 * 64 + tid] + red[64 * 64 + 64 + tid]) + (red[64 * 64 + 128 + tid] + red[64 * 64 + 192 + tid]);
+    __syncthreads();                                        // red is dead: the border columns of the T image are rewritten below
+    if (tid < BTROWS * 2 * 8) {
+      const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
+      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+    }
+    const float ds = strip_allsum(a, mine, n, sy, tid, tag, sx);
+    if (tid < 64) {
+      const int c = tid;
+      const float s = a.gate[n * 64 + c];
+      const float gq = a.qgate ? a.qgate[n * 64 + c] : 1.f;
+      const float dz = (ds * gq) * s * (1.f - s);
+      float dp = 0.f;
+      for (int r = 0; r < a.cr; ++r) {
+        float dh = wave_sum(a.cw2[c * a.cr + r] * dz);
+        dh = (a.hidden[n * a.cr + r] > 0.f) ? dh : 0.f;
+        dp = fmaf(a.cw1[r * 64 + c], dh, dp);
+      }
+      sgate[c] = s * gq;
+      sdp[c] = dp * a.inv_hw;
+      if (sy == 0) {
+        a.dz[n * 64 + c] = dz;
+        if (a.dzq) a.dzq[n * 64 + c] = (ds * s) * gq * (1.f - gq);
+      }
+    }
+    __syncthreads();
+    // d_t2 = dy * gate + dp / HW on every pixel of the tile that lies inside the image (outside stays the zero padding);
+    // the strip's own rows also go to HBM: conv2's weight gradient reads them
+    {
+      const int y0 = sy * BSH - 2;
+      const float4 ga = *reinterpret_cast<const float4*>(sgate + (tid & 7) * 8), gb = *reinterpret_cast<const float4*>(sgate + (tid & 7) * 8 + 4);
+      const float4 pa = *reinterpret_cast<const float4*>(sdp + (tid & 7) * 8), pb = *reinterpret_cast<const float4*>(sdp + (tid & 7) * 8 + 4);
+#pragma unroll
+      for (int i = 0; i < BREGS; ++i) {
+        const int p = tid + BTHREADS * i;
+        const int pix = p >> 3, part = p & 7;
+        const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+        const int y = y0 + lr, x = lc - 1;
+        const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+        if (ok) {
+          uint4* cell = reinterpret_cast<uint4*>(ldx + swz(pix, part));
+          float d[8];
+          unpack8(*cell, d);
+          const uint2 lo = pack4_bf16(fmaf(d[0], ga.x, pa.x), fmaf(d[1], ga.y, pa.y), fmaf(d[2], ga.z, pa.z), fmaf(d[3], ga.w, pa.w));
+          const uint2 hi = pack4_bf16(fmaf(d[4], gb.x, pb.x), fmaf(d[5], gb.y, pb.y), fmaf(d[6], gb.z, pb.z), fmaf(d[7], gb.w, pb.w));
+          const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          *cell = o;
+          if (lr >= 2 && lr < 2 + BSH) *reinterpret_cast<uint4*>(a.t2 + (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8)) = o;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
+  unsigned moff[6];
+  uint4 M[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+    const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+    const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
+    moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
+    M[k] = make_uint4(0, 0, 0, 0);
+    if (BWD) M[k] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
+  }
+  {
+    f32x4 acc[4][3];
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!BWD) { const float4 t = *reinterpret_cast<const float4*>(a.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    unsigned off[8][2];
+    sweep_bases(off, 0u, 4 * rh, px, g);
+    block_sweep<4>(acc, F, lds, off);
+    {
+      const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2];
+      const f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2];
+      float v[8];
+      pair_up(tx, ty, g, v);
+      if (BWD) {
+        float m[8];
+        unpack8(M[k], m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+      const int j = 4 * rh + jr, xx = 16 * c + px;
+      uint4 o = make_uint4(0, 0, 0, 0);
+      if (moff[k] != 0xffffffffu) {
+        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;
+      }
+      *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ----
+  {
+    f32x4 acc[3][3];
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!BWD) { const float4 t = *reinterpret_cast<const float4*>(a.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    // backward: the residual operand dy (its tile in LDS now holds d_t2) is requested before the sweep and lands under it
+    unsigned ooff[4], osoff;
+    uint4 P1p[BWD ? 4 : 1];
+    uint2 P1s = make_uint2(0, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+      const int y = sy * BSH + 3 * rh + r, xx = 16 * c + px;
+      ooff[k] = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
+      if (BWD) P1p[k] = *reinterpret_cast<const uint4*>(a.x + (ooff[k] != 0xffffffffu ? ooff[k] : 0u));
+    }
+    {
+      const int y = sy * BSH + 3 * rh + 2, xx = 32 + px;
+      osoff = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0) : 0xffffffffu;
+      if (BWD) P1s = *reinterpret_cast<const uint2*>(a.x + (osoff != 0xffffffffu ? osoff : 0u));
+    }
+    unsigned off[8][2];
+    sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
+    block_sweep<3>(acc, F, lds, off);
+    // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
+    float V[4][8], vs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][2];
+      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][2];
+      pair_up(tx, ty, g, V[k]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vs[j] = acc[2][2][j];
+
+    if (BWD) {
+      // dx = dy + conv1^T(gt1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ooff[k] != 0xffffffffu) {
+          float m[8];
+          unpack8(P1p[BWD ? k : 0], m);
+          if (a.res2) {
+            float e[8];
+            unpack8(*reinterpret_cast<const uint4*>(a.res2 + ooff[k]), e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] += e[j];
+          }
+          const uint2 lo = pack4_bf16(V[k][0] + m[0], V[k][1] + m[1], V[k][2] + m[2], V[k][3] + m[3]);
+          const uint2 hi = pack4_bf16(V[k][4] + m[4], V[k][5] + m[5], V[k][6] + m[6], V[k][7] + m[7]);
+          *reinterpret_cast<uint4*>(a.out + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+      if (osoff != 0xffffffffu) {
+        float m[4];
+        unpack4_bf16(P1s, m);
+        if (a.res2) {
+          float e[4];
+          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + osoff), e);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[j] += e[j];
+        }
+        *reinterpret_cast<uint2*>(a.out + osoff) = pack4_bf16(vs[0] + m[0], vs[1] + m[1], vs[2] + m[2], vs[3] + m[3]);
+      }
+    } else {
+      // t2 = conv2(t1) + b2: channel sums of the strip for the attention pool, t2 itself to HBM when training
+      float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ooff[k] != 0xffffffffu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ps8[j] += V[k][j];
+          if (a.t2) {
+            const uint2 lo = pack4_bf16(V[k][0], V[k][1], V[k][2], V[k][3]), hi = pack4_bf16(V[k][4], V[k][5], V[k][6], V[k][7]);
+            *reinterpret_cast<uint4*>(a.t2 + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+        }
+      }
+      if (osoff != 0xffffffffu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ps[j] += vs[j];
+        if (a.t2) *reinterpret_cast<uint2*>(a.t2 + osoff) = pack4_bf16(vs[0], vs[1], vs[2], vs[3]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = ps8[j];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        t += __shfl_xor(t, 16);
+        ps8[j] = t;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = ps[j];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        const float up = __shfl_xor(t, 16);
+        ps8[j] += (g & 1) ? up : t;
+        ps8[4 + j] += (g & 1) ? t : up;
+      }
+      if (px == 0 && !(g & 1)) {
+        float* pp = spool + rh * 64 + 16 * q + 4 * g;
+        *reinterpret_cast<float4*>(pp) = make_float4(ps8[0], ps8[1], ps8[2], ps8[3]);
+        *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
+      }
+      __syncthreads();
+      const float mine = (tid < 64) ? spool[tid] + spool[64 + tid] : 0.f;
+      const float tot = strip_allsum(a, mine, n, sy, tid, tag, sx);
+      if (tid < 64) {
+        const int c = tid;
+        const float mean = tot * a.inv_hw;
+        float z = a.cb2[c];
+        for (int r = 0; r < a.cr; ++r) {
+          const float h = fmaxf(wave_sum(a.cw1[r * 64 + c] * mean) + a.cb1[r], 0.f);
+          z = fmaf(a.cw2[c * a.cr + r], h, z);
+          if (sy == 0 && c == 0) a.hidden[n * a.cr + r] = h;
+        }
+        const float gt = 1.f / (1.f + expf(-z));
+        sgate[c] = a.qgate ? gt * a.qgate[n * 64 + c] : gt;
+        if (sy == 0) { a.mean[n * 64 + c] = mean; a.gate[n * 64 + c] = gt; }
+      }
+      __syncthreads();
+      // out = x + gate * t2, the residual operand from the input tile in LDS
+      const float4 ga = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair), gb = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ooff[k] != 0xffffffffu) {
+          const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+          const int srow = 3 * rh + r, xx = 16 * c + px;
+          float m[8];
+          unpack8(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);
+          const uint2 lo = pack4_bf16(fmaf(V[k][0], ga.x, m[0]), fmaf(V[k][1], ga.y, m[1]), fmaf(V[k][2], ga.z, m[2]), fmaf(V[k][3], ga.w, m[3]));
+          const uint2 hi = pack4_bf16(fmaf(V[k][4], gb.x, m[4]), fmaf(V[k][5], gb.y, m[5]), fmaf(V[k][6], gb.z, m[6]), fmaf(V[k][7], gb.w, m[7]));
+          *reinterpret_cast<uint4*>(a.out + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+      }
+      if (osoff != 0xffffffffu) {
+        const int srow = 3 * rh + 2, xx = 32 + px;
+        float m[4];
+        unpack4_bf16(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
+        const float4 gs = *reinterpret_cast<const float4*>(sgate + c0);
+        *reinterpret_cast<uint2*>(a.out + osoff) = pack4_bf16(fmaf(vs[0], gs.x, m[0]), fmaf(vs[1], gs.y, m[1]), fmaf(vs[2], gs.z, m[2]), fmaf(vs[3], gs.w, m[3]));
+      }
+    }
+  }
+}
+
+__global__ void rcab_epoch_kernel(unsigned* epoch) { *epoch += 1u; }
+
+static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const char* what) {
+  if (!p || !p->x || !p->w1 || !p->w2 || !p->out || !p->ca_w1 || !p->ca_b1 || !p->ca_w2 || !p->ca_b2 || !p->hidden || !p->gate ||
+      !p->xchg || !p->epoch || !p->status) { rumpy_set_error("%s: null pointer", what); return RUMPY_E_ARG; }
+  if (!bwd && (!p->b1 || !p->b2 || !p->mean)) { rumpy_set_error("%s: forward needs b1, b2, mean", what); return RUMPY_E_ARG; }
+  if (bwd && (!p->t2_in || !p->mask || !p->t2 || !p->dz)) { rumpy_set_error("%s: backward needs t2_in, mask, t2 (d_t2 out), dz", what); return RUMPY_E_ARG; }
+  if ((p->qgate == nullptr) != (p->dzq == nullptr) && bwd) { rumpy_set_error("%s: qgate and dzq go together", what); return RUMPY_E_ARG; }
+  const int sy_n = (p->H + BSH - 1) / BSH;
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW || p->cr <= 0 || p->cr > RC_MAXR || sy_n > rumpy_device_cus() || p->seq >= 4096u) {
+    rumpy_set_error("%s: needs 0 < W <= 48, ceil(H/6) <= CUs, 0 < Cr <= 16, seq < 4096 (W=%d H=%d Cr=%d seq=%u)", what, p->W, p->H, p->cr, p->seq); return RUMPY_E_ARG; }
+  const int64_t need = rumpy_rcab_xchg_bytes(p->N, p->H);
+  if (p->xchg_bytes < need) { rumpy_set_error("%s: exchange buffer too small (%lld < %lld)", what, (long long)p->xchg_bytes, (long long)need); return RUMPY_E_ARG; }
+  RcabDev d;
+  d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
+  d.t = (uint16_t*)p->t; d.t2 = (uint16_t*)p->t2; d.t2_in = (const uint16_t*)p->t2_in; d.mask = (const uint16_t*)p->mask; d.res2 = (const uint16_t*)p->res2; d.out = (uint16_t*)p->out;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;
+  d.cw1 = p->ca_w1; d.cb1 = p->ca_b1; d.cw2 = p->ca_w2; d.cb2 = p->ca_b2; d.cr = p->cr; d.inv_hw = 1.0f / ((float)p->H * (float)p->W);
+  d.mean = p->mean; d.hidden = p->hidden; d.gate = p->gate; d.qgate = p->qgate; d.dz = p->dz; d.dzq = p->dzq;
+  d.xchg = (unsigned long long*)p->xchg; d.xchg_bytes = (unsigned)need; d.epoch = (const unsigned*)p->epoch; d.seq = p->seq; d.status = (unsigned*)p->status;
+  hipStream_t s = (hipStream_t)stream;
+  rumpy_probe_pre(5, s);
+  if (bwd) hipLaunchKernelGGL(rcab_kernel<true>, dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
+  else hipLaunchKernelGGL(rcab_kernel<false>, dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
+  rumpy_probe_post(5, s);
+  return rumpy_check_launch(what);
+}
+
+extern "C" int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H) { return (int64_t)N * ((H + BSH - 1) / BSH) * 64 * 8; }
+extern "C" int rumpy_rcab_fwd(const rumpy_rcab_args* p, void* stream) { return rcab_launch(p, stream, false, "rumpy_rcab_fwd"); }
+extern "C" int rumpy_rcab_bwd(const rumpy_rcab_args* p, void* stream) { return rcab_launch(p, stream, true, "rumpy_rcab_bwd"); }
+extern "C" int rumpy_rcab_epoch_advance(void* epoch, void* stream) {
+  if (!epoch) { rumpy_set_error("rumpy_rcab_epoch_advance: null pointer"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(rcab_epoch_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned*)epoch);
+  return rumpy_check_launch("rumpy_rcab_epoch_advance");
+}

@@ -108,6 +108,7 @@ class SREngine:
         self.plans = {}
         self.wgrad_pixels_per_job = wgrad_pixels_per_job
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
+        self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
         self.feats = spec.head.cout
         if self.feats != 64:
             raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 (got %d); other widths are not '
@@ -189,6 +190,7 @@ class SREngine:
         plan.scaled = []
         plan.ca_param_items = []
         plan.q_items, plan.q_shape, plan.q_dev = [], None, None
+        plan.rcab_n, plan.rcab_xchg, plan.rcab_epoch, plan.rcab_status = 0, None, None, None
         plan.meta = self._new(plan, N, max(1, spec.num_metadata), dtype=torch.float32) if spec.num_metadata else None
 
         def act():
@@ -265,7 +267,23 @@ class SREngine:
                     hid = self._new(plan, N, ca.Cr, dtype=torch.float32)
                     gate = self._new(plan, N, F, dtype=torch.float32)
                     fused = self.use_block_kernel and W <= 48
-                    if fused:   # conv -> ReLU -> conv (+ pool partial sums) in one launch, no residual yet (the gate comes first)
+                    # the whole RCAB in one launch (conv_rcab.hip): the strips of an image exchange their pool sums, the gate is applied on chip
+                    rc = fused and self.use_rcab_kernel and (H + 5) // 6 <= self.cus and 2 * plan.rcab_n + 2 <= 4096
+                    rc_common, seq = None, None
+                    if rc:
+                        if plan.rcab_xchg is None:
+                            plan.rcab_xchg = torch.zeros(int(self.lib.rumpy_rcab_xchg_bytes(N, H)), dtype=torch.uint8, device=self.device)
+                            plan.rcab_epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
+                            plan.rcab_status = torch.zeros(1, dtype=torch.int32, device=self.device)
+                        seq = 2 * plan.rcab_n
+                        plan.rcab_n += 1
+                        rc_common = dict(N=N, H=H, W=W, cr=ca.Cr, ca_w1=_ptr(ca.w1), ca_b1=_ptr(ca.b1), ca_w2=_ptr(ca.w2), ca_b2=_ptr(ca.b2),
+                                         hidden=_ptr(hid), gate=_ptr(gate), qgate=_ptr(qg), xchg=_ptr(plan.rcab_xchg),
+                                         xchg_bytes=plan.rcab_xchg.numel(), epoch=_ptr(plan.rcab_epoch), status=_ptr(plan.rcab_status))
+                        fwd.append(('rumpy_rcab_fwd', L.RcabArgs(
+                            x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed),
+                            t=_ptr(t1) if train else None, t2=_ptr(t2) if train else None, out=_ptr(y), mean=_ptr(mean), seq=seq, **rc_common)))
+                    elif fused:   # conv -> ReLU -> conv (+ pool partial sums) in one launch, no residual yet (the gate comes first)
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
                             x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed), mask=None,
                             res2=None, t=_ptr(t1), out=_ptr(t2), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, res_mode=1,
@@ -273,31 +291,42 @@ class SREngine:
                     else:
                         self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
                         self._conv(fwd, t1, c2, N, H, W, t2, pool=pool)
-                    # squeeze-excite MLP + gate * t2 + skip in one launch (the MLP is recomputed per workgroup)
-                    fwd.append(('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(
-                        pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2), b2=_ptr(ca.b2), mean=_ptr(mean),
-                        hidden=_ptr(hid), gate=_ptr(gate), t=_ptr(t2), res=_ptr(cur), out=_ptr(y), N=N, HW=H * W, C=F, Cr=ca.Cr,
-                        ntiles=tiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg))))
+                    if not rc:
+                        # squeeze-excite MLP + gate * t2 + skip in one launch (the MLP is recomputed per workgroup)
+                        fwd.append(('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(
+                            pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2), b2=_ptr(ca.b2), mean=_ptr(mean),
+                            hidden=_ptr(hid), gate=_ptr(gate), t=_ptr(t2), res=_ptr(cur), out=_ptr(y), N=N, HW=H * W, C=F, Cr=ca.Cr,
+                            ntiles=tiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg))))
 
-                    def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused, qg=qg, qdz=qdz):
+                    def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused, qg=qg, qdz=qdz,
+                             rc_common=rc_common, rc_seq=seq):
                         # y = x + t2*gate:  dgate = sum(g*t2) -> MLP backward -> dpool ; dt2 = g*gate + dpool
                         nchunks = (H * W + 127) // 128
                         part = self._new(plan, N, nchunks, F, dtype=torch.float32)
                         dz = self._new(plan, N, F, dtype=torch.float32)
                         dt2, dt1, dx = (self._new(plan, N, H, W, F) for _ in range(3))
-                        bwd.append(('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=_ptr(g_out), t=_ptr(t2), partial=_ptr(part),
-                                                                              N=N, HW=H * W, C=F)))
-                        # MLP backward (dpool) + dt2 = g * gate + dpool in one launch; dz is kept for the parameter gradients
-                        # of ALL channel-attention layers, which come from one launch after the backward chain
-                        bwd.append(('rumpy_ca_bwd_fused', L.CaBwdFusedArgs(
-                            dy=_ptr(g_out), partial=_ptr(part), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
-                            dz=_ptr(dz), dt=_ptr(dt2), N=N, HW=H * W, C=F, Cr=ca.Cr, nchunks=nchunks, inv_hw=1.0 / (H * W),
-                            qgate=_ptr(qg), dzq=_ptr(qdz))))
+                        if rc_common is not None:
+                            # sum(g * t2) over the image, MLP backward, dt2 = g * gate + dpool and both data gradients in one launch
+                            bwd.append(('rumpy_rcab_bwd', L.RcabArgs(
+                                x=_ptr(g_out), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, t=_ptr(dt1), t2=_ptr(dt2), t2_in=_ptr(t2),
+                                mask=_ptr(t1), res2=_ptr(extra), out=_ptr(dx), mean=None, dz=_ptr(dz), dzq=_ptr(qdz),
+                                seq=rc_seq + 1, **rc_common)))
+                        else:
+                            bwd.append(('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=_ptr(g_out), t=_ptr(t2), partial=_ptr(part),
+                                                                                  N=N, HW=H * W, C=F)))
+                            # MLP backward (dpool) + dt2 = g * gate + dpool in one launch; dz is kept for the parameter gradients
+                            # of ALL channel-attention layers, which come from one launch after the backward chain
+                            bwd.append(('rumpy_ca_bwd_fused', L.CaBwdFusedArgs(
+                                dy=_ptr(g_out), partial=_ptr(part), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
+                                dz=_ptr(dz), dt=_ptr(dt2), N=N, HW=H * W, C=F, Cr=ca.Cr, nchunks=nchunks, inv_hw=1.0 / (H * W),
+                                qgate=_ptr(qg), dzq=_ptr(qdz))))
                         plan.ca_param_items.append(L.CaMlpBwdArgs(
                             partial=_ptr(dz), mean=_ptr(mean), hidden=_ptr(hid), gate=_ptr(gate), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
                             dpool=_ptr(dz), gw1=_ptr(ca.gw1), gb1=_ptr(ca.gb1), gw2=_ptr(ca.gw2), gb2=_ptr(ca.gb2), N=N, C=F, Cr=ca.Cr,
                             nchunks=1, inv_hw=1.0 / (H * W), scale=1.0))
-                        if fused:   # both data gradients in one launch; the skip operand is the RCAB's incoming gradient
+                        if rc_common is not None:
+                            pass
+                        elif fused:   # both data gradients in one launch; the skip operand is the RCAB's incoming gradient
                             bwd.append(('rumpy_conv_block', L.BlockArgs(
                                 x=_ptr(dt2), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1), res2=_ptr(extra),
                                 t=_ptr(dt1), out=_ptr(dx), N=N, H=H, W=W, relu1=0, scale1=1.0, scale2=1.0, res_mode=2,
@@ -515,6 +544,19 @@ class SREngine:
             self._upload_q_items(plan)
         plan.grad_scale = gs
 
+    def _advance_epoch(self, plan, stream):
+        """new tag epoch for the strip exchanges of the RCAB kernels (forward and backward of one pass share it)"""
+        if plan.rcab_epoch is not None:
+            L.check(self.lib.rumpy_rcab_epoch_advance(_ptr(plan.rcab_epoch), stream), 'rumpy_rcab_epoch_advance')
+
+    def exchange_status(self, plan=None):
+        """0, or the code an RCAB launch left when a strip exchange timed out (synchronises)"""
+        worst = 0
+        for p in ([plan] if plan is not None else list(self.plans.values())):
+            if getattr(p, 'rcab_status', None) is not None:
+                worst = max(worst, int(p.rcab_status.item()))
+        return worst
+
     def _upload_q_items(self, plan):
         arr = (L.QMlpItem * len(plan.q_items))(*plan.q_items)
         raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
@@ -564,6 +606,7 @@ class SREngine:
         plan = self.plan_for(N, H, W, train)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._q_gates(plan, meta, stream)
+        self._advance_epoch(plan, stream)
         # the head / tail kernels read the caller's fp32 NCHW tensors in place and write a fresh output tensor: no copies
         plan.x_ref, plan.target_ref = x, target           # keep them alive until the backward pass has consumed them
         plan.head_args.x = x.data_ptr()
@@ -628,6 +671,7 @@ class SREngine:
             plan.target.copy_(target)
 
             def body(stream):
+                self._advance_epoch(plan, stream)
                 self._run(plan.fwd, stream)
                 L.call('rumpy_tail_fwd', plan.tail_loss, stream)
                 self._backward_launches(plan, stream)

@@ -296,7 +296,7 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
         loss, out = h.run_train(x=x, y=y)
         assert h.net.engine.use_block_kernel == (no_block == '0')
         names = {op for op, _ in h.net.engine.plan_for(2, 20, 20, True).fwd}
-        assert ('rumpy_conv_block' in names) == (no_block == '0')
+        assert (({'edsr': 'rumpy_conv_block', 'rcan': 'rumpy_rcab_fwd'}[name]) in names) == (no_block == '0')
         res.append((float(loss), out, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}))
     assert abs(res[0][0] - res[1][0]) < 1e-4 * abs(res[1][0])
     assert self_psnr(res[0][1], res[1][1]) > 60.0
@@ -306,3 +306,61 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
             assert float(a.norm()) == 0.0, k
         else:
             assert float((a - b).norm() / b.norm()) < 2e-2, k
+
+
+@pytest.mark.parametrize('name,kw,hw', [
+    ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16), 20),           # ragged last strip, groups (skip gradient joins a block)
+    ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=1, reduction=16), (60, 24)),     # 10 strips per image: two exchange rounds
+    ('rcan', dict(scale=4, n_resgroups=1, n_resblocks=3, reduction=16), 48),           # the headline patch shape
+    ('qrcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16, style='standard', include_q_layer=True, metadata=['a', 'b', 'c']), 16),
+])
+def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, monkeypatch):
+    """conv_rcab.hip (RCAB forward / backward in ONE launch, pool sums exchanged between the strips of an image) against the
+    conv_block + ca_fwd_fused / ca_bwd_reduce + ca_bwd_fused + conv_block launches (RUMPY_NO_RCAB=1).  Same operands; the fused
+    kernel applies the gate to the fp32 accumulators instead of the bf16-stored conv output, so outputs agree to bf16 rounding."""
+    sc = kw['scale']
+    x, y = O.synthetic_batch(660, 3, lr_hw=hw, scale=sc)
+    meta = torch.rand(3, 3, 1, 1, generator=torch.Generator().manual_seed(4)) if name == 'qrcan' else None
+    extra = dict(extra_channels=meta) if meta is not None else {}
+    res = []
+    for no_rcab in ('0', '1'):
+        monkeypatch.setenv('RUMPY_NO_RCAB', no_rcab)
+        h = _handler(name, lr=1e-3, **kw)
+        onet = O.build_oracle(name, **({k: v for k, v in kw.items() if k != 'metadata'}), **({'num_metadata': 3} if name == 'qrcan' else {}))
+        h.net.load_state_dict(O.seeded_state_dict(onet, 826))
+        ev, evl, _ = h.run_eval(x=x, y=y, request_loss=True, **extra)           # eval plan: no stores of the intermediates
+        loss, out = h.run_train(x=x, y=y, **extra)
+        H, W = (hw, hw) if isinstance(hw, int) else hw
+        plan = h.net.engine.plan_for(3, H, W, True)
+        fnames, bnames = [op for op, _ in plan.fwd], [op for op, _ in plan.bwd]
+        assert ('rumpy_rcab_fwd' in fnames) == (no_rcab == '0') and ('rumpy_rcab_bwd' in bnames) == (no_rcab == '0')
+        assert ('rumpy_ca_fwd_fused' in fnames) == (no_rcab == '1') and ('rumpy_ca_bwd_reduce' in bnames) == (no_rcab == '1')
+        grads = {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}
+        assert h.net.engine.exchange_status() == 0
+        res.append((float(loss), out, grads, ev, float(evl)))
+    assert abs(res[0][0] - res[1][0]) < 2e-4 * abs(res[1][0])
+    assert self_psnr(res[0][1], res[1][1]) > 58.0 and self_psnr(res[0][3], res[1][3]) > 58.0
+    assert abs(res[0][4] - res[1][4]) < 2e-4 * abs(res[1][4])
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        if float(b.norm()) == 0.0:
+            assert float(a.norm()) == 0.0, k
+        else:
+            assert float((a - b).norm() / b.norm()) < 2e-2, k
+
+
+def test_one_launch_rcab_is_deterministic_at_the_headline_shape():
+    """32 x 48 x 48: 256 strips, one per CU, every image's 8 strips exchange sums - two runs from the same state are bit-identical"""
+    kw = dict(scale=4, n_resgroups=2, n_resblocks=3, reduction=16)
+    x, y = O.synthetic_batch(670, 32, lr_hw=48, scale=4)
+    outs = []
+    for _ in range(2):
+        h = _handler('rcan', lr=1e-3, **kw)
+        h.net.load_state_dict(O.seeded_state_dict(O.build_oracle('rcan', **kw), 826))
+        losses = []
+        for _ in range(3):
+            loss, out = h.run_train(x=x, y=y)
+            losses.append(float(loss))
+        assert h.net.engine.exchange_status() == 0
+        outs.append((losses, out, h.net.flat_p.detach().cpu().clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
