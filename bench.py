@@ -141,7 +141,8 @@ def main():
         plan = hipnet.engine.plan_for(N, 48, 48, True)
         ops = plan.fwd + plan.bwd
         blocks = [a for name, a in ops if name == 'rumpy_conv_block']
-        use_block = len(blocks) > 0
+        rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd')]      # share probe id 5 with the block kernel
+        use_block = len(blocks) + len(rcabs) > 0
         hipnet.use_graph = False          # the probe records events around eager launches (a graph replay has none)
         lib.rumpy_probe_begin(5 if use_block else 1, 80 * args.probe_steps + 8)
         for i in range(args.probe_steps):
@@ -156,8 +157,11 @@ def main():
             # algorithmic bytes: every [N,48,48,64] bf16 tensor a launch must touch once, from the engine's launch plan
             if use_block:
                 flop = 2 * layer_flop                      # the halo-row recompute of the first conv is overhead, not counted
-                tensors = [2 + sum(1 for f in ('t', 'mask', 'res2') if getattr(a, f)) for a in blocks]
+                tensors = [2 + sum(1 for f in ('t', 'mask', 'res2') if getattr(a, f)) for a in blocks] + \
+                          [2 + sum(1 for f in ('t', 't2', 't2_in', 'mask', 'res2') if getattr(a, f)) for a in rcabs]
                 kname = 'conv_block_kernel (residual block: two 3x3 convs 64->64 per launch, fwd + data-gradient launches)'
+                if rcabs:
+                    kname = 'rcab_kernel (residual channel-attention block per launch: two 3x3 convs 64->64 + attention gate; fwd + bwd launches)'
             else:
                 flop = layer_flop
                 tensors = [2 + sum(1 for f in ('mask', 'res1', 'res2') if getattr(a, f))
@@ -185,7 +189,7 @@ def main():
                 # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
                 roofline['traffic'] = PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
-            elif BLOCK_PMC_TRAFFIC_BYTES:
+            elif BLOCK_PMC_TRAFFIC_BYTES and not rcabs:
                 roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
 

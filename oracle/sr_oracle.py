@@ -183,8 +183,9 @@ class MetaAttentionResidualBlock(nn.Module):
     optional node: res = body(x); res = QCALayer_standard(res) (:113-136 -> plain channel attention, keys final_body.conv_du.*);
     res = q_node(res, metadata); res += x.  ``res_scale`` is stored and unused, as in the reference."""
 
-    def __init__(self, feats, reduction, num_metadata, num_layers_in_q_layer=2, q_layer=True):
+    def __init__(self, feats, reduction, num_metadata, num_layers_in_q_layer=2, q_layer=True, style='standard'):
         super().__init__()
+        self.style = style          # 'modulate' (QCALayer.forward :113-115): the attention vector is multiplied by the [N,C,1,1] attributes
         # creation order as the reference (architectures.py:166-172: the two convs first - same seed, same initial weights);
         # registration order as the reference (:173-195: final_body, q_node, body) - it is the order of the state_dict keys
         # and of the optimizer's parameter indices in a checkpoint
@@ -197,7 +198,8 @@ class MetaAttentionResidualBlock(nn.Module):
 
     def forward(self, xm):
         x, meta = xm
-        res = self.final_body(self.body(x))
+        res = self.body(x)
+        res = res * (self.final_body.conv_du(self.final_body.avg_pool(res)) * meta) if self.style == 'modulate' else self.final_body(res)
         if self.q_layer:
             res = self.q_node(res, meta)
         return res + x, meta
@@ -207,10 +209,10 @@ class MetaAttentionGroup(nn.Module):
     """architectures.py:249-299 (QResidualGroup): n QRCABs (the first num_q_layers of them with a q-layer, all if None),
     then ``final_body`` conv, + skip."""
 
-    def __init__(self, feats, reduction, n_blocks, num_metadata, q_layer, num_q_layers, num_layers_in_q_layer):
+    def __init__(self, feats, reduction, n_blocks, num_metadata, q_layer, num_q_layers, num_layers_in_q_layer, style='standard'):
         super().__init__()
         blocks = [MetaAttentionResidualBlock(feats, reduction, num_metadata, num_layers_in_q_layer,
-                                             q_layer=q_layer and (num_q_layers is None or b < num_q_layers)) for b in range(n_blocks)]
+                                             q_layer=q_layer and (num_q_layers is None or b < num_q_layers), style=style) for b in range(n_blocks)]
         self.final_body = conv3x3(feats, feats)          # registered before body (architectures.py:292-293)
         self.body = nn.Sequential(*blocks)
 
@@ -229,14 +231,14 @@ class OracleQRCAN(nn.Module):
                  num_metadata=1, include_q_layer=True, selective_meta_blocks=None, num_q_layers_inner_residual=None,
                  num_layers_in_q_layer=2, style='standard', **_ignored):
         super().__init__()
-        if style != 'standard':
-            raise NotImplementedError('oracle restates QCALayer style "standard" only')
+        if style not in ('standard', 'modulate'):
+            raise NotImplementedError('oracle restates the QCALayer styles "standard" and "modulate" only')
         f = n_feats
         head = conv3x3(in_feats, f)                      # creation order (random init) and registration order (keys) of
         groups = [MetaAttentionGroup(                    # architectures.py:368-433: head, groups, final_body, tail created;
             f, reduction, n_resblocks, num_metadata,     # final_body, head, body, tail registered
             include_q_layer and (selective_meta_blocks is None or bool(selective_meta_blocks[g])),
-            num_q_layers_inner_residual, num_layers_in_q_layer) for g in range(n_resgroups)]
+            num_q_layers_inner_residual, num_layers_in_q_layer, style=style) for g in range(n_resgroups)]
         self.final_body = conv3x3(f, f)
         tail = [make_upsampler(scale, f), conv3x3(f, out_feats)]
         self.head = nn.Sequential(head)
@@ -414,7 +416,7 @@ def build_oracle(name, **internal_params):
         fwd = {k: p[k] for k in ('n_resblocks', 'n_resgroups', 'n_feats', 'out_feats', 'reduction', 'include_q_layer',
                                  'selective_meta_blocks', 'num_q_layers_inner_residual', 'num_layers_in_q_layer') if k in p}
         return OracleQRCAN(scale=p.get('scale', 4), in_feats=p.get('in_features', 3), style=p.get('style', 'standard'),
-                           num_metadata=p['num_metadata'], **fwd)
+                           num_metadata=p.get('num_metadata', 1), **fwd)
     if name == 'contrastiveblindqrcan':
         # ContrastiveBlindQRCANHandler blur_kernel_blind_sr/handlers.py:455-510: QRCAN(num_metadata=encoder_output_size=256, ...) inside
         # ContrastiveBlindSRPipeline
@@ -422,6 +424,22 @@ def build_oracle(name, **internal_params):
         q['num_metadata'] = p.get('encoder_output_size', 256)
         return OracleBlindPipeline(build_oracle('qrcan', **q))
     raise KeyError(name)
+
+
+def scale_qpi(qpi, n_feats=64, min_mu=-0.2, max_mu=0.8, clamp=False, sig=0.2):
+    """QRCANHandler.scale_qpi / gaussian (attention_manipulators/handlers.py:59-73), style 'modulate': a scalar q in [0,1] per image
+    -> a gaussian bump over the channel axis, centre mu = q * (max_mu - min_mu) + min_mu on linspace(0, 1, n_feats), sigma 0.2,
+    evaluated in float64 numpy and cast to float32.  qpi [N,1,1,1] -> [N,n_feats,1,1]."""
+    base = np.linspace(0, 1, n_feats)
+    scaled = (qpi * (max_mu - min_mu)) + min_mu
+    rows = []
+    for i in range(scaled.size(0)):
+        mu = scaled[i].squeeze().numpy()
+        rows.append(torch.from_numpy((1 / (np.sqrt(2 * np.pi) * sig)) * np.exp(-np.power(base - mu, 2.) / (2 * np.power(sig, 2.)))).type(torch.float32))
+    full = torch.stack(rows)
+    if clamp:
+        full = torch.clamp(full, 0, 1)
+    return full.unsqueeze(2).unsqueeze(3)
 
 
 # --------------------------------------------------------------------------------------

@@ -1,10 +1,11 @@
 """QRCAN with meta-attention for the MI355X HIP path - drop-in for rumpy/SISR/models/attention_manipulators/architectures.py
 (QRCAN :313-462, QResidualGroup :249-299, QRCAB :154-228, QCALayer :41-136) and q_layer.py (ParaCALayer :5-45).
 
-Supported configuration (the meta-attention setup of the reference's blind / non-blind QRCAN experiments):
-``style='standard'`` (plain channel attention in QCALayer) with ``include_q_layer=True`` - a ParaCALayer with two FC layers and
-ReLU after every residual block (or the subsets selected by ``selective_meta_blocks`` / ``num_q_layers_inner_residual``).
-Other QCALayer styles and the pixel-attention / dgfmb / SFT / DA-conv nodes raise.
+Supported configurations: ``style='standard'`` (plain channel attention in QCALayer) with ``include_q_layer=True`` -
+the meta-attention setup of the reference's blind / non-blind QRCAN experiments: a ParaCALayer with two FC layers and ReLU after every
+residual block (or the subsets selected by ``selective_meta_blocks`` / ``num_q_layers_inner_residual``) - and ``style='modulate'``, the
+handler's default: the attention vector of every block is multiplied by a [N, 64] attribute vector (QCALayer.forward :113-115).
+The concatenating QCALayer styles and the pixel-attention / dgfmb / SFT / DA-conv nodes raise.
 
 As in rumpy_amd/SISR/models/advanced/architectures.py the module tree only owns the parameters, under the reference's
 state_dict keys AND in the reference's registration order (final_body before head/body/tail, a block's final_body and q_node
@@ -58,15 +59,18 @@ class QRCAN(HipSRNet):
                  num_q_layers_inner_residual=None, num_layers_in_q_layer=2, include_sft_layer=False, include_dgfmb_layer=False,
                  use_dgfmb_outer_reduction=False, include_da_conv_layer=False, staggered_encoding=False, **kwargs):
         super().__init__()
-        unsupported = [k for k, v in (('style=%r' % style, style != 'standard'), ('include_pixel_attention', include_pixel_attention),
+        unsupported = [k for k, v in (('style=%r' % style, style not in ('standard', 'modulate')),
+                                      ('style "modulate" together with q-layers', style == 'modulate' and include_q_layer),
+                                      ('style "modulate" with n_feats != 64', style == 'modulate' and n_feats != 64),
+                                      ('include_pixel_attention', include_pixel_attention),
                                       ('include_sft_layer', include_sft_layer), ('include_dgfmb_layer', include_dgfmb_layer),
                                       ('use_dgfmb_outer_reduction', use_dgfmb_outer_reduction), ('include_da_conv_layer', include_da_conv_layer),
                                       ('staggered_encoding', staggered_encoding)) if v]
         if unsupported:
-            raise RuntimeError('rumpy_amd: QRCAN option(s) %s are not implemented on the HIP path (style "standard" with q-layers only); '
-                               'there is no fallback' % ', '.join(unsupported))
+            raise RuntimeError('rumpy_amd: QRCAN option(s) %s are not implemented on the HIP path (styles "modulate", and "standard" with or '
+                               'without q-layers); there is no fallback' % ', '.join(unsupported))
         f = n_feats
-        self.scale, self.num_metadata = scale, num_metadata
+        self.scale, self.num_metadata, self.style = scale, num_metadata, style
         self.metadata_reduction = nn.Sequential(nn.Identity())
         head = _conv(in_feats, f)
         groups = [_QGroupParams(f, reduction, n_resblocks, num_metadata,
@@ -94,4 +98,5 @@ class QRCAN(HipSRNet):
             body.append(('group', items, self._conv_layer('body.%d.final_body' % gi, grp.final_body)))
         ups = [self._conv_layer('tail.0.%d' % i, m, shuffle=True) for i, m in enumerate(self.tail[0]) if isinstance(m, nn.Conv2d)]
         return NetSpec(self._conv_layer('head.0', self.head[0], kind='head'), body, self._conv_layer('final_body', self.final_body), ups,
-                       self._conv_layer('tail.1', self.tail[1], kind='tail'), self.scale, num_metadata=self.num_metadata if any_q else 0)
+                       self._conv_layer('tail.1', self.tail[1], kind='tail'), self.scale,
+                       num_metadata=64 if self.style == 'modulate' else (self.num_metadata if any_q else 0), modulate=self.style == 'modulate')

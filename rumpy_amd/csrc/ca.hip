@@ -476,7 +476,7 @@ extern "C" int rumpy_ca_bwd_fused(const rumpy_ca_bwd_fused_args* p, void* stream
   CaBwdFused d;
   d.dy = (const uint4*)p->dy; d.partial = p->partial; d.hidden = p->hidden; d.gate = p->gate; d.w1 = p->w1; d.w2 = p->w2;
   d.dz = p->dz; d.dt = (uint4*)p->dt; d.qgate = p->qgate; d.dzq = p->dzq;
-  if ((p->qgate == nullptr) != (p->dzq == nullptr)) { rumpy_set_error("rumpy_ca_bwd_fused: qgate and dzq go together"); return RUMPY_E_ARG; }
+  if (p->dzq && !p->qgate) { rumpy_set_error("rumpy_ca_bwd_fused: dzq without qgate"); return RUMPY_E_ARG; }   // a constant gate (style 'modulate') has no dzq
   d.N = p->N; d.HW = p->HW; d.C = p->C; d.Cr = p->Cr; d.nchunks = p->nchunks; d.inv_hw = p->inv_hw; d.per_image = ca_per_image(p->N, p->HW, p->C);
   hipLaunchKernelGGL(ca_bwd_fused_kernel, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
   return rumpy_check_launch("rumpy_ca_bwd_fused");

@@ -55,12 +55,14 @@ class NetSpec:
     """Topology handed over by the architecture module.
 
     body items: ('resblock', conv1, conv2, res_scale) | ('rcab', conv1, conv2, ca[, q]) | ('group', [items], conv)
-    (q: QLayerParams of a QRCAB's meta-attention node or None; num_metadata > 0 makes forward() expect a metadata matrix)
+    (q: QLayerParams of a QRCAB's meta-attention node or None; num_metadata > 0 makes forward() expect a metadata matrix;
+    modulate: QCALayer style 'modulate' - the [N, 64] metadata matrix itself multiplies every block's attention gate)
     """
 
-    def __init__(self, head, body, body_conv, ups, tail, scale, num_metadata=0):
+    def __init__(self, head, body, body_conv, ups, tail, scale, num_metadata=0, modulate=False):
         self.head, self.body, self.body_conv, self.ups, self.tail, self.scale = head, body, body_conv, ups, tail, scale
         self.num_metadata = num_metadata
+        self.modulate = modulate
 
     def convs(self):
         out = [self.head]
@@ -253,6 +255,10 @@ class SREngine:
                     _, c1, c2, ca = it[:4]
                     q = it[4] if len(it) > 4 else None
                     qh = qg = qdz = None
+                    if spec.modulate:       # attention vector * attributes (constant w.r.t. the parameters: no gradient of its own)
+                        if q is not None or spec.num_metadata != F:
+                            raise RuntimeError('rumpy_amd: style "modulate" takes one attribute per feature channel and no q-layers')
+                        qg = plan.meta
                     if q is not None:      # meta-attention gate of this QRCAB: evaluated for all layers by one launch before the forward ops
                         qh = self._new(plan, N, q.Hq, dtype=torch.float32)
                         qg = self._new(plan, N, F, dtype=torch.float32)
@@ -566,12 +572,14 @@ class SREngine:
 
     def _q_gates(self, plan, meta, stream):
         """metadata [N,M] -> the meta-attention gates of every q-layer (one launch)"""
-        if not plan.q_items:
+        if plan.meta is None:
             return
         if meta is None or tuple(meta.shape) != tuple(plan.meta.shape):
             raise RuntimeError('rumpy_amd: this network needs a metadata matrix of shape %s (got %s)'
                                % (tuple(plan.meta.shape), None if meta is None else tuple(meta.shape)))
         plan.meta.copy_(meta, non_blocking=True)
+        if not plan.q_items:
+            return
         if plan.q_dev is None:
             self._upload_q_items(plan)
         M, Hq = plan.q_shape

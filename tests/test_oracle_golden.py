@@ -256,3 +256,34 @@ def test_g13_blind_pipeline_oracle_matches_reference_handler(golden_dir):
     assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
     with torch.no_grad():
         assert np.allclose(net.E(xe)[0].numpy(), g['eval_embedding'], atol=1e-6)
+
+
+def test_g14_qrcan_default_modulate_style_matches_reference_handler(golden_dir):
+    """QRCAN in the reference handler's DEFAULT configuration (style 'modulate', metadata ['qpi']): oracle network + scale_qpi against
+    three training steps and one evaluation of the REAL reference QRCANHandler, and scale_qpi against its known-answer vectors."""
+    g = np.load(os.path.join(golden_dir, 'g14_qrcan_modulate_small_train.npz'))
+    q = torch.from_numpy(g['kat_q'])
+    assert np.array_equal(O.scale_qpi(q, n_feats=16).numpy(), g['kat_16'])
+    assert np.array_equal(O.scale_qpi(q, n_feats=64, clamp=True, min_mu=-0.1, max_mu=0.9).numpy(), g['kat_64_clamped'])
+    net = O.build_oracle('qrcan', scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='modulate', include_q_layer=False)
+    assert list(net.state_dict().keys()) == [str(k) for k in g['keys']]
+    net.load_state_dict(O.seeded_state_dict(net, 851))
+    h = O.OracleHandler(net, lr=1e-3, scheduler='cosine_annealing_warm_restarts',
+                        scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+
+    def attr(seed, n):
+        qpi = torch.from_numpy(np.random.default_rng(seed).uniform(0, 1, (n, 1)).astype(np.float32)).unsqueeze(2).unsqueeze(3)
+        return O.scale_qpi(qpi, n_feats=16)
+    for step in range(3):
+        xb, yb = O.synthetic_batch(860 + step, 2, lr_hw=12, scale=2)
+        loss, out = h.run_train(xb, yb, extra_channels=attr(870 + step, 2))
+        assert abs(float(loss) - float(g['loss%d' % step])) < 1e-6
+        if step == 0:
+            assert np.allclose(out.numpy(), g['out0'], atol=1e-6)
+            for k, p in net.named_parameters():
+                assert np.allclose(p.grad.numpy(), g['grad0.' + k], atol=1e-6, rtol=1e-4), k
+    for k, v in net.state_dict().items():
+        assert np.allclose(v.numpy(), g['w3.' + k], atol=2e-6), k
+    xe, ye = O.synthetic_batch(880, 1, lr_hw=10, scale=2)
+    ev, evl, _ = h.run_eval(xe, ye, request_loss=True, extra_channels=attr(881, 1))
+    assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6

@@ -162,8 +162,40 @@ def test_qrcan_checkpoint_roundtrip_and_oracle_interchange():
     assert self_psnr(o_b, o_o) >= 50.0 and abs(float(l_b) - float(l_o)) < 3e-3 * float(l_o)
 
 
+@pytest.mark.parametrize('no_rcab', ['0', '1'])
+def test_qrcan_default_modulate_style_against_oracle(no_rcab, monkeypatch):
+    """the handler's default configuration: one quality value per image -> scale_qpi -> attention vector * attributes, through both
+    the one-launch RCAB kernels and the separate attention launches"""
+    monkeypatch.setenv('RUMPY_NO_RCAB', no_rcab)
+    kw = dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16)
+    h = define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, checkpoint_load=False, loss_masking=False,
+                     metadata_list=None, lr=1e-3, **SCHED, **kw)
+    assert h.style == 'modulate'
+    onet = O.build_oracle('qrcan', style='modulate', include_q_layer=False, **kw)
+    assert list(onet.state_dict().keys()) == list(h.net.state_dict().keys())
+    sd = O.seeded_state_dict(onet, 826)
+    onet.load_state_dict(sd)
+    h.net.load_state_dict(sd)
+    oh = O.OracleHandler(onet, lr=1e-3, scheduler=SCHED['scheduler'], scheduler_params=SCHED['scheduler_params'])
+    for step in range(2):
+        x, y = O.synthetic_batch(930 + step, 3, lr_hw=16, scale=2)
+        q = _meta(940 + step, 3, 1)
+        loss, out = h.run_train(x=x, y=y, metadata=q, metadata_keys=[('qpi',)])
+        oloss, oout = oh.run_train(x, y, extra_channels=O.scale_qpi(q.unsqueeze(2).unsqueeze(3), n_feats=64))
+        assert abs(float(loss) - float(oloss)) < (2e-3 if step == 0 else 1e-2) * float(oloss)
+        if step == 0:
+            assert self_psnr(out, oout) >= 50.0
+            print('worst grad rel err', _grad_check(h, oh))
+    xe, ye = O.synthetic_batch(950, 2, lr_hw=(13, 22), scale=2)
+    qe = _meta(951, 2, 1)
+    out, loss, _ = h.run_eval(x=xe, y=ye, request_loss=True, metadata=qe, metadata_keys=[('qpi',)])
+    oout, oloss, _ = oh.run_eval(xe, ye, request_loss=True, extra_channels=O.scale_qpi(qe.unsqueeze(2).unsqueeze(3), n_feats=64))
+    assert self_psnr(out, oout) >= 45.0 and abs(float(loss) - float(oloss)) < 1e-2 * float(oloss)
+    assert h.net.engine.exchange_status() == 0
+
+
 def test_unsupported_qrcan_variants_are_refused():
-    for bad in (dict(style='modulate'), dict(style='standard', include_pixel_attention=True), dict(style='standard', include_sft_layer=True),
+    for bad in (dict(style='max_concat'), dict(style='modulate', include_q_layer=True), dict(style='standard', include_pixel_attention=True), dict(style='standard', include_sft_layer=True),
                 dict(style='standard', srmd_mode=True), dict(style='standard', use_moco=True)):
         with pytest.raises(RuntimeError):
             define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, n_resgroups=1, n_resblocks=1, **bad)
