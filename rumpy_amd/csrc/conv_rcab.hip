@@ -24,6 +24,9 @@ typedef __amdgpu_buffer_rsrc_t rc_rsrc;
 constexpr int RC_SC1 = 16;
 constexpr unsigned RC_SPIN = 1u << 20;
 constexpr int RC_MAXR = 16;
+#ifndef RCAB_ABL
+#define RCAB_ABL 0   // timing experiments only (tools/build_abl.sh): 1 = no polling, 2 = also no product sums / tile transform in backward
+#endif
 
 struct RcabDev {
   const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
@@ -46,6 +49,7 @@ __device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int 
   const int c = tid & 63, w = tid >> 6;
   if (tid < 64) __builtin_amdgcn_raw_buffer_store_b64((rc_u32x2){__float_as_uint(mine), tag}, rr, (unsigned)(((n * a.sy_n + sy) * 64 + c) * 8), 0, RC_SC1);
   float total = 0.f;
+  if (RCAB_ABL >= 1) return mine * a.sy_n;
   for (int s0 = 0; s0 < a.sy_n; s0 += 8) {
     const int s = s0 + w;
     float val = 0.f;
@@ -78,6 +82,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   __shared__ float spool[2 * 64];
   __shared__ __attribute__((aligned(16))) float sgate[64];
   __shared__ __attribute__((aligned(16))) float sdp[64];
+  // the squeeze-excite MLP's operands, fetched with the first loads of the kernel: its 2 * cr dependent steps then read LDS, not L2
+  // (one L2 round trip per step was 4-5 us of the first version)
+  __shared__ float sw1[RC_MAXR * 64];      // [r][c] = conv_du.0.weight
+  __shared__ float sw2t[RC_MAXR * 64];     // [r][c] = conv_du.2.weight[c][r]
+  __shared__ float svec[4 * 64];           // [0] conv_du.0.bias (cr) | [1] conv_du.2.bias | [2] q gate | [3] bwd: forward gate ; hidden at [0][32..]
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + BXBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,6 +98,26 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
   uint4 T2[BWD ? 5 : 1];
+  float mw1[2], mw2[2], mv = 0.f;          // MLP operands of this thread: requested first, written to LDS behind the tile
+  {
+    const int mtot = a.cr * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + BTHREADS * k;     // cr <= 16: at most 1024 weights per matrix
+      mw1[k] = a.cw1[i < mtot ? i : 0];
+      mw2[k] = a.cw2[i < mtot ? i : 0];
+    }
+    // one unconditional load per thread (wave-uniform source select, clamped index): conditional loads would turn later waits into vmcnt(0)
+    const int which = tid >> 6, c = tid & 63;
+    const int cr_c = c < a.cr ? c : 0;
+    const float* src = a.cb2; int idx = c;
+    if (which == 0) { src = a.cb1; idx = cr_c; }
+    else if (which == 2 && a.qgate) { src = a.qgate; idx = n * 64 + c; }
+    else if (which == 3) { src = a.gate; idx = n * 64 + c; }             // forward: not used (the launch's own output buffer)
+    else if (which == 4) { src = a.hidden; idx = n * a.cr + cr_c; }
+    mv = src[idx];
+    if (which == 2 && !a.qgate) mv = 1.f;
+  }
   {
     uint4 R[BREGS];
     const int y0 = sy * BSH - 2;
@@ -126,6 +155,21 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const int p = tid + BTHREADS * i;
       const int pix = p >> 3, part = p & 7;
       if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+    }
+    {
+      const int mtot = a.cr * 64;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = tid + BTHREADS * k;
+        if (i < mtot) {
+          sw1[i] = mw1[k];                                  // [r][c] as stored
+          sw2t[(i % a.cr) * 64 + i / a.cr] = mw2[k];        // [c][r] -> [r][c]
+        }
+      }
+      const int which = tid >> 6, c = tid & 63;
+      if (which == 0) { if (c < RC_MAXR) svec[c] = mv; }      // row 0: bias of conv_du.0 in [0, 16), hidden (backward) in [32, 48)
+      else if (which < 4) svec[which * 64 + c] = mv;
+      else if (which == 4 && c < RC_MAXR) svec[32 + c] = mv;      // hidden[n][r] behind the (<= 16) bias entries of row 0
     }
   }
   bf16x8 F[18];
@@ -178,14 +222,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     const float ds = strip_allsum(a, mine, n, sy, tid, tag, sx);
     if (tid < 64) {
       const int c = tid;
-      const float s = a.gate[n * 64 + c];
-      const float gq = a.qgate ? a.qgate[n * 64 + c] : 1.f;
+      const float s = svec[3 * 64 + c];
+      const float gq = svec[2 * 64 + c];
       const float dz = (ds * gq) * s * (1.f - s);
       float dp = 0.f;
       for (int r = 0; r < a.cr; ++r) {
-        float dh = wave_sum(a.cw2[c * a.cr + r] * dz);
-        dh = (a.hidden[n * a.cr + r] > 0.f) ? dh : 0.f;
-        dp = fmaf(a.cw1[r * 64 + c], dh, dp);
+        float dh = wave_sum(sw2t[r * 64 + c] * dz);
+        dh = (svec[32 + r] > 0.f) ? dh : 0.f;
+        dp = fmaf(sw1[r * 64 + c], dh, dp);
       }
       sgate[c] = s * gq;
       sdp[c] = dp * a.inv_hw;
@@ -392,14 +436,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (tid < 64) {
         const int c = tid;
         const float mean = tot * a.inv_hw;
-        float z = a.cb2[c];
+        float z = svec[64 + c];
         for (int r = 0; r < a.cr; ++r) {
-          const float h = fmaxf(wave_sum(a.cw1[r * 64 + c] * mean) + a.cb1[r], 0.f);
-          z = fmaf(a.cw2[c * a.cr + r], h, z);
+          const float h = fmaxf(wave_sum(sw1[r * 64 + c] * mean) + svec[r], 0.f);
+          z = fmaf(sw2t[r * 64 + c], h, z);
           if (sy == 0 && c == 0) a.hidden[n * a.cr + r] = h;
         }
         const float gt = 1.f / (1.f + expf(-z));
-        sgate[c] = a.qgate ? gt * a.qgate[n * 64 + c] : gt;
+        sgate[c] = gt * svec[2 * 64 + c];
         if (sy == 0) { a.mean[n * 64 + c] = mean; a.gate[n * 64 + c] = gt; }
       }
       __syncthreads();
