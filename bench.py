@@ -189,7 +189,10 @@ def main():
                 # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
                 roofline['traffic'] = PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
-            elif BLOCK_PMC_TRAFFIC_BYTES and not rcabs:
+            elif rcabs:
+                roofline['traffic'] = 62.1e6
+                roofline['traffic_source'] = 'profiles/r01_pmc_rcab.md (separate rocprofv3 --pmc passes, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
+            elif BLOCK_PMC_TRAFFIC_BYTES:
                 roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
 
