@@ -95,6 +95,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   const int strip = blockIdx.x;
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
   const unsigned tag = (*a.epoch << 12) + a.seq;
+  unsigned long long stamps[10];
+  int nst = 0;
+#define RC_STAMP() do { if (RCAB_ABL == 9 && nst < 10) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  RC_STAMP();                              // 0: start
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
   uint4 T2[BWD ? 5 : 1];
@@ -182,6 +186,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   const int gpair = 4 * (g & ~1);
   const int chunk8 = 2 * q + (gpair >> 3);
   __syncthreads();
+  RC_STAMP();                              // 1: input tile in LDS
 
   if (BWD) {
     // ---- phase 0b: ds = sum over the strip of dy * t2 per channel -> all strips of the image -> MLP backward -> d_t2 in place ----
@@ -219,7 +224,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
+    RC_STAMP();                            // (bwd) 2: product sums reduced
     const float ds = strip_allsum(a, mine, n, sy, tid, tag, sx);
+    RC_STAMP();                            // (bwd) 3: exchange done
     if (tid < 64) {
       const int c = tid;
       const float s = svec[3 * 64 + c];
@@ -265,6 +272,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       }
     }
     __syncthreads();
+    RC_STAMP();                            // (bwd) 4: d_t2 tile ready
   }
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
@@ -290,6 +298,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     unsigned off[8][2];
     sweep_bases(off, 0u, 4 * rh, px, g);
     block_sweep<4>(acc, F, lds, off);
+    RC_STAMP();                            // sweep A done
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
@@ -322,6 +331,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     }
   }
   __syncthreads();
+  RC_STAMP();                              // T tile written + barrier
 
   // ---- phase 2: rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ----
   {
@@ -351,6 +361,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     unsigned off[8][2];
     sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
     block_sweep<3>(acc, F, lds, off);
+    RC_STAMP();                            // sweep B done
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
     float V[4][8], vs[4];
 #pragma unroll
@@ -432,7 +443,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       }
       __syncthreads();
       const float mine = (tid < 64) ? spool[tid] + spool[64 + tid] : 0.f;
+      RC_STAMP();                          // (fwd) pool sums + t2 stores issued
       const float tot = strip_allsum(a, mine, n, sy, tid, tag, sx);
+      RC_STAMP();                          // (fwd) exchange done
       if (tid < 64) {
         const int c = tid;
         const float mean = tot * a.inv_hw;
@@ -469,6 +482,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         *reinterpret_cast<uint2*>(a.out + osoff) = pack4_bf16(fmaf(vs[0], gs.x, m[0]), fmaf(vs[1], gs.y, m[1]), fmaf(vs[2], gs.z, m[2]), fmaf(vs[3], gs.w, m[3]));
       }
     }
+  }
+  RC_STAMP();                              // end (stores issued)
+  if (RCAB_ABL == 9 && tid == 0 && a.t) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.t) + (size_t)strip * 16;
+    for (int i = 0; i < 10; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
   }
 }
 

@@ -276,3 +276,40 @@ def eval_bench():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'eval':
     eval_bench()
+
+
+def rcab_bench(N=32, H=48, W=48, reps=40):
+    """one-launch RCAB kernels (conv_rcab.hip) on the headline shape; with RUMPY_AMD_LIB=build_abl/RCAB_ABL_9 also the in-kernel phase stamps"""
+    gen = np.random.default_rng(0)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32)), torch.zeros(64))
+    pa, pb = mk(), mk()
+    f32 = lambda *s: torch.from_numpy(gen.uniform(-0.3, 0.3, s).astype(np.float32)).to(DEV)
+    cw1, cb1, cw2, cb2 = f32(4, 64), f32(4), f32(64, 4), f32(64)
+    act = lambda: torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    x, t1, t2, out, dy, dt1, dt2, dx = (act() for _ in range(8))
+    mean, hid, gate, dz = torch.zeros(N, 64, device=DEV), torch.zeros(N, 4, device=DEV), torch.zeros(N, 64, device=DEV), torch.zeros(N, 64, device=DEV)
+    xchg = torch.zeros(int(L.lib().rumpy_rcab_xchg_bytes(N, H)), dtype=torch.uint8, device=DEV)
+    epoch, status = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    common = dict(N=N, H=H, W=W, cr=4, ca_w1=cw1.data_ptr(), ca_b1=cb1.data_ptr(), ca_w2=cw2.data_ptr(), ca_b2=cb2.data_ptr(), hidden=hid.data_ptr(),
+                  gate=gate.data_ptr(), xchg=xchg.data_ptr(), xchg_bytes=xchg.numel(), epoch=epoch.data_ptr(), status=status.data_ptr())
+    fwd = L.RcabArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                     t=t1.data_ptr(), t2=t2.data_ptr(), out=out.data_ptr(), mean=mean.data_ptr(), seq=0, **common)
+    bwd = L.RcabArgs(x=dy.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), t=dt1.data_ptr(), t2=dt2.data_ptr(), t2_in=t2.data_ptr(),
+                     mask=t1.data_ptr(), out=dx.data_ptr(), dz=dz.data_ptr(), seq=1, **common)
+    for name, fn, a, tbuf in (('fwd', 'rumpy_rcab_fwd', fwd, t1), ('bwd', 'rumpy_rcab_bwd', bwd, dt1)):
+        def run():
+            L.check(L.lib().rumpy_rcab_epoch_advance(epoch.data_ptr(), stream()), 'epoch')
+            for _ in range(reps):
+                L.call(fn, a, stream())
+        us = time_fn(run, iters=5, warm=2) / reps
+        print('rcab %s %dx%dx%d: %.2f us per launch, status %d' % (name, N, H, W, us, int(status.item())))
+        if 'RCAB_ABL_9' in os.environ.get('RUMPY_AMD_LIB', ''):
+            raw = tbuf.view(torch.int16).flatten()[:N * ((H + 5) // 6) * 64].cpu().numpy().view(np.uint64).reshape(-1, 16)[:, :10].astype(np.float64)
+            k = int((raw[0] > 0).sum())
+            rel = (raw[:, :k] - raw[:, :1]) * 0.01          # s_memrealtime: 100 MHz
+            print('   stamps (us from workgroup start, mean over workgroups):', ' '.join('%.2f' % v for v in rel.mean(0)))
+            print('   workgroup start spread %.2f us, end spread %.2f us' % ((raw[:, 0].max() - raw[:, 0].min()) * 0.01, (raw[:, k - 1].max() - raw[:, k - 1].min()) * 0.01))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'rcab':
+    rcab_bench()
