@@ -58,13 +58,28 @@ __device__ __forceinline__ void sweep_bases(unsigned (&off)[8][2], unsigned buff
 // exchange between lane g and g ^ 1 so that even-g lanes end up with 8 consecutive channels of tile X's pixel and odd-g lanes
 // with 8 channels of tile Y's pixel (conv_strip.hip)
 __device__ __forceinline__ void pair_up(const f32x4& tx, const f32x4& ty, int g, float (&v)[8]) {
+  // v_permlane16_swap_b32 (new in gfx950) swaps the odd 16-lane rows of its first operand with the even rows of its second:
+  // even-g lanes get (own X values, the X values of lane g+1), odd-g lanes (the Y values of lane g-1, own Y values) - the whole
+  // exchange in one VALU instruction per dword (the portable form, a select + ds_bpermute + two selects, was a third of the
+  // epilogues' instructions).  Checked on the GPU against lane ids; `g` is implied by the lane's row.
+  (void)g;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float snd = (g & 1) ? tx[j] : ty[j];
-    const float rcv = __shfl_xor(snd, 16);
-    v[j] = (g & 1) ? rcv : tx[j];
-    v[4 + j] = (g & 1) ? ty[j] : rcv;
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(tx[j]), __float_as_uint(ty[j]), false, false);
+    v[j] = __uint_as_float(r[0]);
+    v[4 + j] = __uint_as_float(r[1]);
   }
+}
+// ReLU-mask on PACKED bf16 pairs: keeps the halves of v whose mask half is > 0, i.e. sign bit clear and any other bit set (a NaN with
+// a clear sign bit counts as > 0; the mask operand of the product path is a stored post-ReLU activation).  (t + 0x7fff) sets bit 15 of
+// a half exactly when t != 0 and cannot carry into the next half.  7 integer operations per pair instead of unpack / compare /
+// select / repack per element.
+__device__ __forceinline__ unsigned relu_keep(unsigned m) {
+  const unsigned t = m & 0x7fff7fffu;
+  return ((((t + 0x7fff7fffu) & ~m) & 0x80008000u) >> 15) * 0xffffu;
+}
+__device__ __forceinline__ uint4 relu_mask_packed(uint4 v, uint4 m) {
+  return make_uint4(v.x & relu_keep(m.x), v.y & relu_keep(m.y), v.z & relu_keep(m.z), v.w & relu_keep(m.w));
 }
 __device__ __forceinline__ void unpack8(uint4 u, float (&m)[8]) {
   unpack4_bf16(make_uint2(u.x, u.y), *reinterpret_cast<float(*)[4]>(&m[0]));

@@ -310,12 +310,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2];
       float v[8];
       pair_up(tx, ty, g, v);
-      if (BWD) {
-        float m[8];
-        unpack8(M[k], m);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
-      } else {
+      if (!BWD) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
@@ -325,6 +320,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (moff[k] != 0xffffffffu) {
         const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (BWD) o = relu_mask_packed(o, M[k]);
         if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;

@@ -251,10 +251,10 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
       float v[8], m[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float send = (g & 1) ? tx[j] : ty[j];        // what the partner lane (g ^ 1) needs from me
-        const float recv = __shfl_xor(send, 16);
-        v[j] = (g & 1) ? recv : tx[j];                      // channels gpair .. gpair+3
-        v[4 + j] = (g & 1) ? ty[j] : recv;                  // channels gpair+4 .. gpair+7
+        // v_permlane16_swap_b32 (gfx950): even-g lanes get (own X, X of lane g+1), odd-g lanes (Y of lane g-1, own Y) - see block_common.hpp
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(tx[j]), __float_as_uint(ty[j]), false, false);
+        v[j] = __uint_as_float(r[0]);                       // channels gpair .. gpair+3
+        v[4 + j] = __uint_as_float(r[1]);                   // channels gpair+4 .. gpair+7
       }
       const bool in = poff[k] != 0xffffffffu;
       if (a.mask) {
