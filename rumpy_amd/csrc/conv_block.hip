@@ -97,17 +97,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       for (int c = 0; c < 3; ++c) acc[r][c] = b4;
     unsigned off[8][2];
     sweep_bases(off, 0u, 4 * rh, px, g);
-    block_sweep<4>(acc, F, lds, off);
-    // second filter: L2 hits that land under the epilogue
-    {
-      const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
-#pragma unroll
-      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
-    }
     auto post1 = [&](f32x4 t) -> f32x4 {
       if (a.relu1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], 0.f);
+        for (int j = 0; j < 4; ++j) t[j] = relu_f32(t[j]);
       }
       if (a.scale1 != 1.0f) {
 #pragma unroll
@@ -115,8 +108,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       }
       return t;
     };
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    auto t_pair = [&](int k) {          // k is a constant after unrolling
       const f32x4 tx = post1((k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2]);
       const f32x4 ty = post1((k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2]);
       float v[8];
@@ -131,7 +123,21 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
         if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;     // the strip's own rows only
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
+    };
+    // the four (row k, columns 0 | 1) pairs are final after group 11: their epilogues ride under the MFMAs of column tile 2
+    block_sweep_cm<4>(acc, F, lds, off, [&](int grp) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (grp == 12 + k) t_pair(k);
+    });
+    // second filter: L2 hits that land under the rest of the epilogue
+    {
+      const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
+#pragma unroll
+    for (int k = 4; k < 6; ++k) t_pair(k);
   }
   __syncthreads();
 

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v[j] = acc[r][j] + bj[j];
-              if (a.relu) v[j] = fmaxf(v[j], 0.f);
+              if (a.relu) v[j] = relu_f32(v[j]);
               v[j] *= a.scale;
             }
             if (a.mask) {

@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
     auto own = [&](f32x4 t) -> f32x4 {
       if (a.relu) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], 0.f);
+        for (int j = 0; j < 4; ++j) t[j] = relu_f32(t[j]);
       }
       if (a.scale != 1.0f) {
 #pragma unroll

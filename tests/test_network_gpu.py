@@ -350,9 +350,27 @@ def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, m
 
 
 def test_one_launch_rcab_is_deterministic_at_the_headline_shape():
-    """32 x 48 x 48: 256 strips, one per CU, every image's 8 strips exchange sums - two runs from the same state are bit-identical"""
+    """32 x 48 x 48: 256 strips, one per CU, every image's 8 strips exchange sums.  (a) 16 repeated forward + backward passes on frozen
+    weights give bit-identical outputs AND gradient buffers (this is the check that caught compiler-formed packed-fp32 adds dropping an
+    addend in a few workgroups per launch - csrc/Makefile); (b) two handlers trained from the same state follow bit-identical
+    trajectories."""
     kw = dict(scale=4, n_resgroups=2, n_resblocks=3, reduction=16)
     x, y = O.synthetic_batch(670, 32, lr_hw=48, scale=4)
+    h = _handler('rcan', lr=1e-3, **kw)
+    h.net.load_state_dict(O.seeded_state_dict(O.build_oracle('rcan', **kw), 826))
+    xd, yd = x.cuda(), y.cuda()
+    ref = None
+    for rep in range(16):
+        _, out = h.net.fused_l1_forward_backward(xd, yd)
+        torch.cuda.synchronize()
+        cur = (out.detach().clone(), h.net.flat_g.detach().clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(ref[0], cur[0]), rep
+            assert torch.equal(ref[1].view(torch.int32), cur[1].view(torch.int32)), rep
+    h.net.take_early_loss()
+    assert h.net.engine.exchange_status() == 0
     outs = []
     for _ in range(2):
         h = _handler('rcan', lr=1e-3, **kw)

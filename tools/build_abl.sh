@@ -7,7 +7,7 @@ src=$1; macro=$2; shift 2
 make -s -j6
 for v in "$@"; do
   d=../../build_abl/${macro}_$v; mkdir -p $d
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -D${macro}=$v -c $src -o $d/abl.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $( [ "$src" = conv_rcab.hip ] && echo -Xclang -target-feature -Xclang -packed-fp32-ops ) -D${macro}=$v -c $src -o $d/abl.o
   objs=$(ls *.o | grep -v "^${src%.hip}.o$")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/librumpy_amd.so $objs $d/abl.o
   rm $d/abl.o
