@@ -45,35 +45,6 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 
   }
 }
 
-// The same sweep with the groups ordered COLUMN TILE first (c, channel half, tap column): column tiles 0 and 1 are final after group 11,
-// so the epilogue of the paired tiles (row k, columns 0 | 1) can be issued in the shadow of the MFMAs of column tile 2 - a wave's VALU
-// instructions issue while its MFMAs execute, and the epilogues are instruction-issue-bound.  hook(grp) is placed in front
-// of group grp's MFMAs, inside the same scheduling region.
-template <int ROWS, typename Hook>
-__device__ __forceinline__ void block_sweep_cm(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2],
-                                               Hook&& hook) {
-  bf16x8 I[2][ROWS + 2];
-  auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
-    const int c = grp / 6, half = (grp % 6) / 3, kx = grp % 3;
-#pragma unroll
-    for (int r = 0; r < ROWS + 2; ++r)
-      dst[r] = *reinterpret_cast<const bf16x8*>(lds + off[(2 * r + kx) & 7][half] + (r * BCOLS + 16 * c + kx) * 128);
-  };
-  load_group(0, I[0]);
-#pragma unroll
-  for (int grp = 0; grp < 18; ++grp) {
-    if (grp + 1 < 18) load_group(grp + 1, I[(grp + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-    const int c = grp / 6, half = (grp % 6) / 3, kx = grp % 3;
-    hook(grp);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r)
-        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
-  }
-}
-
 // per-lane read bases of a phase: window row 0 = row `row0` of the image at byte `buffer` of the LDS allocation (folded in here so
 // that every read is one register + a 16-bit immediate)
 __device__ __forceinline__ void sweep_bases(unsigned (&off)[8][2], unsigned buffer, int row0, int px, int g) {

@@ -24,7 +24,9 @@
 // GEN = false: the ResBlock form (residual operand = block input, read from LDS).  GEN = true: the general form used for
 // RCABs - res_mode 1 (no residual) or 2 (residual operand res1 from HBM, prefetched under the second sweep) and the
 // per-(strip, row half) channel sums of scale2 * (convB(T) + b2) for the channel-attention pool.
-template <bool GEN>
+// FORM: 0 = post1 flags read at run time; 1 = forward form (ReLU, no scale1, no mask); 2 = data-gradient form (no ReLU, * scale1, mask):
+// the two forms the engine launches, without the per-value selects and branches of the generic epilogue.
+template <bool GEN, int FORM = 0>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
   unsigned char* const ldx = lds;
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
     moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
     M[k] = make_uint4(0, 0, 0, 0);
-    if (a.mask) M[k] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
+    if (FORM == 2 || (FORM == 0 && a.mask)) M[k] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
   }
   {
     f32x4 acc[4][3];
@@ -98,11 +100,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     unsigned off[8][2];
     sweep_bases(off, 0u, 4 * rh, px, g);
     auto post1 = [&](f32x4 t) -> f32x4 {
-      if (a.relu1) {
+      if (FORM == 1 || (FORM == 0 && a.relu1)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = relu_f32(t[j]);
       }
-      if (a.scale1 != 1.0f) {
+      if (FORM == 2 || (FORM == 0 && a.scale1 != 1.0f)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] *= a.scale1;
       }
@@ -119,25 +121,20 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       if (moff[k] != 0xffffffffu) {
         const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        if (a.mask) o = relu_mask_packed(o, M[k]);
+        if (FORM == 2 || (FORM == 0 && a.mask)) o = relu_mask_packed(o, M[k]);
         if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;     // the strip's own rows only
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
     };
-    // the four (row k, columns 0 | 1) pairs are final after group 11: their epilogues ride under the MFMAs of column tile 2
-    block_sweep_cm<4>(acc, F, lds, off, [&](int grp) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (grp == 12 + k) t_pair(k);
-    });
-    // second filter: L2 hits that land under the rest of the epilogue
+    block_sweep<4>(acc, F, lds, off);
+    // second filter: L2 hits that land under the epilogue
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
 #pragma unroll
-    for (int k = 4; k < 6; ++k) t_pair(k);
+    for (int k = 0; k < 6; ++k) t_pair(k);
   }
   __syncthreads();
 
@@ -278,8 +275,14 @@ extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
   if (p->res_mode < 0 || p->res_mode > 2 || (p->res_mode == 2 && !p->res1)) { rumpy_set_error("rumpy_conv_block: bad res_mode / res1"); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   rumpy_probe_pre(5, s);
-  if (p->res_mode == 0 && !p->pool) hipLaunchKernelGGL(conv_block_kernel<false>, dim3(d.N * d.sy_n), dim3(BTHREADS), 0, s, d);
-  else hipLaunchKernelGGL(conv_block_kernel<true>, dim3(d.N * d.sy_n), dim3(BTHREADS), 0, s, d);
+  const dim3 grid(d.N * d.sy_n);
+  if (p->res_mode == 0 && !p->pool) {
+    if (p->relu1 && p->scale1 == 1.0f && !p->mask) hipLaunchKernelGGL((conv_block_kernel<false, 1>), grid, dim3(BTHREADS), 0, s, d);
+    else if (!p->relu1 && p->mask) hipLaunchKernelGGL((conv_block_kernel<false, 2>), grid, dim3(BTHREADS), 0, s, d);
+    else hipLaunchKernelGGL((conv_block_kernel<false, 0>), grid, dim3(BTHREADS), 0, s, d);
+  } else {
+    hipLaunchKernelGGL((conv_block_kernel<true, 0>), grid, dim3(BTHREADS), 0, s, d);
+  }
   rumpy_probe_post(5, s);
   return rumpy_check_launch("rumpy_conv_block");
 }
