@@ -234,6 +234,10 @@ class HipSRNet(nn.Module):
             self._loss_host = torch.empty(1, dtype=torch.float32).pin_memory()
             self._loss_event = torch.cuda.Event()
         self._loss_host.copy_(loss, non_blocking=True)
+        if plan.rcab_status is not None:          # strip-exchange watchdog of the one-launch RCAB kernels, read back with the loss
+            if getattr(self, '_status_host', None) is None:
+                self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_host.copy_(plan.rcab_status, non_blocking=True)
         self._loss_event.record()
         self.early_loss = True
         self.engine.backward(plan, 1.0 / out.numel())
@@ -245,6 +249,10 @@ class HipSRNet(nn.Module):
             return None
         self.early_loss = False
         self._loss_event.synchronize()
+        st = getattr(self, '_status_host', None)
+        if st is not None and int(st[0]) != 0:
+            raise RuntimeError('rumpy_amd: a strip exchange of the RCAB kernels timed out (code 0x%x): the results of this and the previous '
+                               'step are invalid (GPU shared with another job? set RUMPY_NO_RCAB=1 to use the separate launches)' % int(st[0]))
         return self._loss_host.numpy().copy().reshape(())
 
     def l1_eval(self, x, y, metadata=None):
