@@ -394,3 +394,20 @@ def test_qrcan_default_style_scale_qpi_matches_the_reference_known_answers(golde
     assert tuple(ch.shape) == (5, 64, 1, 1) and np.array_equal(ch.numpy(), g['kat_64_clamped'])
     with pytest.raises(RuntimeError):      # q-layers need the 'standard' style
         define_model('qrcan', device='cpu', model_save_dir=tempfile.mkdtemp(), eval_mode=True, n_resgroups=1, n_resblocks=1, include_q_layer=True)
+
+
+def test_packed_relu_mask_bit_trick_equals_the_float_comparison():
+    """block_common.hpp::relu_keep keeps a bf16 half iff its value is > 0, computed on packed pairs with integer operations: checked here
+    for all 65536 bit patterns in both halves against the float comparison (NaNs with a clear sign bit count as > 0 - documented)."""
+    m = np.arange(65536, dtype=np.uint32)
+    pair = (m << 16) | m[::-1]
+    t = pair & 0x7fff7fff
+    keep = ((((t + 0x7fff7fff) & 0xffffffff) & ~pair & 0x80008000) >> 15) * 0xffff & 0xffffffff
+    hi = (m << 16).astype(np.uint32).view(np.float32)
+    lo = (m[::-1] << 16).astype(np.uint32).view(np.float32)
+    with np.errstate(invalid='ignore'):
+        want = np.where(hi > 0, 0xffff0000, 0).astype(np.uint32) | np.where(lo > 0, 0xffff, 0).astype(np.uint32)
+    nan = np.isnan(hi) | np.isnan(lo)
+    assert np.array_equal(keep[~nan], want[~nan])
+    pos_nan_hi = np.isnan(hi) & ((m & 0x8000) == 0)
+    assert np.all((keep[pos_nan_hi] & 0xffff0000) == 0xffff0000)

@@ -312,6 +312,7 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
     ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16), 20),           # ragged last strip, groups (skip gradient joins a block)
     ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=1, reduction=16), (60, 24)),     # 10 strips per image: two exchange rounds
     ('rcan', dict(scale=4, n_resgroups=1, n_resblocks=3, reduction=16), 48),           # the headline patch shape
+    ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=1, reduction=16), (155, 37)),    # 26 strips per image (4 exchange rounds, ragged last strip), odd width
     ('qrcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16, style='standard', include_q_layer=True, metadata=['a', 'b', 'c']), 16),
 ])
 def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, monkeypatch):
