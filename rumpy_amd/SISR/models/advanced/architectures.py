@@ -87,7 +87,7 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         net = ctx.net
-        net.engine.backward(ctx.plan, 1.0, gout=gout.contiguous().float())
+        net.engine.backward(ctx.plan, 1.0, gout=gout.contiguous().float(), on_ready=getattr(net, 'grad_ready_hook', None))
         net.attach_grads()
         return (None, None, None, None) + tuple(None for _ in net.param_list)
 
@@ -240,7 +240,7 @@ class HipSRNet(nn.Module):
             self._status_host.copy_(plan.rcab_status, non_blocking=True)
         self._loss_event.record()
         self.early_loss = True
-        self.engine.backward(plan, 1.0 / out.numel())
+        self.engine.backward(plan, 1.0 / out.numel(), on_ready=getattr(self, 'grad_ready_hook', None))
         return loss, out
 
     def take_early_loss(self):

@@ -521,6 +521,37 @@ class SREngine:
                 dev = self._to_device_bytes(arr)
                 plan.keep.append(dev)
                 plan.job_dev[mt] = (dev, len(jobs[mt]))
+        # Two-phase form for data-parallel runs (backward(on_ready=...)): the layers in the upper part of the flat gradient buffer
+        # (group A: gradient pointer >= split pointer; about half of the jobs) are finished first, so that their all-reduce can run on
+        # the side stream while the jobs of group B are computed.  Same jobs, same slabs, same reduction order: bitwise the same gradients.
+        plan.split = None
+        per_layer = {}
+        for it in items:
+            if it.mt == 4:
+                per_layer[it.gw] = per_layer.get(it.gw, 0) + it.njobs
+        if len(per_layer) >= 2:
+            total4, acc4, split_ptr = sum(per_layer.values()), 0, None
+            for ptr in sorted(per_layer, reverse=True):
+                acc4 += per_layer[ptr]
+                split_ptr = ptr
+                if 2 * acc4 >= total4:
+                    break
+            item_of_slab = {}
+            for idx, it in enumerate(items):
+                for k in range(it.njobs):
+                    item_of_slab[it.slab + 4 * k * it.slab_stride] = idx
+            in_a = lambda idx: items[idx].gw >= split_ptr
+            ja = [jb for jb in jobs[4] if in_a(item_of_slab[jb.slab])]
+            jb_ = [jb for jb in jobs[4] if not in_a(item_of_slab[jb.slab])]
+            if ja and jb_:
+                dev_a, dev_b = self._to_device_bytes((L.WgradJob * len(ja))(*ja)), self._to_device_bytes((L.WgradJob * len(jb_))(*jb_))
+                idx_a = [i for i in range(len(items)) if in_a(i)]          # the tail conv (mt 1) has the highest pointer of the EDSR / RCAN layouts
+                idx_b = [i for i in range(len(items)) if not in_a(i)]
+                mk = lambda n: torch.empty(max(1, n) * C.sizeof(L.ReduceItem), dtype=torch.uint8, device=self.device)
+                plan.split = dict(ptr=split_ptr, jobs_a=(dev_a, len(ja)), jobs_b=(dev_b, len(jb_)), idx_a=idx_a,
+                                  idx_a_notail=[i for i in idx_a if items[i].mt != 1], idx_b=idx_b,
+                                  red_a=mk(len(idx_a)), red_a_notail=mk(len(idx_a)), red_b=mk(len(idx_b)))
+                plan.keep += [dev_a, dev_b, plan.split['red_a'], plan.split['red_a_notail'], plan.split['red_b']]
         plan.grad_scale = None
 
     def _set_grad_scale(self, plan, gs):
@@ -534,6 +565,12 @@ class SREngine:
         plan.reduce_dev.copy_(torch.from_numpy(raw), non_blocking=False)
         sub = (L.ReduceItem * max(1, len(plan.reduce_keep)))(*[plan.reduce_host[i] for i in plan.reduce_keep])
         plan.reduce_dev_notail.copy_(torch.from_numpy(np.frombuffer(bytes(sub), dtype=np.uint8).copy()), non_blocking=False)
+        if plan.split is not None:
+            for key, idxs in (('red_a', plan.split['idx_a']), ('red_a_notail', plan.split['idx_a_notail']), ('red_b', plan.split['idx_b'])):
+                if idxs:
+                    tab = (L.ReduceItem * len(idxs))(*[plan.reduce_host[i] for i in idxs])
+                    raw_t = torch.from_numpy(np.frombuffer(bytes(tab), dtype=np.uint8).copy())
+                    plan.split[key][:raw_t.numel()].copy_(raw_t, non_blocking=False)
         for a in plan.scaled:
             a.scale = gs
         if plan.ca_param_items:
@@ -633,9 +670,11 @@ class SREngine:
         L.call('rumpy_tail_fwd', plan.tail_plain, stream)
         return out, None, plan
 
-    def backward(self, plan, grad_scale, gout=None):
+    def backward(self, plan, grad_scale, gout=None, on_ready=None):
         """Run the backward pass of the last training forward of `plan`.  gout: optional upstream gradient
-        [N,C,sH,sW] fp32 (replaces the fused sign gradient)."""
+        [N,C,sH,sW] fp32 (replaces the fused sign gradient).  on_ready(ptr): called on the host once every launch that writes a
+        gradient at a device address >= ptr has been queued (data-parallel runs start the all-reduce of that part there and overlap it
+        with the remaining weight-gradient launches)."""
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if gout is not None:
             h, w = plan.HR
@@ -646,6 +685,23 @@ class SREngine:
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
         self._q_param_grads(plan, stream)
+        if on_ready is not None and plan.split is not None:
+            sp = plan.split
+            L.check(self.lib.rumpy_wgrad_grouped(_ptr(sp['jobs_a'][0]), sp['jobs_a'][1], 4, 0, stream), 'rumpy_wgrad_grouped')
+            if 1 in plan.job_dev and not tail_done:
+                dev, n = plan.job_dev[1]
+                L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 1, 1 if plan.HR[1] % 2 else 0, stream), 'rumpy_wgrad_grouped')
+            idx = sp['idx_a_notail'] if tail_done else sp['idx_a']
+            if idx:
+                L.check(self.lib.rumpy_wgrad_reduce(_ptr(sp['red_a_notail'] if tail_done else sp['red_a']), len(idx), stream), 'rumpy_wgrad_reduce')
+            if tail_done:
+                tl = self.spec.tail
+                L.check(self.lib.rumpy_tail_wgrad_reduce(_ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, float(grad_scale), _ptr(tl.gw),
+                                                         _ptr(tl.gb), stream), 'rumpy_tail_wgrad_reduce')
+            on_ready(sp['ptr'])
+            L.check(self.lib.rumpy_wgrad_grouped(_ptr(sp['jobs_b'][0]), sp['jobs_b'][1], 4, 0, stream), 'rumpy_wgrad_grouped')
+            L.check(self.lib.rumpy_wgrad_reduce(_ptr(sp['red_b']), len(sp['idx_b']), stream), 'rumpy_wgrad_reduce')
+            return
         for mt in (4, 1):
             if mt in plan.job_dev and not (mt == 1 and tail_done):
                 dev, n = plan.job_dev[mt]

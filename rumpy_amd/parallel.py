@@ -27,6 +27,8 @@ class GradientAverager:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.buckets = bucket_bounds(self.flat_g.numel(), bucket_elems)
+        self.bucket_elems = bucket_elems
+        self.early_lo = None                 # start of the part whose all-reduce was launched early by begin()
         self.side = torch.cuda.Stream(self.flat_g.device) if self.flat_g.is_cuda else None
         self.pending = []
 
@@ -43,6 +45,33 @@ class GradientAverager:
         else:
             self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def begin(self, ptr):
+        """Engine hook (SREngine.backward(on_ready=...)): every gradient at device address >= ptr is final on the current stream ->
+        start the all-reduce of that upper part of the flat buffer on the side stream; the launches that follow on the main stream (the
+        remaining weight gradients) run next to it.  average() then covers the lower part."""
+        if self.world_size == 1 or self.early_lo is not None:
+            return
+        lo = (int(ptr) - self.flat_g.data_ptr()) // self.flat_g.element_size()
+        if lo <= 0 or lo >= self.flat_g.numel():
+            return
+        self.early_lo = lo
+        self._launch_range(lo, self.flat_g.numel())
+
+    def _launch_range(self, lo, hi):
+        step = max(1, self.bucket_elems)
+        spans = []
+        while hi > lo:                                   # LAST parameters first, like bucket_bounds
+            spans.append((max(lo, hi - step), hi))
+            hi = spans[-1][0]
+        for a, b in spans:
+            view = self.flat_g[a:b]
+            if self.side is not None:
+                self.side.wait_stream(torch.cuda.current_stream(self.flat_g.device))
+                with torch.cuda.stream(self.side):
+                    self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            else:
+                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def finish(self):
         for w in self.pending:
             w.wait()
@@ -54,8 +83,12 @@ class GradientAverager:
         """Sum over ranks of every bucket; the 1/world factor is applied here so the optimizer sees the mean."""
         if self.world_size == 1:
             return
-        for i in range(len(self.buckets)):
-            self.launch_bucket(i)
+        if self.early_lo is not None:        # the upper part is already in flight (begin()): only the rest is launched here
+            self._launch_range(0, self.early_lo)
+            self.early_lo = None
+        else:
+            for i in range(len(self.buckets)):
+                self.launch_bucket(i)
         self.finish()
         self.flat_g.mul_(1.0 / self.world_size)
 

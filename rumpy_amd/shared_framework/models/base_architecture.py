@@ -64,6 +64,9 @@ class BaseModel(nn.Module):
         the flat buffer are averaged over RCCL (rumpy_amd.parallel.GradientAverager) before the optimizer step."""
         from rumpy_amd.parallel import GradientAverager
         self.data_parallel = GradientAverager(self.net)
+        hip = self._hip_net()
+        if hip is not None and self.data_parallel.world_size > 1:
+            hip.grad_ready_hook = self.data_parallel.begin      # all-reduce of the upper half starts under the remaining weight gradients
         if self.data_parallel.world_size > 1:
             print('Model replicated over %d GPU processes (RCCL gradient all-reduce)' % self.data_parallel.world_size)
 

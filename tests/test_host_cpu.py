@@ -211,6 +211,17 @@ avg = GradientAverager(flat_grad=g, bucket_elems=1000)
 assert avg.world_size == 2 and len(avg.buckets) == 11 and avg.buckets[0] == (9007, 10007) and avg.buckets[-1] == (0, 7)
 avg.average()
 assert torch.equal(g, torch.arange(10007, dtype=torch.float32) * 1.5), rank
+# two-phase form (SREngine.backward(on_ready=...)): the upper part is launched early by begin(ptr), average() covers the rest
+g2 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
+avg2 = GradientAverager(flat_grad=g2, bucket_elems=1000)
+avg2.begin(g2.data_ptr() + 4 * 6001)
+assert avg2.early_lo == 6001 and len(avg2.pending) == 5          # [9007,10007) ... [6001,7007): LAST parameters first
+g2[:6001] += 0.0                                                  # "remaining weight gradients" written while the upper part is in flight
+avg2.average()
+assert avg2.early_lo is None and not avg2.pending
+assert torch.equal(g2, torch.arange(10007, dtype=torch.float32) * 1.5), rank
+avg2.begin(g2.data_ptr())                                         # boundary at the start of the buffer: nothing to split
+assert avg2.early_lo is None
 class Net: pass
 n = Net(); n.flat_p = torch.full((5,), float(rank)); n._packed_version = 1
 broadcast_parameters(n, src=0)

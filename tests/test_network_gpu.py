@@ -383,3 +383,36 @@ def test_one_launch_rcab_is_deterministic_at_the_headline_shape():
         assert h.net.engine.exchange_status() == 0
         outs.append((losses, out, h.net.flat_p.detach().cpu().clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize('name,kw', [('edsr', dict(scale=4, num_blocks=4, res_scale=0.1)),
+                                     ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16))])
+def test_two_phase_weight_gradient_is_bitwise_the_single_launch_one(name, kw):
+    """data-parallel form of the backward pass (SREngine.backward(on_ready=...)): the layers in the upper part of the flat gradient
+    buffer are finished first and the hook receives the boundary pointer; same jobs, slabs and reduction order -> identical bits.
+    Also checks what the hook promises: at call time every launch writing at or above the boundary has been queued."""
+    h, _ = _pair(name, 511, sched=False, **kw)
+    sc = kw['scale']
+    x, y = O.synthetic_batch(680, 4, lr_hw=24, scale=sc)
+    xd, yd = x.cuda(), y.cuda()
+    net = h.net
+    net.fused_l1_forward_backward(xd, yd)
+    torch.cuda.synchronize()
+    ref = net.flat_g.detach().clone()
+    seen = {}
+
+    def hook(ptr):
+        lo = (ptr - net.flat_g.data_ptr()) // 4
+        torch.cuda.synchronize()                     # everything queued so far has run: the upper part must be final already
+        seen['lo'] = lo
+        seen['upper'] = net.flat_g[lo:].detach().clone()
+    net.flat_g.zero_()
+    net.grad_ready_hook = hook
+    net.fused_l1_forward_backward(xd, yd)
+    torch.cuda.synchronize()
+    net.grad_ready_hook = None
+    assert 0 < seen['lo'] < net.flat_g.numel()
+    assert 0.2 < seen['lo'] / net.flat_g.numel() < 0.8
+    conv_upper = torch.equal(seen['upper'].view(torch.int32), ref[seen['lo']:].view(torch.int32))
+    assert conv_upper, 'gradients above the boundary were not final when the hook ran'
+    assert torch.equal(net.flat_g.view(torch.int32), ref.view(torch.int32))
