@@ -54,11 +54,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hook (1-GPU boxes): RUMPY_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo, so that the N > 1 code path (broadcast,
+    # two-phase weight gradients, early all-reduce on the side stream, max-over-ranks timing) can run where RCCL cannot
+    one_device = os.environ.get('RUMPY_BENCH_ONE_DEVICE') == '1'
+    if one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if one_device:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     elif args.gpus != 1:
         raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
@@ -132,6 +140,11 @@ def main():
 
     # ---- dominant-kernel timing with HIP events (same process, same steps, right after the timed region) ----
     roofline = None
+    if rank != 0:
+        # the probe steps contain the gradient all-reduce: EVERY rank has to run them (rank 0 alone would wait for its peers forever)
+        for i in range(args.probe_steps):
+            step(i)
+        torch.cuda.synchronize(dev)
     if rank == 0:
         import ctypes
         lib = L.lib()

@@ -416,3 +416,25 @@ def test_two_phase_weight_gradient_is_bitwise_the_single_launch_one(name, kw):
     conv_upper = torch.equal(seen['upper'].view(torch.int32), ref[seen['lo']:].view(torch.int32))
     assert conv_upper, 'gradients above the boundary were not final when the hook ran'
     assert torch.equal(net.flat_g.view(torch.int32), ref.view(torch.int32))
+
+
+def test_bench_runs_with_two_ranks_sharing_the_gpu():
+    """The N > 1 path of bench.py end to end on a 1-GPU box: two processes on cuda:0 over gloo (RUMPY_BENCH_ONE_DEVICE=1; RCCL refuses
+    two ranks on one device).  Covers broadcast of the replicas, the two-phase weight gradient with the early all-reduce on the side
+    stream, max-over-ranks timing - and that every rank runs the probe steps (rank 0 alone once waited for its peers forever)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29571', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
+           '--no-cpu-baseline']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['roofline'] is not None and d['roofline']['launches_timed'] > 0
