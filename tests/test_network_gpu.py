@@ -438,3 +438,24 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0 and d['scaling'] == 'weak'
     assert d['roofline'] is not None and d['roofline']['launches_timed'] > 0
+
+
+@pytest.mark.parametrize('N', [67, 160])
+def test_one_launch_rcab_with_more_strips_than_cus(N, monkeypatch):
+    """N * 8 workgroups per launch >> 256 CUs (536 / 1280), images straddling the residency boundary: workgroup ids are dispatched in
+    order, so the oldest unfinished image always has all of its strips on the chip - no exchange may time out, and the result equals
+    the separate-launch path."""
+    kw = dict(scale=2, n_resgroups=1, n_resblocks=3, reduction=16)
+    x, y = O.synthetic_batch(671, N, lr_hw=48, scale=2)
+    res = {}
+    for no in ('0', '1'):
+        monkeypatch.setenv('RUMPY_NO_RCAB', no)
+        h = _handler('rcan', lr=1e-3, **kw)
+        h.net.load_state_dict(O.seeded_state_dict(O.build_oracle('rcan', **kw), 826))
+        loss, _ = h.net.fused_l1_forward_backward(x.cuda(), y.cuda())
+        torch.cuda.synchronize()
+        h.net.take_early_loss()
+        res[no] = (float(loss), h.net.flat_g.detach().clone(), h.net.engine.exchange_status())
+    assert res['0'][2] == 0
+    assert abs(res['0'][0] - res['1'][0]) < 1e-4 * res['1'][0]
+    assert float((res['0'][1] - res['1'][1]).norm() / res['1'][1].norm()) < 2e-2
