@@ -122,6 +122,8 @@ typedef struct {
   const void* res1;    /* [N,H,W,64] bf16, res_mode 2 */
   float* pool;         /* NULL, or per-(strip, row half) channel sums of scale2*(convB(T)+b2): [N][2*ceil(H/6)][64] fp32, the
                           partial sums rumpy_ca_mlp_fwd reduces (same layout as rumpy_conv3x3's `pool`) */
+  void* maskbits;      /* NULL, or [N,H,W,8] bytes = the ReLU mask of T, one bit per channel (ResBlock form only): WRITTEN by a forward
+                          launch (relu1 = 1), READ instead of `mask` by a data-gradient launch (relu1 = 0) - 1/16 of the mask traffic */
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
 
@@ -147,6 +149,7 @@ typedef struct {
   const float* qgate; float* dz; float* dzq;     /* [N,64] each */
   void* xchg; int64_t xchg_bytes; const void* epoch; void* status;
   uint32_t seq; int32_t pad_;
+  void* maskbits;      /* NULL, or [N,H,W,8] bytes: ReLU mask of t1, written by rumpy_rcab_fwd and read (instead of `mask`) by rumpy_rcab_bwd */
 } rumpy_rcab_args;
 int rumpy_rcab_fwd(const rumpy_rcab_args* a, void* stream);
 int rumpy_rcab_bwd(const rumpy_rcab_args* a, void* stream);

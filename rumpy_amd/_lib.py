@@ -62,7 +62,7 @@ class RcabArgs(_S):
                 ('ca_w1', c_void_p), ('ca_b1', c_void_p), ('ca_w2', c_void_p), ('ca_b2', c_void_p),
                 ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('qgate', c_void_p), ('dz', c_void_p), ('dzq', c_void_p),
                 ('xchg', c_void_p), ('xchg_bytes', c_int64), ('epoch', c_void_p), ('status', c_void_p),
-                ('seq', C.c_uint32), ('pad_', c_int32)]
+                ('seq', C.c_uint32), ('pad_', c_int32), ('maskbits', c_void_p)]
 
 
 class EncBnArgs(_S):
@@ -177,7 +177,7 @@ class BlockArgs(_S):
     _fields_ = [('x', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mask', c_void_p),
                 ('res2', c_void_p), ('t', c_void_p), ('out', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32),
                 ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float), ('res_mode', c_int32), ('res1', c_void_p),
-                ('pool', c_void_p)]
+                ('pool', c_void_p), ('maskbits', c_void_p)]
 
 
 class BlockChainArgs(_S):

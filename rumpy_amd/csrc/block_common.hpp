@@ -16,6 +16,7 @@ struct BlockDev {
   const uint16_t* mask; const uint16_t* res2; uint16_t* t; uint16_t* out;
   int N, H, W, sy_n, relu1; float scale1, scale2;
   int res_mode; const uint16_t* res1; float* pool;
+  unsigned char* mbits;      // ReLU mask as one byte per 8 channels: written by the forward form, read by the data-gradient form (or NULL)
 };
 
 __device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p * 128 + ((chunk ^ (p & 7)) << 4)); }
@@ -93,6 +94,17 @@ __device__ __forceinline__ unsigned relu_keep(unsigned m) {
 }
 __device__ __forceinline__ uint4 relu_mask_packed(uint4 v, uint4 m) {
   return make_uint4(v.x & relu_keep(m.x), v.y & relu_keep(m.y), v.z & relu_keep(m.z), v.w & relu_keep(m.w));
+}
+// The same mask as ONE BYTE per 8 channels: the forward launch stores which halves of its packed post-ReLU vector are non-zero
+// (ReLU leaves +x or +0), the data-gradient launch expands bit j to the keep mask of half j.  The mask operand of a data-gradient
+// launch shrinks from a full bf16 tensor (12.6 MB per launch with the halo rows) to 1/16 of it.
+__device__ __forceinline__ unsigned relu_bits(uint4 o) {
+  auto two = [](unsigned w) { return ((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u); };
+  return two(o.x) | (two(o.y) << 2) | (two(o.z) << 4) | (two(o.w) << 6);
+}
+__device__ __forceinline__ uint4 relu_mask_bits(uint4 v, unsigned b) {
+  auto keep = [](unsigned b2) { return ((b2 & 1u) * 0xffffu) | (((b2 >> 1) & 1u) * 0xffff0000u); };
+  return make_uint4(v.x & keep(b), v.y & keep(b >> 2), v.z & keep(b >> 4), v.w & keep(b >> 6));
 }
 __device__ __forceinline__ void unpack8(uint4 u, float (&m)[8]) {
   unpack4_bf16(make_uint2(u.x, u.y), *reinterpret_cast<float(*)[4]>(&m[0]));

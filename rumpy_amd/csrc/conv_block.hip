@@ -24,7 +24,8 @@
 // GEN = false: the ResBlock form (residual operand = block input, read from LDS).  GEN = true: the general form used for
 // RCABs - res_mode 1 (no residual) or 2 (residual operand res1 from HBM, prefetched under the second sweep) and the
 // per-(strip, row half) channel sums of scale2 * (convB(T) + b2) for the channel-attention pool.
-// FORM: 0 = post1 flags read at run time; 1 = forward form (ReLU, no scale1, no mask); 2 = data-gradient form (no ReLU, * scale1, mask):
+// FORM: 0 = post1 flags read at run time; 1 = forward form (ReLU, no scale1, no mask; stores the mask bytes if asked to); 2 = data-gradient
+// form (no ReLU, * scale1, mask = a bf16 activation); 3 = data-gradient form with the mask as bytes (block_common.hpp::relu_bits):
 // the two forms the engine launches, without the per-value selects and branches of the generic epilogue.
 template <bool GEN, int FORM = 0>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
@@ -79,15 +80,19 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
   // tile pairs: k < 4: X = (row k, col tile 0), Y = (row k, col tile 1); k = 4: X = (0, 2), Y = (1, 2); k = 5: X = (2, 2), Y = (3, 2)
   unsigned moff[6];
-  uint4 M[6];
+  uint4 M[(FORM == 1 || FORM == 3) ? 1 : 6];
+  unsigned MB[FORM == 3 ? 6 : 1];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
     const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
     const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
     moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
-    M[k] = make_uint4(0, 0, 0, 0);
-    if (FORM == 2 || (FORM == 0 && a.mask)) M[k] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
+    if (FORM == 0 || FORM == 2) {
+      M[(FORM == 1 || FORM == 3) ? 0 : k] = make_uint4(0, 0, 0, 0);
+      if (FORM == 2 || a.mask) M[(FORM == 1 || FORM == 3) ? 0 : k] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
+    }
+    if (FORM == 3) MB[FORM == 3 ? k : 0] = a.mbits[(in ? moff[k] : 0u) >> 3];
   }
   {
     f32x4 acc[4][3];
@@ -104,7 +109,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = relu_f32(t[j]);
       }
-      if (FORM == 2 || (FORM == 0 && a.scale1 != 1.0f)) {
+      if (FORM == 2 || FORM == 3 || (FORM == 0 && a.scale1 != 1.0f)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] *= a.scale1;
       }
@@ -121,8 +126,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       if (moff[k] != 0xffffffffu) {
         const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        if (FORM == 2 || (FORM == 0 && a.mask)) o = relu_mask_packed(o, M[k]);
+        if (FORM == 2 || (FORM == 0 && a.mask)) o = relu_mask_packed(o, M[(FORM == 1 || FORM == 3) ? 0 : k]);
+        if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
         if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;     // the strip's own rows only
+        if (FORM == 1 && a.mbits && j >= 1 && j <= BSH) a.mbits[moff[k] >> 3] = (unsigned char)relu_bits(o);
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
     };
@@ -271,13 +278,16 @@ extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
   d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
   d.mask = (const uint16_t*)p->mask; d.res2 = (const uint16_t*)p->res2; d.t = (uint16_t*)p->t; d.out = (uint16_t*)p->out;
   d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = (p->H + BSH - 1) / BSH; d.relu1 = p->relu1; d.scale1 = p->scale1; d.scale2 = p->scale2;
-  d.res_mode = p->res_mode; d.res1 = (const uint16_t*)p->res1; d.pool = p->pool;
+  d.res_mode = p->res_mode; d.res1 = (const uint16_t*)p->res1; d.pool = p->pool; d.mbits = (unsigned char*)p->maskbits;
+  if (p->maskbits && !(p->res_mode == 0 && !p->pool && ((p->relu1 && p->scale1 == 1.0f && !p->mask) || !p->relu1))) {
+    rumpy_set_error("rumpy_conv_block: maskbits goes with the ResBlock forward form (written) or a data-gradient form (read)"); return RUMPY_E_ARG; }
   if (p->res_mode < 0 || p->res_mode > 2 || (p->res_mode == 2 && !p->res1)) { rumpy_set_error("rumpy_conv_block: bad res_mode / res1"); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   rumpy_probe_pre(5, s);
   const dim3 grid(d.N * d.sy_n);
   if (p->res_mode == 0 && !p->pool) {
     if (p->relu1 && p->scale1 == 1.0f && !p->mask) hipLaunchKernelGGL((conv_block_kernel<false, 1>), grid, dim3(BTHREADS), 0, s, d);
+    else if (!p->relu1 && p->maskbits) hipLaunchKernelGGL((conv_block_kernel<false, 3>), grid, dim3(BTHREADS), 0, s, d);
     else if (!p->relu1 && p->mask) hipLaunchKernelGGL((conv_block_kernel<false, 2>), grid, dim3(BTHREADS), 0, s, d);
     else hipLaunchKernelGGL((conv_block_kernel<false, 0>), grid, dim3(BTHREADS), 0, s, d);
   } else {

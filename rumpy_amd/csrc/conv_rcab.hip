@@ -35,6 +35,7 @@ struct RcabDev {
   const float* cw1; const float* cb1; const float* cw2; const float* cb2; int cr; float inv_hw;
   float* mean; float* hidden; float* gate; const float* qgate; float* dz; float* dzq;
   unsigned long long* xchg; unsigned xchg_bytes; const unsigned* epoch; unsigned seq; unsigned* status;
+  unsigned char* mbits;      // ReLU mask of t1 as one byte per 8 channels (block_common.hpp::relu_bits): forward writes, backward reads
 };
 
 __device__ __forceinline__ float wave_sum(float t) {
@@ -75,7 +76,8 @@ __device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int 
   return total;
 }
 
-template <bool BWD>
+// MB (backward only): the ReLU mask comes as bytes (written by the forward launch) instead of the bf16 activation
+template <bool BWD, bool MB = false>
 __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
   __shared__ float sx[8 * 64];
@@ -277,15 +279,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
   unsigned moff[6];
-  uint4 M[6];
+  uint4 M[(BWD && !MB) ? 6 : 1];
+  unsigned MBY[(BWD && MB) ? 6 : 1];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
     const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
     const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
     moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
-    M[k] = make_uint4(0, 0, 0, 0);
-    if (BWD) M[k] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
+    if (BWD && !MB) M[(BWD && !MB) ? k : 0] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
+    if (BWD && MB) MBY[(BWD && MB) ? k : 0] = a.mbits[(in ? moff[k] : 0u) >> 3];
   }
   {
     f32x4 acc[4][3];
@@ -320,8 +323,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (moff[k] != 0xffffffffu) {
         const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        if (BWD) o = relu_mask_packed(o, M[k]);
+        if (BWD && !MB) o = relu_mask_packed(o, M[(BWD && !MB) ? k : 0]);
+        if (BWD && MB) o = relu_mask_bits(o, MBY[(BWD && MB) ? k : 0]);
         if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;
+        if (!BWD && a.mbits && j >= 1 && j <= BSH) a.mbits[moff[k] >> 3] = (unsigned char)relu_bits(o);
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
     }
@@ -520,7 +525,7 @@ static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const c
   if (!p || !p->x || !p->w1 || !p->w2 || !p->out || !p->ca_w1 || !p->ca_b1 || !p->ca_w2 || !p->ca_b2 || !p->hidden || !p->gate ||
       !p->xchg || !p->epoch || !p->status) { rumpy_set_error("%s: null pointer", what); return RUMPY_E_ARG; }
   if (!bwd && (!p->b1 || !p->b2 || !p->mean)) { rumpy_set_error("%s: forward needs b1, b2, mean", what); return RUMPY_E_ARG; }
-  if (bwd && (!p->t2_in || !p->mask || !p->t2 || !p->dz)) { rumpy_set_error("%s: backward needs t2_in, mask, t2 (d_t2 out), dz", what); return RUMPY_E_ARG; }
+  if (bwd && (!p->t2_in || (!p->mask && !p->maskbits) || !p->t2 || !p->dz)) { rumpy_set_error("%s: backward needs t2_in, mask, t2 (d_t2 out), dz", what); return RUMPY_E_ARG; }
   if (bwd && p->dzq && !p->qgate) { rumpy_set_error("%s: dzq without qgate", what); return RUMPY_E_ARG; }
   const int sy_n = (p->H + BSH - 1) / BSH;
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW || p->cr <= 0 || p->cr > RC_MAXR || sy_n > rumpy_device_cus() || p->seq >= 4096u) {
@@ -533,11 +538,12 @@ static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const c
   d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;
   d.cw1 = p->ca_w1; d.cb1 = p->ca_b1; d.cw2 = p->ca_w2; d.cb2 = p->ca_b2; d.cr = p->cr; d.inv_hw = 1.0f / ((float)p->H * (float)p->W);
   d.mean = p->mean; d.hidden = p->hidden; d.gate = p->gate; d.qgate = p->qgate; d.dz = p->dz; d.dzq = p->dzq;
-  d.xchg = (unsigned long long*)p->xchg; d.xchg_bytes = (unsigned)need; d.epoch = (const unsigned*)p->epoch; d.seq = p->seq; d.status = (unsigned*)p->status;
+  d.xchg = (unsigned long long*)p->xchg; d.xchg_bytes = (unsigned)need; d.epoch = (const unsigned*)p->epoch; d.seq = p->seq; d.status = (unsigned*)p->status; d.mbits = (unsigned char*)p->maskbits;
   hipStream_t s = (hipStream_t)stream;
   rumpy_probe_pre(5, s);
-  if (bwd) hipLaunchKernelGGL(rcab_kernel<true>, dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
-  else hipLaunchKernelGGL(rcab_kernel<false>, dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
+  if (bwd && p->maskbits) hipLaunchKernelGGL((rcab_kernel<true, true>), dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
+  else if (bwd) hipLaunchKernelGGL((rcab_kernel<true, false>), dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
+  else hipLaunchKernelGGL((rcab_kernel<false, false>), dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
   rumpy_probe_post(5, s);
   return rumpy_check_launch(what);
 }

@@ -111,6 +111,7 @@ class SREngine:
         self.wgrad_pixels_per_job = wgrad_pixels_per_job
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
+        self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
         self.feats = spec.head.cout
         if self.feats != 64:
             raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 (got %d); other widths are not '
@@ -225,21 +226,24 @@ class SREngine:
                     fused = self.use_block_kernel and W <= 48
                     t1 = act() if (train or not fused) else None
                     y = act()
+                    # the backward launch needs t1 only as a ReLU mask: the forward launch also leaves it as bytes (1/16 of the traffic)
+                    mb = self._new(plan, N, H, W, 8, dtype=torch.uint8) if (fused and train and self.use_mask_bytes) else None
                     if fused:
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
                             x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed), mask=None,
-                            res2=None, t=_ptr(t1), out=_ptr(y), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs))))
+                            res2=None, t=_ptr(t1), out=_ptr(y), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs), maskbits=_ptr(mb))))
                     else:
                         self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
                         self._conv(fwd, t1, c2, N, H, W, y, scale=rs, res1=cur)
 
-                    def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs, fused=fused):
+                    def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs, fused=fused, mb=mb):
                         # y = x + rs*conv2(relu(conv1 x)):  dt1 = rs*dgrad2(g) masked ; dx = g + dgrad1(dt1) (+ extra)
                         dt1, dx = self._new(plan, N, H, W, F), self._new(plan, N, H, W, F)
                         if fused:
                             bwd.append(('rumpy_conv_block', L.BlockArgs(
                                 x=_ptr(g_out), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1),
-                                res2=_ptr(extra), t=_ptr(dt1), out=_ptr(dx), N=N, H=H, W=W, relu1=0, scale1=float(rs), scale2=1.0)))
+                                res2=_ptr(extra), t=_ptr(dt1), out=_ptr(dx), N=N, H=H, W=W, relu1=0, scale1=float(rs), scale2=1.0,
+                                maskbits=_ptr(mb))))
                         else:
                             self._conv(bwd, g_out, c2, N, H, W, dt1, dgrad=True, scale=rs, mask=t1)
                             self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
@@ -283,7 +287,8 @@ class SREngine:
                             plan.rcab_status = torch.zeros(1, dtype=torch.int32, device=self.device)
                         seq = 2 * plan.rcab_n
                         plan.rcab_n += 1
-                        rc_common = dict(N=N, H=H, W=W, cr=ca.Cr, ca_w1=_ptr(ca.w1), ca_b1=_ptr(ca.b1), ca_w2=_ptr(ca.w2), ca_b2=_ptr(ca.b2),
+                        mbr = self._new(plan, N, H, W, 8, dtype=torch.uint8) if (train and self.use_mask_bytes) else None
+                        rc_common = dict(maskbits=_ptr(mbr), N=N, H=H, W=W, cr=ca.Cr, ca_w1=_ptr(ca.w1), ca_b1=_ptr(ca.b1), ca_w2=_ptr(ca.w2), ca_b2=_ptr(ca.b2),
                                          hidden=_ptr(hid), gate=_ptr(gate), qgate=_ptr(qg), xchg=_ptr(plan.rcab_xchg),
                                          xchg_bytes=plan.rcab_xchg.numel(), epoch=_ptr(plan.rcab_epoch), status=_ptr(plan.rcab_status))
                         fwd.append(('rumpy_rcab_fwd', L.RcabArgs(

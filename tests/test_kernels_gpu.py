@@ -632,3 +632,31 @@ def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
     L.call('rumpy_conv_block', a, stream())
     torch.cuda.synchronize()
     assert torch.equal(d1, d1_ref) and torch.equal(dx, dx_ref)
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (32, 48, 48), (2, 24, 24), (2, 20, 20), (1, 5, 9)])
+def test_conv_block_mask_bytes_equal_the_activation_mask(N, H, W):
+    """the ReLU mask handed from the forward block launch to the data-gradient launch as one byte per 8 channels (maskbits) gives
+    bit-identical results to masking with the stored bf16 activation"""
+    gen = np.random.default_rng(N * 100 + W)
+    pa, pb = PackedConv(*_wb(gen, 64, 64)), PackedConv(*_wb(gen, 64, 64))
+    x = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    g = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    t1 = torch.empty(N, H, W, 64, dtype=BF16, device=DEV)
+    y = torch.empty_like(t1)
+    mb = torch.full((N, H, W, 8), 0xAA, dtype=torch.uint8, device=DEV)
+    L.call('rumpy_conv_block', L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                                           t=t1.data_ptr(), out=y.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=0.1, maskbits=mb.data_ptr()), stream())
+    torch.cuda.synchronize()
+    # the bytes are exactly the sign pattern of the stored activation
+    want = ((t1.float() > 0).reshape(N, H, W, 8, 8).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(mb, want)
+    outs = []
+    for bits in (False, True):
+        dt1, dx = torch.zeros_like(t1), torch.zeros_like(t1)
+        L.call('rumpy_conv_block', L.BlockArgs(x=g.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=t1.data_ptr(), t=dt1.data_ptr(),
+                                               out=dx.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=0.1, scale2=1.0, maskbits=mb.data_ptr() if bits else None), stream())
+        torch.cuda.synchronize()
+        outs.append((dt1, dx))
+    assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+    assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
