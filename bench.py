@@ -25,8 +25,8 @@ FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, 
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_BYTES = 35.2e6           # FETCH_SIZE 21.9 MB + WRITE_SIZE 13.3 MB per launch
 PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv3x3_strip.md (separate rocprofv3 --pmc passes; launch with one residual operand)'
-BLOCK_PMC_TRAFFIC_BYTES = 41.4e6     # conv_block_kernel, mean of forward (35.3 MB) and data-gradient (47.5 MB) launches
-BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv_block.md (separate rocprofv3 --pmc passes, FETCH_SIZE + WRITE_SIZE)'
+BLOCK_PMC_TRAFFIC_BYTES = 36.25e6     # conv_block_kernel, mean of forward (35.3 MB) and data-gradient (47.5 MB) launches
+BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_step.md (tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE)'
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
 
@@ -170,8 +170,9 @@ def main():
             # algorithmic bytes: every [N,48,48,64] bf16 tensor a launch must touch once, from the engine's launch plan
             if use_block:
                 flop = 2 * layer_flop                      # the halo-row recompute of the first conv is overhead, not counted
-                tensors = [2 + sum(1 for f in ('t', 'mask', 'res2') if getattr(a, f)) for a in blocks] + \
-                          [2 + sum(1 for f in ('t', 't2', 't2_in', 'mask', 'res2') if getattr(a, f)) for a in rcabs]
+                # (a mask that travels as bytes - maskbits - is 1/16 of a tensor and not counted)
+                tensors = [2 + sum(1 for f in ('t', 'res2') if getattr(a, f)) + (1 if (a.mask and not a.maskbits) else 0) for a in blocks] + \
+                          [2 + sum(1 for f in ('t', 't2', 't2_in', 'res2') if getattr(a, f)) + (1 if (a.mask and not a.maskbits) else 0) for a in rcabs]
                 kname = 'conv_block_kernel (residual block: two 3x3 convs 64->64 per launch, fwd + data-gradient launches)'
                 if rcabs:
                     kname = 'rcab_kernel (residual channel-attention block per launch: two 3x3 convs 64->64 + attention gate; fwd + bwd launches)'
@@ -203,8 +204,8 @@ def main():
                 roofline['traffic'] = PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
             elif rcabs:
-                roofline['traffic'] = 62.1e6
-                roofline['traffic_source'] = 'profiles/r01_pmc_rcab.md (separate rocprofv3 --pmc passes, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
+                roofline['traffic'] = 56.0e6
+                roofline['traffic_source'] = 'profiles/r01_pmc_step.md (tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
             elif BLOCK_PMC_TRAFFIC_BYTES:
                 roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
