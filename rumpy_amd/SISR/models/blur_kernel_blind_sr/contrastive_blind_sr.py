@@ -14,7 +14,10 @@ from rumpy_amd.regression.models.contrastive_learning.encoding_models import Enc
 
 def load_encoder_model(weights, device, direct_load=False):
     """:14-31: the encoder's state dict out of a contrastive-training checkpoint (MoCo-style checkpoints hold it under ``encoder_q.``)."""
-    loc = device if device == torch.device('cpu') else 'cuda:%d' % device
+    if isinstance(device, int) or (isinstance(device, str) and device.isnumeric()):
+        loc = 'cuda:%d' % int(device)          # the reference passes the GPU index
+    else:
+        loc = device                            # torch.device / 'cpu'
     state = torch.load(f=weights, map_location=loc, weights_only=False)
     if direct_load:
         return state
