@@ -136,8 +136,9 @@ int rumpy_conv_block(const rumpy_block_args* a, void* stream);
  * The strips of an image (6 rows each) exchange 64 partial sums through `xchg` (rumpy_rcab_xchg_bytes(N, H) bytes, zeroed ONCE at
  * allocation; one buffer can serve every block of a network, launches on one stream are serialised) as records tagged
  * (*epoch << 12) + seq: `epoch` is a device word the caller advances between passes (rumpy_rcab_epoch_advance), `seq` < 4096 must differ
- * between the launches of one pass.  Needs W <= 48 and ceil(H/6) <= CUs.  *status (device word, zero it once) becomes 0x300 + seq if an
- * exchange timed out. */
+ * between the launches of one pass.  Needs W <= 48, ceil(H/6) <= CUs, and the GPU to itself while a launch runs (kernels of other
+ * processes / streams on the same XCDs can make the strips of an image wait for each other in a circle).  *status (device word, zero it
+ * once) becomes 0x300 + seq if an exchange timed out: the results of that launch are invalid. */
 typedef struct {
   const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
   void* t; void* t2; const void* t2_in; const void* mask;
