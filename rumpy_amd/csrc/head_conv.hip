@@ -2,6 +2,7 @@
 // K = 9*C <= 36 is far too small for MFMA to matter (0.09 % of the network's FLOPs), so both run on the fp32
 // VALU and are exact fp32 like the reference; the image is read straight from the caller's NCHW tensor.
 #include "common.hpp"
+#include <cstdlib>
 
 constexpr int HEAD_MAXC = 4;
 // forward: one wave per workgroup - the headline shape has 73,728 pixels = 1152 waves = 4.5 per CU, which 256-thread
@@ -141,6 +142,105 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict
     s[e] = (red[e] + red[64 * KS + e]) + (red[2 * 64 * KS + e] + red[3 * 64 * KS + e]);
 }
 
+// The same weight gradient on the matrix cores: dW[co][k] = sum over pixels of dy[px][co] * xpatch[px][k] (k = (c, ky, kx), 9C <= 36)
+// is a GEMM with the PIXEL index as K, like the 64-channel weight gradients (wgrad_mfma.hip): A = dy^T through the transposing LDS
+// read, B = the image patches, gathered from the fp32 halo tile and split into a bf16 high and low part (two MFMAs per fragment:
+// 16 mantissa bits, |error| < 2^-16 relative - the reference runs this conv in fp32, and the VALU version above took 35 us, 2.6 % of
+// the EDSR step, as an LDS-read-bound loop).  Wave w owns output channels 16w.. of the 64-channel tile; the four waves build the same
+// B fragments.  Slab layout = head_wgrad_kernel's: [workgroup][cout tile][64][9C + 1] (last column = bias sum, from an MFMA against a
+// ones fragment).  K order inside a 32-pixel step as in wgrad_mfma.hip: lane group g, element e -> tile row 2t + g/2, column
+// 4*(g%2) + e (e < 4) or 8 + 4*(g%2) + e - 4.
+typedef __attribute__((address_space(3))) short4v* head_lds_s4;
+__device__ __forceinline__ bf16x8 head_tr_pair(const unsigned char* p) {
+  const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((head_lds_s4)(p));
+  const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((head_lds_s4)(p + 8 * PIX_STRIDE));
+  union { short8v s; bf16x8 h; } c;
+  c.s = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return c.h;
+}
+__global__ void __launch_bounds__(256) head_wgrad_mfma_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                              float* __restrict__ slab, int N, int C, int H, int W, int cout) {
+  __shared__ float sx[HEAD_MAXC * HALO_PIX];
+  __shared__ __attribute__((aligned(16))) unsigned char sdy[TH * TW * PIX_STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3, n16 = lane & 15;
+  const int ct = blockIdx.y;
+  const int K = 9 * C, KT = (K + 15) / 16;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int ntiles = N * tiles_y * tiles_x;
+  f32x4 acc[3], bacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) acc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  // halo offset of this lane's k index in k tile kt (k = 16 kt + n16 -> c, ky, kx), -1 for the padding columns
+  int koff[3];
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    const int k = 16 * kt + n16;
+    const int c = k / 9, t = k - 9 * c, ky = t / 3, kx = t - 3 * ky;
+    koff[kt] = (k < K) ? c * HALO_PIX + ky * HALO_W + kx : -1;
+  }
+  const int rsel = g >> 1, colA = 4 * (g & 1) + q, colB = 4 * (g & 1);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const TileCoord tc = decode_tile(tile, tiles_x, tiles_y);
+    __syncthreads();
+    for (int i = tid; i < C * HALO_PIX; i += 256) {
+      const int c = i / HALO_PIX, pix = i - c * HALO_PIX;
+      const int r = pix / HALO_W, cc = pix - r * HALO_W;
+      const int y = tc.ty * TH + r - 1, xx = tc.tx * TW + cc - 1;
+      sx[i] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[((size_t)(tc.n * C + c) * H + y) * W + xx] : 0.f;
+    }
+    for (int i = tid; i < TH * TW * 8; i += 256) {
+      const int pix = i >> 3, part8 = i & 7;
+      const int y = tc.ty * TH + (pix >> 4), xx = tc.tx * TW + (pix & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y < H && xx < W) v = *reinterpret_cast<const uint4*>(dy + ((size_t)(tc.n * H + y) * W + xx) * cout + ct * 64 + part8 * 8);
+      *reinterpret_cast<uint4*>(sdy + pix * PIX_STRIDE + part8 * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TH / 2; ++t) {
+      const int row = 2 * t + rsel;
+      const bf16x8 A = head_tr_pair(sdy + (row * TW + colA) * PIX_STRIDE + wave * 32 + p4 * 8);
+      bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, ones, bacc, 0, 0, 0);
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        if (kt < KT) {
+          bf16x8 bh, bl;
+          const float* src = sx + (koff[kt] >= 0 ? koff[kt] : 0) + row * HALO_W + colB;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = src[(e < 4) ? e : e + 4];          // columns colB + e, then 8 + colB + (e - 4)
+            if (koff[kt] < 0) v = 0.f;
+            const __bf16 h = (__bf16)v;
+            bh[e] = h;
+            bl[e] = (__bf16)(v - (float)h);
+          }
+          acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bh, acc[kt], 0, 0, 0);
+          acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, bl, acc[kt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D row = co (4g + e) of the wave's 16, D column = k index n16 of the k tile
+  const int KS = K + 1;
+  float* s = slab + ((size_t)blockIdx.x * gridDim.y + ct) * 64 * KS;
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) {
+    const int k = 16 * kt + n16;
+    if (kt < KT && k < K) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[(16 * wave + 4 * g + e) * KS + k] = acc[kt][e];
+    }
+  }
+  if (n16 == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[(16 * wave + 4 * g + e) * KS + K] = bacc[e];
+  }
+}
+
 // Deterministic reduction of the per-workgroup slabs: 16 outputs x 16 slab parts per 256-thread block; part p adds slabs
 // p, p+16, p+32, .. in order (independent loads, in flight together), the 16 parts are added in a fixed order through LDS.
 __global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const float* __restrict__ slab, int nwg, int C, int cout, float scale,
@@ -171,7 +271,7 @@ __global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const float* __r
   }
 }
 
-// up to three workgroups per CU (46 KB of LDS each): their load / barrier / FMA phases overlap
+// three workgroups per CU (24 KB of LDS each): their load / barrier / MFMA phases overlap
 static int head_wgrad_grid() { return 3 * rumpy_device_cus(); }
 
 extern "C" int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout) {
@@ -202,8 +302,11 @@ extern "C" int rumpy_head_wgrad(const rumpy_head_wgrad_args* p, void* stream) {
   const int ntiles = p->N * ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW);
   const int nwg = ntiles < head_wgrad_grid() ? ntiles : head_wgrad_grid();
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(head_wgrad_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
-                     p->N, p->C, p->H, p->W, p->cout);
+  static const bool valu = getenv("RUMPY_HEAD_WGRAD_VALU") != nullptr;     // A/B switch: the fp32 VALU version
+  if (valu) hipLaunchKernelGGL(head_wgrad_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
+                               p->N, p->C, p->H, p->W, p->cout);
+  else hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
+                          p->N, p->C, p->H, p->W, p->cout);
   const int total = p->cout * (9 * p->C + 1);
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, s, p->slab, nwg, p->C, p->cout,
                      p->scale, p->gw, p->gb);
