@@ -108,7 +108,7 @@ class SREngine:
         self.lib = L.lib()
         self.cus = self.lib.rumpy_device_cus()
         self.plans = {}
-        self.wgrad_pixels_per_job = wgrad_pixels_per_job
+        self.wgrad_pixels_per_job = int(os.environ.get('RUMPY_WGRAD_PIXELS', wgrad_pixels_per_job))    # env: A/B runs of the job size
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
