@@ -169,3 +169,13 @@ def test_unsupported_blind_variants_are_refused():
                 dict(reducer_layer_sizes=[256, 64]), dict(crop_count=2), dict(style='modulate')):
         with pytest.raises(RuntimeError):
             define_model('contrastiveblindqrcan', **{**base, **bad})
+
+
+def test_blind_qrcan_evaluates_images_wider_than_a_strip():
+    """whole-image evaluation (LR 40 x 70): encoder on the full image, QRCAN on the strip conv + separate attention launches"""
+    h, oh = _pair(828, eval_mode=True)
+    xe, ye = O.synthetic_batch(970, 1, lr_hw=(40, 70), scale=2)
+    out, loss, _ = h.run_eval(x=xe, y=ye, request_loss=True)
+    oout, oloss, _ = oh.run_eval(xe, ye, request_loss=True)
+    assert out.shape == oout.shape == (1, 3, 80, 140)
+    assert self_psnr(out, oout) >= 45.0 and abs(float(loss) - float(oloss)) < 1e-2 * float(oloss)

@@ -199,3 +199,37 @@ def test_unsupported_qrcan_variants_are_refused():
                 dict(style='standard', srmd_mode=True), dict(style='standard', use_moco=True)):
         with pytest.raises(RuntimeError):
             define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, n_resgroups=1, n_resblocks=1, **bad)
+
+
+@pytest.mark.parametrize('style', ['standard', 'modulate'])
+def test_qrcan_wide_images_use_the_separate_launches(style):
+    """images wider than 48 pixels cannot use the one-launch RCAB kernels: the strip conv + fused attention launches (with the
+    meta-attention gate as an extra factor) carry training and evaluation there"""
+    kw = dict(scale=2, n_feats=64, n_resgroups=1, n_resblocks=2, reduction=16)
+    if style == 'standard':
+        names = ['a', 'b', 'c', 'd']
+        h, oh = _pair(names, 826, **kw)
+        M = 4
+        attr = lambda seed, n: _meta(seed, n, M).unsqueeze(2).unsqueeze(3)
+    else:
+        h = define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, checkpoint_load=False, loss_masking=False,
+                         metadata_list=None, lr=1e-3, **SCHED, **kw)
+        onet = O.build_oracle('qrcan', style='modulate', include_q_layer=False, **kw)
+        sd = O.seeded_state_dict(onet, 826)
+        onet.load_state_dict(sd)
+        h.net.load_state_dict(sd)
+        oh = O.OracleHandler(onet, lr=1e-3, scheduler=SCHED['scheduler'], scheduler_params=SCHED['scheduler_params'])
+        attr = lambda seed, n: O.scale_qpi(_meta(seed, n, 1).unsqueeze(2).unsqueeze(3), n_feats=64)
+    x, y = O.synthetic_batch(960, 2, lr_hw=(20, 60), scale=2)
+    a = attr(961, 2)
+    loss, out = h.run_train(x=x, y=y, extra_channels=a)
+    oloss, oout = oh.run_train(x, y, extra_channels=a)
+    plan = h.net.engine.plan_for(2, 20, 60, True)
+    assert 'rumpy_rcab_fwd' not in [op for op, _ in plan.fwd] and 'rumpy_ca_fwd_fused' in [op for op, _ in plan.fwd]
+    assert self_psnr(out, oout) >= 50.0 and abs(float(loss) - float(oloss)) < 2e-3 * float(oloss)
+    print('worst grad rel err', _grad_check(h, oh))
+    xe, ye = O.synthetic_batch(962, 1, lr_hw=(33, 70), scale=2)
+    ae = attr(963, 1)
+    ev, evl, _ = h.run_eval(x=xe, y=ye, request_loss=True, extra_channels=ae)
+    oev, oevl, _ = oh.run_eval(xe, ye, request_loss=True, extra_channels=ae)
+    assert self_psnr(ev, oev) >= 45.0 and abs(float(evl) - float(oevl)) < 1e-2 * float(oevl)
