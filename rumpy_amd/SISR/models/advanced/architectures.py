@@ -223,7 +223,7 @@ class HipSRNet(nn.Module):
         Returns (loss device scalar, out).  Gradients land in flat_g / p.grad."""
         if self.use_graph:
             self._ensure_engine()
-            out, loss, _ = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous())
+            out, loss, _ = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous(), meta=self._meta_matrix(metadata, x))
             return loss, out
         out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous(), meta=metadata)
         # The loss is final once the forward pass has run: its read-back is queued HERE (pinned buffer + event), ahead of the

@@ -612,14 +612,18 @@ class SREngine:
             plan.q_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
         plan.q_dev.copy_(torch.from_numpy(raw), non_blocking=False)
 
-    def _q_gates(self, plan, meta, stream):
-        """metadata [N,M] -> the meta-attention gates of every q-layer (one launch)"""
+    def _q_gates(self, plan, meta, stream, launch=True):
+        """metadata [N,M] -> the plan's static metadata buffer, then (launch) the meta-attention gates of every q-layer in one launch"""
         if plan.meta is None:
             return
         if meta is None or tuple(meta.shape) != tuple(plan.meta.shape):
             raise RuntimeError('rumpy_amd: this network needs a metadata matrix of shape %s (got %s)'
                                % (tuple(plan.meta.shape), None if meta is None else tuple(meta.shape)))
         plan.meta.copy_(meta, non_blocking=True)
+        if launch:
+            self._q_gates_launch(plan, stream)
+
+    def _q_gates_launch(self, plan, stream):
         if not plan.q_items:
             return
         if plan.q_dev is None:
@@ -722,7 +726,7 @@ class SREngine:
             L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')
 
     # ------------------------------------------------------------------ hipGraph replay of the fused L1 training pass
-    def train_pass_graphed(self, x, target):
+    def train_pass_graphed(self, x, target, meta=None):
         """forward + L1 + full backward of one batch as ONE captured hipGraph (the per-step launch list is static):
         ~150 kernel launches collapse into a graph replay, which removes the host launch gaps between the short
         per-layer kernels.  Inputs are copied into the plan's static buffers; the returned `out` / `loss` tensors are
@@ -738,9 +742,14 @@ class SREngine:
             plan.tail_loss.target = plan.target.data_ptr()
             plan.x_in.copy_(x)
             plan.target.copy_(target)
+            self._q_gates(plan, meta, None, launch=False)
+
+            if plan.q_items and plan.q_dev is None:
+                self._upload_q_items(plan)          # not inside the capture
 
             def body(stream):
                 self._advance_epoch(plan, stream)
+                self._q_gates_launch(plan, stream)  # reads the plan's static metadata buffer (refreshed before every replay)
                 self._run(plan.fwd, stream)
                 L.call('rumpy_tail_fwd', plan.tail_loss, stream)
                 self._backward_launches(plan, stream)
@@ -756,6 +765,7 @@ class SREngine:
             plan.graph = g
         plan.x_in.copy_(x, non_blocking=True)
         plan.target.copy_(target, non_blocking=True)
+        self._q_gates(plan, meta, None, launch=False)
         plan.graph.replay()
         return plan.out, plan.loss, plan
 

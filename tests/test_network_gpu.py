@@ -215,17 +215,31 @@ def test_full_size_properties_determinism_and_loss_directional_derivative():
     assert abs(float(l2) - pred) < 0.02 * abs(d * float(gb.sum())) + 1e-6, (float(l2), pred, l0)
 
 
-def test_hipgraph_replay_gives_the_same_step_as_eager_launches():
-    h1, _ = _pair('edsr', 506, scale=4, num_blocks=2)
-    h2, _ = _pair('edsr', 506, scale=4, num_blocks=2)
-    h2.net.use_graph = True
+@pytest.mark.parametrize('name,kw', [('edsr', dict(scale=4, num_blocks=2)), ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16)),
+                                     ('qrcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16, style='standard', include_q_layer=True,
+                                                    metadata=['a', 'b', 'c']))])
+def test_hipgraph_replay_gives_the_same_step_as_eager_launches(name, kw):
+    """RUMPY_GRAPH=1 / net.use_graph: forward + L1 + backward as one captured graph.  The RCAB kernels' tag epoch is advanced by a kernel
+    inside the graph and the q-layer gates are evaluated from the plan's static metadata buffer, so replays stay valid."""
+    okw = {k: v for k, v in kw.items() if k != 'metadata'}
+    if name == 'qrcan':
+        okw['num_metadata'] = 3
+    sd = O.seeded_state_dict(O.build_oracle(name, **okw), 506)
+    hs = []
+    for graph in (False, True):
+        h = _handler(name, lr=1e-3, **kw)
+        h.net.load_state_dict(sd)
+        h.net.use_graph = graph
+        hs.append(h)
     for s in (650, 651, 652):
-        x, y = O.synthetic_batch(s, 2, lr_hw=24, scale=4)
-        l1, o1 = h1.run_train(x=x, y=y)
-        l2, o2 = h2.run_train(x=x, y=y)
+        x, y = O.synthetic_batch(s, 2, lr_hw=24, scale=kw['scale'])
+        extra = dict(extra_channels=torch.rand(2, 3, 1, 1, generator=torch.Generator().manual_seed(s))) if name == 'qrcan' else {}
+        l1, o1 = hs[0].run_train(x=x, y=y, **extra)
+        l2, o2 = hs[1].run_train(x=x, y=y, **extra)
         assert float(l1) == float(l2) and torch.equal(o1, o2), s
-    for p, q in zip(h1.net.parameters(), h2.net.parameters()):
+    for p, q in zip(hs[0].net.parameters(), hs[1].net.parameters()):
         assert torch.equal(p.detach(), q.detach())
+    assert hs[1].net.engine.exchange_status() == 0
 
 
 def test_reference_written_checkpoint_continues_identically_on_the_gpu(golden_dir):
