@@ -51,6 +51,15 @@ __device__ __forceinline__ void unpack4_bf16(uint2 v, float (&o)[4]) {
   o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
 }
 
+// XCD-aware work order (cdna_hip_programming.md T1): workgroup ids are dealt round-robin over the 8 XCDs, so consecutive ids - e.g. the
+// vertically adjacent strips of an image, which share 4 of their 10 input rows, or neighbouring tiles with their common halo - would sit
+// behind 8 different L2s and every shared line would come from HBM twice.  Strip = (id % 8) * ceil(n / 8) + id / 8 (bijective form) gives each XCD a contiguous run of strips.
+// A speed choice only: any placement is correct.
+__device__ __forceinline__ int xcd_strip(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
 struct TileCoord { int n, ty, tx; };
 __device__ __forceinline__ TileCoord decode_tile(int tile, int tiles_x, int tiles_y) {
   TileCoord t;

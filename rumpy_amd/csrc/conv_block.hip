@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int q = wave & 3, rh = wave >> 2;
-  const int strip = blockIdx.x;
+  const int strip = xcd_strip(blockIdx.x, gridDim.x);
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
   // LDS, stage s+1 is in flight into registers.  The request is issued on every path (past the end: the current tile
   // again, unused) so that the waits stay counted.  (Two stages deep measured no faster here and spills: with the whole
   // 256-channel filter in registers - 288 of them - this kernel runs one wave per SIMD.)
-  int tile = blockIdx.x;
+  int tile = blockIdx.x;                                // (the XCD-contiguous order of common.hpp measured no gain here)
   if (tile >= ntiles) return;
   const int gstride = (int)gridDim.x;
   uint4 R[6];
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   // loads were issued one iteration ago) and the loads of tile t+2 are issued - every load has two iterations to land, so
   // the kernel is no longer one HBM latency per tile (it reads 151 MB on the headline shape: a bandwidth kernel).
   const int stride = (int)gridDim.x;
-  int tile = blockIdx.x;
+  int tile = xcd_strip(blockIdx.x, gridDim.x);         // contiguous runs of tiles per XCD (halo overlap of neighbours in L2)
   uint4 R[2][6];
   if (tile < ntiles) {
     const TileCoord t = decode_tile(tile, a.tiles_x, a.tiles_y);
@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(256, 2) tail_dgrad_kernel(TailDgradDev a) {
   __shared__ __attribute__((aligned(16))) uint2 sdy[HALO_PIX + 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
-  const TileCoord tc = decode_tile(blockIdx.x, a.tiles_x, a.tiles_y);
+  const TileCoord tc = decode_tile(blockIdx.x, a.tiles_x, a.tiles_y);    // (XCD-contiguous order: 5 us slower for this write-only kernel)
   if (tid < HALO_PIX) {
     const int r = tid / HALO_W, c = tid - r * HALO_W;
     const int y = tc.ty * TH + r - 1, x = tc.tx * TW + c - 1;

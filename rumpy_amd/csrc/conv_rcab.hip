@@ -94,7 +94,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int q = wave & 3, rh = wave >> 2;
-  const int strip = blockIdx.x;
+  // XCD-aware strip order when every XCD gets whole images (then the strips of an image are consecutive in ONE XCD's dispatch order and
+  // the exchange argument at the top of this file holds per XCD: needs ceil(H/6) <= 32 CUs); identity otherwise
+  const int nwg = gridDim.x;
+  const bool remap = ((nwg & 7) == 0) && (((nwg >> 3) % a.sy_n) == 0) && (a.sy_n <= 32);
+  const int strip = remap ? xcd_strip(blockIdx.x, nwg) : (int)blockIdx.x;
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
   const unsigned tag = (*a.epoch << 12) + a.seq;
   unsigned long long stamps[10];

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
   const int ct = blockIdx.y;
   const int nstrips = a.N * a.sy_n * a.sx_n;
 
-  int strip = blockIdx.x;
+  int strip = xcd_strip(blockIdx.x, gridDim.x);        // contiguous runs of strips per XCD: neighbours share halo rows in L2
   if (strip >= nstrips) return;
   // the input loads go out first (longest latency); the filter comes from L2 behind them
   uint4 R[SREGS];
