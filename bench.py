@@ -138,7 +138,9 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * world * args.steps / elapsed
 
-    # ---- dominant-kernel timing with HIP events (same process, same steps, right after the timed region) ----
+    # ---- dominant-kernel timing with HIP events (same process, same steps, right after the timed region); for the block kernels the
+    # events are attached to the dispatches themselves (hipExtLaunchKernelGGL inside the library): kernel begin / end timestamps, no
+    # marker packets in the stream - the figure agrees with the rocprofv3 --kernel-trace --stats average ----
     roofline = None
     if rank != 0:
         # the probe steps contain the gradient all-reduce: EVERY rank has to run them (rank 0 alone would wait for its peers forever)
@@ -157,7 +159,7 @@ def main():
         rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd')]      # share probe id 5 with the block kernel
         use_block = len(blocks) + len(rcabs) > 0
         hipnet.use_graph = False          # the probe records events around eager launches (a graph replay has none)
-        lib.rumpy_probe_begin(5 if use_block else 1, 80 * args.probe_steps + 8)
+        lib.rumpy_probe_begin(5 if use_block else 1, max(80, len(blocks) + len(rcabs)) * args.probe_steps + 8)
         for i in range(args.probe_steps):
             step(i)
         torch.cuda.synchronize(dev)

@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (CDNA4: wave64, MFMA 16x16x32 bf16, 160 KiB LDS/CU).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/rumpy_amd.h"
 
@@ -108,3 +109,11 @@ void rumpy_set_error(const char* fmt, ...);
 int rumpy_check_launch(const char* what);
 void rumpy_probe_pre(int kernel_id, hipStream_t s);
 void rumpy_probe_post(int kernel_id, hipStream_t s);
+bool rumpy_probe_slot(int kernel_id, hipEvent_t* start, hipEvent_t* stop);
+// launch with the timing probe's events attached to the dispatch itself when kernel id `id` is being probed (api.hip)
+#define RUMPY_LAUNCH_PROBED(id, kernel, grid, block, stream, ...)                                                       \
+  do {                                                                                                                  \
+    hipEvent_t e0_ = nullptr, e1_ = nullptr;                                                                            \
+    if (rumpy_probe_slot(id, &e0_, &e1_)) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0_, e1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                               \
+  } while (0)

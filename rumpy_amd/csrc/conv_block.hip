@@ -283,16 +283,14 @@ extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
     rumpy_set_error("rumpy_conv_block: maskbits goes with the ResBlock forward form (written) or a data-gradient form (read)"); return RUMPY_E_ARG; }
   if (p->res_mode < 0 || p->res_mode > 2 || (p->res_mode == 2 && !p->res1)) { rumpy_set_error("rumpy_conv_block: bad res_mode / res1"); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  rumpy_probe_pre(5, s);
   const dim3 grid(d.N * d.sy_n);
   if (p->res_mode == 0 && !p->pool) {
-    if (p->relu1 && p->scale1 == 1.0f && !p->mask) hipLaunchKernelGGL((conv_block_kernel<false, 1>), grid, dim3(BTHREADS), 0, s, d);
-    else if (!p->relu1 && p->maskbits) hipLaunchKernelGGL((conv_block_kernel<false, 3>), grid, dim3(BTHREADS), 0, s, d);
-    else if (!p->relu1 && p->mask) hipLaunchKernelGGL((conv_block_kernel<false, 2>), grid, dim3(BTHREADS), 0, s, d);
-    else hipLaunchKernelGGL((conv_block_kernel<false, 0>), grid, dim3(BTHREADS), 0, s, d);
+    if (p->relu1 && p->scale1 == 1.0f && !p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1>), grid, dim3(BTHREADS), s, d);
+    else if (!p->relu1 && p->maskbits) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 3>), grid, dim3(BTHREADS), s, d);
+    else if (!p->relu1 && p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 2>), grid, dim3(BTHREADS), s, d);
+    else RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 0>), grid, dim3(BTHREADS), s, d);
   } else {
-    hipLaunchKernelGGL((conv_block_kernel<true, 0>), grid, dim3(BTHREADS), 0, s, d);
+    RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<true, 0>), grid, dim3(BTHREADS), s, d);
   }
-  rumpy_probe_post(5, s);
   return rumpy_check_launch("rumpy_conv_block");
 }

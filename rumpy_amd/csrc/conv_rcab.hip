@@ -517,11 +517,10 @@ static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const c
   d.mean = p->mean; d.hidden = p->hidden; d.gate = p->gate; d.qgate = p->qgate; d.dz = p->dz; d.dzq = p->dzq;
   d.xchg = (unsigned long long*)p->xchg; d.xchg_bytes = (unsigned)need; d.epoch = (const unsigned*)p->epoch; d.seq = p->seq; d.status = (unsigned*)p->status; d.mbits = (unsigned char*)p->maskbits;
   hipStream_t s = (hipStream_t)stream;
-  rumpy_probe_pre(5, s);
-  if (bwd && p->maskbits) hipLaunchKernelGGL((rcab_kernel<true, true>), dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
-  else if (bwd) hipLaunchKernelGGL((rcab_kernel<true, false>), dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
-  else hipLaunchKernelGGL((rcab_kernel<false, false>), dim3(d.N * sy_n), dim3(BTHREADS), 0, s, d);
-  rumpy_probe_post(5, s);
+  const dim3 grid(d.N * sy_n);
+  if (bwd && p->maskbits) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, true>), grid, dim3(BTHREADS), s, d);
+  else if (bwd) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, false>), grid, dim3(BTHREADS), s, d);
+  else RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false>), grid, dim3(BTHREADS), s, d);
   return rumpy_check_launch(what);
 }
 
