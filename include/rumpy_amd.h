@@ -513,6 +513,9 @@ int64_t rumpy_ssim_partial_floats(int32_t P, int32_t H, int32_t W);
 /* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
  * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
  * 4 = rumpy_conv_chain ; 5 = rumpy_conv_block and rumpy_block_chain */
+/* a launch list: fn = address of any `int fn(const <args>*, void* stream)` entry point of this library, args = its argument block */
+typedef struct { const void* fn; const void* args; } rumpy_op;
+int rumpy_run_list(const rumpy_op* ops, int32_t n, void* stream);
 int rumpy_probe_begin(int kernel_id, int max_records);
 /* synchronises the recorded events; returns launches seen; *total_ms = summed duration */
 int rumpy_probe_end(double* total_ms);

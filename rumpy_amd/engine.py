@@ -108,6 +108,7 @@ class SREngine:
         self.lib = L.lib()
         self.cus = self.lib.rumpy_device_cus()
         self.plans = {}
+        self._tables = {}      # id(launch list) -> (list, ctypes table, its address, length)
         self.wgrad_pixels_per_job = int(os.environ.get('RUMPY_WGRAD_PIXELS', wgrad_pixels_per_job))    # env: A/B runs of the job size
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
@@ -647,11 +648,21 @@ class SREngine:
         return p
 
     def _run(self, ops, stream):
-        lib = self.lib
-        for name, a in ops:
-            rc = getattr(lib, name)(C.byref(a), stream)
-            if rc != 0:
-                L.check(rc, name)
+        """Launch a list of (entry point name, argument block) in ONE library call (rumpy_run_list walks the table in C: the
+        per-launch ctypes cost, 4-5 us, was most of the host time of a step).  The table is rebuilt when the list object changes."""
+        if not ops:
+            return
+        cache = self._tables.get(id(ops))
+        if cache is None or cache[0] is not ops or cache[3] != len(ops):
+            arr = (L.Op * len(ops))()
+            for i, (name, a) in enumerate(ops):
+                arr[i].fn = C.cast(getattr(self.lib, name), C.c_void_p).value
+                arr[i].args = C.addressof(a)
+            cache = (ops, arr, C.addressof(arr), len(ops))
+            self._tables[id(ops)] = cache
+        rc = self.lib.rumpy_run_list(cache[2], cache[3], stream)
+        if rc != 0:      # -(index + 1) of the entry that failed; its message is in rumpy_last_error()
+            L.check(rc, ops[-rc - 1][0] if (rc < 0 and -rc - 1 < len(ops)) else 'rumpy_run_list')
 
     def forward(self, x, train=False, target=None, meta=None):
         """x (and target): contiguous fp32 [N,C,H,W] on the device; meta: fp32 [N,M] metadata (meta-attention nets only).

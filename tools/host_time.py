@@ -1,0 +1,41 @@
+"""Host (CPU) time per training step against the GPU step time (GPU box): python tools/host_time.py [edsr|rcan]"""
+import os, sys, tempfile, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import sr_oracle as O
+from rumpy_amd.shared_framework.models import define_model
+name = sys.argv[1] if len(sys.argv) > 1 else 'edsr'
+h = define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, scale=4, lr=1e-4)
+x, y = O.synthetic_batch(1, 32, lr_hw=48, scale=4)
+x, y = x.cuda(), y.cuda()
+for _ in range(20):
+    h.run_train(x=x, y=y, keep_on_device=True)
+torch.cuda.synchronize()
+n = 200 if name == 'edsr' else 40
+c0, t0 = time.process_time(), time.perf_counter()
+for _ in range(n):
+    h.run_train(x=x, y=y, keep_on_device=True)
+torch.cuda.synchronize()
+c1, t1 = time.process_time(), time.perf_counter()
+print('%s: wall %.3f ms/step, host CPU time %.3f ms/step (%.0f %% of a core)' % (name, 1e3 * (t1 - t0) / n, 1e3 * (c1 - c0) / n, 100 * (c1 - c0) / (t1 - t0)))
+# pure enqueue time: the same launches without reading the loss back (nothing waits on the GPU until the end)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    h.net.fused_l1_forward_backward(x, y)
+    h._apply_update(False)
+t_enq = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+h.net.take_early_loss()
+print('%s: enqueue only %.3f ms/step (host), everything drained after %.3f ms/step' % (name, 1e3 * t_enq / n, 1e3 * t_all / n))
+# host cost of ONE step's launches into an empty queue (no back-pressure)
+ts = []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    h.net.fused_l1_forward_backward(x, y)
+    h._apply_update(False)
+    ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    h.net.take_early_loss()
+print('%s: one step enqueued into an idle queue: %.3f ms (median of 10)' % (name, 1e3 * sorted(ts)[5]))
