@@ -59,7 +59,10 @@ def main():
     one_device = os.environ.get('RUMPY_BENCH_ONE_DEVICE') == '1'
     if one_device:
         local_rank = 0
-    if world > 1:
+    # second test hook: RUMPY_DP_FORCE=1 under torch.distributed.run with ONE rank keeps the whole data-parallel path on (RCCL communicator,
+    # broadcast, early all-reduce on the side stream) - the only way to run RCCL itself on a 1-GPU box
+    dp = world > 1 or (os.environ.get('RUMPY_DP_FORCE') == '1' and 'RANK' in os.environ)
+    if dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
@@ -89,7 +92,7 @@ def main():
                      eval_mode=False, checkpoint_load=False, loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
                      scheduler_params=SCHED, **extra)
     meta_pool = [torch.rand(N, 5, 1, 1, generator=torch.Generator().manual_seed(77 + i)).to(dev) for i in range(8)] if args.model == 'qrcan' else None
-    if world > 1:
+    if dp:
         broadcast_parameters(h.net)
         h.set_multi_gpu()
     pool = []
@@ -119,7 +122,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -131,7 +134,7 @@ def main():
         loss, _ = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -264,7 +267,7 @@ def main():
                            'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4)},
                 'roofline': roofline, 'cpu_baseline': cpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -11,6 +11,7 @@ import math
 import torch
 
 from . import _lib as L
+from .staging import PinnedRing
 
 
 class FlatAdam(torch.optim.Adam):
@@ -25,9 +26,8 @@ class FlatAdam(torch.optim.Adam):
         self.flat_v = torch.zeros_like(net.flat_p)
         self._step_t = torch.tensor(0.0)
         self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(8, dtype=torch.float32)
-        if dev.type == 'cuda':
-            self._hyper_host = self._hyper_host.pin_memory()
+        # the host runs ahead of the GPU: every step's hyper-parameters get their own fenced pinned slot (staging.PinnedRing)
+        self._hyper_ring = PinnedRing((8,), torch.float32) if dev.type == 'cuda' else None
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._sumsq_partial = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._graphs = {}
@@ -77,13 +77,14 @@ class FlatAdam(torch.optim.Adam):
         beta1, beta2 = group['betas']
         self._step_t += 1
         t = float(self._step_t)
-        h = self._hyper_host
+        slot, h = self._hyper_ring.acquire()
         h[0], h[1], h[2], h[3] = group['lr'], beta1, beta2, group['eps']
         h[4] = 1.0 - beta1 ** t
         h[5] = math.sqrt(1.0 - beta2 ** t)
         h[6] = grad_mult
         h[7] = float(max_norm) if max_norm else 0.0
         self._hyper_dev.copy_(h, non_blocking=True)
+        self._hyper_ring.sent(slot)
         dev = net.flat_p.device
         n = net.flat_p.numel()
 

@@ -6,6 +6,8 @@ Replaces nn.DataParallel (rumpy/shared_framework/models/base_architecture.py:70-
 parameter each step from one Python process.  Equal per-rank shards + mean of per-rank mean-L1 gradients equals the
 reference's global-batch mean-L1 gradient.  Works with any backend (tests use gloo on CPU tensors).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -26,6 +28,9 @@ class GradientAverager:
         self.flat_g = flat_grad if flat_grad is not None else net.flat_g
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # test hook for 1-GPU boxes: RUMPY_DP_FORCE=1 sends the gradients of a ONE-rank group through the collectives too, so that the real
+        # RCCL communicator, the side stream and the bucket slicing run where only one GPU exists (sum over one rank = identity)
+        self.active = self.world_size > 1 or (os.environ.get('RUMPY_DP_FORCE') == '1' and dist.is_available() and dist.is_initialized())
         self.buckets = bucket_bounds(self.flat_g.numel(), bucket_elems)
         self.bucket_elems = bucket_elems
         self.early_lo = None                 # start of the part whose all-reduce was launched early by begin()
@@ -34,7 +39,7 @@ class GradientAverager:
 
     def launch_bucket(self, idx):
         """All-reduce bucket idx asynchronously (call as soon as its gradients are final)."""
-        if self.world_size == 1:
+        if not self.active:
             return
         lo, hi = self.buckets[idx]
         view = self.flat_g[lo:hi]
@@ -49,7 +54,7 @@ class GradientAverager:
         """Engine hook (SREngine.backward(on_ready=...)): every gradient at device address >= ptr is final on the current stream ->
         start the all-reduce of that upper part of the flat buffer on the side stream; the launches that follow on the main stream (the
         remaining weight gradients) run next to it.  average() then covers the lower part."""
-        if self.world_size == 1 or self.early_lo is not None:
+        if not self.active or self.early_lo is not None:
             return
         lo = (int(ptr) - self.flat_g.data_ptr()) // self.flat_g.element_size()
         if lo <= 0 or lo >= self.flat_g.numel():
@@ -81,7 +86,7 @@ class GradientAverager:
 
     def average(self):
         """Sum over ranks of every bucket; the 1/world factor is applied here so the optimizer sees the mean."""
-        if self.world_size == 1:
+        if not self.active:
             return
         if self.early_lo is not None:        # the upper part is already in flight (begin()): only the rest is launched here
             self._launch_range(0, self.early_lo)
@@ -90,12 +95,13 @@ class GradientAverager:
             for i in range(len(self.buckets)):
                 self.launch_bucket(i)
         self.finish()
-        self.flat_g.mul_(1.0 / self.world_size)
+        if self.world_size > 1:
+            self.flat_g.mul_(1.0 / self.world_size)
 
 
 def broadcast_parameters(net, src=0, group=None):
     """Make every replica start from rank src's weights (one flat broadcast)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get('RUMPY_DP_FORCE') == '1'):
         hip = getattr(net, 'hip_generator', net)        # a pipeline trains its generator; its frozen encoder is replicated as well
         dist.broadcast(hip.flat_p, src=src, group=group)
         hip._packed_version = None

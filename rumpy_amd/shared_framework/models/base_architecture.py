@@ -65,9 +65,9 @@ class BaseModel(nn.Module):
         from rumpy_amd.parallel import GradientAverager
         self.data_parallel = GradientAverager(self.net)
         hip = self._hip_net()
-        if hip is not None and self.data_parallel.world_size > 1:
+        if hip is not None and self.data_parallel.active:
             hip.grad_ready_hook = self.data_parallel.begin      # all-reduce of the upper half starts under the remaining weight gradients
-        if self.data_parallel.world_size > 1:
+        if self.data_parallel.active:
             print('Model replicated over %d GPU processes (RCCL gradient all-reduce)' % self.data_parallel.world_size)
 
     # ------------------------------------------------------------------ optimizer / scheduler (:79-198)

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from rumpy_amd import _lib as L
+from rumpy_amd.staging import PinnedRing
 
 
 # numpy mirror of rumpy_patch_item (include/rumpy_amd.h); tests/test_host_cpu.py checks it against the ctypes struct
@@ -52,8 +53,7 @@ class DevicePatchSource:
             self.meta.append((lo, ho, int(lr.shape[0]), int(lr.shape[1])))
         self.images = torch.from_numpy(np.concatenate(chunks)).to(self.device)
         self._meta_np = np.asarray(self.meta, dtype=np.int64)
-        self._ring = [torch.empty((256, ITEM_BYTES), dtype=torch.uint8).pin_memory() for _ in range(4)]
-        self._ring_pos = 0
+        self._ring = PinnedRing((256, ITEM_BYTES), torch.uint8)
 
     def __len__(self):
         return len(self.meta)
@@ -81,16 +81,14 @@ class DevicePatchSource:
             k = int(np.argmax(bad))
             raise ValueError('patch %d: crop %d at (%d, %d) leaves the %dx%d augmented image' % (k, self.crop, p[k, 3], p[k, 4], ah[k], aw[k]))
         # the item table in the C struct's layout (rumpy_patch_item), staged through a small ring of pinned buffers
-        slot = self._ring[self._ring_pos % len(self._ring)]
-        self._ring_pos += 1
-        if slot.shape[0] < n:
-            slot = self._ring[(self._ring_pos - 1) % len(self._ring)] = torch.empty((n, ITEM_BYTES), dtype=torch.uint8).pin_memory()
+        slot_i, slot = self._ring.acquire(min_rows=n)
         rec = np.zeros(n, dtype=ITEM_DTYPE)
         rec['lr_off'], rec['hr_off'], rec['lr_h'], rec['lr_w'] = meta[:, 0], meta[:, 1], meta[:, 2], meta[:, 3]
         rec['hflip'], rec['vflip'], rec['rot'], rec['y'], rec['x'] = p[:, 0] != 0, p[:, 1] != 0, p[:, 2] != 0, p[:, 3], p[:, 4]
         host = slot[:n]
         host.numpy().view(ITEM_DTYPE).reshape(n)[:] = rec
         items_dev = host.to(self.device, non_blocking=True)
+        self._ring.sent(slot_i)
         hc = self.crop * self.scale
         lr = torch.empty(n, self.C, self.crop, self.crop, dtype=torch.float32, device=self.device)
         hr = torch.empty(n, self.C, hc, hc, dtype=torch.float32, device=self.device)

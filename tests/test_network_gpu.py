@@ -454,6 +454,55 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     assert d['roofline'] is not None and d['roofline']['launches_timed'] > 0
 
 
+def test_free_running_training_equals_step_synchronised_training():
+    """run_train waits for the forward pass only, so the host queues step i+1 while the GPU still runs step i's backward pass and Adam.
+    Everything the host rewrites per step must therefore be private to that step (the Adam hyper-parameters once travelled through ONE
+    pinned buffer: the copy of step i could pick up the bias corrections of step i+1).  Headline-size EDSR, first steps (where the bias
+    corrections move most): weights after 6 free-running steps == weights after 6 steps with a device synchronise after each, bitwise."""
+    res = []
+    batches = [tuple(t.cuda() for t in O.synthetic_batch(900 + i, 32, lr_hw=48, scale=4)) for i in range(6)]
+    for sync in (True, False):
+        torch.manual_seed(8)
+        h = _handler('edsr', scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
+                     scheduler_params={'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7})
+        losses = []
+        for xd, yd in batches:                       # already in HBM: nothing in the loop waits for the device but run_train itself
+            loss, _ = h.run_train(x=xd, y=yd, keep_on_device=True)
+            losses.append(float(loss))
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        res.append((losses, h.net.flat_p.detach().clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert torch.equal(res[0][1].view(torch.int32), res[1][1].view(torch.int32))
+
+
+@pytest.mark.parametrize('model', ['edsr', 'rcan'])
+def test_bench_runs_over_rccl_with_one_rank(model):
+    """RCCL itself on a 1-GPU box: bench.py under torch.distributed.run with ONE rank and RUMPY_DP_FORCE=1 keeps the data-parallel path
+    on (nccl communicator bound to the device, flat broadcast, two-phase weight gradient, early all-reduce of the upper half on the side
+    stream, barrier + MAX all-reduce of the time).  A sum over one rank is the identity, so the loss must equal the plain run's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = ['--model', model, '--steps', '6', '--warmup', '2', '--probe-steps', '2', '--no-cpu-baseline']
+    env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29573', os.path.join(root, 'bench.py'), '--gpus', '1'] + tail
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-3000:]
+    assert 'RCCL gradient all-reduce' in out, out[-3000:]
+    d = json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][0])
+    q = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=600, cwd=root)
+    assert q.returncode == 0, q.stdout.decode()[-3000:]
+    e = json.loads([l for l in q.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
+    assert d['n_gpus'] == 1 and d['value'] > 0
+    assert d['config']['loss'] == e['config']['loss'], (d['config']['loss'], e['config']['loss'])
+
+
 @pytest.mark.parametrize('N', [67, 160])
 def test_one_launch_rcab_with_more_strips_than_cus(N, monkeypatch):
     """N * 8 workgroups per launch >> 256 CUs (536 / 1280), images straddling the residency boundary: workgroup ids are dispatched in
