@@ -510,6 +510,47 @@ typedef struct {
 int rumpy_ssim(const rumpy_ssim_args* a, void* stream);
 int64_t rumpy_ssim_partial_floats(int32_t P, int32_t H, int32_t W);
 
+/* ---- direct fp32 convolution for the reference's "basic" models (SRCNN / VDSR: rumpy/SISR/models/basic/architectures.py:6-77, nn.Conv2d with
+ * odd kernel sizes 3..11, padding k/2, 1..64 channels, on single-channel Y images): fp32 NCHW in and out, filters read in the reference's OIHW
+ * layout in place.  Exact fp32 arithmetic (fma order differs from ATen's) - these layers have K = 81 / 1 output channel and are not MFMA-shaped. */
+typedef struct {
+  const float* x;        /* [N,Cin,H,W] */
+  const float* w;        /* forward: [Cout,Cin,k,k].  transposed != 0 (data gradient): the reference filter [Cin,Cout,k,k], read flipped */
+  const float* bias;     /* [Cout] or NULL */
+  const float* mask;     /* optional [N,Cout,H,W]: the output is zeroed where mask <= 0 (ReLU backward, fused into the data gradient) */
+  const float* res;      /* optional [N,Cout,H,W] added to the output (VDSR's global residual, architectures.py:77) */
+  float* y;              /* [N,Cout,H,W] */
+  int32_t N, Cin, Cout, H, W, k;
+  int32_t relu;          /* epilogue max(.,0) (F.relu between the layers, architectures.py:50-51) */
+  int32_t transposed;
+} rumpy_dconv_args;
+int rumpy_dconv(const rumpy_dconv_args* a, void* stream);
+
+/* weight + bias gradient of such a layer: gw[o,i,ky,kx] = scale * sum_{n,y,x} dy[n,o,y,x] * x[n,i,y+ky-k/2,x+kx-k/2], gb[o] = scale * sum dy.
+ * Deterministic: S pixel slabs of partial sums, reduced in a fixed order. */
+typedef struct {
+  const float* x;        /* [N,Cin,H,W] layer input */
+  const float* dy;       /* [N,Cout,H,W] gradient at the layer's (pre-activation) output */
+  float* partial;        /* rumpy_dconv_wgrad_partial_floats(...) floats of scratch */
+  float* gw;             /* [Cout,Cin,k,k] */
+  float* gb;             /* [Cout] or NULL */
+  int32_t N, Cin, Cout, H, W, k;
+  float scale;
+} rumpy_dconv_wgrad_args;
+int rumpy_dconv_wgrad(const rumpy_dconv_wgrad_args* a, void* stream);
+int64_t rumpy_dconv_wgrad_partial_floats(int32_t N, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t k);
+
+/* nn.MSELoss (mean) and its gradient in one pass: loss = mean((out - target)^2), grad = 2 (out - target) / numel (basic/handlers.py:14) */
+typedef struct {
+  const float* out;      /* [n] */
+  const float* target;   /* [n] */
+  float* grad;           /* [n] or NULL */
+  float* partial;        /* 1024 floats of scratch */
+  float* loss;           /* [1] */
+  int64_t n;
+} rumpy_mse_args;
+int rumpy_mse_loss(const rumpy_mse_args* a, void* stream);
+
 /* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
  * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
  * 4 = rumpy_conv_chain ; 5 = rumpy_conv_block and rumpy_block_chain */

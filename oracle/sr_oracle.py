@@ -326,6 +326,34 @@ def seeded_pipeline_state(pipe, seed):
 # --------------------------------------------------------------------------------------
 # handler-level restatement: one train step / one eval step
 # --------------------------------------------------------------------------------------
+class OracleSRCNN(nn.Module):
+    """rumpy/SISR/models/basic/architectures.py:6-60: conv_0 .. conv_{d-1} (nn.Conv2d, padding k//2 for 'same'), F.relu between them,
+    none after the last; defaults 9-5-5 kernels over 1-64-32-1 channels.  Keys ``layer_dict.conv_<i>.weight|bias``."""
+    residual = False
+
+    def __init__(self, kernel_pattern=None, channel_pattern=None, padding='same'):
+        super().__init__()
+        kernel_pattern = [9, 5, 5] if kernel_pattern is None else list(kernel_pattern)
+        channel_pattern = [1, 64, 32, 1] if channel_pattern is None else list(channel_pattern)
+        pads = [k // 2 for k in kernel_pattern] if padding == 'same' else [0] * len(kernel_pattern)      # :26-29
+        self.layer_dict = nn.ModuleDict()
+        self.depth = len(kernel_pattern)
+        for i, (k, pd) in enumerate(zip(kernel_pattern, pads)):
+            self.layer_dict['conv_%d' % i] = nn.Conv2d(channel_pattern[i], channel_pattern[i + 1], kernel_size=k, padding=pd)
+
+    def forward(self, x):
+        out = x
+        for i in range(self.depth):                       # :47-52
+            out = self.layer_dict['conv_%d' % i](out)
+            if i != self.depth - 1:
+                out = F.relu(out)
+        return out + x if self.residual else out          # VDSR :66-77: torch.add(out, residual)
+
+
+class OracleVDSR(OracleSRCNN):
+    residual = True
+
+
 class OracleHandler:
     """Restates BaseModel for the L1 + Adam (+ optional per-batch scheduler) configuration.
 
@@ -340,11 +368,11 @@ class OracleHandler:
     """
 
     def __init__(self, net, lr=1e-4, scheduler=None, scheduler_params=None, optimizer_params=None,
-                 grad_clip=None, eval_mode=False):
+                 grad_clip=None, eval_mode=False, criterion='l1'):
         self.net = net
         self.eval_mode = eval_mode
         self.grad_clip = None if grad_clip == 0 else grad_clip
-        self.criterion = nn.L1Loss()
+        self.criterion = nn.MSELoss() if criterion == 'mse' else nn.L1Loss()      # basic/handlers.py:14,31 use nn.MSELoss
         self.optimizer = None
         self.learning_rate_scheduler = None
         if not eval_mode:
@@ -423,6 +451,13 @@ def build_oracle(name, **internal_params):
         q = dict(p)
         q['num_metadata'] = p.get('encoder_output_size', 256)
         return OracleBlindPipeline(build_oracle('qrcan', **q))
+    if name in ('srcnn', 'vdsr'):
+        # SRCNNHandler / VDSRHandler basic/handlers.py:6-35 (VDSR defaults: 20 x 3x3, 1-64..64-1 channels)
+        kp, cp = p.get('kernel_pattern'), p.get('channel_pattern')
+        if name == 'vdsr':
+            kp = [3] * 20 if kp is None else kp
+            cp = [1] + [64] * 19 + [1] if cp is None else cp
+        return (OracleVDSR if name == 'vdsr' else OracleSRCNN)(kernel_pattern=kp, channel_pattern=cp, padding=p.get('padding', 'same'))
     raise KeyError(name)
 
 

@@ -230,18 +230,22 @@ class HipSRNet(nn.Module):
         # backward launches, so that run_train's `loss.cpu().numpy()` (the reference API returns the loss of every step,
         # base_architecture.py:482-485) waits for the forward pass only and the host can queue the next step while the GPU
         # still runs this step's backward pass and optimizer.
+        self._stage_loss(loss, plan.rcab_status)
+        self.engine.backward(plan, 1.0 / out.numel(), on_ready=getattr(self, 'grad_ready_hook', None))
+        return loss, out
+
+    def _stage_loss(self, loss, status=None):
+        """Queue the read-back of a step's loss (and the strip-exchange watchdog word) into pinned memory, fenced by an event."""
         if self._loss_host is None:
             self._loss_host = torch.empty(1, dtype=torch.float32).pin_memory()
             self._loss_event = torch.cuda.Event()
-        self._loss_host.copy_(loss, non_blocking=True)
-        if plan.rcab_status is not None:          # strip-exchange watchdog of the one-launch RCAB kernels, read back with the loss
+        self._loss_host.copy_(loss.reshape(1), non_blocking=True)
+        if status is not None:          # strip-exchange watchdog of the one-launch RCAB kernels, read back with the loss
             if getattr(self, '_status_host', None) is None:
                 self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._status_host.copy_(plan.rcab_status, non_blocking=True)
+            self._status_host.copy_(status, non_blocking=True)
         self._loss_event.record()
         self.early_loss = True
-        self.engine.backward(plan, 1.0 / out.numel(), on_ready=getattr(self, 'grad_ready_hook', None))
-        return loss, out
 
     def take_early_loss(self):
         """-> 0-d float32 ndarray of the last fused step's loss (waits for its forward pass only), or None."""

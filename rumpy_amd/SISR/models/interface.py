@@ -43,10 +43,30 @@ class SISRInterface:
         return self.model.run_train(x=lr, y=hr, **kwargs)
 
     def net_run_and_process(self, lr=None, hr=None, **kwargs):
-        """-> (rgb ndarray clipped to [0,1], ycbcr ndarray, loss, timing), 'rgb' colourspace branch of interface.py:109-112."""
+        """-> (rgb ndarray, ycbcr ndarray, loss, timing).  'rgb' models (interface.py:109-112): clip + RGB->YCbCr('jpg') in a HIP kernel.
+        'ycbcr' models (SRCNN / VDSR, :113-121): the network sees the Y plane only; Cb / Cr come from the (interpolated) input, the
+        stack is clipped to [0,1] and converted back with the JPEG matrix - per-pixel host arithmetic on the returned image, as in
+        the reference (the RGB result is NOT clipped again there, and is not here)."""
+        if 'rgb' not in self.configuration['colorspace']:
+            f_ref = None if hr is None else hr[:, 0, :, :].unsqueeze(1)
+            out_y, loss, timing = self.model.run_eval(lr[:, 0, :, :].unsqueeze(1), y=f_ref, **kwargs)
+            ycbcr = np.clip(torch.stack([out_y.squeeze(1).cpu(), lr[:, 1, :, :].cpu(), lr[:, 2, :, :].cpu()], 1).numpy(), 0, 1)
+            return self.ycbcr_jpg_to_rgb(ycbcr), ycbcr, loss, timing
         out_rgb, loss, timing = self.model.run_eval(x=lr, y=hr, keep_on_device=True, **kwargs)
         rgb, ycbcr, _ = self.postprocess(out_rgb)
         return rgb.cpu().numpy(), ycbcr.cpu().numpy(), loss, timing
+
+    @staticmethod
+    def ycbcr_jpg_to_rgb(img, max_val=1.0):
+        """[N,3,H,W] YCbCr -> RGB with the full-range JPEG (BT.601) matrix, chroma bias 128/255 of the range
+        (image_functions.py:108-121 with im_type='jpg', which is what colorspace_convert passes, base_interface.py:212)."""
+        img = np.asarray(img, dtype=np.float32)
+        bias = 128. * (max_val / 255)
+        y, cb, cr = img[:, 0], img[:, 1], img[:, 2]
+        r = y + 1.402 * cr - 1.402 * bias
+        g = y - 0.344136 * cb - 0.714136 * cr + (0.714136 + 0.344136) * bias
+        b = y + 1.772 * cb - 1.772 * bias
+        return np.stack([r, g, b], 1).astype(np.float32)
 
     @staticmethod
     def postprocess(out, ref=None):

@@ -204,6 +204,22 @@ class PatchArgs(_S):
                 ('N', c_int32), ('C', c_int32), ('crop', c_int32), ('scale', c_int32)]
 
 
+class DconvArgs(_S):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('mask', c_void_p), ('res', c_void_p), ('y', c_void_p),
+                ('N', c_int32), ('Cin', c_int32), ('Cout', c_int32), ('H', c_int32), ('W', c_int32), ('k', c_int32),
+                ('relu', c_int32), ('transposed', c_int32)]
+
+
+class DconvWgradArgs(_S):
+    _fields_ = [('x', c_void_p), ('dy', c_void_p), ('partial', c_void_p), ('gw', c_void_p), ('gb', c_void_p),
+                ('N', c_int32), ('Cin', c_int32), ('Cout', c_int32), ('H', c_int32), ('W', c_int32), ('k', c_int32),
+                ('scale', c_float)]
+
+
+class MseArgs(_S):
+    _fields_ = [('out', c_void_p), ('target', c_void_p), ('grad', c_void_p), ('partial', c_void_p), ('loss', c_void_p), ('n', c_int64)]
+
+
 # every symbol include/rumpy_amd.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 SYMBOLS = {
@@ -255,6 +271,10 @@ SYMBOLS = {
     'rumpy_ssim': (C.c_int, [_P(SsimArgs), c_void_p]),
     'rumpy_ssim_partial_floats': (c_int64, [c_int32, c_int32, c_int32]),
     'rumpy_patch_gather': (C.c_int, [_P(PatchArgs), c_void_p]),
+    'rumpy_dconv': (C.c_int, [_P(DconvArgs), c_void_p]),
+    'rumpy_dconv_wgrad': (C.c_int, [_P(DconvWgradArgs), c_void_p]),
+    'rumpy_dconv_wgrad_partial_floats': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    'rumpy_mse_loss': (C.c_int, [_P(MseArgs), c_void_p]),
     'rumpy_probe_begin': (C.c_int, [C.c_int, C.c_int]),
     'rumpy_probe_end': (C.c_int, [_P(C.c_double)]),
 }

@@ -223,7 +223,12 @@ class BaseModel(nn.Module):
         return gen if isinstance(gen, HipSRNet) else None
 
     def _fused_l1(self):
-        return self._hip_net() is not None and type(self.criterion) is nn.L1Loss and not self.loss_masking
+        hip = self._hip_net()
+        return hip is not None and getattr(hip, 'supports_fused_l1', True) and type(self.criterion) is nn.L1Loss and not self.loss_masking
+
+    def _fused_mse(self):
+        """SRCNN / VDSR (basic/handlers.py:14,31: nn.MSELoss): forward + loss + backward as one pass of the direct-convolution engine"""
+        return hasattr(self.net, 'fused_mse_forward_backward') and type(self.criterion) is nn.MSELoss and not self.loss_masking
 
     def run_train(self, x, y, tag=None, mask=None, keep_on_device=False, scheduler_skip=False, *args, **kwargs):
         """-> (loss ndarray, out tensor (CPU unless keep_on_device)) as :457-485."""
@@ -234,6 +239,9 @@ class BaseModel(nn.Module):
         x, y = x.to(device=dev, non_blocking=True), y.to(device=dev, non_blocking=True)
         if self._fused_l1():
             loss, out = self.net.fused_l1_forward_backward(x, y, metadata=kwargs.get('extra_channels'))
+            self._apply_update(scheduler_skip)
+        elif self._fused_mse():
+            loss, out = self.net.fused_mse_forward_backward(x, y)
             self._apply_update(scheduler_skip)
         else:
             out = self.run_model(x, image_names=tag, **kwargs)
@@ -264,6 +272,8 @@ class BaseModel(nn.Module):
                 tic = time.perf_counter()
             if want_loss and self._fused_l1():
                 out, loss_t = self.net.l1_eval(x, y.to(device=dev), metadata=kwargs.get('extra_channels'))
+            elif want_loss and self._fused_mse():
+                out, loss_t = self.net.mse_eval(x, y.to(device=dev))
             else:
                 out = self.run_model(x, image_names=tag, **kwargs)
                 loss_t = self.find_loss(out, y.to(device=dev)) if want_loss else None

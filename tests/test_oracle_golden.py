@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import sr_oracle as O
@@ -287,3 +288,46 @@ def test_g14_qrcan_default_modulate_style_matches_reference_handler(golden_dir):
     xe, ye = O.synthetic_batch(880, 1, lr_hw=10, scale=2)
     ev, evl, _ = h.run_eval(xe, ye, request_loss=True, extra_channels=attr(881, 1))
     assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
+
+
+BASIC_CASES = {'srcnn': dict(kw={}, clip=None),
+               'vdsr': dict(kw=dict(kernel_pattern=[3, 3, 3, 3], channel_pattern=[1, 8, 8, 8, 1]), clip=0.1)}
+
+
+def basic_y_batch(seed, n, h, w):
+    g = np.random.default_rng(seed)
+    return (torch.from_numpy(g.uniform(0, 1, (n, 1, h, w)).astype(np.float32)),
+            torch.from_numpy(g.uniform(0, 1, (n, 1, h, w)).astype(np.float32)))
+
+
+@pytest.mark.parametrize('name', ['srcnn', 'vdsr'])
+def test_g15_basic_models_oracle_matches_reference_handlers(golden_dir, name):
+    """oracle SRCNN (BASELINE config 0) / VDSR and the handler-level step (MSE, Adam, VDSR's grad_clip 0.1, per-batch cosine restarts)
+    against three training steps and one evaluation of the REAL reference handlers (tests/golden/make_golden_basic.py)."""
+    g = np.load(os.path.join(golden_dir, 'g15_basic_small_train.npz'))
+    case = BASIC_CASES[name]
+    torch.manual_seed(8)
+    net = O.build_oracle(name, **case['kw'])
+    assert list(net.state_dict().keys()) == [str(k) for k in g[name + '.keys']]
+    init8 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in net.state_dict().values()])
+    assert np.allclose(init8, g[name + '.init8'], rtol=0, atol=1e-12)
+    assert [str(a) for a in g[name + '.attrs']] == ['ycbcr', 'interp', name, 'MSELoss', str(case['clip'])]
+    net.load_state_dict(O.seeded_state_dict(net, 840))
+    h = O.OracleHandler(net, lr=1e-3, scheduler='cosine_annealing_warm_restarts', criterion='mse', grad_clip=case['clip'],
+                        scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+    for step in range(3):
+        xb, yb = basic_y_batch(850 + step, 2, 20, 27)
+        loss, out = h.run_train(xb, yb)
+        assert abs(float(loss) - float(g['%s.loss%d' % (name, step)])) < 1e-6
+        assert abs(h.get_learning_rate() - float(g['%s.lr_after%d' % (name, step)])) < 1e-12
+        if step == 0:
+            assert np.allclose(out.numpy(), g[name + '.out0'], atol=1e-6)
+            for k, p in net.named_parameters():
+                assert np.allclose(p.grad.numpy(), g['%s.grad0.%s' % (name, k)], atol=1e-7, rtol=1e-4), k
+            for k, v in net.state_dict().items():
+                assert np.allclose(v.numpy(), g['%s.w1.%s' % (name, k)], atol=1e-6), k
+    for k, v in net.state_dict().items():
+        assert np.allclose(v.numpy(), g['%s.w3.%s' % (name, k)], atol=2e-6), k
+    xe, ye = basic_y_batch(890, 1, 33, 18)
+    ev, evl, _ = h.run_eval(xe, ye, request_loss=True)
+    assert np.allclose(ev.numpy(), g[name + '.eval_out'], atol=1e-6) and abs(float(evl) - float(g[name + '.eval_loss'])) < 1e-6
