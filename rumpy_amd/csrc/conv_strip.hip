@@ -27,7 +27,7 @@ constexpr int SREGS = (SPIECES + STHREADS - 1) / STHREADS;            // 7 per t
 struct StripDev {
   const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
   const uint16_t* mask; const uint16_t* res1; const uint16_t* res2; float* pool;
-  int N, H, W, cout_tiles, in_mode, out_mode, relu; float scale; int sx_n, sy_n;
+  int N, H, W, cout_tiles, in_mode, out_mode, relu; float scale; int sx_n, sy_n, skew;
 };
 
 struct StripCoord { int n, sy, sx; };
@@ -124,111 +124,19 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
   const uint16_t* p1 = a.mask ? a.res1 : a.res2;
   const uint16_t* p2 = (a.mask && a.res1) ? a.res2 : nullptr;   // only when all three are given (not prefetched)
   int buf = 0;
+  // Phase skew (persistent launches): the two waves that share a SIMD would run MFMAs together and then their epilogues together - the
+  // matrix pipe idles during every epilogue.  Waves selected by a.skew DEFER the epilogue of strip i to the start of iteration i+1
+  // (the accumulators stay in registers over the barrier), so that on each SIMD one wave's epilogue runs under the other's MFMAs.
+  const bool skewed = !STAMP && CHUNKS == 1 && a.skew != 0 &&
+                      (((a.skew == 1) ? (wave >> 2) : (a.skew == 2) ? wave : (wave >> 1)) & 1);
+  bool pending = false;                 // a deferred epilogue is outstanding
+  unsigned poff[4], soff;
+  uint4 P0p[4], P1p[4];
+  uint2 P0s, P1s;
+  f32x4 acc[3][3];
+  float* pool_ptr = nullptr;
 
-  for (; strip < nstrips; strip += gridDim.x) {
-    const StripCoord sc = decode_strip(strip, a.sx_n, a.sy_n);
-    // Epilogue geometry.  The MFMA leaves 4 channels x 1 pixel per lane (8 B); stores that narrow are issue-bound, so tiles
-    // are processed in PAIRS (X, Y): lanes with even g trade their Y values for the neighbour lane's (g+1) X values
-    // (one __shfl_xor(.,16) per dword) and end up with 8 consecutive channels of X's pixel, odd-g lanes with 8 channels
-    // of Y's pixel -> every global access of the epilogue is a 16-byte vector.  4 pairs + 1 single tile per wave:
-    //   pair k<3: X = (row k, col tile 0), Y = (row k, col tile 1); pair 3: X = (0, 2), Y = (1, 2); single: (2, 2).
-    unsigned poff[4], soff;
-    uint4 P0p[4], P1p[4];
-    uint2 P0s, P1s;
-    f32x4 acc[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc[r][c] = bias4;
-
-    unsigned char* stage = lds;
-    bool has_next = false;
-#pragma unroll
-    for (int ch = 0; ch < CHUNKS; ++ch) {
-      // prefetch the next stage: next input chunk of this strip, or chunk 0 of the next strip
-      const int nstrip = (ch + 1 < CHUNKS) ? strip : strip + (int)gridDim.x;
-      const int nch = (ch + 1 < CHUNKS) ? ch + 1 : 0;
-      has_next = nstrip < nstrips;
-      if (has_next) strip_issue<CHUNKS>(R, a.x, a.in_mode, nch, decode_strip(nstrip, a.sx_n, a.sy_n), a.H, a.W, tid);
-      if (ch == CHUNKS - 1) {
-        // element offsets (0xffffffff = outside the image) + prefetch of the mask / residual vectors
-        auto pix_off = [&](int r, int c) -> unsigned {
-          const int y = sc.sy * SH + 3 * rh + r, xx = sc.sx * SW + 16 * c + px;
-          if (y >= a.H || xx >= a.W) return 0xffffffffu;
-          if (a.out_mode == 0) return (unsigned)(((sc.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + 16 * q);
-          return (unsigned)(((sc.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + 16 * q);
-        };
-        const int gpair = 4 * (g & ~1);                    // first of this lane's 8 channels inside the wave's 16
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned ox = (k < 3) ? pix_off(k, 0) : pix_off(0, 2);
-          const unsigned oy = (k < 3) ? pix_off(k, 1) : pix_off(1, 2);
-          const unsigned o = (g & 1) ? oy : ox;
-          poff[k] = (o != 0xffffffffu) ? o + gpair : 0xffffffffu;
-          const unsigned oc = (o != 0xffffffffu) ? o + gpair : 0u;   // clamped: the prefetch loads are unconditional
-          P0p[k] = make_uint4(0, 0, 0, 0); P1p[k] = make_uint4(0, 0, 0, 0);
-          if (p0) P0p[k] = *reinterpret_cast<const uint4*>(p0 + oc);
-          if (p1) P1p[k] = *reinterpret_cast<const uint4*>(p1 + oc);
-        }
-        {
-          const unsigned o = pix_off(2, 2);
-          soff = (o != 0xffffffffu) ? o + 4 * g : 0xffffffffu;
-          const unsigned oc = (o != 0xffffffffu) ? o + 4 * g : 0u;
-          P0s = make_uint2(0, 0); P1s = make_uint2(0, 0);
-          if (p0) P0s = *reinterpret_cast<const uint2*>(p0 + oc);
-          if (p1) P1s = *reinterpret_cast<const uint2*>(p1 + oc);
-        }
-      }
-      stage = lds + buf * SSTAGE;
-      {
-        // 18 groups (channel half, tap column, column tile) of 5 B-fragment reads + 9 MFMAs, software pipelined: the
-        // reads of group i+1 are issued before the MFMAs of group i (two fragment sets), so LDS and the matrix pipe
-        // overlap inside one wave instead of alternating (measured: 2.1 us of reads + 2.3 us of MFMAs otherwise add up)
-        const unsigned char* wbase = stage + (3 * rh * SCOLS + px) * HSTRIDE + g * 16;
-        bf16x8 I[2][5];
-        auto load_group = [&](int grp, bf16x8 (&dst)[5]) {
-          const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
-          const unsigned char* cur = wbase + half * HHALF + (16 * c + kx) * HSTRIDE;
-#pragma unroll
-          for (int r = 0; r < 5; ++r) {
-            if (DBG == 1) dst[r] = F[r];
-            else dst[r] = *reinterpret_cast<const bf16x8*>(cur + r * SCOLS * HSTRIDE);
-          }
-        };
-        load_group(0, I[0]);
-#pragma unroll
-        for (int grp = 0; grp < 18; ++grp) {
-          if (grp + 1 < 18) load_group(grp + 1, I[(grp + 1) & 1]);
-          __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads AHEAD of this group's MFMAs (hipcc sinks them otherwise)
-          const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
-          if (DBG == 2) {
-#pragma unroll
-            for (int r = 0; r < 5; ++r) asm volatile("" :: "v"(I[grp & 1][r]));
-          } else {
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-              for (int r = 0; r < 3; ++r)
-                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
-          }
-        }
-      }
-      if (CHUNKS > 1 && has_next) {     // filter fragments of the next stage (L2 hits) land under the hand-over below
-#pragma unroll
-        for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wbase[(size_t)nch * (4 * 18 * 64) + t * 64]);
-      }
-      if (ch + 1 < CHUNKS) {            // not the last chunk: hand the LDS buffers over and continue accumulating
-        if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
-        __syncthreads();
-        buf ^= 1;
-      }
-    }
-    STAMP_HERE();                       // 3: MFMAs issued
-    // The next strip's registers go to the other LDS buffer HERE, before the epilogue: a wait for them issued behind the
-    // epilogue's stores would have to drain those stores first (the persistent upsampler launches run 16 strips per
-    // workgroup; the single-strip 64 -> 64 launches have no next strip).
-    if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
-    STAMP_HERE();                       // 4: next strip staged
+  auto epilogue = [&]() {
     // ---- epilogue ----
     float ps[4] = {0.f, 0.f, 0.f, 0.f};              // single tile: channels 4g .. 4g+3 of this wave's 16
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // paired tiles: channels 4(g&~1) .. +7
@@ -342,16 +250,123 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
         ps8[4 + j] += (g & 1) ? t : up;                  // channels 4(g&~1) + 4 + j belong to the odd group
       }
       if (px == 0 && !(g & 1)) {
-        float* pp = a.pool + ((size_t)(sc.n * a.sy_n * 2 + 2 * sc.sy + rh) * a.sx_n + sc.sx) * (64 * a.cout_tiles) + ct * 64 + 16 * q + 4 * g;
+        float* pp = pool_ptr;
         *reinterpret_cast<float4*>(pp) = make_float4(ps8[0], ps8[1], ps8[2], ps8[3]);
         *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
       }
     }
+  };
+
+  for (; strip < nstrips; strip += gridDim.x) {
+    const StripCoord sc = decode_strip(strip, a.sx_n, a.sy_n);
+    // Epilogue geometry.  The MFMA leaves 4 channels x 1 pixel per lane (8 B); stores that narrow are issue-bound, so tiles
+    // are processed in PAIRS (X, Y): lanes with even g trade their Y values for the neighbour lane's (g+1) X values
+    // (one __shfl_xor(.,16) per dword) and end up with 8 consecutive channels of X's pixel, odd-g lanes with 8 channels
+    // of Y's pixel -> every global access of the epilogue is a 16-byte vector.  4 pairs + 1 single tile per wave:
+    //   pair k<3: X = (row k, col tile 0), Y = (row k, col tile 1); pair 3: X = (0, 2), Y = (1, 2); single: (2, 2).
+    if (skewed && pending) epilogue();       // strip i-1, under the other wave's MFMAs of strip i
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = bias4;
+    if (a.pool) pool_ptr = a.pool + ((size_t)(sc.n * a.sy_n * 2 + 2 * sc.sy + rh) * a.sx_n + sc.sx) * (64 * a.cout_tiles) + ct * 64 + 16 * q + 4 * g;
+
+    unsigned char* stage = lds;
+    bool has_next = false;
+#pragma unroll
+    for (int ch = 0; ch < CHUNKS; ++ch) {
+      // prefetch the next stage: next input chunk of this strip, or chunk 0 of the next strip
+      const int nstrip = (ch + 1 < CHUNKS) ? strip : strip + (int)gridDim.x;
+      const int nch = (ch + 1 < CHUNKS) ? ch + 1 : 0;
+      has_next = nstrip < nstrips;
+      if (has_next) strip_issue<CHUNKS>(R, a.x, a.in_mode, nch, decode_strip(nstrip, a.sx_n, a.sy_n), a.H, a.W, tid);
+      if (ch == CHUNKS - 1) {
+        // element offsets (0xffffffff = outside the image) + prefetch of the mask / residual vectors
+        auto pix_off = [&](int r, int c) -> unsigned {
+          const int y = sc.sy * SH + 3 * rh + r, xx = sc.sx * SW + 16 * c + px;
+          if (y >= a.H || xx >= a.W) return 0xffffffffu;
+          if (a.out_mode == 0) return (unsigned)(((sc.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + 16 * q);
+          return (unsigned)(((sc.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + 16 * q);
+        };
+        const int gpair = 4 * (g & ~1);                    // first of this lane's 8 channels inside the wave's 16
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned ox = (k < 3) ? pix_off(k, 0) : pix_off(0, 2);
+          const unsigned oy = (k < 3) ? pix_off(k, 1) : pix_off(1, 2);
+          const unsigned o = (g & 1) ? oy : ox;
+          poff[k] = (o != 0xffffffffu) ? o + gpair : 0xffffffffu;
+          const unsigned oc = (o != 0xffffffffu) ? o + gpair : 0u;   // clamped: the prefetch loads are unconditional
+          P0p[k] = make_uint4(0, 0, 0, 0); P1p[k] = make_uint4(0, 0, 0, 0);
+          if (p0) P0p[k] = *reinterpret_cast<const uint4*>(p0 + oc);
+          if (p1) P1p[k] = *reinterpret_cast<const uint4*>(p1 + oc);
+        }
+        {
+          const unsigned o = pix_off(2, 2);
+          soff = (o != 0xffffffffu) ? o + 4 * g : 0xffffffffu;
+          const unsigned oc = (o != 0xffffffffu) ? o + 4 * g : 0u;
+          P0s = make_uint2(0, 0); P1s = make_uint2(0, 0);
+          if (p0) P0s = *reinterpret_cast<const uint2*>(p0 + oc);
+          if (p1) P1s = *reinterpret_cast<const uint2*>(p1 + oc);
+        }
+      }
+      stage = lds + buf * SSTAGE;
+      {
+        // 18 groups (channel half, tap column, column tile) of 5 B-fragment reads + 9 MFMAs, software pipelined: the
+        // reads of group i+1 are issued before the MFMAs of group i (two fragment sets), so LDS and the matrix pipe
+        // overlap inside one wave instead of alternating (measured: 2.1 us of reads + 2.3 us of MFMAs otherwise add up)
+        const unsigned char* wbase = stage + (3 * rh * SCOLS + px) * HSTRIDE + g * 16;
+        bf16x8 I[2][5];
+        auto load_group = [&](int grp, bf16x8 (&dst)[5]) {
+          const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+          const unsigned char* cur = wbase + half * HHALF + (16 * c + kx) * HSTRIDE;
+#pragma unroll
+          for (int r = 0; r < 5; ++r) {
+            if (DBG == 1) dst[r] = F[r];
+            else dst[r] = *reinterpret_cast<const bf16x8*>(cur + r * SCOLS * HSTRIDE);
+          }
+        };
+        load_group(0, I[0]);
+#pragma unroll
+        for (int grp = 0; grp < 18; ++grp) {
+          if (grp + 1 < 18) load_group(grp + 1, I[(grp + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads AHEAD of this group's MFMAs (hipcc sinks them otherwise)
+          const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+          if (DBG == 2) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) asm volatile("" :: "v"(I[grp & 1][r]));
+          } else {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+              for (int r = 0; r < 3; ++r)
+                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
+          }
+        }
+      }
+      if (CHUNKS > 1 && has_next) {     // filter fragments of the next stage (L2 hits) land under the hand-over below
+#pragma unroll
+        for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wbase[(size_t)nch * (4 * 18 * 64) + t * 64]);
+      }
+      if (ch + 1 < CHUNKS) {            // not the last chunk: hand the LDS buffers over and continue accumulating
+        if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+    STAMP_HERE();                       // 3: MFMAs issued
+    // The next strip's registers go to the other LDS buffer HERE, before the epilogue: a wait for them issued behind the
+    // epilogue's stores would have to drain those stores first (the persistent upsampler launches run 16 strips per
+    // workgroup; the single-strip 64 -> 64 launches have no next strip).
+    if (has_next) strip_write(R, lds + (buf ^ 1) * SSTAGE, tid);
+    // (issuing the loads of the strip after the next one here, one iteration earlier, measured 8 % SLOWER on the 96x96 launches)
+    STAMP_HERE();                       // 4: next strip staged
+    if (skewed) pending = true; else epilogue();
     __syncthreads();
     STAMP_HERE();                       // 5: epilogue done
     buf ^= 1;
     if (STAMP) break;
   }
+  if (skewed && pending) epilogue();
   if (STAMP && lane == 0) {
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.pool) + ((size_t)blockIdx.x * 8 + wave) * 8;
     for (int i = 0; i < 8; ++i) dbg[i] = (i < nst) ? stamps[i] : 0ull;
@@ -373,6 +388,7 @@ int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s) {
   d.N = p->N; d.H = p->H; d.W = p->W; d.cout_tiles = p->cout_tiles; d.in_mode = p->in_mode; d.out_mode = p->out_mode;
   d.relu = p->relu; d.scale = p->scale; d.sx_n = cdiv(p->W, SW); d.sy_n = cdiv(p->H, SH);
   const int nstrips = d.N * d.sx_n * d.sy_n;
+  static const int skew_env = getenv("RUMPY_STRIP_SKEW") ? atoi(getenv("RUMPY_STRIP_SKEW")) : 1;   // 0 = off (A/B runs)
   int gx = p->grid_x;
   if (gx <= 0) {
     const int slots = rumpy_device_cus() / p->cout_tiles > 0 ? rumpy_device_cus() / p->cout_tiles : 1;
@@ -380,6 +396,8 @@ int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s) {
     gx = cdiv(nstrips, rounds);
   }
   if (gx > nstrips) gx = nstrips;
+  d.skew = (gx < nstrips) ? skew_env : 0;         // only where a workgroup runs several strips
+
   if (p->relu >= 0x5754 && p->relu <= 0x5756) {   // diagnostic stamp builds (rumpy_debug_conv_stamps)
     const int dbg = p->relu - 0x5754;
     d.relu = 0;
