@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
   // Phase skew (persistent launches): the two waves that share a SIMD would run MFMAs together and then their epilogues together - the
   // matrix pipe idles during every epilogue.  Waves selected by a.skew DEFER the epilogue of strip i to the start of iteration i+1
   // (the accumulators stay in registers over the barrier), so that on each SIMD one wave's epilogue runs under the other's MFMAs.
-  const bool skewed = !STAMP && CHUNKS == 1 && a.skew != 0 &&
+  const bool skewed = !STAMP && a.skew != 0 &&
                       (((a.skew == 1) ? (wave >> 2) : (a.skew == 2) ? wave : (wave >> 1)) & 1);
   bool pending = false;                 // a deferred epilogue is outstanding
   unsigned poff[4], soff;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
 
     unsigned char* stage = lds;
     bool has_next = false;
-#pragma unroll
+#pragma unroll 1
     for (int ch = 0; ch < CHUNKS; ++ch) {
       // prefetch the next stage: next input chunk of this strip, or chunk 0 of the next strip
       const int nstrip = (ch + 1 < CHUNKS) ? strip : strip + (int)gridDim.x;
@@ -344,6 +344,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
         }
       }
       if (CHUNKS > 1 && has_next) {     // filter fragments of the next stage (L2 hits) land under the hand-over below
+        __builtin_amdgcn_sched_barrier(0);   // not above the MFMAs that still read the current fragments (a second set would spill)
 #pragma unroll
         for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wbase[(size_t)nch * (4 * 18 * 64) + t * 64]);
       }

@@ -63,6 +63,32 @@ def test_conv3x3_forward_persistent_grid_variants():
         assert torch.equal(o, base), gx
 
 
+def test_conv3x3_persistent_launches_with_every_epilogue_are_bitwise_the_one_strip_launch():
+    """persistent launches (a workgroup runs several strips) defer the epilogue of half the waves to the next iteration (phase skew,
+    DESIGN.md 4.1 (5)): mask, residuals, pool partials, ReLU + scale, and the 64 -> 256 PixelShuffle store must come out bit for bit
+    as from the launch with one strip per workgroup - for one, several and a ragged number of strips per workgroup."""
+    gen = np.random.default_rng(14)
+    N, H, W = 3, 26, 52
+    w, b = _wb(gen, 64, 64)
+    x, r1, r2, m = (nhwc(_rand(gen, N, 64, H, W)) for _ in range(4))
+    pc = PackedConv(w, b)
+    variants = [dict(relu=True, scale=0.5), dict(scale=0.1, res1=r1, pool=True), dict(res1=r1, res2=r2),
+                dict(use_bias=False, scale=0.1, mask=m, res1=r1, res2=r2), dict(mask=m, pool=True)]
+    for kw in variants:
+        base, bp = hip_conv(x, pc, N, H, W, grid_x=10 ** 6, **kw)          # clamped to the strip count: one strip per workgroup
+        for gx in (1, 4, 7):
+            o, pl = hip_conv(x, pc, N, H, W, grid_x=gx, **kw)
+            assert torch.equal(o, base), (sorted(kw), gx)
+            if bp is not None:
+                assert torch.equal(pl, bp), (sorted(kw), gx)
+    w4, b4 = _wb(gen, 256, 64)
+    pc4 = PackedConv(w4, b4, 0, True)
+    base, _ = hip_conv(x, pc4, N, H, W, out_mode=1, grid_x=10 ** 6)
+    for gx in (1, 5):
+        o, _ = hip_conv(x, pc4, N, H, W, out_mode=1, grid_x=gx)
+        assert torch.equal(o, base), gx
+
+
 def test_conv3x3_epilogue_relu_scale_residuals_mask_pool():
     gen = np.random.default_rng(12)
     N, H, W = 2, 20, 18
