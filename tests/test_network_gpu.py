@@ -454,17 +454,23 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     assert d['roofline'] is not None and d['roofline']['launches_timed'] > 0
 
 
-def test_free_running_training_equals_step_synchronised_training():
+@pytest.mark.parametrize('name,kw,N', [
+    ('edsr', dict(scale=4), 32),
+    ('rcan', dict(scale=4, n_resgroups=2, n_resblocks=4), 32),
+    ('contrastiveblindqrcan', dict(scale=4, n_resgroups=2, n_resblocks=3, style='standard', include_q_layer=True, block_encoder_loading=True,
+                                   selective_meta_blocks=[True, False], num_q_layers_inner_residual=1), 16)])
+def test_free_running_training_equals_step_synchronised_training(name, kw, N):
     """run_train waits for the forward pass only, so the host queues step i+1 while the GPU still runs step i's backward pass and Adam.
     Everything the host rewrites per step must therefore be private to that step (the Adam hyper-parameters once travelled through ONE
     pinned buffer: the copy of step i could pick up the bias corrections of step i+1).  Headline-size EDSR, first steps (where the bias
-    corrections move most): weights after 6 free-running steps == weights after 6 steps with a device synchronise after each, bitwise."""
+    corrections move most): weights after 6 free-running steps == weights after 6 steps with a device synchronise after each, bitwise.
+    Also for the one-launch RCAB kernels (exchange epochs advance per pass) and the blind pipeline (encoder BatchNorm statistics)."""
     res = []
-    batches = [tuple(t.cuda() for t in O.synthetic_batch(900 + i, 32, lr_hw=48, scale=4)) for i in range(6)]
+    batches = [tuple(t.cuda() for t in O.synthetic_batch(900 + i, N, lr_hw=48, scale=4)) for i in range(6)]
     for sync in (True, False):
         torch.manual_seed(8)
-        h = _handler('edsr', scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
-                     scheduler_params={'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7})
+        h = _handler(name, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
+                     scheduler_params={'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}, **kw)
         losses = []
         for xd, yd in batches:                       # already in HBM: nothing in the loop waits for the device but run_train itself
             loss, _ = h.run_train(x=xd, y=yd, keep_on_device=True)
@@ -472,9 +478,11 @@ def test_free_running_training_equals_step_synchronised_training():
             if sync:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
-        res.append((losses, h.net.flat_p.detach().clone()))
+        # every tensor of the model: weights, and for the blind pipeline the encoder's BatchNorm running statistics (updated per step)
+        res.append((losses, [v.detach().clone() for v in h.net.state_dict().values()]))
     assert res[0][0] == res[1][0], (res[0][0], res[1][0])
-    assert torch.equal(res[0][1].view(torch.int32), res[1][1].view(torch.int32))
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('model', ['edsr', 'rcan'])

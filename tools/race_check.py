@@ -22,6 +22,6 @@ def no_fence(self, i, stream=None):
 
 S.PinnedRing.__init__ = one_slot
 S.PinnedRing.sent = no_fence
-rc = pytest.main(['-q', '-x', 'tests/test_network_gpu.py', '-m', 'gpu', '-k', 'free_running'])
+rc = pytest.main(['-q', '-x', 'tests/test_network_gpu.py', '-m', 'gpu', '-k', 'free_running and edsr'])
 print('unfenced single slot: pytest exit code %d (expected: 1 = the test catches the race)' % rc)
 sys.exit(0 if rc == 1 else 1)
