@@ -26,9 +26,20 @@ HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_BYTES = 35.2e6           # FETCH_SIZE 21.9 MB + WRITE_SIZE 13.3 MB per launch
 PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv3x3_strip.md (separate rocprofv3 --pmc passes; launch with one residual operand)'
 BLOCK_PMC_TRAFFIC_BYTES = 36.25e6     # conv_block_kernel, mean of forward (35.3 MB) and data-gradient (47.5 MB) launches
-BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_step.md (tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE)'
+BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE)'
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
+
+
+def synthetic_batch(seed, n, lr_hw=48, scale=4, channels=3):
+    """"DIV2K-shaped" synthetic batch - x uniform[0,1) fp32 [n,3,48,48], y uniform[0,1) fp32 [n,3,192,192] from
+    numpy.random.default_rng(seed) (the same stream the tests draw their inputs from)."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.random((n, channels, lr_hw, lr_hw), dtype=np.float32))
+    y = torch.from_numpy(rng.random((n, channels, lr_hw * scale, lr_hw * scale), dtype=np.float32))
+    return x, y
 
 
 def main():
@@ -77,7 +88,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    from oracle import sr_oracle as O                      # synthetic-batch generator + cpu_baseline leg only
     from rumpy_amd import _lib as L
     from rumpy_amd.parallel import broadcast_parameters
     from rumpy_amd.shared_framework.models import define_model
@@ -97,7 +107,7 @@ def main():
         h.set_multi_gpu()
     pool = []
     for i in range(8):
-        x, y = O.synthetic_batch(1234 + i + 100 * rank, N, lr_hw=48, scale=4)
+        x, y = synthetic_batch(1234 + i + 100 * rank, N)
         pool.append((x.to(dev), y.to(dev)))
 
     src = None
@@ -210,7 +220,7 @@ def main():
                 roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
             elif rcabs:
                 roofline['traffic'] = 56.0e6
-                roofline['traffic_source'] = 'profiles/r01_pmc_step.md (tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
+                roofline['traffic_source'] = 'profiles/r01_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
             elif BLOCK_PMC_TRAFFIC_BYTES:
                 roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
@@ -218,6 +228,7 @@ def main():
     # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import sr_oracle as O                  # the checker, timed as the CPU baseline: the ONLY use of oracle/ in this file
         torch.manual_seed(8)
         onet = O.build_oracle({'blindqrcan': 'contrastiveblindqrcan'}.get(args.model, args.model), scale=4,
                               **{'qrcan': dict(style='standard', include_q_layer=True, num_metadata=5), 'blindqrcan': BLIND}.get(args.model, {}))
@@ -236,7 +247,7 @@ def main():
         cores = max(1, min(usable, args.cpu_threads))   # torch CPU convs stop scaling (and thrash) far below 256 threads
         torch.set_num_threads(cores)
         nb = args.cpu_batch                              # bounded sample: a few patches, same per-patch work
-        xb, yb = O.synthetic_batch(1234, nb, lr_hw=48, scale=4)
+        xb, yb = synthetic_batch(1234, nb)
         t1 = time.perf_counter()
         oh.run_train(xb, yb, extra_channels=cpu_meta)
         warm = time.perf_counter() - t1

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RUMPY_AMD_LIB: load another build of the same C ABI (kernel experiments, tools/); the default is the in-tree library
+# RUMPY_AMD_LIB: load another build of the same C ABI (kernel experiments, tests/tools/); the default is the in-tree library
 LIB_PATH = os.environ.get('RUMPY_AMD_LIB') or os.path.join(_HERE, 'librumpy_amd.so')
 
 c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float

@@ -20,7 +20,7 @@ struct ConvDev {
 };
 
 #ifndef CONV4_ABL
-#define CONV4_ABL 0     // timing experiments only (tools/build_abl.sh): results are wrong for any value but 0
+#define CONV4_ABL 0     // timing experiments only (tests/tools/build_abl.sh): results are wrong for any value but 0
 #endif
 template <int CHUNKS>
 __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(ConvDev a) {

@@ -25,7 +25,7 @@ constexpr int RC_SC1 = 16;
 constexpr unsigned RC_SPIN = 1u << 20;
 constexpr int RC_MAXR = 16;
 #ifndef RCAB_ABL
-#define RCAB_ABL 0   // timing experiments only (tools/build_abl.sh): 1 = no polling, 2 = also no product sums / tile transform in backward
+#define RCAB_ABL 0   // timing experiments only (tests/tools/build_abl.sh): 1 = no polling, 2 = also no product sums / tile transform in backward
 #endif
 
 struct RcabDev {

@@ -13,7 +13,7 @@
 //   * out-of-image pixels are fetched from a zero page; the bias gradient is one extra MFMA against a ones fragment.
 #include "common.hpp"
 #ifndef WGRAD_ABL
-#define WGRAD_ABL 0     // timing experiments only (tools/build_abl.sh): results are wrong for any value but 0
+#define WGRAD_ABL 0     // timing experiments only (tests/tools/build_abl.sh): results are wrong for any value but 0
 #endif
 
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr2;

@@ -536,7 +536,7 @@ def test_one_launch_rcab_with_more_strips_than_cus(N, monkeypatch):
 def test_training_trajectory_follows_the_oracle_on_a_learnable_task(name, kw):
     """40 Adam steps on a task that can be learnt (HR = smooth images, LR = their 2x average pooling, default-initialised weights):
     the loss of the HIP path (bf16 operands and activations) stays within 1 % of the fp32 oracle's at EVERY step while it falls by more
-    than a factor of three - rounding noise does not accumulate into a different optimisation path (tools/trajectory.py: 0.2-0.3 % over
+    than a factor of three - rounding noise does not accumulate into a different optimisation path (tests/tools/trajectory.py: 0.2-0.3 % over
     60-80 steps)."""
     torch.manual_seed(8)
     h = _handler(name, lr=2e-4, **kw)

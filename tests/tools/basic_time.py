@@ -1,5 +1,5 @@
 """Training-step time of the "basic" models (SRCNN 9-5-5 default, VDSR 20 x 3x3 default) on the direct fp32 convolution kernels, with the
-oracle (torch CPU) on the same batch beside it.  python tools/basic_time.py [N H W]"""
+oracle (torch CPU) on the same batch beside it.  python tests/tools/basic_time.py [N H W]"""
 import os
 import sys
 import tempfile
@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sr_oracle as O
 from rumpy_amd.shared_framework.models import define_model
 

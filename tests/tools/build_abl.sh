@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing experiments: builds of the kernel library with one piece of a kernel compiled out (results are WRONG).
-# usage: tools/build_abl.sh <source.hip> <MACRO> <values...>   ->  build_abl/<MACRO>_<v>/librumpy_amd.so
+# usage: tests/tools/build_abl.sh <source.hip> <MACRO> <values...>   ->  build_abl/<MACRO>_<v>/librumpy_amd.so
 set -e
 cd "$(dirname "$0")/../rumpy_amd/csrc"
 src=$1; macro=$2; shift 2

@@ -1,9 +1,9 @@
-"""Bitwise-reproducibility stress (GPU box): python tools/det_probe.py [edsr|rcan|qrcan] [reps]
+"""Bitwise-reproducibility stress (GPU box): python tests/tools/det_probe.py [edsr|rcan|qrcan] [reps]
 The same fused forward + L1 + backward pass is run `reps` times on frozen weights and inputs; the output, the loss and the whole flat
 gradient buffer must be bit-identical every time.  On a mismatch the first differing plan buffer / backward launch is reported.
 (Found: compiler-formed packed-fp32 adds in rcab_kernel<true> dropping an addend sporadically - see csrc/Makefile.)"""
 import os, sys, tempfile, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sr_oracle as O
 from rumpy_amd.shared_framework.models import define_model
 

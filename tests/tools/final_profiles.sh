@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round artefacts for profiles/: the default bench line per model, and rocprofv3 --kernel-trace --stats of the same command (EDSR, RCAN).
-# usage (GPU box): bash tools/final_profiles.sh <tag>      -> gpurun_out/final_<tag>/
+# usage (GPU box): bash tests/tools/final_profiles.sh <tag>      -> gpurun_out/final_<tag>/
 TAG=${1:-x}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final_$TAG

@@ -1,6 +1,6 @@
-"""Host (CPU) time per training step against the GPU step time (GPU box): python tools/host_time.py [edsr|rcan]"""
+"""Host (CPU) time per training step against the GPU step time (GPU box): python tests/tools/host_time.py [edsr|rcan]"""
 import os, sys, tempfile, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sr_oracle as O
 from rumpy_amd.shared_framework.models import define_model
 name = sys.argv[1] if len(sys.argv) > 1 else 'edsr'

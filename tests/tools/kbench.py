@@ -1,11 +1,11 @@
-"""Micro-benchmarks of single kernels on the bench shapes (GPU box only): python tools/kbench.py [conv|wgrad|all]"""
+"""Micro-benchmarks of single kernels on the bench shapes (GPU box only): python tests/tools/kbench.py [conv|wgrad|all]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from gpu_utils import BF16, DEV, PackedConv, hip_wgrad, stream, to_dev_bytes  # noqa: E402

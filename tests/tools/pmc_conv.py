@@ -1,7 +1,7 @@
-"""Run only the headline 64->64 conv a few times (for rocprofv3 --pmc): python tools/pmc_conv.py [H]"""
+"""Run only the headline 64->64 conv a few times (for rocprofv3 --pmc): python tests/tools/pmc_conv.py [H]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from gpu_utils import BF16, DEV, PackedConv, stream
 from rumpy_amd import _lib as L

@@ -1,6 +1,6 @@
 # HBM traffic of the block kernels (conv_block_kernel / rcab_kernel) from PMC counters, measured INSIDE the training step: separate
 # rocprofv3 --pmc passes (MI355X_MICROARCH.md: one counter group per pass, --kernel-trace only) over a short bench run.
-# usage (GPU box): bash tools/pmc_step.sh edsr|rcan
+# usage (GPU box): bash tests/tools/pmc_step.sh edsr|rcan
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 M=${1:-edsr}

@@ -1,4 +1,4 @@
-"""Per-step kernel time breakdown from a rocprofv3 kernel_stats CSV: python tools/prof_summary.py stats.csv steps"""
+"""Per-step kernel time breakdown from a rocprofv3 kernel_stats CSV: python tests/tools/prof_summary.py stats.csv steps"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])

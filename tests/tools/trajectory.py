@@ -1,6 +1,6 @@
-"""Loss trajectory of the HIP path against the CPU oracle over many steps (GPU box): python tools/trajectory.py [edsr|rcan] [steps]"""
+"""Loss trajectory of the HIP path against the CPU oracle over many steps (GPU box): python tests/tools/trajectory.py [edsr|rcan] [steps]"""
 import os, sys, tempfile, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import sr_oracle as O
 from rumpy_amd.shared_framework.models import define_model
 name = sys.argv[1] if len(sys.argv) > 1 else 'edsr'
