@@ -2,7 +2,7 @@
 # Timing experiments: builds of the kernel library with one piece of a kernel compiled out (results are WRONG).
 # usage: tests/tools/build_abl.sh <source.hip> <MACRO> <values...>   ->  build_abl/<MACRO>_<v>/librumpy_amd.so
 set -e
-cd "$(dirname "$0")/../rumpy_amd/csrc"
+cd "$(dirname "$0")/../../rumpy_amd/csrc"
 src=$1; macro=$2; shift 2
 make -s -j6
 for v in "$@"; do
