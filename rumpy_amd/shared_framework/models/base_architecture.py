@@ -24,6 +24,21 @@ from rumpy_amd.optim import FlatAdam
 from rumpy_amd.SISR.models.advanced.architectures import HipSRNet
 
 
+def _on_own_device(fn):
+    """The HIP launches of the C ABI go to the CURRENT device; the reference selects a GPU by index (`sp_gpu`, gpu_check.py:15-25) without
+    making it current.  Make the handler's device current for the duration of its compute entry points."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev = self._torch_device()
+        if dev.type == 'cuda' and torch.cuda.is_available():
+            with torch.cuda.device(dev):
+                return fn(self, *args, **kwargs)
+        return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class BaseModel(nn.Module):
     def __init__(self, device, model_save_dir, eval_mode, grad_clip=None, loss_masking=False, **kwargs):
         # unknown kwargs are accepted and ignored, like base_architecture.py:24
@@ -230,6 +245,7 @@ class BaseModel(nn.Module):
         """SRCNN / VDSR (basic/handlers.py:14,31: nn.MSELoss): forward + loss + backward as one pass of the direct-convolution engine"""
         return hasattr(self.net, 'fused_mse_forward_backward') and type(self.criterion) is nn.MSELoss and not self.loss_masking
 
+    @_on_own_device
     def run_train(self, x, y, tag=None, mask=None, keep_on_device=False, scheduler_skip=False, *args, **kwargs):
         """-> (loss ndarray, out tensor (CPU unless keep_on_device)) as :457-485."""
         if self.eval_mode:
@@ -259,6 +275,7 @@ class BaseModel(nn.Module):
             return loss_np, keep
         return loss_np, out.detach().cpu()
 
+    @_on_own_device
     def run_eval(self, x, y=None, request_loss=False, tag=None, timing=False, keep_on_device=False, *args, **kwargs):
         """-> (out, loss | None, seconds | None) as :488-520."""
         self.net.eval()
