@@ -213,3 +213,20 @@ def test_default_vdsr_trains_on_a_full_size_patch_batch():
     yb = (xb + 0.05 * (yb - 0.5)).clamp(0, 1)           # a learnable residual task
     losses = [float(h.run_train(x=xb, y=yb)[0]) for _ in range(8)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_srcnn_on_the_set5_example_image_eval_psnr_within_0p02_db(golden_dir):
+    """BASELINE config 0 (SRCNN x2 on the reference's example data) through SISRInterface.net_run_and_process: output, clipped YCbCr,
+    RGB, evaluation loss as the REAL reference produced them (fixture G16), and the Y-PSNR within the north star's 0.02 dB."""
+    g = np.load(os.path.join(golden_dir, 'g16_srcnn_set5_eval.npz'))
+    itf = SISRInterface(tempfile.mkdtemp(), 'exp', gpu='single', sp_gpu=0, mode='eval', new_params={'name': 'srcnn', 'internal_params': {}})
+    itf.model.net.load_state_dict(O.seeded_state_dict(O.build_oracle('srcnn'), 842))
+    lr, hr = torch.from_numpy(g['lr_ycbcr']), torch.from_numpy(g['hr_ycbcr'])
+    out_y, _, _ = itf.model.run_eval(lr[:, :1])
+    assert _rel(out_y, torch.from_numpy(g['out_y'])) < 1e-5
+    rgb, ycbcr, loss, _ = itf.net_run_and_process(lr=lr, hr=hr, request_loss=True)
+    assert np.allclose(ycbcr, g['ycbcr'], atol=1e-5) and np.allclose(rgb, g['rgb'], atol=1e-5)
+    assert abs(float(loss) - float(g['loss'])) < 1e-5 * float(g['loss'])
+    p = O.y_psnr(ycbcr, np.clip(g['hr_ycbcr'], 0, 1))
+    print('Y-PSNR hip %.4f vs reference %.4f dB' % (p, float(g['psnr'])))
+    assert abs(p - float(g['psnr'])) <= 0.02

@@ -331,3 +331,19 @@ def test_g15_basic_models_oracle_matches_reference_handlers(golden_dir, name):
     xe, ye = basic_y_batch(890, 1, 33, 18)
     ev, evl, _ = h.run_eval(xe, ye, request_loss=True)
     assert np.allclose(ev.numpy(), g[name + '.eval_out'], atol=1e-6) and abs(float(evl) - float(g[name + '.eval_loss'])) < 1e-6
+
+
+def test_g16_srcnn_on_the_set5_example_image_matches_reference_handler(golden_dir):
+    """BASELINE config 0 on the reference's own example data: the oracle SRCNN on the Y plane of a Set5 crop (x2 bicubic down / up),
+    evaluation loss and Y-PSNR as the REAL reference handler and metric computed them (tests/golden/make_golden_srcnn_set5.py)."""
+    g = np.load(os.path.join(golden_dir, 'g16_srcnn_set5_eval.npz'))
+    net = O.build_oracle('srcnn')
+    net.load_state_dict(O.seeded_state_dict(net, 842))
+    h = O.OracleHandler(net, eval_mode=True, criterion='mse')
+    lr, hr = torch.from_numpy(g['lr_ycbcr']), torch.from_numpy(g['hr_ycbcr'])
+    out, loss, _ = h.run_eval(lr[:, :1], hr[:, :1], request_loss=True)
+    assert np.allclose(out.numpy(), g['out_y'], atol=1e-6) and abs(float(loss) - float(g['loss'])) < 1e-6
+    ycbcr = np.clip(np.concatenate([out.numpy(), g['lr_ycbcr'][:, 1:]], 1), 0, 1)
+    assert np.allclose(ycbcr, g['ycbcr'], atol=1e-6)
+    assert abs(O.y_psnr(ycbcr, np.clip(g['hr_ycbcr'], 0, 1)) - float(g['psnr'])) < 1e-3
+    assert abs(O.y_psnr(np.clip(g['lr_ycbcr'], 0, 1), np.clip(g['hr_ycbcr'], 0, 1)) - float(g['psnr_input'])) < 1e-3
