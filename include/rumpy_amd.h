@@ -449,6 +449,7 @@ typedef struct {
   int64_t n;
   const rumpy_adam_hyper* hyper;  /* DEVICE pointer: lets a captured graph replay with new hyper-parameters */
   const float* sumsq;             /* device scalar (sum of g^2) when hyper->max_norm > 0, else NULL */
+  rumpy_adam_hyper hyper_value;   /* hyper == NULL: the hyper-parameters travel BY VALUE with the launch (eager steps: no staging copy) */
 } rumpy_adam_args;
 int rumpy_adam_step(const rumpy_adam_args* a, void* stream);
 

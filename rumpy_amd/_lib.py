@@ -165,7 +165,7 @@ class AdamHyper(_S):
 
 class AdamArgs(_S):
     _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_int64),
-                ('hyper', c_void_p), ('sumsq', c_void_p)]
+                ('hyper', c_void_p), ('sumsq', c_void_p), ('hyper_value', AdamHyper)]
 
 
 class SumsqArgs(_S):

@@ -4,8 +4,8 @@
 // torch.optim.Adam (no amsgrad, no weight decay) in torch's operation order:
 //   m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g*g; denom = sqrt(v)/sqrt(bias_c2) + eps; p -= (lr/bias_c1) * m/denom
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, const rumpy_adam_hyper* __restrict__ hp, const float* __restrict__ sumsq) {
-  const rumpy_adam_hyper h = *hp;
+                            size_t n, const rumpy_adam_hyper* __restrict__ hp, rumpy_adam_hyper hv, const float* __restrict__ sumsq) {
+  const rumpy_adam_hyper h = hp ? *hp : hv;
   float gm = h.grad_mult;
   if (h.max_norm > 0.f && sumsq) {
     // nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -161,11 +161,12 @@ __global__ void eval_post_kernel(rumpy_eval_post_args a) {
 }
 
 extern "C" int rumpy_adam_step(const rumpy_adam_args* a, void* stream) {
-  if (!a || !a->p || !a->g || !a->m || !a->v || !a->hyper || a->n <= 0) { rumpy_set_error("rumpy_adam_step: bad argument"); return RUMPY_E_ARG; }
+  if (!a || !a->p || !a->g || !a->m || !a->v || a->n <= 0) { rumpy_set_error("rumpy_adam_step: bad argument"); return RUMPY_E_ARG; }
+  if (!a->hyper && !(a->hyper_value.bias_c1 > 0.f && a->hyper_value.sqrt_bias_c2 > 0.f)) { rumpy_set_error("rumpy_adam_step: neither a hyper pointer nor by-value hyper-parameters"); return RUMPY_E_ARG; }
   size_t blocks = ((size_t)a->n + 255) / 256;
   const size_t cap = (size_t)rumpy_device_cus() * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (size_t)a->n, a->hyper, a->sumsq);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (size_t)a->n, a->hyper, a->hyper_value, a->sumsq);
   return rumpy_check_launch("rumpy_adam_step");
 }
 extern "C" int rumpy_sumsq(const rumpy_sumsq_args* a, void* stream) {

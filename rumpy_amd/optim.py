@@ -77,14 +77,16 @@ class FlatAdam(torch.optim.Adam):
         beta1, beta2 = group['betas']
         self._step_t += 1
         t = float(self._step_t)
-        slot, h = self._hyper_ring.acquire()
-        h[0], h[1], h[2], h[3] = group['lr'], beta1, beta2, group['eps']
-        h[4] = 1.0 - beta1 ** t
-        h[5] = math.sqrt(1.0 - beta2 ** t)
-        h[6] = grad_mult
-        h[7] = float(max_norm) if max_norm else 0.0
-        self._hyper_dev.copy_(h, non_blocking=True)
-        self._hyper_ring.sent(slot)
+        hv = L.AdamHyper(lr=group['lr'], beta1=beta1, beta2=beta2, eps=group['eps'], bias_c1=1.0 - beta1 ** t,
+                         sqrt_bias_c2=math.sqrt(1.0 - beta2 ** t), grad_mult=grad_mult, max_norm=float(max_norm) if max_norm else 0.0)
+        graphed = bool(getattr(net, 'use_graph', False))
+        if graphed:
+            # a captured graph replays with new values: they live in device memory and travel through a fenced pinned slot per step
+            slot, h = self._hyper_ring.acquire()
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7] = (hv.lr, hv.beta1, hv.beta2, hv.eps, hv.bias_c1, hv.sqrt_bias_c2,
+                                                              hv.grad_mult, hv.max_norm)
+            self._hyper_dev.copy_(h, non_blocking=True)
+            self._hyper_ring.sent(slot)
         dev = net.flat_p.device
         n = net.flat_p.numel()
 
@@ -95,7 +97,8 @@ class FlatAdam(torch.optim.Adam):
                                                   out=self._sumsq.data_ptr()), stream)
                 sumsq = self._sumsq.data_ptr()
             L.call('rumpy_adam_step', L.AdamArgs(p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(), m=self.flat_m.data_ptr(),
-                                                 v=self.flat_v.data_ptr(), n=n, hyper=self._hyper_dev.data_ptr(), sumsq=sumsq), stream)
+                                                 v=self.flat_v.data_ptr(), n=n, hyper=self._hyper_dev.data_ptr() if graphed else None,
+                                                 sumsq=sumsq, hyper_value=hv), stream)      # eager: by value with the launch
             net.engine.repack(stream)
 
         net._ensure_engine()

@@ -456,16 +456,21 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
 
 @pytest.mark.parametrize('name,kw,N', [
     ('edsr', dict(scale=4), 32),
+    ('edsr', dict(scale=4, _graph=True), 32),      # hipGraph replay: the hyper-parameters go through device memory (fenced pinned staging)
     ('rcan', dict(scale=4, n_resgroups=2, n_resblocks=4), 32),
     ('contrastiveblindqrcan', dict(scale=4, n_resgroups=2, n_resblocks=3, style='standard', include_q_layer=True, block_encoder_loading=True,
                                    selective_meta_blocks=[True, False], num_q_layers_inner_residual=1), 16)])
-def test_free_running_training_equals_step_synchronised_training(name, kw, N):
+def test_free_running_training_equals_step_synchronised_training(name, kw, N, monkeypatch):
     """run_train waits for the forward pass only, so the host queues step i+1 while the GPU still runs step i's backward pass and Adam.
     Everything the host rewrites per step must therefore be private to that step (the Adam hyper-parameters once travelled through ONE
-    pinned buffer: the copy of step i could pick up the bias corrections of step i+1).  Headline-size EDSR, first steps (where the bias
+    pinned buffer: the copy of step i could pick up the bias corrections of step i+1; eager steps now pass them by value with the launch,
+    graph replays through a fenced slot per step).  Headline-size EDSR, first steps (where the bias
     corrections move most): weights after 6 free-running steps == weights after 6 steps with a device synchronise after each, bitwise.
     Also for the one-launch RCAB kernels (exchange epochs advance per pass) and the blind pipeline (encoder BatchNorm statistics)."""
     res = []
+    kw = dict(kw)
+    if kw.pop('_graph', False):
+        monkeypatch.setenv('RUMPY_GRAPH', '1')
     batches = [tuple(t.cuda() for t in O.synthetic_batch(900 + i, N, lr_hw=48, scale=4)) for i in range(6)]
     for sync in (True, False):
         torch.manual_seed(8)
