@@ -561,3 +561,72 @@ def synthetic_batch(seed, n, lr_hw=48, scale=4, channels=3):
 def bf16_round(t):
     """Round-to-nearest-even to bf16 and back to fp32 (what the MFMA operands see)."""
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+_QUAD_TAPS = ((0.15625, 0.9375, -0.09375), (-0.09375, 0.9375, 0.15625))
+
+
+def interpolating_state_dict(module, seed, noise=0.03, detail=0.02, body_gain=1.0):
+    """Seeded weights that put an EDSR / RCAN (x4, 64 features) into the regime of a TRAINED super-resolver (Y-PSNR >= 30 dB on
+    natural images) without shipping trained weights: the network computes a two-stage quadratic x4 interpolation of its input
+    plus a small detail term to which every body convolution contributes.  Test data, not a restatement of reference code
+    (the reference's module classes are filled with it through load_state_dict; fixtures G17 / G18).
+
+      head.0    : channels >= 3: U(-b, b) features (b = 1/sqrt(fan_in), as seeded_state_dict); channel c < 3: centre tap 1 from colour c
+                  + U(-b, b) * noise
+      body.*    : U(-b, b) * body_gain - every RCAB / ResBlock / group conv at the magnitude of the default initialisation
+      body[-1]  : U(-b, b) * detail - the body's output reaches the trunk as a small "detail" term next to the global skip
+      tail.0.{0,2}: a separable x2 interpolation kernel (3-point Lagrange taps at -0.25 / +0.25) from channel c to sub-pixel channel 4c + 2i + j
+                  for every c, + U(-b, b) * noise (no weight is exactly representable in bf16)
+      tail.1    : centre tap 1 from channel c to colour c, + U(-b, b) * noise
+    Everything comes from numpy.random.default_rng(seed) in state_dict order."""
+    base = seeded_state_dict(module, seed)
+    keys = list(base.keys())
+    body_ids = sorted({int(k.split('.')[1]) for k in keys if k.startswith('body.')})
+    last_body = 'body.%d.' % body_ids[-1]
+    sd = OrderedDict()
+    for k, v in base.items():
+        v = v.clone()
+        if k.startswith('head.0.'):
+            v[:3] *= noise              # the three colour-carrying channels: identity + a little of everything
+            if k.endswith('weight'):
+                for c in range(min(3, v.shape[1])):
+                    v[c, c, 1, 1] += 1.0
+        elif k.startswith(last_body):
+            v *= detail
+        elif k.startswith('body.'):
+            v *= body_gain
+        elif k.startswith('tail.0.'):
+            v *= noise
+            if k.endswith('weight'):
+                f = v.shape[1]
+                for c in range(f):
+                    for i in range(2):
+                        for j in range(2):
+                            # sub-pixel row 2h+i sits at h - 0.25 (i = 0) / h + 0.25 (i = 1): quadratic (3-point Lagrange) taps on rows h-1, h, h+1
+                            for ky in range(3):
+                                for kx in range(3):
+                                    v[4 * c + 2 * i + j, c, ky, kx] += _QUAD_TAPS[i][ky] * _QUAD_TAPS[j][kx]
+        elif k.startswith('tail.1.'):
+            v *= noise
+            if k.endswith('weight'):
+                for c in range(v.shape[0]):
+                    v[c, c, 1, 1] += 1.0
+        sd[k] = v
+    return sd
+
+
+def vignetted_pair(hr_u8, lr_hw, scale=4, margin=24):
+    """Evaluation pair for the G17 / G18 fixtures from an RGB uint8 image: a centred (scale*lr_hw)^2 crop multiplied by a raised-cosine
+    vignette (zero at the border over `margin` pixels, so that the zero padding of the convolutions is exact there), quantised to
+    uint8 = HR; LR = PIL bicubic downsample of it (the reference's own resize, image_functions.py:13-41).  Returns (lr_u8, hr_u8)."""
+    from PIL import Image
+    n = scale * lr_hw
+    y0, x0 = (hr_u8.shape[0] - n) // 2, (hr_u8.shape[1] - n) // 2
+    crop = hr_u8[y0:y0 + n, x0:x0 + n].astype(np.float64) / 255.0
+    w = np.ones(n)
+    ramp = 0.5 - 0.5 * np.cos(np.pi * (np.arange(margin) + 0.5) / margin)
+    w[:margin], w[-margin:] = ramp, ramp[::-1]
+    hr = (np.clip(crop * w[:, None, None] * w[None, :, None], 0, 1) * 255 + 0.5).astype(np.uint8)
+    lr = np.asarray(Image.fromarray(hr).resize((lr_hw, lr_hw), Image.BICUBIC))
+    return lr, hr

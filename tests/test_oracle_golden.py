@@ -145,6 +145,30 @@ def test_g7_eval_postprocess_and_y_psnr(golden_dir):
     assert O.psnr(np.zeros((4, 4)), np.zeros((4, 4))) == 100
 
 
+@pytest.mark.parametrize('fn,model,seed', [('g17_edsr_psnr.npz', 'edsr', 501), ('g18_rcan_psnr.npz', 'rcan', 502)])
+def test_g17_g18_full_depth_eval_psnr_in_the_trained_regime(golden_dir, fn, model, seed):
+    """full-depth EDSR-baseline / RCAN (interpolating weights, >= 30 dB): output, clipped Y plane, loss and Y-PSNR of the real reference"""
+    g = _load(golden_dir, fn)
+    assert int(g['seed']) == seed and float(g['psnr']) >= 30.0
+    to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
+    lr_t, hr_t = to_t(g['lr']), to_t(g['hr'])
+    net = O.build_oracle(model, scale=4)
+    net.load_state_dict(O.interpolating_state_dict(net, seed))
+    h = O.OracleHandler(net, eval_mode=True)
+    out, loss, _ = h.run_eval(lr_t, hr_t, request_loss=True)
+    np.testing.assert_allclose(out.numpy()[:, :, ::2, ::2], g['out_s2'], rtol=0, atol=2e-6)
+    rgb, ycbcr, _, _ = O.net_run_and_process(h, lr_t, hr_t, request_loss=True)
+    np.testing.assert_allclose(ycbcr[:, 0], g['y'], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(loss, g['loss'], rtol=1e-5)
+    hr_ycbcr = O.clip01(hr_t.numpy())
+    hr_ycbcr[0] = O.rgb_to_ycbcr_jpg(hr_ycbcr[0])
+    assert abs(O.y_psnr(ycbcr, hr_ycbcr) - float(g['psnr'])) < 1e-4
+    assert O.psnr(g['y'], hr_ycbcr[:, 0], 1) == float(g['psnr'])
+    # the evaluation pair regenerates from the stored HR crop (PIL bicubic, the reference's resize)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.fromarray(g['hr']).resize((64, 64), Image.BICUBIC)), g['lr'])
+
+
 def test_g8_parameter_counts_and_keys(golden_dir):
     with open(os.path.join(golden_dir, 'g8_params.json')) as f:
         g = json.load(f)
