@@ -26,6 +26,13 @@ extern "C" {
 #define RUMPY_E_ARG (-1)     /* invalid argument / unsupported shape */
 #define RUMPY_E_LAUNCH (-2)  /* HIP launch error */
 
+/* Element format of the stored activations and packed filters (`fmt` fields).  Training is bf16 throughout; the kernels an
+ * EVALUATION plan launches (rumpy_head_fwd, rumpy_conv3x3, rumpy_conv_block / rumpy_rcab_fwd forward forms, rumpy_ca_fwd_fused,
+ * rumpy_tail_fwd, rumpy_pack_weights) also take IEEE fp16: same bytes and MFMA rate, 11 instead of 8 significant bits, which is
+ * what keeps the evaluation PSNR of a trained network within +-0.02 dB of the fp32 reference. */
+#define RUMPY_FMT_BF16 0
+#define RUMPY_FMT_F16 1
+
 #define RUMPY_TILE_H 8
 #define RUMPY_TILE_W 16
 
@@ -59,6 +66,7 @@ typedef struct {
   int32_t relu;
   float scale;
   int32_t grid_x;       /* persistent workgroups per cout tile; 0 = library default */
+  int32_t fmt;          /* RUMPY_FMT_*: format of x, w, out, res1, res2 (F16: cin_chunks 1, no mask) */
 } rumpy_conv_args;
 int rumpy_conv3x3(const rumpy_conv_args* a, void* stream);
 /* number of per-image pool partial rows ("tiles") rumpy_conv3x3 writes for an H x W image */
@@ -124,6 +132,8 @@ typedef struct {
                           partial sums rumpy_ca_mlp_fwd reduces (same layout as rumpy_conv3x3's `pool`) */
   void* maskbits;      /* NULL, or [N,H,W,8] bytes = the ReLU mask of T, one bit per channel (ResBlock form only): WRITTEN by a forward
                           launch (relu1 = 1), READ instead of `mask` by a data-gradient launch (relu1 = 0) - 1/16 of the mask traffic */
+  int32_t fmt;         /* RUMPY_FMT_*; F16 only for the ResBlock forward form (relu1 = 1, scale1 = 1, no mask, res_mode 0, no pool) */
+  int32_t pad_;
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
 
@@ -149,7 +159,8 @@ typedef struct {
   float* mean; float* hidden; float* gate;       /* [N,64], [N,cr], [N,64] */
   const float* qgate; float* dz; float* dzq;     /* [N,64] each */
   void* xchg; int64_t xchg_bytes; const void* epoch; void* status;
-  uint32_t seq; int32_t pad_;
+  uint32_t seq;
+  int32_t fmt;         /* RUMPY_FMT_*; F16: rumpy_rcab_fwd only */
   void* maskbits;      /* NULL, or [N,H,W,8] bytes: ReLU mask of t1, written by rumpy_rcab_fwd and read (instead of `mask`) by rumpy_rcab_bwd */
 } rumpy_rcab_args;
 int rumpy_rcab_fwd(const rumpy_rcab_args* a, void* stream);
@@ -183,6 +194,8 @@ typedef struct {
   int32_t N, C, H, W, cout;
   float neg_slope_m1;  /* negative-side slope MINUS ONE of the activation applied to the output: 0 = none (SR head),
                           -0.9f = LeakyReLU(0.1) (first conv of the degradation encoder), -1 = ReLU */
+  int32_t fmt;         /* RUMPY_FMT_* of `out` */
+  int32_t pad_;
 } rumpy_head_fwd_args;
 int rumpy_head_fwd(const rumpy_head_fwd_args* a, void* stream);
 
@@ -219,6 +232,10 @@ typedef struct {
   float* wslab;          /* NULL, or (needs target) rumpy_tail_fwd_grid(..) * rumpy_wgrad_slab_floats(1) floats: the weight /
                             bias gradient of this conv w.r.t. the L1 loss is accumulated in the same pass (one slab per
                             workgroup; rumpy_tail_wgrad_reduce adds them up) instead of re-reading x in rumpy_wgrad_grouped */
+  uint32_t* nonfinite;   /* NULL, or a device word that is OR-ed with 1 when an output value is not finite (an fp16 evaluation plan
+                            that overflowed: the host re-runs the image in bf16) */
+  int32_t fmt;           /* RUMPY_FMT_* of x and w (F16: no dy4 / wslab) */
+  int32_t pad_;
 } rumpy_tail_fwd_args;
 int rumpy_tail_fwd(const rumpy_tail_fwd_args* a, void* stream);
 int rumpy_tail_fwd_grid(int32_t N, int32_t H, int32_t W, int32_t grid_x);   /* workgroups rumpy_tail_fwd launches = slabs written */
@@ -284,13 +301,15 @@ int rumpy_wgrad_reduce(const rumpy_reduce_item* items_device, int32_t nitems, vo
 typedef struct {
   const float* w;      /* [Cout,Cin,3,3] */
   const float* b;      /* [Cout] */
-  void* w_fwd;         /* kind 0: Cout*Cin*9 bf16 in MFMA A-fragment order [cout_tile][cin_chunk][co quarter 4][s = tap*2 +
+  void* w_fwd;         /* kind 0: Cout*Cin*9 elements (format `fmt`) in MFMA A-fragment order [cout_tile][cin_chunk][co quarter 4][s = tap*2 +
                           ci half, 18][lane 64][8] ; kind 2: [18][64][8] */
   void* w_dgrad;       /* kind 0: same for the transposed, flipped filter ; kind 2: [4][2][64][8] ; may be NULL */
   float* b_packed;     /* kind 0: [Cout] in packed channel order ; else NULL */
   int32_t cout, cin;
   int32_t kind;        /* 0: 64-multiple conv ; 2: tail conv (cout<=4, cin=64) */
   int32_t shuffle;     /* kind 0: 1 = output channels grouped by PixelShuffle sub-pixel (co = 4c+q -> tile q, channel c) */
+  int32_t fmt;         /* RUMPY_FMT_* of the images */
+  int32_t pad_;
 } rumpy_pack_item;
 int rumpy_pack_weights(const rumpy_pack_item* items_device, int32_t nitems, void* stream);
 
@@ -372,6 +391,8 @@ typedef struct {
   int32_t N, HW, C, Cr, ntiles;
   float inv_hw;
   const float* qgate;                          /* NULL, or the meta-attention gate [N,C] of a QRCAB: out = res + t * gate * qgate */
+  int32_t fmt;                                 /* RUMPY_FMT_* of t, res, out */
+  int32_t pad_;
 } rumpy_ca_fwd_fused_args;
 int rumpy_ca_fwd_fused(const rumpy_ca_fwd_fused_args* a, void* stream);
 typedef struct {

@@ -81,12 +81,17 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, train, meta, *params):
         out, _, plan = net.engine_forward(x, train=train, meta=meta)
-        ctx.net, ctx.plan = net, plan
+        ctx.net, ctx.plan, ctx.gen = net, plan, plan.gen
         return out
 
     @staticmethod
     def backward(ctx, gout):
         net = ctx.net
+        if ctx.plan.gen != ctx.gen:
+            # the plan's saved activations belong to a LATER forward pass of the same shape (two outputs alive at once, a deferred
+            # backward): the reference's autograd would handle it, this static plan cannot - fail instead of returning wrong gradients
+            raise RuntimeError('rumpy_amd: backward() of an output whose saved activations were overwritten by a later training forward '
+                               'pass of the same shape; run forward and backward of one batch before the next forward pass')
         net.engine.backward(ctx.plan, 1.0, gout=gout.contiguous().float(), on_ready=getattr(net, 'grad_ready_hook', None))
         net.attach_grads()
         return (None, None, None, None) + tuple(None for _ in net.param_list)
@@ -212,7 +217,7 @@ class HipSRNet(nn.Module):
         return meta.reshape(meta.shape[0], -1).to(device=x.device, dtype=torch.float32).contiguous()
 
     def forward(self, x, metadata=None):
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list)
+        train = self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.param_list)
         if train:
             return _NetFn.apply(x, self, True, metadata, *self.param_list)
         out, _, _ = self.engine_forward(x, train=False, meta=metadata)
@@ -223,7 +228,8 @@ class HipSRNet(nn.Module):
         Returns (loss device scalar, out).  Gradients land in flat_g / p.grad."""
         if self.use_graph:
             self._ensure_engine()
-            out, loss, _ = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous(), meta=self._meta_matrix(metadata, x))
+            out, loss, plan = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous(), meta=self._meta_matrix(metadata, x))
+            self._stage_loss(loss, plan.rcab_status)       # the replay's loss and strip-exchange watchdog word, fenced like the eager path's
             return loss, out
         out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous(), meta=metadata)
         # The loss is final once the forward pass has run: its read-back is queued HERE (pinned buffer + event), ahead of the

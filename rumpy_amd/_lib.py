@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('RUMPY_AMD_LIB') or os.path.join(_HERE, 'librumpy_amd.
 c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 TILE_H, TILE_W = 8, 16
+FMT_BF16, FMT_F16 = 0, 1          # include/rumpy_amd.h RUMPY_FMT_*
 
 
 class _S(C.Structure):
@@ -31,7 +32,7 @@ class ConvArgs(_S):
                 ('res1', c_void_p), ('res2', c_void_p), ('pool', c_void_p),
                 ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cin_chunks', c_int32), ('cout_tiles', c_int32),
                 ('in_mode', c_int32), ('out_mode', c_int32), ('relu', c_int32), ('scale', c_float),
-                ('grid_x', c_int32)]
+                ('grid_x', c_int32), ('fmt', c_int32)]
 
 
 class ChainLayer(_S):
@@ -46,7 +47,8 @@ class ChainArgs(_S):
 
 class HeadFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('b', c_void_p), ('out', c_void_p),
-                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32), ('neg_slope_m1', c_float)]
+                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32), ('neg_slope_m1', c_float),
+                ('fmt', c_int32), ('pad_', c_int32)]
 
 
 class EncConvArgs(_S):
@@ -62,7 +64,7 @@ class RcabArgs(_S):
                 ('ca_w1', c_void_p), ('ca_b1', c_void_p), ('ca_w2', c_void_p), ('ca_b2', c_void_p),
                 ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('qgate', c_void_p), ('dz', c_void_p), ('dzq', c_void_p),
                 ('xchg', c_void_p), ('xchg_bytes', c_int64), ('epoch', c_void_p), ('status', c_void_p),
-                ('seq', C.c_uint32), ('pad_', c_int32), ('maskbits', c_void_p)]
+                ('seq', C.c_uint32), ('fmt', c_int32), ('maskbits', c_void_p)]
 
 
 class Op(_S):
@@ -84,7 +86,8 @@ class HeadWgradArgs(_S):
 class TailFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('target', c_void_p),
                 ('dy4', c_void_p), ('loss_partial', c_void_p), ('loss', c_void_p),
-                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('grid_x', c_int32), ('wslab', c_void_p)]
+                ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('grid_x', c_int32), ('wslab', c_void_p),
+                ('nonfinite', c_void_p), ('fmt', c_int32), ('pad_', c_int32)]
 
 
 class TailDgradArgs(_S):
@@ -109,7 +112,7 @@ class ReduceItem(_S):
 
 class PackItem(_S):
     _fields_ = [('w', c_void_p), ('b', c_void_p), ('w_fwd', c_void_p), ('w_dgrad', c_void_p), ('b_packed', c_void_p),
-                ('cout', c_int32), ('cin', c_int32), ('kind', c_int32), ('shuffle', c_int32)]
+                ('cout', c_int32), ('cin', c_int32), ('kind', c_int32), ('shuffle', c_int32), ('fmt', c_int32), ('pad_', c_int32)]
 
 
 class CaMlpFwdArgs(_S):
@@ -143,7 +146,7 @@ class CaFwdFusedArgs(_S):
     _fields_ = [('pool', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mean', c_void_p),
                 ('hidden', c_void_p), ('gate', c_void_p), ('t', c_void_p), ('res', c_void_p), ('out', c_void_p),
                 ('N', c_int32), ('HW', c_int32), ('C', c_int32), ('Cr', c_int32), ('ntiles', c_int32), ('inv_hw', c_float),
-                ('qgate', c_void_p)]
+                ('qgate', c_void_p), ('fmt', c_int32), ('pad_', c_int32)]
 
 
 class CaBwdFusedArgs(_S):
@@ -181,7 +184,7 @@ class BlockArgs(_S):
     _fields_ = [('x', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mask', c_void_p),
                 ('res2', c_void_p), ('t', c_void_p), ('out', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32),
                 ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float), ('res_mode', c_int32), ('res1', c_void_p),
-                ('pool', c_void_p), ('maskbits', c_void_p)]
+                ('pool', c_void_p), ('maskbits', c_void_p), ('fmt', c_int32), ('pad_', c_int32)]
 
 
 class BlockChainArgs(_S):

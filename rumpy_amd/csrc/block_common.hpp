@@ -23,7 +23,7 @@ __device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p 
 
 // MFMA sweep over the 18 (channel half, tap column, column tile) groups for ROWS output rows per wave (window = ROWS + 2
 // input rows).  off[d][half]: per-lane byte address of (window row 0, column px, chunk 4*half + g) for XOR class d.
-template <int ROWS>
+template <int ROWS, int FMT = RUMPY_FMT_BF16>
 __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2]) {
   bf16x8 I[2][ROWS + 2];
   auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
@@ -42,7 +42,7 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int r = 0; r < ROWS; ++r)
-        acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
+        acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c]);
   }
 }
 
@@ -106,8 +106,9 @@ __device__ __forceinline__ uint4 relu_mask_bits(uint4 v, unsigned b) {
   auto keep = [](unsigned b2) { return ((b2 & 1u) * 0xffffu) | (((b2 >> 1) & 1u) * 0xffff0000u); };
   return make_uint4(v.x & keep(b), v.y & keep(b >> 2), v.z & keep(b >> 4), v.w & keep(b >> 6));
 }
+template <int FMT = RUMPY_FMT_BF16>
 __device__ __forceinline__ void unpack8(uint4 u, float (&m)[8]) {
-  unpack4_bf16(make_uint2(u.x, u.y), *reinterpret_cast<float(*)[4]>(&m[0]));
-  unpack4_bf16(make_uint2(u.z, u.w), *reinterpret_cast<float(*)[4]>(&m[4]));
+  unpack4<FMT>(make_uint2(u.x, u.y), *reinterpret_cast<float(*)[4]>(&m[0]));
+  unpack4<FMT>(make_uint2(u.z, u.w), *reinterpret_cast<float(*)[4]>(&m[4]));
 }
 

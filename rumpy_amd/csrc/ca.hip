@@ -228,6 +228,7 @@ struct CaFwdFused {
   const float* qgate;      // [N,C] meta-attention gate (QRCAB q-layer) multiplied into the channel-attention gate, or NULL
 };
 constexpr int CA_PRE = 4;       // vectors per thread requested BEFORE the MLP is recomputed: their latency hides behind it
+template <int FMT>
 __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
   __shared__ float sp[CA_MAXC];
   __shared__ float sh[CA_MAXR];
@@ -271,12 +272,12 @@ __global__ void __launch_bounds__(256) ca_fwd_fused_kernel(CaFwdFused a) {
   auto apply = [&](size_t v, uint4 tv, uint4 rv) {
     const float* gp = sg + (int)(v % cv) * 8;
     float x[4], y[4], ra[4], rb[4];
-    unpack4_bf16(make_uint2(tv.x, tv.y), x);
-    unpack4_bf16(make_uint2(tv.z, tv.w), y);
-    unpack4_bf16(make_uint2(rv.x, rv.y), ra);
-    unpack4_bf16(make_uint2(rv.z, rv.w), rb);
-    const uint2 lo = pack4_bf16(fmaf(x[0], gp[0], ra[0]), fmaf(x[1], gp[1], ra[1]), fmaf(x[2], gp[2], ra[2]), fmaf(x[3], gp[3], ra[3]));
-    const uint2 hi = pack4_bf16(fmaf(y[0], gp[4], rb[0]), fmaf(y[1], gp[5], rb[1]), fmaf(y[2], gp[6], rb[2]), fmaf(y[3], gp[7], rb[3]));
+    unpack4<FMT>(make_uint2(tv.x, tv.y), x);
+    unpack4<FMT>(make_uint2(tv.z, tv.w), y);
+    unpack4<FMT>(make_uint2(rv.x, rv.y), ra);
+    unpack4<FMT>(make_uint2(rv.z, rv.w), rb);
+    const uint2 lo = pack4<FMT>(fmaf(x[0], gp[0], ra[0]), fmaf(x[1], gp[1], ra[1]), fmaf(x[2], gp[2], ra[2]), fmaf(x[3], gp[3], ra[3]));
+    const uint2 hi = pack4<FMT>(fmaf(y[0], gp[4], rb[0]), fmaf(y[1], gp[5], rb[1]), fmaf(y[2], gp[6], rb[2]), fmaf(y[3], gp[7], rb[3]));
     a.out[base + v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
 #pragma unroll
@@ -466,7 +467,9 @@ extern "C" int rumpy_ca_fwd_fused(const rumpy_ca_fwd_fused_args* p, void* stream
     hipLaunchKernelGGL(ca_pool_fold_kernel, dim3(CA_FOLD, p->N), dim3(256), 0, (hipStream_t)stream, const_cast<float*>(p->pool), p->ntiles, p->C);
     d.ntiles = CA_FOLD;
   }
-  hipLaunchKernelGGL(ca_fwd_fused_kernel, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
+  if (p->fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(ca_fwd_fused_kernel<RUMPY_FMT_F16>, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
+  else if (p->fmt == RUMPY_FMT_BF16) hipLaunchKernelGGL(ca_fwd_fused_kernel<RUMPY_FMT_BF16>, dim3(p->N * d.per_image), dim3(256), 0, (hipStream_t)stream, d);
+  else { rumpy_set_error("rumpy_ca_fwd_fused: bad fmt %d", p->fmt); return RUMPY_E_ARG; }
   return rumpy_check_launch("rumpy_ca_fwd_fused");
 }
 extern "C" int rumpy_ca_bwd_fused(const rumpy_ca_bwd_fused_args* p, void* stream) {

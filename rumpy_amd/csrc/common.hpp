@@ -52,6 +52,40 @@ __device__ __forceinline__ void unpack4_bf16(uint2 v, float (&o)[4]) {
   o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
 }
 
+// ---- element format of the stored activations / packed filters (rumpy_amd.h: RUMPY_FMT_*) ----
+// bf16 (training, the default) or IEEE fp16 (evaluation plans: same MFMA rate and bytes, 11 instead of 8 significant bits - the
+// forward pass of a trained SR network stays far inside fp16's range, and rumpy_tail_fwd reports a non-finite output).  The kernels
+// that an evaluation plan launches take the format as a template parameter; everything else (training) is bf16 only.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+template <int FMT> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+  if (FMT == RUMPY_FMT_F16) {
+    union { f16x2v v; uint32_t u; } c;
+    c.v = __builtin_convertvector((f32x2){a, b}, f16x2v);      // v_cvt_pk_f16_f32 (round to nearest even; overflow -> inf)
+    return c.u;
+  }
+  return pack2_bf16(a, b);
+}
+template <int FMT> __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  return make_uint2(pack2<FMT>(a, b), pack2<FMT>(c, d));
+}
+template <int FMT> __device__ __forceinline__ void unpack4(uint2 v, float (&o)[4]) {
+  if (FMT == RUMPY_FMT_F16) {
+    union { uint2 u; _Float16 h[4]; } c; c.u = v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (float)c.h[j];
+  } else {
+    unpack4_bf16(v, o);
+  }
+}
+template <int FMT> __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  if (FMT == RUMPY_FMT_F16) {
+    union { bf16x8 b; f16x8 h; } ua, ub; ua.b = a; ub.b = b;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 // XCD-aware work order (cdna_hip_programming.md T1): workgroup ids are dealt round-robin over the 8 XCDs, so consecutive ids - e.g. the
 // vertically adjacent strips of an image, which share 4 of their 10 input rows, or neighbouring tiles with their common halo - would sit
 // behind 8 different L2s and every shared line would come from HBM twice.  Strip = (id % 8) * ceil(n / 8) + id / 8 (bijective form) gives each XCD a contiguous run of strips.

@@ -27,7 +27,8 @@
 // FORM: 0 = post1 flags read at run time; 1 = forward form (ReLU, no scale1, no mask; stores the mask bytes if asked to); 2 = data-gradient
 // form (no ReLU, * scale1, mask = a bf16 activation); 3 = data-gradient form with the mask as bytes (block_common.hpp::relu_bits):
 // the two forms the engine launches, without the per-value selects and branches of the generic epilogue.
-template <bool GEN, int FORM = 0>
+// FMT: element format (RUMPY_FMT_F16 is instantiated for the ResBlock forward form only: evaluation plans)
+template <bool GEN, int FORM = 0, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
   unsigned char* const ldx = lds;
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       const int j = 4 * rh + jr, xx = 16 * c + px;
       uint4 o = make_uint4(0, 0, 0, 0);                      // outside the image: convB's zero padding
       if (moff[k] != 0xffffffffu) {
-        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
         if (FORM == 2 || (FORM == 0 && a.mask)) o = relu_mask_packed(o, M[(FORM == 1 || FORM == 3) ? 0 : k]);
         if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
     };
-    block_sweep<4>(acc, F, lds, off);
+    block_sweep<4, FMT>(acc, F, lds, off);
     // second filter: L2 hits that land under the epilogue
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     }
     unsigned off[8][2];
     sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
-    block_sweep<3>(acc, F, lds, off);
+    block_sweep<3, FMT>(acc, F, lds, off);
     float ps[4] = {0.f, 0.f, 0.f, 0.f};                         // GEN pool sums: single tile, channels 4g .. 4g+3 of the wave's 16
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    //                paired tiles, channels 4(g&~1) .. +7
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
@@ -187,7 +188,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
       if (y < a.H && xx < a.W) {
         if (!GEN) {
-          unpack8(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);   // residual = the input tile
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);   // residual = the input tile
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
         } else {
@@ -198,18 +199,18 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
             for (int j = 0; j < 8; ++j) ps8[j] += v[j];
           }
           if (a.res_mode == 2) {
-            unpack8(P1p[GEN ? k : 0], m);
+            unpack8<FMT>(P1p[GEN ? k : 0], m);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += m[j];
           }
         }
         const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair);
         if (a.res2) {
-          unpack8(*reinterpret_cast<const uint4*>(a.res2 + o), m);
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(a.res2 + o), m);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
-        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
         *reinterpret_cast<uint4*>(a.out + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
         float v[4] = {acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]};
         float m[4];
         if (!GEN) {
-          unpack4_bf16(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
         } else {
@@ -230,18 +231,18 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
             for (int j = 0; j < 4; ++j) ps[j] += v[j];
           }
           if (a.res_mode == 2) {
-            unpack4_bf16(P1s, m);
+            unpack4<FMT>(P1s, m);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += m[j];
           }
         }
         const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
         if (a.res2) {
-          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + o), m);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res2 + o), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
-        *reinterpret_cast<uint2*>(a.out + o) = pack4_bf16(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>(a.out + o) = pack4<FMT>(v[0], v[1], v[2], v[3]);
       }
     }
     if (GEN && a.pool) {
@@ -282,10 +283,13 @@ extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
   if (p->maskbits && !(p->res_mode == 0 && !p->pool && ((p->relu1 && p->scale1 == 1.0f && !p->mask) || !p->relu1))) {
     rumpy_set_error("rumpy_conv_block: maskbits goes with the ResBlock forward form (written) or a data-gradient form (read)"); return RUMPY_E_ARG; }
   if (p->res_mode < 0 || p->res_mode > 2 || (p->res_mode == 2 && !p->res1)) { rumpy_set_error("rumpy_conv_block: bad res_mode / res1"); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && p->res_mode == 0 && !p->pool && p->relu1 && p->scale1 == 1.0f && !p->mask)) {
+    rumpy_set_error("rumpy_conv_block: fmt %d goes with the ResBlock forward form only", p->fmt); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(d.N * d.sy_n);
   if (p->res_mode == 0 && !p->pool) {
-    if (p->relu1 && p->scale1 == 1.0f && !p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1>), grid, dim3(BTHREADS), s, d);
+    if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);
+    else if (p->relu1 && p->scale1 == 1.0f && !p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1>), grid, dim3(BTHREADS), s, d);
     else if (!p->relu1 && p->maskbits) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 3>), grid, dim3(BTHREADS), s, d);
     else if (!p->relu1 && p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 2>), grid, dim3(BTHREADS), s, d);
     else RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 0>), grid, dim3(BTHREADS), s, d);

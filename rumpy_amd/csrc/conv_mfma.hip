@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
 // ------------------------------------------------------------------------------------------------------
 struct TailDev {
   const uint16_t* x; const uint4* w; const float* bias; float* out; const float* target; uint16_t* dy4;
-  float* loss_partial; float* wslab; int N, C, H, W, tiles_x, tiles_y;
+  float* loss_partial; float* wslab; int N, C, H, W, tiles_x, tiles_y; unsigned* nonfinite;
 };
 
 typedef __attribute__((address_space(3))) short4v* tail_lds_s4;
@@ -191,7 +191,8 @@ __device__ __forceinline__ bf16x8 tail_tr8(unsigned addr, unsigned second) {    
 // weight-gradient pass (which re-read the 151 MB activation: 71 us) disappears.  Pixels are the MFMA K axis: both operands
 // come out of LDS through transposed reads (ds_read_b64_tr_b16, as in wgrad_dma.hip); wave w owns input channels 16w..16w+15,
 // 9 accumulator tiles stay in registers for the whole kernel, each workgroup leaves one slab (format of rumpy_wgrad_slab_floats(1)).
-template <bool WGRAD>
+// FMT: element format of x and w (RUMPY_FMT_F16: evaluation plans, WGRAD = false only)
+template <bool WGRAD, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
   __shared__ __attribute__((aligned(16))) unsigned char ldy[TH * TW * 8 + 16];      // sign gradient of the tile [px][4 ch] bf16 + 16 zero bytes
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   float bj[4] = {0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < a.C; ++j) bj[j] = a.bias[j];
   float lsum = 0.f;
+  unsigned bad = 0u;
   f32x4 wacc[WGRAD ? 9 : 1];
 #pragma unroll
   for (int t = 0; t < (WGRAD ? 9 : 1); ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < 2; ++r)
-            acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WGRAD ? as_bf16x8(ldf[WGRAD ? ((ky * 3 + kx) * 2 + half) * 64 + lane : 0]) : F[WGRAD ? 0 : (ky * 3 + kx) * 2 + half], I[r + ky], acc[r], 0, 0, 0);
+            acc[r] = mfma16<FMT>(WGRAD ? as_bf16x8(ldf[WGRAD ? ((ky * 3 + kx) * 2 + half) * 64 + lane : 0]) : F[WGRAD ? 0 : (ky * 3 + kx) * 2 + half], I[r + ky], acc[r]);
       }
     // all target values are consumed BEFORE the first store: with loads and stores pending together the compiler's
     // s_waitcnt bookkeeping (gfx9: one vmcnt, loads and stores may retire out of order) falls back to draining everything
@@ -286,6 +288,12 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
         dif[r][j] = vout[r][j] - tg[r][j];
         asm volatile("" : "+v"(dif[r][j]));     // materialise here (the optimiser would sink it below the stores)
       }
+    if (a.nonfinite) {      // exponent all ones = inf / NaN in an output value of this lane (the flag is raised at the end of the kernel)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bad |= (inimg[r] && j < a.C && (__float_as_uint(vout[r][j]) & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+    }
     __builtin_amdgcn_sched_barrier(0);
     // the next tile's registers go to the other LDS buffer here - after the MFMAs (its loads had the whole step to land)
     // and before the stores (a wait issued behind them would have to drain them)
@@ -368,6 +376,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
     __syncthreads();
     if (tid == 0) a.loss_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
+  if (a.nonfinite && __any(bad != 0u) && lane == 0) atomicOr(a.nonfinite, 1u);
 }
 
 __global__ void loss_finalize_kernel(const float* partial, int n, float inv_numel, float* loss) {
@@ -450,6 +459,8 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (p->cin_chunks != 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 or 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
   if (p->in_mode == 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: in_mode 1 needs cin_chunks 4"); return RUMPY_E_ARG; }
   if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || p->res1 || p->res2)) { rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4 and no mask/residual"); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && p->cin_chunks == 1 && !p->mask)) {
+    rumpy_set_error("rumpy_conv3x3: fmt %d needs cin_chunks 1 and no mask (forward launches of an evaluation plan)", p->fmt); return RUMPY_E_ARG; }
   // Cin = 256 (upsampler data gradients): the 8x16-tile kernel below measures faster than the 4-chunk strip build
   // (which spills at 256 VGPRs); RUMPY_CONV4_STRIP=1 selects the strip build for A/B runs.
   static const bool strip4 = getenv("RUMPY_CONV4_STRIP") != nullptr;
@@ -535,12 +546,15 @@ extern "C" int rumpy_tail_fwd(const rumpy_tail_fwd_args* p, void* stream) {
   d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = p->out; d.target = p->target;
   d.dy4 = (uint16_t*)p->dy4; d.loss_partial = p->loss_partial; d.wslab = p->wslab; d.N = p->N; d.C = p->C; d.H = p->H; d.W = p->W;
   if (p->wslab && !p->target) { rumpy_set_error("rumpy_tail_fwd: wslab needs target"); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !p->wslab && !p->dy4)) { rumpy_set_error("rumpy_tail_fwd: fmt %d goes without dy4 / wslab", p->fmt); return RUMPY_E_ARG; }
+  d.nonfinite = p->nonfinite;
   d.tiles_x = cdiv(p->W, TW); d.tiles_y = cdiv(p->H, TH);
   const int ntiles = d.N * d.tiles_x * d.tiles_y;
   int gx = p->grid_x > 0 ? p->grid_x : 2 * rumpy_device_cus();
   if (gx > ntiles) gx = ntiles;
   hipStream_t s = (hipStream_t)stream;
   if (p->wslab) hipLaunchKernelGGL(tail_fwd_kernel<true>, dim3(gx), dim3(256), 0, s, d);
+  else if (p->fmt == RUMPY_FMT_F16) hipLaunchKernelGGL((tail_fwd_kernel<false, RUMPY_FMT_F16>), dim3(gx), dim3(256), 0, s, d);
   else hipLaunchKernelGGL(tail_fwd_kernel<false>, dim3(gx), dim3(256), 0, s, d);
   if (p->target) {
     const float inv = 1.0f / ((float)p->N * p->C * p->H * p->W);

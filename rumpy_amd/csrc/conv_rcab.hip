@@ -77,7 +77,8 @@ __device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int 
 }
 
 // MB (backward only): the ReLU mask comes as bytes (written by the forward launch) instead of the bf16 activation
-template <bool BWD, bool MB = false>
+// FMT: element format (RUMPY_FMT_F16 is instantiated for the forward launch only: evaluation plans)
+template <bool BWD, bool MB = false, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
   __shared__ float sx[8 * 64];
@@ -203,8 +204,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const int pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
       if (p < BSH * BSW * 8) {
         float d[8], t[8];
-        unpack8(*reinterpret_cast<const uint4*>(ldx + swz((r + 2) * BCOLS + col + 1, tid & 7)), d);
-        unpack8(T2[i], t);
+        unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((r + 2) * BCOLS + col + 1, tid & 7)), d);
+        unpack8<FMT>(T2[i], t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) part8[j] = fmaf(d[j], t[j], part8[j]);
       }
@@ -268,9 +269,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         if (ok) {
           uint4* cell = reinterpret_cast<uint4*>(ldx + swz(pix, part));
           float d[8];
-          unpack8(*cell, d);
-          const uint2 lo = pack4_bf16(fmaf(d[0], ga.x, pa.x), fmaf(d[1], ga.y, pa.y), fmaf(d[2], ga.z, pa.z), fmaf(d[3], ga.w, pa.w));
-          const uint2 hi = pack4_bf16(fmaf(d[4], gb.x, pb.x), fmaf(d[5], gb.y, pb.y), fmaf(d[6], gb.z, pb.z), fmaf(d[7], gb.w, pb.w));
+          unpack8<FMT>(*cell, d);
+          const uint2 lo = pack4<FMT>(fmaf(d[0], ga.x, pa.x), fmaf(d[1], ga.y, pa.y), fmaf(d[2], ga.z, pa.z), fmaf(d[3], ga.w, pa.w));
+          const uint2 hi = pack4<FMT>(fmaf(d[4], gb.x, pb.x), fmaf(d[5], gb.y, pb.y), fmaf(d[6], gb.z, pb.z), fmaf(d[7], gb.w, pb.w));
           const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
           *cell = o;
           if (lr >= 2 && lr < 2 + BSH) *reinterpret_cast<uint4*>(a.t2 + (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8)) = o;
@@ -304,7 +305,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       for (int c = 0; c < 3; ++c) acc[r][c] = b4;
     unsigned off[8][2];
     sweep_bases(off, 0u, 4 * rh, px, g);
-    block_sweep<4>(acc, F, lds, off);
+    block_sweep<4, FMT>(acc, F, lds, off);
     RC_STAMP();                            // sweep A done
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const int j = 4 * rh + jr, xx = 16 * c + px;
       uint4 o = make_uint4(0, 0, 0, 0);
       if (moff[k] != 0xffffffffu) {
-        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
         if (BWD && !MB) o = relu_mask_packed(o, M[(BWD && !MB) ? k : 0]);
         if (BWD && MB) o = relu_mask_bits(o, MBY[(BWD && MB) ? k : 0]);
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     }
     unsigned off[8][2];
     sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
-    block_sweep<3>(acc, F, lds, off);
+    block_sweep<3, FMT>(acc, F, lds, off);
     RC_STAMP();                            // sweep B done
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
     float V[4][8], vs[4];
@@ -385,28 +386,28 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       for (int k = 0; k < 4; ++k) {
         if (ooff[k] != 0xffffffffu) {
           float m[8];
-          unpack8(P1p[BWD ? k : 0], m);
+          unpack8<FMT>(P1p[BWD ? k : 0], m);
           if (a.res2) {
             float e[8];
-            unpack8(*reinterpret_cast<const uint4*>(a.res2 + ooff[k]), e);
+            unpack8<FMT>(*reinterpret_cast<const uint4*>(a.res2 + ooff[k]), e);
 #pragma unroll
             for (int j = 0; j < 8; ++j) m[j] += e[j];
           }
-          const uint2 lo = pack4_bf16(V[k][0] + m[0], V[k][1] + m[1], V[k][2] + m[2], V[k][3] + m[3]);
-          const uint2 hi = pack4_bf16(V[k][4] + m[4], V[k][5] + m[5], V[k][6] + m[6], V[k][7] + m[7]);
+          const uint2 lo = pack4<FMT>(V[k][0] + m[0], V[k][1] + m[1], V[k][2] + m[2], V[k][3] + m[3]);
+          const uint2 hi = pack4<FMT>(V[k][4] + m[4], V[k][5] + m[5], V[k][6] + m[6], V[k][7] + m[7]);
           *reinterpret_cast<uint4*>(a.out + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
       }
       if (osoff != 0xffffffffu) {
         float m[4];
-        unpack4_bf16(P1s, m);
+        unpack4<FMT>(P1s, m);
         if (a.res2) {
           float e[4];
-          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + osoff), e);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res2 + osoff), e);
 #pragma unroll
           for (int j = 0; j < 4; ++j) m[j] += e[j];
         }
-        *reinterpret_cast<uint2*>(a.out + osoff) = pack4_bf16(vs[0] + m[0], vs[1] + m[1], vs[2] + m[2], vs[3] + m[3]);
+        *reinterpret_cast<uint2*>(a.out + osoff) = pack4<FMT>(vs[0] + m[0], vs[1] + m[1], vs[2] + m[2], vs[3] + m[3]);
       }
     } else {
       // t2 = conv2(t1) + b2: channel sums of the strip for the attention pool, t2 itself to HBM when training
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) ps8[j] += V[k][j];
           if (a.t2) {
-            const uint2 lo = pack4_bf16(V[k][0], V[k][1], V[k][2], V[k][3]), hi = pack4_bf16(V[k][4], V[k][5], V[k][6], V[k][7]);
+            const uint2 lo = pack4<FMT>(V[k][0], V[k][1], V[k][2], V[k][3]), hi = pack4<FMT>(V[k][4], V[k][5], V[k][6], V[k][7]);
             *reinterpret_cast<uint4*>(a.t2 + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
         }
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (osoff != 0xffffffffu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) ps[j] += vs[j];
-        if (a.t2) *reinterpret_cast<uint2*>(a.t2 + osoff) = pack4_bf16(vs[0], vs[1], vs[2], vs[3]);
+        if (a.t2) *reinterpret_cast<uint2*>(a.t2 + osoff) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -474,18 +475,18 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
           const int srow = 3 * rh + r, xx = 16 * c + px;
           float m[8];
-          unpack8(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);
-          const uint2 lo = pack4_bf16(fmaf(V[k][0], ga.x, m[0]), fmaf(V[k][1], ga.y, m[1]), fmaf(V[k][2], ga.z, m[2]), fmaf(V[k][3], ga.w, m[3]));
-          const uint2 hi = pack4_bf16(fmaf(V[k][4], gb.x, m[4]), fmaf(V[k][5], gb.y, m[5]), fmaf(V[k][6], gb.z, m[6]), fmaf(V[k][7], gb.w, m[7]));
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);
+          const uint2 lo = pack4<FMT>(fmaf(V[k][0], ga.x, m[0]), fmaf(V[k][1], ga.y, m[1]), fmaf(V[k][2], ga.z, m[2]), fmaf(V[k][3], ga.w, m[3]));
+          const uint2 hi = pack4<FMT>(fmaf(V[k][4], gb.x, m[4]), fmaf(V[k][5], gb.y, m[5]), fmaf(V[k][6], gb.z, m[6]), fmaf(V[k][7], gb.w, m[7]));
           *reinterpret_cast<uint4*>(a.out + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
       }
       if (osoff != 0xffffffffu) {
         const int srow = 3 * rh + 2, xx = 32 + px;
         float m[4];
-        unpack4_bf16(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
+        unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
         const float4 gs = *reinterpret_cast<const float4*>(sgate + c0);
-        *reinterpret_cast<uint2*>(a.out + osoff) = pack4_bf16(fmaf(vs[0], gs.x, m[0]), fmaf(vs[1], gs.y, m[1]), fmaf(vs[2], gs.z, m[2]), fmaf(vs[3], gs.w, m[3]));
+        *reinterpret_cast<uint2*>(a.out + osoff) = pack4<FMT>(fmaf(vs[0], gs.x, m[0]), fmaf(vs[1], gs.y, m[1]), fmaf(vs[2], gs.z, m[2]), fmaf(vs[3], gs.w, m[3]));
       }
     }
   }
@@ -507,6 +508,7 @@ static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const c
   const int sy_n = (p->H + BSH - 1) / BSH;
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW || p->cr <= 0 || p->cr > RC_MAXR || sy_n > rumpy_device_cus() || p->seq >= 4096u) {
     rumpy_set_error("%s: needs 0 < W <= 48, ceil(H/6) <= CUs, 0 < Cr <= 16, seq < 4096 (W=%d H=%d Cr=%d seq=%u)", what, p->W, p->H, p->cr, p->seq); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !bwd)) { rumpy_set_error("%s: fmt %d is a forward-only format", what, p->fmt); return RUMPY_E_ARG; }
   const int64_t need = rumpy_rcab_xchg_bytes(p->N, p->H);
   if (p->xchg_bytes < need) { rumpy_set_error("%s: exchange buffer too small (%lld < %lld)", what, (long long)p->xchg_bytes, (long long)need); return RUMPY_E_ARG; }
   RcabDev d;
@@ -520,6 +522,7 @@ static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const c
   const dim3 grid(d.N * sy_n);
   if (bwd && p->maskbits) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, true>), grid, dim3(BTHREADS), s, d);
   else if (bwd) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, false>), grid, dim3(BTHREADS), s, d);
+  else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);
   else RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false>), grid, dim3(BTHREADS), s, d);
   return rumpy_check_launch(what);
 }

@@ -83,7 +83,8 @@ __device__ __forceinline__ void strip_write(const uint4 (&R)[SREGS], unsigned ch
 // STAMP = true is a diagnostic build: lane 0 of every wave writes s_memrealtime (100 MHz) stamps at the phase
 // boundaries of its FIRST strip into a.pool (reinterpreted as u64 [workgroup][wave][8]); never used by the product.
 // DBG (diagnostic builds only): 1 = MFMAs without the LDS fragment reads, 2 = LDS fragment reads without the MFMAs
-template <int CHUNKS, bool STAMP, int DBG = 0>
+// FMT: element format of x, w, out and the residual operands (RUMPY_FMT_F16: the evaluation plans)
+template <int CHUNKS, bool STAMP, int DBG = 0, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SSTAGE];
   unsigned long long stamps[8];
@@ -166,8 +167,8 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
       }
       const bool in = poff[k] != 0xffffffffu;
       if (a.mask) {
-        unpack4_bf16(make_uint2(P0p[k].x, P0p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
-        unpack4_bf16(make_uint2(P0p[k].z, P0p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
+        unpack4<FMT>(make_uint2(P0p[k].x, P0p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
+        unpack4<FMT>(make_uint2(P0p[k].z, P0p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
       }
@@ -176,26 +177,26 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
         for (int j = 0; j < 8; ++j) ps8[j] += v[j];
       }
       if (!a.mask && p0) {
-        unpack4_bf16(make_uint2(P0p[k].x, P0p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
-        unpack4_bf16(make_uint2(P0p[k].z, P0p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
+        unpack4<FMT>(make_uint2(P0p[k].x, P0p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
+        unpack4<FMT>(make_uint2(P0p[k].z, P0p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += m[j];
       }
       if (p1) {
-        unpack4_bf16(make_uint2(P1p[k].x, P1p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
-        unpack4_bf16(make_uint2(P1p[k].z, P1p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
+        unpack4<FMT>(make_uint2(P1p[k].x, P1p[k].y), *reinterpret_cast<float(*)[4]>(&m[0]));
+        unpack4<FMT>(make_uint2(P1p[k].z, P1p[k].w), *reinterpret_cast<float(*)[4]>(&m[4]));
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += m[j];
       }
       if (in) {
         if (p2) {
           const uint4 t = *reinterpret_cast<const uint4*>(p2 + poff[k]);
-          unpack4_bf16(make_uint2(t.x, t.y), *reinterpret_cast<float(*)[4]>(&m[0]));
-          unpack4_bf16(make_uint2(t.z, t.w), *reinterpret_cast<float(*)[4]>(&m[4]));
+          unpack4<FMT>(make_uint2(t.x, t.y), *reinterpret_cast<float(*)[4]>(&m[0]));
+          unpack4<FMT>(make_uint2(t.z, t.w), *reinterpret_cast<float(*)[4]>(&m[4]));
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
-        const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
         *reinterpret_cast<uint4*>(a.out + poff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
       float v[4] = {t[0], t[1], t[2], t[3]};
       float m[4];
       if (a.mask) {
-        unpack4_bf16(P0s, m);
+        unpack4<FMT>(P0s, m);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
       }
@@ -213,22 +214,22 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
         for (int j = 0; j < 4; ++j) ps[j] += v[j];
       }
       if (!a.mask && p0) {
-        unpack4_bf16(P0s, m);
+        unpack4<FMT>(P0s, m);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += m[j];
       }
       if (p1) {
-        unpack4_bf16(P1s, m);
+        unpack4<FMT>(P1s, m);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += m[j];
       }
       if (soff != 0xffffffffu) {
         if (p2) {
-          unpack4_bf16(*reinterpret_cast<const uint2*>(p2 + soff), m);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(p2 + soff), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
-        *reinterpret_cast<uint2*>(a.out + soff) = pack4_bf16(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>(a.out + soff) = pack4<FMT>(v[0], v[1], v[2], v[3]);
       }
     }
     if (a.pool && !STAMP) {
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(STHREADS, 2) conv3x3_strip_kernel(StripDev a) 
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
               for (int r = 0; r < 3; ++r)
-                acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c], 0, 0, 0);
+                acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c]);
           }
         }
       }
@@ -405,6 +406,8 @@ int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s) {
     if (dbg == 0) hipLaunchKernelGGL((conv3x3_strip_kernel<1, true, 0>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
     else if (dbg == 1) hipLaunchKernelGGL((conv3x3_strip_kernel<1, true, 1>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
     else hipLaunchKernelGGL((conv3x3_strip_kernel<1, true, 2>), dim3(gx, 1), dim3(STHREADS), 0, s, d);
+  } else if (p->fmt == RUMPY_FMT_F16) {   // evaluation plans: forward launches only (rumpy_conv3x3 checks cin_chunks == 1, no mask)
+    hipLaunchKernelGGL((conv3x3_strip_kernel<1, false, 0, RUMPY_FMT_F16>), dim3(gx, p->cout_tiles), dim3(STHREADS), 0, s, d);
   } else if (p->cin_chunks == 1) {
     hipLaunchKernelGGL((conv3x3_strip_kernel<1, false>), dim3(gx, p->cout_tiles), dim3(STHREADS), 0, s, d);
   } else {

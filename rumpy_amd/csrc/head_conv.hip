@@ -10,7 +10,7 @@ constexpr int HEAD_MAXC = 4;
 constexpr int HEAD_FWD_THREADS = 64;
 
 // one thread = one pixel x 64 output channels; weights transposed to [k = (c,ky,kx)][co] in LDS (broadcast reads)
-template <int C>
+template <int C, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, uint16_t* __restrict__ out,
                                                        int N, int H, int W, int cout, float slope_m1) {
@@ -58,8 +58,8 @@ __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float*
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = fmaf(slope_m1, fminf(acc[j], 0.f), acc[j]);
     }
-    const uint2 lo = pack4_bf16(acc[0], acc[1], acc[2], acc[3]);
-    const uint2 hi = pack4_bf16(acc[4], acc[5], acc[6], acc[7]);
+    const uint2 lo = pack4<FMT>(acc[0], acc[1], acc[2], acc[3]);
+    const uint2 hi = pack4<FMT>(acc[4], acc[5], acc[6], acc[7]);
     *reinterpret_cast<uint4*>(op + cb) = make_uint4(lo.x, lo.y, hi.x, hi.y);
   }
 }
@@ -286,12 +286,24 @@ extern "C" int rumpy_head_fwd(const rumpy_head_fwd_args* p, void* stream) {
   dim3 grid((unsigned)((total + HEAD_FWD_THREADS - 1) / HEAD_FWD_THREADS), p->cout / 64);
   hipStream_t s = (hipStream_t)stream;
   uint16_t* o = (uint16_t*)p->out;
-  switch (p->C) {
-    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
-    case 2: hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
-    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
-    default: hipLaunchKernelGGL(head_fwd_kernel<4>, grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1); break;
+  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("rumpy_head_fwd: bad fmt %d", p->fmt); return RUMPY_E_ARG; }
+#define HEAD_LAUNCH(C_, F_) hipLaunchKernelGGL((head_fwd_kernel<C_, F_>), grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1)
+  if (p->fmt == RUMPY_FMT_F16) {
+    switch (p->C) {
+      case 1: HEAD_LAUNCH(1, RUMPY_FMT_F16); break;
+      case 2: HEAD_LAUNCH(2, RUMPY_FMT_F16); break;
+      case 3: HEAD_LAUNCH(3, RUMPY_FMT_F16); break;
+      default: HEAD_LAUNCH(4, RUMPY_FMT_F16); break;
+    }
+  } else {
+    switch (p->C) {
+      case 1: HEAD_LAUNCH(1, RUMPY_FMT_BF16); break;
+      case 2: HEAD_LAUNCH(2, RUMPY_FMT_BF16); break;
+      case 3: HEAD_LAUNCH(3, RUMPY_FMT_BF16); break;
+      default: HEAD_LAUNCH(4, RUMPY_FMT_BF16); break;
+    }
   }
+#undef HEAD_LAUNCH
   return rumpy_check_launch("rumpy_head_fwd");
 }
 

@@ -60,8 +60,9 @@ __global__ void sum_final_kernel(const float* __restrict__ partial, int n, float
 // co(t, c) = shuffle ? 4*c + t : 64*t + c
 // kind 2 (tail, Cout <= 4, Cin = 64): forward image [s][lane][8]: row r < Cout real, zero otherwise;
 //   dgrad image [wave][ks][lane][8]: row ci = 16*wave + r, k = 32*ks + 8g + e -> tap = k>>2, c = k&3: W[c][ci][2-ky][2-kx]
-__global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
-  const rumpy_pack_item it = items[blockIdx.y];
+template <int FMT> __device__ __forceinline__ uint16_t pack1(float f) { return (uint16_t)(pack2<FMT>(f, 0.f) & 0xffffu); }
+template <int FMT>
+__device__ __forceinline__ void pack_item(const rumpy_pack_item& it) {
   uint16_t* wf = (uint16_t*)it.w_fwd;
   uint16_t* wd = (uint16_t*)it.w_dgrad;
   const int Co = it.cout, Ci = it.cin;
@@ -80,7 +81,7 @@ __global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
         const int c = 16 * wave + r;
         const int co = it.shuffle ? 4 * c + ct : 64 * ct + c;
         const float* src = it.w + ((size_t)co * Ci + 64 * ch + 32 * half + 8 * g) * 9 + ky * 3 + kx;
-        const uint2 lo = pack4_bf16(src[0], src[9], src[18], src[27]), hi = pack4_bf16(src[36], src[45], src[54], src[63]);
+        const uint2 lo = pack4<FMT>(src[0], src[9], src[18], src[27]), hi = pack4<FMT>(src[36], src[45], src[54], src[63]);
         reinterpret_cast<uint4*>(wf)[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
       if (wd) {  // dgrad: r2 = ct'*ctn + ch'; the 8 elements are 8 output channels (stride Ci*9, or 4*Ci*9 when shuffled)
@@ -90,8 +91,8 @@ __global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
         const size_t co0 = it.shuffle ? (size_t)4 * cc0 + chp : (size_t)64 * chp + cc0;
         const size_t cstep = (size_t)(it.shuffle ? 4 : 1) * Ci * 9;
         const float* src = it.w + (co0 * Ci + ci) * 9 + (2 - ky) * 3 + (2 - kx);
-        const uint2 lo = pack4_bf16(src[0], src[cstep], src[2 * cstep], src[3 * cstep]);
-        const uint2 hi = pack4_bf16(src[4 * cstep], src[5 * cstep], src[6 * cstep], src[7 * cstep]);
+        const uint2 lo = pack4<FMT>(src[0], src[cstep], src[2 * cstep], src[3 * cstep]);
+        const uint2 hi = pack4<FMT>(src[4 * cstep], src[5 * cstep], src[6 * cstep], src[7 * cstep]);
         reinterpret_cast<uint4*>(wd)[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
@@ -108,7 +109,7 @@ __global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
       const int r = lane & 15, g = lane >> 4;
       const int half = s & 1, tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
       const int ci = 32 * half + 8 * g + e;
-      wf[i] = (r < Co) ? f32_to_bf16_bits(it.w[((size_t)r * Ci + ci) * 9 + ky * 3 + kx]) : (uint16_t)0;
+      wf[i] = (r < Co) ? pack1<FMT>(it.w[((size_t)r * Ci + ci) * 9 + ky * 3 + kx]) : (uint16_t)0;
     }
     if (wd) {
       for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * 2 * 64 * 8; i += gridDim.x * blockDim.x) {
@@ -118,12 +119,17 @@ __global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
         uint16_t v = 0;
         if (tap < 9 && c < Co) {
           const int ky = tap / 3, kx = tap - 3 * ky;
-          v = f32_to_bf16_bits(it.w[((size_t)c * Ci + 16 * wave + r) * 9 + (2 - ky) * 3 + (2 - kx)]);
+          v = pack1<FMT>(it.w[((size_t)c * Ci + 16 * wave + r) * 9 + (2 - ky) * 3 + (2 - kx)]);
         }
         wd[i] = v;
       }
     }
   }
+}
+__global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
+  const rumpy_pack_item it = items[blockIdx.y];
+  if (it.fmt == RUMPY_FMT_F16) pack_item<RUMPY_FMT_F16>(it);
+  else pack_item<RUMPY_FMT_BF16>(it);
 }
 
 // ---- eval post-processing: clip, RGB -> YCbCr ('jpg' matrix), squared Y error vs the clipped reference ----

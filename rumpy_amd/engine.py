@@ -31,6 +31,7 @@ class ConvLayer:
         self.name, self.weight, self.bias, self.kind, self.shuffle = name, weight, bias, kind, shuffle
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.w_fwd = self.w_dgrad = self.b_packed = None
+        self.w_fwd_h = None       # fp16 forward image (evaluation plans), allocated with the first such plan
         self.gw = self.gb = None  # views into the flat gradient buffer
 
 
@@ -113,6 +114,14 @@ class SREngine:
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
+        # Evaluation plans store activations and filters as IEEE fp16 (same MFMA rate and bytes as bf16, 11 instead of 8 significant bits):
+        # bf16 storage alone costs a >= 30 dB model 0.02-0.03 dB of Y-PSNR against the fp32 reference (fixtures G17 / G18).
+        # Training stays bf16 (gradient range).  An output that is not finite (fp16 overflow) switches the engine back to bf16 for good.
+        self.eval_fmt = L.FMT_BF16 if os.environ.get('RUMPY_EVAL_BF16') == '1' else L.FMT_F16
+        self.max_eval_plans = max(1, int(os.environ.get('RUMPY_EVAL_PLANS', '4')))     # LRU bound on cached evaluation plans (one per image size)
+        self.pack_gen = 0          # bumped by every repack(); the fp16 images follow lazily (h_gen)
+        self.h_gen = -1
+        self._pack_items_h = None
         self.feats = spec.head.cout
         if self.feats != 64:
             raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 (got %d); other widths are not '
@@ -160,6 +169,28 @@ class SREngine:
         """fp32 OIHW master weights -> bf16 MFMA-fragment images (after every optimizer step / weight load)."""
         s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.rumpy_pack_weights(_ptr(self._pack_items), self._n_pack, s), 'rumpy_pack_weights')
+        self.pack_gen += 1
+
+    def _alloc_packed_h(self):
+        """fp16 forward images of every MFMA conv (evaluation plans only: no data-gradient image, the packed biases are shared)"""
+        items = []
+        for cv in self.spec.convs():
+            if cv.kind == 'head':
+                continue
+            kind = 0 if cv.kind == 'main' else 2
+            cv.w_fwd_h = torch.empty(cv.cout * cv.cin * 9 if kind == 0 else 18 * 64 * 8, dtype=torch.float16, device=self.device)
+            items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd_h), w_dgrad=None, b_packed=None, cout=cv.cout,
+                                    cin=cv.cin, kind=kind, shuffle=1 if (kind == 0 and cv.shuffle) else 0, fmt=L.FMT_F16))
+        self._pack_items_h_host = (L.PackItem * len(items))(*items)
+        self._pack_items_h = self._to_device_bytes(self._pack_items_h_host)
+
+    def _repack_h(self, stream):
+        """bring the fp16 images up to date with the master weights (no-op when nothing was re-packed since)"""
+        if self._pack_items_h is None:
+            self._alloc_packed_h()
+        if self.h_gen != self.pack_gen:
+            L.check(self.lib.rumpy_pack_weights(_ptr(self._pack_items_h), self._n_pack, stream), 'rumpy_pack_weights')
+            self.h_gen = self.pack_gen
 
     # ------------------------------------------------------------------ plan construction
     def _new(self, plan, *shape, dtype=BF16):
@@ -168,21 +199,27 @@ class SREngine:
         return t
 
     def _conv(self, ops, x, cv, N, H, W, out, dgrad=False, relu=False, scale=1.0, mask=None, res1=None, res2=None,
-              pool=None, in_mode=0, out_mode=0, bias=True):
+              pool=None, in_mode=0, out_mode=0, bias=True, fmt=0):
         if dgrad:
             w, cin_chunks, cout_tiles, b = cv.w_dgrad, cv.cout // 64, cv.cin // 64, None
         else:
-            w, cin_chunks, cout_tiles, b = cv.w_fwd, cv.cin // 64, cv.cout // 64, (cv.b_packed if bias else None)
+            w, cin_chunks, cout_tiles, b = (cv.w_fwd_h if fmt else cv.w_fwd), cv.cin // 64, cv.cout // 64, (cv.b_packed if bias else None)
         a = L.ConvArgs(x=_ptr(x), w=_ptr(w), bias=_ptr(b), out=_ptr(out), mask=_ptr(mask), res1=_ptr(res1), res2=_ptr(res2),
                        pool=_ptr(pool), N=N, H=H, W=W, cin_chunks=cin_chunks, cout_tiles=cout_tiles, in_mode=in_mode,
-                       out_mode=out_mode, relu=1 if relu else 0, scale=float(scale), grid_x=0)
+                       out_mode=out_mode, relu=1 if relu else 0, scale=float(scale), grid_x=0, fmt=fmt)
         ops.append(('rumpy_conv3x3', a))
 
-    def _build(self, N, H, W, train):
+    def _build(self, N, H, W, train, fmt=0):
         spec, lib = self.spec, self.lib
         F = self.feats
+        if fmt and train:
+            raise RuntimeError('rumpy_amd: training plans are bf16')
+        if fmt and self._pack_items_h is None:
+            self._alloc_packed_h()
+        wf = (lambda cv: cv.w_fwd_h) if fmt else (lambda cv: cv.w_fwd)       # forward filter image of this plan's format
         plan = _Plan()
-        plan.N, plan.H, plan.W, plan.train = N, H, W, train
+        plan.N, plan.H, plan.W, plan.train, plan.fmt = N, H, W, train, fmt
+        plan.gen = 0              # forward-pass counter of a training plan: a backward pass must belong to the LAST forward pass
         Cin, Cout = spec.head.cin, spec.tail.cout
         plan.x_in = self._new(plan, N, Cin, H, W, dtype=torch.float32)
         fwd, bwd = plan.fwd, plan.bwd
@@ -195,6 +232,8 @@ class SREngine:
         plan.ca_param_items = []
         plan.q_items, plan.q_shape, plan.q_dev = [], None, None
         plan.rcab_n, plan.rcab_xchg, plan.rcab_epoch, plan.rcab_status = 0, None, None, None
+        # device status words read back together: [0] a non-finite output value (rumpy_tail_fwd, evaluation plans), [1] strip-exchange watchdog
+        plan.flags = torch.zeros(2, dtype=torch.int32, device=self.device)
         plan.meta = self._new(plan, N, max(1, spec.num_metadata), dtype=torch.float32) if spec.num_metadata else None
 
         def act():
@@ -210,7 +249,7 @@ class SREngine:
         a0 = act()
         protected.append(a0.data_ptr())
         plan.head_args = L.HeadFwdArgs(x=_ptr(plan.x_in), w=_ptr(spec.head.weight), b=_ptr(spec.head.bias),
-                                       out=_ptr(a0), N=N, C=Cin, H=H, W=W, cout=F)
+                                       out=_ptr(a0), N=N, C=Cin, H=H, W=W, cout=F, fmt=fmt)
         fwd.append(('rumpy_head_fwd', plan.head_args))
 
         def emit_items(items, cur):
@@ -231,11 +270,11 @@ class SREngine:
                     mb = self._new(plan, N, H, W, 8, dtype=torch.uint8) if (fused and train and self.use_mask_bytes) else None
                     if fused:
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
-                            x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed), mask=None,
-                            res2=None, t=_ptr(t1), out=_ptr(y), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs), maskbits=_ptr(mb))))
+                            x=_ptr(cur), w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed), mask=None,
+                            res2=None, t=_ptr(t1), out=_ptr(y), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs), maskbits=_ptr(mb), fmt=fmt)))
                     else:
-                        self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
-                        self._conv(fwd, t1, c2, N, H, W, y, scale=rs, res1=cur)
+                        self._conv(fwd, cur, c1, N, H, W, t1, relu=True, fmt=fmt)
+                        self._conv(fwd, t1, c2, N, H, W, y, scale=rs, res1=cur, fmt=fmt)
 
                     def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs, fused=fused, mb=mb):
                         # y = x + rs*conv2(relu(conv1 x)):  dt1 = rs*dgrad2(g) masked ; dx = g + dgrad1(dt1) (+ extra)
@@ -280,12 +319,14 @@ class SREngine:
                     fused = self.use_block_kernel and W <= 48
                     # the whole RCAB in one launch (conv_rcab.hip): the strips of an image exchange their pool sums, the gate is applied on chip
                     rc = fused and self.use_rcab_kernel and (H + 5) // 6 <= self.cus and 2 * plan.rcab_n + 2 <= 4096
+                    if fmt and not rc:
+                        fused = False          # the general form of the block kernel is bf16 only: separate launches then
                     rc_common, seq = None, None
                     if rc:
                         if plan.rcab_xchg is None:
                             plan.rcab_xchg = torch.zeros(int(self.lib.rumpy_rcab_xchg_bytes(N, H)), dtype=torch.uint8, device=self.device)
                             plan.rcab_epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
-                            plan.rcab_status = torch.zeros(1, dtype=torch.int32, device=self.device)
+                            plan.rcab_status = plan.flags[1:2]
                         seq = 2 * plan.rcab_n
                         plan.rcab_n += 1
                         mbr = self._new(plan, N, H, W, 8, dtype=torch.uint8) if (train and self.use_mask_bytes) else None
@@ -293,22 +334,22 @@ class SREngine:
                                          hidden=_ptr(hid), gate=_ptr(gate), qgate=_ptr(qg), xchg=_ptr(plan.rcab_xchg),
                                          xchg_bytes=plan.rcab_xchg.numel(), epoch=_ptr(plan.rcab_epoch), status=_ptr(plan.rcab_status))
                         fwd.append(('rumpy_rcab_fwd', L.RcabArgs(
-                            x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed),
-                            t=_ptr(t1) if train else None, t2=_ptr(t2) if train else None, out=_ptr(y), mean=_ptr(mean), seq=seq, **rc_common)))
+                            x=_ptr(cur), w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed),
+                            t=_ptr(t1) if train else None, t2=_ptr(t2) if train else None, out=_ptr(y), mean=_ptr(mean), seq=seq, fmt=fmt, **rc_common)))
                     elif fused:   # conv -> ReLU -> conv (+ pool partial sums) in one launch, no residual yet (the gate comes first)
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
                             x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed), mask=None,
                             res2=None, t=_ptr(t1), out=_ptr(t2), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, res_mode=1,
                             res1=None, pool=_ptr(pool))))
                     else:
-                        self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
-                        self._conv(fwd, t1, c2, N, H, W, t2, pool=pool)
+                        self._conv(fwd, cur, c1, N, H, W, t1, relu=True, fmt=fmt)
+                        self._conv(fwd, t1, c2, N, H, W, t2, pool=pool, fmt=fmt)
                     if not rc:
                         # squeeze-excite MLP + gate * t2 + skip in one launch (the MLP is recomputed per workgroup)
                         fwd.append(('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(
                             pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2), b2=_ptr(ca.b2), mean=_ptr(mean),
                             hidden=_ptr(hid), gate=_ptr(gate), t=_ptr(t2), res=_ptr(cur), out=_ptr(y), N=N, HW=H * W, C=F, Cr=ca.Cr,
-                            ntiles=tiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg))))
+                            ntiles=tiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg), fmt=fmt)))
 
                     def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused, qg=qg, qdz=qdz,
                              rc_common=rc_common, rc_seq=seq):
@@ -360,7 +401,7 @@ class SREngine:
                     protected.append(x_in.data_ptr())
                     inner, sub_nodes = emit_items(sub, x_in)
                     y = act()
-                    self._conv(fwd, inner, gconv, N, H, W, y, res1=x_in)
+                    self._conv(fwd, inner, gconv, N, H, W, y, res1=x_in, fmt=fmt)
                     protected.pop()
                     nodes.append(('group', gconv, inner, sub_nodes))
                     if inner is not x_in:
@@ -371,13 +412,13 @@ class SREngine:
 
         last, tree = emit_items(spec.body, a0)
         r = act()
-        self._conv(fwd, last, spec.body_conv, N, H, W, r, res1=a0)
+        self._conv(fwd, last, spec.body_conv, N, H, W, r, res1=a0, fmt=fmt)
         # ---- upsampler ----
         ups_in = []
         u, h, w = r, H, W
         for cv in spec.ups:
             nxt = self._new(plan, N, 2 * h, 2 * w, F)
-            self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1)
+            self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1, fmt=fmt)
             ups_in.append((cv, u, h, w))
             u, h, w = nxt, 2 * h, 2 * w
         # ---- tail (+ fused L1) ----
@@ -388,15 +429,18 @@ class SREngine:
         plan.loss_partial = self._new(plan, max(tail_grid, 1), dtype=torch.float32)
         plan.target = self._new(plan, N, Cout, h, w, dtype=torch.float32)
         plan.dy4 = self._new(plan, N, h, w, 4) if train else None
-        plan.tail_plain = L.TailFwdArgs(x=_ptr(u), w=_ptr(spec.tail.w_fwd), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
-                                        target=None, dy4=None, loss_partial=None, loss=None, N=N, C=Cout, H=h, W=w, grid_x=tail_grid)
+        plan.nonfinite = None if train else plan.flags[0:1]      # raised by the tail kernel (fp16 overflow)
+        plan.tail_plain = L.TailFwdArgs(x=_ptr(u), w=_ptr(wf(spec.tail)), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
+                                        target=None, dy4=None, loss_partial=None, loss=None, N=N, C=Cout, H=h, W=w, grid_x=tail_grid,
+                                        nonfinite=_ptr(plan.nonfinite), fmt=fmt)
         # fused L1 training path: the tail conv's weight gradient is accumulated inside the same pass (one slab per workgroup)
         plan.tail_slabs = int(lib.rumpy_tail_fwd_grid(N, h, w, tail_grid))
         plan.tail_wslab = self._new(plan, plan.tail_slabs * int(lib.rumpy_wgrad_slab_floats(1)), dtype=torch.float32) if train else None
         plan.tail_fused = False
-        plan.tail_loss = L.TailFwdArgs(x=_ptr(u), w=_ptr(spec.tail.w_fwd), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
+        plan.tail_loss = L.TailFwdArgs(x=_ptr(u), w=_ptr(wf(spec.tail)), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
                                        target=_ptr(plan.target), dy4=_ptr(plan.dy4), loss_partial=_ptr(plan.loss_partial),
-                                       loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid, wslab=_ptr(plan.tail_wslab))
+                                       loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid, wslab=_ptr(plan.tail_wslab),
+                                       nonfinite=_ptr(plan.nonfinite), fmt=fmt)
         if not train:
             return plan
 
@@ -639,12 +683,20 @@ class SREngine:
                     'rumpy_q_mlp_bwd_params')
 
     # ------------------------------------------------------------------ execution
-    def plan_for(self, N, H, W, train):
-        key = (N, H, W, bool(train))
-        p = self.plans.get(key)
+    def plan_for(self, N, H, W, train, fmt=0):
+        """the cached plan of a shape.  Training plans are kept; evaluation plans (one per image size, each owning its activation
+        buffers - hundreds of MB for a full-size image) live in an LRU of `max_eval_plans`."""
+        key = (N, H, W, bool(train), int(fmt))
+        p = self.plans.pop(key, None)
         if p is None:
-            p = self._build(N, H, W, bool(train))
-            self.plans[key] = p
+            p = self._build(N, H, W, bool(train), int(fmt))
+        self.plans[key] = p                 # most recently used last
+        if not train:
+            ev = [k for k in self.plans if not k[3]]
+            for k in ev[:max(0, len(ev) - self.max_eval_plans)]:
+                old = self.plans.pop(k)
+                for ops in (old.fwd, old.bwd):
+                    self._tables.pop(id(ops), None)
         return p
 
     def _run(self, ops, stream):
@@ -668,8 +720,12 @@ class SREngine:
         """x (and target): contiguous fp32 [N,C,H,W] on the device; meta: fp32 [N,M] metadata (meta-attention nets only).
         Returns (out fp32 [N,C,sH,sW], loss tensor | None, plan)."""
         N, _, H, W = x.shape
-        plan = self.plan_for(N, H, W, train)
+        fmt = 0 if train else self.eval_fmt
+        plan = self.plan_for(N, H, W, train, fmt)
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if fmt:
+            self._repack_h(stream)
+        plan.gen += 1
         self._q_gates(plan, meta, stream)
         self._advance_epoch(plan, stream)
         # the head / tail kernels read the caller's fp32 NCHW tensors in place and write a fresh output tensor: no copies
@@ -684,11 +740,29 @@ class SREngine:
             plan.tail_loss.target = target.data_ptr()
             L.call('rumpy_tail_fwd', plan.tail_loss, stream)
             plan.tail_fused = plan.tail_wslab is not None      # the tail weight gradient w.r.t. the L1 loss now sits in tail_wslab
-            return out, plan.loss, plan
-        plan.tail_plain.out = out.data_ptr()
-        plan.tail_fused = False
-        L.call('rumpy_tail_fwd', plan.tail_plain, stream)
-        return out, None, plan
+            loss = plan.loss
+        else:
+            plan.tail_plain.out = out.data_ptr()
+            plan.tail_fused = False
+            L.call('rumpy_tail_fwd', plan.tail_plain, stream)
+            loss = None
+        if not train:
+            # evaluation passes read both status words back here (one small copy; it synchronises - every caller of an evaluation pass
+            # fetches the image next anyway), so that neither problem can go unnoticed on any return path of the handlers
+            bad, xch = plan.flags.tolist()
+            if xch:
+                plan.flags.zero_()
+                raise RuntimeError('rumpy_amd: a strip exchange of the RCAB kernels timed out (code 0x%x); the evaluation output is invalid '
+                                   '(GPU shared with another job? RUMPY_NO_RCAB=1 selects the separate launches)' % xch)
+            if bad and fmt:             # fp16 overflowed somewhere in this network: bf16 has fp32's range
+                import warnings
+                warnings.warn('rumpy_amd: an fp16 evaluation pass produced a non-finite output; evaluation of this network continues in bf16')
+                plan.flags.zero_()
+                self.eval_fmt = L.FMT_BF16
+                return self.forward(x, train=False, target=target, meta=meta)
+            if bad:
+                plan.flags.zero_()      # bf16 plan: the fp32 reference would not be finite either; nothing to fall back to
+        return out, loss, plan
 
     def backward(self, plan, grad_scale, gout=None, on_ready=None):
         """Run the backward pass of the last training forward of `plan`.  gout: optional upstream gradient

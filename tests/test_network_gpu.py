@@ -3,7 +3,9 @@ vectors.  The HIP path keeps fp32 master weights but feeds bf16 operands to the 
 bf16, so network-level tolerances are stated as PSNR-equivalent bounds:
   * forward vs fp32 oracle: self-PSNR >= 60 dB for EDSR-baseline, >= 45 dB for RCAN stacks,
   * parameter gradients vs fp32 oracle: relative Frobenius error <= 3e-2 per tensor, cosine >= 0.999,
-  * eval Y-PSNR vs the reference's value: |delta| <= 0.02 dB (BASELINE.json north_star)."""
+  * eval Y-PSNR vs the reference's value: |delta| <= 0.02 dB (BASELINE.json north_star) - on fixtures G17 / G18, full-depth networks
+    in the >= 30 dB regime, where the bound CAN fail: the shift is 10 log10(1 + MSE_hip / MSE_model), so the forward self-PSNR must
+    also exceed the model's PSNR by 23.4 dB.  Evaluation plans run in fp16 for that reason (bf16 plans miss it: shown below)."""
 import os
 import tempfile
 
@@ -93,6 +95,71 @@ def test_rcan_small_train_step_against_oracle():
     print('worst grad rel err', worst)
 
 
+def _full_depth_step(name, wseed, N, kw, tol, cos_min):
+    """one run_train step of a FULL-DEPTH network (BASELINE configs 2 / 3) against the oracle: loss, output, every gradient tensor
+    (relative Frobenius error + cosine, worst ones printed), learning rate, and the weights after the Adam step"""
+    h, oh = _pair(name, wseed, lr=1e-4, scale=4, **kw)
+    w0 = {k: p.detach().cpu().clone() for k, p in h.net.named_parameters()}
+    x, y = O.synthetic_batch(wseed + 1000, N, lr_hw=48, scale=4)
+    loss, out = h.run_train(x=x, y=y)
+    oloss, oout = oh.run_train(x, y)
+    sp = self_psnr(out, oout)
+    rows = []
+    for (k, p), (k2, q) in zip(h.net.named_parameters(), oh.net.named_parameters()):
+        assert k == k2
+        g, r = p.grad.detach().float().cpu().double().reshape(-1), q.grad.double().reshape(-1)
+        assert torch.isfinite(g).all(), k
+        rel = float((g - r).norm() / (r.norm() + 1e-30))
+        cos = float((g @ r) / (g.norm() * r.norm() + 1e-30))
+        rows.append((rel, cos, k))
+    rows.sort(reverse=True)
+    allg = torch.cat([p.grad.detach().float().cpu().double().reshape(-1) for p in h.net.parameters()])
+    allr = torch.cat([q.grad.double().reshape(-1) for q in oh.net.parameters()])
+    tot_rel = float((allg - allr).norm() / allr.norm())
+    med = float(np.median([r[0] for r in rows]))
+    print('%s full depth (%d tensors, N=%d): loss %.6f vs %.6f, forward self-PSNR %.1f dB, whole-gradient rel %.3e, median tensor rel %.3e, worst:'
+          % (name, len(rows), N, float(loss), float(oloss), sp, tot_rel, med))
+    for rel, cos, k in rows[:5]:
+        print('    %-40s rel %.3e  cos %.6f' % (k, rel, cos))
+    assert abs(float(loss) - float(oloss)) < 2e-3 * float(oloss)
+    assert abs(h.get_learning_rate() - oh.get_learning_rate()) < 1e-12
+    # The squeeze-excite MLP has 4 hidden ReLU units per block and sees ONE vector per image: a unit whose pre-activation is within the
+    # forward error of zero for one of the N images switches, and the gradient rows of that unit change by O(1) - a discontinuity of the
+    # function, not an accumulating error (tests/tools/precision_sim.py predicts the same tensors).  Those tensors are bounded as a
+    # pool over the network and by their number; every 3x3-conv tensor individually.
+    se = [r for r in rows if 'conv_du' in r[2]]
+    for rel, cos, k in rows:
+        if 'conv_du' not in k:
+            assert rel < tol and cos > cos_min, 'grad %s: rel %.3e cos %.6f' % (k, rel, cos)
+    if se:
+        hp, op = dict(h.net.named_parameters()), dict(oh.net.named_parameters())
+        pg = torch.cat([hp[k].grad.detach().float().cpu().double().reshape(-1) for _, _, k in se])
+        pr = torch.cat([op[k].grad.double().reshape(-1) for _, _, k in se])
+        pooled = float((pg - pr).norm() / pr.norm())
+        switched = [k for rel, _, k in se if rel >= 2 * tol]
+        print('    squeeze-excite MLP tensors: pooled rel %.3e, %d of %d beyond %.0e (switched hidden units)' % (pooled, len(switched), len(se), 2 * tol))
+        assert pooled < tol and len(switched) <= max(2, len(se) // 20)
+    # Adam's first step is lr * g / (|g| + eps): the update of an element flips with the sign of a near-zero gradient, so the step is
+    # compared as a direction (cosine over ALL parameters) and by its size
+    dh = torch.cat([(p.detach().cpu() - w0[k]).double().reshape(-1) for k, p in h.net.named_parameters()])
+    do = torch.cat([(q.detach() - w0[k]).double().reshape(-1) for k, q in oh.net.named_parameters()])
+    cosu = float((dh @ do) / (dh.norm() * do.norm()))
+    print('    Adam step: cosine of the whole update %.5f, |update| %.4e vs %.4e' % (cosu, float(dh.norm()), float(do.norm())))
+    assert cosu > 0.97 and abs(float(dh.norm()) / float(do.norm()) - 1.0) < 0.02
+    assert float(dh.abs().max()) <= 1.0001e-4
+    return tot_rel, rows[0]
+
+
+def test_edsr_baseline_full_depth_gradient_parity():
+    """EDSR-baseline x4 (16 blocks, BASELINE config 2), N = 8, 48 x 48: rel < 3e-2, cosine > 0.999 on every one of the 74 gradient tensors"""
+    _full_depth_step('edsr', 521, 8, {}, 3e-2, 0.999)
+
+
+def test_rcan_full_depth_gradient_parity():
+    """RCAN x4 (10 groups x 20 RCAB = 400 bf16-stored stages of back-propagation, BASELINE config 3), N = 2, 48 x 48"""
+    _full_depth_step('rcan', 522, 2, {}, 3e-2, 0.999)
+
+
 def test_generic_autograd_path_matches_fused_path():
     """criterion other than the stock nn.L1Loss -> whole-network autograd node, same kernels"""
     h, _ = _pair('edsr', 503, scale=2, num_blocks=1, res_scale=0.1, sched=False)
@@ -154,6 +221,106 @@ def test_eval_psnr_within_0p02_db_of_reference(golden_dir):
     assert abs(p_dev - ps) < 1e-3
 
 
+def _psnr_case(golden_dir, fn, model, seed):
+    g = np.load(os.path.join(golden_dir, fn))
+    to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
+    lr_t, hr_t = to_t(g['lr']), to_t(g['hr'])
+    onet = O.build_oracle(model, scale=4)
+    sd = O.interpolating_state_dict(onet, seed)
+    onet.load_state_dict(sd)
+    oout, _, _ = O.OracleHandler(onet, eval_mode=True).run_eval(lr_t)
+    assert float((oout[:, :, ::2, ::2] - torch.from_numpy(g['out_s2'])).abs().max()) < 1e-5      # the oracle reproduces the reference's output here
+    hr_ycbcr = O.clip01(hr_t.numpy())
+    hr_ycbcr[0] = O.rgb_to_ycbcr_jpg(hr_ycbcr[0])
+    return g, lr_t, hr_t, sd, oout, hr_ycbcr
+
+
+@pytest.mark.parametrize('fn,model,seed', [('g17_edsr_psnr.npz', 'edsr', 501), ('g18_rcan_psnr.npz', 'rcan', 502)])
+def test_full_depth_eval_psnr_within_0p02_db_in_the_trained_regime(golden_dir, fn, model, seed):
+    """G17 (EDSR-baseline, 16 blocks) / G18 (RCAN 10 x 20): a >= 30 dB model evaluated by the real reference.  Bounds: |dPSNR| <= 0.02 dB
+    AND forward self-PSNR >= reference PSNR + 23.4 dB (the margin at which ANY error pattern stays within 0.02 dB)."""
+    g, lr_t, hr_t, sd, oout, hr_ycbcr = _psnr_case(golden_dir, fn, model, seed)
+    ref = float(g['psnr'])
+    assert ref >= 30.0
+    itf = SISRInterface(tempfile.mkdtemp(), 'exp', gpu='single', sp_gpu=0, mode='eval', scale=4, new_params={'name': model, 'internal_params': {'scale': 4}})
+    itf.model.net.load_state_dict(sd)
+    rgb, ycbcr, loss, _ = itf.net_run_and_process(lr=lr_t, hr=hr_t, request_loss=True)
+    ps = O.y_psnr(ycbcr, hr_ycbcr)
+    out, _, _ = itf.model.run_eval(x=lr_t)
+    sp = self_psnr(out, oout)
+    print('%s: Y-PSNR hip %.4f vs reference %.4f (delta %+.4f dB); forward self-PSNR %.2f dB (needs >= %.2f)' % (model, ps, ref, ps - ref, sp, ref + 23.4))
+    assert abs(ps - ref) <= 0.02
+    assert sp >= ref + 23.4
+    # L1 loss of a 33 dB model: 0.02, a third of it from the black vignette border where |out - hr| is of the size of the fp16 error itself
+    assert abs(float(loss) - float(g['loss'])) < 5e-3 * float(g['loss'])
+    assert itf.model.net.engine.eval_fmt == 1          # fp16 evaluation plans, no overflow fallback happened
+    out_d, _, _ = itf.model.run_eval(x=lr_t, keep_on_device=True)
+    _, _, p_dev = SISRInterface.postprocess(out_d, hr_t)
+    assert abs(p_dev - ps) < 1e-3
+
+
+def test_bf16_evaluation_plans_miss_the_bound_fp16_plans_keep(golden_dir, monkeypatch):
+    """why evaluation runs in fp16: the same G18 case through bf16 plans (RUMPY_EVAL_BF16=1) lands below reference + 23.4 dB"""
+    g, lr_t, hr_t, sd, oout, hr_ycbcr = _psnr_case(golden_dir, 'g18_rcan_psnr.npz', 'rcan', 502)
+    monkeypatch.setenv('RUMPY_EVAL_BF16', '1')
+    h = _handler('rcan', eval_mode=True, scale=4)
+    h.net.load_state_dict(sd)
+    out, _, _ = h.run_eval(x=lr_t)
+    assert h.net.engine.eval_fmt == 0
+    sp_bf16 = self_psnr(out, oout)
+    monkeypatch.delenv('RUMPY_EVAL_BF16')
+    h2 = _handler('rcan', eval_mode=True, scale=4)
+    h2.net.load_state_dict(sd)
+    out2, _, _ = h2.run_eval(x=lr_t)
+    sp_f16 = self_psnr(out2, oout)
+    print('RCAN G18 forward self-PSNR: bf16 plans %.2f dB, fp16 plans %.2f dB (needs %.2f)' % (sp_bf16, sp_f16, float(g['psnr']) + 23.4))
+    assert sp_bf16 >= 45.0 and sp_f16 >= sp_bf16 + 10.0
+
+
+def test_fp16_evaluation_overflow_falls_back_to_bf16_plans():
+    """activations beyond fp16's range: the tail kernel raises the non-finite flag, the engine warns, re-runs the image in bf16 and stays there"""
+    h, oh = _pair('edsr', 511, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1)
+    x, _ = O.synthetic_batch(641, 1, lr_hw=20, scale=2)
+    out, _, _ = h.run_eval(x=x)
+    assert h.net.engine.eval_fmt == 1 and self_psnr(out, oh.run_eval(x)[0]) >= 75.0
+    with torch.no_grad():
+        h.net.head[0].weight.mul_(3e5)
+        oh.net.head[0].weight.mul_(3e5)
+    with pytest.warns(UserWarning, match='non-finite'):
+        out, _, _ = h.run_eval(x=x)
+    assert h.net.engine.eval_fmt == 0 and torch.isfinite(out).all()
+    oout, _, _ = oh.run_eval(x)
+    assert float((out - oout).norm() / oout.norm()) < 2e-2
+    out2, _, _ = h.run_eval(x=x)                      # sticky: no second warning, same result
+    assert torch.equal(out, out2)
+
+
+def test_evaluation_plan_cache_is_bounded():
+    h, _ = _pair('edsr', 512, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1)
+    eng = None
+    for i, hw in enumerate([(12, 12), (12, 13), (13, 12), (14, 14), (15, 15), (16, 16), (12, 12)]):
+        x, _ = O.synthetic_batch(650 + i, 1, lr_hw=hw, scale=2)
+        h.run_eval(x=x)
+        eng = h.net.engine
+        assert len([k for k in eng.plans if not k[3]]) <= eng.max_eval_plans
+    assert len(eng._tables) <= 2 * len(eng.plans)
+
+
+def test_backward_of_a_stale_forward_pass_raises():
+    """two training forward passes of one shape share a static plan: the first output's backward must fail loudly"""
+    h, _ = _pair('edsr', 513, scale=2, num_blocks=1, res_scale=0.1, sched=False)
+    h.net.train()
+    x1, _ = O.synthetic_batch(660, 1, lr_hw=12, scale=2)
+    x2, _ = O.synthetic_batch(661, 1, lr_hw=12, scale=2)
+    o1 = h.net(x1.cuda())
+    o2 = h.net(x2.cuda())
+    with pytest.raises(RuntimeError, match='overwritten by a later training forward'):
+        o1.sum().backward()
+    o2.sum().backward()                                # the latest one is fine
+    h.net.eval()
+    assert not h.net(x1.cuda()).requires_grad          # eval mode: the evaluation plan, no autograd node
+
+
 def test_arbitrary_image_size_eval():
     h, oh = _pair('edsr', 504, eval_mode=True, scale=4, num_blocks=2)
     x, _ = O.synthetic_batch(630, 1, lr_hw=(37, 53), scale=4)
@@ -207,11 +374,13 @@ def test_full_size_properties_determinism_and_loss_directional_derivative():
     assert float(l1.item()) == l0 and torch.equal(o0, o1) and torch.equal(g0, h.net.flat_g)
     assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
     gb = h.net.tail[1].bias.grad.clone()
+    le = float(h.run_eval(x=x, y=y, request_loss=True)[1])     # evaluation passes store fp16, training passes bf16: compare like with like
+    assert abs(le - l0) < 1e-3 * l0
     d = 1e-3
     with torch.no_grad():
         h.net.tail[1].bias += d
     l2, _, = h.run_eval(x=x, y=y, request_loss=True)[1], None
-    pred = l0 + d * float(gb.sum())
+    pred = le + d * float(gb.sum())
     assert abs(float(l2) - pred) < 0.02 * abs(d * float(gb.sum())) + 1e-6, (float(l2), pred, l0)
 
 

@@ -80,3 +80,71 @@ if __name__ == '__main__':
     for mode in ('bf16', 'split', 'fp32'):
         out = sim_forward(net, x, mode)
         print('  trunk %-5s: self-PSNR %.2f dB, max abs %.2e' % (mode, self_psnr(out, ref), float((out - ref).abs().max())))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# training step: the same storage roundings in the forward AND the backward direction (every stored activation gradient is bf16)
+class _Round(torch.autograd.Function):
+    """bf16 rounding of a stored tensor: the value in the forward pass, its gradient in the backward pass"""
+
+    @staticmethod
+    def forward(ctx, t, fwd, bwd):
+        ctx.bwd = bwd
+        return rb(t) if fwd else t
+
+    @staticmethod
+    def backward(ctx, g):
+        return (rb(g) if ctx.bwd else g), None, None
+
+
+def R(t, fwd=True, bwd=True):
+    return _Round.apply(t, fwd, bwd)
+
+
+def convg(x, m):
+    """forward: bf16 operands; backward: the incoming gradient is a stored bf16 tensor, weight gradient fp32 from bf16 operands"""
+    return F.conv2d(x, R(m.weight, True, False), m.bias, padding=1)
+
+
+def sim_train_grads(net, x, y, trunk_bwd=True):
+    """L1 train step of engine.py's plan with its roundings; returns {name: grad}.  trunk_bwd=False keeps the trunk GRADIENT in fp32"""
+    net.zero_grad()
+    a0 = R(F.conv2d(x, net.head[0].weight, net.head[0].bias, padding=1), True, trunk_bwd)
+    cur = a0
+    body = list(net.body)
+    for m in body[:-1]:
+        if isinstance(m, O.ScaledResidualBlock):
+            t1 = R(F.relu(convg(cur, m.body[0])))
+            cur = R(cur + m.res_scale * convg(t1, m.body[2]), True, trunk_bwd)
+        else:
+            gin = cur
+            for b in list(m.body)[:-1]:
+                t1 = R(F.relu(convg(cur, b.body[0])))
+                t2 = R(convg(t1, b.body[2]), False, True)          # forward: fp32 accumulators; backward: d_t2 stored bf16
+                gate = b.body[3].conv_du(t2.mean((2, 3), keepdim=True))
+                cur = R(cur + gate * t2, True, trunk_bwd)
+            cur = R(convg(cur, m.body[-1]) + gin, True, trunk_bwd)
+    r = R(convg(cur, body[-1]) + a0)
+    u = r
+    for m in net.tail[0]:
+        u = R(convg(u, m)) if isinstance(m, torch.nn.Conv2d) else m(u)
+    out = convg(u, net.tail[1])
+    loss = (out - y).abs().mean()
+    loss.backward()
+    return {k: p.grad.clone() for k, p in net.named_parameters()}, float(loss)
+
+
+def grad_report(name='rcan', seed=522, N=2, hw=48, **kw):
+    net = O.build_oracle(name, scale=4, **kw)
+    net.load_state_dict(O.seeded_state_dict(net, seed))
+    x, y = O.synthetic_batch(seed + 1000, N, lr_hw=hw, scale=4)
+    net.zero_grad()
+    (net(x) - y).abs().mean().backward()
+    ref = {k: p.grad.clone() for k, p in net.named_parameters()}
+    for tb in (True, False):
+        g, _ = sim_train_grads(net, x, y, trunk_bwd=tb)
+        rows = sorted(((float((g[k] - ref[k]).norm() / (ref[k].norm() + 1e-30)), k) for k in ref), reverse=True)
+        allg, allr = torch.cat([g[k].reshape(-1) for k in ref]), torch.cat([ref[k].reshape(-1) for k in ref])
+        print('%s N=%d %dx%d, gradient trunk %s: whole-gradient rel %.3e, median %.3e, worst %s' % (
+            name, N, hw, hw, 'bf16' if tb else 'fp32', float((allg - allr).norm() / allr.norm()), float(np.median([r[0] for r in rows])),
+            ', '.join('%s %.2e' % (k, r) for r, k in rows[:3])))
