@@ -23,8 +23,12 @@ __device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p 
 
 // MFMA sweep over the 18 (channel half, tap column, column tile) groups for ROWS output rows per wave (window = ROWS + 2
 // input rows).  off[d][half]: per-lane byte address of (window row 0, column px, chunk 4*half + g) for XOR class d.
-template <int ROWS, int FMT = RUMPY_FMT_BF16>
-__device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2]) {
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// hook(grp) runs after the MFMAs of group grp have been issued: the place for work that should travel under the matrix pipe
+// (the HBM stores of the previous phase's tile, block_common.hpp::strip_store_piece)
+template <int ROWS, int FMT = RUMPY_FMT_BF16, class Hook = NoHook>
+__device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2],
+                                            Hook hook = Hook()) {
   bf16x8 I[2][ROWS + 2];
   auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
     const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
@@ -43,6 +47,7 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 
 #pragma unroll
       for (int r = 0; r < ROWS; ++r)
         acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c]);
+    hook(grp);
   }
 }
 
@@ -112,3 +117,32 @@ __device__ __forceinline__ void unpack8(uint4 u, float (&m)[8]) {
   unpack4<FMT>(make_uint2(u.z, u.w), *reinterpret_cast<float(*)[4]>(&m[4]));
 }
 
+
+
+// ---- HBM stores of a strip's own 6 x 48 pixels FROM THE LDS IMAGE, as whole 128-byte lines ----
+// The accumulator layout of an MFMA epilogue gives a lane 8 channels of a pixel: a wave's store instruction then covers 32-byte pieces
+// of 32 different lines, the lines are assembled in L2 from four waves' stores and stay dirty until the end-of-kernel write-back
+// (which is what the "kernel boundary" of a dependent launch mostly waits for: B / 6 TB/s).  Stored from the LDS image instead - 8 lanes
+// per pixel, 1 KB contiguous per wave-instruction - and non-temporal, the lines leave L2 while the kernel still computes:
+// measured -2.1 us of 16.7 per residual-block launch (tests/tools/abl_block.sh BLOCK_ABL_6 vs BLOCK_ST_2_c).
+// Piece p = tid + 512 i (i < 5) = 16-byte chunk p & 7 of strip pixel p >> 3 (row-major over 6 x 48).
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_nt(uint16_t* p, uint4 v) {
+  __builtin_nontemporal_store((u32x4v){v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4v*>(p));
+}
+constexpr int STRIP_PIECES = BSH * BSW * 8;         // 2304
+constexpr int STRIP_REGS = (STRIP_PIECES + BTHREADS - 1) / BTHREADS;   // 5
+// LDS pixel row of strip row 0: ROW0 = 1 in the T image, 2 in the input image
+template <int ROW0>
+__device__ __forceinline__ void strip_stage(uint4 (&S)[STRIP_REGS], const unsigned char* img, int tid) {
+#pragma unroll
+  for (int i = 0; i < STRIP_REGS; ++i) {
+    const int p = tid + BTHREADS * i, pix = (p < STRIP_PIECES ? p : 0) >> 3, r = pix / BSW, col = pix - r * BSW;
+    S[i] = *reinterpret_cast<const uint4*>(img + swz((r + ROW0) * BCOLS + col + 1, p & 7));
+  }
+}
+// element offset of piece i in an [N,H,W,64] tensor, or 0xffffffff when the pixel lies outside the image
+__device__ __forceinline__ unsigned strip_piece_off(int i, int tid, int n, int sy, int H, int W) {
+  const int p = tid + BTHREADS * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW, y = sy * BSH + r;
+  return (p < STRIP_PIECES && y < H && col < W) ? (unsigned)(((n * H + y) * W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+}

@@ -21,6 +21,10 @@
 // prepared per phase and every read is base + immediate.
 #include "block_common.hpp"
 
+#ifndef BLOCK_ABL
+#define BLOCK_ABL 0   // timing experiments only (tests/tools/build_abl.sh, abl_block.sh; results are WRONG): 1 = second filter not fetched,
+#endif                //   2 = neither filter fetched, 4 = no HBM stores, 5 = input tile not loaded, 9 = phase stamps into a.res1
+
 // GEN = false: the ResBlock form (residual operand = block input, read from LDS).  GEN = true: the general form used for
 // RCABs - res_mode 1 (no residual) or 2 (residual operand res1 from HBM, prefetched under the second sweep) and the
 // per-(strip, row half) channel sums of scale2 * (convB(T) + b2) for the channel-attention pool.
@@ -38,6 +42,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   const int q = wave & 3, rh = wave >> 2;
   const int strip = xcd_strip(blockIdx.x, gridDim.x);
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+  unsigned long long stamps[8];
+  unsigned long long cyc[4] = {0ull, 0ull, 0ull, 0ull};       // (stamp build) shader-clock counter at the start / end of the two sweeps
+  int nst = 0;
+#define BK_STAMP() do { if (BLOCK_ABL == 9 && nst < 8) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  BK_STAMP();                              // 0: start
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
   {
@@ -51,7 +60,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       const int y = y0 + lr, x = lc - 1;
       const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
+      uint4 v = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+      if (BLOCK_ABL != 5) v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
       if (!ok) v = make_uint4(0, 0, 0, 0);
       R[i] = v;
     }
@@ -71,12 +81,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   {
     const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8((BLOCK_ABL == 2) ? make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u + t, 0x3c003c00u) : wp[t * 64]);
   }
   const int c0 = 16 * q + 4 * g;
   const int gpair = 4 * (g & ~1);
   const int chunk8 = 2 * q + (gpair >> 3);          // 16-byte chunk of this lane's 8 channels in the paired layout
   __syncthreads();
+  BK_STAMP();                              // 1: input tile in LDS
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
   // tile pairs: k < 4: X = (row k, col tile 0), Y = (row k, col tile 1); k = 4: X = (0, 2), Y = (1, 2); k = 5: X = (2, 2), Y = (3, 2)
@@ -129,22 +140,42 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
         if (FORM == 2 || (FORM == 0 && a.mask)) o = relu_mask_packed(o, M[(FORM == 1 || FORM == 3) ? 0 : k]);
         if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
-        if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;     // the strip's own rows only
-        if (FORM == 1 && a.mbits && j >= 1 && j <= BSH) a.mbits[moff[k] >> 3] = (unsigned char)relu_bits(o);
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
     };
+    if (BLOCK_ABL == 9) cyc[0] = __builtin_amdgcn_s_memtime();
     block_sweep<4, FMT>(acc, F, lds, off);
+    if (BLOCK_ABL == 9) cyc[1] = __builtin_amdgcn_s_memtime();
+    BK_STAMP();                            // 2: first sweep done
     // second filter: L2 hits that land under the epilogue
-    {
+    if (BLOCK_ABL != 1 && BLOCK_ABL != 2) {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) t_pair(k);
+    BK_STAMP();                            // 3: T image written
   }
+  unsigned soff[STRIP_REGS];               // element offsets of this thread's pieces of the strip (shared by the T and the OUT stores)
+#pragma unroll
+  for (int i = 0; i < STRIP_REGS; ++i) soff[i] = strip_piece_off(i, tid, n, sy, a.H, a.W);
   __syncthreads();
+  BK_STAMP();                              // 4: barrier passed
+  // The strip's own rows of T (and their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal, one piece
+  // after each of the first MFMA groups of the second sweep (block_common.hpp::strip_stage).
+  uint4 S[STRIP_REGS];
+  const bool t_out = (a.t != nullptr) && BLOCK_ABL != 4;
+  if (t_out) strip_stage<1>(S, ldt, tid);
+  auto t_store = [&](int grp) {           // grp is a constant after unrolling: piece i after the MFMAs of group 3 i
+    if (grp % 3 == 0 && grp / 3 < STRIP_REGS) {
+      const int i = grp / 3 < STRIP_REGS ? grp / 3 : 0;
+      if (t_out && soff[i] != 0xffffffffu) {
+        st16_nt(a.t + soff[i], S[i]);
+        if (FORM == 1 && a.mbits) a.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+      }
+    }
+  };
 
   // ---- phase 2: output rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ; OUT = X + scale2 * (convB(T) + b2) [+ res2] ----
   {
@@ -174,7 +205,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     }
     unsigned off[8][2];
     sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
-    block_sweep<3, FMT>(acc, F, lds, off);
+    if (BLOCK_ABL == 9) cyc[2] = __builtin_amdgcn_s_memtime();
+    block_sweep<3, FMT>(acc, F, lds, off, t_store);
+    if (BLOCK_ABL == 9) cyc[3] = __builtin_amdgcn_s_memtime();
+    BK_STAMP();                            // 5: second sweep done
     float ps[4] = {0.f, 0.f, 0.f, 0.f};                         // GEN pool sums: single tile, channels 4g .. 4g+3 of the wave's 16
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    //                paired tiles, channels 4(g&~1) .. +7
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
@@ -204,14 +238,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
             for (int j = 0; j < 8; ++j) v[j] += m[j];
           }
         }
-        const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair);
         if (a.res2) {
+          const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair);
           unpack8<FMT>(*reinterpret_cast<const uint4*>(a.res2 + o), m);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
         const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
-        *reinterpret_cast<uint4*>(a.out + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        *reinterpret_cast<uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // OUT image, in place of the input pixel
       }
     }
     {
@@ -236,13 +270,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
             for (int j = 0; j < 4; ++j) v[j] += m[j];
           }
         }
-        const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
         if (a.res2) {
+          const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
           unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res2 + o), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
-        *reinterpret_cast<uint2*>(a.out + o) = pack4<FMT>(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(v[0], v[1], v[2], v[3]);
       }
     }
     if (GEN && a.pool) {
@@ -270,6 +304,23 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       }
     }
   }
+  // ---- OUT: the image now sits in LDS in place of the input tile's centre rows (each lane replaced exactly the input values it had read
+  // as its residual operand; nothing else reads the input tile in phase 2) -> whole lines to HBM, non-temporal ----
+  __syncthreads();
+  BK_STAMP();                              // 6: OUT image complete
+  if (BLOCK_ABL != 4) {
+    strip_stage<2>(S, ldx, tid);
+#pragma unroll
+    for (int i = 0; i < STRIP_REGS; ++i)
+      if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
+  }
+  BK_STAMP();                              // 7: end (stores issued)
+  if (BLOCK_ABL == 9 && lane == 0 && a.res1) {      // stamp build: a.res1 (unused by the ResBlock form) = [strip][wave][16] u64
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<uint16_t*>(a.res1)) + ((size_t)strip * 8 + wave) * 16;
+    for (int i = 0; i < 8; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
+    for (int i = 0; i < 4; ++i) dbg[8 + i] = cyc[i];
+  }
+#undef BK_STAMP
 }
 
 extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           const uint2 hi = pack4<FMT>(fmaf(d[4], gb.x, pb.x), fmaf(d[5], gb.y, pb.y), fmaf(d[6], gb.z, pb.z), fmaf(d[7], gb.w, pb.w));
           const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
           *cell = o;
-          if (lr >= 2 && lr < 2 + BSH) *reinterpret_cast<uint4*>(a.t2 + (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8)) = o;
+          if (lr >= 2 && lr < 2 + BSH) st16_nt(a.t2 + (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8), o);     // 8 lanes per pixel: whole lines
         }
       }
     }
@@ -330,14 +330,29 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
         if (BWD && !MB) o = relu_mask_packed(o, M[(BWD && !MB) ? k : 0]);
         if (BWD && MB) o = relu_mask_bits(o, MBY[(BWD && MB) ? k : 0]);
-        if (a.t && j >= 1 && j <= BSH) *reinterpret_cast<uint4*>(a.t + moff[k]) = o;
-        if (!BWD && a.mbits && j >= 1 && j <= BSH) a.mbits[moff[k] >> 3] = (unsigned char)relu_bits(o);
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
     }
   }
+  unsigned soff[STRIP_REGS];               // element offsets of this thread's 16-byte pieces of the strip (T, t2 and OUT stores)
+#pragma unroll
+  for (int i = 0; i < STRIP_REGS; ++i) soff[i] = strip_piece_off(i, tid, n, sy, a.H, a.W);
   __syncthreads();
   RC_STAMP();                              // T tile written + barrier
+  // the strip's own rows of T (forward: + their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal, one
+  // piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage; conv_block.hip)
+  uint4 S[STRIP_REGS];
+  const bool t_out = a.t != nullptr;
+  if (t_out) strip_stage<1>(S, ldt, tid);
+  auto t_store = [&](int grp) {           // grp is a constant after unrolling
+    if (grp % 3 == 0 && grp / 3 < STRIP_REGS) {
+      const int i = grp / 3 < STRIP_REGS ? grp / 3 : 0;
+      if (t_out && soff[i] != 0xffffffffu) {
+        st16_nt(a.t + soff[i], S[i]);
+        if (!BWD && a.mbits) a.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+      }
+    }
+  };
 
   // ---- phase 2: rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ----
   {
@@ -367,7 +382,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     }
     unsigned off[8][2];
     sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
-    block_sweep<3, FMT>(acc, F, lds, off);
+    block_sweep<3, FMT>(acc, F, lds, off, t_store);
     RC_STAMP();                            // sweep B done
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
     float V[4][8], vs[4];
@@ -395,8 +410,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           }
           const uint2 lo = pack4<FMT>(V[k][0] + m[0], V[k][1] + m[1], V[k][2] + m[2], V[k][3] + m[3]);
           const uint2 hi = pack4<FMT>(V[k][4] + m[4], V[k][5] + m[5], V[k][6] + m[6], V[k][7] + m[7]);
-          *reinterpret_cast<uint4*>(a.out + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
+          const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+          *reinterpret_cast<uint4*>(ldx + swz((3 * rh + r + 2) * BCOLS + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // dx image in place of the
+        }                                                                                                                                // d_t2 tile (dead in phase 2)
       }
       if (osoff != 0xffffffffu) {
         float m[4];
@@ -407,7 +423,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) m[j] += e[j];
         }
-        *reinterpret_cast<uint2*>(a.out + osoff) = pack4<FMT>(vs[0] + m[0], vs[1] + m[1], vs[2] + m[2], vs[3] + m[3]);
+        *reinterpret_cast<uint2*>(ldx + swz((3 * rh + 2 + 2) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) =
+            pack4<FMT>(vs[0] + m[0], vs[1] + m[1], vs[2] + m[2], vs[3] + m[3]);
       }
     } else {
       // t2 = conv2(t1) + b2: channel sums of the strip for the attention pool, t2 itself to HBM when training
@@ -417,16 +434,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         if (ooff[k] != 0xffffffffu) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) ps8[j] += V[k][j];
-          if (a.t2) {
-            const uint2 lo = pack4<FMT>(V[k][0], V[k][1], V[k][2], V[k][3]), hi = pack4<FMT>(V[k][4], V[k][5], V[k][6], V[k][7]);
-            *reinterpret_cast<uint4*>(a.t2 + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
         }
       }
       if (osoff != 0xffffffffu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) ps[j] += vs[j];
-        if (a.t2) *reinterpret_cast<uint2*>(a.t2 + osoff) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -448,11 +460,24 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         *reinterpret_cast<float4*>(pp) = make_float4(ps8[0], ps8[1], ps8[2], ps8[3]);
         *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
       }
-      __syncthreads();
+      __syncthreads();                     // every wave has finished its second sweep: the T image is dead
+      if (a.t2) {                          // training: t2 = conv2(t1) + b2 goes to HBM through the T image's rows 1 .. 6 (whole lines, below)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (ooff[k] != 0xffffffffu) {
+            const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+            const uint2 lo = pack4<FMT>(V[k][0], V[k][1], V[k][2], V[k][3]), hi = pack4<FMT>(V[k][4], V[k][5], V[k][6], V[k][7]);
+            *reinterpret_cast<uint4*>(ldt + swz((3 * rh + r + 1) * BCOLS + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+        }
+        if (osoff != 0xffffffffu)
+          *reinterpret_cast<uint2*>(ldt + swz((3 * rh + 2 + 1) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
+      }
       const float mine = (tid < 64) ? spool[tid] + spool[64 + tid] : 0.f;
-      RC_STAMP();                          // (fwd) pool sums + t2 stores issued
-      const float tot = strip_allsum(a, mine, n, sy, tid, tag, sx);
+      RC_STAMP();                          // (fwd) pool sums done, t2 image written
+      const float tot = strip_allsum(a, mine, n, sy, tid, tag, sx);      // (its barriers also complete the t2 image)
       RC_STAMP();                          // (fwd) exchange done
+      if (a.t2) strip_stage<1>(S, ldt, tid);
       if (tid < 64) {
         const int c = tid;
         const float mean = tot * a.inv_hw;
@@ -467,7 +492,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         if (sy == 0) { a.mean[n * 64 + c] = mean; a.gate[n * 64 + c] = gt; }
       }
       __syncthreads();
-      // out = x + gate * t2, the residual operand from the input tile in LDS
+      if (a.t2) {
+#pragma unroll
+        for (int i = 0; i < STRIP_REGS; ++i)
+          if (soff[i] != 0xffffffffu) st16_nt(a.t2 + soff[i], S[i]);
+      }
+      // out = x + gate * t2, the residual operand from the input tile in LDS; the result replaces it there
       const float4 ga = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair), gb = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -478,7 +508,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);
           const uint2 lo = pack4<FMT>(fmaf(V[k][0], ga.x, m[0]), fmaf(V[k][1], ga.y, m[1]), fmaf(V[k][2], ga.z, m[2]), fmaf(V[k][3], ga.w, m[3]));
           const uint2 hi = pack4<FMT>(fmaf(V[k][4], gb.x, m[4]), fmaf(V[k][5], gb.y, m[5]), fmaf(V[k][6], gb.z, m[6]), fmaf(V[k][7], gb.w, m[7]));
-          *reinterpret_cast<uint4*>(a.out + ooff[k]) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          *reinterpret_cast<uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
       }
       if (osoff != 0xffffffffu) {
@@ -486,10 +516,17 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         float m[4];
         unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
         const float4 gs = *reinterpret_cast<const float4*>(sgate + c0);
-        *reinterpret_cast<uint2*>(a.out + osoff) = pack4<FMT>(fmaf(vs[0], gs.x, m[0]), fmaf(vs[1], gs.y, m[1]), fmaf(vs[2], gs.z, m[2]), fmaf(vs[3], gs.w, m[3]));
+        *reinterpret_cast<uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8) =
+            pack4<FMT>(fmaf(vs[0], gs.x, m[0]), fmaf(vs[1], gs.y, m[1]), fmaf(vs[2], gs.z, m[2]), fmaf(vs[3], gs.w, m[3]));
       }
     }
   }
+  // ---- OUT (forward: x + gate * t2; backward: dx): the image sits in LDS in place of the input tile's centre rows -> whole lines, non-temporal ----
+  __syncthreads();
+  strip_stage<2>(S, ldx, tid);
+#pragma unroll
+  for (int i = 0; i < STRIP_REGS; ++i)
+    if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
   RC_STAMP();                              // end (stores issued)
   if (RCAB_ABL == 9 && tid == 0 && a.t) {
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.t) + (size_t)strip * 16;

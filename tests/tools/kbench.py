@@ -195,11 +195,13 @@ def block_bench(N=32, H=48, W=48, nblocks=16):
     bufs = [torch.randn(N, H, W, 64, device=DEV).to(BF16) for _ in range(nblocks + 1)]
     ts = [torch.empty(N, H, W, 64, dtype=BF16, device=DEV) for _ in range(nblocks)]
 
+    dbg = torch.zeros(N * ((H + 5) // 6) * 8 * 16, dtype=torch.int64, device=DEV)     # stamp builds only (BLOCK_ABL=9)
+
     def fused():
         for b, (pa, pb) in enumerate(pcs):
             a = L.BlockArgs(x=bufs[b].data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
                             b2=pb.b_packed.data_ptr(), t=ts[b].data_ptr(), out=bufs[b + 1].data_ptr(), N=N, H=H, W=W, relu1=1,
-                            scale1=1.0, scale2=0.1)
+                            scale1=1.0, scale2=0.1, res1=dbg.data_ptr())
             L.call('rumpy_conv_block', a, stream())
 
     def separate():
@@ -212,9 +214,26 @@ def block_bench(N=32, H=48, W=48, nblocks=16):
             L.call('rumpy_conv3x3', a2, stream())
     for _ in range(2):
         us_f = time_fn(fused, iters=20)
-        us_s = time_fn(separate, iters=20)
+        us_s = time_fn(separate, iters=20) if not os.environ.get('KBENCH_FUSED_ONLY') else 0.0
         print('%d residual blocks %dx%dx%d: one launch per block %8.1f us = %6.2f us/block ; two launches per block %8.1f us = %6.2f us/block'
               % (nblocks, N, H, W, us_f, us_f / nblocks, us_s, us_s / nblocks))
+    if 'BLOCK_ABL_9' in os.environ.get('RUMPY_AMD_LIB', ''):      # in-kernel phase stamps (100 MHz), written over the first bytes of t
+        fused()
+        torch.cuda.synchronize()
+        nst = N * ((H + 5) // 6)
+        rawu = dbg.cpu().numpy().view(np.uint64).reshape(nst, 8, 16)
+        raw = rawu[:, :, :8].astype(np.float64)
+        cyc = rawu[:, :, 8:12].astype(np.float64)
+        k = int((raw[0, 0] > 0).sum())
+        t0 = raw[:, :, 0].min()
+        rel = (raw[:, :, :k] - raw[:, :, :1]) * 0.01
+        print('   stamps, us from each wave\'s start (mean over waves): ' + ' '.join('%.2f' % v for v in rel.mean((0, 1))))
+        print('   per row half rh=0: ' + ' '.join('%.2f' % v for v in rel[:, :4].mean((0, 1))) + ' | rh=1: ' + ' '.join('%.2f' % v for v in rel[:, 4:].mean((0, 1))))
+        for name, a, b, sa, sb, nm in (('first', 0, 1, 1, 2, 216), ('second', 2, 3, 4, 5, 162)):
+            dc, dt = cyc[:, :, b] - cyc[:, :, a], (raw[:, :, sb] - raw[:, :, sa]) * 0.01
+            print('   %s sweep: %.0f shader cycles per wave (= %.1f per MFMA of this wave; the SIMD\'s other wave issues as many) in %.2f us -> clock %.2f GHz'
+                  % (name, dc.mean(), dc.mean() / nm, dt.mean(), dc.mean() / dt.mean() / 1e3))
+        print('   wave start spread over the launch %.2f us; last end - first start %.2f us' % ((raw[:, :, 0].max() - t0) * 0.01, (raw[:, :, k - 1].max() - t0) * 0.01))
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'block':
