@@ -225,6 +225,24 @@ def main():
                 roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
 
+    # ---- informational: the step exactly as the reference's caller makes it (SISRInterface.train_batch, interface.py:97-101): batch on the HOST,
+    # output returned to the HOST (keep_on_device=False): 15 MB up + 14 MB down over PCIe per step.  Never `value`. ----
+    as_called = None
+    if rank == 0 and world == 1 and src is None and meta_pool is None:
+        host_pool = [(x.cpu(), y.cpu()) for x, y in pool[:4]]
+        for i in range(3):
+            h.run_train(x=host_pool[i % 4][0], y=host_pool[i % 4][1])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        n_ac = 20
+        for i in range(n_ac):
+            h.run_train(x=host_pool[i % 4][0], y=host_pool[i % 4][1])
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t1
+        as_called = {'value': round(N * n_ac / dt, 1), 'unit': 'LR patches/s', 'ms_per_step': round(1e3 * dt / n_ac, 3), 'steps': n_ac,
+                     'what': 'run_train(x, y) with pageable host tensors in and the output copied back to the host (keep_on_device=False), '
+                             'as SISRInterface.train_batch calls it; PCIe-inclusive, informational'}
+
     # ---- CPU baseline: the oracle (torch-CPU fp32 restatement of the reference) on the host cores, rank 0, N=1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -276,7 +294,11 @@ def main():
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),
                            'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4)},
-                'roofline': roofline, 'cpu_baseline': cpu}
+                'roofline': roofline, 'cpu_baseline': cpu, 'as_called': as_called,
+                # what the collectives really ran on (the driver's scaling run can check that RCCL saw N ranks on N devices)
+                'distributed': {'world_size': dist.get_world_size() if dp else 1, 'backend': dist.get_backend() if dp else None,
+                                'device_count': torch.cuda.device_count(), 'ranks_on_one_device': bool(one_device),
+                                'grad_allreduce_mb': round(getattr(h.net, 'hip_generator', h.net).flat_g.numel() * 4 / 1e6, 2) if dp else 0.0}}
         print(json.dumps(line), flush=True)
     if dp:
         dist.destroy_process_group()

@@ -580,6 +580,9 @@ int rumpy_mse_loss(const rumpy_mse_args* a, void* stream);
 typedef struct { const void* fn; const void* args; } rumpy_op;
 int rumpy_run_list(const rumpy_op* ops, int32_t n, void* stream);
 int rumpy_probe_begin(int kernel_id, int max_records);
+/* diagnostic (tests only): `blocks` workgroups holding 80 KiB of LDS each spin for about `microseconds` on `stream` - a stand-in for a
+ * foreign kernel (an RCCL collective on a side stream) that occupies CUs while the product kernels run */
+int rumpy_debug_occupy(int32_t blocks, float microseconds, void* stream);
 /* synchronises the recorded events; returns launches seen; *total_ms = summed duration */
 int rumpy_probe_end(double* total_ms);
 

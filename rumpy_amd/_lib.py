@@ -278,6 +278,7 @@ SYMBOLS = {
     'rumpy_dconv_wgrad': (C.c_int, [_P(DconvWgradArgs), c_void_p]),
     'rumpy_dconv_wgrad_partial_floats': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'rumpy_mse_loss': (C.c_int, [_P(MseArgs), c_void_p]),
+    'rumpy_debug_occupy': (C.c_int, [c_int32, c_float, c_void_p]),
     'rumpy_probe_begin': (C.c_int, [C.c_int, C.c_int]),
     'rumpy_probe_end': (C.c_int, [_P(C.c_double)]),
 }

@@ -35,7 +35,22 @@ extern "C" int rumpy_run_list(const rumpy_op* ops, int32_t n, void* stream) {
   }
   return RUMPY_OK;
 }
-extern "C" int rumpy_abi_version(void) { return 1; }
+extern "C" int rumpy_abi_version(void) { return 2; }
+
+// diagnostic (tests only): `blocks` workgroups that each hold 80 KiB of LDS (at most two per CU) and spin for about `microseconds` -
+// a stand-in for a foreign kernel (an RCCL collective on the side stream) that occupies CUs while the product kernels run
+__global__ void __launch_bounds__(256) occupy_kernel(unsigned long long ticks, unsigned* sink) {
+  __shared__ unsigned hold[80 * 1024 / 4];
+  hold[threadIdx.x] = threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (sink && hold[(threadIdx.x * 7) & 255] == 0xffffffffu) *sink = 1u;
+}
+extern "C" int rumpy_debug_occupy(int32_t blocks, float microseconds, void* stream) {
+  if (blocks <= 0 || !(microseconds > 0.f) || microseconds > 5e6f) { rumpy_set_error("rumpy_debug_occupy: bad argument"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.f), (unsigned*)nullptr);
+  return rumpy_check_launch("rumpy_debug_occupy");
+}
 extern "C" int rumpy_device_cus(void) {
   static int cus = 0;
   if (cus == 0) {

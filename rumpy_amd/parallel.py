@@ -84,10 +84,12 @@ class GradientAverager:
         if self.side is not None:
             torch.cuda.current_stream(self.flat_g.device).wait_stream(self.side)
 
-    def average(self):
-        """Sum over ranks of every bucket; the 1/world factor is applied here so the optimizer sees the mean."""
+    def average(self, scale_in_place=False):
+        """Sum over ranks of every bucket -> returns the factor that turns the sum into the mean (1 / world).  The fused optimizer takes it
+        as `grad_mult` (rumpy_adam_step multiplies every gradient by it in the same pass: no extra kernel, flat_g then holds the SUM);
+        scale_in_place=True applies it here with a torch op instead (stock torch optimizers only)."""
         if not self.active:
-            return
+            return 1.0
         if self.early_lo is not None:        # the upper part is already in flight (begin()): only the rest is launched here
             self._launch_range(0, self.early_lo)
             self.early_lo = None
@@ -95,8 +97,11 @@ class GradientAverager:
             for i in range(len(self.buckets)):
                 self.launch_bucket(i)
         self.finish()
-        if self.world_size > 1:
-            self.flat_g.mul_(1.0 / self.world_size)
+        mult = 1.0 / self.world_size
+        if scale_in_place and self.world_size > 1:
+            self.flat_g.mul_(mult)
+            return 1.0
+        return mult
 
 
 def broadcast_parameters(net, src=0, group=None):

@@ -209,7 +209,8 @@ class BaseModel(nn.Module):
     def _apply_update(self, scheduler_skip=False):
         grad_mult = 1.0
         if self.data_parallel is not None:
-            self.data_parallel.average()             # RCCL all-reduce (mean) of the flat gradient buffer
+            # RCCL all-reduce (sum) of the flat gradient buffer; the 1 / world factor travels into the fused Adam launch as grad_mult
+            grad_mult = self.data_parallel.average(scale_in_place=not isinstance(self.optimizer, FlatAdam))
         if isinstance(self.optimizer, FlatAdam):
             self.optimizer.step(grad_mult=grad_mult, max_norm=self.grad_clip)
         else:

@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(h, s), s
     lib = _lib.lib()
-    assert lib.rumpy_abi_version() == 1
+    assert lib.rumpy_abi_version() == 2
     assert lib.rumpy_wgrad_slab_floats(4) == 64 * 576 + 64 and lib.rumpy_wgrad_slab_floats(1) == 16 * 576 + 16
 
 
@@ -212,17 +212,20 @@ dist.init_process_group('gloo')
 g = torch.arange(10007, dtype=torch.float32) * (rank + 1)
 avg = GradientAverager(flat_grad=g, bucket_elems=1000)
 assert avg.world_size == 2 and len(avg.buckets) == 11 and avg.buckets[0] == (9007, 10007) and avg.buckets[-1] == (0, 7)
-avg.average()
-assert torch.equal(g, torch.arange(10007, dtype=torch.float32) * 1.5), rank
+mult = avg.average()                                              # the SUM lands in the buffer; the mean factor goes to the fused Adam (grad_mult)
+assert mult == 0.5 and torch.equal(g, torch.arange(10007, dtype=torch.float32) * 3.0), rank
+g1 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
+assert GradientAverager(flat_grad=g1, bucket_elems=1000).average(scale_in_place=True) == 1.0       # stock torch optimizers: scaled here
+assert torch.equal(g1, torch.arange(10007, dtype=torch.float32) * 1.5), rank
 # two-phase form (SREngine.backward(on_ready=...)): the upper part is launched early by begin(ptr), average() covers the rest
 g2 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
 avg2 = GradientAverager(flat_grad=g2, bucket_elems=1000)
 avg2.begin(g2.data_ptr() + 4 * 6001)
 assert avg2.early_lo == 6001 and len(avg2.pending) == 5          # [9007,10007) ... [6001,7007): LAST parameters first
 g2[:6001] += 0.0                                                  # "remaining weight gradients" written while the upper part is in flight
-avg2.average()
+assert avg2.average() == 0.5
 assert avg2.early_lo is None and not avg2.pending
-assert torch.equal(g2, torch.arange(10007, dtype=torch.float32) * 1.5), rank
+assert torch.equal(g2, torch.arange(10007, dtype=torch.float32) * 3.0), rank
 avg2.begin(g2.data_ptr())                                         # boundary at the start of the buffer: nothing to split
 assert avg2.early_lo is None
 class Net: pass

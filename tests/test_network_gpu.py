@@ -685,6 +685,47 @@ def test_bench_runs_over_rccl_with_one_rank(model):
     assert d['config']['loss'] == e['config']['loss'], (d['config']['loss'], e['config']['loss'])
 
 
+def test_bench_line_reports_what_the_collectives_ran_on():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29574',
+           os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--probe-steps', '1', '--no-cpu-baseline']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')][0])['distributed']
+    assert d['world_size'] == 1 and d['backend'] == 'nccl' and d['device_count'] >= 1 and d['ranks_on_one_device'] is False
+    assert abs(d['grad_allreduce_mb'] - 6.07) < 0.01
+
+
+def test_rcab_launches_next_to_a_foreign_kernel_that_holds_cus():
+    """the one-launch RCAB kernels spin on their sibling strips - can they wedge behind a collective that occupies CUs on
+    the side stream?  A stand-in (rumpy_debug_occupy: 48 workgroups x 80 KiB LDS, i.e. 24-48 CUs unavailable to the 115-KiB RCAB workgroups,
+    for 30 ms at a time) runs on a side stream for the WHOLE of three RCAN training steps at the headline strip count (256 workgroups per
+    launch).  Strips are dispatched in order and the foreign kernel waits for nobody, so the oldest unfinished image always completes:
+    no exchange may time out and every number must equal the undisturbed run's, bit for bit."""
+    from rumpy_amd import _lib as L
+    kw = dict(scale=2, n_resgroups=2, n_resblocks=3, reduction=16)
+    x, y = O.synthetic_batch(671, 32, lr_hw=48, scale=2)
+    res = []
+    for disturbed in (False, True):
+        h, _ = _pair('rcan', 541, sched=False, **kw)
+        side = torch.cuda.Stream()
+        losses = []
+        for step in range(3):
+            if disturbed:
+                for _ in range(4):
+                    L.check(L.lib().rumpy_debug_occupy(48, 30000.0, side.cuda_stream), 'occupy')
+            loss, out = h.run_train(x=x, y=y)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        assert h.net.engine.exchange_status() == 0
+        res.append((losses, out.clone(), h.net.flat_p.detach().clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
 @pytest.mark.parametrize('N', [67, 160])
 def test_one_launch_rcab_with_more_strips_than_cus(N, monkeypatch):
     """N * 8 workgroups per launch >> 256 CUs (536 / 1280), images straddling the residency boundary: workgroup ids are dispatched in
