@@ -21,6 +21,9 @@
 // prepared per phase and every read is base + immediate.
 #include "block_common.hpp"
 
+#ifndef BLOCK_OUT_PLAIN
+#define BLOCK_OUT_PLAIN 0   // A/B: OUT stored with the default policy (lines stay in the XCD's L2 for the next launch, dirty until the boundary)
+#endif
 #ifndef BLOCK_ABL
 #define BLOCK_ABL 0   // timing experiments only (tests/tools/build_abl.sh, abl_block.sh; results are WRONG): 1 = second filter not fetched,
 #endif                //   2 = neither filter fetched, 4 = no HBM stores, 5 = input tile not loaded, 9 = phase stamps into a.res1
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     strip_stage<2>(S, ldx, tid);
 #pragma unroll
     for (int i = 0; i < STRIP_REGS; ++i)
-      if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
+      if (soff[i] != 0xffffffffu) { if (BLOCK_OUT_PLAIN) *reinterpret_cast<uint4*>(a.out + soff[i]) = S[i]; else st16_nt(a.out + soff[i], S[i]); }
   }
   BK_STAMP();                              // 7: end (stores issued)
   if (BLOCK_ABL == 9 && lane == 0 && a.res1) {      // stamp build: a.res1 (unused by the ResBlock form) = [strip][wave][16] u64
