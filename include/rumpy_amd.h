@@ -75,35 +75,6 @@ int rumpy_conv_pool_tiles(int32_t H, int32_t W, int32_t cin_chunks);
  * s_memrealtime (100 MHz) phase stamps of each wave's first strip */
 int rumpy_debug_conv_stamps(const rumpy_conv_args* a, void* stream);
 
-/* ---- layer-resident chain of 64->64 3x3 convs (EDSR body, forward or data-gradient direction) in one launch ----
- * Every layer has rumpy_conv3x3 semantics with cin_chunks = cout_tiles = 1; layer l+1's input is layer l's output, kept
- * in LDS by the workgroup that owns the strip; halo rows travel between vertical neighbours through `xchg` as
- * epoch-tagged 8-byte records (see conv_chain.hip).
- * Requirements: W <= 48 and N * ceil(H/6) <= rumpy_device_cus() (all strips co-resident), nothing else running on the GPU.
- * *status != 0 afterwards means a hand-off timed out (results invalid). */
-typedef struct {
-  const void* w;        /* packed filter (fwd or dgrad image) */
-  const float* bias;    /* packed bias or NULL */
-  void* out;            /* [N,H,W,64] bf16, always written */
-  const void* mask;     /* as rumpy_conv_args */
-  const void* res1;
-  const void* res2;
-  int32_t relu;
-  float scale;
-} rumpy_chain_layer;
-typedef struct {
-  const void* x;                    /* [N,H,W,64] bf16 input of layer 0 */
-  const rumpy_chain_layer* layers;  /* DEVICE array */
-  int32_t nlayers;
-  int32_t N, H, W;
-  void* xchg;                       /* rumpy_conv_chain_xchg_bytes(N*ceil(H/6)) bytes: zeroed ONCE by the caller when
-                                       allocated, then owned by the library (halo-row records + epoch header) */
-  uint32_t* status;                 /* 1 word (zeroed by the call) */
-  uint64_t* stamps;                 /* NULL, or diagnostics: [strip][wave 8][layer < 8][8] s_memrealtime stamps */
-} rumpy_chain_args;
-int rumpy_conv_chain(const rumpy_chain_args* a, void* stream);
-int64_t rumpy_conv_chain_xchg_bytes(int32_t nstrips);
-
 /* ---- residual block in one launch: two 3x3 convs 64 -> 64, the activation between them stays in LDS (conv_block.hip) ----
  *   T = post1(convA(X)),  post1 = [+b1] [ReLU] [* scale1] [zero where mask <= 0];   OUT = X + scale2 * (convB(T) + b2) [+ res2]
  * forward of ResBlock (rumpy/SISR/models/advanced/common.py ResBlock, used by EDSR architectures.py:196-241):
@@ -167,22 +138,6 @@ int rumpy_rcab_fwd(const rumpy_rcab_args* a, void* stream);
 int rumpy_rcab_bwd(const rumpy_rcab_args* a, void* stream);
 int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H);
 int rumpy_rcab_epoch_advance(void* epoch, void* stream);
-
-/* ---- a chain of residual blocks in one launch, the strip resident in LDS from block to block (conv_block_chain.hip) ----
- * blocks: DEVICE array of rumpy_block_args, block b+1's input is block b's output (x is read from blocks[0] only; res2 must be
- * NULL).  Needs N*ceil(H/6) <= CUs (every strip co-resident), W <= 48 and nothing else occupying CUs while it runs.
- * xchg: rumpy_block_chain_xchg_bytes(N*ceil(H/6)) bytes, zeroed ONCE by the caller at allocation, then owned by the library.
- * status: one device word, 0 after a clean run (a neighbour hand-off that timed out stores 0x200 + block index). */
-typedef struct {
-  const rumpy_block_args* blocks;
-  int32_t nblocks;
-  int32_t N, H, W;
-  int32_t masked;      /* 1: the blocks carry ReLU masks (data-gradient chains), 0: none does (the masks are not even loaded) */
-  void* xchg;
-  uint32_t* status;
-} rumpy_block_chain_args;
-int rumpy_block_chain(const rumpy_block_chain_args* a, void* stream);
-int64_t rumpy_block_chain_xchg_bytes(int32_t nstrips);
 
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
  * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */
@@ -575,7 +530,7 @@ int rumpy_mse_loss(const rumpy_mse_args* a, void* stream);
 
 /* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
  * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
- * 4 = rumpy_conv_chain ; 5 = rumpy_conv_block and rumpy_block_chain */
+ * 4 = (experimental chain kernels, tests/tools/csrc) ; 5 = rumpy_conv_block, rumpy_rcab_* */
 /* a launch list: fn = address of any `int fn(const <args>*, void* stream)` entry point of this library, args = its argument block */
 typedef struct { const void* fn; const void* args; } rumpy_op;
 int rumpy_run_list(const rumpy_op* ops, int32_t n, void* stream);

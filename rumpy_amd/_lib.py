@@ -35,16 +35,6 @@ class ConvArgs(_S):
                 ('grid_x', c_int32), ('fmt', c_int32)]
 
 
-class ChainLayer(_S):
-    _fields_ = [('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('mask', c_void_p), ('res1', c_void_p),
-                ('res2', c_void_p), ('relu', c_int32), ('scale', c_float)]
-
-
-class ChainArgs(_S):
-    _fields_ = [('x', c_void_p), ('layers', c_void_p), ('nlayers', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32),
-                ('xchg', c_void_p), ('status', c_void_p), ('stamps', c_void_p)]
-
-
 class HeadFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('b', c_void_p), ('out', c_void_p),
                 ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32), ('neg_slope_m1', c_float),
@@ -187,11 +177,6 @@ class BlockArgs(_S):
                 ('pool', c_void_p), ('maskbits', c_void_p), ('fmt', c_int32), ('pad_', c_int32)]
 
 
-class BlockChainArgs(_S):
-    _fields_ = [('blocks', c_void_p), ('nblocks', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('masked', c_int32),
-                ('xchg', c_void_p), ('status', c_void_p)]
-
-
 class SsimArgs(_S):
     _fields_ = [('a', c_void_p), ('b', c_void_p), ('partial', c_void_p), ('out', c_void_p), ('P', c_int32), ('H', c_int32),
                 ('W', c_int32), ('data_range', c_float)]
@@ -232,8 +217,6 @@ SYMBOLS = {
     'rumpy_conv3x3': (C.c_int, [_P(ConvArgs), c_void_p]),
     'rumpy_conv_pool_tiles': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_debug_conv_stamps': (C.c_int, [_P(ConvArgs), c_void_p]),
-    'rumpy_conv_chain_xchg_bytes': (c_int64, [c_int32]),
-    'rumpy_conv_chain': (C.c_int, [_P(ChainArgs), c_void_p]),
     'rumpy_head_fwd': (C.c_int, [_P(HeadFwdArgs), c_void_p]),
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
     'rumpy_rcab_fwd': (C.c_int, [_P(RcabArgs), c_void_p]),
@@ -269,8 +252,6 @@ SYMBOLS = {
     'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
     'rumpy_run_list': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_conv_block': (C.c_int, [_P(BlockArgs), c_void_p]),
-    'rumpy_block_chain': (C.c_int, [_P(BlockChainArgs), c_void_p]),
-    'rumpy_block_chain_xchg_bytes': (c_int64, [c_int32]),
     'rumpy_ssim': (C.c_int, [_P(SsimArgs), c_void_p]),
     'rumpy_ssim_partial_floats': (c_int64, [c_int32, c_int32, c_int32]),
     'rumpy_patch_gather': (C.c_int, [_P(PatchArgs), c_void_p]),

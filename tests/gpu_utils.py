@@ -11,6 +11,47 @@ BF16 = torch.bfloat16
 DEV = 'cuda:0'
 
 
+# ---- the experimental persistent-chain kernels (tests/tools/csrc/librumpy_exp.so: measurement tools, not the product library) ----
+class ChainLayer(L._S):
+    _fields_ = [('w', C.c_void_p), ('bias', C.c_void_p), ('out', C.c_void_p), ('mask', C.c_void_p), ('res1', C.c_void_p),
+                ('res2', C.c_void_p), ('relu', C.c_int32), ('scale', C.c_float)]
+
+
+class ChainArgs(L._S):
+    _fields_ = [('x', C.c_void_p), ('layers', C.c_void_p), ('nlayers', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('xchg', C.c_void_p), ('status', C.c_void_p), ('stamps', C.c_void_p)]
+
+
+class BlockChainArgs(L._S):
+    _fields_ = [('blocks', C.c_void_p), ('nblocks', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('masked', C.c_int32),
+                ('xchg', C.c_void_p), ('status', C.c_void_p)]
+
+
+_exp = None
+
+
+def exp_lib():
+    """ctypes handle of the experimental library (built by __graft_entry__.build() / make -C tests/tools/csrc)"""
+    global _exp
+    if _exp is None:
+        import os
+        path = os.environ.get('RUMPY_EXP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'csrc', 'librumpy_exp.so')
+        h = C.CDLL(path)
+        for name, res, args in (('rumpy_conv_chain', C.c_int, [C.POINTER(ChainArgs), C.c_void_p]), ('rumpy_conv_chain_xchg_bytes', C.c_int64, [C.c_int32]),
+                                ('rumpy_block_chain', C.c_int, [C.POINTER(BlockChainArgs), C.c_void_p]), ('rumpy_block_chain_xchg_bytes', C.c_int64, [C.c_int32]),
+                                ('rumpy_last_error', C.c_char_p, [])):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _exp = h
+    return _exp
+
+
+def exp_call(name, args, stream_):
+    rc = getattr(exp_lib(), name)(C.byref(args), stream_)
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (name, rc, (exp_lib().rumpy_last_error() or b'?').decode()))
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 

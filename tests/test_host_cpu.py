@@ -50,14 +50,14 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_structs_match_the_header_layout():
     """compile a C probe against include/rumpy_amd.h and compare sizeof / offsetof with the ctypes mirrors"""
     _lib = _lib_or_skip()
-    pairs = {'rumpy_conv_args': _lib.ConvArgs, 'rumpy_chain_layer': _lib.ChainLayer, 'rumpy_chain_args': _lib.ChainArgs, 'rumpy_head_fwd_args': _lib.HeadFwdArgs, 'rumpy_enc_conv_args': _lib.EncConvArgs, 'rumpy_rcab_args': _lib.RcabArgs, 'rumpy_enc_bn_args': _lib.EncBnArgs, 'rumpy_head_wgrad_args': _lib.HeadWgradArgs,
+    pairs = {'rumpy_conv_args': _lib.ConvArgs, 'rumpy_head_fwd_args': _lib.HeadFwdArgs, 'rumpy_enc_conv_args': _lib.EncConvArgs, 'rumpy_rcab_args': _lib.RcabArgs, 'rumpy_enc_bn_args': _lib.EncBnArgs, 'rumpy_head_wgrad_args': _lib.HeadWgradArgs,
              'rumpy_tail_fwd_args': _lib.TailFwdArgs, 'rumpy_tail_dgrad_args': _lib.TailDgradArgs,
              'rumpy_nchw_to_nhwc4_args': _lib.NchwToNhwc4Args, 'rumpy_wgrad_job': _lib.WgradJob, 'rumpy_reduce_item': _lib.ReduceItem,
              'rumpy_pack_item': _lib.PackItem, 'rumpy_ca_mlp_fwd_args': _lib.CaMlpFwdArgs, 'rumpy_ca_scale_args': _lib.CaScaleArgs,
              'rumpy_ca_bwd_reduce_args': _lib.CaBwdReduceArgs, 'rumpy_ca_mlp_bwd_args': _lib.CaMlpBwdArgs,
              'rumpy_ca_bwd_apply_args': _lib.CaBwdApplyArgs, 'rumpy_adam_hyper': _lib.AdamHyper, 'rumpy_adam_args': _lib.AdamArgs,
              'rumpy_sumsq_args': _lib.SumsqArgs, 'rumpy_eval_post_args': _lib.EvalPostArgs, 'rumpy_block_args': _lib.BlockArgs,
-             'rumpy_block_chain_args': _lib.BlockChainArgs, 'rumpy_ca_fwd_fused_args': _lib.CaFwdFusedArgs, 'rumpy_ca_bwd_fused_args': _lib.CaBwdFusedArgs,
+             'rumpy_ca_fwd_fused_args': _lib.CaFwdFusedArgs, 'rumpy_ca_bwd_fused_args': _lib.CaBwdFusedArgs,
              'rumpy_q_mlp_item': _lib.QMlpItem, 'rumpy_ssim_args': _lib.SsimArgs, 'rumpy_patch_item': _lib.PatchItem, 'rumpy_patch_args': _lib.PatchArgs,
              'rumpy_dconv_args': _lib.DconvArgs, 'rumpy_dconv_wgrad_args': _lib.DconvWgradArgs, 'rumpy_mse_args': _lib.MseArgs, 'rumpy_op': _lib.Op}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rumpy_amd.h"', 'int main(void){']

@@ -10,11 +10,11 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 try:
-    from tests.gpu_utils import (BF16, DEV, PackedConv, assert_bf16_close, assert_f32_close, bf16r, hip_conv, hip_wgrad,
-                                 nchw, nhwc, pack_bias_ref, pack_ref, stream, to_dev_bytes)
+    from tests.gpu_utils import (BF16, DEV, BlockChainArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, assert_f32_close, bf16r,
+                                 exp_call, exp_lib, hip_conv, hip_wgrad, nchw, nhwc, pack_bias_ref, pack_ref, stream, to_dev_bytes)
 except ImportError:  # pytest rootdir import mode
-    from gpu_utils import (BF16, DEV, PackedConv, assert_bf16_close, assert_f32_close, bf16r, hip_conv, hip_wgrad,
-                           nchw, nhwc, pack_bias_ref, pack_ref, stream, to_dev_bytes)
+    from gpu_utils import (BF16, DEV, BlockChainArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, assert_f32_close, bf16r,
+                           exp_call, exp_lib, hip_conv, hip_wgrad, nchw, nhwc, pack_bias_ref, pack_ref, stream, to_dev_bytes)
 from rumpy_amd import _lib as L
 
 
@@ -477,19 +477,19 @@ def _chain_reference_and_run(N, H, W, nlayers, seed):
                     return outs[k]
             return t
         use_bias = cfg.get('use_bias', True)
-        layers.append(L.ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=(pcs[l].b_packed.data_ptr() if use_bias else None),
+        layers.append(ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=(pcs[l].b_packed.data_ptr() if use_bias else None),
                                    out=outs[l].data_ptr(), mask=p(remap(cfg.get('mask'))), res1=p(remap(cfg.get('res1'))),
                                    res2=p(remap(cfg.get('res2'))), relu=1 if cfg.get('relu') else 0, scale=float(cfg.get('scale', 1.0))))
-    ldev = to_dev_bytes((L.ChainLayer * nlayers)(*layers))
+    ldev = to_dev_bytes((ChainLayer * nlayers)(*layers))
     nstrips = N * ((H + 5) // 6)
-    xchg = torch.zeros(int(L.lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
+    xchg = torch.zeros(int(exp_lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
     status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
-    a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
+    a = ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
                     xchg=xchg.data_ptr(), status=status.data_ptr())
     for _ in range(3):                 # repeated launches on the same exchange buffer: the epoch base moves on every call
         for o in outs:
             o.fill_(float('nan'))
-        L.call('rumpy_conv_chain', a, stream())
+        exp_call('rumpy_conv_chain', a, stream())
     torch.cuda.synchronize()
     assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
     return outs_ref, outs
@@ -506,10 +506,10 @@ def test_conv_chain_matches_layer_by_layer(N, H, W, nlayers):
 
 def test_conv_chain_rejects_shapes_that_cannot_be_resident():
     t = torch.zeros(64, dtype=BF16, device=DEV)
-    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
-    assert L.lib().rumpy_conv_chain(a, None) == -1
-    a = L.ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
-    assert L.lib().rumpy_conv_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()
+    a = ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_conv_chain(a, None) == -1
+    a = ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_conv_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -594,14 +594,14 @@ def _block_chain_case(N, H, W, nblocks, fwd, seed):
     table = (L.BlockArgs * nblocks)(*[args(b, x if b == 0 else outs[b - 1], ts[b], outs[b]) for b in range(nblocks)])
     tdev = to_dev_bytes(table)
     nstrips = N * ((H + 5) // 6)
-    xchg = torch.zeros(int(L.lib().rumpy_block_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
+    xchg = torch.zeros(int(exp_lib().rumpy_block_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
     status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
-    a = L.BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0 if fwd else 1, xchg=xchg.data_ptr(),
+    a = BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0 if fwd else 1, xchg=xchg.data_ptr(),
                          status=status.data_ptr())
     for _ in range(3):                 # repeated launches on the same exchange buffer: the tag base moves on every call
         for o in outs + ts:
             o.fill_(float('nan'))
-        L.call('rumpy_block_chain', a, stream())
+        exp_call('rumpy_block_chain', a, stream())
     torch.cuda.synchronize()
     assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
     return ref_t, ref_o, ts, outs
@@ -619,10 +619,10 @@ def test_block_chain_matches_block_by_block(N, H, W, nblocks, fwd):
 
 def test_block_chain_rejects_shapes_that_cannot_be_resident():
     t = torch.zeros(64, dtype=BF16, device=DEV)
-    a = L.BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
-    assert L.lib().rumpy_block_chain(a, None) == -1
-    a = L.BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
-    assert L.lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()
+    a = BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_block_chain(a, None) == -1
+    a = BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
 
 
 @pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (8, 48, 48)])

@@ -17,8 +17,12 @@
 // Needs every strip co-resident: N * ceil(H/6) <= CUs (one 512-thread workgroup per CU, 115 KB LDS), W <= 48, and no other
 // kernel occupying CUs.  A timed-out spin sets *status (the host raises on it); the kernel always terminates.
 #include "block_common.hpp"
+#include "rumpy_experimental.h"
 #include <type_traits>
 
+#ifndef BCHAIN_ABL
+#define BCHAIN_ABL 0     // 9: phase stamps of block 8 into a.status + 16 words... (diagnostic builds only, tests/tools/build_abl.sh)
+#endif
 constexpr int BCREC = 2 * BSW * 32;     // 8-byte records of one edge: 2 rows x 48 pixels x 32 channel pairs
 constexpr int BCHDR = 8;                // header records (word 0 = tag base)
 constexpr unsigned BCSPIN = 1u << 20;
@@ -98,6 +102,9 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
     bias1 = (bc_f32x4){__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};   // zeros without a bias
   }
 
+  unsigned long long stamps[10];
+  int nst = 0;
+#define BC_STAMP() do { if (BCHAIN_ABL == 9 && b == 8 && nst < 10) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (int b = 0; b < a.nblocks; ++b) {
     // an opaque zero per block: the lane geometry derived from it is recomputed here instead of being hoisted out of the
     // block loop into dozens of long-lived registers (which spill: conv_chain.hip)
@@ -141,6 +148,7 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
       for (int k = 0; k < 12; ++k) ok = ok && (!rec_used(k) || hreg[k].y == want);
       return ok;
     };
+    BC_STAMP();                                         // 0: block start
     fetch_halo();                                       // on every path: without a neighbour the own slot is read and ignored
 
     // (2) convA on the two T rows of this wave that need no halo row (RH 0: T rows 2,3 from input rows 2..5; RH 1: T rows 4,5
@@ -156,6 +164,7 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
       sweep_bases(off, 0u, (RH == 0) ? 2 : 4, px, g);
       block_sweep<2>(accL, F, lds, off);
     }
+    BC_STAMP();                                         // 1: first half of sweep 1 done
     // ReLU-mask vectors of epilogue 1 (data-gradient chains): requested now, they land under the halo step and the second half
     auto t_offset = [&](int k) -> unsigned {          // byte offset of pair k's vector in a [N,H,W,64] tensor, BC_OOB outside the image
       const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
@@ -185,6 +194,7 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
       }
       __syncthreads();
     }
+    BC_STAMP();                                         // 2: halo rows in LDS + barrier
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -194,6 +204,7 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
       sweep_bases(off, 0u, (RH == 0) ? 0 : 6, px, g);
       block_sweep<2>(accD, F, lds, off);
     }
+    BC_STAMP();                                         // 3: second half of sweep 1 done
     // second filter + its bias: L2 hits that land under the epilogue
 #pragma unroll
     for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(bc_load16(rw2, (unsigned)(q * 18 * 1024 + lane * 16 + t * 1024)));
@@ -244,7 +255,9 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
       do_pair(std::integral_constant<int, 0>{}); do_pair(std::integral_constant<int, 1>{}); do_pair(std::integral_constant<int, 2>{});
       do_pair(std::integral_constant<int, 3>{}); do_pair(std::integral_constant<int, 4>{}); do_pair(std::integral_constant<int, 5>{});
     }
+    BC_STAMP();                                         // 4: epilogue 1 done
     __syncthreads();
+    BC_STAMP();                                         // 5: barrier
 
     // (4) convB: output rows 3RH .. 3RH+2 of the strip from T rows r .. r+2
     f32x4 acc[3][3];
@@ -258,6 +271,7 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
       sweep_bases(off, (unsigned)BXBYTES, 3 * RH, px, g);
       block_sweep<3>(acc, F, lds, off);
     }
+    BC_STAMP();                                         // 6: sweep 2 done
     // the next block's first filter + bias: they land under the epilogue and the halo wait
 #pragma unroll
     for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(bc_load16(rw1n, (unsigned)(q * 18 * 1024 + lane * 16 + t * 1024)));
@@ -318,8 +332,15 @@ __device__ __forceinline__ void block_chain_body(const BChainDev& a, unsigned ch
         if (more && in) *reinterpret_cast<uint2*>(xp) = o;
       }
     }
+    BC_STAMP();                                         // 7: epilogue 2 done
     if (more) __syncthreads();      // the next block's input is complete in LDS
+    BC_STAMP();                                         // 8: barrier
   }
+  if (BCHAIN_ABL == 9 && lane == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.xchg) + (a.xchg_bytes >> 3) + ((size_t)strip * 8 + q + 4 * RH) * 16;
+    for (int i = 0; i < 10; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
+  }
+#undef BC_STAMP
 }
 
 template <bool MASK>

@@ -20,6 +20,7 @@
 // Needs all strips co-resident: grid = N * ceil(H/6) <= number of CUs, one 512-thread workgroup per CU (153.6 KB LDS),
 // W <= 48, nothing else on the GPU.  A timed-out spin sets *status; the kernel always terminates.
 #include "common.hpp"
+#include "rumpy_experimental.h"
 #include <type_traits>
 
 constexpr int CSH = 6, CSW = 48;

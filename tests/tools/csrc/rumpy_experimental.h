@@ -1,0 +1,63 @@
+/*
+ * rumpy_experimental.h - C ABI of the EXPERIMENTAL persistent-chain kernels (not part of the product library, not launched by the engine):
+ * a whole chain of 64->64 layers / residual blocks in ONE launch with the strip resident in LDS and halo rows exchanged between
+ * workgroups as epoch-tagged records.  Built, parity-tested and measured (tests/test_kernels_gpu.py, tests/tools/kbench.py chain|bchain);
+ * they tie with or lose to the per-block launches, so they live with the measurement tools:
+ * tests/tools/csrc/ -> tests/tools/csrc/librumpy_exp.so.
+ */
+#ifndef RUMPY_EXPERIMENTAL_H
+#define RUMPY_EXPERIMENTAL_H
+#include "rumpy_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- layer-resident chain of 64->64 3x3 convs (EDSR body, forward or data-gradient direction) in one launch ----
+ * Every layer has rumpy_conv3x3 semantics with cin_chunks = cout_tiles = 1; layer l+1's input is layer l's output, kept
+ * in LDS by the workgroup that owns the strip; halo rows travel between vertical neighbours through `xchg` as
+ * epoch-tagged 8-byte records (see conv_chain.hip).
+ * Requirements: W <= 48 and N * ceil(H/6) <= rumpy_device_cus() (all strips co-resident), nothing else running on the GPU.
+ * *status != 0 afterwards means a hand-off timed out (results invalid). */
+typedef struct {
+  const void* w;        /* packed filter (fwd or dgrad image) */
+  const float* bias;    /* packed bias or NULL */
+  void* out;            /* [N,H,W,64] bf16, always written */
+  const void* mask;     /* as rumpy_conv_args */
+  const void* res1;
+  const void* res2;
+  int32_t relu;
+  float scale;
+} rumpy_chain_layer;
+typedef struct {
+  const void* x;                    /* [N,H,W,64] bf16 input of layer 0 */
+  const rumpy_chain_layer* layers;  /* DEVICE array */
+  int32_t nlayers;
+  int32_t N, H, W;
+  void* xchg;                       /* rumpy_conv_chain_xchg_bytes(N*ceil(H/6)) bytes: zeroed ONCE by the caller when
+                                       allocated, then owned by the library (halo-row records + epoch header) */
+  uint32_t* status;                 /* 1 word (zeroed by the call) */
+  uint64_t* stamps;                 /* NULL, or diagnostics: [strip][wave 8][layer < 8][8] s_memrealtime stamps */
+} rumpy_chain_args;
+int rumpy_conv_chain(const rumpy_chain_args* a, void* stream);
+int64_t rumpy_conv_chain_xchg_bytes(int32_t nstrips);
+
+/* ---- a chain of residual blocks in one launch, the strip resident in LDS from block to block (conv_block_chain.hip) ----
+ * blocks: DEVICE array of rumpy_block_args, block b+1's input is block b's output (x is read from blocks[0] only; res2 must be
+ * NULL).  Needs N*ceil(H/6) <= CUs (every strip co-resident), W <= 48 and nothing else occupying CUs while it runs.
+ * xchg: rumpy_block_chain_xchg_bytes(N*ceil(H/6)) bytes, zeroed ONCE by the caller at allocation, then owned by the library.
+ * status: one device word, 0 after a clean run (a neighbour hand-off that timed out stores 0x200 + block index). */
+typedef struct {
+  const rumpy_block_args* blocks;
+  int32_t nblocks;
+  int32_t N, H, W;
+  int32_t masked;      /* 1: the blocks carry ReLU masks (data-gradient chains), 0: none does (the masks are not even loaded) */
+  void* xchg;
+  uint32_t* status;
+} rumpy_block_chain_args;
+int rumpy_block_chain(const rumpy_block_chain_args* a, void* stream);
+int64_t rumpy_block_chain_xchg_bytes(int32_t nstrips);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -8,7 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from gpu_utils import BF16, DEV, PackedConv, hip_wgrad, stream, to_dev_bytes  # noqa: E402
+from gpu_utils import BF16, DEV, BlockChainArgs, ChainArgs, ChainLayer, PackedConv, exp_call, exp_lib, hip_wgrad, stream, to_dev_bytes  # noqa: E402
 from rumpy_amd import _lib as L  # noqa: E402
 
 
@@ -92,19 +92,19 @@ def chain_bench(N=32, H=48, W=48, nlayers=33):
     layers = []
     for l in range(nlayers):
         res = (outs[l - 2] if l >= 2 else x) if (l % 2 == 1) else None
-        layers.append(L.ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=pcs[l].b_packed.data_ptr(), out=outs[l].data_ptr(),
+        layers.append(ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=pcs[l].b_packed.data_ptr(), out=outs[l].data_ptr(),
                                    res1=(res.data_ptr() if res is not None else None), relu=1 if l % 2 == 0 else 0,
                                    scale=1.0 if l % 2 == 0 else 0.1))
-    ldev = to_dev_bytes((L.ChainLayer * nlayers)(*layers))
+    ldev = to_dev_bytes((ChainLayer * nlayers)(*layers))
     nstrips = N * ((H + 5) // 6)
-    xchg = torch.zeros(int(L.lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)
+    xchg = torch.zeros(int(exp_lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
-    a = L.ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
+    a = ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
                     xchg=xchg.data_ptr(), status=status.data_ptr())
-    us = time_fn(lambda: L.call('rumpy_conv_chain', a, stream()), iters=20)
+    us = time_fn(lambda: exp_call('rumpy_conv_chain', a, stream()), iters=20)
     st = torch.zeros(nstrips * 8 * 8 * 8, dtype=torch.int64, device=DEV)
     a.stamps = st.data_ptr()
-    L.call('rumpy_conv_chain', a, stream())
+    exp_call('rumpy_conv_chain', a, stream())
     torch.cuda.synchronize()
     a.stamps = None
     d = st.cpu().numpy().reshape(nstrips, 8, 8, 8).astype(np.float64)
@@ -252,18 +252,27 @@ def bchain_bench(N=32, H=48, W=48, nblocks=16):
                          scale1=1.0, scale2=0.1) for b, (pa, pb) in enumerate(pcs)]
     tdev = to_dev_bytes((L.BlockArgs * nblocks)(*items))
     nstrips = N * ((H + 5) // 6)
-    xchg = torch.zeros(int(L.lib().rumpy_block_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)
+    xb = int(exp_lib().rumpy_block_chain_xchg_bytes(nstrips))
+    xchg = torch.zeros(xb + nstrips * 8 * 16 * 8, dtype=torch.uint8, device=DEV)       # + room for the stamps of a BCHAIN_ABL=9 build
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
-    a = L.BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0, xchg=xchg.data_ptr(), status=status.data_ptr())
+    a = BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0, xchg=xchg.data_ptr(), status=status.data_ptr())
 
     def per_block():
         for it in items:
             L.call('rumpy_conv_block', it, stream())
     for _ in range(2):
-        us_c = time_fn(lambda: L.call('rumpy_block_chain', a, stream()), iters=20)
+        us_c = time_fn(lambda: exp_call('rumpy_block_chain', a, stream()), iters=20)
         us_b = time_fn(per_block, iters=20)
         print('%d residual blocks %dx%dx%d: one launch for the chain %8.1f us = %6.2f us/block (status %d); one launch per block %8.1f us = %6.2f us/block'
               % (nblocks, N, H, W, us_c, us_c / nblocks, int(status.item()), us_b, us_b / nblocks))
+
+
+    if 'BCHAIN_ABL_9' in os.environ.get('RUMPY_EXP_LIB', ''):
+        raw = xchg[xb:].cpu().numpy().view(np.uint64).reshape(nstrips, 8, 16)[:, :, :10].astype(np.float64)
+        k = int((raw[0, 0] > 0).sum())
+        rel = (raw[:, :, :k] - raw[:, :, :1]) * 0.01
+        print('   block 8 stamps, us from the block start: rh=0: ' + ' '.join('%.2f' % v for v in rel[:, :4].mean((0, 1))) + ' | rh=1: ' + ' '.join('%.2f' % v for v in rel[:, 4:].mean((0, 1))))
+        print('   block-8 start spread over the strips %.2f us' % ((raw[:, :, 0].max() - raw[:, :, 0].min()) * 0.01))
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'bchain':
