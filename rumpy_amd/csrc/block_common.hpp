@@ -146,3 +146,31 @@ __device__ __forceinline__ unsigned strip_piece_off(int i, int tid, int n, int s
   const int p = tid + BTHREADS * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW, y = sy * BSH + r;
   return (p < STRIP_PIECES && y < H && col < W) ? (unsigned)(((n * H + y) * W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
 }
+
+
+// ---- row-half groups: waves 0..3 (rh = 0) and 4..7 (rh = 1) synchronise among themselves through LDS counters ----
+// The workgroup barrier between the two phases made the row half that finishes its sweep first (the older waves win the matrix pipe)
+// idle through the other half's epilogue with the pipe empty (0.96 us of a 14.9 us residual-block launch, stamps of tests/tools/kbench.py
+// block).  A group now counts its waves in (gate_arrive) when its rows of an LDS image are written and whoever needs those rows waits
+// for the count (gate_wait): the first group starts its second sweep on the output rows that depend on its own T rows only.
+__device__ __forceinline__ void gate_arrive(unsigned* cnt, int lane) {
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // behind this wave's LDS writes
+}
+__device__ __forceinline__ void gate_wait(unsigned* cnt, unsigned target) {
+  while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+// a group's 3 strip rows as 16-byte pieces: p = tg + 256 i (tg = thread within the group, i < 5, p < 1152) = chunk p & 7 of pixel p >> 3
+constexpr int GROUP_PIECES = 3 * BSW * 8;            // 1152
+constexpr int GROUP_REGS = (GROUP_PIECES + 255) / 256;   // 5 (the last one half used)
+template <int ROW0>
+__device__ __forceinline__ void group_stage(uint4 (&S)[GROUP_REGS], const unsigned char* img, int tg, int rh) {
+#pragma unroll
+  for (int i = 0; i < GROUP_REGS; ++i) {
+    const int p = tg + 256 * i, pix = (p < GROUP_PIECES ? p : 0) >> 3, r = pix / BSW, col = pix - r * BSW;
+    S[i] = *reinterpret_cast<const uint4*>(img + swz((3 * rh + r + ROW0) * BCOLS + col + 1, p & 7));
+  }
+}
+__device__ __forceinline__ unsigned group_piece_off(int i, int tg, int rh, int n, int sy, int H, int W) {
+  const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW, y = sy * BSH + 3 * rh + r;
+  return (p < GROUP_PIECES && y < H && col < W) ? (unsigned)(((n * H + y) * W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+}

@@ -38,11 +38,12 @@
 template <bool GEN, int FORM = 0, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  __shared__ unsigned gate[4];             // waves of row half 0 / 1 that have written their T rows, their OUT rows (block_common.hpp::gate_*)
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + BXBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
-  const int q = wave & 3, rh = wave >> 2;
+  const int q = wave & 3, rh = __builtin_amdgcn_readfirstlane(wave >> 2), tg = tid & 255;
   const int strip = xcd_strip(blockIdx.x, gridDim.x);
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
   unsigned long long stamps[8];
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       if (!ok) v = make_uint4(0, 0, 0, 0);
       R[i] = v;
     }
+    if (tid < 4) gate[tid] = 0u;
     // border columns of the T image are convB's zero padding and are never written by the epilogue
     if (tid < BTROWS * 2 * 8) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
@@ -158,21 +160,26 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) t_pair(k);
+    gate_arrive(&gate[rh], lane);          // this wave's 16 channels of T rows 4rh .. 4rh+3 are in LDS
     BK_STAMP();                            // 3: T image written
   }
-  unsigned soff[STRIP_REGS];               // element offsets of this thread's pieces of the strip (shared by the T and the OUT stores)
+  unsigned soff[GROUP_REGS];               // element offsets of this thread's pieces of its row half's 3 strip rows (T and OUT stores)
 #pragma unroll
-  for (int i = 0; i < STRIP_REGS; ++i) soff[i] = strip_piece_off(i, tid, n, sy, a.H, a.W);
-  __syncthreads();
-  BK_STAMP();                              // 4: barrier passed
-  // The strip's own rows of T (and their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal, one piece
-  // after each of the first MFMA groups of the second sweep (block_common.hpp::strip_stage).
-  uint4 S[STRIP_REGS];
+  for (int i = 0; i < GROUP_REGS; ++i) soff[i] = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+  // No workgroup barrier between the phases: output rows 0, 1 need T rows 0 .. 3 (row half 0's own), output row 2 also row 4, output rows
+  // 3 .. 5 T rows 3 .. 7 - each row half waits for exactly the T rows it reads (block_common.hpp: row-half groups).  The input image is
+  // overwritten (OUT, in place) only behind a wait for the OTHER half's T rows, i.e. when nobody sweeps over it any more.
+  gate_wait(&gate[rh], 4u);
+  if (rh == 1) gate_wait(&gate[0], 4u);
+  BK_STAMP();                              // 4: this row half's T rows complete
+  // The row half's own strip rows of T (and their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal, one
+  // piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage).
+  uint4 S[GROUP_REGS];
   const bool t_out = (a.t != nullptr) && BLOCK_ABL != 4;
-  if (t_out) strip_stage<1>(S, ldt, tid);
+  if (t_out) group_stage<1>(S, ldt, tg, rh);
   auto t_store = [&](int grp) {           // grp is a constant after unrolling: piece i after the MFMAs of group 3 i
-    if (grp % 3 == 0 && grp / 3 < STRIP_REGS) {
-      const int i = grp / 3 < STRIP_REGS ? grp / 3 : 0;
+    if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
+      const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
       if (t_out && soff[i] != 0xffffffffu) {
         st16_nt(a.t + soff[i], S[i]);
         if (FORM == 1 && a.mbits) a.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
@@ -207,9 +214,17 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       if (a.res_mode == 2) P1s = *reinterpret_cast<const uint2*>(a.res1 + (rsoff != 0xffffffffu ? rsoff : 0u));
     }
     unsigned off[8][2];
-    sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
     if (BLOCK_ABL == 9) cyc[2] = __builtin_amdgcn_s_memtime();
-    block_sweep<3, FMT>(acc, F, lds, off, t_store);
+    if (rh == 0) {
+      sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), F, lds, off, t_store);       // output rows 0, 1 <- T rows 0 .. 3
+      gate_wait(&gate[1], 4u);
+      sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
+      block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), F, lds, off);                // output row 2 <- T rows 2 .. 4
+    } else {
+      sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
+      block_sweep<3, FMT>(acc, F, lds, off, t_store);                                              // output rows 3 .. 5 <- T rows 3 .. 7
+    }
     if (BLOCK_ABL == 9) cyc[3] = __builtin_amdgcn_s_memtime();
     BK_STAMP();                            // 5: second sweep done
     float ps[4] = {0.f, 0.f, 0.f, 0.f};                         // GEN pool sums: single tile, channels 4g .. 4g+3 of the wave's 16
@@ -307,14 +322,15 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       }
     }
   }
-  // ---- OUT: the image now sits in LDS in place of the input tile's centre rows (each lane replaced exactly the input values it had read
-  // as its residual operand; nothing else reads the input tile in phase 2) -> whole lines to HBM, non-temporal ----
-  __syncthreads();
-  BK_STAMP();                              // 6: OUT image complete
+  // ---- OUT: the row half's 3 rows now sit in LDS in place of the input tile's centre rows (each lane replaced exactly the input values it
+  // had read as its residual operand; nothing else reads the input tile in phase 2) -> whole lines to HBM, non-temporal ----
+  gate_arrive(&gate[2 + rh], lane);
+  gate_wait(&gate[2 + rh], 4u);
+  BK_STAMP();                              // 6: this row half's OUT rows complete
   if (BLOCK_ABL != 4) {
-    strip_stage<2>(S, ldx, tid);
+    group_stage<2>(S, ldx, tg, rh);
 #pragma unroll
-    for (int i = 0; i < STRIP_REGS; ++i)
+    for (int i = 0; i < GROUP_REGS; ++i)
       if (soff[i] != 0xffffffffu) { if (BLOCK_OUT_PLAIN) *reinterpret_cast<uint4*>(a.out + soff[i]) = S[i]; else st16_nt(a.out + soff[i], S[i]); }
   }
   BK_STAMP();                              // 7: end (stores issued)
