@@ -89,12 +89,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   // (one L2 round trip per step was 4-5 us of the first version)
   __shared__ float sw1[RC_MAXR * 64];      // [r][c] = conv_du.0.weight
   __shared__ float sw2t[RC_MAXR * 64];     // [r][c] = conv_du.2.weight[c][r]
+  __shared__ unsigned gate[4];              // row-half groups (block_common.hpp::gate_*): waves that have written their T rows / OUT rows
   __shared__ float svec[4 * 64];           // [0] conv_du.0.bias (cr) | [1] conv_du.2.bias | [2] q gate | [3] bwd: forward gate ; hidden at [0][32..]
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + BXBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
-  const int q = wave & 3, rh = wave >> 2;
+  const int q = wave & 3, rh = __builtin_amdgcn_readfirstlane(wave >> 2), tg = tid & 255;
+  if (tid < 4) gate[tid] = 0u;              // (ordered before every use by the barrier behind the tile load)
   // XCD-aware strip order when every XCD gets whole images (then the strips of an image are consecutive in ONE XCD's dispatch order and
   // the exchange argument at the top of this file holds per XCD: needs ceil(H/6) <= 32 CUs); identity otherwise
   const int nwg = gridDim.x;
@@ -333,23 +335,27 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
     }
+    gate_arrive(&gate[rh], lane);          // this wave's 16 channels of T rows 4rh .. 4rh+3 are in LDS
   }
-  unsigned soff[STRIP_REGS];               // element offsets of this thread's 16-byte pieces of the strip (T, t2 and OUT stores)
+  unsigned soffg[GROUP_REGS];              // element offsets of this thread's 16-byte pieces of its row half's 3 strip rows (T; backward: OUT)
 #pragma unroll
-  for (int i = 0; i < STRIP_REGS; ++i) soff[i] = strip_piece_off(i, tid, n, sy, a.H, a.W);
-  __syncthreads();
-  RC_STAMP();                              // T tile written + barrier
-  // the strip's own rows of T (forward: + their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal, one
-  // piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage; conv_block.hip)
+  for (int i = 0; i < GROUP_REGS; ++i) soffg[i] = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+  // no workgroup barrier between the phases: each row half waits for exactly the T rows it reads (conv_block.hip, block_common.hpp)
+  gate_wait(&gate[rh], 4u);
+  if (rh == 1) gate_wait(&gate[0], 4u);
+  RC_STAMP();                              // this row half's T rows complete
+  // the row half's own strip rows of T (forward: + their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal,
+  // one piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage; conv_block.hip)
   uint4 S[STRIP_REGS];
+  unsigned soff[STRIP_REGS];               // (forward) element offsets of this thread's pieces of the whole strip: t2 and OUT stores
   const bool t_out = a.t != nullptr;
-  if (t_out) strip_stage<1>(S, ldt, tid);
+  if (t_out) group_stage<1>(S, ldt, tg, rh);
   auto t_store = [&](int grp) {           // grp is a constant after unrolling
-    if (grp % 3 == 0 && grp / 3 < STRIP_REGS) {
-      const int i = grp / 3 < STRIP_REGS ? grp / 3 : 0;
-      if (t_out && soff[i] != 0xffffffffu) {
-        st16_nt(a.t + soff[i], S[i]);
-        if (!BWD && a.mbits) a.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+    if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
+      const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
+      if (t_out && soffg[i] != 0xffffffffu) {
+        st16_nt(a.t + soffg[i], S[i]);
+        if (!BWD && a.mbits) a.mbits[soffg[i] >> 3] = (unsigned char)relu_bits(S[i]);
       }
     }
   };
@@ -381,8 +387,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (BWD) P1s = *reinterpret_cast<const uint2*>(a.x + (osoff != 0xffffffffu ? osoff : 0u));
     }
     unsigned off[8][2];
-    sweep_bases(off, (unsigned)BXBYTES, 3 * rh, px, g);
-    block_sweep<3, FMT>(acc, F, lds, off, t_store);
+    if (rh == 0) {
+      sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), F, lds, off, t_store);       // rows 0, 1 <- T rows 0 .. 3 (this half's own)
+      gate_wait(&gate[1], 4u);
+      sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
+      block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), F, lds, off);                // row 2 <- T rows 2 .. 4
+    } else {
+      sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
+      block_sweep<3, FMT>(acc, F, lds, off, t_store);                                              // rows 3 .. 5 <- T rows 3 .. 7
+    }
     RC_STAMP();                            // sweep B done
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
     float V[4][8], vs[4];
@@ -461,6 +475,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
       }
       __syncthreads();                     // every wave has finished its second sweep: the T image is dead
+#pragma unroll
+      for (int i = 0; i < STRIP_REGS; ++i) soff[i] = strip_piece_off(i, tid, n, sy, a.H, a.W);
       if (a.t2) {                          // training: t2 = conv2(t1) + b2 goes to HBM through the T image's rows 1 .. 6 (whole lines, below)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -522,11 +538,20 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     }
   }
   // ---- OUT (forward: x + gate * t2; backward: dx): the image sits in LDS in place of the input tile's centre rows -> whole lines, non-temporal ----
-  __syncthreads();
-  strip_stage<2>(S, ldx, tid);
+  if (BWD) {                               // per row half: its 3 rows are complete when its 4 waves have arrived
+    gate_arrive(&gate[2 + rh], lane);
+    gate_wait(&gate[2 + rh], 4u);
+    group_stage<2>(S, ldx, tg, rh);
 #pragma unroll
-  for (int i = 0; i < STRIP_REGS; ++i)
-    if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
+    for (int i = 0; i < GROUP_REGS; ++i)
+      if (soffg[i] != 0xffffffffu) st16_nt(a.out + soffg[i], S[i]);
+  } else {
+    __syncthreads();
+    strip_stage<2>(S, ldx, tid);
+#pragma unroll
+    for (int i = 0; i < STRIP_REGS; ++i)
+      if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
+  }
   RC_STAMP();                              // end (stores issued)
   if (RCAB_ABL == 9 && tid == 0 && a.t) {
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.t) + (size_t)strip * 16;
