@@ -25,8 +25,8 @@ FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, 
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_BYTES = 35.2e6           # FETCH_SIZE 21.9 MB + WRITE_SIZE 13.3 MB per launch
 PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv3x3_strip.md (separate rocprofv3 --pmc passes; launch with one residual operand)'
-BLOCK_PMC_TRAFFIC_BYTES = 36.25e6     # conv_block_kernel, mean of forward (35.3 MB) and data-gradient (47.5 MB) launches
-BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE)'
+BLOCK_PMC_TRAFFIC_BYTES = 30.7e6      # conv_block_kernel, mean of forward (30.4 MB) and data-gradient (31.0 MB) launches
+BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r02_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, 2 x FETCH_SIZE + WRITE_SIZE)'
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
 
@@ -219,8 +219,8 @@ def main():
                 roofline['traffic'] = PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
             elif rcabs:
-                roofline['traffic'] = 56.0e6
-                roofline['traffic_source'] = 'profiles/r01_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
+                roofline['traffic'] = 45.3e6
+                roofline['traffic_source'] = 'profiles/r02_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
             elif BLOCK_PMC_TRAFFIC_BYTES:
                 roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE

@@ -397,6 +397,7 @@ __global__ void loss_finalize_kernel(const float* partial, int n, float inv_nume
 // k-steps); B-fragment element e of lane group g is (tap = 8*ks + 2g + e/4, channel e%4), i.e. two 8-byte LDS
 // reads per k-step.  Write-bound (the output is the largest gradient tensor).
 // ------------------------------------------------------------------------------------------------------
+typedef unsigned int tail_u32x4 __attribute__((ext_vector_type(4)));
 struct TailDgradDev { const uint16_t* dy4; const uint4* w; uint16_t* dx; int N, H, W, tiles_x, tiles_y; };
 
 __global__ void __launch_bounds__(256, 2) tail_dgrad_kernel(TailDgradDev a) {
@@ -416,10 +417,13 @@ __global__ void __launch_bounds__(256, 2) tail_dgrad_kernel(TailDgradDev a) {
   const bf16x8 F1 = as_bf16x8(a.w[(wave * 2 + 1) * 64 + lane]);
   __syncthreads();
   const int c0 = 16 * wave + 4 * g;
-  const int xx = tc.tx * TW + px;
   // taps of this lane group: ks=0 -> 2g, 2g+1 ; ks=1 -> 8+2g (only g==0 real), 9+2g (never)
   const int ta = 2 * g, tb = 2 * g + 1;
   const int kya = ta / 3, kxa = ta - 3 * kya, kyb = tb / 3, kxb = tb - 3 * kyb;
+  // The MFMA leaves a lane 4 channels of a pixel: stored directly, the 151 MB output would leave as 8-byte pieces of lines that four waves
+  // assemble in L2.  The tile goes through LDS instead (16 KB, 16-byte chunk index XOR pixel & 7) and leaves as whole 128-byte lines,
+  // 2 KB contiguous per tile row, non-temporal (conv_block.hip: -2 us per launch there; here 42 -> see DESIGN.md 4).
+  __shared__ __attribute__((aligned(16))) unsigned char sout[TH * TW * 128];
 #pragma unroll
   for (int r = 0; r < TH; ++r) {
     union { uint2 u[2]; bf16x8 b; } B0, B1;
@@ -430,9 +434,18 @@ __global__ void __launch_bounds__(256, 2) tail_dgrad_kernel(TailDgradDev a) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F0, B0.b, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1, B1.b, acc, 0, 0, 0);
-    const int y = tc.ty * TH + r;
-    if (y < a.H && xx < a.W)
-      *reinterpret_cast<uint2*>(a.dx + ((size_t)(tc.n * a.H + y) * a.W + xx) * 64 + c0) = pack4_bf16(acc[0], acc[1], acc[2], acc[3]);
+    const int pix = r * TW + px;
+    *reinterpret_cast<uint2*>(sout + pix * 128 + (((c0 >> 3) ^ (pix & 7)) << 4) + (g & 1) * 8) = pack4_bf16(acc[0], acc[1], acc[2], acc[3]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TH * TW * 8 / 256; ++i) {
+    const int p = tid + 256 * i, pix = p >> 3, c = p & 7;
+    const int y = tc.ty * TH + (pix >> 4), x = tc.tx * TW + (pix & 15);
+    if (y < a.H && x < a.W) {
+      const uint4 v = *reinterpret_cast<const uint4*>(sout + pix * 128 + ((c ^ (pix & 7)) << 4));
+      __builtin_nontemporal_store((tail_u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<tail_u32x4*>(a.dx + ((size_t)(tc.n * a.H + y) * a.W + x) * 64 + c * 8));
+    }
   }
 }
 
