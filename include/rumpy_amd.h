@@ -161,7 +161,7 @@ typedef struct {
   const float* x;   /* [N,C,H,W] fp32 */
   const void* dy;   /* [N,H,W,cout] bf16 */
   float* slab;
-  float* gw;
+  float* gw;        /* NULL: the slab reduction is left to rumpy_finish_reduce */
   float* gb;
   int32_t N, C, H, W, cout;
   float scale;
@@ -428,6 +428,38 @@ typedef struct {
   rumpy_adam_hyper hyper_value;   /* hyper == NULL: the hyper-parameters travel BY VALUE with the launch (eager steps: no staging copy) */
 } rumpy_adam_args;
 int rumpy_adam_step(const rumpy_adam_args* a, void* stream);
+
+/* ---- end-of-step housekeeping in two launches (finish.hip) ----
+ * rumpy_finish_reduce: rumpy_wgrad_reduce over `items` + the tail conv's slab reduction (rumpy_tail_wgrad_reduce) + the head conv's
+ * (the second half of rumpy_head_wgrad, which skips it when called with gw == NULL) in ONE launch; any part may be absent (NULL slabs / 0
+ * items).  Same summation order as the separate entry points: bitwise the same gradients. */
+typedef struct {
+  const rumpy_reduce_item* items; int32_t nitems; int32_t pad_;
+  const float* tail_slabs; int32_t tail_nslabs, tail_C; float tail_scale; int32_t pad2_; float* tail_gw; float* tail_gb;
+  const float* head_slabs; int32_t head_nslabs, head_C, head_cout; float head_scale; float* head_gw; float* head_gb;
+} rumpy_finish_reduce_args;
+int rumpy_finish_reduce(const rumpy_finish_reduce_args* a, void* stream);
+/* slabs rumpy_head_wgrad writes for an N x H x W image batch (= head_nslabs above) */
+int rumpy_head_wgrad_slabs(int32_t N, int32_t H, int32_t W);
+
+/* rumpy_adam_pack: rumpy_adam_step over the parameters named by `items` AND rumpy_pack_weights of the convs among them, in ONE launch
+ * (one workgroup per item; every parameter must be covered by exactly one item).  Offsets are in floats from the start of the flat
+ * buffers p / g / m / v.  kind 0: 16 output channels (quarter q of cout tile ct) x 32 input channels (half hf of cin chunk ch) x 9 taps of a
+ * conv [cout, cin, 3, 3] at woff -> Adam + the vectors of both packed images that this set makes up; kind 1: n <= any plain values at
+ * woff; kind 2: the n = cout <= 4096 biases of such a conv at woff -> Adam + b_packed; kind 3: the tail conv, weights [cout <= 4, 64, 3, 3]
+ * at woff (n = cout * 576), bias at boff -> Adam + its two images (rumpy_pack_item kind 2). */
+typedef struct {
+  int32_t kind, woff, n, cout, cin, shuffle, ct, ch, q, hf, boff, pad_;
+  void* w_fwd; void* w_dgrad; float* b_packed;
+} rumpy_update_item;
+typedef struct {
+  const rumpy_update_item* items; int32_t nitems; int32_t pad_;
+  float* p; const float* g; float* m; float* v;
+  const rumpy_adam_hyper* hyper;  /* DEVICE pointer or NULL (then hyper_value), as rumpy_adam_args */
+  const float* sumsq;
+  rumpy_adam_hyper hyper_value;
+} rumpy_adam_pack_args;
+int rumpy_adam_pack(const rumpy_adam_pack_args* a, void* stream);
 
 /* out[0] = sum(g[i]^2) (deterministic two-pass; `partial` >= 1024 floats) */
 typedef struct {

@@ -184,6 +184,8 @@ class HipSRNet(nn.Module):
                                'there is no CPU path (parameters are on %s)' % self.flat_p.device)
         if self.engine is None:
             self.engine = SREngine(self._spec(), self.flat_p.device)
+            if self.engine.use_finish and all(p.requires_grad for p in self.param_list):
+                self.engine.build_update_table(self.flat_p, self.param_list, self.offsets)
         v = self._weights_version()
         if self._packed_version != v:
             self.engine.repack()

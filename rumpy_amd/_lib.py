@@ -105,6 +105,20 @@ class PackItem(_S):
                 ('cout', c_int32), ('cin', c_int32), ('kind', c_int32), ('shuffle', c_int32), ('fmt', c_int32), ('pad_', c_int32)]
 
 
+class FinishReduceArgs(_S):
+    _fields_ = [('items', c_void_p), ('nitems', c_int32), ('pad_', c_int32),
+                ('tail_slabs', c_void_p), ('tail_nslabs', c_int32), ('tail_C', c_int32), ('tail_scale', c_float), ('pad2_', c_int32),
+                ('tail_gw', c_void_p), ('tail_gb', c_void_p),
+                ('head_slabs', c_void_p), ('head_nslabs', c_int32), ('head_C', c_int32), ('head_cout', c_int32), ('head_scale', c_float),
+                ('head_gw', c_void_p), ('head_gb', c_void_p)]
+
+
+class UpdateItem(_S):
+    _fields_ = [('kind', c_int32), ('woff', c_int32), ('n', c_int32), ('cout', c_int32), ('cin', c_int32), ('shuffle', c_int32), ('ct', c_int32),
+                ('ch', c_int32), ('q', c_int32), ('hf', c_int32), ('boff', c_int32), ('pad_', c_int32),
+                ('w_fwd', c_void_p), ('w_dgrad', c_void_p), ('b_packed', c_void_p)]
+
+
 class CaMlpFwdArgs(_S):
     _fields_ = [('pool', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p),
                 ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p),
@@ -158,6 +172,11 @@ class AdamHyper(_S):
 
 class AdamArgs(_S):
     _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_int64),
+                ('hyper', c_void_p), ('sumsq', c_void_p), ('hyper_value', AdamHyper)]
+
+
+class AdamPackArgs(_S):
+    _fields_ = [('items', c_void_p), ('nitems', c_int32), ('pad_', c_int32), ('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p),
                 ('hyper', c_void_p), ('sumsq', c_void_p), ('hyper_value', AdamHyper)]
 
 
@@ -249,6 +268,9 @@ SYMBOLS = {
     'rumpy_ca_bwd_apply': (C.c_int, [_P(CaBwdApplyArgs), c_void_p]),
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),
     'rumpy_sumsq': (C.c_int, [_P(SumsqArgs), c_void_p]),
+    'rumpy_finish_reduce': (C.c_int, [_P(FinishReduceArgs), c_void_p]),
+    'rumpy_head_wgrad_slabs': (C.c_int, [c_int32, c_int32, c_int32]),
+    'rumpy_adam_pack': (C.c_int, [_P(AdamPackArgs), c_void_p]),
     'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
     'rumpy_run_list': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_conv_block': (C.c_int, [_P(BlockArgs), c_void_p]),

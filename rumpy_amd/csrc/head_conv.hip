@@ -274,6 +274,10 @@ __global__ void __launch_bounds__(256) head_wgrad_reduce_kernel(const float* __r
 // three workgroups per CU (24 KB of LDS each): their load / barrier / MFMA phases overlap
 static int head_wgrad_grid() { return 3 * rumpy_device_cus(); }
 
+extern "C" int rumpy_head_wgrad_slabs(int32_t N, int32_t H, int32_t W) {
+  const int ntiles = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  return ntiles < head_wgrad_grid() ? ntiles : head_wgrad_grid();
+}
 extern "C" int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout) {
   return (int64_t)head_wgrad_grid() * cout * (9 * C + 1);
 }
@@ -308,7 +312,7 @@ extern "C" int rumpy_head_fwd(const rumpy_head_fwd_args* p, void* stream) {
 }
 
 extern "C" int rumpy_head_wgrad(const rumpy_head_wgrad_args* p, void* stream) {
-  if (!p || !p->x || !p->dy || !p->slab || !p->gw || !p->gb) { rumpy_set_error("rumpy_head_wgrad: null pointer"); return RUMPY_E_ARG; }
+  if (!p || !p->x || !p->dy || !p->slab || (p->gw && !p->gb)) { rumpy_set_error("rumpy_head_wgrad: null pointer"); return RUMPY_E_ARG; }
   if (p->C < 1 || p->C > HEAD_MAXC || p->cout <= 0 || p->cout % 64 || p->N <= 0 || p->H <= 0 || p->W <= 0) {
     rumpy_set_error("rumpy_head_wgrad: unsupported shape"); return RUMPY_E_ARG; }
   const int ntiles = p->N * ((p->H + TH - 1) / TH) * ((p->W + TW - 1) / TW);
@@ -320,6 +324,7 @@ extern "C" int rumpy_head_wgrad(const rumpy_head_wgrad_args* p, void* stream) {
   else hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
                           p->N, p->C, p->H, p->W, p->cout);
   const int total = p->cout * (9 * p->C + 1);
+  if (p->gw)          // (gw == NULL: rumpy_finish_reduce adds the slabs up together with the other layers')
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, s, p->slab, nwg, p->C, p->cout,
                      p->scale, p->gw, p->gb);
   return rumpy_check_launch("rumpy_head_wgrad");

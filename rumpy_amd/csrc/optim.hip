@@ -17,6 +17,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   const float step = h.lr / h.bias_c1;
   const float w1 = 1.f - h.beta1, w2 = 1.f - h.beta2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)      // no fused multiply-adds: every product is rounded where torch rounds it (finish.hip::adam_one is the same arithmetic)
     const float gi = g[i] * gm;
     float mi = m[i], vi = v[i];
     mi = mi + w1 * (gi - mi);

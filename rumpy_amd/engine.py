@@ -119,6 +119,9 @@ class SREngine:
         # Training stays bf16 (gradient range).  An output that is not finite (fp16 overflow) switches the engine back to bf16 for good.
         self.eval_fmt = L.FMT_BF16 if os.environ.get('RUMPY_EVAL_BF16') == '1' else L.FMT_F16
         self.max_eval_plans = max(1, int(os.environ.get('RUMPY_EVAL_PLANS', '4')))     # LRU bound on cached evaluation plans (one per image size)
+        # end-of-step housekeeping as two launches (csrc/finish.hip): one reduction launch for all slab kinds, Adam + re-pack in one
+        self.use_finish = os.environ.get('RUMPY_NO_FINISH') != '1'
+        self.update_items = None   # device table of rumpy_update_item (build_update_table), n items
         self.pack_gen = 0          # bumped by every repack(); the fp16 images follow lazily (h_gen)
         self.h_gen = -1
         self._pack_items_h = None
@@ -170,6 +173,54 @@ class SREngine:
         s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
         L.check(self.lib.rumpy_pack_weights(_ptr(self._pack_items), self._n_pack, s), 'rumpy_pack_weights')
         self.pack_gen += 1
+
+    def build_update_table(self, flat_p, params, offsets):
+        """Item table of rumpy_adam_pack over the flat parameter buffer: every parameter exactly once.  64-multiple convs become sets of
+        16 output x 32 input channels (kind 0) + their bias (kind 2), the tail conv one item (kind 3), everything else plain ranges (kind 1,
+        neighbours merged: the four tensors of a channel-attention block are one range)."""
+        base = flat_p.data_ptr()
+        off_of = lambda t: (t.data_ptr() - base) // 4
+        roles = {}
+        for cv in self.spec.convs():
+            if cv.kind == 'main':
+                roles[off_of(cv.weight)] = ('w', cv)
+                roles[off_of(cv.bias)] = ('b', cv)
+            elif cv.kind == 'tail':
+                roles[off_of(cv.weight)] = ('tw', cv)
+                roles[off_of(cv.bias)] = ('tb', cv)
+        items, plain = [], []
+        for p, off in zip(params, offsets):
+            role = roles.get(off)
+            if role is None:
+                if plain and plain[-1][0] + plain[-1][1] == off:
+                    plain[-1][1] += p.numel()
+                else:
+                    plain.append([off, p.numel()])
+                continue
+            kind, cv = role
+            if kind == 'w':
+                for ct in range(cv.cout // 64):
+                    for ch in range(cv.cin // 64):
+                        for q in range(4):
+                            for hf in range(2):
+                                items.append(L.UpdateItem(kind=0, woff=off, n=16 * 288, cout=cv.cout, cin=cv.cin, shuffle=1 if cv.shuffle else 0, ct=ct,
+                                                          ch=ch, q=q, hf=hf, w_fwd=_ptr(cv.w_fwd), w_dgrad=_ptr(cv.w_dgrad)))
+            elif kind == 'b':
+                if cv.cout > 4096:
+                    raise RuntimeError('rumpy_amd: conv %s has more than 4096 output channels' % cv.name)
+                items.append(L.UpdateItem(kind=2, woff=off, n=cv.cout, cout=cv.cout, cin=cv.cin, shuffle=1 if cv.shuffle else 0, b_packed=_ptr(cv.b_packed)))
+            elif kind == 'tw':
+                items.append(L.UpdateItem(kind=3, woff=off, n=cv.cout * 576, cout=cv.cout, cin=cv.cin, boff=off_of(cv.bias), w_fwd=_ptr(cv.w_fwd),
+                                          w_dgrad=_ptr(cv.w_dgrad)))
+            # 'tb': covered by the tail item
+        for off, n in plain:
+            for lo in range(0, n, 16384):
+                items.append(L.UpdateItem(kind=1, woff=off + lo, n=min(16384, n - lo)))
+        covered = sum(it.n for it in items) + sum(it.cout for it in items if it.kind == 3)
+        if covered != flat_p.numel():
+            raise RuntimeError('rumpy_amd: update table covers %d of %d parameters' % (covered, flat_p.numel()))
+        self._update_items_host = (L.UpdateItem * len(items))(*items)
+        self.update_items = (self._to_device_bytes(self._update_items_host), len(items))
 
     def _alloc_packed_h(self):
         """fp16 forward images of every MFMA conv (evaluation plans only: no data-gradient image, the packed biases are shared)"""
@@ -489,8 +540,10 @@ class SREngine:
 
         # ---- head weight gradient ----
         slab = self._new(plan, int(lib.rumpy_head_wgrad_slab_floats(Cin, F)), dtype=torch.float32)
-        a = L.HeadWgradArgs(x=_ptr(plan.x_in), dy=_ptr(g_a0), slab=_ptr(slab), gw=_ptr(spec.head.gw), gb=_ptr(spec.head.gb),
-                            N=N, C=Cin, H=H, W=W, cout=F, scale=1.0)
+        # with the one-launch reduction (finish.hip) the head conv's slabs are added up there: gw = NULL defers it
+        a = L.HeadWgradArgs(x=_ptr(plan.x_in), dy=_ptr(g_a0), slab=_ptr(slab), gw=None if self.use_finish else _ptr(spec.head.gw),
+                            gb=_ptr(spec.head.gb), N=N, C=Cin, H=H, W=W, cout=F, scale=1.0)
+        plan.head_slab, plan.head_nslabs = slab, int(lib.rumpy_head_wgrad_slabs(N, H, W))
         bwd.append(('rumpy_head_wgrad', a))
         plan.scaled.append(a)
         plan.head_wgrad_args = a
@@ -779,6 +832,7 @@ class SREngine:
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
         self._q_param_grads(plan, stream)
+        gs = float(grad_scale)
         if on_ready is not None and plan.split is not None:
             sp = plan.split
             L.check(self.lib.rumpy_wgrad_grouped(_ptr(sp['jobs_a'][0]), sp['jobs_a'][1], 4, 0, stream), 'rumpy_wgrad_grouped')
@@ -786,15 +840,10 @@ class SREngine:
                 dev, n = plan.job_dev[1]
                 L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 1, 1 if plan.HR[1] % 2 else 0, stream), 'rumpy_wgrad_grouped')
             idx = sp['idx_a_notail'] if tail_done else sp['idx_a']
-            if idx:
-                L.check(self.lib.rumpy_wgrad_reduce(_ptr(sp['red_a_notail'] if tail_done else sp['red_a']), len(idx), stream), 'rumpy_wgrad_reduce')
-            if tail_done:
-                tl = self.spec.tail
-                L.check(self.lib.rumpy_tail_wgrad_reduce(_ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, float(grad_scale), _ptr(tl.gw),
-                                                         _ptr(tl.gb), stream), 'rumpy_tail_wgrad_reduce')
+            self._reduce(plan, stream, sp['red_a_notail'] if tail_done else sp['red_a'], len(idx), gs, tail=tail_done, head=False)
             on_ready(sp['ptr'])
             L.check(self.lib.rumpy_wgrad_grouped(_ptr(sp['jobs_b'][0]), sp['jobs_b'][1], 4, 0, stream), 'rumpy_wgrad_grouped')
-            L.check(self.lib.rumpy_wgrad_reduce(_ptr(sp['red_b']), len(sp['idx_b']), stream), 'rumpy_wgrad_reduce')
+            self._reduce(plan, stream, sp['red_b'], len(sp['idx_b']), gs, tail=False, head=True)
             return
         for mt in (4, 1):
             if mt in plan.job_dev and not (mt == 1 and tail_done):
@@ -802,13 +851,29 @@ class SREngine:
                 variant = 1 if (mt == 1 and plan.HR[1] % 2) else 0     # dy4 pixel-pair DMA needs an even width
                 L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, variant, stream), 'rumpy_wgrad_grouped')
         if tail_done:
-            if plan.reduce_keep:
-                L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev_notail), len(plan.reduce_keep), stream), 'rumpy_wgrad_reduce')
-            tl = self.spec.tail
-            L.check(self.lib.rumpy_tail_wgrad_reduce(_ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, float(grad_scale), _ptr(tl.gw),
-                                                     _ptr(tl.gb), stream), 'rumpy_tail_wgrad_reduce')
+            self._reduce(plan, stream, plan.reduce_dev_notail, len(plan.reduce_keep), gs, tail=True, head=True)
         else:
-            L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev), plan.n_reduce, stream), 'rumpy_wgrad_reduce')
+            self._reduce(plan, stream, plan.reduce_dev, plan.n_reduce, gs, tail=False, head=True)
+
+    def _reduce(self, plan, stream, items_dev, nitems, grad_scale, tail, head):
+        """Slab reductions -> parameter gradients: `nitems` entries of the grouped weight-gradient table, the fused tail conv's slabs
+        (tail) and the head conv's (head).  One launch (rumpy_finish_reduce); RUMPY_NO_FINISH=1: the separate entry points (A/B)."""
+        tl, hd = self.spec.tail, self.spec.head
+        if self.use_finish:
+            a = L.FinishReduceArgs(items=_ptr(items_dev) if nitems else None, nitems=nitems)
+            if tail:
+                a.tail_slabs, a.tail_nslabs, a.tail_C, a.tail_scale = _ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, grad_scale
+                a.tail_gw, a.tail_gb = _ptr(tl.gw), _ptr(tl.gb)
+            if head:
+                a.head_slabs, a.head_nslabs, a.head_C, a.head_cout, a.head_scale = _ptr(plan.head_slab), plan.head_nslabs, hd.cin, hd.cout, grad_scale
+                a.head_gw, a.head_gb = _ptr(hd.gw), _ptr(hd.gb)
+            L.call('rumpy_finish_reduce', a, stream)
+            return
+        if nitems:
+            L.check(self.lib.rumpy_wgrad_reduce(_ptr(items_dev), nitems, stream), 'rumpy_wgrad_reduce')
+        if tail:
+            L.check(self.lib.rumpy_tail_wgrad_reduce(_ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, grad_scale, _ptr(tl.gw), _ptr(tl.gb), stream),
+                    'rumpy_tail_wgrad_reduce')
 
     # ------------------------------------------------------------------ hipGraph replay of the fused L1 training pass
     def train_pass_graphed(self, x, target, meta=None):
@@ -868,8 +933,4 @@ class SREngine:
         if 4 in plan.job_dev:
             dev, n = plan.job_dev[4]
             L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 4, 0, stream), 'rumpy_wgrad_grouped')
-        if plan.reduce_keep:
-            L.check(self.lib.rumpy_wgrad_reduce(_ptr(plan.reduce_dev_notail), len(plan.reduce_keep), stream), 'rumpy_wgrad_reduce')
-        tl = self.spec.tail
-        L.check(self.lib.rumpy_tail_wgrad_reduce(_ptr(plan.tail_wslab), plan.tail_slabs, tl.cout, float(plan.grad_scale), _ptr(tl.gw),
-                                                 _ptr(tl.gb), stream), 'rumpy_tail_wgrad_reduce')
+        self._reduce(plan, stream, plan.reduce_dev_notail, len(plan.reduce_keep), float(plan.grad_scale), tail=True, head=True)

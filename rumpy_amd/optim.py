@@ -96,12 +96,21 @@ class FlatAdam(torch.optim.Adam):
                 L.call('rumpy_sumsq', L.SumsqArgs(g=net.flat_g.data_ptr(), n=n, partial=self._sumsq_partial.data_ptr(),
                                                   out=self._sumsq.data_ptr()), stream)
                 sumsq = self._sumsq.data_ptr()
+            upd = getattr(net.engine, 'update_items', None)
+            if upd is not None:
+                # Adam AND the re-packing of the bf16 filter images in one launch (csrc/finish.hip): every parameter is an item of the table
+                L.call('rumpy_adam_pack', L.AdamPackArgs(items=upd[0].data_ptr(), nitems=upd[1], p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(),
+                                                         m=self.flat_m.data_ptr(), v=self.flat_v.data_ptr(),
+                                                         hyper=self._hyper_dev.data_ptr() if graphed else None, sumsq=sumsq, hyper_value=hv), stream)
+                return
             L.call('rumpy_adam_step', L.AdamArgs(p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(), m=self.flat_m.data_ptr(),
                                                  v=self.flat_v.data_ptr(), n=n, hyper=self._hyper_dev.data_ptr() if graphed else None,
                                                  sumsq=sumsq, hyper_value=hv), stream)      # eager: by value with the launch
             net.engine.repack(stream)
 
         net._ensure_engine()
+        if hasattr(net.engine, 'pack_gen'):
+            net.engine.pack_gen += 1          # new bf16 images: the fp16 images of the evaluation plans follow lazily (also under graph replays)
         if not getattr(net, 'use_graph', False):
             launches(torch.cuda.current_stream(dev).cuda_stream)
             net.mark_weights_clean()

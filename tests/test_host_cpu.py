@@ -59,6 +59,7 @@ def test_ctypes_structs_match_the_header_layout():
              'rumpy_sumsq_args': _lib.SumsqArgs, 'rumpy_eval_post_args': _lib.EvalPostArgs, 'rumpy_block_args': _lib.BlockArgs,
              'rumpy_ca_fwd_fused_args': _lib.CaFwdFusedArgs, 'rumpy_ca_bwd_fused_args': _lib.CaBwdFusedArgs,
              'rumpy_q_mlp_item': _lib.QMlpItem, 'rumpy_ssim_args': _lib.SsimArgs, 'rumpy_patch_item': _lib.PatchItem, 'rumpy_patch_args': _lib.PatchArgs,
+             'rumpy_finish_reduce_args': _lib.FinishReduceArgs, 'rumpy_update_item': _lib.UpdateItem, 'rumpy_adam_pack_args': _lib.AdamPackArgs,
              'rumpy_dconv_args': _lib.DconvArgs, 'rumpy_dconv_wgrad_args': _lib.DconvWgradArgs, 'rumpy_mse_args': _lib.MseArgs, 'rumpy_op': _lib.Op}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rumpy_amd.h"', 'int main(void){']
     for cname, st in pairs.items():

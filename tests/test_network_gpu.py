@@ -685,6 +685,38 @@ def test_bench_runs_over_rccl_with_one_rank(model):
     assert d['config']['loss'] == e['config']['loss'], (d['config']['loss'], e['config']['loss'])
 
 
+@pytest.mark.parametrize('name,kw,N,hw', [('edsr', dict(scale=4, num_blocks=3), 4, 24), ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16), 3, 20),
+                                         ('edsr', dict(scale=4), 32, 48)])
+def test_two_launch_housekeeping_is_bitwise_the_seven_launch_form(name, kw, N, hw, monkeypatch):
+    """csrc/finish.hip: one reduction launch for all slab kinds + Adam and re-pack in one launch (set-based, through LDS) against the separate
+    rumpy_wgrad_reduce / rumpy_tail_wgrad_reduce / head reduction / rumpy_adam_step / rumpy_pack_weights launches (RUMPY_NO_FINISH=1):
+    gradients, parameters, Adam moments and every packed filter image equal bit for bit over three steps (grad clipping on in step 3)."""
+    res = []
+    for no_finish in (True, False):
+        if no_finish:
+            monkeypatch.setenv('RUMPY_NO_FINISH', '1')
+        else:
+            monkeypatch.delenv('RUMPY_NO_FINISH', raising=False)
+        h, _ = _pair(name, 551, lr=1e-3, **kw)
+        losses = []
+        for step in range(3):
+            x, y = O.synthetic_batch(680 + step, N, lr_hw=hw, scale=kw['scale'])
+            h.grad_clip = 0.05 if step == 2 else None
+            loss, _ = h.run_train(x=x, y=y)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        eng = h.net.engine
+        assert (eng.update_items is None) == no_finish
+        packed = [t.clone() for cv in eng.spec.convs() for t in (cv.w_fwd, cv.w_dgrad, cv.b_packed) if t is not None]
+        res.append((losses, h.net.flat_g.clone(), h.net.flat_p.clone(), h.optimizer.flat_m.clone(), h.optimizer.flat_v.clone(), packed))
+    a, b = res
+    assert a[0] == b[0]
+    for i in (1, 2, 3, 4):
+        assert torch.equal(a[i], b[i]), ('flat_g', 'flat_p', 'flat_m', 'flat_v')[i - 1]
+    assert len(a[5]) == len(b[5]) and all(torch.equal(u.view(torch.int16) if u.dtype == torch.bfloat16 else u, v.view(torch.int16) if v.dtype == torch.bfloat16 else v)
+                                           for u, v in zip(a[5], b[5]))
+
+
 def test_bench_line_reports_what_the_collectives_ran_on():
     import json
     import subprocess
