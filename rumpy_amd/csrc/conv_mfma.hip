@@ -572,6 +572,7 @@ __global__ void nchw_to_nhwc4_kernel(const float* src, uint16_t* dst, int N, int
 // ------------------------------------------------------------------------------------------------------
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s);   // conv_strip.hip
+int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s);          // conv_up.hip
 
 extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->out) { rumpy_set_error("rumpy_conv3x3: null pointer"); return RUMPY_E_ARG; }
@@ -588,6 +589,11 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     hipStream_t s1 = (hipStream_t)stream;
     const int kid1 = (p->cout_tiles == 1 && p->cin_chunks == 1) ? 1 : 3;
     rumpy_probe_pre(kid1, s1);
+    // plain forward convs with several output tiles (the upsampler convs): conv_up.hip (output through LDS as whole non-temporal lines)
+    static const bool up_old = getenv("RUMPY_UP_OLD") != nullptr;      // A/B switch
+    if (!up_old && p->cin_chunks == 1 && p->cout_tiles > 1 && p->in_mode == 0 && !p->mask && !p->res1 && !p->res2 && !p->pool && !p->relu && p->scale == 1.0f)
+      rumpy_conv_up_launch(p, s1);
+    else
     rumpy_conv3x3_strip_launch(p, s1);
     rumpy_probe_post(kid1, s1);
     return rumpy_check_launch("rumpy_conv3x3");

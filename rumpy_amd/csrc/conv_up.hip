@@ -1,0 +1,145 @@
+// The upsampler convolutions (64 -> 256 + PixelShuffle, common.py:23-48 Upsampler) as their own kernel: conv3x3_strip_kernel's work split
+// (strip of 6 x 48 output pixels, wave (q, rh) = 16 output channels x 3 rows, filter slice stationary over a persistent loop of strips,
+// next strip's input prefetched through registers into the other LDS stage) on the block kernels' LDS image (unpadded 128-byte pixels, 16-byte
+// chunk index XOR pixel & 7: 51 KB per stage instead of 77) - which leaves room for the OUTPUT image of a strip (38 KB): the epilogue writes
+// its packed values there and the strip leaves as whole 128-byte lines with non-temporal stores, one piece after every third MFMA group of
+// the NEXT strip's sweep (block_common.hpp::strip_stage; conv_block.hip).  The MFMA epilogue's own layout would store 32-byte pieces of 32
+// lines per wave-instruction: 1.3 TB/s on the 151 MB of the second upsampler conv (tests/tools/kbench.py up), with or without the shuffle.
+#include "block_common.hpp"
+
+struct UpDev {
+  const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
+  int N, H, W, cout_tiles, out_mode, sx_n, sy_n;
+};
+constexpr int UPROWS = BSH + 2;                          // 8 input rows
+constexpr int UPSTAGE = UPROWS * BCOLS * 128;           // 51200
+constexpr int UPOUT = BSH * BCOLS * 128;                // 38400: output image, rows 0 .. 5, columns 1 .. 48 used
+constexpr int UPPIECES = UPROWS * BCOLS * 8;            // 3200
+constexpr int UPREGS = (UPPIECES + BTHREADS - 1) / BTHREADS;   // 7
+
+struct UpCoord { int n, sy, sx; };
+__device__ __forceinline__ UpCoord up_decode(int s, int sx_n, int sy_n) {
+  UpCoord c;
+  c.sx = s % sx_n;
+  const int r = s / sx_n;
+  c.sy = r % sy_n;
+  c.n = r / sy_n;
+  return c;
+}
+__device__ __forceinline__ void up_issue(uint4 (&R)[UPREGS], const uint16_t* __restrict__ x, UpCoord c, int H, int W, int tid) {
+  const int y0 = c.sy * BSH - 1, x0 = c.sx * BSW - 1;
+#pragma unroll
+  for (int i = 0; i < UPREGS; ++i) {
+    const int p = tid + BTHREADS * i;
+    const int pix = p >> 3, part = p & 7;
+    const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+    const int y = y0 + lr, xx = x0 + lc;
+    const bool ok = (p < UPPIECES) & ((unsigned)y < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+    const int e = ok ? ((c.n * H + y) * W + xx) * 64 + part * 8 : 0;
+    uint4 v = *reinterpret_cast<const uint4*>(x + (unsigned)e);      // unconditional (clamped address): the waits stay counted
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    R[i] = v;
+  }
+}
+__device__ __forceinline__ void up_write(const uint4 (&R)[UPREGS], unsigned char* stage, int tid) {
+#pragma unroll
+  for (int i = 0; i < UPREGS; ++i) {
+    const int p = tid + BTHREADS * i;
+    if (p < UPPIECES) *reinterpret_cast<uint4*>(stage + swz(p >> 3, p & 7)) = R[i];
+  }
+}
+// element offset of piece i of strip c in the output tensor (0xffffffff outside the image): plain [N,H,W,64*tiles] or pixel-shuffled [N,2H,2W,64]
+__device__ __forceinline__ unsigned up_piece_off(int i, int tid, UpCoord c, int ct, const UpDev& a) {
+  const int p = tid + BTHREADS * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+  const int y = c.sy * BSH + r, xx = c.sx * BSW + col;
+  if (!(p < STRIP_PIECES && y < a.H && xx < a.W)) return 0xffffffffu;
+  if (a.out_mode == 0) return (unsigned)(((c.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + (p & 7) * 8);
+  return (unsigned)(((c.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + (p & 7) * 8);
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * UPSTAGE + UPOUT];
+  unsigned char* const ldo = lds + 2 * UPSTAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int q = wave & 3, rh = wave >> 2;
+  const int ct = blockIdx.y;
+  const int nstrips = a.N * a.sy_n * a.sx_n;
+  int strip = xcd_strip(blockIdx.x, gridDim.x);
+  if (strip >= nstrips) return;
+  uint4 R[UPREGS];
+  up_issue(R, a.x, up_decode(strip, a.sx_n, a.sy_n), a.H, a.W, tid);
+  bf16x8 F[18];
+  {
+    const uint4* wp = a.w + ((size_t)(ct * 4 + q) * 18) * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+  }
+  const int c0 = 16 * q + 4 * g;
+  const int gpair = 4 * (g & ~1);
+  const int chunk8 = 2 * q + (gpair >> 3);
+  f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (a.bias) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + ct * 64 + c0); bias4 = (f32x4){b4.x, b4.y, b4.z, b4.w}; }
+  up_write(R, lds, tid);
+  __syncthreads();
+
+  int buf = 0;
+  for (; strip < nstrips; strip += gridDim.x) {
+    const UpCoord sc = up_decode(strip, a.sx_n, a.sy_n);
+    const bool has_next = strip + (int)gridDim.x < nstrips;
+    up_issue(R, a.x, up_decode(has_next ? strip + (int)gridDim.x : strip, a.sx_n, a.sy_n), a.H, a.W, tid);    // past the end: this strip again, unused
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = bias4;
+    unsigned off[8][2];
+    sweep_bases(off, (unsigned)(buf * UPSTAGE), 3 * rh, px, g);
+    block_sweep<3, FMT>(acc, F, lds, off);
+    if (has_next) up_write(R, lds + (buf ^ 1) * UPSTAGE, tid);
+    // epilogue: the packed values go to the output image in LDS (pairs k < 3: (row k, col tile 0 | 1); k = 3: (rows 0 | 1, col tile 2); single: (2, 2))
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][2];
+      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][2];
+      float v[8];
+      pair_up(tx, ty, g, v);
+      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+      const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+      *reinterpret_cast<uint4*>(ldo + swz((3 * rh + r) * BCOLS + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    *reinterpret_cast<uint2*>(ldo + swz((3 * rh + 2) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) =
+        pack4<FMT>(acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]);
+    __syncthreads();                      // output image and next input stage complete
+    {
+      uint4 S[STRIP_REGS];
+      strip_stage<0>(S, ldo, tid);
+#pragma unroll
+      for (int i = 0; i < STRIP_REGS; ++i) {
+        const unsigned o = up_piece_off(i, tid, sc, ct, a);
+        if (o != 0xffffffffu) st16_nt(a.out + o, S[i]);      // whole lines, non-temporal; they drain under the next strip's sweep
+      }
+    }
+    __syncthreads();                      // every wave has read its pieces: the next epilogue may overwrite the image
+    buf ^= 1;
+  }
+}
+
+int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s) {
+  UpDev d;
+  d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = (uint16_t*)p->out;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.cout_tiles = p->cout_tiles; d.out_mode = p->out_mode;
+  d.sx_n = (p->W + BSW - 1) / BSW; d.sy_n = (p->H + BSH - 1) / BSH;
+  const int nstrips = d.N * d.sx_n * d.sy_n;
+  int gx = p->grid_x;
+  if (gx <= 0) {
+    const int slots = rumpy_device_cus() / p->cout_tiles > 0 ? rumpy_device_cus() / p->cout_tiles : 1;
+    const int rounds = (nstrips + slots - 1) / slots;
+    gx = (nstrips + rounds - 1) / rounds;
+  }
+  if (gx > nstrips) gx = nstrips;
+  if (p->fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(conv_up_kernel<RUMPY_FMT_F16>, dim3(gx, p->cout_tiles), dim3(BTHREADS), 0, s, d);
+  else hipLaunchKernelGGL(conv_up_kernel<RUMPY_FMT_BF16>, dim3(gx, p->cout_tiles), dim3(BTHREADS), 0, s, d);
+  return 0;
+}

@@ -341,3 +341,22 @@ def rcab_bench(N=32, H=48, W=48, reps=40):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'rcab':
     rcab_bench()
+
+
+def up_bench():
+    """the upsampler convs (64 -> 256, PixelShuffle fused into the store) on the headline shapes, against the same conv with a plain [N,H,W,256] output"""
+    gen = np.random.default_rng(0)
+    pc = PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (256, 64, 3, 3)).astype(np.float32)), torch.zeros(256), shuffle=True)
+    for (N, H, W) in ((32, 48, 48), (32, 96, 96)):
+        x = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+        out = torch.empty(N, 2 * H, 2 * W, 64, dtype=BF16, device=DEV)
+        flop = 2.0 * N * H * W * 256 * 576
+        for mode in (1, 0):
+            a = L.ConvArgs(x=x.data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b_packed.data_ptr(), out=out.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=4,
+                           in_mode=0, out_mode=mode, relu=0, scale=1.0, grid_x=0)
+            us = time_fn(lambda: L.call('rumpy_conv3x3', a, stream()), iters=20)
+            print('conv 64->256 %s %dx%dx%d: %7.2f us  %6.1f TFLOP/s  output %.2f TB/s' % ('+ PixelShuffle' if mode else 'plain output ', N, H, W, us, flop / us / 1e6, out.numel() * 2 / us / 1e6))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'up':
+    up_bench()
