@@ -591,7 +591,8 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     rumpy_probe_pre(kid1, s1);
     // plain forward convs with several output tiles (the upsampler convs): conv_up.hip (output through LDS as whole non-temporal lines)
     static const bool up_old = getenv("RUMPY_UP_OLD") != nullptr;      // A/B switch
-    if (!up_old && p->cin_chunks == 1 && p->cout_tiles > 1 && p->in_mode == 0 && !p->mask && !p->res1 && !p->res2 && !p->pool && !p->relu && p->scale == 1.0f)
+    const char* up_force = getenv("RUMPY_UP_FORCE");                    // diagnostic (kbench.py up1): single-tile convs through conv_up too
+    if (!up_old && p->cin_chunks == 1 && (p->cout_tiles > 1 || (up_force && up_force[0] == '1')) && p->in_mode == 0 && !p->mask && !p->res1 && !p->res2 && !p->pool && !p->relu && p->scale == 1.0f)
       rumpy_conv_up_launch(p, s1);
     else
     rumpy_conv3x3_strip_launch(p, s1);

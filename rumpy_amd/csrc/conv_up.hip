@@ -7,6 +7,9 @@
 // lines per wave-instruction: 1.3 TB/s on the 151 MB of the second upsampler conv (tests/tools/kbench.py up), with or without the shuffle.
 #include "block_common.hpp"
 
+#ifndef UP_ABL
+#define UP_ABL 0      // 9: phase stamps of one iteration per wave behind the 256 bias values (diagnostic builds: tests/tools/build_abl.sh, kbench.py up)
+#endif
 struct UpDev {
   const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
   int N, H, W, cout_tiles, out_mode, sx_n, sy_n;
@@ -57,6 +60,15 @@ __device__ __forceinline__ unsigned up_piece_off(int i, int tid, UpCoord c, int 
   return (unsigned)(((c.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + (p & 7) * 8);
 }
 
+// the same for the 3 rows of a row half (block_common.hpp::group_stage): piece p = tg + 256 i
+__device__ __forceinline__ unsigned up_group_off(int i, int tg, int rh, UpCoord c, int ct, const UpDev& a) {
+  const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+  const int y = c.sy * BSH + 3 * rh + r, xx = c.sx * BSW + col;
+  if (!(p < GROUP_PIECES && y < a.H && xx < a.W)) return 0xffffffffu;
+  if (a.out_mode == 0) return (unsigned)(((c.n * a.H + y) * a.W + xx) * (64 * a.cout_tiles) + ct * 64 + (p & 7) * 8);
+  return (unsigned)(((c.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + (p & 7) * 8);
+}
+
 template <int FMT>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * UPSTAGE + UPOUT];
@@ -81,14 +93,37 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
   const int chunk8 = 2 * q + (gpair >> 3);
   f32x4 bias4 = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (a.bias) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + ct * 64 + c0); bias4 = (f32x4){b4.x, b4.y, b4.z, b4.w}; }
+  __shared__ unsigned gate[5];            // 0: waves that have written their share of an input stage; 1: waves that have finished a sweep;
+  if (tid < 5) gate[tid] = 0u;            // 2 + rh: waves of a row half that have written their output rows; 4: (spare)
+  __shared__ unsigned gate_rd[2];         // waves of a row half that have read their pieces of the output image back
+  if (tid < 2) gate_rd[tid] = 0u;
   up_write(R, lds, tid);
-  __syncthreads();
+  __syncthreads();                        // first stage + zeroed counters (the only workgroup barrier of the kernel)
+  const int rhu = __builtin_amdgcn_readfirstlane(rh), tg = tid & 255;
+  // the loads of the strip after the next one are issued BEFORE the stores of the current one (vector-memory operations return in issue
+  // order: a stage write must not wait behind 5 non-temporal stores).  Measured neutral: what an iteration really costs beside its 162 MFMAs
+  // per wave is the address arithmetic of loads / stores / LDS images (about 600 VALU instructions per wave and strip, issued beside the
+  // partner wave's MFMAs: stamps of tests/tools/kbench.py up with the UP_ABL=9 build)
+  {
+    const int s2 = strip + (int)gridDim.x;
+    up_issue(R, a.x, up_decode(s2 < nstrips ? s2 : strip, a.sx_n, a.sy_n), a.H, a.W, tid);
+  }
 
+  // Persistent loop WITHOUT workgroup barriers: the two row halves (waves 0-3 / 4-7) drift half an iteration apart - the older waves win the
+  // matrix pipe, finish their sweep first and run their stage write / epilogue / stores under the other half's sweep (block_common.hpp:
+  // row-half groups).  Every wait is for exactly what the next step touches:
+  //   input stage of strip k complete (all 8 waves wrote their pieces)          -> gate[0] >= 8 k        (k counts strips of this workgroup from 1)
+  //   both halves done with the sweep that read the stage about to be refilled  -> gate[1] >= 8 (k - 1)
+  //   this half's output rows of strip k complete                               -> gate[2 + rh] >= 4 k
+  //   this half's pieces of strip k - 1 read back (its rows may be overwritten) -> gate_rd[rh] >= 4 (k - 1)
   int buf = 0;
-  for (; strip < nstrips; strip += gridDim.x) {
+  unsigned k = 1;
+  unsigned long long stamps[10];
+  int nst = 0;
+#define UP_STAMP() do { if (UP_ABL == 9 && k == 5 && nst < 10) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  for (; strip < nstrips; strip += gridDim.x, ++k) {
     const UpCoord sc = up_decode(strip, a.sx_n, a.sy_n);
     const bool has_next = strip + (int)gridDim.x < nstrips;
-    up_issue(R, a.x, up_decode(has_next ? strip + (int)gridDim.x : strip, a.sx_n, a.sy_n), a.H, a.W, tid);    // past the end: this strip again, unused
     f32x4 acc[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -96,34 +131,60 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
       for (int c = 0; c < 3; ++c) acc[r][c] = bias4;
     unsigned off[8][2];
     sweep_bases(off, (unsigned)(buf * UPSTAGE), 3 * rh, px, g);
+    UP_STAMP();                                            // 0: iteration start
+    if (k > 1) gate_wait(&gate[0], 8u * (k - 1));          // (the first stage is behind the workgroup barrier)
+    UP_STAMP();                                            // 1: input stage complete
     block_sweep<3, FMT>(acc, F, lds, off);
-    if (has_next) up_write(R, lds + (buf ^ 1) * UPSTAGE, tid);
-    // epilogue: the packed values go to the output image in LDS (pairs k < 3: (row k, col tile 0 | 1); k = 3: (rows 0 | 1, col tile 2); single: (2, 2))
+    UP_STAMP();                                            // 2: sweep done
+    gate_arrive(&gate[1], lane);
+    if (has_next) {
+      gate_wait(&gate[1], 8u * (k - 1));                   // nobody sweeps over the other stage any more
+      UP_STAMP();                                          // (3a) other stage free
+      up_write(R, lds + (buf ^ 1) * UPSTAGE, tid);
+      gate_arrive(&gate[0], lane);
+      UP_STAMP();                                          // (3b) stage written
+    }
+    {   // the strip after the next one (past the end: this strip again, unused): issued on every path, before this strip's stores
+      const int s2 = strip + 2 * (int)gridDim.x;
+      up_issue(R, a.x, up_decode(s2 < nstrips ? s2 : strip, a.sx_n, a.sy_n), a.H, a.W, tid);
+    }
+    UP_STAMP();                                            // 3: next stage written, loads issued
+    // epilogue: the packed values go to this half's rows of the output image (pairs k < 3: (row k, col tile 0 | 1); 3: (rows 0 | 1, col tile 2); single: (2, 2))
+    gate_wait(&gate_rd[rhu], 4u * (k - 1));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][2];
-      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][2];
+    for (int kk = 0; kk < 4; ++kk) {
+      const f32x4 tx = (kk < 3) ? acc[kk < 3 ? kk : 0][0] : acc[0][2];
+      const f32x4 ty = (kk < 3) ? acc[kk < 3 ? kk : 0][1] : acc[1][2];
       float v[8];
       pair_up(tx, ty, g, v);
-      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+      const int r = (kk < 3) ? kk : (g & 1), c = (kk < 3) ? (g & 1) : 2;
       const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
       *reinterpret_cast<uint4*>(ldo + swz((3 * rh + r) * BCOLS + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
     *reinterpret_cast<uint2*>(ldo + swz((3 * rh + 2) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) =
         pack4<FMT>(acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]);
-    __syncthreads();                      // output image and next input stage complete
+    UP_STAMP();                                            // 4: epilogue done
+    gate_arrive(&gate[2 + rhu], lane);
+    gate_wait(&gate[2 + rhu], 4u * k);
+    UP_STAMP();                                            // 5: this half's output rows complete
     {
-      uint4 S[STRIP_REGS];
-      strip_stage<0>(S, ldo, tid);
+      uint4 S[GROUP_REGS];
+      group_stage<0>(S, ldo, tg, rhu);
 #pragma unroll
-      for (int i = 0; i < STRIP_REGS; ++i) {
-        const unsigned o = up_piece_off(i, tid, sc, ct, a);
-        if (o != 0xffffffffu) st16_nt(a.out + o, S[i]);      // whole lines, non-temporal; they drain under the next strip's sweep
+      for (int i = 0; i < GROUP_REGS; ++i) {
+        const unsigned o = up_group_off(i, tg, rhu, sc, ct, a);
+        if (o != 0xffffffffu) st16_nt(a.out + o, S[i]);      // whole lines, non-temporal; they drain under the sweeps
       }
     }
-    __syncthreads();                      // every wave has read its pieces: the next epilogue may overwrite the image
+    gate_arrive(&gate_rd[rhu], lane);     // (release: behind the reads above)
+    UP_STAMP();                                            // 6: stores issued
     buf ^= 1;
   }
+  if (UP_ABL == 9 && lane == 0 && a.bias) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias) + 256) + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16;
+    for (int i = 0; i < 10; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
+  }
+#undef UP_STAMP
 }
 
 int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s) {

@@ -347,6 +347,11 @@ def up_bench():
     """the upsampler convs (64 -> 256, PixelShuffle fused into the store) on the headline shapes, against the same conv with a plain [N,H,W,256] output"""
     gen = np.random.default_rng(0)
     pc = PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (256, 64, 3, 3)).astype(np.float32)), torch.zeros(256), shuffle=True)
+    stamped = 'UP_ABL_9' in os.environ.get('RUMPY_AMD_LIB', '')
+    if stamped:        # the stamp build writes [workgroup][wave][8] u64 behind the 256 bias values
+        big = torch.zeros(256 + 2 * 256 * 8 * 16, dtype=torch.float32, device=DEV)
+        big[:256] = pc.b_packed
+        pc.b_packed = big
     for (N, H, W) in ((32, 48, 48), (32, 96, 96)):
         x = torch.randn(N, H, W, 64, device=DEV).to(BF16)
         out = torch.empty(N, 2 * H, 2 * W, 64, dtype=BF16, device=DEV)
@@ -356,7 +361,33 @@ def up_bench():
                            in_mode=0, out_mode=mode, relu=0, scale=1.0, grid_x=0)
             us = time_fn(lambda: L.call('rumpy_conv3x3', a, stream()), iters=20)
             print('conv 64->256 %s %dx%dx%d: %7.2f us  %6.1f TFLOP/s  output %.2f TB/s' % ('+ PixelShuffle' if mode else 'plain output ', N, H, W, us, flop / us / 1e6, out.numel() * 2 / us / 1e6))
+            if stamped and mode == 1 and H == 96:
+                torch.cuda.synchronize()
+                raw = pc.b_packed[256:].cpu().numpy().view(np.uint64).reshape(-1, 8, 16)[:, :, :10].astype(np.float64)
+                raw = raw[raw[:, 0, 0] > 0]
+                rel = (raw - raw[:, :, :1]) * 0.01
+                print('   iteration 5, us from its start: rh=0: ' + ' '.join('%.2f' % v for v in rel[:, :4, :10].mean((0, 1))) + ' | rh=1: ' + ' '.join('%.2f' % v for v in rel[:, 4:, :10].mean((0, 1))))
+                print('   rh=1 starts %.2f us after rh=0' % ((raw[:, 4:, 0].mean(1) - raw[:, :4, 0].mean(1)).mean() * 0.01))
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'up':
     up_bench()
+
+
+def up1_bench():
+    """write-pattern probe: conv_up_kernel on a 64 -> 64 conv (ONE output tile: contiguous lines) at 32x192x192 - the output volume of the second upsampler conv"""
+    gen = np.random.default_rng(0)
+    pc = PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32)), torch.zeros(64))
+    N, H, W = 32, 192, 192
+    x = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    out = torch.empty(N, H, W, 64, dtype=BF16, device=DEV)
+    a = L.ConvArgs(x=x.data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b_packed.data_ptr(), out=out.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1,
+                   in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0)
+    for env in ('0', '1'):
+        os.environ['RUMPY_UP_FORCE'] = env
+        us = time_fn(lambda: L.call('rumpy_conv3x3', a, stream()), iters=10)
+        print('conv 64->64 32x192x192 (%s): %7.2f us  %6.1f TFLOP/s  output %.2f TB/s' % ('conv_up_kernel' if env == '1' else 'strip kernel', us, 2.0 * N * H * W * 64 * 576 / us / 1e6, out.numel() * 2 / us / 1e6))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'up1':
+    up1_bench()
