@@ -590,9 +590,13 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     const int kid1 = (p->cout_tiles == 1 && p->cin_chunks == 1) ? 1 : 3;
     rumpy_probe_pre(kid1, s1);
     // plain forward convs with several output tiles (the upsampler convs): conv_up.hip (output through LDS as whole non-temporal lines)
-    static const bool up_old = getenv("RUMPY_UP_OLD") != nullptr;      // A/B switch
-    const char* up_force = getenv("RUMPY_UP_FORCE");                    // diagnostic (kbench.py up1): single-tile convs through conv_up too
-    if (!up_old && p->cin_chunks == 1 && (p->cout_tiles > 1 || (up_force && up_force[0] == '1')) && p->in_mode == 0 && !p->mask && !p->res1 && !p->res2 && !p->pool && !p->relu && p->scale == 1.0f)
+    const bool up_old = getenv("RUMPY_UP_OLD") != nullptr;             // A/B switch (read per call: the tests toggle it)
+    // conv_up.hip (output through LDS as whole non-temporal lines) takes every Cin = 64 launch without ReLU mask / pool sums that runs more
+    // than one strip per workgroup or several output tiles: the upsampler convs, and all plain layers of a whole-image evaluation
+    const int up_strips = p->N * cdiv(p->H, 6) * cdiv(p->W, 48);
+    const char* up_force = getenv("RUMPY_UP_FORCE");                    // diagnostic (kbench.py up1): "1" = every eligible launch, "0" = multi-tile ones only
+    const bool up_many = up_force ? up_force[0] == '1' : up_strips > rumpy_device_cus();
+    if (!up_old && p->cin_chunks == 1 && (p->cout_tiles > 1 || up_many) && p->in_mode == 0 && !p->mask && !p->pool && (p->out_mode == 0 || (!p->res1 && !p->res2)))
       rumpy_conv_up_launch(p, s1);
     else
     rumpy_conv3x3_strip_launch(p, s1);

@@ -12,7 +12,8 @@
 #endif
 struct UpDev {
   const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
-  int N, H, W, cout_tiles, out_mode, sx_n, sy_n;
+  const uint16_t* res1; const uint16_t* res2;      // optional residual operands, layout of out (out_mode 0)
+  int N, H, W, cout_tiles, out_mode, sx_n, sy_n, relu; float scale;
 };
 constexpr int UPROWS = BSH + 2;                          // 8 input rows
 constexpr int UPSTAGE = UPROWS * BCOLS * 128;           // 51200
@@ -151,6 +152,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
     UP_STAMP();                                            // 3: next stage written, loads issued
     // epilogue: the packed values go to this half's rows of the output image (pairs k < 3: (row k, col tile 0 | 1); 3: (rows 0 | 1, col tile 2); single: (2, 2))
     gate_wait(&gate_rd[rhu], 4u * (k - 1));
+    const bool post = a.relu || a.scale != 1.0f || a.res1 || a.res2;      // uniform: the upsampler convs skip all of it
+    auto own = [&](float x) -> float { if (a.relu) x = relu_f32(x); return x * a.scale; };
+    auto res_off = [&](int r, int xx, int ch) -> unsigned {                 // element offset in a residual tensor, 0xffffffff outside the image
+      const int y = sc.sy * BSH + 3 * rh + r, xg = sc.sx * BSW + xx;
+      return (y < a.H && xg < a.W) ? (unsigned)(((sc.n * a.H + y) * a.W + xg) * (64 * a.cout_tiles) + ct * 64 + ch) : 0xffffffffu;
+    };
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const f32x4 tx = (kk < 3) ? acc[kk < 3 ? kk : 0][0] : acc[0][2];
@@ -158,11 +165,49 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
       float v[8];
       pair_up(tx, ty, g, v);
       const int r = (kk < 3) ? kk : (g & 1), c = (kk < 3) ? (g & 1) : 2;
+      if (post) {
+        const unsigned o = res_off(r, 16 * c + px, 16 * q + gpair);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = own(v[j]);
+        if (o != 0xffffffffu) {
+          float m[8];
+          if (a.res1) {
+            unpack8<FMT>(*reinterpret_cast<const uint4*>(a.res1 + o), m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += m[j];
+          }
+          if (a.res2) {
+            unpack8<FMT>(*reinterpret_cast<const uint4*>(a.res2 + o), m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += m[j];
+          }
+        }
+      }
       const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
       *reinterpret_cast<uint4*>(ldo + swz((3 * rh + r) * BCOLS + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
-    *reinterpret_cast<uint2*>(ldo + swz((3 * rh + 2) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) =
-        pack4<FMT>(acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]);
+    {
+      float v[4] = {acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]};
+      if (post) {
+        const unsigned o = res_off(2, 32 + px, c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = own(v[j]);
+        if (o != 0xffffffffu) {
+          float m[4];
+          if (a.res1) {
+            unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res1 + o), m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += m[j];
+          }
+          if (a.res2) {
+            unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res2 + o), m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += m[j];
+          }
+        }
+      }
+      *reinterpret_cast<uint2*>(ldo + swz((3 * rh + 2) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(v[0], v[1], v[2], v[3]);
+    }
     UP_STAMP();                                            // 4: epilogue done
     gate_arrive(&gate[2 + rhu], lane);
     gate_wait(&gate[2 + rhu], 4u * k);
@@ -190,6 +235,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
 int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s) {
   UpDev d;
   d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = (uint16_t*)p->out;
+  d.res1 = (const uint16_t*)p->res1; d.res2 = (const uint16_t*)p->res2; d.relu = p->relu; d.scale = p->scale;
   d.N = p->N; d.H = p->H; d.W = p->W; d.cout_tiles = p->cout_tiles; d.out_mode = p->out_mode;
   d.sx_n = (p->W + BSW - 1) / BSW; d.sy_n = (p->H + BSH - 1) / BSH;
   const int nstrips = d.N * d.sx_n * d.sy_n;

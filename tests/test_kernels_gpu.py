@@ -122,6 +122,31 @@ def test_conv3x3_epilogue_relu_scale_residuals_mask_pool():
     assert_bf16_close(nchw(o), conv + bf16r(r1), 'pool+res output')
 
 
+def test_conv_up_kernel_is_bitwise_the_strip_kernel(monkeypatch):
+    """conv_up.hip (output image in LDS -> whole non-temporal lines; what large launches without mask / pool sums use) against conv_strip.hip on
+    the same launches: plain, ReLU + scale + two residual operands, several output tiles, PixelShuffle - ragged sizes, several strips per workgroup"""
+    gen = np.random.default_rng(31)
+    for (N, H, W, co) in ((3, 20, 100, 64), (2, 13, 37, 128), (1, 50, 49, 64)):
+        w = torch.from_numpy(gen.uniform(-0.05, 0.05, (co, 64, 3, 3)).astype(np.float32))
+        b = torch.from_numpy(gen.uniform(-0.1, 0.1, (co,)).astype(np.float32))
+        pc = PackedConv(w, b)
+        x = nhwc(_rand(gen, N, 64, H, W))
+        r1, r2 = nhwc(_rand(gen, N, co, H, W)), nhwc(_rand(gen, N, co, H, W))
+        outs = []
+        for force in ('0', '1'):
+            monkeypatch.setenv('RUMPY_UP_FORCE', force)
+            if co == 128:
+                monkeypatch.setenv('RUMPY_UP_OLD' if force == '0' else 'RUMPY_UP_XX', '1')       # multi-tile launches use conv_up by default
+            o1, _ = hip_conv(x, pc, N, H, W, grid_x=3)
+            o2, _ = hip_conv(x, pc, N, H, W, relu=True, scale=0.3, res1=r1, res2=r2, grid_x=5)
+            outs.append((o1, o2))
+            monkeypatch.delenv('RUMPY_UP_OLD', raising=False)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (N, H, W, co)
+        ref = F.conv2d(bf16r(nchw(x)), bf16r(w), b, padding=1)
+        assert_bf16_close(nchw(outs[1][0]), ref, 'conv_up plain')
+    monkeypatch.delenv('RUMPY_UP_FORCE', raising=False)
+
+
 def test_conv3x3_upsampler_forward_pixel_shuffle_fused():
     gen = np.random.default_rng(13)
     N, H, W = 2, 11, 19

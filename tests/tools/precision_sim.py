@@ -148,3 +148,53 @@ def grad_report(name='rcan', seed=522, N=2, hw=48, **kw):
         print('%s N=%d %dx%d, gradient trunk %s: whole-gradient rel %.3e, median %.3e, worst %s' % (
             name, N, hw, hw, 'bf16' if tb else 'fp32', float((allg - allr).norm() / allr.norm()), float(np.median([r[0] for r in rows])),
             ', '.join('%s %.2e' % (k, r) for r, k in rows[:3])))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# fp8 (BASELINE config 5 names "fp8 MFMA conv"): what e4m3 operands would cost the evaluation PSNR of the G18 model
+def fp8_report():
+    """python -c "import sys; sys.path.insert(0, 'tests/tools'); import precision_sim as P; P.fp8_report()" """
+    global rb
+
+    def f8(t):      # e4m3 with a per-tensor power-of-two scale (amax -> below 240)
+        a = float(t.abs().max())
+        if a == 0:
+            return t
+        sc = 2.0 ** np.floor(np.log2(240.0 / a))
+        return (t * sc).to(torch.float8_e4m3fn).float() / sc
+
+    def h16(t):
+        return t.to(torch.float16).float()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'golden', 'g18_rcan_psnr.npz'))
+    to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.)[None]
+    lt, ht = to_t(g['lr']), to_t(g['hr'])
+    net = O.build_oracle('rcan', scale=4)
+    net.load_state_dict(O.interpolating_state_dict(net, 502))
+    with torch.no_grad():
+        ref = net(lt)
+    hy = O.rgb_to_ycbcr_jpg(O.clip01(ht.numpy())[0])
+    yp = lambda o: O.psnr(O.rgb_to_ycbcr_jpg(O.clip01(o.numpy())[0])[0], hy[0])
+    keep, rb = rb, f8
+    o = sim_forward(net, lt, 'bf16')
+    rb = keep
+    print('G18 RCAN, e4m3 storage + MFMA operands everywhere (per-tensor scale): self-PSNR %.2f dB, dPSNR %+.3f dB (reference %.2f dB)'
+          % (self_psnr(o, ref), yp(o) - yp(ref), yp(ref)))
+    with torch.no_grad():
+        c8 = lambda x, m: F.conv2d(f8(x), f8(m.weight), m.bias, padding=1)
+        c16 = lambda x, m: F.conv2d(h16(x), h16(m.weight), m.bias, padding=1)
+        a0 = h16(F.conv2d(lt, net.head[0].weight, net.head[0].bias, padding=1))
+        cur = a0
+        body = list(net.body)
+        for m in body[:-1]:
+            gin = cur
+            for b in list(m.body)[:-1]:
+                t1 = f8(F.relu(c8(cur, b.body[0])))
+                t2 = c8(t1, b.body[2])
+                cur = h16(cur + b.body[3].conv_du(t2.mean((2, 3), keepdim=True)) * t2)
+            cur = h16(c16(cur, m.body[-1]) + gin)
+        u = h16(c16(cur, body[-1]) + a0)
+        for m in net.tail[0]:
+            u = h16(c16(u, m)) if isinstance(m, torch.nn.Conv2d) else m(u)
+        o = c16(u, net.tail[1])
+    print('G18 RCAN, e4m3 MFMA operands inside the RCABs only, fp16 trunk / upsampler / tail: self-PSNR %.2f dB, dPSNR %+.3f dB'
+          % (self_psnr(o, ref), yp(o) - yp(ref)))
