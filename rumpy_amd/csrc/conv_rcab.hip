@@ -553,8 +553,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
   }
   RC_STAMP();                              // end (stores issued)
-  if (RCAB_ABL == 9 && tid == 0 && a.t) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.t) + (size_t)strip * 16;
+  if (RCAB_ABL == 9 && lane == 0) {       // stamp build: [strip][wave][16] u64 behind the first 16 words of the status buffer (kbench.py rcab)
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.status + 16) + ((size_t)strip * 8 + wave) * 16;
     for (int i = 0; i < 10; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
   }
 }

@@ -317,7 +317,8 @@ def rcab_bench(N=32, H=48, W=48, reps=40):
     x, t1, t2, out, dy, dt1, dt2, dx = (act() for _ in range(8))
     mean, hid, gate, dz = torch.zeros(N, 64, device=DEV), torch.zeros(N, 4, device=DEV), torch.zeros(N, 64, device=DEV), torch.zeros(N, 64, device=DEV)
     xchg = torch.zeros(int(L.lib().rumpy_rcab_xchg_bytes(N, H)), dtype=torch.uint8, device=DEV)
-    epoch, status = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    nst = N * ((H + 5) // 6)
+    epoch, status = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(16 + nst * 8 * 16 * 2, dtype=torch.int32, device=DEV)   # + stamps of a RCAB_ABL=9 build
     common = dict(N=N, H=H, W=W, cr=4, ca_w1=cw1.data_ptr(), ca_b1=cb1.data_ptr(), ca_w2=cw2.data_ptr(), ca_b2=cb2.data_ptr(), hidden=hid.data_ptr(),
                   gate=gate.data_ptr(), xchg=xchg.data_ptr(), xchg_bytes=xchg.numel(), epoch=epoch.data_ptr(), status=status.data_ptr())
     fwd = L.RcabArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
@@ -330,13 +331,13 @@ def rcab_bench(N=32, H=48, W=48, reps=40):
             for _ in range(reps):
                 L.call(fn, a, stream())
         us = time_fn(run, iters=5, warm=2) / reps
-        print('rcab %s %dx%dx%d: %.2f us per launch, status %d' % (name, N, H, W, us, int(status.item())))
+        print('rcab %s %dx%dx%d: %.2f us per launch, status %d' % (name, N, H, W, us, int(status[0].item())))
         if 'RCAB_ABL_9' in os.environ.get('RUMPY_AMD_LIB', ''):
-            raw = tbuf.view(torch.int16).flatten()[:N * ((H + 5) // 6) * 64].cpu().numpy().view(np.uint64).reshape(-1, 16)[:, :10].astype(np.float64)
-            k = int((raw[0] > 0).sum())
-            rel = (raw[:, :k] - raw[:, :1]) * 0.01          # s_memrealtime: 100 MHz
-            print('   stamps (us from workgroup start, mean over workgroups):', ' '.join('%.2f' % v for v in rel.mean(0)))
-            print('   workgroup start spread %.2f us, end spread %.2f us' % ((raw[:, 0].max() - raw[:, 0].min()) * 0.01, (raw[:, k - 1].max() - raw[:, k - 1].min()) * 0.01))
+            raw = status[16:].cpu().numpy().view(np.uint64).reshape(nst, 8, 16)[:, :, :10].astype(np.float64)
+            k = int((raw[0, 0] > 0).sum())
+            rel = (raw[:, :, :k] - raw[:, :, :1]) * 0.01          # s_memrealtime: 100 MHz
+            print('   stamps, us from each wave\'s start: rh=0: ' + ' '.join('%.2f' % v for v in rel[:, :4].mean((0, 1))) + ' | rh=1: ' + ' '.join('%.2f' % v for v in rel[:, 4:].mean((0, 1))))
+            print('   wave start spread %.2f us; last end - first start %.2f us' % ((raw[:, :, 0].max() - raw[:, :, 0].min()) * 0.01, (raw[:, :, k - 1].max() - raw[:, :, 0].min()) * 0.01))
 
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'rcab':
