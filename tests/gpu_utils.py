@@ -30,6 +30,16 @@ class BlockChainArgs(L._S):
 _exp = None
 
 
+class ChainBlock(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w1', C.c_void_p), ('b1', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p), ('res2', C.c_void_p),
+                ('t', C.c_void_p), ('out', C.c_void_p), ('maskbits', C.c_void_p), ('scale1', C.c_float), ('scale2', C.c_float)]
+
+
+class BodyChainArgs(C.Structure):
+    _fields_ = [('blocks', C.c_void_p), ('nblocks', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('backward', C.c_int32),
+                ('fmt', C.c_int32), ('flags', C.c_void_p), ('epoch', C.c_void_p), ('status', C.c_void_p)]
+
+
 def exp_lib():
     """ctypes handle of the experimental library (built by __graft_entry__.build() / make -C tests/tools/csrc)"""
     global _exp
@@ -39,6 +49,8 @@ def exp_lib():
         h = C.CDLL(path)
         for name, res, args in (('rumpy_conv_chain', C.c_int, [C.POINTER(ChainArgs), C.c_void_p]), ('rumpy_conv_chain_xchg_bytes', C.c_int64, [C.c_int32]),
                                 ('rumpy_block_chain', C.c_int, [C.POINTER(BlockChainArgs), C.c_void_p]), ('rumpy_block_chain_xchg_bytes', C.c_int64, [C.c_int32]),
+                                ('rumpy_body_chain', C.c_int, [C.POINTER(BodyChainArgs), C.c_void_p]),
+                                ('rumpy_body_chain_flag_bytes', C.c_int64, [C.c_int32, C.c_int32]),
                                 ('rumpy_last_error', C.c_char_p, [])):
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args

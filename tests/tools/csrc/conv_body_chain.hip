@@ -1,0 +1,348 @@
+// The EDSR body (a chain of residual blocks, forward or data-gradient direction) in ONE persistent launch: conv_block.hip's block with the
+// strip resident in LDS from block to block.
+//
+// Per-block launches pay, per block: the launch gap (1.3-1.5 us), the load of the 10-row input tile (2.65 us until the first MFMA) and the
+// wave start / end spread.  Here a workgroup keeps its strip (6 rows x <= 48 columns of one image) for the whole chain: a block's OUT is written in
+// place over the input image's centre rows (as conv_block.hip already does for its whole-line stores) and IS the next block's input; only the
+// two rows above and below come from the vertical neighbours - read back from the OUT tensor the neighbour has just stored:
+//   * OUT rows leave as whole lines with WRITE-THROUGH stores (sc1: visible to every XCD once acknowledged; with whole lines they cost what the
+//     non-temporal stores of conv_block.hip cost), the row half's four waves wait for their acknowledgements (s_waitcnt vmcnt(0), behind the
+//     halo-free half of the next block's first sweep), then ONE lane publishes {launch epoch, block index} in the strip's flag word (sc1);
+//   * the neighbour polls that word (sc1 loads) before the halo-dependent half of its first sweep and fetches the two rows with sc1 loads.
+// Placement-independent (no same-XCD assumption), no fences.  Row halves synchronise through LDS counters only (block_common.hpp): there is
+// no workgroup barrier inside the loop.  Needs every strip co-resident (N * ceil(H/6) <= CUs, one 512-thread workgroup per CU) and nothing else
+// occupying CUs; a poll that does not complete within ~0.1 s stores a code in *status and the host falls back to per-block launches.
+//
+// The first conv of a block is swept in two halves: T rows that need no halo row first (row half 0: T rows 2, 3 from input rows 2 .. 5; row
+// half 1: T rows 4, 5 from rows 4 .. 7), then - halo rows in LDS - T rows 0, 1 / 6, 7.  Everything else is conv_block.hip (forms 1 and 3).
+#include "block_common.hpp"
+#include "rumpy_experimental.h"
+
+#ifndef CHAIN_ABL
+#define CHAIN_ABL 0   // timing only (WRONG results): 1 = no flag wait / halo rows, 2 = 1 + OUT stored non-temporal, 3 = 1 + no T stores, 4 = all three; 9 = phase stamps of the middle block, per wave, behind the flag words (tests/tools/chain_stamps.py)
+#endif
+#define CHAIN_STAMPS (CHAIN_ABL >= 9)   // 9 = stamps; 10 + v = stamps with ablation v
+#define CHAIN_CUT (CHAIN_ABL >= 10 ? CHAIN_ABL - 10 : CHAIN_ABL)
+struct ChainBlk {
+  const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
+  const uint16_t* res2; uint16_t* t; uint16_t* out; unsigned char* mbits; float scale1, scale2;
+};
+struct ChainDev { const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* flags; const unsigned* epoch; unsigned* status; };
+constexpr unsigned CH_SPIN = 1u << 20;
+typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ch_store16_sc1(uint16_t* p, uint4 v) {
+  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");   // s_nop: the >64-bit store data hazard is ours inside asm
+}
+__device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
+  ch_u32x4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory");
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
+
+// FORM 1: forward (ReLU, mask bytes written if given); FORM 3: data gradient (* scale1, mask bytes read)
+template <int FORM, int FMT = RUMPY_FMT_BF16>
+__global__ void __launch_bounds__(BTHREADS, 2) body_chain_kernel(ChainDev a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  __shared__ unsigned gate[8];             // per row half: T rows written [0,1], OUT rows written [2,3], halo rows in LDS [4,5], stores acknowledged [6,7]
+  unsigned char* const ldx = lds;
+  unsigned char* const ldt = lds + BXBYTES;
+  const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = wave & 3, rh = wave >> 2;
+  const int strip = xcd_strip(blockIdx.x, gridDim.x);
+  const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+  const bool has_nb = (rh == 0) ? (sy > 0) : (sy + 1 < a.sy_n);
+  const int nb_strip = (rh == 0) ? strip - 1 : strip + 1;
+  const unsigned epoch = *a.epoch;
+  const ChainBlk b0 = a.blk[0];
+
+  // ---- block 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (conv_block.hip) ----
+  {
+    uint4 R[BREGS];
+    const int y0 = sy * BSH - 2;
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+      const int y = y0 + lr, x = lc - 1;
+      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
+      uint4 v = *reinterpret_cast<const uint4*>(b0.x + (unsigned)e);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      R[i] = v;
+    }
+    if (tid < 8) gate[tid] = 0u;
+    if (tid < BTROWS * 2 * 8) {            // border columns of the T image: convB's zero padding, never written by the epilogues
+      const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
+      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+    }
+  }
+  bf16x8 F[18];
+  {
+    const uint4* wp = b0.w1 + (size_t)q * 18 * 64 + lane0;
+#pragma unroll
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+  }
+  __syncthreads();
+
+  unsigned long long stamps[16];
+  int nst = 0;
+#define CH_STAMP() do { if (CHAIN_STAMPS && b == a.nblk / 2 && nst < 16) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  for (int b = 0; b < a.nblk; ++b) {
+    const ChainBlk blk = a.blk[b];
+    CH_STAMP();                                          // 0: block start
+    if (CHAIN_STAMPS && b == a.nblk / 2) stamps[12] = __builtin_amdgcn_s_memtime();
+    // Lane geometry is recomputed per block from an opaque copy of the lane id: hoisted out of the loop it would hold ~100 VGPRs for the
+    // whole chain (the sweeps' read bases alone are 5 x 16) and spill; per block it is ~150 VALU instructions.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int px = lane & 15, g = lane >> 4, tg = 64 * q + lane;
+    const int c0 = 16 * q + 4 * g;
+    const int gpair = 4 * (g & ~1);
+    const int chunk8 = 2 * q + (gpair >> 3);
+    // lane geometry that does not change from block to block: offsets of the T pairs and of this thread's store pieces in a [N,H,W,64] tensor
+    unsigned moff[6], soff[GROUP_REGS];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+      const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+      const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
+      moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < GROUP_REGS; ++i) soff[i] = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+    // halo pieces of this row half: 2 rows x 48 columns x 8 chunks = 768 = 3 per thread; rows 6sy-2, 6sy-1 (half 0) or 6sy+6, 6sy+7 (half 1)
+    unsigned hoff[3], hlds[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+      const int y = (rh == 0) ? sy * BSH - 2 + r : sy * BSH + BSH + r;
+      hoff[i] = (has_nb && (unsigned)y < (unsigned)a.H && col < a.W) ? (unsigned)(((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+      hlds[i] = swz(((rh == 0) ? r : BSH + 2 + r) * BCOLS + col + 1, p & 7);
+    }
+    const unsigned done = 4u * (unsigned)b;              // gate counts at the end of block b - 1
+    unsigned MB[FORM == 3 ? 6 : 1];
+    if (FORM == 3) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) MB[FORM == 3 ? k : 0] = blk.mbits[(moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3];
+    }
+    f32x4 acc[4][3];                                     // wave row jr (T row 4rh + jr)
+    {
+      f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (blk.b1) { const float4 t = *reinterpret_cast<const float4*>(blk.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    }
+    unsigned off[8][2];
+    if (b == 0) {
+      sweep_bases(off, 0u, 4 * rh, px, g);
+      block_sweep<4, FMT>(acc, F, lds, off);
+    } else {
+      // (a) the two T rows that need no halo row: row half 0 -> T rows 2, 3 (wave rows 2, 3); row half 1 -> T rows 4, 5 (wave rows 0, 1)
+      gate_wait(&gate[2], done);
+      gate_wait(&gate[3], done);                         // both halves' OUT rows of block b - 1 are in LDS (and nobody reads the old T image)
+      CH_STAMP();                                        // 1: input rows complete
+      sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
+      CH_STAMP();                                        // 2: halo-free sweep done
+      // (b) publish block b - 1: this wave's OUT stores are acknowledged -> count in -> one lane stores the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CH_STAMP();                                        // 3: stores acknowledged
+      gate_arrive(&gate[6 + rh], lane);
+      if (q == 0) {
+        gate_wait(&gate[6 + rh], done);
+        if (lane == 0) __hip_atomic_store(a.flags + 2 * strip + rh, (epoch << 8) + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // (c) the neighbour's two rows: poll its flag, fetch, write to the halo rows of the input image
+      if (has_nb && !(CHAIN_CUT >= 1 && CHAIN_CUT <= 4)) {
+        const unsigned want = (epoch << 8) + (unsigned)b;
+        unsigned spins = 0;
+        for (;;) {
+          const unsigned f = __hip_atomic_load(a.flags + 2 * nb_strip + (1 - rh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f >> 8) == epoch && (f & 0xffu) >= (want & 0xffu)) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + (unsigned)b); break; }
+        }
+      }
+      CH_STAMP();                                        // 4: neighbour's flag seen
+      uint4 Hr[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (CHAIN_CUT >= 1 && CHAIN_CUT <= 4) Hr[i] = make_uint4(0, 0, 0, 0); else Hr[i] = ch_load16_sc1(blk.x + (hoff[i] != 0xffffffffu ? hoff[i] : 0u));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (hoff[i] != 0xffffffffu) *reinterpret_cast<uint4*>(ldx + hlds[i]) = Hr[i];
+      CH_STAMP();                                        // 5: halo rows loaded
+      gate_arrive(&gate[4 + rh], lane);
+      gate_wait(&gate[4 + rh], done);
+      CH_STAMP();                                        // 6: halo rows of the row half in LDS
+      // (d) the two T rows that do: row half 0 -> T rows 0, 1 (input rows 0 .. 3); row half 1 -> T rows 6, 7 (input rows 6 .. 9)
+      sweep_bases(off, 0u, (rh == 0) ? 0 : 6, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 0 : 2]), F, lds, off);
+    }
+    CH_STAMP();                                          // 7 (1 in block 0): first conv swept
+    // second filter: L2 hits that land under the epilogue
+    {
+      const uint4* wp = blk.w2 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    }
+    // ---- epilogue 1 (conv_block.hip): pairs k < 4: (row k, col tile 0 | 1); k = 4: rows 0 | 1 of col tile 2; k = 5: rows 2 | 3 ----
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2];
+      f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2];
+      if (FORM == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { tx[j] = relu_f32(tx[j]); ty[j] = relu_f32(ty[j]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { tx[j] *= blk.scale1; ty[j] *= blk.scale1; }
+      }
+      float v[8];
+      pair_up(tx, ty, g, v);
+      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+      uint4 o = make_uint4(0, 0, 0, 0);                  // outside the image: convB's zero padding
+      if (moff[k] != 0xffffffffu) {
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+        o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
+      }
+      *reinterpret_cast<uint4*>(ldt + swz((4 * rh + jr) * BCOLS + 16 * c + px + 1, chunk8)) = o;
+    }
+    gate_arrive(&gate[rh], lane);
+    gate_wait(&gate[rh], done + 4u);
+    if (rh == 1) gate_wait(&gate[0], done + 4u);
+    CH_STAMP();                                          // 8: T rows complete
+    // the row half's own strip rows of T (+ mask bytes) -> HBM from the LDS image: whole lines, non-temporal, under the second sweep
+    uint4 S[GROUP_REGS];
+    const bool t_out = blk.t != nullptr && CHAIN_CUT != 3 && CHAIN_CUT != 4;
+    if (t_out) group_stage<1>(S, ldt, tg, rh);
+    auto t_store = [&](int grp) {
+      if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
+        const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
+        if (t_out && soff[i] != 0xffffffffu) {
+          st16_nt(blk.t + soff[i], S[i]);
+          if (FORM == 1 && blk.mbits) blk.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+        }
+      }
+    };
+    // ---- phase 2: OUT = X + scale2 * (convB(T) + b2) [+ res2], in place over the input image's centre rows ----
+    f32x4 acc2[3][3];
+    {
+      f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (blk.b2) { const float4 t = *reinterpret_cast<const float4*>(blk.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc2[r][c] = b4;
+    }
+    if (rh == 0) {
+      sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[0]), F, lds, off, t_store);
+      gate_wait(&gate[1], done + 4u);
+      sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
+      block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc2[2]), F, lds, off);
+    } else {
+      sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
+      block_sweep<3, FMT>(acc2, F, lds, off, t_store);
+    }
+    CH_STAMP();                                          // 9: second conv swept
+    if (b + 1 < a.nblk) {                                // the next block's first filter lands under the epilogue and the halo step
+      const uint4* wp = a.blk[b + 1].w1 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = (k < 3) ? acc2[k < 3 ? k : 0][0] : acc2[0][2];
+      const f32x4 ty = (k < 3) ? acc2[k < 3 ? k : 0][1] : acc2[1][2];
+      float v[8], m[8];
+      pair_up(tx, ty, g, v);
+      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+      const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
+      if (y < a.H && xx < a.W) {
+        unsigned char* cell = ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8);
+        unpack8<FMT>(*reinterpret_cast<const uint4*>(cell), m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
+        if (blk.res2) {
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair)), m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += m[j];
+        }
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<uint4*>(cell) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
+    {
+      const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px;
+      if (y < a.H && xx < a.W) {
+        unsigned char* cell = ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8;
+        float v[4] = {acc2[2][2][0], acc2[2][2][1], acc2[2][2][2], acc2[2][2][3]};
+        float m[4];
+        unpack4<FMT>(*reinterpret_cast<const uint2*>(cell), m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
+        if (blk.res2) {
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0)), m);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += m[j];
+        }
+        *reinterpret_cast<uint2*>(cell) = pack4<FMT>(v[0], v[1], v[2], v[3]);
+      }
+    }
+    gate_arrive(&gate[2 + rh], lane);
+    gate_wait(&gate[2 + rh], done + 4u);
+    CH_STAMP();                                          // 10: OUT rows complete
+    {                                                    // this row half's 3 OUT rows -> HBM: whole lines, write-through (the neighbours read them back)
+      group_stage<2>(S, ldx, tg, rh);
+#pragma unroll
+      for (int i = 0; i < GROUP_REGS; ++i)
+        if (soff[i] != 0xffffffffu) { if (CHAIN_CUT == 2 || CHAIN_CUT == 4) st16_nt(blk.out + soff[i], S[i]); else ch_store16_sc1(blk.out + soff[i], S[i]); }
+    }
+    CH_STAMP();                                          // 11: stores issued
+    if (CHAIN_STAMPS && b == a.nblk / 2) stamps[13] = __builtin_amdgcn_s_memtime();
+  }
+  if (CHAIN_STAMPS && lane0 == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.flags + 2 * gridDim.x) + ((size_t)strip * 8 + wave) * 16;
+    for (int i = 0; i < 16; ++i) dbg[i] = (i < nst || i == 12 || i == 13) ? stamps[i] : 0ull;
+  }
+#undef CH_STAMP
+}
+
+__global__ void body_chain_epoch_kernel(unsigned* epoch) { *epoch = (*epoch + 1u) & 0xffffffu; }
+
+extern "C" int64_t rumpy_body_chain_flag_bytes(int32_t N, int32_t H) {
+  const int64_t strips = (int64_t)N * ((H + BSH - 1) / BSH);
+  return strips * 2 * 4 + (CHAIN_STAMPS ? strips * 8 * 16 * 8 : 0);
+}
+
+extern "C" int rumpy_body_chain(const rumpy_body_chain_args* p, void* stream) {
+  if (!p || !p->blocks || !p->flags || !p->epoch || !p->status || p->nblocks <= 0 || p->nblocks > 255) { rumpy_set_error("rumpy_body_chain: bad argument"); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW) { rumpy_set_error("rumpy_body_chain: needs 0 < W <= 48 (got %d)", p->W); return RUMPY_E_ARG; }
+  const int sy_n = (p->H + BSH - 1) / BSH;
+  if (p->N * sy_n > rumpy_device_cus()) { rumpy_set_error("rumpy_body_chain: %d strips do not fit %d CUs (all must be co-resident)", p->N * sy_n, rumpy_device_cus()); return RUMPY_E_ARG; }
+  ChainDev d;
+  d.blk = reinterpret_cast<const ChainBlk*>(p->blocks); d.nblk = p->nblocks; d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;
+  d.flags = (unsigned*)p->flags; d.epoch = (const unsigned*)p->epoch; d.status = (unsigned*)p->status;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(body_chain_epoch_kernel, dim3(1), dim3(1), 0, s, (unsigned*)p->epoch);
+  const dim3 grid(p->N * sy_n);
+  if (p->backward) RUMPY_LAUNCH_PROBED(5, (body_chain_kernel<3>), grid, dim3(BTHREADS), s, d);
+  else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (body_chain_kernel<1, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);
+  else RUMPY_LAUNCH_PROBED(5, (body_chain_kernel<1>), grid, dim3(BTHREADS), s, d);
+  return rumpy_check_launch("rumpy_body_chain");
+}

@@ -57,6 +57,26 @@ typedef struct {
 int rumpy_block_chain(const rumpy_block_chain_args* a, void* stream);
 int64_t rumpy_block_chain_xchg_bytes(int32_t nstrips);
 
+/* ---- the same chain, second design (conv_body_chain.hip): OUT rows leave as whole write-through lines, ONE flag word per (strip, row half)
+ * and block announces them, the neighbour reads its two halo rows back from the OUT tensor (sc1 loads).  Placement-independent.
+ * `blocks` = DEVICE array of rumpy_chain_block; block b's x MUST be block b-1's out.  Forms of rumpy_conv_block's ResBlock launches:
+ * backward = 0: t = relu(conv1(x)+b1) [mask bytes -> maskbits], out = x + scale2*(conv2(t)+b2) [+ res2]; backward = 1: t = maskbits . scale1*convA(x),
+ * out = x + scale2*convB(t) [+ res2].  flags = rumpy_body_chain_flag_bytes(N, H) bytes, epoch / status = device words, all zeroed once.
+ * *status = 0x500 + block after a hand-off that timed out. */
+typedef struct {
+  const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
+  const void* res2; void* t; void* out; void* maskbits;
+  float scale1, scale2;
+} rumpy_chain_block;
+typedef struct {
+  const void* blocks;
+  int32_t nblocks, N, H, W;
+  int32_t backward, fmt;   /* fmt: RUMPY_FMT_*; F16 with backward = 0 only */
+  void* flags; void* epoch; void* status;
+} rumpy_body_chain_args;
+int rumpy_body_chain(const rumpy_body_chain_args* a, void* stream);
+int64_t rumpy_body_chain_flag_bytes(int32_t N, int32_t H);
+
 #ifdef __cplusplus
 }
 #endif
