@@ -13,17 +13,43 @@
 #include "common.hpp"
 
 // ---------------------------------------------------------------------------------------------------------------- reductions
-__device__ __forceinline__ void fin_reduce_main(const rumpy_reduce_item& it, int bx, int nbx) {
-  const int nelem = it.co_count * 576;
-  for (int e = bx * 256 + (int)threadIdx.x; e < nelem + it.co_count; e += nbx * 256) {
-    if (e < nelem) {
-      const int c = e / 576, rem = e - c * 576, tap = rem >> 6, ci = rem & 63;
-      float s = 0.f;
-      for (int k = 0; k < it.njobs; ++k) s += it.slab[(size_t)k * it.slab_stride + e];
-      const int co = it.co_mode ? 4 * c + it.co_off : it.co_off + c;
-      it.gw[((size_t)co * it.ci_total + it.ci_off + ci) * 9 + tap] = s * it.scale;
-    } else if (it.write_bias) {
-      const int c = e - nelem;
+// Four output-channel rows (4 x 576 values: contiguous in every slab AND in the gradient tensor) per 256-thread block.  16-byte loads, the
+// njobs loads of a thread independent of each other (one add chain in job order, as wgrad_reduce_kernel: same bits); the [tap][ci] order of a
+// slab row is turned into the tensor's [ci][tap] order through LDS so that both sides are coalesced (the one-element-per-thread form wrote
+// 4-byte values at a 36-byte stride and read 4 bytes per lane: 2.1 TB/s over 70 MB of slabs).
+constexpr int FIN_ROWS = 4;
+__device__ __forceinline__ void fin_reduce_rows(const rumpy_reduce_item& it, int r0, int nrows, float* __restrict__ T) {
+  const int tid = threadIdx.x;
+  const int rows = (it.co_count - r0 < nrows) ? it.co_count - r0 : nrows;
+  if (rows <= 0) return;
+  const size_t stride4 = (size_t)it.slab_stride >> 2;
+  for (int v = tid; v < rows * 144; v += 256) {
+    const float4* sp = reinterpret_cast<const float4*>(it.slab + (size_t)r0 * 576) + v;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 9 <= it.njobs; k += 9) {            // nine loads in flight (a layer at 48 x 48 has nine jobs), added in job order
+      float4 t[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) t[u] = sp[(size_t)(k + u) * stride4];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) { s.x += t[u].x; s.y += t[u].y; s.z += t[u].z; s.w += t[u].w; }
+    }
+    for (; k < it.njobs; ++k) {
+      const float4 t = sp[(size_t)k * stride4];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    const int e = 4 * v, cl = e / 576, rem = e - cl * 576, tap = rem >> 6, ci = rem & 63;
+    float* d = T + cl * 576 + ci * 9 + tap;
+    d[0] = s.x * it.scale; d[9] = s.y * it.scale; d[18] = s.z * it.scale; d[27] = s.w * it.scale;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < rows * 576; idx += 256) {
+    const int cl = idx / 576, j = idx - cl * 576, c = r0 + cl;
+    const int co = it.co_mode ? 4 * c + it.co_off : it.co_off + c;
+    it.gw[((size_t)co * it.ci_total + it.ci_off) * 9 + j] = T[idx];
+  }
+  if (it.write_bias && r0 == 0) {
+    for (int c = tid; c < it.co_count; c += 256) {
       float s = 0.f;
       for (int k = 0; k < it.njobs; ++k) s += it.slab[(size_t)k * it.slab_stride + 16 * it.mt * 576 + c];
       const int co = it.co_mode ? 4 * c + it.co_off : it.co_off + c;
@@ -37,6 +63,7 @@ __device__ __forceinline__ float fin_slab_sum16(const float* __restrict__ slabs,
   float s0 = 0.f, s1 = 0.f;
   if (live) {
     int k = grp;
+#pragma unroll 4
     for (; k + 16 < nslabs; k += 32) { s0 += slabs[(size_t)k * stride + src]; s1 += slabs[(size_t)(k + 16) * stride + src]; }
     if (k < nslabs) s0 += slabs[(size_t)k * stride + src];
   }
@@ -51,9 +78,10 @@ __device__ __forceinline__ float fin_slab_sum16(const float* __restrict__ slabs,
 }
 __global__ void __launch_bounds__(256) finish_reduce_kernel(rumpy_finish_reduce_args a, int nb_main, int nb_tail) {
   __shared__ float part[16][17];
+  __shared__ float T[FIN_ROWS * 576];
   const int b = blockIdx.x;
   if (b < nb_main) {
-    fin_reduce_main(a.items[b / 145], b % 145, 145);
+    fin_reduce_rows(a.items[b >> 4], FIN_ROWS * (b & 15), FIN_ROWS, T);
   } else if (b < nb_main + nb_tail) {          // tail conv: slabs [nslabs][16*576 + 16], rows 0 .. C-1 used
     const int el = threadIdx.x & 15, nelem = a.tail_C * 576;
     const int e = (b - nb_main) * 16 + el;
@@ -82,7 +110,7 @@ extern "C" int rumpy_finish_reduce(const rumpy_finish_reduce_args* p, void* stre
   if (!p || p->nitems < 0 || (p->nitems > 0 && !p->items)) { rumpy_set_error("rumpy_finish_reduce: bad argument"); return RUMPY_E_ARG; }
   if (p->tail_slabs && (!p->tail_gw || !p->tail_gb || p->tail_nslabs <= 0 || p->tail_C < 1 || p->tail_C > 4)) { rumpy_set_error("rumpy_finish_reduce: bad tail arguments"); return RUMPY_E_ARG; }
   if (p->head_slabs && (!p->head_gw || !p->head_gb || p->head_nslabs <= 0 || p->head_C < 1 || p->head_C > 4 || p->head_cout <= 0)) { rumpy_set_error("rumpy_finish_reduce: bad head arguments"); return RUMPY_E_ARG; }
-  const int nb_main = 145 * p->nitems;
+  const int nb_main = 16 * p->nitems;           // 64 output channels per item at most, FIN_ROWS per block
   const int nb_tail = p->tail_slabs ? (p->tail_C * 576 + p->tail_C + 15) / 16 : 0;
   const int nb_head = p->head_slabs ? (p->head_cout * (9 * p->head_C + 1) + 15) / 16 : 0;
   if (nb_main + nb_tail + nb_head == 0) return RUMPY_OK;
@@ -104,17 +132,21 @@ __device__ __forceinline__ AdamCoef adam_coef(const rumpy_adam_hyper& h, const f
   c.gm = gm; c.step = h.lr / h.bias_c1; c.w1 = 1.f - h.beta1; c.w2 = 1.f - h.beta2; c.beta2 = h.beta2; c.sb2 = h.sqrt_bias_c2; c.eps = h.eps;
   return c;
 }
-// adam_kernel's update of one element (optim.hip), returns the new parameter value
-__device__ __forceinline__ float adam_one(const AdamCoef& c, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t i) {
+// adam_kernel's update of one element (optim.hip) on register values
+__device__ __forceinline__ void adam_reg(const AdamCoef& c, float& p, float graw, float& m, float& v) {
 #pragma clang fp contract(off)      // every product is rounded where torch rounds it (clip / mean factor first, then the moments): same bits as adam_kernel
-  const float gi = g[i] * c.gm;
-  float mi = m[i], vi = v[i];
-  mi = mi + c.w1 * (gi - mi);
-  vi = vi * c.beta2 + c.w2 * gi * gi;
-  const float denom = sqrtf(vi) / c.sb2 + c.eps;
-  const float pn = p[i] - c.step * (mi / denom);
-  p[i] = pn; m[i] = mi; v[i] = vi;
-  return pn;
+  const float gi = graw * c.gm;
+  m = m + c.w1 * (gi - m);
+  v = v * c.beta2 + c.w2 * gi * gi;
+  const float denom = sqrtf(v) / c.sb2 + c.eps;
+  p = p - c.step * (m / denom);
+}
+// ... of one element in memory, returns the new parameter value
+__device__ __forceinline__ float adam_one(const AdamCoef& c, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t i) {
+  float pi = p[i], mi = m[i], vi = v[i];
+  adam_reg(c, pi, g[i], mi, vi);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+  return pi;
 }
 
 constexpr int AP_ROW = 288;                   // 32 input channels x 9 taps: contiguous in the OIHW master copy
@@ -127,11 +159,26 @@ __global__ void __launch_bounds__(256) adam_pack_kernel(rumpy_adam_pack_args a) 
   if (it.kind == 0) {
     // ---- 16 output channels (quarter q of cout tile ct) x 32 input channels (half hf of cin chunk ch) x 9 taps of a 64-multiple conv ----
     const int chn = it.cin / 64, ctn = it.cout / 64;
-    for (int idx = tid; idx < 16 * AP_ROW; idx += 256) {
-      const int cl = idx / AP_ROW, j = idx - cl * AP_ROW;
-      const int cc = 16 * it.q + cl;
-      const int co = it.shuffle ? 4 * cc + it.ct : 64 * it.ct + cc;
-      P[idx] = adam_one(c, a.p, a.g, a.m, a.v, (size_t)it.woff + ((size_t)co * it.cin + 64 * it.ch + 32 * it.hf) * 9 + j);
+    if ((it.woff & 3) == 0) {
+      // rows of 288 contiguous floats, 16 bytes per lane (the 4-byte form ran at 2 TB/s); element-wise the same arithmetic
+      for (int v = tid; v < 16 * (AP_ROW / 4); v += 256) {
+        const int cl = v / (AP_ROW / 4), j4 = v - cl * (AP_ROW / 4);
+        const int cc = 16 * it.q + cl;
+        const int co = it.shuffle ? 4 * cc + it.ct : 64 * it.ct + cc;
+        const size_t i = (size_t)it.woff + ((size_t)co * it.cin + 64 * it.ch + 32 * it.hf) * 9 + 4 * j4;
+        const float4 g4 = *reinterpret_cast<const float4*>(a.g + i);
+        float4 p4 = *reinterpret_cast<const float4*>(a.p + i), m4 = *reinterpret_cast<const float4*>(a.m + i), v4 = *reinterpret_cast<const float4*>(a.v + i);
+        adam_reg(c, p4.x, g4.x, m4.x, v4.x); adam_reg(c, p4.y, g4.y, m4.y, v4.y); adam_reg(c, p4.z, g4.z, m4.z, v4.z); adam_reg(c, p4.w, g4.w, m4.w, v4.w);
+        *reinterpret_cast<float4*>(a.p + i) = p4; *reinterpret_cast<float4*>(a.m + i) = m4; *reinterpret_cast<float4*>(a.v + i) = v4;
+        *reinterpret_cast<float4*>(P + cl * AP_ROW + 4 * j4) = p4;
+      }
+    } else {
+      for (int idx = tid; idx < 16 * AP_ROW; idx += 256) {
+        const int cl = idx / AP_ROW, j = idx - cl * AP_ROW;
+        const int cc = 16 * it.q + cl;
+        const int co = it.shuffle ? 4 * cc + it.ct : 64 * it.ct + cc;
+        P[idx] = adam_one(c, a.p, a.g, a.m, a.v, (size_t)it.woff + ((size_t)co * it.cin + 64 * it.ch + 32 * it.hf) * 9 + j);
+      }
     }
     __syncthreads();
     uint4* wf = reinterpret_cast<uint4*>(it.w_fwd);
