@@ -138,6 +138,13 @@ __device__ __forceinline__ void halo_write(const uint4 (&R)[6], unsigned char* l
   }
 }
 
+// device-side argument block of the tile kernels (conv_mfma.hip, conv_dgrad4.hip)
+struct ConvDev {
+  const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
+  const uint16_t* mask; const uint16_t* res1; const uint16_t* res2; float* pool;
+  int N, H, W, cout_tiles, in_mode, out_mode, relu; float scale; int tiles_x, tiles_y;
+};
+
 // host side
 void rumpy_set_error(const char* fmt, ...);
 int rumpy_check_launch(const char* what);

@@ -1,0 +1,191 @@
+// Cin = 256 -> 64 3x3 convolution as a STREAMING kernel: the data gradient of the upsampler convs (common.py:30-33 Upsampler, backward of
+// conv 64 -> 256 + PixelShuffle(2): input = the gradient in the shuffled layout [N,2H,2W,64] or a plain [N,H,W,256] tensor).
+//
+// History of this shape (tests/tools/abl_conv4.sh, kbench.py conv4; 32 x 96 x 96, where the MFMAs need 46 us at the 1.8 GHz the chip holds):
+// conv3x3_kernel<4> (conv_mfma.hip: one wave per SIMD, register-staged input, workgroup barriers) 108 us; a K-split form with two waves per
+// SIMD (round 2, removed) 96 us; a streaming K-split form with LDS-DMA rings and gates instead of barriers 97 us; this kernel 93-98 us.
+// Four structures, one time - because what they share is what costs: in-kernel cycle counters of this kernel (D4_ABL=9 build) say sweeping
+// 56 % (the MFMA loop itself runs at 84 % of the matrix pipe), ISSUING the DMA 26 % (213 cycles per global_load_lds: address arithmetic plus
+// the wait for a slot in a vector-memory queue that a bandwidth-bound gather keeps full - the gather alone, MFMAs compiled out, takes 60 us
+// = 3.5 TB/s of 128-byte pieces, whatever the prefetch depth), waiting for a stage 10 %, epilogue 8 %.  A wave that feeds the memory pipe
+// cannot feed the matrix pipe meanwhile, and every wave here must do both (the filter fills its registers: no spare wave).  Interleaving
+// the DMA issue with the MFMAs made it worse (110 us).  Kept because it is the simplest of the four and 0.5 % faster on the step.
+// Structure: ONE wave per SIMD (512 registers: the whole filter AND three fragment sets), but a wave that does not wait for itself:
+//   * input by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write phase) into a ring of 6 chunk stages, FOUR stages (one whole
+//     tile) ahead of the MFMAs; waits are counted (s_waitcnt vmcnt(N), N = DMA pieces issued after the awaited stage: loads return in
+//     order, so the bound holds whatever the stores do);
+//   * stage image = block_common.hpp's: 128-byte pixels, unpadded (a DMA wave-instruction writes 1 KiB contiguously), 16-byte chunk index
+//     XOR-ed with (pixel & 7) on the SOURCE address; 10 x 18 halo pixels = 23 pieces of 8 pixels; out-of-image pixels come from a zero page;
+//   * fragment reads of units j + 1, j + 2 (tap column, channel half, row half) are issued BEFORE the 12 MFMAs of unit j (block_sweep's pipelining);
+//   * no workgroup barrier: the four waves meet on one LDS counter per stage (landed = every wave's pieces have arrived AND every wave is done
+//     with the stage whose slot the next DMA overwrites); no K split, so no partial-sum exchange either: same MFMA order per accumulator as
+//     conv3x3_kernel<4> (chunks 0 .. 3 in turn): bitwise that kernel (tests/test_kernels_gpu.py).
+#include "block_common.hpp"
+#ifndef D4_ABL
+#define D4_ABL 0      // timing only (results WRONG): 1 = no DMA, 2 = no MFMAs, 3 = no fragment reads (tests/tools/build_abl.sh conv_dgrad4.hip D4_ABL ...)
+#endif
+
+constexpr int D4_PIECES = 23;                         // 184 pixel slots >= 180 halo pixels
+constexpr int D4_STAGE = D4_PIECES * 1024;
+constexpr int D4_NST = 6;                             // ring slots: the stage in use, four in flight, one being refilled
+#ifndef D4_AHEAD
+#define D4_AHEAD 4
+#endif
+#ifndef D4_RD
+#define D4_RD 2         // fragment sets read ahead of the MFMAs (units of 6 reads / 12 MFMAs)
+#endif
+constexpr int D4_RING = D4_NST * D4_STAGE;            // 141,312 B
+constexpr int D4_PW = 6;                              // DMA pieces per wave and stage (4 waves x 6 >= 23; the surplus repeats piece 22)
+
+__device__ __attribute__((aligned(256))) uint4 g_zero_page4[16];
+typedef __attribute__((address_space(3))) unsigned char* d4_lds_u8;
+
+__device__ __forceinline__ void d4_dma16(const void* gsrc, unsigned lds_dst) {     // wgrad_dma.hip::dma16
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void d4_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+
+__global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[D4_RING];
+  __shared__ unsigned landed;            // stages landed: 4 arrivals each
+  const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, g = lane >> 4;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const int tile0 = blockIdx.x, tstride = (int)gridDim.x;
+  if (tile0 >= ntiles) return;
+  const int nt = (ntiles - tile0 + tstride - 1) / tstride;
+  const int nstage = 4 * nt;
+  const unsigned ring = (unsigned)(size_t)(d4_lds_u8)lds;
+  if (tid == 0) landed = 0u;
+
+  bf16x8 F[4][18];
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+    for (int s = 0; s < 18; ++s) F[ch][s] = as_bf16x8(a.w[((ch * 4 + q) * 18 + s) * 64 + lane]);
+
+  // this wave's DMA pieces of a stage: piece q + 4k; lane = (pixel sub 0..7, 16-byte slot 0..7); source chunk = slot ^ (pixel & 7)
+  const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_page4;
+  // per-lane geometry of the wave's six pieces, fixed for the kernel: halo row / column of the lane's pixel and its source chunk offset
+  int pr[D4_PW], pc[D4_PW];
+#pragma unroll
+  for (int k = 0; k < D4_PW; ++k) {
+    const int piece = (q + 4 * k < D4_PIECES) ? q + 4 * k : D4_PIECES - 1;
+    const int pix = piece * 8 + (lane >> 3);
+    const int r = pix / HALO_W, c = pix - r * HALO_W;
+    pr[k] = (pix < HALO_PIX) ? r - 1 : -100000;                     // a pixel slot past the halo is out of the image for every tile
+    pc[k] = ((c - 1) << 8) | (((lane & 7) ^ (pix & 7)) * 8);         // column (may be -1: arithmetic shift) and source chunk offset in elements
+  }
+  // piece k of stage u (tile tile0 + (u / 4) * tstride, input chunk u & 3): ~12 VALU + the DMA; called one piece at a time from inside the
+  // MFMA stream, where a lone wave per SIMD has issue slots to spare (a stage's six pieces issued in one go at the top of a chunk cost
+  // 190 VALU instructions there: a third of the chunk's MFMA time with nothing to overlap them)
+  auto issue_piece = [&](int u, int k) {
+    const TileCoord tc = decode_tile(tile0 + (u >> 2) * tstride, a.tiles_x, a.tiles_y);
+    const int ch = u & 3;
+    const unsigned dst = ring + (unsigned)(u % D4_NST) * D4_STAGE;
+    const int piece = (q + 4 * k < D4_PIECES) ? q + 4 * k : D4_PIECES - 1;
+    const int y = tc.ty * TH + pr[k], x = tc.tx * TW + (pc[k] >> 8);
+    const int sch = pc[k] & 255;
+    const bool ok = ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+    unsigned e;
+    if (a.in_mode == 0) e = (unsigned)(((tc.n * a.H + y) * a.W + x) * 256 + ch * 64 + sch);
+    else e = (unsigned)(((tc.n * 2 * a.H + 2 * y + (ch >> 1)) * (2 * a.W) + 2 * x + (ch & 1)) * 64 + sch);
+    const unsigned long long src = ok ? (unsigned long long)(uintptr_t)a.x + 2ull * e : zero;
+    if (D4_ABL != 1) d4_dma16((const void*)(uintptr_t)src, __builtin_amdgcn_readfirstlane(dst + piece * 1024));
+  };
+  auto issue = [&](int u) {
+#pragma unroll
+    for (int k = 0; k < D4_PW; ++k) issue_piece(u, k);
+  };
+  // fragment read bases (block_common.hpp::sweep_bases with an 18-pixel row): class d = (2 r + kx) & 7 of window row r, tap column kx
+  unsigned off[8][2];
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) off[d][h] = (unsigned)(px * 128 + (((4 * h + g) ^ ((px + d) & 7)) << 4));
+
+  __syncthreads();                        // counter zeroed
+#pragma unroll
+  for (int u = 0; u < D4_AHEAD; ++u)
+    if (u < nstage) issue(u);
+
+  const int c0 = 16 * q + 4 * g;
+  unsigned long long t_issue = 0ull, t_wait = 0ull, t_mfma = 0ull;      // D4_ABL 8 / 9: shader cycles spent issuing DMA, waiting for a stage, sweeping
+#define D4_T() ((D4_ABL >= 8) ? __builtin_amdgcn_s_memtime() : 0ull)
+  const unsigned long long clk0 = (D4_ABL >= 8) ? __builtin_amdgcn_s_memtime() : 0ull, rt0 = (D4_ABL >= 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  for (int it = 0; it < nt; ++it) {
+    const TileCoord tc = decode_tile(tile0 + it * tstride, a.tiles_x, a.tiles_y);
+    const int xx = tc.tx * TW + px;
+    f32x4 acc[TH];
+#pragma unroll
+    for (int r = 0; r < TH; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const int u = 4 * it + ch;
+      // stage u has landed once at most the pieces issued after it are outstanding (stages u+1 .. u+3, fewer at the end); then the waves meet
+      const unsigned long long ta = D4_T();
+      const int younger = (nstage - 1 - u < D4_AHEAD - 1) ? nstage - 1 - u : D4_AHEAD - 1;
+      if (younger >= 4) d4_wait<4 * D4_PW>(); else if (younger == 3) d4_wait<3 * D4_PW>(); else if (younger == 2) d4_wait<2 * D4_PW>(); else if (younger == 1) d4_wait<D4_PW>(); else d4_wait<0>();
+      gate_arrive(&landed, lane);
+      gate_wait(&landed, 4u * (unsigned)(u + 1));
+      const unsigned long long tb = D4_T();
+      if (u + D4_AHEAD < nstage) issue(u + D4_AHEAD);   // into a slot every wave is past (stage u - 2's)
+      const unsigned long long tc_ = D4_T();
+      const unsigned char* cur = lds + (u % D4_NST) * D4_STAGE;
+      // 12 units (tap column, channel half, row half) of 6 fragment reads + 12 MFMAs; the reads of unit j + 1 travel under the MFMAs of unit j
+      bf16x8 I[D4_RD + 1][6];
+      auto load_unit = [&](int j, bf16x8 (&dst)[6]) {
+        const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          if (D4_ABL != 3 || j == 0) dst[r] = *reinterpret_cast<const bf16x8*>(cur + off[(2 * r + kx) & 7][half] + ((4 * pass + r) * HALO_W + kx) * 128);
+      };
+#pragma unroll
+      for (int j = 0; j < D4_RD; ++j) load_unit(j, I[j]);
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        if (j + D4_RD < 12) load_unit(j + D4_RD, I[(j + D4_RD) % (D4_RD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (D4_ABL != 2) acc[4 * pass + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[4 * pass + r], 0, 0, 0);
+            else asm volatile("" :: "v"(I[j % (D4_RD + 1)][r + ky]), "v"(F[ch][(ky * 3 + kx) * 2 + half]));
+      }
+      if (D4_ABL >= 8) { const unsigned long long td = D4_T(); t_wait += tb - ta; t_issue += tc_ - tb; t_mfma += td - tc_; }
+    }
+    // ---- epilogue: lane holds channels c0 .. c0+3 of pixel (row r, column px); the residual operand is read here (plain loads: the
+    // compiler's wait for them drains the DMA queue - everything older - which costs one stage's slack once per tile) ----
+#pragma unroll
+    for (int r = 0; r < TH; ++r) {
+      const int y = tc.ty * TH + r;
+      if (y < a.H && xx < a.W) {
+        const size_t e = ((size_t)(tc.n * a.H + y) * a.W + xx) * 64 + c0;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[r][j] * a.scale;
+        if (a.res1) {
+          float m[4];
+          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res1 + e), m);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += m[j];
+        }
+        *reinterpret_cast<uint2*>(a.out + e) = pack4_bf16(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  if (D4_ABL >= 8 && a.bias && lane == 0) {      // clock probe: a.bias (unused by this kernel) = [grid][2] u64: shader cycles, 100 MHz ticks of the tile loop
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias)) + 8 * (4 * blockIdx.x + q);
+    dbg[0] = __builtin_amdgcn_s_memtime() - clk0; dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0; dbg[2] = t_wait; dbg[3] = t_issue; dbg[4] = t_mfma;
+  }
+}
+
+int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(conv4d_kernel, dim3(grid), dim3(256), 0, s, d);
+  return 0;
+}

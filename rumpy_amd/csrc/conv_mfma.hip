@@ -13,11 +13,6 @@
 #include "common.hpp"
 #include <cstdlib>
 
-struct ConvDev {
-  const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
-  const uint16_t* mask; const uint16_t* res1; const uint16_t* res2; float* pool;
-  int N, H, W, cout_tiles, in_mode, out_mode, relu; float scale; int tiles_x, tiles_y;
-};
 
 #ifndef CONV4_ABL
 #define CONV4_ABL 0     // timing experiments only (tests/tools/build_abl.sh): results are wrong for any value but 0
@@ -164,113 +159,6 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
       __syncthreads();
       buf ^= 1;
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Cin = 256 (data gradient of the upsampler convs), K split over two wave groups: conv4k_kernel.
-// conv3x3_kernel<4> keeps the whole 256-channel filter in 288 registers, i.e. ONE wave per SIMD: its MFMAs, LDS reads, loads and epilogue
-// run strictly one after the other (tests/tools/abl_conv4.sh: 108 us at 32x96x96, 55 us without the MFMAs, 88 us without the loads).
-// Here 8 waves = 4 channel quarters x 2 K halves: wave (q, kh) holds the filter of input chunks 2kh, 2kh+1 only (144 registers) and
-// accumulates ITS half of K for the whole 8 x 16-pixel tile; the kh = 1 waves hand their fp32 partial sums to their kh = 0 partners
-// through LDS, which add them and run the epilogue.  Two waves per SIMD: one wave's LDS reads / waits / epilogue sit under the other's
-// MFMAs.  Each group stages its own chunks (its 256 threads, its own pair of LDS buffers): same addressing as conv3x3_kernel.
-// ------------------------------------------------------------------------------------------------------
-constexpr int C4K_XBUF = 4 * TH * 4 * 64 * 4;          // fp32 partial sums of the four kh = 1 waves: 32 KB
-template <bool DUMMY>
-__global__ void __launch_bounds__(512, 2) conv4k_kernel(ConvDev a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * X_STAGE_BYTES + C4K_XBUF];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int px = lane & 15, g = lane >> 4;
-  const int q = wave & 3, kh = wave >> 2, tg = tid & 255;
-  const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  unsigned char* const gl = lds + kh * 2 * X_STAGE_BYTES;                 // this group's two stage buffers
-  float* const xb = reinterpret_cast<float*>(lds + 4 * X_STAGE_BYTES) + q * (TH * 4 * 64);
-
-  bf16x8 F[2][18];
-#pragma unroll
-  for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-    for (int s = 0; s < 18; ++s) F[ch][s] = as_bf16x8(a.w[(((2 * kh + ch) * 4 + q) * 18 + s) * 64 + lane]);
-
-  int tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  const int gstride = (int)gridDim.x;
-  uint4 R[6];
-  {
-    const TileCoord t = decode_tile(tile, a.tiles_x, a.tiles_y);
-    halo_issue(R, a.x, a.in_mode, 256, a.in_mode == 0 ? 2 * kh * 64 : 2 * kh, t.n, t.ty, t.tx, a.H, a.W, tg);
-    halo_write(R, gl, tg);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (; tile < ntiles; tile += gstride) {
-    const TileCoord tc = decode_tile(tile, a.tiles_x, a.tiles_y);
-    f32x4 acc[TH];
-#pragma unroll
-    for (int r = 0; r < TH; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      {   // the next stage of this group: its second chunk of this tile, or its first chunk of the next tile (past the end: this tile again, unused)
-        const int ntile0 = (ch == 0) ? tile : tile + gstride;
-        const int nch = 2 * kh + ((ch == 0) ? 1 : 0);
-        const int ntile = (ntile0 < ntiles) ? ntile0 : tile;
-        const TileCoord tn = decode_tile(ntile, a.tiles_x, a.tiles_y);
-        halo_issue(R, a.x, a.in_mode, 256, a.in_mode == 0 ? nch * 64 : nch, tn.n, tn.ty, tn.tx, a.H, a.W, tg);
-      }
-      const bool has_next = (ch == 0) || (tile + gstride < ntiles);
-      const unsigned char* cur = gl + buf * X_STAGE_BYTES;
-      // 6 groups (tap column, channel half) x two passes of 4 output rows: 6 B-fragment reads + 12 MFMAs each (the partner wave of the SIMD
-      // covers the read latency: no second fragment set, the registers go to the filter)
-#pragma unroll
-      for (int grp = 0; grp < 6; ++grp) {
-        const int kx = grp >> 1, half = grp & 1;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-          bf16x8 I[6];
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-            I[r] = *reinterpret_cast<const bf16x8*>(cur + ((4 * pass + r) * HALO_W + px + kx) * PIX_STRIDE + half * 64 + g * 16);
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              acc[4 * pass + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[r + ky], acc[4 * pass + r], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (has_next) halo_write(R, gl + (buf ^ 1) * X_STAGE_BYTES, tg);
-      if (ch == 1 && kh == 1) {        // this half of K is complete: hand the partial sums to the kh = 0 partner (same lane, same layout)
-#pragma unroll
-        for (int r = 0; r < TH; ++r) *reinterpret_cast<f32x4*>(xb + (r * 64 + lane) * 4) = acc[r];
-      }
-      __syncthreads();
-      buf ^= 1;
-    }
-    if (kh == 0) {
-      // ---- epilogue (conv3x3_kernel): lane holds channels c0..c0+3 of pixel (row r, column px) ----
-      const int c0 = 16 * q + 4 * g;
-      const int xx = tc.tx * TW + px;
-#pragma unroll
-      for (int r = 0; r < TH; ++r) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(xb + (r * 64 + lane) * 4);
-        const int y = tc.ty * TH + r;
-        if (y < a.H && xx < a.W) {
-          const size_t e = ((size_t)(tc.n * a.H + y) * a.W + xx) * 64 + c0;
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (acc[r][j] + o[j]) * a.scale;
-          if (a.res1) {
-            float m[4];
-            unpack4_bf16(*reinterpret_cast<const uint2*>(a.res1 + e), m);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += m[j];
-          }
-          *reinterpret_cast<uint2*>(a.out + e) = pack4_bf16(v[0], v[1], v[2], v[3]);
-        }
-      }
-    }
-    __syncthreads();                   // the partial sums have been consumed: the next tile may overwrite them
   }
 }
 
@@ -574,6 +462,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s);   // conv_strip.hip
 int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s);          // conv_up.hip
 
+int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s);      // conv_dgrad4.hip
 extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->out) { rumpy_set_error("rumpy_conv3x3: null pointer"); return RUMPY_E_ARG; }
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cout_tiles <= 0) { rumpy_set_error("rumpy_conv3x3: bad shape"); return RUMPY_E_ARG; }
@@ -621,14 +510,15 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   const int kid = 3;
   rumpy_probe_pre(kid, s);
   dim3 grid(gx, p->cout_tiles);
-  // the data gradients of the upsampler convs (what the engine launches with Cin = 256): K split over two wave groups
-  static const bool old4 = getenv("RUMPY_CONV4_OLD") != nullptr;      // A/B switch
-  const bool plain = p->cout_tiles == 1 && p->out_mode == 0 && !p->bias && !p->relu && !p->mask && !p->res2 && !p->pool;
+  // the data gradients of the upsampler convs (what the engine launches with Cin = 256)
+  const bool old4 = getenv("RUMPY_CONV4_OLD") != nullptr;             // A/B switch (read per call: tests toggle it)
+  // (RUMPY_D4_PROBE: the clock-probe build of conv_dgrad4.hip takes its debug buffer in `bias`)
+  const bool plain = p->cout_tiles == 1 && p->out_mode == 0 && (!p->bias || getenv("RUMPY_D4_PROBE")) && !p->relu && !p->mask && !p->res2 && !p->pool;
   if (plain && !old4) {
     int g2 = p->grid_x > 0 ? p->grid_x : rumpy_device_cus();
     const int rounds = cdiv(ntiles, g2);
     g2 = cdiv(ntiles, rounds);
-    hipLaunchKernelGGL(conv4k_kernel<false>, dim3(g2), dim3(512), 0, s, d);
+    rumpy_conv4d_launch(d, g2, s);       // streaming form (conv_dgrad4.hip); RUMPY_CONV4_OLD=1 keeps the register-staged kernel below (A/B, tests)
   } else
   hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
   rumpy_probe_post(kid, s);

@@ -179,6 +179,33 @@ def test_conv3x3_dgrad_plain_and_unshuffle():
     assert_bf16_close(nchw(o), x.grad, 'dgrad upsampler (PixelShuffle^T gather)')
 
 
+def test_streaming_cin256_kernel_is_bitwise_the_register_staged_kernel(monkeypatch):
+    """conv_dgrad4.hip (LDS-DMA ring four stages ahead, pipelined fragment reads, one LDS counter per stage instead of workgroup barriers) against
+    conv3x3_kernel<4> (RUMPY_CONV4_OLD=1: same MFMA order per accumulator) on the launches the engine makes with Cin = 256: PixelShuffle^T gather
+    and plain input, with and without the residual operand, ragged sizes, one to several tiles per workgroup (grid_x), a single tile; and
+    against torch for the gather case"""
+    gen = np.random.default_rng(41)
+    w, b = _wb(gen, 256, 64)
+    pc = PackedConv(w, b, 0, True)
+    for (N, H, W, gx) in ((2, 13, 17, 0), (3, 40, 50, 7), (1, 8, 16, 0), (2, 24, 33, 2), (1, 5, 3, 1), (2, 96, 96, 0)):
+        gy = nhwc(_rand(gen, N, 64, 2 * H, 2 * W))
+        gp = nhwc(_rand(gen, N, 256, H, W))
+        r1 = nhwc(_rand(gen, N, 64, H, W))
+        outs = []
+        for env in ('RUMPY_CONV4_OLD', None):
+            monkeypatch.delenv('RUMPY_CONV4_OLD', raising=False)
+            if env:
+                monkeypatch.setenv(env, '1')
+            outs.append((hip_conv(gy, pc, N, H, W, dgrad=True, in_mode=1, grid_x=gx)[0],
+                         hip_conv(gy, pc, N, H, W, dgrad=True, in_mode=1, scale=0.7, res1=r1, grid_x=gx)[0],
+                         hip_conv(gp, pc, N, H, W, dgrad=True, in_mode=0, res1=r1, grid_x=gx)[0]))
+        for k in range(3):
+            assert torch.equal(outs[0][k].view(torch.int16), outs[1][k].view(torch.int16)), (N, H, W, gx, k)
+        x = torch.zeros(N, 64, H, W, requires_grad=True)
+        F.pixel_shuffle(F.conv2d(x, bf16r(w), None, padding=1), 2).backward(nchw(gy).float())
+        assert_bf16_close(nchw(outs[1][0]), x.grad, 'streaming dgrad upsampler')
+
+
 def test_conv3x3_rejects_bad_arguments():
     a = L.ConvArgs(x=None, w=None, out=None, N=1, H=1, W=1, cin_chunks=1, cout_tiles=1)
     assert L.lib().rumpy_conv3x3(a, None) == -1
