@@ -402,3 +402,28 @@ def up1_bench():
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'up1':
     up1_bench()
+
+
+def tail_bench(N=32, H=192, W=192):
+    """tail conv 64 -> 3 (+ L1 loss, sign gradient, its own weight gradient) at the headline output size: which part costs what"""
+    gen = np.random.default_rng(0)
+    w = torch.from_numpy(gen.uniform(-0.04, 0.04, (3, 64, 3, 3)).astype(np.float32))
+    pt = PackedConv(w, torch.zeros(3), kind=2)
+    x = torch.randn(N, H, W, 64, device=DEV).to(BF16)
+    y = torch.rand(N, 3, H, W, device=DEV)
+    out = torch.empty(N, 3, H, W, device=DEV)
+    dy4 = torch.empty(N, H, W, 4, dtype=BF16, device=DEV)
+    grid = int(L.lib().rumpy_tail_fwd_grid(N, H, W, 0))
+    part = torch.zeros(grid, device=DEV)
+    loss = torch.zeros(1, device=DEV)
+    wslab = torch.zeros(grid * (16 * 576 + 16), device=DEV)
+    base = dict(x=x.data_ptr(), w=pt.w_fwd.data_ptr(), bias=pt.b.data_ptr(), out=out.data_ptr(), N=N, C=3, H=H, W=W, grid_x=0)
+    for lab, extra in (('forward only', {}), ('+ L1 loss, sign gradient', dict(target=y.data_ptr(), dy4=dy4.data_ptr(), loss_partial=part.data_ptr(), loss=loss.data_ptr())),
+                       ('+ weight gradient', dict(target=y.data_ptr(), dy4=dy4.data_ptr(), loss_partial=part.data_ptr(), loss=loss.data_ptr(), wslab=wslab.data_ptr()))):
+        a = L.TailFwdArgs(**base, **extra)
+        us = time_fn(lambda: L.call('rumpy_tail_fwd', a, stream()), iters=20)
+        print('tail %dx%dx%d %-28s %7.2f us  %5.2f TB/s of input' % (N, H, W, lab, us, x.numel() * 2 / us / 1e6))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'tail':
+    tail_bench()
