@@ -15,12 +15,14 @@ class _BasicFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, net, *params):
         ctx.net = net
-        return net.engine.forward(x, train=True)
+        out = net.engine.forward(x, train=True)
+        ctx.acts = net.engine.acts             # this pass's own activations: a second forward before backward() does not replace them
+        return out
 
     @staticmethod
     def backward(ctx, gout):
         net = ctx.net
-        net.engine.backward(gout)
+        net.engine.backward(gout, acts=ctx.acts)
         net.attach_grads()
         return (None, None) + tuple(None for _ in net.param_list)
 

@@ -54,11 +54,14 @@ class BasicEngine:
         self.acts = acts if train else None
         return cur
 
-    def backward(self, gout, scale=1.0):
-        """gout: gradient at the network output [N,Cout,H,W] fp32; parameter gradients (x scale) overwrite the flat gradient views."""
-        if self.acts is None:
+    def backward(self, gout, scale=1.0, acts=None):
+        """gout: gradient at the network output [N,Cout,H,W] fp32; parameter gradients (x scale) overwrite the flat gradient views.
+        acts: the activation list of the forward pass this gradient belongs to (every training forward allocates its own; the autograd node
+        keeps it, so two forward passes before a backward pass do not mix); default: the last training forward's."""
+        acts = self.acts if acts is None else acts
+        if acts is None:
             raise RuntimeError('rumpy_amd basic models: backward without a training forward pass')
-        acts, s = self.acts, self._stream()
+        s = self._stream()
         N, _, H, W = acts[0].shape
         g = gout.float().contiguous()
         for i in range(len(self.layers) - 1, -1, -1):

@@ -204,6 +204,24 @@ def test_other_criteria_run_through_the_autograd_node_and_checkpoints_interchang
         assert _rel(o2, onet2(xe)) < 1e-5
 
 
+def test_two_forward_passes_before_a_backward_pass_keep_their_own_activations():
+    """the whole-network autograd node keeps the activations of ITS forward pass - a second forward of another batch before
+    backward() must not change the first one's gradients (the reference's autograd behaves so)"""
+    h = _handler('srcnn', lr=1e-3, kernel_pattern=[5, 3, 3], channel_pattern=[1, 12, 6, 1])
+    h.net.train()
+    xa, ya = y_batch(880, 2, 18, 18)
+    xb, _ = y_batch(881, 2, 18, 18)
+    xa, ya, xb = xa.cuda(), ya.cuda(), xb.cuda()
+    out = h.net(xa)
+    torch.nn.functional.l1_loss(out, ya).backward()
+    ref = [p.grad.clone() for p in h.net.parameters()]
+    out = h.net(xa)
+    h.net(xb)                                  # another training forward in between
+    torch.nn.functional.l1_loss(out, ya).backward()
+    for p, r in zip(h.net.parameters(), ref):
+        assert torch.equal(p.grad, r)
+
+
 def test_default_vdsr_trains_on_a_full_size_patch_batch():
     """the 20-layer default VDSR (665,921 parameters, grad_clip 0.1) on a 16 x 1 x 64 x 64 batch: loss falls, everything finite"""
     torch.manual_seed(8)
