@@ -377,6 +377,35 @@ typedef struct {
 int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
 int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
 
+/* ---- the other QCALayer styles (rumpy/SISR/models/attention_manipulators/architectures.py:41-136: 'max_concat', 'mini_concat',
+ * 'extended_attention', 'softmax'): the gate of a block is an MLP of at most four layers over the block's channel means and the image's
+ * attribute vector (qca_style.hip).  Layer l: v = [previous output (n_prev) ; attr (M) if cat]; v = relu(v) if relu_in; out = act(W v + b),
+ * act: 0 none, 1 ReLU, 2 sigmoid, 3 sigmoid then softmax over the outputs (last layer only).  These launches stand where rumpy_ca_mlp_fwd /
+ * rumpy_ca_mlp_bwd stand for the plain CALayer: pool -> rumpy_qca_gate_fwd -> rumpy_ca_scale_res_fwd; rumpy_ca_bwd_reduce ->
+ * rumpy_qca_gate_bwd -> rumpy_ca_bwd_apply; then ONE rumpy_qca_bwd_params over all layers of a network (items: DEVICE array of the
+ * arguments of the gate launches, with gw / gb / scale set).  fp32 throughout. */
+#define RUMPY_QCA_ACT_STRIDE 320   /* saved floats per image: the C means + every layer's outputs */
+typedef struct {
+  const float* w; const float* b;   /* [n_out][n_prev + (cat ? M : 0)], [n_out] */
+  float* gw; float* gb;             /* gradients, written by rumpy_qca_bwd_params */
+  int32_t n_prev, n_out, cat, relu_in, act, pad_;
+} rumpy_qca_layer;
+typedef struct {
+  rumpy_qca_layer layers[4];
+  int32_t nlayers, N, C, M, ntiles, nchunks;
+  float inv_hw, scale;
+  const float* pool;     /* fwd in: [N][ntiles][C] per-tile channel sums of the block's second conv */
+  const float* attr;     /* [N][M] attribute vectors */
+  float* acts;           /* [N][RUMPY_QCA_ACT_STRIDE] fwd out / bwd in */
+  float* gate;           /* [N][C] fwd out / bwd in */
+  const float* partial;  /* bwd in: [N][nchunks][C] from rumpy_ca_bwd_reduce */
+  float* dpool;          /* bwd out: [N][C] d(mean) / HW, for rumpy_ca_bwd_apply */
+  float* delta;          /* bwd out: [N][RUMPY_QCA_ACT_STRIDE] pre-activation gradients, layout of acts */
+} rumpy_qca_args;
+int rumpy_qca_gate_fwd(const rumpy_qca_args* a, void* stream);
+int rumpy_qca_gate_bwd(const rumpy_qca_args* a, void* stream);
+int rumpy_qca_bwd_params(const rumpy_qca_args* items_device, int32_t nitems, void* stream);
+
 /* ---- degradation encoder of the blind-SR pipeline (frozen; rumpy/regression/models/contrastive_learning/encoding_models.py:5-55,
  * called by ContrastiveBlindSRPipeline.forward, rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:241-329):
  * nn.Conv2d(cin, cout, 3, stride, padding=1) + eval-mode BatchNorm2d (folded into w / bias by the host) + LeakyReLU, NHWC bf16 in and

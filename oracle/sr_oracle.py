@@ -178,6 +178,50 @@ class MetaAttention(nn.Module):
         return x * self.attribute_integrator(attributes)
 
 
+class StyledChannelAttention(nn.Module):
+    """rumpy/SISR/models/attention_manipulators/architectures.py:41-136 (QCALayer) for the styles whose squeeze-excite MLP also reads the
+    attribute vector: 'max_concat' (:116-117), 'mini_concat' (:118-120), 'extended_attention' (:121-124), 'softmax' (:125-127).
+    Modules, creation order and keys as :66-108; forward(x, attributes [N,M,1,1]) -> x * gate."""
+
+    def __init__(self, feats, reduction, style, num_metadata):
+        super().__init__()
+        if reduction < 16:
+            raise RuntimeError('Using an extreme channel attention reduction value')
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.style, cr = style, feats // reduction
+        cin = feats if style == 'mini_concat' else feats + num_metadata
+        if style in ('max_concat', 'softmax'):
+            self.conv_du = nn.Sequential(nn.Conv2d(cin, cr, 1), nn.ReLU(), nn.Conv2d(cr, feats, 1), nn.Sigmoid())
+        elif style == 'mini_concat':
+            self.pre_concat = nn.Conv2d(cin, cr, 1)
+            self.conv_du = nn.Sequential(nn.ReLU(), nn.Conv2d(cr + num_metadata, feats, 1), nn.Sigmoid())
+        elif style == 'extended_attention':
+            self.feature_convs = nn.ModuleList(nn.Sequential(nn.Conv2d(i, o, 1), nn.ReLU()) for i, o in
+                                               ((cin, feats // 2), (feats // 2 + num_metadata, feats // 4), (feats // 4 + num_metadata, cr)))
+            self.final_conv = nn.Sequential(nn.Conv2d(cr, feats, 1), nn.Sigmoid())
+        else:
+            raise NotImplementedError(style)
+        if style == 'softmax':
+            self.softmax = nn.Softmax(dim=1)
+
+    def forward(self, x, attributes):
+        y = self.avg_pool(x)
+        if self.style == 'max_concat':
+            y = self.conv_du(torch.cat((y, attributes), dim=1))
+        elif self.style == 'mini_concat':
+            y = self.conv_du(torch.cat((self.pre_concat(y), attributes), dim=1))
+        elif self.style == 'extended_attention':
+            for sec in self.feature_convs:
+                y = sec(torch.cat((y, attributes), dim=1))
+            y = self.final_conv(y)
+        else:
+            y = self.softmax(self.conv_du(torch.cat((y, attributes), dim=1)))
+        return x * y
+
+
+STYLED = ('max_concat', 'mini_concat', 'extended_attention', 'softmax')
+
+
 class MetaAttentionResidualBlock(nn.Module):
     """rumpy/SISR/models/attention_manipulators/architectures.py:154-228 (QRCAB) for style='standard', q_layer=True, no other
     optional node: res = body(x); res = QCALayer_standard(res) (:113-136 -> plain channel attention, keys final_body.conv_du.*);
@@ -190,7 +234,7 @@ class MetaAttentionResidualBlock(nn.Module):
         # registration order as the reference (:173-195: final_body, q_node, body) - it is the order of the state_dict keys
         # and of the optimizer's parameter indices in a checkpoint
         convs = [conv3x3(feats, feats), nn.ReLU(), conv3x3(feats, feats)]
-        self.final_body = ChannelAttention(feats, reduction)
+        self.final_body = StyledChannelAttention(feats, reduction, style, num_metadata) if style in STYLED else ChannelAttention(feats, reduction)
         self.q_layer = q_layer
         if q_layer:
             self.q_node = MetaAttention(feats, num_metadata, num_layers_in_q_layer)
@@ -199,7 +243,12 @@ class MetaAttentionResidualBlock(nn.Module):
     def forward(self, xm):
         x, meta = xm
         res = self.body(x)
-        res = res * (self.final_body.conv_du(self.final_body.avg_pool(res)) * meta) if self.style == 'modulate' else self.final_body(res)
+        if self.style == 'modulate':
+            res = res * (self.final_body.conv_du(self.final_body.avg_pool(res)) * meta)
+        elif self.style in STYLED:
+            res = self.final_body(res, meta)
+        else:
+            res = self.final_body(res)
         if self.q_layer:
             res = self.q_node(res, meta)
         return res + x, meta
@@ -231,8 +280,8 @@ class OracleQRCAN(nn.Module):
                  num_metadata=1, include_q_layer=True, selective_meta_blocks=None, num_q_layers_inner_residual=None,
                  num_layers_in_q_layer=2, style='standard', **_ignored):
         super().__init__()
-        if style not in ('standard', 'modulate'):
-            raise NotImplementedError('oracle restates the QCALayer styles "standard" and "modulate" only')
+        if style not in ('standard', 'modulate') + STYLED:
+            raise NotImplementedError('oracle: unknown QCALayer style %r' % style)
         f = n_feats
         head = conv3x3(in_feats, f)                      # creation order (random init) and registration order (keys) of
         groups = [MetaAttentionGroup(                    # architectures.py:368-433: head, groups, final_body, tail created;

@@ -10,7 +10,7 @@ from .architectures import QRCAN
 class QRCANHandler(QModel):
     """RCAN with meta-attention on hand-written gfx950 kernels: the reference's default style 'modulate' (one quality value per image,
     spread by ``scale_qpi`` into a gaussian bump over the 64 channels that multiplies every block's attention vector) and
-    ``style='standard'`` with ``include_q_layer=True`` (q-layers on a metadata vector).  The concatenating styles and the SRMD / SFT
+    ``style='standard'`` with ``include_q_layer=True`` (q-layers on a metadata vector).  The other styles ('max_concat', 'mini_concat', 'extended_attention', 'softmax') run with the gate MLP as separate launches; the SRMD / SFT
     metadata planes are refused by the architecture."""
 
     def __init__(self, device, model_save_dir, eval_mode=False, lr=1e-4, scale=4, in_features=3, scheduler=None,

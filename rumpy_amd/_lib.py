@@ -146,6 +146,20 @@ class CaBwdApplyArgs(_S):
                 ('N', c_int32), ('HW', c_int32), ('C', c_int32)]
 
 
+class QcaLayer(_S):
+    _fields_ = [('w', c_void_p), ('b', c_void_p), ('gw', c_void_p), ('gb', c_void_p), ('n_prev', c_int32), ('n_out', c_int32), ('cat', c_int32),
+                ('relu_in', c_int32), ('act', c_int32), ('pad_', c_int32)]
+
+
+class QcaArgs(_S):
+    _fields_ = [('layers', QcaLayer * 4), ('nlayers', c_int32), ('N', c_int32), ('C', c_int32), ('M', c_int32), ('ntiles', c_int32),
+                ('nchunks', c_int32), ('inv_hw', c_float), ('scale', c_float), ('pool', c_void_p), ('attr', c_void_p), ('acts', c_void_p),
+                ('gate', c_void_p), ('partial', c_void_p), ('dpool', c_void_p), ('delta', c_void_p)]
+
+
+QCA_ACT_STRIDE = 320
+
+
 class CaFwdFusedArgs(_S):
     _fields_ = [('pool', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mean', c_void_p),
                 ('hidden', c_void_p), ('gate', c_void_p), ('t', c_void_p), ('res', c_void_p), ('out', c_void_p),
@@ -262,6 +276,9 @@ SYMBOLS = {
     'rumpy_ca_mlp_bwd': (C.c_int, [_P(CaMlpBwdArgs), c_void_p]),
     'rumpy_ca_fwd_fused': (C.c_int, [_P(CaFwdFusedArgs), c_void_p]),
     'rumpy_ca_bwd_fused': (C.c_int, [_P(CaBwdFusedArgs), c_void_p]),
+    'rumpy_qca_gate_fwd': (C.c_int, [_P(QcaArgs), c_void_p]),
+    'rumpy_qca_gate_bwd': (C.c_int, [_P(QcaArgs), c_void_p]),
+    'rumpy_qca_bwd_params': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_q_mlp_fwd': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_q_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_ca_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),

@@ -44,6 +44,18 @@ class CALayerParams:
         self.gw1 = self.gb1 = self.gw2 = self.gb2 = None
 
 
+class StyledCAParams:
+    """QCALayer in one of the styles whose gate MLP also takes the attribute vector (attention_manipulators/architectures.py:41-136:
+    'max_concat', 'mini_concat', 'extended_attention', 'softmax'): a list of layers
+    (w [n_out, n_in], b, gw, gb, cat: attributes appended to the input, relu_in: ReLU on the input vector, act: 0 none / 1 ReLU / 2 sigmoid /
+    3 sigmoid + softmax) for rumpy_qca_gate_fwd / _bwd (csrc/qca_style.hip)."""
+
+    def __init__(self, name, layers, num_metadata):
+        self.name, self.layers, self.M = name, layers, num_metadata
+        self.C = layers[-1]['w'].shape[0]
+        self.gen = True
+
+
 class QLayerParams(CALayerParams):
     """Meta-attention q-layer (ParaCALayer, attention_manipulators/q_layer.py:5-45, two FC layers): w1 [Hq,M], w2 [C,Hq]."""
 
@@ -118,6 +130,11 @@ class SREngine:
         # bf16 storage alone costs a >= 30 dB model 0.02-0.03 dB of Y-PSNR against the fp32 reference (fixtures G17 / G18).
         # Training stays bf16 (gradient range).  An output that is not finite (fp16 overflow) switches the engine back to bf16 for good.
         self.eval_fmt = L.FMT_BF16 if os.environ.get('RUMPY_EVAL_BF16') == '1' else L.FMT_F16
+
+        def styled(items):
+            return any((it[0] == 'rcab' and getattr(it[3], 'gen', False)) or (it[0] == 'group' and styled(it[1])) for it in items)
+        if styled(spec.body):
+            self.eval_fmt = L.FMT_BF16      # the separate channel-attention launches of the styled QCALayers are bf16 only
         self.max_eval_plans = max(1, int(os.environ.get('RUMPY_EVAL_PLANS', '4')))     # LRU bound on cached evaluation plans (one per image size)
         # end-of-step housekeeping as two launches (csrc/finish.hip): one reduction launch for all slab kinds, Adam + re-pack in one
         self.use_finish = os.environ.get('RUMPY_NO_FINISH') != '1'
@@ -281,6 +298,7 @@ class SREngine:
         protected = []          # data_ptrs of live skip sources (eval-mode buffer reuse must not recycle them)
         plan.scaled = []
         plan.ca_param_items = []
+        plan.qca_items, plan.qca_dev = [], None      # gate MLPs of the styled QCALayers: parameter gradients in one launch
         plan.q_items, plan.q_shape, plan.q_dev = [], None, None
         plan.rcab_n, plan.rcab_xchg, plan.rcab_epoch, plan.rcab_status = 0, None, None, None
         # device status words read back together: [0] a non-finite output value (rumpy_tail_fwd, evaluation plans), [1] strip-exchange watchdog
@@ -362,6 +380,9 @@ class SREngine:
                                                        gate=_ptr(qg), dzq=_ptr(qdz), gw1=_ptr(q.gw1), gb1=_ptr(q.gb1), gw2=_ptr(q.gw2),
                                                        gb2=_ptr(q.gb2), scale=1.0))
                         plan.q_shape = (q.M, q.Hq)
+                    if getattr(ca, 'gen', False):
+                        cur = self._emit_styled_rcab(plan, fwd, bwd, wjobs, nodes, c1, c2, ca, cur, N, H, W, tiles, train, act, release)
+                        continue
                     t1, t2, y = act(), act(), act()
                     pool = self._new(plan, N, tiles, F, dtype=torch.float32)
                     mean = self._new(plan, N, F, dtype=torch.float32)
@@ -552,6 +573,61 @@ class SREngine:
         self._emit_wgrad(plan, wjobs, N)
         return plan
 
+    def _emit_styled_rcab(self, plan, fwd, bwd, wjobs, nodes, c1, c2, ca, cur, N, H, W, tiles, train, act, release):
+        """A QRCAB whose channel-attention gate also reads the attribute vector (StyledCAParams): the residual block in one launch with pool
+        sums (or two conv launches when W > 48), the gate MLP in its own launch, gate * t2 + x by the streaming kernel; backward in the
+        same pieces.  bf16 plans only (the engine keeps evaluation of such networks in bf16)."""
+        F = self.feats
+        fused = self.use_block_kernel and W <= 48
+        t1, t2, y = act(), act(), act()
+        pool = self._new(plan, N, tiles, F, dtype=torch.float32)
+        acts = self._new(plan, N, L.QCA_ACT_STRIDE, dtype=torch.float32)
+        gate = self._new(plan, N, F, dtype=torch.float32)
+        if fused:
+            fwd.append(('rumpy_conv_block', L.BlockArgs(x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed),
+                                                        mask=None, res2=None, t=_ptr(t1), out=_ptr(t2), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0,
+                                                        res_mode=1, res1=None, pool=_ptr(pool))))
+        else:
+            self._conv(fwd, cur, c1, N, H, W, t1, relu=True)
+            self._conv(fwd, t1, c2, N, H, W, t2, pool=pool)
+
+        def qca_args(**kw):
+            a = L.QcaArgs(nlayers=len(ca.layers), N=N, C=F, M=ca.M, ntiles=tiles, inv_hw=1.0 / (H * W), scale=1.0, attr=_ptr(plan.meta),
+                          acts=_ptr(acts), gate=_ptr(gate), **kw)
+            for i, ly in enumerate(ca.layers):
+                a.layers[i] = L.QcaLayer(w=_ptr(ly['w']), b=_ptr(ly['b']), gw=_ptr(ly['gw']), gb=_ptr(ly['gb']), n_prev=ly['n_prev'],
+                                         n_out=ly['w'].shape[0], cat=ly['cat'], relu_in=ly['relu_in'], act=ly['act'])
+            return a
+        fwd.append(('rumpy_qca_gate_fwd', qca_args(pool=_ptr(pool))))
+        fwd.append(('rumpy_ca_scale_res_fwd', L.CaScaleArgs(t=_ptr(t2), res=_ptr(cur), gate=_ptr(gate), out=_ptr(y), N=N, HW=H * W, C=F)))
+
+        def node(g_out, extra, x_in=cur, t1=t1, t2=t2):
+            nchunks = (H * W + 127) // 128
+            part = self._new(plan, N, nchunks, F, dtype=torch.float32)
+            dpool = self._new(plan, N, F, dtype=torch.float32)
+            delta = self._new(plan, N, L.QCA_ACT_STRIDE, dtype=torch.float32)
+            dt2, dt1, dx = (self._new(plan, N, H, W, F) for _ in range(3))
+            bwd.append(('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=_ptr(g_out), t=_ptr(t2), partial=_ptr(part), N=N, HW=H * W, C=F)))
+            ga = qca_args(partial=_ptr(part), nchunks=nchunks, dpool=_ptr(dpool), delta=_ptr(delta))
+            bwd.append(('rumpy_qca_gate_bwd', ga))
+            plan.qca_items.append(ga)
+            bwd.append(('rumpy_ca_bwd_apply', L.CaBwdApplyArgs(dy=_ptr(g_out), gate=_ptr(gate), dpool=_ptr(dpool), dt=_ptr(dt2), N=N, HW=H * W, C=F)))
+            if fused:
+                bwd.append(('rumpy_conv_block', L.BlockArgs(x=_ptr(dt2), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1),
+                                                            res2=_ptr(extra), t=_ptr(dt1), out=_ptr(dx), N=N, H=H, W=W, relu1=0, scale1=1.0, scale2=1.0,
+                                                            res_mode=2, res1=_ptr(g_out), pool=None)))
+            else:
+                self._conv(bwd, dt2, c2, N, H, W, dt1, dgrad=True, mask=t1)
+                self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
+            wjobs.append((c2, t1, dt2, H, W, 0, 1.0, 4))
+            wjobs.append((c1, x_in, dt1, H, W, 0, 1.0, 4))
+            return dx
+        nodes.append(node)
+        release(t1)
+        release(t2)
+        release(cur)
+        return y
+
     def _add_extra(self, plan, ops, g, extra, N, H, W):
         """g + extra through the CA scale kernel with a unit gate (rare path: group without residual units)."""
         F = self.feats
@@ -688,6 +764,10 @@ class SREngine:
             for a in plan.q_items:
                 a.scale = gs
             self._upload_q_items(plan)
+        if plan.qca_items:
+            for a in plan.qca_items:
+                a.scale = gs
+            plan.qca_dev = self._to_device_bytes((L.QcaArgs * len(plan.qca_items))(*plan.qca_items))
         plan.grad_scale = gs
 
     def _advance_epoch(self, plan, stream):
@@ -832,6 +912,7 @@ class SREngine:
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
         self._q_param_grads(plan, stream)
+        self._qca_param_grads(plan, stream)
         gs = float(grad_scale)
         if on_ready is not None and plan.split is not None:
             sp = plan.split
@@ -919,6 +1000,10 @@ class SREngine:
         plan.graph.replay()
         return plan.out, plan.loss, plan
 
+    def _qca_param_grads(self, plan, stream):
+        if plan.qca_items:
+            L.check(self.lib.rumpy_qca_bwd_params(_ptr(plan.qca_dev), len(plan.qca_items), stream), 'rumpy_qca_bwd_params')
+
     def _ca_param_grads(self, plan, stream):
         if plan.ca_param_items:
             a0 = plan.ca_param_items[0]
@@ -930,6 +1015,7 @@ class SREngine:
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
         self._q_param_grads(plan, stream)
+        self._qca_param_grads(plan, stream)
         if 4 in plan.job_dev:
             dev, n = plan.job_dev[4]
             L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 4, 0, stream), 'rumpy_wgrad_grouped')

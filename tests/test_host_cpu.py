@@ -60,6 +60,7 @@ def test_ctypes_structs_match_the_header_layout():
              'rumpy_ca_fwd_fused_args': _lib.CaFwdFusedArgs, 'rumpy_ca_bwd_fused_args': _lib.CaBwdFusedArgs,
              'rumpy_q_mlp_item': _lib.QMlpItem, 'rumpy_ssim_args': _lib.SsimArgs, 'rumpy_patch_item': _lib.PatchItem, 'rumpy_patch_args': _lib.PatchArgs,
              'rumpy_finish_reduce_args': _lib.FinishReduceArgs, 'rumpy_update_item': _lib.UpdateItem, 'rumpy_adam_pack_args': _lib.AdamPackArgs,
+             'rumpy_qca_layer': _lib.QcaLayer, 'rumpy_qca_args': _lib.QcaArgs,
              'rumpy_dconv_args': _lib.DconvArgs, 'rumpy_dconv_wgrad_args': _lib.DconvWgradArgs, 'rumpy_mse_args': _lib.MseArgs, 'rumpy_op': _lib.Op}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rumpy_amd.h"', 'int main(void){']
     for cname, st in pairs.items():
@@ -367,6 +368,19 @@ def test_qrcan_module_tree_has_the_reference_key_and_creation_order(golden_dir):
     assert qk and all(k.startswith('body.1.body.0.q_node') for k in qk)
     with pytest.raises(RuntimeError):
         QRCAN(style='modulate', **kw)
+
+
+@pytest.mark.parametrize('style', ['max_concat', 'mini_concat', 'extended_attention', 'softmax'])
+def test_styled_qcalayer_module_tree_has_the_reference_keys_and_creation_order(golden_dir, style):
+    """the QCALayer styles whose gate MLP reads the attribute vector: state_dict keys against the REAL reference QRCAN's (golden G19) and the
+    default initialisation under seed 8 against the reference's per-tensor checksums (same creation order -> same weights)"""
+    from rumpy_amd.SISR.models.attention_manipulators.architectures import QRCAN
+    g = np.load(os.path.join(golden_dir, 'g19_qrcan_styles_small_train.npz'))
+    torch.manual_seed(8)
+    net = QRCAN(style=style, include_q_layer=False, num_metadata=5, scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16)
+    assert list(net.state_dict().keys()) == [str(k) for k in g[style + '.keys']]
+    init8 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in net.state_dict().values()])
+    assert np.allclose(init8, g[style + '.init8'], rtol=0, atol=1e-12)
 
 
 def test_qmodel_metadata_vector_follows_the_reference_selection_rules():

@@ -247,6 +247,39 @@ def test_g12_qrcan_meta_attention_oracle_matches_reference_handler(golden_dir):
     assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
 
 
+@pytest.mark.parametrize('si,style', list(enumerate(('max_concat', 'mini_concat', 'extended_attention', 'softmax'))))
+def test_g19_qcalayer_styles_oracle_matches_reference_handler(golden_dir, si, style):
+    """oracle QRCAN with the QCALayer styles whose gate MLP also reads the attribute vector, against three training steps and one evaluation
+    of the REAL reference QRCANHandler per style (tests/golden/make_golden_qrcan_styles.py)."""
+    g = np.load(os.path.join(golden_dir, 'g19_qrcan_styles_small_train.npz'))
+    kw = dict(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style=style, include_q_layer=False, num_metadata=5)
+    net = O.build_oracle('qrcan', **kw)
+    assert list(net.state_dict().keys()) == [str(k) for k in g[style + '.keys']]
+    torch.manual_seed(8)
+    net8 = O.build_oracle('qrcan', **kw)
+    init8 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in net8.state_dict().values()])
+    assert np.allclose(init8, g[style + '.init8'], rtol=0, atol=1e-12)
+    net.load_state_dict(O.seeded_state_dict(net, 900 + si))
+    h = O.OracleHandler(net, lr=1e-3, scheduler='cosine_annealing_warm_restarts',
+                        scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+
+    def meta(seed, n):
+        return torch.from_numpy(np.random.default_rng(seed).uniform(0, 1, (n, 5)).astype(np.float32)).unsqueeze(2).unsqueeze(3)
+    for step in range(3):
+        xb, yb = O.synthetic_batch(910 + 10 * si + step, 2, lr_hw=12, scale=2)
+        loss, out = h.run_train(xb, yb, extra_channels=meta(950 + 10 * si + step, 2))
+        assert abs(float(loss) - float(g['%s.loss%d' % (style, step)])) < 1e-6
+        if step == 0:
+            assert np.allclose(out.numpy(), g[style + '.out0'], atol=1e-6)
+            for k, p in net.named_parameters():
+                assert np.allclose(p.grad.numpy(), g['%s.grad0.%s' % (style, k)], atol=1e-6, rtol=1e-4), k
+    for k, v in net.state_dict().items():
+        assert np.allclose(v.numpy(), g['%s.w3.%s' % (style, k)], atol=2e-6), k
+    xe, ye = O.synthetic_batch(990 + si, 1, lr_hw=10, scale=2)
+    ev, evl, _ = h.run_eval(xe, ye, request_loss=True, extra_channels=meta(995 + si, 1))
+    assert np.allclose(ev.numpy(), g[style + '.eval_out'], atol=1e-6) and abs(float(evl) - float(g[style + '.eval_loss'])) < 1e-6
+
+
 def test_g13_blind_pipeline_oracle_matches_reference_handler(golden_dir):
     """frozen contrastive encoder + QRCAN (OracleBlindPipeline) against three training steps and one evaluation of the REAL reference
     ContrastiveBlindQRCANHandler (tests/golden/make_golden_blind.py) - including the BatchNorm mode the reference actually runs the

@@ -195,7 +195,7 @@ def test_qrcan_default_modulate_style_against_oracle(no_rcab, monkeypatch):
 
 
 def test_unsupported_qrcan_variants_are_refused():
-    for bad in (dict(style='max_concat'), dict(style='modulate', include_q_layer=True), dict(style='standard', include_pixel_attention=True), dict(style='standard', include_sft_layer=True),
+    for bad in (dict(style='no_such_style'), dict(style='modulate', include_q_layer=True), dict(style='standard', include_pixel_attention=True), dict(style='standard', include_sft_layer=True),
                 dict(style='standard', srmd_mode=True), dict(style='standard', use_moco=True)):
         with pytest.raises(RuntimeError):
             define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, n_resgroups=1, n_resblocks=1, **bad)
