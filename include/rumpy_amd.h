@@ -511,6 +511,8 @@ typedef struct {
   int32_t N, H, W;
 } rumpy_eval_post_args;
 int rumpy_eval_post(const rumpy_eval_post_args* a, void* stream);
+/* image save (rumpy/sr_tools/visualization.py:31-62 safe_image_save): [N,C,H,W] fp32 -> [N,H,W,C] uint8 = trunc(clip(v * 255 / max_val, 0, 255)) */
+int rumpy_to_uint8_hwc(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, float max_val, void* stream);
 
 /* ---- device-side training-patch pipeline: crop + flips + transpose + uint8 -> float/255 ----
  * Replaces SuperResImages.__getitem__ / image_augment_crop (rumpy/sr_tools/data_handler.py:570-645),

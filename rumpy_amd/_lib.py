@@ -289,6 +289,7 @@ SYMBOLS = {
     'rumpy_head_wgrad_slabs': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_adam_pack': (C.c_int, [_P(AdamPackArgs), c_void_p]),
     'rumpy_eval_post': (C.c_int, [_P(EvalPostArgs), c_void_p]),
+    'rumpy_to_uint8_hwc': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'rumpy_run_list': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_conv_block': (C.c_int, [_P(BlockArgs), c_void_p]),
     'rumpy_ssim': (C.c_int, [_P(SsimArgs), c_void_p]),

@@ -167,6 +167,25 @@ __global__ void eval_post_kernel(rumpy_eval_post_args a) {
   }
 }
 
+// ---- image save: fp32 planes -> interleaved uint8 (rumpy/sr_tools/visualization.py:56: np.clip(im * 255 / max_val, 0, 255).astype(np.uint8),
+// i.e. TRUNCATION towards zero, after the CHW -> HWC transpose of :53-54) ----
+__global__ void to_uint8_hwc_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, int N, int C, int H, int W, float max_val) {
+  const size_t hw = (size_t)H * W, total = (size_t)N * hw * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t c = i % C, p = (i / C) % hw, n = i / (C * hw);
+    const float v = fminf(fmaxf(src[(n * C + c) * hw + p] * 255.f / max_val, 0.f), 255.f);      // numpy's order: (im * 255) / max_val, both in fp32
+    dst[i] = (unsigned char)(int)v;
+  }
+}
+extern "C" int rumpy_to_uint8_hwc(const float* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, float max_val, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || H <= 0 || W <= 0 || !(max_val > 0.f)) { rumpy_set_error("rumpy_to_uint8_hwc: bad argument"); return RUMPY_E_ARG; }
+  const size_t total = (size_t)N * C * H * W;
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(to_uint8_hwc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned char*)dst, N, C, H, W, max_val);
+  return rumpy_check_launch("rumpy_to_uint8_hwc");
+}
+
 extern "C" int rumpy_adam_step(const rumpy_adam_args* a, void* stream) {
   if (!a || !a->p || !a->g || !a->m || !a->v || a->n <= 0) { rumpy_set_error("rumpy_adam_step: bad argument"); return RUMPY_E_ARG; }
   if (!a->hyper && !(a->hyper_value.bias_c1 > 0.f && a->hyper_value.sqrt_bias_c2 > 0.f)) { rumpy_set_error("rumpy_adam_step: neither a hyper pointer nor by-value hyper-parameters"); return RUMPY_E_ARG; }

@@ -500,3 +500,19 @@ def test_basic_models_resolve_with_the_reference_keys_and_refuse_the_cpu(golden_
             h.run_train(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
         with pytest.raises(RuntimeError):
             h.run_eval(torch.zeros(1, 1, 8, 8))
+
+
+def test_safe_image_save_numpy_path_matches_the_reference_expression(tmp_path):
+    """rumpy/sr_tools/visualization.py:31-62 on host arrays: clip(im * 255 / max_val, 0, 255).astype(uint8) (truncation), CHW -> HWC, files readable"""
+    from PIL import Image
+    from rumpy_amd.sr_tools.visualization import safe_image_save, to_uint8_hwc
+    gen = np.random.default_rng(5)
+    im = gen.uniform(-0.2, 1.2, (2, 3, 9, 13)).astype(np.float32)
+    im[0, 0, 0, 0], im[0, 1, 0, 0], im[0, 2, 0, 0] = 0.999, 254.9999 / 255, 1.0
+    u8 = to_uint8_hwc(im)
+    ref = np.clip(im.transpose(0, 2, 3, 1) * 255 / 1, 0, 255).astype(np.uint8)
+    assert u8.dtype == np.uint8 and np.array_equal(u8, ref) and tuple(u8[0, 0, 0]) == (254, 254, 255)
+    safe_image_save(im, str(tmp_path), ['a.png', 'sub/b.png'], config='rgb')
+    assert np.array_equal(np.asarray(Image.open(tmp_path / 'a.png')), ref[0]) and np.array_equal(np.asarray(Image.open(tmp_path / 'sub' / 'b.png')), ref[1])
+    safe_image_save(torch.from_numpy(im) * 2, str(tmp_path), ['c.png', 'd.png'], config='rgb', max_val=2)
+    assert np.array_equal(np.asarray(Image.open(tmp_path / 'c.png')), ref[0])

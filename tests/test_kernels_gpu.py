@@ -738,3 +738,19 @@ def test_conv_block_mask_bytes_equal_the_activation_mask(N, H, W):
         outs.append((dt1, dx))
     assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
     assert torch.equal(outs[0][1].view(torch.int16), outs[1][1].view(torch.int16))
+
+
+def test_device_image_save_is_the_host_expression(tmp_path):
+    """rumpy_to_uint8_hwc (sr_tools/visualization.py: what saves evaluation outputs that are still on the GPU) against numpy's
+    clip(im * 255 / max_val, 0, 255).astype(uint8) of visualization.py:56 - truncation, values outside [0, max_val], odd sizes, 1 and 3 channels"""
+    from PIL import Image
+    from rumpy_amd.sr_tools.visualization import safe_image_save, to_uint8_hwc
+    gen = np.random.default_rng(6)
+    for shape, mv in (((2, 3, 37, 53), 1), ((1, 1, 5, 7), 1), ((3, 3, 64, 64), 2.5)):
+        im = gen.uniform(-0.3 * mv, 1.3 * mv, shape).astype(np.float32)
+        im.reshape(-1)[:4] = np.array([0.999, 254.9999 / 255, 1.0, 0.5], dtype=np.float32) * mv
+        ref = np.clip(im.transpose(0, 2, 3, 1) * 255 / mv, 0, 255).astype(np.uint8)
+        assert np.array_equal(to_uint8_hwc(torch.from_numpy(im).to(DEV), mv), ref), shape
+    im = gen.uniform(0, 1, (2, 3, 20, 30)).astype(np.float32)
+    safe_image_save(torch.from_numpy(im).to(DEV), str(tmp_path), ['x.png', 'y.png'], config='rgb')
+    assert np.array_equal(np.asarray(Image.open(tmp_path / 'y.png')), np.clip(im[1].transpose(1, 2, 0) * 255, 0, 255).astype(np.uint8))
