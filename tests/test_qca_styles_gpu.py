@@ -125,3 +125,9 @@ def test_styled_qrcan_train_steps_and_eval_against_oracle(style):
     ev, evl, _ = h.run_eval(x=xe, y=ye, request_loss=True, metadata=me, metadata_keys=keys)
     oev, oevl, _ = oh.run_eval(xe, ye, request_loss=True, extra_channels=me.unsqueeze(2).unsqueeze(3))
     assert self_psnr(ev, oev) >= 45.0 and abs(float(evl) - float(oevl)) < 1e-2 * float(oevl)
+    # a wide image (W > 48): the conv pair runs as two strip launches with pool sums, the gate path is the same
+    xw, yw = O.synthetic_batch(852, 1, lr_hw=(13, 70), scale=2)
+    mw = _meta(853, 1, len(names))
+    ew, ewl, _ = h.run_eval(x=xw, y=yw, request_loss=True, metadata=mw, metadata_keys=keys)
+    oew, oewl, _ = oh.run_eval(xw, yw, request_loss=True, extra_channels=mw.unsqueeze(2).unsqueeze(3))
+    assert self_psnr(ew, oew) >= 45.0 and abs(float(ewl) - float(oewl)) < 1e-2 * float(oewl)
