@@ -233,6 +233,10 @@ typedef struct {
 /* variant 0 = streaming LDS-DMA kernel (mt == 1 needs an even image width: its dy pieces are pixel pairs);
  * variant 1 = register-staged kernel (any width; also the A/B reference) */
 int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t njobs, int32_t mt, int32_t variant, void* stream);
+/* The same jobs (mt = 4, streaming kernel) as per-workgroup LISTS: workgroup w of `nshares` runs jobs first[w] .. first[w+1]-1 one after the
+ * other (first: DEVICE array of nshares + 1 offsets into jobs_device).  The engine cuts the cost-weighted concatenated tile sequence of all
+ * layers into equal shares, one per CU; a share's part of one layer is one job with its own slab. */
+int rumpy_wgrad_shares(const rumpy_wgrad_job* jobs_device, const int32_t* first_device, int32_t nshares, void* stream);
 int64_t rumpy_wgrad_slab_floats(int32_t mt);
 
 typedef struct {

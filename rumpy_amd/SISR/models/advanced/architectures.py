@@ -233,6 +233,9 @@ class HipSRNet(nn.Module):
             out, loss, plan = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous(), meta=self._meta_matrix(metadata, x))
             self._stage_loss(loss, plan.rcab_status)       # the replay's loss and strip-exchange watchdog word, fenced like the eager path's
             return loss, out
+        if getattr(self, 'grad_ready_hook', None) is not None:
+            self._ensure_engine()
+            self.engine.set_two_phase()       # data-parallel form: the weight-gradient shares are cut per gradient-buffer half (plans rebuilt once)
         out, loss, plan = self.engine_forward(x, train=True, target=y.float().contiguous(), meta=metadata)
         # The loss is final once the forward pass has run: its read-back is queued HERE (pinned buffer + event), ahead of the
         # backward launches, so that run_train's `loss.cpu().numpy()` (the reference API returns the loss of every step,

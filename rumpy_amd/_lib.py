@@ -267,6 +267,7 @@ SYMBOLS = {
     'rumpy_tail_dgrad': (C.c_int, [_P(TailDgradArgs), c_void_p]),
     'rumpy_nchw_to_nhwc4': (C.c_int, [_P(NchwToNhwc4Args), c_void_p]),
     'rumpy_wgrad_grouped': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'rumpy_wgrad_shares': (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
     'rumpy_wgrad_slab_floats': (c_int64, [c_int32]),
     'rumpy_wgrad_reduce': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_pack_weights': (C.c_int, [c_void_p, c_int32, c_void_p]),

@@ -112,18 +112,20 @@ __device__ __forceinline__ void tile_issue(const DmaJob& j, const PieceGeom (&pg
   }
 }
 
+// one job (a tile range of one layer / cin chunk / cout tile) -> its slab; called by all 512 threads of a workgroup
 template <int MT>
-__global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job* __restrict__ jobs) {
+__device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict__ jp) {
   constexpr int DSTAGE = DmaCfg<MT>::STAGE;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[DmaCfg<MT>::LDS];
-  const rumpy_wgrad_job* jp = jobs + blockIdx.x;
   DmaJob j;
   j.x = (const uint16_t*)jp->x; j.dy = (const uint16_t*)jp->dy; j.n0 = jp->n0; j.H = jp->H; j.W = jp->W;
   j.x_cstride = jp->x_cstride; j.x_coff = jp->x_coff; j.dy_mode = jp->dy_mode; j.dy_cstride = jp->dy_cstride; j.dy_coff = jp->dy_coff;
   j.tiles_x = (j.W + TW - 1) / TW; j.tiles_y = (j.H + TH - 1) / TH;
   const int t0 = jp->t0, ntiles = jp->t1 - jp->t0;
   float* slab = jp->slab;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));       // opaque per job: the per-lane read offsets and piece geometry are recomputed, not kept across the job loop (93 spills otherwise)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w4 = wave & 3, kh = wave >> 2;
   const int g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;
   const unsigned lds0 = (unsigned)(size_t)(lds_u8)lds;
@@ -248,8 +250,24 @@ __global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job
   }
 }
 
+// first == NULL: one job per workgroup (grid = jobs).  first != NULL: workgroup w runs jobs first[w] .. first[w+1]-1 one after the other -
+// the engine cuts the cost-weighted concatenated tile sequence of all layers into equal shares, one per CU; a share may end one layer and
+// begin the next (a job = a share's part of one layer, with its own slab).
+template <int MT>
+__global__ void __launch_bounds__(512, 2) wgrad_dma_kernel(const rumpy_wgrad_job* __restrict__ jobs, const int* __restrict__ first) {
+  const int j0 = first ? first[blockIdx.x] : (int)blockIdx.x, j1 = first ? first[blockIdx.x + 1] : (int)blockIdx.x + 1;
+  for (int j = j0; j < j1; ++j) {
+    if (j > j0) __syncthreads();          // the previous job's K-half / bias exchange used the ring's LDS
+    wgrad_dma_job<MT>(jobs + j);
+  }
+}
+
 int rumpy_wgrad_dma_launch(const rumpy_wgrad_job* jobs_device, int njobs, int mt, hipStream_t s) {
-  if (mt == 4) hipLaunchKernelGGL(wgrad_dma_kernel<4>, dim3(njobs), dim3(512), 0, s, jobs_device);
-  else hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(njobs), dim3(512), 0, s, jobs_device);
+  if (mt == 4) hipLaunchKernelGGL(wgrad_dma_kernel<4>, dim3(njobs), dim3(512), 0, s, jobs_device, (const int*)nullptr);
+  else hipLaunchKernelGGL(wgrad_dma_kernel<1>, dim3(njobs), dim3(512), 0, s, jobs_device, (const int*)nullptr);
+  return 0;
+}
+int rumpy_wgrad_dma_launch_shares(const rumpy_wgrad_job* jobs_device, const int* first_device, int nshares, hipStream_t s) {
+  hipLaunchKernelGGL(wgrad_dma_kernel<4>, dim3(nshares), dim3(512), 0, s, jobs_device, first_device);
   return 0;
 }

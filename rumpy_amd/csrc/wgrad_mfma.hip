@@ -205,6 +205,16 @@ __global__ void wgrad_reduce_kernel(const rumpy_reduce_item* __restrict__ items)
 extern "C" int64_t rumpy_wgrad_slab_floats(int32_t mt) { return (int64_t)16 * mt * 576 + 16 * mt; }
 
 int rumpy_wgrad_dma_launch(const rumpy_wgrad_job* jobs_device, int njobs, int mt, hipStream_t s);   // wgrad_dma.hip
+int rumpy_wgrad_dma_launch_shares(const rumpy_wgrad_job* jobs_device, const int* first_device, int nshares, hipStream_t s);
+
+extern "C" int rumpy_wgrad_shares(const rumpy_wgrad_job* jobs_device, const int32_t* first_device, int32_t nshares, void* stream) {
+  if (!jobs_device || !first_device || nshares <= 0) { rumpy_set_error("rumpy_wgrad_shares: bad argument"); return RUMPY_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  rumpy_probe_pre(2, s);
+  rumpy_wgrad_dma_launch_shares(jobs_device, first_device, nshares, s);
+  rumpy_probe_post(2, s);
+  return rumpy_check_launch("rumpy_wgrad_shares");
+}
 
 extern "C" int rumpy_wgrad_grouped(const rumpy_wgrad_job* jobs_device, int32_t njobs, int32_t mt, int32_t variant, void* stream) {
   if (!jobs_device || njobs <= 0 || (mt != 1 && mt != 4)) { rumpy_set_error("rumpy_wgrad_grouped: bad argument"); return RUMPY_E_ARG; }

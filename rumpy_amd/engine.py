@@ -123,6 +123,15 @@ class SREngine:
         self.plans = {}
         self._tables = {}      # id(launch list) -> (list, ctypes table, its address, length)
         self.wgrad_pixels_per_job = int(os.environ.get('RUMPY_WGRAD_PIXELS', wgrad_pixels_per_job))    # env: A/B runs of the job size
+        # Weight-gradient work as equal SHARES of the concatenated tile sequence of all 64-channel layers, one share per CU (rumpy_wgrad_shares:
+        # a workgroup runs its share's jobs one after the other; 477 equal jobs on 256 CUs took two rounds of 64 tiles where the average is
+        # 119, and left one slab per job to reduce: 288 -> 262 us for the launch, 34 -> 18 us for the reduction).  RUMPY_WGRAD_JOBS=1: fixed-size
+        # jobs, one workgroup each (A/B).  Every tile costs the same (weighting the gathered upsampler layers differently was slower either
+        # way).  two_phase: the shares are cut separately for the layers of the upper and of the lower part of the gradient buffer, so that the
+        # data-parallel form (upper part first, its all-reduce under the rest) and the one-launch form run the SAME jobs: bitwise equal
+        # gradients.  Set by the first backward pass with a gradient-ready hook / RUMPY_WGRAD_AB=1.
+        self.wgrad_shares = os.environ.get('RUMPY_WGRAD_JOBS') != '1'
+        self.wgrad_two_phase = os.environ.get('RUMPY_WGRAD_AB') == '1'
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
@@ -646,17 +655,63 @@ class SREngine:
         # first pass: count slabs
         layout = []
         total = 0
+        ntiles_of = lambda H, W: N * ((H + L.TILE_H - 1) // L.TILE_H) * ((W + L.TILE_W - 1) // L.TILE_W)
+        # ---- shares (mt = 4 units only): group the units (two_phase: layers at / above the split pointer = group 0, finished first), cut each
+        # group's tile sequence into `cus` equal shares; a unit's ranges are its intersections with the shares ----
+        units4 = [(cv, ch, ct, ntiles_of(H, W), 1)
+                  for (cv, x, dy, H, W, dy_mode, scale, mt) in wjobs if mt == 4 for ch in range(cv.cin // 64) for ct in range(cv.cout // 64)]
+        share_ranges, share_split_ptr, share_counts = None, None, None
+        if self.wgrad_shares and units4:
+            group_of = [0] * len(units4)
+            if self.wgrad_two_phase:
+                per_layer = {}
+                for cv, ch, ct, nt, wt in units4:
+                    per_layer[_ptr(cv.gw)] = per_layer.get(_ptr(cv.gw), 0) + nt
+                if len(per_layer) >= 2:
+                    tot, acc = sum(per_layer.values()), 0
+                    for ptr in sorted(per_layer, reverse=True):
+                        acc += per_layer[ptr]
+                        share_split_ptr = ptr
+                        if 2 * acc >= tot:
+                            break
+                    group_of = [0 if _ptr(u[0].gw) >= share_split_ptr else 1 for u in units4]
+                    if len(set(group_of)) < 2:
+                        group_of, share_split_ptr = [0] * len(units4), None
+            share_ranges, share_counts, base_share = [None] * len(units4), {}, 0
+            for grp in sorted(set(group_of)):
+                idx = [i for i in range(len(units4)) if group_of[i] == grp]
+                T = sum(units4[i][3] for i in idx)
+                nsh = max(1, min(self.cus, T))
+                pos = 0
+                for i in idx:
+                    nt, rs, t = units4[i][3], [], 0
+                    while t < nt:                      # share k covers tiles [k T / nsh, (k+1) T / nsh) of the group's sequence
+                        k = min(nsh - 1, ((pos + t + 1) * nsh - 1) // T)
+                        t1 = min(nt, max(t + 1, ((k + 1) * T + nsh - 1) // nsh - pos))
+                        rs.append((t, t1, base_share + k))
+                        t = t1
+                    share_ranges[i] = rs
+                    pos += nt
+                share_counts[grp] = (base_share, nsh)
+                base_share += nsh
+        u4 = 0
         for (cv, x, dy, H, W, dy_mode, scale, mt) in wjobs:
-            # split the layer's N*tiles_y*tiles_x pixel tiles into jobs of about wgrad_pixels_per_job pixels
-            ntile = N * ((H + L.TILE_H - 1) // L.TILE_H) * ((W + L.TILE_W - 1) // L.TILE_W)
+            # split the layer's N*tiles_y*tiles_x pixel tiles into jobs of about wgrad_pixels_per_job pixels (fixed-size jobs), or take the
+            # unit's share ranges
+            ntile = ntiles_of(H, W)
             per = max(1, self.wgrad_pixels_per_job // (L.TILE_H * L.TILE_W))
             njob = max(1, (ntile + per - 1) // per)
             per = (ntile + njob - 1) // njob
-            ranges = [(t0, min(ntile, t0 + per)) for t0 in range(0, ntile, per)]
+            fixed = [(t0, min(ntile, t0 + per), -1) for t0 in range(0, ntile, per)]
             cin_chunks = cv.cin // 64
             cout_tiles = cv.cout // 64 if mt == 4 else 1
             for ch in range(cin_chunks):
                 for ct in range(cout_tiles):
+                    ranges = fixed
+                    if mt == 4 and share_ranges is not None:
+                        ranges = share_ranges[u4]
+                    if mt == 4:
+                        u4 += 1
                     layout.append((cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, total))
                     total += len(ranges) * slab_floats[mt]
         slabs = self._new(plan, max(total, 1), dtype=torch.float32)
@@ -664,7 +719,7 @@ class SREngine:
         keyed = {4: [], 1: []}
         for li, (cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, off) in enumerate(layout):
             sf = slab_floats[mt]
-            for k, (t0, t1) in enumerate(ranges):
+            for k, (t0, t1, share) in enumerate(ranges):
                 if dy_mode == 0:
                     dcs, dco = cv.cout, ct * 64
                 elif dy_mode == 1:
@@ -673,7 +728,7 @@ class SREngine:
                     dcs, dco = 4, 0
                 # launch order: jobs that read the same x tiles (the cout tiles of one tile range) sit next to each other,
                 # so the x halo re-reads of an upsampler conv hit L2; slab addresses do not depend on the order
-                keyed[mt].append(((id(x), k, li), L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=0, n1=N,
+                keyed[mt].append(((id(x), k, li, share), L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=0, n1=N,
                                                               t0=t0, t1=t1, H=H, W=W, x_cstride=cv.cin, x_coff=ch * 64, dy_mode=dy_mode,
                                                               dy_cstride=dcs, dy_coff=dco, mt=mt)))
             items.append(L.ReduceItem(slab=base + 4 * off, slab_stride=sf, njobs=len(ranges), mt=mt,
@@ -685,6 +740,20 @@ class SREngine:
             for key, _ in keyed[mt]:
                 first_seen.setdefault(key[0], len(first_seen))
             jobs[mt] = [jb for _, jb in sorted(keyed[mt], key=lambda kj: (first_seen[kj[0][0]], kj[0][1], kj[0][2]))]
+        plan.shares = None
+        if share_ranges is not None:
+            # jobs in share order (within a share: layer order); first[s] = index of share s's first job
+            order = sorted(keyed[4], key=lambda kj: (kj[0][3], kj[0][2]))
+            jobs[4] = [jb for _, jb in order]
+            nshares = sum(n for _, n in share_counts.values())
+            first = [0] * (nshares + 1)
+            for key, _ in order:
+                first[key[3] + 1] += 1
+            for k in range(nshares):
+                first[k + 1] += first[k]
+            first_dev = torch.tensor(first, dtype=torch.int32, device=self.device)
+            plan.keep.append(first_dev)
+            plan.shares = dict(first=first_dev, n=nshares, groups=share_counts)
         plan.reduce_scales = [it.scale for it in items]
         plan.reduce_host = (L.ReduceItem * len(items))(*items)
         plan.reduce_dev = torch.empty(C.sizeof(plan.reduce_host), dtype=torch.uint8, device=self.device)
@@ -708,7 +777,17 @@ class SREngine:
         for it in items:
             if it.mt == 4:
                 per_layer[it.gw] = per_layer.get(it.gw, 0) + it.njobs
-        if len(per_layer) >= 2:
+        if plan.shares is not None:
+            if share_split_ptr is not None:           # two groups of shares: the same job table, two windows of `first`
+                in_a = lambda idx: items[idx].gw >= share_split_ptr
+                idx_a = [i for i in range(len(items)) if in_a(i)]
+                idx_b = [i for i in range(len(items)) if not in_a(i)]
+                mk = lambda n: torch.empty(max(1, n) * C.sizeof(L.ReduceItem), dtype=torch.uint8, device=self.device)
+                plan.split = dict(ptr=share_split_ptr, shares_a=share_counts[0], shares_b=share_counts[1], idx_a=idx_a,
+                                  idx_a_notail=[i for i in idx_a if items[i].mt != 1], idx_b=idx_b,
+                                  red_a=mk(len(idx_a)), red_a_notail=mk(len(idx_a)), red_b=mk(len(idx_b)))
+                plan.keep += [plan.split['red_a'], plan.split['red_a_notail'], plan.split['red_b']]
+        elif len(per_layer) >= 2:
             total4, acc4, split_ptr = sum(per_layer.values()), 0, None
             for ptr in sorted(per_layer, reverse=True):
                 acc4 += per_layer[ptr]
@@ -916,25 +995,47 @@ class SREngine:
         gs = float(grad_scale)
         if on_ready is not None and plan.split is not None:
             sp = plan.split
-            L.check(self.lib.rumpy_wgrad_grouped(_ptr(sp['jobs_a'][0]), sp['jobs_a'][1], 4, 0, stream), 'rumpy_wgrad_grouped')
+            self._wgrad4(plan, stream, 'a')
             if 1 in plan.job_dev and not tail_done:
                 dev, n = plan.job_dev[1]
                 L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 1, 1 if plan.HR[1] % 2 else 0, stream), 'rumpy_wgrad_grouped')
             idx = sp['idx_a_notail'] if tail_done else sp['idx_a']
             self._reduce(plan, stream, sp['red_a_notail'] if tail_done else sp['red_a'], len(idx), gs, tail=tail_done, head=False)
             on_ready(sp['ptr'])
-            L.check(self.lib.rumpy_wgrad_grouped(_ptr(sp['jobs_b'][0]), sp['jobs_b'][1], 4, 0, stream), 'rumpy_wgrad_grouped')
+            self._wgrad4(plan, stream, 'b')
             self._reduce(plan, stream, sp['red_b'], len(sp['idx_b']), gs, tail=False, head=True)
             return
-        for mt in (4, 1):
-            if mt in plan.job_dev and not (mt == 1 and tail_done):
-                dev, n = plan.job_dev[mt]
-                variant = 1 if (mt == 1 and plan.HR[1] % 2) else 0     # dy4 pixel-pair DMA needs an even width
-                L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, mt, variant, stream), 'rumpy_wgrad_grouped')
+        if 4 in plan.job_dev:
+            self._wgrad4(plan, stream)
+        if 1 in plan.job_dev and not tail_done:
+            dev, n = plan.job_dev[1]
+            L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 1, 1 if plan.HR[1] % 2 else 0, stream), 'rumpy_wgrad_grouped')      # dy4 pixel-pair DMA needs an even width
         if tail_done:
             self._reduce(plan, stream, plan.reduce_dev_notail, len(plan.reduce_keep), gs, tail=True, head=True)
         else:
             self._reduce(plan, stream, plan.reduce_dev, plan.n_reduce, gs, tail=False, head=True)
+
+    def _wgrad4(self, plan, stream, group=None):
+        """the weight-gradient launch of the 64-channel layers: all of them, or group 'a' / 'b' of a two-phase plan"""
+        dev, n = plan.job_dev[4]
+        if plan.shares is not None:
+            lo, cnt = (0, plan.shares['n']) if group is None else plan.split['shares_' + group]
+            L.check(self.lib.rumpy_wgrad_shares(_ptr(dev), plan.shares['first'].data_ptr() + 4 * lo, cnt, stream), 'rumpy_wgrad_shares')
+        elif group is None:
+            L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 4, 0, stream), 'rumpy_wgrad_grouped')
+        else:
+            gd, gn = plan.split['jobs_' + group]
+            L.check(self.lib.rumpy_wgrad_grouped(_ptr(gd), gn, 4, 0, stream), 'rumpy_wgrad_grouped')
+
+    def set_two_phase(self):
+        """from now on training plans cut the weight-gradient shares per gradient-buffer half (data-parallel runs); existing ones are dropped"""
+        if self.wgrad_two_phase or not self.wgrad_shares:
+            return
+        self.wgrad_two_phase = True
+        for k in [k for k in self.plans if k[3]]:
+            old = self.plans.pop(k)
+            for ops in (old.fwd, old.bwd):
+                self._tables.pop(id(ops), None)
 
     def _reduce(self, plan, stream, items_dev, nitems, grad_scale, tail, head):
         """Slab reductions -> parameter gradients: `nitems` entries of the grouped weight-gradient table, the fused tail conv's slabs
@@ -1017,6 +1118,5 @@ class SREngine:
         self._q_param_grads(plan, stream)
         self._qca_param_grads(plan, stream)
         if 4 in plan.job_dev:
-            dev, n = plan.job_dev[4]
-            L.check(self.lib.rumpy_wgrad_grouped(_ptr(dev), n, 4, 0, stream), 'rumpy_wgrad_grouped')
+            self._wgrad4(plan, stream)
         self._reduce(plan, stream, plan.reduce_dev_notail, len(plan.reduce_keep), float(plan.grad_scale), tail=True, head=True)

@@ -197,9 +197,10 @@ def hip_conv(x, pc, N, H, W, dgrad=False, relu=False, scale=1.0, mask=None, res1
     return out, pl
 
 
-def hip_wgrad(jobs_spec, mt, reduce_spec, gw, gb, variant=0):
+def hip_wgrad(jobs_spec, mt, reduce_spec, gw, gb, variant=0, shares=None):
     """jobs_spec: list of dict(x, dy, n0, n1, H, W, x_cstride, x_coff, dy_mode, dy_cstride, dy_coff);
-    reduce_spec: list of dict(first_job, njobs, co_count, co_mode, co_off, ci_total, ci_off, write_bias, scale)."""
+    reduce_spec: list of dict(first_job, njobs, co_count, co_mode, co_off, ci_total, ci_off, write_bias, scale);
+    shares: None (one job per workgroup, rumpy_wgrad_grouped) or the list of first-job offsets of rumpy_wgrad_shares."""
     lib = L.lib()
     sf = int(lib.rumpy_wgrad_slab_floats(mt))
     slabs = torch.full((len(jobs_spec) * sf,), float('nan'), dtype=torch.float32, device=DEV)
@@ -211,7 +212,11 @@ def hip_wgrad(jobs_spec, mt, reduce_spec, gw, gb, variant=0):
                                H=j['H'], W=j['W'], x_cstride=j['x_cstride'], x_coff=j['x_coff'], dy_mode=j['dy_mode'],
                                dy_cstride=j['dy_cstride'], dy_coff=j['dy_coff'], mt=mt))
     jd = to_dev_bytes((L.WgradJob * len(jobs))(*jobs))
-    L.check(lib.rumpy_wgrad_grouped(jd.data_ptr(), len(jobs), mt, variant, stream()), 'wgrad')
+    if shares is None:
+        L.check(lib.rumpy_wgrad_grouped(jd.data_ptr(), len(jobs), mt, variant, stream()), 'wgrad')
+    else:
+        fd = torch.tensor(shares, dtype=torch.int32, device=DEV)
+        L.check(lib.rumpy_wgrad_shares(jd.data_ptr(), fd.data_ptr(), len(shares) - 1, stream()), 'wgrad shares')
     items = []
     for r in reduce_spec:
         items.append(L.ReduceItem(slab=slabs.data_ptr() + 4 * r['first_job'] * sf, slab_stride=sf, njobs=r['njobs'], mt=mt,

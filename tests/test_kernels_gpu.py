@@ -492,6 +492,23 @@ def test_wgrad_jobs_split_by_tile_subranges():
     assert_f32_close(gb, rb, 'bgrad tile sub-ranges', rel=1e-4)
 
 
+def test_wgrad_shares_run_job_lists_bitwise_like_one_job_per_workgroup():
+    """rumpy_wgrad_shares: a workgroup runs a LIST of jobs (here of two layers with different shapes, incl. an empty share and a share
+    that ends one layer and begins the next) - every slab equals the one-job-per-workgroup launch's bit for bit"""
+    gen = np.random.default_rng(29)
+    N = 2
+    xa, ga = nhwc(_rand(gen, N, 64, 20, 40)), nhwc(_rand(gen, N, 64, 20, 40))        # 18 tiles
+    xb, gb_ = nhwc(_rand(gen, N, 64, 9, 17)), nhwc(_rand(gen, N, 64, 9, 17))         # 8 tiles
+    mk = lambda x, dy, H, W, a, b: dict(x=x, dy=dy, n0=0, n1=N, t0=a, t1=b, H=H, W=W, x_cstride=64, x_coff=0, dy_mode=0, dy_cstride=64, dy_coff=0)
+    jobs = [mk(xa, ga, 20, 40, 0, 7), mk(xa, ga, 20, 40, 7, 13), mk(xa, ga, 20, 40, 13, 18), mk(xb, gb_, 9, 17, 0, 3), mk(xb, gb_, 9, 17, 3, 8)]
+    red = [dict(first_job=0, njobs=3, co_count=64, co_mode=0, co_off=0, ci_total=64, ci_off=0, write_bias=1, scale=1.0)]
+    gw1, gb1 = torch.zeros(64, 64, 3, 3, device=DEV), torch.zeros(64, device=DEV)
+    gw2, gb2 = torch.zeros(64, 64, 3, 3, device=DEV), torch.zeros(64, device=DEV)
+    s1 = hip_wgrad(jobs, 4, red, gw1, gb1)
+    s2 = hip_wgrad(jobs, 4, red, gw2, gb2, shares=[0, 1, 1, 4, 5])          # shares: [job 0], [], [jobs 1-3: two layers], [job 4]
+    assert torch.equal(s1.view(torch.int32), s2.view(torch.int32)) and torch.equal(gw1, gw2) and torch.equal(gb1, gb2)
+
+
 def _chain_reference_and_run(N, H, W, nlayers, seed):
     """Run a chain of 64->64 convs (alternating ResBlock-style epilogues) once through rumpy_conv_chain and once layer by
     layer through rumpy_conv3x3; returns the two lists of outputs."""

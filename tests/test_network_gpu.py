@@ -579,6 +579,8 @@ def test_two_phase_weight_gradient_is_bitwise_the_single_launch_one(name, kw):
     x, y = O.synthetic_batch(680, 4, lr_hw=24, scale=sc)
     xd, yd = x.cuda(), y.cuda()
     net = h.net
+    net._ensure_engine()
+    net.engine.set_two_phase()            # the plan form data-parallel runs use: the same jobs serve the one-launch and the two-phase pass
     net.fused_l1_forward_backward(xd, yd)
     torch.cuda.synchronize()
     ref = net.flat_g.detach().clone()
@@ -677,8 +679,10 @@ def test_bench_runs_over_rccl_with_one_rank(model):
     assert p.returncode == 0, out[-3000:]
     assert 'RCCL gradient all-reduce' in out, out[-3000:]
     d = json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][0])
+    # the plain run with the plan form of data-parallel runs (weight-gradient shares cut per gradient-buffer half: RUMPY_WGRAD_AB=1), so
+    # that both runs execute the same jobs; the default one-launch plans cut all layers together (another fp32 summation order)
     q = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       timeout=600, cwd=root)
+                       timeout=600, cwd=root, env=dict(os.environ, RUMPY_WGRAD_AB='1'))
     assert q.returncode == 0, q.stdout.decode()[-3000:]
     e = json.loads([l for l in q.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
     assert d['n_gpus'] == 1 and d['value'] > 0
