@@ -681,7 +681,7 @@ class SREngine:
             for grp in sorted(set(group_of)):
                 idx = [i for i in range(len(units4)) if group_of[i] == grp]
                 T = sum(units4[i][3] for i in idx)
-                nsh = max(1, min(self.cus, T))
+                nsh = max(1, min(int(os.environ.get('RUMPY_WGRAD_NSH', self.cus)), T))      # env: A/B runs of the share count
                 pos = 0
                 for i in idx:
                     nt, rs, t = units4[i][3], [], 0
