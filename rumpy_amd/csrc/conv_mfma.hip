@@ -190,31 +190,32 @@ __device__ __forceinline__ bf16x8 tail_tr8(unsigned addr, unsigned second) {    
 template <bool WGRAD, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
-  __shared__ __attribute__((aligned(16))) unsigned char ldy[TH * TW * 8 + 16];      // sign gradient of the tile [px][4 ch] bf16 + 16 zero bytes
+  // WGRAD: the tile's sign gradient as THREE shifted copies [kx][halo index h][4 ch] bf16, entry h = r * 18 + c + kx = dy(r, c) (zero elsewhere;
+  // 160 entries = 5 MFMA K steps) + 16 zero bytes: against input rows ky .. ky + 7 of the halo tile (flattened index ky * 18 + h) the MFMA rows
+  // (kx, channel) give all three taps of a filter row at once - 15 MFMAs and 35 LDS reads per tile where one tap per MFMA took 36 and 80
+  constexpr int DYC = 160 * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char ldy[WGRAD ? 3 * DYC + 16 : 16];
   __shared__ float red[4];
   __shared__ float redb[4][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  // forward filter: stationary in 72 VGPRs, or - WGRAD, where 36 accumulator registers are needed on top - in 18 KB of LDS
-  // (18 extra fragment reads per tile)
-  __shared__ __attribute__((aligned(16))) uint4 ldf[WGRAD ? 18 * 64 : 1];
-  bf16x8 F[WGRAD ? 1 : 18];
-  if (WGRAD) {
-    for (int i = tid; i < 18 * 64; i += 256) ldf[i] = a.w[i];
-  } else {
+  // forward filter: stationary in 72 VGPRs (round 2: in the WGRAD form too - its weight-gradient accumulators shrank from 36 to 12 registers;
+  // the filter used to sit in 18 KB of LDS there, one more fragment read per MFMA)
+  bf16x8 F[18];
 #pragma unroll
-    for (int s = 0; s < 18; ++s) F[WGRAD ? 0 : s] = as_bf16x8(a.w[s * 64 + lane]);
-  }
+  for (int s = 0; s < 18; ++s) F[s] = as_bf16x8(a.w[s * 64 + lane]);
   float bj[4] = {0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < a.C; ++j) bj[j] = a.bias[j];
   float lsum = 0.f;
   unsigned bad = 0u;
-  f32x4 wacc[WGRAD ? 9 : 1];
+  f32x4 wacc[WGRAD ? 3 : 1];            // per filter row ky: D rows (kx, channel) x 16 input channels of this wave
 #pragma unroll
-  for (int t = 0; t < (WGRAD ? 9 : 1); ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < (WGRAD ? 3 : 1); ++t) wacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  if (WGRAD && tid < 4) *reinterpret_cast<unsigned*>(ldy + TH * TW * 8 + tid * 4) = 0u;
+  if (WGRAD) {                          // entries no tile pixel maps to stay zero for the whole kernel; every other one is rewritten per tile
+    for (int i = tid; i < (3 * DYC + 16) / 4; i += 256) *reinterpret_cast<unsigned*>(ldy + i * 4) = 0u;
+  }
 
   // Register-staged input pipeline, TWO tiles deep: while tile t is multiplied out of LDS, tile t+1 sits in registers (its
   // loads were issued one iteration ago) and the loads of tile t+2 are issued - every load has two iterations to land, so
@@ -270,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < 2; ++r)
-            acc[r] = mfma16<FMT>(WGRAD ? as_bf16x8(ldf[WGRAD ? ((ky * 3 + kx) * 2 + half) * 64 + lane : 0]) : F[WGRAD ? 0 : (ky * 3 + kx) * 2 + half], I[r + ky], acc[r]);
+            acc[r] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r]);
       }
     // all target values are consumed BEFORE the first store: with loads and stores pending together the compiler's
     // s_waitcnt bookkeeping (gfx9: one vmcnt, loads and stores may retire out of order) falls back to draining everything
@@ -314,8 +315,10 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
           *reinterpret_cast<uint2*>(a.dy4 + ((size_t)(tc.n * a.H + y) * a.W + xx) * 4) = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
         }
       }
-      if (WGRAD && g == 0) {          // the tile's sign gradient in LDS (zero outside the image), and its per-channel sums (bias gradient)
-        *reinterpret_cast<uint2*>(ldy + ((2 * wave + r) * TW + px) * 8) = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
+      if (WGRAD && g == 0) {          // the tile's sign gradient into its three shifted copies (zero outside the image), and its per-channel sums (bias gradient)
+        const uint2 d4 = pack4_bf16(sg[0], sg[1], sg[2], sg[3]);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) *reinterpret_cast<uint2*>(ldy + kx * DYC + ((2 * wave + r) * HALO_W + px + kx) * 8) = d4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) bsum[j] += sg[j];
       }
@@ -324,18 +327,19 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
       __syncthreads();                // the whole tile's sign gradient is in LDS
       const unsigned xb = (unsigned)(size_t)(tail_lds_u8)cur, yb = (unsigned)(size_t)(tail_lds_u8)ldy;
       const int qq = (lane >> 2) & 3, p4 = lane & 3;
+      const unsigned chan = (unsigned)((2 * wave + (p4 >> 1)) * 16 + (p4 & 1) * 8);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {          // 32 pixels (2 rows x 16) per MFMA K step
-        const int rsel = 2 * ks + (g >> 1), col0 = 4 * (g & 1) + qq;
-        // A = dy^T: rows = output channels (only lanes p4 == 0 carry the 4 real ones, the others read zeros)
-        const bf16x8 A = tail_tr8(yb + ((p4 == 0) ? (unsigned)((rsel * TW + col0) * 8) : (unsigned)(TH * TW * 8)), (p4 == 0) ? 64u : 0u);
+      for (int ks = 0; ks < 5; ++ks) {          // 32 halo-index entries per MFMA K step
+        const int h = 32 * ks + 16 * (g >> 1) + 4 * (g & 1) + qq;
+        // A rows = (kx = p4, channel): lanes p4 < 3 read their copy, p4 = 3 the zero bytes
+        const bf16x8 A = tail_tr8(yb + ((p4 < 3) ? (unsigned)(p4 * DYC + h * 8) : (unsigned)(3 * DYC)), (p4 < 3) ? 64u : 0u);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - 3 * ky;
-          const unsigned ix = (unsigned)((rsel + ky) * HALO_W + col0 + kx);
-          const bf16x8 B = tail_tr8(xb + ix * PIX_STRIDE + (unsigned)((2 * wave + (p4 >> 1)) * 16 + (p4 & 1) * 8), 8u * PIX_STRIDE);
-          wacc[WGRAD ? tap : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, wacc[WGRAD ? tap : 0], 0, 0, 0);
-          if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);    // at most three B fragments in flight: the register budget is full
+        for (int ky = 0; ky < 3; ++ky) {
+          // B = input pixels ky * 18 + h (and + 8); past the halo tile (last K step only, where A is zero) any finite pixel will do
+          int i1 = ky * HALO_W + h, i2 = i1 + 8;
+          if (ks == 4) { i1 = i1 < HALO_PIX ? i1 : HALO_PIX - 1; i2 = i2 < HALO_PIX ? i2 : HALO_PIX - 1; }
+          const bf16x8 B = tail_tr8(xb + (unsigned)i1 * PIX_STRIDE + chan, (unsigned)(i2 - i1) * PIX_STRIDE);
+          wacc[WGRAD ? ky : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, wacc[WGRAD ? ky : 0], 0, 0, 0);
         }
       }
     }
@@ -346,13 +350,13 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
     if (tile + stride < ntiles) step(tile + stride, lds + X_STAGE_BYTES, R[0], R[1], lds);
   }
   if (WGRAD) {
-    // slab of this workgroup: [co 16][tap 9][ci 64] + [16] bias sums; D rows 0..3 (the real output channels) live in lanes 0..15
+    // slab of this workgroup: [co 16][tap 9][ci 64] + [16] bias sums
     float* slab = a.wslab + (size_t)blockIdx.x * (16 * 576 + 16);
-    if (g == 0) {
+    if (g < 3) {                       // D rows 4 g + e = (kx = g, channel e)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) slab[(e * 9 + tap) * 64 + 16 * wave + px] = wacc[WGRAD ? tap : 0][e];
+        for (int e = 0; e < 4; ++e) slab[(e * 9 + ky * 3 + g) * 64 + 16 * wave + px] = wacc[WGRAD ? ky : 0][e];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
