@@ -22,7 +22,8 @@
 //     conv3x3_kernel<4> (chunks 0 .. 3 in turn): bitwise that kernel (tests/test_kernels_gpu.py).
 #include "block_common.hpp"
 #ifndef D4_ABL
-#define D4_ABL 0      // timing only (results WRONG): 1 = no DMA, 2 = no MFMAs, 3 = no fragment reads (tests/tools/build_abl.sh conv_dgrad4.hip D4_ABL ...)
+#define D4_ABL 0      // timing only (results WRONG): 1 = no DMA, 2 = no MFMAs, 3 = no fragment reads (tests/tools/build_abl.sh conv_dgrad4.hip D4_ABL ...; the
+                      // in-kernel cycle counters quoted in DESIGN.md 4.2 came from a probe build that is not kept)
 #endif
 
 constexpr int D4_PIECES = 23;                         // 184 pixel slots >= 180 halo pixels
@@ -113,9 +114,6 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     if (u < nstage) issue(u);
 
   const int c0 = 16 * q + 4 * g;
-  unsigned long long t_issue = 0ull, t_wait = 0ull, t_mfma = 0ull;      // D4_ABL 8 / 9: shader cycles spent issuing DMA, waiting for a stage, sweeping
-#define D4_T() ((D4_ABL >= 8) ? __builtin_amdgcn_s_memtime() : 0ull)
-  const unsigned long long clk0 = (D4_ABL >= 8) ? __builtin_amdgcn_s_memtime() : 0ull, rt0 = (D4_ABL >= 8) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   for (int it = 0; it < nt; ++it) {
     const TileCoord tc = decode_tile(tile0 + it * tstride, a.tiles_x, a.tiles_y);
     const int xx = tc.tx * TW + px;
@@ -126,14 +124,11 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     for (int ch = 0; ch < 4; ++ch) {
       const int u = 4 * it + ch;
       // stage u has landed once at most the pieces issued after it are outstanding (stages u+1 .. u+3, fewer at the end); then the waves meet
-      const unsigned long long ta = D4_T();
       const int younger = (nstage - 1 - u < D4_AHEAD - 1) ? nstage - 1 - u : D4_AHEAD - 1;
       if (younger >= 4) d4_wait<4 * D4_PW>(); else if (younger == 3) d4_wait<3 * D4_PW>(); else if (younger == 2) d4_wait<2 * D4_PW>(); else if (younger == 1) d4_wait<D4_PW>(); else d4_wait<0>();
       gate_arrive(&landed, lane);
       gate_wait(&landed, 4u * (unsigned)(u + 1));
-      const unsigned long long tb = D4_T();
       if (u + D4_AHEAD < nstage) issue(u + D4_AHEAD);   // into a slot every wave is past (stage u - 2's)
-      const unsigned long long tc_ = D4_T();
       const unsigned char* cur = lds + (u % D4_NST) * D4_STAGE;
       // 12 units (tap column, channel half, row half) of 6 fragment reads + 12 MFMAs; the reads of unit j + 1 travel under the MFMAs of unit j
       bf16x8 I[D4_RD + 1][6];
@@ -157,7 +152,6 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
             if (D4_ABL != 2) acc[4 * pass + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[4 * pass + r], 0, 0, 0);
             else asm volatile("" :: "v"(I[j % (D4_RD + 1)][r + ky]), "v"(F[ch][(ky * 3 + kx) * 2 + half]));
       }
-      if (D4_ABL >= 8) { const unsigned long long td = D4_T(); t_wait += tb - ta; t_issue += tc_ - tb; t_mfma += td - tc_; }
     }
     // ---- epilogue: lane holds channels c0 .. c0+3 of pixel (row r, column px); the residual operand is read here (plain loads: the
     // compiler's wait for them drains the DMA queue - everything older - which costs one stage's slack once per tile) ----
@@ -178,10 +172,6 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
         *reinterpret_cast<uint2*>(a.out + e) = pack4_bf16(v[0], v[1], v[2], v[3]);
       }
     }
-  }
-  if (D4_ABL >= 8 && a.bias && lane == 0) {      // clock probe: a.bias (unused by this kernel) = [grid][2] u64: shader cycles, 100 MHz ticks of the tile loop
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias)) + 8 * (4 * blockIdx.x + q);
-    dbg[0] = __builtin_amdgcn_s_memtime() - clk0; dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0; dbg[2] = t_wait; dbg[3] = t_issue; dbg[4] = t_mfma;
   }
 }
 

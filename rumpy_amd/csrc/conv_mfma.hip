@@ -516,8 +516,7 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   dim3 grid(gx, p->cout_tiles);
   // the data gradients of the upsampler convs (what the engine launches with Cin = 256)
   const bool old4 = getenv("RUMPY_CONV4_OLD") != nullptr;             // A/B switch (read per call: tests toggle it)
-  // (RUMPY_D4_PROBE: the clock-probe build of conv_dgrad4.hip takes its debug buffer in `bias`)
-  const bool plain = p->cout_tiles == 1 && p->out_mode == 0 && (!p->bias || getenv("RUMPY_D4_PROBE")) && !p->relu && !p->mask && !p->res2 && !p->pool;
+  const bool plain = p->cout_tiles == 1 && p->out_mode == 0 && !p->bias && !p->relu && !p->mask && !p->res2 && !p->pool;
   if (plain && !old4) {
     int g2 = p->grid_x > 0 ? p->grid_x : rumpy_device_cus();
     const int rounds = cdiv(ntiles, g2);

@@ -145,16 +145,6 @@ def conv4_bench(N=32, H=96, W=96):
     a = L.ConvArgs(x=dy.data_ptr(), w=pc.w_dgrad.data_ptr(), out=out.data_ptr(), N=N, H=H, W=W, cin_chunks=4, cout_tiles=1,
                    in_mode=1, out_mode=0, relu=0, scale=1.0, grid_x=0)
     us = time_fn(lambda: L.call('rumpy_conv3x3', a, stream()), iters=20)
-    if 'D4_ABL_9' in os.environ.get('RUMPY_AMD_LIB', '') or 'D4_ABL_8' in os.environ.get('RUMPY_AMD_LIB', ''):     # probe builds: per wave, shader cycles of the tile loop and of its parts
-        dbg = torch.zeros(256 * 4 * 8, dtype=torch.int64, device=DEV)
-        a.bias = dbg.data_ptr()
-        L.call('rumpy_conv3x3', a, stream())
-        torch.cuda.synchronize()
-        d = dbg.cpu().numpy().reshape(-1, 8).astype(np.float64)
-        d = d[d[:, 1] > 0]
-        print('   tile loop: %.1f us mean, shader clock %.2f GHz; of its cycles: waiting for a stage %.0f %%, issuing DMA %.0f %%, sweeping %.0f %%'
-              % (d[:, 1].mean() / 100.0, (d[:, 0] / d[:, 1]).mean() / 10.0, 100 * (d[:, 2] / d[:, 0]).mean(), 100 * (d[:, 3] / d[:, 0]).mean(), 100 * (d[:, 4] / d[:, 0]).mean()))
-        a.bias = None
     flop = 2.0 * N * H * W * 64 * 256 * 9
     print('conv 256->64 (PixelShuffle^T gather) %dx%dx%d: %7.2f us  %6.1f TFLOP/s  %5.2f TB/s input' % (N, H, W, us, flop / us / 1e6, dy.numel() * 2 / us / 1e6))
 
