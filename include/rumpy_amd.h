@@ -441,6 +441,33 @@ typedef struct {
 } rumpy_enc_bn_args;
 int rumpy_enc_bn_train(const rumpy_enc_bn_args* a, void* stream);
 int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C);
+/* The same, out of place and keeping what the backward pass needs: `out` [P, C] bf16 = LeakyReLU(BN(x)), x untouched;
+ * `saved` [2, C] = batch mean, 1 / sqrt(biased variance + eps); a->scale_shift ([2, C]) must stay alive until rumpy_enc_bn_bwd has run. */
+int rumpy_enc_bn_train_keep(const rumpy_enc_bn_args* a, void* out, float* saved, void* stream);
+
+/* ---- training the degradation encoder (MoCo / SupMoCo: rumpy/regression/models/contrastive_learning/moco.py:132-187, supmoco.py:52-128) ----
+ * Backward of one BatchNorm2d(train) + LeakyReLU stage: from the gradient at the stage's output to the gradient at the conv output feeding
+ * it, plus dgamma / dbeta.  The conv gradients are rumpy_enc_conv on the dgrad filter image (data) and rumpy_wgrad_grouped / _reduce
+ * (weights; rumpy_head_wgrad for the first layer).  `up` = 2 writes pixel (oy, ox) at (2 oy, 2 ox) of an [N, Hz, Wz, C] grid the caller
+ * zeroed once: the stride-1 data / weight gradient over that grid is the stride-2 convolution's.  Deterministic. */
+typedef struct {
+  const void* z;             /* [N*Ho*Wo, C] bf16: the conv output the forward pass normalised (x of rumpy_enc_bn_train_keep) */
+  const void* da;            /* [N*Ho*Wo, C] bf16 gradient at the LeakyReLU output ; NULL: */
+  const float* dpool;        /* [N, C] gradient at the AdaptiveAvgPool2d(1) output behind the stage: da[n, p, c] = dpool[n, c] / (Ho*Wo) */
+  const float* scale_shift;  /* [2, C] of the forward pass */
+  const float* saved;        /* [2, C] of the forward pass */
+  const float* gamma;        /* [C] */
+  float* dgamma; float* dbeta;   /* [C], overwritten (x scale); may be NULL */
+  void* dz;                  /* [N, Hz, Wz, C] bf16 */
+  float* partial;            /* scratch, >= rumpy_enc_bn_partial_floats(N*Ho*Wo, C) floats */
+  float* coef;               /* scratch [3, C] */
+  int32_t N, Ho, Wo, C, up, Hz, Wz;
+  float neg_slope, scale;
+  int32_t pad_;
+} rumpy_enc_bn_bwd_args;
+int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* a, void* stream);
+/* key-encoder momentum update over flat fp32 buffers: k = k * m + q * one_minus_m (two rounded products, then the sum: moco.py:71) */
+int rumpy_ema(float* k, const float* q, int64_t n, float m, float one_minus_m, void* stream);
 
 /* ---- optimizer: torch.optim.Adam semantics (base_architecture.py:93-95,437), flat fp32 buffers ---- */
 typedef struct {

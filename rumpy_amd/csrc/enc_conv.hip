@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) enc_bn_stats_kernel(const uint4* __restri
 __global__ void __launch_bounds__(64) enc_bn_finalize_kernel(const float* __restrict__ partial, int nblk, int P, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
-                                                             float* __restrict__ scale_shift, float eps, float momentum) {
+                                                             float* __restrict__ scale_shift, float* __restrict__ saved, float eps, float momentum) {
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c < C) {
     double s = 0.0, q = 0.0;
@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(64) enc_bn_finalize_kernel(const float* __rest
     const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
     scale_shift[c] = sc;
     scale_shift[C + c] = beta[c] - (float)mean * sc;
+    if (saved) { saved[c] = (float)mean; saved[C + c] = (float)(1.0 / sqrt(var + (double)eps)); }   // for rumpy_enc_bn_bwd
     if (rmean) {                                           // running statistics: unbiased variance (torch.nn.BatchNorm2d)
       rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
       rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * ((double)P / (double)(P - 1)));
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(64) enc_bn_finalize_kernel(const float* __rest
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
-__global__ void __launch_bounds__(256) enc_bn_apply_kernel(uint4* __restrict__ x, const float* __restrict__ scale_shift, size_t total_vec, int C,
+__global__ void __launch_bounds__(256) enc_bn_apply_kernel(const uint4* x, uint4* out, const float* __restrict__ scale_shift, size_t total_vec, int C,
                                                            float neg_slope) {
   const int cvec = C / 8;
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total_vec; v += (size_t)gridDim.x * 256) {
@@ -175,27 +176,32 @@ __global__ void __launch_bounds__(256) enc_bn_apply_kernel(uint4* __restrict__ x
       f[i] = y > 0.f ? y : y * neg_slope;
     }
     const uint2 lo = pack4_bf16(f[0], f[1], f[2], f[3]), hi = pack4_bf16(f[4], f[5], f[6], f[7]);
-    x[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    out[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
   }
 }
 
 extern "C" int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C) { return (int64_t)bn_blocks(P) * 2 * C; }
-extern "C" int rumpy_enc_bn_train(const rumpy_enc_bn_args* p, void* stream) {
-  if (!p || !p->x || !p->gamma || !p->beta || !p->partial || !p->scale_shift) { rumpy_set_error("rumpy_enc_bn_train: null pointer"); return RUMPY_E_ARG; }
-  if ((p->running_mean == nullptr) != (p->running_var == nullptr)) { rumpy_set_error("rumpy_enc_bn_train: running_mean and running_var go together"); return RUMPY_E_ARG; }
+static int enc_bn_train(const rumpy_enc_bn_args* p, void* out, float* saved, void* stream, const char* who) {
+  if (!p || !p->x || !p->gamma || !p->beta || !p->partial || !p->scale_shift) { rumpy_set_error("%s: null pointer", who); return RUMPY_E_ARG; }
+  if ((p->running_mean == nullptr) != (p->running_var == nullptr)) { rumpy_set_error("%s: running_mean and running_var go together", who); return RUMPY_E_ARG; }
   if (p->P < 2 || p->C <= 0 || p->C % 64) {   // torch refuses a single value per channel in training mode, too
-    rumpy_set_error("rumpy_enc_bn_train: needs more than one value per channel and C %% 64 == 0 (P=%d C=%d)", p->P, p->C); return RUMPY_E_ARG; }
+    rumpy_set_error("%s: needs more than one value per channel and C %% 64 == 0 (P=%d C=%d)", who, p->P, p->C); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   const int nblk = bn_blocks(p->P), chunk = (p->P + nblk - 1) / nblk;
   hipLaunchKernelGGL(enc_bn_stats_kernel, dim3(nblk, p->C / 64), dim3(256), 0, s, (const uint4*)p->x, p->partial, p->P, p->C, chunk);
   hipLaunchKernelGGL(enc_bn_finalize_kernel, dim3(p->C / 64), dim3(64), 0, s, p->partial, nblk, p->P, p->C, p->gamma, p->beta, p->running_mean,
-                     p->running_var, (long long*)p->num_batches_tracked, p->scale_shift, p->eps, p->momentum);
+                     p->running_var, (long long*)p->num_batches_tracked, p->scale_shift, saved, p->eps, p->momentum);
   const size_t tv = (size_t)p->P * (p->C / 8);
   size_t blocks = (tv + 255) / 256;
   const size_t cap = (size_t)rumpy_device_cus() * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(enc_bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)p->x, p->scale_shift, tv, p->C, p->neg_slope);
-  return rumpy_check_launch("rumpy_enc_bn_train");
+  hipLaunchKernelGGL(enc_bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)p->x, (uint4*)out, p->scale_shift, tv, p->C, p->neg_slope);
+  return rumpy_check_launch(who);
+}
+extern "C" int rumpy_enc_bn_train(const rumpy_enc_bn_args* p, void* stream) { return enc_bn_train(p, p ? p->x : nullptr, nullptr, stream, "rumpy_enc_bn_train"); }
+extern "C" int rumpy_enc_bn_train_keep(const rumpy_enc_bn_args* p, void* out, float* saved, void* stream) {
+  if (!out || !saved) { rumpy_set_error("rumpy_enc_bn_train_keep: null pointer"); return RUMPY_E_ARG; }
+  return enc_bn_train(p, out, saved, stream, "rumpy_enc_bn_train_keep");
 }
 
 extern "C" int rumpy_enc_conv(const rumpy_enc_conv_args* p, void* stream) {

@@ -2,15 +2,22 @@
 rumpy/regression/models/contrastive_learning/encoding_models.py:5-55 (``Encoder``, the DASR encoder: six 3x3 convs
 3-64-64-128/2-128-256/2-256 with BatchNorm + LeakyReLU(0.1), global average pool, ``mlp`` 256-256-256).
 
-Inference only: the blind-SR handlers keep it frozen (``encoder_freeze_mode='all'``); training the encoder itself (MoCo / SupMoCo,
-rumpy/regression) is outside the hot path.  The torch modules below only OWN the parameters and buffers under the reference's keys
-(``E.{0,1,3,4,...}.*``, ``mlp.{0,2}.*``) and creation order; ``forward`` runs hand-written HIP kernels (rumpy_head_fwd, rumpy_enc_conv,
-rumpy_enc_bn_train, rumpy_enc_pool) and fails loudly without a GPU.  Both BatchNorm modes are implemented because the reference uses
-both: running statistics under ``.eval()`` (folded into the filters, one launch per layer) and batch statistics + running-statistics
-update under ``.train()`` - which is the mode the reference's run_train leaves the frozen encoder in (base_architecture.py:472).
+The torch modules below only OWN the parameters and buffers under the reference's keys (``E.{0,1,3,4,...}.*``, ``mlp.{0,2}.*``) and
+creation order; the convolutional trunk runs hand-written HIP kernels and fails loudly without a GPU:
 
-Only the pooled feature vector ``fea`` (embedding_type 'pre-q', the handlers' default) is produced; the ``mlp`` head ('q') is kept as
-parameters for checkpoint interchange and refused at run time."""
+* inference (the blind-SR handlers keep the encoder frozen, ``encoder_freeze_mode='all'``): rumpy_head_fwd, rumpy_enc_conv, rumpy_enc_pool,
+  with both BatchNorm modes because the reference uses both - running statistics under ``.eval()`` (folded into the filters, one launch
+  per layer) and batch statistics + running-statistics update under ``.train()``, which is the mode the reference's run_train leaves the
+  frozen encoder in (base_architecture.py:472);
+* training (MoCo / SupMoCo, moco.py / supmoco.py): ``forward`` under ``.train()`` with trainable trunk parameters is one autograd node whose
+  backward pass is HIP as well - rumpy_enc_bn_bwd per stage (BatchNorm + LeakyReLU + the pool's backward), rumpy_enc_conv on the filters'
+  dgrad images for the data gradients (a stride-2 layer's gradient is written at every second pixel of a zeroed stride-1 grid), the SR
+  path's rumpy_wgrad_grouped / rumpy_wgrad_reduce and rumpy_head_wgrad for the weight gradients.  Parameters then live in ONE flat fp32
+  buffer with a flat gradient buffer beside it (``flatten()``), which the fused Adam launch and the key encoder's momentum update walk.
+
+The ``mlp`` head (two 256 x 256 linear layers on an [N, 256] matrix) is plain torch (rocBLAS) with torch autograd."""
+import ctypes as C
+
 import numpy as np
 import torch
 from torch import nn
@@ -24,6 +31,27 @@ SLOPE = 0.1
 
 def _ptr(t):
     return None if t is None else t.data_ptr()
+
+
+def _dev_bytes(ctypes_array, dev):
+    return torch.from_numpy(np.frombuffer(bytes(ctypes_array), dtype=np.uint8).copy()).to(dev)
+
+
+class _TrunkFn(torch.autograd.Function):
+    """The six conv + BatchNorm(train) + LeakyReLU stages and the pool as ONE autograd node: both directions are HIP launches.  Parameter
+    gradients are written (not accumulated) into the encoder's flat gradient buffer, whose views are the parameters' ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, x, enc, *params):
+        fea, ctx.token, ctx.x = enc._train_forward(x)
+        ctx.enc = enc
+        ctx.nparams = len(params)
+        return fea
+
+    @staticmethod
+    def backward(ctx, dfea):
+        ctx.enc._train_backward(ctx.x, ctx.token, dfea)
+        return (None, None) + (None,) * ctx.nparams
 
 
 class Encoder(nn.Module):
@@ -42,6 +70,56 @@ class Encoder(nn.Module):
         self._packed = None          # (key, raw filter images)
         self._folded = None          # (key, folded filter images)
         self._stats_epoch = 0        # bumped whenever a kernel rewrites the running statistics
+        self._train_plans = {}
+        self._train_images = None    # (key, [(w_fwd, w_dgrad, b_packed)] of convs 1..5, keep-alive)
+        self._token = 0              # forward passes of the training plan: a backward pass must belong to the last one
+        self.flat_p = self.flat_g = None
+        self.param_list, self.offsets, self.grad_views = None, None, None
+
+    # ------------------------------------------------------------------ flat parameter storage (training)
+    def flatten(self):
+        """Move every parameter into one flat fp32 buffer (parameters become views, module order) with a flat gradient buffer beside it."""
+        self.param_list = list(self.parameters())
+        dev = self.param_list[0].device
+        total = sum(p.numel() for p in self.param_list)
+        flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets, off = [], 0
+        with torch.no_grad():
+            for p in self.param_list:
+                n = p.numel()
+                flat_p[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = flat_p[off:off + n].view(p.shape)
+                self.offsets.append(off)
+                off += n
+        self.flat_p = flat_p
+        self.grad_views = [self.flat_g[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.param_list)]
+        self._packed = self._folded = self._train_images = None
+        self._train_plans = {}
+        self.attach_grads()
+
+    def attach_grads(self):
+        """Gradient views as ``.grad``.  The trunk's are overwritten by every backward pass; the mlp head's are accumulated into by torch
+        autograd, so they start every step from zero."""
+        n_trunk = 24                          # 6 x (conv weight, bias, BatchNorm weight, bias) come first in module order
+        for i, (p, g) in enumerate(zip(self.param_list, self.grad_views)):
+            if p.requires_grad:
+                if i >= n_trunk:
+                    g.zero_()
+                p.grad = g
+
+    def _apply(self, fn, recurse=True):
+        was_flat = self.flat_p is not None
+        super()._apply(fn)
+        if was_flat:                          # .to(device) replaced the parameter storages
+            self.flatten()
+        else:
+            self._packed = self._folded = self._train_images = None
+        return self
+
+    def weights_rewritten(self):
+        """flat_p was rewritten by a kernel (fused Adam, the momentum update): the bf16 filter images are stale."""
+        self._packed = self._folded = self._train_images = None
 
     # ------------------------------------------------------------------ filter images
     def _convs(self):
@@ -54,15 +132,17 @@ class Encoder(nn.Module):
             ts += [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
         return tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + ((self._stats_epoch,) if with_stats else ())
 
-    def _pack(self, weights, biases, dev):
-        """[(w fp32 OIHW, b)] of the five 64-multiple convs -> MFMA fragment images through rumpy_pack_weights"""
+    def _pack(self, weights, biases, dev, dgrad=False):
+        """[(w fp32 OIHW, b)] of the five 64-multiple convs -> MFMA fragment images through rumpy_pack_weights
+        (dgrad: also the transposed + flipped image the data gradient convolves with)"""
         items, out = [], []
         for w, b in zip(weights, biases):
             cout, cin = w.shape[:2]
             wf = torch.empty(cout * cin * 9, dtype=BF16, device=dev)
+            wd = torch.empty(cout * cin * 9, dtype=BF16, device=dev) if dgrad else None
             bp = torch.empty(cout, dtype=torch.float32, device=dev)
-            items.append(L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(wf), w_dgrad=None, b_packed=_ptr(bp), cout=cout, cin=cin, kind=0, shuffle=0))
-            out.append((wf, bp))
+            items.append(L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(wf), w_dgrad=_ptr(wd), b_packed=_ptr(bp), cout=cout, cin=cin, kind=0, shuffle=0))
+            out.append((wf, wd, bp) if dgrad else (wf, bp))
         tab = torch.from_numpy(np.frombuffer(bytes((L.PackItem * len(items))(*items)), dtype=np.uint8).copy()).to(dev)
         L.check(L.lib().rumpy_pack_weights(_ptr(tab), len(items), torch.cuda.current_stream(dev).cuda_stream), 'rumpy_pack_weights')
         return out, (tab, weights, biases)
@@ -119,8 +199,6 @@ class Encoder(nn.Module):
         dev = x.device
         N, _, H, W = x.shape
         train = self.training
-        if any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError('rumpy_amd: the encoder is inference-only on the HIP path (encoder_freeze_mode="all")')
         plan = self._plan(N, H, W, dev)
         imgs = self._raw_images(dev) if train else self._folded_images(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -149,6 +227,158 @@ class Encoder(nn.Module):
         L.check(L.lib().rumpy_enc_pool(_ptr(acts[5]), _ptr(fea), N, h * w, 256, stream), 'rumpy_enc_pool')
         return fea
 
+    # ------------------------------------------------------------------ training: forward that keeps what the backward pass needs
+    def _trunk_params(self):
+        convs, bns = self._convs()
+        return [t for c, b in zip(convs, bns) for t in (c.weight, c.bias, b.weight, b.bias)]
+
+    def _training_images(self, dev):
+        key = self._key(False)
+        if self._train_images is None or self._train_images[0] != key:
+            convs, _ = self._convs()
+            ws = [c.weight.detach() for c in convs]
+            bs = [c.bias.detach() for c in convs]
+            imgs, keep = self._pack(ws[1:], bs[1:], dev, dgrad=True)
+            self._train_images = (key, imgs, keep)
+        return self._train_images[1]
+
+    def _train_plan(self, N, H, W, dev):
+        key = (N, H, W, dev.index)
+        p = self._train_plans.get(key)
+        if p is not None:
+            return p
+        lib = L.lib()
+        new = lambda *shape, dtype=BF16: torch.empty(*shape, dtype=dtype, device=dev)
+        z, a, dz, da, dims, h, w = [], [], [], [], [], H, W
+        for cin, cout, stride in LAYERS:
+            hi, wi = h, w                                   # this conv's input size = the grid its gradients live on
+            h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
+            dims.append((hi, wi, h, w))
+            z.append(new(N, h, w, cout))
+            a.append(new(N, h, w, cout))
+            # gradient at the conv output on the stride-1 grid of the conv's input (stride 2: every second pixel, the rest stays zero)
+            dz.append(torch.zeros(N, hi, wi, cout, dtype=BF16, device=dev) if stride == 2 else new(N, h, w, cout))
+            da.append(new(N, h, w, cout))                   # gradient at the stage's (LeakyReLU) output; the last one comes from the pool
+        part = new(max(int(lib.rumpy_enc_bn_partial_floats(t.shape[0] * t.shape[1] * t.shape[2], t.shape[3])) for t in z), dtype=torch.float32)
+        p = dict(z=z, a=a, dz=dz, da=da, dims=dims, partial=part, coef=new(3 * 256, dtype=torch.float32),
+                 ss=[new(2 * c, dtype=torch.float32) for _, c, _ in LAYERS], saved=[new(2 * c, dtype=torch.float32) for _, c, _ in LAYERS],
+                 zero_bias=torch.zeros(256, dtype=torch.float32, device=dev),
+                 head_slab=new(max(1, int(lib.rumpy_head_wgrad_slab_floats(3, 64))), dtype=torch.float32))
+        # ---- weight-gradient jobs of convs 1..5: unit = (layer, cin chunk, cout tile); a unit's pixel tiles are cut into ranges of `per` tiles,
+        # one job + one slab each; one reduce item per unit (rumpy_wgrad_grouped / rumpy_wgrad_reduce of the SR path)
+        ntiles = lambda hh, ww: N * ((hh + L.TILE_H - 1) // L.TILE_H) * ((ww + L.TILE_W - 1) // L.TILE_W)
+        units = [(i, ch, ct) for i in range(1, 6) for ch in range(LAYERS[i][0] // 64) for ct in range(LAYERS[i][1] // 64)]
+        total_tiles = sum(ntiles(*dims[i][:2]) for i, _, _ in units)
+        per = max(1, -(-total_tiles // (2 * max(1, int(lib.rumpy_device_cus())))))
+        sf = int(lib.rumpy_wgrad_slab_floats(4))
+        nslab = sum(-(-ntiles(*dims[i][:2]) // per) for i, _, _ in units)
+        slabs = new(nslab * sf, dtype=torch.float32)
+        convs, _ = self._convs()
+        gidx = {id(q): j for j, q in enumerate(self.param_list)}
+        jobs, items, off = [], [], 0
+        for i, ch, ct in units:
+            cin, cout, _ = LAYERS[i]
+            hi, wi = dims[i][:2]
+            nt = ntiles(hi, wi)
+            ranges = [(t0, min(nt, t0 + per)) for t0 in range(0, nt, per)]
+            for k, (t0, t1) in enumerate(ranges):
+                jobs.append(L.WgradJob(x=_ptr(a[i - 1]), dy=_ptr(dz[i]), slab=slabs.data_ptr() + 4 * (off + k * sf), n0=0, n1=N, t0=t0, t1=t1,
+                                       H=hi, W=wi, x_cstride=cin, x_coff=ch * 64, dy_mode=0, dy_cstride=cout, dy_coff=ct * 64, mt=4))
+            items.append(L.ReduceItem(slab=slabs.data_ptr() + 4 * off, slab_stride=sf, njobs=len(ranges), mt=4, co_count=64, co_mode=0,
+                                      co_off=ct * 64, ci_total=cin, ci_off=ch * 64, write_bias=1 if ch == 0 else 0, scale=1.0,
+                                      gw=_ptr(self.grad_views[gidx[id(convs[i].weight)]]), gb=_ptr(self.grad_views[gidx[id(convs[i].bias)]])))
+            off += len(ranges) * sf
+        p.update(slabs=slabs, jobs=_dev_bytes((L.WgradJob * len(jobs))(*jobs), dev), njobs=len(jobs),
+                 items=_dev_bytes((L.ReduceItem * len(items))(*items), dev), nitems=len(items), flat_g_ptr=self.flat_g.data_ptr())
+        if len(self._train_plans) > 4:
+            self._train_plans.clear()
+        self._train_plans[key] = p
+        return p
+
+    def _train_forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError('rumpy_amd: the degradation encoder runs on the GPU only (no CPU fallback)')
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError('rumpy_amd: encoder input must be [N,3,H,W]')
+        if self.flat_p is None or self.E[0].weight.data_ptr() != self.flat_p.data_ptr():
+            self.flatten()
+        x = x.detach().float().contiguous()
+        dev = x.device
+        N, _, H, W = x.shape
+        plan = self._train_plan(N, H, W, dev)
+        imgs = self._training_images(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        convs, bns = self._convs()
+        z, a = plan['z'], plan['a']
+        L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(x), w=_ptr(convs[0].weight), b=_ptr(convs[0].bias), out=_ptr(z[0]), N=N, C=3, H=H, W=W,
+                                               cout=64, neg_slope_m1=0.0), stream)
+        for i, (cin, cout, stride) in enumerate(LAYERS):
+            hi, wi, ho, wo = plan['dims'][i]
+            if i > 0:
+                wf, _, bp = imgs[i - 1]
+                L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
+                                                       cout=cout, stride=stride, neg_slope=1.0), stream)
+            bn = bns[i]
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+            args = L.EncBnArgs(x=_ptr(z[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias), running_mean=_ptr(bn.running_mean),
+                               running_var=_ptr(bn.running_var), num_batches_tracked=_ptr(bn.num_batches_tracked), partial=_ptr(plan['partial']),
+                               scale_shift=_ptr(plan['ss'][i]), P=N * ho * wo, C=cout, eps=bn.eps, momentum=mom, neg_slope=SLOPE)
+            L.check(L.lib().rumpy_enc_bn_train_keep(C.byref(args), _ptr(a[i]), _ptr(plan['saved'][i]), stream), 'rumpy_enc_bn_train_keep')
+        self._stats_epoch += 1
+        fea = torch.empty(N, 256, dtype=torch.float32, device=dev)
+        ho, wo = plan['dims'][5][2:]
+        L.check(L.lib().rumpy_enc_pool(_ptr(a[5]), _ptr(fea), N, ho * wo, 256, stream), 'rumpy_enc_pool')
+        self._token += 1
+        plan['token'] = self._token
+        return fea, (N, H, W, self._token), x
+
+    def _train_backward(self, x, token, dfea):
+        N, H, W, tok = token
+        dev = x.device
+        plan = self._train_plans.get((N, H, W, dev.index))
+        if plan is None or plan.get('token') != tok:
+            raise RuntimeError('rumpy_amd: backward pass of an encoder forward pass whose activations were overwritten by a later one '
+                               '(one training forward per backward on this path)')
+        if plan['flat_g_ptr'] != self.flat_g.data_ptr():
+            raise RuntimeError('rumpy_amd: the encoder was re-flattened between forward and backward')
+        lib = L.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        imgs = self._training_images(dev)
+        convs, bns = self._convs()
+        gidx = {id(q): j for j, q in enumerate(self.param_list)}
+        gv = lambda t: self.grad_views[gidx[id(t)]]
+        dfea = dfea.detach().float().contiguous()
+        z, a, dz, da = plan['z'], plan['a'], plan['dz'], plan['da']
+        for i in range(5, -1, -1):
+            cin, cout, stride = LAYERS[i]
+            hi, wi, ho, wo = plan['dims'][i]
+            bn = bns[i]
+            L.call('rumpy_enc_bn_bwd', L.EncBnBwdArgs(z=_ptr(z[i]), da=None if i == 5 else _ptr(da[i]), dpool=_ptr(dfea) if i == 5 else None,
+                                                      scale_shift=_ptr(plan['ss'][i]), saved=_ptr(plan['saved'][i]), gamma=_ptr(bn.weight),
+                                                      dgamma=_ptr(gv(bn.weight)), dbeta=_ptr(gv(bn.bias)), dz=_ptr(dz[i]),
+                                                      partial=_ptr(plan['partial']), coef=_ptr(plan['coef']), N=N, Ho=ho, Wo=wo, C=cout,
+                                                      up=stride, Hz=hi if stride == 2 else ho, Wz=wi if stride == 2 else wo,
+                                                      neg_slope=SLOPE, scale=1.0), stream)
+            if i > 0:      # data gradient: the stride-1 convolution of dz (on the input's grid) with the transposed, flipped filter
+                _, wd, _ = imgs[i - 1]
+                L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(dz[i]), w=_ptr(wd), bias=_ptr(plan['zero_bias']), out=_ptr(da[i - 1]), N=N, H=hi, W=wi,
+                                                       cin=cout, cout=cin, stride=1, neg_slope=1.0), stream)
+        L.check(lib.rumpy_wgrad_grouped(_ptr(plan['jobs']), plan['njobs'], 4, 0, stream), 'rumpy_wgrad_grouped')
+        L.check(lib.rumpy_wgrad_reduce(_ptr(plan['items']), plan['nitems'], stream), 'rumpy_wgrad_reduce')
+        L.call('rumpy_head_wgrad', L.HeadWgradArgs(x=_ptr(x), dy=_ptr(dz[0]), slab=_ptr(plan['head_slab']), gw=_ptr(gv(convs[0].weight)),
+                                                   gb=_ptr(gv(convs[0].bias)), N=N, C=3, H=H, W=W, cout=64, scale=1.0), stream)
+        plan['token'] = None
+        for t in self._trunk_params():
+            if t.requires_grad:
+                t.grad = gv(t)
+
     def forward(self, x):
-        """(fea, out_dict) like the reference; the 'q' entry (mlp head) is not computed on this path."""
-        return self.features(x), {}
+        """(fea, {'q': mlp(fea)}) like the reference.  Under ``.train()`` with gradients enabled and a trainable trunk the trunk is one
+        autograd node (HIP both ways); otherwise it is the inference path (no gradient reaches the trunk: ``encoder_freeze_mode`` 'all' /
+        'pre_q', or evaluation)."""
+        trunk = self._trunk_params()
+        if self.training and torch.is_grad_enabled() and any(t.requires_grad for t in trunk):
+            fea = _TrunkFn.apply(x, self, *trunk)
+        else:
+            fea = self.features(x)
+        return fea, {'q': self.mlp(fea)}

@@ -1,0 +1,91 @@
+"""Contrastive encoder-training handlers of the MI355X path - same class names, kwargs and return values as
+rumpy/regression/models/contrastive_learning/handlers.py:12-163 (``MocoContrastiveHandler`` -> 'mococontrastive',
+``SupMoCoHandler`` -> 'supmoco'), so ``define_model(name, **kwargs)`` resolves to them.  They train the degradation encoder the blind-SR
+handlers load as ``pre_trained_encoder_weights``.  Not built: WeakCon / SupCon, the drop-down head and its direct regression loss."""
+import torch
+
+from . import BaseContrastive
+from .moco import MoCo
+from .supmoco import SupMoCo
+
+
+def _split_crops(x, crop_count, device):
+    """[N, crops, 3, H, W] (or anything that views to [N * crops, 3, H, W]) -> (first crop of every image, all the other crops) (:47-53)"""
+    x = x.view(-1, 3, x.shape[-2], x.shape[-1]).to(device=device)
+    first = torch.arange(0, x.shape[0], crop_count, device=x.device)
+    rest = torch.ones(x.shape[0], dtype=torch.bool, device=x.device)
+    rest[first] = False
+    return x[first], x[rest]
+
+
+class MocoContrastiveHandler(BaseContrastive):
+    def __init__(self, device, model_save_dir, eval_mode=False, output_size=10, scheduler=None, scheduler_params=None, lr=1e-4,
+                 model_name=None, crop_count=2, moco_t=0.07, **kwargs):
+        super(MocoContrastiveHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode, **kwargs)
+        self.crop_count = crop_count
+        self.net = MoCo(base_encoder=self.define_encoder_model(model_name), T=moco_t, positives=crop_count - 1)
+        self.activate_device()
+        self.criterion = torch.nn.CrossEntropyLoss()
+        self.training_setup(lr, scheduler, scheduler_params, device=device, perceptual=None)
+
+    def run_model(self, x, *args, **kwargs):
+        embedding, q = self.net.forward(x, x, get_q=True, **kwargs)
+        return embedding, q
+
+    def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):
+        """x: [N, 6, H, W] (query crop | key crop on the channel axis) for crop_count 2, else [N, crops, 3, H, W]: the first crop of an image
+        is its query, the others its keys -> (contrastive loss, logits [N, 1 + K] on the CPU) (:37-63)"""
+        if self.eval_mode:
+            raise RuntimeError('Model initialized in eval mode, training not possible.')
+        self.net.train()
+        dev = self._torch_device()
+        if self.crop_count == 2:
+            x = x.to(device=dev)
+            im_q, im_k = x[:, 0:3, ...], x[:, 3:, ...]
+        else:
+            im_q, im_k = _split_crops(x, self.crop_count, dev)
+        _, output, target = self.net(im_q=im_q, im_k=im_k)
+        loss_contrast = self.criterion(output, target.to(device=dev))
+        self.standard_update(loss_contrast)
+        return loss_contrast.detach().cpu().numpy(), output.detach().cpu()
+
+
+class SupMoCoHandler(BaseContrastive):
+    def __init__(self, device, model_save_dir, eval_mode=False, output_size=10, scheduler=None, scheduler_params=None, lr=1e-4,
+                 model_name='default', crop_count=2, moco_t=0.07, data_type='noise', dropdown=None, dropdown_metadata_target=None,
+                 include_direct_loss=False, direct_loss_only=False, contrastive_dropdown=True, **kwargs):
+        super(SupMoCoHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode, **kwargs)
+        if dropdown is not None or include_direct_loss or direct_loss_only:
+            raise RuntimeError('rumpy_amd: the encoder drop-down head and its direct regression loss are not on the HIP path; there is no fallback')
+        self.crop_count = crop_count
+        self.temperature = moco_t
+        self.data_type = data_type
+        self.net = SupMoCo(base_encoder=self.define_encoder_model(model_name), positives_per_class=crop_count - 1, dim=256,
+                           contrastive_dropdown=contrastive_dropdown, T=moco_t, device=device, dropdown=None)
+        self.activate_device()
+        self.criterion = torch.nn.CrossEntropyLoss()
+        self.training_setup(lr, scheduler, scheduler_params, device=device, perceptual=None)
+        self.include_direct_loss = False
+        self.dropdown = None
+        self.dropdown_metadata_target = dropdown_metadata_target
+        self.contrastive_dropdown = contrastive_dropdown
+        self.direct_loss_only = False
+        self.target_loss = torch.nn.L1Loss()
+
+    def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):
+        """x: [N, crops, 3, H, W]; y: the batch's degradation metadata [N, M] with kwargs['metadata_keys'] naming its columns
+        -> (contrastive loss, embedding [N, 256] on the CPU) (:115-158)"""
+        if self.eval_mode:
+            raise RuntimeError('Model initialized in eval mode, training not possible.')
+        self.net.train()
+        dev = self._torch_device()
+        labels = self.class_logic(y, kwargs['metadata_keys'])
+        im_q, im_k = _split_crops(x, self.crop_count, dev)
+        embedding, logits, full_labels, _ = self.net(im_q, im_k, labels.squeeze())
+        loss_contrast = self.criterion(logits, full_labels.to(dev))
+        self.standard_update(loss_contrast)
+        return loss_contrast.detach().cpu().numpy(), embedding.detach().cpu()
+
+    def run_model(self, x, *args, **kwargs):
+        embedding, q = self.net.forward(x, x, get_q=True, **kwargs)
+        return embedding, q

@@ -1,0 +1,144 @@
+"""MoCo over the HIP degradation encoder - mirror of rumpy/regression/models/contrastive_learning/moco.py:8-187 (``MoCo``: query encoder,
+momentum key encoder, queue of negative keys; the reference's two changes to the original are kept: several positive keys per query,
+and the DASR encoder as backbone).
+
+What runs where: both encoders' convolutional trunks are HIP (encoding_models.py: forward, and for the query encoder the whole backward
+pass); the key encoder's momentum update is one launch over the two flat parameter buffers (rumpy_ema); Adam is the fused launch over the
+query encoder's flat buffers (rumpy_amd.optim.FlatAdam through the ``flat_protocol`` attributes below).  The contrastive head - two
+256 x 256 linear layers, L2 normalisation, the [N, 256] x [256, K] logits GEMM, cross-entropy - is plain torch on [N, 256] / [N, 1 + K]
+matrices (rocBLAS GEMMs), with torch autograd delivering d loss / d fea to the trunk's autograd node.
+
+Data parallel (one process per GPU): every rank enqueues the keys of ALL ranks, in rank order (the step the reference marks at
+moco.py:78 ``# keys = concat_all_gather(keys)``), so the replicas' queues stay identical; gradients are averaged by the handler."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from rumpy_amd import _lib as L
+from .encoding_models import Encoder
+
+
+class _EncoderUpdateHooks:
+    """What FlatAdam expects of ``net.engine``: after the fused update rewrote flat_p, the bf16 filter images are stale (they are rebuilt by
+    the next forward pass)."""
+
+    def __init__(self, encoder):
+        self.encoder = encoder
+
+    def repack(self, stream=None):
+        self.encoder.weights_rewritten()
+
+    def exchange_status(self):
+        return 0
+
+
+class MoCo(nn.Module):
+    flat_protocol = True             # BaseModel: param_list / offsets / flat_p / flat_g / attach_grads / engine of the trainable part
+    supports_fused_l1 = False
+
+    def __init__(self, base_encoder, dim=256, K=32 * 256, m=0.999, T=0.07, mlp=True, positives=1, dropdown=None):
+        """dim: feature dimension; K: queue size (negative keys); m: momentum of the key encoder; T: softmax temperature (:18-24)"""
+        super(MoCo, self).__init__()
+        if base_encoder is not Encoder:
+            raise RuntimeError('rumpy_amd: only the default (DASR) encoder is on the HIP path, not %r' % (getattr(base_encoder, '__name__', base_encoder),))
+        self.K, self.m, self.T = K, m, T
+        self.vector_dim = dim
+        self.dropdown = dropdown
+        self.positives = positives
+        self.encoder_q = base_encoder(dropdown)
+        self.encoder_k = base_encoder(dropdown)
+        for param_q, param_k in zip(self.encoder_q.parameters(), self.encoder_k.parameters()):
+            param_k.data.copy_(param_q.data)
+            param_k.requires_grad = False              # the key encoder follows by momentum, not by gradient (:52-54)
+        self.register_buffer('queue', nn.functional.normalize(torch.randn(dim, K), dim=0))
+        self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.long))
+        self.use_graph = False
+        self._hooks = None
+
+    # ------------------------------------------------------------------ flat protocol (the trainable part = the query encoder)
+    def _flat(self):
+        q, k = self.encoder_q, self.encoder_k
+        if q.flat_p is None or q.E[0].weight.data_ptr() != q.flat_p.data_ptr():
+            q.flatten()
+        if k.flat_p is None or k.E[0].weight.data_ptr() != k.flat_p.data_ptr():
+            k.flatten()
+        return q
+
+    param_list = property(lambda self: self._flat().param_list)
+    offsets = property(lambda self: self._flat().offsets)
+    flat_p = property(lambda self: self._flat().flat_p)
+    flat_g = property(lambda self: self._flat().flat_g)
+
+    def attach_grads(self):
+        self._flat().attach_grads()
+
+    def _ensure_engine(self):
+        if not self.flat_p.is_cuda:
+            raise RuntimeError('rumpy_amd: this network only runs on an MI355X through the HIP extension; '
+                               'there is no CPU path (parameters are on %s)' % self.flat_p.device)
+
+    @property
+    def engine(self):
+        if self._hooks is None or self._hooks.encoder is not self.encoder_q:
+            self._hooks = _EncoderUpdateHooks(self.encoder_q)
+        return self._hooks
+
+    def mark_weights_clean(self):
+        pass
+
+    def mark_weights_updated(self):
+        self.encoder_q.weights_rewritten()
+        self.encoder_k.weights_rewritten()
+
+    # ------------------------------------------------------------------ MoCo
+    @torch.no_grad()
+    def _momentum_update_key_encoder(self):
+        """param_k = param_k * m + param_q * (1 - m) for every parameter (:66-72), one launch over the flat buffers"""
+        q = self._flat()
+        k = self.encoder_k
+        if not k.flat_p.is_cuda:
+            raise RuntimeError('rumpy_amd: MoCo trains on the GPU only (no CPU fallback)')
+        L.check(L.lib().rumpy_ema(k.flat_p.data_ptr(), q.flat_p.data_ptr(), k.flat_p.numel(), float(self.m), float(1. - self.m),
+                                  torch.cuda.current_stream(k.flat_p.device).cuda_stream), 'rumpy_ema')
+        k.weights_rewritten()
+
+    @torch.no_grad()
+    def _gathered(self, t):
+        """rank-ordered concatenation over the data-parallel group (identity on one process)"""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, t.contiguous())
+            return torch.cat(parts, dim=0)
+        return t
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys):
+        """:74-89"""
+        keys = self._gathered(keys)
+        batch_size = keys.shape[0]
+        ptr = int(self.queue_ptr)
+        assert self.K % batch_size == 0  # for simplicity
+        self.queue[:, ptr:ptr + batch_size] = keys.transpose(0, 1)
+        self.queue_ptr[0] = (ptr + batch_size) % self.K
+
+    def forward(self, im_q, im_k, **kwargs):
+        """training: (embedding, logits [N, 1 + K], labels (zeros)) ; evaluation: embedding, or (embedding, q) with get_q (:132-187)"""
+        if not self.training:
+            embedding, q = self.encoder_q(im_q)
+            if kwargs.get('get_q'):
+                return embedding, q['q']
+            return embedding
+        n = im_q.shape[0]
+        embedding, heads = self.encoder_q(im_q)
+        q = nn.functional.normalize(heads['q'], dim=1)                          # queries  [N, C]
+        with torch.no_grad():                                                   # the keys carry no gradient
+            self._momentum_update_key_encoder()
+            k = nn.functional.normalize(self.encoder_k(im_k)[1]['q'], dim=1)    # keys     [N * positives, C]
+        # column 0: the positive logit = mean over the query's own key crops of q . k ; columns 1..K: q against the queue ; all / T
+        # (one positive: q . k / T, :150-151,170-172; several: (sum_p q . k_p / T) / positives, :153-158,174-177)
+        pos = torch.einsum('nc,npc->np', q, k.view(n, self.positives, self.vector_dim)).mean(dim=1, keepdim=True)
+        neg = q @ self.queue.detach().clone()
+        logits = torch.cat([pos, neg], dim=1) / self.T
+        labels = torch.zeros(n, dtype=torch.long)                               # cross-entropy target: column 0
+        self._dequeue_and_enqueue(k[::self.positives])                          # one key per query joins the queue (:181-184)
+        return embedding, logits, labels

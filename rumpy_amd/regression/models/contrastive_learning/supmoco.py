@@ -1,0 +1,68 @@
+"""SupMoCo over the HIP degradation encoder - mirror of rumpy/regression/models/contrastive_learning/supmoco.py:7-138 (``SupMoCo``,
+https://arxiv.org/abs/2101.11058): MoCo whose positives are, besides the query's own key crops, every queue entry carrying the query's class
+label.  The encoders, the momentum update and the optimizer are MoCo's (moco.py); the logits - q . k products, the one-hot label
+matrices [N, classes + 1] x [classes + 1, K], the [N, K] x [K, 256] positive-feature sum and the [N, 256] x [256, K] negatives - are
+plain torch GEMMs with torch autograd, as in the reference."""
+import torch
+import torch.nn as nn
+
+from .moco import MoCo
+
+
+class SupMoCo(MoCo):
+    def __init__(self, device, positives_per_class=4, contrastive_dropdown=True, **kwargs):
+        super(SupMoCo, self).__init__(**kwargs)
+        self.num_classes = 0
+        self.positives_per_class = positives_per_class
+        self.device = device
+        self.contrastive_dropdown = contrastive_dropdown
+
+    def register_classes(self, num_classes):
+        """:28-32: (re)start the queue's label track - every slot gets the "no class" label ``num_classes`` - and the queue pointer"""
+        self.set_class_count(num_classes)
+        dev = self.queue.device
+        self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.long, device=dev))
+        self.register_buffer('queue_labels', (torch.ones(self.K, device=dev) * num_classes).to(torch.int64))
+
+    def set_class_count(self, num_classes):
+        self.num_classes = num_classes
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, keys, labels):
+        keys, labels = self._gathered(keys), self._gathered(labels)
+        batch_size = keys.shape[0]
+        ptr = int(self.queue_ptr)
+        assert self.K % batch_size == 0  # for simplicity
+        self.queue[:, ptr:ptr + batch_size] = keys.transpose(0, 1)
+        self.queue_labels[ptr:ptr + batch_size] = labels
+        self.queue_ptr[0] = (ptr + batch_size) % self.K
+
+    def forward(self, im_q, im_k, labels=None, **kwargs):
+        """training: (embedding, logits [N, 1 + K], zeros, encoder outputs) ; evaluation as MoCo (:52-138)"""
+        if not self.training:
+            embedding, q_out = self.encoder_q(im_q)
+            if kwargs.get('get_q'):
+                return embedding, (q_out if self.dropdown else q_out['q'])
+            return embedding
+        if self.num_classes == 0:
+            raise RuntimeError('Maximum number of classes must be registered before running a training step.')
+        if labels is None:
+            raise RuntimeError('Labels required for a training step.')
+        n, P = im_q.shape[0], self.positives_per_class
+        embedding, heads = self.encoder_q(im_q)
+        q = nn.functional.normalize(heads['q'], dim=1)                          # [N, C]
+        with torch.no_grad():
+            self._momentum_update_key_encoder()
+            k = nn.functional.normalize(self.encoder_k(im_k)[1]['q'], dim=1)    # [N * P, C]
+        labels = labels.to(device=self.queue.device, dtype=torch.int64).reshape(-1)
+        # queue entry j is a positive of query n when their class labels agree (:93-97 builds the same 0/1 matrix as a product of one-hot
+        # matrices); free slots carry the label `num_classes`, which no query has
+        same = (labels.view(-1, 1) == self.queue_labels.view(1, -1)).to(q.dtype)            # [N, K]
+        pos_batch = torch.einsum('nc,npc->np', q, k.view(n, P, self.vector_dim)).sum(dim=1)  # the query's own key crops
+        pos_queue = (q * (same @ self.queue.t())).sum(dim=1)                                # q . (sum of its positive queue features)
+        l_pos = (pos_batch + pos_queue) / self.T / (P + same.sum(dim=1))                    # mean positive logit (:99-112)
+        l_neg = (q @ self.queue.detach().clone()) / self.T
+        logits = torch.cat([l_pos.unsqueeze(1), l_neg], dim=1)
+        full_labels = torch.zeros(n, dtype=torch.long)
+        self._dequeue_and_enqueue(k[::P], labels)                                           # one key per query, with the query's label
+        return embedding, logits, full_labels, heads

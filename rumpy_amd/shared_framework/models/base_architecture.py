@@ -233,7 +233,7 @@ class BaseModel(nn.Module):
         return new_masks
 
     def _hip_net(self):
-        if isinstance(self.net, HipSRNet):
+        if isinstance(self.net, HipSRNet) or getattr(self.net, 'flat_protocol', False):     # flat_protocol: MoCo over the HIP encoder
             return self.net
         gen = getattr(self.net, 'hip_generator', None)
         return gen if isinstance(gen, HipSRNet) else None
@@ -300,6 +300,8 @@ class BaseModel(nn.Module):
                 toc = time.perf_counter()
             loss = loss_t.detach().reshape(()).cpu().numpy() if loss_t is not None else None
         secs = (toc - tic) if timing else None
+        if isinstance(out, tuple):       # contrastive models return (embedding, q): handed back as they are (:514-515)
+            return out, loss, secs
         if keep_on_device:
             return out.detach(), loss, secs
         # (the strip-exchange watchdog and the non-finite flag of an evaluation pass are checked inside SREngine.forward, on every return path)

@@ -1,0 +1,138 @@
+"""Golden fixture G20 (contrastive training of the degradation encoder: MoCo and SupMoCo steps) from the REAL reference
+handlers.
+
+Runs ONLY in the build container (needs /root/reference):   python tests/golden/make_golden_contrastive.py
+define_model('mococontrastive') and define_model('supmoco') - the handlers of the reference's own contrastive tests
+(automated_testing/contrastive_tests/test_contrastive_cpu_execute.py:33-50) - are built on the CPU with the default (DASR) encoder, their
+encoders set from oracle.sr_oracle.seeded_encoder_state and their queues from oracle.contrastive_oracle.seeded_queue, and driven through
+the reference's run_train for two steps each on oracle.contrastive_oracle.contrastive_batch inputs.  Stored: losses, logits, every
+gradient's norm and a strided sample of it, weights / running statistics / queue after the steps, and the class labels the reference's
+class_logic assigns to a table of metadata rows under its three labelling strategies."""
+import os
+import runpy
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+shim = runpy.run_path(os.path.join(HERE, 'make_golden.py'), run_name='shim_only')
+O = shim['O']
+from oracle import contrastive_oracle as CO  # noqa: E402
+from rumpy.shared_framework.models import define_model  # noqa: E402
+from rumpy.regression.models.contrastive_learning import class_retrieval, partition_metadata, register_metadata  # noqa: E402
+
+STRIDE = 97
+NOISE_KEYS = [('gaussian_noise_scale',), ('poisson_noise_scale',), ('gray_noise_boolean',)]
+ALL_KEYS = NOISE_KEYS + [('jpeg_quality_factor',), ('jm_qpi',), ('realesrganblur-kernel_type',), ('realesrganblur-sigma_x',), ('realesrganblur-sigma_y',)]
+
+
+def seed_net(net, seed):
+    enc = O.seeded_encoder_state(O.OracleEncoder(), seed)
+    net.encoder_q.load_state_dict(enc)
+    net.encoder_k.load_state_dict(enc)
+    net.queue = CO.seeded_queue(256, net.K, seed + 1)
+    net.queue_ptr[0] = 0
+
+
+def dump(d, tag, h):
+    for k, p in h.net.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            g = p.grad.detach().numpy().reshape(-1)
+            d['%s.gnorm.%s' % (tag, k)] = np.asarray(np.linalg.norm(g.astype(np.float64)))
+            d['%s.gsample.%s' % (tag, k)] = g[::STRIDE].copy()
+
+
+def dump_state(d, tag, h, ncols):
+    for k, v in h.net.state_dict().items():
+        a = v.detach().numpy()
+        if k.startswith('queue'):
+            continue
+        d['%s.sum.%s' % (tag, k)] = np.asarray(a.astype(np.float64).sum())
+        d['%s.sample.%s' % (tag, k)] = a.reshape(-1)[::STRIDE].copy()
+    d[tag + '.queue_head'] = h.net.queue[:, :ncols].numpy().copy()
+    d[tag + '.queue_ptr'] = h.net.queue_ptr.numpy().copy()
+
+
+def metadata_rows(seed, n):
+    """rows over ALL_KEYS: [gaussian, poisson, gray, jpeg, jm, kernel type, sigma x, sigma y]"""
+    rng = np.random.default_rng(seed)
+    rows = np.zeros((n, 8), dtype=np.float32)
+    for r in rows:
+        if rng.random() < 0.5:
+            r[0] = rng.uniform(0.02, 1)
+        else:
+            r[1] = rng.uniform(0.02, 1)
+        r[2] = float(rng.random() < 0.5)
+        if rng.random() < 0.5:
+            r[3] = rng.uniform(0.02, 1)
+        else:
+            r[4] = rng.uniform(0.02, 1)
+        r[5] = float(rng.integers(0, 7))
+        r[6], r[7] = rng.uniform(0, 1, 2)
+    return rows
+
+
+def main():
+    torch.manual_seed(0)
+    d = {}
+    # ---- MoCo, two crops per image (query | key on the channel axis) ----
+    h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False, model_name='default',
+                     crop_count=2, lr=1e-3)
+    seed_net(h.net, 2000)
+    d['moco.keys'] = np.array(list(h.net.state_dict().keys()))
+    for step in range(2):
+        x = CO.contrastive_batch(2010 + step, 8, 2).view(8, 6, 32, 32)
+        loss, logits = h.run_train(x=x, y=None)
+        d['moco.loss%d' % step] = np.asarray(loss)
+        d['moco.logits%d' % step] = logits.numpy()[:, :48].copy()
+        d['moco.logits_rowsum%d' % step] = logits.numpy().astype(np.float64).sum(1)
+        if step == 0:
+            dump(d, 'moco.step0', h)
+    dump_state(d, 'moco.after2', h, 16)
+    # ---- MoCo, three crops (two positives per query) ----
+    h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False, model_name='default',
+                     crop_count=3, lr=1e-3)
+    seed_net(h.net, 2100)
+    loss, logits = h.run_train(x=CO.contrastive_batch(2110, 4, 3).view(4, 9, 32, 32), y=None)     # crops on the channel axis
+    d['moco3.loss0'] = np.asarray(loss)
+    d['moco3.logits0'] = logits.numpy()[:, :48].copy()
+    dump(d, 'moco3.step0', h)
+    dump_state(d, 'moco3.after1', h, 4)
+    # ---- SupMoCo, three crops, noise labels ----
+    h = define_model('supmoco', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False, model_name='default',
+                     crop_count=3, lr=1e-3, data_type='noise', labelling_strategy='double_precision')
+    seed_net(h.net, 2200)
+    meta = np.array([[0.8, 0, 1], [0, 0.3, 0], [0.7, 0, 1], [0, 0.9, 1]], dtype=np.float32)      # images 0 and 2 share a class
+    d['sup.meta'] = meta
+    for step in range(2):
+        x = CO.contrastive_batch(2210 + step, 4, 3).view(4, 9, 32, 32)
+        loss, emb = h.run_train(x=x, y=torch.from_numpy(meta), metadata_keys=NOISE_KEYS)
+        d['sup.loss%d' % step] = np.asarray(loss)
+        d['sup.embedding%d' % step] = emb.numpy().copy()
+        if step == 1:
+            dump(d, 'sup.step1', h)
+    d['sup.total_classes'] = np.asarray(h.total_classes)
+    d['sup.queue_labels_head'] = h.net.queue_labels[:8].numpy().copy()
+    dump_state(d, 'sup.after2', h, 8)
+    # ---- class labels: the reference's decision logic on a table of rows, three strategies x two data selections ----
+    rows = metadata_rows(2300, 64)
+    d['labels.rows'] = rows
+    for strategy in ('default', 'double_precision', 'triple_precision'):
+        for tag, keys, sel in (('noise', NOISE_KEYS, 'noise'), ('all', ALL_KEYS, 'all')):
+            names = register_metadata([k[0] for k in keys])
+            m_map = {k: names.index(k) for k in names}
+            fam, mags, total = partition_metadata(m_map, sel, labelling_strategy=strategy)
+            lab = [class_retrieval(torch.from_numpy(r[:len(keys)]), fam, m_map, mags, total, labelling_strategy=strategy) for r in rows]
+            d['labels.%s.%s' % (strategy, tag)] = np.asarray(lab, dtype=np.int64)
+            d['labels.%s.%s.total' % (strategy, tag)] = np.asarray(int(total))
+    np.savez_compressed(os.path.join(HERE, 'g20_contrastive_train.npz'), **d)
+    print('wrote g20: moco losses', d['moco.loss0'], d['moco.loss1'], 'moco3', d['moco3.loss0'], 'supmoco', d['sup.loss0'], d['sup.loss1'],
+          'classes', d['sup.total_classes'], 'queue labels', d['sup.queue_labels_head'])
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,287 @@
+"""-m gpu parity of the degradation encoder's TRAINING path: the BatchNorm + LeakyReLU backward kernel and the momentum
+update against plain torch, the encoder trunk's gradients and whole MoCo / SupMoCo training steps behind define_model('mococontrastive' |
+'supmoco') against the CPU oracle (oracle/contrastive_oracle.py, pinned on the real reference handlers by golden G20).
+
+Tolerances: the trunk stores filters, conv outputs and stage outputs (and their gradients) as bf16, with fp32 accumulation.  Two references:
+* the oracle with ``bf16_storage`` (the same graph rounded at the same points; differences = summation order, and the rare element whose
+  bf16 rounding that order decides - a few per cent of them, fp32 summation error 1e-4 against a bf16 step of 4e-3 - and the LeakyReLU
+  signs that follow): whole gradient <= 6e-2 relative, every tensor <= 1.2e-1 (measured 3.5-4e-2 / 7.5e-2);
+* the fp32 oracle: whole gradient <= 1.5e-1, every tensor <= 3e-1.  That is the price of bf16 storage on THIS network, not of the kernels:
+  a LeakyReLU input whose sign changes under a 2^-9 relative perturbation changes its gradient tenfold, about 0.3 % of the elements do,
+  and sqrt(0.003) x 0.9 = 5 % per rounding point (filters, conv outputs, stage outputs each give 6-9 % alone in the CPU simulation, all
+  together 10 %: measured 5-10 % on the GPU).  Gradient rounding alone costs 2e-3.
+The conv biases in front of a training-mode BatchNorm have a mathematically zero gradient (noise on both sides): smallness only."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import contrastive_oracle as CO
+from oracle import sr_oracle as O
+from rumpy_amd import _lib as L
+from rumpy_amd.regression.models.contrastive_learning.encoding_models import Encoder
+from rumpy_amd.shared_framework.models import define_model
+
+DEV = torch.device('cuda:0')
+BF16 = torch.bfloat16
+ZERO_GRAD_BIASES = ('E.0.bias', 'E.3.bias', 'E.6.bias', 'E.9.bias', 'E.12.bias', 'E.15.bias')
+
+
+def _stream():
+    return torch.cuda.current_stream(DEV).cuda_stream
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).norm() / (b.double().cpu().norm() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize('N,Ho,Wo,C,up,pool', [(3, 12, 12, 256, 1, True), (2, 24, 24, 128, 2, False), (2, 7, 5, 64, 2, False),
+                                               (4, 48, 48, 64, 1, False), (1, 3, 3, 128, 1, True)])
+def test_bn_lrelu_backward_kernel_against_torch(N, Ho, Wo, C, up, pool):
+    g = torch.Generator().manual_seed(N * 100 + Ho + C + up)
+    P = N * Ho * Wo
+    z = (torch.randn(N, Ho, Wo, C, generator=g) * 1.5 + 0.3).to(BF16)
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.3
+    if pool:
+        dpool = torch.randn(N, C, generator=g)
+        da = (dpool[:, None, None, :] / (Ho * Wo)).expand(N, Ho, Wo, C).contiguous()
+    else:
+        da = torch.randn(N, Ho, Wo, C, generator=g).to(BF16).float()
+    # reference: float64 autograd through batch_norm(train) + leaky_relu on the same bf16 values
+    zr = z.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a_ref = F.leaky_relu(F.batch_norm(zr, None, None, gr, br, training=True, eps=1e-5), 0.1)
+    (a_ref * da.double().permute(0, 3, 1, 2)).sum().backward()
+    # kernels
+    zd, gd, bd = z.to(DEV), gamma.to(DEV), beta.to(DEV)
+    out = torch.empty_like(zd)
+    part = torch.empty(int(L.lib().rumpy_enc_bn_partial_floats(P, C)), dtype=torch.float32, device=DEV)
+    ss, saved, coef = (torch.empty(n * C, dtype=torch.float32, device=DEV) for n in (2, 2, 3))
+    fa = L.EncBnArgs(x=zd.data_ptr(), gamma=gd.data_ptr(), beta=bd.data_ptr(), running_mean=None, running_var=None, num_batches_tracked=None,
+                     partial=part.data_ptr(), scale_shift=ss.data_ptr(), P=P, C=C, eps=1e-5, momentum=0.1, neg_slope=0.1)
+    import ctypes
+    L.check(L.lib().rumpy_enc_bn_train_keep(ctypes.byref(fa), out.data_ptr(), saved.data_ptr(), _stream()), 'keep')
+    torch.cuda.synchronize()
+    assert torch.equal(zd.cpu(), z)                                            # out of place: the conv output is kept
+    assert _rel(out.float().cpu().permute(0, 3, 1, 2), a_ref.detach()) < 4e-3
+    Hz, Wz = (2 * Ho - 1 + 1, 2 * Wo) if up == 2 else (Ho, Wo)
+    dz = torch.zeros(N, Hz, Wz, C, dtype=BF16, device=DEV)
+    dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    dad = None if pool else da.to(DEV, BF16)
+    dpd = dpool.to(DEV) if pool else None
+    L.call('rumpy_enc_bn_bwd', L.EncBnBwdArgs(z=zd.data_ptr(), da=None if pool else dad.data_ptr(), dpool=dpd.data_ptr() if pool else None,
+                                              scale_shift=ss.data_ptr(), saved=saved.data_ptr(), gamma=gd.data_ptr(), dgamma=dgam.data_ptr(),
+                                              dbeta=dbet.data_ptr(), dz=dz.data_ptr(), partial=part.data_ptr(), coef=coef.data_ptr(), N=N, Ho=Ho,
+                                              Wo=Wo, C=C, up=up, Hz=Hz, Wz=Wz, neg_slope=0.1, scale=1.0), _stream())
+    torch.cuda.synchronize()
+    assert _rel(dgam, gr.grad) < 1e-4 and _rel(dbet, br.grad) < 1e-4
+    got = dz.float().cpu()
+    if up == 2:
+        assert float(got[:, 1::2].abs().max()) == 0.0 and float(got[:, :, 1::2].abs().max()) == 0.0     # the zeroed grid stays zero
+        got = got[:, ::2, ::2][:, :Ho, :Wo]
+    assert _rel(got.permute(0, 3, 1, 2), zr.grad) < 4e-3                       # bf16 rounding of the result
+
+
+def test_momentum_update_kernel_is_the_torch_expression_bitwise():
+    g = torch.Generator().manual_seed(5)
+    k, q = torch.randn(100003, generator=g), torch.randn(100003, generator=g)
+    m = 0.999
+    want = k * m + q * (1. - m)                                               # moco.py:71
+    kd, qd = k.to(DEV), q.to(DEV)
+    L.check(L.lib().rumpy_ema(kd.data_ptr(), qd.data_ptr(), kd.numel(), float(m), float(1. - m), _stream()), 'ema')
+    torch.cuda.synchronize()
+    assert torch.equal(kd.cpu(), want)
+
+
+# ---------------------------------------------------------------------------------------------------------------- encoder trunk
+def _pair(seed):
+    e, oe = Encoder(), O.OracleEncoder()
+    sd = O.seeded_encoder_state(oe, seed)
+    oe.load_state_dict(sd)
+    e.load_state_dict(sd)
+    return e.to(DEV), oe
+
+
+def _check_encoder_grads(e_named, o_named, tol, worst_tol):
+    """whole-gradient relative error <= tol, every tensor <= worst_tol (zero-gradient biases: small on both sides)"""
+    num = den = 0.0
+    worst = (0.0, None)
+    o = dict(o_named)
+    for k, p in e_named:
+        if not p.requires_grad:
+            continue
+        ge, go = p.grad.detach().double().cpu(), o[k].grad.detach().double()
+        if k.split('encoder_q.')[-1] in ZERO_GRAD_BIASES:
+            scale = max(float(v.grad.abs().max()) for kk, v in o.items() if v.grad is not None and kk.endswith('weight'))
+            assert float(ge.abs().max()) <= 2e-2 * scale + 1e-7, (k, float(ge.abs().max()), scale)
+            continue
+        num += float((ge - go).pow(2).sum())
+        den += float(go.pow(2).sum())
+        r = float((ge - go).norm() / (go.norm() + 1e-30))
+        if r > worst[0]:
+            worst = (r, k)
+    whole = (num / den) ** 0.5
+    assert whole <= tol, (whole, worst)
+    assert worst[0] <= worst_tol, worst
+    return whole, worst
+
+
+@pytest.mark.parametrize('N,hw', [(8, (32, 32)), (3, (48, 48)), (2, (37, 29))])
+def test_encoder_trunk_forward_and_gradients_against_oracle(N, hw):
+    e, oe = _pair(300 + N)
+    _, ob = _pair(300 + N)
+    ob.bf16_storage = True
+    e.train()
+    x = CO.contrastive_batch(310 + N, N, 1, hw=max(hw))[:, 0, :, :hw[0], :hw[1]].contiguous()
+    g = torch.Generator().manual_seed(N)
+    r1, r2 = torch.randn(N, 256, generator=g), torch.randn(N, 256, generator=g)
+    outs = []
+    for o in (oe, ob):
+        o.train()
+        fo, qo = o(x)
+        ((fo * r1).sum() + (qo['q'] * r2).sum()).backward()
+        outs.append((fo.detach(), qo['q'].detach()))
+    fe, qe = e(x.to(DEV))
+    assert fe.requires_grad
+    assert _rel(fe.detach(), outs[0][0]) < 1.5e-2 and _rel(qe['q'].detach(), outs[0][1]) < 2e-2          # fp32 graph
+    assert _rel(fe.detach(), outs[1][0]) < 3e-3 and _rel(qe['q'].detach(), outs[1][1]) < 4e-3            # bf16-storage graph
+    ((fe * r1.to(DEV)).sum() + (qe['q'] * r2.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    _check_encoder_grads(list(e.named_parameters()), list(ob.named_parameters()), 6e-2, 1.2e-1)
+    _check_encoder_grads(list(e.named_parameters()), list(oe.named_parameters()), 1.5e-1, 3e-1)
+    # BatchNorm running statistics moved like torch's
+    for k, v in oe.state_dict().items():
+        if 'running' in k:
+            assert _rel(e.state_dict()[k], v) < 5e-3, k
+        if 'num_batches' in k:
+            assert int(e.state_dict()[k]) == int(v) == 1
+
+
+def test_second_training_forward_invalidates_the_first_ones_backward():
+    e, _ = _pair(9)
+    e.train()
+    x = CO.contrastive_batch(1, 2, 1)[:, 0].to(DEV)
+    f1, _ = e(x)
+    f2, _ = e(x)
+    f2.sum().backward()
+    with pytest.raises(RuntimeError, match='overwritten'):
+        f1.sum().backward()
+
+
+def test_frozen_trunk_trains_the_head_only():
+    """encoder_freeze_mode 'pre_q' of the blind pipeline: only mlp.* is trainable - the trunk runs the inference kernels, torch autograd the head"""
+    e, oe = _pair(12)
+    for k, p in list(e.named_parameters()) + list(oe.named_parameters()):
+        p.requires_grad = 'mlp' in k
+    e.train(); oe.train()
+    x = CO.contrastive_batch(2, 4, 1)[:, 0]
+    (oe(x)[1]['q'] ** 2).sum().backward()
+    fea, q = e(x.to(DEV))
+    assert not fea.requires_grad
+    (q['q'] ** 2).sum().backward()
+    for (k, p), (_, po) in zip(e.named_parameters(), oe.named_parameters()):
+        if 'mlp' in k:
+            assert _rel(p.grad, po.grad) < 3e-2, k
+
+
+# ---------------------------------------------------------------------------------------------------------------- whole steps behind the handlers
+def _seed_handler(h, oh, seed):
+    enc = O.seeded_encoder_state(O.OracleEncoder(), seed)
+    queue = CO.seeded_queue(256, oh.net.K, seed + 1)
+    for net in (h.net, oh.net):
+        net.encoder_q.load_state_dict(enc)
+        net.encoder_k.load_state_dict(enc)
+        net.queue.copy_(queue)
+        net.queue_ptr[0] = 0
+
+
+def _warm_queue(h, oh, seed, n):
+    """mid-training state: the head of the queue holds keys of earlier batches (the oracle's), so the negatives matter and the loss is O(1)"""
+    with torch.no_grad():
+        oh.net.eval()
+        k = F.normalize(oh.net.encoder_k(CO.contrastive_batch(seed, n, 1)[:, 0])[1]['q'], dim=1)
+        for net in (h.net, oh.net):
+            net.queue[:, :n] = k.t().to(net.queue.device)
+            net.queue_ptr[0] = n
+
+
+def _check_step(h, oh, loss, out, oloss, ologits, logits_tol=0.25):
+    assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (float(loss), float(oloss))
+    # logits are cosines / T (T = 0.07): 0.25 = a cosine error of 0.0175 from six bf16 layers and the head
+    assert float((out - ologits).abs().max()) <= logits_tol, float((out - ologits).abs().max())
+
+
+@pytest.mark.parametrize('crops,N', [(2, 8), (3, 4)])
+def test_moco_training_step_against_oracle(crops, N):
+    h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=crops, lr=1e-3)
+    oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=crops, lr=1e-3)
+    oh.net.encoder_q.bf16_storage = oh.net.encoder_k.bf16_storage = True
+    assert list(h.net.state_dict().keys()) == list(oh.net.state_dict().keys())
+    assert type(h.optimizer).__name__ == 'FlatAdam'
+    _seed_handler(h, oh, 400 + crops)
+    _warm_queue(h, oh, 450 + crops, 64)
+    k_before = h.net.encoder_k.flat_p.clone()
+    x = CO.contrastive_batch(410 + crops, N, crops).view(N, 3 * crops, 32, 32)
+    oloss, ologits, _ = oh.run_train(x)
+    loss, out = h.run_train(x=x, y=None)
+    assert out.shape == (N, 1 + 8192) and not out.is_cuda
+    _check_step(h, oh, loss, out, oloss, ologits)
+    _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+    # key encoder: momentum update of the PRE-step query weights (exact arithmetic), untouched by the optimizer
+    want_k = torch.cat([p.detach().reshape(-1) for p in oh.net.encoder_k.parameters()])
+    assert torch.allclose(h.net.encoder_k.flat_p.cpu(), want_k, atol=1e-7, rtol=1e-6)
+    assert not torch.equal(h.net.encoder_k.flat_p, k_before)
+    # queue: this batch's keys (one per image) after the warm columns
+    assert int(h.net.queue_ptr) == int(oh.net.queue_ptr) == 64 + N
+    assert float((h.net.queue[:, 64:64 + N].cpu() - oh.net.queue[:, 64:64 + N]).abs().max()) < 2.5e-2
+    assert torch.equal(h.net.queue[:, 64 + N:].cpu(), oh.net.queue[:, 64 + N:])
+    # Adam: first step moves every weight with a non-negligible gradient by lr against the gradient's sign
+    moved = torch.cat([p.detach().reshape(-1) for p in h.net.encoder_q.parameters()]).cpu()
+    omoved = torch.cat([p.detach().reshape(-1) for p in oh.net.encoder_q.parameters()])
+    assert float((moved - omoved).abs().mean()) < 1e-4
+    # a second step runs on the re-packed filters and stays close to the oracle's
+    x2 = CO.contrastive_batch(420 + crops, N, crops).view(N, 3 * crops, 32, 32)
+    oloss2, ologits2, _ = oh.run_train(x2)
+    loss2, out2 = h.run_train(x=x2, y=None)
+    _check_step(h, oh, loss2, out2, oloss2, ologits2, logits_tol=0.6)
+
+
+def test_supmoco_training_steps_against_oracle():
+    keys = [('gaussian_noise_scale',), ('poisson_noise_scale',), ('gray_noise_boolean',)]
+    meta = torch.tensor([[0.8, 0, 1], [0, 0.3, 0], [0.7, 0, 1], [0, 0.9, 1]])
+    h = define_model('supmoco', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
+                     data_type='noise', labelling_strategy='double_precision')
+    oh = CO.OracleContrastiveHandler('supmoco', crop_count=3, lr=1e-3)
+    oh.net.encoder_q.bf16_storage = oh.net.encoder_k.bf16_storage = True
+    _seed_handler(h, oh, 500)
+    col, fam, weights, total = CO.oracle_label_structure([k[0] for k in keys], 'noise', 'double_precision')
+    olabels = torch.tensor([CO.oracle_class_label(r, col, fam, weights, 'double_precision') for r in meta.numpy()])
+    oh.net.register_classes(total)
+    for step in range(2):
+        x = CO.contrastive_batch(510 + step, 4, 3).view(4, 9, 32, 32)
+        oloss, ologits, ofea = oh.run_train(x, olabels)
+        loss, emb = h.run_train(x=x, y=meta, metadata_keys=keys)
+        assert h.total_classes == total and h.net.num_classes == total
+        assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (step, float(loss), float(oloss))
+        assert _rel(emb, ofea) < 5e-3
+        if step == 1:       # the second step has queue positives (images 0 and 2 share a class with the first step's keys)
+            _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+        else:               # both sides start the second step from the oracle's state (Adam's first step amplifies gradient noise into +-lr)
+            assert float((h.net.encoder_q.flat_p.cpu() - torch.cat([p.detach().reshape(-1) for p in oh.net.encoder_q.parameters()])).abs().mean()) < 1e-4
+            h.net.load_state_dict(oh.net.state_dict())
+    assert torch.equal(h.net.queue_labels[:8].cpu(), oh.net.queue_labels[:8]) and int(h.net.queue_ptr) == 8
+
+
+def test_contrastive_handlers_evaluate_like_the_reference_test():
+    """automated_testing/contrastive_tests/test_contrastive_cpu_execute.py:33-50: run_eval of a [1, 3, 16, 16] image -> (embedding [1, 256], q)"""
+    for name in ('mococontrastive', 'supmoco'):
+        h = define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=4)
+        (emb, q), loss, timing = h.run_eval(x=torch.rand(1, 3, 16, 16), y=None)
+        assert emb.shape == (1, 256) and q.shape == (1, 256) and loss is None and timing is None
+        assert h.get_embedding_len() == 256
