@@ -17,6 +17,7 @@ creation order; the convolutional trunk runs hand-written HIP kernels and fails 
 
 The ``mlp`` head (two 256 x 256 linear layers on an [N, 256] matrix) is plain torch (rocBLAS) with torch autograd."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -35,6 +36,29 @@ def _ptr(t):
 
 def _dev_bytes(ctypes_array, dev):
     return torch.from_numpy(np.frombuffer(bytes(ctypes_array), dtype=np.uint8).copy()).to(dev)
+
+
+class _LaunchGraph:
+    """A fixed launch list over fixed buffers: eager the first time (which also warms every lazily initialised piece up), captured as a
+    hipGraph the second, replayed from then on - the trunk is ~20 (forward) / ~30 (backward) short launches, and issuing them one by one
+    from Python takes longer than they run.  RUMPY_ENC_GRAPH=0 keeps it eager (A/B, debugging)."""
+    enabled = os.environ.get('RUMPY_ENC_GRAPH', '1') != '0'
+
+    def __init__(self):
+        self.calls, self.graph = 0, None
+
+    def run(self, launches, dev):
+        self.calls += 1
+        if not self.enabled or self.calls == 1 or torch.cuda.is_current_stream_capturing():
+            launches()
+            return
+        if self.graph is None:
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launches()
+            self.graph = g
+        self.graph.replay()
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -72,6 +96,7 @@ class Encoder(nn.Module):
         self._stats_epoch = 0        # bumped whenever a kernel rewrites the running statistics
         self._train_plans = {}
         self._train_images = None    # (key, [(w_fwd, w_dgrad, b_packed)] of convs 1..5, keep-alive)
+        self._img_store = {}         # slot -> persistent image buffers + pack table (captured graphs hold their addresses)
         self._token = 0              # forward passes of the training plan: a backward pass must belong to the last one
         self.flat_p = self.flat_g = None
         self.param_list, self.offsets, self.grad_views = None, None, None
@@ -95,7 +120,7 @@ class Encoder(nn.Module):
         self.flat_p = flat_p
         self.grad_views = [self.flat_g[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.param_list)]
         self._packed = self._folded = self._train_images = None
-        self._train_plans = {}
+        self._train_plans, self._plans, self._img_store = {}, {}, {}       # captured graphs hold the old storages' addresses
         self.attach_grads()
 
     def attach_grads(self):
@@ -115,6 +140,7 @@ class Encoder(nn.Module):
             self.flatten()
         else:
             self._packed = self._folded = self._train_images = None
+            self._train_plans, self._plans, self._img_store = {}, {}, {}
         return self
 
     def weights_rewritten(self):
@@ -123,7 +149,17 @@ class Encoder(nn.Module):
 
     # ------------------------------------------------------------------ filter images
     def _convs(self):
-        return [self.E[3 * i] for i in range(6)], [self.E[3 * i + 1] for i in range(6)]
+        c = self.__dict__.get('_conv_cache')
+        if c is None or c[0] is not self.E:               # nn.Sequential indexing is slow enough to show in a 2 ms step
+            mods = list(self.E.children())
+            c = self.__dict__['_conv_cache'] = (self.E, [mods[3 * i] for i in range(6)], [mods[3 * i + 1] for i in range(6)])
+        return c[1], c[2]
+
+    def train(self, mode=True):
+        """nn.Module.train walks every sub-module; the handlers call it at every step (base_architecture.py:472) - skipped when nothing changes"""
+        if self.training == mode and self.E.training == mode and self.mlp.training == mode and all(b.training == mode for b in self._convs()[1]):
+            return self
+        return super().train(mode)
 
     def _key(self, with_stats):
         convs, bns = self._convs()
@@ -132,20 +168,27 @@ class Encoder(nn.Module):
             ts += [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
         return tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + ((self._stats_epoch,) if with_stats else ())
 
-    def _pack(self, weights, biases, dev, dgrad=False):
+    def _pack(self, weights, biases, dev, dgrad=False, slot='raw'):
         """[(w fp32 OIHW, b)] of the five 64-multiple convs -> MFMA fragment images through rumpy_pack_weights
-        (dgrad: also the transposed + flipped image the data gradient convolves with)"""
-        items, out = [], []
-        for w, b in zip(weights, biases):
-            cout, cin = w.shape[:2]
-            wf = torch.empty(cout * cin * 9, dtype=BF16, device=dev)
-            wd = torch.empty(cout * cin * 9, dtype=BF16, device=dev) if dgrad else None
-            bp = torch.empty(cout, dtype=torch.float32, device=dev)
-            items.append(L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(wf), w_dgrad=_ptr(wd), b_packed=_ptr(bp), cout=cout, cin=cin, kind=0, shuffle=0))
-            out.append((wf, wd, bp) if dgrad else (wf, bp))
-        tab = torch.from_numpy(np.frombuffer(bytes((L.PackItem * len(items))(*items)), dtype=np.uint8).copy()).to(dev)
-        L.check(L.lib().rumpy_pack_weights(_ptr(tab), len(items), torch.cuda.current_stream(dev).cuda_stream), 'rumpy_pack_weights')
-        return out, (tab, weights, biases)
+        (dgrad: also the transposed + flipped image the data gradient convolves with).  The images of a slot live in persistent buffers -
+        captured launch graphs read them - and so does the item table as long as the sources' addresses stay."""
+        st = self._img_store.get(slot)
+        if st is None or st['dev'] != dev:
+            out = []
+            for w in weights:
+                cout, cin = w.shape[:2]
+                wf = torch.empty(cout * cin * 9, dtype=BF16, device=dev)
+                wd = torch.empty(cout * cin * 9, dtype=BF16, device=dev) if dgrad else None
+                bp = torch.empty(cout, dtype=torch.float32, device=dev)
+                out.append((wf, wd, bp) if dgrad else (wf, bp))
+            st = self._img_store[slot] = dict(dev=dev, imgs=out, src=None, tab=None)
+        src = tuple(_ptr(t) for t in list(weights) + list(biases))
+        if st['src'] != src:
+            items = [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[0]), w_dgrad=_ptr(im[1]) if dgrad else None, b_packed=_ptr(im[-1]),
+                                cout=w.shape[0], cin=w.shape[1], kind=0, shuffle=0) for w, b, im in zip(weights, biases, st['imgs'])]
+            st['tab'], st['src'] = _dev_bytes((L.PackItem * len(items))(*items), dev), src
+        L.check(L.lib().rumpy_pack_weights(_ptr(st['tab']), len(weights), torch.cuda.current_stream(dev).cuda_stream), 'rumpy_pack_weights')
+        return st['imgs'], (st['tab'], weights, biases)
 
     def _raw_images(self, dev):
         key = self._key(False)
@@ -168,8 +211,11 @@ class Encoder(nn.Module):
                     s = bn.weight.float() / torch.sqrt(bn.running_var.float() + bn.eps)
                     ws.append((c.weight.float() * s[:, None, None, None]).contiguous())
                     bs.append(((c.bias.float() - bn.running_mean.float()) * s + bn.bias.float()).contiguous())
-            imgs, keep = self._pack(ws[1:], bs[1:], dev)
-            self._folded = (key, [(ws[0], bs[0])] + imgs, keep)
+            imgs, keep = self._pack(ws[1:], bs[1:], dev, slot='folded')
+            head = self._img_store['folded'].setdefault('head', (torch.empty_like(ws[0]), torch.empty_like(bs[0])))
+            head[0].copy_(ws[0])
+            head[1].copy_(bs[0])
+            self._folded = (key, [head] + imgs, keep)
         return self._folded[1]
 
     # ------------------------------------------------------------------ execution
@@ -183,7 +229,9 @@ class Encoder(nn.Module):
                 acts.append(torch.empty(N, h, w, cout, dtype=BF16, device=dev))
             part = torch.empty(max(int(L.lib().rumpy_enc_bn_partial_floats(a.shape[0] * a.shape[1] * a.shape[2], a.shape[3])) for a in acts),
                                dtype=torch.float32, device=dev)
-            p = dict(acts=acts, partial=part, scale_shift=torch.empty(2 * 256, dtype=torch.float32, device=dev))
+            p = dict(acts=acts, partial=part, scale_shift=torch.empty(2 * 256, dtype=torch.float32, device=dev),
+                     x=torch.empty(N, 3, H, W, dtype=torch.float32, device=dev), fea=torch.empty(N, 256, dtype=torch.float32, device=dev),
+                     graphs={}, gkey={})
             if len(self._plans) > 8:
                 self._plans.clear()
             self._plans[k] = p
@@ -195,42 +243,58 @@ class Encoder(nn.Module):
             raise RuntimeError('rumpy_amd: the degradation encoder runs on the GPU only (no CPU fallback)')
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError('rumpy_amd: encoder input must be [N,3,H,W]')
-        x = x.float().contiguous()
         dev = x.device
         N, _, H, W = x.shape
         train = self.training
         plan = self._plan(N, H, W, dev)
         imgs = self._raw_images(dev) if train else self._folded_images(dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
         _, bns = self._convs()
         acts = plan['acts']
         w0, b0 = imgs[0]
-        L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(x), w=_ptr(w0), b=_ptr(b0), out=_ptr(acts[0]), N=N, C=3, H=H, W=W, cout=64,
-                                               neg_slope_m1=0.0 if train else SLOPE - 1.0), stream)
-        h, w = H, W
-        for i, (cin, cout, stride) in enumerate(LAYERS):
-            if i > 0:
-                wf, bp = imgs[i]
-                L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(acts[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(acts[i]), N=N, H=h, W=w, cin=cin,
-                                                       cout=cout, stride=stride, neg_slope=1.0 if train else SLOPE), stream)
-                h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
-            if train:
-                bn = bns[i]
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
-                L.call('rumpy_enc_bn_train', L.EncBnArgs(x=_ptr(acts[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias), running_mean=_ptr(bn.running_mean),
-                                                         running_var=_ptr(bn.running_var), num_batches_tracked=_ptr(bn.num_batches_tracked),
-                                                         partial=_ptr(plan['partial']), scale_shift=_ptr(plan['scale_shift']), P=N * h * w, C=cout,
-                                                         eps=bn.eps, momentum=mom, neg_slope=SLOPE), stream)
+        xs, fea = plan['x'], plan['fea']
+        xs.copy_(x)
+        graphable = all(bn.momentum is not None for bn in bns)      # a cumulative average changes its factor every step
+
+        def launches():
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(xs), w=_ptr(w0), b=_ptr(b0), out=_ptr(acts[0]), N=N, C=3, H=H, W=W, cout=64,
+                                                   neg_slope_m1=0.0 if train else SLOPE - 1.0), stream)
+            h, w = H, W
+            for i, (cin, cout, stride) in enumerate(LAYERS):
+                if i > 0:
+                    wf, bp = imgs[i]
+                    L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(acts[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(acts[i]), N=N, H=h, W=w, cin=cin,
+                                                           cout=cout, stride=stride, neg_slope=1.0 if train else SLOPE), stream)
+                    h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
+                if train:
+                    bn = bns[i]
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+                    L.call('rumpy_enc_bn_train', L.EncBnArgs(x=_ptr(acts[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias),
+                                                             running_mean=_ptr(bn.running_mean), running_var=_ptr(bn.running_var),
+                                                             num_batches_tracked=_ptr(bn.num_batches_tracked), partial=_ptr(plan['partial']),
+                                                             scale_shift=_ptr(plan['scale_shift']), P=N * h * w, C=cout, eps=bn.eps, momentum=mom,
+                                                             neg_slope=SLOPE), stream)
+            L.check(L.lib().rumpy_enc_pool(_ptr(acts[5]), _ptr(fea), N, h * w, 256, stream), 'rumpy_enc_pool')
+
+        # the launch list depends on the mode and on the addresses it reads: parameters, statistics and the slot's image buffers
+        gkey = (train, _ptr(w0), _ptr(imgs[1][0]), _ptr(bns[0].weight), _ptr(bns[0].running_mean))
+        if graphable:
+            if plan['gkey'].get(train) != gkey:
+                plan['graphs'][train], plan['gkey'][train] = _LaunchGraph(), gkey
+            plan['graphs'][train].run(launches, dev)
+        else:
+            launches()
         if train:
             self._stats_epoch += 1
-        fea = torch.empty(N, 256, dtype=torch.float32, device=dev)
-        L.check(L.lib().rumpy_enc_pool(_ptr(acts[5]), _ptr(fea), N, h * w, 256, stream), 'rumpy_enc_pool')
-        return fea
+        return fea.clone()
 
     # ------------------------------------------------------------------ training: forward that keeps what the backward pass needs
     def _trunk_params(self):
         convs, bns = self._convs()
-        return [t for c, b in zip(convs, bns) for t in (c.weight, c.bias, b.weight, b.bias)]
+        c = self.__dict__.get('_trunk_cache')
+        if c is None or c[0] is not convs[0].weight:      # Parameter objects are replaced by .to() / flatten() only
+            c = self.__dict__['_trunk_cache'] = (convs[0].weight, [t for cv, b in zip(convs, bns) for t in (cv.weight, cv.bias, b.weight, b.bias)])
+        return c[1]
 
     def _training_images(self, dev):
         key = self._key(False)
@@ -238,7 +302,7 @@ class Encoder(nn.Module):
             convs, _ = self._convs()
             ws = [c.weight.detach() for c in convs]
             bs = [c.bias.detach() for c in convs]
-            imgs, keep = self._pack(ws[1:], bs[1:], dev, dgrad=True)
+            imgs, keep = self._pack(ws[1:], bs[1:], dev, dgrad=True, slot='train')
             self._train_images = (key, imgs, keep)
         return self._train_images[1]
 
@@ -262,7 +326,8 @@ class Encoder(nn.Module):
         part = new(max(int(lib.rumpy_enc_bn_partial_floats(t.shape[0] * t.shape[1] * t.shape[2], t.shape[3])) for t in z), dtype=torch.float32)
         p = dict(z=z, a=a, dz=dz, da=da, dims=dims, partial=part, coef=new(3 * 256, dtype=torch.float32),
                  ss=[new(2 * c, dtype=torch.float32) for _, c, _ in LAYERS], saved=[new(2 * c, dtype=torch.float32) for _, c, _ in LAYERS],
-                 zero_bias=torch.zeros(256, dtype=torch.float32, device=dev),
+                 zero_bias=torch.zeros(256, dtype=torch.float32, device=dev), x=new(N, 3, H, W, dtype=torch.float32),
+                 fea=new(N, 256, dtype=torch.float32), dfea=new(N, 256, dtype=torch.float32),
                  head_slab=new(max(1, int(lib.rumpy_head_wgrad_slab_floats(3, 64))), dtype=torch.float32))
         # ---- weight-gradient jobs of convs 1..5: unit = (layer, cin chunk, cout tile); a unit's pixel tiles are cut into ranges of `per` tiles,
         # one job + one slab each; one reduce item per unit (rumpy_wgrad_grouped / rumpy_wgrad_reduce of the SR path)
@@ -302,35 +367,46 @@ class Encoder(nn.Module):
             raise RuntimeError('rumpy_amd: encoder input must be [N,3,H,W]')
         if self.flat_p is None or self.E[0].weight.data_ptr() != self.flat_p.data_ptr():
             self.flatten()
-        x = x.detach().float().contiguous()
         dev = x.device
         N, _, H, W = x.shape
         plan = self._train_plan(N, H, W, dev)
         imgs = self._training_images(dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
         convs, bns = self._convs()
         z, a = plan['z'], plan['a']
-        L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(x), w=_ptr(convs[0].weight), b=_ptr(convs[0].bias), out=_ptr(z[0]), N=N, C=3, H=H, W=W,
-                                               cout=64, neg_slope_m1=0.0), stream)
-        for i, (cin, cout, stride) in enumerate(LAYERS):
-            hi, wi, ho, wo = plan['dims'][i]
-            if i > 0:
-                wf, _, bp = imgs[i - 1]
-                L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
-                                                       cout=cout, stride=stride, neg_slope=1.0), stream)
-            bn = bns[i]
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
-            args = L.EncBnArgs(x=_ptr(z[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias), running_mean=_ptr(bn.running_mean),
-                               running_var=_ptr(bn.running_var), num_batches_tracked=_ptr(bn.num_batches_tracked), partial=_ptr(plan['partial']),
-                               scale_shift=_ptr(plan['ss'][i]), P=N * ho * wo, C=cout, eps=bn.eps, momentum=mom, neg_slope=SLOPE)
-            L.check(L.lib().rumpy_enc_bn_train_keep(C.byref(args), _ptr(a[i]), _ptr(plan['saved'][i]), stream), 'rumpy_enc_bn_train_keep')
+        xs, fea = plan['x'], plan['fea']
+        xs.copy_(x.detach())
+
+        def launches():
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(xs), w=_ptr(convs[0].weight), b=_ptr(convs[0].bias), out=_ptr(z[0]), N=N, C=3, H=H, W=W,
+                                                   cout=64, neg_slope_m1=0.0), stream)
+            for i, (cin, cout, stride) in enumerate(LAYERS):
+                hi, wi, ho, wo = plan['dims'][i]
+                if i > 0:
+                    wf, _, bp = imgs[i - 1]
+                    L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
+                                                           cout=cout, stride=stride, neg_slope=1.0), stream)
+                bn = bns[i]
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+                args = L.EncBnArgs(x=_ptr(z[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias), running_mean=_ptr(bn.running_mean),
+                                   running_var=_ptr(bn.running_var), num_batches_tracked=_ptr(bn.num_batches_tracked),
+                                   partial=_ptr(plan['partial']), scale_shift=_ptr(plan['ss'][i]), P=N * ho * wo, C=cout, eps=bn.eps, momentum=mom,
+                                   neg_slope=SLOPE)
+                L.check(L.lib().rumpy_enc_bn_train_keep(C.byref(args), _ptr(a[i]), _ptr(plan['saved'][i]), stream), 'rumpy_enc_bn_train_keep')
+            ho, wo = plan['dims'][5][2:]
+            L.check(L.lib().rumpy_enc_pool(_ptr(a[5]), _ptr(fea), N, ho * wo, 256, stream), 'rumpy_enc_pool')
+
+        gkey = (_ptr(convs[0].weight), _ptr(imgs[0][0]), _ptr(bns[0].weight), _ptr(bns[0].running_mean))
+        if plan.get('gkey') != gkey:
+            plan['gkey'], plan['fwd_graph'], plan['bwd_graph'] = gkey, _LaunchGraph(), _LaunchGraph()
+        if all(bn.momentum is not None for bn in bns):
+            plan['fwd_graph'].run(launches, dev)
+        else:
+            launches()
         self._stats_epoch += 1
-        fea = torch.empty(N, 256, dtype=torch.float32, device=dev)
-        ho, wo = plan['dims'][5][2:]
-        L.check(L.lib().rumpy_enc_pool(_ptr(a[5]), _ptr(fea), N, ho * wo, 256, stream), 'rumpy_enc_pool')
         self._token += 1
         plan['token'] = self._token
-        return fea, (N, H, W, self._token), x
+        return fea.clone(), (N, H, W, self._token), xs
 
     def _train_backward(self, x, token, dfea):
         N, H, W, tok = token
@@ -342,31 +418,36 @@ class Encoder(nn.Module):
         if plan['flat_g_ptr'] != self.flat_g.data_ptr():
             raise RuntimeError('rumpy_amd: the encoder was re-flattened between forward and backward')
         lib = L.lib()
-        stream = torch.cuda.current_stream(dev).cuda_stream
         imgs = self._training_images(dev)
         convs, bns = self._convs()
         gidx = {id(q): j for j, q in enumerate(self.param_list)}
         gv = lambda t: self.grad_views[gidx[id(t)]]
-        dfea = dfea.detach().float().contiguous()
+        dpool = plan['dfea']
+        dpool.copy_(dfea.detach())
         z, a, dz, da = plan['z'], plan['a'], plan['dz'], plan['da']
-        for i in range(5, -1, -1):
-            cin, cout, stride = LAYERS[i]
-            hi, wi, ho, wo = plan['dims'][i]
-            bn = bns[i]
-            L.call('rumpy_enc_bn_bwd', L.EncBnBwdArgs(z=_ptr(z[i]), da=None if i == 5 else _ptr(da[i]), dpool=_ptr(dfea) if i == 5 else None,
-                                                      scale_shift=_ptr(plan['ss'][i]), saved=_ptr(plan['saved'][i]), gamma=_ptr(bn.weight),
-                                                      dgamma=_ptr(gv(bn.weight)), dbeta=_ptr(gv(bn.bias)), dz=_ptr(dz[i]),
-                                                      partial=_ptr(plan['partial']), coef=_ptr(plan['coef']), N=N, Ho=ho, Wo=wo, C=cout,
-                                                      up=stride, Hz=hi if stride == 2 else ho, Wz=wi if stride == 2 else wo,
-                                                      neg_slope=SLOPE, scale=1.0), stream)
-            if i > 0:      # data gradient: the stride-1 convolution of dz (on the input's grid) with the transposed, flipped filter
-                _, wd, _ = imgs[i - 1]
-                L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(dz[i]), w=_ptr(wd), bias=_ptr(plan['zero_bias']), out=_ptr(da[i - 1]), N=N, H=hi, W=wi,
-                                                       cin=cout, cout=cin, stride=1, neg_slope=1.0), stream)
-        L.check(lib.rumpy_wgrad_grouped(_ptr(plan['jobs']), plan['njobs'], 4, 0, stream), 'rumpy_wgrad_grouped')
-        L.check(lib.rumpy_wgrad_reduce(_ptr(plan['items']), plan['nitems'], stream), 'rumpy_wgrad_reduce')
-        L.call('rumpy_head_wgrad', L.HeadWgradArgs(x=_ptr(x), dy=_ptr(dz[0]), slab=_ptr(plan['head_slab']), gw=_ptr(gv(convs[0].weight)),
-                                                   gb=_ptr(gv(convs[0].bias)), N=N, C=3, H=H, W=W, cout=64, scale=1.0), stream)
+
+        def launches():
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for i in range(5, -1, -1):
+                cin, cout, stride = LAYERS[i]
+                hi, wi, ho, wo = plan['dims'][i]
+                bn = bns[i]
+                L.call('rumpy_enc_bn_bwd', L.EncBnBwdArgs(z=_ptr(z[i]), da=None if i == 5 else _ptr(da[i]), dpool=_ptr(dpool) if i == 5 else None,
+                                                          scale_shift=_ptr(plan['ss'][i]), saved=_ptr(plan['saved'][i]), gamma=_ptr(bn.weight),
+                                                          dgamma=_ptr(gv(bn.weight)), dbeta=_ptr(gv(bn.bias)), dz=_ptr(dz[i]),
+                                                          partial=_ptr(plan['partial']), coef=_ptr(plan['coef']), N=N, Ho=ho, Wo=wo, C=cout,
+                                                          up=stride, Hz=hi if stride == 2 else ho, Wz=wi if stride == 2 else wo,
+                                                          neg_slope=SLOPE, scale=1.0), stream)
+                if i > 0:      # data gradient: the stride-1 convolution of dz (on the input's grid) with the transposed, flipped filter
+                    _, wd, _ = imgs[i - 1]
+                    L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(dz[i]), w=_ptr(wd), bias=_ptr(plan['zero_bias']), out=_ptr(da[i - 1]), N=N, H=hi,
+                                                           W=wi, cin=cout, cout=cin, stride=1, neg_slope=1.0), stream)
+            L.check(lib.rumpy_wgrad_grouped(_ptr(plan['jobs']), plan['njobs'], 4, 0, stream), 'rumpy_wgrad_grouped')
+            L.check(lib.rumpy_wgrad_reduce(_ptr(plan['items']), plan['nitems'], stream), 'rumpy_wgrad_reduce')
+            L.call('rumpy_head_wgrad', L.HeadWgradArgs(x=_ptr(x), dy=_ptr(dz[0]), slab=_ptr(plan['head_slab']), gw=_ptr(gv(convs[0].weight)),
+                                                       gb=_ptr(gv(convs[0].bias)), N=N, C=3, H=H, W=W, cout=64, scale=1.0), stream)
+
+        plan['bwd_graph'].run(launches, dev)
         plan['token'] = None
         for t in self._trunk_params():
             if t.requires_grad:

@@ -54,15 +54,22 @@ class MoCo(nn.Module):
         self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.long))
         self.use_graph = False
         self._hooks = None
+        self._ptr_seen = None            # (version counter of queue_ptr, its value): the pointer is read back from the GPU only when it
+                                         # was written from outside (load_state_dict, register_classes) - int(tensor) is a full device sync
 
     # ------------------------------------------------------------------ flat protocol (the trainable part = the query encoder)
     def _flat(self):
         q, k = self.encoder_q, self.encoder_k
-        if q.flat_p is None or q.E[0].weight.data_ptr() != q.flat_p.data_ptr():
-            q.flatten()
-        if k.flat_p is None or k.E[0].weight.data_ptr() != k.flat_p.data_ptr():
-            k.flatten()
+        for e in (q, k):
+            if e.flat_p is None or e._convs()[0][0].weight.data_ptr() != e.flat_p.data_ptr():
+                e.flatten()
         return q
+
+    def train(self, mode=True):
+        """the handlers call net.train() at every step: the walk over ~60 sub-modules is skipped when nothing changes"""
+        if self.training == mode and self.encoder_q.training == mode and self.encoder_k.training == mode:
+            return self
+        return super().train(mode)
 
     param_list = property(lambda self: self._flat().param_list)
     offsets = property(lambda self: self._flat().offsets)
@@ -111,15 +118,25 @@ class MoCo(nn.Module):
             return torch.cat(parts, dim=0)
         return t
 
+    def _queue_pointer(self):
+        seen = self._ptr_seen
+        if seen is not None and seen[0] == (id(self.queue_ptr), self.queue_ptr._version):
+            return seen[1]
+        return int(self.queue_ptr)
+
+    def _advance_queue_pointer(self, ptr):
+        self.queue_ptr[0] = ptr
+        self._ptr_seen = ((id(self.queue_ptr), self.queue_ptr._version), ptr)
+
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys):
         """:74-89"""
         keys = self._gathered(keys)
         batch_size = keys.shape[0]
-        ptr = int(self.queue_ptr)
+        ptr = self._queue_pointer()
         assert self.K % batch_size == 0  # for simplicity
         self.queue[:, ptr:ptr + batch_size] = keys.transpose(0, 1)
-        self.queue_ptr[0] = (ptr + batch_size) % self.K
+        self._advance_queue_pointer((ptr + batch_size) % self.K)
 
     def forward(self, im_q, im_k, **kwargs):
         """training: (embedding, logits [N, 1 + K], labels (zeros)) ; evaluation: embedding, or (embedding, q) with get_q (:132-187)"""
@@ -139,6 +156,6 @@ class MoCo(nn.Module):
         pos = torch.einsum('nc,npc->np', q, k.view(n, self.positives, self.vector_dim)).mean(dim=1, keepdim=True)
         neg = q @ self.queue.detach().clone()
         logits = torch.cat([pos, neg], dim=1) / self.T
-        labels = torch.zeros(n, dtype=torch.long)                               # cross-entropy target: column 0
+        labels = torch.zeros(n, dtype=torch.long, device=logits.device)         # cross-entropy target: column 0
         self._dequeue_and_enqueue(k[::self.positives])                          # one key per query joins the queue (:181-184)
         return embedding, logits, labels

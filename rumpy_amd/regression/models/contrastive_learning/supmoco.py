@@ -31,11 +31,11 @@ class SupMoCo(MoCo):
     def _dequeue_and_enqueue(self, keys, labels):
         keys, labels = self._gathered(keys), self._gathered(labels)
         batch_size = keys.shape[0]
-        ptr = int(self.queue_ptr)
+        ptr = self._queue_pointer()
         assert self.K % batch_size == 0  # for simplicity
         self.queue[:, ptr:ptr + batch_size] = keys.transpose(0, 1)
         self.queue_labels[ptr:ptr + batch_size] = labels
-        self.queue_ptr[0] = (ptr + batch_size) % self.K
+        self._advance_queue_pointer((ptr + batch_size) % self.K)
 
     def forward(self, im_q, im_k, labels=None, **kwargs):
         """training: (embedding, logits [N, 1 + K], zeros, encoder outputs) ; evaluation as MoCo (:52-138)"""
@@ -63,6 +63,6 @@ class SupMoCo(MoCo):
         l_pos = (pos_batch + pos_queue) / self.T / (P + same.sum(dim=1))                    # mean positive logit (:99-112)
         l_neg = (q @ self.queue.detach().clone()) / self.T
         logits = torch.cat([l_pos.unsqueeze(1), l_neg], dim=1)
-        full_labels = torch.zeros(n, dtype=torch.long)
+        full_labels = torch.zeros(n, dtype=torch.long, device=logits.device)
         self._dequeue_and_enqueue(k[::P], labels)                                           # one key per query, with the query's label
         return embedding, logits, full_labels, heads

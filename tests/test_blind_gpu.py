@@ -87,13 +87,14 @@ def test_encoder_both_batchnorm_modes_against_oracle(N, hw):
     assert torch.equal(fea, fea2)                        # deterministic, and eval leaves the statistics alone
 
 
-def test_encoder_refuses_cpu_and_trainable_parameters():
+def test_encoder_refuses_cpu_and_single_value_batchnorm():
     e, _ = _encoders(3)
     with pytest.raises(RuntimeError):
         e(torch.zeros(1, 3, 8, 8))
-    next(e.parameters()).requires_grad = True
-    with pytest.raises(RuntimeError):
-        e(torch.zeros(1, 3, 8, 8, device=DEV))
+    e.train()
+    with pytest.raises(RuntimeError):          # 1 x 2 x 2 -> one value per channel after the second stride-2 conv: torch refuses that, too
+        e(torch.zeros(1, 3, 2, 2, device=DEV))
+    # (trainable parameters: tests/test_contrastive_gpu.py - the trunk's backward pass is HIP as well)
 
 
 def _pair(wseed, eval_mode=False, lr=1e-3):

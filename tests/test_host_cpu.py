@@ -516,3 +516,69 @@ def test_safe_image_save_numpy_path_matches_the_reference_expression(tmp_path):
     assert np.array_equal(np.asarray(Image.open(tmp_path / 'a.png')), ref[0]) and np.array_equal(np.asarray(Image.open(tmp_path / 'sub' / 'b.png')), ref[1])
     safe_image_save(torch.from_numpy(im) * 2, str(tmp_path), ['c.png', 'd.png'], config='rgb', max_val=2)
     assert np.array_equal(np.asarray(Image.open(tmp_path / 'c.png')), ref[0])
+
+
+# ------------------------------------------------------------------ contrastive encoder training: host side
+def test_contrastive_handlers_contract_on_cpu():
+    """define_model('mococontrastive' | 'supmoco'): reference state_dict keys, the fused optimizer over the query encoder's flat buffer,
+    the key encoder frozen, checkpoints the blind pipeline's encoder loader reads, and a loud failure instead of a CPU training step."""
+    from oracle import contrastive_oracle as CO
+    from rumpy_amd.SISR.models.blur_kernel_blind_sr.contrastive_blind_sr import load_encoder_model
+    for name, okind in (('mococontrastive', 'mococontrastive'), ('supmoco', 'supmoco')):
+        h = _handler(name, model_name='default', crop_count=3, lr=1e-3)
+        onet = CO.OracleContrastiveHandler(okind, crop_count=3).net
+        assert list(h.net.state_dict().keys()) == list(onet.state_dict().keys())
+        assert [tuple(v.shape) for v in h.net.state_dict().values()] == [tuple(v.shape) for v in onet.state_dict().values()]
+        q, k = h.net.encoder_q, h.net.encoder_k
+        assert all(p.requires_grad for p in q.parameters()) and not any(p.requires_grad for p in k.parameters())
+        assert all(torch.equal(a, b) for a, b in zip(q.parameters(), k.parameters()))
+        assert type(h.optimizer).__name__ == 'FlatAdam' and h.optimizer.net is h.net
+        assert h.net.flat_p.numel() == 1278784 == sum(p.numel() for p in q.parameters())
+        assert q.E[0].weight.data_ptr() == h.net.flat_p.data_ptr() and q.mlp[2].bias.grad.data_ptr() == h.net.flat_g[-256:].data_ptr()
+        assert torch.allclose(h.net.queue.norm(dim=0), torch.ones(8192), atol=1e-5) and int(h.net.queue_ptr) == 0
+        assert h.model_name == name and h.colorspace == 'rgb' and h.im_input == 'unmodified' and h.eval_request_loss is False
+        if not torch.cuda.is_available():
+            with pytest.raises(RuntimeError, match='GPU only|no CPU'):
+                h.run_train(x=torch.rand(2, 9, 16, 16), y=torch.tensor([[0.8, 0.0, 1.0], [0.0, 0.3, 0.0]]),
+                            metadata_keys=[('gaussian_noise_scale',), ('poisson_noise_scale',), ('gray_noise_boolean',)])
+        h.save_model('enc')
+        enc_sd = load_encoder_model(os.path.join(h.model_save_dir, 'enc_0'), torch.device('cpu'))      # <name>_<epoch>
+        assert list(enc_sd.keys()) == list(q.state_dict().keys()) and torch.equal(enc_sd['mlp.2.bias'], q.mlp[2].bias.detach())
+    for bad in (dict(model_name='resnet18'), dict(model_name='default', dropdown=8)):
+        with pytest.raises(RuntimeError, match='HIP path'):
+            _handler('supmoco', **bad)
+
+
+_KEYS_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from rumpy_amd.regression.models.contrastive_learning.encoding_models import Encoder
+from rumpy_amd.regression.models.contrastive_learning.moco import MoCo
+from rumpy_amd.regression.models.contrastive_learning.supmoco import SupMoCo
+rank = int(os.environ['RANK'])
+dist.init_process_group('gloo')
+torch.manual_seed(0)
+m = MoCo(base_encoder=Encoder, K=64)
+keys = torch.full((4, 256), float(rank + 1))
+m._dequeue_and_enqueue(keys)                      # every rank enqueues the keys of BOTH ranks, in rank order
+assert int(m.queue_ptr) == 8 and torch.equal(m.queue[:, :4], torch.ones(256, 4)) and torch.equal(m.queue[:, 4:8], torch.full((256, 4), 2.0))
+s = SupMoCo(device='cpu', base_encoder=Encoder, K=64, positives_per_class=2)
+s.register_classes(5)
+s._dequeue_and_enqueue(keys, torch.tensor([rank, rank, 3, 4]))
+assert int(s.queue_ptr) == 8 and s.queue_labels[:10].tolist() == [0, 0, 3, 4, 1, 1, 3, 4, 5, 5]
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_moco_queue_takes_the_keys_of_every_rank_gloo_world_size_2():
+    d = tempfile.mkdtemp()
+    script = os.path.join(d, 'k.py')
+    with open(script, 'w') as f:
+        f.write(_KEYS_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29641', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
