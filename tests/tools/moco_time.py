@@ -26,3 +26,16 @@ for i in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print('MoCo step N=%d %dx%d: %.3f ms/step, %.0f crops/s (query + key), loss %.4f' % (N, hw, hw, dt * 1e3, 2 * N / dt, float(loss)))
+if len(sys.argv) > 4 and sys.argv[4] == 'cpu':
+    # the oracle's MoCo step on the host cores (bounded sample), for the same crops
+    oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=2, lr=1e-4)
+    torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    xc = xs[0][:8].cpu()
+    oh.run_train(xc)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 10.0:
+        oh.run_train(xc)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    print('CPU oracle MoCo step N=8: %.1f ms/step, %.0f crops/s on %d threads' % (dt * 1e3, 16 / dt, torch.get_num_threads()))
