@@ -109,6 +109,48 @@ class OracleSupMoCo(OracleMoCo):
         return fea, logits, torch.zeros(logits.shape[0], dtype=torch.long)
 
 
+class OracleWeakCon(OracleSupMoCo):
+    """weak_con.py:7-113: negatives weighted by the distance between degradation vectors"""
+
+    def register_vector(self, vector_size):
+        self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.long))                                  # :18
+        self.register_buffer('queue_vectors', torch.zeros(vector_size, self.K))                             # :19
+
+    @torch.no_grad()
+    def enqueue(self, keys, vectors):
+        n, ptr = keys.shape[0], int(self.queue_ptr)                                                          # :22-34
+        self.queue[:, ptr:ptr + n] = keys.t()
+        self.queue_vectors[:, ptr:ptr + n] = vectors
+        self.queue_ptr[0] = (ptr + n) % self.K
+
+    def forward(self, im_q, im_k, q_vector):
+        fea, q, k = self.keys_and_queries(im_q, im_k)
+        P, n = self.positives, q_vector.size()[1]
+        l_pos = torch.mul(q.unsqueeze(1), k.reshape(im_q.shape[0], P, self.dim))                             # :64-65
+        l_pos = (l_pos.sum(dim=2) / self.T).sum(dim=1) / P                                                   # :66-69
+        l_neg = torch.einsum('nc,ck->nk', [q, self.queue.clone().detach()])                                  # :72
+        weights = torch.cdist(q_vector.transpose(1, 0), self.queue_vectors.transpose(1, 0))                  # :90
+        l_neg = l_neg * weights / self.T                                                                     # :92-94
+        logits = torch.cat([l_pos.unsqueeze(1), l_neg], dim=1)                                               # :97
+        self.enqueue(k[[i * P for i in range(n)]], q_vector)                                                 # :103
+        return fea, logits, torch.zeros(logits.shape[0], dtype=torch.long)
+
+
+def oracle_supcon_loss(features, labels, temperature=0.07, base_temperature=0.07):
+    """rumpy/sr_tools/loss_functions.py:41-130 (SupConLoss, contrast_mode 'all', labels given): features [bsz, views, C]"""
+    bsz, views = features.shape[0], features.shape[1]
+    mask = torch.eq(labels.contiguous().view(-1, 1), labels.contiguous().view(-1, 1).T).float()             # :83-86
+    contrast = torch.cat(torch.unbind(features, dim=1), dim=0)                                              # :91
+    adc = torch.div(torch.matmul(contrast, contrast.T), temperature)                                        # :102-104
+    logits = adc - torch.max(adc, dim=1, keepdim=True)[0].detach()                                          # :106-107
+    mask = mask.repeat(views, views)                                                                        # :110
+    logits_mask = torch.scatter(torch.ones_like(mask), 1, torch.arange(bsz * views).view(-1, 1), 0)         # :112-117
+    mask = mask * logits_mask
+    log_prob = logits - torch.log((torch.exp(logits) * logits_mask).sum(1, keepdim=True) + 1e-6)            # :121-122
+    mean_log_prob_pos = (mask * log_prob).sum(1) / mask.sum(1)                                              # :125
+    return (-(temperature / base_temperature) * mean_log_prob_pos).view(views, bsz).mean()                  # :128-129
+
+
 def split_crops(x, crop_count):
     """handlers.py:47-53 / 120-124: [N, crops, 3, H, W] -> (first crop of every image, the other crops)"""
     x = x.view(-1, 3, x.shape[-2], x.shape[-1])
@@ -125,12 +167,26 @@ class OracleContrastiveHandler:
         self.kind, self.crop_count = kind, crop_count
         if kind == 'mococontrastive':
             self.net = OracleMoCo(T=moco_t, positives=crop_count - 1, K=K)
+        elif kind == 'weakcon':
+            self.net = OracleWeakCon(T=moco_t, positives_per_class=crop_count - 1, K=K)
+        elif kind == 'supcon':
+            self.net = OracleEncoder()
         else:
             self.net = OracleSupMoCo(T=moco_t, positives_per_class=crop_count - 1, K=K)
         self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr)
 
     def run_train(self, x, labels=None):
         self.net.train()
+        if self.kind == 'supcon':
+            # handlers.py:241-252 with q = the encoder's 'q' output (the reference line indexes the output dict as a tensor and raises)
+            x = x.view(-1, 3, x.shape[-2], x.shape[-1])
+            fea, out = self.net(x)
+            logits = out['q'].view(-1, self.crop_count, out['q'].shape[1])
+            loss = oracle_supcon_loss(logits, labels)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+            return loss.detach(), logits.detach(), fea.detach()
         if self.kind == 'mococontrastive':
             im_q, im_k = (x[:, 0:3], x[:, 3:]) if self.crop_count == 2 else split_crops(x, self.crop_count)
             fea, logits, target = self.net(im_q, im_k)
@@ -181,6 +237,20 @@ def oracle_label_structure(keys, data_type, strategy):
         radix += [7, 3, 3]
     weights = [int(np.prod(radix[:j])) if j else 1 for j in range(len(radix))]
     return col, fam, weights, int(np.prod(radix))
+
+
+def oracle_degradation_vector(row, col, fam):
+    """:168-200 (vector_retrieval): two slots per family"""
+    v = []
+    if 'noise' in fam:
+        g = row[col['gaussian_noise_scale']]
+        v += [g, 0.0] if g > 0 else [0.0, row[col['poisson_noise_scale']]]
+    if 'compression' in fam:
+        jpeg = ('jpeg_quality_factor' in col and row[col['jpeg_quality_factor']] > 0) or 'jm_qpi' not in col
+        v += [row[col['jpeg_quality_factor']], 0.0] if jpeg else [0.0, row[col['jm_qpi']]]
+    if 'blur' in fam:
+        v += [row[col['sigma_x']], row[col['sigma_y']]]
+    return np.asarray(v, dtype=np.float32)
 
 
 def oracle_class_label(row, col, fam, weights, strategy):

@@ -78,7 +78,25 @@ class _TrunkFn(torch.autograd.Function):
         return (None, None) + (None,) * ctx.nparams
 
 
+class _RepackHook:
+    """what FlatAdam expects of ``net.engine``: the fused update rewrote flat_p, so the bf16 filter images are stale"""
+
+    def __init__(self, encoder):
+        self.encoder = encoder
+
+    def repack(self, stream=None):
+        self.encoder.weights_rewritten()
+
+    def exchange_status(self):
+        return 0
+
+
 class Encoder(nn.Module):
+    # a flattened encoder as a handler's whole net (SupConHandler): the attributes BaseModel / FlatAdam look for (after ``flatten()``)
+    flat_protocol = True
+    supports_fused_l1 = False
+    use_graph = False
+
     def __init__(self, dropdown_q=None):
         super(Encoder, self).__init__()
         if dropdown_q is not None:
@@ -142,6 +160,20 @@ class Encoder(nn.Module):
             self._packed = self._folded = self._train_images = None
             self._train_plans, self._plans, self._img_store = {}, {}, {}
         return self
+
+    def _ensure_engine(self):
+        if self.flat_p is None or not self.flat_p.is_cuda:
+            raise RuntimeError('rumpy_amd: this network only runs on an MI355X through the HIP extension; there is no CPU path')
+
+    @property
+    def engine(self):
+        return _RepackHook(self)
+
+    def mark_weights_clean(self):
+        pass
+
+    def mark_weights_updated(self):
+        self.weights_rewritten()
 
     def weights_rewritten(self):
         """flat_p was rewritten by a kernel (fused Adam, the momentum update): the bf16 filter images are stale."""

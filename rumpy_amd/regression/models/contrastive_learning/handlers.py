@@ -1,12 +1,15 @@
 """Contrastive encoder-training handlers of the MI355X path - same class names, kwargs and return values as
 rumpy/regression/models/contrastive_learning/handlers.py:12-163 (``MocoContrastiveHandler`` -> 'mococontrastive',
-``SupMoCoHandler`` -> 'supmoco'), so ``define_model(name, **kwargs)`` resolves to them.  They train the degradation encoder the blind-SR
-handlers load as ``pre_trained_encoder_weights``.  Not built: WeakCon / SupCon, the drop-down head and its direct regression loss."""
+``SupMoCoHandler`` -> 'supmoco', ``WeakConHandler`` -> 'weakcon' (:166-216), ``SupConHandler`` -> 'supcon' (:219-257)), so
+``define_model(name, **kwargs)`` resolves to them.  They train the degradation encoder the blind-SR handlers load as
+``pre_trained_encoder_weights``.  Not built: the drop-down head and its direct regression loss, torchvision / IDMN backbones."""
 import torch
 
+from rumpy_amd.sr_tools.loss_functions import SupConLoss
 from . import BaseContrastive
 from .moco import MoCo
 from .supmoco import SupMoCo
+from .weak_con import WeakCon
 
 
 def _split_crops(x, crop_count, device):
@@ -88,4 +91,67 @@ class SupMoCoHandler(BaseContrastive):
 
     def run_model(self, x, *args, **kwargs):
         embedding, q = self.net.forward(x, x, get_q=True, **kwargs)
+        return embedding, q
+
+
+class WeakConHandler(BaseContrastive):
+    def __init__(self, device, model_save_dir, eval_mode=False, output_size=10, scheduler=None, scheduler_params=None, lr=1e-4,
+                 model_name='default', crop_count=2, moco_t=0.07, data_type='noise', **kwargs):
+        super(WeakConHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode, **kwargs)
+        self.crop_count = crop_count
+        self.temperature = moco_t
+        self.data_type = data_type
+        self.net = WeakCon(base_encoder=self.define_encoder_model(model_name), positives_per_class=crop_count - 1, T=moco_t, device=device)
+        self.activate_device()
+        self.criterion = torch.nn.CrossEntropyLoss()
+        self.training_setup(lr, scheduler, scheduler_params, device=device, perceptual=None)
+
+    def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):
+        """as SupMoCoHandler.run_train, with the batch's degradation VECTORS (vector_logic) in place of class labels (:190-211)"""
+        if self.eval_mode:
+            raise RuntimeError('Model initialized in eval mode, training not possible.')
+        self.net.train()
+        dev = self._torch_device()
+        vectors = self.vector_logic(y, kwargs['metadata_keys']).to(device=dev)
+        im_q, im_k = _split_crops(x, self.crop_count, dev)
+        embedding, logits, full_labels = self.net(im_q, im_k, vectors.squeeze())
+        loss_contrast = self.criterion(logits, full_labels.to(dev))
+        self.standard_update(loss_contrast)
+        return loss_contrast.detach().cpu().numpy(), embedding.detach().cpu()
+
+    def run_model(self, x, *args, **kwargs):
+        embedding, q = self.net.forward(x, x, get_q=True, **kwargs)
+        return embedding, q
+
+
+class SupConHandler(BaseContrastive):
+    """One encoder, no queue: the supervised contrastive loss over the batch's crops, views = crops of an image (:219-257).
+    Two statements of the reference's version cannot run with any encoder its code base defines and are repaired here, stated: it indexes
+    the encoder's output dict as a tensor (``q.view``, :248 - here ``q['q']``), and it never sets the ``data_type`` its class_logic asks
+    for (here a ``data_type`` argument like the sibling handlers', default 'noise').  The loss itself is the reference's (G20)."""
+
+    def __init__(self, device, model_save_dir, eval_mode=False, output_size=10, scheduler=None, model_name='default', scheduler_params=None,
+                 lr=1e-4, crop_count=2, data_type='noise', **kwargs):
+        super(SupConHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode, **kwargs)
+        self.data_type = data_type
+        self.net = self.define_encoder_model(model_name)()
+        self.activate_device()
+        self.net.flatten()                       # flat parameter / gradient buffers: the fused Adam launch (FlatAdam) walks them
+        self.criterion = SupConLoss()
+        self.training_setup(lr, scheduler, scheduler_params, device=device, perceptual=None)
+        self.crop_count = crop_count
+
+    def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):
+        if self.eval_mode:
+            raise RuntimeError('Model initialized in eval mode, training not possible.')
+        self.net.train()
+        x = x.view(-1, 3, x.size()[-2], x.size()[-1]).to(device=self._torch_device())
+        embedding, q = self.net(x)
+        labels = self.class_logic(y, kwargs['metadata_keys'])
+        loss_contrast = self.criterion(q['q'].view(-1, self.crop_count, q['q'].size()[1]), labels)
+        self.standard_update(loss_contrast)
+        return loss_contrast.detach().cpu().numpy(), embedding.detach().cpu()
+
+    def run_model(self, x, *args, **kwargs):
+        embedding, q = self.net.forward(x)
         return embedding, q

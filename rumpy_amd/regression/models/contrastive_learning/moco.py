@@ -18,20 +18,6 @@ from rumpy_amd import _lib as L
 from .encoding_models import Encoder
 
 
-class _EncoderUpdateHooks:
-    """What FlatAdam expects of ``net.engine``: after the fused update rewrote flat_p, the bf16 filter images are stale (they are rebuilt by
-    the next forward pass)."""
-
-    def __init__(self, encoder):
-        self.encoder = encoder
-
-    def repack(self, stream=None):
-        self.encoder.weights_rewritten()
-
-    def exchange_status(self):
-        return 0
-
-
 class MoCo(nn.Module):
     flat_protocol = True             # BaseModel: param_list / offsets / flat_p / flat_g / attach_grads / engine of the trainable part
     supports_fused_l1 = False
@@ -53,7 +39,6 @@ class MoCo(nn.Module):
         self.register_buffer('queue', nn.functional.normalize(torch.randn(dim, K), dim=0))
         self.register_buffer('queue_ptr', torch.zeros(1, dtype=torch.long))
         self.use_graph = False
-        self._hooks = None
         self._ptr_seen = None            # (version counter of queue_ptr, its value): the pointer is read back from the GPU only when it
                                          # was written from outside (load_state_dict, register_classes) - int(tensor) is a full device sync
 
@@ -86,9 +71,7 @@ class MoCo(nn.Module):
 
     @property
     def engine(self):
-        if self._hooks is None or self._hooks.encoder is not self.encoder_q:
-            self._hooks = _EncoderUpdateHooks(self.encoder_q)
-        return self._hooks
+        return self.encoder_q.engine          # FlatAdam's repack hook: the query encoder's filter images are stale after an update
 
     def mark_weights_clean(self):
         pass

@@ -233,7 +233,7 @@ class BaseModel(nn.Module):
         return new_masks
 
     def _hip_net(self):
-        if isinstance(self.net, HipSRNet) or getattr(self.net, 'flat_protocol', False):     # flat_protocol: MoCo over the HIP encoder
+        if isinstance(self.net, HipSRNet) or (getattr(self.net, 'flat_protocol', False) and self.net.flat_p is not None):   # MoCo / a flattened Encoder
             return self.net
         gen = getattr(self.net, 'hip_generator', None)
         return gen if isinstance(gen, HipSRNet) else None

@@ -5,7 +5,7 @@ Runs ONLY in the build container (needs /root/reference):   python tests/golden/
 define_model('mococontrastive') and define_model('supmoco') - the handlers of the reference's own contrastive tests
 (automated_testing/contrastive_tests/test_contrastive_cpu_execute.py:33-50) - are built on the CPU with the default (DASR) encoder, their
 encoders set from oracle.sr_oracle.seeded_encoder_state and their queues from oracle.contrastive_oracle.seeded_queue, and driven through
-the reference's run_train for two steps each on oracle.contrastive_oracle.contrastive_batch inputs.  Stored: losses, logits, every
+the reference's run_train for two steps each on oracle.contrastive_oracle.contrastive_batch inputs.  stored: losses, logits, every
 gradient's norm and a strided sample of it, weights / running statistics / queue after the steps, and the class labels the reference's
 class_logic assigns to a table of metadata rows under its three labelling strategies."""
 import os
@@ -23,7 +23,8 @@ shim = runpy.run_path(os.path.join(HERE, 'make_golden.py'), run_name='shim_only'
 O = shim['O']
 from oracle import contrastive_oracle as CO  # noqa: E402
 from rumpy.shared_framework.models import define_model  # noqa: E402
-from rumpy.regression.models.contrastive_learning import class_retrieval, partition_metadata, register_metadata  # noqa: E402
+from rumpy.regression.models.contrastive_learning import class_retrieval, partition_metadata, register_metadata, vector_retrieval  # noqa: E402
+from rumpy.sr_tools.loss_functions import SupConLoss  # noqa: E402
 
 STRIDE = 97
 NOISE_KEYS = [('gaussian_noise_scale',), ('poisson_noise_scale',), ('gray_noise_boolean',)]
@@ -129,6 +130,29 @@ def main():
             lab = [class_retrieval(torch.from_numpy(r[:len(keys)]), fam, m_map, mags, total, labelling_strategy=strategy) for r in rows]
             d['labels.%s.%s' % (strategy, tag)] = np.asarray(lab, dtype=np.int64)
             d['labels.%s.%s.total' % (strategy, tag)] = np.asarray(int(total))
+            d['vectors.%s.%s' % (strategy, tag)] = np.stack([vector_retrieval(torch.from_numpy(r[:len(keys)]), fam, m_map).numpy() for r in rows])
+    # ---- WeakCon, three crops, noise vectors ----
+    h = define_model('weakcon', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False, model_name='default',
+                     crop_count=3, lr=1e-3, data_type='noise')
+    seed_net(h.net, 2400)
+    for step in range(2):
+        x = CO.contrastive_batch(2410 + step, 4, 3).view(4, 9, 32, 32)
+        loss, emb = h.run_train(x=x, y=torch.from_numpy(meta), metadata_keys=NOISE_KEYS)
+        d['weak.loss%d' % step] = np.asarray(loss)
+        d['weak.embedding%d' % step] = emb.numpy().copy()
+        if step == 1:
+            dump(d, 'weak.step1', h)
+    d['weak.queue_vectors_head'] = h.net.queue_vectors[:, :8].numpy().copy()
+    dump_state(d, 'weak.after2', h, 8)
+    # ---- SupConLoss on seeded features (the SupConHandler itself raises in the reference: handlers.py:248 indexes the encoder's output
+    # dict as a tensor), value and gradient ----
+    rng = np.random.default_rng(2500)
+    feats = torch.from_numpy(rng.standard_normal((6, 3, 32)).astype(np.float32) * 0.3).requires_grad_(True)
+    labels = torch.tensor([[0., 1., 0., 2., 1., 0.]])
+    loss = SupConLoss()(feats, labels)
+    loss.backward()
+    d['supcon.features'], d['supcon.labels'] = feats.detach().numpy().copy(), labels.numpy()
+    d['supcon.loss'], d['supcon.grad'] = np.asarray(loss.detach()), feats.grad.numpy().copy()
     np.savez_compressed(os.path.join(HERE, 'g20_contrastive_train.npz'), **d)
     print('wrote g20: moco losses', d['moco.loss0'], d['moco.loss1'], 'moco3', d['moco3.loss0'], 'supmoco', d['sup.loss0'], d['sup.loss1'],
           'classes', d['sup.total_classes'], 'queue labels', d['sup.queue_labels_head'])

@@ -278,9 +278,61 @@ def test_supmoco_training_steps_against_oracle():
     assert torch.equal(h.net.queue_labels[:8].cpu(), oh.net.queue_labels[:8]) and int(h.net.queue_ptr) == 8
 
 
+def test_weakcon_training_steps_against_oracle():
+    keys = [('gaussian_noise_scale',), ('poisson_noise_scale',), ('gray_noise_boolean',)]
+    meta = torch.tensor([[0.8, 0, 1], [0, 0.3, 0], [0.7, 0, 1], [0, 0.9, 1]])
+    h = define_model('weakcon', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
+                     data_type='noise')
+    oh = CO.OracleContrastiveHandler('weakcon', crop_count=3, lr=1e-3)
+    oh.net.encoder_q.bf16_storage = oh.net.encoder_k.bf16_storage = True
+    _seed_handler(h, oh, 600)
+    col, fam, _, _ = CO.oracle_label_structure([k[0] for k in keys], 'noise', 'default')
+    vectors = torch.from_numpy(np.stack([CO.oracle_degradation_vector(r, col, fam) for r in meta.numpy()]).T.copy())
+    oh.net.register_vector(vectors.shape[0])
+    for step in range(2):
+        x = CO.contrastive_batch(610 + step, 4, 3).view(4, 9, 32, 32)
+        oloss, ologits, ofea = oh.run_train(x, vectors)
+        loss, emb = h.run_train(x=x, y=meta, metadata_keys=keys)
+        assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (step, float(loss), float(oloss))
+        assert _rel(emb, ofea) < 5e-3
+        if step == 1:       # the second step's negatives carry non-zero weights for the first step's keys
+            _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+        else:
+            h.net.load_state_dict(oh.net.state_dict())
+    assert torch.allclose(h.net.queue_vectors[:, :8].cpu(), oh.net.queue_vectors[:, :8]) and int(h.net.queue_ptr) == 8
+
+
+def test_supcon_training_step_against_oracle():
+    """one encoder, SupConLoss over the crops of the batch (the reference handler raises at handlers.py:248 - it indexes the encoder's output
+    dict as a tensor; the loss itself is pinned by G20, the encoder by G13 / G20)"""
+    keys = [('gaussian_noise_scale',), ('poisson_noise_scale',), ('gray_noise_boolean',)]
+    meta = torch.tensor([[0.8, 0, 1], [0, 0.3, 0], [0.7, 0, 1], [0, 0.9, 1]])
+    h = define_model('supcon', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
+                     data_type='noise', labelling_strategy='double_precision')
+    oh = CO.OracleContrastiveHandler('supcon', crop_count=3, lr=1e-3)
+    oh.net.bf16_storage = True
+    enc = O.seeded_encoder_state(O.OracleEncoder(), 700)
+    for k in list(enc):
+        if k.startswith('mlp.2'):
+            enc[k] = enc[k] * 0.05         # the handler feeds q un-normalised into logits / 0.07: keep them in exp()'s range
+    h.net.load_state_dict(enc)
+    oh.net.load_state_dict(enc)
+    assert type(h.optimizer).__name__ == 'FlatAdam'
+    col, fam, weights, total = CO.oracle_label_structure([k[0] for k in keys], 'noise', 'double_precision')
+    olabels = torch.tensor([[float(CO.oracle_class_label(r, col, fam, weights, 'double_precision')) for r in meta.numpy()]])
+    x = CO.contrastive_batch(710, 4, 3).view(4, 9, 32, 32)
+    oloss, _, ofea = oh.run_train(x, olabels)
+    before = h.net.flat_p.clone()
+    loss, emb = h.run_train(x=x, y=meta, metadata_keys=keys)
+    assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (float(loss), float(oloss))
+    assert _rel(emb, ofea) < 5e-3
+    _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+    assert not torch.equal(h.net.flat_p, before)
+
+
 def test_contrastive_handlers_evaluate_like_the_reference_test():
     """automated_testing/contrastive_tests/test_contrastive_cpu_execute.py:33-50: run_eval of a [1, 3, 16, 16] image -> (embedding [1, 256], q)"""
-    for name in ('mococontrastive', 'supmoco'):
+    for name in ('mococontrastive', 'supmoco', 'weakcon'):
         h = define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=4)
         (emb, q), loss, timing = h.run_eval(x=torch.rand(1, 3, 16, 16), y=None)
         assert emb.shape == (1, 256) and q.shape == (1, 256) and loss is None and timing is None

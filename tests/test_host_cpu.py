@@ -524,7 +524,7 @@ def test_contrastive_handlers_contract_on_cpu():
     the key encoder frozen, checkpoints the blind pipeline's encoder loader reads, and a loud failure instead of a CPU training step."""
     from oracle import contrastive_oracle as CO
     from rumpy_amd.SISR.models.blur_kernel_blind_sr.contrastive_blind_sr import load_encoder_model
-    for name, okind in (('mococontrastive', 'mococontrastive'), ('supmoco', 'supmoco')):
+    for name, okind in (('mococontrastive', 'mococontrastive'), ('supmoco', 'supmoco'), ('weakcon', 'weakcon')):
         h = _handler(name, model_name='default', crop_count=3, lr=1e-3)
         onet = CO.OracleContrastiveHandler(okind, crop_count=3).net
         assert list(h.net.state_dict().keys()) == list(onet.state_dict().keys())

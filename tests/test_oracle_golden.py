@@ -512,3 +512,49 @@ def test_g20_class_labels_oracle_and_product_match_reference(golden_dir):
             got = [class_retrieval(torch.from_numpy(r[:len(keys)]), fam2, m_map, mags2, tot2, labelling_strategy=strategy) for r in rows]
             assert got == list(want), (strategy, tag)
     assert len(set(g['labels.triple_precision.all'].tolist())) > 40          # the table spreads over the classes
+
+
+def test_g20_weakcon_oracle_matches_reference_handler(golden_dir):
+    from oracle import contrastive_oracle as CO
+    g = np.load(os.path.join(golden_dir, 'g20_contrastive_train.npz'))
+    keys = ['gaussian_noise_scale', 'poisson_noise_scale', 'gray_noise_boolean']
+    col, fam, _, _ = CO.oracle_label_structure(keys, 'noise', 'default')
+    vectors = torch.from_numpy(np.stack([CO.oracle_degradation_vector(r, col, fam) for r in g['sup.meta']]).T.copy())      # [V, N]
+    h = CO.OracleContrastiveHandler('weakcon', crop_count=3, lr=1e-3)
+    _g20_seed(h.net, 2400)
+    h.net.register_vector(vectors.shape[0])
+    for step in range(2):
+        loss, _, emb = h.run_train(CO.contrastive_batch(2410 + step, 4, 3).view(4, 9, 32, 32), vectors)
+        assert abs(float(loss) - float(g['weak.loss%d' % step])) <= 2e-5 * max(1.0, float(g['weak.loss%d' % step]))
+        assert np.allclose(emb.numpy(), g['weak.embedding%d' % step], atol=2e-5)
+    _g20_check_grads(g, 'weak.step1', h.net)
+    assert np.allclose(h.net.queue_vectors[:, :8].numpy(), g['weak.queue_vectors_head'])
+    _g20_check_state(g, 'weak.after2', h.net, 8)
+
+
+def test_g20_supcon_loss_and_degradation_vectors_match_reference(golden_dir):
+    """the reference's SupConLoss (value + gradient on seeded features) against the oracle's restatement and the product's loss module; the
+    reference's vector_retrieval over the metadata table against the oracle's and the product's host logic"""
+    from oracle import contrastive_oracle as CO
+    from rumpy_amd.regression.models.contrastive_learning import partition_metadata, register_metadata, vector_retrieval
+    from rumpy_amd.sr_tools.loss_functions import SupConLoss
+    g = np.load(os.path.join(golden_dir, 'g20_contrastive_train.npz'))
+    for fn in (lambda f, l: CO.oracle_supcon_loss(f, l), lambda f, l: SupConLoss()(f, l)):
+        feats = torch.from_numpy(g['supcon.features']).requires_grad_(True)
+        loss = fn(feats, torch.from_numpy(g['supcon.labels']))
+        loss.backward()
+        assert abs(float(loss) - float(g['supcon.loss'])) <= 1e-5 * float(g['supcon.loss'])
+        assert np.allclose(feats.grad.numpy(), g['supcon.grad'], rtol=1e-4, atol=1e-6)
+    feats = torch.from_numpy(g['supcon.features'])
+    assert abs(float(SupConLoss()(feats)) - float(CO.oracle_supcon_loss(feats, torch.arange(6.)))) < 1e-5      # SimCLR case: every sample its own class
+    rows = g['labels.rows']
+    noise = ['gaussian_noise_scale', 'poisson_noise_scale', 'gray_noise_boolean']
+    every = noise + ['jpeg_quality_factor', 'jm_qpi', 'realesrganblur-kernel_type', 'realesrganblur-sigma_x', 'realesrganblur-sigma_y']
+    for tag, keys, sel in (('noise', noise, 'noise'), ('all', every, 'all')):
+        want = g['vectors.default.%s' % tag]
+        col, fam, _, _ = CO.oracle_label_structure(keys, sel, 'default')
+        assert np.array_equal(np.stack([CO.oracle_degradation_vector(r[:len(keys)], col, fam) for r in rows]), want)
+        names = register_metadata(keys)
+        m_map = {k: names.index(k) for k in names}
+        fam2, _, _ = partition_metadata(m_map, sel)
+        assert np.array_equal(np.stack([vector_retrieval(torch.from_numpy(r[:len(keys)]), fam2, m_map).numpy() for r in rows]), want)
