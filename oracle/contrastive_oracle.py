@@ -285,3 +285,66 @@ def contrastive_batch(seed, n, crops, hw=32, shared=0.5):
     sigma = torch.from_numpy(rng.uniform(0.0, 0.25, (n, 1, 1, 1, 1)).astype(np.float32))
     noise = torch.from_numpy(rng.standard_normal((n, crops, 3, hw, hw)).astype(np.float32))
     return (shared * base + (1 - shared) * own + sigma * noise).clamp(0, 1).contiguous()
+
+
+# ---- the blind-SR handler's joint SR + contrastive losses (rumpy/SISR/models/blur_kernel_blind_sr/handlers.py:513-586) ----
+class OracleJointPipeline(nn.Module):
+    """contrastive_blind_sr.py:159-201,330-348: G (a QRCAN oracle) driven by the embedding of a MoCo / SupMoCo module E"""
+
+    def __init__(self, generator, mode, crop_count, freeze):
+        super().__init__()
+        self.G = generator
+        self.mode = mode
+        self.E = OracleMoCo() if mode == 'moco' else OracleSupMoCo(positives_per_class=crop_count - 1)      # :161-166 (MoCo: one positive)
+        for name, p in self.E.named_parameters():                                                          # :173-179
+            if freeze == 'all' or 'mlp' not in name:
+                p.requires_grad = False
+
+    def forward(self, x, x_key=None, labels=None):
+        if self.training:
+            fea, logits, target = self.E(x, x_key) if self.mode == 'moco' else self.E(x, x_key, labels)     # :332-335
+            return self.G(x, fea.unsqueeze(2).unsqueeze(3)), logits, target                                 # :337-338
+        return self.G(x, self.E.encoder_q(x)[0].unsqueeze(2).unsqueeze(3))                                  # :340-348 (embed_digit 0)
+
+
+class OracleJointHandler:
+    """ContrastiveBlindQRCANHandler.run_train for combined_loss_mode 'moco' / 'supmoco' (handlers.py:513-586) and BaseModel.run_eval"""
+
+    def __init__(self, generator, mode, crop_count, freeze, lr=1e-4):
+        self.net = OracleJointPipeline(generator, mode, crop_count, freeze)
+        self.mode, self.crop_count = mode, crop_count
+        self.optimizer = torch.optim.Adam([p for p in self.net.parameters() if p.requires_grad], lr=lr)
+
+    def run_train(self, x, y, labels=None):
+        self.net.train()
+        x, y = x.flatten(1, 2), y.flatten(1, 2)                                                             # :520-523
+        if self.mode == 'moco':
+            sr, logits, target = self.net(x[:, 0:3], x[:, 3:])                                              # :527
+            y_sr = y[:, 0:3]
+        else:
+            x, y = x.view(-1, 3, x.shape[2], x.shape[3]), y.view(-1, 3, y.shape[2], y.shape[3])              # :547-548
+            first = [i * self.crop_count for i in range(x.shape[0] // self.crop_count)]
+            rest = [i for i in range(x.shape[0]) if i not in first]
+            sr, logits, target = self.net(x[first], x[rest], labels)                                        # :554
+            y_sr = y[first]
+        l_con, l_sr = F.cross_entropy(logits, target), F.l1_loss(sr, y_sr)                                  # :530-531 / :558-559
+        loss = l_con + l_sr
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        return {'train-loss': loss.detach(), 'l1-loss': l_sr.detach(), 'contrast-loss': l_con.detach()}, logits.detach()
+
+    def run_eval(self, x, y):
+        self.net.eval()
+        with torch.no_grad():
+            out = self.net(x)
+            return out, F.l1_loss(out, y)
+
+
+def joint_batch(seed, n, crops):
+    """LR crops [n, crops, 3, 16, 16] and x2 HR targets (bilinear upsampling + a seeded residual) for the joint-loss fixtures"""
+    x = contrastive_batch(seed, n, crops, hw=16)
+    rng = np.random.default_rng(seed + 7)
+    y = F.interpolate(x.view(-1, 3, 16, 16), scale_factor=2, mode='bilinear', align_corners=False).view(n, crops, 3, 32, 32)
+    y = (y + torch.from_numpy(rng.uniform(-0.05, 0.05, tuple(y.shape)).astype(np.float32))).clamp(0, 1)
+    return x, y

@@ -1,15 +1,24 @@
-"""Blind-SR pipeline (frozen contrastive degradation encoder -> metadata-modulated SR network) on the MI355X path - mirror of
-rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:14-329 for the configuration the reference's own test and BASELINE
-config 5 use: ``contrastive_encoder='default'``, ``embedding_type='pre-q'``, ``encoder_freeze_mode='all'``, SR loss only.
+"""Blind-SR pipeline (contrastive degradation encoder -> metadata-modulated SR network) on the MI355X path - mirror of
+rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:14-329 for ``contrastive_encoder='default'``, ``embedding_type='pre-q'``:
+
+* SR loss only (``combined_loss_mode=None``: the reference's own test and BASELINE config 5), the encoder frozen (``encoder_freeze_mode='all'``);
+* the joint losses ``combined_loss_mode='moco' | 'supmoco'`` (:159-201,330-348): ``E`` is a MoCo / SupMoCo module (query + key encoder + queue,
+  rumpy_amd/regression/models/contrastive_learning), a training forward returns (sr, logits, labels), and the handler adds the
+  cross-entropy of the logits to the L1 loss.  Built for the freeze modes in which no gradient has to travel from the SR network's
+  metadata input back into the encoder trunk: 'all' (the reference default: the contrastive loss is monitored, the key encoder and the
+  queue keep moving, nothing of E is trained) and 'pre_q' (only the ``mlp`` heads train - from the contrastive loss; the embedding is the
+  pooled feature vector in front of them).  An unfrozen trunk is refused: the generator's backward pass does not produce d loss / d metadata.
 
 ``ContrastiveBlindSRPipeline`` keeps the reference's sub-module names (``G`` then ``E``: they prefix every checkpoint key) and forward
 semantics: embedding = E(x)[0] (pooled 256-vector) [-> optional min-max / mean-std normalisation] -> G(x, embedding[:, :, None, None]).
-Refused loudly (not built): other encoders (DCLS, torchvision backbones), the 'q' / 'q-dropdown' embeddings, partial freezing,
-auxiliary encoders, the reducer, MoCo / SupMoCo / non-blind combined losses, SFT / SRMD metadata planes, contrastive_eval plotting."""
+Refused loudly (not built): other encoders (DCLS, torchvision backbones), the 'q' / 'q-dropdown' embeddings, auxiliary encoders, the
+reducer and the non-blind loss, SFT / SRMD metadata planes, contrastive_eval plotting."""
 import torch
 from torch import nn
 
 from rumpy_amd.regression.models.contrastive_learning.encoding_models import Encoder
+from rumpy_amd.regression.models.contrastive_learning.moco import MoCo
+from rumpy_amd.regression.models.contrastive_learning.supmoco import SupMoCo
 
 
 def load_encoder_model(weights, device, direct_load=False):
@@ -58,7 +67,7 @@ class ContrastiveBlindSRPipeline(nn.Module):
         super(ContrastiveBlindSRPipeline, self).__init__()
         refused = [n for n, v in (('embedding_type=%r' % (embedding_type,), embedding_type != 'pre-q'),
                                   ('auxiliary_encoder_weights', auxiliary_encoder_weights is not None), ('staggered_encoding', staggered_encoding),
-                                  ('combined_loss_mode=%r' % (combined_loss_mode,), combined_loss_mode is not None), ('sft_mode', sft_mode),
+                                  ('combined_loss_mode=%r' % (combined_loss_mode,), combined_loss_mode not in (None, 'moco', 'supmoco')), ('sft_mode', sft_mode),
                                   ('srmd_mode', srmd_mode), ('contrastive_eval', contrastive_eval), ('encoder_dropdown', encoder_dropdown is not None),
                                   ('reducer_layer_sizes', reducer_layer_sizes is not None)) if v]
         if refused:
@@ -67,7 +76,7 @@ class ContrastiveBlindSRPipeline(nn.Module):
             raise RuntimeError('Normalization type not recognized')
         if block_encoder_loading:       # :118-121: a testing switch of the reference - never read encoder weights from file
             checkpoint_load = True
-        self.combined_loss_mode = None
+        self.combined_loss_mode = combined_loss_mode
         self.eval_mode = eval_mode
         self.staggered_encoding = False
         self.aux_E = None
@@ -79,8 +88,41 @@ class ContrastiveBlindSRPipeline(nn.Module):
         self.sft_mode = self.srmd_mode = False
         self.G = generator
         self.embed_digit, self.q_type = 0, None
-        self.E = setup_encoder(contrastive_encoder, encoder_freeze_mode, pre_trained_encoder_weights, device, encoder_dropdown,
-                               load_required=not checkpoint_load)
+        if combined_loss_mode is None:
+            self.E = setup_encoder(contrastive_encoder, encoder_freeze_mode, pre_trained_encoder_weights, device, encoder_dropdown,
+                                   load_required=not checkpoint_load)
+        else:
+            self.E = self._setup_contrastive_encoder(contrastive_encoder, encoder_freeze_mode, pre_trained_encoder_weights, device, crop_count,
+                                                     contrastive_dropdown, load_required=not checkpoint_load)
+
+    def _setup_contrastive_encoder(self, contrastive_encoder, encoder_freeze_mode, weights, device, crop_count, contrastive_dropdown, load_required):
+        """:159-201: MoCo / SupMoCo around the default encoder, frozen per encoder_freeze_mode, state from a contrastive-training checkpoint"""
+        if contrastive_encoder != 'default':
+            raise RuntimeError('rumpy_amd: only the default (DASR) contrastive encoder is on the HIP path, not %r' % (contrastive_encoder,))
+        if encoder_freeze_mode not in ('all', 'pre_q'):
+            raise RuntimeError('rumpy_amd: joint SR + contrastive training needs encoder_freeze_mode "all" or "pre_q" on the HIP path: the '
+                               "generator's backward pass does not produce the gradient of its metadata input (train the encoder with its own "
+                               "handlers: define_model('mococontrastive' | 'supmoco'))")
+        if self.combined_loss_mode == 'moco':
+            E = MoCo(base_encoder=Encoder, dropdown=None)
+        else:
+            if crop_count is None:
+                raise RuntimeError('combined_loss_mode "supmoco" needs crop_count')
+            E = SupMoCo(device=device, base_encoder=Encoder, contrastive_dropdown=contrastive_dropdown, positives_per_class=crop_count - 1, dropdown=None)
+        for name, param in E.named_parameters():
+            if encoder_freeze_mode == 'all' or 'mlp' not in name:
+                param.requires_grad = False
+        if load_required:
+            loc = 'cuda:%d' % int(device) if isinstance(device, int) or (isinstance(device, str) and device.isnumeric()) else device
+            state = torch.load(f=weights, map_location=loc, weights_only=False)
+            for encoder_name in ('encoder_q', 'encoder_k'):
+                getattr(E, encoder_name).load_state_dict({k[10:]: v for k, v in state['network'].items() if encoder_name in k})
+            E.queue = state['network']['queue']
+            if 'queue_labels' in state['network']:
+                E.queue_labels = state['network']['queue_labels']
+            E.queue_ptr = state['network']['queue_ptr']
+            print('Encoder weights loaded from %s' % weights)
+        return E
 
     # the trainable part, for the handler's fused optimizer / gradient all-reduce
     @property
@@ -103,13 +145,24 @@ class ContrastiveBlindSRPipeline(nn.Module):
         return (vectors - as_t(norm_params['mean'])) / as_t(norm_params['std'])
 
     def embedding(self, x):
-        emb = self.E(x)[self.embed_digit]
+        """degradation representation of x as the generator's metadata [N, 256, 1, 1] (no gradient path into the encoder)"""
+        enc = self.E if self.combined_loss_mode is None else self.E.encoder_q
+        with torch.no_grad():
+            emb = enc.features(x)                    # the pooled vector, embed_digit 0; BatchNorm mode = the encoder's own train / eval flag
         if self.encoding_normalization_type is not None:
             emb = self.normalize(emb, self.encoding_normalization_params)
         return emb.unsqueeze(2).unsqueeze(3)
 
     def forward(self, x, x_key=None, labels=None, **kwargs):
-        return self.G(x, self.embedding(x))
+        if self.combined_loss_mode is None or not self.training:
+            return self.G(x, self.embedding(x))
+        # :330-338: one contrastive step of E (query = x, keys = x_key) whose embedding drives the generator
+        if self.combined_loss_mode == 'moco':
+            embedding, logits, labels = self.E(x, x_key)
+        else:
+            embedding, logits, labels, _ = self.E(x, x_key, labels)
+        sr = self.G(x, embedding.detach().unsqueeze(2).unsqueeze(3))
+        return sr, logits, labels
 
     # fused L1 train / eval steps of the generator, with the embedding as its metadata
     def fused_l1_forward_backward(self, x, y, metadata=None):

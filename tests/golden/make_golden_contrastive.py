@@ -158,5 +158,64 @@ def main():
           'classes', d['sup.total_classes'], 'queue labels', d['sup.queue_labels_head'])
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and 'joint' not in sys.argv[1:]:
     main()
+
+
+# ---- G21: the blind-SR handler's joint SR + contrastive losses (combined_loss_mode 'moco' / 'supmoco') ----
+JOINT_KW = dict(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True,
+                selective_meta_blocks=[True, False], num_q_layers_inner_residual=1)
+
+
+def main_joint():
+    torch.manual_seed(0)
+    d = {}
+    tmp = tempfile.mkdtemp()
+    # a SupMoCo checkpoint of the reference, for the 'supmoco' joint mode (its queue labels only exist in a trained / registered queue)
+    hs = define_model('supmoco', model_save_dir=tmp, device=torch.device('cpu'), eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
+                      data_type='noise', labelling_strategy='double_precision')
+    seed_net(hs.net, 2600)
+    meta = np.array([[0.8, 0, 1], [0, 0.3, 0], [0.7, 0, 1], [0, 0.9, 1]], dtype=np.float32)
+    hs.run_train(x=CO.contrastive_batch(2610, 4, 3, hw=16).view(4, 9, 16, 16), y=torch.from_numpy(meta), metadata_keys=NOISE_KEYS)
+    hs.save_model('enc')                 # (tests rebuild this checkpoint with the oracle's SupMoCo step from the same seeds)
+    ckpt = os.path.join(tmp, 'enc_0')
+    for tag, mode, crops, freeze, extra in (('moco_all', 'moco', 2, 'all', dict(block_encoder_loading=True)),
+                                            ('moco_preq', 'moco', 2, 'pre_q', dict(block_encoder_loading=True)),
+                                            ('supmoco_preq', 'supmoco', 3, 'pre_q', dict(pre_trained_encoder_weights=ckpt, data_type='noise',
+                                                                                         labelling_strategy='double_precision'))):
+        h = define_model('contrastiveblindqrcan', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False,
+                         checkpoint_load=False, loss_masking=False, metadata_list=None, lr=1e-3, combined_loss_mode=mode, crop_count=crops,
+                         encoder_train_eval='train', encoder_freeze_mode=freeze, **extra, **JOINT_KW)
+        og = O.build_oracle('qrcan', num_metadata=256, **JOINT_KW)
+        h.net.G.load_state_dict(O.seeded_state_dict(og, 2700))
+        if mode == 'moco':
+            seed_net(h.net.E, 2710)
+        d[tag + '.keys'] = np.array(list(h.net.state_dict().keys()))
+        d[tag + '.trainable'] = np.array([k for k, p in h.net.named_parameters() if p.requires_grad])
+        for step in range(2):
+            x, y = CO.joint_batch(2720 + step, 4, crops)
+            kw = dict(metadata=torch.from_numpy(meta), metadata_keys=NOISE_KEYS) if mode == 'supmoco' else {}
+            pkg, logits = h.run_train(x=x, y=y, **kw)
+            for k, v in pkg.items():
+                d['%s.%s%d' % (tag, k, step)] = np.asarray(v)
+            d['%s.logits%d' % (tag, step)] = logits.numpy()[:, :48].copy()
+            if step == 0:
+                for k, p in h.net.named_parameters():
+                    if p.requires_grad and p.grad is not None:
+                        g = p.grad.detach().numpy().reshape(-1)
+                        d['%s.gnorm.%s' % (tag, k)] = np.asarray(np.linalg.norm(g.astype(np.float64)))
+                        d['%s.gsample.%s' % (tag, k)] = g[::(29 if k.startswith('G.') else 211)].copy()
+        for k, v in h.net.state_dict().items():
+            if not k.startswith('E.queue'):
+                d['%s.after2.%s' % (tag, k)] = v.detach().numpy().reshape(-1)[::(29 if k.startswith('G.') else 211)].copy()
+        d[tag + '.queue_head'] = h.net.E.queue[:, :12].numpy().copy()
+        xe, ye = CO.joint_batch(2790, 2, 1)
+        ev, evl, _ = h.run_eval(x=xe[:, 0], y=ye[:, 0], request_loss=True)
+        d[tag + '.eval_out'] = ev.numpy()[:, :, ::3, ::3].copy()
+        d[tag + '.eval_loss'] = np.asarray(evl)
+        print(tag, {k: float(v) for k, v in pkg.items()}, 'trainable', len(d[tag + '.trainable']), 'eval loss', float(evl))
+    np.savez_compressed(os.path.join(HERE, 'g21_blind_joint_train.npz'), **d)
+
+
+if __name__ == '__main__' and 'joint' in sys.argv[1:]:
+    main_joint()

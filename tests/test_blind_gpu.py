@@ -163,10 +163,70 @@ def test_blind_qrcan_checkpoint_roundtrip():
     assert torch.equal(e_a, e_b)
 
 
+@pytest.mark.parametrize('mode,crops,freeze', [('moco', 2, 'all'), ('moco', 2, 'pre_q'), ('supmoco', 3, 'pre_q')])
+def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze):
+    """combined_loss_mode 'moco' / 'supmoco' (handlers.py:526-586): L1 + cross-entropy of the MoCo / SupMoCo logits per step; the oracle is
+    pinned on the real reference handler by G21.  The encoder trunks are frozen in these modes (forward only): the oracle evaluates them
+    with the HIP path's bf16 storage points, the generator is checked like in every other network test."""
+    from oracle import contrastive_oracle as CO
+    from tests.test_oracle_golden import G21_KEYS, G21_META, _g20_seed, g21_supmoco_pretrained_state
+    extra, labels = dict(block_encoder_loading=True), None
+    if mode == 'supmoco':
+        sd, labels, total = g21_supmoco_pretrained_state()
+        ckpt = os.path.join(tempfile.mkdtemp(), 'enc_0')
+        torch.save({'network': sd, 'model_name': 'supmoco', 'model_epoch': 0}, ckpt)
+        extra = dict(pre_trained_encoder_weights=ckpt, data_type='noise', labelling_strategy='double_precision')
+    h = define_model('contrastiveblindqrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, checkpoint_load=False,
+                     loss_masking=False, metadata_list=None, lr=1e-3, combined_loss_mode=mode, crop_count=crops, encoder_train_eval='train',
+                     encoder_freeze_mode=freeze, **extra, **KW)
+    oh = CO.OracleJointHandler(O.build_oracle('qrcan', num_metadata=256, **KW), mode, crops, freeze, lr=1e-3)
+    oh.net.E.encoder_q.bf16_storage = oh.net.E.encoder_k.bf16_storage = True
+    assert list(h.net.state_dict().keys()) == list(oh.net.state_dict().keys()) or mode == 'supmoco'     # (queue_labels appears with the classes)
+    assert [k for k, p in h.net.named_parameters() if p.requires_grad] == [k for k, p in oh.net.named_parameters() if p.requires_grad]
+    assert type(h.optimizer).__name__ == ('FlatAdam' if freeze == 'all' else 'Adam')
+    gsd = O.seeded_state_dict(oh.net.G, 2800)
+    oh.net.G.load_state_dict(gsd)
+    h.net.G.load_state_dict(gsd)
+    if mode == 'moco':
+        _g20_seed(oh.net.E, 2810)
+        h.net.E.load_state_dict(oh.net.E.state_dict())
+    else:
+        oh.net.E.register_classes(total)
+        oh.net.E.load_state_dict(sd)
+        assert torch.equal(h.net.E.queue_labels.cpu(), sd['queue_labels']) and int(h.net.E.queue_ptr) == int(sd['queue_ptr'])
+    kw = dict(metadata=torch.from_numpy(G21_META), metadata_keys=[(k,) for k in G21_KEYS]) if mode == 'supmoco' else {}
+    for step in range(2):
+        x, y = CO.joint_batch(2820 + step, 4, crops)
+        opkg, ologits = oh.run_train(x, y, labels)
+        pkg, logits = h.run_train(x=x, y=y, **kw)
+        assert set(pkg) == {'train-loss', 'l1-loss', 'contrast-loss'} and logits.shape == (4, 1 + 8192) and not logits.is_cuda
+        for k in pkg:
+            assert abs(float(pkg[k]) - float(opkg[k])) <= 2e-2 * max(1.0, float(opkg[k])), (step, k, float(pkg[k]), float(opkg[k]))
+        assert float((logits - ologits).abs().max()) <= (0.25 if step == 0 else 0.6)
+        if step == 0:
+            class G:
+                pass
+            a, b = G(), G()
+            a.net, b.net = h.net.G, oh.net.G
+            print('worst generator grad rel err', _grad_check(a, b))
+            for (k, p), (_, po) in zip(h.net.E.named_parameters(), oh.net.E.named_parameters()):
+                if po.requires_grad:
+                    assert _rel(p.grad.cpu(), po.grad) < 5e-2, k                      # the mlp heads ('pre_q'), from the contrastive loss
+                else:
+                    assert p.grad is None, k
+    assert int(h.net.E.queue_ptr) == int(oh.net.E.queue_ptr)
+    assert _rel(h.net.E.encoder_k.flat_p.cpu(), torch.cat([p.detach().reshape(-1) for p in oh.net.E.encoder_k.parameters()])) < 1e-5
+    xe, ye = CO.joint_batch(2890, 2, 1)
+    out, loss, _ = h.run_eval(x=xe[:, 0], y=ye[:, 0], request_loss=True)
+    oout, oloss = oh.run_eval(xe[:, 0], ye[:, 0])
+    assert self_psnr(out, oout) >= 40.0 and abs(float(loss) - float(oloss)) < 2e-2 * float(oloss)
+
+
 def test_unsupported_blind_variants_are_refused():
     base = dict(model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, block_encoder_loading=True, n_resgroups=1, n_resblocks=1,
                 style='standard', include_q_layer=True)
-    for bad in (dict(embedding_type='q'), dict(encoder_freeze_mode='pre_q'), dict(combined_loss_mode='moco'), dict(srmd_mode=True),
+    for bad in (dict(embedding_type='q'), dict(encoder_freeze_mode='pre_q'), dict(combined_loss_mode='nonblind'),
+                dict(combined_loss_mode='moco', encoder_freeze_mode='none'), dict(combined_loss_mode='supmoco', encoder_freeze_mode='pre_q'), dict(srmd_mode=True),
                 dict(reducer_layer_sizes=[256, 64]), dict(crop_count=2), dict(style='modulate')):
         with pytest.raises(RuntimeError):
             define_model('contrastiveblindqrcan', **{**base, **bad})

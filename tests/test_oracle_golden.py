@@ -558,3 +558,55 @@ def test_g20_supcon_loss_and_degradation_vectors_match_reference(golden_dir):
         m_map = {k: names.index(k) for k in names}
         fam2, _, _ = partition_metadata(m_map, sel)
         assert np.array_equal(np.stack([vector_retrieval(torch.from_numpy(r[:len(keys)]), fam2, m_map).numpy() for r in rows]), want)
+
+
+# ---- G21: the blind handler's joint SR + contrastive losses ------------------------------------------------------------------------
+G21_KW = dict(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True,
+              selective_meta_blocks=[True, False], num_q_layers_inner_residual=1)
+G21_META = np.array([[0.8, 0, 1], [0, 0.3, 0], [0.7, 0, 1], [0, 0.9, 1]], dtype=np.float32)
+G21_KEYS = ['gaussian_noise_scale', 'poisson_noise_scale', 'gray_noise_boolean']
+
+
+def g21_supmoco_pretrained_state():
+    """the SupMoCo checkpoint the fixture's 'supmoco' case was started from: one step of the (G20-pinned) oracle handler from the same seeds"""
+    from oracle import contrastive_oracle as CO
+    col, fam, weights, total = CO.oracle_label_structure(G21_KEYS, 'noise', 'double_precision')
+    labels = torch.tensor([CO.oracle_class_label(r, col, fam, weights, 'double_precision') for r in G21_META])
+    hs = CO.OracleContrastiveHandler('supmoco', crop_count=3, lr=1e-3)
+    _g20_seed(hs.net, 2600)
+    hs.net.register_classes(total)
+    hs.run_train(CO.contrastive_batch(2610, 4, 3, hw=16).view(4, 9, 16, 16), labels)
+    return hs.net.state_dict(), labels, total
+
+
+@pytest.mark.parametrize('tag,mode,crops,freeze', [('moco_all', 'moco', 2, 'all'), ('moco_preq', 'moco', 2, 'pre_q'), ('supmoco_preq', 'supmoco', 3, 'pre_q')])
+def test_g21_joint_loss_oracle_matches_reference_handler(golden_dir, tag, mode, crops, freeze):
+    """two joint training steps + one evaluation of the REAL ContrastiveBlindQRCANHandler with combined_loss_mode 'moco' / 'supmoco'
+    (tests/golden/make_golden_contrastive.py joint)"""
+    from oracle import contrastive_oracle as CO
+    g = np.load(os.path.join(golden_dir, 'g21_blind_joint_train.npz'))
+    h = CO.OracleJointHandler(O.build_oracle('qrcan', num_metadata=256, **G21_KW), mode, crops, freeze, lr=1e-3)
+    assert list(h.net.state_dict().keys())[:len(h.net.G.state_dict())] == [str(k) for k in g[tag + '.keys']][:len(h.net.G.state_dict())]
+    assert [k for k, p in h.net.named_parameters() if p.requires_grad] == [str(k) for k in g[tag + '.trainable']]
+    h.net.G.load_state_dict(O.seeded_state_dict(h.net.G, 2700))
+    labels = None
+    if mode == 'moco':
+        _g20_seed(h.net.E, 2710)
+    else:
+        sd, labels, total = g21_supmoco_pretrained_state()
+        h.net.E.register_classes(total)
+        h.net.E.load_state_dict(sd)
+    for step in range(2):
+        x, y = CO.joint_batch(2720 + step, 4, crops)
+        pkg, logits = h.run_train(x, y, labels)
+        for k in ('train-loss', 'l1-loss', 'contrast-loss'):
+            assert abs(float(pkg[k]) - float(g['%s.%s%d' % (tag, k, step)])) <= 3e-4, (k, step, float(pkg[k]), float(g['%s.%s%d' % (tag, k, step)]))
+        assert np.allclose(logits.numpy()[:, :48], g['%s.logits%d' % (tag, step)], atol=3e-3)
+        if step == 0:
+            for k, p in h.net.named_parameters():
+                if p.requires_grad:
+                    ref = float(g['%s.gnorm.%s' % (tag, k)])
+                    assert abs(float(p.grad.double().norm()) - ref) <= 2e-3 * ref + 1e-9, k
+    xe, ye = CO.joint_batch(2790, 2, 1)
+    ev, evl = h.run_eval(xe[:, 0], ye[:, 0])
+    assert np.allclose(ev.numpy()[:, :, ::3, ::3], g[tag + '.eval_out'], atol=2e-4) and abs(float(evl) - float(g[tag + '.eval_loss'])) < 1e-4
