@@ -380,6 +380,9 @@ typedef struct {
 } rumpy_q_mlp_item;
 int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
 int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream);
+/* gradient at the metadata input: dmeta[N, M] = sum over the layers of scale * W1^T (relu'(hidden) * W2^T dzq) - what autograd hands to whatever
+ * produced the metadata (the degradation encoder of the blind pipeline when its trunk trains jointly: contrastive_blind_sr.py:337) */
+int rumpy_q_mlp_bwd_meta(const rumpy_q_mlp_item* items_device, int32_t nitems, int32_t N, int32_t M, int32_t Hq, int32_t C, float* dmeta, void* stream);
 
 /* ---- the other QCALayer styles (rumpy/SISR/models/attention_manipulators/architectures.py:41-136: 'max_concat', 'mini_concat',
  * 'extended_attention', 'softmax'): the gate of a block is an MLP of at most four layers over the block's channel means and the image's

@@ -297,7 +297,7 @@ class OracleJointPipeline(nn.Module):
         self.mode = mode
         self.E = OracleMoCo() if mode == 'moco' else OracleSupMoCo(positives_per_class=crop_count - 1)      # :161-166 (MoCo: one positive)
         for name, p in self.E.named_parameters():                                                          # :173-179
-            if freeze == 'all' or 'mlp' not in name:
+            if freeze == 'all' or (freeze == 'pre_q' and 'mlp' not in name):
                 p.requires_grad = False
 
     def forward(self, x, x_key=None, labels=None):

@@ -82,6 +82,8 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, x, net, train, meta, *params):
         out, _, plan = net.engine_forward(x, train=train, meta=meta)
         ctx.net, ctx.plan, ctx.gen = net, plan, plan.gen
+        # a metadata tensor with a gradient path of its own (the embedding of a jointly trained degradation encoder) gets its gradient too
+        ctx.meta_shape = tuple(meta.shape) if (meta is not None and ctx.needs_input_grad[3]) else None
         return out
 
     @staticmethod
@@ -94,7 +96,8 @@ class _NetFn(torch.autograd.Function):
                                'pass of the same shape; run forward and backward of one batch before the next forward pass')
         net.engine.backward(ctx.plan, 1.0, gout=gout.contiguous().float(), on_ready=getattr(net, 'grad_ready_hook', None))
         net.attach_grads()
-        return (None, None, None, None) + tuple(None for _ in net.param_list)
+        dmeta = net.engine.meta_grad(ctx.plan).reshape(ctx.meta_shape) if ctx.meta_shape is not None else None
+        return (None, None, None, dmeta) + tuple(None for _ in net.param_list)
 
 
 class HipSRNet(nn.Module):

@@ -4,10 +4,12 @@ rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:14-329 for ``cont
 * SR loss only (``combined_loss_mode=None``: the reference's own test and BASELINE config 5), the encoder frozen (``encoder_freeze_mode='all'``);
 * the joint losses ``combined_loss_mode='moco' | 'supmoco'`` (:159-201,330-348): ``E`` is a MoCo / SupMoCo module (query + key encoder + queue,
   rumpy_amd/regression/models/contrastive_learning), a training forward returns (sr, logits, labels), and the handler adds the
-  cross-entropy of the logits to the L1 loss.  Built for the freeze modes in which no gradient has to travel from the SR network's
-  metadata input back into the encoder trunk: 'all' (the reference default: the contrastive loss is monitored, the key encoder and the
-  queue keep moving, nothing of E is trained) and 'pre_q' (only the ``mlp`` heads train - from the contrastive loss; the embedding is the
-  pooled feature vector in front of them).  An unfrozen trunk is refused: the generator's backward pass does not produce d loss / d metadata.
+  cross-entropy of the logits to the L1 loss.  ``encoder_freeze_mode`` as in the reference (:173-179): 'all' (its default: the contrastive
+  loss is monitored, the key encoder and the queue keep moving, nothing of E is trained), 'pre_q' (only the ``mlp`` heads train - from
+  the contrastive loss; the embedding is the pooled feature vector in front of them), anything else = the whole query encoder trains, from
+  the contrastive loss AND from the SR loss through the generator's metadata input: the generator's autograd node then returns
+  d loss / d metadata (rumpy_q_mlp_bwd_meta over its q-layers; q-layer networks only) and the encoder trunk's HIP backward pass takes it
+  from there.
 
 ``ContrastiveBlindSRPipeline`` keeps the reference's sub-module names (``G`` then ``E``: they prefix every checkpoint key) and forward
 semantics: embedding = E(x)[0] (pooled 256-vector) [-> optional min-max / mean-std normalisation] -> G(x, embedding[:, :, None, None]).
@@ -99,10 +101,6 @@ class ContrastiveBlindSRPipeline(nn.Module):
         """:159-201: MoCo / SupMoCo around the default encoder, frozen per encoder_freeze_mode, state from a contrastive-training checkpoint"""
         if contrastive_encoder != 'default':
             raise RuntimeError('rumpy_amd: only the default (DASR) contrastive encoder is on the HIP path, not %r' % (contrastive_encoder,))
-        if encoder_freeze_mode not in ('all', 'pre_q'):
-            raise RuntimeError('rumpy_amd: joint SR + contrastive training needs encoder_freeze_mode "all" or "pre_q" on the HIP path: the '
-                               "generator's backward pass does not produce the gradient of its metadata input (train the encoder with its own "
-                               "handlers: define_model('mococontrastive' | 'supmoco'))")
         if self.combined_loss_mode == 'moco':
             E = MoCo(base_encoder=Encoder, dropdown=None)
         else:
@@ -110,7 +108,7 @@ class ContrastiveBlindSRPipeline(nn.Module):
                 raise RuntimeError('combined_loss_mode "supmoco" needs crop_count')
             E = SupMoCo(device=device, base_encoder=Encoder, contrastive_dropdown=contrastive_dropdown, positives_per_class=crop_count - 1, dropdown=None)
         for name, param in E.named_parameters():
-            if encoder_freeze_mode == 'all' or 'mlp' not in name:
+            if encoder_freeze_mode == 'all' or (encoder_freeze_mode == 'pre_q' and 'mlp' not in name):
                 param.requires_grad = False
         if load_required:
             loc = 'cuda:%d' % int(device) if isinstance(device, int) or (isinstance(device, str) and device.isnumeric()) else device
@@ -161,7 +159,7 @@ class ContrastiveBlindSRPipeline(nn.Module):
             embedding, logits, labels = self.E(x, x_key)
         else:
             embedding, logits, labels, _ = self.E(x, x_key, labels)
-        sr = self.G(x, embedding.detach().unsqueeze(2).unsqueeze(3))
+        sr = self.G(x, embedding.unsqueeze(2).unsqueeze(3))       # a trainable trunk receives the SR loss's gradient through this input
         return sr, logits, labels
 
     # fused L1 train / eval steps of the generator, with the embedding as its metadata

@@ -81,3 +81,9 @@ class ContrastiveBlindQRCANHandler(BaseContrastive):
 
     def run_model(self, x, *args, **kwargs):
         return self.net.forward(x, **kwargs)
+
+    def set_multi_gpu(self, device_ids=None):
+        if any(p.requires_grad for p in self.net.E.parameters()):
+            raise RuntimeError('rumpy_amd: data-parallel gradient averaging covers the generator\'s flat gradient buffer; with trainable encoder '
+                               'parameters (joint losses, encoder_freeze_mode other than "all") it is not built')
+        super().set_multi_gpu(device_ids)

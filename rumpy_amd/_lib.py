@@ -292,6 +292,7 @@ SYMBOLS = {
     'rumpy_qca_bwd_params': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_q_mlp_fwd': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_q_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'rumpy_q_mlp_bwd_meta': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'rumpy_ca_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_ca_bwd_apply': (C.c_int, [_P(CaBwdApplyArgs), c_void_p]),
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),

@@ -580,11 +580,45 @@ __global__ void __launch_bounds__(256) q_mlp_bwd_params_kernel(const rumpy_q_mlp
   }
 }
 
+// d loss / d metadata of all q-layers of a network: dmeta[n][m] = scale * sum_layers sum_h dh_l[n][h] * W1_l[h][m], dh as above.  grid (N),
+// 256 threads; the layers are summed in table order (deterministic).  The metadata of the blind pipeline is the degradation encoder's
+// embedding: this is the gradient that reaches the encoder from the SR loss when its trunk is trained jointly.
+__global__ void __launch_bounds__(256) q_mlp_bwd_meta_kernel(const rumpy_q_mlp_item* __restrict__ items, int nitems, int N, int M, int Hq, int C,
+                                                             float* __restrict__ dmeta) {
+  __shared__ float sdz[Q_MAXC];
+  __shared__ float sdh[Q_MAXH];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  float acc = 0.f;                                     // M <= 256: one output per thread
+  for (int l = 0; l < nitems; ++l) {
+    const rumpy_q_mlp_item it = items[l];
+    for (int c = tid; c < C; c += 256) sdz[c] = it.dzq[(size_t)n * C + c];
+    __syncthreads();
+    for (int h = tid; h < Hq; h += 256) {
+      float d = 0.f;
+      for (int c = 0; c < C; ++c) d = fmaf(it.w2[(size_t)c * Hq + h], sdz[c], d);
+      sdh[h] = (it.hidden[(size_t)n * Hq + h] > 0.f) ? d : 0.f;
+    }
+    __syncthreads();
+    if (tid < M) {
+      float s = 0.f;
+      for (int h = 0; h < Hq; ++h) s = fmaf(sdh[h], it.w1[(size_t)h * M + tid], s);
+      acc += s * it.scale;
+    }
+    __syncthreads();
+  }
+  if (tid < M) dmeta[(size_t)n * M + tid] = acc;
+}
+
 static bool q_shape_ok(int N, int M, int Hq, int C) { return N > 0 && N <= Q_MAXN && M > 0 && M <= Q_MAXM && Hq > 0 && Hq <= Q_MAXH && C > 0 && C <= Q_MAXC; }
 extern "C" int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream) {
   if (!items_device || !meta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_fwd: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }
   hipLaunchKernelGGL(q_mlp_fwd_kernel, dim3(nitems, (N + Q_NB - 1) / Q_NB), dim3(256), 0, (hipStream_t)stream, items_device, meta, N, M, Hq, C);
   return rumpy_check_launch("rumpy_q_mlp_fwd");
+}
+extern "C" int rumpy_q_mlp_bwd_meta(const rumpy_q_mlp_item* items_device, int32_t nitems, int32_t N, int32_t M, int32_t Hq, int32_t C, float* dmeta, void* stream) {
+  if (!items_device || !dmeta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_bwd_meta: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(q_mlp_bwd_meta_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, items_device, nitems, N, M, Hq, C, dmeta);
+  return rumpy_check_launch("rumpy_q_mlp_bwd_meta");
 }
 extern "C" int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream) {
   if (!items_device || !meta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_bwd_params: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }

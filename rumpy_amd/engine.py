@@ -894,6 +894,18 @@ class SREngine:
             L.check(self.lib.rumpy_q_mlp_bwd_params(_ptr(plan.q_dev), len(plan.q_items), _ptr(plan.meta), plan.N, M, Hq, self.feats, stream),
                     'rumpy_q_mlp_bwd_params')
 
+    def meta_grad(self, plan):
+        """d loss / d metadata [N, M] of the backward pass that has just run on `plan` (q-layer networks: the metadata enters through the
+        ParaCALayer MLPs only).  Asked for by the autograd node when the metadata itself has a gradient path (a jointly trained encoder)."""
+        if not plan.q_items or plan.qca_items:
+            raise RuntimeError('rumpy_amd: the gradient of the metadata input is built for q-layer networks (style "standard" + '
+                               'include_q_layer) only')
+        M, Hq = plan.q_shape
+        dmeta = torch.empty(plan.N, M, dtype=torch.float32, device=self.device)
+        L.check(self.lib.rumpy_q_mlp_bwd_meta(_ptr(plan.q_dev), len(plan.q_items), plan.N, M, Hq, self.feats, _ptr(dmeta),
+                                              torch.cuda.current_stream(self.device).cuda_stream), 'rumpy_q_mlp_bwd_meta')
+        return dmeta
+
     # ------------------------------------------------------------------ execution
     def plan_for(self, N, H, W, train, fmt=0):
         """the cached plan of a shape.  Training plans are kept; evaluation plans (one per image size, each owning its activation

@@ -181,6 +181,7 @@ def main_joint():
     ckpt = os.path.join(tmp, 'enc_0')
     for tag, mode, crops, freeze, extra in (('moco_all', 'moco', 2, 'all', dict(block_encoder_loading=True)),
                                             ('moco_preq', 'moco', 2, 'pre_q', dict(block_encoder_loading=True)),
+                                            ('moco_free', 'moco', 2, 'none', dict(block_encoder_loading=True)),
                                             ('supmoco_preq', 'supmoco', 3, 'pre_q', dict(pre_trained_encoder_weights=ckpt, data_type='noise',
                                                                                          labelling_strategy='double_precision'))):
         h = define_model('contrastiveblindqrcan', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False,

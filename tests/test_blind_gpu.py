@@ -163,7 +163,7 @@ def test_blind_qrcan_checkpoint_roundtrip():
     assert torch.equal(e_a, e_b)
 
 
-@pytest.mark.parametrize('mode,crops,freeze', [('moco', 2, 'all'), ('moco', 2, 'pre_q'), ('supmoco', 3, 'pre_q')])
+@pytest.mark.parametrize('mode,crops,freeze', [('moco', 2, 'all'), ('moco', 2, 'pre_q'), ('moco', 2, 'none'), ('supmoco', 3, 'pre_q')])
 def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze):
     """combined_loss_mode 'moco' / 'supmoco' (handlers.py:526-586): L1 + cross-entropy of the MoCo / SupMoCo logits per step; the oracle is
     pinned on the real reference handler by G21.  The encoder trunks are frozen in these modes (forward only): the oracle evaluates them
@@ -184,6 +184,9 @@ def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze
     assert list(h.net.state_dict().keys()) == list(oh.net.state_dict().keys()) or mode == 'supmoco'     # (queue_labels appears with the classes)
     assert [k for k, p in h.net.named_parameters() if p.requires_grad] == [k for k, p in oh.net.named_parameters() if p.requires_grad]
     assert type(h.optimizer).__name__ == ('FlatAdam' if freeze == 'all' else 'Adam')
+    if freeze != 'all':
+        with pytest.raises(RuntimeError, match='data-parallel'):
+            h.set_multi_gpu()
     gsd = O.seeded_state_dict(oh.net.G, 2800)
     oh.net.G.load_state_dict(gsd)
     h.net.G.load_state_dict(gsd)
@@ -210,8 +213,12 @@ def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze
             a.net, b.net = h.net.G, oh.net.G
             print('worst generator grad rel err', _grad_check(a, b))
             for (k, p), (_, po) in zip(h.net.E.named_parameters(), oh.net.E.named_parameters()):
-                if po.requires_grad:
-                    assert _rel(p.grad.cpu(), po.grad) < 5e-2, k                      # the mlp heads ('pre_q'), from the contrastive loss
+                if po.requires_grad and 'mlp' in k:
+                    assert _rel(p.grad.cpu(), po.grad) < 5e-2, k                      # the heads, from the contrastive loss
+                elif po.requires_grad:                                                # 'none': the query trunk, from both losses (the SR loss
+                    if k.split('.', 1)[1] in ('E.0.bias', 'E.3.bias', 'E.6.bias', 'E.9.bias', 'E.12.bias', 'E.15.bias'):      # through d metadata)
+                        continue                                                      # zero gradient in front of a training BatchNorm
+                    assert _rel(p.grad.cpu(), po.grad) < 1.5e-1, (k, _rel(p.grad.cpu(), po.grad))   # see tests/test_contrastive_gpu.py
                 else:
                     assert p.grad is None, k
     assert int(h.net.E.queue_ptr) == int(oh.net.E.queue_ptr)
@@ -226,7 +233,7 @@ def test_unsupported_blind_variants_are_refused():
     base = dict(model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, block_encoder_loading=True, n_resgroups=1, n_resblocks=1,
                 style='standard', include_q_layer=True)
     for bad in (dict(embedding_type='q'), dict(encoder_freeze_mode='pre_q'), dict(combined_loss_mode='nonblind'),
-                dict(combined_loss_mode='moco', encoder_freeze_mode='none'), dict(combined_loss_mode='supmoco', encoder_freeze_mode='pre_q'), dict(srmd_mode=True),
+                dict(combined_loss_mode='supmoco', encoder_freeze_mode='pre_q'), dict(srmd_mode=True),
                 dict(reducer_layer_sizes=[256, 64]), dict(crop_count=2), dict(style='modulate')):
         with pytest.raises(RuntimeError):
             define_model('contrastiveblindqrcan', **{**base, **bad})

@@ -579,7 +579,8 @@ def g21_supmoco_pretrained_state():
     return hs.net.state_dict(), labels, total
 
 
-@pytest.mark.parametrize('tag,mode,crops,freeze', [('moco_all', 'moco', 2, 'all'), ('moco_preq', 'moco', 2, 'pre_q'), ('supmoco_preq', 'supmoco', 3, 'pre_q')])
+@pytest.mark.parametrize('tag,mode,crops,freeze', [('moco_all', 'moco', 2, 'all'), ('moco_preq', 'moco', 2, 'pre_q'), ('moco_free', 'moco', 2, 'none'),
+                                                   ('supmoco_preq', 'supmoco', 3, 'pre_q')])
 def test_g21_joint_loss_oracle_matches_reference_handler(golden_dir, tag, mode, crops, freeze):
     """two joint training steps + one evaluation of the REAL ContrastiveBlindQRCANHandler with combined_loss_mode 'moco' / 'supmoco'
     (tests/golden/make_golden_contrastive.py joint)"""
@@ -606,6 +607,9 @@ def test_g21_joint_loss_oracle_matches_reference_handler(golden_dir, tag, mode, 
             for k, p in h.net.named_parameters():
                 if p.requires_grad:
                     ref = float(g['%s.gnorm.%s' % (tag, k)])
+                    if '.E.' in k and k.endswith('bias') and k.split('.')[-2] in ('0', '3', '6', '9', '12', '15'):
+                        assert float(p.grad.double().norm()) <= 1e-5 and ref <= 1e-5, k       # zero gradient in front of a training BatchNorm
+                        continue
                     assert abs(float(p.grad.double().norm()) - ref) <= 2e-3 * ref + 1e-9, k
     xe, ye = CO.joint_batch(2790, 2, 1)
     ev, evl = h.run_eval(xe[:, 0], ye[:, 0])

@@ -63,7 +63,12 @@ def test_q_mlp_kernels_against_torch(N, M, Hq):
     s = torch.cuda.current_stream(dev).cuda_stream
     L.check(lib.rumpy_q_mlp_fwd(tab.data_ptr(), len(items), md.data_ptr(), N, M, Hq, C, s), 'fwd')
     L.check(lib.rumpy_q_mlp_bwd_params(tab.data_ptr(), len(items), md.data_ptr(), N, M, Hq, C, s), 'bwd')
+    dmeta = torch.full((N, M), float('nan'), device=dev)
+    L.check(lib.rumpy_q_mlp_bwd_meta(tab.data_ptr(), len(items), N, M, Hq, C, dmeta.data_ptr(), s), 'bwd_meta')
     torch.cuda.synchronize()
+    mref = meta.clone().requires_grad_(True)        # gradient at the metadata input: the sum over the layers
+    sum(((torch.relu(mref @ w1.t() + b1) @ w2.t() + b2) * dz).sum() for w1, b1, w2, b2, dz, _, _ in keep).backward()
+    assert torch.allclose(dmeta.cpu(), 0.5 * mref.grad, atol=2e-4, rtol=1e-4)
     for w1, b1, w2, b2, dz, d, outs in keep:
         p = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
         hid = torch.relu(meta @ p[0].t() + p[1])
@@ -109,6 +114,29 @@ def test_qrcan_train_steps_against_oracle(names, kw):
                 if 'q_node' in k:
                     assert float(p.grad.abs().max()) > 0, k
     assert h.metadata_keys_used_in_training == names
+
+
+def test_qrcan_returns_the_gradient_of_its_metadata_input():
+    """a metadata tensor with requires_grad (the embedding of a jointly trained encoder) gets d loss / d metadata from the network's autograd
+    node, against the oracle's autograd"""
+    kw = dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16, selective_meta_blocks=[True, True], num_q_layers_inner_residual=1)
+    h, oh = _pair(['e%03d' % i for i in range(256)], 77, **kw)
+    x, _ = O.synthetic_batch(78, 3, lr_hw=16, scale=2)
+    m = (torch.randn(3, 256, 1, 1, generator=torch.Generator().manual_seed(79)) * 0.5)
+    r = torch.randn(3, 3, 32, 32, generator=torch.Generator().manual_seed(80))
+    mo = m.clone().requires_grad_(True)
+    oh.net.train()
+    (oh.net(x, mo) * r).sum().backward()
+    md = m.to('cuda:0').requires_grad_(True)
+    h.net.train()
+    (h.net(x.to('cuda:0'), md) * r.to('cuda:0')).sum().backward()
+    assert md.grad is not None and md.grad.shape == (3, 256, 1, 1)
+    rel = float((md.grad.cpu().double() - mo.grad.double()).norm() / mo.grad.double().norm())
+    assert rel < 3e-2, rel
+    # without a gradient path of its own the metadata gets none (and nothing extra is launched)
+    md2 = m.to('cuda:0')
+    (h.net(x.to('cuda:0'), md2) * r.to('cuda:0')).sum().backward()
+    assert md2.grad is None
 
 
 def test_qrcan_metadata_is_selected_by_key_and_changes_the_output():
