@@ -158,3 +158,13 @@ bool rumpy_probe_slot(int kernel_id, hipEvent_t* start, hipEvent_t* stop);
     if (rumpy_probe_slot(id, &e0_, &e1_)) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0_, e1_, 0, __VA_ARGS__); \
     else hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                               \
   } while (0)
+
+// BatchNorm statistics of the degradation encoder (enc_conv.hip forward, enc_train.hip backward): number of pixel blocks = partial-sum rows.
+// 256 workgroups in all (blocks x C/64 channel groups) when the map is large enough: one per CU, each with 8 loads in flight per thread.
+static inline int rumpy_bn_blocks(int P, int C) {
+  int cap = 256 / (C / 64 > 0 ? C / 64 : 1);
+  if (cap < 64) cap = 64;
+  int b = (P + 255) / 256;
+  return b > cap ? cap : (b < 1 ? 1 : b);
+}
+

@@ -5,9 +5,11 @@
 // host, once - the encoder is frozen) and LeakyReLU(0.1); the first conv (3->64) goes through rumpy_head_fwd.  0.3 % of a blind-QRCAN
 // step's FLOPs, so the kernel is the plain form of the implicit GEMM the SR body uses:
 //   D[co 16][px 16] += A[co][k = 32 input channels of one tap] * B[k][px]          (v_mfma_f32_16x16x32_bf16)
-// workgroup = 4 output rows x 16 output columns x 64 output channels; wave w owns channels 16w.. of all four rows; per 64-channel
+// workgroup = R = 4 output rows x 16 output columns x 64 output channels; wave w owns channels 16w.. of all R rows; per 64-channel
 // input chunk the halo tile is staged in LDS (unpadded 128-B pixels, 16-B chunk index XOR (pixel & 7)) and the wave's 18 filter
 // fragments are read straight from the packed image (kind-0 layout of rumpy_pack_weights, 1 KB coalesced per fragment).
+// (R = 8 - half the filter-fragment traffic per pixel - was measured SLOWER: 125 vs 95 us for 64 -> 64 at 256 x 48 x 48, 256 VGPRs.  The SR
+// path's strip kernel does that shape in 43 us but takes cin = 64 or 256 only; tests/tools/enc_conv_ab.py.)
 #include "common.hpp"
 
 struct EncConv {
@@ -16,9 +18,9 @@ struct EncConv {
   float neg_slope;
 };
 
-template <int S>
+template <int S, int R>
 __global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
-  constexpr int IR = 3 * S + 3, IC = 15 * S + 3;          // input rows / columns under a 4 x 16 output tile
+  constexpr int IR = (R - 1) * S + 3, IC = 15 * S + 3;    // input rows / columns under an R x 16 output tile
   __shared__ uint4 lds[IR * IC * 8];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
   const int ct = blockIdx.y;
@@ -26,11 +28,11 @@ __global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
   const int tx = t % a.tiles_x; t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int n = t / a.tiles_y;
-  const int oy0 = ty * 4, ox0 = tx * 16, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int oy0 = ty * R, ox0 = tx * 16, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int cin8 = a.chn * 8;                              // 16-byte vectors per input pixel
-  f32x4 acc[4];
+  f32x4 acc[R];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int ch = 0; ch < a.chn; ++ch) {
     __syncthreads();
     for (int v = tid; v < IR * IC * 8; v += 256) {
@@ -53,7 +55,7 @@ __global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
       for (int half = 0; half < 2; ++half) {
         const int chunk = half * 4 + g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < R; ++r) {
           const int p = (r * S + ky) * IC + j * S + kx;
           const uint4 b = lds[p * 8 + (chunk ^ (p & 7))];
           acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(F[tap * 2 + half]), as_bf16x8(b), acc[r], 0, 0, 0);
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
   const int cout = a.ctn * 64;
   const int ox = ox0 + j;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < R; ++r) {
     const int oy = oy0 + r;
     if (oy < a.Ho && ox < a.Wo) {
       float v0 = acc[r][0] + bv.x, v1 = acc[r][1] + bv.y, v2 = acc[r][2] + bv.z, v3 = acc[r][3] + bv.w;
@@ -105,8 +107,6 @@ __global__ void __launch_bounds__(256) enc_pool_kernel(const uint4* __restrict__
 // (base_architecture.py:472 after handlers.py:517), so its BatchNorms normalise with BATCH statistics and update their running
 // statistics even though no parameter of the encoder is trained.  Three launches on the conv's bf16 output [P = N*H*W, C]:
 // per-block partial sums (fixed order), finalize (fp64 combine -> scale/shift, running statistics, counter), apply + LeakyReLU in place.
-constexpr int BN_MAXBLK = 64;
-static int bn_blocks(int P) { int b = (P + 255) / 256; return b > BN_MAXBLK ? BN_MAXBLK : (b < 1 ? 1 : b); }
 
 __global__ void __launch_bounds__(256) enc_bn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ partial, int P, int C, int chunk) {
   __shared__ float red[32][129];
@@ -116,15 +116,23 @@ __global__ void __launch_bounds__(256) enc_bn_stats_kernel(const uint4* __restri
   float s[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
-  for (int p = p0 + pr; p < p1; p += 32) {
-    const uint4 v = x[(size_t)p * cvec + cg * 8 + c8];
+  auto add = [&](const uint4 v) {
     float f[8];
     { float lo[4], hi[4]; unpack4_bf16(make_uint2(v.x, v.y), lo); unpack4_bf16(make_uint2(v.z, v.w), hi);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; } }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] = fmaf(f[i], f[i], q[i]); }
+  };
+  int p = p0 + pr;
+  for (; p + 7 * 32 < p1; p += 8 * 32) {           // eight loads in flight per thread; summed in pixel order all the same
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = x[(size_t)(p + 32 * k) * cvec + cg * 8 + c8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) add(v[k]);
   }
+  for (; p < p1; p += 32) add(x[(size_t)p * cvec + cg * 8 + c8]);
 #pragma unroll
   for (int i = 0; i < 8; ++i) { red[pr][c8 * 8 + i] = s[i]; red[pr][64 + c8 * 8 + i] = q[i]; }
   __syncthreads();
@@ -136,15 +144,22 @@ __global__ void __launch_bounds__(256) enc_bn_stats_kernel(const uint4* __restri
   }
 }
 
-__global__ void __launch_bounds__(64) enc_bn_finalize_kernel(const float* __restrict__ partial, int nblk, int P, int C,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
-                                                             float* __restrict__ scale_shift, float* __restrict__ saved, float eps, float momentum) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(256) enc_bn_finalize_kernel(const float* __restrict__ partial, int nblk, int P, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
+                                                              float* __restrict__ scale_shift, float* __restrict__ saved, float eps, float momentum) {
+  __shared__ double red[4][64][2];
+  const int part = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s = 0.0, q = 0.0;                           // four threads per channel, blocks part, part + 4, ..: fixed order
   if (c < C) {
-    double s = 0.0, q = 0.0;
 #pragma unroll 8
-    for (int b = 0; b < nblk; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; q += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = part; b < nblk; b += 4) { s += (double)partial[((size_t)b * 2) * C + c]; q += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+  }
+  red[part][threadIdx.x & 63][0] = s; red[part][threadIdx.x & 63][1] = q;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    s = ((red[0][threadIdx.x][0] + red[1][threadIdx.x][0]) + red[2][threadIdx.x][0]) + red[3][threadIdx.x][0];
+    q = ((red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) + red[2][threadIdx.x][1]) + red[3][threadIdx.x][1];
     const double mean = s / P;
     double var = q / P - mean * mean;                      // biased variance: what the batch is normalised with
     if (var < 0.0) var = 0.0;
@@ -180,16 +195,16 @@ __global__ void __launch_bounds__(256) enc_bn_apply_kernel(const uint4* x, uint4
   }
 }
 
-extern "C" int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C) { return (int64_t)bn_blocks(P) * 2 * C; }
+extern "C" int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C) { return (int64_t)rumpy_bn_blocks(P, C) * 2 * C; }
 static int enc_bn_train(const rumpy_enc_bn_args* p, void* out, float* saved, void* stream, const char* who) {
   if (!p || !p->x || !p->gamma || !p->beta || !p->partial || !p->scale_shift) { rumpy_set_error("%s: null pointer", who); return RUMPY_E_ARG; }
   if ((p->running_mean == nullptr) != (p->running_var == nullptr)) { rumpy_set_error("%s: running_mean and running_var go together", who); return RUMPY_E_ARG; }
   if (p->P < 2 || p->C <= 0 || p->C % 64) {   // torch refuses a single value per channel in training mode, too
     rumpy_set_error("%s: needs more than one value per channel and C %% 64 == 0 (P=%d C=%d)", who, p->P, p->C); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  const int nblk = bn_blocks(p->P), chunk = (p->P + nblk - 1) / nblk;
+  const int nblk = rumpy_bn_blocks(p->P, p->C), chunk = (p->P + nblk - 1) / nblk;
   hipLaunchKernelGGL(enc_bn_stats_kernel, dim3(nblk, p->C / 64), dim3(256), 0, s, (const uint4*)p->x, p->partial, p->P, p->C, chunk);
-  hipLaunchKernelGGL(enc_bn_finalize_kernel, dim3(p->C / 64), dim3(64), 0, s, p->partial, nblk, p->P, p->C, p->gamma, p->beta, p->running_mean,
+  hipLaunchKernelGGL(enc_bn_finalize_kernel, dim3(p->C / 64), dim3(256), 0, s, p->partial, nblk, p->P, p->C, p->gamma, p->beta, p->running_mean,
                      p->running_var, (long long*)p->num_batches_tracked, p->scale_shift, saved, p->eps, p->momentum);
   const size_t tv = (size_t)p->P * (p->C / 8);
   size_t blocks = (tv + 255) / 256;
@@ -216,8 +231,8 @@ extern "C" int rumpy_enc_conv(const rumpy_enc_conv_args* p, void* stream) {
   a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + 3) / 4;
   a.neg_slope = p->neg_slope;
   const dim3 grid((unsigned)(p->N * a.tiles_x * a.tiles_y), (unsigned)a.ctn);
-  if (p->stride == 1) hipLaunchKernelGGL(enc_conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(enc_conv_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (p->stride == 1) hipLaunchKernelGGL((enc_conv_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((enc_conv_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   return rumpy_check_launch("rumpy_enc_conv");
 }
 

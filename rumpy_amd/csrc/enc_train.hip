@@ -13,25 +13,36 @@
 // (2 x 2 x 2 B per element), dz written once.
 #include "common.hpp"
 
-constexpr int BNB_MAXBLK = 64;      // as enc_conv.hip's forward statistics: rumpy_enc_bn_partial_floats(P, C) covers both
-static int bnb_blocks(int P) { int b = (P + 255) / 256; return b > BNB_MAXBLK ? BNB_MAXBLK : (b < 1 ? 1 : b); }
 
 struct BnBwd {
   const uint4* z; const uint4* da; const float* dpool; const float* scale_shift; const float* saved;
   int P, C, HW; float inv_hw, neg_slope;
 };
 
-// the 8 channels c0.. of pixel p: dy and xh
-__device__ __forceinline__ void bnb_load(const BnBwd& a, int p, int cv, int cvec, float (&dy)[8], float (&xh)[8]) {
-  const int c0 = cv * 8;
-  const uint4 zv = a.z[(size_t)p * cvec + cv];
+// per-thread constants of its 8 channels: forward scale / shift, batch mean, 1 / sigma
+struct BnbCh { float sc[8], sh[8], mu[8], is[8]; };
+__device__ __forceinline__ BnbCh bnb_channels(const BnBwd& a, int c0) {
+  BnbCh k;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { k.sc[i] = a.scale_shift[c0 + i]; k.sh[i] = a.scale_shift[a.C + c0 + i]; k.mu[i] = a.saved[c0 + i]; k.is[i] = a.saved[a.C + c0 + i]; }
+  return k;
+}
+// raw operands of pixel p, channels 8 cv..: the conv output and (unless the pool's gradient stands in) the stage-output gradient
+struct BnbRaw { uint4 z, d; };
+__device__ __forceinline__ BnbRaw bnb_fetch(const BnBwd& a, int p, int cv, int cvec) {
+  BnbRaw r;
+  r.z = a.z[(size_t)p * cvec + cv];
+  r.d = a.da ? a.da[(size_t)p * cvec + cv] : make_uint4(0, 0, 0, 0);
+  return r;
+}
+// -> dy and xh of those 8 channels
+__device__ __forceinline__ void bnb_decode(const BnBwd& a, const BnbCh& k, const BnbRaw& r, int p, int c0, float (&dy)[8], float (&xh)[8]) {
   float z[8], d[8];
-  { float lo[4], hi[4]; unpack4_bf16(make_uint2(zv.x, zv.y), lo); unpack4_bf16(make_uint2(zv.z, zv.w), hi);
+  { float lo[4], hi[4]; unpack4_bf16(make_uint2(r.z.x, r.z.y), lo); unpack4_bf16(make_uint2(r.z.z, r.z.w), hi);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { z[i] = lo[i]; z[4 + i] = hi[i]; } }
   if (a.da) {
-    const uint4 dv = a.da[(size_t)p * cvec + cv];
-    float lo[4], hi[4]; unpack4_bf16(make_uint2(dv.x, dv.y), lo); unpack4_bf16(make_uint2(dv.z, dv.w), hi);
+    float lo[4], hi[4]; unpack4_bf16(make_uint2(r.d.x, r.d.y), lo); unpack4_bf16(make_uint2(r.d.z, r.d.w), hi);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { d[i] = lo[i]; d[4 + i] = hi[i]; }
   } else {                                                  // AdaptiveAvgPool2d(1) backward: every pixel of image n gets dpool[n] / HW
@@ -41,46 +52,63 @@ __device__ __forceinline__ void bnb_load(const BnBwd& a, int p, int cv, int cvec
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const float y = fmaf(z[i], a.scale_shift[c0 + i], a.scale_shift[a.C + c0 + i]);     // the forward pass's own arithmetic: same sign
+    const float y = fmaf(z[i], k.sc[i], k.sh[i]);           // the forward pass's own arithmetic: same sign
     dy[i] = y > 0.f ? d[i] : d[i] * a.neg_slope;
-    xh[i] = (z[i] - a.saved[c0 + i]) * a.saved[a.C + c0 + i];
+    xh[i] = (z[i] - k.mu[i]) * k.is[i];
   }
 }
 
 __global__ void __launch_bounds__(256) enc_bnb_stats_kernel(BnBwd a, float* __restrict__ partial, int chunk) {
   __shared__ float red[32][129];
   const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x, c8 = tid & 7, pr = tid >> 3;
-  const int cvec = a.C / 8;
+  const int cvec = a.C / 8, cv = cg * 8 + c8, c0 = cv * 8;
   const int p0 = b * chunk, p1 = min(a.P, p0 + chunk);
+  const BnbCh k = bnb_channels(a, c0);
   float s[8], q[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
-  for (int p = p0 + pr; p < p1; p += 32) {
+  auto add = [&](const BnbRaw& r, int p) {
     float dy[8], xh[8];
-    bnb_load(a, p, cg * 8 + c8, cvec, dy, xh);
+    bnb_decode(a, k, r, p, c0, dy, xh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] += dy[i]; q[i] = fmaf(dy[i], xh[i], q[i]); }
+  };
+  int p = p0 + pr;
+  for (; p + 3 * 32 < p1; p += 4 * 32) {               // four pixels (eight loads) in flight per thread; summed in pixel order all the same
+    BnbRaw r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = bnb_fetch(a, p + 32 * j, cv, cvec);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) add(r[j], p + 32 * j);
   }
+  for (; p < p1; p += 32) add(bnb_fetch(a, p, cv, cvec), p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) { red[pr][c8 * 8 + i] = s[i]; red[pr][64 + c8 * 8 + i] = q[i]; }
   __syncthreads();
   if (tid < 128) {
     float tot = 0.f;
-    for (int k = 0; k < 32; ++k) tot += red[k][tid];
+    for (int j = 0; j < 32; ++j) tot += red[j][tid];
     const int which = tid >> 6, c = cg * 64 + (tid & 63);
     partial[((size_t)b * 2 + which) * a.C + c] = tot;
   }
 }
 
 // -> dgamma, dbeta (x scale) and the three per-channel coefficients of the apply pass, coef[3][C]: gamma * invstd, dbeta / P, dgamma / P
-__global__ void __launch_bounds__(64) enc_bnb_finalize_kernel(const float* __restrict__ partial, int nblk, int P, int C, const float* __restrict__ gamma,
-                                                              const float* __restrict__ saved, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ coef, float scale) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
+__global__ void __launch_bounds__(256) enc_bnb_finalize_kernel(const float* __restrict__ partial, int nblk, int P, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ saved, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ coef, float scale) {
+  __shared__ double red[4][64][2];
+  const int part = threadIdx.x >> 6, c = blockIdx.x * 64 + (threadIdx.x & 63);
+  double s = 0.0, q = 0.0;                           // four threads per channel, blocks part, part + 4, ..: fixed order
+  if (c < C) {
 #pragma unroll 8
-  for (int b = 0; b < nblk; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; q += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = part; b < nblk; b += 4) { s += (double)partial[((size_t)b * 2) * C + c]; q += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+  }
+  red[part][threadIdx.x & 63][0] = s; red[part][threadIdx.x & 63][1] = q;
+  __syncthreads();
+  if (part != 0 || c >= C) return;
+  s = ((red[0][threadIdx.x][0] + red[1][threadIdx.x][0]) + red[2][threadIdx.x][0]) + red[3][threadIdx.x][0];
+  q = ((red[0][threadIdx.x][1] + red[1][threadIdx.x][1]) + red[2][threadIdx.x][1]) + red[3][threadIdx.x][1];
   if (dbeta) dbeta[c] = (float)s * scale;
   if (dgamma) dgamma[c] = (float)q * scale;
   coef[c] = gamma[c] * saved[C + c];
@@ -94,7 +122,7 @@ __global__ void __launch_bounds__(256) enc_bnb_apply_kernel(BnBwd a, const float
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
     const int cv = (int)(v % cvec), p = (int)(v / cvec), c0 = cv * 8;
     float dy[8], xh[8], r[8];
-    bnb_load(a, p, cv, cvec, dy, xh);
+    bnb_decode(a, bnb_channels(a, c0), bnb_fetch(a, p, cv, cvec), p, c0, dy, xh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = coef[c0 + i] * (dy[i] - coef[a.C + c0 + i] - xh[i] * coef[2 * a.C + c0 + i]);
     const uint2 lo = pack4_bf16(r[0], r[1], r[2], r[3]), hi = pack4_bf16(r[4], r[5], r[6], r[7]);
@@ -119,9 +147,9 @@ extern "C" int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* p, void* stream) {
   BnBwd a;
   a.z = (const uint4*)p->z; a.da = (const uint4*)p->da; a.dpool = p->dpool; a.scale_shift = p->scale_shift; a.saved = p->saved;
   a.P = (int)P; a.C = p->C; a.HW = p->Ho * p->Wo; a.inv_hw = 1.f / (float)a.HW; a.neg_slope = p->neg_slope;
-  const int nblk = bnb_blocks(a.P), chunk = (a.P + nblk - 1) / nblk;
+  const int nblk = rumpy_bn_blocks(a.P, a.C), chunk = (a.P + nblk - 1) / nblk;
   hipLaunchKernelGGL(enc_bnb_stats_kernel, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
-  hipLaunchKernelGGL(enc_bnb_finalize_kernel, dim3(a.C / 64), dim3(64), 0, s, p->partial, nblk, a.P, a.C, p->gamma, p->saved, p->dgamma, p->dbeta,
+  hipLaunchKernelGGL(enc_bnb_finalize_kernel, dim3(a.C / 64), dim3(256), 0, s, p->partial, nblk, a.P, a.C, p->gamma, p->saved, p->dgamma, p->dbeta,
                      p->coef, p->scale);
   const size_t tv = (size_t)a.P * (a.C / 8);
   size_t blocks = (tv + 255) / 256;
