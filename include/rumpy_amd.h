@@ -214,6 +214,32 @@ typedef struct {
 } rumpy_nchw_to_nhwc4_args;
 int rumpy_nchw_to_nhwc4(const rumpy_nchw_to_nhwc4_args* a, void* stream);
 
+/* ---- beyond "64 features, PixelShuffle(2)" (round 2): EDSR at the reference's shipped width (Documentation/sample_config_files/div2k/edsr.toml:43-45,
+ * 256 features) and the x3 upsampler (rumpy/SISR/models/advanced/common.py:39-44) ----
+ * nn.PixelShuffle(r) (common.py:33,42) on an NHWC 16-bit map: dst[n, r h + i, r w + j, c] = src[n, h, w, c r^2 + i r + j] ; inverse != 0: the
+ * opposite direction (what the backward pass applies to the incoming gradient).  N, H, W, F describe the LOW-resolution side: lo = [N,H,W,F r^2],
+ * hi = [N,rH,rW,F].  The 64-feature x2 path fuses this into the conv kernels instead. */
+typedef struct {
+  const void* src;
+  void* dst;
+  int32_t N, H, W, F, r, inverse;
+} rumpy_pixel_shuffle_args;
+int rumpy_pixel_shuffle(const rumpy_pixel_shuffle_args* a, void* stream);
+/* tail conv F -> C (C <= 4) for F = 64 k up to 512, on the fp32 VALU from the fp32 master filter w [C,F,3,3] (architectures.py:229):
+ * rumpy_tail_fwd_wide: x = [N,H,W,F] bf16, out = fp32 NCHW [N,C,H,W] (+ bias) ; nonfinite: optional device flag, set when an output is not finite
+ * rumpy_tail_dgrad_wide: x = dy4 [N,H,W,4] bf16 (rumpy_nchw_to_nhwc4), out = dx [N,H,W,F] bf16 ; bias / nonfinite unused
+ * (the weight gradient is rumpy_wgrad_grouped with mt = 1 jobs per 64-channel chunk, as for F = 64) */
+typedef struct {
+  const void* x;
+  const float* w;
+  const float* bias;
+  void* out;
+  int32_t* nonfinite;
+  int32_t N, H, W, F, C, pad_;
+} rumpy_tail_wide_args;
+int rumpy_tail_fwd_wide(const rumpy_tail_wide_args* a, void* stream);
+int rumpy_tail_dgrad_wide(const rumpy_tail_wide_args* a, void* stream);
+
 /* ---- weight gradient of the 3x3 convs: grouped launch over a job table + deterministic slab reduction ----
  * Replaces the wgrad/bias-grad half of loss.backward() (base_architecture.py:432) for every nn.Conv2d(k=3)
  * with 64-multiple input channels.  One job = one (layer, cin chunk, cout tile, image range); it leaves

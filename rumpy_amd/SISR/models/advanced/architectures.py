@@ -288,11 +288,13 @@ class EDSR(HipSRNet):
         self.head = nn.Sequential(_conv(in_features, f))
         self.body = nn.Sequential(*([_ResBlockParams(f, res_scale) for _ in range(num_blocks)] + [_conv(f, f)]))
         self.tail = nn.Sequential(_upsampler(scale, f), _conv(f, out_features))
+        # the fused forward + L1 + backward pass is built from 64-feature kernels: wider nets train through the generic autograd node
+        self.supports_fused_l1 = f == 64
         self._finalize()
 
     def _spec(self):
-        if self.scale not in (1, 2, 4, 8):
-            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path (PixelShuffle(3) not implemented)' % self.scale)
+        if self.scale not in (1, 2, 3, 4, 8):
+            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path' % self.scale)
         body = []
         blocks = list(self.body)[:-1]
         for i, b in enumerate(blocks):
@@ -320,8 +322,8 @@ class RCAN(HipSRNet):
         self._finalize()
 
     def _spec(self):
-        if self.scale not in (1, 2, 4, 8):
-            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path (PixelShuffle(3) not implemented)' % self.scale)
+        if self.scale not in (1, 2, 3, 4, 8):
+            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path' % self.scale)
         body = []
         groups = list(self.body)[:-1]
         for gi, grp in enumerate(groups):

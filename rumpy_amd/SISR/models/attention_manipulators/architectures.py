@@ -133,8 +133,8 @@ class QRCAN(HipSRNet):
         return StyledCAParams(name, layers, self.num_metadata)
 
     def _spec(self):
-        if self.scale not in (1, 2, 4, 8):
-            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path (PixelShuffle(3) not implemented)' % self.scale)
+        if self.scale not in (1, 2, 3, 4, 8):
+            raise RuntimeError('rumpy_amd: scale %s not supported by the HIP path' % self.scale)
         body, any_q = [], False
         for gi, grp in enumerate(self.body):
             items = []

@@ -95,6 +95,16 @@ class NchwToNhwc4Args(_S):
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32)]
 
 
+class PixelShuffleArgs(_S):
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('F', c_int32), ('r', c_int32),
+                ('inverse', c_int32)]
+
+
+class TailWideArgs(_S):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('nonfinite', c_void_p),
+                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('F', c_int32), ('C', c_int32), ('pad_', c_int32)]
+
+
 class WgradJob(_S):
     _fields_ = [('x', c_void_p), ('dy', c_void_p), ('slab', c_void_p), ('n0', c_int32), ('n1', c_int32), ('t0', c_int32), ('t1', c_int32),
                 ('H', c_int32), ('W', c_int32), ('x_cstride', c_int32), ('x_coff', c_int32),
@@ -276,6 +286,9 @@ SYMBOLS = {
     'rumpy_tail_wgrad_reduce': (C.c_int, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     'rumpy_tail_dgrad': (C.c_int, [_P(TailDgradArgs), c_void_p]),
     'rumpy_nchw_to_nhwc4': (C.c_int, [_P(NchwToNhwc4Args), c_void_p]),
+    'rumpy_pixel_shuffle': (C.c_int, [_P(PixelShuffleArgs), c_void_p]),
+    'rumpy_tail_fwd_wide': (C.c_int, [_P(TailWideArgs), c_void_p]),
+    'rumpy_tail_dgrad_wide': (C.c_int, [_P(TailWideArgs), c_void_p]),
     'rumpy_wgrad_grouped': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_wgrad_shares': (C.c_int, [c_void_p, c_void_p, c_int32, c_void_p]),
     'rumpy_wgrad_slab_floats': (c_int64, [c_int32]),

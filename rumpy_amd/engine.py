@@ -152,17 +152,34 @@ class SREngine:
         self.h_gen = -1
         self._pack_items_h = None
         self.feats = spec.head.cout
-        if self.feats != 64:
-            raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 (got %d); other widths are not '
-                               'implemented yet and there is no fallback' % self.feats)
+        if self.feats not in (64, 256):
+            raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 and 256 (got %d); other widths are not '
+                               'implemented and there is no fallback' % self.feats)
+        # wide = the reference's shipped EDSR width (div2k/edsr.toml: 256 features): every 3x3 conv runs the Cin = 256 form of rumpy_conv3x3
+        # (one launch per layer, epilogues fused), the tail its fp32 VALU form; the one-launch residual-block kernels are 64-feature kernels.
+        self.wide = self.feats != 64
+        # an upsampler stage that is not "64 features, PixelShuffle(2)" (x3: conv F -> 9F, or any stage of a wide net): the conv writes its
+        # natural channel order, rumpy_pixel_shuffle permutes (forward) / un-permutes the gradient (backward): csrc/wide.hip
+        self.generic_up = self.wide or any(cv.cout != 4 * cv.cin for cv in spec.ups)
         if spec.head.cin > 4 or spec.tail.cout > 4:
             raise RuntimeError('rumpy_amd: image channels must be <= 4')
-        if spec.tail.cin != 64:
-            raise RuntimeError('rumpy_amd: tail conv needs 64 input features (got %d)' % spec.tail.cin)
+        if spec.tail.cin != self.feats:
+            raise RuntimeError('rumpy_amd: tail conv needs %d input features (got %d)' % (self.feats, spec.tail.cin))
+        if self.wide and (spec.cas() or spec.num_metadata or any(it[0] != 'resblock' for it in spec.body)):
+            raise RuntimeError('rumpy_amd: n_feats = 256 is built for EDSR (residual blocks); the channel-attention kernels are 64-feature kernels')
         for cv in spec.convs():
             if cv.kind == 'main' and (cv.cin not in (64, 256) or cv.cout % 64):
                 raise RuntimeError('rumpy_amd: conv %s %d->%d unsupported (Cin must be 64 or 256, Cout a multiple of 64)'
                                    % (cv.name, cv.cin, cv.cout))
+        for cv in spec.ups:
+            r2 = cv.cout // cv.cin
+            if cv.cout != r2 * cv.cin or r2 not in (4, 9):
+                raise RuntimeError('rumpy_amd: upsampler conv %s %d->%d is neither a x2 nor a x3 stage' % (cv.name, cv.cin, cv.cout))
+            if self.generic_up:
+                cv.shuffle = False          # natural channel order; the permutation is its own pass
+        if self.wide:
+            self.eval_fmt = L.FMT_BF16      # the Cin = 256 conv kernel is bf16 only
+            self.use_finish = False         # the one-launch housekeeping tables describe 64-feature tails; the separate entry points are generic
         self._alloc_packed()
         self.packed_version = None
 
@@ -181,6 +198,8 @@ class SREngine:
                 items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd), w_dgrad=_ptr(cv.w_dgrad),
                                         b_packed=_ptr(cv.b_packed), cout=cv.cout, cin=cv.cin, kind=0,
                                         shuffle=1 if cv.shuffle else 0))
+            elif self.wide:   # tail of a wide net: rumpy_tail_*_wide read the fp32 master filter
+                continue
             else:  # tail
                 cv.w_fwd = torch.empty(18 * 64 * 8, dtype=BF16, device=dev)
                 cv.w_dgrad = torch.empty(4 * 2 * 64 * 8, dtype=BF16, device=dev)
@@ -341,7 +360,7 @@ class SREngine:
                     # one launch per block when a strip spans the image width (conv_block.hip): the activation between the two
                     # convs stays in LDS (it is still stored when training: the backward pass masks with it and the weight
                     # gradient of conv2 reads it); RUMPY_NO_BLOCK=1 keeps the two-launch path for A/B runs
-                    fused = self.use_block_kernel and W <= 48
+                    fused = self.use_block_kernel and W <= 48 and not self.wide
                     t1 = act() if (train or not fused) else None
                     y = act()
                     # the backward launch needs t1 only as a ReLU mask: the forward launch also leaves it as bytes (1/16 of the traffic)
@@ -498,10 +517,16 @@ class SREngine:
         ups_in = []
         u, h, w = r, H, W
         for cv in spec.ups:
-            nxt = self._new(plan, N, 2 * h, 2 * w, F)
-            self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1, fmt=fmt)
-            ups_in.append((cv, u, h, w))
-            u, h, w = nxt, 2 * h, 2 * w
+            rr = 3 if cv.cout == 9 * cv.cin else 2
+            nxt = self._new(plan, N, rr * h, rr * w, F)
+            if self.generic_up:
+                pre = self._new(plan, N, h, w, cv.cout)          # natural channel order, then the PixelShuffle permutation as its own pass
+                self._conv(fwd, u, cv, N, h, w, pre, fmt=fmt)
+                fwd.append(('rumpy_pixel_shuffle', L.PixelShuffleArgs(src=_ptr(pre), dst=_ptr(nxt), N=N, H=h, W=w, F=F, r=rr, inverse=0)))
+            else:
+                self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1, fmt=fmt)
+            ups_in.append((cv, u, h, w, rr))
+            u, h, w = nxt, rr * h, rr * w
         # ---- tail (+ fused L1) ----
         plan.out = self._new(plan, N, Cout, h, w, dtype=torch.float32)
         plan.HR = (h, w)
@@ -511,29 +536,51 @@ class SREngine:
         plan.target = self._new(plan, N, Cout, h, w, dtype=torch.float32)
         plan.dy4 = self._new(plan, N, h, w, 4) if train else None
         plan.nonfinite = None if train else plan.flags[0:1]      # raised by the tail kernel (fp16 overflow)
-        plan.tail_plain = L.TailFwdArgs(x=_ptr(u), w=_ptr(wf(spec.tail)), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
-                                        target=None, dy4=None, loss_partial=None, loss=None, N=N, C=Cout, H=h, W=w, grid_x=tail_grid,
-                                        nonfinite=_ptr(plan.nonfinite), fmt=fmt)
-        # fused L1 training path: the tail conv's weight gradient is accumulated inside the same pass (one slab per workgroup)
-        plan.tail_slabs = int(lib.rumpy_tail_fwd_grid(N, h, w, tail_grid))
-        plan.tail_wslab = self._new(plan, plan.tail_slabs * int(lib.rumpy_wgrad_slab_floats(1)), dtype=torch.float32) if train else None
         plan.tail_fused = False
-        plan.tail_loss = L.TailFwdArgs(x=_ptr(u), w=_ptr(wf(spec.tail)), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
-                                       target=_ptr(plan.target), dy4=_ptr(plan.dy4), loss_partial=_ptr(plan.loss_partial),
-                                       loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid, wslab=_ptr(plan.tail_wslab),
-                                       nonfinite=_ptr(plan.nonfinite), fmt=fmt)
+        if self.wide:
+            # F -> 3 on the fp32 VALU from the master filter; no fused L1 form (the handlers take the generic loss path for wide nets)
+            plan.tail_wide = L.TailWideArgs(x=_ptr(u), w=_ptr(spec.tail.weight), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
+                                            nonfinite=_ptr(plan.nonfinite), N=N, H=h, W=w, F=F, C=Cout)
+            plan.tail_plain = plan.tail_loss = None
+            plan.tail_slabs, plan.tail_wslab = 0, None
+        else:
+            plan.tail_plain = L.TailFwdArgs(x=_ptr(u), w=_ptr(wf(spec.tail)), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
+                                            target=None, dy4=None, loss_partial=None, loss=None, N=N, C=Cout, H=h, W=w, grid_x=tail_grid,
+                                            nonfinite=_ptr(plan.nonfinite), fmt=fmt)
+            # fused L1 training path: the tail conv's weight gradient is accumulated inside the same pass (one slab per workgroup)
+            plan.tail_slabs = int(lib.rumpy_tail_fwd_grid(N, h, w, tail_grid))
+            plan.tail_wslab = self._new(plan, plan.tail_slabs * int(lib.rumpy_wgrad_slab_floats(1)), dtype=torch.float32) if train else None
+            plan.tail_loss = L.TailFwdArgs(x=_ptr(u), w=_ptr(wf(spec.tail)), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
+                                           target=_ptr(plan.target), dy4=_ptr(plan.dy4), loss_partial=_ptr(plan.loss_partial),
+                                           loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid, wslab=_ptr(plan.tail_wslab),
+                                           nonfinite=_ptr(plan.nonfinite), fmt=fmt)
         if not train:
             return plan
 
         # =============================== backward ===============================
         plan.gout_stage = None
         g = self._new(plan, N, h, w, F)
-        bwd.append(('rumpy_tail_dgrad', L.TailDgradArgs(dy4=_ptr(plan.dy4), w=_ptr(spec.tail.w_dgrad), dx=_ptr(g), N=N, H=h, W=w)))
+        if self.wide:
+            bwd.append(('rumpy_tail_dgrad_wide', L.TailWideArgs(x=_ptr(plan.dy4), w=_ptr(spec.tail.weight), bias=None, out=_ptr(g), nonfinite=None,
+                                                                N=N, H=h, W=w, F=F, C=Cout)))
+        else:
+            bwd.append(('rumpy_tail_dgrad', L.TailDgradArgs(dy4=_ptr(plan.dy4), w=_ptr(spec.tail.w_dgrad), dx=_ptr(g), N=N, H=h, W=w)))
         wjobs.append((spec.tail, u, plan.dy4, h, w, 2, 1.0, 1))
-        for cv, uin, uh, uw in reversed(ups_in):
+        for cv, uin, uh, uw, rr in reversed(ups_in):
             gin = self._new(plan, N, uh, uw, F)
-            self._conv(bwd, g, cv, N, uh, uw, gin, dgrad=True, in_mode=1)
-            wjobs.append((cv, uin, g, uh, uw, 1, 1.0, 4))
+            if self.generic_up:
+                # the gradient un-permuted into the conv's natural channel order: data and weight gradient are a plain conv's then.  The data
+                # gradient has Cin = r^2 F input channels - beyond rumpy_conv3x3's 64 / 256 - and runs the encoder's general conv kernel.
+                gpre = self._new(plan, N, uh, uw, cv.cout)
+                bwd.append(('rumpy_pixel_shuffle', L.PixelShuffleArgs(src=_ptr(g), dst=_ptr(gpre), N=N, H=uh, W=uw, F=F, r=rr, inverse=1)))
+                if not hasattr(plan, 'zero_bias'):
+                    plan.zero_bias = torch.zeros(max(64, F), dtype=torch.float32, device=self.device)
+                bwd.append(('rumpy_enc_conv', L.EncConvArgs(x=_ptr(gpre), w=_ptr(cv.w_dgrad), bias=_ptr(plan.zero_bias), out=_ptr(gin), N=N, H=uh, W=uw,
+                                                            cin=cv.cout, cout=cv.cin, stride=1, neg_slope=1.0)))
+                wjobs.append((cv, uin, gpre, uh, uw, 0, 1.0, 4))
+            else:
+                self._conv(bwd, g, cv, N, uh, uw, gin, dgrad=True, in_mode=1)
+                wjobs.append((cv, uin, g, uh, uw, 1, 1.0, 4))
             g = gin
         g_r = g                                      # grad wrt r = body_conv(last) + a0
         g_last = self._new(plan, N, H, W, F)
@@ -959,7 +1006,13 @@ class SREngine:
             plan.head_wgrad_args.x = x.data_ptr()
         out = torch.empty_like(plan.out)
         self._run(plan.fwd, stream)
-        if target is not None:
+        if self.wide:
+            if target is not None:
+                raise RuntimeError('rumpy_amd: the fused L1 pass is a 64-feature kernel; wide nets take the generic loss path')
+            plan.tail_wide.out = out.data_ptr()
+            L.call('rumpy_tail_fwd_wide', plan.tail_wide, stream)
+            loss = None
+        elif target is not None:
             plan.tail_loss.out = out.data_ptr()
             plan.tail_loss.target = target.data_ptr()
             L.call('rumpy_tail_fwd', plan.tail_loss, stream)
