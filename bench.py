@@ -52,8 +52,8 @@ def main():
     ap.add_argument('--probe-steps', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan', 'blindqrcan'), default='edsr',
-                    help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block, blindqrcan = frozen contrastive degradation encoder + QRCAN (BASELINE config 5 in bf16; q-layers as in the reference test config); all for information')
+    ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan', 'blindqrcan', 'edsr256'), default='edsr',
+                    help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block, blindqrcan = frozen contrastive degradation encoder + QRCAN (BASELINE config 5 in bf16; q-layers as in the reference test config), edsr256 = EDSR at the reference\'s shipped width (div2k/edsr.toml: 256 features x 32 blocks); all for information')
     ap.add_argument('--device-patches', action='store_true',
                     help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
     args = ap.parse_args()
@@ -93,12 +93,12 @@ def main():
     from rumpy_amd.shared_framework.models import define_model
 
     N = args.batch
-    flop_per_patch = FLOP_PER_PATCH_TRAIN if args.model == 'edsr' else 220.04e9
+    flop_per_patch = {'edsr': FLOP_PER_PATCH_TRAIN, 'edsr256': 694.7e9}.get(args.model, 220.04e9)
     torch.manual_seed(8)                                    # reference default seed (net_train.py:20)
     BLIND = dict(style='standard', include_q_layer=True, selective_meta_blocks=[True] + [False] * 9, num_q_layers_inner_residual=1)
     extra = {'qrcan': dict(style='standard', include_q_layer=True, metadata=['m%d' % i for i in range(5)]),
-             'blindqrcan': dict(block_encoder_loading=True, **BLIND)}.get(args.model, {})      # encoder weights: random init (no checkpoint offline)
-    h = define_model({'blindqrcan': 'contrastiveblindqrcan'}.get(args.model, args.model), model_save_dir=tempfile.mkdtemp(), device=local_rank,
+             'blindqrcan': dict(block_encoder_loading=True, **BLIND), 'edsr256': dict(num_features=256, num_blocks=32, res_scale=0.1)}.get(args.model, {})      # encoder weights: random init (no checkpoint offline)
+    h = define_model({'blindqrcan': 'contrastiveblindqrcan', 'edsr256': 'edsr'}.get(args.model, args.model), model_save_dir=tempfile.mkdtemp(), device=local_rank,
                      eval_mode=False, checkpoint_load=False, loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
                      scheduler_params=SCHED, **extra)
     meta_pool = [torch.rand(N, 5, 1, 1, generator=torch.Generator().manual_seed(77 + i)).to(dev) for i in range(8)] if args.model == 'qrcan' else None
@@ -171,8 +171,9 @@ def main():
         blocks = [a for name, a in ops if name == 'rumpy_conv_block']
         rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd')]      # share probe id 5 with the block kernel
         use_block = len(blocks) + len(rcabs) > 0
+        wide_convs = [a for name, a in ops if name == 'rumpy_conv3x3' and a.cin_chunks == 4] if getattr(hipnet.engine, 'wide', False) else []
         hipnet.use_graph = False          # the probe records events around eager launches (a graph replay has none)
-        lib.rumpy_probe_begin(5 if use_block else 1, max(80, len(blocks) + len(rcabs)) * args.probe_steps + 8)
+        lib.rumpy_probe_begin(5 if use_block else (3 if wide_convs else 1), max(80, len(blocks) + len(rcabs), len(wide_convs) + 8) * args.probe_steps + 8)
         for i in range(args.probe_steps):
             step(i)
         torch.cuda.synchronize(dev)
@@ -183,7 +184,13 @@ def main():
             layer_flop = 2.0 * N * 48 * 48 * 64 * 576      # algorithmic FLOPs of one 64->64 3x3 layer
             tensor_bytes = N * 48 * 48 * 64 * 2
             # algorithmic bytes: every [N,48,48,64] bf16 tensor a launch must touch once, from the engine's launch plan
-            if use_block:
+            if wide_convs:
+                # every rumpy_conv3x3 launch of the step (body 256 -> 256 forward + data gradient, upsampler forward): mean flops / mean duration
+                flop = sum(2.0 * a.N * a.H * a.W * 256 * 64 * a.cout_tiles * 9 for a in wide_convs) / len(wide_convs)
+                tensor_bytes = 1
+                tensors = [a.N * a.H * a.W * 2 * (256 + 64 * a.cout_tiles + 256 * sum(1 for f in ('mask', 'res1', 'res2') if getattr(a, f))) for a in wide_convs]
+                kname = 'conv3x3_kernel<4> (Cin = 256 form of the 3x3 conv with fused epilogues: all launches of an EDSR 256 x 32 step)'
+            elif use_block:
                 flop = 2 * layer_flop                      # the halo-row recompute of the first conv is overhead, not counted
                 # (a mask that travels as bytes - maskbits - is 1/16 of a tensor and not counted)
                 tensors = [2 + sum(1 for f in ('t', 'res2') if getattr(a, f)) + (1 if (a.mask and not a.maskbits) else 0) for a in blocks] + \
@@ -214,7 +221,9 @@ def main():
                 roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None}
             roofline.update(common)
-            if not use_block:
+            if wide_convs:
+                pass                                   # no PMC pass was taken for this kernel: traffic stays null
+            elif not use_block:
                 # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
                 roofline['traffic'] = PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
@@ -248,8 +257,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import sr_oracle as O                  # the checker, timed as the CPU baseline: the ONLY use of oracle/ in this file
         torch.manual_seed(8)
-        onet = O.build_oracle({'blindqrcan': 'contrastiveblindqrcan'}.get(args.model, args.model), scale=4,
-                              **{'qrcan': dict(style='standard', include_q_layer=True, num_metadata=5), 'blindqrcan': BLIND}.get(args.model, {}))
+        onet = O.build_oracle({'blindqrcan': 'contrastiveblindqrcan', 'edsr256': 'edsr'}.get(args.model, args.model), scale=4,
+                              **{'qrcan': dict(style='standard', include_q_layer=True, num_metadata=5), 'blindqrcan': BLIND,
+                                 'edsr256': dict(num_features=256, num_blocks=32, res_scale=0.1)}.get(args.model, {}))
         cpu_meta = torch.rand(args.cpu_batch, 5, 1, 1) if args.model == 'qrcan' else None
         oh = O.OracleHandler(onet, lr=1e-4, scheduler='cosine_annealing_warm_restarts', scheduler_params=SCHED)
         try:
@@ -289,7 +299,7 @@ def main():
                 'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
                          'random-init weights (seed 8)') if args.device_patches else
                         'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
-                'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)' + {'qrcan': ' + meta-attention q-layers, 5 metadata entries', 'blindqrcan': ' + frozen contrastive degradation encoder (256-vector) driving q-layers in group 0 block 0'}.get(args.model, '')) +
+                'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'EDSR x4 (256 feats x 32 blocks, the reference\'s div2k/edsr.toml)' if args.model == 'edsr256' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)' + {'qrcan': ' + meta-attention q-layers, 5 metadata entries', 'blindqrcan': ' + frozen contrastive degradation encoder (256-vector) driving q-layers in group 0 block 0'}.get(args.model, '')) +
                                        ' train step, 48x48 LR patches, batch %d per GPU' % N,
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),

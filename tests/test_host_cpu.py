@@ -582,3 +582,24 @@ def test_moco_queue_takes_the_keys_of_every_rank_gloo_world_size_2():
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_wide_edsr_and_x3_construct_like_the_reference_and_other_widths_are_refused():
+    """div2k/edsr.toml: 256 features x 32 blocks -> the reference's 43,089,923 parameters and key order (G8); scale 3 builds the conv F -> 9F
+    upsampler; a width the kernels do not take fails when the engine is built, loudly"""
+    h = _handler('edsr', scale=4, num_features=256, num_blocks=32, res_scale=0.1)
+    assert sum(p.numel() for p in h.net.parameters()) == 43089923
+    o = O.build_oracle('edsr', scale=4, num_features=256, num_blocks=32, res_scale=0.1)
+    assert list(h.net.state_dict().keys()) == list(o.state_dict().keys())
+    assert h.net.supports_fused_l1 is False and type(h.optimizer).__name__ == 'FlatAdam'
+    h3 = _handler('edsr', scale=3, num_blocks=2)
+    assert tuple(h3.net.tail[0][0].weight.shape) == (576, 64, 3, 3) and h3.net.supports_fused_l1 is True
+    assert [tuple(v.shape) for v in h3.net.state_dict().values()] == [tuple(v.shape) for v in O.build_oracle('edsr', scale=3, num_blocks=2).state_dict().values()]
+    from rumpy_amd.engine import SREngine
+    for bad in (dict(num_features=128), dict(scale=5)):
+        try:
+            hb = _handler('edsr', num_blocks=1, **{**dict(scale=2), **bad})
+        except (RuntimeError, NotImplementedError):
+            continue
+        with pytest.raises(RuntimeError, match='n_feats|scale'):
+            SREngine(hb.net._spec(), torch.device('cpu'))
