@@ -470,7 +470,7 @@ int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s);      // conv
 extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->out) { rumpy_set_error("rumpy_conv3x3: null pointer"); return RUMPY_E_ARG; }
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cout_tiles <= 0) { rumpy_set_error("rumpy_conv3x3: bad shape"); return RUMPY_E_ARG; }
-  if (p->cin_chunks != 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 or 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
+  if (p->cin_chunks < 1 || p->cin_chunks > 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 .. 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
   if (p->in_mode == 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: in_mode 1 needs cin_chunks 4"); return RUMPY_E_ARG; }
   if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || p->res1 || p->res2)) { rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4 and no mask/residual"); return RUMPY_E_ARG; }
   if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && p->cin_chunks == 1 && !p->mask)) {
@@ -478,7 +478,7 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   // Cin = 256 (upsampler data gradients): the 8x16-tile kernel below measures faster than the 4-chunk strip build
   // (which spills at 256 VGPRs); RUMPY_CONV4_STRIP=1 selects the strip build for A/B runs.
   static const bool strip4 = getenv("RUMPY_CONV4_STRIP") != nullptr;
-  if (p->cin_chunks == 1 || strip4) {   // strip kernel (conv_strip.hip)
+  if (p->cin_chunks == 1 || (strip4 && p->cin_chunks == 4)) {   // strip kernel (conv_strip.hip)
     hipStream_t s1 = (hipStream_t)stream;
     const int kid1 = (p->cout_tiles == 1 && p->cin_chunks == 1) ? 1 : 3;
     rumpy_probe_pre(kid1, s1);
@@ -517,13 +517,15 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   // the data gradients of the upsampler convs (what the engine launches with Cin = 256)
   const bool old4 = getenv("RUMPY_CONV4_OLD") != nullptr;             // A/B switch (read per call: tests toggle it)
   const bool plain = p->cout_tiles == 1 && p->out_mode == 0 && !p->bias && !p->relu && !p->mask && !p->res2 && !p->pool;
-  if (plain && !old4) {
+  if (plain && !old4 && p->cin_chunks == 4) {
     int g2 = p->grid_x > 0 ? p->grid_x : rumpy_device_cus();
     const int rounds = cdiv(ntiles, g2);
     g2 = cdiv(ntiles, rounds);
     rumpy_conv4d_launch(d, g2, s);       // streaming form (conv_dgrad4.hip); RUMPY_CONV4_OLD=1 keeps the register-staged kernel below (A/B, tests)
-  } else
+  } else if (p->cin_chunks == 4)
   hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
+  else if (p->cin_chunks == 3) hipLaunchKernelGGL(conv3x3_kernel<3>, grid, dim3(256), 0, s, d);      // 192 / 128 features (EDSR widths between the
+  else hipLaunchKernelGGL(conv3x3_kernel<2>, grid, dim3(256), 0, s, d);                               // baseline's 64 and the shipped 256)
   rumpy_probe_post(kid, s);
   return rumpy_check_launch("rumpy_conv3x3");
 }

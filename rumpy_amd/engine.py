@@ -152,11 +152,12 @@ class SREngine:
         self.h_gen = -1
         self._pack_items_h = None
         self.feats = spec.head.cout
-        if self.feats not in (64, 256):
-            raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64 and 256 (got %d); other widths are not '
+        if self.feats not in (64, 128, 192, 256):
+            raise RuntimeError('rumpy_amd: the HIP path is built for n_feats = 64, 128, 192 and 256 (got %d); other widths are not '
                                'implemented and there is no fallback' % self.feats)
-        # wide = the reference's shipped EDSR width (div2k/edsr.toml: 256 features): every 3x3 conv runs the Cin = 256 form of rumpy_conv3x3
-        # (one launch per layer, epilogues fused), the tail its fp32 VALU form; the one-launch residual-block kernels are 64-feature kernels.
+        # wide = more than 64 features, up to the reference's shipped EDSR width (div2k/edsr.toml: 256): every 3x3 conv runs the 2 / 3 / 4
+        # input-chunk form of rumpy_conv3x3 (one launch per layer, epilogues fused), the tail its fp32 VALU form; the one-launch
+        # residual-block kernels are 64-feature kernels.
         self.wide = self.feats != 64
         # an upsampler stage that is not "64 features, PixelShuffle(2)" (x3: conv F -> 9F, or any stage of a wide net): the conv writes its
         # natural channel order, rumpy_pixel_shuffle permutes (forward) / un-permutes the gradient (backward): csrc/wide.hip
@@ -166,10 +167,10 @@ class SREngine:
         if spec.tail.cin != self.feats:
             raise RuntimeError('rumpy_amd: tail conv needs %d input features (got %d)' % (self.feats, spec.tail.cin))
         if self.wide and (spec.cas() or spec.num_metadata or any(it[0] != 'resblock' for it in spec.body)):
-            raise RuntimeError('rumpy_amd: n_feats = 256 is built for EDSR (residual blocks); the channel-attention kernels are 64-feature kernels')
+            raise RuntimeError('rumpy_amd: n_feats > 64 is built for EDSR (residual blocks); the channel-attention kernels are 64-feature kernels')
         for cv in spec.convs():
-            if cv.kind == 'main' and (cv.cin not in (64, 256) or cv.cout % 64):
-                raise RuntimeError('rumpy_amd: conv %s %d->%d unsupported (Cin must be 64 or 256, Cout a multiple of 64)'
+            if cv.kind == 'main' and (cv.cin not in (64, 128, 192, 256) or cv.cout % 64):
+                raise RuntimeError('rumpy_amd: conv %s %d->%d unsupported (Cin must be 64, 128, 192 or 256, Cout a multiple of 64)'
                                    % (cv.name, cv.cin, cv.cout))
         for cv in spec.ups:
             r2 = cv.cout // cv.cin
@@ -178,7 +179,7 @@ class SREngine:
             if self.generic_up:
                 cv.shuffle = False          # natural channel order; the permutation is its own pass
         if self.wide:
-            self.eval_fmt = L.FMT_BF16      # the Cin = 256 conv kernel is bf16 only
+            self.eval_fmt = L.FMT_BF16      # the multi-chunk conv kernel is bf16 only
             self.use_finish = False         # the one-launch housekeeping tables describe 64-feature tails; the separate entry points are generic
         self._alloc_packed()
         self.packed_version = None

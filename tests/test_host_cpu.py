@@ -596,7 +596,7 @@ def test_wide_edsr_and_x3_construct_like_the_reference_and_other_widths_are_refu
     assert tuple(h3.net.tail[0][0].weight.shape) == (576, 64, 3, 3) and h3.net.supports_fused_l1 is True
     assert [tuple(v.shape) for v in h3.net.state_dict().values()] == [tuple(v.shape) for v in O.build_oracle('edsr', scale=3, num_blocks=2).state_dict().values()]
     from rumpy_amd.engine import SREngine
-    for bad in (dict(num_features=128), dict(scale=5)):
+    for bad in (dict(num_features=96), dict(num_features=320), dict(scale=5)):
         try:
             hb = _handler('edsr', num_blocks=1, **{**dict(scale=2), **bad})
         except (RuntimeError, NotImplementedError):

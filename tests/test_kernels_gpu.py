@@ -206,12 +206,36 @@ def test_streaming_cin256_kernel_is_bitwise_the_register_staged_kernel(monkeypat
         assert_bf16_close(nchw(outs[1][0]), x.grad, 'streaming dgrad upsampler')
 
 
+@pytest.mark.parametrize('cin,cout', [(128, 128), (192, 64), (128, 192), (256, 256), (192, 192)])
+def test_conv3x3_two_three_and_four_input_chunks_with_epilogues(cin, cout):
+    """EDSR widths above 64 features (128, 192, the shipped 256): one launch per layer with the epilogues of the 64-feature strip kernel,
+    forward and - on the dgrad image - data gradient, on a ragged image"""
+    gen = np.random.default_rng(cin + cout)
+    N, H, W = 2, 13, 21
+    w, b = _wb(gen, cout, cin)
+    x = _rand(gen, N, cin, H, W)
+    r1, r2, m = (_rand(gen, N, cout, H, W) for _ in range(3))
+    pc = PackedConv(w, b)
+    conv = F.conv2d(bf16r(x), bf16r(w), b, padding=1)
+    o, _ = hip_conv(nhwc(x), pc, N, H, W, relu=True)
+    assert_bf16_close(nchw(o), conv.clamp_min(0), 'relu')
+    o, _ = hip_conv(nhwc(x), pc, N, H, W, scale=0.1, res1=nhwc(r1))
+    assert_bf16_close(nchw(o), conv * 0.1 + bf16r(r1), 'scale + residual')
+    # data gradient of this layer: input = a gradient with `cout` channels, output `cin` channels, ReLU mask + two residuals
+    gy = _rand(gen, N, cout, H, W)
+    mi, ri, ri2 = (_rand(gen, N, cin, H, W) for _ in range(3))
+    xr = bf16r(x).clone().requires_grad_(True)
+    (F.conv2d(xr, bf16r(w), None, padding=1) * bf16r(gy)).sum().backward()
+    o, _ = hip_conv(nhwc(gy), pc, N, H, W, dgrad=True, scale=0.1, mask=nhwc(mi), res1=nhwc(ri), res2=nhwc(ri2))
+    assert_bf16_close(nchw(o), xr.grad * 0.1 * (bf16r(mi) > 0).float() + bf16r(ri) + bf16r(ri2), 'dgrad + mask + residuals')
+
+
 def test_conv3x3_rejects_bad_arguments():
     a = L.ConvArgs(x=None, w=None, out=None, N=1, H=1, W=1, cin_chunks=1, cout_tiles=1)
     assert L.lib().rumpy_conv3x3(a, None) == -1
     assert b'null' in L.lib().rumpy_last_error()
     t = torch.zeros(64, dtype=BF16, device=DEV)
-    a = L.ConvArgs(x=t.data_ptr(), w=t.data_ptr(), out=t.data_ptr(), N=1, H=1, W=1, cin_chunks=3, cout_tiles=1)
+    a = L.ConvArgs(x=t.data_ptr(), w=t.data_ptr(), out=t.data_ptr(), N=1, H=1, W=1, cin_chunks=5, cout_tiles=1)
     assert L.lib().rumpy_conv3x3(a, None) == -1
 
 

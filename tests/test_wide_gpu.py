@@ -79,6 +79,8 @@ from tests.test_network_gpu import _grad_check, _pair, self_psnr  # noqa: E402
     ('edsr', dict(scale=4, num_features=256, num_blocks=2, res_scale=0.1), 24, 2),       # the shipped width (edsr.toml:43-45), two blocks
     ('edsr', dict(scale=2, num_features=256, num_blocks=3, res_scale=0.1), (20, 28), 1),
     ('edsr', dict(scale=3, num_features=256, num_blocks=1, res_scale=0.1), 16, 2),       # wide AND x3
+    ('edsr', dict(scale=4, num_features=128, num_blocks=2, res_scale=0.1), 24, 2),       # the 2- and 3-chunk builds of the conv kernel
+    ('edsr', dict(scale=2, num_features=192, num_blocks=2, res_scale=1.0), (20, 28), 1),
     ('edsr', dict(scale=3, num_blocks=2, res_scale=0.1), 24, 2),                          # 64 features, x3 upsampler (PixelShuffle(3))
     ('rcan', dict(scale=3, n_resgroups=2, n_resblocks=2, reduction=16), 16, 2),
 ])
