@@ -361,15 +361,17 @@ class OracleBlindPipeline(nn.Module):
     ``self.net.train()`` (base_architecture.py:472) - so during training the frozen encoder normalises with BATCH statistics and
     keeps updating its running statistics; run_eval (``self.net.eval()``, :503) uses those running statistics."""
 
-    def __init__(self, generator):
+    def __init__(self, generator, embedding_type='pre-q'):
         super().__init__()
         self.G = generator
         self.E = OracleEncoder()
+        self.embedding_type = embedding_type          # :134-145: 'pre-q' = E(x)[0], 'q' = E(x)[1]['q']
         for p in self.E.parameters():
             p.requires_grad = False
 
     def forward(self, x):
-        emb = self.E(x)[0]
+        fea, out = self.E(x)
+        emb = fea if self.embedding_type == 'pre-q' else out['q']
         return self.G(x, emb.unsqueeze(2).unsqueeze(3))
 
 
@@ -529,7 +531,7 @@ def build_oracle(name, **internal_params):
         # ContrastiveBlindSRPipeline
         q = dict(p)
         q['num_metadata'] = p.get('encoder_output_size', 256)
-        return OracleBlindPipeline(build_oracle('qrcan', **q))
+        return OracleBlindPipeline(build_oracle('qrcan', **q), embedding_type=p.get('embedding_type', 'pre-q'))
     if name in ('srcnn', 'vdsr'):
         # SRCNNHandler / VDSRHandler basic/handlers.py:6-35 (VDSR defaults: 20 x 3x3, 1-64..64-1 channels)
         kp, cp = p.get('kernel_pattern'), p.get('channel_pattern')

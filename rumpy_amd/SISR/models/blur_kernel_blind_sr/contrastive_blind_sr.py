@@ -1,5 +1,5 @@
 """Blind-SR pipeline (contrastive degradation encoder -> metadata-modulated SR network) on the MI355X path - mirror of
-rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:14-329 for ``contrastive_encoder='default'``, ``embedding_type='pre-q'``:
+rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:14-329 for ``contrastive_encoder='default'``, ``embedding_type`` 'pre-q' / 'q':
 
 * SR loss only (``combined_loss_mode=None``: the reference's own test and BASELINE config 5), the encoder frozen (``encoder_freeze_mode='all'``);
 * the joint losses ``combined_loss_mode='moco' | 'supmoco'`` (:159-201,330-348): ``E`` is a MoCo / SupMoCo module (query + key encoder + queue,
@@ -13,7 +13,7 @@ rumpy/SISR/models/blur_kernel_blind_sr/contrastive_blind_sr.py:14-329 for ``cont
 
 ``ContrastiveBlindSRPipeline`` keeps the reference's sub-module names (``G`` then ``E``: they prefix every checkpoint key) and forward
 semantics: embedding = E(x)[0] (pooled 256-vector) [-> optional min-max / mean-std normalisation] -> G(x, embedding[:, :, None, None]).
-Refused loudly (not built): other encoders (DCLS, torchvision backbones), the 'q' / 'q-dropdown' embeddings, auxiliary encoders, the
+Refused loudly (not built): other encoders (DCLS, torchvision backbones), the 'q-dropdown' embedding, auxiliary encoders, the
 reducer and the non-blind loss, SFT / SRMD metadata planes, contrastive_eval plotting."""
 import torch
 from torch import nn
@@ -67,7 +67,7 @@ class ContrastiveBlindSRPipeline(nn.Module):
                  contrastive_eval=False, encoder_dropdown=None, contrastive_dropdown=False, reducer_layer_sizes=None,
                  block_encoder_loading=False, **kwargs):
         super(ContrastiveBlindSRPipeline, self).__init__()
-        refused = [n for n, v in (('embedding_type=%r' % (embedding_type,), embedding_type != 'pre-q'),
+        refused = [n for n, v in (('embedding_type=%r' % (embedding_type,), embedding_type not in ('pre-q', 'q')),
                                   ('auxiliary_encoder_weights', auxiliary_encoder_weights is not None), ('staggered_encoding', staggered_encoding),
                                   ('combined_loss_mode=%r' % (combined_loss_mode,), combined_loss_mode not in (None, 'moco', 'supmoco')), ('sft_mode', sft_mode),
                                   ('srmd_mode', srmd_mode), ('contrastive_eval', contrastive_eval), ('encoder_dropdown', encoder_dropdown is not None),
@@ -89,7 +89,8 @@ class ContrastiveBlindSRPipeline(nn.Module):
         self.model_save_dir = kwargs.get('model_save_dir')
         self.sft_mode = self.srmd_mode = False
         self.G = generator
-        self.embed_digit, self.q_type = 0, None
+        # :134-145: 'pre-q' = the pooled feature vector, 'q' = the mlp head's output on it (both 256 wide)
+        self.embed_digit, self.q_type = (0, None) if embedding_type == 'pre-q' else (1, 'q')
         if combined_loss_mode is None:
             self.E = setup_encoder(contrastive_encoder, encoder_freeze_mode, pre_trained_encoder_weights, device, encoder_dropdown,
                                    load_required=not checkpoint_load)
@@ -146,7 +147,9 @@ class ContrastiveBlindSRPipeline(nn.Module):
         """degradation representation of x as the generator's metadata [N, 256, 1, 1] (no gradient path into the encoder)"""
         enc = self.E if self.combined_loss_mode is None else self.E.encoder_q
         with torch.no_grad():
-            emb = enc.features(x)                    # the pooled vector, embed_digit 0; BatchNorm mode = the encoder's own train / eval flag
+            emb = enc.features(x)                    # the pooled vector; BatchNorm mode = the encoder's own train / eval flag
+            if self.q_type == 'q':
+                emb = enc.mlp(emb)
         if self.encoding_normalization_type is not None:
             emb = self.normalize(emb, self.encoding_normalization_params)
         return emb.unsqueeze(2).unsqueeze(3)

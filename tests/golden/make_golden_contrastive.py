@@ -215,6 +215,17 @@ def main_joint():
         d[tag + '.eval_out'] = ev.numpy()[:, :, ::3, ::3].copy()
         d[tag + '.eval_loss'] = np.asarray(evl)
         print(tag, {k: float(v) for k, v in pkg.items()}, 'trainable', len(d[tag + '.trainable']), 'eval loss', float(evl))
+    # ---- the 'q' embedding (contrastive_blind_sr.py:137-139: the mlp head's output drives the generator), SR loss only ----
+    h = define_model('contrastiveblindqrcan', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False, checkpoint_load=False,
+                     loss_masking=False, metadata_list=None, lr=1e-3, block_encoder_loading=True, embedding_type='q', **JOINT_KW)
+    opipe = O.build_oracle('contrastiveblindqrcan', **JOINT_KW)
+    h.net.load_state_dict(O.seeded_pipeline_state(opipe, 2900))
+    for step in range(2):
+        x, y = CO.joint_batch(2910 + step, 3, 1)
+        loss, out = h.run_train(x=x[:, 0], y=y[:, 0])
+        d['qemb.loss%d' % step] = np.asarray(loss)
+        if step == 0:
+            d['qemb.out0'] = out.numpy()[:, :, ::3, ::3].copy()
     np.savez_compressed(os.path.join(HERE, 'g21_blind_joint_train.npz'), **d)
 
 

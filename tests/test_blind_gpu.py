@@ -229,10 +229,28 @@ def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze
     assert self_psnr(out, oout) >= 40.0 and abs(float(loss) - float(oloss)) < 2e-2 * float(oloss)
 
 
+def test_blind_qrcan_q_embedding_against_oracle():
+    """embedding_type='q' (contrastive_blind_sr.py:137-139): the mlp head's output is the metadata; oracle pinned by G21"""
+    h = define_model('contrastiveblindqrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, checkpoint_load=False,
+                     loss_masking=False, metadata_list=None, block_encoder_loading=True, lr=1e-3, embedding_type='q', **SCHED, **KW)
+    onet = O.build_oracle('contrastiveblindqrcan', embedding_type='q', **KW)
+    sd = O.seeded_pipeline_state(onet, 830)
+    onet.load_state_dict(sd)
+    h.net.load_state_dict(sd)
+    oh = O.OracleHandler(onet, lr=1e-3, scheduler=SCHED['scheduler'], scheduler_params=SCHED['scheduler_params'])
+    x, y = O.synthetic_batch(931, 3, lr_hw=16, scale=2)
+    loss, out = h.run_train(x=x, y=y)
+    oloss, oout = oh.run_train(x, y)
+    assert abs(float(loss) - float(oloss)) < 2e-3 * float(oloss) and self_psnr(out, oout) >= 50.0
+    pre = O.build_oracle('contrastiveblindqrcan', **KW)
+    pre.load_state_dict(sd)
+    assert self_psnr(out, O.OracleHandler(pre, lr=1e-3).run_train(x, y)[1]) < self_psnr(out, oout) - 0.5     # closer to the 'q' oracle than to the pre-q one
+
+
 def test_unsupported_blind_variants_are_refused():
     base = dict(model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, block_encoder_loading=True, n_resgroups=1, n_resblocks=1,
                 style='standard', include_q_layer=True)
-    for bad in (dict(embedding_type='q'), dict(encoder_freeze_mode='pre_q'), dict(combined_loss_mode='nonblind'),
+    for bad in (dict(embedding_type='q-dropdown'), dict(encoder_freeze_mode='pre_q'), dict(combined_loss_mode='nonblind'),
                 dict(combined_loss_mode='supmoco', encoder_freeze_mode='pre_q'), dict(srmd_mode=True),
                 dict(reducer_layer_sizes=[256, 64]), dict(crop_count=2), dict(style='modulate')):
         with pytest.raises(RuntimeError):

@@ -614,3 +614,22 @@ def test_g21_joint_loss_oracle_matches_reference_handler(golden_dir, tag, mode, 
     xe, ye = CO.joint_batch(2790, 2, 1)
     ev, evl = h.run_eval(xe[:, 0], ye[:, 0])
     assert np.allclose(ev.numpy()[:, :, ::3, ::3], g[tag + '.eval_out'], atol=2e-4) and abs(float(evl) - float(g[tag + '.eval_loss'])) < 1e-4
+
+
+def test_g21_q_embedding_oracle_matches_reference_handler(golden_dir):
+    """embedding_type='q': the encoder's mlp-head output (not the pooled vector) is the generator's metadata - two SR-loss steps of the real handler"""
+    from oracle import contrastive_oracle as CO
+    g = np.load(os.path.join(golden_dir, 'g21_blind_joint_train.npz'))
+    net = O.build_oracle('contrastiveblindqrcan', embedding_type='q', **G21_KW)
+    net.load_state_dict(O.seeded_pipeline_state(net, 2900))
+    h = O.OracleHandler(net, lr=1e-3)
+    for step in range(2):
+        x, y = CO.joint_batch(2910 + step, 3, 1)
+        loss, out = h.run_train(x[:, 0], y[:, 0])
+        assert abs(float(loss) - float(g['qemb.loss%d' % step])) < 1e-6
+        if step == 0:
+            assert np.allclose(out.numpy()[:, :, ::3, ::3], g['qemb.out0'], atol=1e-6)
+    other = O.build_oracle('contrastiveblindqrcan', **G21_KW)          # and it is not the pre-q pipeline
+    other.load_state_dict(O.seeded_pipeline_state(other, 2900))
+    x, y = CO.joint_batch(2910, 3, 1)
+    assert abs(float(O.OracleHandler(other, lr=1e-3).run_train(x[:, 0], y[:, 0])[0]) - float(g['qemb.loss0'])) > 1e-5
