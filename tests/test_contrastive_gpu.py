@@ -337,3 +337,15 @@ def test_contrastive_handlers_evaluate_like_the_reference_test():
         (emb, q), loss, timing = h.run_eval(x=torch.rand(1, 3, 16, 16), y=None)
         assert emb.shape == (1, 256) and q.shape == (1, 256) and loss is None and timing is None
         assert h.get_embedding_len() == 256
+
+
+@pytest.mark.parametrize('name', ['supmoco', 'mococontrastive', 'weakcon'])
+def test_reference_contrastive_test_through_the_regression_interface(name, tmp_path):
+    """automated_testing/contrastive_tests/test_contrastive_cpu_execute.py:21-60, with the device this path runs on:
+    RegressionInterface(..., new_params={'name': .., 'internal_params': {'crop_count': 4, 'model_name': 'default'}}) ->
+    net_run_and_process(dummy [1, 3, 16, 16]) -> result[0].shape == (1, 256)"""
+    from rumpy_amd.regression.models.interface import RegressionInterface
+    model = RegressionInterface(model_loc=tmp_path, experiment='test', gpu='single', sp_gpu=0, mode='train',
+                                new_params={'name': name, 'internal_params': {'crop_count': 4, 'model_name': 'default'}}, no_directories=True)
+    result, _, _ = model.net_run_and_process(torch.rand((1, 3, 16, 16), dtype=torch.float32))
+    assert result[0].shape == (1, 256)
