@@ -349,3 +349,24 @@ def test_reference_contrastive_test_through_the_regression_interface(name, tmp_p
                                 new_params={'name': name, 'internal_params': {'crop_count': 4, 'model_name': 'default'}}, no_directories=True)
     result, _, _ = model.net_run_and_process(torch.rand((1, 3, 16, 16), dtype=torch.float32))
     assert result[0].shape == (1, 256)
+
+
+def test_moco_step_is_bitwise_reproducible():
+    """two handlers, same seeded state, same batch: loss, logits, every gradient, queue and key encoder come out bit for bit (fixed-order
+    reductions in every kernel of the trunk; the head is deterministic library GEMMs)"""
+    res = []
+    for _ in range(2):
+        h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=2, lr=1e-3)
+        oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=2, lr=1e-3)
+        _seed_handler(h, oh, 900)
+        out = []
+        for step in range(3):                     # eager, captured, replayed launch lists
+            x = CO.contrastive_batch(910 + step, 8, 2).view(8, 6, 32, 32)
+            loss, logits = h.run_train(x=x, y=None)
+            out.append((float(loss), logits.clone(), h.net.flat_g.clone().cpu(), h.net.flat_p.clone().cpu(), h.net.encoder_k.flat_p.clone().cpu(),
+                        h.net.queue[:, :24].clone().cpu()))
+        res.append(out)
+    for a, b in zip(*res):
+        assert a[0] == b[0]
+        for ta, tb in zip(a[1:], b[1:]):
+            assert torch.equal(ta, tb)
