@@ -62,11 +62,17 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
   const unsigned ring = (unsigned)(size_t)(d4_lds_u8)lds;
   if (tid == 0) landed = 0u;
 
+  // output tile ct of cout_tiles (round 2: the 256 -> 256 convs of EDSR at the reference's shipped width run here too, with the epilogues of
+  // conv3x3_kernel<4>: bias, ReLU, scale, ReLU mask, two residuals); filter image [ct][chunk][wave][18][lane]
+  const int ct = blockIdx.y, cstr = 64 * a.cout_tiles;
   bf16x8 F[4][18];
+  {
+    const uint4* wp = a.w + (size_t)ct * 4 * (4 * 18 * 64);
 #pragma unroll
-  for (int ch = 0; ch < 4; ++ch)
+    for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-    for (int s = 0; s < 18; ++s) F[ch][s] = as_bf16x8(a.w[((ch * 4 + q) * 18 + s) * 64 + lane]);
+      for (int s = 0; s < 18; ++s) F[ch][s] = as_bf16x8(wp[((ch * 4 + q) * 18 + s) * 64 + lane]);
+  }
 
   // this wave's DMA pieces of a stage: piece q + 4k; lane = (pixel sub 0..7, 16-byte slot 0..7); source chunk = slot ^ (pixel & 7)
   const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_page4;
@@ -114,6 +120,11 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     if (u < nstage) issue(u);
 
   const int c0 = 16 * q + 4 * g;
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + ct * 64 + c0);
+    bj[0] = b4.x; bj[1] = b4.y; bj[2] = b4.z; bj[3] = b4.w;
+  }
   for (int it = 0; it < nt; ++it) {
     const TileCoord tc = decode_tile(tile0 + it * tstride, a.tiles_x, a.tiles_y);
     const int xx = tc.tx * TW + px;
@@ -159,13 +170,29 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     for (int r = 0; r < TH; ++r) {
       const int y = tc.ty * TH + r;
       if (y < a.H && xx < a.W) {
-        const size_t e = ((size_t)(tc.n * a.H + y) * a.W + xx) * 64 + c0;
+        const size_t e = ((size_t)(tc.n * a.H + y) * a.W + xx) * cstr + ct * 64 + c0;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[r][j] * a.scale;
+        for (int j = 0; j < 4; ++j) {                     // conv3x3_kernel<4>'s epilogue, operation for operation
+          v[j] = acc[r][j] + bj[j];
+          if (a.relu) v[j] = relu_f32(v[j]);
+          v[j] *= a.scale;
+        }
+        if (a.mask) {
+          float m[4];
+          unpack4_bf16(*reinterpret_cast<const uint2*>(a.mask + e), m);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
+        }
         if (a.res1) {
           float m[4];
           unpack4_bf16(*reinterpret_cast<const uint2*>(a.res1 + e), m);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += m[j];
+        }
+        if (a.res2) {
+          float m[4];
+          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + e), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
@@ -176,6 +203,6 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
 }
 
 int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(conv4d_kernel, dim3(grid), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(conv4d_kernel, dim3(grid, d.cout_tiles), dim3(256), 0, s, d);
   return 0;
 }

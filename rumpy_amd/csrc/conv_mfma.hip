@@ -516,12 +516,14 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   dim3 grid(gx, p->cout_tiles);
   // the data gradients of the upsampler convs (what the engine launches with Cin = 256)
   const bool old4 = getenv("RUMPY_CONV4_OLD") != nullptr;             // A/B switch (read per call: tests toggle it)
-  const bool plain = p->cout_tiles == 1 && p->out_mode == 0 && !p->bias && !p->relu && !p->mask && !p->res2 && !p->pool;
+  // streaming form (conv_dgrad4.hip): every Cin = 256 launch that writes the plain layout without pool sums - the upsampler's data gradients
+  // and the body convs of the wide EDSR; RUMPY_CONV4_OLD=1 keeps the register-staged kernel below (A/B, tests)
+  const bool plain = p->out_mode == 0 && !p->pool;
   if (plain && !old4 && p->cin_chunks == 4) {
-    int g2 = p->grid_x > 0 ? p->grid_x : rumpy_device_cus();
+    int g2 = p->grid_x > 0 ? p->grid_x : (rumpy_device_cus() / p->cout_tiles > 0 ? rumpy_device_cus() / p->cout_tiles : 1);
     const int rounds = cdiv(ntiles, g2);
     g2 = cdiv(ntiles, rounds);
-    rumpy_conv4d_launch(d, g2, s);       // streaming form (conv_dgrad4.hip); RUMPY_CONV4_OLD=1 keeps the register-staged kernel below (A/B, tests)
+    rumpy_conv4d_launch(d, g2, s);
   } else if (p->cin_chunks == 4)
   hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
   else if (p->cin_chunks == 3) hipLaunchKernelGGL(conv3x3_kernel<3>, grid, dim3(256), 0, s, d);      // 192 / 128 features (EDSR widths between the

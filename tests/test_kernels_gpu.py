@@ -206,6 +206,27 @@ def test_streaming_cin256_kernel_is_bitwise_the_register_staged_kernel(monkeypat
         assert_bf16_close(nchw(outs[1][0]), x.grad, 'streaming dgrad upsampler')
 
 
+def test_streaming_cin256_kernel_with_output_tiles_and_epilogues_is_bitwise_the_register_staged_kernel(monkeypatch):
+    """the 256 -> 256 convs of the wide EDSR (four 64-channel output tiles; bias + ReLU, scale + residual, mask + two residuals): the streaming
+    kernel against conv3x3_kernel<4> (RUMPY_CONV4_OLD=1), bit for bit, ragged sizes and several tiles per workgroup"""
+    gen = np.random.default_rng(43)
+    w, b = _wb(gen, 256, 256)
+    pc = PackedConv(w, b)
+    for (N, H, W, gx) in ((2, 13, 17, 0), (1, 48, 48, 0), (3, 24, 33, 3), (1, 5, 3, 1)):
+        x = nhwc(_rand(gen, N, 256, H, W))
+        r1, r2, m = (nhwc(_rand(gen, N, 256, H, W)) for _ in range(3))
+        variants = [dict(relu=True), dict(scale=0.1, res1=r1), dict(dgrad=True, scale=0.1, mask=m), dict(dgrad=True, res1=r1, res2=r2),
+                    dict(use_bias=False, scale=0.5, mask=m, res1=r1, res2=r2)]
+        outs = []
+        for env in ('RUMPY_CONV4_OLD', None):
+            monkeypatch.delenv('RUMPY_CONV4_OLD', raising=False)
+            if env:
+                monkeypatch.setenv(env, '1')
+            outs.append([hip_conv(x, pc, N, H, W, grid_x=gx, **kw)[0] for kw in variants])
+        for k in range(len(variants)):
+            assert torch.equal(outs[0][k].view(torch.int16), outs[1][k].view(torch.int16)), (N, H, W, gx, sorted(variants[k]))
+
+
 @pytest.mark.parametrize('cin,cout', [(128, 128), (192, 64), (128, 192), (256, 256), (192, 192)])
 def test_conv3x3_two_three_and_four_input_chunks_with_epilogues(cin, cout):
     """EDSR widths above 64 features (128, 192, the shipped 256): one launch per layer with the epilogues of the 64-feature strip kernel,
