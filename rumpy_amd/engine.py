@@ -180,7 +180,6 @@ class SREngine:
                 cv.shuffle = False          # natural channel order; the permutation is its own pass
         if self.wide:
             self.eval_fmt = L.FMT_BF16      # the multi-chunk conv kernel is bf16 only
-            self.use_finish = False         # the one-launch housekeeping tables describe 64-feature tails; the separate entry points are generic
         self._alloc_packed()
         self.packed_version = None
 
@@ -231,7 +230,7 @@ class SREngine:
             if cv.kind == 'main':
                 roles[off_of(cv.weight)] = ('w', cv)
                 roles[off_of(cv.bias)] = ('b', cv)
-            elif cv.kind == 'tail':
+            elif cv.kind == 'tail' and not self.wide:      # a wide net's tail has no packed image: its weight and bias are plain ranges
                 roles[off_of(cv.weight)] = ('tw', cv)
                 roles[off_of(cv.bias)] = ('tb', cv)
         items, plain = [], []
