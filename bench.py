@@ -222,7 +222,8 @@ def main():
                             'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None}
             roofline.update(common)
             if wide_convs:
-                pass                                   # no PMC pass was taken for this kernel: traffic stays null
+                roofline['traffic'] = 70.0e6           # batch 16: measured once, not re-measured here
+                roofline['traffic_source'] = 'profiles/r02_pmc_wide.md (tests/tools/pmc_wide.sh: separate rocprofv3 --pmc passes over bench.py --model edsr256 --batch 16, 2 x FETCH_SIZE + WRITE_SIZE)'
             elif not use_block:
                 # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
                 roofline['traffic'] = PMC_TRAFFIC_BYTES

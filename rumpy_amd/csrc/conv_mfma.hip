@@ -523,6 +523,10 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     int g2 = p->grid_x > 0 ? p->grid_x : (rumpy_device_cus() / p->cout_tiles > 0 ? rumpy_device_cus() / p->cout_tiles : 1);
     const int rounds = cdiv(ntiles, g2);
     g2 = cdiv(ntiles, rounds);
+    // several output tiles: workgroup (x, ct) has linear id ct * g2 + x and lands on XCD id % 8 - with g2 a multiple of 8 the cout_tiles
+    // workgroups that read the same input tiles share an XCD, i.e. an L2 (PMC: 118 MB fetched per 256 -> 256 launch at 16 x 48 x 48 with
+    // g2 = 58, four times the input; profiles/r02_pmc_wide.md)
+    if (p->grid_x <= 0 && p->cout_tiles > 1 && g2 >= 8) g2 = ((g2 + 7) & ~7) <= rumpy_device_cus() / p->cout_tiles ? ((g2 + 7) & ~7) : (g2 & ~7);
     rumpy_conv4d_launch(d, g2, s);
   } else if (p->cin_chunks == 4)
   hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
