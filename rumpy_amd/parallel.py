@@ -24,7 +24,9 @@ def bucket_bounds(n, bucket_elems):
 
 
 class GradientAverager:
-    def __init__(self, net=None, flat_grad=None, bucket_elems=1 << 20, group=None):
+    def __init__(self, net=None, flat_grad=None, bucket_elems=None, group=None):
+        if bucket_elems is None:      # collectives per step = host time per step (a torch.distributed call costs the host 30-50 us): few, large ones
+            bucket_elems = int(os.environ.get('RUMPY_DP_BUCKET', 1 << 23))
         self.flat_g = flat_grad if flat_grad is not None else net.flat_g
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1

@@ -80,7 +80,7 @@ class BaseModel(nn.Module):
         from rumpy_amd.parallel import GradientAverager
         self.data_parallel = GradientAverager(self.net)
         hip = self._hip_net()
-        if hip is not None and self.data_parallel.active:
+        if hip is not None and self.data_parallel.active and os.environ.get('RUMPY_DP_LATE') != '1':      # (A/B: one all-reduce after the backward pass)
             hip.grad_ready_hook = self.data_parallel.begin      # all-reduce of the upper half starts under the remaining weight gradients
         if self.data_parallel.active:
             print('Model replicated over %d GPU processes (RCCL gradient all-reduce)' % self.data_parallel.world_size)
