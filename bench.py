@@ -42,6 +42,94 @@ def synthetic_batch(seed, n, lr_hw=48, scale=4, channels=3):
     return x, y
 
 
+def bench_moco(args):
+    """--model moco (information): one MoCo training step of the degradation encoder (define_model('mococontrastive'),
+    crop_count 2: N query + N key crops of 48x48) per step on one GPU.  Same line format; `roofline` prices the trunk's 64 -> 64 3x3 conv
+    (rumpy_enc_conv, the largest launch of the step) from HIP-event timings of eager launches taken in this process."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
+        raise SystemExit('--model moco is a one-GPU line')
+    from rumpy_amd import _lib as L
+    from rumpy_amd.shared_framework.models import define_model
+    dev = torch.device('cuda', 0)
+    N = args.batch
+    torch.manual_seed(8)
+    h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=2, lr=1e-4)
+    rng = np.random.default_rng(1234)
+    pool = [torch.from_numpy(rng.random((N, 6, 48, 48), dtype=np.float32)).to(dev) for _ in range(8)]
+    for i in range(args.warmup):
+        h.run_train(x=pool[i % 8], y=None)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = h.run_train(x=pool[i % 8], y=None)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    # dominant launch: conv 64 -> 64 on [N, 48, 48], with the plan's own buffers and filter image
+    enc = h.net.encoder_q
+    plan = enc._train_plans[(N, 48, 48, 0)]
+    wf, _, bp = enc._training_images(dev)[0]
+    a = L.EncConvArgs(x=plan['a'][0].data_ptr(), w=wf.data_ptr(), bias=bp.data_ptr(), out=plan['z'][1].data_ptr(), N=N, H=48, W=48, cin=64, cout=64,
+                      stride=1, neg_slope=1.0)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    for _ in range(5):
+        L.call('rumpy_enc_conv', a, s)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        L.call('rumpy_enc_conv', a, s)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    avg_s = e0.elapsed_time(e1) * 1e-3 / 50
+    flop = 2.0 * N * 48 * 48 * 64 * 64 * 9
+    alg_bytes = 2.0 * N * 48 * 48 * 64 * 2
+    tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
+    roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                'traffic': None, 'kernel': 'enc_conv_kernel<1, 4> (3x3 conv 64 -> 64 of the encoder trunk, the largest launch of the step)',
+                'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': 50, 'algorithmic_gflop_per_launch': round(flop / 1e9, 3),
+                'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
+                'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import contrastive_oracle as CO            # the checker, timed as the CPU baseline: the ONLY use of oracle/ here
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except AttributeError:
+            usable = os.cpu_count() or 1
+        try:                                             # container CPU quota (cgroup v2)
+            q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+            if q != 'max':
+                usable = max(1, min(usable, int(int(q) / int(per))))
+        except Exception:
+            pass
+        cores = max(1, min(usable, args.cpu_threads))
+        torch.set_num_threads(cores)
+        oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=2, lr=1e-4)
+        xc = pool[0][:args.cpu_batch].cpu()
+        oh.run_train(xc)
+        best, total, timed = 1e30, 0.0, 0
+        while timed < 3 or (total < 10.0 and timed < 200):
+            t2 = time.perf_counter()
+            oh.run_train(xc)
+            dt = time.perf_counter() - t2
+            best, total, timed = min(best, dt), total + dt, timed + 1
+        cpu = {'value': round(2 * args.cpu_batch / best, 1), 'unit': 'LR crops/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '1 warm-up + %d timed MoCo steps of %d + %d 48x48 crops (%.1f s of CPU work; value = best step), torch CPU fp32 oracle'
+                         % (timed, args.cpu_batch, args.cpu_batch, total)}
+    # 2.752 GFLOP per (query, key) pair and step: encoder forward 0.688 (SURVEY.md 8d) x (3 for the query: forward + data + weight gradient, 1 for the key)
+    line = {'metric': '48px LR crops/sec (MoCo train step) DASR encoder bf16', 'value': round(2 * N * args.steps / elapsed, 1), 'unit': 'LR crops/s',
+            'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic uniform[0,1) crops, random-init weights (seed 8)',
+            'config': {'workload': 'MoCo step of the degradation encoder (query + key encoder, 8192-entry queue), %d + %d crops of 48x48 per step' % (N, N),
+                       'global_batch': N, 'parallelism': 'dp1', 'optimizer': 'Adam lr 1e-4', 'loss': float(loss),
+                       'train_tflops': round(N * args.steps / elapsed * 2.752e9 / 1e12, 2)},
+            'roofline': roofline, 'cpu_baseline': cpu}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -52,11 +140,13 @@ def main():
     ap.add_argument('--probe-steps', type=int, default=5)
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan', 'blindqrcan', 'edsr256'), default='edsr',
+    ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan', 'blindqrcan', 'edsr256', 'moco'), default='edsr',
                     help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block, blindqrcan = frozen contrastive degradation encoder + QRCAN (BASELINE config 5 in bf16; q-layers as in the reference test config), edsr256 = EDSR at the reference\'s shipped width (div2k/edsr.toml: 256 features x 32 blocks); all for information')
     ap.add_argument('--device-patches', action='store_true',
                     help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
     args = ap.parse_args()
+    if args.model == 'moco':
+        return bench_moco(args)
 
     import numpy as np
     import torch
