@@ -61,6 +61,17 @@ class _LaunchGraph:
         self.graph.replay()
 
 
+def _conv_plain(x, w, bias, out, N, H, W, cin, cout, stream):
+    """stride-1 3x3 conv without activation (a training-mode stage, or a data gradient): the SR path's kernels where they take the shape and are
+    faster - Cin = 64 (strip kernel: 43 vs 95 us for 64 -> 64 at 256 x 48 x 48) and Cin = 256 on maps of 24+ rows (128 vs 188 us for 256 -> 128 at
+    256 x 24 x 24; tests/tools/enc_conv_ab.py) -, else the encoder's general kernel.  Same filter images, same bf16 NHWC layout."""
+    if cin == 64 or (cin == 256 and H >= 24):
+        L.call('rumpy_conv3x3', L.ConvArgs(x=x, w=w, bias=bias, out=out, mask=None, res1=None, res2=None, pool=None, N=N, H=H, W=W,
+                                           cin_chunks=cin // 64, cout_tiles=cout // 64, in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0, fmt=0), stream)
+    else:
+        L.call('rumpy_enc_conv', L.EncConvArgs(x=x, w=w, bias=bias, out=out, N=N, H=H, W=W, cin=cin, cout=cout, stride=1, neg_slope=1.0), stream)
+
+
 class _TrunkFn(torch.autograd.Function):
     """The six conv + BatchNorm(train) + LeakyReLU stages and the pool as ONE autograd node: both directions are HIP launches.  Parameter
     gradients are written (not accumulated) into the encoder's flat gradient buffer, whose views are the parameters' ``.grad``."""
@@ -295,8 +306,11 @@ class Encoder(nn.Module):
             for i, (cin, cout, stride) in enumerate(LAYERS):
                 if i > 0:
                     wf, bp = imgs[i]
-                    L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(acts[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(acts[i]), N=N, H=h, W=w, cin=cin,
-                                                           cout=cout, stride=stride, neg_slope=1.0 if train else SLOPE), stream)
+                    if train and stride == 1:
+                        _conv_plain(_ptr(acts[i - 1]), _ptr(wf), _ptr(bp), _ptr(acts[i]), N, h, w, cin, cout, stream)
+                    else:
+                        L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(acts[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(acts[i]), N=N, H=h, W=w, cin=cin,
+                                                               cout=cout, stride=stride, neg_slope=1.0 if train else SLOPE), stream)
                     h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
                 if train:
                     bn = bns[i]
@@ -416,8 +430,11 @@ class Encoder(nn.Module):
                 hi, wi, ho, wo = plan['dims'][i]
                 if i > 0:
                     wf, _, bp = imgs[i - 1]
-                    L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
-                                                           cout=cout, stride=stride, neg_slope=1.0), stream)
+                    if stride == 1:
+                        _conv_plain(_ptr(a[i - 1]), _ptr(wf), _ptr(bp), _ptr(z[i]), N, hi, wi, cin, cout, stream)
+                    else:
+                        L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
+                                                               cout=cout, stride=stride, neg_slope=1.0), stream)
                 bn = bns[i]
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                 args = L.EncBnArgs(x=_ptr(z[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias), running_mean=_ptr(bn.running_mean),
@@ -472,8 +489,8 @@ class Encoder(nn.Module):
                                                           neg_slope=SLOPE, scale=1.0), stream)
                 if i > 0:      # data gradient: the stride-1 convolution of dz (on the input's grid) with the transposed, flipped filter
                     _, wd, _ = imgs[i - 1]
-                    L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(dz[i]), w=_ptr(wd), bias=_ptr(plan['zero_bias']), out=_ptr(da[i - 1]), N=N, H=hi,
-                                                           W=wi, cin=cout, cout=cin, stride=1, neg_slope=1.0), stream)
+                    _conv_plain(_ptr(dz[i]), _ptr(wd), None if cout in (64, 256) and (cout == 64 or hi >= 24) else _ptr(plan['zero_bias']), _ptr(da[i - 1]),
+                                N, hi, wi, cout, cin, stream)
             L.check(lib.rumpy_wgrad_grouped(_ptr(plan['jobs']), plan['njobs'], 4, 0, stream), 'rumpy_wgrad_grouped')
             L.check(lib.rumpy_wgrad_reduce(_ptr(plan['items']), plan['nitems'], stream), 'rumpy_wgrad_reduce')
             L.call('rumpy_head_wgrad', L.HeadWgradArgs(x=_ptr(x), dy=_ptr(dz[0]), slab=_ptr(plan['head_slab']), gw=_ptr(gv(convs[0].weight)),

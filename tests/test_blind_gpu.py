@@ -207,11 +207,14 @@ def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze
             assert abs(float(pkg[k]) - float(opkg[k])) <= 2e-2 * max(1.0, float(opkg[k])), (step, k, float(pkg[k]), float(opkg[k]))
         assert float((logits - ologits).abs().max()) <= (0.25 if step == 0 else 0.6)
         if step == 0:
-            class G:
-                pass
-            a, b = G(), G()
-            a.net, b.net = h.net.G, oh.net.G
-            print('worst generator grad rel err', _grad_check(a, b))
+            # generator gradients like every network test, except the q-layers' own parameters: their MLP reads the embedding (dW1 = dh (x) embedding,
+            # dh masked by relu(W1 embedding + b1)) and carries the embedding's error - BatchNorm statistics over 4 images x 4 x 4 pixels at this
+            # test size, bf16 trunk: 1e-1 / cosine 0.99 there
+            for (k, p), (_, q) in zip(h.net.G.named_parameters(), oh.net.G.named_parameters()):
+                g, r = p.grad.detach().float().cpu().double().reshape(-1), q.grad.double().reshape(-1)
+                rel, cos = float((g - r).norm() / (r.norm() + 1e-30)), float((g @ r) / (g.norm() * r.norm() + 1e-30))
+                loose = 'q_node' in k
+                assert rel < (1e-1 if loose else 3e-2) and cos > (0.99 if loose else 0.999), 'grad %s: rel %.3e cos %.6f' % (k, rel, cos)
             for (k, p), (_, po) in zip(h.net.E.named_parameters(), oh.net.E.named_parameters()):
                 if po.requires_grad and 'mlp' in k:
                     assert _rel(p.grad.cpu(), po.grad) < 5e-2, k                      # the heads, from the contrastive loss
