@@ -45,7 +45,7 @@ def synthetic_batch(seed, n, lr_hw=48, scale=4, channels=3):
 def bench_moco(args):
     """--model moco (information): one MoCo training step of the degradation encoder (define_model('mococontrastive'),
     crop_count 2: N query + N key crops of 48x48) per step on one GPU.  Same line format; `roofline` prices the trunk's 64 -> 64 3x3 conv
-    (rumpy_enc_conv, the largest launch of the step) from HIP-event timings of eager launches taken in this process."""
+    (the largest launch of the step) from HIP-event timings of eager launches taken in this process."""
     import numpy as np
     import torch
     if not torch.cuda.is_available():
@@ -72,15 +72,15 @@ def bench_moco(args):
     enc = h.net.encoder_q
     plan = enc._train_plans[(N, 48, 48, 0)]
     wf, _, bp = enc._training_images(dev)[0]
-    a = L.EncConvArgs(x=plan['a'][0].data_ptr(), w=wf.data_ptr(), bias=bp.data_ptr(), out=plan['z'][1].data_ptr(), N=N, H=48, W=48, cin=64, cout=64,
-                      stride=1, neg_slope=1.0)
+    from rumpy_amd.regression.models.contrastive_learning.encoding_models import _conv_plain
     s = torch.cuda.current_stream(dev).cuda_stream
+    launch = lambda: _conv_plain(plan['a'][0].data_ptr(), wf.data_ptr(), bp.data_ptr(), plan['z'][1].data_ptr(), N, 48, 48, 64, 64, s)   # as the step launches it
     for _ in range(5):
-        L.call('rumpy_enc_conv', a, s)
+        launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(50):
-        L.call('rumpy_enc_conv', a, s)
+        launch()
     e1.record()
     torch.cuda.synchronize(dev)
     avg_s = e0.elapsed_time(e1) * 1e-3 / 50
@@ -88,7 +88,7 @@ def bench_moco(args):
     alg_bytes = 2.0 * N * 48 * 48 * 64 * 2
     tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
     roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
-                'traffic': None, 'kernel': 'enc_conv_kernel<1, 4> (3x3 conv 64 -> 64 of the encoder trunk, the largest launch of the step)',
+                'traffic': None, 'kernel': 'conv3x3_strip_kernel via rumpy_conv3x3 (3x3 conv 64 -> 64 of the encoder trunk, the largest launch of the step)',
                 'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': 50, 'algorithmic_gflop_per_launch': round(flop / 1e9, 3),
                 'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
                 'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}

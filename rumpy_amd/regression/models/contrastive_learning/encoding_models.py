@@ -61,11 +61,14 @@ class _LaunchGraph:
         self.graph.replay()
 
 
+_SR_CONVS = os.environ.get('RUMPY_ENC_OWN_CONV') != '1'      # A/B: the encoder's own kernel for every launch
+
+
 def _conv_plain(x, w, bias, out, N, H, W, cin, cout, stream):
     """stride-1 3x3 conv without activation (a training-mode stage, or a data gradient): the SR path's kernels where they take the shape and are
     faster - Cin = 64 (strip kernel: 43 vs 95 us for 64 -> 64 at 256 x 48 x 48) and Cin = 256 on maps of 24+ rows (128 vs 188 us for 256 -> 128 at
     256 x 24 x 24; tests/tools/enc_conv_ab.py) -, else the encoder's general kernel.  Same filter images, same bf16 NHWC layout."""
-    if cin == 64 or (cin == 256 and H >= 24):
+    if _SR_CONVS and (cin == 64 or (cin == 256 and H >= 24)):
         L.call('rumpy_conv3x3', L.ConvArgs(x=x, w=w, bias=bias, out=out, mask=None, res1=None, res2=None, pool=None, N=N, H=H, W=W,
                                            cin_chunks=cin // 64, cout_tiles=cout // 64, in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0, fmt=0), stream)
     else:
@@ -489,7 +492,7 @@ class Encoder(nn.Module):
                                                           neg_slope=SLOPE, scale=1.0), stream)
                 if i > 0:      # data gradient: the stride-1 convolution of dz (on the input's grid) with the transposed, flipped filter
                     _, wd, _ = imgs[i - 1]
-                    _conv_plain(_ptr(dz[i]), _ptr(wd), None if cout in (64, 256) and (cout == 64 or hi >= 24) else _ptr(plan['zero_bias']), _ptr(da[i - 1]),
+                    _conv_plain(_ptr(dz[i]), _ptr(wd), _ptr(plan['zero_bias']), _ptr(da[i - 1]),
                                 N, hi, wi, cout, cin, stream)
             L.check(lib.rumpy_wgrad_grouped(_ptr(plan['jobs']), plan['njobs'], 4, 0, stream), 'rumpy_wgrad_grouped')
             L.check(lib.rumpy_wgrad_reduce(_ptr(plan['items']), plan['nitems'], stream), 'rumpy_wgrad_reduce')
