@@ -3,7 +3,10 @@ rumpy/regression/models/contrastive_learning/handlers.py:12-163 (``MocoContrasti
 ``SupMoCoHandler`` -> 'supmoco', ``WeakConHandler`` -> 'weakcon' (:166-216), ``SupConHandler`` -> 'supcon' (:219-257)), so
 ``define_model(name, **kwargs)`` resolves to them.  They train the degradation encoder the blind-SR handlers load as
 ``pre_trained_encoder_weights``.  Not built: the drop-down head and its direct regression loss, torchvision / IDMN backbones."""
+import os
+
 import torch
+import torch.distributed as dist
 
 from rumpy_amd.sr_tools.loss_functions import SupConLoss
 from . import BaseContrastive
@@ -12,13 +15,20 @@ from .supmoco import SupMoCo
 from .weak_con import WeakCon
 
 
+_CROP_INDEX = {}
+
+
 def _split_crops(x, crop_count, device):
-    """[N, crops, 3, H, W] (or anything that views to [N * crops, 3, H, W]) -> (first crop of every image, all the other crops) (:47-53)"""
-    x = x.view(-1, 3, x.shape[-2], x.shape[-1]).to(device=device)
-    first = torch.arange(0, x.shape[0], crop_count, device=x.device)
-    rest = torch.ones(x.shape[0], dtype=torch.bool, device=x.device)
-    rest[first] = False
-    return x[first], x[rest]
+    """[N, crops, 3, H, W] (or anything that views to [N * crops, 3, H, W]) -> (first crop of every image, all the other crops) (:47-53).
+    The two index vectors live on the device, one pair per (count, crops): selecting through them is the same launch at every step."""
+    x = x.reshape(-1, 3, x.shape[-2], x.shape[-1]).to(device=device)
+    key = (x.shape[0], crop_count, x.device)
+    if key not in _CROP_INDEX:
+        first = [i for i in range(0, x.shape[0], crop_count)]
+        rest = [i for i in range(x.shape[0]) if i % crop_count]
+        _CROP_INDEX[key] = (torch.tensor(first, dtype=torch.long, device=x.device), torch.tensor(rest, dtype=torch.long, device=x.device))
+    first, rest = _CROP_INDEX[key]
+    return x.index_select(0, first), x.index_select(0, rest)
 
 
 class MocoContrastiveHandler(BaseContrastive):
@@ -35,21 +45,59 @@ class MocoContrastiveHandler(BaseContrastive):
         embedding, q = self.net.forward(x, x, get_q=True, **kwargs)
         return embedding, q
 
-    def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):
-        """x: [N, 6, H, W] (query crop | key crop on the channel axis) for crop_count 2, else [N, crops, 3, H, W]: the first crop of an image
-        is its query, the others its keys -> (contrastive loss, logits [N, 1 + K] on the CPU) (:37-63)"""
-        if self.eval_mode:
-            raise RuntimeError('Model initialized in eval mode, training not possible.')
-        self.net.train()
-        dev = self._torch_device()
+    def _forward_backward(self, x, dev):
         if self.crop_count == 2:
-            x = x.to(device=dev)
             im_q, im_k = x[:, 0:3, ...], x[:, 3:, ...]
         else:
             im_q, im_k = _split_crops(x, self.crop_count, dev)
         _, output, target = self.net(im_q=im_q, im_k=im_k)
         loss_contrast = self.criterion(output, target.to(device=dev))
-        self.standard_update(loss_contrast)
+        self.optimizer.zero_grad()
+        loss_contrast.backward()
+        return loss_contrast, output
+
+    def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):
+        """x: [N, 6, H, W] (query crop | key crop on the channel axis) for crop_count 2, else [N, 3 * crops, H, W]: the first crop of an image
+        is its query, the others its keys -> (contrastive loss, logits [N, 1 + K] on the CPU) (:37-63).
+
+        The step's launch list is the same at every step - both trunks, the momentum update, the torch head and its autograd, the enqueue
+        through a device-side slot vector - and the 32-crop step is host-bound (1.7 ms of Python for 1.15 ms of kernels): after two eager
+        steps of a batch shape it is captured as ONE hipGraph and replayed (forward + loss + backward; the optimizer and the scheduler stay
+        outside: their numbers change every step).  RUMPY_MOCO_STEP_GRAPH=0 or a process group (the key all-gather) keep it eager."""
+        if self.eval_mode:
+            raise RuntimeError('Model initialized in eval mode, training not possible.')
+        self.net.train()
+        dev = self._torch_device()
+        x = x.to(device=dev)
+        graphable = (os.environ.get('RUMPY_MOCO_STEP_GRAPH', '1') != '0' and x.is_cuda and not (dist.is_available() and dist.is_initialized())
+                     and type(self.optimizer).__name__ == 'FlatAdam')
+        if not graphable:
+            loss_contrast, output = self._forward_backward(x, dev)
+        else:
+            key = (tuple(x.shape), x.dtype)
+            st = self.__dict__.setdefault('_step_graphs', {}).setdefault(key, {'calls': 0})
+            st['calls'] += 1
+            if st['calls'] <= 2:
+                loss_contrast, output = self._forward_backward(x, dev)
+            else:
+                if 'graph' not in st:
+                    st['x'] = torch.empty_like(x)
+                    st['x'].copy_(x)
+                    torch.cuda.synchronize(dev)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        st['loss'], st['out'] = self._forward_backward(st['x'], dev)
+                    st['graph'] = g
+                    st['n_keys'] = x.shape[0] * (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1)
+                    # capture does not execute: what the host-side bookkeeping recorded during it is taken back, the replay below redoes it
+                    self.net._moved(-st['n_keys'])
+                st['x'].copy_(x)
+                st['graph'].replay()
+                self.net._moved(st['n_keys'])
+                self.net.encoder_q._stats_epoch += 1
+                self.net.encoder_k._stats_epoch += 1
+                loss_contrast, output = st['loss'], st['out']
+        self._apply_update()
         return loss_contrast.detach().cpu().numpy(), output.detach().cpu()
 
 

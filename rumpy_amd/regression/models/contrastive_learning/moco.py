@@ -111,15 +111,33 @@ class MoCo(nn.Module):
         self.queue_ptr[0] = ptr
         self._ptr_seen = ((id(self.queue_ptr), self.queue_ptr._version), ptr)
 
+    def _slots(self, batch_size, ptr):
+        """device vector of the queue columns the next `batch_size` keys go to, advanced ON THE DEVICE by every enqueue - so that the enqueue
+        is the same launch list at every step (a captured step graph replays it) while the host keeps its own copy of the pointer"""
+        st = self.__dict__.get('_slot_state')
+        if st is None or st[0] != batch_size or st[1] != ptr or st[2].device != self.queue.device:
+            idx = (torch.arange(batch_size, device=self.queue.device, dtype=torch.long) + ptr) % self.K
+            st = [batch_size, ptr, idx]
+            self.__dict__['_slot_state'] = st
+        return st
+
+    def _moved(self, batch_size):
+        """host bookkeeping of one enqueue (also what a step-graph replay calls: the device side moved inside the graph)"""
+        st = self.__dict__['_slot_state']
+        st[1] = (st[1] + batch_size) % self.K
+        self._ptr_seen = ((id(self.queue_ptr), self.queue_ptr._version), st[1])
+
     @torch.no_grad()
     def _dequeue_and_enqueue(self, keys):
         """:74-89"""
         keys = self._gathered(keys)
         batch_size = keys.shape[0]
-        ptr = self._queue_pointer()
         assert self.K % batch_size == 0  # for simplicity
-        self.queue[:, ptr:ptr + batch_size] = keys.transpose(0, 1)
-        self._advance_queue_pointer((ptr + batch_size) % self.K)
+        st = self._slots(batch_size, self._queue_pointer())
+        self.queue.index_copy_(1, st[2], keys.transpose(0, 1))
+        st[2].add_(batch_size).remainder_(self.K)
+        self.queue_ptr.add_(batch_size).remainder_(self.K)
+        self._moved(batch_size)
 
     def forward(self, im_q, im_k, **kwargs):
         """training: (embedding, logits [N, 1 + K], labels (zeros)) ; evaluation: embedding, or (embedding, q) with get_q (:132-187)"""

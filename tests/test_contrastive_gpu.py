@@ -351,22 +351,29 @@ def test_reference_contrastive_test_through_the_regression_interface(name, tmp_p
     assert result[0].shape == (1, 256)
 
 
-def test_moco_step_is_bitwise_reproducible():
-    """two handlers, same seeded state, same batch: loss, logits, every gradient, queue and key encoder come out bit for bit (fixed-order
-    reductions in every kernel of the trunk; the head is deterministic library GEMMs)"""
+@pytest.mark.parametrize('crops,N', [(2, 8), (3, 4)])
+def test_moco_step_is_bitwise_reproducible_and_the_step_graph_is_the_eager_step(crops, N, monkeypatch):
+    """three handlers, same seeded state, same batches: the default one (two eager steps, then the whole step - both trunks, momentum update,
+    torch head + autograd, enqueue - captured as one graph and replayed), a second default one, and one kept eager (RUMPY_MOCO_STEP_GRAPH=0):
+    loss, logits, every gradient, the weights after Adam, the key encoder, the queue and its pointer come out bit for bit, step by step"""
     res = []
-    for _ in range(2):
-        h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=2, lr=1e-3)
-        oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=2, lr=1e-3)
+    for mode in ('graph', 'graph', 'eager'):
+        monkeypatch.setenv('RUMPY_MOCO_STEP_GRAPH', '0' if mode == 'eager' else '1')
+        h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=crops, lr=1e-3)
+        oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=crops, lr=1e-3)
         _seed_handler(h, oh, 900)
         out = []
-        for step in range(3):                     # eager, captured, replayed launch lists
-            x = CO.contrastive_batch(910 + step, 8, 2).view(8, 6, 32, 32)
+        for step in range(6):
+            x = CO.contrastive_batch(910 + step, N, crops).view(N, 3 * crops, 32, 32)
             loss, logits = h.run_train(x=x, y=None)
             out.append((float(loss), logits.clone(), h.net.flat_g.clone().cpu(), h.net.flat_p.clone().cpu(), h.net.encoder_k.flat_p.clone().cpu(),
-                        h.net.queue[:, :24].clone().cpu()))
+                        h.net.queue[:, :8 * N].clone().cpu(), h.net.queue_ptr.clone().cpu(),
+                        h.net.encoder_q.E[1].running_var.clone().cpu(), h.net.encoder_k.E[16].num_batches_tracked.clone().cpu()))
+        assert int(h.net.queue_ptr) == 6 * N == h.net._queue_pointer()
+        assert ('graph' in next(iter(h._step_graphs.values()))) == (mode == 'graph') if mode == 'graph' else not getattr(h, '_step_graphs', {})
         res.append(out)
-    for a, b in zip(*res):
-        assert a[0] == b[0]
-        for ta, tb in zip(a[1:], b[1:]):
-            assert torch.equal(ta, tb)
+    for other in res[1:]:
+        for step, (a, b) in enumerate(zip(res[0], other)):
+            assert a[0] == b[0], step
+            for i, (ta, tb) in enumerate(zip(a[1:], b[1:])):
+                assert torch.equal(ta, tb), (step, i)
