@@ -31,6 +31,41 @@ def _split_crops(x, crop_count, device):
     return x.index_select(0, first), x.index_select(0, rest)
 
 
+def _graphed_step(handler, forward_backward, inputs, dev):
+    """forward + loss + backward of a queue-based contrastive handler: forward_backward(*inputs, dev) -> (loss, returned tensor).
+
+    The step's launch list is the same at every step - both trunks, the momentum update, the torch head and its autograd, the enqueue through
+    a device-side slot vector - and the 32-crop step is host-bound (1.7 ms of Python for 1.15 ms of kernels): after two eager steps of a
+    batch shape it is captured as ONE hipGraph and replayed (inputs copied into static buffers; the optimizer and the scheduler stay
+    outside: their numbers change every step).  RUMPY_MOCO_STEP_GRAPH=0 or a process group (the key all-gather) keep it eager."""
+    graphable = (os.environ.get('RUMPY_MOCO_STEP_GRAPH', '1') != '0' and all(t.is_cuda for t in inputs)
+                 and not (dist.is_available() and dist.is_initialized()) and type(handler.optimizer).__name__ == 'FlatAdam')
+    if not graphable:
+        return forward_backward(*inputs, dev)
+    key = tuple((tuple(t.shape), t.dtype) for t in inputs)
+    st = handler.__dict__.setdefault('_step_graphs', {}).setdefault(key, {'calls': 0})
+    st['calls'] += 1
+    if st['calls'] <= 2:
+        return forward_backward(*inputs, dev)
+    if 'graph' not in st:
+        st['in'] = [t.clone() for t in inputs]
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st['loss'], st['out'] = forward_backward(*st['in'], dev)
+        st['graph'] = g
+        st['n_keys'] = handler.net.__dict__['_slot_state'][0]
+        # capture does not execute: what the host-side bookkeeping recorded during it is taken back, the replay below redoes it
+        handler.net._moved(-st['n_keys'])
+    for buf, t in zip(st['in'], inputs):
+        buf.copy_(t)
+    st['graph'].replay()
+    handler.net._moved(st['n_keys'])
+    handler.net.encoder_q._stats_epoch += 1
+    handler.net.encoder_k._stats_epoch += 1
+    return st['loss'], st['out']
+
+
 class MocoContrastiveHandler(BaseContrastive):
     def __init__(self, device, model_save_dir, eval_mode=False, output_size=10, scheduler=None, scheduler_params=None, lr=1e-4,
                  model_name=None, crop_count=2, moco_t=0.07, **kwargs):
@@ -58,45 +93,12 @@ class MocoContrastiveHandler(BaseContrastive):
 
     def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):
         """x: [N, 6, H, W] (query crop | key crop on the channel axis) for crop_count 2, else [N, 3 * crops, H, W]: the first crop of an image
-        is its query, the others its keys -> (contrastive loss, logits [N, 1 + K] on the CPU) (:37-63).
-
-        The step's launch list is the same at every step - both trunks, the momentum update, the torch head and its autograd, the enqueue
-        through a device-side slot vector - and the 32-crop step is host-bound (1.7 ms of Python for 1.15 ms of kernels): after two eager
-        steps of a batch shape it is captured as ONE hipGraph and replayed (forward + loss + backward; the optimizer and the scheduler stay
-        outside: their numbers change every step).  RUMPY_MOCO_STEP_GRAPH=0 or a process group (the key all-gather) keep it eager."""
+        is its query, the others its keys -> (contrastive loss, logits [N, 1 + K] on the CPU) (:37-63)"""
         if self.eval_mode:
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
         dev = self._torch_device()
-        x = x.to(device=dev)
-        graphable = (os.environ.get('RUMPY_MOCO_STEP_GRAPH', '1') != '0' and x.is_cuda and not (dist.is_available() and dist.is_initialized())
-                     and type(self.optimizer).__name__ == 'FlatAdam')
-        if not graphable:
-            loss_contrast, output = self._forward_backward(x, dev)
-        else:
-            key = (tuple(x.shape), x.dtype)
-            st = self.__dict__.setdefault('_step_graphs', {}).setdefault(key, {'calls': 0})
-            st['calls'] += 1
-            if st['calls'] <= 2:
-                loss_contrast, output = self._forward_backward(x, dev)
-            else:
-                if 'graph' not in st:
-                    st['x'] = torch.empty_like(x)
-                    st['x'].copy_(x)
-                    torch.cuda.synchronize(dev)
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        st['loss'], st['out'] = self._forward_backward(st['x'], dev)
-                    st['graph'] = g
-                    st['n_keys'] = x.shape[0] * (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1)
-                    # capture does not execute: what the host-side bookkeeping recorded during it is taken back, the replay below redoes it
-                    self.net._moved(-st['n_keys'])
-                st['x'].copy_(x)
-                st['graph'].replay()
-                self.net._moved(st['n_keys'])
-                self.net.encoder_q._stats_epoch += 1
-                self.net.encoder_k._stats_epoch += 1
-                loss_contrast, output = st['loss'], st['out']
+        loss_contrast, output = _graphed_step(self, self._forward_backward, (x.to(device=dev),), dev)
         self._apply_update()
         return loss_contrast.detach().cpu().numpy(), output.detach().cpu()
 
@@ -130,12 +132,18 @@ class SupMoCoHandler(BaseContrastive):
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
         dev = self._torch_device()
-        labels = self.class_logic(y, kwargs['metadata_keys'])
-        im_q, im_k = _split_crops(x, self.crop_count, dev)
-        embedding, logits, full_labels, _ = self.net(im_q, im_k, labels.squeeze())
-        loss_contrast = self.criterion(logits, full_labels.to(dev))
-        self.standard_update(loss_contrast)
+        labels = self.class_logic(y, kwargs['metadata_keys']).reshape(-1).to(device=dev, dtype=torch.int64)      # host logic, per batch
+        loss_contrast, embedding = _graphed_step(self, self._forward_backward, (x.to(device=dev), labels), dev)
+        self._apply_update()
         return loss_contrast.detach().cpu().numpy(), embedding.detach().cpu()
+
+    def _forward_backward(self, x, labels, dev):
+        im_q, im_k = _split_crops(x, self.crop_count, dev)
+        embedding, logits, full_labels, _ = self.net(im_q, im_k, labels)
+        loss_contrast = self.criterion(logits, full_labels.to(dev))
+        self.optimizer.zero_grad()
+        loss_contrast.backward()
+        return loss_contrast, embedding
 
     def run_model(self, x, *args, **kwargs):
         embedding, q = self.net.forward(x, x, get_q=True, **kwargs)
@@ -160,12 +168,18 @@ class WeakConHandler(BaseContrastive):
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
         dev = self._torch_device()
-        vectors = self.vector_logic(y, kwargs['metadata_keys']).to(device=dev)
+        vectors = self.vector_logic(y, kwargs['metadata_keys']).to(device=dev)                                   # host logic, per batch
+        loss_contrast, embedding = _graphed_step(self, self._forward_backward, (x.to(device=dev), vectors.contiguous()), dev)
+        self._apply_update()
+        return loss_contrast.detach().cpu().numpy(), embedding.detach().cpu()
+
+    def _forward_backward(self, x, vectors, dev):
         im_q, im_k = _split_crops(x, self.crop_count, dev)
         embedding, logits, full_labels = self.net(im_q, im_k, vectors.squeeze())
         loss_contrast = self.criterion(logits, full_labels.to(dev))
-        self.standard_update(loss_contrast)
-        return loss_contrast.detach().cpu().numpy(), embedding.detach().cpu()
+        self.optimizer.zero_grad()
+        loss_contrast.backward()
+        return loss_contrast, embedding
 
     def run_model(self, x, *args, **kwargs):
         embedding, q = self.net.forward(x, x, get_q=True, **kwargs)

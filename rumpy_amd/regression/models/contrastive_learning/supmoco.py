@@ -31,11 +31,13 @@ class SupMoCo(MoCo):
     def _dequeue_and_enqueue(self, keys, labels):
         keys, labels = self._gathered(keys), self._gathered(labels)
         batch_size = keys.shape[0]
-        ptr = self._queue_pointer()
         assert self.K % batch_size == 0  # for simplicity
-        self.queue[:, ptr:ptr + batch_size] = keys.transpose(0, 1)
-        self.queue_labels[ptr:ptr + batch_size] = labels
-        self._advance_queue_pointer((ptr + batch_size) % self.K)
+        st = self._slots(batch_size, self._queue_pointer())          # device-side slot vector: the same launches at every step (moco.py)
+        self.queue.index_copy_(1, st[2], keys.transpose(0, 1))
+        self.queue_labels.index_copy_(0, st[2], labels)
+        st[2].add_(batch_size).remainder_(self.K)
+        self.queue_ptr.add_(batch_size).remainder_(self.K)
+        self._moved(batch_size)
 
     def forward(self, im_q, im_k, labels=None, **kwargs):
         """training: (embedding, logits [N, 1 + K], zeros, encoder outputs) ; evaluation as MoCo (:52-138)"""

@@ -23,11 +23,13 @@ class WeakCon(SupMoCo):
     def _dequeue_and_enqueue(self, keys, vectors):
         keys, vectors = self._gathered(keys), self._gathered(vectors.t().contiguous()).t()
         batch_size = keys.shape[0]
-        ptr = self._queue_pointer()
         assert self.K % batch_size == 0  # for simplicity
-        self.queue[:, ptr:ptr + batch_size] = keys.transpose(0, 1)
-        self.queue_vectors[:, ptr:ptr + batch_size] = vectors
-        self._advance_queue_pointer((ptr + batch_size) % self.K)
+        st = self._slots(batch_size, self._queue_pointer())          # device-side slot vector: the same launches at every step (moco.py)
+        self.queue.index_copy_(1, st[2], keys.transpose(0, 1))
+        self.queue_vectors.index_copy_(1, st[2], vectors)
+        st[2].add_(batch_size).remainder_(self.K)
+        self.queue_ptr.add_(batch_size).remainder_(self.K)
+        self._moved(batch_size)
 
     def forward(self, im_q, im_k, q_vector=None, **kwargs):
         """training: (embedding, logits [N, 1 + K], zeros) with q_vector [V, N] the queries' degradation vectors ; evaluation as MoCo (:36-113)"""

@@ -377,3 +377,32 @@ def test_moco_step_is_bitwise_reproducible_and_the_step_graph_is_the_eager_step(
             assert a[0] == b[0], step
             for i, (ta, tb) in enumerate(zip(a[1:], b[1:])):
                 assert torch.equal(ta, tb), (step, i)
+
+
+@pytest.mark.parametrize('name', ['supmoco', 'weakcon'])
+def test_supmoco_and_weakcon_step_graphs_are_the_eager_steps(name, monkeypatch):
+    """the captured step of the label- / vector-carrying handlers (inputs = crops + the batch's labels or degradation vectors, copied into
+    static buffers) against the eager step, bit for bit over six steps with changing metadata"""
+    keys = [('gaussian_noise_scale',), ('poisson_noise_scale',), ('gray_noise_boolean',)]
+    metas = [torch.tensor([[0.8, 0, 1], [0, 0.3, 0], [0.7, 0, 1], [0, 0.9, 1]]), torch.tensor([[0, 0.6, 1], [0.2, 0, 0], [0, 0.9, 0], [0.9, 0, 1]])]
+    res = []
+    for mode in ('graph', 'eager'):
+        monkeypatch.setenv('RUMPY_MOCO_STEP_GRAPH', '0' if mode == 'eager' else '1')
+        h = define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
+                         data_type='noise', labelling_strategy='double_precision')
+        oh = CO.OracleContrastiveHandler(name, crop_count=3, lr=1e-3)
+        _seed_handler(h, oh, 950)
+        out = []
+        for step in range(6):
+            x = CO.contrastive_batch(960 + step, 4, 3).view(4, 9, 32, 32)
+            loss, emb = h.run_train(x=x, y=metas[step % 2], metadata_keys=keys)
+            track = h.net.queue_labels if name == 'supmoco' else h.net.queue_vectors
+            out.append((float(loss), emb.clone(), h.net.flat_g.clone().cpu(), h.net.flat_p.clone().cpu(), h.net.queue[:, :24].clone().cpu(),
+                        track[..., :24].clone().cpu(), h.net.queue_ptr.clone().cpu()))
+        assert int(h.net.queue_ptr) == 24 == h.net._queue_pointer()
+        assert ('graph' in next(iter(getattr(h, '_step_graphs', {'x': {}}).values()))) == (mode == 'graph')
+        res.append(out)
+    for step, (a, b) in enumerate(zip(*res)):
+        assert a[0] == b[0], step
+        for i, (ta, tb) in enumerate(zip(a[1:], b[1:])):
+            assert torch.equal(ta, tb), (step, i)
