@@ -57,6 +57,7 @@ def _graphed_step(handler, forward_backward, inputs, dev):
         st['n_keys'] = handler.net.__dict__['_slot_state'][0]
         # capture does not execute: what the host-side bookkeeping recorded during it is taken back, the replay below redoes it
         handler.net._moved(-st['n_keys'])
+    handler.net._slots(st['n_keys'], handler.net._queue_pointer())       # (a checkpoint loaded since the last step moves the slot vector in place)
     for buf, t in zip(st['in'], inputs):
         buf.copy_(t)
     st['graph'].replay()

@@ -115,10 +115,12 @@ class MoCo(nn.Module):
         """device vector of the queue columns the next `batch_size` keys go to, advanced ON THE DEVICE by every enqueue - so that the enqueue
         is the same launch list at every step (a captured step graph replays it) while the host keeps its own copy of the pointer"""
         st = self.__dict__.get('_slot_state')
-        if st is None or st[0] != batch_size or st[1] != ptr or st[2].device != self.queue.device:
-            idx = (torch.arange(batch_size, device=self.queue.device, dtype=torch.long) + ptr) % self.K
-            st = [batch_size, ptr, idx]
+        if st is None or st[0] != batch_size or st[2].device != self.queue.device:
+            st = [batch_size, ptr, (torch.arange(batch_size, device=self.queue.device, dtype=torch.long) + ptr) % self.K]
             self.__dict__['_slot_state'] = st
+        elif st[1] != ptr:          # the pointer was moved from outside (a loaded checkpoint): same vector - a captured step holds its address
+            st[2].copy_((torch.arange(batch_size, device=self.queue.device, dtype=torch.long) + ptr) % self.K)
+            st[1] = ptr
         return st
 
     def _moved(self, batch_size):

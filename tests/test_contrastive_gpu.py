@@ -371,6 +371,14 @@ def test_moco_step_is_bitwise_reproducible_and_the_step_graph_is_the_eager_step(
                         h.net.encoder_q.E[1].running_var.clone().cpu(), h.net.encoder_k.E[16].num_batches_tracked.clone().cpu()))
         assert int(h.net.queue_ptr) == 6 * N == h.net._queue_pointer()
         assert ('graph' in next(iter(h._step_graphs.values()))) == (mode == 'graph') if mode == 'graph' else not getattr(h, '_step_graphs', {})
+        # a checkpoint round trip between steps: the queue pointer written by load_state_dict is picked up by the next (replayed) step
+        sd = {k: v.clone() for k, v in h.net.state_dict().items()}
+        sd['queue_ptr'] = torch.tensor([8192 - N])
+        h.net.load_state_dict(sd)
+        x = CO.contrastive_batch(990, N, crops).view(N, 3 * crops, 32, 32)
+        loss, logits = h.run_train(x=x, y=None)
+        out.append((float(loss), logits.clone(), h.net.queue[:, -N:].clone().cpu(), h.net.queue[:, :N].clone().cpu(), h.net.queue_ptr.clone().cpu()))
+        assert int(h.net.queue_ptr) == 0 == h.net._queue_pointer()            # wrapped around the end of the queue
         res.append(out)
     for other in res[1:]:
         for step, (a, b) in enumerate(zip(res[0], other)):
