@@ -42,7 +42,8 @@ def _graphed_step(handler, forward_backward, inputs, dev):
                  and not (dist.is_available() and dist.is_initialized()) and type(handler.optimizer).__name__ == 'FlatAdam')
     if not graphable:
         return forward_backward(*inputs, dev)
-    key = tuple((tuple(t.shape), t.dtype) for t in inputs)
+    net = handler.net          # a captured step holds the addresses of the parameter buffers and of the queue: part of its key
+    key = tuple((tuple(t.shape), t.dtype) for t in inputs) + (net.flat_p.data_ptr(), net.encoder_k.flat_p.data_ptr(), net.queue.data_ptr())
     st = handler.__dict__.setdefault('_step_graphs', {}).setdefault(key, {'calls': 0})
     st['calls'] += 1
     if st['calls'] <= 2:
