@@ -135,6 +135,15 @@ class HipSRNet(nn.Module):
         self.engine = None
         self._packed_version = None
 
+    def train(self, mode=True):
+        """The handlers call net.train() / net.eval() at every step (base_architecture.py:472,503) and nn.Module.train walks every sub-module -
+        0.1-0.3 ms of host time per step here, for modules that only OWN parameters (nothing in them has a mode): walked once per change."""
+        if self.training == mode and self.__dict__.get('_mode_walked') == mode:
+            return self
+        super().train(mode)
+        self.__dict__['_mode_walked'] = mode
+        return self
+
     def attach_grads(self):
         for p, g in zip(self.param_list, self.grad_views):
             if p.requires_grad:
