@@ -80,7 +80,13 @@ class BaseModel(nn.Module):
         from rumpy_amd.parallel import GradientAverager
         self.data_parallel = GradientAverager(self.net)
         hip = self._hip_net()
-        if hip is not None and self.data_parallel.active and os.environ.get('RUMPY_DP_LATE') != '1':      # (A/B: one all-reduce after the backward pass)
+        # Early half or one all-reduce after the backward pass?  Starting the upper half's all-reduce under the remaining weight gradients costs
+        # ~75 us of split launches (two half weight-gradient launches, two reductions, one more cross-stream hop) and hides half of
+        # the transfer: it pays for the 62 MB of an RCAN (0.5 ms of xGMI time), not for the 6 MB of EDSR-baseline (60-100 us, half of it hidden
+        # = less than the split costs).  Threshold: 4 M gradient elements; RUMPY_DP_EARLY=1 / RUMPY_DP_LATE=1 force either form (A/B).
+        early = hip is not None and hip.flat_g.numel() >= (4 << 20)
+        early = (early or os.environ.get('RUMPY_DP_EARLY') == '1') and os.environ.get('RUMPY_DP_LATE') != '1'
+        if hip is not None and self.data_parallel.active and early:
             hip.grad_ready_hook = self.data_parallel.begin      # all-reduce of the upper half starts under the remaining weight gradients
         if self.data_parallel.active:
             print('Model replicated over %d GPU processes (RCCL gradient all-reduce)' % self.data_parallel.world_size)

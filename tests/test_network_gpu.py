@@ -661,17 +661,18 @@ def test_free_running_training_equals_step_synchronised_training(name, kw, N, mo
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('model', ['edsr', 'rcan'])
-def test_bench_runs_over_rccl_with_one_rank(model):
+@pytest.mark.parametrize('model,early', [('edsr', False), ('edsr', True), ('rcan', True)])
+def test_bench_runs_over_rccl_with_one_rank(model, early):
     """RCCL itself on a 1-GPU box: bench.py under torch.distributed.run with ONE rank and RUMPY_DP_FORCE=1 keeps the data-parallel path
-    on (nccl communicator bound to the device, flat broadcast, two-phase weight gradient, early all-reduce of the upper half on the side
-    stream, barrier + MAX all-reduce of the time).  A sum over one rank is the identity, so the loss must equal the plain run's."""
+    on (nccl communicator bound to the device, flat broadcast, barrier + MAX all-reduce of the time) in both of its forms: one all-reduce
+    after the backward pass (what EDSR-baseline's 6 MB get) and the two-phase weight gradient with the early all-reduce of the upper half
+    on the side stream (RCAN's 62 MB; RUMPY_DP_EARLY=1 for EDSR).  A sum over one rank is the identity, so the loss must equal the plain run's."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tail = ['--model', model, '--steps', '6', '--warmup', '2', '--probe-steps', '2', '--no-cpu-baseline']
-    env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', **({'RUMPY_DP_EARLY': '1'} if early else {}))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', '29573', os.path.join(root, 'bench.py'), '--gpus', '1'] + tail
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
@@ -682,7 +683,7 @@ def test_bench_runs_over_rccl_with_one_rank(model):
     # the plain run with the plan form of data-parallel runs (weight-gradient shares cut per gradient-buffer half: RUMPY_WGRAD_AB=1), so
     # that both runs execute the same jobs; the default one-launch plans cut all layers together (another fp32 summation order)
     q = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       timeout=600, cwd=root, env=dict(os.environ, RUMPY_WGRAD_AB='1'))
+                       timeout=600, cwd=root, env=dict(os.environ, **({'RUMPY_WGRAD_AB': '1'} if early else {})))
     assert q.returncode == 0, q.stdout.decode()[-3000:]
     e = json.loads([l for l in q.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
     assert d['n_gpus'] == 1 and d['value'] > 0
