@@ -633,3 +633,26 @@ def test_g21_q_embedding_oracle_matches_reference_handler(golden_dir):
     other.load_state_dict(O.seeded_pipeline_state(other, 2900))
     x, y = CO.joint_batch(2910, 3, 1)
     assert abs(float(O.OracleHandler(other, lr=1e-3).run_train(x[:, 0], y[:, 0])[0]) - float(g['qemb.loss0'])) > 1e-5
+
+
+@pytest.mark.parametrize('tag,name,kw', [('edsr128x3', 'edsr', dict(scale=3, num_features=128, num_blocks=2, res_scale=0.1)),
+                                         ('edsr256x2', 'edsr', dict(scale=2, num_features=256, num_blocks=1, res_scale=0.1)),
+                                         ('rcanx3', 'rcan', dict(scale=3, n_resgroups=2, n_resblocks=2, n_feats=16, reduction=4))])
+def test_g22_wide_and_x3_oracle_matches_reference_handler(golden_dir, tag, name, kw):
+    """the oracle at other widths and with PixelShuffle(3) against one training step + one evaluation of the REAL reference handlers
+    (tests/golden/make_golden_wide.py): what the GPU tests of DESIGN.md 8f.6 compare against"""
+    g = np.load(os.path.join(golden_dir, 'g22_wide_x3.npz'))
+    net = O.build_oracle(name, **kw)
+    assert sum(p.numel() for p in net.parameters()) == int(g[tag + '.params'])
+    net.load_state_dict(O.seeded_state_dict(net, 3000))
+    h = O.OracleHandler(net, lr=1e-3)
+    x, y = O.synthetic_batch(3010, 2, lr_hw=12, scale=kw['scale'])
+    loss, out = h.run_train(x, y)
+    assert abs(float(loss) - float(g[tag + '.loss'])) < 1e-6 and np.allclose(out.numpy()[:, :, ::3, ::3], g[tag + '.out'], atol=1e-6)
+    for k, p in net.named_parameters():
+        ref = float(g['%s.gnorm.%s' % (tag, k)])
+        assert abs(float(p.grad.double().norm()) - ref) <= 1e-4 * ref + 1e-10, k
+        assert np.allclose(p.grad.numpy().reshape(-1)[::211], g['%s.gsample.%s' % (tag, k)], rtol=1e-3, atol=1e-7), k
+    xe, ye = O.synthetic_batch(3020, 1, lr_hw=(10, 14), scale=kw['scale'])
+    ev, evl, _ = h.run_eval(xe, ye, request_loss=True)
+    assert np.allclose(ev.numpy()[:, :, ::3, ::3], g[tag + '.eval_out'], atol=1e-6) and abs(float(evl) - float(g[tag + '.eval_loss'])) < 1e-6
