@@ -235,7 +235,8 @@ typedef struct {
   const float* bias;
   void* out;
   int32_t* nonfinite;
-  int32_t N, H, W, F, C, pad_;
+  int32_t N, H, W, F, C;
+  int32_t fmt;            /* RUMPY_FMT_* of x (rumpy_tail_fwd_wide; evaluation plans store fp16) ; the data gradient is bf16 */
 } rumpy_tail_wide_args;
 int rumpy_tail_fwd_wide(const rumpy_tail_wide_args* a, void* stream);
 int rumpy_tail_dgrad_wide(const rumpy_tail_wide_args* a, void* stream);

@@ -102,7 +102,7 @@ class PixelShuffleArgs(_S):
 
 class TailWideArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('nonfinite', c_void_p),
-                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('F', c_int32), ('C', c_int32), ('pad_', c_int32)]
+                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('F', c_int32), ('C', c_int32), ('fmt', c_int32)]
 
 
 class WgradJob(_S):

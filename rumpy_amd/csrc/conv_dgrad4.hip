@@ -49,6 +49,7 @@ __device__ __forceinline__ void d4_dma16(const void* gsrc, unsigned lds_dst) {  
 template <int N> __device__ __forceinline__ void d4_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 
+template <int FMT>      // element format of activations and filters (RUMPY_FMT_F16: evaluation plans of the wide nets)
 __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[D4_RING];
   __shared__ unsigned landed;            // stages landed: 4 arrivals each
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (D4_ABL != 2) acc[4 * pass + r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[4 * pass + r], 0, 0, 0);
+            if (D4_ABL != 2) acc[4 * pass + r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[4 * pass + r]);
             else asm volatile("" :: "v"(I[j % (D4_RD + 1)][r + ky]), "v"(F[ch][(ky * 3 + kx) * 2 + half]));
       }
     }
@@ -180,29 +181,30 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
         }
         if (a.mask) {
           float m[4];
-          unpack4_bf16(*reinterpret_cast<const uint2*>(a.mask + e), m);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(a.mask + e), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
         }
         if (a.res1) {
           float m[4];
-          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res1 + e), m);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res1 + e), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
         if (a.res2) {
           float m[4];
-          unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + e), m);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res2 + e), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
-        *reinterpret_cast<uint2*>(a.out + e) = pack4_bf16(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>(a.out + e) = pack4<FMT>(v[0], v[1], v[2], v[3]);
       }
     }
   }
 }
 
-int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s) {
-  hipLaunchKernelGGL(conv4d_kernel, dim3(grid, d.cout_tiles), dim3(256), 0, s, d);
+int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s, int fmt) {
+  if (fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(conv4d_kernel<RUMPY_FMT_F16>, dim3(grid, d.cout_tiles), dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(conv4d_kernel<RUMPY_FMT_BF16>, dim3(grid, d.cout_tiles), dim3(256), 0, s, d);
   return 0;
 }

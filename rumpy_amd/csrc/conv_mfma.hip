@@ -17,7 +17,7 @@
 #ifndef CONV4_ABL
 #define CONV4_ABL 0     // timing experiments only (tests/tools/build_abl.sh): results are wrong for any value but 0
 #endif
-template <int CHUNKS>
+template <int CHUNKS, int FMT = RUMPY_FMT_BF16>      // FMT: element format of activations and filters (RUMPY_FMT_F16: evaluation plans)
 __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(ConvDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int r = 0; r < TH; ++r)
-              if (CONV4_ABL != 1) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F[ch][(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r], 0, 0, 0);
+              if (CONV4_ABL != 1) acc[r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r]);
               else asm volatile("" :: "v"(I[grp & 1][r + ky]));
         }
       }
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
             }
             if (a.mask) {
               float m[4];
-              unpack4_bf16(*reinterpret_cast<const uint2*>(a.mask + o), m);
+              unpack4<FMT>(*reinterpret_cast<const uint2*>(a.mask + o), m);
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] = (m[j] > 0.f) ? v[j] : 0.f;
             }
@@ -130,17 +130,17 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
             for (int j = 0; j < 4; ++j) ps[j] += v[j];
             if (a.res1) {
               float m[4];
-              unpack4_bf16(*reinterpret_cast<const uint2*>(a.res1 + o), m);
+              unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res1 + o), m);
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] += m[j];
             }
             if (a.res2) {
               float m[4];
-              unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + o), m);
+              unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res2 + o), m);
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] += m[j];
             }
-            if (CONV4_ABL != 3) *reinterpret_cast<uint2*>(a.out + o) = pack4_bf16(v[0], v[1], v[2], v[3]);
+            if (CONV4_ABL != 3) *reinterpret_cast<uint2*>(a.out + o) = pack4<FMT>(v[0], v[1], v[2], v[3]);
           }
         }
         if (a.pool) {
@@ -466,15 +466,15 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s);   // conv_strip.hip
 int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s);          // conv_up.hip
 
-int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s);      // conv_dgrad4.hip
+int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s, int fmt);      // conv_dgrad4.hip
 extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->out) { rumpy_set_error("rumpy_conv3x3: null pointer"); return RUMPY_E_ARG; }
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cout_tiles <= 0) { rumpy_set_error("rumpy_conv3x3: bad shape"); return RUMPY_E_ARG; }
   if (p->cin_chunks < 1 || p->cin_chunks > 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 .. 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
   if (p->in_mode == 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: in_mode 1 needs cin_chunks 4"); return RUMPY_E_ARG; }
   if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || p->res1 || p->res2)) { rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4 and no mask/residual"); return RUMPY_E_ARG; }
-  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && p->cin_chunks == 1 && !p->mask)) {
-    rumpy_set_error("rumpy_conv3x3: fmt %d needs cin_chunks 1 and no mask (forward launches of an evaluation plan)", p->fmt); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !p->mask && p->in_mode == 0)) {
+    rumpy_set_error("rumpy_conv3x3: fmt %d needs a plain input and no mask (forward launches of an evaluation plan)", p->fmt); return RUMPY_E_ARG; }
   // Cin = 256 (upsampler data gradients): the 8x16-tile kernel below measures faster than the 4-chunk strip build
   // (which spills at 256 VGPRs); RUMPY_CONV4_STRIP=1 selects the strip build for A/B runs.
   static const bool strip4 = getenv("RUMPY_CONV4_STRIP") != nullptr;
@@ -527,7 +527,11 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     // workgroups that read the same input tiles share an XCD, i.e. an L2 (PMC: 118 MB fetched per 256 -> 256 launch at 16 x 48 x 48 with
     // g2 = 58, four times the input; profiles/r02_pmc_wide.md)
     if (p->grid_x <= 0 && p->cout_tiles > 1 && g2 >= 8) g2 = ((g2 + 7) & ~7) <= rumpy_device_cus() / p->cout_tiles ? ((g2 + 7) & ~7) : (g2 & ~7);
-    rumpy_conv4d_launch(d, g2, s);
+    rumpy_conv4d_launch(d, g2, s, p->fmt);
+  } else if (p->fmt == RUMPY_FMT_F16) {      // evaluation plans of the wide nets
+    if (p->cin_chunks == 4) hipLaunchKernelGGL((conv3x3_kernel<4, RUMPY_FMT_F16>), grid, dim3(256), 0, s, d);
+    else if (p->cin_chunks == 3) hipLaunchKernelGGL((conv3x3_kernel<3, RUMPY_FMT_F16>), grid, dim3(256), 0, s, d);
+    else hipLaunchKernelGGL((conv3x3_kernel<2, RUMPY_FMT_F16>), grid, dim3(256), 0, s, d);
   } else if (p->cin_chunks == 4)
   hipLaunchKernelGGL(conv3x3_kernel<4>, grid, dim3(256), 0, s, d);
   else if (p->cin_chunks == 3) hipLaunchKernelGGL(conv3x3_kernel<3>, grid, dim3(256), 0, s, d);      // 192 / 128 features (EDSR widths between the

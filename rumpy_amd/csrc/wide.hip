@@ -78,6 +78,7 @@ extern "C" int rumpy_pixel_shuffle(const rumpy_pixel_shuffle_args* p, void* stre
 // LDS as [tap][ci][4] floats (one 16-byte broadcast read per (tap, ci): the C <= 4 output channels together); the four slices' partial sums
 // meet in LDS in a fixed order.  out: fp32 NCHW, like the 64-feature tail kernel writes it.
 constexpr int TW_MAXF = 512;
+template <int FMT>      // element format of x (RUMPY_FMT_F16: evaluation plans)
 __global__ void __launch_bounds__(256) tail_fwd_wide_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                             float* __restrict__ out, int N, int H, int W, int F, int C, int* __restrict__ nonfinite) {
   extern __shared__ float4 swide[];                       // [9 * F] float4 filter, then [4][64] float4 partial sums
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(256) tail_fwd_wide_kernel(const uint16_t* __re
         for (int c8 = 0; c8 < cs / 8; ++c8) {
           const uint4 v = xp[c8];
           float f[8];
-          { float lo[4], hi[4]; unpack4_bf16(make_uint2(v.x, v.y), lo); unpack4_bf16(make_uint2(v.z, v.w), hi);
+          { float lo[4], hi[4]; unpack4<FMT>(make_uint2(v.x, v.y), lo); unpack4<FMT>(make_uint2(v.z, v.w), hi);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; } }
 #pragma unroll
@@ -198,10 +199,17 @@ extern "C" int rumpy_tail_fwd_wide(const rumpy_tail_wide_args* p, void* stream) 
   if (!tail_wide_ok(p, "rumpy_tail_fwd_wide")) return RUMPY_E_ARG;
   if (!p->bias) { rumpy_set_error("rumpy_tail_fwd_wide: null bias"); return RUMPY_E_ARG; }
   const size_t lds = ((size_t)9 * p->F + 256) * sizeof(float4);
-  if (!wide_lds(tail_fwd_wide_kernel, lds)) { rumpy_set_error("rumpy_tail_fwd_wide: cannot reserve %zu bytes of LDS", lds); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("rumpy_tail_fwd_wide: unknown fmt %d", p->fmt); return RUMPY_E_ARG; }
+  if (!wide_lds(tail_fwd_wide_kernel<RUMPY_FMT_BF16>, lds) || !wide_lds(tail_fwd_wide_kernel<RUMPY_FMT_F16>, lds)) {
+    rumpy_set_error("rumpy_tail_fwd_wide: cannot reserve %zu bytes of LDS", lds); return RUMPY_E_ARG; }
   const int segs = (p->W + 63) / 64;
-  hipLaunchKernelGGL(tail_fwd_wide_kernel, dim3((unsigned)((size_t)p->N * p->H * segs)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)p->x,
-                     p->w, p->bias, (float*)p->out, p->N, p->H, p->W, p->F, p->C, p->nonfinite);
+  const dim3 grid((unsigned)((size_t)p->N * p->H * segs));
+  if (p->fmt == RUMPY_FMT_F16)
+    hipLaunchKernelGGL(tail_fwd_wide_kernel<RUMPY_FMT_F16>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)p->x, p->w, p->bias, (float*)p->out,
+                       p->N, p->H, p->W, p->F, p->C, p->nonfinite);
+  else
+    hipLaunchKernelGGL(tail_fwd_wide_kernel<RUMPY_FMT_BF16>, grid, dim3(256), lds, (hipStream_t)stream, (const uint16_t*)p->x, p->w, p->bias, (float*)p->out,
+                       p->N, p->H, p->W, p->F, p->C, p->nonfinite);
   return rumpy_check_launch("rumpy_tail_fwd_wide");
 }
 

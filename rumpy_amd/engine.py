@@ -178,8 +178,6 @@ class SREngine:
                 raise RuntimeError('rumpy_amd: upsampler conv %s %d->%d is neither a x2 nor a x3 stage' % (cv.name, cv.cin, cv.cout))
             if self.generic_up:
                 cv.shuffle = False          # natural channel order; the permutation is its own pass
-        if self.wide:
-            self.eval_fmt = L.FMT_BF16      # the multi-chunk conv kernel is bf16 only
         self._alloc_packed()
         self.packed_version = None
 
@@ -271,7 +269,7 @@ class SREngine:
         """fp16 forward images of every MFMA conv (evaluation plans only: no data-gradient image, the packed biases are shared)"""
         items = []
         for cv in self.spec.convs():
-            if cv.kind == 'head':
+            if cv.kind == 'head' or (cv.kind == 'tail' and self.wide):      # (a wide net's tail reads its fp32 master filter)
                 continue
             kind = 0 if cv.kind == 'main' else 2
             cv.w_fwd_h = torch.empty(cv.cout * cv.cin * 9 if kind == 0 else 18 * 64 * 8, dtype=torch.float16, device=self.device)
@@ -540,7 +538,7 @@ class SREngine:
         if self.wide:
             # F -> 3 on the fp32 VALU from the master filter; no fused L1 form (the handlers take the generic loss path for wide nets)
             plan.tail_wide = L.TailWideArgs(x=_ptr(u), w=_ptr(spec.tail.weight), bias=_ptr(spec.tail.bias), out=_ptr(plan.out),
-                                            nonfinite=_ptr(plan.nonfinite), N=N, H=h, W=w, F=F, C=Cout)
+                                            nonfinite=_ptr(plan.nonfinite), N=N, H=h, W=w, F=F, C=Cout, fmt=fmt)
             plan.tail_plain = plan.tail_loss = None
             plan.tail_slabs, plan.tail_wslab = 0, None
         else:

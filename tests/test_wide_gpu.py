@@ -124,3 +124,43 @@ def test_shipped_edsr_config_builds_with_the_reference_parameter_count(golden_di
     assert out.shape == (4, 3, 192, 192) and np.isfinite(float(loss)) and torch.isfinite(out).all()
     loss2, _ = h.run_train(x=x, y=y, keep_on_device=True)
     assert float(loss2) < float(loss)                   # the same batch again: the step went downhill
+
+
+@pytest.mark.parametrize('feats,blocks', [(256, 32), (128, 8)])
+def test_wide_eval_psnr_within_0p02_db_in_the_trained_regime(golden_dir, feats, blocks):
+    """the evaluation bound of DESIGN.md 2.1 for the wide nets: a >= 30 dB EDSR at 256 features x 32 blocks (the shipped configuration) / 128 x 8,
+    weights from oracle.interpolating_state_dict, the Set5 crop of fixture G17, through SISRInterface.net_run_and_process: Y-PSNR within
+    0.02 dB of the fp32 oracle's and forward self-PSNR >= its PSNR + 23.4 dB - with the fp16 evaluation plans the multi-chunk conv kernels
+    and the wide tail kernel now have (bf16 plans, RUMPY_EVAL_BF16=1, are shown beside them)."""
+    from rumpy_amd.SISR.models.interface import SISRInterface
+    g = np.load(os.path.join(golden_dir, 'g17_edsr_psnr.npz'))
+    to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
+    lr_t, hr_t = to_t(g['lr']), to_t(g['hr'])
+    kw = dict(scale=4, num_features=feats, num_blocks=blocks, res_scale=0.1)
+    onet = O.build_oracle('edsr', **kw)
+    sd = O.interpolating_state_dict(onet, 503)
+    onet.load_state_dict(sd)
+    oout, _, _ = O.OracleHandler(onet, eval_mode=True).run_eval(lr_t)
+    hr_y = O.clip01(hr_t.numpy())
+    hr_y[0] = O.rgb_to_ycbcr_jpg(hr_y[0])
+    oy = O.clip01(oout.numpy())
+    oy[0] = O.rgb_to_ycbcr_jpg(oy[0])
+    ref = O.y_psnr(oy, hr_y)
+    assert ref >= 30.0
+    itf = SISRInterface(tempfile.mkdtemp(), 'exp', gpu='single', sp_gpu=0, mode='eval', scale=4, new_params={'name': 'edsr', 'internal_params': kw})
+    itf.model.net.load_state_dict(sd)
+    rgb, ycbcr, _, _ = itf.net_run_and_process(lr=lr_t, hr=hr_t, request_loss=True)
+    ps = O.y_psnr(ycbcr, hr_y)
+    out, _, _ = itf.model.run_eval(x=lr_t)
+    sp = self_psnr(out, oout)
+    os.environ['RUMPY_EVAL_BF16'] = '1'
+    try:
+        hb = define_model('edsr', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, checkpoint_load=False, loss_masking=False, **kw)
+        hb.net.load_state_dict(sd)
+        sp_bf16 = self_psnr(hb.run_eval(x=lr_t)[0], oout)
+    finally:
+        del os.environ['RUMPY_EVAL_BF16']
+    print('EDSR %d x %d: Y-PSNR hip %.4f vs oracle %.4f (delta %+.4f dB); forward self-PSNR fp16 plans %.2f dB (needs >= %.2f), bf16 plans %.2f dB'
+          % (feats, blocks, ps, ref, ps - ref, sp, ref + 23.4, sp_bf16))
+    assert itf.model.net.engine.eval_fmt == 1 and hb.net.engine.eval_fmt == 0
+    assert abs(ps - ref) <= 0.02 and sp >= ref + 23.4 and sp >= sp_bf16 + 8.0
