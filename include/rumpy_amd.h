@@ -288,7 +288,8 @@ typedef struct {
   const float* w;      /* [Cout,Cin,3,3] */
   const float* b;      /* [Cout] */
   void* w_fwd;         /* kind 0: Cout*Cin*9 elements (format `fmt`) in MFMA A-fragment order [cout_tile][cin_chunk][co quarter 4][s = tap*2 +
-                          ci half, 18][lane 64][8] ; kind 2: [18][64][8] */
+                          ci half, 18][lane 64][8] ; kind 2: [18][64][8] - with fmt RUMPY_FMT_F16 TWICE that: the fp16 filter image, then the image of
+                          its rounding residual w - fp16(w) (evaluation plans: rumpy_tail_fwd multiplies both) */
   void* w_dgrad;       /* kind 0: same for the transposed, flipped filter ; kind 2: [4][2][64][8] ; may be NULL */
   float* b_packed;     /* kind 0: [Cout] in packed channel order ; else NULL */
   int32_t cout, cin;

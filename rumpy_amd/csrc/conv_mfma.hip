@@ -205,6 +205,15 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   bf16x8 F[18];
 #pragma unroll
   for (int s = 0; s < 18; ++s) F[s] = as_bf16x8(a.w[s * 64 + lane]);
+  // fp16 evaluation plans: the filter as TWO fp16 images, the rounded filter and its rounding residual (rumpy_pack_weights, kind 2, fmt F16),
+  // multiplied one after the other into the same accumulators.  This layer's weights shape the image itself: their fp16 rounding is a fixed
+  // perturbation of the output, CORRELATED with the model's own error - it moved the Y-PSNR of 32 dB EDSRs by up to -0.034 dB (the other
+  // layers' weight rounding: +0.006; all activation rounding together: 0.002; tests/tools/psnr_seeds.py).  HBM-bound kernel: free.
+  bf16x8 Flo[FMT == RUMPY_FMT_F16 ? 18 : 1];
+  if (FMT == RUMPY_FMT_F16) {
+#pragma unroll
+    for (int s = 0; s < 18; ++s) Flo[s % (FMT == RUMPY_FMT_F16 ? 18 : 1)] = as_bf16x8(a.w[(18 + s) * 64 + lane]);
+  }
   float bj[4] = {0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < a.C; ++j) bj[j] = a.bias[j];
   float lsum = 0.f;
@@ -270,8 +279,10 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
+          for (int r = 0; r < 2; ++r) {
             acc[r] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r]);
+            if (FMT == RUMPY_FMT_F16) acc[r] = mfma16<FMT>(Flo[((ky * 3 + kx) * 2 + half) % (FMT == RUMPY_FMT_F16 ? 18 : 1)], I[r + ky], acc[r]);
+          }
       }
     // all target values are consumed BEFORE the first store: with loads and stores pending together the compiler's
     // s_waitcnt bookkeeping (gfx9: one vmcnt, loads and stores may retire out of order) falls back to draining everything

@@ -110,7 +110,13 @@ __device__ __forceinline__ void pack_item(const rumpy_pack_item& it) {
       const int r = lane & 15, g = lane >> 4;
       const int half = s & 1, tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
       const int ci = 32 * half + 8 * g + e;
-      wf[i] = (r < Co) ? pack1<FMT>(it.w[((size_t)r * Ci + ci) * 9 + ky * 3 + kx]) : (uint16_t)0;
+      const float wv = (r < Co) ? it.w[((size_t)r * Ci + ci) * 9 + ky * 3 + kx] : 0.f;
+      wf[i] = (r < Co) ? pack1<FMT>(wv) : (uint16_t)0;
+      if (FMT == RUMPY_FMT_F16) {          // second image behind the first: the rounding residual w - fp16(w), itself in fp16 (tail_fwd_kernel)
+        float back[4];
+        unpack4<FMT>(make_uint2((uint32_t)wf[i], 0u), back);
+        wf[18 * 64 * 8 + i] = (r < Co) ? pack1<FMT>(wv - back[0]) : (uint16_t)0;
+      }
     }
     if (wd) {
       for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 4 * 2 * 64 * 8; i += gridDim.x * blockDim.x) {

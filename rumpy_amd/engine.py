@@ -272,7 +272,7 @@ class SREngine:
             if cv.kind == 'head' or (cv.kind == 'tail' and self.wide):      # (a wide net's tail reads its fp32 master filter)
                 continue
             kind = 0 if cv.kind == 'main' else 2
-            cv.w_fwd_h = torch.empty(cv.cout * cv.cin * 9 if kind == 0 else 18 * 64 * 8, dtype=torch.float16, device=self.device)
+            cv.w_fwd_h = torch.empty(cv.cout * cv.cin * 9 if kind == 0 else 2 * 18 * 64 * 8, dtype=torch.float16, device=self.device)      # tail: filter + residual image
             items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd_h), w_dgrad=None, b_packed=None, cout=cv.cout,
                                     cin=cv.cin, kind=kind, shuffle=1 if (kind == 0 and cv.shuffle) else 0, fmt=L.FMT_F16))
         self._pack_items_h_host = (L.PackItem * len(items))(*items)

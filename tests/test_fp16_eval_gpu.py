@@ -40,7 +40,7 @@ class Packed16:
     def __init__(self, w, b, kind=0, shuffle=False):
         self.w, self.b = w.float().contiguous().to(DEV), b.float().contiguous().to(DEV)
         self.cout, self.cin = w.shape[0], w.shape[1]
-        self.w_fwd = torch.zeros(self.cout * self.cin * 9 if kind == 0 else 18 * 64 * 8, dtype=F16, device=DEV)
+        self.w_fwd = torch.zeros(self.cout * self.cin * 9 if kind == 0 else 2 * 18 * 64 * 8, dtype=F16, device=DEV)       # tail: filter + rounding-residual image
         self.b_packed = torch.zeros(self.cout, dtype=torch.float32, device=DEV) if kind == 0 else None
         it = L.PackItem(w=self.w.data_ptr(), b=self.b.data_ptr(), w_fwd=self.w_fwd.data_ptr(), w_dgrad=None,
                         b_packed=self.b_packed.data_ptr() if kind == 0 else None, cout=self.cout, cin=self.cin, kind=kind,
@@ -131,8 +131,10 @@ def test_fp16_upsampler_conv_pixel_shuffle_and_head_and_tail():
                       loss=loss.data_ptr(), N=N, C=3, H=H, W=W, nonfinite=flag.data_ptr(), fmt=L.FMT_F16)
     L.call('rumpy_tail_fwd', a, stream())
     torch.cuda.synchronize()
-    ref = F.conv2d(f16r(x), f16r(tw), tb, padding=1)
-    assert rel_err(res.cpu(), ref) < 1e-5 and int(flag.item()) == 0
+    # the filter enters as fp16 image + fp16 image of its rounding residual: 22 significant bits - the reference is the UNROUNDED filter
+    ref = F.conv2d(f16r(x).double(), tw.double(), tb.double(), padding=1).float()
+    assert rel_err(res.cpu(), ref) < 2e-6 and int(flag.item()) == 0
+    assert rel_err(res.cpu(), F.conv2d(f16r(x), f16r(tw), tb, padding=1)) > 1e-4          # and visibly not the fp16-rounded one
     assert abs(float(loss.item()) - float((res - y).abs().mean())) < 1e-6
     xd[1, 3, 5, 7] = float('inf')
     L.call('rumpy_tail_fwd', a, stream())

@@ -808,3 +808,32 @@ def test_training_trajectory_follows_the_oracle_on_a_learnable_task(name, kw):
         first = float(l) if first is None else first
         last = float(l)
     assert last < first / 3
+
+
+@pytest.mark.parametrize('model,seeds,bound', [('edsr', (601, 602, 603, 604), 0.012), ('rcan', (601, 603), 0.016)])
+def test_eval_psnr_bound_over_other_seeded_models(golden_dir, model, seeds, bound):
+    """the +-0.02 dB evaluation bound beyond the two fixtures: other >= 30 dB models (oracle.interpolating_state_dict, other seeds) on the
+    Set5 crop of G17 against the fp32 oracle evaluated here.  Seeds 601 / 602 were -0.027 / -0.020 dB for EDSR until the tail conv's filter
+    entered the fp16 evaluation plans as image + rounding-residual image (tail_fwd_kernel): the last layer's weight rounding is a fixed,
+    error-correlated perturbation of the image (CPU simulation: -0.034 dB from it alone, +0.006 from all other weights, 0.002 from every
+    activation rounding together).  Measured after: EDSR +0.007 / -0.001 / -0.000 / -0.001, RCAN +0.005 / -0.012."""
+    g = np.load(os.path.join(golden_dir, 'g17_edsr_psnr.npz'))
+    to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
+    lr_t, hr_t = to_t(g['lr']), to_t(g['hr'])
+    hr_y = O.clip01(hr_t.numpy())
+    hr_y[0] = O.rgb_to_ycbcr_jpg(hr_y[0])
+    itf = SISRInterface(tempfile.mkdtemp(), 'exp', gpu='single', sp_gpu=0, mode='eval', scale=4, new_params={'name': model, 'internal_params': {'scale': 4}})
+    for seed in seeds:
+        onet = O.build_oracle(model, scale=4)
+        sd = O.interpolating_state_dict(onet, seed)
+        onet.load_state_dict(sd)
+        oout, _, _ = O.OracleHandler(onet, eval_mode=True).run_eval(lr_t)
+        oy = O.clip01(oout.numpy())
+        oy[0] = O.rgb_to_ycbcr_jpg(oy[0])
+        ref = O.y_psnr(oy, hr_y)
+        itf.model.net.load_state_dict(sd)
+        _, ycbcr, _, _ = itf.net_run_and_process(lr=lr_t, hr=hr_t)
+        ps = O.y_psnr(ycbcr, hr_y)
+        print('%s seed %d: oracle %.4f dB, hip %.4f dB, delta %+.4f dB' % (model, seed, ref, ps, ps - ref))
+        assert ref >= 30.0 and abs(ps - ref) <= bound, (seed, ps - ref)
+    assert itf.model.net.engine.eval_fmt == 1

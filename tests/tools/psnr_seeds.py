@@ -1,0 +1,33 @@
+"""Evaluation Y-PSNR of the HIP path against the fp32 oracle for several seeded >= 30 dB models (oracle.interpolating_state_dict) on the Set5 crop
+of fixture G17: how much room the +-0.02 dB bound has beyond the two fixtures.   python tests/tools/psnr_seeds.py edsr|rcan [seeds...]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import sr_oracle as O  # noqa: E402
+from rumpy_amd.SISR.models.interface import SISRInterface  # noqa: E402
+
+model = sys.argv[1] if len(sys.argv) > 1 else 'edsr'
+seeds = [int(a) for a in sys.argv[2:]] or [601, 602, 603, 604]
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'golden', 'g17_edsr_psnr.npz'))
+to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
+lr_t, hr_t = to_t(g['lr']), to_t(g['hr'])
+hr_y = O.clip01(hr_t.numpy())
+hr_y[0] = O.rgb_to_ycbcr_jpg(hr_y[0])
+itf = SISRInterface(tempfile.mkdtemp(), 'exp', gpu='single', sp_gpu=0, mode='eval', scale=4, new_params={'name': model, 'internal_params': {'scale': 4}})
+for seed in seeds:
+    onet = O.build_oracle(model, scale=4)
+    sd = O.interpolating_state_dict(onet, seed)
+    onet.load_state_dict(sd)
+    oout, _, _ = O.OracleHandler(onet, eval_mode=True).run_eval(lr_t)
+    oy = O.clip01(oout.numpy())
+    oy[0] = O.rgb_to_ycbcr_jpg(oy[0])
+    ref = O.y_psnr(oy, hr_y)
+    itf.model.net.load_state_dict(sd)
+    _, ycbcr, _, _ = itf.net_run_and_process(lr=lr_t, hr=hr_t)
+    ps = O.y_psnr(ycbcr, hr_y)
+    print('%s seed %d: oracle %.4f dB, hip %.4f dB, delta %+.4f dB' % (model, seed, ref, ps, ps - ref))
