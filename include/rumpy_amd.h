@@ -32,6 +32,7 @@ extern "C" {
  * what keeps the evaluation PSNR of a trained network within +-0.02 dB of the fp32 reference. */
 #define RUMPY_FMT_BF16 0
 #define RUMPY_FMT_F16 1
+#define RUMPY_FMT_F16_RESIDUAL 2   /* rumpy_pack_weights, kind 0 only: the fp16 image of w - fp16(w), the rounding residual of the RUMPY_FMT_F16 image */
 
 #define RUMPY_TILE_H 8
 #define RUMPY_TILE_W 16

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('RUMPY_AMD_LIB') or os.path.join(_HERE, 'librumpy_amd.
 c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 TILE_H, TILE_W = 8, 16
-FMT_BF16, FMT_F16 = 0, 1          # include/rumpy_amd.h RUMPY_FMT_*
+FMT_BF16, FMT_F16, FMT_F16_RESIDUAL = 0, 1, 2          # include/rumpy_amd.h RUMPY_FMT_*
 
 
 class _S(C.Structure):

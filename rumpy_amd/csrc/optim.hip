@@ -62,6 +62,13 @@ __global__ void sum_final_kernel(const float* __restrict__ partial, int n, float
 // kind 2 (tail, Cout <= 4, Cin = 64): forward image [s][lane][8]: row r < Cout real, zero otherwise;
 //   dgrad image [wave][ks][lane][8]: row ci = 16*wave + r, k = 32*ks + 8g + e -> tap = k>>2, c = k&3: W[c][ci][2-ky][2-kx]
 template <int FMT> __device__ __forceinline__ uint16_t pack1(float f) { return (uint16_t)(pack2<FMT>(f, 0.f) & 0xffffu); }
+// PFMT = RUMPY_FMT_F16_RESIDUAL: what fp16 drops of the value, itself as fp16 (the second image of a filter whose rounding must not show:
+// evaluation plans run the conv on the fp16 image and add the conv on this one)
+__device__ __forceinline__ float f16_residual(float v) { return v - (float)(_Float16)v; }
+template <int PFMT> __device__ __forceinline__ uint2 pk4(float a, float b, float c, float d) {
+  if (PFMT == RUMPY_FMT_F16_RESIDUAL) return pack4<RUMPY_FMT_F16>(f16_residual(a), f16_residual(b), f16_residual(c), f16_residual(d));
+  return pack4 < PFMT == RUMPY_FMT_F16_RESIDUAL ? RUMPY_FMT_F16 : PFMT > (a, b, c, d);
+}
 template <int FMT>
 __device__ __forceinline__ void pack_item(const rumpy_pack_item& it) {
   uint16_t* wf = (uint16_t*)it.w_fwd;
@@ -82,7 +89,7 @@ __device__ __forceinline__ void pack_item(const rumpy_pack_item& it) {
         const int c = 16 * wave + r;
         const int co = it.shuffle ? 4 * c + ct : 64 * ct + c;
         const float* src = it.w + ((size_t)co * Ci + 64 * ch + 32 * half + 8 * g) * 9 + ky * 3 + kx;
-        const uint2 lo = pack4<FMT>(src[0], src[9], src[18], src[27]), hi = pack4<FMT>(src[36], src[45], src[54], src[63]);
+        const uint2 lo = pk4<FMT>(src[0], src[9], src[18], src[27]), hi = pk4<FMT>(src[36], src[45], src[54], src[63]);
         reinterpret_cast<uint4*>(wf)[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
       if (wd) {  // dgrad: r2 = ct'*ctn + ch'; the 8 elements are 8 output channels (stride Ci*9, or 4*Ci*9 when shuffled)
@@ -92,8 +99,8 @@ __device__ __forceinline__ void pack_item(const rumpy_pack_item& it) {
         const size_t co0 = it.shuffle ? (size_t)4 * cc0 + chp : (size_t)64 * chp + cc0;
         const size_t cstep = (size_t)(it.shuffle ? 4 : 1) * Ci * 9;
         const float* src = it.w + (co0 * Ci + ci) * 9 + (2 - ky) * 3 + (2 - kx);
-        const uint2 lo = pack4<FMT>(src[0], src[cstep], src[2 * cstep], src[3 * cstep]);
-        const uint2 hi = pack4<FMT>(src[4 * cstep], src[5 * cstep], src[6 * cstep], src[7 * cstep]);
+        const uint2 lo = pk4<FMT>(src[0], src[cstep], src[2 * cstep], src[3 * cstep]);
+        const uint2 hi = pk4<FMT>(src[4 * cstep], src[5 * cstep], src[6 * cstep], src[7 * cstep]);
         reinterpret_cast<uint4*>(wd)[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
@@ -136,6 +143,7 @@ __device__ __forceinline__ void pack_item(const rumpy_pack_item& it) {
 __global__ void pack_kernel(const rumpy_pack_item* __restrict__ items) {
   const rumpy_pack_item it = items[blockIdx.y];
   if (it.fmt == RUMPY_FMT_F16) pack_item<RUMPY_FMT_F16>(it);
+  else if (it.fmt == RUMPY_FMT_F16_RESIDUAL) pack_item<RUMPY_FMT_F16_RESIDUAL>(it);
   else pack_item<RUMPY_FMT_BF16>(it);
 }
 

@@ -275,15 +275,22 @@ class SREngine:
             cv.w_fwd_h = torch.empty(cv.cout * cv.cin * 9 if kind == 0 else 2 * 18 * 64 * 8, dtype=torch.float16, device=self.device)      # tail: filter + residual image
             items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd_h), w_dgrad=None, b_packed=None, cout=cv.cout,
                                     cin=cv.cin, kind=kind, shuffle=1 if (kind == 0 and cv.shuffle) else 0, fmt=L.FMT_F16))
+            if self.generic_up and any(cv is u for u in self.spec.ups):
+                # the upsampler filters of the wide nets also enter evaluation as image + rounding-residual image (a second conv launch adds
+                # the residual's contribution): their fp16 rounding alone moved a 32 dB EDSR 256 x 32 by -0.022 dB
+                cv.w_fwd_h_lo = torch.empty(cv.cout * cv.cin * 9, dtype=torch.float16, device=self.device)
+                items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd_h_lo), w_dgrad=None, b_packed=None, cout=cv.cout,
+                                        cin=cv.cin, kind=0, shuffle=0, fmt=L.FMT_F16_RESIDUAL))
         self._pack_items_h_host = (L.PackItem * len(items))(*items)
         self._pack_items_h = self._to_device_bytes(self._pack_items_h_host)
+        self._n_pack_h = len(items)
 
     def _repack_h(self, stream):
         """bring the fp16 images up to date with the master weights (no-op when nothing was re-packed since)"""
         if self._pack_items_h is None:
             self._alloc_packed_h()
         if self.h_gen != self.pack_gen:
-            L.check(self.lib.rumpy_pack_weights(_ptr(self._pack_items_h), self._n_pack, stream), 'rumpy_pack_weights')
+            L.check(self.lib.rumpy_pack_weights(_ptr(self._pack_items_h), self._n_pack_h, stream), 'rumpy_pack_weights')
             self.h_gen = self.pack_gen
 
     # ------------------------------------------------------------------ plan construction
@@ -519,7 +526,16 @@ class SREngine:
             nxt = self._new(plan, N, rr * h, rr * w, F)
             if self.generic_up:
                 pre = self._new(plan, N, h, w, cv.cout)          # natural channel order, then the PixelShuffle permutation as its own pass
-                self._conv(fwd, u, cv, N, h, w, pre, fmt=fmt)
+                if fmt:
+                    # fp16 evaluation plan: conv(x, w - fp16(w)) FIRST (the filter's rounding residual, _alloc_packed_h: small values, stored with
+                    # their own exponent), then the conv on the fp16 filter adds it in fp32 before the one rounding of the result - the other
+                    # order loses the correction in the second rounding (it is a quarter of an fp16 step of the result)
+                    fwd.append(('rumpy_conv3x3', L.ConvArgs(x=_ptr(u), w=_ptr(cv.w_fwd_h_lo), bias=None, out=_ptr(pre), mask=None, res1=None,
+                                                            res2=None, pool=None, N=N, H=h, W=w, cin_chunks=cv.cin // 64, cout_tiles=cv.cout // 64,
+                                                            in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0, fmt=fmt)))
+                    self._conv(fwd, u, cv, N, h, w, pre, res1=pre, fmt=fmt)
+                else:
+                    self._conv(fwd, u, cv, N, h, w, pre, fmt=fmt)
                 fwd.append(('rumpy_pixel_shuffle', L.PixelShuffleArgs(src=_ptr(pre), dst=_ptr(nxt), N=N, H=h, W=w, F=F, r=rr, inverse=0)))
             else:
                 self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1, fmt=fmt)

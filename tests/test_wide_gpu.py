@@ -130,8 +130,8 @@ def test_shipped_edsr_config_builds_with_the_reference_parameter_count(golden_di
 def test_wide_eval_psnr_within_0p02_db_in_the_trained_regime(golden_dir, feats, blocks):
     """the evaluation bound of DESIGN.md 2.1 for the wide nets: a >= 30 dB EDSR at 256 features x 32 blocks (the shipped configuration) / 128 x 8,
     weights from oracle.interpolating_state_dict, the Set5 crop of fixture G17, through SISRInterface.net_run_and_process: Y-PSNR within
-    0.02 dB of the fp32 oracle's and forward self-PSNR >= its PSNR + 23.4 dB - with the fp16 evaluation plans the multi-chunk conv kernels
-    and the wide tail kernel now have (bf16 plans, RUMPY_EVAL_BF16=1, are shown beside them)."""
+    0.006 dB of the fp32 oracle's (measured 0.001) and forward self-PSNR >= its PSNR + 23.4 dB - with the fp16 evaluation plans the multi-chunk
+    conv kernels and the wide tail kernel now have (bf16 plans, RUMPY_EVAL_BF16=1, are shown beside them)."""
     from rumpy_amd.SISR.models.interface import SISRInterface
     g = np.load(os.path.join(golden_dir, 'g17_edsr_psnr.npz'))
     to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
@@ -163,4 +163,15 @@ def test_wide_eval_psnr_within_0p02_db_in_the_trained_regime(golden_dir, feats, 
     print('EDSR %d x %d: Y-PSNR hip %.4f vs oracle %.4f (delta %+.4f dB); forward self-PSNR fp16 plans %.2f dB (needs >= %.2f), bf16 plans %.2f dB'
           % (feats, blocks, ps, ref, ps - ref, sp, ref + 23.4, sp_bf16))
     assert itf.model.net.engine.eval_fmt == 1 and hb.net.engine.eval_fmt == 0
-    assert abs(ps - ref) <= 0.02 and sp >= ref + 23.4 and sp >= sp_bf16 + 8.0
+    assert abs(ps - ref) <= 0.006 and sp >= ref + 23.4 and sp >= sp_bf16 + 8.0
+    # other seeded models.  Seed 602 was -0.023 dB at 256 features (seed 503 above: +0.017) until the upsampler filters entered evaluation as
+    # image + rounding-residual image, the residual's conv FIRST and the main conv adding it in fp32 (the other order loses it: -0.016)
+    for seed in (602, 605):
+        sd2 = O.interpolating_state_dict(onet, seed)
+        onet.load_state_dict(sd2)
+        o2 = O.clip01(O.OracleHandler(onet, eval_mode=True).run_eval(lr_t)[0].numpy())
+        o2[0] = O.rgb_to_ycbcr_jpg(o2[0])
+        itf.model.net.load_state_dict(sd2)
+        d2 = O.y_psnr(itf.net_run_and_process(lr=lr_t, hr=hr_t)[1], hr_y) - O.y_psnr(o2, hr_y)
+        print('  seed %d: delta %+.4f dB' % (seed, d2))
+        assert abs(d2) <= 0.006, (seed, d2)

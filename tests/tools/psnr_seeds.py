@@ -1,5 +1,5 @@
 """Evaluation Y-PSNR of the HIP path against the fp32 oracle for several seeded >= 30 dB models (oracle.interpolating_state_dict) on the Set5 crop
-of fixture G17: how much room the +-0.02 dB bound has beyond the two fixtures.   python tests/tools/psnr_seeds.py edsr|rcan [seeds...]"""
+of fixture G17: how much room the +-0.02 dB bound has beyond the two fixtures.   python tests/tools/psnr_seeds.py edsr|rcan|edsr256|edsr128 [seeds...]"""
 import os
 import sys
 import tempfile
@@ -12,15 +12,17 @@ from oracle import sr_oracle as O  # noqa: E402
 from rumpy_amd.SISR.models.interface import SISRInterface  # noqa: E402
 
 model = sys.argv[1] if len(sys.argv) > 1 else 'edsr'
+KW = {'edsr256': dict(num_features=256, num_blocks=32, res_scale=0.1), 'edsr128': dict(num_features=128, num_blocks=16, res_scale=0.1)}.get(model, {})
+model = 'edsr' if model.startswith('edsr') else model
 seeds = [int(a) for a in sys.argv[2:]] or [601, 602, 603, 604]
 g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'golden', 'g17_edsr_psnr.npz'))
 to_t = lambda a: torch.from_numpy(a.transpose(2, 0, 1).astype(np.float32) / 255.).unsqueeze(0)
 lr_t, hr_t = to_t(g['lr']), to_t(g['hr'])
 hr_y = O.clip01(hr_t.numpy())
 hr_y[0] = O.rgb_to_ycbcr_jpg(hr_y[0])
-itf = SISRInterface(tempfile.mkdtemp(), 'exp', gpu='single', sp_gpu=0, mode='eval', scale=4, new_params={'name': model, 'internal_params': {'scale': 4}})
+itf = SISRInterface(tempfile.mkdtemp(), 'exp', gpu='single', sp_gpu=0, mode='eval', scale=4, new_params={'name': model, 'internal_params': dict(scale=4, **KW)})
 for seed in seeds:
-    onet = O.build_oracle(model, scale=4)
+    onet = O.build_oracle(model, scale=4, **KW)
     sd = O.interpolating_state_dict(onet, seed)
     onet.load_state_dict(sd)
     oout, _, _ = O.OracleHandler(onet, eval_mode=True).run_eval(lr_t)
