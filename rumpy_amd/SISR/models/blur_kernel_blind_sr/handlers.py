@@ -83,7 +83,17 @@ class ContrastiveBlindQRCANHandler(BaseContrastive):
         return self.net.forward(x, **kwargs)
 
     def set_multi_gpu(self, device_ids=None):
-        if any(p.requires_grad for p in self.net.E.parameters()):
-            raise RuntimeError('rumpy_amd: data-parallel gradient averaging covers the generator\'s flat gradient buffer; with trainable encoder '
-                               'parameters (joint losses, encoder_freeze_mode other than "all") it is not built')
+        """The generator's flat gradient buffer is averaged by BaseModel's GradientAverager; trainable encoder parameters (joint losses,
+        ``encoder_freeze_mode`` other than "all") by one more coalesced all-reduce before the optimizer step.  The MoCo / SupMoCo queues
+        stay identical on every rank (each enqueues the keys of all ranks, moco.py); the encoder's BatchNorm running statistics follow
+        each rank's own shard, as under DistributedDataParallel without SyncBatchNorm (the reference's nn.DataParallel keeps replica 0's,
+        i.e. rank 0's here - the rank that writes the checkpoints)."""
+        from rumpy_amd.parallel import ParameterGradientAverager
         super().set_multi_gpu(device_ids)
+        trainable = [p for p in self.net.E.parameters() if p.requires_grad]
+        self.encoder_data_parallel = ParameterGradientAverager(trainable) if trainable else None
+
+    def _apply_update(self, scheduler_skip=False):
+        if getattr(self, 'encoder_data_parallel', None) is not None:
+            self.encoder_data_parallel.average()
+        super()._apply_update(scheduler_skip)

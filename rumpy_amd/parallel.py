@@ -106,6 +106,45 @@ class GradientAverager:
         return mult
 
 
+class ParameterGradientAverager:
+    """Mean over the ranks of the ``.grad`` of a list of parameters that do NOT live in the generator's flat gradient buffer - the
+    trainable encoder of the blind pipeline's joint losses (1.3 M elements: conv / BatchNorm / mlp-head gradients, some of them views of
+    the encoder's own flat buffer, the head's plain autograd tensors).  One coalesced all-reduce per step: the gradients are gathered
+    into one staging buffer (``torch._foreach_copy_``: a handful of launches), summed over the ranks, and written back scaled by 1 / world."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world_size > 1 or (os.environ.get('RUMPY_DP_FORCE') == '1' and dist.is_available() and dist.is_initialized())
+        self._stage = self._views = None
+
+    def average(self):
+        if not self.active:
+            return
+        live = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not self.params:
+            return
+        dev = self.params[0].device
+        if self._stage is None or self._stage.device != dev:
+            sizes = [p.numel() for p in self.params]
+            self._stage = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            self._views = [v.view(p.shape) for v, p in zip(self._stage.split(sizes), self.params)]
+        if len(live) != len(self.params):
+            # a parameter without a gradient on THIS rank may have one on another: the collective's size must not depend on the rank - it
+            # enters the sum as zero (and stays without a gradient here)
+            self._stage.zero_()
+        grads = [self.params[i].grad for i in live]
+        views = [self._views[i] for i in live]
+        if grads:
+            torch._foreach_copy_(views, grads)
+        dist.all_reduce(self._stage, op=dist.ReduceOp.SUM, group=self.group)
+        if self.world_size > 1:
+            self._stage.mul_(1.0 / self.world_size)
+        if grads:
+            torch._foreach_copy_(grads, views)
+
+
 def broadcast_parameters(net, src=0, group=None):
     """Make every replica start from rank src's weights (one flat broadcast)."""
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get('RUMPY_DP_FORCE') == '1'):
@@ -116,4 +155,6 @@ def broadcast_parameters(net, src=0, group=None):
         if enc is not None:
             for t in enc.state_dict().values():
                 dist.broadcast(t, src=src, group=group)
-            enc._packed = enc._folded = None
+            for mod in enc.modules():           # the encoder itself, or the query / key encoders of a MoCo module (joint losses)
+                if hasattr(mod, 'weights_rewritten'):
+                    mod.weights_rewritten()

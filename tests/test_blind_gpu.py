@@ -184,9 +184,6 @@ def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze
     assert list(h.net.state_dict().keys()) == list(oh.net.state_dict().keys()) or mode == 'supmoco'     # (queue_labels appears with the classes)
     assert [k for k, p in h.net.named_parameters() if p.requires_grad] == [k for k, p in oh.net.named_parameters() if p.requires_grad]
     assert type(h.optimizer).__name__ == ('FlatAdam' if freeze == 'all' else 'Adam')
-    if freeze != 'all':
-        with pytest.raises(RuntimeError, match='data-parallel'):
-            h.set_multi_gpu()
     gsd = O.seeded_state_dict(oh.net.G, 2800)
     oh.net.G.load_state_dict(gsd)
     h.net.G.load_state_dict(gsd)
@@ -230,6 +227,59 @@ def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze
     out, loss, _ = h.run_eval(x=xe[:, 0], y=ye[:, 0], request_loss=True)
     oout, oloss = oh.run_eval(xe[:, 0], ye[:, 0])
     assert self_psnr(out, oout) >= 40.0 and abs(float(loss) - float(oloss)) < 2e-2 * float(oloss)
+
+
+_JOINT_DP_WORKER = r"""
+import os, sys, tempfile, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from oracle import sr_oracle as O
+from oracle import contrastive_oracle as CO
+from rumpy_amd.shared_framework.models import define_model
+from rumpy_amd.parallel import broadcast_parameters
+KW = %(kw)r
+def run(dp):
+    torch.manual_seed(5)
+    h = define_model('contrastiveblindqrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, checkpoint_load=False,
+                     loss_masking=False, metadata_list=None, lr=1e-3, combined_loss_mode='moco', crop_count=2, encoder_train_eval='train',
+                     encoder_freeze_mode='none', block_encoder_loading=True, **KW)
+    if dp:
+        h.set_multi_gpu()
+        assert h.data_parallel.active and h.encoder_data_parallel.active
+        assert len(h.encoder_data_parallel.params) == len([p for p in h.net.E.parameters() if p.requires_grad]) > 24
+        broadcast_parameters(h.net)
+    losses = []
+    for step in range(3):
+        x, y = CO.joint_batch(2920 + step, 4, 2)
+        pkg, logits = h.run_train(x=x, y=y)
+        losses.append({k: float(v) for k, v in pkg.items()})
+    torch.cuda.synchronize()
+    return losses, {k: v.detach().clone() for k, v in h.net.state_dict().items()}, h
+a = run(False)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+b = run(True)
+assert b[2].encoder_data_parallel._stage is not None and b[2].encoder_data_parallel._stage.numel() > 1000000
+assert a[0] == b[0], (a[0], b[0])
+for k in a[1]:
+    assert torch.equal(a[1][k], b[1][k]), k            # a sum over one rank is the identity: same parameters, queue, statistics bit for bit
+dist.destroy_process_group()
+print('joint dp ok')
+"""
+
+
+def test_joint_losses_train_data_parallel_over_rccl_with_one_rank():
+    """set_multi_gpu with a TRAINABLE encoder (joint MoCo loss, encoder_freeze_mode 'none'): the generator's flat gradient buffer goes through
+    GradientAverager, the encoder's gradients (trunk views, BatchNorm, mlp head) through ParameterGradientAverager's one coalesced all-reduce
+    - here over a real one-rank RCCL communicator (RUMPY_DP_FORCE=1), where the sum is the identity: three steps must leave every parameter,
+    the queue and the BatchNorm statistics bitwise equal to the run without data parallelism.  (Two ranks: tests/test_host_cpu.py, gloo.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(tempfile.mkdtemp(), 'jdp.py')
+    with open(script, 'w') as f:
+        f.write(_JOINT_DP_WORKER % {'root': root, 'kw': KW})
+    env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', RANK='0', WORLD_SIZE='1')
+    p = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    assert p.returncode == 0 and 'joint dp ok' in p.stdout.decode(), p.stdout.decode()[-3000:]
 
 
 def test_blind_qrcan_q_embedding_against_oracle():

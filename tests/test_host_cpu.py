@@ -230,6 +230,22 @@ assert avg2.early_lo is None and not avg2.pending
 assert torch.equal(g2, torch.arange(10007, dtype=torch.float32) * 3.0), rank
 avg2.begin(g2.data_ptr())                                         # boundary at the start of the buffer: nothing to split
 assert avg2.early_lo is None
+# parameters outside the flat buffer (the blind pipeline's trainable encoder): one coalesced all-reduce, mean written back into .grad;
+# a parameter without a gradient on one rank enters as zero and stays without one there
+from rumpy_amd.parallel import ParameterGradientAverager
+ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2)), torch.zeros(4)]
+flat = torch.zeros(15)
+ps[0].grad = flat.view(3, 5); flat += rank + 1.0                   # a view of a flat gradient buffer, like the encoder trunk's
+if rank == 0:
+    ps[1].grad = torch.full((7,), 4.0)
+ps[2].grad = torch.tensor([1.0, -1.0]) * (rank + 1)
+pavg = ParameterGradientAverager(ps)
+assert pavg.active and len(pavg.params) == 3
+for rep in range(2):
+    pavg.average()
+assert torch.equal(flat, torch.full((15,), 1.5)) and ps[0].grad.data_ptr() == flat.data_ptr()
+assert (ps[1].grad is None) if rank == 1 else torch.equal(ps[1].grad, torch.full((7,), 1.0))          # (4 + 0) / 2, then (2 + 0) / 2
+assert torch.equal(ps[2].grad, torch.tensor([1.5, -1.5]))
 class Net: pass
 n = Net(); n.flat_p = torch.full((5,), float(rank)); n._packed_version = 1
 broadcast_parameters(n, src=0)
