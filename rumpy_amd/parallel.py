@@ -35,6 +35,7 @@ class GradientAverager:
         self.active = self.world_size > 1 or (os.environ.get('RUMPY_DP_FORCE') == '1' and dist.is_available() and dist.is_initialized())
         self.buckets = bucket_bounds(self.flat_g.numel(), bucket_elems)
         self.bucket_elems = bucket_elems
+        self.inline = os.environ.get('RUMPY_DP_INLINE', '1') == '1'
         self.early_lo = None                 # start of the part whose all-reduce was launched early by begin()
         self.side = torch.cuda.Stream(self.flat_g.device) if self.flat_g.is_cuda else None
         self.pending = []
@@ -95,6 +96,11 @@ class GradientAverager:
         if self.early_lo is not None:        # the upper part is already in flight (begin()): only the rest is launched here
             self._launch_range(0, self.early_lo)
             self.early_lo = None
+        elif self.inline and len(self.buckets) == 1:
+            # nothing left to run beside it (the whole backward pass is behind us, the optimizer waits for the result): ONE blocking-form
+            # collective issued from the CURRENT stream - no side stream, no work handle; c10d's process group enqueues a sync op on the
+            # caller's stream (torch >= 2.8), which removes the event hops main -> side -> communicator stream -> main around it
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
         else:
             for i in range(len(self.buckets)):
                 self.launch_bucket(i)

@@ -219,6 +219,10 @@ assert mult == 0.5 and torch.equal(g, torch.arange(10007, dtype=torch.float32) *
 g1 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
 assert GradientAverager(flat_grad=g1, bucket_elems=1000).average(scale_in_place=True) == 1.0       # stock torch optimizers: scaled here
 assert torch.equal(g1, torch.arange(10007, dtype=torch.float32) * 1.5), rank
+g3 = torch.arange(10007, dtype=torch.float32) * (rank + 1)        # one bucket: the blocking-form collective from the caller's stream
+avg3 = GradientAverager(flat_grad=g3)
+assert avg3.inline and len(avg3.buckets) == 1 and avg3.average() == 0.5 and not avg3.pending
+assert torch.equal(g3, torch.arange(10007, dtype=torch.float32) * 3.0), rank
 # two-phase form (SREngine.backward(on_ready=...)): the upper part is launched early by begin(ptr), average() covers the rest
 g2 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
 avg2 = GradientAverager(flat_grad=g2, bucket_elems=1000)
