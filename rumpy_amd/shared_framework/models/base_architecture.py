@@ -65,6 +65,11 @@ class BaseModel(nn.Module):
 
     # ------------------------------------------------------------------ devices
     def activate_device(self):
+        dev = self._torch_device()
+        if dev.type == 'cuda' and torch.cuda.is_available():
+            # the C-ABI launches go to torch's stream OF THIS DEVICE with raw pointers: HIP resolves a kernel for the calling thread's
+            # current device, so the handler's GPU becomes the current one (one process per GPU; the reference's sp_gpu index, gpu_check.py:15-25)
+            torch.cuda.set_device(dev)
         self.net.to(self.device)
 
     def _torch_device(self):
