@@ -157,6 +157,15 @@ def broadcast_parameters(net, src=0, group=None):
         hip = getattr(net, 'hip_generator', net)        # a pipeline trains its generator; its frozen encoder is replicated as well
         dist.broadcast(hip.flat_p, src=src, group=group)
         hip._packed_version = None
+        if hip is net and hasattr(net, 'state_dict'):
+            # whatever a flat-protocol module holds beside its trainable flat buffer (MoCo: the key encoder, the queue and its pointer, the
+            # BatchNorm statistics of both encoders) - tensors inside flat_p's storage have just travelled
+            own = hip.flat_p.untyped_storage().data_ptr()
+            rest = [t for t in net.state_dict().values() if t.untyped_storage().data_ptr() != own]
+            for t in rest:
+                dist.broadcast(t, src=src, group=group)
+            if rest and hasattr(net, 'mark_weights_updated'):
+                net.mark_weights_updated()
         enc = getattr(net, 'E', None) if hip is not net else None
         if enc is not None:
             for t in enc.state_dict().values():

@@ -582,6 +582,19 @@ m = MoCo(base_encoder=Encoder, K=64)
 keys = torch.full((4, 256), float(rank + 1))
 m._dequeue_and_enqueue(keys)                      # every rank enqueues the keys of BOTH ranks, in rank order
 assert int(m.queue_ptr) == 8 and torch.equal(m.queue[:, :4], torch.ones(256, 4)) and torch.equal(m.queue[:, 4:8], torch.full((256, 4), 2.0))
+# replicas start from rank 0's module: the trainable flat buffer in one broadcast, then everything else it holds (key encoder, queue, pointer,
+# BatchNorm statistics)
+from rumpy_amd.parallel import broadcast_parameters
+torch.manual_seed(100 + rank)
+m2 = MoCo(base_encoder=Encoder, K=64)
+m2.encoder_q.flatten(); m2.encoder_k.flatten()
+m2.queue_ptr[0] = 8 * rank
+m2.encoder_q.E[1].running_mean += rank
+broadcast_parameters(m2)
+ref = [torch.zeros_like(t) for t in m2.state_dict().values()]
+for t, r in zip(m2.state_dict().values(), ref):
+    r.copy_(t); dist.broadcast(r, src=0)
+assert all(torch.equal(t, r) for t, r in zip(m2.state_dict().values(), ref)) and int(m2.queue_ptr) == 0
 s = SupMoCo(device='cpu', base_encoder=Encoder, K=64, positives_per_class=2)
 s.register_classes(5)
 s._dequeue_and_enqueue(keys, torch.tensor([rank, rank, 3, 4]))
