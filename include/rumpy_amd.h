@@ -57,7 +57,7 @@ typedef struct {
   const float* bias;    /* packed-order bias [64*cout_tiles] or NULL */
   void* out;            /* out_mode 0: [N,H,W,64*cout_tiles] ; out_mode 1: [N,2H,2W,64], tile q=2i+j stored at (2h+i,2w+j) */
   const void* mask;     /* bf16, layout of out (out_mode 0 only) or NULL */
-  const void* res1;     /* bf16, layout of out, or NULL */
+  const void* res1;     /* bf16, layout of out, or NULL; with out_mode 1 (cin_chunks 1 only, res2 NULL): conv-output order [N,H,W,256] */
   const void* res2;     /* bf16, layout of out, or NULL */
   float* pool;          /* [N][rumpy_conv_pool_tiles()][64*cout_tiles] per-tile channel sums, or NULL */
   int32_t N, H, W;

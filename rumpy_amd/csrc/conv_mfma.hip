@@ -483,7 +483,11 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cout_tiles <= 0) { rumpy_set_error("rumpy_conv3x3: bad shape"); return RUMPY_E_ARG; }
   if (p->cin_chunks < 1 || p->cin_chunks > 4) { rumpy_set_error("rumpy_conv3x3: cin_chunks must be 1 .. 4 (got %d)", p->cin_chunks); return RUMPY_E_ARG; }
   if (p->in_mode == 1 && p->cin_chunks != 4) { rumpy_set_error("rumpy_conv3x3: in_mode 1 needs cin_chunks 4"); return RUMPY_E_ARG; }
-  if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || p->res1 || p->res2)) { rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4 and no mask/residual"); return RUMPY_E_ARG; }
+  // out_mode 1 (PixelShuffle fused into the store): no mask; a residual operand only in the Cin = 64 form (conv_up.hip reads it in
+  // conv-output order [N, H, W, 256] - the rounding-residual launch of an fp16 evaluation plan's upsampler stage)
+  const bool shuffled_res = p->out_mode == 1 && p->res1 && !p->res2 && p->cin_chunks == 1 && p->in_mode == 0 && !p->pool;
+  if (p->out_mode == 1 && (p->cout_tiles != 4 || p->mask || ((p->res1 || p->res2) && !shuffled_res))) {
+    rumpy_set_error("rumpy_conv3x3: out_mode 1 needs cout_tiles 4, no mask and no residual (one residual operand with cin_chunks 1)"); return RUMPY_E_ARG; }
   if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !p->mask && p->in_mode == 0)) {
     rumpy_set_error("rumpy_conv3x3: fmt %d needs a plain input and no mask (forward launches of an evaluation plan)", p->fmt); return RUMPY_E_ARG; }
   // Cin = 256 (upsampler data gradients): the 8x16-tile kernel below measures faster than the 4-chunk strip build
@@ -500,7 +504,7 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     const int up_strips = p->N * cdiv(p->H, 6) * cdiv(p->W, 48);
     const char* up_force = getenv("RUMPY_UP_FORCE");                    // diagnostic (kbench.py up1): "1" = every eligible launch, "0" = multi-tile ones only
     const bool up_many = up_force ? up_force[0] == '1' : up_strips > rumpy_device_cus();
-    if (!up_old && p->cin_chunks == 1 && (p->cout_tiles > 1 || up_many) && p->in_mode == 0 && !p->mask && !p->pool && (p->out_mode == 0 || (!p->res1 && !p->res2)))
+    if (shuffled_res || (!up_old && p->cin_chunks == 1 && (p->cout_tiles > 1 || up_many) && p->in_mode == 0 && !p->mask && !p->pool && (p->out_mode == 0 || (!p->res1 && !p->res2))))
       rumpy_conv_up_launch(p, s1);
     else
     rumpy_conv3x3_strip_launch(p, s1);

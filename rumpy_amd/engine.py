@@ -162,6 +162,8 @@ class SREngine:
         # an upsampler stage that is not "64 features, PixelShuffle(2)" (x3: conv F -> 9F, or any stage of a wide net): the conv writes its
         # natural channel order, rumpy_pixel_shuffle permutes (forward) / un-permutes the gradient (backward): csrc/wide.hip
         self.generic_up = self.wide or any(cv.cout != 4 * cv.cin for cv in spec.ups)
+        # fp16 evaluation plans of the 64-feature nets: upsampler filters as image + rounding-residual image too (two conv launches per stage)
+        self.eval_up_residual = os.environ.get('RUMPY_EVAL_UP_RESIDUAL', '1') == '1'
         if spec.head.cin > 4 or spec.tail.cout > 4:
             raise RuntimeError('rumpy_amd: image channels must be <= 4')
         if spec.tail.cin != self.feats:
@@ -275,12 +277,12 @@ class SREngine:
             cv.w_fwd_h = torch.empty(cv.cout * cv.cin * 9 if kind == 0 else 2 * 18 * 64 * 8, dtype=torch.float16, device=self.device)      # tail: filter + residual image
             items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd_h), w_dgrad=None, b_packed=None, cout=cv.cout,
                                     cin=cv.cin, kind=kind, shuffle=1 if (kind == 0 and cv.shuffle) else 0, fmt=L.FMT_F16))
-            if self.generic_up and any(cv is u for u in self.spec.ups):
-                # the upsampler filters of the wide nets also enter evaluation as image + rounding-residual image (a second conv launch adds
-                # the residual's contribution): their fp16 rounding alone moved a 32 dB EDSR 256 x 32 by -0.022 dB
+            if (self.generic_up or self.eval_up_residual) and any(cv is u for u in self.spec.ups):
+                # the upsampler filters also enter evaluation as image + rounding-residual image (a second conv launch adds the residual's
+                # contribution): their fp16 rounding alone moved a 32 dB EDSR 256 x 32 by -0.022 dB, a 64-feature RCAN by -0.011
                 cv.w_fwd_h_lo = torch.empty(cv.cout * cv.cin * 9, dtype=torch.float16, device=self.device)
                 items.append(L.PackItem(w=_ptr(cv.weight), b=_ptr(cv.bias), w_fwd=_ptr(cv.w_fwd_h_lo), w_dgrad=None, b_packed=None, cout=cv.cout,
-                                        cin=cv.cin, kind=0, shuffle=0, fmt=L.FMT_F16_RESIDUAL))
+                                        cin=cv.cin, kind=0, shuffle=1 if cv.shuffle else 0, fmt=L.FMT_F16_RESIDUAL))
         self._pack_items_h_host = (L.PackItem * len(items))(*items)
         self._pack_items_h = self._to_device_bytes(self._pack_items_h_host)
         self._n_pack_h = len(items)
@@ -537,6 +539,15 @@ class SREngine:
                 else:
                     self._conv(fwd, u, cv, N, h, w, pre, fmt=fmt)
                 fwd.append(('rumpy_pixel_shuffle', L.PixelShuffleArgs(src=_ptr(pre), dst=_ptr(nxt), N=N, H=h, W=w, F=F, r=rr, inverse=0)))
+            elif fmt and self.eval_up_residual:
+                # 64 features, fp16 evaluation plan: the same two launches with the PixelShuffle fused into the second one's store - the
+                # residual's conv leaves its (small) result in conv-output order (channel tile = sub-pixel position, as the packed image has
+                # it), the main conv reads it as its residual operand at that very index and adds it in fp32 before the one rounding
+                pre = self._new(plan, N, h, w, cv.cout)
+                fwd.append(('rumpy_conv3x3', L.ConvArgs(x=_ptr(u), w=_ptr(cv.w_fwd_h_lo), bias=None, out=_ptr(pre), mask=None, res1=None,
+                                                        res2=None, pool=None, N=N, H=h, W=w, cin_chunks=cv.cin // 64, cout_tiles=cv.cout // 64,
+                                                        in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0, fmt=fmt)))
+                self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1, res1=pre, fmt=fmt)
             else:
                 self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1, fmt=fmt)
             ups_in.append((cv, u, h, w, rr))

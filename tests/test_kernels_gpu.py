@@ -158,6 +158,26 @@ def test_conv3x3_upsampler_forward_pixel_shuffle_fused():
     assert_bf16_close(nchw(o), ref, 'conv 64->256 + PixelShuffle(2)')
 
 
+def test_conv3x3_upsampler_pixel_shuffle_with_a_residual_operand_in_conv_output_order():
+    """the second launch of an fp16 evaluation plan's upsampler stage: conv + residual operand + PixelShuffle in the store.  The operand is
+    indexed like the conv's own (pre-shuffle) output, channel tile = sub-pixel position: operand[n, y, x, 64 t + c] belongs to natural
+    channel 4 c + t.  Several strips per workgroup, ragged sizes, one strip; and still refused: two residual operands, a mask."""
+    gen = np.random.default_rng(131)
+    w, b = _wb(gen, 256, 64)
+    pc = PackedConv(w, b, 0, True)
+    for (N, H, W, gx) in ((2, 11, 19, 0), (3, 40, 50, 5), (1, 5, 3, 1), (9, 48, 48, 0)):
+        x = _rand(gen, N, 64, H, W)
+        r_nat = _rand(gen, N, 256, H, W)                                        # natural channel order, NCHW
+        r_perm = bf16r(r_nat).view(N, 64, 4, H, W).permute(0, 3, 4, 2, 1).reshape(N, H, W, 256).contiguous().to(DEV).to(BF16)
+        o, _ = hip_conv(nhwc(x), pc, N, H, W, out_mode=1, res1=r_perm, grid_x=gx)
+        ref = F.pixel_shuffle(F.conv2d(bf16r(x), bf16r(w), b, padding=1) + bf16r(r_nat), 2)
+        assert_bf16_close(nchw(o), ref, 'conv 64->256 + residual + PixelShuffle(2) %s' % ((N, H, W, gx),))
+    with pytest.raises(RuntimeError, match='out_mode 1'):
+        hip_conv(nhwc(x), pc, N, H, W, out_mode=1, res1=r_perm, res2=r_perm)
+    with pytest.raises(RuntimeError, match='out_mode 1'):
+        hip_conv(nhwc(x), pc, N, H, W, out_mode=1, mask=r_perm)
+
+
 def test_conv3x3_dgrad_plain_and_unshuffle():
     gen = np.random.default_rng(14)
     N, H, W = 2, 13, 17
