@@ -339,6 +339,10 @@ def lib():
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError('rumpy_amd: %s is missing - build it with `python -c "import __graft_entry__ as g; '
                                'g.build()"` (or make -C rumpy_amd/csrc). There is no CPU fallback.' % LIB_PATH)
+        # torch first: the process must run on ONE HIP runtime - the one torch ships and loads; this library (NEEDED libamdhip64.so.7) then
+        # binds to that copy.  Loaded the other way round, the system's runtime comes in first and the two end up with different views of
+        # the device ("no ROCm-capable device is detected" from every launch here)
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(h, name)
