@@ -130,6 +130,43 @@ def bench_moco(args):
     print(json.dumps(line), flush=True)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` called plainly (no RANK in the environment): this process - which has not touched the GPU and never will -
+    starts the N rank processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would set
+    them), relays rank 0's JSON line and exits with the worst return code.  Children are fresh interpreters (subprocess, never exec)."""
+    import socket
+    import subprocess
+    one_device = os.environ.get('RUMPY_BENCH_ONE_DEVICE') == '1'
+    if not one_device:
+        import torch                         # device_count() reads the driver's device list without initialising a HIP context
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d, but this node exposes %d GPU(s)\n' % (n, have))
+            return 2
+    with socket.socket() as sk:              # a free rendezvous port
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(os.environ.get('MASTER_PORT', port)), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env.setdefault('OMP_NUM_THREADS', '8')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:    # a peer that outlives a failed rank 0 waits in a collective: end exactly that process
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0 or '')
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -144,7 +181,17 @@ def main():
                     help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block, blindqrcan = frozen contrastive degradation encoder + QRCAN (BASELINE config 5 in bf16; q-layers as in the reference test config), edsr256 = EDSR at the reference\'s shipped width (div2k/edsr.toml: 256 features x 32 blocks); all for information')
     ap.add_argument('--device-patches', action='store_true',
                     help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
+    ap.add_argument('--allreduce-form', choices=('auto', 'inline', 'early', 'side'), default='auto',
+                    help='data-parallel runs: how the gradient all-reduce is issued (auto = early half for >= 4 M gradient elements, else one '
+                         'inline collective after the backward pass); reported as distributed.allreduce_form')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.allreduce_form != 'auto':
+        for k in ('RUMPY_DP_EARLY', 'RUMPY_DP_LATE', 'RUMPY_DP_INLINE'):
+            os.environ.pop(k, None)
+        os.environ.update({'inline': {'RUMPY_DP_LATE': '1', 'RUMPY_DP_INLINE': '1'}, 'early': {'RUMPY_DP_EARLY': '1'},
+                           'side': {'RUMPY_DP_LATE': '1', 'RUMPY_DP_INLINE': '0'}}[args.allreduce_form])
     if args.model == 'moco':
         return bench_moco(args)
 
@@ -171,8 +218,8 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    elif args.gpus != 1:
-        raise SystemExit('--gpus %d needs torch.distributed.run with --nproc-per-node %d' % (args.gpus, args.gpus))
+    if dp and world != args.gpus and os.environ.get('RUMPY_DP_FORCE') != '1':
+        raise SystemExit('--gpus %d, but WORLD_SIZE is %d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
     torch.cuda.set_device(local_rank)
@@ -399,6 +446,7 @@ def main():
                 # what the collectives really ran on (the driver's scaling run can check that RCCL saw N ranks on N devices)
                 'distributed': {'world_size': dist.get_world_size() if dp else 1, 'backend': dist.get_backend() if dp else None,
                                 'device_count': torch.cuda.device_count(), 'ranks_on_one_device': bool(one_device),
+                                'allreduce_form': getattr(getattr(h, 'data_parallel', None), 'form', None) if dp else None,
                                 'grad_allreduce_mb': round(getattr(h.net, 'hip_generator', h.net).flat_g.numel() * 4 / 1e6, 2) if dp else 0.0}}
         print(json.dumps(line), flush=True)
     if dp:

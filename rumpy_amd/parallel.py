@@ -37,6 +37,10 @@ class GradientAverager:
         self.bucket_elems = bucket_elems
         self.inline = os.environ.get('RUMPY_DP_INLINE', '1') == '1'
         self.early_lo = None                 # start of the part whose all-reduce was launched early by begin()
+        # which form average() takes (reported by bench.py as distributed.allreduce_form): 'inline' = ONE blocking-form collective on the
+        # caller's stream after the backward pass; 'side' = asynchronous buckets on the side stream after the backward pass; 'early' = the
+        # upper half on the side stream under the remaining weight gradients (set by BaseModel.set_multi_gpu when it installs begin())
+        self.form = 'inline' if (self.inline and len(self.buckets) == 1) else 'side'
         self.side = torch.cuda.Stream(self.flat_g.device) if self.flat_g.is_cuda else None
         self.pending = []
 

@@ -93,6 +93,7 @@ class BaseModel(nn.Module):
         early = (early or os.environ.get('RUMPY_DP_EARLY') == '1') and os.environ.get('RUMPY_DP_LATE') != '1'
         if hip is not None and self.data_parallel.active and early:
             hip.grad_ready_hook = self.data_parallel.begin      # all-reduce of the upper half starts under the remaining weight gradients
+            self.data_parallel.form = 'early'
         if self.data_parallel.active:
             print('Model replicated over %d GPU processes (RCCL gradient all-reduce)' % self.data_parallel.world_size)
 

@@ -636,3 +636,20 @@ def test_wide_edsr_and_x3_construct_like_the_reference_and_other_widths_are_refu
             continue
         with pytest.raises(RuntimeError, match='n_feats|scale'):
             SREngine(hb.net._spec(), torch.device('cpu'))
+
+
+def test_bench_launcher_refuses_more_gpus_than_the_node_has_and_relays_the_children():
+    """`python bench.py --gpus N` without RANK starts the ranks itself (bench.py::launch_ranks).  On this GPU-less container: more GPUs
+    than devices -> non-zero exit with a message before any child starts; with RUMPY_BENCH_ONE_DEVICE=1 the children start and fail
+    loudly (no GPU), and the parent returns their code instead of hanging."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RUMPY_BENCH_ONE_DEVICE')}
+    if torch.cuda.device_count() < 8:
+        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode != 0 and b'--gpus 8' in p.stderr and b'{"metric"' not in p.stdout
+    if not torch.cuda.is_available():
+        env['RUMPY_BENCH_ONE_DEVICE'] = '1'
+        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode != 0 and b'{"metric"' not in p.stdout

@@ -625,6 +625,29 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     assert d['roofline'] is not None and d['roofline']['launches_timed'] > 0
 
 
+def test_bench_starts_its_own_ranks_when_called_plainly():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run (the form the driver uses for its 1-GPU line): the parent process starts
+    the two ranks itself before touching the GPU, relays rank 0's line and returns their code.  Two ranks share cuda:0 over gloo here
+    (RUMPY_BENCH_ONE_DEVICE=1); the line says which all-reduce form ran."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update(RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for form, want in (('auto', 'inline'), ('early', 'early')):
+        cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
+               '--no-cpu-baseline', '--allreduce-form', form]
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+        out = p.stdout.decode()
+        assert p.returncode == 0, (out + p.stderr.decode())[-3000:]
+        lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+        assert len(lines) == 1, out[-3000:]
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0
+        assert d['distributed']['world_size'] == 2 and d['distributed']['allreduce_form'] == want
+
+
 @pytest.mark.parametrize('name,kw,N', [
     ('edsr', dict(scale=4), 32),
     ('edsr', dict(scale=4, _graph=True), 32),      # hipGraph replay: the hyper-parameters go through device memory (fenced pinned staging)
