@@ -221,6 +221,7 @@ class HipSRNet(nn.Module):
         self._ensure_engine()
         if not x.is_cuda:
             raise RuntimeError('rumpy_amd: input must be on the GPU')
+        self.engine.eval_defer = bool(getattr(self, 'eval_defer', False))      # set by BaseModel.run_eval(keep_on_device=True)
         return self.engine.forward(x.float().contiguous(), train=train, target=target, meta=self._meta_matrix(meta, x))
 
     @staticmethod

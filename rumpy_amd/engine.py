@@ -164,6 +164,10 @@ class SREngine:
         self.generic_up = self.wide or any(cv.cout != 4 * cv.cin for cv in spec.ups)
         # fp16 evaluation plans of the 64-feature nets: upsampler filters as image + rounding-residual image too (two conv launches per stage)
         self.eval_up_residual = os.environ.get('RUMPY_EVAL_UP_RESIDUAL', '1') == '1'
+        # evaluation status words (non-finite output, strip-exchange watchdog): read back synchronously after every pass, or - eval_defer,
+        # set by run_eval(keep_on_device=True) around its pass - staged into pinned memory and examined at the next pass / check_eval()
+        self.eval_defer = False
+        self._flag_host = self._flag_pending = None
         if spec.head.cin > 4 or spec.tail.cout > 4:
             raise RuntimeError('rumpy_amd: image channels must be <= 4')
         if spec.tail.cin != self.feats:
@@ -1016,6 +1020,8 @@ class SREngine:
         """x (and target): contiguous fp32 [N,C,H,W] on the device; meta: fp32 [N,M] metadata (meta-attention nets only).
         Returns (out fp32 [N,C,sH,sW], loss tensor | None, plan)."""
         N, _, H, W = x.shape
+        if not train:
+            self.check_eval()
         fmt = 0 if train else self.eval_fmt
         plan = self.plan_for(N, H, W, train, fmt)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -1048,9 +1054,21 @@ class SREngine:
             plan.tail_fused = False
             L.call('rumpy_tail_fwd', plan.tail_plain, stream)
             loss = None
-        if not train:
-            # evaluation passes read both status words back here (one small copy; it synchronises - every caller of an evaluation pass
-            # fetches the image next anyway), so that neither problem can go unnoticed on any return path of the handlers
+        if not train and self.eval_defer:
+            # the caller keeps the output on the device (run_eval(keep_on_device=True), validation loops): the status words are copied into
+            # pinned memory behind the pass and fenced by an event - no host synchronisation here; they are examined at the next
+            # evaluation pass or by check_eval() (a non-finite fp16 pass then switches the FOLLOWING passes to bf16: its own output has
+            # been handed out already, non-finite values included)
+            if self._flag_host is None:
+                self._flag_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._flag_host.copy_(plan.flags, non_blocking=True)
+            plan.flags.zero_()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._flag_pending = (ev, fmt)
+        elif not train:
+            # evaluation passes read both status words back here (one small copy; it synchronises - these callers fetch the image next
+            # anyway), so that neither problem can go unnoticed on any return path of the handlers
             bad, xch = plan.flags.tolist()
             if xch:
                 plan.flags.zero_()
@@ -1065,6 +1083,24 @@ class SREngine:
             if bad:
                 plan.flags.zero_()      # bf16 plan: the fp32 reference would not be finite either; nothing to fall back to
         return out, loss, plan
+
+    def check_eval(self):
+        """examine the status words of a deferred evaluation pass (eval_defer): waits for that pass only.  Raises on a strip-exchange
+        time-out; a non-finite fp16 output switches the engine to bf16 evaluation plans from here on."""
+        pend, self._flag_pending = self._flag_pending, None
+        if pend is None:
+            return
+        ev, fmt = pend
+        ev.synchronize()
+        bad, xch = self._flag_host.tolist()
+        if xch:
+            raise RuntimeError('rumpy_amd: a strip exchange of the RCAB kernels timed out (code 0x%x); the output of the previous evaluation '
+                               'pass is invalid (GPU shared with another job? RUMPY_NO_RCAB=1 selects the separate launches)' % xch)
+        if bad and fmt and self.eval_fmt != L.FMT_BF16:
+            import warnings
+            warnings.warn('rumpy_amd: the previous fp16 evaluation pass produced a non-finite output (it was kept on the device, unchecked); '
+                          'evaluation of this network continues in bf16')
+            self.eval_fmt = L.FMT_BF16
 
     def backward(self, plan, grad_scale, gout=None, on_ready=None):
         """Run the backward pass of the last training forward of `plan`.  gout: optional upstream gradient

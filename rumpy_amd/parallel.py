@@ -91,10 +91,10 @@ class GradientAverager:
         if self.side is not None:
             torch.cuda.current_stream(self.flat_g.device).wait_stream(self.side)
 
-    def average(self, scale_in_place=False):
-        """Sum over ranks of every bucket -> returns the factor that turns the sum into the mean (1 / world).  The fused optimizer takes it
-        as `grad_mult` (rumpy_adam_step multiplies every gradient by it in the same pass: no extra kernel, flat_g then holds the SUM);
-        scale_in_place=True applies it here with a torch op instead (stock torch optimizers only)."""
+    def average_sum(self):
+        """SUM over ranks of every bucket, left in flat_g -> returns the factor that turns the sum into the mean (1 / world).  For the fused
+        optimizer only, which takes the factor as `grad_mult` (rumpy_adam_step multiplies every gradient by it in the same pass: no extra
+        kernel).  Anything that reads flat_g / p.grad afterwards sees world-times-larger values: everybody else calls average()."""
         if not self.active:
             return 1.0
         if self.early_lo is not None:        # the upper part is already in flight (begin()): only the rest is launched here
@@ -109,11 +109,13 @@ class GradientAverager:
             for i in range(len(self.buckets)):
                 self.launch_bucket(i)
         self.finish()
-        mult = 1.0 / self.world_size
-        if scale_in_place and self.world_size > 1:
+        return 1.0 / self.world_size
+
+    def average(self):
+        """the mean over ranks, in place: flat_g (and every p.grad viewing it) holds the averaged gradient afterwards"""
+        mult = self.average_sum()
+        if mult != 1.0:
             self.flat_g.mul_(mult)
-            return 1.0
-        return mult
 
 
 class ParameterGradientAverager:
@@ -136,23 +138,35 @@ class ParameterGradientAverager:
         if not self.params:
             return
         dev = self.params[0].device
+        n = len(self.params)
         if self._stage is None or self._stage.device != dev:
             sizes = [p.numel() for p in self.params]
-            self._stage = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-            self._views = [v.view(p.shape) for v, p in zip(self._stage.split(sizes), self.params)]
-        if len(live) != len(self.params):
+            self._stage = torch.empty(sum(sizes) + n, dtype=torch.float32, device=dev)     # + one "has a gradient on this rank" flag per parameter
+            self._views = [v.view(p.shape) for v, p in zip(self._stage[:sum(sizes)].split(sizes), self.params)]
+            self._have = self._stage[sum(sizes):]
+        if len(live) != n:
             # a parameter without a gradient on THIS rank may have one on another: the collective's size must not depend on the rank - it
-            # enters the sum as zero (and stays without a gradient here)
+            # enters the sum as zero
             self._stage.zero_()
+        flags = torch.zeros(n, dtype=torch.float32)
+        flags[live] = 1.0
+        self._have.copy_(flags, non_blocking=True)
         grads = [self.params[i].grad for i in live]
         views = [self._views[i] for i in live]
         if grads:
             torch._foreach_copy_(views, grads)
         dist.all_reduce(self._stage, op=dist.ReduceOp.SUM, group=self.group)
         if self.world_size > 1:
-            self._stage.mul_(1.0 / self.world_size)
+            self._stage[:self._stage.numel() - n].mul_(1.0 / self.world_size)
         if grads:
             torch._foreach_copy_(grads, views)
+        if len(live) != n:
+            # ... and where another rank had one, the mean becomes this rank's gradient too: every replica takes the same optimizer step
+            # (a parameter stepped on some ranks only would let the replicas drift apart)
+            have = self._have.tolist()
+            for i in range(n):
+                if self.params[i].grad is None and have[i] > 0:
+                    self.params[i].grad = self._views[i].clone()
 
 
 def broadcast_parameters(net, src=0, group=None):

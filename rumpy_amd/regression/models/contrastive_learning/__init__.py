@@ -192,7 +192,7 @@ class BaseContrastive(BaseModel):
         return labels.to(device=self._torch_device())
 
     def vector_logic(self, metadata, keys):
-        """degradation vectors [size, N] (WeakCon's targets, :382-396; the WeakCon model itself is not on the HIP path)"""
+        """degradation vectors [size, N] (WeakCon's targets, :382-396; the model is weak_con.py)"""
         if not self.metadata_registered:
             self.register_training_metadata([key[0] for key in keys])
             self.metadata_registered = True

@@ -110,6 +110,7 @@ class Encoder(nn.Module):
     flat_protocol = True
     supports_fused_l1 = False
     use_graph = False
+    _evictions = 0                   # bumped whenever cached plans (and with them buffers a captured graph may hold) are dropped
 
     def __init__(self, dropdown_q=None):
         super(Encoder, self).__init__()
@@ -280,6 +281,7 @@ class Encoder(nn.Module):
                      graphs={}, gkey={})
             if len(self._plans) > 8:
                 self._plans.clear()
+                self._evictions += 1         # whoever captured launches over these buffers (a handler's step graph) must drop them
             self._plans[k] = p
         return p
 
@@ -406,6 +408,7 @@ class Encoder(nn.Module):
                  items=_dev_bytes((L.ReduceItem * len(items))(*items), dev), nitems=len(items), flat_g_ptr=self.flat_g.data_ptr())
         if len(self._train_plans) > 4:
             self._train_plans.clear()
+            self._evictions += 1
         self._train_plans[key] = p
         return p
 

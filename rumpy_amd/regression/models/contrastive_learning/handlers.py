@@ -42,8 +42,16 @@ def _graphed_step(handler, forward_backward, inputs, dev):
                  and not (dist.is_available() and dist.is_initialized()) and type(handler.optimizer).__name__ == 'FlatAdam')
     if not graphable:
         return forward_backward(*inputs, dev)
-    net = handler.net          # a captured step holds the addresses of the parameter buffers and of the queue: part of its key
-    key = tuple((tuple(t.shape), t.dtype) for t in inputs) + (net.flat_p.data_ptr(), net.encoder_k.flat_p.data_ptr(), net.queue.data_ptr())
+    net = handler.net          # a captured step holds the addresses of the parameter buffers, of the queue and of its side tracks: part of its key
+    key = tuple((tuple(t.shape), t.dtype) for t in inputs) + (net.flat_p.data_ptr(), net.encoder_k.flat_p.data_ptr(), net.queue.data_ptr(),
+                                                               net.queue_ptr.data_ptr()) + \
+        tuple(getattr(net, n).data_ptr() for n in ('queue_labels', 'queue_vectors') if getattr(net, n, None) is not None)
+    # ... and plan buffers of both trunks (z / a / dz / da, BatchNorm partials): when an encoder has dropped cached plans since, every captured
+    # step may point into freed memory - all of them go (the next two calls of a shape run eagerly and rebuild what they need)
+    ev = (net.encoder_q._evictions, net.encoder_k._evictions)
+    if handler.__dict__.get('_step_graph_evictions') != ev:
+        handler.__dict__['_step_graphs'] = {}
+        handler.__dict__['_step_graph_evictions'] = ev
     st = handler.__dict__.setdefault('_step_graphs', {}).setdefault(key, {'calls': 0})
     st['calls'] += 1
     if st['calls'] <= 2:

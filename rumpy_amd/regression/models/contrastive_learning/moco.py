@@ -113,14 +113,19 @@ class MoCo(nn.Module):
 
     def _slots(self, batch_size, ptr):
         """device vector of the queue columns the next `batch_size` keys go to, advanced ON THE DEVICE by every enqueue - so that the enqueue
-        is the same launch list at every step (a captured step graph replays it) while the host keeps its own copy of the pointer"""
-        st = self.__dict__.get('_slot_state')
-        if st is None or st[0] != batch_size or st[2].device != self.queue.device:
-            st = [batch_size, ptr, (torch.arange(batch_size, device=self.queue.device, dtype=torch.long) + ptr) % self.K]
-            self.__dict__['_slot_state'] = st
-        elif st[1] != ptr:          # the pointer was moved from outside (a loaded checkpoint): same vector - a captured step holds its address
+        is the same launch list at every step (a captured step graph replays it) while the host keeps its own copy of the pointer.
+        ONE vector per (key count, device), created once and never replaced: a captured step holds its address, so a step with another
+        batch size in between (a last partial batch) must not free it - its content is brought up to the host's pointer IN PLACE when the
+        shape comes back."""
+        table = self.__dict__.setdefault('_slot_table', {})
+        k = (batch_size, self.queue.device)
+        st = table.get(k)
+        if st is None:
+            st = table[k] = [batch_size, ptr, (torch.arange(batch_size, device=self.queue.device, dtype=torch.long) + ptr) % self.K]
+        elif st[1] != ptr:          # moved from outside: a loaded checkpoint, or steps of another batch size since this vector's last use
             st[2].copy_((torch.arange(batch_size, device=self.queue.device, dtype=torch.long) + ptr) % self.K)
             st[1] = ptr
+        self.__dict__['_slot_state'] = st
         return st
 
     def _moved(self, batch_size):

@@ -222,7 +222,10 @@ class BaseModel(nn.Module):
         grad_mult = 1.0
         if self.data_parallel is not None:
             # RCCL all-reduce (sum) of the flat gradient buffer; the 1 / world factor travels into the fused Adam launch as grad_mult
-            grad_mult = self.data_parallel.average(scale_in_place=not isinstance(self.optimizer, FlatAdam))
+            if isinstance(self.optimizer, FlatAdam):
+                grad_mult = self.data_parallel.average_sum()
+            else:
+                self.data_parallel.average()            # stock torch optimizers read p.grad: the mean, in place
         if isinstance(self.optimizer, FlatAdam):
             self.optimizer.step(grad_mult=grad_mult, max_norm=self.grad_clip)
         else:
@@ -294,6 +297,11 @@ class BaseModel(nn.Module):
         self.net.eval()
         dev = self._torch_device()
         tic = toc = None
+        hip = self._hip_net()
+        if isinstance(hip, HipSRNet):
+            # output kept on the device and no loss asked for: nothing of this pass is read on the host, so its status words are not either -
+            # they are staged behind the pass and examined at the next one (SREngine.check_eval)
+            hip.eval_defer = bool(keep_on_device and not (request_loss and y is not None) and not timing)
         with torch.no_grad():
             x = x.to(device=dev)
             want_loss = request_loss and y is not None

@@ -387,6 +387,36 @@ def test_moco_step_is_bitwise_reproducible_and_the_step_graph_is_the_eager_step(
                 assert torch.equal(ta, tb), (step, i)
 
 
+def test_moco_step_graph_survives_other_batch_shapes_and_plan_evictions(monkeypatch):
+    """A captured step holds device addresses: the enqueue slot vector and the trunks' plan buffers.  Batch shapes A A A A B A A (B = a last
+    partial batch, the reference's DataLoader keeps it): the replay of A after B must enqueue at the host's pointer - the slot vector of a key
+    count is created once and updated in place, never replaced.  Then six more shapes push A's plans out of the encoder's cache: the
+    captured steps are dropped with them and A is rebuilt.  Everything bit for bit against the handler kept eager."""
+    shapes = [8, 8, 8, 8, 4, 8, 8] + [2, 16, 1, 32, 64, 128] + [8, 8, 8, 8]
+    res = []
+    for mode in ('graph', 'eager'):
+        monkeypatch.setenv('RUMPY_MOCO_STEP_GRAPH', '0' if mode == 'eager' else '1')
+        h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=2, lr=1e-3)
+        oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=2, lr=1e-3)
+        _seed_handler(h, oh, 901)
+        out, ptr = [], 0
+        for step, N in enumerate(shapes):
+            x = CO.contrastive_batch(1200 + step, N, 2).view(N, 6, 32, 32)
+            loss, logits = h.run_train(x=x, y=None)
+            ptr = (ptr + N) % 8192
+            assert int(h.net.queue_ptr) == ptr == h.net._queue_pointer(), step
+            out.append((float(loss), logits.clone(), h.net.flat_p.clone().cpu(), h.net.encoder_k.flat_p.clone().cpu(), h.net.queue[:, :512].clone().cpu()))
+            if mode == 'graph' and step == 6:
+                assert any('graph' in st for st in h._step_graphs.values())       # shape A was replayed around B
+        if mode == 'graph':
+            assert h.net.encoder_q._evictions + h.net.encoder_k._evictions > 0           # ... and its plans were dropped on the way
+        res.append(out)
+    for step, (a, b) in enumerate(zip(*res)):
+        assert a[0] == b[0], step
+        for i, (ta, tb) in enumerate(zip(a[1:], b[1:])):
+            assert torch.equal(ta, tb), (step, i)
+
+
 @pytest.mark.parametrize('name', ['supmoco', 'weakcon'])
 def test_supmoco_and_weakcon_step_graphs_are_the_eager_steps(name, monkeypatch):
     """the captured step of the label- / vector-carrying handlers (inputs = crops + the batch's labels or degradation vectors, copied into

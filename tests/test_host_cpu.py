@@ -214,14 +214,14 @@ dist.init_process_group('gloo')
 g = torch.arange(10007, dtype=torch.float32) * (rank + 1)
 avg = GradientAverager(flat_grad=g, bucket_elems=1000)
 assert avg.world_size == 2 and len(avg.buckets) == 11 and avg.buckets[0] == (9007, 10007) and avg.buckets[-1] == (0, 7)
-mult = avg.average()                                              # the SUM lands in the buffer; the mean factor goes to the fused Adam (grad_mult)
+mult = avg.average_sum()                                          # the SUM lands in the buffer; the mean factor goes to the fused Adam (grad_mult)
 assert mult == 0.5 and torch.equal(g, torch.arange(10007, dtype=torch.float32) * 3.0), rank
 g1 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
-assert GradientAverager(flat_grad=g1, bucket_elems=1000).average(scale_in_place=True) == 1.0       # stock torch optimizers: scaled here
+assert GradientAverager(flat_grad=g1, bucket_elems=1000).average() is None                          # everybody else: the mean, in place
 assert torch.equal(g1, torch.arange(10007, dtype=torch.float32) * 1.5), rank
 g3 = torch.arange(10007, dtype=torch.float32) * (rank + 1)        # one bucket: the blocking-form collective from the caller's stream
 avg3 = GradientAverager(flat_grad=g3)
-assert avg3.inline and len(avg3.buckets) == 1 and avg3.average() == 0.5 and not avg3.pending
+assert avg3.inline and len(avg3.buckets) == 1 and avg3.form == 'inline' and avg3.average_sum() == 0.5 and not avg3.pending
 assert torch.equal(g3, torch.arange(10007, dtype=torch.float32) * 3.0), rank
 # two-phase form (SREngine.backward(on_ready=...)): the upper part is launched early by begin(ptr), average() covers the rest
 g2 = torch.arange(10007, dtype=torch.float32) * (rank + 1)
@@ -229,13 +229,13 @@ avg2 = GradientAverager(flat_grad=g2, bucket_elems=1000)
 avg2.begin(g2.data_ptr() + 4 * 6001)
 assert avg2.early_lo == 6001 and len(avg2.pending) == 5          # [9007,10007) ... [6001,7007): LAST parameters first
 g2[:6001] += 0.0                                                  # "remaining weight gradients" written while the upper part is in flight
-assert avg2.average() == 0.5
+assert avg2.average_sum() == 0.5
 assert avg2.early_lo is None and not avg2.pending
 assert torch.equal(g2, torch.arange(10007, dtype=torch.float32) * 3.0), rank
 avg2.begin(g2.data_ptr())                                         # boundary at the start of the buffer: nothing to split
 assert avg2.early_lo is None
 # parameters outside the flat buffer (the blind pipeline's trainable encoder): one coalesced all-reduce, mean written back into .grad;
-# a parameter without a gradient on one rank enters as zero and stays without one there
+# a parameter without a gradient on one rank enters as zero and receives the mean there too (every replica takes the same step)
 from rumpy_amd.parallel import ParameterGradientAverager
 ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2)), torch.zeros(4)]
 flat = torch.zeros(15)
@@ -248,7 +248,7 @@ assert pavg.active and len(pavg.params) == 3
 for rep in range(2):
     pavg.average()
 assert torch.equal(flat, torch.full((15,), 1.5)) and ps[0].grad.data_ptr() == flat.data_ptr()
-assert (ps[1].grad is None) if rank == 1 else torch.equal(ps[1].grad, torch.full((7,), 1.0))          # (4 + 0) / 2, then (2 + 0) / 2
+assert torch.equal(ps[1].grad, torch.full((7,), 2.0))          # (4 + 0) / 2 on both ranks, then (2 + 2) / 2
 assert torch.equal(ps[2].grad, torch.tensor([1.5, -1.5]))
 class Net: pass
 n = Net(); n.flat_p = torch.full((5,), float(rank)); n._packed_version = 1

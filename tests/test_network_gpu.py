@@ -295,6 +295,28 @@ def test_fp16_evaluation_overflow_falls_back_to_bf16_plans():
     assert torch.equal(out, out2)
 
 
+def test_kept_on_device_evaluation_defers_the_status_read_back_to_the_next_pass():
+    """run_eval(keep_on_device=True) reads nothing back on the host: the status words are staged behind the pass (pinned copy + event)
+    and examined at the next pass - an fp16 overflow is reported there and switches the following passes to bf16"""
+    h, oh = _pair('edsr', 511, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1)
+    x, _ = O.synthetic_batch(641, 1, lr_hw=20, scale=2)
+    out, _, _ = h.run_eval(x=x, keep_on_device=True)
+    assert out.is_cuda and h.net.engine._flag_pending is not None and h.net.engine.eval_fmt == 1
+    assert self_psnr(out.cpu(), oh.run_eval(x)[0]) >= 75.0
+    h.net.engine.check_eval()
+    assert h.net.engine._flag_pending is None and h.net.engine.eval_fmt == 1
+    with torch.no_grad():
+        h.net.head[0].weight.mul_(3e5)
+        oh.net.head[0].weight.mul_(3e5)
+    out, _, _ = h.run_eval(x=x, keep_on_device=True)            # overflows, unchecked: non-finite values handed out
+    assert not torch.isfinite(out).all() and h.net.engine.eval_fmt == 1
+    with pytest.warns(UserWarning, match='previous fp16 evaluation pass'):
+        out2, _, _ = h.run_eval(x=x)                            # examined here; this pass already runs in bf16
+    assert h.net.engine.eval_fmt == 0 and torch.isfinite(out2).all()
+    oout, _, _ = oh.run_eval(x)
+    assert float((out2 - oout).norm() / oout.norm()) < 2e-2
+
+
 def test_evaluation_plan_cache_is_bounded():
     h, _ = _pair('edsr', 512, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1)
     eng = None

@@ -3,7 +3,10 @@
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/dptrace; rm -rf $OUT; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0 RUMPY_DP_FORCE=1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o p -- python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29599 $R/bench.py --gpus 1 --steps 20 --warmup 10 --probe-steps 0 --no-cpu-baseline > $OUT/log 2>&1
+# the rank itself stands behind `--` (no launcher in between: the profiler's preloaded library may already have initialised the GPU in the
+# process it starts, and a launcher's fork + exec from there is what this pool forbids); bench.py takes the rendezvous from these variables
+export RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29599
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o p -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 10 --probe-steps 0 --no-cpu-baseline > $OUT/log 2>&1
 cd $R
 python3 - <<PY
 import csv, glob
