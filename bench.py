@@ -130,6 +130,130 @@ def bench_moco(args):
     print(json.dumps(line), flush=True)
 
 
+def _usable_cores(cap):
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    try:                                             # container CPU quota (cgroup v2): "<quota> <period>" or "max <period>"
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            usable = max(1, min(usable, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(usable, cap)), usable
+
+
+def bench_eval(args):
+    """--mode eval (information; north_star: "training/inference path"): the evaluation forward pass of a whole image as eval_sisr makes
+    it (run_eval of ONE fp32 NCHW image, rumpy/SISR/models/interface.py:103-124; EDSR / RCAN are not chopped), default a 510 x 339 LR image
+    (a DIV2K x4 validation image).  Plans are IEEE fp16 with the upsampler filters as image + rounding-residual image (two
+    conv launches per stage); the line prices that against the one-launch form (RUMPY_EVAL_UP_RESIDUAL=0) in the same process.
+    value = LR megapixels per second with the image resident in HBM and the output left there (keep_on_device)."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback exists for the product path)')
+    if args.gpus != 1 or int(os.environ.get('WORLD_SIZE', '1')) != 1:
+        raise SystemExit('--mode eval is a one-GPU line')
+    import ctypes
+    from rumpy_amd import _lib as L
+    from rumpy_amd.shared_framework.models import define_model
+    dev = torch.device('cuda', 0)
+    H, W = args.eval_size
+    name = {'edsr256': 'edsr'}.get(args.model, args.model)
+    extra = {'edsr256': dict(num_features=256, num_blocks=32, res_scale=0.1)}.get(args.model, {})
+    if args.model not in ('edsr', 'rcan', 'edsr256'):
+        raise SystemExit('--mode eval takes --model edsr | rcan | edsr256')
+    fwd_flop_per_px = {'edsr': 9.138e9, 'rcan': 73.35e9, 'edsr256': 231.6e9}[args.model] / 2304.0      # SURVEY.md 8(a): forward FLOPs per 48 x 48 patch
+    rng = np.random.default_rng(4321)
+    pool = [torch.from_numpy(rng.random((1, 3, H, W), dtype=np.float32)).to(dev) for _ in range(4)]
+
+    def build(up_residual):
+        os.environ['RUMPY_EVAL_UP_RESIDUAL'] = '1' if up_residual else '0'
+        torch.manual_seed(8)
+        return define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, checkpoint_load=False, loss_masking=False,
+                            scale=4, **extra)
+
+    def run(h, steps, warmup):
+        for i in range(warmup):
+            h.run_eval(x=pool[i % 4], keep_on_device=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out, _, _ = h.run_eval(x=pool[i % 4], keep_on_device=True)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps, out
+    steps, warmup = min(args.steps, 100), min(args.warmup, 10)
+    h = build(True)
+    sec, out = run(h, steps, warmup)
+    eng = h.net.engine
+    eng.check_eval()
+    plan = eng.plan_for(1, H, W, False, eng.eval_fmt)
+    ops = [op for op, _ in plan.fwd]
+    blocks = [a for op, a in plan.fwd if op in ('rumpy_conv_block', 'rumpy_rcab_fwd')]
+    roofline = None
+    if blocks:
+        lib = L.lib()
+        lib.rumpy_probe_begin(5, len(blocks) * 5 + 8)
+        for i in range(5):
+            h.run_eval(x=pool[i % 4], keep_on_device=True)
+        torch.cuda.synchronize(dev)
+        tot = ctypes.c_double(0.0)
+        n_launch = lib.rumpy_probe_end(ctypes.byref(tot))
+        if n_launch > 0:
+            avg_s = tot.value * 1e-3 / n_launch
+            flop = 2 * 2.0 * H * W * 64 * 576                    # two 64 -> 64 3x3 convs per launch
+            alg_bytes = 2.0 * H * W * 64 * 2                      # evaluation: block input and output only, fp16
+            tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
+            roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                        'kernel': ('rcab_kernel' if 'rumpy_rcab_fwd' in ops else 'conv_block_kernel') + ' forward form, fp16, column tiles (one residual block per launch)',
+                        'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch, 'launches_per_image': len(blocks),
+                        'algorithmic_gflop_per_launch': round(flop / 1e9, 3), 'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
+                        'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}
+    h1 = build(False)
+    sec1, _ = run(h1, steps, warmup)
+    os.environ.pop('RUMPY_EVAL_UP_RESIDUAL', None)
+    os.environ['RUMPY_BLOCK_W48'] = '1'              # A/B: two launches per block on images wider than one strip (the round-2 path)
+    h2 = build(True)
+    sec2, _ = run(h2, steps, warmup)
+    os.environ.pop('RUMPY_BLOCK_W48', None)
+    del h1, h2
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import sr_oracle as O                  # the checker, timed as the CPU baseline: the ONLY use of oracle/ in this function
+        cores, usable = _usable_cores(args.cpu_threads)
+        torch.set_num_threads(cores)
+        torch.manual_seed(8)
+        onet = O.build_oracle(name, scale=4, **extra)
+        oh = O.OracleHandler(onet, lr=1e-4, eval_mode=True)
+        ch, cw = max(16, H // 3), max(16, W // 3)             # bounded sample: a ninth of the image, same per-pixel work
+        xc = pool[0][:, :, :ch, :cw].cpu()
+        oh.run_eval(xc)
+        best, total, timed = 1e30, 0.0, 0
+        while timed < 3 or (total < 10.0 and timed < 40):
+            t2 = time.perf_counter()
+            oh.run_eval(xc)
+            dt = time.perf_counter() - t2
+            best, total, timed = min(best, dt), total + dt, timed + 1
+        cpu = {'value': round(ch * cw / best / 1e6, 4), 'unit': 'LR Mpix/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+               'sample': '1 warm-up + %d timed forward passes of a %d x %d LR crop (%.1f s of CPU work; value = best pass), torch CPU fp32 oracle; '
+                         'host reports %d logical CPUs, %d usable under the cgroup quota' % (timed, cw, ch, total, os.cpu_count() or 0, usable)}
+    line = {'metric': 'LR megapixels/sec (whole-image evaluation forward) %s x4 fp16' % args.model.upper(), 'value': round(H * W / sec / 1e6, 3),
+            'unit': 'LR Mpix/s', 'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(1e3 * sec, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic uniform[0,1) image, random-init weights (seed 8)',
+            'config': {'workload': '%s x4 evaluation forward of one %d x %d LR image (%d x %d output), fp16 evaluation plans, image resident in HBM'
+                                   % ({'edsr': 'EDSR-baseline', 'rcan': 'RCAN 10 x 20', 'edsr256': 'EDSR 256 x 32'}[args.model], W, H, 4 * W, 4 * H),
+                       'fwd_tflops': round(H * W * fwd_flop_per_px / sec / 1e12, 2),
+                       'fwd_mfma_frac': round(H * W * fwd_flop_per_px / sec / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                       'launches_per_image': len(ops) + 1, 'one_launch_blocks': len(blocks),
+                       'ms_upsampler_one_launch_form': round(1e3 * sec1, 4),           # RUMPY_EVAL_UP_RESIDUAL=0: what the doubled upsampler launches cost
+                       'ms_two_launches_per_block': round(1e3 * sec2, 4)},             # RUMPY_BLOCK_W48=1: the round-2 path for W > 48
+            'roofline': roofline, 'cpu_baseline': cpu}
+    print(json.dumps(line), flush=True)
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` called plainly (no RANK in the environment): this process - which has not touched the GPU and never will -
     starts the N rank processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would set
@@ -181,6 +305,10 @@ def main():
                     help='edsr = the headline workload (BASELINE.json metric); rcan = RCAN x4 10x20 (BASELINE config 3), qrcan = the same with a meta-attention q-layer (5 metadata entries) in every block, blindqrcan = frozen contrastive degradation encoder + QRCAN (BASELINE config 5 in bf16; q-layers as in the reference test config), edsr256 = EDSR at the reference\'s shipped width (div2k/edsr.toml: 256 features x 32 blocks); all for information')
     ap.add_argument('--device-patches', action='store_true',
                     help='draw every batch on the fly from a device-resident uint8 image cache (SURVEY.md 8f.1) instead of the pre-generated pool')
+    ap.add_argument('--lr-size', type=int, default=48, help='LR patch side of the training step (48 = the headline metric; the reference\'s shipped '
+                                                            'div2k configs crop 64: --lr-size 64 --batch 8 is div2k/rcan.toml)')
+    ap.add_argument('--mode', choices=('train', 'eval'), default='train', help='eval = whole-image evaluation forward (information)')
+    ap.add_argument('--eval-size', type=int, nargs=2, default=(339, 510), metavar=('H', 'W'), help='LR image of --mode eval')
     ap.add_argument('--allreduce-form', choices=('auto', 'inline', 'early', 'side'), default='auto',
                     help='data-parallel runs: how the gradient all-reduce is issued (auto = early half for >= 4 M gradient elements, else one '
                          'inline collective after the backward pass); reported as distributed.allreduce_form')
@@ -194,6 +322,8 @@ def main():
                            'side': {'RUMPY_DP_LATE': '1', 'RUMPY_DP_INLINE': '0'}}[args.allreduce_form])
     if args.model == 'moco':
         return bench_moco(args)
+    if args.mode == 'eval':
+        return bench_eval(args)
 
     import numpy as np
     import torch
@@ -230,7 +360,8 @@ def main():
     from rumpy_amd.shared_framework.models import define_model
 
     N = args.batch
-    flop_per_patch = {'edsr': FLOP_PER_PATCH_TRAIN, 'edsr256': 694.7e9}.get(args.model, 220.04e9)
+    P = args.lr_size
+    flop_per_patch = {'edsr': FLOP_PER_PATCH_TRAIN, 'edsr256': 694.7e9}.get(args.model, 220.04e9) * (P * P / 2304.0)      # SURVEY.md 8(d), per 48 x 48 patch
     torch.manual_seed(8)                                    # reference default seed (net_train.py:20)
     BLIND = dict(style='standard', include_q_layer=True, selective_meta_blocks=[True] + [False] * 9, num_q_layers_inner_residual=1)
     extra = {'qrcan': dict(style='standard', include_q_layer=True, metadata=['m%d' % i for i in range(5)]),
@@ -244,7 +375,7 @@ def main():
         h.set_multi_gpu()
     pool = []
     for i in range(8):
-        x, y = synthetic_batch(1234 + i + 100 * rank, N)
+        x, y = synthetic_batch(1234 + i + 100 * rank, N, lr_hw=P)
         pool.append((x.to(dev), y.to(dev)))
 
     src = None
@@ -255,7 +386,7 @@ def main():
         gen = np.random.default_rng(99 + rank)
         lrs = [gen.integers(0, 256, (192, 256, 3), dtype=np.uint8) for _ in range(64)]
         hrs = [gen.integers(0, 256, (768, 1024, 3), dtype=np.uint8) for _ in range(64)]
-        src = DevicePatchSource(lrs, hrs, 4, 48, device=dev)
+        src = DevicePatchSource(lrs, hrs, 4, P, device=dev)
         random.seed(8 + rank)
 
     def step(i):
@@ -303,7 +434,7 @@ def main():
         # dominant kernel: the residual-block kernel (two 64->64 convs per launch, conv_block.hip) when the engine uses it,
         # otherwise the single-layer strip kernel
         hipnet = getattr(h.net, 'hip_generator', h.net)
-        plan = hipnet.engine.plan_for(N, 48, 48, True)
+        plan = hipnet.engine.plan_for(N, P, P, True)
         ops = plan.fwd + plan.bwd
         blocks = [a for name, a in ops if name == 'rumpy_conv_block']
         rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd')]      # share probe id 5 with the block kernel
@@ -318,9 +449,9 @@ def main():
         n_launch = lib.rumpy_probe_end(ctypes.byref(tot))
         if n_launch > 0:
             avg_s = tot.value * 1e-3 / n_launch
-            layer_flop = 2.0 * N * 48 * 48 * 64 * 576      # algorithmic FLOPs of one 64->64 3x3 layer
-            tensor_bytes = N * 48 * 48 * 64 * 2
-            # algorithmic bytes: every [N,48,48,64] bf16 tensor a launch must touch once, from the engine's launch plan
+            layer_flop = 2.0 * N * P * P * 64 * 576      # algorithmic FLOPs of one 64->64 3x3 layer
+            tensor_bytes = N * P * P * 64 * 2
+            # algorithmic bytes: every [N,P,P,64] bf16 tensor a launch must touch once, from the engine's launch plan
             if wide_convs:
                 # every rumpy_conv3x3 launch of the step (body 256 -> 256 forward + data gradient, upsampler forward): mean flops / mean duration
                 flop = sum(2.0 * a.N * a.H * a.W * 256 * 64 * a.cout_tiles * 9 for a in wide_convs) / len(wide_convs)
@@ -368,7 +499,7 @@ def main():
             elif rcabs:
                 roofline['traffic'] = 45.3e6
                 roofline['traffic_source'] = 'profiles/r02_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
-            elif BLOCK_PMC_TRAFFIC_BYTES:
+            elif BLOCK_PMC_TRAFFIC_BYTES and P == 48 and N == 32:
                 roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
                 roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
 
@@ -413,7 +544,7 @@ def main():
         cores = max(1, min(usable, args.cpu_threads))   # torch CPU convs stop scaling (and thrash) far below 256 threads
         torch.set_num_threads(cores)
         nb = args.cpu_batch                              # bounded sample: a few patches, same per-patch work
-        xb, yb = synthetic_batch(1234, nb)
+        xb, yb = synthetic_batch(1234, nb, lr_hw=P)
         t1 = time.perf_counter()
         oh.run_train(xb, yb, extra_channels=cpu_meta)
         warm = time.perf_counter() - t1
@@ -425,20 +556,20 @@ def main():
             dt = time.perf_counter() - t2
             best, total, timed = min(best, dt), total + dt, timed + 1
         cpu = {'value': round(nb / best, 3), 'unit': 'LR patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-               'sample': '1 warm-up + %d timed %s x4 train steps of %d 48x48 patches (%.1f s of CPU work; value = best step, mean step %.3f s), '
+               'sample': '1 warm-up + %d timed %s x4 train steps of %d %dx%d patches (%.1f s of CPU work; value = best step, mean step %.3f s), '
                          'torch CPU fp32 oracle; host reports %d logical CPUs, %d usable under the cgroup quota'
-                         % (timed, {'edsr': 'EDSR-baseline'}.get(args.model, args.model.upper()), nb, total, total / timed, os.cpu_count() or 0, usable),
+                         % (timed, {'edsr': 'EDSR-baseline'}.get(args.model, args.model.upper()), nb, P, P, total, total / timed, os.cpu_count() or 0, usable),
                's_per_step': round(best, 3), 'warmup_s': round(warm, 3)}
 
     if rank == 0:
-        line = {'metric': '48px LR patches/sec (train step) %s x4 bf16' % args.model.upper(), 'value': round(value, 2), 'unit': 'LR patches/s',
+        line = {'metric': '%dpx LR patches/sec (train step) %s x4 bf16' % (P, args.model.upper()), 'value': round(value, 2), 'unit': 'LR patches/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
                 'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
                          'random-init weights (seed 8)') if args.device_patches else
                         'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
                 'config': {'workload': ('EDSR-baseline x4 (64 feats x 16 blocks)' if args.model == 'edsr' else 'EDSR x4 (256 feats x 32 blocks, the reference\'s div2k/edsr.toml)' if args.model == 'edsr256' else 'RCAN x4 (10 groups x 20 RCABs, 64 feats)' + {'qrcan': ' + meta-attention q-layers, 5 metadata entries', 'blindqrcan': ' + frozen contrastive degradation encoder (256-vector) driving q-layers in group 0 block 0'}.get(args.model, '')) +
-                                       ' train step, 48x48 LR patches, batch %d per GPU' % N,
+                                       ' train step, %dx%d LR patches, batch %d per GPU' % (P, P, N),
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),
                            'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4)},

@@ -84,7 +84,10 @@ int rumpy_debug_conv_stamps(const rumpy_conv_args* a, void* stream);
  *   w2 = conv1's data-gradient image, b2 = NULL, scale2 = 1, res2 = extra skip gradient or NULL; T = gradient w.r.t. the activation.
  * RCAB (architectures.py:60-84) forward: as ResBlock with res_mode = 1, scale2 = 1 and `pool` set (the channel-attention gate
  * and the skip follow in rumpy_ca_*); its data gradient: X = gradient after the gate, res_mode = 2, res1 = dOUT of the RCAB.
- * All tensors [N,H,W,64] bf16, W <= 48 (a strip spans the image width); `t` may be NULL (inference: the activation is not stored). */
+ * All tensors [N,H,W,64] bf16 (fp16: `fmt`); `t` may be NULL (inference: the activation is not stored).  Any W: up to 48 columns a
+ * strip of 6 rows spans the image; wider images (ABI 3) are cut into column tiles of 32 or 48 output columns whose workgroups also
+ * compute the intermediate activation on one halo column per side (the reference's shipped training crops are 64 x 64,
+ * Documentation/sample_config_files/div2k/edsr.toml:16,26; every evaluation image is wider than 48). */
 typedef struct {
   const void* x;
   const void* w1; const float* b1;
@@ -100,14 +103,16 @@ typedef struct {
   int32_t res_mode;    /* 0: OUT = X + ..., the residual operand is the block input (taken from LDS) ; 1: no residual ;
                           2: the residual operand is `res1` */
   const void* res1;    /* [N,H,W,64] bf16, res_mode 2 */
-  float* pool;         /* NULL, or per-(strip, row half) channel sums of scale2*(convB(T)+b2): [N][2*ceil(H/6)][64] fp32, the
-                          partial sums rumpy_ca_mlp_fwd reduces (same layout as rumpy_conv3x3's `pool`) */
+  float* pool;         /* NULL, or per-(column tile, strip, row half) channel sums of scale2*(convB(T)+b2):
+                          [N][rumpy_block_pool_tiles(H, W)][64] fp32, the partial sums rumpy_ca_mlp_fwd / rumpy_ca_fwd_fused reduce */
   void* maskbits;      /* NULL, or [N,H,W,8] bytes = the ReLU mask of T, one bit per channel (ResBlock form only): WRITTEN by a forward
                           launch (relu1 = 1), READ instead of `mask` by a data-gradient launch (relu1 = 0) - 1/16 of the mask traffic */
-  int32_t fmt;         /* RUMPY_FMT_*; F16 only for the ResBlock forward form (relu1 = 1, scale1 = 1, no mask, res_mode 0, no pool) */
-  int32_t pad_;
+  int32_t fmt;         /* RUMPY_FMT_*; F16 for the forward forms (ResBlock: relu1 = 1, scale1 = 1, no mask; RCAB: res_mode 1 / 2) */
+  int32_t col_tile;    /* 0: automatic (one strip across the image up to W = 48, column tiles of 32 or 48 columns beyond);
+                          2 / 3: column tiles of 32 / 48 columns whatever W (tests: the two geometries against each other); not with `pool` */
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
+int rumpy_block_pool_tiles(int32_t H, int32_t W);   /* rows of `pool` per image: 2 * ceil(H/6) * column tiles */
 
 /* ---- a whole residual channel-attention block per launch (conv_rcab.hip): RCAB, rumpy/SISR/models/advanced/architectures.py:60-84, and
  * QRCAB, rumpy/SISR/models/attention_manipulators/architectures.py:154-228 (gate_q = `qgate`).
@@ -115,10 +120,10 @@ int rumpy_conv_block(const rumpy_block_args* a, void* stream);
  *                    w1 / w2 = forward filter images of conv1 / conv2; t, t2 = stores of t1, t2 (training) or NULL; mean, hidden, gate: out.
  *   rumpy_rcab_bwd:  x = dy ; ds = sum_hw(dy*t2_in) -> dz [, dzq] ; d_t2 = dy*gate[*qgate] + dp/HW -> t2 ; t = [mask > 0] . conv2^T(d_t2) ;
  *                    out = dy + conv1^T(t).  w1 / w2 = DATA-GRADIENT filter images of conv2 / conv1; hidden, gate: in (from the forward launch).
- * The strips of an image (6 rows each) exchange 64 partial sums through `xchg` (rumpy_rcab_xchg_bytes(N, H) bytes, zeroed ONCE at
+ * The strips of an image (6 rows each; times column tiles when W > 48) exchange 64 partial sums through `xchg` (rumpy_rcab_xchg_bytes(N, H, W) bytes, zeroed ONCE at
  * allocation; one buffer can serve every block of a network, launches on one stream are serialised) as records tagged
  * (*epoch << 12) + seq: `epoch` is a device word the caller advances between passes (rumpy_rcab_epoch_advance), `seq` < 4096 must differ
- * between the launches of one pass.  Needs W <= 48, ceil(H/6) <= CUs, and the GPU to itself while a launch runs (kernels of other
+ * between the launches of one pass.  Needs rumpy_rcab_strips(H, W) <= CUs, and the GPU to itself while a launch runs (kernels of other
  * processes / streams on the same XCDs can make the strips of an image wait for each other in a circle).  *status (device word, zero it
  * once) becomes 0x300 + seq if an exchange timed out: the results of that launch are invalid. */
 typedef struct {
@@ -137,7 +142,8 @@ typedef struct {
 } rumpy_rcab_args;
 int rumpy_rcab_fwd(const rumpy_rcab_args* a, void* stream);
 int rumpy_rcab_bwd(const rumpy_rcab_args* a, void* stream);
-int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H);
+int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H, int32_t W);
+int rumpy_rcab_strips(int32_t H, int32_t W);      /* workgroups per image = ceil(H/6) * column tiles: must be <= the device's CUs */
 int rumpy_rcab_epoch_advance(void* epoch, void* stream);
 
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----

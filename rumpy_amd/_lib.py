@@ -224,7 +224,7 @@ class BlockArgs(_S):
     _fields_ = [('x', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('mask', c_void_p),
                 ('res2', c_void_p), ('t', c_void_p), ('out', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32),
                 ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float), ('res_mode', c_int32), ('res1', c_void_p),
-                ('pool', c_void_p), ('maskbits', c_void_p), ('fmt', c_int32), ('pad_', c_int32)]
+                ('pool', c_void_p), ('maskbits', c_void_p), ('fmt', c_int32), ('col_tile', c_int32)]
 
 
 class SsimArgs(_S):
@@ -271,7 +271,9 @@ SYMBOLS = {
     'rumpy_head_wgrad': (C.c_int, [_P(HeadWgradArgs), c_void_p]),
     'rumpy_rcab_fwd': (C.c_int, [_P(RcabArgs), c_void_p]),
     'rumpy_rcab_bwd': (C.c_int, [_P(RcabArgs), c_void_p]),
-    'rumpy_rcab_xchg_bytes': (c_int64, [c_int32, c_int32]),
+    'rumpy_rcab_xchg_bytes': (c_int64, [c_int32, c_int32, c_int32]),
+    'rumpy_rcab_strips': (C.c_int, [c_int32, c_int32]),
+    'rumpy_block_pool_tiles': (C.c_int, [c_int32, c_int32]),
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
     'rumpy_enc_conv': (C.c_int, [_P(EncConvArgs), c_void_p]),
     'rumpy_enc_bn_train': (C.c_int, [_P(EncBnArgs), c_void_p]),

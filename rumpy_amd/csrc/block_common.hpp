@@ -11,11 +11,43 @@ constexpr int BTHREADS = 512;
 constexpr int BPIECES = BXROWS * BCOLS * 8;         // 4000 16-byte pieces of the input tile
 constexpr int BREGS = (BPIECES + BTHREADS - 1) / BTHREADS;   // 8
 
+// ---- geometry of a workgroup's strip (round 3: the one-launch kernels take images wider than one strip) ----
+// NC = 16-column MFMA tiles per output row.  CT = false: the strip spans the image (W <= 16 NC): one zero halo column per side in both LDS
+// images (the round-1/2 geometry = BlockGeo<3, false>).  CT = true: the image is cut into column tiles of OW = 16 NC output columns; the
+// second conv then needs T on one REAL halo column per side, so the input image carries two halo columns per side and every wave computes
+// one more (half-filled) MFMA tile in the first phase: its 4 T rows x the 2 halo columns (block_common.hpp::halo_sweep).
+template <int NC_, bool CT_> struct BlockGeo {
+  static constexpr int NC = NC_, OW = 16 * NC_;
+  static constexpr bool CT = CT_;
+  static constexpr int XH = CT_ ? 2 : 1;                 // halo columns per side of the input image
+  static constexpr int XC = OW + 2 * XH;                 // columns of the input image in LDS
+  static constexpr int TC = OW + 2;                      // columns of the T image in LDS
+  static constexpr int XBYTES = BXROWS * XC * 128, TBYTES = BTROWS * TC * 128;
+  static constexpr int XPIECES = BXROWS * XC * 8;        // 16-byte pieces of the input tile
+  static constexpr int XREGS = (XPIECES + BTHREADS - 1) / BTHREADS;
+  static constexpr int GPIECES = 3 * OW * 8;             // a row half's 3 strip rows as 16-byte pieces
+  static constexpr int GREGS = (GPIECES + 255) / 256;
+  static constexpr int SPIECES = BSH * OW * 8;           // the whole strip
+  static constexpr int SREGS = (SPIECES + BTHREADS - 1) / BTHREADS;
+};
+typedef BlockGeo<3, false> GeoL;       // W <= 48: BXBYTES / BTBYTES / BCOLS above
+
+// column tiles of a W-pixel-wide image: 48- or 32-column tiles, whichever costs less with a workgroup priced at (its 16-column units + 1):
+// the halo tile, the two extra input columns per side and what a workgroup pays once (prologue, epilogue tails) are about one unit's time.
+// 64 columns -> 2 x 32 (the reference's training crops), 100 -> 3 x 48, 128 -> 3 x 48, 510 -> 11 x 48.
+static inline void block_col_tiles(int W, int* nc, int* ct_n) {
+  if (W <= BSW) { *nc = 3; *ct_n = 1; return; }
+  const int units = (W + 15) / 16;
+  const int t3 = (units + 2) / 3, t2 = (units + 1) / 2;
+  if (4 * t3 <= 3 * t2) { *nc = 3; *ct_n = t3; } else { *nc = 2; *ct_n = t2; }
+}
+
 struct BlockDev {
   const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
   const uint16_t* mask; const uint16_t* res2; uint16_t* t; uint16_t* out;
   int N, H, W, sy_n, relu1; float scale1, scale2;
   int res_mode; const uint16_t* res1; float* pool;
+  int ct_n;                  // column tiles per strip row (1 when the strip spans the image)
   unsigned char* mbits;      // ReLU mask as one byte per 8 channels: written by the forward form, read by the data-gradient form (or NULL)
 };
 
@@ -26,22 +58,23 @@ __device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p 
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // hook(grp) runs after the MFMAs of group grp have been issued: the place for work that should travel under the matrix pipe
 // (the HBM stores of the previous phase's tile, block_common.hpp::strip_store_piece)
-template <int ROWS, int FMT = RUMPY_FMT_BF16, class Hook = NoHook>
-__device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2],
+template <int ROWS, int FMT = RUMPY_FMT_BF16, class Hook = NoHook, int NC = 3, int COLS = BCOLS>
+__device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2],
                                             Hook hook = Hook()) {
+  constexpr int NG = 6 * NC;            // (channel half, tap column, column tile) groups
   bf16x8 I[2][ROWS + 2];
   auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
-    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+    const int half = grp / (3 * NC), kx = (grp % (3 * NC)) / NC, c = grp % NC;
 #pragma unroll
     for (int r = 0; r < ROWS + 2; ++r)
-      dst[r] = *reinterpret_cast<const bf16x8*>(lds + off[(2 * r + kx) & 7][half] + (r * BCOLS + 16 * c + kx) * 128);
+      dst[r] = *reinterpret_cast<const bf16x8*>(lds + off[(r * COLS + kx) & 7][half] + (r * COLS + 16 * c + kx) * 128);
   };
   load_group(0, I[0]);
 #pragma unroll
-  for (int grp = 0; grp < 18; ++grp) {
-    if (grp + 1 < 18) load_group(grp + 1, I[(grp + 1) & 1]);
+  for (int grp = 0; grp < NG; ++grp) {
+    if (grp + 1 < NG) load_group(grp + 1, I[(grp + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs
-    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+    const int half = grp / (3 * NC), kx = (grp % (3 * NC)) / NC, c = grp % NC;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -51,14 +84,36 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][3], const bf16x8 
   }
 }
 
-// per-lane read bases of a phase: window row 0 = row `row0` of the image at byte `buffer` of the LDS allocation (folded in here so
-// that every read is one register + a 16-bit immediate)
-__device__ __forceinline__ void sweep_bases(unsigned (&off)[8][2], unsigned buffer, int row0, int px, int g) {
-  const int p0 = row0 * BCOLS + px;
+// per-lane read bases of a phase: window row 0 = row `row0` of the image (COLS columns) at byte `buffer` of the LDS allocation, window
+// column 0 = image column c0 (folded in here so that every read is one register + a 16-bit immediate)
+template <int COLS = BCOLS>
+__device__ __forceinline__ void sweep_bases(unsigned (&off)[8][2], unsigned buffer, int row0, int px, int g, int c0 = 0) {
+  const int p0 = row0 * COLS + px + c0;
 #pragma unroll
   for (int d = 0; d < 8; ++d)
 #pragma unroll
     for (int h = 0; h < 2; ++h) off[d][h] = buffer + (unsigned)(p0 * 128 + (((4 * h + g) ^ ((p0 + d) & 7)) << 4));
+}
+
+// ---- column-tiled strips: T on the two halo columns (block_common.hpp::BlockGeo) ----
+// One MFMA tile per wave whose 16 "pixels" are lane px -> (T row 4 rh + ((px >> 1) & 3), halo side px & 1); lanes px >= 8 repeat lanes
+// px - 8 (their results are not used).  Same accumulation order per output element as block_sweep: (channel half, tap column) groups,
+// tap row innermost - the values are bitwise those of a tile that holds the same pixels in any other arrangement.
+// hoff: sweep_bases-style bases of the lane's own input window (row = its T row, column = its T column in input-image columns).
+template <int FMT, int COLS>
+__device__ __forceinline__ f32x4 halo_sweep(f32x4 acc, const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&hoff)[8][2]) {
+  bf16x8 I[18];
+#pragma unroll
+  for (int t = 0; t < 18; ++t) {
+    const int half = t / 9, kx = (t % 9) / 3, ky = t % 3;
+    I[t] = *reinterpret_cast<const bf16x8*>(lds + hoff[(ky * COLS + kx) & 7][half] + (ky * COLS + kx) * 128);
+  }
+#pragma unroll
+  for (int t = 0; t < 18; ++t) {
+    const int half = t / 9, kx = (t % 9) / 3, ky = t % 3;
+    acc = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[t], acc);
+  }
+  return acc;
 }
 
 // exchange between lane g and g ^ 1 so that even-g lanes end up with 8 consecutive channels of tile X's pixel and odd-g lanes
@@ -132,19 +187,22 @@ __device__ __forceinline__ void st16_nt(uint16_t* p, uint4 v) {
 }
 constexpr int STRIP_PIECES = BSH * BSW * 8;         // 2304
 constexpr int STRIP_REGS = (STRIP_PIECES + BTHREADS - 1) / BTHREADS;   // 5
-// LDS pixel row of strip row 0: ROW0 = 1 in the T image, 2 in the input image
-template <int ROW0>
-__device__ __forceinline__ void strip_stage(uint4 (&S)[STRIP_REGS], const unsigned char* img, int tid) {
+// LDS pixel row of strip row 0: ROW0 = 1 in the T image, 2 in the input image (which also selects the image's column count and the
+// column of strip column 0: geometry G)
+template <int ROW0, class G = GeoL>
+__device__ __forceinline__ void strip_stage(uint4 (&S)[G::SREGS], const unsigned char* img, int tid) {
+  constexpr int COLS = ROW0 == 2 ? G::XC : G::TC, CO = ROW0 == 2 ? G::XH : 1;
 #pragma unroll
-  for (int i = 0; i < STRIP_REGS; ++i) {
-    const int p = tid + BTHREADS * i, pix = (p < STRIP_PIECES ? p : 0) >> 3, r = pix / BSW, col = pix - r * BSW;
-    S[i] = *reinterpret_cast<const uint4*>(img + swz((r + ROW0) * BCOLS + col + 1, p & 7));
+  for (int i = 0; i < G::SREGS; ++i) {
+    const int p = tid + BTHREADS * i, pix = (p < G::SPIECES ? p : 0) >> 3, r = pix / G::OW, col = pix - r * G::OW;
+    S[i] = *reinterpret_cast<const uint4*>(img + swz((r + ROW0) * COLS + col + CO, p & 7));
   }
 }
-// element offset of piece i in an [N,H,W,64] tensor, or 0xffffffff when the pixel lies outside the image
-__device__ __forceinline__ unsigned strip_piece_off(int i, int tid, int n, int sy, int H, int W) {
-  const int p = tid + BTHREADS * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW, y = sy * BSH + r;
-  return (p < STRIP_PIECES && y < H && col < W) ? (unsigned)(((n * H + y) * W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+// element offset of piece i in an [N,H,W,64] tensor, or 0xffffffff when the pixel lies outside the image (x0 = image column of strip column 0)
+template <class G = GeoL>
+__device__ __forceinline__ unsigned strip_piece_off(int i, int tid, int n, int sy, int H, int W, int x0 = 0) {
+  const int p = tid + BTHREADS * i, pix = p >> 3, r = pix / G::OW, col = pix - r * G::OW, y = sy * BSH + r;
+  return (p < G::SPIECES && y < H && x0 + col < W) ? (unsigned)(((n * H + y) * W + x0 + col) * 64 + (p & 7) * 8) : 0xffffffffu;
 }
 
 
@@ -162,15 +220,17 @@ __device__ __forceinline__ void gate_wait(unsigned* cnt, unsigned target) {
 // a group's 3 strip rows as 16-byte pieces: p = tg + 256 i (tg = thread within the group, i < 5, p < 1152) = chunk p & 7 of pixel p >> 3
 constexpr int GROUP_PIECES = 3 * BSW * 8;            // 1152
 constexpr int GROUP_REGS = (GROUP_PIECES + 255) / 256;   // 5 (the last one half used)
-template <int ROW0>
-__device__ __forceinline__ void group_stage(uint4 (&S)[GROUP_REGS], const unsigned char* img, int tg, int rh) {
+template <int ROW0, class G = GeoL>
+__device__ __forceinline__ void group_stage(uint4 (&S)[G::GREGS], const unsigned char* img, int tg, int rh) {
+  constexpr int COLS = ROW0 == 2 ? G::XC : G::TC, CO = ROW0 == 2 ? G::XH : 1;
 #pragma unroll
-  for (int i = 0; i < GROUP_REGS; ++i) {
-    const int p = tg + 256 * i, pix = (p < GROUP_PIECES ? p : 0) >> 3, r = pix / BSW, col = pix - r * BSW;
-    S[i] = *reinterpret_cast<const uint4*>(img + swz((3 * rh + r + ROW0) * BCOLS + col + 1, p & 7));
+  for (int i = 0; i < G::GREGS; ++i) {
+    const int p = tg + 256 * i, pix = (p < G::GPIECES ? p : 0) >> 3, r = pix / G::OW, col = pix - r * G::OW;
+    S[i] = *reinterpret_cast<const uint4*>(img + swz((3 * rh + r + ROW0) * COLS + col + CO, p & 7));
   }
 }
-__device__ __forceinline__ unsigned group_piece_off(int i, int tg, int rh, int n, int sy, int H, int W) {
-  const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW, y = sy * BSH + 3 * rh + r;
-  return (p < GROUP_PIECES && y < H && col < W) ? (unsigned)(((n * H + y) * W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+template <class G = GeoL>
+__device__ __forceinline__ unsigned group_piece_off(int i, int tg, int rh, int n, int sy, int H, int W, int x0 = 0) {
+  const int p = tg + 256 * i, pix = p >> 3, r = pix / G::OW, col = pix - r * G::OW, y = sy * BSH + 3 * rh + r;
+  return (p < G::GPIECES && y < H && x0 + col < W) ? (unsigned)(((n * H + y) * W + x0 + col) * 64 + (p & 7) * 8) : 0xffffffffu;
 }

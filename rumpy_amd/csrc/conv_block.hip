@@ -19,6 +19,13 @@
 // (checked by enumeration against the 4 x 16-lane groups of MI355X_MICROARCH.md, LDS table).  The XOR term of a read depends
 // on lane constants and on (2*row + tap column) & 7 only (50 = 2 mod 8, 16 = 0 mod 8): 8 x 2 per-lane base addresses are
 // prepared per phase and every read is base + immediate.
+//
+// Round 3: images wider than one strip.  G = BlockGeo<NC, true> (block_common.hpp) cuts the image into column tiles of 16 NC output
+// columns (NC = 2 or 3; 64 x 64 crops - the reference's shipped training shape - are two tiles of 32): the input image in LDS then has
+// two halo columns per side, and T on the one halo column per side that convB needs is one more MFMA tile per wave (its 4 T rows x 2
+// columns = 8 of the tile's 16 pixels; halo_sweep), computed before the main sweep of the first phase.  Everything else - work split,
+// sweeps, row-half gates, whole-line stores - is the W <= 48 kernel with the geometry as a template parameter; per accumulator the MFMA
+// order is unchanged, so the results are bitwise those of the two-launch path (test_conv_block_column_tiles_*).
 #include "block_common.hpp"
 
 #ifndef BLOCK_OUT_PLAIN
@@ -35,34 +42,41 @@
 // form (no ReLU, * scale1, mask = a bf16 activation); 3 = data-gradient form with the mask as bytes (block_common.hpp::relu_bits):
 // the two forms the engine launches, without the per-value selects and branches of the generic epilogue.
 // FMT: element format (RUMPY_FMT_F16 is instantiated for the ResBlock forward form only: evaluation plans)
-template <bool GEN, int FORM = 0, int FMT = RUMPY_FMT_BF16>
+template <bool GEN, int FORM = 0, int FMT = RUMPY_FMT_BF16, class G = GeoL>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  constexpr int NC = G::NC, XC = G::XC, TC = G::TC, XH = G::XH;
+  constexpr int NP1 = NC == 3 ? 6 : 4;     // paired tiles of the first phase (4 rows x NC column tiles)
+  constexpr int NP2 = NC == 3 ? 4 : 3;     // ... of the second phase (3 rows x NC; NC = 3 leaves one single tile)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::XBYTES + G::TBYTES];
   __shared__ unsigned gate[4];             // waves of row half 0 / 1 that have written their T rows, their OUT rows (block_common.hpp::gate_*)
   unsigned char* const ldx = lds;
-  unsigned char* const ldt = lds + BXBYTES;
+  unsigned char* const ldt = lds + G::XBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int q = wave & 3, rh = __builtin_amdgcn_readfirstlane(wave >> 2), tg = tid & 255;
   const int strip = xcd_strip(blockIdx.x, gridDim.x);
-  const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+  // strip -> (image, column tile, strip row), strip rows fastest: vertical neighbours (4 shared input rows of 10) sit next to each other
+  int n, sy, ct = 0;
+  if (G::CT) { sy = strip % a.sy_n; const int r = strip / a.sy_n; ct = r % a.ct_n; n = r / a.ct_n; }
+  else { n = strip / a.sy_n; sy = strip - n * a.sy_n; }
+  const int x0 = ct * G::OW;               // image column of the strip's first output column
   unsigned long long stamps[8];
   unsigned long long cyc[4] = {0ull, 0ull, 0ull, 0ull};       // (stamp build) shader-clock counter at the start / end of the two sweeps
   int nst = 0;
 #define BK_STAMP() do { if (BLOCK_ABL == 9 && nst < 8) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
   BK_STAMP();                              // 0: start
 
-  // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
+  // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns x0-XH .. x0+OW+XH-1 -> LDS (branch-free loads, zero outside the image) ----
   {
-    uint4 R[BREGS];
+    uint4 R[G::XREGS];
     const int y0 = sy * BSH - 2;
 #pragma unroll
-    for (int i = 0; i < BREGS; ++i) {
+    for (int i = 0; i < G::XREGS; ++i) {
       const int p = tid + BTHREADS * i;
       const int pix = p >> 3, part = p & 7;
-      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
-      const int y = y0 + lr, x = lc - 1;
-      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const int lr = pix / XC, lc = pix - lr * XC;
+      const int y = y0 + lr, x = x0 - XH + lc;
+      const bool ok = (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
       uint4 v = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
       if (BLOCK_ABL != 5) v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
@@ -70,16 +84,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       R[i] = v;
     }
     if (tid < 4) gate[tid] = 0u;
-    // border columns of the T image are convB's zero padding and are never written by the epilogue
-    if (tid < BTROWS * 2 * 8) {
+    // border columns of the T image: convB's zero padding, never written by the epilogue (column tiles: real T values, written by the halo tile)
+    if (!G::CT && tid < BTROWS * 2 * 8) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
-      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < BREGS; ++i) {
+    for (int i = 0; i < G::XREGS; ++i) {
       const int p = tid + BTHREADS * i;
       const int pix = p >> 3, part = p & 7;
-      if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+      if (p < G::XPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
     }
   }
   bf16x8 F[18];
@@ -96,13 +110,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
   // tile pairs: k < 4: X = (row k, col tile 0), Y = (row k, col tile 1); k = 4: X = (0, 2), Y = (1, 2); k = 5: X = (2, 2), Y = (3, 2)
-  unsigned moff[6];
-  uint4 M[(FORM == 1 || FORM == 3) ? 1 : 6];
-  unsigned MB[FORM == 3 ? 6 : 1];
+  unsigned moff[NP1];
+  uint4 M[(FORM == 1 || FORM == 3) ? 1 : NP1];
+  unsigned MB[FORM == 3 ? NP1 : 1];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < NP1; ++k) {
     const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
-    const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+    const int y = sy * BSH - 1 + 4 * rh + jr, xx = x0 + 16 * c + px;
     const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
     moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
     if (FORM == 0 || FORM == 2) {
@@ -111,16 +125,26 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     }
     if (FORM == 3) MB[FORM == 3 ? k : 0] = a.mbits[(in ? moff[k] : 0u) >> 3];
   }
+  // column tiles: this lane's pixel of the halo tile = T row hj, halo side px & 1 (lanes px >= 8 repeat lanes px - 8 and store nothing)
+  const int hj = 4 * rh + ((px >> 1) & 3), htc = (px & 1) ? TC - 1 : 0;
+  unsigned hoffe = 0xffffffffu;            // element offset of (that pixel, channel c0) in an [N,H,W,64] tensor, or outside the image
+  uint2 HM = make_uint2(0, 0);
+  unsigned HB = 0;
+  if (G::CT) {
+    const int y = sy * BSH - 1 + hj, xx = x0 - 1 + htc;
+    if (((unsigned)y < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W)) hoffe = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
+    if (FORM == 2 || (FORM == 0 && a.mask)) HM = *reinterpret_cast<const uint2*>(a.mask + (hoffe != 0xffffffffu ? hoffe : 0u));
+    if (FORM == 3) HB = a.mbits[(hoffe != 0xffffffffu ? hoffe : 0u) >> 3];
+  }
   {
-    f32x4 acc[4][3];
+    f32x4 acc[4][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.b1) { const float4 t = *reinterpret_cast<const float4*>(a.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+      for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     unsigned off[8][2];
-    sweep_bases(off, 0u, 4 * rh, px, g);
     auto post1 = [&](f32x4 t) -> f32x4 {
       if (FORM == 1 || (FORM == 0 && a.relu1)) {
 #pragma unroll
@@ -133,8 +157,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       return t;
     };
     auto t_pair = [&](int k) {          // k is a constant after unrolling
-      const f32x4 tx = post1((k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2]);
-      const f32x4 ty = post1((k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2]);
+      const f32x4 tx = post1((k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][NC - 1]);
+      const f32x4 ty = post1((k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][NC - 1]);
       float v[8];
       pair_up(tx, ty, g, v);
       const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
@@ -146,10 +170,27 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
         if (FORM == 2 || (FORM == 0 && a.mask)) o = relu_mask_packed(o, M[(FORM == 1 || FORM == 3) ? 0 : k]);
         if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
       }
-      *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
+      *reinterpret_cast<uint4*>(ldt + swz(j * TC + xx + 1, chunk8)) = o;
     };
     if (BLOCK_ABL == 9) cyc[0] = __builtin_amdgcn_s_memtime();
-    block_sweep<4, FMT>(acc, F, lds, off);
+    if (G::CT) {
+      // T on the halo columns first (its accumulator is dead before the main sweep's 4 x NC tiles are live)
+      sweep_bases<XC>(off, 0u, hj, 0, g, htc);
+      const f32x4 th = post1(halo_sweep<FMT, XC>(b4, F, lds, off));
+      uint2 o = make_uint2(0, 0);
+      if (hoffe != 0xffffffffu) {
+        o = pack4<FMT>(th[0], th[1], th[2], th[3]);
+        if (FORM == 2 || (FORM == 0 && a.mask)) o = make_uint2(o.x & relu_keep(HM.x), o.y & relu_keep(HM.y));
+        if (FORM == 3) {
+          const unsigned b = HB >> (4 * (g & 1));
+          const uint4 m4 = relu_mask_bits(make_uint4(o.x, o.y, 0, 0), b);
+          o = make_uint2(m4.x, m4.y);
+        }
+      }
+      if (px < 8) *reinterpret_cast<uint2*>(ldt + swz(hj * TC + htc, 2 * q + (g >> 1)) + (g & 1) * 8) = o;
+    }
+    sweep_bases<XC>(off, 0u, 4 * rh, px, g, G::CT ? 1 : 0);
+    block_sweep<4, FMT, NoHook, NC, XC>(acc, F, lds, off);
     if (BLOCK_ABL == 9) cyc[1] = __builtin_amdgcn_s_memtime();
     BK_STAMP();                            // 2: first sweep done
     // second filter: L2 hits that land under the epilogue
@@ -159,13 +200,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) t_pair(k);
+    for (int k = 0; k < NP1; ++k) t_pair(k);
     gate_arrive(&gate[rh], lane);          // this wave's 16 channels of T rows 4rh .. 4rh+3 are in LDS
     BK_STAMP();                            // 3: T image written
   }
-  unsigned soff[GROUP_REGS];               // element offsets of this thread's pieces of its row half's 3 strip rows (T and OUT stores)
+  unsigned soff[G::GREGS];                 // element offsets of this thread's pieces of its row half's 3 strip rows (T and OUT stores)
 #pragma unroll
-  for (int i = 0; i < GROUP_REGS; ++i) soff[i] = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+  for (int i = 0; i < G::GREGS; ++i) soff[i] = group_piece_off<G>(i, tg, rh, n, sy, a.H, a.W, x0);
   // No workgroup barrier between the phases: output rows 0, 1 need T rows 0 .. 3 (row half 0's own), output row 2 also row 4, output rows
   // 3 .. 5 T rows 3 .. 7 - each row half waits for exactly the T rows it reads (block_common.hpp: row-half groups).  The input image is
   // overwritten (OUT, in place) only behind a wait for the OTHER half's T rows, i.e. when nobody sweeps over it any more.
@@ -174,12 +215,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   BK_STAMP();                              // 4: this row half's T rows complete
   // The row half's own strip rows of T (and their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal, one
   // piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage).
-  uint4 S[GROUP_REGS];
+  uint4 S[G::GREGS];
   const bool t_out = (a.t != nullptr) && BLOCK_ABL != 4;
-  if (t_out) group_stage<1>(S, ldt, tg, rh);
+  if (t_out) group_stage<1, G>(S, ldt, tg, rh);
   auto t_store = [&](int grp) {           // grp is a constant after unrolling: piece i after the MFMAs of group 3 i
-    if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
-      const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
+    if (grp % 3 == 0 && grp / 3 < G::GREGS) {
+      const int i = grp / 3 < G::GREGS ? grp / 3 : 0;
       if (t_out && soff[i] != 0xffffffffu) {
         st16_nt(a.t + soff[i], S[i]);
         if (FORM == 1 && a.mbits) a.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
@@ -189,41 +230,43 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
 
   // ---- phase 2: output rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ; OUT = X + scale2 * (convB(T) + b2) [+ res2] ----
   {
-    f32x4 acc[3][3];
+    f32x4 acc[3][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.b2) { const float4 t = *reinterpret_cast<const float4*>(a.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+      for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     // GEN, res_mode 2: the residual vectors are requested before the sweep and land under it
-    unsigned roff[4], rsoff;
-    uint4 P1p[GEN ? 4 : 1];
+    unsigned roff[NP2], rsoff = 0xffffffffu;
+    uint4 P1p[GEN ? NP2 : 1];
     uint2 P1s = make_uint2(0, 0);
     if (GEN) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NP2; ++k) {
         const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-        const int y = sy * BSH + 3 * rh + r, xx = 16 * c + px;
+        const int y = sy * BSH + 3 * rh + r, xx = x0 + 16 * c + px;
         roff[k] = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
         P1p[k] = make_uint4(0, 0, 0, 0);
         if (a.res_mode == 2) P1p[k] = *reinterpret_cast<const uint4*>(a.res1 + (roff[k] != 0xffffffffu ? roff[k] : 0u));
       }
-      const int y = sy * BSH + 3 * rh + 2, xx = 32 + px;
-      rsoff = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0) : 0xffffffffu;
-      if (a.res_mode == 2) P1s = *reinterpret_cast<const uint2*>(a.res1 + (rsoff != 0xffffffffu ? rsoff : 0u));
+      if (NC == 3) {
+        const int y = sy * BSH + 3 * rh + 2, xx = x0 + 32 + px;
+        rsoff = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0) : 0xffffffffu;
+        if (a.res_mode == 2) P1s = *reinterpret_cast<const uint2*>(a.res1 + (rsoff != 0xffffffffu ? rsoff : 0u));
+      }
     }
     unsigned off[8][2];
     if (BLOCK_ABL == 9) cyc[2] = __builtin_amdgcn_s_memtime();
     if (rh == 0) {
-      sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
-      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), F, lds, off, t_store);       // output rows 0, 1 <- T rows 0 .. 3
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, 0, px, g);
+      block_sweep<2, FMT, decltype(t_store), NC, TC>(*reinterpret_cast<f32x4(*)[2][NC]>(&acc[0]), F, lds, off, t_store);   // output rows 0, 1 <- T rows 0 .. 3
       gate_wait(&gate[1], 4u);
-      sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
-      block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), F, lds, off);                // output row 2 <- T rows 2 .. 4
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, 2, px, g);
+      block_sweep<1, FMT, NoHook, NC, TC>(*reinterpret_cast<f32x4(*)[1][NC]>(&acc[2]), F, lds, off);                        // output row 2 <- T rows 2 .. 4
     } else {
-      sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
-      block_sweep<3, FMT>(acc, F, lds, off, t_store);                                              // output rows 3 .. 5 <- T rows 3 .. 7
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, 3, px, g);
+      block_sweep<3, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                           // output rows 3 .. 5 <- T rows 3 .. 7
     }
     if (BLOCK_ABL == 9) cyc[3] = __builtin_amdgcn_s_memtime();
     BK_STAMP();                            // 5: second sweep done
@@ -231,16 +274,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    //                paired tiles, channels 4(g&~1) .. +7
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][2];
-      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][2];
+    for (int k = 0; k < NP2; ++k) {
+      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][NC - 1];
+      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][NC - 1];
       float v[8], m[8];
       pair_up(tx, ty, g, v);
       const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
       const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
-      if (y < a.H && xx < a.W) {
+      if (y < a.H && x0 + xx < a.W) {
         if (!GEN) {
-          unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);   // residual = the input tile
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * XC + xx + XH, chunk8)), m);   // residual = the input tile
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
         } else {
@@ -257,22 +300,22 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
           }
         }
         if (a.res2) {
-          const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair);
+          const unsigned o = (unsigned)(((n * a.H + y) * a.W + x0 + xx) * 64 + 16 * q + gpair);
           unpack8<FMT>(*reinterpret_cast<const uint4*>(a.res2 + o), m);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
         const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
-        *reinterpret_cast<uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // OUT image, in place of the input pixel
+        *reinterpret_cast<uint4*>(ldx + swz((srow + 2) * XC + xx + XH, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // OUT image, in place of the input pixel
       }
     }
-    {
+    if (NC == 3) {
       const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px;
-      if (y < a.H && xx < a.W) {
-        float v[4] = {acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]};
+      if (y < a.H && x0 + xx < a.W) {
+        float v[4] = {acc[2][NC - 1][0], acc[2][NC - 1][1], acc[2][NC - 1][2], acc[2][NC - 1][3]};
         float m[4];
         if (!GEN) {
-          unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * XC + xx + XH, 2 * q + (g >> 1)) + (g & 1) * 8), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
         } else {
@@ -289,12 +332,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
           }
         }
         if (a.res2) {
-          const unsigned o = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
+          const unsigned o = (unsigned)(((n * a.H + y) * a.W + x0 + xx) * 64 + c0);
           unpack4<FMT>(*reinterpret_cast<const uint2*>(a.res2 + o), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
-        *reinterpret_cast<uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>(ldx + swz((srow + 2) * XC + xx + XH, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(v[0], v[1], v[2], v[3]);
       }
     }
     if (GEN && a.pool) {
@@ -316,7 +359,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
         ps8[4 + j] += (g & 1) ? t : up;
       }
       if (px == 0 && !(g & 1)) {
-        float* pp = a.pool + ((size_t)(n * a.sy_n * 2 + 2 * sy + rh)) * 64 + 16 * q + 4 * g;
+        // one row of partial sums per (column tile, strip row, row half) of an image
+        float* pp = a.pool + ((size_t)((n * a.ct_n + ct) * a.sy_n * 2 + 2 * sy + rh)) * 64 + 16 * q + 4 * g;
         *reinterpret_cast<float4*>(pp) = make_float4(ps8[0], ps8[1], ps8[2], ps8[3]);
         *reinterpret_cast<float4*>(pp + 4) = make_float4(ps8[4], ps8[5], ps8[6], ps8[7]);
       }
@@ -328,9 +372,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   gate_wait(&gate[2 + rh], 4u);
   BK_STAMP();                              // 6: this row half's OUT rows complete
   if (BLOCK_ABL != 4) {
-    group_stage<2>(S, ldx, tg, rh);
+    group_stage<2, G>(S, ldx, tg, rh);
 #pragma unroll
-    for (int i = 0; i < GROUP_REGS; ++i)
+    for (int i = 0; i < G::GREGS; ++i)
       if (soff[i] != 0xffffffffu) { if (BLOCK_OUT_PLAIN) *reinterpret_cast<uint4*>(a.out + soff[i]) = S[i]; else st16_nt(a.out + soff[i], S[i]); }
   }
   BK_STAMP();                              // 7: end (stores issued)
@@ -342,29 +386,54 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
 #undef BK_STAMP
 }
 
+template <class G>
+static void block_launch(const rumpy_block_args* p, const BlockDev& d, hipStream_t s) {
+  const dim3 grid(d.N * d.sy_n * d.ct_n);
+  if (p->res_mode == 0 && !p->pool) {
+    if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1, RUMPY_FMT_F16, G>), grid, dim3(BTHREADS), s, d);
+    else if (p->relu1 && p->scale1 == 1.0f && !p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+    else if (!p->relu1 && p->maskbits) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 3, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+    else if (!p->relu1 && p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 2, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+    else RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 0, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+  } else if (p->fmt == RUMPY_FMT_F16) {
+    RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<true, 0, RUMPY_FMT_F16, G>), grid, dim3(BTHREADS), s, d);
+  } else {
+    RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<true, 0, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+  }
+}
+
+// rows of per-image pool partial sums a rumpy_conv_block launch with `pool` writes: 2 per (strip row, column tile)
+extern "C" int rumpy_block_pool_tiles(int32_t H, int32_t W) {
+  int nc, ct_n;
+  block_col_tiles(W, &nc, &ct_n);
+  return 2 * ((H + BSH - 1) / BSH) * ct_n;
+}
+
 extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
   if (!p || !p->x || !p->w1 || !p->w2 || !p->out) { rumpy_set_error("rumpy_conv_block: null pointer"); return RUMPY_E_ARG; }
-  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW) { rumpy_set_error("rumpy_conv_block: needs 0 < W <= 48 (got %d)", p->W); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("rumpy_conv_block: bad shape (N=%d H=%d W=%d)", p->N, p->H, p->W); return RUMPY_E_ARG; }
+  if ((int64_t)p->N * p->H * p->W * 64 >= (int64_t)0xffffffffu) { rumpy_set_error("rumpy_conv_block: tensor beyond 32-bit element offsets"); return RUMPY_E_ARG; }
   BlockDev d;
   d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
   d.mask = (const uint16_t*)p->mask; d.res2 = (const uint16_t*)p->res2; d.t = (uint16_t*)p->t; d.out = (uint16_t*)p->out;
   d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = (p->H + BSH - 1) / BSH; d.relu1 = p->relu1; d.scale1 = p->scale1; d.scale2 = p->scale2;
   d.res_mode = p->res_mode; d.res1 = (const uint16_t*)p->res1; d.pool = p->pool; d.mbits = (unsigned char*)p->maskbits;
+  int nc;
+  block_col_tiles(p->W, &nc, &d.ct_n);
+  bool tiled = p->W > BSW;
+  if (p->col_tile) {
+    if ((p->col_tile != 2 && p->col_tile != 3) || p->pool) { rumpy_set_error("rumpy_conv_block: col_tile is 0, 2 or 3 (and not with pool)"); return RUMPY_E_ARG; }
+    nc = p->col_tile; d.ct_n = (p->W + 16 * nc - 1) / (16 * nc); tiled = true;
+  }
   if (p->maskbits && !(p->res_mode == 0 && !p->pool && ((p->relu1 && p->scale1 == 1.0f && !p->mask) || !p->relu1))) {
     rumpy_set_error("rumpy_conv_block: maskbits goes with the ResBlock forward form (written) or a data-gradient form (read)"); return RUMPY_E_ARG; }
   if (p->res_mode < 0 || p->res_mode > 2 || (p->res_mode == 2 && !p->res1)) { rumpy_set_error("rumpy_conv_block: bad res_mode / res1"); return RUMPY_E_ARG; }
-  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && p->res_mode == 0 && !p->pool && p->relu1 && p->scale1 == 1.0f && !p->mask)) {
-    rumpy_set_error("rumpy_conv_block: fmt %d goes with the ResBlock forward form only", p->fmt); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("rumpy_conv_block: fmt %d", p->fmt); return RUMPY_E_ARG; }
+  if (p->fmt == RUMPY_FMT_F16 && p->res_mode == 0 && !p->pool && !(p->relu1 && p->scale1 == 1.0f && !p->mask)) {
+    rumpy_set_error("rumpy_conv_block: fmt %d goes with the forward forms only", p->fmt); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(d.N * d.sy_n);
-  if (p->res_mode == 0 && !p->pool) {
-    if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);
-    else if (p->relu1 && p->scale1 == 1.0f && !p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1>), grid, dim3(BTHREADS), s, d);
-    else if (!p->relu1 && p->maskbits) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 3>), grid, dim3(BTHREADS), s, d);
-    else if (!p->relu1 && p->mask) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 2>), grid, dim3(BTHREADS), s, d);
-    else RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 0>), grid, dim3(BTHREADS), s, d);
-  } else {
-    RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<true, 0>), grid, dim3(BTHREADS), s, d);
-  }
+  if (!tiled) block_launch<GeoL>(p, d, s);
+  else if (nc == 3) block_launch<BlockGeo<3, true> >(p, d, s);
+  else block_launch<BlockGeo<2, true> >(p, d, s);
   return rumpy_check_launch("rumpy_conv_block");
 }

@@ -17,6 +17,10 @@
 // in order, so the oldest unfinished image always has all of its strips on the chip as long as ceil(H/6) <= CUs (checked by the host).
 // A poll that does not complete within ~0.1 s stores a code in *status and gives up (wrong numbers, reported by the host; no hang).
 // Sums over strips are taken in strip order by every workgroup: all strips of an image use bit-identical gates, run to run.
+//
+// Round 3: images wider than 48 pixels run as column tiles (block_common.hpp::BlockGeo<NC, true>, conv_block.hip): a "strip" of the
+// exchange is then a (column tile, strip row) pair, ns = ceil(H/6) * column tiles of them per image, all of which must be resident
+// together (ns <= CUs; the reference's 64 x 64 training crops are 22).
 #include "block_common.hpp"
 
 typedef unsigned int rc_u32x2 __attribute__((ext_vector_type(2)));
@@ -32,6 +36,7 @@ struct RcabDev {
   const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
   uint16_t* t; uint16_t* t2; const uint16_t* t2_in; const uint16_t* mask; const uint16_t* res2; uint16_t* out;
   int N, H, W, sy_n;
+  int ct_n, ns;              // column tiles per strip row, strips (workgroups) per image = sy_n * ct_n
   const float* cw1; const float* cb1; const float* cw2; const float* cb2; int cr; float inv_hw;
   float* mean; float* hidden; float* gate; const float* qgate; float* dz; float* dzq;
   unsigned long long* xchg; unsigned xchg_bytes; const unsigned* epoch; unsigned seq; unsigned* status;
@@ -45,17 +50,17 @@ __device__ __forceinline__ float wave_sum(float t) {
 
 // all-gather of one fp32 per (strip, channel) among the strips of image n; returns (threads < 64: channel tid) the sum over strips
 // in strip order.  sx: LDS scratch of 8 * 64 floats.  Called by all 512 threads.
-__device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int n, int sy, int tid, unsigned tag, float* sx) {
+__device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int n, int si, int tid, unsigned tag, float* sx) {
   const rc_rsrc rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, a.xchg_bytes, 0x00020000);
   const int c = tid & 63, w = tid >> 6;
-  if (tid < 64) __builtin_amdgcn_raw_buffer_store_b64((rc_u32x2){__float_as_uint(mine), tag}, rr, (unsigned)(((n * a.sy_n + sy) * 64 + c) * 8), 0, RC_SC1);
+  if (tid < 64) __builtin_amdgcn_raw_buffer_store_b64((rc_u32x2){__float_as_uint(mine), tag}, rr, (unsigned)(((n * a.ns + si) * 64 + c) * 8), 0, RC_SC1);
   float total = 0.f;
-  if (RCAB_ABL >= 1) return mine * a.sy_n;
-  for (int s0 = 0; s0 < a.sy_n; s0 += 8) {
+  if (RCAB_ABL >= 1) return mine * a.ns;
+  for (int s0 = 0; s0 < a.ns; s0 += 8) {
     const int s = s0 + w;
     float val = 0.f;
-    if (s < a.sy_n) {                                       // wave-uniform
-      const unsigned byte = (unsigned)(((n * a.sy_n + s) * 64 + c) * 8);
+    if (s < a.ns) {                                         // wave-uniform
+      const unsigned byte = (unsigned)(((n * a.ns + s) * 64 + c) * 8);
       rc_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rr, byte, 0, RC_SC1);
       unsigned spins = 0;
       while (!__all(r.y == tag)) {
@@ -70,7 +75,7 @@ __device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int 
     __syncthreads();
     if (tid < 64) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) total += sx[k * 64 + c];  // strips beyond sy_n contributed zeros
+      for (int k = 0; k < 8; ++k) total += sx[k * 64 + c];  // strips beyond ns contributed zeros
     }
   }
   return total;
@@ -78,9 +83,12 @@ __device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int 
 
 // MB (backward only): the ReLU mask comes as bytes (written by the forward launch) instead of the bf16 activation
 // FMT: element format (RUMPY_FMT_F16 is instantiated for the forward launch only: evaluation plans)
-template <bool BWD, bool MB = false, int FMT = RUMPY_FMT_BF16>
+template <bool BWD, bool MB = false, int FMT = RUMPY_FMT_BF16, class G = GeoL>
 __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  constexpr int NC = G::NC, XC = G::XC, TC = G::TC, XH = G::XH, OW = G::OW;
+  constexpr int NP1 = NC == 3 ? 6 : 4;     // paired tiles of the first phase (4 rows x NC column tiles)
+  constexpr int NP2 = NC == 3 ? 4 : 3;     // ... of the second phase (3 rows x NC; NC = 3 leaves one single tile)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::XBYTES + G::TBYTES];
   __shared__ float sx[8 * 64];
   __shared__ float spool[2 * 64];
   __shared__ __attribute__((aligned(16))) float sgate[64];
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   __shared__ unsigned gate[4];              // row-half groups (block_common.hpp::gate_*): waves that have written their T rows / OUT rows
   __shared__ float svec[4 * 64];           // [0] conv_du.0.bias (cr) | [1] conv_du.2.bias | [2] q gate | [3] bwd: forward gate ; hidden at [0][32..]
   unsigned char* const ldx = lds;
-  unsigned char* const ldt = lds + BXBYTES;
+  unsigned char* const ldt = lds + G::XBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int q = wave & 3, rh = __builtin_amdgcn_readfirstlane(wave >> 2), tg = tid & 255;
@@ -100,9 +108,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   // XCD-aware strip order when every XCD gets whole images (then the strips of an image are consecutive in ONE XCD's dispatch order and
   // the exchange argument at the top of this file holds per XCD: needs ceil(H/6) <= 32 CUs); identity otherwise
   const int nwg = gridDim.x;
-  const bool remap = ((nwg & 7) == 0) && (((nwg >> 3) % a.sy_n) == 0) && (a.sy_n <= 32);
+  const bool remap = ((nwg & 7) == 0) && (((nwg >> 3) % a.ns) == 0) && (a.ns <= 32);
   const int strip = remap ? xcd_strip(blockIdx.x, nwg) : (int)blockIdx.x;
-  const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+  // strip -> (image, strip of the image) -> (column tile, strip row), strip rows fastest (conv_block.hip)
+  const int n = strip / a.ns, si = strip - n * a.ns;
+  int sy = si, ct = 0;
+  if (G::CT) { ct = si / a.sy_n; sy = si - ct * a.sy_n; }
+  const int x0 = ct * OW;                  // image column of the strip's first output column
   const unsigned tag = (*a.epoch << 12) + a.seq;
   unsigned long long stamps[10];
   int nst = 0;
@@ -110,7 +122,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   RC_STAMP();                              // 0: start
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
-  uint4 T2[BWD ? 5 : 1];
+  uint4 T2[BWD ? G::SREGS : 1];
   float mw1[2], mw2[2], mv = 0.f;          // MLP operands of this thread: requested first, written to LDS behind the tile
   {
     const int mtot = a.cr * 64;
@@ -132,42 +144,42 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     if (which == 2 && !a.qgate) mv = 1.f;
   }
   {
-    uint4 R[BREGS];
+    uint4 R[G::XREGS];
     const int y0 = sy * BSH - 2;
 #pragma unroll
-    for (int i = 0; i < BREGS; ++i) {
+    for (int i = 0; i < G::XREGS; ++i) {
       const int p = tid + BTHREADS * i;
       const int pix = p >> 3, part = p & 7;
-      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
-      const int y = y0 + lr, x = lc - 1;
-      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const int lr = pix / XC, lc = pix - lr * XC;
+      const int y = y0 + lr, x = x0 - XH + lc;
+      const bool ok = (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
       uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
       if (!ok) v = make_uint4(0, 0, 0, 0);
       R[i] = v;
     }
-    if (BWD) {   // the strip's own rows of the forward conv2 output: piece p = tid + 512 i -> (pixel p >> 3 of 6 x 48, chunk tid & 7)
+    if (BWD) {   // the strip's own rows of the forward conv2 output: piece p = tid + 512 i -> (pixel p >> 3 of 6 x OW, chunk tid & 7)
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < G::SREGS; ++i) {
         const int p = tid + BTHREADS * i;
-        const int pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+        const int pix = p >> 3, r = pix / OW, col = pix - r * OW;
         const int y = sy * BSH + r;
-        const bool ok = (p < BSH * BSW * 8) & (y < a.H) & (col < a.W);
-        const int e = ok ? ((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8 : 0;
+        const bool ok = (p < G::SPIECES) & (y < a.H) & (x0 + col < a.W);
+        const int e = ok ? ((n * a.H + y) * a.W + x0 + col) * 64 + (p & 7) * 8 : 0;
         uint4 v = *reinterpret_cast<const uint4*>(a.t2_in + (unsigned)e);
         if (!ok) v = make_uint4(0, 0, 0, 0);
         T2[i] = v;
       }
     }
-    if (tid < BTROWS * 2 * 8) {
+    if (!G::CT && tid < BTROWS * 2 * 8) {       // (column tiles: the halo tile of the first phase writes these columns)
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
-      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < BREGS; ++i) {
+    for (int i = 0; i < G::XREGS; ++i) {
       const int p = tid + BTHREADS * i;
       const int pix = p >> 3, part = p & 7;
-      if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+      if (p < G::XPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
     }
     {
       const int mtot = a.cr * 64;
@@ -201,12 +213,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     // ---- phase 0b: ds = sum over the strip of dy * t2 per channel -> all strips of the image -> MLP backward -> d_t2 in place ----
     float part8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < G::SREGS; ++i) {
       const int p = tid + BTHREADS * i;
-      const int pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
-      if (p < BSH * BSW * 8) {
+      const int pix = p >> 3, r = pix / OW, col = pix - r * OW;
+      if (p < G::SPIECES) {
         float d[8], t[8];
-        unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((r + 2) * BCOLS + col + 1, tid & 7)), d);
+        unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((r + 2) * XC + col + XH, tid & 7)), d);
         unpack8<FMT>(T2[i], t);
 #pragma unroll
         for (int j = 0; j < 8; ++j) part8[j] = fmaf(d[j], t[j], part8[j]);
@@ -229,12 +241,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     float mine = 0.f;
     if (tid < 64) mine = (red[64 * 64 + tid] + red[64 * 64 + 64 + tid]) + (red[64 * 64 + 128 + tid] + red[64 * 64 + 192 + tid]);
     __syncthreads();                                        // red is dead: the border columns of the T image are rewritten below
-    if (tid < BTROWS * 2 * 8) {
+    if (!G::CT && tid < BTROWS * 2 * 8) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
-      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
     RC_STAMP();                            // (bwd) 2: product sums reduced
-    const float ds = strip_allsum(a, mine, n, sy, tid, tag, sx);
+    const float ds = strip_allsum(a, mine, n, si, tid, tag, sx);
     RC_STAMP();                            // (bwd) 3: exchange done
     if (tid < 64) {
       const int c = tid;
@@ -249,7 +261,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       }
       sgate[c] = s * gq;
       sdp[c] = dp * a.inv_hw;
-      if (sy == 0) {
+      if (si == 0) {
         a.dz[n * 64 + c] = dz;
         if (a.dzq) a.dzq[n * 64 + c] = (ds * s) * gq * (1.f - gq);
       }
@@ -262,12 +274,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const float4 ga = *reinterpret_cast<const float4*>(sgate + (tid & 7) * 8), gb = *reinterpret_cast<const float4*>(sgate + (tid & 7) * 8 + 4);
       const float4 pa = *reinterpret_cast<const float4*>(sdp + (tid & 7) * 8), pb = *reinterpret_cast<const float4*>(sdp + (tid & 7) * 8 + 4);
 #pragma unroll
-      for (int i = 0; i < BREGS; ++i) {
+      for (int i = 0; i < G::XREGS; ++i) {
         const int p = tid + BTHREADS * i;
         const int pix = p >> 3, part = p & 7;
-        const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
-        const int y = y0 + lr, x = lc - 1;
-        const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+        const int lr = pix / XC, lc = pix - lr * XC;
+        const int y = y0 + lr, x = x0 - XH + lc;
+        const bool ok = (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
         if (ok) {
           uint4* cell = reinterpret_cast<uint4*>(ldx + swz(pix, part));
           float d[8];
@@ -276,7 +288,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           const uint2 hi = pack4<FMT>(fmaf(d[4], gb.x, pb.x), fmaf(d[5], gb.y, pb.y), fmaf(d[6], gb.z, pb.z), fmaf(d[7], gb.w, pb.w));
           const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
           *cell = o;
-          if (lr >= 2 && lr < 2 + BSH) st16_nt(a.t2 + (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8), o);     // 8 lanes per pixel: whole lines
+          if (lr >= 2 && lr < 2 + BSH && (!G::CT || (lc >= XH && lc < XH + OW)))      // the strip's own pixels (halo columns belong to the neighbours)
+            st16_nt(a.t2 + (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8), o);     // 8 lanes per pixel: whole lines
         }
       }
     }
@@ -285,29 +298,58 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   }
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
-  unsigned moff[6];
-  uint4 M[(BWD && !MB) ? 6 : 1];
-  unsigned MBY[(BWD && MB) ? 6 : 1];
+  unsigned moff[NP1];
+  uint4 M[(BWD && !MB) ? NP1 : 1];
+  unsigned MBY[(BWD && MB) ? NP1 : 1];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < NP1; ++k) {
     const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
-    const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+    const int y = sy * BSH - 1 + 4 * rh + jr, xx = x0 + 16 * c + px;
     const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
     moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
     if (BWD && !MB) M[(BWD && !MB) ? k : 0] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
     if (BWD && MB) MBY[(BWD && MB) ? k : 0] = a.mbits[(in ? moff[k] : 0u) >> 3];
   }
+  // column tiles: this lane's pixel of the halo tile = T row hj, halo side px & 1 (conv_block.hip)
+  const int hj = 4 * rh + ((px >> 1) & 3), htc = (px & 1) ? TC - 1 : 0;
+  unsigned hoffe = 0xffffffffu;
+  uint2 HM = make_uint2(0, 0);
+  unsigned HB = 0;
+  if (G::CT) {
+    const int y = sy * BSH - 1 + hj, xx = x0 - 1 + htc;
+    if (((unsigned)y < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W)) hoffe = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
+    if (BWD && !MB) HM = *reinterpret_cast<const uint2*>(a.mask + (hoffe != 0xffffffffu ? hoffe : 0u));
+    if (BWD && MB) HB = a.mbits[(hoffe != 0xffffffffu ? hoffe : 0u) >> 3];
+  }
   {
-    f32x4 acc[4][3];
+    f32x4 acc[4][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!BWD) { const float4 t = *reinterpret_cast<const float4*>(a.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+      for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     unsigned off[8][2];
-    sweep_bases(off, 0u, 4 * rh, px, g);
-    block_sweep<4, FMT>(acc, F, lds, off);
+    if (G::CT) {
+      sweep_bases<XC>(off, 0u, hj, 0, g, htc);
+      f32x4 th = halo_sweep<FMT, XC>(b4, F, lds, off);
+      if (!BWD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) th[j] = relu_f32(th[j]);
+      }
+      uint2 o = make_uint2(0, 0);
+      if (hoffe != 0xffffffffu) {
+        o = pack4<FMT>(th[0], th[1], th[2], th[3]);
+        if (BWD && !MB) o = make_uint2(o.x & relu_keep(HM.x), o.y & relu_keep(HM.y));
+        if (BWD && MB) {
+          const uint4 m4 = relu_mask_bits(make_uint4(o.x, o.y, 0, 0), HB >> (4 * (g & 1)));
+          o = make_uint2(m4.x, m4.y);
+        }
+      }
+      if (px < 8) *reinterpret_cast<uint2*>(ldt + swz(hj * TC + htc, 2 * q + (g >> 1)) + (g & 1) * 8) = o;
+    }
+    sweep_bases<XC>(off, 0u, 4 * rh, px, g, G::CT ? 1 : 0);
+    block_sweep<4, FMT, NoHook, NC, XC>(acc, F, lds, off);
     RC_STAMP();                            // sweep A done
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
@@ -315,9 +357,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2];
-      const f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2];
+    for (int k = 0; k < NP1; ++k) {
+      const f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][NC - 1];
+      const f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][NC - 1];
       float v[8];
       pair_up(tx, ty, g, v);
       if (!BWD) {
@@ -333,26 +375,27 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         if (BWD && !MB) o = relu_mask_packed(o, M[(BWD && !MB) ? k : 0]);
         if (BWD && MB) o = relu_mask_bits(o, MBY[(BWD && MB) ? k : 0]);
       }
-      *reinterpret_cast<uint4*>(ldt + swz(j * BCOLS + xx + 1, chunk8)) = o;
+      *reinterpret_cast<uint4*>(ldt + swz(j * TC + xx + 1, chunk8)) = o;
     }
     gate_arrive(&gate[rh], lane);          // this wave's 16 channels of T rows 4rh .. 4rh+3 are in LDS
   }
-  unsigned soffg[GROUP_REGS];              // element offsets of this thread's 16-byte pieces of its row half's 3 strip rows (T; backward: OUT)
+  unsigned soffg[G::GREGS];                // element offsets of this thread's 16-byte pieces of its row half's 3 strip rows (T; backward: OUT)
 #pragma unroll
-  for (int i = 0; i < GROUP_REGS; ++i) soffg[i] = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+  for (int i = 0; i < G::GREGS; ++i) soffg[i] = group_piece_off<G>(i, tg, rh, n, sy, a.H, a.W, x0);
   // no workgroup barrier between the phases: each row half waits for exactly the T rows it reads (conv_block.hip, block_common.hpp)
   gate_wait(&gate[rh], 4u);
   if (rh == 1) gate_wait(&gate[0], 4u);
   RC_STAMP();                              // this row half's T rows complete
   // the row half's own strip rows of T (forward: + their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal,
   // one piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage; conv_block.hip)
-  uint4 S[STRIP_REGS];
-  unsigned soff[STRIP_REGS];               // (forward) element offsets of this thread's pieces of the whole strip: t2 and OUT stores
+  static_assert(G::SREGS >= G::GREGS, "S holds a row half's pieces and, later, the whole strip's");
+  uint4 S[G::SREGS];
+  unsigned soff[G::SREGS];                 // (forward) element offsets of this thread's pieces of the whole strip: t2 and OUT stores
   const bool t_out = a.t != nullptr;
-  if (t_out) group_stage<1>(S, ldt, tg, rh);
+  if (t_out) group_stage<1, G>(*reinterpret_cast<uint4(*)[G::GREGS]>(&S[0]), ldt, tg, rh);
   auto t_store = [&](int grp) {           // grp is a constant after unrolling
-    if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
-      const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
+    if (grp % 3 == 0 && grp / 3 < G::GREGS) {
+      const int i = grp / 3 < G::GREGS ? grp / 3 : 0;
       if (t_out && soffg[i] != 0xffffffffu) {
         st16_nt(a.t + soffg[i], S[i]);
         if (!BWD && a.mbits) a.mbits[soffg[i] >> 3] = (unsigned char)relu_bits(S[i]);
@@ -362,57 +405,57 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 
   // ---- phase 2: rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ----
   {
-    f32x4 acc[3][3];
+    f32x4 acc[3][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!BWD) { const float4 t = *reinterpret_cast<const float4*>(a.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+      for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     // backward: the residual operand dy (its tile in LDS now holds d_t2) is requested before the sweep and lands under it.  (Taking it
     // from the LDS tile before the transform - 18 more live registers - measured 0.7 % slower on the RCAN step: this read hits L2 / MALL.)
-    unsigned ooff[4], osoff;
-    uint4 P1p[BWD ? 4 : 1];
+    unsigned ooff[NP2], osoff = 0xffffffffu;
+    uint4 P1p[BWD ? NP2 : 1];
     uint2 P1s = make_uint2(0, 0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NP2; ++k) {
       const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-      const int y = sy * BSH + 3 * rh + r, xx = 16 * c + px;
+      const int y = sy * BSH + 3 * rh + r, xx = x0 + 16 * c + px;
       ooff[k] = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
       if (BWD) P1p[k] = *reinterpret_cast<const uint4*>(a.x + (ooff[k] != 0xffffffffu ? ooff[k] : 0u));
     }
-    {
-      const int y = sy * BSH + 3 * rh + 2, xx = 32 + px;
+    if (NC == 3) {
+      const int y = sy * BSH + 3 * rh + 2, xx = x0 + 32 + px;
       osoff = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0) : 0xffffffffu;
       if (BWD) P1s = *reinterpret_cast<const uint2*>(a.x + (osoff != 0xffffffffu ? osoff : 0u));
     }
     unsigned off[8][2];
     if (rh == 0) {
-      sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
-      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), F, lds, off, t_store);       // rows 0, 1 <- T rows 0 .. 3 (this half's own)
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, 0, px, g);
+      block_sweep<2, FMT, decltype(t_store), NC, TC>(*reinterpret_cast<f32x4(*)[2][NC]>(&acc[0]), F, lds, off, t_store);   // rows 0, 1 <- T rows 0 .. 3 (this half's own)
       gate_wait(&gate[1], 4u);
-      sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
-      block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), F, lds, off);                // row 2 <- T rows 2 .. 4
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, 2, px, g);
+      block_sweep<1, FMT, NoHook, NC, TC>(*reinterpret_cast<f32x4(*)[1][NC]>(&acc[2]), F, lds, off);                        // row 2 <- T rows 2 .. 4
     } else {
-      sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
-      block_sweep<3, FMT>(acc, F, lds, off, t_store);                                              // rows 3 .. 5 <- T rows 3 .. 7
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, 3, px, g);
+      block_sweep<3, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                           // rows 3 .. 5 <- T rows 3 .. 7
     }
     RC_STAMP();                            // sweep B done
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
-    float V[4][8], vs[4];
+    float V[NP2][8], vs[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][2];
-      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][2];
+    for (int k = 0; k < NP2; ++k) {
+      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][NC - 1];
+      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][NC - 1];
       pair_up(tx, ty, g, V[k]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vs[j] = acc[2][2][j];
+    for (int j = 0; j < 4; ++j) vs[j] = acc[2][NC - 1][j];      // (NC = 3 only: the single tile; osoff stays "outside" otherwise)
 
     if (BWD) {
       // dx = dy + conv1^T(gt1)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NP2; ++k) {
         if (ooff[k] != 0xffffffffu) {
           float m[8];
           unpack8<FMT>(P1p[BWD ? k : 0], m);
@@ -425,7 +468,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           const uint2 lo = pack4<FMT>(V[k][0] + m[0], V[k][1] + m[1], V[k][2] + m[2], V[k][3] + m[3]);
           const uint2 hi = pack4<FMT>(V[k][4] + m[4], V[k][5] + m[5], V[k][6] + m[6], V[k][7] + m[7]);
           const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-          *reinterpret_cast<uint4*>(ldx + swz((3 * rh + r + 2) * BCOLS + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // dx image in place of the
+          *reinterpret_cast<uint4*>(ldx + swz((3 * rh + r + 2) * XC + 16 * c + px + XH, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // dx image in place of the
         }                                                                                                                                // d_t2 tile (dead in phase 2)
       }
       if (osoff != 0xffffffffu) {
@@ -437,14 +480,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) m[j] += e[j];
         }
-        *reinterpret_cast<uint2*>(ldx + swz((3 * rh + 2 + 2) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) =
+        *reinterpret_cast<uint2*>(ldx + swz((3 * rh + 2 + 2) * XC + 32 + px + XH, 2 * q + (g >> 1)) + (g & 1) * 8) =
             pack4<FMT>(vs[0] + m[0], vs[1] + m[1], vs[2] + m[2], vs[3] + m[3]);
       }
     } else {
       // t2 = conv2(t1) + b2: channel sums of the strip for the attention pool, t2 itself to HBM when training
       float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NP2; ++k) {
         if (ooff[k] != 0xffffffffu) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) ps8[j] += V[k][j];
@@ -476,24 +519,24 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       }
       __syncthreads();                     // every wave has finished its second sweep: the T image is dead
 #pragma unroll
-      for (int i = 0; i < STRIP_REGS; ++i) soff[i] = strip_piece_off(i, tid, n, sy, a.H, a.W);
+      for (int i = 0; i < G::SREGS; ++i) soff[i] = strip_piece_off<G>(i, tid, n, sy, a.H, a.W, x0);
       if (a.t2) {                          // training: t2 = conv2(t1) + b2 goes to HBM through the T image's rows 1 .. 6 (whole lines, below)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NP2; ++k) {
           if (ooff[k] != 0xffffffffu) {
             const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
             const uint2 lo = pack4<FMT>(V[k][0], V[k][1], V[k][2], V[k][3]), hi = pack4<FMT>(V[k][4], V[k][5], V[k][6], V[k][7]);
-            *reinterpret_cast<uint4*>(ldt + swz((3 * rh + r + 1) * BCOLS + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            *reinterpret_cast<uint4*>(ldt + swz((3 * rh + r + 1) * TC + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
         }
         if (osoff != 0xffffffffu)
-          *reinterpret_cast<uint2*>(ldt + swz((3 * rh + 2 + 1) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
+          *reinterpret_cast<uint2*>(ldt + swz((3 * rh + 2 + 1) * TC + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
       }
       const float mine = (tid < 64) ? spool[tid] + spool[64 + tid] : 0.f;
       RC_STAMP();                          // (fwd) pool sums done, t2 image written
-      const float tot = strip_allsum(a, mine, n, sy, tid, tag, sx);      // (its barriers also complete the t2 image)
+      const float tot = strip_allsum(a, mine, n, si, tid, tag, sx);      // (its barriers also complete the t2 image)
       RC_STAMP();                          // (fwd) exchange done
-      if (a.t2) strip_stage<1>(S, ldt, tid);
+      if (a.t2) strip_stage<1, G>(S, ldt, tid);
       if (tid < 64) {
         const int c = tid;
         const float mean = tot * a.inv_hw;
@@ -501,38 +544,38 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         for (int r = 0; r < a.cr; ++r) {
           const float h = fmaxf(wave_sum(sw1[r * 64 + c] * mean) + svec[r], 0.f);
           z = fmaf(sw2t[r * 64 + c], h, z);
-          if (sy == 0 && c == 0) a.hidden[n * a.cr + r] = h;
+          if (si == 0 && c == 0) a.hidden[n * a.cr + r] = h;
         }
         const float gt = 1.f / (1.f + expf(-z));
         sgate[c] = gt * svec[2 * 64 + c];
-        if (sy == 0) { a.mean[n * 64 + c] = mean; a.gate[n * 64 + c] = gt; }
+        if (si == 0) { a.mean[n * 64 + c] = mean; a.gate[n * 64 + c] = gt; }
       }
       __syncthreads();
       if (a.t2) {
 #pragma unroll
-        for (int i = 0; i < STRIP_REGS; ++i)
+        for (int i = 0; i < G::SREGS; ++i)
           if (soff[i] != 0xffffffffu) st16_nt(a.t2 + soff[i], S[i]);
       }
       // out = x + gate * t2, the residual operand from the input tile in LDS; the result replaces it there
       const float4 ga = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair), gb = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair + 4);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NP2; ++k) {
         if (ooff[k] != 0xffffffffu) {
           const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
           const int srow = 3 * rh + r, xx = 16 * c + px;
           float m[8];
-          unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)), m);
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * XC + xx + XH, chunk8)), m);
           const uint2 lo = pack4<FMT>(fmaf(V[k][0], ga.x, m[0]), fmaf(V[k][1], ga.y, m[1]), fmaf(V[k][2], ga.z, m[2]), fmaf(V[k][3], ga.w, m[3]));
           const uint2 hi = pack4<FMT>(fmaf(V[k][4], gb.x, m[4]), fmaf(V[k][5], gb.y, m[5]), fmaf(V[k][6], gb.z, m[6]), fmaf(V[k][7], gb.w, m[7]));
-          *reinterpret_cast<uint4*>(ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          *reinterpret_cast<uint4*>(ldx + swz((srow + 2) * XC + xx + XH, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
       }
       if (osoff != 0xffffffffu) {
         const int srow = 3 * rh + 2, xx = 32 + px;
         float m[4];
-        unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8), m);
+        unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * XC + xx + XH, 2 * q + (g >> 1)) + (g & 1) * 8), m);
         const float4 gs = *reinterpret_cast<const float4*>(sgate + c0);
-        *reinterpret_cast<uint2*>(ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8) =
+        *reinterpret_cast<uint2*>(ldx + swz((srow + 2) * XC + xx + XH, 2 * q + (g >> 1)) + (g & 1) * 8) =
             pack4<FMT>(fmaf(vs[0], gs.x, m[0]), fmaf(vs[1], gs.y, m[1]), fmaf(vs[2], gs.z, m[2]), fmaf(vs[3], gs.w, m[3]));
       }
     }
@@ -541,15 +584,15 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   if (BWD) {                               // per row half: its 3 rows are complete when its 4 waves have arrived
     gate_arrive(&gate[2 + rh], lane);
     gate_wait(&gate[2 + rh], 4u);
-    group_stage<2>(S, ldx, tg, rh);
+    group_stage<2, G>(*reinterpret_cast<uint4(*)[G::GREGS]>(&S[0]), ldx, tg, rh);
 #pragma unroll
-    for (int i = 0; i < GROUP_REGS; ++i)
+    for (int i = 0; i < G::GREGS; ++i)
       if (soffg[i] != 0xffffffffu) st16_nt(a.out + soffg[i], S[i]);
   } else {
     __syncthreads();
-    strip_stage<2>(S, ldx, tid);
+    strip_stage<2, G>(S, ldx, tid);
 #pragma unroll
-    for (int i = 0; i < STRIP_REGS; ++i)
+    for (int i = 0; i < G::SREGS; ++i)
       if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
   }
   RC_STAMP();                              // end (stores issued)
@@ -561,35 +604,53 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 
 __global__ void rcab_epoch_kernel(unsigned* epoch) { *epoch += 1u; }
 
+template <class G>
+static void rcab_dispatch(const rumpy_rcab_args* p, const RcabDev& d, hipStream_t s, bool bwd) {
+  const dim3 grid(d.N * d.ns);
+  if (bwd && p->maskbits) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, true, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+  else if (bwd) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, false, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+  else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false, RUMPY_FMT_F16, G>), grid, dim3(BTHREADS), s, d);
+  else RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+}
+
+// strips (workgroups) of one image: strip rows x column tiles; all of them exchange their pool sums, so all must be resident together
+extern "C" int rumpy_rcab_strips(int32_t H, int32_t W) {
+  int nc, ct_n;
+  block_col_tiles(W, &nc, &ct_n);
+  return ((H + BSH - 1) / BSH) * ct_n;
+}
+
 static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const char* what) {
   if (!p || !p->x || !p->w1 || !p->w2 || !p->out || !p->ca_w1 || !p->ca_b1 || !p->ca_w2 || !p->ca_b2 || !p->hidden || !p->gate ||
       !p->xchg || !p->epoch || !p->status) { rumpy_set_error("%s: null pointer", what); return RUMPY_E_ARG; }
   if (!bwd && (!p->b1 || !p->b2 || !p->mean)) { rumpy_set_error("%s: forward needs b1, b2, mean", what); return RUMPY_E_ARG; }
   if (bwd && (!p->t2_in || (!p->mask && !p->maskbits) || !p->t2 || !p->dz)) { rumpy_set_error("%s: backward needs t2_in, mask, t2 (d_t2 out), dz", what); return RUMPY_E_ARG; }
   if (bwd && p->dzq && !p->qgate) { rumpy_set_error("%s: dzq without qgate", what); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("%s: bad shape", what); return RUMPY_E_ARG; }
   const int sy_n = (p->H + BSH - 1) / BSH;
-  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW || p->cr <= 0 || p->cr > RC_MAXR || sy_n > rumpy_device_cus() || p->seq >= 4096u) {
-    rumpy_set_error("%s: needs 0 < W <= 48, ceil(H/6) <= CUs, 0 < Cr <= 16, seq < 4096 (W=%d H=%d Cr=%d seq=%u)", what, p->W, p->H, p->cr, p->seq); return RUMPY_E_ARG; }
+  int nc, ct_n;
+  block_col_tiles(p->W, &nc, &ct_n);
+  const int ns = sy_n * ct_n;
+  if (p->cr <= 0 || p->cr > RC_MAXR || ns > rumpy_device_cus() || p->seq >= 4096u || (int64_t)p->N * p->H * p->W * 64 >= (int64_t)0xffffffffu) {
+    rumpy_set_error("%s: needs strips per image = ceil(H/6) * column tiles <= CUs, 0 < Cr <= 16, seq < 4096 (W=%d H=%d strips=%d Cr=%d seq=%u)", what, p->W, p->H, ns, p->cr, p->seq); return RUMPY_E_ARG; }
   if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !bwd)) { rumpy_set_error("%s: fmt %d is a forward-only format", what, p->fmt); return RUMPY_E_ARG; }
-  const int64_t need = rumpy_rcab_xchg_bytes(p->N, p->H);
+  const int64_t need = rumpy_rcab_xchg_bytes(p->N, p->H, p->W);
   if (p->xchg_bytes < need) { rumpy_set_error("%s: exchange buffer too small (%lld < %lld)", what, (long long)p->xchg_bytes, (long long)need); return RUMPY_E_ARG; }
   RcabDev d;
   d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
   d.t = (uint16_t*)p->t; d.t2 = (uint16_t*)p->t2; d.t2_in = (const uint16_t*)p->t2_in; d.mask = (const uint16_t*)p->mask; d.res2 = (const uint16_t*)p->res2; d.out = (uint16_t*)p->out;
-  d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n; d.ct_n = ct_n; d.ns = ns;
   d.cw1 = p->ca_w1; d.cb1 = p->ca_b1; d.cw2 = p->ca_w2; d.cb2 = p->ca_b2; d.cr = p->cr; d.inv_hw = 1.0f / ((float)p->H * (float)p->W);
   d.mean = p->mean; d.hidden = p->hidden; d.gate = p->gate; d.qgate = p->qgate; d.dz = p->dz; d.dzq = p->dzq;
   d.xchg = (unsigned long long*)p->xchg; d.xchg_bytes = (unsigned)need; d.epoch = (const unsigned*)p->epoch; d.seq = p->seq; d.status = (unsigned*)p->status; d.mbits = (unsigned char*)p->maskbits;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(d.N * sy_n);
-  if (bwd && p->maskbits) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, true>), grid, dim3(BTHREADS), s, d);
-  else if (bwd) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, false>), grid, dim3(BTHREADS), s, d);
-  else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);
-  else RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false>), grid, dim3(BTHREADS), s, d);
+  if (p->W <= BSW) rcab_dispatch<GeoL>(p, d, s, bwd);
+  else if (nc == 3) rcab_dispatch<BlockGeo<3, true> >(p, d, s, bwd);
+  else rcab_dispatch<BlockGeo<2, true> >(p, d, s, bwd);
   return rumpy_check_launch(what);
 }
 
-extern "C" int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H) { return (int64_t)N * ((H + BSH - 1) / BSH) * 64 * 8; }
+extern "C" int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H, int32_t W) { return (int64_t)N * rumpy_rcab_strips(H, W) * 64 * 8; }
 extern "C" int rumpy_rcab_fwd(const rumpy_rcab_args* p, void* stream) { return rcab_launch(p, stream, false, "rumpy_rcab_fwd"); }
 extern "C" int rumpy_rcab_bwd(const rumpy_rcab_args* p, void* stream) { return rcab_launch(p, stream, true, "rumpy_rcab_bwd"); }
 extern "C" int rumpy_rcab_epoch_advance(void* epoch, void* stream) {

@@ -133,6 +133,7 @@ class SREngine:
         self.wgrad_shares = os.environ.get('RUMPY_WGRAD_JOBS') != '1'
         self.wgrad_two_phase = os.environ.get('RUMPY_WGRAD_AB') == '1'
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
+        self.block_any_width = os.environ.get('RUMPY_BLOCK_W48') != '1'    # ... also for images wider than one strip (column tiles); =1: A/B, two launches per block there
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
         # Evaluation plans store activations and filters as IEEE fp16 (same MFMA rate and bytes as bf16, 11 instead of 8 significant bits):
@@ -331,6 +332,8 @@ class SREngine:
         plan.x_in = self._new(plan, N, Cin, H, W, dtype=torch.float32)
         fwd, bwd = plan.fwd, plan.bwd
         tiles = int(lib.rumpy_conv_pool_tiles(H, W, 1))     # per-image pool partial rows written by the 64->64 conv
+        # ... and by the one-launch residual block (column tiles when W > 48: another count of partial rows)
+        btiles = int(lib.rumpy_block_pool_tiles(H, W))
         wjobs = []      # (layer, x, dy, H, W, dy_mode, scale, mt)
 
         free_pool = []
@@ -368,10 +371,10 @@ class SREngine:
             for it in items:
                 if it[0] == 'resblock':
                     _, c1, c2, rs = it
-                    # one launch per block when a strip spans the image width (conv_block.hip): the activation between the two
-                    # convs stays in LDS (it is still stored when training: the backward pass masks with it and the weight
+                    # one launch per block (conv_block.hip; images wider than 48 pixels as column tiles since round 3): the activation
+                    # between the two convs stays in LDS (it is still stored when training: the backward pass masks with it and the weight
                     # gradient of conv2 reads it); RUMPY_NO_BLOCK=1 keeps the two-launch path for A/B runs
-                    fused = self.use_block_kernel and W <= 48 and not self.wide
+                    fused = self.use_block_kernel and (W <= 48 or self.block_any_width) and not self.wide
                     t1 = act() if (train or not fused) else None
                     y = act()
                     # the backward launch needs t1 only as a ReLU mask: the forward launch also leaves it as bytes (1/16 of the traffic)
@@ -423,19 +426,19 @@ class SREngine:
                         cur = self._emit_styled_rcab(plan, fwd, bwd, wjobs, nodes, c1, c2, ca, cur, N, H, W, tiles, train, act, release)
                         continue
                     t1, t2, y = act(), act(), act()
-                    pool = self._new(plan, N, tiles, F, dtype=torch.float32)
+                    fused = self.use_block_kernel and (W <= 48 or self.block_any_width)
+                    # the whole RCAB in one launch (conv_rcab.hip): the strips of an image exchange their pool sums, the gate is applied on chip
+                    # (every strip of an image - strip rows x column tiles - has to be resident at the same time)
+                    rc = fused and self.use_rcab_kernel and int(self.lib.rumpy_rcab_strips(H, W)) <= self.cus and 2 * plan.rcab_n + 2 <= 4096
+                    ptiles = btiles if (fused and not rc) else tiles
+                    pool = self._new(plan, N, ptiles, F, dtype=torch.float32)
                     mean = self._new(plan, N, F, dtype=torch.float32)
                     hid = self._new(plan, N, ca.Cr, dtype=torch.float32)
                     gate = self._new(plan, N, F, dtype=torch.float32)
-                    fused = self.use_block_kernel and W <= 48
-                    # the whole RCAB in one launch (conv_rcab.hip): the strips of an image exchange their pool sums, the gate is applied on chip
-                    rc = fused and self.use_rcab_kernel and (H + 5) // 6 <= self.cus and 2 * plan.rcab_n + 2 <= 4096
-                    if fmt and not rc:
-                        fused = False          # the general form of the block kernel is bf16 only: separate launches then
                     rc_common, seq = None, None
                     if rc:
                         if plan.rcab_xchg is None:
-                            plan.rcab_xchg = torch.zeros(int(self.lib.rumpy_rcab_xchg_bytes(N, H)), dtype=torch.uint8, device=self.device)
+                            plan.rcab_xchg = torch.zeros(int(self.lib.rumpy_rcab_xchg_bytes(N, H, W)), dtype=torch.uint8, device=self.device)
                             plan.rcab_epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
                             plan.rcab_status = plan.flags[1:2]
                         seq = 2 * plan.rcab_n
@@ -449,9 +452,9 @@ class SREngine:
                             t=_ptr(t1) if train else None, t2=_ptr(t2) if train else None, out=_ptr(y), mean=_ptr(mean), seq=seq, fmt=fmt, **rc_common)))
                     elif fused:   # conv -> ReLU -> conv (+ pool partial sums) in one launch, no residual yet (the gate comes first)
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
-                            x=_ptr(cur), w1=_ptr(c1.w_fwd), b1=_ptr(c1.b_packed), w2=_ptr(c2.w_fwd), b2=_ptr(c2.b_packed), mask=None,
-                            res2=None, t=_ptr(t1), out=_ptr(t2), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, res_mode=1,
-                            res1=None, pool=_ptr(pool))))
+                            x=_ptr(cur), w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed), mask=None,
+                            res2=None, t=_ptr(t1) if train else None, out=_ptr(t2), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, res_mode=1,
+                            res1=None, pool=_ptr(pool), fmt=fmt)))
                     else:
                         self._conv(fwd, cur, c1, N, H, W, t1, relu=True, fmt=fmt)
                         self._conv(fwd, t1, c2, N, H, W, t2, pool=pool, fmt=fmt)
@@ -460,7 +463,7 @@ class SREngine:
                         fwd.append(('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(
                             pool=_ptr(pool), w1=_ptr(ca.w1), b1=_ptr(ca.b1), w2=_ptr(ca.w2), b2=_ptr(ca.b2), mean=_ptr(mean),
                             hidden=_ptr(hid), gate=_ptr(gate), t=_ptr(t2), res=_ptr(cur), out=_ptr(y), N=N, HW=H * W, C=F, Cr=ca.Cr,
-                            ntiles=tiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg), fmt=fmt)))
+                            ntiles=ptiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg), fmt=fmt)))
 
                     def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused, qg=qg, qdz=qdz,
                              rc_common=rc_common, rc_seq=seq):
@@ -663,7 +666,9 @@ class SREngine:
         sums (or two conv launches when W > 48), the gate MLP in its own launch, gate * t2 + x by the streaming kernel; backward in the
         same pieces.  bf16 plans only (the engine keeps evaluation of such networks in bf16)."""
         F = self.feats
-        fused = self.use_block_kernel and W <= 48
+        fused = self.use_block_kernel and (W <= 48 or self.block_any_width)
+        if fused:
+            tiles = int(self.lib.rumpy_block_pool_tiles(H, W))
         t1, t2, y = act(), act(), act()
         pool = self._new(plan, N, tiles, F, dtype=torch.float32)
         acts = self._new(plan, N, L.QCA_ACT_STRIDE, dtype=torch.float32)

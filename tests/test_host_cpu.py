@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(h, s), s
     lib = _lib.lib()
-    assert lib.rumpy_abi_version() == 2
+    assert lib.rumpy_abi_version() == 3
     assert lib.rumpy_wgrad_slab_floats(4) == 64 * 576 + 64 and lib.rumpy_wgrad_slab_floats(1) == 16 * 576 + 16
 
 

@@ -664,7 +664,9 @@ def _run_block(x, pa, pb, N, H, W, fwd, rs, mask=None, extra=None, store_t=True)
     return t, out
 
 
-@pytest.mark.parametrize('N,H,W', [(1, 6, 16), (2, 13, 48), (3, 20, 37), (1, 5, 9), (32, 48, 48)])
+@pytest.mark.parametrize('N,H,W', [(1, 6, 16), (2, 13, 48), (3, 20, 37), (1, 5, 9), (32, 48, 48),
+                                   # wider than one strip: column tiles of 32 / 48 output columns with the activation's halo columns computed
+                                   (1, 7, 49), (2, 13, 64), (1, 20, 100), (2, 9, 128), (8, 64, 64), (1, 31, 170)])
 def test_conv_block_matches_two_layer_launches(N, H, W):
     gen = np.random.default_rng(100 + H + W)
     mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
@@ -690,10 +692,37 @@ def test_conv_block_matches_two_layer_launches(N, H, W):
     assert_bf16_close(gx.float(), gx_ref.float(), 'block data gradient', rel=2e-3, amax=2.0 ** -7)
 
 
-def test_conv_block_rejects_wide_images():
-    t = torch.zeros(64, dtype=BF16, device=DEV)
-    a = L.BlockArgs(x=t.data_ptr(), w1=t.data_ptr(), w2=t.data_ptr(), out=t.data_ptr(), N=1, H=6, W=49, relu1=1, scale1=1.0, scale2=1.0)
-    assert L.lib().rumpy_conv_block(a, None) == -1 and b'W <= 48' in L.lib().rumpy_last_error()
+@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (1, 5, 9), (2, 13, 64), (1, 20, 100)])
+def test_conv_block_geometries_agree_bitwise(N, H, W):
+    """one strip across the image (W <= 48), column tiles of 32 and column tiles of 48 columns (col_tile = 2 / 3 forces them at any W)
+    compute every output element with the same MFMA sequence: activation and output are bitwise equal, forward and data gradient, with
+    the ReLU mask as the stored activation and as bytes"""
+    gen = np.random.default_rng(500 + H + W)
+    pa, pb = PackedConv(*_wb(gen, 64, 64)), PackedConv(*_wb(gen, 64, 64))
+    rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    x, g, extra = rnd(), rnd(), rnd()
+    res = []
+    for ct in ((0, 2, 3) if W <= 48 else (2, 3)):
+        t, y = (torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(2))
+        mb = torch.full((N, H, W, 8), 0xAA, dtype=torch.uint8, device=DEV)
+        L.call('rumpy_conv_block', L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
+                                               b2=pb.b_packed.data_ptr(), t=t.data_ptr(), out=y.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0,
+                                               scale2=0.1, maskbits=mb.data_ptr(), col_tile=ct), stream())
+        outs = [t, y, mb]
+        for bits in (False, True):
+            dt, dx = (torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(2))
+            L.call('rumpy_conv_block', L.BlockArgs(x=g.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=t.data_ptr(),
+                                                   res2=extra.data_ptr(), t=dt.data_ptr(), out=dx.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=0.1,
+                                                   scale2=1.0, maskbits=mb.data_ptr() if bits else None, col_tile=ct), stream())
+            outs += [dt, dx]
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(o.float()).all() for o in outs if o.dtype == BF16), ct
+        res.append(outs)
+    for other in res[1:]:
+        for i, (a, b) in enumerate(zip(res[0], other)):
+            assert torch.equal(a.view(torch.int16) if a.dtype == BF16 else a, b.view(torch.int16) if b.dtype == BF16 else b), i
+    a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), w2=pb.w_fwd.data_ptr(), out=x.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, col_tile=4)
+    assert L.lib().rumpy_conv_block(a, None) == -1 and b'col_tile' in L.lib().rumpy_last_error()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -759,7 +788,7 @@ def test_block_chain_rejects_shapes_that_cannot_be_resident():
     assert exp_lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
 
 
-@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (8, 48, 48)])
+@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (8, 48, 48), (2, 13, 64), (1, 20, 100)])
 def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
     """general form of the block kernel (RCAB): no residual + pool partial sums forward; external residual operand backward"""
     gen = np.random.default_rng(300 + H + W)
@@ -771,7 +800,8 @@ def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
     # forward: t1 = relu(conv1 x + b1); t2 = conv2 t1 + b2 with per-(strip, row half) channel sums
     t_ref, _ = hip_conv(x, pa, N, H, W, relu=True)
     y_ref, pool_ref = hip_conv(t_ref, pb, N, H, W, pool=True)
-    tiles = int(L.lib().rumpy_conv_pool_tiles(H, W, 1))
+    tiles = int(L.lib().rumpy_block_pool_tiles(H, W))       # (W <= 48: the strip kernel's count and layout)
+    assert W > 48 or tiles == int(L.lib().rumpy_conv_pool_tiles(H, W, 1))
     t = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
     y = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
     pool = torch.full((N, tiles, 64), float('nan'), dtype=torch.float32, device=DEV)
@@ -780,7 +810,10 @@ def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
     L.call('rumpy_conv_block', a, stream())
     torch.cuda.synchronize()
     assert torch.equal(t, t_ref) and torch.equal(y, y_ref)
-    assert_f32_close(pool, pool_ref, 'pool partial sums', rel=1e-5)
+    if W <= 48:
+        assert_f32_close(pool, pool_ref, 'pool partial sums', rel=1e-5)
+    else:       # column tiles: other partial rows, the same sums
+        assert_f32_close(pool.sum(1), pool_ref.sum(1), 'pool sums', rel=1e-5)
     # data gradient: dt1 = mask(t1) . conv2^T(dt2); dx = conv1^T(dt1) + g + extra
     dt2, g, extra = rnd(), rnd(), rnd()
     d1_ref, _ = hip_conv(dt2, pb, N, H, W, dgrad=True, mask=t_ref)
@@ -794,7 +827,7 @@ def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
     assert torch.equal(d1, d1_ref) and torch.equal(dx, dx_ref)
 
 
-@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (32, 48, 48), (2, 24, 24), (2, 20, 20), (1, 5, 9)])
+@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (32, 48, 48), (2, 24, 24), (2, 20, 20), (1, 5, 9), (2, 24, 64), (1, 13, 100)])
 def test_conv_block_mask_bytes_equal_the_activation_mask(N, H, W):
     """the ReLU mask handed from the forward block launch to the data-gradient launch as one byte per 8 channels (maskbits) gives
     bit-identical results to masking with the stored bf16 activation"""

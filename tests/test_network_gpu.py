@@ -95,12 +95,12 @@ def test_rcan_small_train_step_against_oracle():
     print('worst grad rel err', worst)
 
 
-def _full_depth_step(name, wseed, N, kw, tol, cos_min):
+def _full_depth_step(name, wseed, N, kw, tol, cos_min, lr_hw=48):
     """one run_train step of a FULL-DEPTH network (BASELINE configs 2 / 3) against the oracle: loss, output, every gradient tensor
     (relative Frobenius error + cosine, worst ones printed), learning rate, and the weights after the Adam step"""
     h, oh = _pair(name, wseed, lr=1e-4, scale=4, **kw)
     w0 = {k: p.detach().cpu().clone() for k, p in h.net.named_parameters()}
-    x, y = O.synthetic_batch(wseed + 1000, N, lr_hw=48, scale=4)
+    x, y = O.synthetic_batch(wseed + 1000, N, lr_hw=lr_hw, scale=4)
     loss, out = h.run_train(x=x, y=y)
     oloss, oout = oh.run_train(x, y)
     sp = self_psnr(out, oout)
@@ -158,6 +158,26 @@ def test_edsr_baseline_full_depth_gradient_parity():
 def test_rcan_full_depth_gradient_parity():
     """RCAN x4 (10 groups x 20 RCAB = 400 bf16-stored stages of back-propagation, BASELINE config 3), N = 2, 48 x 48"""
     _full_depth_step('rcan', 522, 2, {}, 3e-2, 0.999)
+
+
+def test_edsr_baseline_full_depth_gradient_parity_at_the_shipped_crop_size():
+    """64 x 64 LR crops (Documentation/sample_config_files/div2k/edsr.toml:16,26 of the reference): wider than one strip - every residual
+    block runs the column-tiled one-launch kernel (two tiles of 32 columns), forward and data gradient"""
+    h = _handler('edsr', scale=4)
+    h.net._ensure_engine()
+    plan = h.net.engine.plan_for(4, 64, 64, True)
+    assert sum(1 for op, _ in plan.fwd if op == 'rumpy_conv_block') == 16 and sum(1 for op, _ in plan.bwd if op == 'rumpy_conv_block') == 16
+    _full_depth_step('edsr', 523, 4, {}, 3e-2, 0.999, lr_hw=64)
+
+
+def test_rcan_full_depth_gradient_parity_at_the_shipped_crop_size():
+    """RCAN x4 10 x 20 on one 64 x 64 crop (div2k/rcan.toml:16,26): 22 strips per image (11 strip rows x 2 column tiles) exchange their pool sums
+    inside the one-launch RCAB kernels"""
+    h = _handler('rcan', scale=4)
+    h.net._ensure_engine()
+    plan = h.net.engine.plan_for(1, 64, 64, True)
+    assert sum(1 for op, _ in plan.fwd if op == 'rumpy_rcab_fwd') == 200 and sum(1 for op, _ in plan.bwd if op == 'rumpy_rcab_bwd') == 200
+    _full_depth_step('rcan', 524, 1, {}, 3e-2, 0.999, lr_hw=64)
 
 
 def test_generic_autograd_path_matches_fused_path():
@@ -350,6 +370,39 @@ def test_arbitrary_image_size_eval():
     oout, _, _ = oh.run_eval(x)
     assert out.shape == (1, 3, 148, 212)
     assert self_psnr(out, oout) >= 60.0
+    assert 'rumpy_conv_block' in {op for op, _ in h.net.engine.plan_for(1, 37, 53, False, h.net.engine.eval_fmt).fwd}      # column tiles
+
+
+@pytest.mark.parametrize('name,kw', [('edsr', dict(scale=2, num_blocks=3, res_scale=0.1)), ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16))])
+def test_wide_image_eval_and_training_against_oracle_and_against_the_two_launch_path(name, kw, monkeypatch):
+    """images wider than one strip (W > 48): the one-launch block / RCAB kernels as column tiles against the oracle - a 150 x 211 evaluation
+    image (RCAN: 25 strip rows x 5 column tiles = 125 strips per image exchange their pool sums; fp16 plans) and a training step on 64 x 80 crops - and against the
+    engine that keeps two launches per block there (RUMPY_BLOCK_W48=1)"""
+    res = []
+    for w48 in ('0', '1'):
+        monkeypatch.setenv('RUMPY_BLOCK_W48', w48)
+        h, oh = _pair(name, 531, sched=False, **kw)
+        xe, _ = O.synthetic_batch(631, 1, lr_hw=(150, 211), scale=2)
+        out, _, _ = h.run_eval(x=xe)
+        x, y = O.synthetic_batch(632, 2, lr_hw=(64, 80), scale=2)
+        loss, tout = h.run_train(x=x, y=y)
+        eng = h.net.engine
+        fused_op = {'edsr': 'rumpy_conv_block', 'rcan': 'rumpy_rcab_fwd'}[name]
+        assert (fused_op in {op for op, _ in eng.plan_for(1, 150, 211, False, eng.eval_fmt).fwd}) == (w48 == '0')
+        assert (fused_op in {op for op, _ in eng.plan_for(2, 64, 80, True).fwd}) == (w48 == '0')
+        assert eng.exchange_status() == 0
+        if w48 == '0':
+            oout, _, _ = oh.run_eval(xe)
+            assert self_psnr(out, oout) >= (70.0 if name == 'edsr' else 60.0)
+            oloss, otout = oh.run_train(x, y)
+            assert abs(float(loss) - float(oloss)) < 2e-3 * float(oloss) and self_psnr(tout, otout) >= 50.0
+            _grad_check(h, oh)
+        res.append((out, float(loss), tout, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}))
+    assert self_psnr(res[0][0], res[1][0]) > 65.0 and self_psnr(res[0][2], res[1][2]) > 58.0
+    assert abs(res[0][1] - res[1][1]) < 2e-4 * abs(res[1][1])
+    for k in res[0][3]:
+        a, b = res[0][3][k], res[1][3][k]
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-2, k
 
 
 def test_checkpoint_roundtrip_and_interchange():
@@ -519,6 +572,9 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
     ('rcan', dict(scale=4, n_resgroups=1, n_resblocks=3, reduction=16), 48),           # the headline patch shape
     ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=1, reduction=16), (155, 37)),    # 26 strips per image (4 exchange rounds, ragged last strip), odd width
     ('qrcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16, style='standard', include_q_layer=True, metadata=['a', 'b', 'c']), 16),
+    ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16), 64),              # column tiles: 2 x 32 columns, 22 strips per image
+    ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=1, reduction=16), (20, 100)),       # 3 column tiles of 48 (ragged last one), 12 strips per image
+    ('qrcan', dict(scale=2, n_resgroups=1, n_resblocks=1, reduction=16, style='standard', include_q_layer=True, metadata=['a', 'b', 'c']), (13, 130)),   # 3 tiles of 48
 ])
 def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, monkeypatch):
     """conv_rcab.hip (RCAB forward / backward in ONE launch, pool sums exchanged between the strips of an image) against the
