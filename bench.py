@@ -23,10 +23,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, fwd + wgrad + dgrad
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PMC_TRAFFIC_BYTES = 35.2e6           # FETCH_SIZE 21.9 MB + WRITE_SIZE 13.3 MB per launch
-PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_conv3x3_strip.md (separate rocprofv3 --pmc passes; launch with one residual operand)'
-BLOCK_PMC_TRAFFIC_BYTES = 30.7e6      # conv_block_kernel, mean of forward (30.4 MB) and data-gradient (31.0 MB) launches
-BLOCK_PMC_TRAFFIC_SOURCE = 'profiles/r02_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, 2 x FETCH_SIZE + WRITE_SIZE)'
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
 
@@ -128,6 +125,34 @@ def bench_moco(args):
                        'train_tflops': round(N * args.steps / elapsed * 2.752e9 / 1e12, 2)},
             'roofline': roofline, 'cpu_baseline': cpu}
     print(json.dumps(line), flush=True)
+
+
+def source_sha16(rel_paths):
+    """sha256[:16] over the given source files (relative to the repo root): what a committed PMC measurement is keyed on"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in rel_paths:
+        with open(os.path.join(ROOT, rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (tests/tools/pmc_step.sh writes the
+    entries: separate rocprofv3 --pmc passes over this very command, 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).
+    An entry counts only while the kernel sources it was measured on are unchanged (sha256 of the files): otherwise (None, why) - the
+    line then says `traffic: null` instead of quoting a number of other code."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            e = json.load(f).get(key)
+    except Exception as ex:      # noqa: BLE001
+        return None, 'no profiles/pmc_traffic.json (%s)' % type(ex).__name__
+    if e is None:
+        return None, 'no PMC entry for %s' % key
+    now = source_sha16(e['sources'])
+    if now != e['sha16']:
+        return None, 'PMC entry for %s was measured on other kernel sources (sha16 %s, now %s): re-run tests/tools/pmc_step.sh' % (key, e['sha16'], now)
+    return float(e['bytes_per_launch']), e['source']
 
 
 def _usable_cores(cap):
@@ -489,19 +514,9 @@ def main():
                 roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None}
             roofline.update(common)
-            if wide_convs:
-                roofline['traffic'] = 70.0e6           # batch 16: measured once, not re-measured here
-                roofline['traffic_source'] = 'profiles/r02_pmc_wide.md (tests/tools/pmc_wide.sh: separate rocprofv3 --pmc passes over bench.py --model edsr256 --batch 16, 2 x FETCH_SIZE + WRITE_SIZE)'
-            elif not use_block:
-                # HBM bytes of one residual-add launch from the PMC passes committed under profiles/ (not re-measured here)
-                roofline['traffic'] = PMC_TRAFFIC_BYTES
-                roofline['traffic_source'] = PMC_TRAFFIC_SOURCE
-            elif rcabs:
-                roofline['traffic'] = 45.3e6
-                roofline['traffic_source'] = 'profiles/r02_pmc_step.md (tests/tools/pmc_step.sh: separate rocprofv3 --pmc passes over a bench run, FETCH_SIZE + WRITE_SIZE, mean of forward and backward launches)'
-            elif BLOCK_PMC_TRAFFIC_BYTES and P == 48 and N == 32:
-                roofline['traffic'] = BLOCK_PMC_TRAFFIC_BYTES
-                roofline['traffic_source'] = BLOCK_PMC_TRAFFIC_SOURCE
+            # HBM bytes per launch from the PMC passes committed under profiles/ (not re-measured here; null when the kernel changed since)
+            kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else 'rcab_kernel' if rcabs else 'conv_block_kernel'
+            roofline['traffic'], roofline['traffic_source'] = pmc_traffic('%s:%s:N%d:P%d' % (kind, args.model, N, P))
 
     # ---- informational: the step exactly as the reference's caller makes it (SISRInterface.train_batch, interface.py:97-101): batch on the HOST,
     # output returned to the HOST (keep_on_device=False): 15 MB up + 14 MB down over PCIe per step.  Never `value`. ----

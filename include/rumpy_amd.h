@@ -72,9 +72,6 @@ typedef struct {
 int rumpy_conv3x3(const rumpy_conv_args* a, void* stream);
 /* number of per-image pool partial rows ("tiles") rumpy_conv3x3 writes for an H x W image */
 int rumpy_conv_pool_tiles(int32_t H, int32_t W, int32_t cin_chunks);
-/* diagnostic (never on the product path): stamped build of the Cin=64 kernel; a->pool receives grid_x*4*8 u64 of
- * s_memrealtime (100 MHz) phase stamps of each wave's first strip */
-int rumpy_debug_conv_stamps(const rumpy_conv_args* a, void* stream);
 
 /* ---- residual block in one launch: two 3x3 convs 64 -> 64, the activation between them stays in LDS (conv_block.hip) ----
  *   T = post1(convA(X)),  post1 = [+b1] [ReLU] [* scale1] [zero where mask <= 0];   OUT = X + scale2 * (convB(T) + b2) [+ res2]
@@ -660,18 +657,12 @@ typedef struct {
 } rumpy_mse_args;
 int rumpy_mse_loss(const rumpy_mse_args* a, void* stream);
 
-/* ---- timing probe: HIP events around every launch of one kernel family on its own stream ----
- * kernel_id: 1 = rumpy_conv3x3 with cin_chunks==1 and cout_tiles==1 ; 2 = rumpy_wgrad_grouped ; 3 = any rumpy_conv3x3 ;
- * 4 = (experimental chain kernels, tests/tools/csrc) ; 5 = rumpy_conv_block, rumpy_rcab_* */
 /* a launch list: fn = address of any `int fn(const <args>*, void* stream)` entry point of this library, args = its argument block */
 typedef struct { const void* fn; const void* args; } rumpy_op;
 int rumpy_run_list(const rumpy_op* ops, int32_t n, void* stream);
-int rumpy_probe_begin(int kernel_id, int max_records);
-/* diagnostic (tests only): `blocks` workgroups holding 80 KiB of LDS each spin for about `microseconds` on `stream` - a stand-in for a
- * foreign kernel (an RCCL collective on a side stream) that occupies CUs while the product kernels run */
-int rumpy_debug_occupy(int32_t blocks, float microseconds, void* stream);
-/* synchronises the recorded events; returns launches seen; *total_ms = summed duration */
-int rumpy_probe_end(double* total_ms);
+
+/* (the timing probe of bench.py and the diagnostics of tests / tools are declared in include/rumpy_amd_debug.h: measurement hooks of the
+ * same library, not part of the drop-in boundary) */
 
 #ifdef __cplusplus
 }

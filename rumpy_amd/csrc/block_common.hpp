@@ -78,8 +78,14 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r)
+      for (int r = 0; r < ROWS; ++r) {
+#if defined(BLOCK_ABL) && BLOCK_ABL == 7
+        // timing experiment (results WRONG): 5 of every 9 MFMAs - the matrix-pipe time of the block-scaled fp8 form (K = 128 at twice the
+        // cycles: five MFMAs per output tile where bf16 issues eighteen at half the cycles), every other instruction unchanged
+        if (((grp * 3 + ky) * ROWS + r) % 9 >= 5) continue;
+#endif
         acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c]);
+      }
     hook(grp);
   }
 }

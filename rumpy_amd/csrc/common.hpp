@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/rumpy_amd.h"
+#include "../../include/rumpy_amd_debug.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'tools: parity tests of measurement tools (tests/tools/chain_tests.py), run explicitly on the GPU box')
 
 
 @pytest.fixture(scope='session')

@@ -574,78 +574,6 @@ def test_wgrad_shares_run_job_lists_bitwise_like_one_job_per_workgroup():
     assert torch.equal(s1.view(torch.int32), s2.view(torch.int32)) and torch.equal(gw1, gw2) and torch.equal(gb1, gb2)
 
 
-def _chain_reference_and_run(N, H, W, nlayers, seed):
-    """Run a chain of 64->64 convs (alternating ResBlock-style epilogues) once through rumpy_conv_chain and once layer by
-    layer through rumpy_conv3x3; returns the two lists of outputs."""
-    gen = np.random.default_rng(seed)
-    x = nhwc(_rand(gen, N, 64, H, W))
-    extra_res = nhwc(_rand(gen, N, 64, H, W))
-    mask_t = nhwc(_rand(gen, N, 64, H, W))
-    pcs = [PackedConv(*_wb(gen, 64, 64)) for _ in range(nlayers)]
-    outs_ref, cfgs = [], []
-    cur = x
-    for l in range(nlayers):
-        kind = l % 4
-        if kind == 0:
-            cfg = dict(relu=True)                                   # ResBlock conv1
-        elif kind == 1:
-            cfg = dict(scale=0.1, res1=(outs_ref[l - 2] if l >= 2 else x))   # ResBlock conv2: + block input
-        elif kind == 2:
-            cfg = dict(use_bias=False, scale=0.1, mask=mask_t)      # data-gradient style
-        else:
-            cfg = dict(use_bias=False, res1=outs_ref[l - 2], res2=extra_res)
-        o, _ = hip_conv(cur, pcs[l], N, H, W, **cfg)
-        outs_ref.append(o)
-        cfgs.append(cfg)
-        cur = o
-    # chain launch writing into fresh buffers; residual sources must be the CHAIN's own earlier outputs
-    outs = [torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(nlayers)]
-    layers = []
-    p = lambda t: None if t is None else t.data_ptr()
-    for l, cfg in enumerate(cfgs):
-        def remap(t):
-            if t is None:
-                return None
-            for k, r in enumerate(outs_ref):
-                if t is r:
-                    return outs[k]
-            return t
-        use_bias = cfg.get('use_bias', True)
-        layers.append(ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=(pcs[l].b_packed.data_ptr() if use_bias else None),
-                                   out=outs[l].data_ptr(), mask=p(remap(cfg.get('mask'))), res1=p(remap(cfg.get('res1'))),
-                                   res2=p(remap(cfg.get('res2'))), relu=1 if cfg.get('relu') else 0, scale=float(cfg.get('scale', 1.0))))
-    ldev = to_dev_bytes((ChainLayer * nlayers)(*layers))
-    nstrips = N * ((H + 5) // 6)
-    xchg = torch.zeros(int(exp_lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
-    status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
-    a = ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
-                    xchg=xchg.data_ptr(), status=status.data_ptr())
-    for _ in range(3):                 # repeated launches on the same exchange buffer: the epoch base moves on every call
-        for o in outs:
-            o.fill_(float('nan'))
-        exp_call('rumpy_conv_chain', a, stream())
-    torch.cuda.synchronize()
-    assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
-    return outs_ref, outs
-
-
-@pytest.mark.parametrize('N,H,W,nlayers', [(1, 6, 16, 2), (2, 12, 48, 5), (3, 20, 37, 8), (32, 48, 48, 33)])
-def test_conv_chain_matches_layer_by_layer(N, H, W, nlayers):
-    ref, got = _chain_reference_and_run(N, H, W, nlayers, 31 + H)
-    for l, (r, g) in enumerate(zip(ref, got)):
-        assert torch.isfinite(g.float()).all(), l
-        # same bf16 operands, same fp32 products; only the order of the halo-row term in the sum differs
-        assert_bf16_close(g.float(), r.float(), 'chain layer %d' % l, rel=2e-3 * (1 + l), amax=2.0 ** -6 * (1 + l))
-
-
-def test_conv_chain_rejects_shapes_that_cannot_be_resident():
-    t = torch.zeros(64, dtype=BF16, device=DEV)
-    a = ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
-    assert exp_lib().rumpy_conv_chain(a, None) == -1
-    a = ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
-    assert exp_lib().rumpy_conv_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
-
-
 # ---------------------------------------------------------------------------------------------------------------------
 # residual block in one launch (conv_block.hip) against the same two layers through rumpy_conv3x3
 # ---------------------------------------------------------------------------------------------------------------------
@@ -726,66 +654,82 @@ def test_conv_block_geometries_agree_bitwise(N, H, W):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# chain of residual blocks in one launch (conv_block_chain.hip) against one rumpy_conv_block launch per block
+# residual block in one launch (conv_block.hip) against the same two layers through rumpy_conv3x3
 # ---------------------------------------------------------------------------------------------------------------------
-def _block_chain_case(N, H, W, nblocks, fwd, seed):
-    gen = np.random.default_rng(seed)
+def _run_block(x, pa, pb, N, H, W, fwd, rs, mask=None, extra=None, store_t=True):
+    t = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) if store_t else None
+    out = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    p = lambda z: None if z is None else z.data_ptr()
+    if fwd:
+        a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                        mask=None, res2=None, t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs))
+    else:   # data gradient: first through conv2 (pb) masked, then through conv1 (pa)
+        a = L.BlockArgs(x=x.data_ptr(), w1=pb.w_dgrad.data_ptr(), b1=None, w2=pa.w_dgrad.data_ptr(), b2=None, mask=p(mask), res2=p(extra),
+                        t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=float(rs), scale2=1.0)
+    L.call('rumpy_conv_block', a, stream())
+    torch.cuda.synchronize()
+    return t, out
+
+
+@pytest.mark.parametrize('N,H,W', [(1, 6, 16), (2, 13, 48), (3, 20, 37), (1, 5, 9), (32, 48, 48),
+                                   # wider than one strip: column tiles of 32 / 48 output columns with the activation's halo columns computed
+                                   (1, 7, 49), (2, 13, 64), (1, 20, 100), (2, 9, 128), (8, 64, 64), (1, 31, 170)])
+def test_conv_block_matches_two_layer_launches(N, H, W):
+    gen = np.random.default_rng(100 + H + W)
     mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
                             torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
-    pcs = [(mk(), mk()) for _ in range(nblocks)]
+    pa, pb = mk(), mk()
     x = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
-    masks = [torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16) for _ in range(nblocks)]
     rs = 0.1
-    p = lambda z: None if z is None else z.data_ptr()
-
-    def args(b, xin, t, out):
-        pa, pb = pcs[b]
-        if fwd:
-            return L.BlockArgs(x=p(xin), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
-                               t=p(t), out=p(out), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=rs)
-        return L.BlockArgs(x=p(xin), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=p(masks[b]), t=p(t), out=p(out), N=N, H=H, W=W,
-                           relu1=0, scale1=rs, scale2=1.0)
-    mkbuf = lambda: torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
-    # reference: one launch per block
-    ref_t, ref_o, cur = [], [], x
-    for b in range(nblocks):
-        t, o = mkbuf(), mkbuf()
-        L.call('rumpy_conv_block', args(b, cur, t, o), stream())
-        ref_t.append(t); ref_o.append(o); cur = o
-    # chain
-    ts, outs = [mkbuf() for _ in range(nblocks)], [mkbuf() for _ in range(nblocks)]
-    table = (L.BlockArgs * nblocks)(*[args(b, x if b == 0 else outs[b - 1], ts[b], outs[b]) for b in range(nblocks)])
-    tdev = to_dev_bytes(table)
-    nstrips = N * ((H + 5) // 6)
-    xchg = torch.zeros(int(exp_lib().rumpy_block_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
-    status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
-    a = BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0 if fwd else 1, xchg=xchg.data_ptr(),
-                         status=status.data_ptr())
-    for _ in range(3):                 # repeated launches on the same exchange buffer: the tag base moves on every call
-        for o in outs + ts:
-            o.fill_(float('nan'))
-        exp_call('rumpy_block_chain', a, stream())
-    torch.cuda.synchronize()
-    assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
-    return ref_t, ref_o, ts, outs
+    # forward: t = relu(conv1 x + b1); y = x + rs * (conv2 t + b2)
+    t_ref, _ = hip_conv(x, pa, N, H, W, relu=True)
+    y_ref, _ = hip_conv(t_ref, pb, N, H, W, scale=rs, res1=x)
+    t, y = _run_block(x, pa, pb, N, H, W, True, rs)
+    assert torch.equal(t, t_ref), 'activation between the two convs'
+    assert_bf16_close(y.float(), y_ref.float(), 'block forward', rel=2e-3, amax=2.0 ** -7)
+    _, y2 = _run_block(x, pa, pb, N, H, W, True, rs, store_t=False)        # inference: activation not stored
+    assert torch.equal(y2, y)
+    # data gradient: gt = mask(t) . rs * conv2^T(g); gx = g + conv1^T(gt) + extra
+    g = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    extra = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    gt_ref, _ = hip_conv(g, pb, N, H, W, dgrad=True, scale=rs, mask=t_ref)
+    gx_ref, _ = hip_conv(gt_ref, pa, N, H, W, dgrad=True, res1=g, res2=extra)
+    gt, gx = _run_block(g, pa, pb, N, H, W, False, rs, mask=t_ref, extra=extra)
+    assert torch.equal(gt, gt_ref), 'gradient w.r.t. the activation'
+    assert_bf16_close(gx.float(), gx_ref.float(), 'block data gradient', rel=2e-3, amax=2.0 ** -7)
 
 
-@pytest.mark.parametrize('N,H,W,nblocks', [(1, 6, 16, 2), (2, 13, 48, 3), (3, 20, 37, 4), (1, 26, 9, 5), (32, 48, 48, 16)])
-@pytest.mark.parametrize('fwd', [True, False])
-def test_block_chain_matches_block_by_block(N, H, W, nblocks, fwd):
-    ref_t, ref_o, ts, outs = _block_chain_case(N, H, W, nblocks, fwd, 7 + H + nblocks)
-    for b in range(nblocks):
-        # same operands and the same operation order per pixel: bit-identical
-        assert torch.equal(ts[b], ref_t[b]), ('activation', b)
-        assert torch.equal(outs[b], ref_o[b]), ('output', b)
-
-
-def test_block_chain_rejects_shapes_that_cannot_be_resident():
-    t = torch.zeros(64, dtype=BF16, device=DEV)
-    a = BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
-    assert exp_lib().rumpy_block_chain(a, None) == -1
-    a = BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
-    assert exp_lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
+@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (1, 5, 9), (2, 13, 64), (1, 20, 100)])
+def test_conv_block_geometries_agree_bitwise(N, H, W):
+    """one strip across the image (W <= 48), column tiles of 32 and column tiles of 48 columns (col_tile = 2 / 3 forces them at any W)
+    compute every output element with the same MFMA sequence: activation and output are bitwise equal, forward and data gradient, with
+    the ReLU mask as the stored activation and as bytes"""
+    gen = np.random.default_rng(500 + H + W)
+    pa, pb = PackedConv(*_wb(gen, 64, 64)), PackedConv(*_wb(gen, 64, 64))
+    rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    x, g, extra = rnd(), rnd(), rnd()
+    res = []
+    for ct in ((0, 2, 3) if W <= 48 else (2, 3)):
+        t, y = (torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(2))
+        mb = torch.full((N, H, W, 8), 0xAA, dtype=torch.uint8, device=DEV)
+        L.call('rumpy_conv_block', L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
+                                               b2=pb.b_packed.data_ptr(), t=t.data_ptr(), out=y.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0,
+                                               scale2=0.1, maskbits=mb.data_ptr(), col_tile=ct), stream())
+        outs = [t, y, mb]
+        for bits in (False, True):
+            dt, dx = (torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(2))
+            L.call('rumpy_conv_block', L.BlockArgs(x=g.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=t.data_ptr(),
+                                                   res2=extra.data_ptr(), t=dt.data_ptr(), out=dx.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=0.1,
+                                                   scale2=1.0, maskbits=mb.data_ptr() if bits else None, col_tile=ct), stream())
+            outs += [dt, dx]
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(o.float()).all() for o in outs if o.dtype == BF16), ct
+        res.append(outs)
+    for other in res[1:]:
+        for i, (a, b) in enumerate(zip(res[0], other)):
+            assert torch.equal(a.view(torch.int16) if a.dtype == BF16 else a, b.view(torch.int16) if b.dtype == BF16 else b), i
+    a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), w2=pb.w_fwd.data_ptr(), out=x.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, col_tile=4)
+    assert L.lib().rumpy_conv_block(a, None) == -1 and b'col_tile' in L.lib().rumpy_last_error()
 
 
 @pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (8, 48, 48), (2, 13, 64), (1, 20, 100)])

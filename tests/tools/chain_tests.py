@@ -1,0 +1,168 @@
+"""Parity tests of the EXPERIMENTAL persistent-chain kernels (tests/tools/csrc -> librumpy_exp.so: measurement tools that tie with or lose
+to the per-block launches).  They are not product code and not part of `pytest -m gpu` (the file name keeps
+them out of the default collection); run them on the GPU box with
+
+    python -m pytest tests/tools/chain_tests.py -q
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gpu_utils import (BF16, DEV, BlockChainArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, exp_call, exp_lib, hip_conv,   # noqa: E402
+                       stream, to_dev_bytes)
+from rumpy_amd import _lib as L          # noqa: E402
+
+pytestmark = pytest.mark.tools
+
+
+def _rand(gen, *shape, scale=1.0):
+    return torch.from_numpy(gen.standard_normal(shape).astype(np.float32) * scale)
+
+
+def _wb(gen, co, ci):
+    b = 1.0 / np.sqrt(ci * 9)
+    return (torch.from_numpy(gen.uniform(-b, b, (co, ci, 3, 3)).astype(np.float32)),
+            torch.from_numpy(gen.uniform(-b, b, (co,)).astype(np.float32)))
+
+
+def _chain_reference_and_run(N, H, W, nlayers, seed):
+    """Run a chain of 64->64 convs (alternating ResBlock-style epilogues) once through rumpy_conv_chain and once layer by
+    layer through rumpy_conv3x3; returns the two lists of outputs."""
+    gen = np.random.default_rng(seed)
+    x = nhwc(_rand(gen, N, 64, H, W))
+    extra_res = nhwc(_rand(gen, N, 64, H, W))
+    mask_t = nhwc(_rand(gen, N, 64, H, W))
+    pcs = [PackedConv(*_wb(gen, 64, 64)) for _ in range(nlayers)]
+    outs_ref, cfgs = [], []
+    cur = x
+    for l in range(nlayers):
+        kind = l % 4
+        if kind == 0:
+            cfg = dict(relu=True)                                   # ResBlock conv1
+        elif kind == 1:
+            cfg = dict(scale=0.1, res1=(outs_ref[l - 2] if l >= 2 else x))   # ResBlock conv2: + block input
+        elif kind == 2:
+            cfg = dict(use_bias=False, scale=0.1, mask=mask_t)      # data-gradient style
+        else:
+            cfg = dict(use_bias=False, res1=outs_ref[l - 2], res2=extra_res)
+        o, _ = hip_conv(cur, pcs[l], N, H, W, **cfg)
+        outs_ref.append(o)
+        cfgs.append(cfg)
+        cur = o
+    # chain launch writing into fresh buffers; residual sources must be the CHAIN's own earlier outputs
+    outs = [torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(nlayers)]
+    layers = []
+    p = lambda t: None if t is None else t.data_ptr()
+    for l, cfg in enumerate(cfgs):
+        def remap(t):
+            if t is None:
+                return None
+            for k, r in enumerate(outs_ref):
+                if t is r:
+                    return outs[k]
+            return t
+        use_bias = cfg.get('use_bias', True)
+        layers.append(ChainLayer(w=pcs[l].w_fwd.data_ptr(), bias=(pcs[l].b_packed.data_ptr() if use_bias else None),
+                                   out=outs[l].data_ptr(), mask=p(remap(cfg.get('mask'))), res1=p(remap(cfg.get('res1'))),
+                                   res2=p(remap(cfg.get('res2'))), relu=1 if cfg.get('relu') else 0, scale=float(cfg.get('scale', 1.0))))
+    ldev = to_dev_bytes((ChainLayer * nlayers)(*layers))
+    nstrips = N * ((H + 5) // 6)
+    xchg = torch.zeros(int(exp_lib().rumpy_conv_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
+    status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    a = ChainArgs(x=x.data_ptr(), layers=ldev.data_ptr(), nlayers=nlayers, N=N, H=H, W=W,
+                    xchg=xchg.data_ptr(), status=status.data_ptr())
+    for _ in range(3):                 # repeated launches on the same exchange buffer: the epoch base moves on every call
+        for o in outs:
+            o.fill_(float('nan'))
+        exp_call('rumpy_conv_chain', a, stream())
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
+    return outs_ref, outs
+
+
+@pytest.mark.parametrize('N,H,W,nlayers', [(1, 6, 16, 2), (2, 12, 48, 5), (3, 20, 37, 8), (32, 48, 48, 33)])
+def test_conv_chain_matches_layer_by_layer(N, H, W, nlayers):
+    ref, got = _chain_reference_and_run(N, H, W, nlayers, 31 + H)
+    for l, (r, g) in enumerate(zip(ref, got)):
+        assert torch.isfinite(g.float()).all(), l
+        # same bf16 operands, same fp32 products; only the order of the halo-row term in the sum differs
+        assert_bf16_close(g.float(), r.float(), 'chain layer %d' % l, rel=2e-3 * (1 + l), amax=2.0 ** -6 * (1 + l))
+
+
+def test_conv_chain_rejects_shapes_that_cannot_be_resident():
+    t = torch.zeros(64, dtype=BF16, device=DEV)
+    a = ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_conv_chain(a, None) == -1
+    a = ChainArgs(x=t.data_ptr(), layers=t.data_ptr(), nlayers=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_conv_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
+
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# chain of residual blocks in one launch (conv_block_chain.hip) against one rumpy_conv_block launch per block
+# ---------------------------------------------------------------------------------------------------------------------
+def _block_chain_case(N, H, W, nblocks, fwd, seed):
+    gen = np.random.default_rng(seed)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
+                            torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
+    pcs = [(mk(), mk()) for _ in range(nblocks)]
+    x = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    masks = [torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16) for _ in range(nblocks)]
+    rs = 0.1
+    p = lambda z: None if z is None else z.data_ptr()
+
+    def args(b, xin, t, out):
+        pa, pb = pcs[b]
+        if fwd:
+            return L.BlockArgs(x=p(xin), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                               t=p(t), out=p(out), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=rs)
+        return L.BlockArgs(x=p(xin), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=p(masks[b]), t=p(t), out=p(out), N=N, H=H, W=W,
+                           relu1=0, scale1=rs, scale2=1.0)
+    mkbuf = lambda: torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    # reference: one launch per block
+    ref_t, ref_o, cur = [], [], x
+    for b in range(nblocks):
+        t, o = mkbuf(), mkbuf()
+        L.call('rumpy_conv_block', args(b, cur, t, o), stream())
+        ref_t.append(t); ref_o.append(o); cur = o
+    # chain
+    ts, outs = [mkbuf() for _ in range(nblocks)], [mkbuf() for _ in range(nblocks)]
+    table = (L.BlockArgs * nblocks)(*[args(b, x if b == 0 else outs[b - 1], ts[b], outs[b]) for b in range(nblocks)])
+    tdev = to_dev_bytes(table)
+    nstrips = N * ((H + 5) // 6)
+    xchg = torch.zeros(int(exp_lib().rumpy_block_chain_xchg_bytes(nstrips)), dtype=torch.uint8, device=DEV)   # zeroed once
+    status = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    a = BlockChainArgs(blocks=tdev.data_ptr(), nblocks=nblocks, N=N, H=H, W=W, masked=0 if fwd else 1, xchg=xchg.data_ptr(),
+                         status=status.data_ptr())
+    for _ in range(3):                 # repeated launches on the same exchange buffer: the tag base moves on every call
+        for o in outs + ts:
+            o.fill_(float('nan'))
+        exp_call('rumpy_block_chain', a, stream())
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0, 'hand-off timed out: status %#x' % int(status.item())
+    return ref_t, ref_o, ts, outs
+
+
+@pytest.mark.parametrize('N,H,W,nblocks', [(1, 6, 16, 2), (2, 13, 48, 3), (3, 20, 37, 4), (1, 26, 9, 5), (32, 48, 48, 16)])
+@pytest.mark.parametrize('fwd', [True, False])
+def test_block_chain_matches_block_by_block(N, H, W, nblocks, fwd):
+    ref_t, ref_o, ts, outs = _block_chain_case(N, H, W, nblocks, fwd, 7 + H + nblocks)
+    for b in range(nblocks):
+        # same operands and the same operation order per pixel: bit-identical
+        assert torch.equal(ts[b], ref_t[b]), ('activation', b)
+        assert torch.equal(outs[b], ref_o[b]), ('output', b)
+
+
+def test_block_chain_rejects_shapes_that_cannot_be_resident():
+    t = torch.zeros(64, dtype=BF16, device=DEV)
+    a = BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=1, H=6, W=49, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_block_chain(a, None) == -1
+    a = BlockChainArgs(blocks=t.data_ptr(), nblocks=1, N=64, H=48, W=48, xchg=t.data_ptr(), status=t.data_ptr())
+    assert exp_lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
+
+

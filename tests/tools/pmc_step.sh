@@ -9,14 +9,31 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 python3 - <<PY
-import csv,glob,collections
-for d in sorted(glob.glob('gpurun_out/pmcs_${M}_*')):
-    for f in glob.glob(d+'/*counter_collection.csv'):
-        by=collections.defaultdict(list)
+import csv, glob, collections, json, os, sys
+sys.path.insert(0, '$R')
+import bench
+M = '${M}'
+means = collections.defaultdict(dict)
+for d in sorted(glob.glob('gpurun_out/pmcs_%s_*' % M)):
+    for f in glob.glob(d + '/*counter_collection.csv'):
+        by = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if 'rcab_kernel' in r['Kernel_Name'] or 'conv_block_kernel' in r['Kernel_Name']:
-                by[(r['Kernel_Name'][:48], r['Counter_Name'])].append(float(r['Counter_Value']))
-        for k,v in sorted(by.items()):
-            v=v[len(v)//2:]
-            print(d, k, 'mean per launch %.1f KB' % (sum(v)/len(v)), 'n', len(v))
+                by[(r['Kernel_Name'][:64], r['Counter_Name'])].append(float(r['Counter_Value']))
+        for k, v in sorted(by.items()):
+            v = v[len(v) // 2:]
+            print(d, k, 'mean per launch %.1f KB' % (sum(v) / len(v)), 'n', len(v))
+            means[k[0]][k[1]] = sum(v) / len(v)
+# per kernel form: 2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, KB of 1024 B; entry = mean over the forms (a step
+# launches the forward and the data-gradient form equally often)
+forms = {k: (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024 for k, c in means.items() if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c}
+if forms:
+    kind = 'rcab_kernel' if M != 'edsr' else 'conv_block_kernel'
+    srcs = ['rumpy_amd/csrc/block_common.hpp', 'rumpy_amd/csrc/conv_rcab.hip' if kind == 'rcab_kernel' else 'rumpy_amd/csrc/conv_block.hip']
+    entry = {'bytes_per_launch': sum(forms.values()) / len(forms), 'per_form_bytes': forms, 'sources': srcs, 'sha16': bench.source_sha16(srcs),
+             'source': 'profiles/pmc_traffic.json <- tests/tools/pmc_step.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --model %s '
+                       '(32 x 48 x 48), 2 x FETCH_SIZE + WRITE_SIZE, mean over the forward and data-gradient launches' % (M, M)}
+    out = 'gpurun_out/pmc_traffic_%s.json' % M
+    json.dump({'%s:%s:N32:P48' % (kind, M): entry}, open(out, 'w'), indent=1)
+    print('wrote', out, '(merge into profiles/pmc_traffic.json)')
 PY
