@@ -71,7 +71,8 @@ def bench_moco(args):
     wf, _, bp = enc._training_images(dev)[0]
     from rumpy_amd.regression.models.contrastive_learning.encoding_models import _conv_plain
     s = torch.cuda.current_stream(dev).cuda_stream
-    launch = lambda: _conv_plain(plan['a'][0].data_ptr(), wf.data_ptr(), bp.data_ptr(), plan['z'][1].data_ptr(), N, 48, 48, 64, 64, s)   # as the step launches it
+    from rumpy_amd.regression.models.contrastive_learning.encoding_models import TRAIN_FMT
+    launch = lambda: _conv_plain(plan['a'][0].data_ptr(), wf.data_ptr(), bp.data_ptr(), plan['z'][1].data_ptr(), N, 48, 48, 64, 64, s, fmt=TRAIN_FMT)   # as the step launches it
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

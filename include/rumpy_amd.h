@@ -456,15 +456,17 @@ typedef struct {
   void* out;           /* [N,Ho,Wo,cout] bf16, Ho = (H-1)/stride + 1 */
   int32_t N, H, W, cin, cout, stride;
   float neg_slope;     /* LeakyReLU slope (1 = no activation, 0 = ReLU) */
-  int32_t pad_;
+  int32_t fmt;     /* RUMPY_FMT_BF16 | RUMPY_FMT_F16: element format of x, w and out (ABI 3: the TRAINING forward pass of the encoder stores its
+                      filters, conv outputs and stage outputs as fp16 - the gradient of this BatchNorm + LeakyReLU network is 3-4 x closer to the
+                      fp32 reference's than with 8-bit mantissas; gradients and the data-gradient convs stay bf16) */
 } rumpy_enc_conv_args;
 int rumpy_enc_conv(const rumpy_enc_conv_args* a, void* stream);
-int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, int32_t fmt, void* stream);
 /* training-mode nn.BatchNorm2d + LeakyReLU in place on a conv output (the reference runs its frozen encoder under net.train() inside
  * run_train: base_architecture.py:472): batch statistics over P = N*H*W values per channel (biased variance), running statistics updated
  * with `momentum` (unbiased variance) and the counter incremented, as torch does.  Deterministic. */
 typedef struct {
-  void* x;                       /* [P, C] bf16, in and out */
+  void* x;                       /* [P, C] bf16 (fmt: fp16), in and out */
   const float* gamma; const float* beta;
   float* running_mean; float* running_var;   /* [C], updated; both NULL = leave untouched */
   int64_t* num_batches_tracked;  /* device scalar, += 1; may be NULL */
@@ -472,13 +474,15 @@ typedef struct {
   float* scale_shift;            /* scratch [2, C] */
   int32_t P, C;
   float eps, momentum, neg_slope;
-  int32_t pad_;
+  int32_t fmt;                   /* RUMPY_FMT_*: format of x and of the output */
 } rumpy_enc_bn_args;
 int rumpy_enc_bn_train(const rumpy_enc_bn_args* a, void* stream);
 int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C);
-/* The same, out of place and keeping what the backward pass needs: `out` [P, C] bf16 = LeakyReLU(BN(x)), x untouched;
- * `saved` [2, C] = batch mean, 1 / sqrt(biased variance + eps); a->scale_shift ([2, C]) must stay alive until rumpy_enc_bn_bwd has run. */
-int rumpy_enc_bn_train_keep(const rumpy_enc_bn_args* a, void* out, float* saved, void* stream);
+/* The same, out of place and keeping what the backward pass needs: `out` [P, C] (a->fmt) = LeakyReLU(BN(x)), x untouched; `out_bf16` = NULL or
+ * a second copy of the output rounded to bf16 (the weight-gradient kernels take bf16 operands: with fp16 stage outputs the next conv reads
+ * `out`, its weight gradient `out_bf16`); `saved` [2, C] = batch mean, 1 / sqrt(biased variance + eps); a->scale_shift ([2, C]) must stay
+ * alive until rumpy_enc_bn_bwd has run. */
+int rumpy_enc_bn_train_keep(const rumpy_enc_bn_args* a, void* out, void* out_bf16, float* saved, void* stream);
 
 /* ---- training the degradation encoder (MoCo / SupMoCo: rumpy/regression/models/contrastive_learning/moco.py:132-187, supmoco.py:52-128) ----
  * Backward of one BatchNorm2d(train) + LeakyReLU stage: from the gradient at the stage's output to the gradient at the conv output feeding
@@ -486,7 +490,7 @@ int rumpy_enc_bn_train_keep(const rumpy_enc_bn_args* a, void* out, float* saved,
  * (weights; rumpy_head_wgrad for the first layer).  `up` = 2 writes pixel (oy, ox) at (2 oy, 2 ox) of an [N, Hz, Wz, C] grid the caller
  * zeroed once: the stride-1 data / weight gradient over that grid is the stride-2 convolution's.  Deterministic. */
 typedef struct {
-  const void* z;             /* [N*Ho*Wo, C] bf16: the conv output the forward pass normalised (x of rumpy_enc_bn_train_keep) */
+  const void* z;             /* [N*Ho*Wo, C] bf16 (fmt: fp16): the conv output the forward pass normalised (x of rumpy_enc_bn_train_keep) */
   const void* da;            /* [N*Ho*Wo, C] bf16 gradient at the LeakyReLU output ; NULL: */
   const float* dpool;        /* [N, C] gradient at the AdaptiveAvgPool2d(1) output behind the stage: da[n, p, c] = dpool[n, c] / (Ho*Wo) */
   const float* scale_shift;  /* [2, C] of the forward pass */
@@ -498,7 +502,7 @@ typedef struct {
   float* coef;               /* scratch [3, C] */
   int32_t N, Ho, Wo, C, up, Hz, Wz;
   float neg_slope, scale;
-  int32_t pad_;
+  int32_t fmt;               /* RUMPY_FMT_*: format of z (da and dz are bf16) */
 } rumpy_enc_bn_bwd_args;
 int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* a, void* stream);
 /* key-encoder momentum update over flat fp32 buffers: k = k * m + q * one_minus_m (two rounded products, then the sum: moco.py:71) */

@@ -44,7 +44,7 @@ class HeadFwdArgs(_S):
 class EncConvArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p),
                 ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cin', c_int32), ('cout', c_int32), ('stride', c_int32),
-                ('neg_slope', c_float), ('pad_', c_int32)]
+                ('neg_slope', c_float), ('fmt', c_int32)]
 
 
 class RcabArgs(_S):
@@ -64,14 +64,14 @@ class Op(_S):
 class EncBnArgs(_S):
     _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
                 ('num_batches_tracked', c_void_p), ('partial', c_void_p), ('scale_shift', c_void_p),
-                ('P', c_int32), ('C', c_int32), ('eps', c_float), ('momentum', c_float), ('neg_slope', c_float), ('pad_', c_int32)]
+                ('P', c_int32), ('C', c_int32), ('eps', c_float), ('momentum', c_float), ('neg_slope', c_float), ('fmt', c_int32)]
 
 
 class EncBnBwdArgs(_S):
     _fields_ = [('z', c_void_p), ('da', c_void_p), ('dpool', c_void_p), ('scale_shift', c_void_p), ('saved', c_void_p), ('gamma', c_void_p),
                 ('dgamma', c_void_p), ('dbeta', c_void_p), ('dz', c_void_p), ('partial', c_void_p), ('coef', c_void_p),
                 ('N', c_int32), ('Ho', c_int32), ('Wo', c_int32), ('C', c_int32), ('up', c_int32), ('Hz', c_int32), ('Wz', c_int32),
-                ('neg_slope', c_float), ('scale', c_float), ('pad_', c_int32)]
+                ('neg_slope', c_float), ('scale', c_float), ('fmt', c_int32)]
 
 
 class HeadWgradArgs(_S):
@@ -278,10 +278,10 @@ SYMBOLS = {
     'rumpy_enc_conv': (C.c_int, [_P(EncConvArgs), c_void_p]),
     'rumpy_enc_bn_train': (C.c_int, [_P(EncBnArgs), c_void_p]),
     'rumpy_enc_bn_partial_floats': (c_int64, [c_int32, c_int32]),
-    'rumpy_enc_bn_train_keep': (C.c_int, [_P(EncBnArgs), c_void_p, c_void_p, c_void_p]),
+    'rumpy_enc_bn_train_keep': (C.c_int, [_P(EncBnArgs), c_void_p, c_void_p, c_void_p, c_void_p]),
     'rumpy_enc_bn_bwd': (C.c_int, [_P(EncBnBwdArgs), c_void_p]),
     'rumpy_ema': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
-    'rumpy_enc_pool': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'rumpy_enc_pool': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),
     'rumpy_tail_fwd': (C.c_int, [_P(TailFwdArgs), c_void_p]),
     'rumpy_tail_fwd_grid': (C.c_int, [c_int32, c_int32, c_int32, c_int32]),

@@ -18,7 +18,7 @@ struct EncConv {
   float neg_slope;
 };
 
-template <int S, int R>
+template <int S, int R, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
   constexpr int IR = (R - 1) * S + 3, IC = 15 * S + 3;    // input rows / columns under an R x 16 output tile
   __shared__ uint4 lds[IR * IC * 8];
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
         for (int r = 0; r < R; ++r) {
           const int p = (r * S + ky) * IC + j * S + kx;
           const uint4 b = lds[p * 8 + (chunk ^ (p & 7))];
-          acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(F[tap * 2 + half]), as_bf16x8(b), acc[r], 0, 0, 0);
+          acc[r] = mfma16<FMT>(as_bf16x8(F[tap * 2 + half]), as_bf16x8(b), acc[r]);
         }
       }
     }
@@ -74,24 +74,32 @@ __global__ void __launch_bounds__(256) enc_conv_kernel(EncConv a) {
       float v0 = acc[r][0] + bv.x, v1 = acc[r][1] + bv.y, v2 = acc[r][2] + bv.z, v3 = acc[r][3] + bv.w;
       v0 = v0 > 0.f ? v0 : v0 * a.neg_slope; v1 = v1 > 0.f ? v1 : v1 * a.neg_slope;
       v2 = v2 > 0.f ? v2 : v2 * a.neg_slope; v3 = v3 > 0.f ? v3 : v3 * a.neg_slope;
-      *reinterpret_cast<uint2*>(a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * cout + co) = pack4_bf16(v0, v1, v2, v3);
+      *reinterpret_cast<uint2*>(a.out + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * cout + co) = pack4<FMT>(v0, v1, v2, v3);
     }
   }
 }
 
-// AdaptiveAvgPool2d(1) over an NHWC bf16 map -> fp32 [N, C]; grid (N, C/64), fixed summation order (deterministic).
+// 8 stored elements -> fp32
+template <int FMT> __device__ __forceinline__ void enc_unpack8(const uint4 v, float (&f)[8]) {
+  float lo[4], hi[4];
+  unpack4<FMT>(make_uint2(v.x, v.y), lo);
+  unpack4<FMT>(make_uint2(v.z, v.w), hi);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; }
+}
+
+// AdaptiveAvgPool2d(1) over an NHWC bf16 / fp16 map -> fp32 [N, C]; grid (N, C/64), fixed summation order (deterministic).
+template <int FMT>
 __global__ void __launch_bounds__(256) enc_pool_kernel(const uint4* __restrict__ x, float* __restrict__ out, int HW, int C) {
   __shared__ float red[32][65];
   const int n = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x, c8 = tid & 7, pr = tid >> 3;
   const int cvec = C / 8;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int p = pr; p < HW; p += 32) {
-    const uint4 v = x[((size_t)n * HW + p) * cvec + cg * 8 + c8];
-    float lo[4], hi[4];
-    unpack4_bf16(make_uint2(v.x, v.y), lo);
-    unpack4_bf16(make_uint2(v.z, v.w), hi);
+    float f[8];
+    enc_unpack8<FMT>(x[((size_t)n * HW + p) * cvec + cg * 8 + c8], f);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { s[i] += lo[i]; s[4 + i] += hi[i]; }
+    for (int i = 0; i < 8; ++i) s[i] += f[i];
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) red[pr][c8 * 8 + i] = s[i];
@@ -108,6 +116,7 @@ __global__ void __launch_bounds__(256) enc_pool_kernel(const uint4* __restrict__
 // statistics even though no parameter of the encoder is trained.  Three launches on the conv's bf16 output [P = N*H*W, C]:
 // per-block partial sums (fixed order), finalize (fp64 combine -> scale/shift, running statistics, counter), apply + LeakyReLU in place.
 
+template <int FMT>
 __global__ void __launch_bounds__(256) enc_bn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ partial, int P, int C, int chunk) {
   __shared__ float red[32][129];
   const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x, c8 = tid & 7, pr = tid >> 3;
@@ -118,9 +127,7 @@ __global__ void __launch_bounds__(256) enc_bn_stats_kernel(const uint4* __restri
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
   auto add = [&](const uint4 v) {
     float f[8];
-    { float lo[4], hi[4]; unpack4_bf16(make_uint2(v.x, v.y), lo); unpack4_bf16(make_uint2(v.z, v.w), hi);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; } }
+    enc_unpack8<FMT>(v, f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] += f[i]; q[i] = fmaf(f[i], f[i], q[i]); }
   };
@@ -175,48 +182,54 @@ __global__ void __launch_bounds__(256) enc_bn_finalize_kernel(const float* __res
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
 
-__global__ void __launch_bounds__(256) enc_bn_apply_kernel(const uint4* x, uint4* out, const float* __restrict__ scale_shift, size_t total_vec, int C,
-                                                           float neg_slope) {
+template <int FMT>
+__global__ void __launch_bounds__(256) enc_bn_apply_kernel(const uint4* x, uint4* out, uint4* out_bf16, const float* __restrict__ scale_shift, size_t total_vec,
+                                                           int C, float neg_slope) {
   const int cvec = C / 8;
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total_vec; v += (size_t)gridDim.x * 256) {
     const int c0 = (int)(v % cvec) * 8;
-    const uint4 in = x[v];
     float f[8];
-    { float lo[4], hi[4]; unpack4_bf16(make_uint2(in.x, in.y), lo); unpack4_bf16(make_uint2(in.z, in.w), hi);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { f[i] = lo[i]; f[4 + i] = hi[i]; } }
+    enc_unpack8<FMT>(x[v], f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float y = fmaf(f[i], scale_shift[c0 + i], scale_shift[C + c0 + i]);
       f[i] = y > 0.f ? y : y * neg_slope;
     }
-    const uint2 lo = pack4_bf16(f[0], f[1], f[2], f[3]), hi = pack4_bf16(f[4], f[5], f[6], f[7]);
+    const uint2 lo = pack4<FMT>(f[0], f[1], f[2], f[3]), hi = pack4<FMT>(f[4], f[5], f[6], f[7]);
     out[v] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    if (out_bf16) {                                        // the weight-gradient kernels' operand: the same values as bf16
+      const uint2 l2 = pack4_bf16(f[0], f[1], f[2], f[3]), h2 = pack4_bf16(f[4], f[5], f[6], f[7]);
+      out_bf16[v] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    }
   }
 }
 
 extern "C" int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C) { return (int64_t)rumpy_bn_blocks(P, C) * 2 * C; }
-static int enc_bn_train(const rumpy_enc_bn_args* p, void* out, float* saved, void* stream, const char* who) {
+static int enc_bn_train(const rumpy_enc_bn_args* p, void* out, void* out_bf16, float* saved, void* stream, const char* who) {
   if (!p || !p->x || !p->gamma || !p->beta || !p->partial || !p->scale_shift) { rumpy_set_error("%s: null pointer", who); return RUMPY_E_ARG; }
   if ((p->running_mean == nullptr) != (p->running_var == nullptr)) { rumpy_set_error("%s: running_mean and running_var go together", who); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("%s: fmt %d", who, p->fmt); return RUMPY_E_ARG; }
+  const bool h16 = p->fmt == RUMPY_FMT_F16;
   if (p->P < 2 || p->C <= 0 || p->C % 64) {   // torch refuses a single value per channel in training mode, too
     rumpy_set_error("%s: needs more than one value per channel and C %% 64 == 0 (P=%d C=%d)", who, p->P, p->C); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   const int nblk = rumpy_bn_blocks(p->P, p->C), chunk = (p->P + nblk - 1) / nblk;
-  hipLaunchKernelGGL(enc_bn_stats_kernel, dim3(nblk, p->C / 64), dim3(256), 0, s, (const uint4*)p->x, p->partial, p->P, p->C, chunk);
+  if (h16) hipLaunchKernelGGL(enc_bn_stats_kernel<RUMPY_FMT_F16>, dim3(nblk, p->C / 64), dim3(256), 0, s, (const uint4*)p->x, p->partial, p->P, p->C, chunk);
+  else hipLaunchKernelGGL(enc_bn_stats_kernel<RUMPY_FMT_BF16>, dim3(nblk, p->C / 64), dim3(256), 0, s, (const uint4*)p->x, p->partial, p->P, p->C, chunk);
   hipLaunchKernelGGL(enc_bn_finalize_kernel, dim3(p->C / 64), dim3(256), 0, s, p->partial, nblk, p->P, p->C, p->gamma, p->beta, p->running_mean,
                      p->running_var, (long long*)p->num_batches_tracked, p->scale_shift, saved, p->eps, p->momentum);
   const size_t tv = (size_t)p->P * (p->C / 8);
   size_t blocks = (tv + 255) / 256;
   const size_t cap = (size_t)rumpy_device_cus() * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(enc_bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)p->x, (uint4*)out, p->scale_shift, tv, p->C, p->neg_slope);
+  if (h16) hipLaunchKernelGGL(enc_bn_apply_kernel<RUMPY_FMT_F16>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)p->x, (uint4*)out, (uint4*)out_bf16, p->scale_shift, tv, p->C, p->neg_slope);
+  else hipLaunchKernelGGL(enc_bn_apply_kernel<RUMPY_FMT_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)p->x, (uint4*)out, (uint4*)out_bf16, p->scale_shift, tv, p->C, p->neg_slope);
   return rumpy_check_launch(who);
 }
-extern "C" int rumpy_enc_bn_train(const rumpy_enc_bn_args* p, void* stream) { return enc_bn_train(p, p ? p->x : nullptr, nullptr, stream, "rumpy_enc_bn_train"); }
-extern "C" int rumpy_enc_bn_train_keep(const rumpy_enc_bn_args* p, void* out, float* saved, void* stream) {
+extern "C" int rumpy_enc_bn_train(const rumpy_enc_bn_args* p, void* stream) { return enc_bn_train(p, p ? p->x : nullptr, nullptr, nullptr, stream, "rumpy_enc_bn_train"); }
+extern "C" int rumpy_enc_bn_train_keep(const rumpy_enc_bn_args* p, void* out, void* out_bf16, float* saved, void* stream) {
   if (!out || !saved) { rumpy_set_error("rumpy_enc_bn_train_keep: null pointer"); return RUMPY_E_ARG; }
-  return enc_bn_train(p, out, saved, stream, "rumpy_enc_bn_train_keep");
+  return enc_bn_train(p, out, out_bf16, saved, stream, "rumpy_enc_bn_train_keep");
 }
 
 extern "C" int rumpy_enc_conv(const rumpy_enc_conv_args* p, void* stream) {
@@ -231,13 +244,18 @@ extern "C" int rumpy_enc_conv(const rumpy_enc_conv_args* p, void* stream) {
   a.tiles_x = (a.Wo + 15) / 16; a.tiles_y = (a.Ho + 3) / 4;
   a.neg_slope = p->neg_slope;
   const dim3 grid((unsigned)(p->N * a.tiles_x * a.tiles_y), (unsigned)a.ctn);
-  if (p->stride == 1) hipLaunchKernelGGL((enc_conv_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (p->fmt == RUMPY_FMT_F16) {
+    if (p->stride == 1) hipLaunchKernelGGL((enc_conv_kernel<1, 4, RUMPY_FMT_F16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((enc_conv_kernel<2, 4, RUMPY_FMT_F16>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (p->fmt != RUMPY_FMT_BF16) { rumpy_set_error("rumpy_enc_conv: fmt %d", p->fmt); return RUMPY_E_ARG; }
+  else if (p->stride == 1) hipLaunchKernelGGL((enc_conv_kernel<1, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((enc_conv_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   return rumpy_check_launch("rumpy_enc_conv");
 }
 
-extern "C" int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
-  if (!x || !out || N <= 0 || HW <= 0 || C <= 0 || C % 64) { rumpy_set_error("rumpy_enc_pool: bad argument"); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(enc_pool_kernel, dim3(N, C / 64), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, out, HW, C);
+extern "C" int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, int32_t fmt, void* stream) {
+  if (!x || !out || N <= 0 || HW <= 0 || C <= 0 || C % 64 || (fmt != RUMPY_FMT_BF16 && fmt != RUMPY_FMT_F16)) { rumpy_set_error("rumpy_enc_pool: bad argument"); return RUMPY_E_ARG; }
+  if (fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(enc_pool_kernel<RUMPY_FMT_F16>, dim3(N, C / 64), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, out, HW, C);
+  else hipLaunchKernelGGL(enc_pool_kernel<RUMPY_FMT_BF16>, dim3(N, C / 64), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, out, HW, C);
   return rumpy_check_launch("rumpy_enc_pool");
 }

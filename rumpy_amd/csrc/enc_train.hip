@@ -35,10 +35,11 @@ __device__ __forceinline__ BnbRaw bnb_fetch(const BnBwd& a, int p, int cv, int c
   r.d = a.da ? a.da[(size_t)p * cvec + cv] : make_uint4(0, 0, 0, 0);
   return r;
 }
-// -> dy and xh of those 8 channels
+// -> dy and xh of those 8 channels (FMT: format of the stored conv output z; the gradient da is bf16)
+template <int FMT>
 __device__ __forceinline__ void bnb_decode(const BnBwd& a, const BnbCh& k, const BnbRaw& r, int p, int c0, float (&dy)[8], float (&xh)[8]) {
   float z[8], d[8];
-  { float lo[4], hi[4]; unpack4_bf16(make_uint2(r.z.x, r.z.y), lo); unpack4_bf16(make_uint2(r.z.z, r.z.w), hi);
+  { float lo[4], hi[4]; unpack4<FMT>(make_uint2(r.z.x, r.z.y), lo); unpack4<FMT>(make_uint2(r.z.z, r.z.w), hi);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { z[i] = lo[i]; z[4 + i] = hi[i]; } }
   if (a.da) {
@@ -58,6 +59,7 @@ __device__ __forceinline__ void bnb_decode(const BnBwd& a, const BnbCh& k, const
   }
 }
 
+template <int FMT>
 __global__ void __launch_bounds__(256) enc_bnb_stats_kernel(BnBwd a, float* __restrict__ partial, int chunk) {
   __shared__ float red[32][129];
   const int b = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x, c8 = tid & 7, pr = tid >> 3;
@@ -69,7 +71,7 @@ __global__ void __launch_bounds__(256) enc_bnb_stats_kernel(BnBwd a, float* __re
   for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
   auto add = [&](const BnbRaw& r, int p) {
     float dy[8], xh[8];
-    bnb_decode(a, k, r, p, c0, dy, xh);
+    bnb_decode<FMT>(a, k, r, p, c0, dy, xh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s[i] += dy[i]; q[i] = fmaf(dy[i], xh[i], q[i]); }
   };
@@ -116,13 +118,14 @@ __global__ void __launch_bounds__(256) enc_bnb_finalize_kernel(const float* __re
   coef[2 * C + c] = (float)(q / P);
 }
 
+template <int FMT>
 __global__ void __launch_bounds__(256) enc_bnb_apply_kernel(BnBwd a, const float* __restrict__ coef, uint4* __restrict__ dz, int Wo, int up, int Hz, int Wz) {
   const int cvec = a.C / 8;
   const size_t total = (size_t)a.P * cvec;
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
     const int cv = (int)(v % cvec), p = (int)(v / cvec), c0 = cv * 8;
     float dy[8], xh[8], r[8];
-    bnb_decode(a, bnb_channels(a, c0), bnb_fetch(a, p, cv, cvec), p, c0, dy, xh);
+    bnb_decode<FMT>(a, bnb_channels(a, c0), bnb_fetch(a, p, cv, cvec), p, c0, dy, xh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = coef[c0 + i] * (dy[i] - coef[a.C + c0 + i] - xh[i] * coef[2 * a.C + c0 + i]);
     const uint2 lo = pack4_bf16(r[0], r[1], r[2], r[3]), hi = pack4_bf16(r[4], r[5], r[6], r[7]);
@@ -139,6 +142,8 @@ extern "C" int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* p, void* stream) {
   if (!p || !p->z || (!p->da && !p->dpool) || !p->scale_shift || !p->saved || !p->gamma || !p->dz || !p->partial || !p->coef) {
     rumpy_set_error("rumpy_enc_bn_bwd: null pointer"); return RUMPY_E_ARG; }
   const long long P = (long long)p->N * p->Ho * p->Wo;
+  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("rumpy_enc_bn_bwd: fmt %d", p->fmt); return RUMPY_E_ARG; }
+  const bool h16 = p->fmt == RUMPY_FMT_F16;
   if (p->N <= 0 || p->Ho <= 0 || p->Wo <= 0 || P < 2 || P > 0x7fffffffLL || p->C <= 0 || p->C % 64 || (p->up != 1 && p->up != 2) ||
       p->Hz < p->up * (p->Ho - 1) + 1 || p->Wz < p->up * (p->Wo - 1) + 1) {
     rumpy_set_error("rumpy_enc_bn_bwd: unsupported shape (N=%d Ho=%d Wo=%d C=%d up=%d Hz=%d Wz=%d)", p->N, p->Ho, p->Wo, p->C, p->up, p->Hz, p->Wz);
@@ -148,14 +153,16 @@ extern "C" int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* p, void* stream) {
   a.z = (const uint4*)p->z; a.da = (const uint4*)p->da; a.dpool = p->dpool; a.scale_shift = p->scale_shift; a.saved = p->saved;
   a.P = (int)P; a.C = p->C; a.HW = p->Ho * p->Wo; a.inv_hw = 1.f / (float)a.HW; a.neg_slope = p->neg_slope;
   const int nblk = rumpy_bn_blocks(a.P, a.C), chunk = (a.P + nblk - 1) / nblk;
-  hipLaunchKernelGGL(enc_bnb_stats_kernel, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
+  if (h16) hipLaunchKernelGGL(enc_bnb_stats_kernel<RUMPY_FMT_F16>, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
+  else hipLaunchKernelGGL(enc_bnb_stats_kernel<RUMPY_FMT_BF16>, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
   hipLaunchKernelGGL(enc_bnb_finalize_kernel, dim3(a.C / 64), dim3(256), 0, s, p->partial, nblk, a.P, a.C, p->gamma, p->saved, p->dgamma, p->dbeta,
                      p->coef, p->scale);
   const size_t tv = (size_t)a.P * (a.C / 8);
   size_t blocks = (tv + 255) / 256;
   const size_t cap = (size_t)rumpy_device_cus() * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(enc_bnb_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, p->coef, (uint4*)p->dz, p->Wo, p->up, p->Hz, p->Wz);
+  if (h16) hipLaunchKernelGGL(enc_bnb_apply_kernel<RUMPY_FMT_F16>, dim3((unsigned)blocks), dim3(256), 0, s, a, p->coef, (uint4*)p->dz, p->Wo, p->up, p->Hz, p->Wz);
+  else hipLaunchKernelGGL(enc_bnb_apply_kernel<RUMPY_FMT_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, a, p->coef, (uint4*)p->dz, p->Wo, p->up, p->Hz, p->Wz);
   return rumpy_check_launch("rumpy_enc_bn_bwd");
 }
 

@@ -84,7 +84,7 @@ __device__ __forceinline__ void pack_item(const rumpy_pack_item& it) {
       const int wave = (int)(r2 & 3); r2 >>= 2;
       const int r = lane & 15, g = lane >> 4;
       const int half = s & 1, tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky;
-      {  // forward: r2 = ct*chn + ch; the 8 elements are 8 consecutive input channels (stride 9 floats in the master copy)
+      if (wf) {  // forward: r2 = ct*chn + ch; the 8 elements are 8 consecutive input channels (stride 9 floats in the master copy)
         const int ch = (int)(r2 % chn), ct = (int)(r2 / chn);
         const int c = 16 * wave + r;
         const int co = it.shuffle ? 4 * c + ct : 64 * ct + c;

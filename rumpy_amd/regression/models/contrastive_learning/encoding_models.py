@@ -61,18 +61,27 @@ class _LaunchGraph:
         self.graph.replay()
 
 
+# Storage format of the TRAINING forward pass (filter images, conv outputs z, stage outputs a): IEEE fp16 since round 3.  The gradient of this
+# network is dominated by LeakyReLU(0.1) inputs that change sign under the storage rounding (a tenfold change of that element's gradient):
+# with 8-bit mantissas (bf16) the trunk's gradient is 5-10 % off the fp32 reference's, with fp16's 11 bits 2-3 % (CPU simulation of the
+# rounding points and GPU agree).  Values after BatchNorm are O(1): far inside fp16's range.  The backward pass keeps
+# bf16 (gradient range): the weight-gradient kernels read a bf16 copy of every stage output, written by the same BatchNorm apply pass.
+# RUMPY_ENC_TRAIN_BF16=1: the round-2 all-bf16 forward pass (A/B).
+TRAIN_FMT = L.FMT_BF16 if os.environ.get('RUMPY_ENC_TRAIN_BF16') == '1' else L.FMT_F16
+TRAIN_DT = torch.float16 if TRAIN_FMT == L.FMT_F16 else BF16
+
 _SR_CONVS = os.environ.get('RUMPY_ENC_OWN_CONV') != '1'      # A/B: the encoder's own kernel for every launch
 
 
-def _conv_plain(x, w, bias, out, N, H, W, cin, cout, stream):
+def _conv_plain(x, w, bias, out, N, H, W, cin, cout, stream, fmt=0):
     """stride-1 3x3 conv without activation (a training-mode stage, or a data gradient): the SR path's kernels where they take the shape and are
     faster - Cin = 64 (strip kernel: 43 vs 95 us for 64 -> 64 at 256 x 48 x 48) and Cin = 256 on maps of 24+ rows (128 vs 188 us for 256 -> 128 at
     256 x 24 x 24; tests/tools/enc_conv_ab.py) -, else the encoder's general kernel.  Same filter images, same bf16 NHWC layout."""
     if _SR_CONVS and (cin == 64 or (cin == 256 and H >= 24)):
         L.call('rumpy_conv3x3', L.ConvArgs(x=x, w=w, bias=bias, out=out, mask=None, res1=None, res2=None, pool=None, N=N, H=H, W=W,
-                                           cin_chunks=cin // 64, cout_tiles=cout // 64, in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0, fmt=0), stream)
+                                           cin_chunks=cin // 64, cout_tiles=cout // 64, in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0, fmt=fmt), stream)
     else:
-        L.call('rumpy_enc_conv', L.EncConvArgs(x=x, w=w, bias=bias, out=out, N=N, H=H, W=W, cin=cin, cout=cout, stride=1, neg_slope=1.0), stream)
+        L.call('rumpy_enc_conv', L.EncConvArgs(x=x, w=w, bias=bias, out=out, N=N, H=H, W=W, cin=cin, cout=cout, stride=1, neg_slope=1.0, fmt=fmt), stream)
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -215,7 +224,7 @@ class Encoder(nn.Module):
             ts += [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
         return tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts) + ((self._stats_epoch,) if with_stats else ())
 
-    def _pack(self, weights, biases, dev, dgrad=False, slot='raw'):
+    def _pack(self, weights, biases, dev, dgrad=False, slot='raw', fwd_fmt=0):
         """[(w fp32 OIHW, b)] of the five 64-multiple convs -> MFMA fragment images through rumpy_pack_weights
         (dgrad: also the transposed + flipped image the data gradient convolves with).  The images of a slot live in persistent buffers -
         captured launch graphs read them - and so does the item table as long as the sources' addresses stay."""
@@ -224,17 +233,23 @@ class Encoder(nn.Module):
             out = []
             for w in weights:
                 cout, cin = w.shape[:2]
-                wf = torch.empty(cout * cin * 9, dtype=BF16, device=dev)
+                wf = torch.empty(cout * cin * 9, dtype=torch.float16 if fwd_fmt == L.FMT_F16 else BF16, device=dev)
                 wd = torch.empty(cout * cin * 9, dtype=BF16, device=dev) if dgrad else None
                 bp = torch.empty(cout, dtype=torch.float32, device=dev)
                 out.append((wf, wd, bp) if dgrad else (wf, bp))
             st = self._img_store[slot] = dict(dev=dev, imgs=out, src=None, tab=None)
         src = tuple(_ptr(t) for t in list(weights) + list(biases))
         if st['src'] != src:
-            items = [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[0]), w_dgrad=_ptr(im[1]) if dgrad else None, b_packed=_ptr(im[-1]),
-                                cout=w.shape[0], cin=w.shape[1], kind=0, shuffle=0) for w, b, im in zip(weights, biases, st['imgs'])]
-            st['tab'], st['src'] = _dev_bytes((L.PackItem * len(items))(*items), dev), src
-        L.check(L.lib().rumpy_pack_weights(_ptr(st['tab']), len(weights), torch.cuda.current_stream(dev).cuda_stream), 'rumpy_pack_weights')
+            if fwd_fmt and dgrad:      # forward image in fp16, data-gradient image in bf16: two items per conv
+                items = [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[0]), w_dgrad=None, b_packed=_ptr(im[-1]), cout=w.shape[0], cin=w.shape[1], kind=0,
+                                    shuffle=0, fmt=fwd_fmt) for w, b, im in zip(weights, biases, st['imgs'])] + \
+                        [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=None, w_dgrad=_ptr(im[1]), b_packed=None, cout=w.shape[0], cin=w.shape[1], kind=0,
+                                    shuffle=0) for w, b, im in zip(weights, biases, st['imgs'])]
+            else:
+                items = [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[0]), w_dgrad=_ptr(im[1]) if dgrad else None, b_packed=_ptr(im[-1]),
+                                    cout=w.shape[0], cin=w.shape[1], kind=0, shuffle=0, fmt=fwd_fmt) for w, b, im in zip(weights, biases, st['imgs'])]
+            st['tab'], st['src'], st['n'] = _dev_bytes((L.PackItem * len(items))(*items), dev), src, len(items)
+        L.check(L.lib().rumpy_pack_weights(_ptr(st['tab']), st['n'], torch.cuda.current_stream(dev).cuda_stream), 'rumpy_pack_weights')
         return st['imgs'], (st['tab'], weights, biases)
 
     def _raw_images(self, dev):
@@ -243,7 +258,7 @@ class Encoder(nn.Module):
             convs, _ = self._convs()
             ws = [c.weight.detach().float().contiguous() for c in convs]
             bs = [c.bias.detach().float().contiguous() for c in convs]
-            imgs, keep = self._pack(ws[1:], bs[1:], dev)
+            imgs, keep = self._pack(ws[1:], bs[1:], dev, fwd_fmt=TRAIN_FMT)       # batch-statistics mode = the training forward's storage format
             self._packed = (key, [(ws[0], bs[0])] + imgs, keep)
         return self._packed[1]
 
@@ -302,20 +317,23 @@ class Encoder(nn.Module):
         xs, fea = plan['x'], plan['fea']
         xs.copy_(x)
         graphable = all(bn.momentum is not None for bn in bns)      # a cumulative average changes its factor every step
+        # batch-statistics mode (a MoCo key encoder, the blind pipeline's frozen encoder under net.train()) stores like the training forward pass:
+        # fp16 (same 2-byte elements: the plan's buffers serve both modes); evaluation mode (BatchNorm folded into the filters) stays bf16
+        fmt = TRAIN_FMT if train else L.FMT_BF16
 
         def launches():
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(xs), w=_ptr(w0), b=_ptr(b0), out=_ptr(acts[0]), N=N, C=3, H=H, W=W, cout=64,
-                                                   neg_slope_m1=0.0 if train else SLOPE - 1.0), stream)
+                                                   neg_slope_m1=0.0 if train else SLOPE - 1.0, fmt=fmt), stream)
             h, w = H, W
             for i, (cin, cout, stride) in enumerate(LAYERS):
                 if i > 0:
                     wf, bp = imgs[i]
                     if train and stride == 1:
-                        _conv_plain(_ptr(acts[i - 1]), _ptr(wf), _ptr(bp), _ptr(acts[i]), N, h, w, cin, cout, stream)
+                        _conv_plain(_ptr(acts[i - 1]), _ptr(wf), _ptr(bp), _ptr(acts[i]), N, h, w, cin, cout, stream, fmt=fmt)
                     else:
                         L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(acts[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(acts[i]), N=N, H=h, W=w, cin=cin,
-                                                               cout=cout, stride=stride, neg_slope=1.0 if train else SLOPE), stream)
+                                                               cout=cout, stride=stride, neg_slope=1.0 if train else SLOPE, fmt=fmt), stream)
                     h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
                 if train:
                     bn = bns[i]
@@ -324,8 +342,8 @@ class Encoder(nn.Module):
                                                              running_mean=_ptr(bn.running_mean), running_var=_ptr(bn.running_var),
                                                              num_batches_tracked=_ptr(bn.num_batches_tracked), partial=_ptr(plan['partial']),
                                                              scale_shift=_ptr(plan['scale_shift']), P=N * h * w, C=cout, eps=bn.eps, momentum=mom,
-                                                             neg_slope=SLOPE), stream)
-            L.check(L.lib().rumpy_enc_pool(_ptr(acts[5]), _ptr(fea), N, h * w, 256, stream), 'rumpy_enc_pool')
+                                                             neg_slope=SLOPE, fmt=fmt), stream)
+            L.check(L.lib().rumpy_enc_pool(_ptr(acts[5]), _ptr(fea), N, h * w, 256, fmt, stream), 'rumpy_enc_pool')
 
         # the launch list depends on the mode and on the addresses it reads: parameters, statistics and the slot's image buffers
         gkey = (train, _ptr(w0), _ptr(imgs[1][0]), _ptr(bns[0].weight), _ptr(bns[0].running_mean))
@@ -353,7 +371,7 @@ class Encoder(nn.Module):
             convs, _ = self._convs()
             ws = [c.weight.detach() for c in convs]
             bs = [c.bias.detach() for c in convs]
-            imgs, keep = self._pack(ws[1:], bs[1:], dev, dgrad=True, slot='train')
+            imgs, keep = self._pack(ws[1:], bs[1:], dev, dgrad=True, slot='train', fwd_fmt=TRAIN_FMT)
             self._train_images = (key, imgs, keep)
         return self._train_images[1]
 
@@ -364,18 +382,19 @@ class Encoder(nn.Module):
             return p
         lib = L.lib()
         new = lambda *shape, dtype=BF16: torch.empty(*shape, dtype=dtype, device=dev)
-        z, a, dz, da, dims, h, w = [], [], [], [], [], H, W
+        z, a, abf, dz, da, dims, h, w = [], [], [], [], [], [], H, W
         for cin, cout, stride in LAYERS:
             hi, wi = h, w                                   # this conv's input size = the grid its gradients live on
             h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
             dims.append((hi, wi, h, w))
-            z.append(new(N, h, w, cout))
-            a.append(new(N, h, w, cout))
+            z.append(new(N, h, w, cout, dtype=TRAIN_DT))       # forward storage: fp16 (TRAIN_FMT)
+            a.append(new(N, h, w, cout, dtype=TRAIN_DT))
+            abf.append(new(N, h, w, cout) if (TRAIN_FMT and len(abf) < 5) else None)     # bf16 copy of a stage output: the next conv's weight-gradient operand
             # gradient at the conv output on the stride-1 grid of the conv's input (stride 2: every second pixel, the rest stays zero)
             dz.append(torch.zeros(N, hi, wi, cout, dtype=BF16, device=dev) if stride == 2 else new(N, h, w, cout))
             da.append(new(N, h, w, cout))                   # gradient at the stage's (LeakyReLU) output; the last one comes from the pool
         part = new(max(int(lib.rumpy_enc_bn_partial_floats(t.shape[0] * t.shape[1] * t.shape[2], t.shape[3])) for t in z), dtype=torch.float32)
-        p = dict(z=z, a=a, dz=dz, da=da, dims=dims, partial=part, coef=new(3 * 256, dtype=torch.float32),
+        p = dict(z=z, a=a, abf=abf, dz=dz, da=da, dims=dims, partial=part, coef=new(3 * 256, dtype=torch.float32),
                  ss=[new(2 * c, dtype=torch.float32) for _, c, _ in LAYERS], saved=[new(2 * c, dtype=torch.float32) for _, c, _ in LAYERS],
                  zero_bias=torch.zeros(256, dtype=torch.float32, device=dev), x=new(N, 3, H, W, dtype=torch.float32),
                  fea=new(N, 256, dtype=torch.float32), dfea=new(N, 256, dtype=torch.float32),
@@ -398,7 +417,7 @@ class Encoder(nn.Module):
             nt = ntiles(hi, wi)
             ranges = [(t0, min(nt, t0 + per)) for t0 in range(0, nt, per)]
             for k, (t0, t1) in enumerate(ranges):
-                jobs.append(L.WgradJob(x=_ptr(a[i - 1]), dy=_ptr(dz[i]), slab=slabs.data_ptr() + 4 * (off + k * sf), n0=0, n1=N, t0=t0, t1=t1,
+                jobs.append(L.WgradJob(x=_ptr(abf[i - 1] if TRAIN_FMT else a[i - 1]), dy=_ptr(dz[i]), slab=slabs.data_ptr() + 4 * (off + k * sf), n0=0, n1=N, t0=t0, t1=t1,
                                        H=hi, W=wi, x_cstride=cin, x_coff=ch * 64, dy_mode=0, dy_cstride=cout, dy_coff=ct * 64, mt=4))
             items.append(L.ReduceItem(slab=slabs.data_ptr() + 4 * off, slab_stride=sf, njobs=len(ranges), mt=4, co_count=64, co_mode=0,
                                       co_off=ct * 64, ci_total=cin, ci_off=ch * 64, write_bias=1 if ch == 0 else 0, scale=1.0,
@@ -431,25 +450,25 @@ class Encoder(nn.Module):
         def launches():
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(xs), w=_ptr(convs[0].weight), b=_ptr(convs[0].bias), out=_ptr(z[0]), N=N, C=3, H=H, W=W,
-                                                   cout=64, neg_slope_m1=0.0), stream)
+                                                   cout=64, neg_slope_m1=0.0, fmt=TRAIN_FMT), stream)
             for i, (cin, cout, stride) in enumerate(LAYERS):
                 hi, wi, ho, wo = plan['dims'][i]
                 if i > 0:
                     wf, _, bp = imgs[i - 1]
                     if stride == 1:
-                        _conv_plain(_ptr(a[i - 1]), _ptr(wf), _ptr(bp), _ptr(z[i]), N, hi, wi, cin, cout, stream)
+                        _conv_plain(_ptr(a[i - 1]), _ptr(wf), _ptr(bp), _ptr(z[i]), N, hi, wi, cin, cout, stream, fmt=TRAIN_FMT)
                     else:
                         L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
-                                                               cout=cout, stride=stride, neg_slope=1.0), stream)
+                                                               cout=cout, stride=stride, neg_slope=1.0, fmt=TRAIN_FMT), stream)
                 bn = bns[i]
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
                 args = L.EncBnArgs(x=_ptr(z[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias), running_mean=_ptr(bn.running_mean),
                                    running_var=_ptr(bn.running_var), num_batches_tracked=_ptr(bn.num_batches_tracked),
                                    partial=_ptr(plan['partial']), scale_shift=_ptr(plan['ss'][i]), P=N * ho * wo, C=cout, eps=bn.eps, momentum=mom,
-                                   neg_slope=SLOPE)
-                L.check(L.lib().rumpy_enc_bn_train_keep(C.byref(args), _ptr(a[i]), _ptr(plan['saved'][i]), stream), 'rumpy_enc_bn_train_keep')
+                                   neg_slope=SLOPE, fmt=TRAIN_FMT)
+                L.check(L.lib().rumpy_enc_bn_train_keep(C.byref(args), _ptr(a[i]), _ptr(plan['abf'][i]), _ptr(plan['saved'][i]), stream), 'rumpy_enc_bn_train_keep')
             ho, wo = plan['dims'][5][2:]
-            L.check(L.lib().rumpy_enc_pool(_ptr(a[5]), _ptr(fea), N, ho * wo, 256, stream), 'rumpy_enc_pool')
+            L.check(L.lib().rumpy_enc_pool(_ptr(a[5]), _ptr(fea), N, ho * wo, 256, TRAIN_FMT, stream), 'rumpy_enc_pool')
 
         gkey = (_ptr(convs[0].weight), _ptr(imgs[0][0]), _ptr(bns[0].weight), _ptr(bns[0].running_mean))
         if plan.get('gkey') != gkey:
@@ -492,7 +511,7 @@ class Encoder(nn.Module):
                                                           dgamma=_ptr(gv(bn.weight)), dbeta=_ptr(gv(bn.bias)), dz=_ptr(dz[i]),
                                                           partial=_ptr(plan['partial']), coef=_ptr(plan['coef']), N=N, Ho=ho, Wo=wo, C=cout,
                                                           up=stride, Hz=hi if stride == 2 else ho, Wz=wi if stride == 2 else wo,
-                                                          neg_slope=SLOPE, scale=1.0), stream)
+                                                          neg_slope=SLOPE, scale=1.0, fmt=TRAIN_FMT), stream)
                 if i > 0:      # data gradient: the stride-1 convolution of dz (on the input's grid) with the transposed, flipped filter
                     _, wd, _ = imgs[i - 1]
                     _conv_plain(_ptr(dz[i]), _ptr(wd), _ptr(plan['zero_bias']), _ptr(da[i - 1]),

@@ -2,14 +2,14 @@
 update against plain torch, the encoder trunk's gradients and whole MoCo / SupMoCo training steps behind define_model('mococontrastive' |
 'supmoco') against the CPU oracle (oracle/contrastive_oracle.py, pinned on the real reference handlers by golden G20).
 
-Tolerances: the trunk stores filters, conv outputs and stage outputs (and their gradients) as bf16, with fp32 accumulation.  Two references:
-* the oracle with ``bf16_storage`` (the same graph rounded at the same points; differences = summation order, and the rare element whose
-  bf16 rounding that order decides - a few per cent of them, fp32 summation error 1e-4 against a bf16 step of 4e-3 - and the LeakyReLU
-  signs that follow): whole gradient <= 6e-2 relative, every tensor <= 1.2e-1 (measured 3.5-4e-2 / 7.5e-2);
-* the fp32 oracle: whole gradient <= 1.5e-1, every tensor <= 3e-1.  That is the price of bf16 storage on THIS network, not of the kernels:
-  a LeakyReLU input whose sign changes under a 2^-9 relative perturbation changes its gradient tenfold, about 0.3 % of the elements do,
-  and sqrt(0.003) x 0.9 = 5 % per rounding point (filters, conv outputs, stage outputs each give 6-9 % alone in the CPU simulation, all
-  together 10 %: measured 5-10 % on the GPU).  Gradient rounding alone costs 2e-3.
+Tolerances (round 3): the TRAINING forward pass stores filters, conv outputs and stage outputs as IEEE fp16 (their gradients as bf16), with fp32
+accumulation.  The acceptance criterion is the fp32 oracle - what the reference computes:
+* fp32 oracle: whole gradient <= FP32_WHOLE, every tensor <= FP32_TENSOR (constants below; round 2, with bf16 storage: 1.5e-1 / 3e-1, measured
+  5-10 %).  What remains is a property of 16-bit storage on THIS network, not of the kernels: a LeakyReLU(0.1) input whose sign changes under
+  the storage rounding changes its gradient tenfold; fp16's 2^-12 flips 8 x fewer of them than bf16's 2^-9 (CPU simulation of the rounding
+  points: 2.1-2.8e-2 whole, 5.4e-2 worst tensor; bf16 5-10e-2 / 1.4-1.8e-1);
+* the oracle with the HIP path's storage points (``bf16_storage``: the same graph rounded at the same points; differences = summation order
+  and the rare element whose rounding that order decides) stays as the tight DIAGNOSTIC: EMU_WHOLE / EMU_TENSOR.
 The conv biases in front of a training-mode BatchNorm have a mathematically zero gradient (noise on both sides): smallness only."""
 import tempfile
 
@@ -28,6 +28,9 @@ from rumpy_amd.shared_framework.models import define_model
 
 DEV = torch.device('cuda:0')
 BF16 = torch.bfloat16
+FP32_WHOLE, FP32_TENSOR = 3.5e-2, 1.2e-1     # against the fp32 oracle (acceptance): measured 0.5-2.9e-2 / 3.4-9.6e-2 over the ten cases of this file
+                                             # (round 2, bf16 forward storage: bounds 1.5e-1 / 3e-1, measured 5-10e-2 / 14-21e-2)
+EMU_WHOLE, EMU_TENSOR = 3e-2, 6e-2           # against the oracle with the HIP path's storage points (diagnostic): measured 0.3-2.1e-2 / 1.6-4.9e-2
 ZERO_GRAD_BIASES = ('E.0.bias', 'E.3.bias', 'E.6.bias', 'E.9.bias', 'E.12.bias', 'E.15.bias')
 
 
@@ -66,7 +69,7 @@ def test_bn_lrelu_backward_kernel_against_torch(N, Ho, Wo, C, up, pool):
     fa = L.EncBnArgs(x=zd.data_ptr(), gamma=gd.data_ptr(), beta=bd.data_ptr(), running_mean=None, running_var=None, num_batches_tracked=None,
                      partial=part.data_ptr(), scale_shift=ss.data_ptr(), P=P, C=C, eps=1e-5, momentum=0.1, neg_slope=0.1)
     import ctypes
-    L.check(L.lib().rumpy_enc_bn_train_keep(ctypes.byref(fa), out.data_ptr(), saved.data_ptr(), _stream()), 'keep')
+    L.check(L.lib().rumpy_enc_bn_train_keep(ctypes.byref(fa), out.data_ptr(), None, saved.data_ptr(), _stream()), 'keep')
     torch.cuda.synchronize()
     assert torch.equal(zd.cpu(), z)                                            # out of place: the conv output is kept
     assert _rel(out.float().cpu().permute(0, 3, 1, 2), a_ref.detach()) < 4e-3
@@ -153,8 +156,10 @@ def test_encoder_trunk_forward_and_gradients_against_oracle(N, hw):
     assert _rel(fe.detach(), outs[1][0]) < 3e-3 and _rel(qe['q'].detach(), outs[1][1]) < 4e-3            # bf16-storage graph
     ((fe * r1.to(DEV)).sum() + (qe['q'] * r2.to(DEV)).sum()).backward()
     torch.cuda.synchronize()
-    _check_encoder_grads(list(e.named_parameters()), list(ob.named_parameters()), 6e-2, 1.2e-1)
-    _check_encoder_grads(list(e.named_parameters()), list(oe.named_parameters()), 1.5e-1, 3e-1)
+    w32 = _check_encoder_grads(list(e.named_parameters()), list(oe.named_parameters()), FP32_WHOLE, FP32_TENSOR)      # fp32 graph: the criterion
+    wem = _check_encoder_grads(list(e.named_parameters()), list(ob.named_parameters()), EMU_WHOLE, EMU_TENSOR)        # same storage points: diagnostic
+    print('encoder trunk N=%d %s: gradient vs fp32 oracle whole %.3e worst %.3e (%s); vs storage-point oracle whole %.3e worst %.3e'
+          % (N, hw, w32[0], w32[1][0], w32[1][1], wem[0], wem[1][0]))
     # BatchNorm running statistics moved like torch's
     for k, v in oe.state_dict().items():
         if 'running' in k:
@@ -211,6 +216,21 @@ def _warm_queue(h, oh, seed, n):
             net.queue_ptr[0] = n
 
 
+def _storage_point_oracle(name, **kw):
+    oe = CO.OracleContrastiveHandler(name, **kw)
+    for enc in ([oe.net] if name == 'supcon' else [oe.net.encoder_q, oe.net.encoder_k]):
+        enc.bf16_storage = True
+    return oe
+
+
+def _check_both(h, oh, oe, what):
+    """gradient of the step against the fp32 oracle (the criterion) and against the oracle with the HIP path's storage points (diagnostic)"""
+    w32 = _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), FP32_WHOLE, FP32_TENSOR)
+    wem = _check_encoder_grads(list(h.net.named_parameters()), list(oe.net.named_parameters()), EMU_WHOLE, EMU_TENSOR)
+    print('%s: gradient vs fp32 oracle whole %.3e worst %.3e (%s); vs storage-point oracle whole %.3e worst %.3e'
+          % (what, w32[0], w32[1][0], w32[1][1], wem[0], wem[1][0]))
+
+
 def _check_step(h, oh, loss, out, oloss, ologits, logits_tol=0.25):
     assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (float(loss), float(oloss))
     # logits are cosines / T (T = 0.07): 0.25 = a cosine error of 0.0175 from six bf16 layers and the head
@@ -220,19 +240,21 @@ def _check_step(h, oh, loss, out, oloss, ologits, logits_tol=0.25):
 @pytest.mark.parametrize('crops,N', [(2, 8), (3, 4)])
 def test_moco_training_step_against_oracle(crops, N):
     h = define_model('mococontrastive', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=crops, lr=1e-3)
-    oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=crops, lr=1e-3)
-    oh.net.encoder_q.bf16_storage = oh.net.encoder_k.bf16_storage = True
+    oh = CO.OracleContrastiveHandler('mococontrastive', crop_count=crops, lr=1e-3)          # the fp32 graph: what the reference computes
+    oe = _storage_point_oracle('mococontrastive', crop_count=crops, lr=1e-3)                # the same with the HIP path's storage points (diagnostic)
     assert list(h.net.state_dict().keys()) == list(oh.net.state_dict().keys())
     assert type(h.optimizer).__name__ == 'FlatAdam'
     _seed_handler(h, oh, 400 + crops)
     _warm_queue(h, oh, 450 + crops, 64)
+    oe.net.load_state_dict(oh.net.state_dict())
     k_before = h.net.encoder_k.flat_p.clone()
     x = CO.contrastive_batch(410 + crops, N, crops).view(N, 3 * crops, 32, 32)
     oloss, ologits, _ = oh.run_train(x)
+    oe.run_train(x)
     loss, out = h.run_train(x=x, y=None)
     assert out.shape == (N, 1 + 8192) and not out.is_cuda
     _check_step(h, oh, loss, out, oloss, ologits)
-    _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+    _check_both(h, oh, oe, 'moco %d crops' % crops)
     # key encoder: momentum update of the PRE-step query weights (exact arithmetic), untouched by the optimizer
     want_k = torch.cat([p.detach().reshape(-1) for p in oh.net.encoder_k.parameters()])
     assert torch.allclose(h.net.encoder_k.flat_p.cpu(), want_k, atol=1e-7, rtol=1e-6)
@@ -258,20 +280,23 @@ def test_supmoco_training_steps_against_oracle():
     h = define_model('supmoco', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
                      data_type='noise', labelling_strategy='double_precision')
     oh = CO.OracleContrastiveHandler('supmoco', crop_count=3, lr=1e-3)
-    oh.net.encoder_q.bf16_storage = oh.net.encoder_k.bf16_storage = True
+    oe = _storage_point_oracle('supmoco', crop_count=3, lr=1e-3)
     _seed_handler(h, oh, 500)
     col, fam, weights, total = CO.oracle_label_structure([k[0] for k in keys], 'noise', 'double_precision')
     olabels = torch.tensor([CO.oracle_class_label(r, col, fam, weights, 'double_precision') for r in meta.numpy()])
     oh.net.register_classes(total)
+    oe.net.register_classes(total)
     for step in range(2):
         x = CO.contrastive_batch(510 + step, 4, 3).view(4, 9, 32, 32)
+        oe.net.load_state_dict(oh.net.state_dict())
         oloss, ologits, ofea = oh.run_train(x, olabels)
+        oe.run_train(x, olabels)
         loss, emb = h.run_train(x=x, y=meta, metadata_keys=keys)
         assert h.total_classes == total and h.net.num_classes == total
         assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (step, float(loss), float(oloss))
         assert _rel(emb, ofea) < 5e-3
         if step == 1:       # the second step has queue positives (images 0 and 2 share a class with the first step's keys)
-            _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+            _check_both(h, oh, oe, 'supmoco')
         else:               # both sides start the second step from the oracle's state (Adam's first step amplifies gradient noise into +-lr)
             assert float((h.net.encoder_q.flat_p.cpu() - torch.cat([p.detach().reshape(-1) for p in oh.net.encoder_q.parameters()])).abs().mean()) < 1e-4
             h.net.load_state_dict(oh.net.state_dict())
@@ -284,19 +309,22 @@ def test_weakcon_training_steps_against_oracle():
     h = define_model('weakcon', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
                      data_type='noise')
     oh = CO.OracleContrastiveHandler('weakcon', crop_count=3, lr=1e-3)
-    oh.net.encoder_q.bf16_storage = oh.net.encoder_k.bf16_storage = True
+    oe = _storage_point_oracle('weakcon', crop_count=3, lr=1e-3)
     _seed_handler(h, oh, 600)
     col, fam, _, _ = CO.oracle_label_structure([k[0] for k in keys], 'noise', 'default')
     vectors = torch.from_numpy(np.stack([CO.oracle_degradation_vector(r, col, fam) for r in meta.numpy()]).T.copy())
     oh.net.register_vector(vectors.shape[0])
+    oe.net.register_vector(vectors.shape[0])
     for step in range(2):
         x = CO.contrastive_batch(610 + step, 4, 3).view(4, 9, 32, 32)
+        oe.net.load_state_dict(oh.net.state_dict())
         oloss, ologits, ofea = oh.run_train(x, vectors)
+        oe.run_train(x, vectors)
         loss, emb = h.run_train(x=x, y=meta, metadata_keys=keys)
         assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (step, float(loss), float(oloss))
         assert _rel(emb, ofea) < 5e-3
         if step == 1:       # the second step's negatives carry non-zero weights for the first step's keys
-            _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+            _check_both(h, oh, oe, 'weakcon')
         else:
             h.net.load_state_dict(oh.net.state_dict())
     assert torch.allclose(h.net.queue_vectors[:, :8].cpu(), oh.net.queue_vectors[:, :8]) and int(h.net.queue_ptr) == 8
@@ -310,23 +338,25 @@ def test_supcon_training_step_against_oracle():
     h = define_model('supcon', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=False, model_name='default', crop_count=3, lr=1e-3,
                      data_type='noise', labelling_strategy='double_precision')
     oh = CO.OracleContrastiveHandler('supcon', crop_count=3, lr=1e-3)
-    oh.net.bf16_storage = True
+    oe = _storage_point_oracle('supcon', crop_count=3, lr=1e-3)
     enc = O.seeded_encoder_state(O.OracleEncoder(), 700)
     for k in list(enc):
         if k.startswith('mlp.2'):
             enc[k] = enc[k] * 0.05         # the handler feeds q un-normalised into logits / 0.07: keep them in exp()'s range
     h.net.load_state_dict(enc)
     oh.net.load_state_dict(enc)
+    oe.net.load_state_dict(enc)
     assert type(h.optimizer).__name__ == 'FlatAdam'
     col, fam, weights, total = CO.oracle_label_structure([k[0] for k in keys], 'noise', 'double_precision')
     olabels = torch.tensor([[float(CO.oracle_class_label(r, col, fam, weights, 'double_precision')) for r in meta.numpy()]])
     x = CO.contrastive_batch(710, 4, 3).view(4, 9, 32, 32)
     oloss, _, ofea = oh.run_train(x, olabels)
+    oe.run_train(x, olabels)
     before = h.net.flat_p.clone()
     loss, emb = h.run_train(x=x, y=meta, metadata_keys=keys)
     assert abs(float(loss) - float(oloss)) <= 0.03 * max(1.0, abs(float(oloss))), (float(loss), float(oloss))
     assert _rel(emb, ofea) < 5e-3
-    _check_encoder_grads(list(h.net.named_parameters()), list(oh.net.named_parameters()), 6e-2, 1.5e-1)
+    _check_both(h, oh, oe, 'supcon')
     assert not torch.equal(h.net.flat_p, before)
 
 

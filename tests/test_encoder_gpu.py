@@ -57,7 +57,7 @@ def test_enc_conv_against_torch(N, H, W, cin, cout, stride):
     assert float((got - ref).abs().max()) <= 2e-3 * scale + 2 ** -8 * scale, float((got - ref).abs().max())
     # pooling of that map
     pooled = torch.zeros(N, cout, device=DEV)
-    L.check(L.lib().rumpy_enc_pool(out.data_ptr(), pooled.data_ptr(), N, Ho * Wo, cout, _stream()), 'pool')
+    L.check(L.lib().rumpy_enc_pool(out.data_ptr(), pooled.data_ptr(), N, Ho * Wo, cout, 0, _stream()), 'pool')
     torch.cuda.synchronize()
     assert torch.allclose(pooled.cpu(), out.float().cpu().mean((1, 2)), atol=1e-5, rtol=1e-5)
 
