@@ -508,6 +508,47 @@ int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* a, void* stream);
 /* key-encoder momentum update over flat fp32 buffers: k = k * m + q * one_minus_m (two rounded products, then the sum: moco.py:71) */
 int rumpy_ema(float* k, const float* q, int64_t n, float m, float one_minus_m, void* stream);
 
+/* ---- the contrastive head of the encoder-training step (csrc/contrastive.hip; ABI 3): mlp head, L2 normalisation, MoCo / SupMoCo logits and
+ * the softmax cross-entropy - rumpy/regression/models/contrastive_learning/encoding_models.py:43-55, moco.py:147-177, supmoco.py:75-119,
+ * handlers.py:57 - forward and backward, exact fp32 (the reference's precision: these are cosines / 0.07), fixed summation orders.
+ * rumpy_sgemm: C[m, n] = act(alpha * sum_k A(m, k) B(k, n) + bias[n]) [+ C], A(m, k) = A[m*sam + k*sak], B(k, n) = B[k*sbk + n*sbn], row
+ * stride ldc; act = LeakyReLU(leaky_slope) (1 = none).  Products with few outputs and a long K (rumpy_sgemm_partial_floats(M, N, K) > 0)
+ * run split over K and need `partial` of that many floats. */
+typedef struct {
+  const float* A; const float* B; float* C;
+  const float* bias;     /* [N] or NULL */
+  float* partial;        /* scratch for the split-K form, or NULL */
+  int32_t M, N, K, ldc;
+  int64_t sam, sak, sbk, sbn;
+  float alpha, leaky_slope;
+  int32_t accumulate;    /* 1: C += result */
+  int32_t pad_;
+} rumpy_sgemm_args;
+int rumpy_sgemm(const rumpy_sgemm_args* a, void* stream);
+int64_t rumpy_sgemm_partial_floats(int32_t M, int32_t N, int32_t K);
+/* y = x / max(||x||_2, 1e-12) per row of [N, C] (nn.functional.normalize(dim=1)), inv[n] = the factor; backward dx = (dy - y (y . dy)) inv */
+int rumpy_l2norm_rows(const float* x, float* y, float* inv, int32_t N, int32_t C, void* stream);
+int rumpy_l2norm_rows_bwd(const float* dy, const float* y, const float* inv, float* dx, int32_t N, int32_t C, void* stream);
+/* out[n * ldo] = scale * a[n, :] . b[n, :] */
+int rumpy_rowdot(const float* a, const float* b, float* out, int32_t N, int32_t C, int32_t ldo, float scale, void* stream);
+/* same[n, j] = (labels[n] == queue_labels[j]) as 0 / 1 floats ([N, K]; int64 labels), cnt[n] = row sum (supmoco.py:93-97) */
+int rumpy_label_match(const void* labels, const void* queue_labels, float* same, float* cnt, int32_t N, int32_t K, void* stream);
+/* v[n, :] = (sum_p k[n * P + p, :] + s[n, :]) * rscale / (P + cnt[n])  (s = cnt = NULL: MoCo) - the vector the positive logit is q . v with */
+int rumpy_pos_vector(const float* k, const float* s, const float* cnt, float* v, int32_t N, int32_t P, int32_t C, float rscale, void* stream);
+/* nn.CrossEntropyLoss(reduction='mean') over logits [N, M], int64 targets: lse [N], rowloss [N], loss [1]; backward dlogits = (softmax - onehot) * *gout / N */
+int rumpy_ce_rows(const float* logits, const void* target, float* lse, float* rowloss, float* loss, int32_t N, int32_t M, void* stream);
+int rumpy_ce_rows_bwd(const float* logits, const void* target, const float* lse, const float* gout, float* dlogits, int32_t N, int32_t M, void* stream);
+/* out[c] = sum_n x[n, c] ; dh[i] *= (h[i] > 0 ? 1 : slope) with h the LeakyReLU output */
+int rumpy_colsum(const float* x, float* out, int32_t N, int32_t C, void* stream);
+int rumpy_lrelu_bwd(float* dh, const float* h, int64_t n, float slope, void* stream);
+/* dst[n, :] += coef[n * ldcoef] * src[n, :] */
+int rumpy_row_axpy(float* dst, const float* src, const float* coef, int32_t N, int32_t C, int32_t ldcoef, void* stream);
+/* MoCo's enqueue (moco.py:74-89, supmoco.py:34-50) in one launch: queue[:, slots[i]] = keys[i * key_stride, :] (queue [C, K] fp32; one key per
+ * query), queue_labels[slots[i]] = labels[i] (both NULL: no label track), then slots[i] = (slots[i] + n) % K and *queue_ptr = (*queue_ptr + n) % K
+ * (int64 device words; queue_ptr may be NULL) */
+int rumpy_moco_enqueue(float* queue, const float* keys, void* slots, void* queue_ptr, void* queue_labels, const void* labels,
+                       int32_t n, int32_t key_stride, int32_t C, int32_t K, void* stream);
+
 /* ---- optimizer: torch.optim.Adam semantics (base_architecture.py:93-95,437), flat fp32 buffers ---- */
 typedef struct {
   float lr, beta1, beta2, eps;

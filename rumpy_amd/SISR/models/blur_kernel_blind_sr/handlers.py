@@ -40,7 +40,8 @@ class ContrastiveBlindQRCANHandler(BaseContrastive):
         self.model_name = 'blind_qrcan'
         self.encoder_type = encoder_type
         self.combined_loss_mode = combined_loss_mode
-        self.contrast_loss = torch.nn.CrossEntropyLoss()
+        from rumpy_amd.regression.models.contrastive_learning.head import HipCrossEntropyLoss
+        self.contrast_loss = HipCrossEntropyLoss()          # nn.CrossEntropyLoss() of the reference (:528), forward and backward in HIP
         self.colorspace = 'augmented_rgb'
         self.im_input = 'unmodified'
         self.activate_device()

@@ -258,6 +258,12 @@ class MseArgs(_S):
     _fields_ = [('out', c_void_p), ('target', c_void_p), ('grad', c_void_p), ('partial', c_void_p), ('loss', c_void_p), ('n', c_int64)]
 
 
+class SgemmArgs(_S):
+    _fields_ = [('A', c_void_p), ('B', c_void_p), ('C', c_void_p), ('bias', c_void_p), ('partial', c_void_p),
+                ('M', c_int32), ('N', c_int32), ('K', c_int32), ('ldc', c_int32), ('sam', c_int64), ('sak', c_int64), ('sbk', c_int64), ('sbn', c_int64),
+                ('alpha', c_float), ('leaky_slope', c_float), ('accumulate', c_int32), ('pad_', c_int32)]
+
+
 # every symbol include/rumpy_amd.h declares: name -> (restype, argtypes)
 _P = C.POINTER
 SYMBOLS = {
@@ -275,6 +281,19 @@ SYMBOLS = {
     'rumpy_rcab_strips': (C.c_int, [c_int32, c_int32]),
     'rumpy_block_pool_tiles': (C.c_int, [c_int32, c_int32]),
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
+    'rumpy_sgemm': (C.c_int, [_P(SgemmArgs), c_void_p]),
+    'rumpy_sgemm_partial_floats': (c_int64, [c_int32, c_int32, c_int32]),
+    'rumpy_l2norm_rows': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_l2norm_rows_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_rowdot': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'rumpy_label_match': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_pos_vector': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'rumpy_ce_rows': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_ce_rows_bwd': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_colsum': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_lrelu_bwd': (C.c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    'rumpy_row_axpy': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'rumpy_moco_enqueue': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_enc_conv': (C.c_int, [_P(EncConvArgs), c_void_p]),
     'rumpy_enc_bn_train': (C.c_int, [_P(EncBnArgs), c_void_p]),
     'rumpy_enc_bn_partial_floats': (c_int64, [c_int32, c_int32]),

@@ -536,4 +536,5 @@ class Encoder(nn.Module):
             fea = _TrunkFn.apply(x, self, *trunk)
         else:
             fea = self.features(x)
-        return fea, {'q': self.mlp(fea)}
+        from .head import mlp_head         # the mlp head forward and backward in HIP (csrc/contrastive.hip)
+        return fea, {'q': mlp_head(self.mlp, fea)}

@@ -10,6 +10,7 @@ import torch.distributed as dist
 
 from rumpy_amd.sr_tools.loss_functions import SupConLoss
 from . import BaseContrastive
+from .head import HipCrossEntropyLoss
 from .moco import MoCo
 from .supmoco import SupMoCo
 from .weak_con import WeakCon
@@ -83,7 +84,7 @@ class MocoContrastiveHandler(BaseContrastive):
         self.crop_count = crop_count
         self.net = MoCo(base_encoder=self.define_encoder_model(model_name), T=moco_t, positives=crop_count - 1)
         self.activate_device()
-        self.criterion = torch.nn.CrossEntropyLoss()
+        self.criterion = HipCrossEntropyLoss()          # nn.CrossEntropyLoss() of the reference, forward and backward in HIP (head.py)
         self.training_setup(lr, scheduler, scheduler_params, device=device, perceptual=None)
 
     def run_model(self, x, *args, **kwargs):
@@ -126,7 +127,7 @@ class SupMoCoHandler(BaseContrastive):
         self.net = SupMoCo(base_encoder=self.define_encoder_model(model_name), positives_per_class=crop_count - 1, dim=256,
                            contrastive_dropdown=contrastive_dropdown, T=moco_t, device=device, dropdown=None)
         self.activate_device()
-        self.criterion = torch.nn.CrossEntropyLoss()
+        self.criterion = HipCrossEntropyLoss()          # nn.CrossEntropyLoss() of the reference, forward and backward in HIP (head.py)
         self.training_setup(lr, scheduler, scheduler_params, device=device, perceptual=None)
         self.include_direct_loss = False
         self.dropdown = None
@@ -169,7 +170,7 @@ class WeakConHandler(BaseContrastive):
         self.data_type = data_type
         self.net = WeakCon(base_encoder=self.define_encoder_model(model_name), positives_per_class=crop_count - 1, T=moco_t, device=device)
         self.activate_device()
-        self.criterion = torch.nn.CrossEntropyLoss()
+        self.criterion = HipCrossEntropyLoss()          # nn.CrossEntropyLoss() of the reference, forward and backward in HIP (head.py)
         self.training_setup(lr, scheduler, scheduler_params, device=device, perceptual=None)
 
     def run_train(self, x, y, tag=None, mask=None, *args, **kwargs):

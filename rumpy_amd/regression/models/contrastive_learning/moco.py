@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from rumpy_amd import _lib as L
 from .encoding_models import Encoder
+from .head import moco_logits, normalize_rows
 
 
 class MoCo(nn.Module):
@@ -101,6 +102,21 @@ class MoCo(nn.Module):
             return torch.cat(parts, dim=0)
         return t
 
+    def _zero_labels(self, n, dev):
+        z = self.__dict__.setdefault('_zeros', {}).get((n, dev))
+        if z is None:
+            z = self.__dict__['_zeros'][(n, dev)] = torch.zeros(n, dtype=torch.long, device=dev)
+        return z
+
+    @torch.no_grad()
+    def _keys_of_all_ranks(self, keys, stride=1, labels=None):
+        """data parallel: every rank enqueues the keys (and labels) of ALL ranks in rank order (the step the reference marks at moco.py:78), so
+        the replicas' queues stay identical -> (keys, stride, labels) as the enqueue takes them; identity on one process"""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            keys, stride = self._gathered(keys[::stride].contiguous()), 1
+            labels = None if labels is None else self._gathered(labels)
+        return keys, stride, labels
+
     def _queue_pointer(self):
         seen = self._ptr_seen
         if seen is not None and seen[0] == (id(self.queue_ptr), self.queue_ptr._version):
@@ -135,15 +151,20 @@ class MoCo(nn.Module):
         self._ptr_seen = ((id(self.queue_ptr), self.queue_ptr._version), st[1])
 
     @torch.no_grad()
-    def _dequeue_and_enqueue(self, keys):
-        """:74-89"""
-        keys = self._gathered(keys)
-        batch_size = keys.shape[0]
+    def _dequeue_and_enqueue(self, keys, stride=1, labels=None):
+        """:74-89 (supmoco.py:34-50 with the label track): every `stride`-th row of `keys` joins the queue at the device-side slot vector, which
+        advances with the queue pointer - one launch (rumpy_moco_enqueue)"""
+        keys, stride, labels = self._keys_of_all_ranks(keys, stride, labels)
+        if not keys.is_cuda:
+            raise RuntimeError('rumpy_amd: the MoCo queue lives on the GPU (rumpy_moco_enqueue); there is no CPU path')
+        keys = keys.contiguous()
+        batch_size = keys.shape[0] // stride
         assert self.K % batch_size == 0  # for simplicity
         st = self._slots(batch_size, self._queue_pointer())
-        self.queue.index_copy_(1, st[2], keys.transpose(0, 1))
-        st[2].add_(batch_size).remainder_(self.K)
-        self.queue_ptr.add_(batch_size).remainder_(self.K)
+        L.check(L.lib().rumpy_moco_enqueue(self.queue.data_ptr(), keys.data_ptr(), st[2].data_ptr(), self.queue_ptr.data_ptr(),
+                                           None if labels is None else self.queue_labels.data_ptr(), None if labels is None else labels.contiguous().data_ptr(),
+                                           batch_size, stride, keys.shape[1], self.K, torch.cuda.current_stream(keys.device).cuda_stream), 'rumpy_moco_enqueue')
+        # (queue_ptr is advanced by the kernel, behind torch's version counter: the host copy of the pointer is what _moved keeps)
         self._moved(batch_size)
 
     def forward(self, im_q, im_k, **kwargs):
@@ -155,15 +176,13 @@ class MoCo(nn.Module):
             return embedding
         n = im_q.shape[0]
         embedding, heads = self.encoder_q(im_q)
-        q = nn.functional.normalize(heads['q'], dim=1)                          # queries  [N, C]
         with torch.no_grad():                                                   # the keys carry no gradient
             self._momentum_update_key_encoder()
-            k = nn.functional.normalize(self.encoder_k(im_k)[1]['q'], dim=1)    # keys     [N * positives, C]
-        # column 0: the positive logit = mean over the query's own key crops of q . k ; columns 1..K: q against the queue ; all / T
-        # (one positive: q . k / T, :150-151,170-172; several: (sum_p q . k_p / T) / positives, :153-158,174-177)
-        pos = torch.einsum('nc,npc->np', q, k.view(n, self.positives, self.vector_dim)).mean(dim=1, keepdim=True)
-        neg = q @ self.queue.detach().clone()
-        logits = torch.cat([pos, neg], dim=1) / self.T
-        labels = torch.zeros(n, dtype=torch.long, device=logits.device)         # cross-entropy target: column 0
-        self._dequeue_and_enqueue(k[::self.positives])                          # one key per query joins the queue (:181-184)
+            k = normalize_rows(self.encoder_k(im_k)[1]['q'])                    # keys     [N * positives, C], L2-normalised
+        # queries: q = normalize(mlp(fea)).  Column 0: the positive logit = mean over the query's own key crops of q . k ; columns 1..K: q
+        # against the queue ; all / T (one positive: q . k / T, :150-151,170-172; several: (sum_p q . k_p / T) / positives, :153-158,174-177):
+        # normalisation, both products and their backward pass are HIP (head.py)
+        logits = moco_logits(heads['q'], k, self.queue, self.T, self.positives)
+        labels = self._zero_labels(n, logits.device)                            # cross-entropy target: column 0
+        self._dequeue_and_enqueue(k, stride=self.positives)                     # one key per query joins the queue (:181-184)
         return embedding, logits, labels

@@ -6,6 +6,7 @@ plain torch GEMMs with torch autograd, as in the reference."""
 import torch
 import torch.nn as nn
 
+from .head import moco_logits, normalize_rows
 from .moco import MoCo
 
 
@@ -27,18 +28,6 @@ class SupMoCo(MoCo):
     def set_class_count(self, num_classes):
         self.num_classes = num_classes
 
-    @torch.no_grad()
-    def _dequeue_and_enqueue(self, keys, labels):
-        keys, labels = self._gathered(keys), self._gathered(labels)
-        batch_size = keys.shape[0]
-        assert self.K % batch_size == 0  # for simplicity
-        st = self._slots(batch_size, self._queue_pointer())          # device-side slot vector: the same launches at every step (moco.py)
-        self.queue.index_copy_(1, st[2], keys.transpose(0, 1))
-        self.queue_labels.index_copy_(0, st[2], labels)
-        st[2].add_(batch_size).remainder_(self.K)
-        self.queue_ptr.add_(batch_size).remainder_(self.K)
-        self._moved(batch_size)
-
     def forward(self, im_q, im_k, labels=None, **kwargs):
         """training: (embedding, logits [N, 1 + K], zeros, encoder outputs) ; evaluation as MoCo (:52-138)"""
         if not self.training:
@@ -52,19 +41,14 @@ class SupMoCo(MoCo):
             raise RuntimeError('Labels required for a training step.')
         n, P = im_q.shape[0], self.positives_per_class
         embedding, heads = self.encoder_q(im_q)
-        q = nn.functional.normalize(heads['q'], dim=1)                          # [N, C]
         with torch.no_grad():
             self._momentum_update_key_encoder()
-            k = nn.functional.normalize(self.encoder_k(im_k)[1]['q'], dim=1)    # [N * P, C]
-        labels = labels.to(device=self.queue.device, dtype=torch.int64).reshape(-1)
-        # queue entry j is a positive of query n when their class labels agree (:93-97 builds the same 0/1 matrix as a product of one-hot
-        # matrices); free slots carry the label `num_classes`, which no query has
-        same = (labels.view(-1, 1) == self.queue_labels.view(1, -1)).to(q.dtype)            # [N, K]
-        pos_batch = torch.einsum('nc,npc->np', q, k.view(n, P, self.vector_dim)).sum(dim=1)  # the query's own key crops
-        pos_queue = (q * (same @ self.queue.t())).sum(dim=1)                                # q . (sum of its positive queue features)
-        l_pos = (pos_batch + pos_queue) / self.T / (P + same.sum(dim=1))                    # mean positive logit (:99-112)
-        l_neg = (q @ self.queue.detach().clone()) / self.T
-        logits = torch.cat([l_pos.unsqueeze(1), l_neg], dim=1)
-        full_labels = torch.zeros(n, dtype=torch.long, device=logits.device)
-        self._dequeue_and_enqueue(k[::P], labels)                                           # one key per query, with the query's label
+            k = normalize_rows(self.encoder_k(im_k)[1]['q'])                    # [N * P, C]
+        labels = labels.to(device=self.queue.device, dtype=torch.int64).reshape(-1).contiguous()
+        # q = normalize(mlp(fea)).  Queue entry j is a positive of query n when their class labels agree (:93-97 builds that 0/1 matrix as a
+        # product of one-hot matrices; here a label comparison, rumpy_label_match); free slots carry the label `num_classes`, which no query has.
+        # l_pos = (sum_p q . k_p + q . sum of its positive queue features) / T / (P + their number) (:99-112), l_neg = q @ queue / T: HIP, head.py
+        logits = moco_logits(heads['q'], k, self.queue, self.T, P, labels=labels, queue_labels=self.queue_labels)
+        full_labels = self._zero_labels(n, logits.device)
+        self._dequeue_and_enqueue(k, stride=P, labels=labels)                               # one key per query, with the query's label
         return embedding, logits, full_labels, heads

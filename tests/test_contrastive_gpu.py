@@ -474,3 +474,102 @@ def test_supmoco_and_weakcon_step_graphs_are_the_eager_steps(name, monkeypatch):
         assert a[0] == b[0], step
         for i, (ta, tb) in enumerate(zip(a[1:], b[1:])):
             assert torch.equal(ta, tb), (step, i)
+
+
+# ---------------------------------------------------------------------------------------------------------------- the contrastive head in HIP (round 3)
+def test_sgemm_every_operand_layout_bias_activation_and_the_split_k_form():
+    """rumpy_sgemm against float64 torch for the shapes / strides the head uses: row-major and transposed operands, an offset output with its own
+    row stride (the logits' columns 1..K), bias + LeakyReLU epilogue, accumulation, and the split-K form (few outputs, K = 8192)"""
+    from rumpy_amd.regression.models.contrastive_learning.head import sgemm
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    # (M, N, K, transA, transB)
+    for M, N, K, ta, tb in ((8, 256, 256, False, True), (37, 8192, 256, False, False), (256, 256, 19, True, False), (32, 256, 8192, False, True),
+                            (5, 70, 1100, False, False), (64, 64, 64, True, True)):
+        A = rnd(K, M) if ta else rnd(M, K)
+        B = rnd(N, K) if tb else rnd(K, N)
+        bias = rnd(N)
+        ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+        C = torch.full((M, N + 3), float('nan'), device=DEV)
+        sgemm(A, B, C, M, N, K, 1 if ta else K, M if ta else 1, 1 if tb else N, K if tb else 1, N + 3, alpha=0.5, bias=bias, slope=0.1, c_off=2)
+        want = torch.nn.functional.leaky_relu(0.5 * ref + bias.double(), 0.1)
+        got = C[:, 2:2 + N]
+        assert torch.isnan(C[:, :2]).all() and torch.isnan(C[:-1, 2 + N:]).all()
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-5, (M, N, K)
+        C2 = torch.ones(M, N, device=DEV)
+        sgemm(A, B, C2, M, N, K, 1 if ta else K, M if ta else 1, 1 if tb else N, K if tb else 1, N, accumulate=True)
+        assert float((C2.double() - 1.0 - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-5
+        C3 = torch.ones(M, N, device=DEV)
+        sgemm(A, B, C3, M, N, K, 1 if ta else K, M if ta else 1, 1 if tb else N, K if tb else 1, N, accumulate=True)
+        assert torch.equal(C2, C3)                                              # fixed summation order
+
+
+@pytest.mark.parametrize('N,P,labelled', [(8, 1, False), (4, 3, False), (4, 2, True), (32, 1, False)])
+def test_hip_contrastive_head_against_torch_autograd(N, P, labelled):
+    """mlp head -> normalisation -> MoCo / SupMoCo logits -> cross-entropy through head.py against the reference's torch expressions
+    (moco.py:147-177, supmoco.py:88-119) in float64: loss, logits, and the gradients of fea and of the four mlp tensors"""
+    from rumpy_amd.regression.models.contrastive_learning import head as H
+    g = torch.Generator().manual_seed(40 + N + P)
+    K, C, T = 8192, 256, 0.07
+    fea = torch.randn(N, C, generator=g)
+    mlp = torch.nn.Sequential(torch.nn.Linear(C, C), torch.nn.LeakyReLU(0.1, True), torch.nn.Linear(C, C))
+    k = torch.nn.functional.normalize(torch.randn(N * P, C, generator=g), dim=1)
+    queue = torch.nn.functional.normalize(torch.randn(C, K, generator=g), dim=0)
+    labels = torch.randint(0, 5, (N,), generator=g) if labelled else None
+    qlabels = torch.randint(0, 6, (K,), generator=g) if labelled else None
+    # ---- reference, float64
+    m64 = torch.nn.Sequential(torch.nn.Linear(C, C), torch.nn.LeakyReLU(0.1), torch.nn.Linear(C, C)).double()
+    m64.load_state_dict({kk: v.double() for kk, v in mlp.state_dict().items()})
+    f64 = fea.double().requires_grad_(True)
+    q = torch.nn.functional.normalize(m64(f64), dim=1)
+    if labelled:
+        same = (labels.view(-1, 1) == qlabels.view(1, -1)).double()
+        pos = torch.einsum('nc,npc->np', q, k.double().view(N, P, C)).sum(1) + (q * (same @ queue.double().t())).sum(1)
+        l_pos = pos / T / (P + same.sum(1))
+    else:
+        l_pos = torch.einsum('nc,npc->np', q, k.double().view(N, P, C)).mean(1) / T
+    ref_logits = torch.cat([l_pos[:, None], q @ queue.double() / T], 1)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, torch.zeros(N, dtype=torch.long))
+    ref_loss.backward()
+    # ---- HIP
+    mlp = mlp.to(DEV)
+    fd = fea.to(DEV).requires_grad_(True)
+    qd = H.mlp_head(mlp, fd)
+    logits = H.moco_logits(qd, k.to(DEV), queue.to(DEV), T, P, labels=None if labels is None else labels.to(DEV),
+                           queue_labels=None if qlabels is None else qlabels.to(DEV))
+    loss = H.HipCrossEntropyLoss()(logits, torch.zeros(N, dtype=torch.long, device=DEV))
+    loss.backward()
+    assert float((logits.double().cpu() - ref_logits).abs().max()) < 2e-4 and abs(float(loss) - float(ref_loss)) < 1e-5 * max(1.0, float(ref_loss))
+    assert _rel(fd.grad, f64.grad) < 1e-4
+    for (kk, p), (_, r) in zip(mlp.named_parameters(), m64.named_parameters()):
+        assert _rel(p.grad, r.grad) < 1e-4, kk
+    # gradients written straight into existing .grad tensors (the encoders' flat gradient views) ACCUMULATE like torch's
+    before = {kk: p.grad.clone() for kk, p in mlp.named_parameters()}
+    fd2 = fea.to(DEV).requires_grad_(True)
+    H.HipCrossEntropyLoss()(H.moco_logits(H.mlp_head(mlp, fd2), k.to(DEV), queue.to(DEV), T, P, labels=None if labels is None else labels.to(DEV),
+                                          queue_labels=None if qlabels is None else qlabels.to(DEV)), torch.zeros(N, dtype=torch.long, device=DEV)).backward()
+    for kk, p in mlp.named_parameters():
+        assert _rel(p.grad, 2 * before[kk]) < 1e-5, kk
+
+
+def test_moco_enqueue_kernel_is_the_index_copy():
+    """rumpy_moco_enqueue against the torch statements it replaces (moco.py:74-89 / supmoco.py:34-50): strided key selection, queue columns,
+    label track, device-side slot vector and pointer, wrap-around at the end of the queue"""
+    K, C, n, stride = 64, 256, 8, 3
+    g = torch.Generator().manual_seed(3)
+    queue = torch.randn(C, K, generator=g).to(DEV)
+    qlabels = torch.full((K,), 9, dtype=torch.int64, device=DEV)
+    ptr = torch.tensor([K - 4], dtype=torch.int64, device=DEV)
+    slots = (torch.arange(n, device=DEV) + (K - 4)) % K
+    want_q, want_l = queue.clone(), qlabels.clone()
+    for step in range(3):
+        keys = torch.randn(n * stride, C, generator=g).to(DEV)
+        labels = torch.randint(0, 5, (n,), generator=g).to(DEV)
+        cur = slots.clone()
+        want_q.index_copy_(1, cur, keys[::stride].t())
+        want_l.index_copy_(0, cur, labels)
+        L.check(L.lib().rumpy_moco_enqueue(queue.data_ptr(), keys.data_ptr(), slots.data_ptr(), ptr.data_ptr(), qlabels.data_ptr(), labels.data_ptr(),
+                                           n, stride, C, K, _stream()), 'rumpy_moco_enqueue')
+        torch.cuda.synchronize()
+        assert torch.equal(queue, want_q) and torch.equal(qlabels, want_l)
+        assert torch.equal(slots, (cur + n) % K) and int(ptr) == (K - 4 + (step + 1) * n) % K

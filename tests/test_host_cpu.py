@@ -64,7 +64,8 @@ def test_ctypes_structs_match_the_header_layout():
              'rumpy_q_mlp_item': _lib.QMlpItem, 'rumpy_ssim_args': _lib.SsimArgs, 'rumpy_patch_item': _lib.PatchItem, 'rumpy_patch_args': _lib.PatchArgs,
              'rumpy_finish_reduce_args': _lib.FinishReduceArgs, 'rumpy_update_item': _lib.UpdateItem, 'rumpy_adam_pack_args': _lib.AdamPackArgs,
              'rumpy_qca_layer': _lib.QcaLayer, 'rumpy_qca_args': _lib.QcaArgs,
-             'rumpy_dconv_args': _lib.DconvArgs, 'rumpy_dconv_wgrad_args': _lib.DconvWgradArgs, 'rumpy_mse_args': _lib.MseArgs, 'rumpy_op': _lib.Op}
+             'rumpy_dconv_args': _lib.DconvArgs, 'rumpy_dconv_wgrad_args': _lib.DconvWgradArgs, 'rumpy_mse_args': _lib.MseArgs, 'rumpy_op': _lib.Op,
+             'rumpy_sgemm_args': _lib.SgemmArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rumpy_amd.h"', 'int main(void){']
     for cname, st in pairs.items():
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))
@@ -583,8 +584,14 @@ dist.init_process_group('gloo')
 torch.manual_seed(0)
 m = MoCo(base_encoder=Encoder, K=64)
 keys = torch.full((4, 256), float(rank + 1))
-m._dequeue_and_enqueue(keys)                      # every rank enqueues the keys of BOTH ranks, in rank order
-assert int(m.queue_ptr) == 8 and torch.equal(m.queue[:, :4], torch.ones(256, 4)) and torch.equal(m.queue[:, 4:8], torch.full((256, 4), 2.0))
+# every rank enqueues the keys of BOTH ranks, in rank order (the enqueue itself is one HIP launch: no CPU path, checked on the GPU)
+allk, stride, _ = m._keys_of_all_ranks(torch.stack([keys, keys * 7], dim=1).reshape(8, 256), stride=2)
+assert stride == 1 and allk.shape == (8, 256) and torch.equal(allk[:4], torch.ones(4, 256)) and torch.equal(allk[4:], torch.full((4, 256), 2.0))
+try:
+    m._dequeue_and_enqueue(keys)
+    raise SystemExit('a CPU enqueue must fail loudly')
+except RuntimeError as e:
+    assert 'no CPU path' in str(e)
 # replicas start from rank 0's module: the trainable flat buffer in one broadcast, then everything else it holds (key encoder, queue, pointer,
 # BatchNorm statistics)
 from rumpy_amd.parallel import broadcast_parameters
@@ -600,8 +607,8 @@ for t, r in zip(m2.state_dict().values(), ref):
 assert all(torch.equal(t, r) for t, r in zip(m2.state_dict().values(), ref)) and int(m2.queue_ptr) == 0
 s = SupMoCo(device='cpu', base_encoder=Encoder, K=64, positives_per_class=2)
 s.register_classes(5)
-s._dequeue_and_enqueue(keys, torch.tensor([rank, rank, 3, 4]))
-assert int(s.queue_ptr) == 8 and s.queue_labels[:10].tolist() == [0, 0, 3, 4, 1, 1, 3, 4, 5, 5]
+allk, stride, alll = s._keys_of_all_ranks(keys, 1, torch.tensor([rank, rank, 3, 4]))
+assert allk.shape == (8, 256) and alll.tolist() == [0, 0, 3, 4, 1, 1, 3, 4]
 dist.destroy_process_group()
 print('rank', rank, 'ok')
 '''

@@ -166,7 +166,7 @@ def trajectory(name='rcan', steps=60):
             opt.step()
         curves[label] = np.array(losses)
     ref = curves['fp32']
-    print('%s, %d steps: loss at steps 0 / %d / %d; largest relative difference to the fp32 run over all steps' % (name, steps // 2, steps - 1))
+    print('%s, %d steps: loss at steps 0 / %d / %d; largest relative difference to the fp32 run over all steps' % (name, steps, steps // 2, steps - 1))
     for label, c in curves.items():
         print('  %-18s %.5f  %.5f  %.5f   max |dloss| / loss %.4f' % (label, c[0], c[steps // 2], c[-1], float(np.max(np.abs(c - ref) / ref))))
 
