@@ -31,6 +31,12 @@
 #ifndef BLOCK_OUT_PLAIN
 #define BLOCK_OUT_PLAIN 0   // A/B: OUT stored with the default policy (lines stay in the XCD's L2 for the next launch, dirty until the boundary)
 #endif
+#ifndef BLOCK_FFIRST
+#define BLOCK_FFIRST 0  // A/B: 1 = the first filter is requested before the input tile
+#endif
+#ifndef BLOCK_EARLY
+#define BLOCK_EARLY 1   // A/B: 0 = the whole input tile behind one wait (round 2)
+#endif
 #ifndef BLOCK_ABL
 #define BLOCK_ABL 0   // timing experiments only (tests/tools/build_abl.sh, abl_block.sh; results are WRONG): 1 = second filter not fetched,
 #endif                //   2 = neither filter fetched, 4 = no HBM stores, 5 = input tile not loaded, 9 = phase stamps into a.res1
@@ -48,7 +54,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   constexpr int NP1 = NC == 3 ? 6 : 4;     // paired tiles of the first phase (4 rows x NC column tiles)
   constexpr int NP2 = NC == 3 ? 4 : 3;     // ... of the second phase (3 rows x NC; NC = 3 leaves one single tile)
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::XBYTES + G::TBYTES];
-  __shared__ unsigned gate[4];             // waves of row half 0 / 1 that have written their T rows, their OUT rows (block_common.hpp::gate_*)
+  __shared__ unsigned gate[8];             // waves of row half 0 / 1 that have written their T rows [0, 1], their OUT rows [2, 3] (block_common.hpp::gate_*);
+                                           // [4] waves that have written the early part of the input tile, [5] row half 1's waves: the late part
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + G::XBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -67,45 +74,67 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   BK_STAMP();                              // 0: start
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns x0-XH .. x0+OW+XH-1 -> LDS (branch-free loads, zero outside the image) ----
-  {
-    uint4 R[G::XREGS];
-    const int y0 = sy * BSH - 2;
+  // Round 3 (BLOCK_EARLY): the tile arrives bandwidth-priced (every CU asks for its 64 KB at the same moment: 2.8 us), and row half 0 only sweeps
+  // over input rows 0 .. 5.  The pieces of those rows (R0 rounds of 512) are loaded by all threads first and announced on their own LDS counter;
+  // the rest is loaded by row half 1's threads (row half 0 issues as many loads of one cached line instead: every wave runs the same,
+  // unconditional load sequence, so the compiler's waits stay counted).  Row half 0 starts its first sweep when rows 0 .. 5 are in LDS, row half
+  // 1 when everything is; the first conv's filter is requested before the tile, so its (L2-hit) latency lies under the tile's.
+  constexpr int R0 = BLOCK_EARLY ? (6 * XC * 8 + BTHREADS - 1) / BTHREADS : G::XREGS;      // rounds that cover input rows 0 .. 5
+  constexpr int LATE = G::XPIECES - R0 * BTHREADS > 0 ? G::XPIECES - R0 * BTHREADS : 0;
+  constexpr int R1 = (LATE + 255) / 256;                                                     // rounds of row half 1's 256 threads for the rest
+  if (tid < 8) gate[tid] = 0u;
+  __syncthreads();                         // (nothing is in flight yet: a bare s_barrier) the counters are zero before anybody arrives
+  bf16x8 F[18];
+  auto fetch_filter = [&]() {
+    const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < G::XREGS; ++i) {
-      const int p = tid + BTHREADS * i;
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8((BLOCK_ABL == 2) ? make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u + t, 0x3c003c00u) : wp[t * 64]);
+  };
+  if (BLOCK_FFIRST) fetch_filter();
+  {
+    uint4 R[R0], Rl[R1 > 0 ? R1 : 1];
+    const int y0 = sy * BSH - 2;
+    auto fetch = [&](int p, bool live) -> uint4 {
       const int pix = p >> 3, part = p & 7;
       const int lr = pix / XC, lc = pix - lr * XC;
       const int y = y0 + lr, x = x0 - XH + lc;
-      const bool ok = (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const bool ok = live & (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
       uint4 v = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
       if (BLOCK_ABL != 5) v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
       if (!ok) v = make_uint4(0, 0, 0, 0);
-      R[i] = v;
-    }
-    if (tid < 4) gate[tid] = 0u;
+      return v;
+    };
+#pragma unroll
+    for (int i = 0; i < R0; ++i) R[i] = fetch(tid + BTHREADS * i, true);
+#pragma unroll
+    for (int i = 0; i < R1; ++i) Rl[i] = fetch(R0 * BTHREADS + tg + 256 * i, rh == 1);
+    if (!BLOCK_FFIRST) fetch_filter();       // behind the tile's requests (returns in order): under the tile's latency, not in front of it
     // border columns of the T image: convB's zero padding, never written by the epilogue (column tiles: real T values, written by the halo tile)
     if (!G::CT && tid < BTROWS * 2 * 8) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < G::XREGS; ++i) {
+    for (int i = 0; i < R0; ++i) {
       const int p = tid + BTHREADS * i;
-      const int pix = p >> 3, part = p & 7;
-      if (p < G::XPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+      if (p < G::XPIECES) *reinterpret_cast<uint4*>(ldx + swz(p >> 3, p & 7)) = R[i];
     }
-  }
-  bf16x8 F[18];
-  {
-    const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
+    gate_arrive(&gate[4], lane);           // this wave's pieces of input rows 0 .. 5 (and a bit) are in LDS
+    if (R1 > 0 && rh == 1) {
 #pragma unroll
-    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8((BLOCK_ABL == 2) ? make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u + t, 0x3c003c00u) : wp[t * 64]);
+      for (int i = 0; i < R1; ++i) {
+        const int p = R0 * BTHREADS + tg + 256 * i;
+        if (p < G::XPIECES) *reinterpret_cast<uint4*>(ldx + swz(p >> 3, p & 7)) = Rl[i];
+      }
+      gate_arrive(&gate[5], lane);
+    }
   }
   const int c0 = 16 * q + 4 * g;
   const int gpair = 4 * (g & ~1);
   const int chunk8 = 2 * q + (gpair >> 3);          // 16-byte chunk of this lane's 8 channels in the paired layout
-  __syncthreads();
+  gate_wait(&gate[4], 8u);                 // input rows 0 .. 5: all eight waves' early pieces
+  if (R1 > 0 && rh == 1) gate_wait(&gate[5], 4u);   // rows 6 .. 9: row half 1's own late pieces
   BK_STAMP();                              // 1: input tile in LDS
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
