@@ -166,7 +166,7 @@ def test_fp16_residual_block_and_rcab_launches(N, H, W):
     d = lambda t: t.contiguous().to(DEV)
     cw1d, cb1d, cw2d, cb2d = d(cw1), d(cb1), d(cw2), d(cb2)
     mean, hid, gate = (torch.zeros(N, k, device=DEV) for k in (64, Cr, 64))
-    xchg = torch.zeros(int(L.lib().rumpy_rcab_xchg_bytes(N, H)), dtype=torch.uint8, device=DEV)
+    xchg = torch.zeros(int(L.lib().rumpy_rcab_xchg_bytes(N, H, W)), dtype=torch.uint8, device=DEV)
     epoch, status = torch.ones(1, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
     out = torch.full((N, H, W, 64), float('nan'), dtype=F16, device=DEV)
     L.call('rumpy_rcab_fwd', L.RcabArgs(x=xd.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),

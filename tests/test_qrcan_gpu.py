@@ -229,10 +229,13 @@ def test_unsupported_qrcan_variants_are_refused():
             define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, n_resgroups=1, n_resblocks=1, **bad)
 
 
+@pytest.mark.parametrize('no_rcab', ['0', '1'])
 @pytest.mark.parametrize('style', ['standard', 'modulate'])
-def test_qrcan_wide_images_use_the_separate_launches(style):
-    """images wider than 48 pixels cannot use the one-launch RCAB kernels: the strip conv + fused attention launches (with the
-    meta-attention gate as an extra factor) carry training and evaluation there"""
+def test_qrcan_wide_images_one_launch_rcab_and_the_separate_launches(style, no_rcab, monkeypatch):
+    """images wider than 48 pixels: the one-launch RCAB kernels as column tiles (round 3), and - RUMPY_NO_RCAB=1, or more strips per image than
+    CUs - the one-launch conv pair with pool sums + the fused attention launches (with the meta-attention gate as an extra factor); both carry
+    training and evaluation against the oracle"""
+    monkeypatch.setenv('RUMPY_NO_RCAB', no_rcab)
     kw = dict(scale=2, n_feats=64, n_resgroups=1, n_resblocks=2, reduction=16)
     if style == 'standard':
         names = ['a', 'b', 'c', 'd']
@@ -253,7 +256,8 @@ def test_qrcan_wide_images_use_the_separate_launches(style):
     loss, out = h.run_train(x=x, y=y, extra_channels=a)
     oloss, oout = oh.run_train(x, y, extra_channels=a)
     plan = h.net.engine.plan_for(2, 20, 60, True)
-    assert 'rumpy_rcab_fwd' not in [op for op, _ in plan.fwd] and 'rumpy_ca_fwd_fused' in [op for op, _ in plan.fwd]
+    ops = [op for op, _ in plan.fwd]
+    assert ('rumpy_rcab_fwd' in ops) == (no_rcab == '0') and ('rumpy_ca_fwd_fused' in ops and 'rumpy_conv_block' in ops) == (no_rcab == '1')
     assert self_psnr(out, oout) >= 50.0 and abs(float(loss) - float(oloss)) < 2e-3 * float(oloss)
     print('worst grad rel err', _grad_check(h, oh))
     xe, ye = O.synthetic_batch(962, 1, lr_hw=(33, 70), scale=2)

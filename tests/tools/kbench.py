@@ -316,7 +316,7 @@ def rcab_bench(N=32, H=48, W=48, reps=40):
     act = lambda: torch.randn(N, H, W, 64, device=DEV).to(BF16)
     x, t1, t2, out, dy, dt1, dt2, dx = (act() for _ in range(8))
     mean, hid, gate, dz = torch.zeros(N, 64, device=DEV), torch.zeros(N, 4, device=DEV), torch.zeros(N, 64, device=DEV), torch.zeros(N, 64, device=DEV)
-    xchg = torch.zeros(int(L.lib().rumpy_rcab_xchg_bytes(N, H)), dtype=torch.uint8, device=DEV)
+    xchg = torch.zeros(int(L.lib().rumpy_rcab_xchg_bytes(N, H, W)), dtype=torch.uint8, device=DEV)
     nst = N * ((H + 5) // 6)
     epoch, status = torch.zeros(1, dtype=torch.int32, device=DEV), torch.zeros(16 + nst * 8 * 16 * 2, dtype=torch.int32, device=DEV)   # + stamps of a RCAB_ABL=9 build
     common = dict(N=N, H=H, W=W, cr=4, ca_w1=cw1.data_ptr(), ca_b1=cb1.data_ptr(), ca_w2=cw2.data_ptr(), ca_b2=cb2.data_ptr(), hidden=hid.data_ptr(),
