@@ -517,7 +517,7 @@ def main():
             roofline.update(common)
             # HBM bytes per launch from the PMC passes committed under profiles/ (not re-measured here; null when the kernel changed since)
             kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else 'rcab_kernel' if rcabs else 'conv_block_kernel'
-            roofline['traffic'], roofline['traffic_source'] = pmc_traffic('%s:%s:N%d:P%d' % (kind, args.model, N, P))
+            roofline['traffic'], roofline['traffic_source'] = pmc_traffic('%s:N%d:P%d' % (kind, N, P))
 
     # ---- informational: the step exactly as the reference's caller makes it (SISRInterface.train_batch, interface.py:97-101): batch on the HOST,
     # output returned to the HOST (keep_on_device=False): 15 MB up + 14 MB down over PCIe per step.  Never `value`. ----

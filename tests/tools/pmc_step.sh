@@ -34,6 +34,6 @@ if forms:
              'source': 'profiles/pmc_traffic.json <- tests/tools/pmc_step.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --model %s '
                        '(32 x 48 x 48), 2 x FETCH_SIZE + WRITE_SIZE, mean over the forward and data-gradient launches' % (M, M)}
     out = 'gpurun_out/pmc_traffic_%s.json' % M
-    json.dump({'%s:%s:N32:P48' % (kind, M): entry}, open(out, 'w'), indent=1)
+    json.dump({'%s:N32:P48' % kind: entry}, open(out, 'w'), indent=1)
     print('wrote', out, '(merge into profiles/pmc_traffic.json)')
 PY
