@@ -155,6 +155,8 @@ typedef struct {
                           -0.9f = LeakyReLU(0.1) (first conv of the degradation encoder), -1 = ReLU */
   int32_t fmt;         /* RUMPY_FMT_* of `out` */
   int32_t pad_;
+  const float* const* x_ind;   /* NULL, or a device word holding the address to read instead of `x` (rumpy_set_pointers): a captured
+                                  hipGraph of the training step then follows the caller's batch without a copy into a fixed buffer */
 } rumpy_head_fwd_args;
 int rumpy_head_fwd(const rumpy_head_fwd_args* a, void* stream);
 
@@ -169,6 +171,7 @@ typedef struct {
   float* gb;
   int32_t N, C, H, W, cout;
   float scale;
+  const float* const* x_ind;   /* as in rumpy_head_fwd_args */
 } rumpy_head_wgrad_args;
 int rumpy_head_wgrad(const rumpy_head_wgrad_args* a, void* stream);
 int64_t rumpy_head_wgrad_slab_floats(int32_t C, int32_t cout);
@@ -195,8 +198,14 @@ typedef struct {
                             that overflowed: the host re-runs the image in bf16) */
   int32_t fmt;           /* RUMPY_FMT_* of x and w (F16: no dy4 / wslab) */
   int32_t pad_;
+  const float* const* target_ind;   /* NULL, or a device word holding the address to read instead of `target` (which must still be non-NULL:
+                                       it says that there IS a target); see rumpy_head_fwd_args.x_ind */
 } rumpy_tail_fwd_args;
 int rumpy_tail_fwd(const rumpy_tail_fwd_args* a, void* stream);
+/* table[0] = p0, table[1] = p1 in stream order (one tiny launch; the values travel as kernel arguments, no host buffer to keep alive):
+ * the pointer table behind x_ind / target_ind.  Replaces the two device-to-device copies of the batch into the plan's fixed buffers that a
+ * captured training step otherwise needs (base_architecture.py:425-431 hands run_train a new x / y every call). */
+int rumpy_set_pointers(void* table, const void* p0, const void* p1, void* stream);
 int rumpy_tail_fwd_grid(int32_t N, int32_t H, int32_t W, int32_t grid_x);   /* workgroups rumpy_tail_fwd launches = slabs written */
 /* gw [C,64,3,3] / gb [C] = scale * sum of the slabs (fixed order) */
 int rumpy_tail_wgrad_reduce(const float* wslab, int32_t nslabs, int32_t C, float scale, float* gw, float* gb, void* stream);

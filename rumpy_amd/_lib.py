@@ -38,7 +38,7 @@ class ConvArgs(_S):
 class HeadFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('b', c_void_p), ('out', c_void_p),
                 ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32), ('neg_slope_m1', c_float),
-                ('fmt', c_int32), ('pad_', c_int32)]
+                ('fmt', c_int32), ('pad_', c_int32), ('x_ind', c_void_p)]
 
 
 class EncConvArgs(_S):
@@ -77,14 +77,14 @@ class EncBnBwdArgs(_S):
 class HeadWgradArgs(_S):
     _fields_ = [('x', c_void_p), ('dy', c_void_p), ('slab', c_void_p), ('gw', c_void_p), ('gb', c_void_p),
                 ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('cout', c_int32),
-                ('scale', c_float)]
+                ('scale', c_float), ('x_ind', c_void_p)]
 
 
 class TailFwdArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p), ('target', c_void_p),
                 ('dy4', c_void_p), ('loss_partial', c_void_p), ('loss', c_void_p),
                 ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32), ('grid_x', c_int32), ('wslab', c_void_p),
-                ('nonfinite', c_void_p), ('fmt', c_int32), ('pad_', c_int32)]
+                ('nonfinite', c_void_p), ('fmt', c_int32), ('pad_', c_int32), ('target_ind', c_void_p)]
 
 
 class TailDgradArgs(_S):
@@ -303,6 +303,7 @@ SYMBOLS = {
     'rumpy_enc_pool': (C.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_head_wgrad_slab_floats': (c_int64, [c_int32, c_int32]),
     'rumpy_tail_fwd': (C.c_int, [_P(TailFwdArgs), c_void_p]),
+    'rumpy_set_pointers': (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     'rumpy_tail_fwd_grid': (C.c_int, [c_int32, c_int32, c_int32, c_int32]),
     'rumpy_tail_wgrad_reduce': (C.c_int, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     'rumpy_tail_dgrad': (C.c_int, [_P(TailDgradArgs), c_void_p]),

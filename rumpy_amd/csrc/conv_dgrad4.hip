@@ -32,6 +32,12 @@ constexpr int D4_NST = 6;                             // ring slots: the stage i
 #ifndef D4_AHEAD
 #define D4_AHEAD 4
 #endif
+#ifndef D4_XCD
+#define D4_XCD 0        // 1: A/B - the tiles of a round dealt out in contiguous runs per XCD (common.hpp xcd_strip), so that neighbouring tiles, which
+#endif                  // share 41 % of their halo pixels, meet in ONE L2.  Measured SLOWER (round 3, same box, kbench.py conv4: 32x96x96 114.0-115.1 against
+                        // 101.7-102.5 us, 32x48x48 39.3-40.2 against 36.9-37.7): dealt round-robin, a round's 256 tiles load all eight L2s and their memory
+                        // channels evenly at every moment; in runs, each XCD streams one compact region and the halo lines it saves were L2 hits of the
+                        // Infinity Cache anyway (profiles/r03_conv4_xcd_ab.txt)
 #ifndef D4_RD
 #define D4_RD 2         // fragment sets read ahead of the MFMAs (units of 6 reads / 12 MFMAs)
 #endif
@@ -60,6 +66,11 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
   if (tile0 >= ntiles) return;
   const int nt = (ntiles - tile0 + tstride - 1) / tstride;
   const int nstage = 4 * nt;
+  // round `it` covers tiles [it * grid, (it + 1) * grid); workgroup b sits on XCD b % 8 (D4_XCD above)
+  auto tile_of = [&](int it) {
+    const int base = it * tstride, left = ntiles - base;
+    return base + (D4_XCD ? xcd_strip(tile0, left < tstride ? left : tstride) : tile0);
+  };
   const unsigned ring = (unsigned)(size_t)(d4_lds_u8)lds;
   if (tid == 0) landed = 0u;
 
@@ -91,7 +102,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
   // MFMA stream, where a lone wave per SIMD has issue slots to spare (a stage's six pieces issued in one go at the top of a chunk cost
   // 190 VALU instructions there: a third of the chunk's MFMA time with nothing to overlap them)
   auto issue_piece = [&](int u, int k) {
-    const TileCoord tc = decode_tile(tile0 + (u >> 2) * tstride, a.tiles_x, a.tiles_y);
+    const TileCoord tc = decode_tile(tile_of(u >> 2), a.tiles_x, a.tiles_y);
     const int ch = u & 3;
     const unsigned dst = ring + (unsigned)(u % D4_NST) * D4_STAGE;
     const int piece = (q + 4 * k < D4_PIECES) ? q + 4 * k : D4_PIECES - 1;
@@ -127,7 +138,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     bj[0] = b4.x; bj[1] = b4.y; bj[2] = b4.z; bj[3] = b4.w;
   }
   for (int it = 0; it < nt; ++it) {
-    const TileCoord tc = decode_tile(tile0 + it * tstride, a.tiles_x, a.tiles_y);
+    const TileCoord tc = decode_tile(tile_of(it), a.tiles_x, a.tiles_y);
     const int xx = tc.tx * TW + px;
     f32x4 acc[TH];
 #pragma unroll

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
 // ------------------------------------------------------------------------------------------------------
 struct TailDev {
   const uint16_t* x; const uint4* w; const float* bias; float* out; const float* target; uint16_t* dy4;
-  float* loss_partial; float* wslab; int N, C, H, W, tiles_x, tiles_y; unsigned* nonfinite;
+  float* loss_partial; float* wslab; int N, C, H, W, tiles_x, tiles_y; unsigned* nonfinite; const float* const* target_ind;
 };
 
 typedef __attribute__((address_space(3))) short4v* tail_lds_s4;
@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const float* const target = a.target_ind ? *a.target_ind : a.target;      // the batch of this replay (rumpy_set_pointers)
   // forward filter: stationary in 72 VGPRs (round 2: in the WGRAD form too - its weight-gradient accumulators shrank from 36 to 12 registers;
   // the filter used to sit in 18 KB of LDS there, one more fragment read per MFMA)
   bf16x8 F[18];
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
     // some valid address, value unused): a fixed number of loads per iteration lets the compiler wait with counted
     // vmcnt values - the epilogue below used to drain the whole queue once per channel.
     const int xx = tc.tx * TW + px;
-    const float* tsrc = a.target ? a.target : a.out;
+    const float* tsrc = target ? target : a.out;
     float tg[2][4];
     size_t obase[2];
     bool inimg[2];
@@ -603,7 +604,7 @@ extern "C" int rumpy_tail_fwd(const rumpy_tail_fwd_args* p, void* stream) {
   if ((p->dy4 || p->loss_partial || p->loss) && !p->target) { rumpy_set_error("rumpy_tail_fwd: loss outputs need target"); return RUMPY_E_ARG; }
   if (p->target && (!p->loss_partial || !p->loss)) { rumpy_set_error("rumpy_tail_fwd: target needs loss_partial and loss"); return RUMPY_E_ARG; }
   TailDev d;
-  d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = p->out; d.target = p->target;
+  d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = p->out; d.target = p->target; d.target_ind = p->target ? p->target_ind : nullptr;
   d.dy4 = (uint16_t*)p->dy4; d.loss_partial = p->loss_partial; d.wslab = p->wslab; d.N = p->N; d.C = p->C; d.H = p->H; d.W = p->W;
   if (p->wslab && !p->target) { rumpy_set_error("rumpy_tail_fwd: wslab needs target"); return RUMPY_E_ARG; }
   if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !p->wslab && !p->dy4)) { rumpy_set_error("rumpy_tail_fwd: fmt %d goes without dy4 / wslab", p->fmt); return RUMPY_E_ARG; }

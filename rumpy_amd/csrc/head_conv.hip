@@ -11,9 +11,10 @@ constexpr int HEAD_FWD_THREADS = 64;
 
 // one thread = one pixel x 64 output channels; weights transposed to [k = (c,ky,kx)][co] in LDS (broadcast reads)
 template <int C, int FMT = RUMPY_FMT_BF16>
-__global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float* x, const float* const* x_ind, const float* __restrict__ w,
                                                        const float* __restrict__ b, uint16_t* __restrict__ out,
                                                        int N, int H, int W, int cout, float slope_m1) {
+  if (x_ind) x = *x_ind;          // the batch of this replay (rumpy_set_pointers)
   __shared__ __attribute__((aligned(16))) float sw[9 * HEAD_MAXC * 64];
   __shared__ float sb[64];
   const int ct = blockIdx.y;
@@ -68,8 +69,9 @@ __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float*
 // channel quad c4 = (tid >> 2) & 15 -> co 4*c4..4*c4+3, tap part kp = tid & 3 -> k = kp, kp+4, ... < 9*C):
 // per pixel one 8-byte LDS read of dy feeds up to 36 FMAs.  The four pixel quarters are added through LDS in a
 // fixed order; slab per workgroup: [cout_tiles][64][9*C + 1] (last column = bias sum).
-__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* x, const float* const* x_ind, const uint16_t* __restrict__ dy,
                                                          float* __restrict__ slab, int N, int C, int H, int W, int cout) {
+  if (x_ind) x = *x_ind;
   __shared__ float sx[HEAD_MAXC * HALO_PIX];
   __shared__ __attribute__((aligned(16))) uint16_t sdy[TH * TW * 64];
   __shared__ float red[4 * 64 * (9 * HEAD_MAXC + 1)];
@@ -158,8 +160,9 @@ __device__ __forceinline__ bf16x8 head_tr_pair(const unsigned char* p) {
   c.s = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return c.h;
 }
-__global__ void __launch_bounds__(256) head_wgrad_mfma_kernel(const float* __restrict__ x, const uint16_t* __restrict__ dy,
+__global__ void __launch_bounds__(256) head_wgrad_mfma_kernel(const float* x, const float* const* x_ind, const uint16_t* __restrict__ dy,
                                                               float* __restrict__ slab, int N, int C, int H, int W, int cout) {
+  if (x_ind) x = *x_ind;
   __shared__ float sx[HEAD_MAXC * HALO_PIX];
   __shared__ __attribute__((aligned(16))) unsigned char sdy[TH * TW * PIX_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -291,7 +294,7 @@ extern "C" int rumpy_head_fwd(const rumpy_head_fwd_args* p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   uint16_t* o = (uint16_t*)p->out;
   if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("rumpy_head_fwd: bad fmt %d", p->fmt); return RUMPY_E_ARG; }
-#define HEAD_LAUNCH(C_, F_) hipLaunchKernelGGL((head_fwd_kernel<C_, F_>), grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1)
+#define HEAD_LAUNCH(C_, F_) hipLaunchKernelGGL((head_fwd_kernel<C_, F_>), grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->x_ind, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1)
   if (p->fmt == RUMPY_FMT_F16) {
     switch (p->C) {
       case 1: HEAD_LAUNCH(1, RUMPY_FMT_F16); break;
@@ -319,13 +322,24 @@ extern "C" int rumpy_head_wgrad(const rumpy_head_wgrad_args* p, void* stream) {
   const int nwg = ntiles < head_wgrad_grid() ? ntiles : head_wgrad_grid();
   hipStream_t s = (hipStream_t)stream;
   static const bool valu = getenv("RUMPY_HEAD_WGRAD_VALU") != nullptr;     // A/B switch: the fp32 VALU version
-  if (valu) hipLaunchKernelGGL(head_wgrad_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
+  if (valu) hipLaunchKernelGGL(head_wgrad_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, p->x_ind, (const uint16_t*)p->dy, p->slab,
                                p->N, p->C, p->H, p->W, p->cout);
-  else hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, (const uint16_t*)p->dy, p->slab,
+  else hipLaunchKernelGGL(head_wgrad_mfma_kernel, dim3(nwg, p->cout / 64), dim3(256), 0, s, p->x, p->x_ind, (const uint16_t*)p->dy, p->slab,
                           p->N, p->C, p->H, p->W, p->cout);
   const int total = p->cout * (9 * p->C + 1);
   if (p->gw)          // (gw == NULL: rumpy_finish_reduce adds the slabs up together with the other layers')
   hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, s, p->slab, nwg, p->C, p->cout,
                      p->scale, p->gw, p->gb);
   return rumpy_check_launch("rumpy_head_wgrad");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the pointer table behind x_ind / target_ind
+// ------------------------------------------------------------------------------------------------------
+__global__ void set_pointers_kernel(const void** table, const void* p0, const void* p1) { table[0] = p0; table[1] = p1; }
+
+extern "C" int rumpy_set_pointers(void* table, const void* p0, const void* p1, void* stream) {
+  if (!table) { rumpy_set_error("rumpy_set_pointers: null table"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(set_pointers_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const void**)table, p0, p1);
+  return rumpy_check_launch("rumpy_set_pointers");
 }

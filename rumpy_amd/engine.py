@@ -133,6 +133,7 @@ class SREngine:
         self.wgrad_shares = os.environ.get('RUMPY_WGRAD_JOBS') != '1'
         self.wgrad_two_phase = os.environ.get('RUMPY_WGRAD_AB') == '1'
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
+        self.batch_by_pointer = os.environ.get('RUMPY_BATCH_COPY') != '1'  # captured training step reads the caller's x / target through a pointer table; =1: A/B, copies into fixed buffers
         self.block_any_width = os.environ.get('RUMPY_BLOCK_W48') != '1'    # ... also for images wider than one strip (column tiles); =1: A/B, two launches per block there
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
@@ -1038,8 +1039,12 @@ class SREngine:
         # the head / tail kernels read the caller's fp32 NCHW tensors in place and write a fresh output tensor: no copies
         plan.x_ref, plan.target_ref = x, target           # keep them alive until the backward pass has consumed them
         plan.head_args.x = x.data_ptr()
+        plan.head_args.x_ind = None           # (a captured step of the same plan reads through its pointer table; its launches keep their own copy of the arguments)
         if train:
             plan.head_wgrad_args.x = x.data_ptr()
+            plan.head_wgrad_args.x_ind = None
+            if getattr(plan, 'tail_loss', None) is not None:
+                plan.tail_loss.target_ind = None
         out = torch.empty_like(plan.out)
         self._run(plan.fwd, stream)
         if self.wide:
@@ -1203,8 +1208,14 @@ class SREngine:
             plan.head_wgrad_args.x = plan.x_in.data_ptr()
             plan.tail_loss.out = plan.out.data_ptr()
             plan.tail_loss.target = plan.target.data_ptr()
-            plan.x_in.copy_(x)
-            plan.target.copy_(target)
+            if self.batch_by_pointer:
+                # the captured launches read x / target through a two-word device table (rumpy_set_pointers before every replay):
+                # no device-to-device copy of the batch into the plan's buffers (14 MB of target per step on the headline shape)
+                plan.batch_ptrs = torch.zeros(2, dtype=torch.int64, device=self.device)
+                plan.head_args.x_ind = plan.batch_ptrs.data_ptr()
+                plan.head_wgrad_args.x_ind = plan.batch_ptrs.data_ptr()
+                plan.tail_loss.target_ind = plan.batch_ptrs.data_ptr() + 8
+            self._bind_batch(plan, x, target, cur)
             self._q_gates(plan, meta, None, launch=False)
 
             if plan.q_items and plan.q_dev is None:
@@ -1226,11 +1237,27 @@ class SREngine:
             with torch.cuda.graph(g):
                 body(torch.cuda.current_stream(self.device).cuda_stream)
             plan.graph = g
-        plan.x_in.copy_(x, non_blocking=True)
-        plan.target.copy_(target, non_blocking=True)
+        self._bind_batch(plan, x, target, cur)
         self._q_gates(plan, meta, None, launch=False)
         plan.graph.replay()
         return plan.out, plan.loss, plan
+
+    def _bind_batch(self, plan, x, target, cur):
+        """make the captured step read this batch: by pointer when the caller's tensors are what the kernels read (fp32, contiguous, on
+        this device - the caller keeps them alive until the step has run, as for any stream-ordered op), by copy otherwise"""
+        def direct(t, like):
+            return (t.is_cuda and t.device == like.device and t.dtype == torch.float32 and t.is_contiguous() and t.shape == like.shape)
+        if getattr(plan, 'batch_ptrs', None) is None:
+            plan.x_in.copy_(x, non_blocking=True)
+            plan.target.copy_(target, non_blocking=True)
+            return
+        if not direct(x, plan.x_in):
+            plan.x_in.copy_(x, non_blocking=True)
+            x = plan.x_in
+        if not direct(target, plan.target):
+            plan.target.copy_(target, non_blocking=True)
+            target = plan.target
+        L.check(self.lib.rumpy_set_pointers(plan.batch_ptrs.data_ptr(), x.data_ptr(), target.data_ptr(), cur.cuda_stream), 'rumpy_set_pointers')
 
     def _qca_param_grads(self, plan, stream):
         if plan.qca_items:

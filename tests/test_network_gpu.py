@@ -486,6 +486,37 @@ def test_hipgraph_replay_gives_the_same_step_as_eager_launches(name, kw):
     assert hs[1].net.engine.exchange_status() == 0
 
 
+def test_captured_step_follows_the_callers_batch_by_pointer():
+    """The captured training step reads x / y through a two-word device table (rumpy_set_pointers): batches that live at different
+    addresses, a batch that is not what the kernels can read in place (a strided view: copied into the plan's buffer), and the
+    copy-always form (RUMPY_BATCH_COPY=1) all give the same steps, bit for bit."""
+    kw = dict(scale=4, num_blocks=2)
+    sd = O.seeded_state_dict(O.build_oracle('edsr', **kw), 507)
+    hs = []
+    for by_pointer in (True, False):
+        h = _handler('edsr', lr=1e-3, **kw)
+        h.net.load_state_dict(sd)
+        h.net.use_graph = True
+        h.net._ensure_engine()
+        h.net.engine.batch_by_pointer = by_pointer
+        hs.append(h)
+    pool = [tuple(t.cuda() for t in O.synthetic_batch(s, 2, lr_hw=24, scale=4)) for s in (660, 661, 662)]
+    wide = torch.zeros(2, 3, 24, 48, device='cuda')
+    for i in (0, 1, 2, 1, 0):
+        x, y = pool[i]
+        if i == 2:                       # same values behind a strided view
+            wide[..., ::2] = x
+            x = wide[..., ::2]
+            assert not x.is_contiguous()
+        l1, o1 = hs[0].run_train(x=x, y=y, keep_on_device=True)
+        l2, o2 = hs[1].run_train(x=x, y=y, keep_on_device=True)
+        assert float(l1) == float(l2) and torch.equal(o1, o2), i
+    for p, q in zip(hs[0].net.parameters(), hs[1].net.parameters()):
+        assert torch.equal(p.detach(), q.detach())
+    assert any(getattr(pl, 'batch_ptrs', None) is not None for pl in hs[0].net.engine.plans.values())
+    assert not any(getattr(pl, 'batch_ptrs', None) is not None for pl in hs[1].net.engine.plans.values())
+
+
 def test_reference_written_checkpoint_continues_identically_on_the_gpu(golden_dir):
     """G11: the checkpoint FILE written by the real reference handler is loaded into the HIP handler; the
     evaluation at the saved state and the NEXT training step (loss, learning rate, weights - i.e. the restored Adam moments
