@@ -15,6 +15,9 @@
 #ifndef WGRAD_ABL
 #define WGRAD_ABL 0     // timing experiments only (tests/tools/build_abl.sh): results are wrong for any value but 0
 #endif
+#ifndef WGRAD_STAGGER
+#define WGRAD_STAGGER 1 // 0: A/B - every wave issues its DMA pieces right behind the tile's barrier (rounds 1-2)
+#endif
 
 typedef __attribute__((address_space(3))) short4v* lds_s4_ptr2;
 typedef __attribute__((address_space(3))) unsigned char* lds_u8;
@@ -177,13 +180,18 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     else if (younger == 1) { if (PW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + AHEAD < ntiles && WGRAD_ABL != 3) {
-      const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
-      tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
-    }
+    // The two waves of a SIMD are (w4, kh = 0) and (w4, kh = 1).  WGRAD_STAGGER: the kh = 0 wave issues its DMA pieces of tile t + AHEAD here,
+    // the kh = 1 wave between its two k-steps - the barrier above lines all eight waves up once per tile, and a wave that feeds the
+    // vector-memory queue (5 pieces, 100-185 issue cycles each next to LDS reads: MI355X_MICROARCH.md) cannot feed the matrix pipe meanwhile;
+    // staggered, one wave of every SIMD issues MFMAs while its sibling issues DMA.  The counted waits are unchanged (a wave's pieces of
+    // tile t + AHEAD are still its youngest at the top of step t + 1), and so is every accumulation order.
+    const bool more = (t + AHEAD < ntiles) && WGRAD_ABL != 3;
+    const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
+    if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
     const unsigned sb = lds0 + slot * DSTAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (WGRAD_STAGGER && ks == 1 && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
       bf16x8 A[MT];
 #pragma unroll
       for (int ct = 0; ct < MT; ++ct) {

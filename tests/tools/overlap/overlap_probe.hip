@@ -21,6 +21,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 __device__ __forceinline__ void st16_nt(uint4* p, uint4 v) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y);
@@ -85,7 +86,10 @@ __global__ void __launch_bounds__(THREADS) strip_probe(const uint4* __restrict__
     uint4 v = *reinterpret_cast<const uint4*>(lds + ((i * THREADS + tid) * 16 + (IN_BYTES - OUT_BYTES) / 2) % IN_BYTES);
     v.x ^= bit; v.z ^= bit;
     if (MODE & 2) { if (v.x == 0x12345678u && v.y == 0x9abcdef0u) out[tid] = v; }      // (never true on this data; keeps the values alive)
-    else if (MODE & 4) out[blockIdx.x * (OUT_BYTES / 16) + i * THREADS + tid] = v;
+    else if (MODE & (4 | 128)) out[blockIdx.x * (OUT_BYTES / 16) + i * THREADS + tid] = v;
+    else if (MODE & 16) asm volatile("global_store_dwordx4 %0, %1, off sc0" :: "v"(out + blockIdx.x * (OUT_BYTES / 16) + i * THREADS + tid), "v"((u32x4){v.x, v.y, v.z, v.w}) : "memory");
+    else if (MODE & 32) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(out + blockIdx.x * (OUT_BYTES / 16) + i * THREADS + tid), "v"((u32x4){v.x, v.y, v.z, v.w}) : "memory");
+    else if (MODE & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(out + blockIdx.x * (OUT_BYTES / 16) + i * THREADS + tid), "v"((u32x4){v.x, v.y, v.z, v.w}) : "memory");
     else st16_nt(out + blockIdx.x * (OUT_BYTES / 16) + i * THREADS + tid, v);
   }
 }
@@ -165,6 +169,12 @@ int main(int argc, char** argv) {
       timed(strip_probe<512, 65536, 36864, 384, 115200, 1>, "no tile load:");
       timed(strip_probe<512, 65536, 36864, 384, 115200, 2>, "no stores:");
       timed(strip_probe<512, 65536, 36864, 384, 115200, 4>, "default-policy stores:");
+      timed(strip_probe<512, 65536, 36864, 384, 115200, 16>, "sc0 stores:");
+      timed(strip_probe<512, 65536, 36864, 384, 115200, 32>, "sc1 stores:");
+      timed(strip_probe<512, 65536, 36864, 384, 115200, 64>, "sc0 sc1 stores:");
+      timed(strip_probe<512, 65536, 36864, 384, 115200, 128>, "default-policy stores + early agent release:");
+      timed(strip_probe<512, 65536, 36864, 384, 115200, 8 + 4>, "no MFMA loop, default-policy stores:");
+      timed(strip_probe<512, 65536, 36864, 384, 115200, 8 + 32>, "no MFMA loop, sc1 stores:");
       timed(strip_probe<512, 65536, 36864, 384, 115200, 9>, "no tile load, no MFMA loop:");
       timed(strip_probe<512, 65536, 36864, 384, 115200, 10>, "no stores, no MFMA loop:");
       timed(strip_probe<512, 65536, 36864, 384, 115200, 11>, "nothing but the launch (filter fetch, barriers):");
