@@ -19,9 +19,37 @@ from torch import nn
 from rumpy_amd.engine import CALayerParams, ConvLayer, NetSpec, QLayerParams, SREngine
 
 
-def _conv(cin, cout, k=3):
+def _ceil64(f):
+    return (f + 63) // 64 * 64
+
+
+def _embed(mod, pin=None, pout=None):
+    """Feature widths the kernels do not have (not a multiple of 64): the layer is built at the reference's shape - same RNG use, same
+    initial values - and then EMBEDDED in the top-left corner of a zero filter of the next kernel width (pin / pout: padded input /
+    output channels; the reference accepts any width, architectures.py:145,207).  Padded channels carry exact zeros through every layer
+    (zero filter rows and biases, ReLU(0) = 0, residual adds of zeros, PixelShuffle rows c * r^2 + s of c >= f) and receive exactly zero
+    gradients (their inputs or their upstream gradients are zero), so Adam leaves them at zero: the network computes the reference's
+    function at the cost of the padded width.  ``state_dict`` / ``load_state_dict`` / the optimizer's checkpoint crop and pad
+    (``_rumpy_real_shape``), so files interchange with the reference at its shapes."""
+    co, ci = mod.weight.shape[:2]
+    pin, pout = pin or ci, pout or co
+    if (pin, pout) == (ci, co):
+        return mod
+    with torch.no_grad():
+        w = torch.zeros(pout, pin, *mod.weight.shape[2:], dtype=mod.weight.dtype)
+        w[:co, :ci] = mod.weight
+        b = torch.zeros(pout, dtype=mod.bias.dtype)
+        b[:co] = mod.bias
+    real_w, real_b = tuple(mod.weight.shape), tuple(mod.bias.shape)
+    mod.weight, mod.bias = nn.Parameter(w), nn.Parameter(b)
+    mod.weight._rumpy_real_shape, mod.bias._rumpy_real_shape = real_w, real_b
+    mod.in_channels, mod.out_channels = pin, pout
+    return mod
+
+
+def _conv(cin, cout, k=3, pin=None, pout=None):
     # default_conv, common.py:6-9 (parameter container; same default init / RNG use as nn.Conv2d there)
-    return nn.Conv2d(cin, cout, k, padding=k // 2, bias=True)
+    return _embed(nn.Conv2d(cin, cout, k, padding=k // 2, bias=True), pin, pout)
 
 
 class _Holder(nn.Module):
@@ -34,41 +62,43 @@ class _Holder(nn.Module):
 
 class _ResBlockParams(_Holder):
     # common.py:51-75: body = [conv, ReLU, conv] -> keys body.0.*, body.2.*
-    def __init__(self, feats, res_scale):
-        super().__init__([_conv(feats, feats), nn.ReLU(True), _conv(feats, feats)])
+    def __init__(self, feats, res_scale, pad=None):
+        super().__init__([_conv(feats, feats, pin=pad, pout=pad), nn.ReLU(True), _conv(feats, feats, pin=pad, pout=pad)])
         self.res_scale = res_scale
 
 
 class _CAParams(nn.Module):
     # architectures.py:24-44: conv_du = [conv1x1, ReLU, conv1x1, Sigmoid] -> keys conv_du.0.*, conv_du.2.*
-    def __init__(self, feats, reduction):
+    def __init__(self, feats, reduction, pad=None):
         super().__init__()
         self.avg_pool = nn.AdaptiveAvgPool2d(1)
-        self.conv_du = nn.Sequential(nn.Conv2d(feats, feats // reduction, 1, padding=0, bias=True), nn.ReLU(inplace=True),
-                                     nn.Conv2d(feats // reduction, feats, 1, padding=0, bias=True), nn.Sigmoid())
+        self.conv_du = nn.Sequential(_embed(nn.Conv2d(feats, feats // reduction, 1, padding=0, bias=True), pin=pad), nn.ReLU(inplace=True),
+                                     _embed(nn.Conv2d(feats // reduction, feats, 1, padding=0, bias=True), pout=pad), nn.Sigmoid())
 
 
 class _RCABParams(_Holder):
     # architectures.py:60-84: body = [conv, ReLU, conv, CALayer]; res_scale is stored and IGNORED (:79-84)
-    def __init__(self, feats, reduction, res_scale):
-        super().__init__([_conv(feats, feats), nn.ReLU(True), _conv(feats, feats), _CAParams(feats, reduction)])
+    def __init__(self, feats, reduction, res_scale, pad=None):
+        super().__init__([_conv(feats, feats, pin=pad, pout=pad), nn.ReLU(True), _conv(feats, feats, pin=pad, pout=pad),
+                          _CAParams(feats, reduction, pad)])
         self.res_scale = res_scale
 
 
 class _GroupParams(_Holder):
     # architectures.py:107-124: body = n x RCAB + conv
-    def __init__(self, feats, reduction, res_scale, n_resblocks):
-        super().__init__([_RCABParams(feats, reduction, res_scale) for _ in range(n_resblocks)] + [_conv(feats, feats)])
+    def __init__(self, feats, reduction, res_scale, n_resblocks, pad=None):
+        super().__init__([_RCABParams(feats, reduction, res_scale, pad) for _ in range(n_resblocks)] + [_conv(feats, feats, pin=pad, pout=pad)])
 
 
-def _upsampler(scale, feats):
-    # common.py:23-48, act=False, bn=False
+def _upsampler(scale, feats, pad=None):
+    # common.py:23-48, act=False, bn=False.  (Padded widths: output channel c * r^2 + s of the conv becomes channel c of the shuffled image, so
+    # the reference's rows are the first r^2 * feats of the padded filter - the same corner embedding as everywhere.)
     mods = []
     if (scale & (scale - 1)) == 0:
         for _ in range(int(math.log(scale, 2))):
-            mods += [_conv(feats, 4 * feats), nn.PixelShuffle(2)]
+            mods += [_conv(feats, 4 * feats, pin=pad, pout=4 * pad if pad else None), nn.PixelShuffle(2)]
     elif scale == 3:
-        mods += [_conv(feats, 9 * feats), nn.PixelShuffle(3)]
+        mods += [_conv(feats, 9 * feats, pin=pad, pout=9 * pad if pad else None), nn.PixelShuffle(3)]
     else:
         raise NotImplementedError
     return nn.Sequential(*mods)
@@ -105,6 +135,7 @@ class HipSRNet(nn.Module):
 
     def _finalize(self):
         self.param_list = list(self.parameters())
+        self._note_real_shapes()
         self.flat_p = self.flat_g = None
         # RUMPY_GRAPH=1 replays the fused training pass as a captured hipGraph.  Off by default: measured on MI355X the
         # step is GPU-bound (dependent kernel boundaries), eager launches keep up and a replay gains nothing (1.99 vs 2.03 ms)
@@ -157,6 +188,36 @@ class HipSRNet(nn.Module):
             if self.flat_p is None or self.param_list[0].data_ptr() != self.flat_p.data_ptr():
                 self._flatten()
         return self
+
+    # ---- widths embedded in the next kernel width (_embed): checkpoints keep the reference's shapes ----
+    def _note_real_shapes(self):
+        named = list(self.named_parameters())
+        self._real_by_name = {k: tuple(p._rumpy_real_shape) for k, p in named if getattr(p, '_rumpy_real_shape', None) is not None}
+        self.real_shapes = [self._real_by_name.get(k) for k, _ in named]       # aligned with param_list (None: not padded)
+        if self._real_by_name:
+            self._register_load_state_dict_pre_hook(self._pad_loaded_state)
+
+    def real_numel(self):
+        """parameter count of the reference's network (what its logs print), without the zero padding"""
+        return sum(math.prod(shp or p.shape) for shp, p in zip(self.real_shapes, self.param_list))
+
+    def state_dict(self, *args, **kw):
+        sd = super().state_dict(*args, **kw)
+        prefix = kw.get('prefix', args[1] if len(args) > 1 else '')
+        for k, shp in self._real_by_name.items():
+            if prefix + k in sd:
+                sd[prefix + k] = sd[prefix + k][tuple(slice(0, n) for n in shp)].detach().clone()
+        return sd
+
+    def _pad_loaded_state(self, state_dict, prefix, *unused):
+        """load_state_dict pre-hook (also reached through a parent module's load): entries at the reference's shapes -> zero-padded"""
+        own = dict(self.named_parameters())
+        for k, shp in self._real_by_name.items():
+            v = state_dict.get(prefix + k)
+            if v is not None and tuple(v.shape) == shp:
+                full = torch.zeros(own[k].shape, dtype=v.dtype, device=v.device)
+                full[tuple(slice(0, n) for n in shp)] = v
+                state_dict[prefix + k] = full
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)
@@ -294,12 +355,13 @@ class EDSR(HipSRNet):
     def __init__(self, in_features=3, out_features=3, net_features=64, num_blocks=16, scale=4, res_scale=0.1):
         super().__init__()
         f = net_features
+        P = _ceil64(f) if f % 64 else None       # a width between the kernel widths runs embedded in the next one (_embed)
         self.scale, self.res_scale = scale, res_scale
-        self.head = nn.Sequential(_conv(in_features, f))
-        self.body = nn.Sequential(*([_ResBlockParams(f, res_scale) for _ in range(num_blocks)] + [_conv(f, f)]))
-        self.tail = nn.Sequential(_upsampler(scale, f), _conv(f, out_features))
+        self.head = nn.Sequential(_conv(in_features, f, pout=P))
+        self.body = nn.Sequential(*([_ResBlockParams(f, res_scale, P) for _ in range(num_blocks)] + [_conv(f, f, pin=P, pout=P)]))
+        self.tail = nn.Sequential(_upsampler(scale, f, P), _conv(f, out_features, pin=P))
         # the fused forward + L1 + backward pass is built from 64-feature kernels: wider nets train through the generic autograd node
-        self.supports_fused_l1 = f == 64
+        self.supports_fused_l1 = (P or f) == 64
         self._finalize()
 
     def _spec(self):
@@ -324,11 +386,12 @@ class RCAN(HipSRNet):
                  res_scale=1.0, **kwargs):
         super().__init__()
         f = n_feats
+        P = _ceil64(f) if f % 64 else None       # fewer than 64 features: embedded in the 64-feature kernels (_embed)
         self.scale = scale
-        self.head = nn.Sequential(_conv(in_feats, f))
-        self.body = nn.Sequential(*([_GroupParams(f, reduction, res_scale, n_resblocks) for _ in range(n_resgroups)]
-                                    + [_conv(f, f)]))
-        self.tail = nn.Sequential(_upsampler(scale, f), _conv(f, out_feats))
+        self.head = nn.Sequential(_conv(in_feats, f, pout=P))
+        self.body = nn.Sequential(*([_GroupParams(f, reduction, res_scale, n_resblocks, P) for _ in range(n_resgroups)]
+                                    + [_conv(f, f, pin=P, pout=P)]))
+        self.tail = nn.Sequential(_upsampler(scale, f, P), _conv(f, out_feats, pin=P))
         self._finalize()
 
     def _spec(self):

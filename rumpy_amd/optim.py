@@ -49,18 +49,41 @@ class FlatAdam(torch.optim.Adam):
         # gradients are overwritten (not accumulated) by every backward pass of the engine
         self.net.attach_grads()
 
+    def state_dict(self):
+        """torch.optim.Adam's layout; moments of a parameter that lives embedded in a wider zero filter (architectures._embed) are written at
+        the reference's shape, like the parameter itself"""
+        sd = super().state_dict()
+        real = getattr(self.net, 'real_shapes', None)
+        if real and any(real):
+            for idx, st in sd['state'].items():
+                shp = real[idx]
+                if shp is not None:
+                    st = dict(st)
+                    for k in ('exp_avg', 'exp_avg_sq'):
+                        if k in st:
+                            st[k] = st[k][tuple(slice(0, n) for n in shp)].clone()
+                    sd['state'][idx] = st
+        return sd
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         # torch deep-copied the loaded state: pull it back into the flat buffers
         net = self.net
         step = 0.0
+
+        def padded(t, p):
+            if tuple(t.shape) == tuple(p.shape):
+                return t
+            full = torch.zeros(p.shape, dtype=t.dtype, device=t.device)      # moments at the reference's shape -> the embedded layout
+            full[tuple(slice(0, n) for n in t.shape)] = t
+            return full
         with torch.no_grad():
             for p, off in zip(net.param_list, net.offsets):
                 st = self.state.get(p, None)
                 n = p.numel()
                 if st and 'exp_avg' in st:
-                    self.flat_m[off:off + n].copy_(st['exp_avg'].reshape(-1))
-                    self.flat_v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                    self.flat_m[off:off + n].copy_(padded(st['exp_avg'], p).reshape(-1))
+                    self.flat_v[off:off + n].copy_(padded(st['exp_avg_sq'], p).reshape(-1))
                     step = float(st['step'])
                 else:
                     self.flat_m[off:off + n].zero_()

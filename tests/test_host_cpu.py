@@ -151,7 +151,7 @@ def test_compute_without_gpu_fails_loudly():
         h.optimizer.step()
     with pytest.raises(RuntimeError, match='multiple of 64|n_feats = 64'):
         from rumpy_amd.engine import SREngine
-        hh = _handler('edsr', scale=4, num_blocks=1, num_features=16)
+        hh = _handler('edsr', scale=4, num_blocks=1, num_features=272)       # beyond the widest kernel (widths up to 256 run embedded in the next kernel width)
         SREngine(hh.net._spec(), torch.device('cpu'))
 
 
@@ -639,7 +639,18 @@ def test_wide_edsr_and_x3_construct_like_the_reference_and_other_widths_are_refu
     assert tuple(h3.net.tail[0][0].weight.shape) == (576, 64, 3, 3) and h3.net.supports_fused_l1 is True
     assert [tuple(v.shape) for v in h3.net.state_dict().values()] == [tuple(v.shape) for v in O.build_oracle('edsr', scale=3, num_blocks=2).state_dict().values()]
     from rumpy_amd.engine import SREngine
-    for bad in (dict(num_features=96), dict(num_features=320), dict(scale=5)):
+    # widths between the kernel widths are embedded in the next one (architectures._embed): reference shapes outside, padded filters inside
+    h96 = _handler('edsr', scale=2, num_features=96, num_blocks=1)
+    o96 = O.build_oracle('edsr', scale=2, num_features=96, num_blocks=1)
+    assert [(k, tuple(v.shape)) for k, v in h96.net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in o96.state_dict().items()]
+    assert tuple(h96.net.body[0].body[0].weight.shape) == (128, 128, 3, 3) and h96.net.real_numel() == sum(p.numel() for p in o96.parameters())
+    sd96 = O.seeded_state_dict(o96, 5)
+    h96.net.load_state_dict(sd96)
+    assert all(torch.equal(v, sd96[k]) for k, v in h96.net.state_dict().items())
+    w = h96.net.body[0].body[0].weight.detach()
+    assert float(w[96:].abs().sum()) == 0.0 and float(w[:, 96:].abs().sum()) == 0.0
+    assert [tuple(st['exp_avg'].shape) for st in h96.optimizer.state_dict()['state'].values()] == [tuple(v.shape) for v in o96.state_dict().values()]
+    for bad in (dict(num_features=320), dict(scale=5)):
         try:
             hb = _handler('edsr', num_blocks=1, **{**dict(scale=2), **bad})
         except (RuntimeError, NotImplementedError):
