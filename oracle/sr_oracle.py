@@ -716,3 +716,27 @@ def vignetted_pair(hr_u8, lr_hw, scale=4, margin=24):
     hr = (np.clip(crop * w[:, None, None] * w[None, :, None], 0, 1) * 255 + 0.5).astype(np.uint8)
     lr = np.asarray(Image.fromarray(hr).resize((lr_hw, lr_hw), Image.BICUBIC))
     return lr, hr
+
+
+def forward_chop(run, x, scale, max_combined_im_size, shave=10):
+    """Tiled whole-image evaluation as the reference restates it twice, word for word: SANHandler.forward_chop
+    (rumpy/SISR/models/advanced/handlers.py:85-123) and ContrastiveBlindQEDSRHandler.forward_chop
+    (rumpy/SISR/models/blur_kernel_blind_sr/handlers.py:907-945).  `run(chunk)` super-resolves one chunk (the handlers' run_eval(...)[0])."""
+    b, c, h, w = x.size()
+    h_half, w_half = h // 2, w // 2
+    h_size, w_size = h_half + shave, w_half + shave
+    lr_list = [x[:, :, 0:h_size, 0:w_size], x[:, :, 0:h_size, (w - w_size):w],
+               x[:, :, (h - h_size):h, 0:w_size], x[:, :, (h - h_size):h, (w - w_size):w]]
+    if w_size * h_size < max_combined_im_size:
+        sr_list = [run(chunk) for chunk in lr_list]
+    else:
+        sr_list = [forward_chop(run, patch, scale, max_combined_im_size, shave=shave) for patch in lr_list]
+    h, w = scale * h, scale * w
+    h_half, w_half = scale * h_half, scale * w_half
+    h_size, w_size = scale * h_size, scale * w_size
+    output = x.new(b, c, h, w)
+    output[:, :, 0:h_half, 0:w_half] = sr_list[0][:, :, 0:h_half, 0:w_half]
+    output[:, :, 0:h_half, w_half:w] = sr_list[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
+    output[:, :, h_half:h, 0:w_half] = sr_list[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
+    output[:, :, h_half:h, w_half:w] = sr_list[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
+    return output

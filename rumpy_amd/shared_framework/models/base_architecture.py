@@ -334,9 +334,10 @@ class BaseModel(nn.Module):
     def print_parameters(self, verbose=False):
         total = 0
         for name, value in self.named_parameters():
+            shape = getattr(value, '_rumpy_real_shape', None) or value.shape      # (a width embedded in the next kernel width counts at the reference's shape)
             if verbose:
-                print(name, value.shape)
-            total += int(np.prod(value.shape))
+                print(name, tuple(shape))
+            total += int(np.prod(shape))
         if verbose:
             print('Total number of trainable parameters:', total)
         return total

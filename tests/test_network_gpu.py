@@ -16,6 +16,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import sr_oracle as O
+from rumpy_amd.shared_framework.models.base_architecture import BaseModel
 from rumpy_amd.shared_framework.models import define_model
 from rumpy_amd.SISR.models.interface import SISRInterface
 
@@ -515,6 +516,38 @@ def test_captured_step_follows_the_callers_batch_by_pointer():
         assert torch.equal(p.detach(), q.detach())
     assert any(getattr(pl, 'batch_ptrs', None) is not None for pl in hs[0].net.engine.plans.values())
     assert not any(getattr(pl, 'batch_ptrs', None) is not None for pl in hs[1].net.engine.plans.values())
+
+
+@pytest.mark.parametrize('name,kw', [('edsr', dict(scale=4, num_blocks=2)), ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16))])
+def test_tiled_whole_image_evaluation_is_the_references_forward_chop(name, kw):
+    """SURVEY.md 8(f)2: `max_combined_im_size` makes run_eval the reference's forward_chop (overlapping quarters, recursion, stitched halves;
+    advanced/handlers.py:85-134).  Against the oracle's restatement of it around the ORACLE network: same tiles, same stitching - the two
+    outputs differ by what the networks differ on a tile; and each tile is bitwise what run_eval returns for that tile alone."""
+    sd = O.seeded_state_dict(O.build_oracle(name, **kw), 509)
+    h = _handler(name, eval_mode=True, max_combined_im_size=1500, **kw)
+    h.net.load_state_dict(sd)
+    onet = O.build_oracle(name, **kw)
+    onet.load_state_dict(sd)
+    oh = O.OracleHandler(onet, eval_mode=True)
+    x, y = O.synthetic_batch(690, 1, lr_hw=(61, 83), scale=kw['scale'])          # 61 x 83: quarters of 40 x 51 >= 1500 -> one level of recursion
+    out, loss, _ = h.run_eval(x=x, y=y, request_loss=True)
+    ref = O.forward_chop(lambda c: oh.run_eval(c)[0], x, kw['scale'], 1500)
+    assert out.shape == ref.shape == (1, 3, 61 * kw['scale'], 83 * kw['scale']) and not out.is_cuda
+    assert self_psnr(out, ref) >= 50.0, self_psnr(out, ref)
+    assert abs(float(loss) - float((ref - y).abs().mean())) < 1e-2 * float(loss)
+    # the same stitching around the HIP handler's own whole-tile evaluation: bit for bit
+    own = O.forward_chop(lambda c: BaseModel.run_eval(h, c.contiguous())[0], x, kw['scale'], 1500)
+    assert torch.equal(out, own)
+    # against the whole image: this EDSR's receptive field (head 1 + 2 blocks x 2 + body end 1 + 2 upsampler convs at LR / LR*2 scale + tail)
+    # stays inside the 10-pixel overlap, so its tiles reproduce the whole image BIT FOR BIT (every output pixel sees the same inputs in the
+    # same order); RCAN's channel attention pools over the tile, so there the option changes the result - as it does in the reference
+    h.max_combined_im_size = None
+    whole, _, _ = h.run_eval(x=x)
+    assert whole.shape == out.shape
+    if name == 'edsr':
+        assert torch.equal(whole, out)
+    else:
+        assert not torch.equal(whole, out) and self_psnr(whole, out) >= 30.0
 
 
 def test_reference_written_checkpoint_continues_identically_on_the_gpu(golden_dir):
