@@ -40,6 +40,18 @@ class BodyChainArgs(C.Structure):
                 ('fmt', C.c_int32), ('flags', C.c_void_p), ('epoch', C.c_void_p), ('status', C.c_void_p)]
 
 
+class BlockSplitArgs(C.Structure):
+    _fields_ = [('block', L.BlockArgs), ('flags', C.c_int32), ('pad_', C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+SPLIT_FORK, SPLIT_JOIN, SPLIT_ONE_STREAM = 1, 2, 4
+
+
 def exp_lib():
     """ctypes handle of the experimental library (built by __graft_entry__.build() / make -C tests/tools/csrc)"""
     global _exp
@@ -51,6 +63,7 @@ def exp_lib():
                                 ('rumpy_block_chain', C.c_int, [C.POINTER(BlockChainArgs), C.c_void_p]), ('rumpy_block_chain_xchg_bytes', C.c_int64, [C.c_int32]),
                                 ('rumpy_body_chain', C.c_int, [C.POINTER(BodyChainArgs), C.c_void_p]),
                                 ('rumpy_body_chain_flag_bytes', C.c_int64, [C.c_int32, C.c_int32]),
+                                ('rumpy_conv_block_split', C.c_int, [C.POINTER(BlockSplitArgs), C.c_void_p]),
                                 ('rumpy_last_error', C.c_char_p, [])):
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args

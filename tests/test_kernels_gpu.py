@@ -653,85 +653,6 @@ def test_conv_block_geometries_agree_bitwise(N, H, W):
     assert L.lib().rumpy_conv_block(a, None) == -1 and b'col_tile' in L.lib().rumpy_last_error()
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# residual block in one launch (conv_block.hip) against the same two layers through rumpy_conv3x3
-# ---------------------------------------------------------------------------------------------------------------------
-def _run_block(x, pa, pb, N, H, W, fwd, rs, mask=None, extra=None, store_t=True):
-    t = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) if store_t else None
-    out = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
-    p = lambda z: None if z is None else z.data_ptr()
-    if fwd:
-        a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
-                        mask=None, res2=None, t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs))
-    else:   # data gradient: first through conv2 (pb) masked, then through conv1 (pa)
-        a = L.BlockArgs(x=x.data_ptr(), w1=pb.w_dgrad.data_ptr(), b1=None, w2=pa.w_dgrad.data_ptr(), b2=None, mask=p(mask), res2=p(extra),
-                        t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=float(rs), scale2=1.0)
-    L.call('rumpy_conv_block', a, stream())
-    torch.cuda.synchronize()
-    return t, out
-
-
-@pytest.mark.parametrize('N,H,W', [(1, 6, 16), (2, 13, 48), (3, 20, 37), (1, 5, 9), (32, 48, 48),
-                                   # wider than one strip: column tiles of 32 / 48 output columns with the activation's halo columns computed
-                                   (1, 7, 49), (2, 13, 64), (1, 20, 100), (2, 9, 128), (8, 64, 64), (1, 31, 170)])
-def test_conv_block_matches_two_layer_launches(N, H, W):
-    gen = np.random.default_rng(100 + H + W)
-    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
-                            torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
-    pa, pb = mk(), mk()
-    x = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
-    rs = 0.1
-    # forward: t = relu(conv1 x + b1); y = x + rs * (conv2 t + b2)
-    t_ref, _ = hip_conv(x, pa, N, H, W, relu=True)
-    y_ref, _ = hip_conv(t_ref, pb, N, H, W, scale=rs, res1=x)
-    t, y = _run_block(x, pa, pb, N, H, W, True, rs)
-    assert torch.equal(t, t_ref), 'activation between the two convs'
-    assert_bf16_close(y.float(), y_ref.float(), 'block forward', rel=2e-3, amax=2.0 ** -7)
-    _, y2 = _run_block(x, pa, pb, N, H, W, True, rs, store_t=False)        # inference: activation not stored
-    assert torch.equal(y2, y)
-    # data gradient: gt = mask(t) . rs * conv2^T(g); gx = g + conv1^T(gt) + extra
-    g = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
-    extra = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
-    gt_ref, _ = hip_conv(g, pb, N, H, W, dgrad=True, scale=rs, mask=t_ref)
-    gx_ref, _ = hip_conv(gt_ref, pa, N, H, W, dgrad=True, res1=g, res2=extra)
-    gt, gx = _run_block(g, pa, pb, N, H, W, False, rs, mask=t_ref, extra=extra)
-    assert torch.equal(gt, gt_ref), 'gradient w.r.t. the activation'
-    assert_bf16_close(gx.float(), gx_ref.float(), 'block data gradient', rel=2e-3, amax=2.0 ** -7)
-
-
-@pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (1, 5, 9), (2, 13, 64), (1, 20, 100)])
-def test_conv_block_geometries_agree_bitwise(N, H, W):
-    """one strip across the image (W <= 48), column tiles of 32 and column tiles of 48 columns (col_tile = 2 / 3 forces them at any W)
-    compute every output element with the same MFMA sequence: activation and output are bitwise equal, forward and data gradient, with
-    the ReLU mask as the stored activation and as bytes"""
-    gen = np.random.default_rng(500 + H + W)
-    pa, pb = PackedConv(*_wb(gen, 64, 64)), PackedConv(*_wb(gen, 64, 64))
-    rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
-    x, g, extra = rnd(), rnd(), rnd()
-    res = []
-    for ct in ((0, 2, 3) if W <= 48 else (2, 3)):
-        t, y = (torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(2))
-        mb = torch.full((N, H, W, 8), 0xAA, dtype=torch.uint8, device=DEV)
-        L.call('rumpy_conv_block', L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
-                                               b2=pb.b_packed.data_ptr(), t=t.data_ptr(), out=y.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0,
-                                               scale2=0.1, maskbits=mb.data_ptr(), col_tile=ct), stream())
-        outs = [t, y, mb]
-        for bits in (False, True):
-            dt, dx = (torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(2))
-            L.call('rumpy_conv_block', L.BlockArgs(x=g.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), mask=t.data_ptr(),
-                                                   res2=extra.data_ptr(), t=dt.data_ptr(), out=dx.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=0.1,
-                                                   scale2=1.0, maskbits=mb.data_ptr() if bits else None, col_tile=ct), stream())
-            outs += [dt, dx]
-        torch.cuda.synchronize()
-        assert all(torch.isfinite(o.float()).all() for o in outs if o.dtype == BF16), ct
-        res.append(outs)
-    for other in res[1:]:
-        for i, (a, b) in enumerate(zip(res[0], other)):
-            assert torch.equal(a.view(torch.int16) if a.dtype == BF16 else a, b.view(torch.int16) if b.dtype == BF16 else b), i
-    a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), w2=pb.w_fwd.data_ptr(), out=x.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=1.0, col_tile=4)
-    assert L.lib().rumpy_conv_block(a, None) == -1 and b'col_tile' in L.lib().rumpy_last_error()
-
-
 @pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (8, 48, 48), (2, 13, 64), (1, 20, 100)])
 def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
     """general form of the block kernel (RCAB): no residual + pool partial sums forward; external residual operand backward"""

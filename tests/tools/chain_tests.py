@@ -12,7 +12,8 @@ import pytest
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from gpu_utils import (BF16, DEV, BlockChainArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, exp_call, exp_lib, hip_conv,   # noqa: E402
+import ctypes as C                  # noqa: E402
+from gpu_utils import (BF16, DEV, SPLIT_FORK, SPLIT_JOIN, SPLIT_ONE_STREAM, BlockChainArgs, BlockSplitArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, exp_call, exp_lib, hip_conv,   # noqa: E402
                        stream, to_dev_bytes)
 from rumpy_amd import _lib as L          # noqa: E402
 
@@ -166,3 +167,55 @@ def test_block_chain_rejects_shapes_that_cannot_be_resident():
     assert exp_lib().rumpy_block_chain(a, None) == -1 and b'co-resident' in exp_lib().rumpy_last_error()
 
 
+@pytest.mark.parametrize('N,H,W', [(32, 48, 48), (2, 13, 48), (3, 20, 37), (1, 5, 9), (5, 7, 16), (1, 48, 48)])
+def test_half_strip_block_launches_are_bitwise_the_whole_strip_launches(N, H, W):
+    """rumpy_conv_block_split (tests/tools/csrc/conv_hblock.hip, experimental library): the two ResBlock forms of a training step as half-strip launches of the two halves of the
+    batch - on two streams (fork / join inside the call) and on one - against rumpy_conv_block: OUT, T and the ReLU mask bytes bit for bit,
+    forward and data gradient (mask bytes read, second residual operand)."""
+    gen = np.random.default_rng(300 + H + W + N)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.06, 0.06, (64, 64, 3, 3)).astype(np.float32)),
+                            torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
+    pa, pb = mk(), mk()
+    x = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV, BF16)
+    extra = torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV, BF16)
+    p = lambda z: None if z is None else z.data_ptr()
+
+    def run(fwd, how, bits_in=None):
+        t = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+        out = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+        bits = torch.full((N, H, W, 8), 0xAA, dtype=torch.uint8, device=DEV) if fwd else bits_in
+        if fwd:
+            a = L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                            mask=None, res2=None, t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=0.1, maskbits=bits.data_ptr())
+        else:
+            a = L.BlockArgs(x=x.data_ptr(), w1=pb.w_dgrad.data_ptr(), b1=None, w2=pa.w_dgrad.data_ptr(), b2=None, mask=None, res2=p(extra),
+                            t=p(t), out=out.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=0.1, scale2=1.0, maskbits=bits.data_ptr())
+        if how == 'whole':
+            L.call('rumpy_conv_block', a, stream())
+        else:
+            sa = BlockSplitArgs(block=a, flags={'two': SPLIT_FORK | SPLIT_JOIN, 'one': SPLIT_ONE_STREAM}[how])
+            exp_call('rumpy_conv_block_split', sa, stream())
+        torch.cuda.synchronize()
+        return t, out, bits
+    for fwd in (True, False):
+        bits_in = None
+        if not fwd:
+            bits_in = run(True, 'whole')[2]
+        ref = run(fwd, 'whole', bits_in)
+        for how in ('two', 'one'):
+            got = run(fwd, how, bits_in)
+            for i, (r, g_) in enumerate(zip(ref, got)):
+                assert torch.equal(r.view(torch.int16) if r.dtype == BF16 else r, g_.view(torch.int16) if g_.dtype == BF16 else g_), (fwd, how, i)
+    # a chain of launches between one fork and one join: the two halves only follow their own stream
+    cur_w, cur_s = x.clone(), x.clone()
+    for blk in range(4):
+        nxt_w, nxt_s = torch.empty_like(x), torch.empty_like(x)
+        mkargs = lambda src, dst: L.BlockArgs(x=src.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(),
+                                              mask=None, res2=None, t=None, out=dst.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=0.1)
+        L.call('rumpy_conv_block', mkargs(cur_w, nxt_w), stream())
+        exp_call('rumpy_conv_block_split', BlockSplitArgs(block=mkargs(cur_s, nxt_s), flags=(SPLIT_FORK if blk == 0 else 0) | (SPLIT_JOIN if blk == 3 else 0)), stream())
+        cur_w, cur_s = nxt_w, nxt_s
+    torch.cuda.synchronize()
+    assert torch.equal(cur_w.view(torch.int16), cur_s.view(torch.int16))
+    bad = BlockSplitArgs(block=L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), w2=pb.w_fwd.data_ptr(), out=x.data_ptr(), N=1, H=8, W=64, relu1=1, scale1=1.0, scale2=1.0), flags=0)
+    assert exp_lib().rumpy_conv_block_split(C.byref(bad), None) == -1 and b'W <= 48' in exp_lib().rumpy_last_error()

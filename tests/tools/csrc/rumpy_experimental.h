@@ -77,6 +77,24 @@ typedef struct {
 int rumpy_body_chain(const rumpy_body_chain_args* a, void* stream);
 int64_t rumpy_body_chain_flag_bytes(int32_t N, int32_t H);
 
+/* ---- round 3: half-strip residual-block launches, two chains side by side (conv_hblock.hip; measured NOT to pay) ----
+ * The two ResBlock forms of a training step (forward: relu1, scale1 = 1, maskbits written; data gradient: !relu1, maskbits read; bf16,
+ * W <= 48) as HALF-strip launches (3 output rows per 256-thread workgroup, 76.8 KB of LDS: two workgroups per CU; csrc/conv_hblock.hip):
+ * images [0, ceil(N/2)) on `stream`, the rest on the device's second stream - two launch chains whose boundaries, tile loads and
+ * epilogues run under each other's MFMA sweeps.  Results are bitwise rumpy_conv_block's.  A run of consecutive split launches is opened
+ * by RUMPY_SPLIT_FORK on its first launch (the second stream waits for everything queued on `stream` so far) and closed by
+ * RUMPY_SPLIT_JOIN on its last (`stream` waits for the second stream); every launch between the two must be a split launch on the same
+ * `stream`.  RUMPY_SPLIT_ONE_STREAM: both halves on `stream` (A/B, tests). */
+#define RUMPY_SPLIT_FORK 1
+#define RUMPY_SPLIT_JOIN 2
+#define RUMPY_SPLIT_ONE_STREAM 4
+typedef struct {
+  rumpy_block_args block;
+  int32_t flags;
+  int32_t pad_;
+} rumpy_block_split_args;
+int rumpy_conv_block_split(const rumpy_block_split_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

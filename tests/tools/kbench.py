@@ -8,7 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from gpu_utils import BF16, DEV, BlockChainArgs, ChainArgs, ChainLayer, PackedConv, exp_call, exp_lib, hip_wgrad, stream, to_dev_bytes  # noqa: E402
+from gpu_utils import BF16, DEV, SPLIT_FORK, SPLIT_JOIN, SPLIT_ONE_STREAM, BlockChainArgs, BlockSplitArgs, ChainArgs, ChainLayer, PackedConv, exp_call, exp_lib, hip_wgrad, stream, to_dev_bytes  # noqa: E402
 from rumpy_amd import _lib as L  # noqa: E402
 
 
@@ -212,11 +212,45 @@ def block_bench(N=32, H=48, W=48, nblocks=16):
             a2 = L.ConvArgs(x=ts[b].data_ptr(), w=pb.w_fwd.data_ptr(), bias=pb.b_packed.data_ptr(), out=bufs[b + 1].data_ptr(),
                             res1=bufs[b].data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1, relu=0, scale=0.1, grid_x=0)
             L.call('rumpy_conv3x3', a2, stream())
+    bits = torch.zeros(N, H, W, 8, dtype=torch.uint8, device=DEV)
+
+    def split(one_stream=False):
+        # half-strip launches of the two batch halves (conv_hblock.hip): two chains between one fork and one join
+        for b, (pa, pb) in enumerate(pcs):
+            a = L.BlockArgs(x=bufs[b].data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
+                            b2=pb.b_packed.data_ptr(), t=ts[b].data_ptr(), out=bufs[b + 1].data_ptr(), N=N, H=H, W=W, relu1=1,
+                            scale1=1.0, scale2=0.1, maskbits=bits.data_ptr())
+            fl = SPLIT_ONE_STREAM if one_stream else ((SPLIT_FORK if b == 0 else 0) | (SPLIT_JOIN if b == nblocks - 1 else 0))
+            exp_call('rumpy_conv_block_split', BlockSplitArgs(block=a, flags=fl), stream())
     for _ in range(2):
         us_f = time_fn(fused, iters=20)
         us_s = time_fn(separate, iters=20) if not os.environ.get('KBENCH_FUSED_ONLY') else 0.0
         print('%d residual blocks %dx%dx%d: one launch per block %8.1f us = %6.2f us/block ; two launches per block %8.1f us = %6.2f us/block'
               % (nblocks, N, H, W, us_f, us_f / nblocks, us_s, us_s / nblocks))
+        if W <= 48:
+            us_2 = time_fn(split, iters=20)
+            us_1 = time_fn(lambda: split(True), iters=20)
+            print('   half-strip launches of the two batch halves: on two streams %8.1f us = %6.2f us/block ; on one stream %8.1f us = %6.2f us/block'
+                  % (us_2, us_2 / nblocks, us_1, us_1 / nblocks))
+    if W <= 48:
+        # the same chains replayed from captured graphs: no host time between the launches
+        def graphed(fn):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            return g
+        gf, gs = graphed(fused), graphed(split)
+        for _ in range(2):
+            us_f = time_fn(gf.replay, iters=20)
+            us_2 = time_fn(gs.replay, iters=20)
+            print('   graph replays: one launch per block %8.1f us = %6.2f us/block ; half-strip launches on two streams %8.1f us = %6.2f us/block'
+                  % (us_f, us_f / nblocks, us_2, us_2 / nblocks))
     if 'BLOCK_ABL_9' in os.environ.get('RUMPY_AMD_LIB', ''):      # in-kernel phase stamps (100 MHz), written over the first bytes of t
         fused()
         torch.cuda.synchronize()
