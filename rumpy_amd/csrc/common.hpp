@@ -96,6 +96,48 @@ __device__ __forceinline__ int xcd_strip(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
 }
 
+// A pointer that a kernel reads from device memory (the x_ind / target_ind tables of rumpy_set_pointers) is a GENERIC pointer to the compiler:
+// every load through it becomes a flat_load, which counts on both wait counters and is unordered, so the counted s_waitcnt vmcnt(N) of the
+// surrounding code degrade to full drains (tail_fwd_kernel: +5 us per launch, round 3).  Read as a global-address-space pointer, the loads
+// stay global_load.
+typedef const float __attribute__((address_space(1)))* rumpy_global_cfloat;
+__device__ __forceinline__ const float* load_global_ptr(const float* const* slot) {
+  const unsigned long long v = *reinterpret_cast<const unsigned long long*>(slot);
+  return (const float*)reinterpret_cast<rumpy_global_cfloat>(v);
+}
+
+// ---- cross-lane sums without the LDS crossbar ----
+// __shfl_xor is ds_bpermute_b32: an LDS-latency operation per stage, five or six dependent ones per sum.  The same butterflies on the VALU
+// (round 3): xor 1 / 2 = DPP quad permutes, xor 4 / 8 = DPP row_half_mirror / row_mirror (lane i <-> 7 - i / 15 - i: after the previous stages
+// all lanes of a quad / of an 8-lane half hold the same value, so the mirrored partner carries what the xor partner carries), xor 16 / 32 =
+// v_permlane16_swap / v_permlane32_swap (gfx950).  Every add has the operands of the shuffle version (in either order): same bits -
+// tests/tools/overlap/dpp_check.hip compares them on the GPU.
+__device__ __forceinline__ float dpp_quad1(float v) { const int i = __float_as_int(v); return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, false)); }
+__device__ __forceinline__ float dpp_quad2(float v) { const int i = __float_as_int(v); return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x4E, 0xF, 0xF, false)); }
+__device__ __forceinline__ float dpp_half_mirror(float v) { const int i = __float_as_int(v); return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x141, 0xF, 0xF, false)); }
+__device__ __forceinline__ float dpp_row_mirror(float v) { const int i = __float_as_int(v); return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x140, 0xF, 0xF, false)); }
+// sum over the 16 lanes of a row (the 16 pixels of an MFMA tile), in every lane: the xor 1, 2, 4, 8 butterfly
+__device__ __forceinline__ float row16_sum(float t) {
+  t += dpp_quad1(t); t += dpp_quad2(t); t += dpp_half_mirror(t); t += dpp_row_mirror(t);
+  return t;
+}
+// the value of lane ^ 16 (g = lane >> 4)
+__device__ __forceinline__ float lane_xor16(float t, int g) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return __uint_as_float((g & 1) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float t, int lane) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return __uint_as_float((lane & 32) ? r[0] : r[1]);
+}
+// sum over the wave, in every lane (the xor 1 .. 32 butterfly)
+__device__ __forceinline__ float wave64_sum(float t, int lane) {
+  t = row16_sum(t);
+  t += lane_xor16(t, lane >> 4);
+  t += lane_xor32(t, lane);
+  return t;
+}
+
 struct TileCoord { int n, ty, tx; };
 __device__ __forceinline__ TileCoord decode_tile(int tile, int tiles_x, int tiles_y) {
   TileCoord t;

@@ -374,16 +374,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       // reduce over the 16 pixel lanes, fold the odd-g lanes into the even ones, add the single tile's 4+4 channels
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float t = ps8[j];
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        t += __shfl_xor(t, 16);
+        float t = row16_sum(ps8[j]);                    // (common.hpp: the butterflies on the VALU, same bits)
+        t += lane_xor16(t, g);
         ps8[j] = t;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float t = ps[j];
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        const float up = __shfl_xor(t, 16);             // the same sums of lane group g ^ 1
+        const float t = row16_sum(ps[j]);
+        const float up = lane_xor16(t, g);              // the same sums of lane group g ^ 1
         ps8[j] += (g & 1) ? up : t;
         ps8[4 + j] += (g & 1) ? t : up;
       }

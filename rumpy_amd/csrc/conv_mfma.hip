@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px = lane & 15, g = lane >> 4;
   const int ntiles = a.N * a.tiles_y * a.tiles_x;
-  const float* const target = a.target_ind ? *a.target_ind : a.target;      // the batch of this replay (rumpy_set_pointers)
+  const float* const target = a.target_ind ? load_global_ptr(a.target_ind) : a.target;      // the batch of this replay (rumpy_set_pointers)
   // forward filter: stationary in 72 VGPRs (round 2: in the WGRAD form too - its weight-gradient accumulators shrank from 36 to 12 registers;
   // the filter used to sit in 18 KB of LDS there, one more fragment read per MFMA)
   bf16x8 F[18];

@@ -43,10 +43,7 @@ struct RcabDev {
   unsigned char* mbits;      // ReLU mask of t1 as one byte per 8 channels (block_common.hpp::relu_bits): forward writes, backward reads
 };
 
-__device__ __forceinline__ float wave_sum(float t) {
-  t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8); t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);
-  return t;
-}
+__device__ __forceinline__ float wave_sum(float t) { return wave64_sum(t, (int)(threadIdx.x & 63)); }   // common.hpp: on the VALU, same bits as six __shfl_xor stages
 
 // all-gather of one fp32 per (strip, channel) among the strips of image n; returns (threads < 64: channel tid) the sum over strips
 // in strip order.  sx: LDS scratch of 8 * 64 floats.  Called by all 512 threads.
@@ -254,10 +251,22 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const float gq = svec[2 * 64 + c];
       const float dz = (ds * gq) * s * (1.f - s);
       float dp = 0.f;
-      for (int r = 0; r < a.cr; ++r) {
-        float dh = wave_sum(sw2t[r * 64 + c] * dz);
-        dh = (svec[32 + r] > 0.f) ? dh : 0.f;
-        dp = fmaf(sw1[r * 64 + c], dh, dp);
+      for (int r0 = 0; r0 < a.cr; r0 += 4) {          // four hidden units per round, as in the forward launch
+        float dhs[4], w1[4], hid[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = (r0 + i < a.cr) ? r0 + i : r0;
+          dhs[i] = sw2t[r * 64 + c] * dz; w1[i] = sw1[r * 64 + c]; hid[i] = svec[32 + r];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dhs[i] = wave_sum(dhs[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (r0 + i < a.cr) {
+            const float dh = (hid[i] > 0.f) ? dhs[i] : 0.f;
+            dp = fmaf(w1[i], dh, dp);
+          }
+        }
       }
       sgate[c] = s * gq;
       sdp[c] = dp * a.inv_hw;
@@ -499,16 +508,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float t = ps8[j];
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        t += __shfl_xor(t, 16);
+        float t = row16_sum(ps8[j]);
+        t += lane_xor16(t, g);
         ps8[j] = t;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float t = ps[j];
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        const float up = __shfl_xor(t, 16);
+        const float t = row16_sum(ps[j]);
+        const float up = lane_xor16(t, g);
         ps8[j] += (g & 1) ? up : t;
         ps8[4 + j] += (g & 1) ? t : up;
       }
@@ -541,16 +548,30 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         const int c = tid;
         const float mean = tot * a.inv_hw;
         float z = svec[64 + c];
-        for (int r = 0; r < a.cr; ++r) {
-          const float h = fmaxf(wave_sum(sw1[r * 64 + c] * mean) + svec[r], 0.f);
-          z = fmaf(sw2t[r * 64 + c], h, z);
-          if (si == 0 && c == 0) a.hidden[n * a.cr + r] = h;
+        for (int r0 = 0; r0 < a.cr; r0 += 4) {        // four hidden units per round (cr = 4 for the reference's reduction 16): their LDS operands are
+          float hs[4], w2[4], b1[4];                    // requested together and their four wave sums are independent instruction chains
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = (r0 + i < a.cr) ? r0 + i : r0;
+            hs[i] = sw1[r * 64 + c] * mean; w2[i] = sw2t[r * 64 + c]; b1[i] = svec[r];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) hs[i] = wave_sum(hs[i]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (r0 + i < a.cr) {
+              const float h = fmaxf(hs[i] + b1[i], 0.f);
+              z = fmaf(w2[i], h, z);
+              if (si == 0 && c == 0) a.hidden[n * a.cr + r0 + i] = h;
+            }
+          }
         }
         const float gt = 1.f / (1.f + expf(-z));
         sgate[c] = gt * svec[2 * 64 + c];
         if (si == 0) { a.mean[n * 64 + c] = mean; a.gate[n * 64 + c] = gt; }
       }
       __syncthreads();
+      RC_STAMP();                          // (fwd) gate ready
       if (a.t2) {
 #pragma unroll
         for (int i = 0; i < G::SREGS; ++i)
@@ -590,6 +611,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (soffg[i] != 0xffffffffu) st16_nt(a.out + soffg[i], S[i]);
   } else {
     __syncthreads();
+    RC_STAMP();                            // (fwd) OUT image complete
     strip_stage<2, G>(S, ldx, tid);
 #pragma unroll
     for (int i = 0; i < G::SREGS; ++i)

@@ -14,7 +14,7 @@ template <int C, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float* x, const float* const* x_ind, const float* __restrict__ w,
                                                        const float* __restrict__ b, uint16_t* __restrict__ out,
                                                        int N, int H, int W, int cout, float slope_m1) {
-  if (x_ind) x = *x_ind;          // the batch of this replay (rumpy_set_pointers)
+  if (x_ind) x = load_global_ptr(x_ind);          // the batch of this replay (rumpy_set_pointers)
   __shared__ __attribute__((aligned(16))) float sw[9 * HEAD_MAXC * 64];
   __shared__ float sb[64];
   const int ct = blockIdx.y;
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float*
 // fixed order; slab per workgroup: [cout_tiles][64][9*C + 1] (last column = bias sum).
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* x, const float* const* x_ind, const uint16_t* __restrict__ dy,
                                                          float* __restrict__ slab, int N, int C, int H, int W, int cout) {
-  if (x_ind) x = *x_ind;
+  if (x_ind) x = load_global_ptr(x_ind);
   __shared__ float sx[HEAD_MAXC * HALO_PIX];
   __shared__ __attribute__((aligned(16))) uint16_t sdy[TH * TW * 64];
   __shared__ float red[4 * 64 * (9 * HEAD_MAXC + 1)];
@@ -162,7 +162,7 @@ __device__ __forceinline__ bf16x8 head_tr_pair(const unsigned char* p) {
 }
 __global__ void __launch_bounds__(256) head_wgrad_mfma_kernel(const float* x, const float* const* x_ind, const uint16_t* __restrict__ dy,
                                                               float* __restrict__ slab, int N, int C, int H, int W, int cout) {
-  if (x_ind) x = *x_ind;
+  if (x_ind) x = load_global_ptr(x_ind);
   __shared__ float sx[HEAD_MAXC * HALO_PIX];
   __shared__ __attribute__((aligned(16))) unsigned char sdy[TH * TW * PIX_STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C                  # noqa: E402
-from gpu_utils import (BF16, DEV, SPLIT_FORK, SPLIT_JOIN, SPLIT_ONE_STREAM, BlockChainArgs, BlockSplitArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, exp_call, exp_lib, hip_conv,   # noqa: E402
+from gpu_utils import (BF16, DEV, SPLIT_FORK, SPLIT_JOIN, SPLIT_ONE_STREAM, BlockChainArgs, BlockSplitArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, exp_call, exp_lib, hip_conv, nhwc,   # noqa: E402
                        stream, to_dev_bytes)
 from rumpy_amd import _lib as L          # noqa: E402
 
