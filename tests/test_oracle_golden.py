@@ -656,3 +656,32 @@ def test_g22_wide_and_x3_oracle_matches_reference_handler(golden_dir, tag, name,
     xe, ye = O.synthetic_batch(3020, 1, lr_hw=(10, 14), scale=kw['scale'])
     ev, evl, _ = h.run_eval(xe, ye, request_loss=True)
     assert np.allclose(ev.numpy()[:, :, ::3, ::3], g[tag + '.eval_out'], atol=1e-6) and abs(float(evl) - float(g[tag + '.eval_loss'])) < 1e-6
+
+
+def _g23_tile_function(scale):
+    """the stand-in per-tile 'network' of tests/golden/make_golden_chop.py: every pixel repeated scale x scale times + a position term"""
+    def run(chunk):
+        up = chunk.repeat_interleave(scale, dim=2).repeat_interleave(scale, dim=3)
+        h, w = up.shape[2], up.shape[3]
+        pos = (torch.arange(h, dtype=torch.float32).view(1, 1, h, 1) * 0.001953125 + torch.arange(w, dtype=torch.float32).view(1, 1, 1, w) * 0.00048828125)
+        return up + pos
+    return run
+
+
+@pytest.mark.parametrize('tag', ['recursive', 'flat', 'x4'])
+def test_g23_forward_chop_oracle_and_handler_code_match_the_reference_method(golden_dir, tag):
+    """G23 = the REAL ContrastiveBlindQEDSRHandler.forward_chop (blur_kernel_blind_sr/handlers.py:907-945) run on a stand-in object around a
+    fixed per-tile function (tests/golden/make_golden_chop.py): the oracle's restatement AND the stitching code the HIP handlers run
+    (`_TiledEval.forward_chop`, pure torch, called here on a stand-in as well) reproduce it exactly - tiles, overlap, recursion threshold."""
+    import types
+    from rumpy_amd.SISR.models.advanced.handlers import _TiledEval
+    g = np.load(os.path.join(golden_dir, 'g23_forward_chop.npz'))
+    x, ref = torch.from_numpy(g[tag + '_x']), torch.from_numpy(g[tag + '_out'])
+    scale, limit = (int(v) for v in g[tag + '_meta'])
+    run = _g23_tile_function(scale)
+    assert torch.equal(O.forward_chop(run, x, scale, limit), ref)
+    stub = types.SimpleNamespace(max_combined_im_size=limit, scale=scale, run_chopped_eval=lambda c: run(c))
+    stub.forward_chop = types.MethodType(_TiledEval.forward_chop, stub)
+    assert torch.equal(stub.forward_chop(x), ref)
+    assert not torch.equal(run(x), ref)                      # the tiles' own positions show: it is not the whole-image result
+
