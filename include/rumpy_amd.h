@@ -68,6 +68,10 @@ typedef struct {
   float scale;
   int32_t grid_x;       /* persistent workgroups per cout tile; 0 = library default */
   int32_t fmt;          /* RUMPY_FMT_*: format of x, w, out, res1, res2 (F16: cin_chunks 1, no mask) */
+  const void* w_lo;     /* NULL, or (fmt F16, Cin = 64 forward launches that conv_up.hip takes: the upsampler convs of an evaluation plan) the
+                           filter's rounding-residual image (rumpy_pack_weights fmt RUMPY_FMT_F16_RESIDUAL): out = epilogue(conv(x, w_lo) +
+                           conv(x, w)), both sums in the same fp32 accumulators - one launch and one pass over x instead of a residual launch
+                           into a scratch tensor that the main launch reads back (round 3) */
 } rumpy_conv_args;
 int rumpy_conv3x3(const rumpy_conv_args* a, void* stream);
 /* number of per-image pool partial rows ("tiles") rumpy_conv3x3 writes for an H x W image */

@@ -32,7 +32,7 @@ class ConvArgs(_S):
                 ('res1', c_void_p), ('res2', c_void_p), ('pool', c_void_p),
                 ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cin_chunks', c_int32), ('cout_tiles', c_int32),
                 ('in_mode', c_int32), ('out_mode', c_int32), ('relu', c_int32), ('scale', c_float),
-                ('grid_x', c_int32), ('fmt', c_int32)]
+                ('grid_x', c_int32), ('fmt', c_int32), ('w_lo', c_void_p)]
 
 
 class HeadFwdArgs(_S):

@@ -505,13 +505,17 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     const int up_strips = p->N * cdiv(p->H, 6) * cdiv(p->W, 48);
     const char* up_force = getenv("RUMPY_UP_FORCE");                    // diagnostic (kbench.py up1): "1" = every eligible launch, "0" = multi-tile ones only
     const bool up_many = up_force ? up_force[0] == '1' : up_strips > rumpy_device_cus();
-    if (shuffled_res || (!up_old && p->cin_chunks == 1 && (p->cout_tiles > 1 || up_many) && p->in_mode == 0 && !p->mask && !p->pool && (p->out_mode == 0 || (!p->res1 && !p->res2))))
+    const bool up_ok = p->cin_chunks == 1 && p->in_mode == 0 && !p->mask && !p->pool && (p->out_mode == 0 || (!p->res1 && !p->res2));
+    if (p->w_lo && !(p->fmt == RUMPY_FMT_F16 && (shuffled_res || up_ok))) {
+      rumpy_set_error("rumpy_conv3x3: w_lo goes with fmt F16 and a Cin = 64 forward launch without mask / pool (conv_up.hip)"); return RUMPY_E_ARG; }
+    if (shuffled_res || p->w_lo || (!up_old && (p->cout_tiles > 1 || up_many) && up_ok))
       rumpy_conv_up_launch(p, s1);
     else
     rumpy_conv3x3_strip_launch(p, s1);
     rumpy_probe_post(kid1, s1);
     return rumpy_check_launch("rumpy_conv3x3");
   }
+  if (p->w_lo) { rumpy_set_error("rumpy_conv3x3: w_lo goes with cin_chunks 1"); return RUMPY_E_ARG; }
   ConvDev d;
   d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = (uint16_t*)p->out;
   d.mask = (const uint16_t*)p->mask; d.res1 = (const uint16_t*)p->res1; d.res2 = (const uint16_t*)p->res2; d.pool = p->pool;

@@ -11,7 +11,7 @@
 #define UP_ABL 0      // 9: phase stamps of one iteration per wave behind the 256 bias values (diagnostic builds: tests/tools/build_abl.sh, kbench.py up)
 #endif
 struct UpDev {
-  const uint16_t* x; const uint4* w; const float* bias; uint16_t* out;
+  const uint16_t* x; const uint4* w; const uint4* w_lo; const float* bias; uint16_t* out;      // w_lo: NULL, or the filter's rounding-residual image (fp16 evaluation plans)
   const uint16_t* res1; const uint16_t* res2;      // optional residual operands, layout of out (out_mode 0)
   int N, H, W, cout_tiles, out_mode, sx_n, sy_n, relu; float scale;
 };
@@ -70,7 +70,8 @@ __device__ __forceinline__ unsigned up_group_off(int i, int tg, int rh, UpCoord 
   return (unsigned)(((c.n * 2 * a.H + 2 * y + (ct >> 1)) * (2 * a.W) + 2 * xx + (ct & 1)) * 64 + (p & 7) * 8);
 }
 
-template <int FMT>
+// TWO: two filter images per launch (a.w_lo: fp16 evaluation plans; its own instantiation - the training kernel's registers stay as they were)
+template <int FMT, bool TWO = false>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * UPSTAGE + UPOUT];
   unsigned char* const ldo = lds + 2 * UPSTAGE;
@@ -84,11 +85,17 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
   uint4 R[UPREGS];
   up_issue(R, a.x, up_decode(strip, a.sx_n, a.sy_n), a.H, a.W, tid);
   bf16x8 F[18];
-  {
-    const uint4* wp = a.w + ((size_t)(ct * 4 + q) * 18) * 64 + lane;
+  // Two filter images per launch (a.w_lo, round 3): every strip is swept with the rounding-residual image first and with the filter
+  // second, into the same fp32 accumulators - the slice in the registers is swapped twice per strip (18 L2 hits per wave, requested right
+  // behind the sweep that read the old slice: they land under the partner wave's MFMAs / this wave's epilogue).
+  constexpr bool two = TWO;
+  auto fetch_filter = [&](const uint4* img) {
+    asm volatile("" : "+s"(img));         // opaque: the two images are re-read every strip ON PURPOSE (hoisted out of the loop they would need 144 registers)
+    const uint4* wp = img + ((size_t)(ct * 4 + q) * 18) * 64 + lane;
 #pragma unroll
     for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
-  }
+  };
+  fetch_filter(two ? a.w_lo : a.w);
   const int c0 = 16 * q + 4 * g;
   const int gpair = 4 * (g & ~1);
   const int chunk8 = 2 * q + (gpair >> 3);
@@ -136,6 +143,15 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
     if (k > 1) gate_wait(&gate[0], 8u * (k - 1));          // (the first stage is behind the workgroup barrier)
     UP_STAMP();                                            // 1: input stage complete
     block_sweep<3, FMT>(acc, F, lds, off);
+    if (two) {
+      __builtin_amdgcn_sched_barrier(0);                   // (the new slice goes INTO the registers of the old one: not hoisted above the sweep's last reads)
+      fetch_filter(a.w);                                   // residual image done: the filter itself, same accumulators
+      __builtin_amdgcn_sched_barrier(0);
+      block_sweep<3, FMT>(acc, F, lds, off);
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) fetch_filter(a.w_lo);                  // for the next strip: lands under the epilogue below
+      __builtin_amdgcn_sched_barrier(0);
+    }
     UP_STAMP();                                            // 2: sweep done
     gate_arrive(&gate[1], lane);
     if (has_next) {
@@ -234,7 +250,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
 
 int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s) {
   UpDev d;
-  d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.bias = p->bias; d.out = (uint16_t*)p->out;
+  d.x = (const uint16_t*)p->x; d.w = (const uint4*)p->w; d.w_lo = (const uint4*)p->w_lo; d.bias = p->bias; d.out = (uint16_t*)p->out;
   d.res1 = (const uint16_t*)p->res1; d.res2 = (const uint16_t*)p->res2; d.relu = p->relu; d.scale = p->scale;
   d.N = p->N; d.H = p->H; d.W = p->W; d.cout_tiles = p->cout_tiles; d.out_mode = p->out_mode;
   d.sx_n = (p->W + BSW - 1) / BSW; d.sy_n = (p->H + BSH - 1) / BSH;
@@ -246,7 +262,8 @@ int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s) {
     gx = (nstrips + rounds - 1) / rounds;
   }
   if (gx > nstrips) gx = nstrips;
-  if (p->fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(conv_up_kernel<RUMPY_FMT_F16>, dim3(gx, p->cout_tiles), dim3(BTHREADS), 0, s, d);
+  if (p->fmt == RUMPY_FMT_F16 && p->w_lo) hipLaunchKernelGGL((conv_up_kernel<RUMPY_FMT_F16, true>), dim3(gx, p->cout_tiles), dim3(BTHREADS), 0, s, d);
+  else if (p->fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(conv_up_kernel<RUMPY_FMT_F16>, dim3(gx, p->cout_tiles), dim3(BTHREADS), 0, s, d);
   else hipLaunchKernelGGL(conv_up_kernel<RUMPY_FMT_BF16>, dim3(gx, p->cout_tiles), dim3(BTHREADS), 0, s, d);
   return 0;
 }

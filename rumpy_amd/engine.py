@@ -166,6 +166,7 @@ class SREngine:
         self.generic_up = self.wide or any(cv.cout != 4 * cv.cin for cv in spec.ups)
         # fp16 evaluation plans of the 64-feature nets: upsampler filters as image + rounding-residual image too (two conv launches per stage)
         self.eval_up_residual = os.environ.get('RUMPY_EVAL_UP_RESIDUAL', '1') == '1'
+        self.eval_up_fused = os.environ.get('RUMPY_EVAL_UP_FUSED', '1') == '1'      # ... in ONE launch per stage (conv_up.hip sweeps both images); =0: A/B, two launches
         # evaluation status words (non-finite output, strip-exchange watchdog): read back synchronously after every pass, or - eval_defer,
         # set by run_eval(keep_on_device=True) around its pass - staged into pinned memory and examined at the next pass / check_eval()
         self.eval_defer = False
@@ -308,14 +309,14 @@ class SREngine:
         return t
 
     def _conv(self, ops, x, cv, N, H, W, out, dgrad=False, relu=False, scale=1.0, mask=None, res1=None, res2=None,
-              pool=None, in_mode=0, out_mode=0, bias=True, fmt=0):
+              pool=None, in_mode=0, out_mode=0, bias=True, fmt=0, w_lo=None):
         if dgrad:
             w, cin_chunks, cout_tiles, b = cv.w_dgrad, cv.cout // 64, cv.cin // 64, None
         else:
             w, cin_chunks, cout_tiles, b = (cv.w_fwd_h if fmt else cv.w_fwd), cv.cin // 64, cv.cout // 64, (cv.b_packed if bias else None)
         a = L.ConvArgs(x=_ptr(x), w=_ptr(w), bias=_ptr(b), out=_ptr(out), mask=_ptr(mask), res1=_ptr(res1), res2=_ptr(res2),
                        pool=_ptr(pool), N=N, H=H, W=W, cin_chunks=cin_chunks, cout_tiles=cout_tiles, in_mode=in_mode,
-                       out_mode=out_mode, relu=1 if relu else 0, scale=float(scale), grid_x=0, fmt=fmt)
+                       out_mode=out_mode, relu=1 if relu else 0, scale=float(scale), grid_x=0, fmt=fmt, w_lo=_ptr(w_lo))
         ops.append(('rumpy_conv3x3', a))
 
     def _build(self, N, H, W, train, fmt=0):
@@ -547,8 +548,13 @@ class SREngine:
                 else:
                     self._conv(fwd, u, cv, N, h, w, pre, fmt=fmt)
                 fwd.append(('rumpy_pixel_shuffle', L.PixelShuffleArgs(src=_ptr(pre), dst=_ptr(nxt), N=N, H=h, W=w, F=F, r=rr, inverse=0)))
+            elif fmt and self.eval_up_residual and self.eval_up_fused:
+                # 64 features, fp16 evaluation plan (round 3): ONE launch sweeps every strip with the filter's rounding-residual image and then
+                # with the fp16 filter into the same fp32 accumulators (conv_up.hip, w_lo) - no residual launch, no scratch tensor written and
+                # read back (4 x the stage's input), one pass over the input; the sum is rounded once, as before
+                self._conv(fwd, u, cv, N, h, w, nxt, out_mode=1, fmt=fmt, w_lo=cv.w_fwd_h_lo)
             elif fmt and self.eval_up_residual:
-                # 64 features, fp16 evaluation plan: the same two launches with the PixelShuffle fused into the second one's store - the
+                # RUMPY_EVAL_UP_FUSED=0 (A/B; round 2): the same as two launches with the PixelShuffle fused into the second one's store - the
                 # residual's conv leaves its (small) result in conv-output order (channel tile = sub-pixel position, as the packed image has
                 # it), the main conv reads it as its residual operand at that very index and adds it in fp32 before the one rounding
                 pre = self._new(plan, N, h, w, cv.cout)

@@ -144,6 +144,59 @@ def test_fp16_upsampler_conv_pixel_shuffle_and_head_and_tail():
     assert L.lib().rumpy_tail_fwd(a, None) == -1 and b'fmt' in L.lib().rumpy_last_error()
 
 
+@pytest.mark.parametrize('N,H,W,shuffle', [(2, 9, 14, True), (1, 20, 37, True), (3, 13, 60, True), (1, 7, 50, False)])
+def test_fp16_upsampler_conv_with_both_filter_images_in_one_launch(N, H, W, shuffle):
+    """rumpy_conv_args.w_lo (round 3): an upsampler stage of an evaluation plan sweeps the filter's rounding-residual image and the fp16 filter in
+    ONE launch, same fp32 accumulators.  The result is the conv with the UNROUNDED filter rounded once to fp16 (checked against float64), is at
+    least as close to it as round 2's two launches through a scratch tensor (residual launch, then main launch with res1), and differs visibly
+    from the conv with the fp16-rounded filter alone."""
+    gen = np.random.default_rng(40 + H + W)
+    w, b = _wb(gen, 256, 64)
+    x = torch.from_numpy(gen.standard_normal((N, 64, H, W)).astype(np.float32))
+    xd = nhwc16(x)
+    pc = Packed16(w, b, 0, shuffle)
+    lo = torch.zeros(256 * 64 * 9, dtype=F16, device=DEV)
+    it = L.PackItem(w=pc.w.data_ptr(), b=pc.b.data_ptr(), w_fwd=lo.data_ptr(), w_dgrad=None, b_packed=None, cout=256, cin=64, kind=0,
+                    shuffle=1 if shuffle else 0, fmt=L.FMT_F16_RESIDUAL)
+    items = to_dev_bytes((L.PackItem * 1)(it))
+    L.check(L.lib().rumpy_pack_weights(items.data_ptr(), 1, stream()), 'pack residual image')
+    om = 1 if shuffle else 0
+    shape = (N, 2 * H, 2 * W, 64) if shuffle else (N, H, W, 256)
+
+    def launch(**kw):
+        out = torch.full(shape, float('nan'), dtype=F16, device=DEV)
+        a = L.ConvArgs(x=xd.data_ptr(), w=pc.w_fwd.data_ptr(), bias=pc.b_packed.data_ptr(), out=out.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=4,
+                       out_mode=om, relu=0, scale=1.0, grid_x=0, fmt=L.FMT_F16)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        L.call('rumpy_conv3x3', a, stream())
+        torch.cuda.synchronize()
+        return out
+    one = launch(w_lo=lo.data_ptr())
+    if shuffle:
+        sc = torch.full((N, H, W, 256), float('nan'), dtype=F16, device=DEV)
+        a = L.ConvArgs(x=xd.data_ptr(), w=lo.data_ptr(), bias=None, out=sc.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=4, out_mode=0, relu=0,
+                       scale=1.0, grid_x=0, fmt=L.FMT_F16)
+        L.call('rumpy_conv3x3', a, stream())
+        two = launch(res1=sc.data_ptr())
+    plain = launch()
+    ref = F.conv2d(f16r(x).double(), w.double(), b.double(), padding=1)
+    ref = F.pixel_shuffle(ref, 2) if shuffle else ref
+    got = lambda t: (nchw(t) if shuffle else nchw(t)).double()
+    e_one, e_plain = rel_err(got(one), ref), rel_err(got(plain), ref)
+    e_round = rel_err(ref.to(F16).double(), ref)                # what ONE fp16 rounding of the exact result costs
+    print('one launch %.3e, fp16 filter alone %.3e, rounding of the exact result %.3e' % (e_one, e_plain, e_round))
+    assert e_one < 1.05 * e_round, (e_one, e_round)
+    assert e_plain > 1.3 * e_one                                # the fp16-rounded filter alone is visibly further away
+    if shuffle:
+        e_two = rel_err(got(two), ref)
+        assert e_one <= e_two * 1.02, (e_one, e_two)
+        assert rel_err(got(one), got(two)) < 1.5e-4
+    bad = L.ConvArgs(x=xd.data_ptr(), w=pc.w_fwd.data_ptr(), bias=None, out=one.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=4, out_mode=om,
+                     relu=0, scale=1.0, grid_x=0, fmt=L.FMT_BF16, w_lo=lo.data_ptr())
+    assert L.lib().rumpy_conv3x3(bad, None) == -1 and b'w_lo' in L.lib().rumpy_last_error()
+
+
 @pytest.mark.parametrize('N,H,W', [(1, 6, 16), (2, 13, 48), (3, 20, 37)])
 def test_fp16_residual_block_and_rcab_launches(N, H, W):
     gen = np.random.default_rng(100 + H + W)
