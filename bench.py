@@ -198,8 +198,10 @@ def bench_eval(args):
     def build(up_residual):
         os.environ['RUMPY_EVAL_UP_RESIDUAL'] = '1' if up_residual else '0'
         torch.manual_seed(8)
-        return define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, checkpoint_load=False, loss_masking=False,
-                            scale=4, **extra)
+        h = define_model(name, model_save_dir=tempfile.mkdtemp(), device=0, eval_mode=True, checkpoint_load=False, loss_masking=False,
+                         scale=4, **extra)
+        h.defer_eval_status = True        # this loop keeps every image on the device and examines the status words itself (check_eval below)
+        return h
 
     def run(h, steps, warmup):
         for i in range(warmup):
@@ -225,6 +227,7 @@ def bench_eval(args):
         for i in range(5):
             h.run_eval(x=pool[i % 4], keep_on_device=True)
         torch.cuda.synchronize(dev)
+        eng.check_eval()
         tot = ctypes.c_double(0.0)
         n_launch = lib.rumpy_probe_end(ctypes.byref(tot))
         if n_launch > 0:
@@ -240,10 +243,12 @@ def bench_eval(args):
                         'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}
     h1 = build(False)
     sec1, _ = run(h1, steps, warmup)
+    h1.net.engine.check_eval()
     os.environ.pop('RUMPY_EVAL_UP_RESIDUAL', None)
     os.environ['RUMPY_BLOCK_W48'] = '1'              # A/B: two launches per block on images wider than one strip (the round-2 path)
     h2 = build(True)
     sec2, _ = run(h2, steps, warmup)
+    h2.net.engine.check_eval()
     os.environ.pop('RUMPY_BLOCK_W48', None)
     del h1, h2
     cpu = None
@@ -280,17 +285,54 @@ def bench_eval(args):
     print(json.dumps(line), flush=True)
 
 
+def count_gpus_without_hip(topology=None, environ=None):
+    """GPUs this process would see, counted WITHOUT loading anything that initialises HIP / HSA (the launcher parent must stay a process that
+    has never touched the GPU): the KFD topology's nodes with simd_count > 0 (CPU agents have 0), cut down by the ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES
+    lists the runtime honours (each list: entries up to the first invalid one; an entry is an index into what the previous filter left, or a
+    GPU-<uuid>).  None when the topology is not readable (the ranks then find out themselves and fail with their own message)."""
+    topology = topology or os.environ.get('RUMPY_KFD_TOPOLOGY', '/sys/class/kfd/kfd/topology/nodes')
+    environ = os.environ if environ is None else environ
+    try:
+        nodes = sorted(os.listdir(topology), key=lambda d: (len(d), d))
+    except OSError:
+        return None
+    have = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(topology, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue          # (a node this cgroup may not read is a device it may not use either)
+        if int(props.get('simd_count', '0')) > 0:
+            have += 1
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if var not in environ:
+            continue
+        kept = 0
+        for entry in environ[var].split(','):
+            entry = entry.strip()
+            if entry.startswith('GPU-') or (entry.isdigit() and int(entry) < have):
+                kept += 1
+            else:
+                break
+        have = kept
+    return have
+
+
 def launch_ranks(n, argv):
-    """`python bench.py --gpus N` called plainly (no RANK in the environment): this process - which has not touched the GPU and never will -
+    """`python bench.py --gpus N` called plainly (no RANK in the environment): this process - which imports nothing that touches the GPU -
     starts the N rank processes itself (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would set
-    them), relays rank 0's JSON line and exits with the worst return code.  Children are fresh interpreters (subprocess, never exec)."""
+    them), relays rank 0's JSON line and exits with the worst return code.  Children are fresh interpreters (subprocess, never exec).
+    Supervision (what torchrun's agent does): every child is polled; when one exits non-zero the others - which would wait for it in a
+    collective for ever - are killed (exactly the PIDs started here) and that code is returned; the same after RUMPY_BENCH_TIMEOUT seconds
+    (default 3600) with code 124."""
     import socket
     import subprocess
+    import threading
     one_device = os.environ.get('RUMPY_BENCH_ONE_DEVICE') == '1'
     if not one_device:
-        import torch                         # device_count() reads the driver's device list without initialising a HIP context
-        have = torch.cuda.device_count()
-        if have < n:
+        have = count_gpus_without_hip()
+        if have is not None and have < n:
             sys.stderr.write('bench.py: --gpus %d, but this node exposes %d GPU(s)\n' % (n, have))
             return 2
     with socket.socket() as sk:              # a free rendezvous port
@@ -303,16 +345,31 @@ def launch_ranks(n, argv):
         env.setdefault('OMP_NUM_THREADS', '8')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=120 if rc == 0 else 5)
-        except subprocess.TimeoutExpired:    # a peer that outlives a failed rank 0 waits in a collective: end exactly that process
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get('RUMPY_BENCH_TIMEOUT', '3600'))
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed:
+            rc = failed[0]
+            sys.stderr.write('bench.py: rank %d exited with code %d; ending the other ranks\n' % (codes.index(failed[0]), rc))
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            rc = 124
+            sys.stderr.write('bench.py: ranks still running after RUMPY_BENCH_TIMEOUT; ending them\n')
+            break
+        time.sleep(0.1)
+    for p in procs:
+        if p.poll() is None:                 # a peer of a failed rank waits in a collective: end exactly that process
             p.kill()
-            p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out0 or '')
+        p.wait()
+    reader.join(timeout=5)
+    sys.stdout.write((out0[0] if out0 else '') or '')
     sys.stdout.flush()
     return rc
 
@@ -430,18 +487,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss, _ = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dp:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region():
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize fences; MAX over the ranks"""
+        for i in range(args.warmup):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss, _ = step(i)
+        fence()
+        own = time.perf_counter() - t0
+        worst = own
+        if dp:
+            t = torch.tensor([own], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            worst = float(t.item())
+        return worst, own, loss
+
+    # The driver runs ONE plain command per N: when no all-reduce form is forced, a data-parallel run times the region twice inside the same
+    # process group - one inline collective behind the backward pass, then the early half on the side stream under the remaining weight
+    # gradients (DESIGN.md 6) - reports the faster as `value` and both under `distributed.forms`; every rank prints its own time to stderr.
+    forms_ms = forms_loss = None
+    hipnet0 = getattr(h.net, 'hip_generator', h.net)
+    if dp and args.allreduce_form == 'auto' and hasattr(hipnet0, 'engine_forward') and not getattr(hipnet0, 'use_graph', False) \
+            and not any(os.environ.get(k) for k in ('RUMPY_DP_EARLY', 'RUMPY_DP_LATE')):
+        forms_ms, forms_loss, best = {}, {}, None
+        for form in ('inline', 'early'):
+            h.set_allreduce_form(form)
+            e, own, l = timed_region()
+            forms_ms[h.data_parallel.form] = round(1e3 * e / args.steps, 4)
+            forms_loss[h.data_parallel.form] = float(l)
+            sys.stderr.write('bench.py: rank %d, all-reduce form %s: %.4f ms per step (max over ranks %.4f)\n'
+                             % (rank, h.data_parallel.form, 1e3 * own / args.steps, 1e3 * e / args.steps))
+            if best is None or e < best[0]:
+                best = (e, l, form)
+        elapsed, loss, chosen = best
+        h.set_allreduce_form(chosen)        # (the probe steps below run the reported form)
+    else:
+        elapsed, own, loss = timed_region()
+        if dp:
+            sys.stderr.write('bench.py: rank %d: %.4f ms per step (max over ranks %.4f)\n' % (rank, 1e3 * own / args.steps, 1e3 * elapsed / args.steps))
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * world * args.steps / elapsed
 
@@ -594,6 +679,7 @@ def main():
                 'distributed': {'world_size': dist.get_world_size() if dp else 1, 'backend': dist.get_backend() if dp else None,
                                 'device_count': torch.cuda.device_count(), 'ranks_on_one_device': bool(one_device),
                                 'allreduce_form': getattr(getattr(h, 'data_parallel', None), 'form', None) if dp else None,
+                                'forms_loss': forms_loss, 'forms': forms_ms,       # ms per step of every form timed in this run (--allreduce-form auto: inline, then early); `value` is the faster
                                 'grad_allreduce_mb': round(getattr(h.net, 'hip_generator', h.net).flat_g.numel() * 4 / 1e6, 2) if dp else 0.0}}
         print(json.dumps(line), flush=True)
     if dp:

@@ -19,26 +19,36 @@ class _TiledEval(BaseModel):
     max_combined_im_size = None
 
     def forward_chop(self, x, shave=10):
-        b, c, h, w = x.shape
-        h_half, w_half = h // 2, w // 2
-        h_size, w_size = h_half + shave, w_half + shave
-        lr_list = [x[:, :, 0:h_size, 0:w_size], x[:, :, 0:h_size, (w - w_size):w],
-                   x[:, :, (h - h_size):h, 0:w_size], x[:, :, (h - h_size):h, (w - w_size):w]]
-        if w_size * h_size < self.max_combined_im_size:
-            sr_list = [self.run_chopped_eval(chunk.contiguous()) for chunk in lr_list]
-        else:
-            sr_list = [self.forward_chop(patch, shave=shave) for patch in lr_list]
+        """Each image axis of length L is covered by two windows of L // 2 + shave pixels, one anchored at either end; a window OWNS the
+        output indices of its own half ([0, L // 2) or [L // 2, L)).  The four (row window, column window) quadrants are super-resolved on
+        their own - recursively while a quadrant still has max_combined_im_size pixels or more - and each contributes the part it owns."""
+        rows, cols = x.shape[-2:]
         s = self.scale
-        h, w, h_half, w_half, h_size, w_size = s * h, s * w, s * h_half, s * w_half, s * h_size, s * w_size
-        output = sr_list[0].new_empty(b, sr_list[0].shape[1], h, w)
-        output[:, :, 0:h_half, 0:w_half] = sr_list[0][:, :, 0:h_half, 0:w_half]
-        output[:, :, 0:h_half, w_half:w] = sr_list[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
-        output[:, :, h_half:h, 0:w_half] = sr_list[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
-        output[:, :, h_half:h, w_half:w] = sr_list[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
+
+        def windows(L):             # (window start, window end, first owned index, one past the last owned index)
+            half = L // 2
+            return (0, half + shave, 0, half), (L - half - shave, L, half, L)
+
+        recurse = (rows // 2 + shave) * (cols // 2 + shave) >= self.max_combined_im_size
+        output = None
+        for r0, r1, own_r0, own_r1 in windows(rows):
+            for c0, c1, own_c0, own_c1 in windows(cols):
+                quadrant = x[..., r0:r1, c0:c1]
+                sr = self.forward_chop(quadrant, shave=shave) if recurse else self.run_chopped_eval(quadrant.contiguous())
+                if output is None:
+                    output = sr.new_empty(x.shape[0], sr.shape[1], s * rows, s * cols)
+                output[..., s * own_r0:s * own_r1, s * own_c0:s * own_c1] = \
+                    sr[..., s * (own_r0 - r0):s * (own_r1 - r0), s * (own_c0 - c0):s * (own_c1 - c0)]
         return output
 
     def run_chopped_eval(self, x):
-        return super().run_eval(x, keep_on_device=True)[0]
+        # every quadrant's status words are examined before it is stitched in (BaseModel.defer_eval_status is not honoured here): an fp16
+        # overflow re-runs THAT quadrant in bf16 inside SREngine.forward, a strip-exchange time-out raises
+        defer, self.defer_eval_status = self.defer_eval_status, False
+        try:
+            return super().run_eval(x, keep_on_device=True)[0]
+        finally:
+            self.defer_eval_status = defer
 
     def run_eval(self, x, y=None, request_loss=False, tag=None, timing=False, keep_on_device=False, *args, **kwargs):
         if self.max_combined_im_size is None:

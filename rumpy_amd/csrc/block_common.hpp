@@ -79,11 +79,6 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
-#if defined(BLOCK_ABL) && BLOCK_ABL == 7
-        // timing experiment (results WRONG): 5 of every 9 MFMAs - the matrix-pipe time of the block-scaled fp8 form (K = 128 at twice the
-        // cycles: five MFMAs per output tile where bf16 issues eighteen at half the cycles), every other instruction unchanged
-        if (((grp * 3 + ky) * ROWS + r) % 9 >= 5) continue;
-#endif
         acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c]);
       }
     hook(grp);
@@ -129,10 +124,6 @@ __device__ __forceinline__ void pair_up(const f32x4& tx, const f32x4& ty, int g,
   // even-g lanes get (own X values, the X values of lane g+1), odd-g lanes (the Y values of lane g-1, own Y values) - the whole
   // exchange in one VALU instruction per dword (the portable form, a select + ds_bpermute + two selects, was a third of the
   // epilogues' instructions).  Checked on the GPU against lane ids; `g` is implied by the lane's row.
-#ifndef PAIR_ABL
-#define PAIR_ABL 0
-#endif
-#if PAIR_ABL == 0
   (void)g;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -140,15 +131,6 @@ __device__ __forceinline__ void pair_up(const f32x4& tx, const f32x4& ty, int g,
     v[j] = __uint_as_float(r[0]);
     v[4 + j] = __uint_as_float(r[1]);
   }
-#else
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float snd = (g & 1) ? tx[j] : ty[j];
-    const float rcv = __shfl_xor(snd, 16);
-    v[j] = (g & 1) ? rcv : tx[j];
-    v[4 + j] = (g & 1) ? ty[j] : rcv;
-  }
-#endif
 }
 // ReLU-mask on PACKED bf16 pairs: keeps the halves of v whose mask half is > 0, i.e. sign bit clear and any other bit set (a NaN with
 // a clear sign bit counts as > 0; the mask operand of the product path is a stored post-ReLU activation).  (t + 0x7fff) sets bit 15 of
@@ -185,7 +167,7 @@ __device__ __forceinline__ void unpack8(uint4 u, float (&m)[8]) {
 // of 32 different lines, the lines are assembled in L2 from four waves' stores and stay dirty until the end-of-kernel write-back
 // (which is what the "kernel boundary" of a dependent launch mostly waits for: B / 6 TB/s).  Stored from the LDS image instead - 8 lanes
 // per pixel, 1 KB contiguous per wave-instruction - and non-temporal, the lines leave L2 while the kernel still computes:
-// measured -2.1 us of 16.7 per residual-block launch (tests/tools/abl_block.sh BLOCK_ABL_6 vs BLOCK_ST_2_c).
+// measured -2.1 us of 16.7 per residual-block launch (round-2 ablation builds, tests/tools/patches/abl_r03.patch).
 // Piece p = tid + 512 i (i < 5) = 16-byte chunk p & 7 of strip pixel p >> 3 (row-major over 6 x 48).
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st16_nt(uint16_t* p, uint4 v) {

@@ -28,18 +28,8 @@
 // order is unchanged, so the results are bitwise those of the two-launch path (test_conv_block_column_tiles_*).
 #include "block_common.hpp"
 
-#ifndef BLOCK_OUT_PLAIN
-#define BLOCK_OUT_PLAIN 0   // A/B: OUT stored with the default policy (lines stay in the XCD's L2 for the next launch, dirty until the boundary)
-#endif
-#ifndef BLOCK_FFIRST
-#define BLOCK_FFIRST 0  // A/B: 1 = the first filter is requested before the input tile
-#endif
-#ifndef BLOCK_EARLY
-#define BLOCK_EARLY 1   // A/B: 0 = the whole input tile behind one wait (round 2)
-#endif
-#ifndef BLOCK_ABL
-#define BLOCK_ABL 0   // timing experiments only (tests/tools/build_abl.sh, abl_block.sh; results are WRONG): 1 = second filter not fetched,
-#endif                //   2 = neither filter fetched, 4 = no HBM stores, 5 = input tile not loaded, 9 = phase stamps into a.res1
+// (The timing-experiment builds of rounds 1-3 - phase stamps, pieces compiled out, alternative prologue orders - live as a patch under
+// tests/tools/patches/abl_r03.patch; this file holds the product kernel only.)
 
 // GEN = false: the ResBlock form (residual operand = block input, read from LDS).  GEN = true: the general form used for
 // RCABs - res_mode 1 (no residual) or 2 (residual operand res1 from HBM, prefetched under the second sweep) and the
@@ -67,19 +57,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   if (G::CT) { sy = strip % a.sy_n; const int r = strip / a.sy_n; ct = r % a.ct_n; n = r / a.ct_n; }
   else { n = strip / a.sy_n; sy = strip - n * a.sy_n; }
   const int x0 = ct * G::OW;               // image column of the strip's first output column
-  unsigned long long stamps[8];
-  unsigned long long cyc[4] = {0ull, 0ull, 0ull, 0ull};       // (stamp build) shader-clock counter at the start / end of the two sweeps
-  int nst = 0;
-#define BK_STAMP() do { if (BLOCK_ABL == 9 && nst < 8) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-  BK_STAMP();                              // 0: start
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns x0-XH .. x0+OW+XH-1 -> LDS (branch-free loads, zero outside the image) ----
-  // Round 3 (BLOCK_EARLY): the tile arrives bandwidth-priced (every CU asks for its 64 KB at the same moment: 2.8 us), and row half 0 only sweeps
+  // Round 3: the tile arrives bandwidth-priced (every CU asks for its 64 KB at the same moment: 2.8 us), and row half 0 only sweeps
   // over input rows 0 .. 5.  The pieces of those rows (R0 rounds of 512) are loaded by all threads first and announced on their own LDS counter;
   // the rest is loaded by row half 1's threads (row half 0 issues as many loads of one cached line instead: every wave runs the same,
   // unconditional load sequence, so the compiler's waits stay counted).  Row half 0 starts its first sweep when rows 0 .. 5 are in LDS, row half
   // 1 when everything is; the first conv's filter is requested before the tile, so its (L2-hit) latency lies under the tile's.
-  constexpr int R0 = BLOCK_EARLY ? (6 * XC * 8 + BTHREADS - 1) / BTHREADS : G::XREGS;      // rounds that cover input rows 0 .. 5
+  constexpr int R0 = (6 * XC * 8 + BTHREADS - 1) / BTHREADS;                               // rounds that cover input rows 0 .. 5
   constexpr int LATE = G::XPIECES - R0 * BTHREADS > 0 ? G::XPIECES - R0 * BTHREADS : 0;
   constexpr int R1 = (LATE + 255) / 256;                                                     // rounds of row half 1's 256 threads for the rest
   if (tid < 8) gate[tid] = 0u;
@@ -88,9 +73,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   auto fetch_filter = [&]() {
     const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8((BLOCK_ABL == 2) ? make_uint4(0x3c003c00u + lane, 0x3c003c00u, 0x3c003c00u + t, 0x3c003c00u) : wp[t * 64]);
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
   };
-  if (BLOCK_FFIRST) fetch_filter();
   {
     uint4 R[R0], Rl[R1 > 0 ? R1 : 1];
     const int y0 = sy * BSH - 2;
@@ -100,8 +84,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       const int y = y0 + lr, x = x0 - XH + lc;
       const bool ok = live & (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
-      uint4 v = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
-      if (BLOCK_ABL != 5) v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
+      uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
       if (!ok) v = make_uint4(0, 0, 0, 0);
       return v;
     };
@@ -109,7 +92,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     for (int i = 0; i < R0; ++i) R[i] = fetch(tid + BTHREADS * i, true);
 #pragma unroll
     for (int i = 0; i < R1; ++i) Rl[i] = fetch(R0 * BTHREADS + tg + 256 * i, rh == 1);
-    if (!BLOCK_FFIRST) fetch_filter();       // behind the tile's requests (returns in order): under the tile's latency, not in front of it
+    fetch_filter();                          // behind the tile's requests (returns in order): under the tile's latency, not in front of it
     // border columns of the T image: convB's zero padding, never written by the epilogue (column tiles: real T values, written by the halo tile)
     if (!G::CT && tid < BTROWS * 2 * 8) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
@@ -135,7 +118,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   const int chunk8 = 2 * q + (gpair >> 3);          // 16-byte chunk of this lane's 8 channels in the paired layout
   gate_wait(&gate[4], 8u);                 // input rows 0 .. 5: all eight waves' early pieces
   if (R1 > 0 && rh == 1) gate_wait(&gate[5], 4u);   // rows 6 .. 9: row half 1's own late pieces
-  BK_STAMP();                              // 1: input tile in LDS
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
   // tile pairs: k < 4: X = (row k, col tile 0), Y = (row k, col tile 1); k = 4: X = (0, 2), Y = (1, 2); k = 5: X = (2, 2), Y = (3, 2)
@@ -201,7 +183,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       }
       *reinterpret_cast<uint4*>(ldt + swz(j * TC + xx + 1, chunk8)) = o;
     };
-    if (BLOCK_ABL == 9) cyc[0] = __builtin_amdgcn_s_memtime();
     if (G::CT) {
       // T on the halo columns first (its accumulator is dead before the main sweep's 4 x NC tiles are live)
       sweep_bases<XC>(off, 0u, hj, 0, g, htc);
@@ -220,10 +201,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     }
     sweep_bases<XC>(off, 0u, 4 * rh, px, g, G::CT ? 1 : 0);
     block_sweep<4, FMT, NoHook, NC, XC>(acc, F, lds, off);
-    if (BLOCK_ABL == 9) cyc[1] = __builtin_amdgcn_s_memtime();
-    BK_STAMP();                            // 2: first sweep done
     // second filter: L2 hits that land under the epilogue
-    if (BLOCK_ABL != 1 && BLOCK_ABL != 2) {
+    {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
@@ -231,7 +210,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
 #pragma unroll
     for (int k = 0; k < NP1; ++k) t_pair(k);
     gate_arrive(&gate[rh], lane);          // this wave's 16 channels of T rows 4rh .. 4rh+3 are in LDS
-    BK_STAMP();                            // 3: T image written
   }
   unsigned soff[G::GREGS];                 // element offsets of this thread's pieces of its row half's 3 strip rows (T and OUT stores)
 #pragma unroll
@@ -241,11 +219,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   // overwritten (OUT, in place) only behind a wait for the OTHER half's T rows, i.e. when nobody sweeps over it any more.
   gate_wait(&gate[rh], 4u);
   if (rh == 1) gate_wait(&gate[0], 4u);
-  BK_STAMP();                              // 4: this row half's T rows complete
   // The row half's own strip rows of T (and their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal, one
   // piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage).
   uint4 S[G::GREGS];
-  const bool t_out = (a.t != nullptr) && BLOCK_ABL != 4;
+  const bool t_out = a.t != nullptr;
   if (t_out) group_stage<1, G>(S, ldt, tg, rh);
   auto t_store = [&](int grp) {           // grp is a constant after unrolling: piece i after the MFMAs of group 3 i
     if (grp % 3 == 0 && grp / 3 < G::GREGS) {
@@ -286,7 +263,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       }
     }
     unsigned off[8][2];
-    if (BLOCK_ABL == 9) cyc[2] = __builtin_amdgcn_s_memtime();
     if (rh == 0) {
       sweep_bases<TC>(off, (unsigned)G::XBYTES, 0, px, g);
       block_sweep<2, FMT, decltype(t_store), NC, TC>(*reinterpret_cast<f32x4(*)[2][NC]>(&acc[0]), F, lds, off, t_store);   // output rows 0, 1 <- T rows 0 .. 3
@@ -297,8 +273,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       sweep_bases<TC>(off, (unsigned)G::XBYTES, 3, px, g);
       block_sweep<3, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                           // output rows 3 .. 5 <- T rows 3 .. 7
     }
-    if (BLOCK_ABL == 9) cyc[3] = __builtin_amdgcn_s_memtime();
-    BK_STAMP();                            // 5: second sweep done
     float ps[4] = {0.f, 0.f, 0.f, 0.f};                         // GEN pool sums: single tile, channels 4g .. 4g+3 of the wave's 16
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    //                paired tiles, channels 4(g&~1) .. +7
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
@@ -397,20 +371,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   // had read as its residual operand; nothing else reads the input tile in phase 2) -> whole lines to HBM, non-temporal ----
   gate_arrive(&gate[2 + rh], lane);
   gate_wait(&gate[2 + rh], 4u);
-  BK_STAMP();                              // 6: this row half's OUT rows complete
-  if (BLOCK_ABL != 4) {
-    group_stage<2, G>(S, ldx, tg, rh);
+  group_stage<2, G>(S, ldx, tg, rh);
 #pragma unroll
-    for (int i = 0; i < G::GREGS; ++i)
-      if (soff[i] != 0xffffffffu) { if (BLOCK_OUT_PLAIN) *reinterpret_cast<uint4*>(a.out + soff[i]) = S[i]; else st16_nt(a.out + soff[i], S[i]); }
-  }
-  BK_STAMP();                              // 7: end (stores issued)
-  if (BLOCK_ABL == 9 && lane == 0 && a.res1) {      // stamp build: a.res1 (unused by the ResBlock form) = [strip][wave][16] u64
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<uint16_t*>(a.res1)) + ((size_t)strip * 8 + wave) * 16;
-    for (int i = 0; i < 8; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
-    for (int i = 0; i < 4; ++i) dbg[8 + i] = cyc[i];
-  }
-#undef BK_STAMP
+  for (int i = 0; i < G::GREGS; ++i)
+    if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
 }
 
 template <class G>

@@ -4,7 +4,7 @@
 // History of this shape (tests/tools/abl_conv4.sh, kbench.py conv4; 32 x 96 x 96, where the MFMAs need 46 us at the 1.8 GHz the chip holds):
 // conv3x3_kernel<4> (conv_mfma.hip: one wave per SIMD, register-staged input, workgroup barriers) 108 us; a K-split form with two waves per
 // SIMD (round 2, removed) 96 us; a streaming K-split form with LDS-DMA rings and gates instead of barriers 97 us; this kernel 93-98 us.
-// Four structures, one time - because what they share is what costs: in-kernel cycle counters of this kernel (D4_ABL=9 build) say sweeping
+// Four structures, one time - because what they share is what costs: in-kernel cycle counters of this kernel (a round-2 probe build) say sweeping
 // 56 % (the MFMA loop itself runs at 84 % of the matrix pipe), ISSUING the DMA 26 % (213 cycles per global_load_lds: address arithmetic plus
 // the wait for a slot in a vector-memory queue that a bandwidth-bound gather keeps full - the gather alone, MFMAs compiled out, takes 60 us
 // = 3.5 TB/s of 128-byte pieces, whatever the prefetch depth), waiting for a stage 10 %, epilogue 8 %.  A wave that feeds the memory pipe
@@ -21,10 +21,6 @@
 //     with the stage whose slot the next DMA overwrites); no K split, so no partial-sum exchange either: same MFMA order per accumulator as
 //     conv3x3_kernel<4> (chunks 0 .. 3 in turn): bitwise that kernel (tests/test_kernels_gpu.py).
 #include "block_common.hpp"
-#ifndef D4_ABL
-#define D4_ABL 0      // timing only (results WRONG): 1 = no DMA, 2 = no MFMAs, 3 = no fragment reads (tests/tools/build_abl.sh conv_dgrad4.hip D4_ABL ...; the
-                      // in-kernel cycle counters quoted in DESIGN.md 4.2 came from a probe build that is not kept)
-#endif
 
 constexpr int D4_PIECES = 23;                         // 184 pixel slots >= 180 halo pixels
 constexpr int D4_STAGE = D4_PIECES * 1024;
@@ -113,7 +109,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     if (a.in_mode == 0) e = (unsigned)(((tc.n * a.H + y) * a.W + x) * 256 + ch * 64 + sch);
     else e = (unsigned)(((tc.n * 2 * a.H + 2 * y + (ch >> 1)) * (2 * a.W) + 2 * x + (ch & 1)) * 64 + sch);
     const unsigned long long src = ok ? (unsigned long long)(uintptr_t)a.x + 2ull * e : zero;
-    if (D4_ABL != 1) d4_dma16((const void*)(uintptr_t)src, __builtin_amdgcn_readfirstlane(dst + piece * 1024));
+    d4_dma16((const void*)(uintptr_t)src, __builtin_amdgcn_readfirstlane(dst + piece * 1024));
   };
   auto issue = [&](int u) {
 #pragma unroll
@@ -159,7 +155,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
         const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
-          if (D4_ABL != 3 || j == 0) dst[r] = *reinterpret_cast<const bf16x8*>(cur + off[(2 * r + kx) & 7][half] + ((4 * pass + r) * HALO_W + kx) * 128);
+          dst[r] = *reinterpret_cast<const bf16x8*>(cur + off[(2 * r + kx) & 7][half] + ((4 * pass + r) * HALO_W + kx) * 128);
       };
 #pragma unroll
       for (int j = 0; j < D4_RD; ++j) load_unit(j, I[j]);
@@ -172,8 +168,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (D4_ABL != 2) acc[4 * pass + r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[4 * pass + r]);
-            else asm volatile("" :: "v"(I[j % (D4_RD + 1)][r + ky]), "v"(F[ch][(ky * 3 + kx) * 2 + half]));
+            acc[4 * pass + r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[4 * pass + r]);
       }
     }
     // ---- epilogue: lane holds channels c0 .. c0+3 of pixel (row r, column px); the residual operand is read here (plain loads: the

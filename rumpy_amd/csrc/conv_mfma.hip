@@ -14,9 +14,6 @@
 #include <cstdlib>
 
 
-#ifndef CONV4_ABL
-#define CONV4_ABL 0     // timing experiments only (tests/tools/build_abl.sh): results are wrong for any value but 0
-#endif
 template <int CHUNKS, int FMT = RUMPY_FMT_BF16>      // FMT: element format of activations and filters (RUMPY_FMT_F16: evaluation plans)
 __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(ConvDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * X_STAGE_BYTES];
@@ -70,7 +67,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
         const int nch = (ch + 1 < CHUNKS) ? ch + 1 : 0;
         const int ntile = (ntile0 < ntiles) ? ntile0 : tile;
         const TileCoord tn = decode_tile(ntile, a.tiles_x, a.tiles_y);
-        if (CONV4_ABL != 2) halo_issue(R, a.x, a.in_mode, cstride, a.in_mode == 0 ? nch * 64 : nch, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
+        halo_issue(R, a.x, a.in_mode, cstride, a.in_mode == 0 ? nch * 64 : nch, tn.n, tn.ty, tn.tx, a.H, a.W, tid);
       }
       const bool has_next = (ch + 1 < CHUNKS) || (tile + gstride < ntiles);
       const unsigned char* cur = lds + buf * X_STAGE_BYTES;
@@ -94,8 +91,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int r = 0; r < TH; ++r)
-              if (CONV4_ABL != 1) acc[r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r]);
-              else asm volatile("" :: "v"(I[grp & 1][r + ky]));
+              acc[r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r]);
         }
       }
       // stage s+1 goes to the other LDS buffer BEFORE the epilogue's stores (a wait issued behind them would drain them)
@@ -140,7 +136,7 @@ __global__ void __launch_bounds__(256, (CHUNKS == 1) ? 2 : 1) conv3x3_kernel(Con
 #pragma unroll
               for (int j = 0; j < 4; ++j) v[j] += m[j];
             }
-            if (CONV4_ABL != 3) *reinterpret_cast<uint2*>(a.out + o) = pack4<FMT>(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<uint2*>(a.out + o) = pack4<FMT>(v[0], v[1], v[2], v[3]);
           }
         }
         if (a.pool) {
@@ -497,6 +493,10 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (p->cin_chunks == 1 || (strip4 && p->cin_chunks == 4)) {   // strip kernel (conv_strip.hip)
     hipStream_t s1 = (hipStream_t)stream;
     const int kid1 = (p->cout_tiles == 1 && p->cin_chunks == 1) ? 1 : 3;
+    // (every argument check sits above the probe's start event: a refused call leaves no unbalanced record)
+    const bool up_ok = p->cin_chunks == 1 && p->in_mode == 0 && !p->mask && !p->pool && (p->out_mode == 0 || (!p->res1 && !p->res2));
+    if (p->w_lo && !(p->fmt == RUMPY_FMT_F16 && (shuffled_res || up_ok))) {
+      rumpy_set_error("rumpy_conv3x3: w_lo goes with fmt F16 and a Cin = 64 forward launch without mask / pool (conv_up.hip)"); return RUMPY_E_ARG; }
     rumpy_probe_pre(kid1, s1);
     // plain forward convs with several output tiles (the upsampler convs): conv_up.hip (output through LDS as whole non-temporal lines)
     const bool up_old = getenv("RUMPY_UP_OLD") != nullptr;             // A/B switch (read per call: the tests toggle it)
@@ -505,9 +505,6 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
     const int up_strips = p->N * cdiv(p->H, 6) * cdiv(p->W, 48);
     const char* up_force = getenv("RUMPY_UP_FORCE");                    // diagnostic (kbench.py up1): "1" = every eligible launch, "0" = multi-tile ones only
     const bool up_many = up_force ? up_force[0] == '1' : up_strips > rumpy_device_cus();
-    const bool up_ok = p->cin_chunks == 1 && p->in_mode == 0 && !p->mask && !p->pool && (p->out_mode == 0 || (!p->res1 && !p->res2));
-    if (p->w_lo && !(p->fmt == RUMPY_FMT_F16 && (shuffled_res || up_ok))) {
-      rumpy_set_error("rumpy_conv3x3: w_lo goes with fmt F16 and a Cin = 64 forward launch without mask / pool (conv_up.hip)"); return RUMPY_E_ARG; }
     if (shuffled_res || p->w_lo || (!up_old && (p->cout_tiles > 1 || up_many) && up_ok))
       rumpy_conv_up_launch(p, s1);
     else

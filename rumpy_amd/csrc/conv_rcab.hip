@@ -28,9 +28,6 @@ typedef __amdgpu_buffer_rsrc_t rc_rsrc;
 constexpr int RC_SC1 = 16;
 constexpr unsigned RC_SPIN = 1u << 20;
 constexpr int RC_MAXR = 16;
-#ifndef RCAB_ABL
-#define RCAB_ABL 0   // timing experiments only (tests/tools/build_abl.sh): 1 = no polling, 2 = also no product sums / tile transform in backward
-#endif
 
 struct RcabDev {
   const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
@@ -52,7 +49,6 @@ __device__ __forceinline__ float strip_allsum(const RcabDev& a, float mine, int 
   const int c = tid & 63, w = tid >> 6;
   if (tid < 64) __builtin_amdgcn_raw_buffer_store_b64((rc_u32x2){__float_as_uint(mine), tag}, rr, (unsigned)(((n * a.ns + si) * 64 + c) * 8), 0, RC_SC1);
   float total = 0.f;
-  if (RCAB_ABL >= 1) return mine * a.ns;
   for (int s0 = 0; s0 < a.ns; s0 += 8) {
     const int s = s0 + w;
     float val = 0.f;
@@ -113,10 +109,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   if (G::CT) { ct = si / a.sy_n; sy = si - ct * a.sy_n; }
   const int x0 = ct * OW;                  // image column of the strip's first output column
   const unsigned tag = (*a.epoch << 12) + a.seq;
-  unsigned long long stamps[10];
-  int nst = 0;
-#define RC_STAMP() do { if (RCAB_ABL == 9 && nst < 10) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
-  RC_STAMP();                              // 0: start
 
   // ---- phase 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (branch-free loads, zero outside the image) ----
   uint4 T2[BWD ? G::SREGS : 1];
@@ -204,7 +196,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   const int gpair = 4 * (g & ~1);
   const int chunk8 = 2 * q + (gpair >> 3);
   __syncthreads();
-  RC_STAMP();                              // 1: input tile in LDS
 
   if (BWD) {
     // ---- phase 0b: ds = sum over the strip of dy * t2 per channel -> all strips of the image -> MLP backward -> d_t2 in place ----
@@ -242,9 +233,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
-    RC_STAMP();                            // (bwd) 2: product sums reduced
     const float ds = strip_allsum(a, mine, n, si, tid, tag, sx);
-    RC_STAMP();                            // (bwd) 3: exchange done
     if (tid < 64) {
       const int c = tid;
       const float s = svec[3 * 64 + c];
@@ -303,7 +292,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       }
     }
     __syncthreads();
-    RC_STAMP();                            // (bwd) 4: d_t2 tile ready
   }
 
   // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) from input rows j .. j+2 ----
@@ -359,7 +347,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     }
     sweep_bases<XC>(off, 0u, 4 * rh, px, g, G::CT ? 1 : 0);
     block_sweep<4, FMT, NoHook, NC, XC>(acc, F, lds, off);
-    RC_STAMP();                            // sweep A done
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
@@ -394,7 +381,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   // no workgroup barrier between the phases: each row half waits for exactly the T rows it reads (conv_block.hip, block_common.hpp)
   gate_wait(&gate[rh], 4u);
   if (rh == 1) gate_wait(&gate[0], 4u);
-  RC_STAMP();                              // this row half's T rows complete
   // the row half's own strip rows of T (forward: + their ReLU mask bytes) go to HBM from the finished LDS image: whole lines, non-temporal,
   // one piece after every third MFMA group of the second sweep (block_common.hpp::strip_stage; conv_block.hip)
   static_assert(G::SREGS >= G::GREGS, "S holds a row half's pieces and, later, the whole strip's");
@@ -449,7 +435,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       sweep_bases<TC>(off, (unsigned)G::XBYTES, 3, px, g);
       block_sweep<3, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                           // rows 3 .. 5 <- T rows 3 .. 7
     }
-    RC_STAMP();                            // sweep B done
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
     float V[NP2][8], vs[4];
 #pragma unroll
@@ -540,9 +525,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           *reinterpret_cast<uint2*>(ldt + swz((3 * rh + 2 + 1) * TC + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
       }
       const float mine = (tid < 64) ? spool[tid] + spool[64 + tid] : 0.f;
-      RC_STAMP();                          // (fwd) pool sums done, t2 image written
       const float tot = strip_allsum(a, mine, n, si, tid, tag, sx);      // (its barriers also complete the t2 image)
-      RC_STAMP();                          // (fwd) exchange done
       if (a.t2) strip_stage<1, G>(S, ldt, tid);
       if (tid < 64) {
         const int c = tid;
@@ -571,7 +554,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         if (si == 0) { a.mean[n * 64 + c] = mean; a.gate[n * 64 + c] = gt; }
       }
       __syncthreads();
-      RC_STAMP();                          // (fwd) gate ready
       if (a.t2) {
 #pragma unroll
         for (int i = 0; i < G::SREGS; ++i)
@@ -611,16 +593,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       if (soffg[i] != 0xffffffffu) st16_nt(a.out + soffg[i], S[i]);
   } else {
     __syncthreads();
-    RC_STAMP();                            // (fwd) OUT image complete
     strip_stage<2, G>(S, ldx, tid);
 #pragma unroll
     for (int i = 0; i < G::SREGS; ++i)
       if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
-  }
-  RC_STAMP();                              // end (stores issued)
-  if (RCAB_ABL == 9 && lane == 0) {       // stamp build: [strip][wave][16] u64 behind the first 16 words of the status buffer (kbench.py rcab)
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.status + 16) + ((size_t)strip * 8 + wave) * 16;
-    for (int i = 0; i < 10; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
   }
 }
 

@@ -7,9 +7,6 @@
 // lines per wave-instruction: 1.3 TB/s on the 151 MB of the second upsampler conv (tests/tools/kbench.py up), with or without the shuffle.
 #include "block_common.hpp"
 
-#ifndef UP_ABL
-#define UP_ABL 0      // 9: phase stamps of one iteration per wave behind the 256 bias values (diagnostic builds: tests/tools/build_abl.sh, kbench.py up)
-#endif
 struct UpDev {
   const uint16_t* x; const uint4* w; const uint4* w_lo; const float* bias; uint16_t* out;      // w_lo: NULL, or the filter's rounding-residual image (fp16 evaluation plans)
   const uint16_t* res1; const uint16_t* res2;      // optional residual operands, layout of out (out_mode 0)
@@ -111,7 +108,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
   // the loads of the strip after the next one are issued BEFORE the stores of the current one (vector-memory operations return in issue
   // order: a stage write must not wait behind 5 non-temporal stores).  Measured neutral: what an iteration really costs beside its 162 MFMAs
   // per wave is the address arithmetic of loads / stores / LDS images (about 600 VALU instructions per wave and strip, issued beside the
-  // partner wave's MFMAs: stamps of tests/tools/kbench.py up with the UP_ABL=9 build)
+  // partner wave's MFMAs: stamps of tests/tools/kbench.py up with a round-2 stamp build)
   {
     const int s2 = strip + (int)gridDim.x;
     up_issue(R, a.x, up_decode(s2 < nstrips ? s2 : strip, a.sx_n, a.sy_n), a.H, a.W, tid);
@@ -126,9 +123,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
   //   this half's pieces of strip k - 1 read back (its rows may be overwritten) -> gate_rd[rh] >= 4 (k - 1)
   int buf = 0;
   unsigned k = 1;
-  unsigned long long stamps[10];
-  int nst = 0;
-#define UP_STAMP() do { if (UP_ABL == 9 && k == 5 && nst < 10) stamps[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
   for (; strip < nstrips; strip += gridDim.x, ++k) {
     const UpCoord sc = up_decode(strip, a.sx_n, a.sy_n);
     const bool has_next = strip + (int)gridDim.x < nstrips;
@@ -139,9 +133,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
       for (int c = 0; c < 3; ++c) acc[r][c] = bias4;
     unsigned off[8][2];
     sweep_bases(off, (unsigned)(buf * UPSTAGE), 3 * rh, px, g);
-    UP_STAMP();                                            // 0: iteration start
     if (k > 1) gate_wait(&gate[0], 8u * (k - 1));          // (the first stage is behind the workgroup barrier)
-    UP_STAMP();                                            // 1: input stage complete
     block_sweep<3, FMT>(acc, F, lds, off);
     if (two) {
       __builtin_amdgcn_sched_barrier(0);                   // (the new slice goes INTO the registers of the old one: not hoisted above the sweep's last reads)
@@ -152,20 +144,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
       if (has_next) fetch_filter(a.w_lo);                  // for the next strip: lands under the epilogue below
       __builtin_amdgcn_sched_barrier(0);
     }
-    UP_STAMP();                                            // 2: sweep done
     gate_arrive(&gate[1], lane);
     if (has_next) {
       gate_wait(&gate[1], 8u * (k - 1));                   // nobody sweeps over the other stage any more
-      UP_STAMP();                                          // (3a) other stage free
       up_write(R, lds + (buf ^ 1) * UPSTAGE, tid);
       gate_arrive(&gate[0], lane);
-      UP_STAMP();                                          // (3b) stage written
     }
     {   // the strip after the next one (past the end: this strip again, unused): issued on every path, before this strip's stores
       const int s2 = strip + 2 * (int)gridDim.x;
       up_issue(R, a.x, up_decode(s2 < nstrips ? s2 : strip, a.sx_n, a.sy_n), a.H, a.W, tid);
     }
-    UP_STAMP();                                            // 3: next stage written, loads issued
     // epilogue: the packed values go to this half's rows of the output image (pairs k < 3: (row k, col tile 0 | 1); 3: (rows 0 | 1, col tile 2); single: (2, 2))
     gate_wait(&gate_rd[rhu], 4u * (k - 1));
     const bool post = a.relu || a.scale != 1.0f || a.res1 || a.res2;      // uniform: the upsampler convs skip all of it
@@ -224,10 +212,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
       }
       *reinterpret_cast<uint2*>(ldo + swz((3 * rh + 2) * BCOLS + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(v[0], v[1], v[2], v[3]);
     }
-    UP_STAMP();                                            // 4: epilogue done
     gate_arrive(&gate[2 + rhu], lane);
     gate_wait(&gate[2 + rhu], 4u * k);
-    UP_STAMP();                                            // 5: this half's output rows complete
     {
       uint4 S[GROUP_REGS];
       group_stage<0>(S, ldo, tg, rhu);
@@ -238,14 +224,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_up_kernel(UpDev a) {
       }
     }
     gate_arrive(&gate_rd[rhu], lane);     // (release: behind the reads above)
-    UP_STAMP();                                            // 6: stores issued
     buf ^= 1;
   }
-  if (UP_ABL == 9 && lane == 0 && a.bias) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias) + 256) + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16;
-    for (int i = 0; i < 10; ++i) dbg[i] = i < nst ? stamps[i] : 0ull;
-  }
-#undef UP_STAMP
 }
 
 int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s) {

@@ -12,9 +12,6 @@
 //     lane-linear - which makes every transposed read (8 consecutive pixels x 32 B per 32-lane half) conflict free.
 //   * out-of-image pixels are fetched from a zero page; the bias gradient is one extra MFMA against a ones fragment.
 #include "common.hpp"
-#ifndef WGRAD_ABL
-#define WGRAD_ABL 0     // timing experiments only (tests/tools/build_abl.sh): results are wrong for any value but 0
-#endif
 #ifndef WGRAD_STAGGER
 #define WGRAD_STAGGER 1 // 0: A/B - every wave issues its DMA pieces right behind the tile's barrier (rounds 1-2)
 #endif
@@ -185,7 +182,7 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     // vector-memory queue (5 pieces, 100-185 issue cycles each next to LDS reads: MI355X_MICROARCH.md) cannot feed the matrix pipe meanwhile;
     // staggered, one wave of every SIMD issues MFMAs while its sibling issues DMA.  The counted waits are unchanged (a wave's pieces of
     // tile t + AHEAD are still its youngest at the top of step t + 1), and so is every accumulation order.
-    const bool more = (t + AHEAD < ntiles) && WGRAD_ABL != 3;
+    const bool more = t + AHEAD < ntiles;
     const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
     if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
     const unsigned sb = lds0 + slot * DSTAGE;
@@ -210,11 +207,10 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const unsigned pb = sb + (ks ? (offB[tap] ^ 64u) + 36 * 128 : offB[tap]);
-        const bf16x8 B = (WGRAD_ABL == 2) ? ones : join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
+        const bf16x8 B = join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
 #pragma unroll
         for (int ct = 0; ct < MT; ++ct)
-          if (WGRAD_ABL != 1) acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
-          else asm volatile("" :: "v"(B), "v"(A[ct]));
+          acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
       }
     }
     slot = (slot + 1 >= NST) ? 0 : slot + 1;

@@ -8,6 +8,7 @@ reproduced (paths relative to /root/reference/rumpy):
   :107-124 (ResidualGroup), :24-44 (CALayer); SISR/models/advanced/common.py:23-75 (Upsampler, ResBlock);
   shared_framework/models/base_architecture.py:425-485 (loss.backward + Adam step).
 """
+import collections
 import ctypes as C
 import math
 import os
@@ -1044,6 +1045,11 @@ class SREngine:
         self._advance_epoch(plan, stream)
         # the head / tail kernels read the caller's fp32 NCHW tensors in place and write a fresh output tensor: no copies
         plan.x_ref, plan.target_ref = x, target           # keep them alive until the backward pass has consumed them
+        if train:                                         # (two generations: the backward pass of step i may still run when step i + 1 is queued, _bind_batch)
+            refs = getattr(plan, 'batch_refs', None)
+            if refs is None:
+                refs = plan.batch_refs = collections.deque(maxlen=2)
+            refs.append((x, target))
         plan.head_args.x = x.data_ptr()
         plan.head_args.x_ind = None           # (a captured step of the same plan reads through its pointer table; its launches keep their own copy of the arguments)
         if train:
@@ -1263,6 +1269,15 @@ class SREngine:
         if not direct(target, plan.target):
             plan.target.copy_(target, non_blocking=True)
             target = plan.target
+        # the replay reads the caller's tensors in place (head_wgrad reads x at the very end of the backward pass): a batch dropped by the
+        # caller right after run_train must not be recycled by the caching allocator under the running replay.  Two
+        # generations are held: run_train returns behind the forward pass of step i (loss read-back), so when batch i + 1 is bound the
+        # backward pass of step i may still run, and it is over when batch i + 2 is bound (same stream, behind forward i + 1).
+        plan.x_ref, plan.target_ref = x, target
+        refs = getattr(plan, 'batch_refs', None)
+        if refs is None:
+            refs = plan.batch_refs = collections.deque(maxlen=2)
+        refs.append((x, target))
         L.check(self.lib.rumpy_set_pointers(plan.batch_ptrs.data_ptr(), x.data_ptr(), target.data_ptr(), cur.cuda_stream), 'rumpy_set_pointers')
 
     def _qca_param_grads(self, plan, stream):

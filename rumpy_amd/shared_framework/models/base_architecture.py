@@ -62,6 +62,7 @@ class BaseModel(nn.Module):
         self.legacy_load = True
         self.model_name = self.__class__.__name__.split('Handler')[0].lower()
         self.data_parallel = None
+        self.defer_eval_status = False       # opt-in of a caller that checks a kept-on-device evaluation itself (run_eval)
 
     # ------------------------------------------------------------------ devices
     def activate_device(self):
@@ -96,6 +97,26 @@ class BaseModel(nn.Module):
             self.data_parallel.form = 'early'
         if self.data_parallel.active:
             print('Model replicated over %d GPU processes (RCCL gradient all-reduce)' % self.data_parallel.world_size)
+
+    def set_allreduce_form(self, form):
+        """Select how the gradient all-reduce of a data-parallel run is issued, after set_multi_gpu(): 'inline' = one blocking-form
+        collective on the main stream behind the backward pass, 'side' = asynchronous buckets on the side stream behind the backward pass,
+        'early' = the upper half of the gradient buffer on the side stream under the remaining weight gradients (two-phase weight-gradient
+        plans; a later switch back keeps those plans - same gradients bit for bit, one launch more).  bench.py times 'inline' and then
+        'early' inside one process group when no form is forced, so that the first run on a real node decides by itself."""
+        dp, hip = self.data_parallel, self._hip_net()
+        if dp is None or form not in ('inline', 'side', 'early'):
+            raise RuntimeError('set_allreduce_form(%r): call set_multi_gpu() first; forms are inline | side | early' % (form,))
+        if form == 'early':
+            if hip is None or not hasattr(hip, 'engine_forward'):
+                raise RuntimeError('the early all-reduce form needs a network on the flat-buffer engine')
+            hip.grad_ready_hook = dp.begin
+            dp.form = 'early'
+            return
+        if hip is not None and getattr(hip, 'grad_ready_hook', None) is not None:
+            hip.grad_ready_hook = None
+        dp.inline = form == 'inline'
+        dp.form = 'inline' if (dp.inline and len(dp.buckets) == 1) else 'side'
 
     # ------------------------------------------------------------------ optimizer / scheduler (:79-198)
     def define_optimizer(self, optim_weights, lr=1e-4, optimizer_params=None, optimizer_type='Adam'):
@@ -299,9 +320,11 @@ class BaseModel(nn.Module):
         tic = toc = None
         hip = self._hip_net()
         if isinstance(hip, HipSRNet):
-            # output kept on the device and no loss asked for: nothing of this pass is read on the host, so its status words are not either -
-            # they are staged behind the pass and examined at the next one (SREngine.check_eval)
-            hip.eval_defer = bool(keep_on_device and not (request_loss and y is not None) and not timing)
+            # The status words of an evaluation pass (non-finite fp16 output, strip-exchange watchdog) are read back before the image is
+            # handed out - on every return path, kept on the device or not - unless the CALLER opted in to examining them itself
+            # (`defer_eval_status = True` on the handler: throughput loops that call `net.engine.check_eval()` behind their last image;
+            # the words are then staged behind the pass and examined at the next one)
+            hip.eval_defer = bool(self.defer_eval_status and keep_on_device and not (request_loss and y is not None) and not timing)
         with torch.no_grad():
             x = x.to(device=dev)
             want_loss = request_loss and y is not None

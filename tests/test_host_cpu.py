@@ -7,6 +7,7 @@ import re
 import subprocess
 import sys
 import tempfile
+import time
 
 import numpy as np
 import pytest
@@ -659,18 +660,82 @@ def test_wide_edsr_and_x3_construct_like_the_reference_and_other_widths_are_refu
             SREngine(hb.net._spec(), torch.device('cpu'))
 
 
-def test_bench_launcher_refuses_more_gpus_than_the_node_has_and_relays_the_children():
-    """`python bench.py --gpus N` without RANK starts the ranks itself (bench.py::launch_ranks).  On this GPU-less container: more GPUs
-    than devices -> non-zero exit with a message before any child starts; with RUMPY_BENCH_ONE_DEVICE=1 the children start and fail
-    loudly (no GPU), and the parent returns their code instead of hanging."""
+def test_bench_launcher_refuses_more_gpus_than_the_node_has_and_relays_the_children(tmp_path):
+    """`python bench.py --gpus N` without RANK starts the ranks itself (bench.py::launch_ranks).  More GPUs than the KFD topology shows
+    (a fabricated one-GPU topology here; the count never touches HIP) -> non-zero exit with a message before any child starts; with
+    RUMPY_BENCH_ONE_DEVICE=1 on this GPU-less container the children start and fail loudly (no GPU), and the parent returns their code
+    instead of hanging."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RUMPY_BENCH_ONE_DEVICE')}
-    if torch.cuda.device_count() < 8:
-        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], env=env,
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-        assert p.returncode != 0 and b'--gpus 8' in p.stderr and b'{"metric"' not in p.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'RUMPY_BENCH_ONE_DEVICE') and
+           not k.endswith('_VISIBLE_DEVICES')}            # (this container sets HIP_VISIBLE_DEVICES to the empty list)
+    for i, simd in enumerate((0, 1024)):
+        (tmp_path / str(i)).mkdir()
+        (tmp_path / str(i) / 'properties').write_text('simd_count %d\n' % simd)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'],
+                       env=dict(env, RUMPY_KFD_TOPOLOGY=str(tmp_path)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 2 and b'--gpus 8, but this node exposes 1 GPU' in p.stderr and b'{"metric"' not in p.stdout
     if not torch.cuda.is_available():
         env['RUMPY_BENCH_ONE_DEVICE'] = '1'
         p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert p.returncode != 0 and b'{"metric"' not in p.stdout
+
+
+def test_launcher_counts_gpus_from_the_kfd_topology_without_hip(tmp_path):
+    """bench.py's launcher parent must never initialise HIP: it counts the KFD topology's nodes with simd_count > 0 and
+    applies the *_VISIBLE_DEVICES lists itself.  A fabricated topology (2 CPU agents + 8 GPUs, the shape of an 8 x MI355X node) stands in."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_for_count', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for i in range(10):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n' % ((96, 0) if i < 2 else (0, 1024)))
+    count = lambda **env: bench.count_gpus_without_hip(str(tmp_path), env)
+    assert count() == 8
+    assert count(HIP_VISIBLE_DEVICES='0,1,2,3') == 4
+    assert count(ROCR_VISIBLE_DEVICES='4,5', HIP_VISIBLE_DEVICES='0,1,2,3') == 2       # HIP's indices refer to what ROCR left: 2 and 3 are invalid
+    assert count(HIP_VISIBLE_DEVICES='0,9,1') == 1                                      # the list ends at its first invalid entry
+    assert count(CUDA_VISIBLE_DEVICES='') == 0
+    assert count(ROCR_VISIBLE_DEVICES='GPU-deadbeef00000000,1') == 2
+    assert bench.count_gpus_without_hip(str(tmp_path / 'missing'), {}) is None
+    # and the parent of `bench.py --gpus N` has not loaded torch (the module's import alone must not)
+    code = ('import sys, importlib.util; spec = importlib.util.spec_from_file_location("b", %r); m = importlib.util.module_from_spec(spec); '
+            'spec.loader.exec_module(m); m.count_gpus_without_hip(); print("torch" in sys.modules)' % os.path.join(root, 'bench.py'))
+    out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, timeout=120).stdout.decode().strip()
+    assert out == 'False', out
+
+
+def test_launcher_ends_the_other_ranks_when_one_fails(tmp_path):
+    """a rank > 0 that dies leaves rank 0 waiting in a collective; the launcher polls every child, kills the rest and returns the
+    failing code instead of hanging.  Stand-in children: bench.py's own launch_ranks run on a script whose rank 1 exits 7 and whose rank 0
+    would sleep for an hour."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'bench.py')).read()
+    child = tmp_path / 'bench.py'
+    # the launcher functions verbatim + a main that plays the ranks
+    head = src[:src.index('def main():')]
+    child.write_text(head + """
+def main():
+    if 'RANK' not in os.environ:
+        sys.exit(launch_ranks(2, []))
+    if os.environ['RANK'] == '1':
+        sys.exit(7)
+    time.sleep(3600)
+
+
+if __name__ == '__main__':
+    main()
+""")
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    env['RUMPY_BENCH_ONE_DEVICE'] = '1'
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(child)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 7 and time.time() - t0 < 60 and b'rank 1 exited with code 7' in p.stderr
+    env['RUMPY_BENCH_TIMEOUT'] = '2'
+    child.write_text(child.read_text().replace("sys.exit(7)", "time.sleep(3600)"))
+    p = subprocess.run([sys.executable, str(child)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 124

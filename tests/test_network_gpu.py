@@ -317,9 +317,11 @@ def test_fp16_evaluation_overflow_falls_back_to_bf16_plans():
 
 
 def test_kept_on_device_evaluation_defers_the_status_read_back_to_the_next_pass():
-    """run_eval(keep_on_device=True) reads nothing back on the host: the status words are staged behind the pass (pinned copy + event)
-    and examined at the next pass - an fp16 overflow is reported there and switches the following passes to bf16"""
+    """a caller that opted in (handler.defer_eval_status = True; bench.py's evaluation loop) reads nothing back on the host in
+    run_eval(keep_on_device=True): the status words are staged behind the pass (pinned copy + event) and examined at the next
+    pass - an fp16 overflow is reported there and switches the following passes to bf16"""
     h, oh = _pair('edsr', 511, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1)
+    h.defer_eval_status = True
     x, _ = O.synthetic_batch(641, 1, lr_hw=20, scale=2)
     out, _, _ = h.run_eval(x=x, keep_on_device=True)
     assert out.is_cuda and h.net.engine._flag_pending is not None and h.net.engine.eval_fmt == 1
@@ -336,6 +338,29 @@ def test_kept_on_device_evaluation_defers_the_status_read_back_to_the_next_pass(
     assert h.net.engine.eval_fmt == 0 and torch.isfinite(out2).all()
     oout, _, _ = oh.run_eval(x)
     assert float((out2 - oout).norm() / oout.norm()) < 2e-2
+
+
+def test_kept_on_device_evaluation_is_checked_before_the_image_is_handed_out():
+    """without the opt-in, run_eval(keep_on_device=True) - what SISRInterface.net_run_and_process calls - examines the status
+    words before it returns: an fp16 overflow is re-run in bf16, the caller never sees a non-finite image; the same per quadrant of the
+    tiled evaluation"""
+    h, oh = _pair('edsr', 511, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1)
+    x, _ = O.synthetic_batch(641, 1, lr_hw=20, scale=2)
+    with torch.no_grad():
+        h.net.head[0].weight.mul_(3e5)
+        oh.net.head[0].weight.mul_(3e5)
+    with pytest.warns(UserWarning, match='non-finite'):
+        out, _, _ = h.run_eval(x=x, keep_on_device=True)
+    assert out.is_cuda and torch.isfinite(out).all() and h.net.engine.eval_fmt == 0 and h.net.engine._flag_pending is None
+    oout, _, _ = oh.run_eval(x)
+    assert float((out.cpu() - oout).norm() / oout.norm()) < 2e-2
+    h2, _ = _pair('edsr', 511, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1, max_combined_im_size=400)
+    h2.defer_eval_status = True                 # not honoured by the quadrants
+    with torch.no_grad():
+        h2.net.head[0].weight.mul_(3e5)
+    with pytest.warns(UserWarning, match='non-finite'):
+        out2, _, _ = h2.run_eval(x=x, keep_on_device=True)
+    assert torch.isfinite(out2).all() and h2.net.engine._flag_pending is None and h2.defer_eval_status is True
 
 
 def test_evaluation_plan_cache_is_bounded():
@@ -777,7 +802,7 @@ def test_bench_starts_its_own_ranks_when_called_plainly():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     env.update(RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    for form, want in (('auto', 'inline'), ('early', 'early')):
+    for form, want in (('auto', None), ('early', 'early')):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
                '--no-cpu-baseline', '--allreduce-form', form]
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
@@ -787,7 +812,13 @@ def test_bench_starts_its_own_ranks_when_called_plainly():
         assert len(lines) == 1, out[-3000:]
         d = json.loads(lines[0])
         assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0
-        assert d['distributed']['world_size'] == 2 and d['distributed']['allreduce_form'] == want
+        assert d['distributed']['world_size'] == 2
+        if form == 'auto':       # no form forced: both are timed inside the one process group, the faster one is the line's value
+            forms = d['distributed']['forms']
+            assert set(forms) == {'inline', 'early'} and d['distributed']['allreduce_form'] in forms
+            assert abs(d['ms_per_step'] - min(forms.values())) < 1e-3
+        else:
+            assert d['distributed']['allreduce_form'] == want and d['distributed']['forms'] is None
 
 
 @pytest.mark.parametrize('name,kw,N', [
@@ -852,7 +883,16 @@ def test_bench_runs_over_rccl_with_one_rank(model, early):
     assert q.returncode == 0, q.stdout.decode()[-3000:]
     e = json.loads([l for l in q.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
     assert d['n_gpus'] == 1 and d['value'] > 0
-    assert d['config']['loss'] == e['config']['loss'], (d['config']['loss'], e['config']['loss'])
+    if early:
+        assert d['distributed']['forms'] is None and d['distributed']['allreduce_form'] == 'early'
+        assert d['config']['loss'] == e['config']['loss'], (d['config']['loss'], e['config']['loss'])
+    else:
+        # no form forced: the region is timed twice inside the one process group (inline, then early); the first pass runs the same
+        # W + K steps as the plain run
+        forms = d['distributed']['forms']
+        assert set(forms) == {'inline', 'early'} and d['distributed']['allreduce_form'] in forms
+        assert abs(d['ms_per_step'] - min(forms.values())) < 1e-3
+        assert d['distributed']['forms_loss']['inline'] == e['config']['loss'], (d['distributed']['forms_loss'], e['config']['loss'])
 
 
 @pytest.mark.parametrize('name,kw,N,hw', [('edsr', dict(scale=4, num_blocks=3), 4, 24), ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16), 3, 20),
