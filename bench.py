@@ -25,6 +25,7 @@ FLOP_PER_PATCH_TRAIN = 27.407e9      # EDSR-baseline x4 @48x48, 
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # MI355X dense bf16 (MI355X_MICROARCH.md)
+MFMA_FP8_PEAK_TFLOPS = 5000.0        # MI355X dense fp8 (--precision fp8: the block kernels' sweeps run on v_mfma_scale_f32_16x16x128_f8f6f4)
 SCHED = {'t_mult': 1, 'restart_period': 40000, 'lr_min': 1e-7}
 
 
@@ -391,6 +392,9 @@ def main():
     ap.add_argument('--lr-size', type=int, default=48, help='LR patch side of the training step (48 = the headline metric; the reference\'s shipped '
                                                             'div2k configs crop 64: --lr-size 64 --batch 8 is div2k/rcan.toml)')
     ap.add_argument('--mode', choices=('train', 'eval'), default='train', help='eval = whole-image evaluation forward (information)')
+    ap.add_argument('--precision', choices=('bf16', 'fp8'), default='bf16',
+                    help="training arithmetic of the one-launch residual-block / RCAB kernels: bf16 (default, the headline metric) or the fp8 opt-in "
+                         "(block-scaled fp8 MFMA; BASELINE config 5; its own accuracy class, DESIGN.md 2.2) - for information, never the headline")
     ap.add_argument('--eval-size', type=int, nargs=2, default=(339, 510), metavar=('H', 'W'), help='LR image of --mode eval')
     ap.add_argument('--allreduce-form', choices=('auto', 'inline', 'early', 'side'), default='auto',
                     help='data-parallel runs: how the gradient all-reduce is issued (auto = early half for >= 4 M gradient elements, else one '
@@ -449,6 +453,10 @@ def main():
     BLIND = dict(style='standard', include_q_layer=True, selective_meta_blocks=[True] + [False] * 9, num_q_layers_inner_residual=1)
     extra = {'qrcan': dict(style='standard', include_q_layer=True, metadata=['m%d' % i for i in range(5)]),
              'blindqrcan': dict(block_encoder_loading=True, **BLIND), 'edsr256': dict(num_features=256, num_blocks=32, res_scale=0.1)}.get(args.model, {})      # encoder weights: random init (no checkpoint offline)
+    fp8 = args.precision == 'fp8'
+    if fp8:
+        extra = dict(extra, precision='fp8')
+    mfma_peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS      # the dominant kernel's matrix instruction
     h = define_model({'blindqrcan': 'contrastiveblindqrcan', 'edsr256': 'edsr'}.get(args.model, args.model), model_save_dir=tempfile.mkdtemp(), device=local_rank,
                      eval_mode=False, checkpoint_load=False, loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
                      scheduler_params=SCHED, **extra)
@@ -575,6 +583,8 @@ def main():
                 tensors = [2 + sum(1 for f in ('t', 'res2') if getattr(a, f)) + (1 if (a.mask and not a.maskbits) else 0) for a in blocks] + \
                           [2 + sum(1 for f in ('t', 't2', 't2_in', 'res2') if getattr(a, f)) + (1 if (a.mask and not a.maskbits) else 0) for a in rcabs]
                 kname = 'conv_block_kernel (residual block: two 3x3 convs 64->64 per launch, fwd + data-gradient launches)'
+                if fp8 and blocks and all(a.w1_f8 for a in blocks):
+                    kname = 'conv_block_fp8_kernel (residual block per launch, both sweeps on the block-scaled fp8 MFMA; fwd + data-gradient launches)'
                 if rcabs:
                     kname = 'rcab_kernel (residual channel-attention block per launch: two 3x3 convs 64->64 + attention gate; fwd + bwd launches)'
             else:
@@ -584,21 +594,21 @@ def main():
                            if name == 'rumpy_conv3x3' and a.cin_chunks == 1 and a.cout_tiles == 1 and a.out_mode == 0]
                 kname = 'conv3x3_strip_kernel (3x3 conv 64->64, fwd + dgrad launches)'
             alg_bytes = tensor_bytes * sum(tensors) / max(1, len(tensors))
-            t_mfma, t_hbm = flop / (MFMA_BF16_PEAK_TFLOPS * 1e12), alg_bytes / (HBM_PEAK_GBPS * 1e9)
+            t_mfma, t_hbm = flop / (mfma_peak * 1e12), alg_bytes / (HBM_PEAK_GBPS * 1e9)
             tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
             common = {'kernel': kname,
                       'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch, 'launches_per_step': len(tensors),
                       'algorithmic_gflop_per_launch': round(flop / 1e9, 3), 'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
-                      'mfma': {'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4)},
+                      'mfma': {'achieved': round(tflops, 2), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                               'frac': round(tflops / mfma_peak, 4)},
                       'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}
             # the launch sits at the ridge (C = 64): the binding roof is whichever limit takes longer for one launch
-            if t_hbm >= t_mfma:
+            if t_hbm >= t_mfma and not fp8:      # (the fp8 line keeps the matrix-pipe view beside the bf16 line's; `hbm` is next to it)
                 roofline = {'bound': 'hbm', 'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                             'frac': round(gbps / HBM_PEAK_GBPS, 4), 'traffic': None}
             else:
-                roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None}
+                roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                            'frac': round(tflops / mfma_peak, 4), 'traffic': None}
             roofline.update(common)
             # HBM bytes per launch from the PMC passes committed under profiles/ (not re-measured here; null when the kernel changed since)
             kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else 'rcab_kernel' if rcabs else 'conv_block_kernel'
@@ -665,7 +675,8 @@ def main():
     if rank == 0:
         line = {'metric': '%dpx LR patches/sec (train step) %s x4 bf16' % (P, args.model.upper()), 'value': round(value, 2), 'unit': 'LR patches/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'fp8 (e4m3 forward / e5m2 gradient MFMA operands of the residual-block launches, fp32 accumulation; bf16 storage and bf16 MFMA elsewhere)' if fp8 else 'bf16',
                 'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
                          'random-init weights (seed 8)') if args.device_patches else
                         'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
@@ -673,7 +684,8 @@ def main():
                                        ' train step, %dx%d LR patches, batch %d per GPU' % (P, P, N),
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),
-                           'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4)},
+                           'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4),      # (whole step, against the bf16 peak)
+                           'precision': args.precision},
                 'roofline': roofline, 'cpu_baseline': cpu, 'as_called': as_called,
                 # what the collectives really ran on (the driver's scaling run can check that RCCL saw N ranks on N devices)
                 'distributed': {'world_size': dist.get_world_size() if dp else 1, 'backend': dist.get_backend() if dp else None,

@@ -111,8 +111,34 @@ typedef struct {
   int32_t fmt;         /* RUMPY_FMT_*; F16 for the forward forms (ResBlock: relu1 = 1, scale1 = 1, no mask; RCAB: res_mode 1 / 2) */
   int32_t col_tile;    /* 0: automatic (one strip across the image up to W = 48, column tiles of 32 or 48 columns beyond);
                           2 / 3: column tiles of 32 / 48 columns whatever W (tests: the two geometries against each other); not with `pool` */
+  /* ABI 4 - precision 'fp8' (BASELINE.json config 5: "fp8 MFMA conv"; an opt-in of its own accuracy class).  With w1_f8
+   * set, both sweeps of the launch run on the block-scaled fp8 MFMA (conv_block_fp8.hip): ResBlock forward form (relu1 = 1) or its
+   * mask-byte data-gradient form (relu1 = 0, maskbits), W <= 48, res_mode 0, bf16 tensors in HBM as before; w1 / w2 are not read. */
+  const void* w1_f8;        /* fp8 filter images of rumpy_fp8_pack (forward images, or the data-gradient images of conv2 / conv1), or NULL */
+  const void* w2_f8;
+  const uint32_t* f8_sw1;   /* their e8m0 scale exponents (rumpy_fp8_pack_item.exponent of the same conv) */
+  const uint32_t* f8_sw2;
+  uint32_t* f8_site;        /* this launch's record of RUMPY_FP8_SITE_WORDS words: [0] / [1] exponents of the X / T images (read; written by
+                               rumpy_fp8_rotate), [2 .. 9] / [10 .. 17] amax of X / T as fp32 bit patterns (atomic max by the launch) */
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
+
+/* ---- precision 'fp8': filter images and delayed scaling, all on the device (conv_block_fp8.hip) ----
+ * rumpy_fp8_pack: for every item, fp32 OIHW [64][64][3][3] master filter -> e4m3 images in the order the block-scaled MFMA sweeps read
+ *   (forward and data-gradient image, 40960 bytes each) of w / 2^(e - 127), one exponent e per conv such that amax / scale is in [128, 256);
+ *   e -> *exponent.  After every optimizer step / weight load (replaces nothing in the reference: torch has no fp8 conv; call site of the
+ *   arithmetic it feeds: common.py:6-9 default_conv).
+ * rumpy_fp8_rotate: n site records: exponent of each image tensor <- from the amax its launch left in the previous pass, amax cleared. */
+#define RUMPY_FP8_SITE_WORDS 18
+#define RUMPY_FP8_IMAGE_BYTES 40960
+typedef struct {
+  const float* w;
+  void* img_fwd;            /* may be NULL */
+  void* img_dgrad;          /* may be NULL */
+  uint32_t* exponent;
+} rumpy_fp8_pack_item;
+int rumpy_fp8_pack(const rumpy_fp8_pack_item* items, int32_t n, void* stream);
+int rumpy_fp8_rotate(void* sites, int32_t n, void* stream);
 int rumpy_block_pool_tiles(int32_t H, int32_t W);   /* rows of `pool` per image: 2 * ceil(H/6) * column tiles */
 
 /* ---- a whole residual channel-attention block per launch (conv_rcab.hip): RCAB, rumpy/SISR/models/advanced/architectures.py:60-84, and

@@ -25,6 +25,10 @@ int rumpy_debug_conv_stamps(const rumpy_conv_args* a, void* stream);
  * collective on a side stream) that occupies CUs while the product kernels run (tests/test_network_gpu.py) */
 int rumpy_debug_occupy(int32_t blocks, float microseconds, void* stream);
 
+/* out[2 i] / out[2 i + 1] = the OCP e4m3 / e5m2 byte the hardware conversion gives for in[i] / scale (tests/test_fp8_gpu.py pins rounding and
+ * saturation, which the delayed scaling of precision 'fp8' relies on) */
+int rumpy_fp8_convert(const float* in, float scale, void* out, int32_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,18 @@ class HipSRNet(nn.Module):
         self._packed_version = None
         self._flatten()
 
+    def set_precision(self, precision):
+        """None / 'bf16': the default training arithmetic.  'fp8': the one-launch residual-block / RCAB kernels of training plans run their
+        3x3 sweeps on the block-scaled fp8 MFMA (BASELINE config 5; its own accuracy class).  Evaluation plans are unaffected."""
+        if precision not in (None, 'bf16', 'fp8'):
+            raise RuntimeError("rumpy_amd: precision is None, 'bf16' or 'fp8' (got %r)" % (precision,))
+        self.precision = None if precision == 'bf16' else precision
+        if self.engine is not None and self.precision == 'fp8':
+            self.engine.enable_fp8()
+        elif self.engine is not None and getattr(self.engine, 'fp8', False):
+            self.engine = None          # back to bf16: a fresh engine (plans are rebuilt)
+            self._packed_version = None
+
     # ---- flat parameter storage ----
     def _flatten(self):
         dev = self.param_list[0].device
@@ -257,6 +269,8 @@ class HipSRNet(nn.Module):
                                'there is no CPU path (parameters are on %s)' % self.flat_p.device)
         if self.engine is None:
             self.engine = SREngine(self._spec(), self.flat_p.device)
+            if getattr(self, 'precision', None) == 'fp8':
+                self.engine.enable_fp8()
             if self.engine.use_finish and all(p.requires_grad for p in self.param_list):
                 self.engine.build_update_table(self.flat_p, self.param_list, self.offsets)
         v = self._weights_version()

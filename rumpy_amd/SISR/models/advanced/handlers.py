@@ -70,12 +70,14 @@ class EDSRHandler(_TiledEval):
 
     def __init__(self, device, model_save_dir, eval_mode=False, lr=1e-4, scale=4, in_features=3, hr_data_loc=None,
                  scheduler=None, scheduler_params=None, perceptual=None,
-                 num_features=64, num_blocks=16, res_scale=0.1, max_combined_im_size=None, **kwargs):
+                 num_features=64, num_blocks=16, res_scale=0.1, max_combined_im_size=None, precision=None, **kwargs):
+        # precision (not a reference kwarg): None = bf16 training arithmetic; 'fp8' = residual blocks on the block-scaled fp8 MFMA (opt-in)
         self.max_combined_im_size, self.scale = max_combined_im_size, scale
         super(EDSRHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode,
                                           hr_data_loc=hr_data_loc, **kwargs)
         self.net = EDSR(scale=scale, in_features=in_features, net_features=num_features, num_blocks=num_blocks,
                         res_scale=res_scale)
+        self.net.set_precision(precision)
         self.colorspace = 'rgb'
         self.im_input = 'unmodified'
         self.activate_device()
@@ -87,10 +89,11 @@ class RCANHandler(_TiledEval):
     """RCAN on hand-written gfx950 kernels (reference RCANHandler, handlers.py:28-42; extra kwargs reach RCAN(**kwargs))."""
 
     def __init__(self, device, model_save_dir, eval_mode=False, lr=1e-4, scale=4, in_features=3, perceptual=None,
-                 scheduler=None, scheduler_params=None, max_combined_im_size=None, **kwargs):
+                 scheduler=None, scheduler_params=None, max_combined_im_size=None, precision=None, **kwargs):
         self.max_combined_im_size, self.scale = max_combined_im_size, scale
         super(RCANHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode, **kwargs)
         self.net = RCAN(scale=scale, in_feats=in_features, **kwargs)
+        self.net.set_precision(precision)
         self.colorspace = 'rgb'
         self.im_input = 'unmodified'
         self.activate_device()

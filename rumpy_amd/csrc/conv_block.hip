@@ -400,7 +400,15 @@ extern "C" int rumpy_block_pool_tiles(int32_t H, int32_t W) {
   return 2 * ((H + BSH - 1) / BSH) * ct_n;
 }
 
+int rumpy_conv_block_fp8_launch(const rumpy_block_args* p, hipStream_t s);      // conv_block_fp8.hip
+
 extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
+  if (p && p->w1_f8) {
+    if (!p->x || !p->out || p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("rumpy_conv_block: null pointer / bad shape"); return RUMPY_E_ARG; }
+    if ((int64_t)p->N * p->H * p->W * 64 >= (int64_t)0xffffffffu) { rumpy_set_error("rumpy_conv_block: tensor beyond 32-bit element offsets"); return RUMPY_E_ARG; }
+    const int rc = rumpy_conv_block_fp8_launch(p, (hipStream_t)stream);
+    return rc ? rc : rumpy_check_launch("rumpy_conv_block");
+  }
   if (!p || !p->x || !p->w1 || !p->w2 || !p->out) { rumpy_set_error("rumpy_conv_block: null pointer"); return RUMPY_E_ARG; }
   if (p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("rumpy_conv_block: bad shape (N=%d H=%d W=%d)", p->N, p->H, p->W); return RUMPY_E_ARG; }
   if ((int64_t)p->N * p->H * p->W * 64 >= (int64_t)0xffffffffu) { rumpy_set_error("rumpy_conv_block: tensor beyond 32-bit element offsets"); return RUMPY_E_ARG; }

@@ -1,0 +1,527 @@
+// precision = 'fp8' (BASELINE config 5 names "fp8 MFMA conv"): the residual block of conv_block.hip with BOTH 3x3 sweeps on the block-scaled
+// fp8 matrix instruction of gfx950, v_mfma_scale_f32_16x16x128_f8f6f4 - an opt-in of its own accuracy class, never the default.
+//
+//   FORM 1, forward (training or inference):  T = relu(conv1(X) + b1)            OUT = X + s * (conv2(T) + b2)
+//   FORM 3, data gradient:                    GT = maskbits . s * conv2^T(G)     GX  = G + conv1^T(GT) [+ res2]
+//
+// What is fp8 and what is not.  Only the two operands of the matrix pipe: the filter images (OCP e4m3, one power-of-two scale per conv, packed
+// by rumpy_fp8_pack after every optimizer step) and the activation / gradient images the sweeps read from LDS (e4m3 forward, e5m2 backward; one
+// power-of-two scale per tensor).  Products are exact, accumulation is fp32.  Bias, ReLU, res_scale, the ReLU mask, the residual operand, every
+// tensor in HBM (X, T, OUT stay bf16 - the weight gradients and the neighbouring launches read them) and the optimizer are those of the bf16 path.
+// The scales travel through the instruction's e8m0 scale operands, so no value is ever multiplied by a scale in software.
+//
+// Scale management = delayed scaling, device side only.  A launch reads the e8m0 exponents of its two image tensors from its `site` record and
+// leaves the amax of both (as the values really were this step) in eight sub-slots of the same record (one per XCD: 64 atomics per address and
+// launch); rumpy_fp8_rotate, one small launch in front of every pass, turns last step's amax into this step's exponent such that amax / scale
+// lies in [128, 256) - 1.75 x growth from one step to the next still fits e4m3 (448), far more fits e5m2 - and clears the slots.  The host
+// never reads a scale.  The first pass of a plan runs twice (once to measure; rumpy_amd/engine.py).
+//
+// Geometry = conv_block.hip's W <= 48 geometry (one 6-row strip across the image per 512-thread workgroup, wave (q, rh) = output channels 16 q ..
+// of one row half, row-half gates instead of workgroup barriers, whole-line non-temporal stores from LDS images).  What differs (measured first as
+// tests/tools/fp8/conv_block_fp8.hip in round 3: 11.0 against 13.8 us per inference-form launch):
+//  * LDS holds fp8 images of X (10 x 50 pixels) and T (8 x 50): 64 bytes per pixel, 16-byte chunk index XOR-ed with 2 * ((pixel >> 2) & 1)
+//    (conflict-free ds_read_b128 of chunk g of 16 consecutive pixels); a bf16 image of the strip's own 6 x 48 pixels of X (residual operand; OUT
+//    is written over it and leaves from there) and one of T (leaves for HBM from there; training).  131 KB.  X is converted while its tile is
+//    staged, T in the first phase's epilogue (v_cvt_scalef32_pk_{fp8,bf8}_f32) - never inside a sweep.
+//  * One MFMA has K = 128 = two taps x 64 channels; lane (pixel px, group g) supplies 32 bytes.  The 9 taps of an output tile are 5 MFMAs:
+//      P[ky]  (3x): taps (ky, kx 0 | kx 1): lane bytes 0-15 = channels 16 g .. of the pixel at kx 0, bytes 16-31 = the same channels at kx 1 - a
+//                   fragment is an image ROW property, shared by the three output rows it feeds (as in the bf16 sweep);
+//      Q01        : taps (ky 0 | ky 1, kx 2): lanes g < 2 read the pixel of row r, lanes g >= 2 the pixel of row r + 1, channels 32 (g & 1) ..;
+//      Q2         : tap (ky 2, kx 2) | nothing: bytes 0-15 = channels 16 g .., bytes 16-31 meet zeros in the filter image.
+//    (tests/tools/fp8/fp8_probe.hip: any lane / byte -> k assignment works as long as both operands use the same one.)  5 MFMAs of 32 cycles
+//    against 18 of 16: 0.56 of the matrix-pipe time, and 0.6 of the LDS fragment bytes.
+#include "block_common.hpp"
+
+typedef int f8_v8i __attribute__((ext_vector_type(8)));
+typedef int f8_v4i __attribute__((ext_vector_type(4)));
+typedef short f8_v2s __attribute__((ext_vector_type(2)));
+
+constexpr int F8_C16 = BSH * BSW * 128;            // 36864: a strip's own pixels as a bf16 image
+constexpr int F8_X8 = BXROWS * BCOLS * 64;         // 32000
+constexpr int F8_T8 = BTROWS * BCOLS * 64;         // 25600
+constexpr int F8_OFF_X8 = F8_C16, F8_OFF_T8 = F8_C16 + F8_X8, F8_OFF_T16 = F8_C16 + F8_X8 + F8_T8;
+constexpr int F8_LDS = F8_OFF_T16 + F8_C16;        // 131328
+
+struct BlockF8Dev {
+  const uint16_t* x; const f8_v8i* w1; const float* b1; const f8_v8i* w2; const float* b2;
+  const uint16_t* res2; uint16_t* t; uint16_t* out; unsigned char* mbits;
+  int N, H, W, sy_n; float scale1, scale2;
+  const unsigned* sw1; const unsigned* sw2;        // e8m0 exponents of the two filter images (rumpy_fp8_pack)
+  unsigned* site;                                  // RUMPY_FP8_SITE_WORDS words: [0] exponent of the X image, [1] of the T image, [2 .. 9] amax slots X, [10 .. 17] T
+};
+
+__device__ __forceinline__ unsigned f8_swz(int p, int quarter) { return (unsigned)(p * 64 + ((quarter ^ (((p >> 2) & 1) << 1)) << 4)); }
+
+// 8 fp32 -> 8 fp8 bytes of value / scale (E5M2 = false: OCP e4m3, true: e5m2); round to nearest even, saturating (checked on the hardware:
+// tests/test_fp8_gpu.py::test_fp8_conversions_saturate)
+template <bool E5M2>
+__device__ __forceinline__ uint2 f8_pack8(const float (&f)[8], float scale) {
+  f8_v2s a = {0, 0}, b = {0, 0};
+  if (E5M2) {
+    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(a, f[0], f[1], scale, false);
+    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(a, f[2], f[3], scale, true);
+    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(b, f[4], f[5], scale, false);
+    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(b, f[6], f[7], scale, true);
+  } else {
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, f[0], f[1], scale, false);
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, f[2], f[3], scale, true);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(b, f[4], f[5], scale, false);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(b, f[6], f[7], scale, true);
+  }
+  return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+
+// A = filter fragment (always e4m3), B = image fragment (e4m3 or e5m2); sa / sb = e8m0 exponents, uniform over the lanes
+template <bool E5M2>
+__device__ __forceinline__ f32x4 f8_mfma(f8_v8i a, f8_v8i b, f32x4 c, int sa, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, E5M2 ? 1 : 0, 0, sa, 0, sb);
+}
+
+// max over the wave, in every lane (values >= 0): the butterflies of common.hpp::wave64_sum with max
+__device__ __forceinline__ float f8_wave_max(float t, int lane) {
+  t = fmaxf(t, dpp_quad1(t)); t = fmaxf(t, dpp_quad2(t)); t = fmaxf(t, dpp_half_mirror(t)); t = fmaxf(t, dpp_row_mirror(t));
+  t = fmaxf(t, lane_xor16(t, lane >> 4));
+  t = fmaxf(t, lane_xor32(t, lane));
+  return t;
+}
+
+// bases of the three fragment kinds for window row 0 = image row `row0` of the fp8 image at byte `buffer`:
+//   fb[d]: chunk g of pixel (row0, px) for XOR class d ; hb[d]: chunk 2 (g & 1) of pixel (row0 + (g >> 1), px + 2)
+__device__ __forceinline__ void f8_bases(unsigned (&fb)[8], unsigned (&hb)[8], unsigned buffer, int row0, int px, int g) {
+  const int p0 = row0 * BCOLS + px, ph = (row0 + (g >> 1)) * BCOLS + px + 2;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    fb[d] = buffer + (unsigned)(p0 * 64 + ((g ^ ((((p0 + d) >> 2) & 1) << 1)) << 4));
+    hb[d] = buffer + (unsigned)(ph * 64 + (((2 * (g & 1)) ^ ((((ph + d) >> 2) & 1) << 1)) << 4));
+  }
+}
+
+// hook(i), i = 0 .. 8, runs after the MFMAs of step i have been issued (the HBM stores of the previous phase's tile travel there)
+template <int ROWS, bool E5M2, class Hook = NoHook>
+__device__ __forceinline__ void f8_sweep(f32x4 (&acc)[ROWS][3], const f8_v8i (&A)[5], const unsigned char* lds, const unsigned (&fb)[8],
+                                         const unsigned (&hb)[8], int sa, int sb, Hook hook = Hook()) {
+  f8_v8i F[ROWS + 2], Hh[ROWS], G[ROWS];
+  auto ld16 = [&](unsigned addr) { return *reinterpret_cast<const f8_v4i*>(lds + addr); };
+  auto load_f = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < ROWS + 2; ++r) {
+      const int k0 = r * BCOLS + 16 * c, k1 = k0 + 1;
+      const f8_v4i lo = ld16(fb[k0 & 7] + k0 * 64), hi = ld16(fb[k1 & 7] + k1 * 64);
+      F[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    }
+  };
+  auto load_h = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int k = r * BCOLS + 16 * c;                    // (the + 2 columns and the lane's row are in hb)
+      const f8_v4i lo = ld16(hb[k & 7] + k * 64), hi = ld16(hb[k & 7] + k * 64 + 16);
+      Hh[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    }
+  };
+  auto load_g = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int k = (r + 2) * BCOLS + 16 * c + 2;
+      const f8_v4i lo = ld16(fb[k & 7] + k * 64);
+      G[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, 0, 0, 0, 0};     // the filter image's second half is zero for this MFMA
+    }
+  };
+  load_f(0);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    load_h(c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[ky], F[r + ky], acc[r][c], sa, sb);
+    hook(3 * c);
+    load_g(c);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[3], Hh[r], acc[r][c], sa, sb);
+    hook(3 * c + 1);
+    if (c + 1 < 3) load_f(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[4], G[r], acc[r][c], sa, sb);
+    hook(3 * c + 2);
+  }
+}
+
+// a row half's 3 strip rows of a 6 x 48-pixel bf16 image as 16-byte pieces (block_common.hpp::group_stage for an image without halo)
+__device__ __forceinline__ void f8_stage48(uint4 (&S)[GROUP_REGS], const unsigned char* img, int tg, int rh) {
+#pragma unroll
+  for (int i = 0; i < GROUP_REGS; ++i) {
+    const int p = tg + 256 * i, pix = (p < GROUP_PIECES ? p : 0) >> 3;
+    S[i] = *reinterpret_cast<const uint4*>(img + swz(3 * rh * BSW + pix, p & 7));
+  }
+}
+
+__device__ __forceinline__ int f8_exp(unsigned word) { const int e = (int)(word & 255u); return e ? e : 127; }
+
+template <int FORM>
+__global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev a) {
+  constexpr bool E5M2 = FORM == 3;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[F8_LDS];
+  __shared__ unsigned gate[4];
+  __shared__ unsigned amax_s[2];
+  __shared__ __attribute__((aligned(16))) unsigned char ldummy[64 * 16];
+  unsigned char* const lc16 = lds;
+  unsigned char* const lx8 = lds + F8_OFF_X8;
+  unsigned char* const lt8 = lds + F8_OFF_T8;
+  unsigned char* const lt16 = lds + F8_OFF_T16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int px = lane & 15, g = lane >> 4;
+  const int q = wave & 3, rh = __builtin_amdgcn_readfirstlane(wave >> 2), tg = tid & 255;
+  const int strip = xcd_strip(blockIdx.x, gridDim.x);
+  const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+  const int sbx = f8_exp(a.site[0]), sbt = f8_exp(a.site[1]);
+  const int sa1 = f8_exp(*a.sw1), sa2 = f8_exp(*a.sw2);
+  const float x_scale = __uint_as_float((unsigned)sbx << 23), t_scale = __uint_as_float((unsigned)sbt << 23);
+  float am_x = 0.f, am_t = 0.f;
+  const bool t_keep = a.t != nullptr;
+
+  // ---- phase 0: input tile -> fp8 image (matrix operand); its centre 6 x 48 pixels also as they are (residual operand) ----
+  {
+    uint4 R[BREGS];
+    const int y0 = sy * BSH - 2;
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+      const int y = y0 + lr, x = lc - 1;
+      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
+      uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      R[i] = v;
+    }
+    if (tid < 4) gate[tid] = 0u;
+    if (tid < 2) amax_s[tid] = 0u;
+    if (tid < BTROWS * 2 * 4) {           // border columns of the T image: the second conv's zero padding
+      const int row = tid >> 3, side = (tid >> 2) & 1, quarter = tid & 3;
+      *reinterpret_cast<uint4*>(lt8 + f8_swz(row * BCOLS + side * (BCOLS - 1), quarter)) = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      if (p < BPIECES) {
+        const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+        if (lr >= 2 && lr < 2 + BSH && lc >= 1 && lc <= BSW) *reinterpret_cast<uint4*>(lc16 + swz((lr - 2) * BSW + lc - 1, part)) = R[i];
+        float f[8];
+        unpack8(R[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) am_x = fmaxf(am_x, fabsf(f[j]));
+        *reinterpret_cast<uint2*>(lx8 + f8_swz(pix, part >> 1) + (part & 1) * 8) = f8_pack8<E5M2>(f, x_scale);
+      }
+    }
+  }
+  f8_v8i A[5];
+  {
+    const f8_v8i* wp = a.w1 + (size_t)q * 5 * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) A[t] = wp[t * 64];
+  }
+  const int c0 = 16 * q + 4 * g;
+  const int gpair = 4 * (g & ~1);
+  const int chunk8 = 2 * q + (gpair >> 3);
+  __syncthreads();
+
+  // ---- phase 1: T rows j = 4rh .. 4rh+3 (image rows 6sy-1+j) ----
+  {
+    f32x4 acc[4][3];
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.b1) { const float4 t = *reinterpret_cast<const float4*>(a.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    // FORM 3: the ReLU mask bytes of this lane's pixels (conv_block.hip: one byte per 8 channels), requested before the sweep
+    unsigned MB[FORM == 3 ? 6 : 1];
+    if (FORM == 3) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+        const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+        const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
+        MB[FORM == 3 ? k : 0] = a.mbits[in ? (unsigned)(((n * a.H + y) * a.W + xx) * 8 + chunk8) : 0u];
+      }
+    }
+    unsigned fb[8], hb[8];
+    f8_bases(fb, hb, (unsigned)F8_OFF_X8, 4 * rh, px, g);
+    f8_sweep<4, E5M2>(acc, A, lds, fb, hb, sa1, sbx);
+    {
+      const f8_v8i* wp = a.w2 + (size_t)q * 5 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 5; ++t) A[t] = wp[t * 64];
+    }
+    // the epilogue's addresses and predicates are lane constants: left to itself the compiler computes all of them above the sweep and carries
+    // them through it (the sweep runs at 230 of 256 registers: 110 spilled registers, most of them inside the MFMA loop).  Tying the lane's
+    // pixel index to the last accumulator keeps that arithmetic behind the sweep.
+    int pxe = px, ge = g;
+    asm volatile("" : "+v"(pxe), "+v"(ge) : "v"(acc[3][2]));
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2];
+      const f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2];
+      float v[8];
+      pair_up(tx, ty, g, v);
+      const int jr = (k < 4) ? k : (2 * (k - 4) + (ge & 1)), c = (k < 4) ? (ge & 1) : 2;
+      const int j = 4 * rh + jr, xx = 16 * c + pxe;
+      const int y = sy * BSH - 1 + j;
+      const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
+      // branch-free (selects only): with real branches here LLVM sinks the last column's MFMAs into the epilogue's blocks and their fragments
+      // live - spilled - through all of it (440 bytes of scratch per lane in the first build)
+      if (FORM == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = in ? relu_f32(v[e]) : 0.f;
+      } else {
+        const unsigned mb = in ? MB[FORM == 3 ? k : 0] : 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] * a.scale1 : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) am_t = fmaxf(am_t, fabsf(v[e]));
+      const uint2 o8 = f8_pack8<E5M2>(v, t_scale);            // outside the image: zeros = the second conv's padding
+      const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+      const int gp = 4 * (ge & ~1);
+      *reinterpret_cast<uint2*>(lt8 + f8_swz(j * BCOLS + xx + 1, q) + gp) = o8;        // this wave's 16 channels = quarter q; 8 of them per lane
+      // the strip's own rows also as bf16 (what leaves for HBM); halo rows - and everything when T is not kept - go to a per-lane dummy slot
+      const bool own = t_keep & (j >= 1) & (j <= BSH);
+      *reinterpret_cast<uint4*>(own ? lt16 + swz((j - 1) * BSW + xx, 2 * q + (gp >> 3)) : ldummy + lane * 16) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    // the two amax values of this wave -> the workgroup's (read by the row halves' leaders at the end)
+    am_x = f8_wave_max(am_x, lane);
+    am_t = f8_wave_max(am_t, lane);
+    if (lane == 0) {
+      __hip_atomic_fetch_max(&amax_s[0], __float_as_uint(am_x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_max(&amax_s[1], __float_as_uint(am_t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    gate_arrive(&gate[rh], lane);          // this wave's 16 channels of T rows 4rh .. 4rh+3 are in LDS
+  }
+  gate_wait(&gate[rh], 4u);
+  if (rh == 1) gate_wait(&gate[0], 4u);
+  // (lane constants of the second phase - store offsets, fragment bases, staging addresses - are derived from copies of the lane ids made HERE:
+  // computed from the kernel's first instructions on, as the compiler would, they ride through the first sweep and spill its fragments)
+  int px2 = px, g2 = g, tg2 = tg;
+  asm volatile("" : "+v"(px2), "+v"(g2), "+v"(tg2) :: "memory");
+  unsigned soff[GROUP_REGS];
+#pragma unroll
+  for (int i = 0; i < GROUP_REGS; ++i) soff[i] = group_piece_off(i, tg2, rh, n, sy, a.H, a.W);
+  // the row half's own strip rows of T (and, forward, their ReLU mask bytes) leave for HBM from the finished bf16 image: whole lines, non-temporal,
+  // one piece after every other step of the second sweep
+  // ... issued HERE, in front of the second sweep (they drain under it): staged up front and stored one by one between the sweep's steps, as
+  // conv_block.hip does, the five pieces do not fit next to this sweep's fragments (scratch round trips), and stores inside the sweep are
+  // branches, which let LLVM sink MFMAs past them.
+  if (a.t) {
+    uint4 S[GROUP_REGS];
+    f8_stage48(S, lt16, tg2, rh);
+#pragma unroll
+    for (int i = 0; i < GROUP_REGS; ++i)
+      if (soff[i] != 0xffffffffu) {
+        st16_nt(a.t + soff[i], S[i]);
+        if (FORM == 1 && a.mbits) a.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+      }
+  }
+
+  // ---- phase 2: output rows 3rh .. 3rh+2 ; OUT = X + scale2 * (convB(T) + b2) [+ res2] ----
+  {
+    f32x4 acc[3][3];
+    f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.b2) { const float4 t = *reinterpret_cast<const float4*>(a.b2 + 16 * q + 4 * g2); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    unsigned fb[8], hb[8];
+    if (rh == 0) {
+      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 0, px2, g2);
+      f8_sweep<2, E5M2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, hb, sa2, sbt);   // output rows 0, 1 <- T rows 0 .. 3
+      gate_wait(&gate[1], 4u);
+      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 2, px2, g2);
+      f8_sweep<1, E5M2>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), A, lds, fb, hb, sa2, sbt);                                // output row 2 <- T rows 2 .. 4
+    } else {
+      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 3, px2, g2);
+      f8_sweep<3, E5M2>(acc, A, lds, fb, hb, sa2, sbt);                                           // output rows 3 .. 5 <- T rows 3 .. 7
+    }
+    int px3 = px2, g3 = g2;
+    asm volatile("" : "+v"(px3), "+v"(g3) : "v"(acc[2][2]));
+    const int gp3 = 4 * (g3 & ~1), ch3 = 2 * q + (gp3 >> 3), c03 = 16 * q + 4 * g3;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][2];
+      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][2];
+      float v[8], m[8];
+      pair_up(tx, ty, g3, v);
+      const int r = (k < 3) ? k : (g3 & 1), c = (k < 3) ? (g3 & 1) : 2;
+      const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px3;
+      // branch-free as well: a pixel outside the image computes on the zeros of its LDS slot and is never stored (soff)
+      const bool in = (y < a.H) & (xx < a.W);
+      unsigned char* const pp = lc16 + swz(srow * BSW + xx, ch3);
+      unpack8(*reinterpret_cast<const uint4*>(pp), m);                                            // residual = the input tile
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+      if (a.res2) {
+        unpack8(*reinterpret_cast<const uint4*>(a.res2 + (in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gp3) : 0u)), m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += m[j];
+      }
+      const uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+      *reinterpret_cast<uint4*>(pp) = make_uint4(lo.x, lo.y, hi.x, hi.y);                         // OUT image, in place of the input pixel
+    }
+    {
+      const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px3;
+      const bool in = (y < a.H) & (xx < a.W);
+      float v[4] = {acc[2][2][0], acc[2][2][1], acc[2][2][2], acc[2][2][3]};
+      float m[4];
+      unsigned char* const pp = lc16 + swz(srow * BSW + xx, 2 * q + (g3 >> 1)) + (g3 & 1) * 8;
+      unpack4_bf16(*reinterpret_cast<const uint2*>(pp), m);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], a.scale2, m[j]);
+      if (a.res2) {
+        unpack4_bf16(*reinterpret_cast<const uint2*>(a.res2 + (in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c03) : 0u)), m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += m[j];
+      }
+      *reinterpret_cast<uint2*>(pp) = pack4_bf16(v[0], v[1], v[2], v[3]);
+    }
+  }
+  gate_arrive(&gate[2 + rh], lane);
+  gate_wait(&gate[2 + rh], 4u);
+  {
+    uint4 S[GROUP_REGS];
+    f8_stage48(S, lc16, tg2, rh);
+#pragma unroll
+    for (int i = 0; i < GROUP_REGS; ++i)
+      if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
+  }
+  // this row half's amax (its four waves have added theirs in front of the gate) -> the site's slot of this XCD; the other half adds the rest
+  if (tg2 == 0) {
+    const unsigned slot = blockIdx.x & 7u;
+    atomicMax(a.site + 2 + slot, __hip_atomic_load(&amax_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    atomicMax(a.site + 10 + slot, __hip_atomic_load(&amax_s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+  }
+}
+
+int rumpy_conv_block_fp8_launch(const rumpy_block_args* p, hipStream_t s) {
+  const bool fwd = p->relu1 && p->scale1 == 1.0f && !p->mask;
+  const bool dgrad = !p->relu1 && p->maskbits && !p->b1;
+  if (!(fwd || dgrad) || p->res_mode != 0 || p->pool || p->fmt != RUMPY_FMT_BF16 || p->W > BSW || p->col_tile) {
+    rumpy_set_error("rumpy_conv_block: the fp8 images go with the ResBlock forward form or its mask-byte data-gradient form, bf16 tensors, W <= %d", BSW);
+    return RUMPY_E_ARG;
+  }
+  if (!p->w2_f8 || !p->f8_sw1 || !p->f8_sw2 || !p->f8_site) { rumpy_set_error("rumpy_conv_block: fp8 launch needs w1_f8, w2_f8, f8_sw1, f8_sw2 and f8_site"); return RUMPY_E_ARG; }
+  BlockF8Dev d;
+  d.x = (const uint16_t*)p->x; d.w1 = (const f8_v8i*)p->w1_f8; d.b1 = p->b1; d.w2 = (const f8_v8i*)p->w2_f8; d.b2 = p->b2;
+  d.res2 = (const uint16_t*)p->res2; d.t = (uint16_t*)p->t; d.out = (uint16_t*)p->out; d.mbits = (unsigned char*)p->maskbits;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = (p->H + BSH - 1) / BSH; d.scale1 = p->scale1; d.scale2 = p->scale2;
+  d.sw1 = p->f8_sw1; d.sw2 = p->f8_sw2; d.site = p->f8_site;
+  const dim3 grid(d.N * d.sy_n);
+  if (fwd) RUMPY_LAUNCH_PROBED(5, (conv_block_fp8_kernel<1>), grid, dim3(BTHREADS), s, d);
+  else RUMPY_LAUNCH_PROBED(5, (conv_block_fp8_kernel<3>), grid, dim3(BTHREADS), s, d);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// rumpy_fp8_pack: fp32 OIHW master filters of 64 -> 64 3x3 convs -> the kernel's filter images [q 4][mfma 5][lane 64][32 bytes], forward image
+// (A rows = output channels) and data-gradient image (the transposed, flipped filter: A rows = input channels), e4m3 of w / 2^(e - 127) with ONE
+// exponent e per conv chosen so that amax / scale lies in [128, 256); e goes to *exponent.  One workgroup per conv, after every optimizer step.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fp8_pack_kernel(const rumpy_fp8_pack_item* items) {
+  const rumpy_fp8_pack_item it = items[blockIdx.x];
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float am = 0.f;
+  for (int i = tid; i < 64 * 64 * 9; i += 256) am = fmaxf(am, fabsf(it.w[i]));
+  red[tid] = am;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) red[tid] = fmaxf(red[tid], red[tid + off]);
+    __syncthreads();
+  }
+  am = red[0];
+  int e = (int)((__float_as_uint(am) >> 23) & 255u) - 7;      // amax in [2^(E-127), 2^(E-126)) -> amax / 2^(E-134) in [128, 256)
+  if (am == 0.f || !(am < 3e38f)) e = 127;
+  e = e < 1 ? 1 : (e > 254 ? 254 : e);
+  if (tid == 0) *it.exponent = (unsigned)e;
+  const float scale = __uint_as_float((unsigned)e << 23);
+  // word i of an image = bytes 4 (i & 7) .. + 3 of (lane, mfma, q); fwd: row = output channel co, k = input channel ci, tap (ky, kx);
+  // dgrad: row = input channel, k = output channel, tap flipped
+  for (int img = 0; img < 2; ++img) {
+    unsigned* dst = reinterpret_cast<unsigned*>(img ? it.img_dgrad : it.img_fwd);
+    if (!dst) continue;
+    for (int i = tid; i < 4 * 5 * 64 * 8; i += 256) {
+      const int w4 = i & 7, lane = (i >> 3) & 63, m = (i >> 9) % 5, q = i / (5 * 64 * 8);
+      const int r = lane & 15, g = lane >> 4, row = 16 * q + r;
+      float f[4];
+#pragma unroll
+      for (int b4 = 0; b4 < 4; ++b4) {
+        const int b = 4 * w4 + b4;
+        int k, ky, kx;
+        bool zero = false;
+        if (m < 3) { ky = m; kx = b >> 4; k = 16 * g + (b & 15); }
+        else if (m == 3) { ky = g >> 1; kx = 2; k = 32 * (g & 1) + b; }
+        else { ky = 2; kx = 2; k = 16 * g + (b & 15); zero = b >= 16; }
+        float v = 0.f;
+        if (!zero) v = img ? it.w[((k * 64 + row) * 3 + (2 - ky)) * 3 + (2 - kx)] : it.w[((row * 64 + k) * 3 + ky) * 3 + kx];
+        f[b4] = v;
+      }
+      f8_v2s o = {0, 0};
+      o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(o, f[0], f[1], scale, false);
+      o = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(o, f[2], f[3], scale, true);
+      dst[i] = __builtin_bit_cast(unsigned, o);
+    }
+  }
+}
+
+extern "C" int rumpy_fp8_pack(const rumpy_fp8_pack_item* items, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (!items) { rumpy_set_error("rumpy_fp8_pack: null table"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(fp8_pack_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, items);
+  return rumpy_check_launch("rumpy_fp8_pack");
+}
+
+// rumpy_fp8_rotate: for `n` site records from `sites`: exponent of tensor k <- from the max of its eight amax slots (unchanged when nothing was
+// recorded), slots cleared.  In front of every pass that runs fp8 launches.
+__global__ void fp8_rotate_kernel(unsigned* sites, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n) return;
+  unsigned* rec = sites + (size_t)(i >> 1) * RUMPY_FP8_SITE_WORDS;
+  unsigned* slots = rec + 2 + 8 * (i & 1);
+  unsigned m = 0u;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { m = max(m, slots[s]); slots[s] = 0u; }
+  const int E = (int)((m >> 23) & 255u);
+  if (m != 0u && E != 255) {
+    int e = E - 7;
+    rec[i & 1] = (unsigned)(e < 1 ? 1 : (e > 254 ? 254 : e));
+  } else if ((rec[i & 1] & 255u) == 0u) {
+    rec[i & 1] = 127u;
+  }
+}
+
+extern "C" int rumpy_fp8_rotate(void* sites, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (!sites) { rumpy_set_error("rumpy_fp8_rotate: null table"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(fp8_rotate_kernel, dim3((2 * n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (unsigned*)sites, n);
+  return rumpy_check_launch("rumpy_fp8_rotate");
+}
+
+// test hook of the conversions' overflow behaviour (tests/test_fp8_gpu.py): out[2 i], out[2 i + 1] = the e4m3 / e5m2 byte of in[i] / scale
+__global__ void fp8_convert_kernel(const float* in, float scale, unsigned char* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f8_v2s a = {0, 0}, b = {0, 0};
+  a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, in[i], 0.f, scale, false);
+  b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(b, in[i], 0.f, scale, false);
+  out[2 * i] = (unsigned char)(__builtin_bit_cast(unsigned, a) & 255u);
+  out[2 * i + 1] = (unsigned char)(__builtin_bit_cast(unsigned, b) & 255u);
+}
+extern "C" int rumpy_fp8_convert(const float* in, float scale, void* out, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fp8_convert_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, scale, (unsigned char*)out, n);
+  return rumpy_check_launch("rumpy_fp8_convert");
+}

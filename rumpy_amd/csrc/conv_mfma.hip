@@ -206,10 +206,13 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
   // multiplied one after the other into the same accumulators.  This layer's weights shape the image itself: their fp16 rounding is a fixed
   // perturbation of the output, CORRELATED with the model's own error - it moved the Y-PSNR of 32 dB EDSRs by up to -0.034 dB (the other
   // layers' weight rounding: +0.006; all activation rounding together: 0.002; tests/tools/psnr_seeds.py).  HBM-bound kernel: free.
-  bf16x8 Flo[FMT == RUMPY_FMT_F16 ? 18 : 1];
+  // Round 4: the residual image lives in LDS (18 KB, lane-linear 16-byte fragments: conflict-free), not in 72 more registers - with both
+  // images in registers this build spilled 22 VGPRs to scratch (92 bytes per lane), and every reload sat in the vector-memory queue in front
+  // of the counted waits of the input pipeline: 239 us for the 354 MB of a DIV2K-size evaluation image (1.5 TB/s) where the bf16 build
+  // of the same kernel moves its bytes at 3.4 TB/s.
+  __shared__ __attribute__((aligned(16))) uint4 flo[FMT == RUMPY_FMT_F16 ? 18 * 64 : 1];
   if (FMT == RUMPY_FMT_F16) {
-#pragma unroll
-    for (int s = 0; s < 18; ++s) Flo[s % (FMT == RUMPY_FMT_F16 ? 18 : 1)] = as_bf16x8(a.w[(18 + s) * 64 + lane]);
+    for (int i = tid; i < 18 * 64; i += 256) flo[i % (FMT == RUMPY_FMT_F16 ? 18 * 64 : 1)] = a.w[18 * 64 + i];
   }
   float bj[4] = {0.f, 0.f, 0.f, 0.f};
   for (int j = 0; j < a.C; ++j) bj[j] = a.bias[j];
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) tail_fwd_kernel(TailDev a) {
 #pragma unroll
           for (int r = 0; r < 2; ++r) {
             acc[r] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[r + ky], acc[r]);
-            if (FMT == RUMPY_FMT_F16) acc[r] = mfma16<FMT>(Flo[((ky * 3 + kx) * 2 + half) % (FMT == RUMPY_FMT_F16 ? 18 : 1)], I[r + ky], acc[r]);
+            if (FMT == RUMPY_FMT_F16) acc[r] = mfma16<FMT>(as_bf16x8(flo[(((ky * 3 + kx) * 2 + half) * 64 + lane) % (FMT == RUMPY_FMT_F16 ? 18 * 64 : 1)]), I[r + ky], acc[r]);
           }
       }
     // all target values are consumed BEFORE the first store: with loads and stores pending together the compiler's

@@ -190,6 +190,76 @@ class SREngine:
                 cv.shuffle = False          # natural channel order; the permutation is its own pass
         self._alloc_packed()
         self.packed_version = None
+        # precision 'fp8' (BASELINE config 5; opt-in, enable_fp8): the one-launch residual-block kernels of TRAINING plans run both sweeps on the
+        # block-scaled fp8 MFMA (csrc/conv_block_fp8.hip).  Weight gradients, head / tail / upsampler / body-end convs, the optimizer and every
+        # evaluation plan are unchanged.
+        self.fp8 = False
+        self.f8_gen = -1
+        self._f8_items = None
+
+    # ------------------------------------------------------------------ precision 'fp8'
+    def enable_fp8(self):
+        """from now on training plans run their residual blocks on the fp8 matrix instruction (existing training plans are dropped)"""
+        if self.fp8:
+            return
+        if self.wide:
+            raise RuntimeError("rumpy_amd: precision 'fp8' is built for the 64-feature one-launch block kernels")
+        self.fp8 = True
+        for k in [k for k in self.plans if k[3]]:
+            old = self.plans.pop(k)
+            for ops in (old.fwd, old.bwd):
+                self._tables.pop(id(ops), None)
+        convs = []
+
+        def walk(items):
+            for it in items:
+                if it[0] == 'resblock':
+                    convs.extend([it[1], it[2]])
+                elif it[0] == 'group':
+                    walk(it[1])
+        walk(self.spec.body)
+        self.f8_wscale = torch.full((max(1, len(convs)),), 127, dtype=torch.int32, device=self.device)
+        items = []
+        for i, cv in enumerate(convs):
+            cv.w8_fwd = torch.empty(L.FP8_IMAGE_BYTES, dtype=torch.uint8, device=self.device)
+            cv.w8_dgrad = torch.empty(L.FP8_IMAGE_BYTES, dtype=torch.uint8, device=self.device)
+            cv.w8_scale = self.f8_wscale[i:i + 1]
+            items.append(L.Fp8PackItem(w=_ptr(cv.weight), img_fwd=_ptr(cv.w8_fwd), img_dgrad=_ptr(cv.w8_dgrad), exponent=_ptr(cv.w8_scale)))
+        self._f8_convs = convs
+        if items:
+            self._f8_items_host = (L.Fp8PackItem * len(items))(*items)
+            self._f8_items = (self._to_device_bytes(self._f8_items_host), len(items))
+
+    def _repack_f8(self, stream):
+        """bring the fp8 filter images (and their per-conv scale exponents) up to date with the master weights; no-op when nothing changed"""
+        if self._f8_items is not None and self.f8_gen != self.pack_gen:
+            L.check(self.lib.rumpy_fp8_pack(_ptr(self._f8_items[0]), self._f8_items[1], stream), 'rumpy_fp8_pack')
+            self.f8_gen = self.pack_gen
+
+    def _f8_site(self, plan, which):
+        """one record of RUMPY_FP8_SITE_WORDS words per fp8 launch of a plan (exponents of its two image tensors + their amax slots)"""
+        key = 'f8_' + which
+        buf = getattr(plan, key)
+        if buf is None:
+            n = max(1, len(self._f8_convs) // 2)
+            buf = torch.zeros(n, L.FP8_SITE_WORDS, dtype=torch.int32, device=self.device)
+            buf[:, 0:2] = 127
+            setattr(plan, key, buf)
+        i = getattr(plan, key + '_n')
+        setattr(plan, key + '_n', i + 1)
+        return buf[i].data_ptr()
+
+    def _f8_begin(self, plan, which, ops, stream):
+        """in front of a pass that contains fp8 launches: the first time the pass runs once to measure (every amax is taken from the values as
+        they are, whatever the scales), then - every time - last pass's amax becomes this pass's scale exponents (rumpy_fp8_rotate)"""
+        n = getattr(plan, 'f8_' + which + '_n')
+        if not n:
+            return
+        if not getattr(plan, 'f8_' + which + '_cal'):
+            setattr(plan, 'f8_' + which + '_cal', True)
+            self._run(ops, stream)
+            self._advance_epoch(plan, stream)
+        L.check(self.lib.rumpy_fp8_rotate(getattr(plan, 'f8_' + which).data_ptr(), n, stream), 'rumpy_fp8_rotate')
 
     # ------------------------------------------------------------------ packed filters
     def _alloc_packed(self):
@@ -346,6 +416,9 @@ class SREngine:
         plan.qca_items, plan.qca_dev = [], None      # gate MLPs of the styled QCALayers: parameter gradients in one launch
         plan.q_items, plan.q_shape, plan.q_dev = [], None, None
         plan.rcab_n, plan.rcab_xchg, plan.rcab_epoch, plan.rcab_status = 0, None, None, None
+        plan.f8_f = plan.f8_b = None              # fp8 site records of the forward / backward launches (precision 'fp8')
+        plan.f8_f_n = plan.f8_b_n = 0
+        plan.f8_f_cal = plan.f8_b_cal = False
         # device status words read back together: [0] a non-finite output value (rumpy_tail_fwd, evaluation plans), [1] strip-exchange watchdog
         plan.flags = torch.zeros(2, dtype=torch.int32, device=self.device)
         plan.meta = self._new(plan, N, max(1, spec.num_metadata), dtype=torch.float32) if spec.num_metadata else None
@@ -382,22 +455,27 @@ class SREngine:
                     y = act()
                     # the backward launch needs t1 only as a ReLU mask: the forward launch also leaves it as bytes (1/16 of the traffic)
                     mb = self._new(plan, N, H, W, 8, dtype=torch.uint8) if (fused and train and self.use_mask_bytes) else None
+                    f8 = fused and train and self.fp8 and W <= 48 and mb is not None and hasattr(c1, 'w8_fwd')
+                    f8f = dict(w1_f8=_ptr(c1.w8_fwd), w2_f8=_ptr(c2.w8_fwd), f8_sw1=_ptr(c1.w8_scale), f8_sw2=_ptr(c2.w8_scale),
+                               f8_site=self._f8_site(plan, 'f')) if f8 else {}
                     if fused:
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
                             x=_ptr(cur), w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed), mask=None,
-                            res2=None, t=_ptr(t1), out=_ptr(y), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs), maskbits=_ptr(mb), fmt=fmt)))
+                            res2=None, t=_ptr(t1), out=_ptr(y), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=float(rs), maskbits=_ptr(mb), fmt=fmt, **f8f)))
                     else:
                         self._conv(fwd, cur, c1, N, H, W, t1, relu=True, fmt=fmt)
                         self._conv(fwd, t1, c2, N, H, W, y, scale=rs, res1=cur, fmt=fmt)
 
-                    def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs, fused=fused, mb=mb):
+                    def node(g_out, extra, x_in=cur, t1=t1, c1=c1, c2=c2, rs=rs, fused=fused, mb=mb, f8=f8):
                         # y = x + rs*conv2(relu(conv1 x)):  dt1 = rs*dgrad2(g) masked ; dx = g + dgrad1(dt1) (+ extra)
                         dt1, dx = self._new(plan, N, H, W, F), self._new(plan, N, H, W, F)
+                        f8b = dict(w1_f8=_ptr(c2.w8_dgrad), w2_f8=_ptr(c1.w8_dgrad), f8_sw1=_ptr(c2.w8_scale), f8_sw2=_ptr(c1.w8_scale),
+                                   f8_site=self._f8_site(plan, 'b')) if f8 else {}
                         if fused:
                             bwd.append(('rumpy_conv_block', L.BlockArgs(
                                 x=_ptr(g_out), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1),
                                 res2=_ptr(extra), t=_ptr(dt1), out=_ptr(dx), N=N, H=H, W=W, relu1=0, scale1=float(rs), scale2=1.0,
-                                maskbits=_ptr(mb))))
+                                maskbits=_ptr(mb), **f8b)))
                         else:
                             self._conv(bwd, g_out, c2, N, H, W, dt1, dgrad=True, scale=rs, mask=t1)
                             self._conv(bwd, dt1, c1, N, H, W, dx, dgrad=True, res1=g_out, res2=extra)
@@ -1058,6 +1136,9 @@ class SREngine:
             if getattr(plan, 'tail_loss', None) is not None:
                 plan.tail_loss.target_ind = None
         out = torch.empty_like(plan.out)
+        if train and plan.f8_f_n:
+            self._repack_f8(stream)
+            self._f8_begin(plan, 'f', plan.fwd, stream)
         self._run(plan.fwd, stream)
         if self.wide:
             if target is not None:
@@ -1136,6 +1217,7 @@ class SREngine:
         self._set_grad_scale(plan, float(grad_scale))
         tail_done = plan.tail_fused and gout is None      # an upstream gradient replaces the sign gradient: separate pass then
         plan.tail_fused = False
+        self._f8_begin(plan, 'b', plan.bwd, stream)
         self._run(plan.bwd, stream)
         self._ca_param_grads(plan, stream)
         self._q_param_grads(plan, stream)
@@ -1212,6 +1294,8 @@ class SREngine:
         per-layer kernels.  Inputs are copied into the plan's static buffers; the returned `out` / `loss` tensors are
         the plan's static buffers (valid until the next call).  Returns (out, loss, plan)."""
         N, _, H, W = x.shape
+        if self.fp8:
+            raise RuntimeError("rumpy_amd: precision 'fp8' runs eager steps (its first pass measures the scales; RUMPY_GRAPH=1 is not supported)")
         plan = self.plan_for(N, H, W, True)
         cur = torch.cuda.current_stream(self.device)
         if getattr(plan, 'graph', None) is None:

@@ -47,7 +47,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(h, s), s
     lib = _lib.lib()
-    assert lib.rumpy_abi_version() == 3
+    assert lib.rumpy_abi_version() == 4
     assert lib.rumpy_wgrad_slab_floats(4) == 64 * 576 + 64 and lib.rumpy_wgrad_slab_floats(1) == 16 * 576 + 16
 
 
@@ -66,7 +66,7 @@ def test_ctypes_structs_match_the_header_layout():
              'rumpy_finish_reduce_args': _lib.FinishReduceArgs, 'rumpy_update_item': _lib.UpdateItem, 'rumpy_adam_pack_args': _lib.AdamPackArgs,
              'rumpy_qca_layer': _lib.QcaLayer, 'rumpy_qca_args': _lib.QcaArgs,
              'rumpy_dconv_args': _lib.DconvArgs, 'rumpy_dconv_wgrad_args': _lib.DconvWgradArgs, 'rumpy_mse_args': _lib.MseArgs, 'rumpy_op': _lib.Op,
-             'rumpy_sgemm_args': _lib.SgemmArgs}
+             'rumpy_sgemm_args': _lib.SgemmArgs, 'rumpy_fp8_pack_item': _lib.Fp8PackItem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rumpy_amd.h"', 'int main(void){']
     for cname, st in pairs.items():
         lines.append('printf("%s %%zu", sizeof(%s));' % (cname, cname))

@@ -354,7 +354,7 @@ def test_kept_on_device_evaluation_is_checked_before_the_image_is_handed_out():
     assert out.is_cuda and torch.isfinite(out).all() and h.net.engine.eval_fmt == 0 and h.net.engine._flag_pending is None
     oout, _, _ = oh.run_eval(x)
     assert float((out.cpu() - oout).norm() / oout.norm()) < 2e-2
-    h2, _ = _pair('edsr', 511, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1, max_combined_im_size=400)
+    h2, _ = _pair('edsr', 511, eval_mode=True, scale=2, num_blocks=1, res_scale=0.1, max_combined_im_size=500)
     h2.defer_eval_status = True                 # not honoured by the quadrants
     with torch.no_grad():
         h2.net.head[0].weight.mul_(3e5)
