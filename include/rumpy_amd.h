@@ -118,8 +118,10 @@ typedef struct {
   const void* w2_f8;
   const uint32_t* f8_sw1;   /* their e8m0 scale exponents (rumpy_fp8_pack_item.exponent of the same conv) */
   const uint32_t* f8_sw2;
-  uint32_t* f8_site;        /* this launch's record of RUMPY_FP8_SITE_WORDS words: [0] / [1] exponents of the X / T images (read; written by
-                               rumpy_fp8_rotate), [2 .. 9] / [10 .. 17] amax of X / T as fp32 bit patterns (atomic max by the launch) */
+  uint32_t* f8_site;        /* this launch's record: [0] / [1] e8m0 exponents of the X / T images (read; written by rumpy_fp8_rotate), [2] number
+                               of amax entries (set by the host, >= rumpy_fp8_site_entries), [3] unused, then `entries` pairs {amax of X, amax of
+                               T} as fp32 bit patterns, one pair per (workgroup, row half), written by the launch */
+  int32_t f8_entries;       /* entries the record has room for */
 } rumpy_block_args;
 int rumpy_conv_block(const rumpy_block_args* a, void* stream);
 
@@ -128,8 +130,9 @@ int rumpy_conv_block(const rumpy_block_args* a, void* stream);
  *   (forward and data-gradient image, 40960 bytes each) of w / 2^(e - 127), one exponent e per conv such that amax / scale is in [128, 256);
  *   e -> *exponent.  After every optimizer step / weight load (replaces nothing in the reference: torch has no fp8 conv; call site of the
  *   arithmetic it feeds: common.py:6-9 default_conv).
- * rumpy_fp8_rotate: n site records: exponent of each image tensor <- from the amax its launch left in the previous pass, amax cleared. */
-#define RUMPY_FP8_SITE_WORDS 18
+ * rumpy_fp8_rotate: n site records of `words` words each: exponent of each image tensor <- from the amax its launch left in the previous
+ *   pass (amax / 2^(e - 127) in [128, 256); unchanged when nothing was recorded), entries cleared. */
+#define RUMPY_FP8_SITE_HEAD 4
 #define RUMPY_FP8_IMAGE_BYTES 40960
 typedef struct {
   const float* w;
@@ -138,7 +141,8 @@ typedef struct {
   uint32_t* exponent;
 } rumpy_fp8_pack_item;
 int rumpy_fp8_pack(const rumpy_fp8_pack_item* items, int32_t n, void* stream);
-int rumpy_fp8_rotate(void* sites, int32_t n, void* stream);
+int rumpy_fp8_rotate(void* sites, int32_t n, int32_t words, void* stream);
+int rumpy_fp8_site_entries(int32_t N, int32_t H, int32_t W);   /* amax entries one fp8 launch on [N,H,W,64] writes */
 int rumpy_block_pool_tiles(int32_t H, int32_t W);   /* rows of `pool` per image: 2 * ceil(H/6) * column tiles */
 
 /* ---- a whole residual channel-attention block per launch (conv_rcab.hip): RCAB, rumpy/SISR/models/advanced/architectures.py:60-84, and

@@ -225,14 +225,15 @@ class BlockArgs(_S):
                 ('res2', c_void_p), ('t', c_void_p), ('out', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32),
                 ('relu1', c_int32), ('scale1', c_float), ('scale2', c_float), ('res_mode', c_int32), ('res1', c_void_p),
                 ('pool', c_void_p), ('maskbits', c_void_p), ('fmt', c_int32), ('col_tile', c_int32),
-                ('w1_f8', c_void_p), ('w2_f8', c_void_p), ('f8_sw1', c_void_p), ('f8_sw2', c_void_p), ('f8_site', c_void_p)]
+                ('w1_f8', c_void_p), ('w2_f8', c_void_p), ('f8_sw1', c_void_p), ('f8_sw2', c_void_p), ('f8_site', c_void_p),
+                ('f8_entries', c_int32)]
 
 
 class Fp8PackItem(_S):
     _fields_ = [('w', c_void_p), ('img_fwd', c_void_p), ('img_dgrad', c_void_p), ('exponent', c_void_p)]
 
 
-FP8_SITE_WORDS = 18
+FP8_SITE_HEAD = 4
 FP8_IMAGE_BYTES = 40960
 
 
@@ -290,7 +291,8 @@ SYMBOLS = {
     'rumpy_rcab_strips': (C.c_int, [c_int32, c_int32]),
     'rumpy_block_pool_tiles': (C.c_int, [c_int32, c_int32]),
     'rumpy_fp8_pack': (C.c_int, [c_void_p, c_int32, c_void_p]),
-    'rumpy_fp8_rotate': (C.c_int, [c_void_p, c_int32, c_void_p]),
+    'rumpy_fp8_rotate': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p]),
+    'rumpy_fp8_site_entries': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_fp8_convert': (C.c_int, [c_void_p, C.c_float, c_void_p, c_int32, c_void_p]),
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
     'rumpy_sgemm': (C.c_int, [_P(SgemmArgs), c_void_p]),

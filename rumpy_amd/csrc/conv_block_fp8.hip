@@ -11,10 +11,11 @@
 // The scales travel through the instruction's e8m0 scale operands, so no value is ever multiplied by a scale in software.
 //
 // Scale management = delayed scaling, device side only.  A launch reads the e8m0 exponents of its two image tensors from its `site` record and
-// leaves the amax of both (as the values really were this step) in eight sub-slots of the same record (one per XCD: 64 atomics per address and
-// launch); rumpy_fp8_rotate, one small launch in front of every pass, turns last step's amax into this step's exponent such that amax / scale
-// lies in [128, 256) - 1.75 x growth from one step to the next still fits e4m3 (448), far more fits e5m2 - and clears the slots.  The host
-// never reads a scale.  The first pass of a plan runs twice (once to measure; rumpy_amd/engine.py).
+// leaves the amax of both (as the values really were this step, fp32) in the record, one entry per (workgroup, row half), plain stores;
+// rumpy_fp8_rotate, one small launch in front of every pass, turns last pass's amax into this pass's exponent such that amax / scale lies in
+// [128, 256) - 1.75 x growth from one step to the next still fits e4m3 (448), far more fits e5m2; what outgrows even that is clamped to the
+// largest finite value - and clears the entries.  The host never reads a scale.  The first pass of a plan runs twice (once to measure;
+// rumpy_amd/engine.py).
 //
 // Geometry = conv_block.hip's W <= 48 geometry (one 6-row strip across the image per 512-thread workgroup, wave (q, rh) = output channels 16 q ..
 // of one row half, row-half gates instead of workgroup barriers, whole-line non-temporal stores from LDS images).  What differs (measured first as
@@ -47,7 +48,7 @@ struct BlockF8Dev {
   const uint16_t* res2; uint16_t* t; uint16_t* out; unsigned char* mbits;
   int N, H, W, sy_n; float scale1, scale2;
   const unsigned* sw1; const unsigned* sw2;        // e8m0 exponents of the two filter images (rumpy_fp8_pack)
-  unsigned* site;                                  // RUMPY_FP8_SITE_WORDS words: [0] exponent of the X image, [1] of the T image, [2 .. 9] amax slots X, [10 .. 17] T
+  unsigned* site;                                  // record of this launch (rumpy_amd.h): [0] / [1] exponents of the X / T images, [2] entries, then the amax pairs
 };
 
 __device__ __forceinline__ unsigned f8_swz(int p, int quarter) { return (unsigned)(p * 64 + ((quarter ^ (((p >> 2) & 1) << 1)) << 4)); }
@@ -55,7 +56,13 @@ __device__ __forceinline__ unsigned f8_swz(int p, int quarter) { return (unsigne
 // 8 fp32 -> 8 fp8 bytes of value / scale (E5M2 = false: OCP e4m3, true: e5m2); round to nearest even, saturating (checked on the hardware:
 // tests/test_fp8_gpu.py::test_fp8_conversions_saturate)
 template <bool E5M2>
-__device__ __forceinline__ uint2 f8_pack8(const float (&f)[8], float scale) {
+__device__ __forceinline__ uint2 f8_pack8(const float (&g)[8], float scale) {
+  // the conversion instructions round a slight overflow down to the largest finite value but turn a large one into NaN (measured:
+  // tests/test_fp8_gpu.py::test_fp8_conversions...), and delayed scaling means a value CAN outgrow last step's scale: clamp first (v_med3_f32)
+  const float lim = scale * (E5M2 ? 57344.f : 448.f);
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(g[j], -lim, lim);
   f8_v2s a = {0, 0}, b = {0, 0};
   if (E5M2) {
     a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(a, f[0], f[1], scale, false);
@@ -398,11 +405,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev 
     for (int i = 0; i < GROUP_REGS; ++i)
       if (soff[i] != 0xffffffffu) st16_nt(a.out + soff[i], S[i]);
   }
-  // this row half's amax (its four waves have added theirs in front of the gate) -> the site's slot of this XCD; the other half adds the rest
+  // this row half's amax (its four waves have added theirs in front of the gate) -> this row half's entry of the site record: plain stores, no
+  // global atomics (1024 same-line device-scope atomics per launch cost it 4 us); rumpy_fp8_rotate takes the maximum over the entries
   if (tg2 == 0) {
-    const unsigned slot = blockIdx.x & 7u;
-    atomicMax(a.site + 2 + slot, __hip_atomic_load(&amax_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    atomicMax(a.site + 10 + slot, __hip_atomic_load(&amax_s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    unsigned* e = a.site + RUMPY_FP8_SITE_HEAD + 2 * (2 * blockIdx.x + rh);
+    e[0] = __hip_atomic_load(&amax_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    e[1] = __hip_atomic_load(&amax_s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 }
 
@@ -420,6 +428,7 @@ int rumpy_conv_block_fp8_launch(const rumpy_block_args* p, hipStream_t s) {
   d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = (p->H + BSH - 1) / BSH; d.scale1 = p->scale1; d.scale2 = p->scale2;
   d.sw1 = p->f8_sw1; d.sw2 = p->f8_sw2; d.site = p->f8_site;
   const dim3 grid(d.N * d.sy_n);
+  if (p->f8_entries < 2 * (int)grid.x) { rumpy_set_error("rumpy_conv_block: f8_entries %d < 2 * %u workgroups (rumpy_fp8_site_entries)", p->f8_entries, grid.x); return RUMPY_E_ARG; }
   if (fwd) RUMPY_LAUNCH_PROBED(5, (conv_block_fp8_kernel<1>), grid, dim3(BTHREADS), s, d);
   else RUMPY_LAUNCH_PROBED(5, (conv_block_fp8_kernel<3>), grid, dim3(BTHREADS), s, d);
   return 0;
@@ -430,12 +439,27 @@ int rumpy_conv_block_fp8_launch(const rumpy_block_args* p, hipStream_t s) {
 // (A rows = output channels) and data-gradient image (the transposed, flipped filter: A rows = input channels), e4m3 of w / 2^(e - 127) with ONE
 // exponent e per conv chosen so that amax / scale lies in [128, 256); e goes to *exponent.  One workgroup per conv, after every optimizer step.
 // ---------------------------------------------------------------------------------------------------------------------------------------
+constexpr int F8_PACK_PARTS = 16;     // workgroups per conv: each takes the conv's amax for itself (147 KB from L2) and converts 1/16 of both images
 __global__ void __launch_bounds__(256) fp8_pack_kernel(const rumpy_fp8_pack_item* items) {
-  const rumpy_fp8_pack_item it = items[blockIdx.x];
+  const rumpy_fp8_pack_item it = items[blockIdx.x / F8_PACK_PARTS];
+  const int part = blockIdx.x % F8_PACK_PARTS;
   __shared__ float red[256];
   const int tid = threadIdx.x;
   float am = 0.f;
-  for (int i = tid; i < 64 * 64 * 9; i += 256) am = fmaxf(am, fabsf(it.w[i]));
+  {
+    const float4* w4 = reinterpret_cast<const float4*>(it.w);
+    float4 v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = w4[tid + 256 * i];          // 64 * 64 * 9 / 4 = 9216 = 36 * 256 vectors: four rounds of nine loads in flight
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+        if (r < 3) v[i] = w4[tid + 256 * (9 * (r + 1) + i)];
+      }
+    }
+  }
   red[tid] = am;
   __syncthreads();
   for (int off = 128; off >= 1; off >>= 1) {
@@ -446,14 +470,15 @@ __global__ void __launch_bounds__(256) fp8_pack_kernel(const rumpy_fp8_pack_item
   int e = (int)((__float_as_uint(am) >> 23) & 255u) - 7;      // amax in [2^(E-127), 2^(E-126)) -> amax / 2^(E-134) in [128, 256)
   if (am == 0.f || !(am < 3e38f)) e = 127;
   e = e < 1 ? 1 : (e > 254 ? 254 : e);
-  if (tid == 0) *it.exponent = (unsigned)e;
+  if (tid == 0 && part == 0) *it.exponent = (unsigned)e;
   const float scale = __uint_as_float((unsigned)e << 23);
   // word i of an image = bytes 4 (i & 7) .. + 3 of (lane, mfma, q); fwd: row = output channel co, k = input channel ci, tap (ky, kx);
   // dgrad: row = input channel, k = output channel, tap flipped
+  constexpr int WORDS = 4 * 5 * 64 * 8, PER = WORDS / F8_PACK_PARTS;       // 10240 words per image, 640 per part
   for (int img = 0; img < 2; ++img) {
     unsigned* dst = reinterpret_cast<unsigned*>(img ? it.img_dgrad : it.img_fwd);
     if (!dst) continue;
-    for (int i = tid; i < 4 * 5 * 64 * 8; i += 256) {
+    for (int i = part * PER + tid; i < (part + 1) * PER; i += 256) {
       const int w4 = i & 7, lane = (i >> 3) & 63, m = (i >> 9) % 5, q = i / (5 * 64 * 8);
       const int r = lane & 15, g = lane >> 4, row = 16 * q + r;
       float f[4];
@@ -480,34 +505,53 @@ __global__ void __launch_bounds__(256) fp8_pack_kernel(const rumpy_fp8_pack_item
 extern "C" int rumpy_fp8_pack(const rumpy_fp8_pack_item* items, int32_t n, void* stream) {
   if (n <= 0) return 0;
   if (!items) { rumpy_set_error("rumpy_fp8_pack: null table"); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(fp8_pack_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, items);
+  hipLaunchKernelGGL(fp8_pack_kernel, dim3(n * F8_PACK_PARTS), dim3(256), 0, (hipStream_t)stream, items);
   return rumpy_check_launch("rumpy_fp8_pack");
 }
 
-// rumpy_fp8_rotate: for `n` site records from `sites`: exponent of tensor k <- from the max of its eight amax slots (unchanged when nothing was
-// recorded), slots cleared.  In front of every pass that runs fp8 launches.
-__global__ void fp8_rotate_kernel(unsigned* sites, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * n) return;
-  unsigned* rec = sites + (size_t)(i >> 1) * RUMPY_FP8_SITE_WORDS;
-  unsigned* slots = rec + 2 + 8 * (i & 1);
-  unsigned m = 0u;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) { m = max(m, slots[s]); slots[s] = 0u; }
-  const int E = (int)((m >> 23) & 255u);
-  if (m != 0u && E != 255) {
-    int e = E - 7;
-    rec[i & 1] = (unsigned)(e < 1 ? 1 : (e > 254 ? 254 : e));
-  } else if ((rec[i & 1] & 255u) == 0u) {
-    rec[i & 1] = 127u;
+// rumpy_fp8_rotate: n site records of `words` 32-bit words each from `sites`: exponent of image tensor k <- from the maximum over the record's
+// amax entries (unchanged when nothing was recorded), entries cleared.  In front of every pass that runs fp8 launches; one workgroup per record.
+__global__ void __launch_bounds__(256) fp8_rotate_kernel(unsigned* sites, int words) {
+  unsigned* rec = sites + (size_t)blockIdx.x * words;
+  const int cnt = min((int)rec[2], (words - RUMPY_FP8_SITE_HEAD) / 2);
+  __shared__ unsigned red[2][256];
+  unsigned m0 = 0u, m1 = 0u;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    unsigned* e = rec + RUMPY_FP8_SITE_HEAD + 2 * i;
+    m0 = max(m0, e[0]); m1 = max(m1, e[1]);
+    e[0] = 0u; e[1] = 0u;
+  }
+  red[0][threadIdx.x] = m0; red[1][threadIdx.x] = m1;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      red[0][threadIdx.x] = max(red[0][threadIdx.x], red[0][threadIdx.x + off]);
+      red[1][threadIdx.x] = max(red[1][threadIdx.x], red[1][threadIdx.x + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 2) {
+    const unsigned m = red[threadIdx.x][0];
+    const int E = (int)((m >> 23) & 255u);
+    if (m != 0u && E != 255) {
+      const int e = E - 7;
+      rec[threadIdx.x] = (unsigned)(e < 1 ? 1 : (e > 254 ? 254 : e));
+    } else if ((rec[threadIdx.x] & 255u) == 0u) {
+      rec[threadIdx.x] = 127u;
+    }
   }
 }
 
-extern "C" int rumpy_fp8_rotate(void* sites, int32_t n, void* stream) {
+extern "C" int rumpy_fp8_rotate(void* sites, int32_t n, int32_t words, void* stream) {
   if (n <= 0) return 0;
-  if (!sites) { rumpy_set_error("rumpy_fp8_rotate: null table"); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(fp8_rotate_kernel, dim3((2 * n + 127) / 128), dim3(128), 0, (hipStream_t)stream, (unsigned*)sites, n);
+  if (!sites || words < RUMPY_FP8_SITE_HEAD) { rumpy_set_error("rumpy_fp8_rotate: null table / record shorter than its head"); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(fp8_rotate_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (unsigned*)sites, words);
   return rumpy_check_launch("rumpy_fp8_rotate");
+}
+// entries a launch of rumpy_conv_block with fp8 images writes: two (one per row half) per workgroup
+extern "C" int rumpy_fp8_site_entries(int32_t N, int32_t H, int32_t W) {
+  (void)W;
+  return 2 * N * ((H + BSH - 1) / BSH);
 }
 
 // test hook of the conversions' overflow behaviour (tests/test_fp8_gpu.py): out[2 i], out[2 i + 1] = the e4m3 / e5m2 byte of in[i] / scale

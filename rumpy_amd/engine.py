@@ -237,17 +237,20 @@ class SREngine:
             self.f8_gen = self.pack_gen
 
     def _f8_site(self, plan, which):
-        """one record of RUMPY_FP8_SITE_WORDS words per fp8 launch of a plan (exponents of its two image tensors + their amax slots)"""
+        """one record per fp8 launch of a plan: exponents of its two image tensors, then one amax pair per (workgroup, row half) -> dict of
+        the launch's f8_site / f8_entries arguments"""
         key = 'f8_' + which
         buf = getattr(plan, key)
+        entries = int(self.lib.rumpy_fp8_site_entries(plan.N, plan.H, plan.W))
         if buf is None:
             n = max(1, len(self._f8_convs) // 2)
-            buf = torch.zeros(n, L.FP8_SITE_WORDS, dtype=torch.int32, device=self.device)
+            buf = torch.zeros(n, L.FP8_SITE_HEAD + 2 * entries, dtype=torch.int32, device=self.device)
             buf[:, 0:2] = 127
+            buf[:, 2] = entries
             setattr(plan, key, buf)
         i = getattr(plan, key + '_n')
         setattr(plan, key + '_n', i + 1)
-        return buf[i].data_ptr()
+        return dict(f8_site=buf[i].data_ptr(), f8_entries=entries)
 
     def _f8_begin(self, plan, which, ops, stream):
         """in front of a pass that contains fp8 launches: the first time the pass runs once to measure (every amax is taken from the values as
@@ -259,7 +262,8 @@ class SREngine:
             setattr(plan, 'f8_' + which + '_cal', True)
             self._run(ops, stream)
             self._advance_epoch(plan, stream)
-        L.check(self.lib.rumpy_fp8_rotate(getattr(plan, 'f8_' + which).data_ptr(), n, stream), 'rumpy_fp8_rotate')
+        buf = getattr(plan, 'f8_' + which)
+        L.check(self.lib.rumpy_fp8_rotate(buf.data_ptr(), n, buf.shape[1], stream), 'rumpy_fp8_rotate')
 
     # ------------------------------------------------------------------ packed filters
     def _alloc_packed(self):
@@ -457,7 +461,7 @@ class SREngine:
                     mb = self._new(plan, N, H, W, 8, dtype=torch.uint8) if (fused and train and self.use_mask_bytes) else None
                     f8 = fused and train and self.fp8 and W <= 48 and mb is not None and hasattr(c1, 'w8_fwd')
                     f8f = dict(w1_f8=_ptr(c1.w8_fwd), w2_f8=_ptr(c2.w8_fwd), f8_sw1=_ptr(c1.w8_scale), f8_sw2=_ptr(c2.w8_scale),
-                               f8_site=self._f8_site(plan, 'f')) if f8 else {}
+                               **self._f8_site(plan, 'f')) if f8 else {}
                     if fused:
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
                             x=_ptr(cur), w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed), mask=None,
@@ -470,7 +474,7 @@ class SREngine:
                         # y = x + rs*conv2(relu(conv1 x)):  dt1 = rs*dgrad2(g) masked ; dx = g + dgrad1(dt1) (+ extra)
                         dt1, dx = self._new(plan, N, H, W, F), self._new(plan, N, H, W, F)
                         f8b = dict(w1_f8=_ptr(c2.w8_dgrad), w2_f8=_ptr(c1.w8_dgrad), f8_sw1=_ptr(c2.w8_scale), f8_sw2=_ptr(c1.w8_scale),
-                                   f8_site=self._f8_site(plan, 'b')) if f8 else {}
+                                   **self._f8_site(plan, 'b')) if f8 else {}
                         if fused:
                             bwd.append(('rumpy_conv_block', L.BlockArgs(
                                 x=_ptr(g_out), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, mask=_ptr(t1),
