@@ -170,6 +170,12 @@ typedef struct {
   uint32_t seq;
   int32_t fmt;         /* RUMPY_FMT_*; F16: rumpy_rcab_fwd only */
   void* maskbits;      /* NULL, or [N,H,W,8] bytes: ReLU mask of t1, written by rumpy_rcab_fwd and read (instead of `mask`) by rumpy_rcab_bwd */
+  /* ABI 4 - precision 'fp8' (as in rumpy_block_args; conv_rcab_fp8.hip): with w1_f8 set both sweeps run on the block-scaled fp8 MFMA;
+   * W <= 48, bf16 tensors, backward with maskbits.  Image tensors of the site record: forward x / t1 (e4m3), backward d_t2 / gt1 (e5m2). */
+  const void* w1_f8; const void* w2_f8;
+  const uint32_t* f8_sw1; const uint32_t* f8_sw2;
+  uint32_t* f8_site;
+  int32_t f8_entries;
 } rumpy_rcab_args;
 int rumpy_rcab_fwd(const rumpy_rcab_args* a, void* stream);
 int rumpy_rcab_bwd(const rumpy_rcab_args* a, void* stream);

@@ -15,12 +15,13 @@ class QRCANHandler(QModel):
 
     def __init__(self, device, model_save_dir, eval_mode=False, lr=1e-4, scale=4, in_features=3, scheduler=None,
                  scheduler_params=None, style='modulate', perceptual=None, clamp=False, min_mu=-0.2,
-                 max_mu=0.8, n_feats=64, srmd_mode=False, **kwargs):
+                 max_mu=0.8, n_feats=64, srmd_mode=False, precision=None, **kwargs):
         super(QRCANHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode, **kwargs)
         if srmd_mode:
             raise RuntimeError('rumpy_amd: srmd_mode (metadata concatenated with the input) is not on the HIP path')
         self.srmd_channel_mode = False
         self.net = QRCAN(scale=scale, in_feats=in_features, num_metadata=self.num_metadata, n_feats=n_feats, style=style, **kwargs)
+        self.net.set_precision(precision)      # (not a reference kwarg) None = bf16 ; 'fp8' = the one-launch RCAB kernels on the block-scaled fp8 MFMA, opt-in
         self.colorspace = 'augmented_rgb'
         self.im_input = 'unmodified'
         self.activate_device()

@@ -18,7 +18,7 @@ class ContrastiveBlindQRCANHandler(BaseContrastive):
                  scheduler=None, scheduler_params=None, style='modulate', perceptual=None, n_feats=64, encoder_type='default',
                  encoder_output_size=256, pre_trained_encoder_weights=None, auxiliary_encoder_weights=None, staggered_encoding=False,
                  embedding_type='pre-q', encoder_freeze_mode='all', encoder_train_eval='eval', combined_loss_mode=None, crop_count=None,
-                 data_type='noise', reducer_layer_sizes=None, labelling_strategy='triple_precision', **kwargs):
+                 data_type='noise', reducer_layer_sizes=None, labelling_strategy='triple_precision', precision=None, **kwargs):
         super(ContrastiveBlindQRCANHandler, self).__init__(device=device, model_save_dir=model_save_dir, eval_mode=eval_mode,
                                                            labelling_strategy=labelling_strategy, **kwargs)
         if crop_count is not None and combined_loss_mode is None:
@@ -30,6 +30,8 @@ class ContrastiveBlindQRCANHandler(BaseContrastive):
         self.data_type, self.crop_count, self.encoder_train_eval = data_type, crop_count, encoder_train_eval
         sr_net = QRCAN(scale=scale, in_feats=in_features, num_metadata=encoder_output_size, n_feats=n_feats, style=style,
                        include_sft_layer=include_sft_layer, staggered_encoding=staggered_encoding, **kwargs)
+        # (not a reference kwarg) None = bf16 ; 'fp8' = BASELINE config 5's "fp8 MFMA conv": the generator's RCAB kernels on the block-scaled fp8 MFMA
+        sr_net.set_precision(precision)
         kwargs['model_save_dir'] = model_save_dir
         self.net = ContrastiveBlindSRPipeline(device=device, eval_mode=eval_mode, generator=sr_net, encoder=encoder_type,
                                               pre_trained_encoder_weights=pre_trained_encoder_weights,

@@ -54,7 +54,8 @@ class RcabArgs(_S):
                 ('ca_w1', c_void_p), ('ca_b1', c_void_p), ('ca_w2', c_void_p), ('ca_b2', c_void_p),
                 ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('qgate', c_void_p), ('dz', c_void_p), ('dzq', c_void_p),
                 ('xchg', c_void_p), ('xchg_bytes', c_int64), ('epoch', c_void_p), ('status', c_void_p),
-                ('seq', C.c_uint32), ('fmt', c_int32), ('maskbits', c_void_p)]
+                ('seq', C.c_uint32), ('fmt', c_int32), ('maskbits', c_void_p),
+                ('w1_f8', c_void_p), ('w2_f8', c_void_p), ('f8_sw1', c_void_p), ('f8_sw2', c_void_p), ('f8_site', c_void_p), ('f8_entries', c_int32)]
 
 
 class Op(_S):

@@ -31,17 +31,7 @@
 //      Q2         : tap (ky 2, kx 2) | nothing: bytes 0-15 = channels 16 g .., bytes 16-31 meet zeros in the filter image.
 //    (tests/tools/fp8/fp8_probe.hip: any lane / byte -> k assignment works as long as both operands use the same one.)  5 MFMAs of 32 cycles
 //    against 18 of 16: 0.56 of the matrix-pipe time, and 0.6 of the LDS fragment bytes.
-#include "block_common.hpp"
-
-typedef int f8_v8i __attribute__((ext_vector_type(8)));
-typedef int f8_v4i __attribute__((ext_vector_type(4)));
-typedef short f8_v2s __attribute__((ext_vector_type(2)));
-
-constexpr int F8_C16 = BSH * BSW * 128;            // 36864: a strip's own pixels as a bf16 image
-constexpr int F8_X8 = BXROWS * BCOLS * 64;         // 32000
-constexpr int F8_T8 = BTROWS * BCOLS * 64;         // 25600
-constexpr int F8_OFF_X8 = F8_C16, F8_OFF_T8 = F8_C16 + F8_X8, F8_OFF_T16 = F8_C16 + F8_X8 + F8_T8;
-constexpr int F8_LDS = F8_OFF_T16 + F8_C16;        // 131328
+#include "fp8_common.hpp"
 
 struct BlockF8Dev {
   const uint16_t* x; const f8_v8i* w1; const float* b1; const f8_v8i* w2; const float* b2;
@@ -50,122 +40,6 @@ struct BlockF8Dev {
   const unsigned* sw1; const unsigned* sw2;        // e8m0 exponents of the two filter images (rumpy_fp8_pack)
   unsigned* site;                                  // record of this launch (rumpy_amd.h): [0] / [1] exponents of the X / T images, [2] entries, then the amax pairs
 };
-
-__device__ __forceinline__ unsigned f8_swz(int p, int quarter) { return (unsigned)(p * 64 + ((quarter ^ (((p >> 2) & 1) << 1)) << 4)); }
-
-// 8 fp32 -> 8 fp8 bytes of value / scale (E5M2 = false: OCP e4m3, true: e5m2); round to nearest even, saturating (checked on the hardware:
-// tests/test_fp8_gpu.py::test_fp8_conversions_saturate)
-template <bool E5M2>
-__device__ __forceinline__ uint2 f8_pack8(const float (&g)[8], float scale) {
-  // the conversion instructions round a slight overflow down to the largest finite value but turn a large one into NaN (measured:
-  // tests/test_fp8_gpu.py::test_fp8_conversions...), and delayed scaling means a value CAN outgrow last step's scale: clamp first (v_med3_f32)
-  const float lim = scale * (E5M2 ? 57344.f : 448.f);
-  float f[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(g[j], -lim, lim);
-  f8_v2s a = {0, 0}, b = {0, 0};
-  if (E5M2) {
-    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(a, f[0], f[1], scale, false);
-    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(a, f[2], f[3], scale, true);
-    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(b, f[4], f[5], scale, false);
-    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(b, f[6], f[7], scale, true);
-  } else {
-    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, f[0], f[1], scale, false);
-    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, f[2], f[3], scale, true);
-    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(b, f[4], f[5], scale, false);
-    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(b, f[6], f[7], scale, true);
-  }
-  return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-}
-
-// A = filter fragment (always e4m3), B = image fragment (e4m3 or e5m2); sa / sb = e8m0 exponents, uniform over the lanes
-template <bool E5M2>
-__device__ __forceinline__ f32x4 f8_mfma(f8_v8i a, f8_v8i b, f32x4 c, int sa, int sb) {
-  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, E5M2 ? 1 : 0, 0, sa, 0, sb);
-}
-
-// max over the wave, in every lane (values >= 0): the butterflies of common.hpp::wave64_sum with max
-__device__ __forceinline__ float f8_wave_max(float t, int lane) {
-  t = fmaxf(t, dpp_quad1(t)); t = fmaxf(t, dpp_quad2(t)); t = fmaxf(t, dpp_half_mirror(t)); t = fmaxf(t, dpp_row_mirror(t));
-  t = fmaxf(t, lane_xor16(t, lane >> 4));
-  t = fmaxf(t, lane_xor32(t, lane));
-  return t;
-}
-
-// bases of the three fragment kinds for window row 0 = image row `row0` of the fp8 image at byte `buffer`:
-//   fb[d]: chunk g of pixel (row0, px) for XOR class d ; hb[d]: chunk 2 (g & 1) of pixel (row0 + (g >> 1), px + 2)
-__device__ __forceinline__ void f8_bases(unsigned (&fb)[8], unsigned (&hb)[8], unsigned buffer, int row0, int px, int g) {
-  const int p0 = row0 * BCOLS + px, ph = (row0 + (g >> 1)) * BCOLS + px + 2;
-#pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    fb[d] = buffer + (unsigned)(p0 * 64 + ((g ^ ((((p0 + d) >> 2) & 1) << 1)) << 4));
-    hb[d] = buffer + (unsigned)(ph * 64 + (((2 * (g & 1)) ^ ((((ph + d) >> 2) & 1) << 1)) << 4));
-  }
-}
-
-// hook(i), i = 0 .. 8, runs after the MFMAs of step i have been issued (the HBM stores of the previous phase's tile travel there)
-template <int ROWS, bool E5M2, class Hook = NoHook>
-__device__ __forceinline__ void f8_sweep(f32x4 (&acc)[ROWS][3], const f8_v8i (&A)[5], const unsigned char* lds, const unsigned (&fb)[8],
-                                         const unsigned (&hb)[8], int sa, int sb, Hook hook = Hook()) {
-  f8_v8i F[ROWS + 2], Hh[ROWS], G[ROWS];
-  auto ld16 = [&](unsigned addr) { return *reinterpret_cast<const f8_v4i*>(lds + addr); };
-  auto load_f = [&](int c) {
-#pragma unroll
-    for (int r = 0; r < ROWS + 2; ++r) {
-      const int k0 = r * BCOLS + 16 * c, k1 = k0 + 1;
-      const f8_v4i lo = ld16(fb[k0 & 7] + k0 * 64), hi = ld16(fb[k1 & 7] + k1 * 64);
-      F[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    }
-  };
-  auto load_h = [&](int c) {
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int k = r * BCOLS + 16 * c;                    // (the + 2 columns and the lane's row are in hb)
-      const f8_v4i lo = ld16(hb[k & 7] + k * 64), hi = ld16(hb[k & 7] + k * 64 + 16);
-      Hh[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    }
-  };
-  auto load_g = [&](int c) {
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int k = (r + 2) * BCOLS + 16 * c + 2;
-      const f8_v4i lo = ld16(fb[k & 7] + k * 64);
-      G[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, 0, 0, 0, 0};     // the filter image's second half is zero for this MFMA
-    }
-  };
-  load_f(0);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    load_h(c);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[ky], F[r + ky], acc[r][c], sa, sb);
-    hook(3 * c);
-    load_g(c);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[3], Hh[r], acc[r][c], sa, sb);
-    hook(3 * c + 1);
-    if (c + 1 < 3) load_f(c + 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[4], G[r], acc[r][c], sa, sb);
-    hook(3 * c + 2);
-  }
-}
-
-// a row half's 3 strip rows of a 6 x 48-pixel bf16 image as 16-byte pieces (block_common.hpp::group_stage for an image without halo)
-__device__ __forceinline__ void f8_stage48(uint4 (&S)[GROUP_REGS], const unsigned char* img, int tg, int rh) {
-#pragma unroll
-  for (int i = 0; i < GROUP_REGS; ++i) {
-    const int p = tg + 256 * i, pix = (p < GROUP_PIECES ? p : 0) >> 3;
-    S[i] = *reinterpret_cast<const uint4*>(img + swz(3 * rh * BSW + pix, p & 7));
-  }
-}
-
-__device__ __forceinline__ int f8_exp(unsigned word) { const int e = (int)(word & 255u); return e ? e : 127; }
 
 template <int FORM>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev a) {

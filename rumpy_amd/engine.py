@@ -213,7 +213,7 @@ class SREngine:
 
         def walk(items):
             for it in items:
-                if it[0] == 'resblock':
+                if it[0] == 'resblock' or (it[0] == 'rcab' and not getattr(it[3], 'gen', False)):
                     convs.extend([it[1], it[2]])
                 elif it[0] == 'group':
                     walk(it[1])
@@ -529,12 +529,17 @@ class SREngine:
                         seq = 2 * plan.rcab_n
                         plan.rcab_n += 1
                         mbr = self._new(plan, N, H, W, 8, dtype=torch.uint8) if (train and self.use_mask_bytes) else None
+                        f8 = train and self.fp8 and W <= 48 and mbr is not None and hasattr(c1, 'w8_fwd')
+                        f8f = dict(w1_f8=_ptr(c1.w8_fwd), w2_f8=_ptr(c2.w8_fwd), f8_sw1=_ptr(c1.w8_scale), f8_sw2=_ptr(c2.w8_scale),
+                                   **self._f8_site(plan, 'f')) if f8 else {}
+                        rc_f8b = (lambda c1=c1, c2=c2: dict(w1_f8=_ptr(c2.w8_dgrad), w2_f8=_ptr(c1.w8_dgrad), f8_sw1=_ptr(c2.w8_scale), f8_sw2=_ptr(c1.w8_scale),
+                                               **self._f8_site(plan, 'b'))) if f8 else (lambda: {})
                         rc_common = dict(maskbits=_ptr(mbr), N=N, H=H, W=W, cr=ca.Cr, ca_w1=_ptr(ca.w1), ca_b1=_ptr(ca.b1), ca_w2=_ptr(ca.w2), ca_b2=_ptr(ca.b2),
                                          hidden=_ptr(hid), gate=_ptr(gate), qgate=_ptr(qg), xchg=_ptr(plan.rcab_xchg),
                                          xchg_bytes=plan.rcab_xchg.numel(), epoch=_ptr(plan.rcab_epoch), status=_ptr(plan.rcab_status))
                         fwd.append(('rumpy_rcab_fwd', L.RcabArgs(
                             x=_ptr(cur), w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed),
-                            t=_ptr(t1) if train else None, t2=_ptr(t2) if train else None, out=_ptr(y), mean=_ptr(mean), seq=seq, fmt=fmt, **rc_common)))
+                            t=_ptr(t1) if train else None, t2=_ptr(t2) if train else None, out=_ptr(y), mean=_ptr(mean), seq=seq, fmt=fmt, **rc_common, **f8f)))
                     elif fused:   # conv -> ReLU -> conv (+ pool partial sums) in one launch, no residual yet (the gate comes first)
                         fwd.append(('rumpy_conv_block', L.BlockArgs(
                             x=_ptr(cur), w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed), mask=None,
@@ -551,7 +556,7 @@ class SREngine:
                             ntiles=ptiles, inv_hw=1.0 / (H * W), qgate=_ptr(qg), fmt=fmt)))
 
                     def node(g_out, extra, x_in=cur, t1=t1, t2=t2, c1=c1, c2=c2, ca=ca, mean=mean, hid=hid, gate=gate, fused=fused, qg=qg, qdz=qdz,
-                             rc_common=rc_common, rc_seq=seq):
+                             rc_common=rc_common, rc_seq=seq, rc_f8b=(rc_f8b if rc else None)):
                         # y = x + t2*gate:  dgate = sum(g*t2) -> MLP backward -> dpool ; dt2 = g*gate + dpool
                         nchunks = (H * W + 127) // 128
                         part = self._new(plan, N, nchunks, F, dtype=torch.float32)
@@ -562,7 +567,7 @@ class SREngine:
                             bwd.append(('rumpy_rcab_bwd', L.RcabArgs(
                                 x=_ptr(g_out), w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, t=_ptr(dt1), t2=_ptr(dt2), t2_in=_ptr(t2),
                                 mask=_ptr(t1), res2=_ptr(extra), out=_ptr(dx), mean=None, dz=_ptr(dz), dzq=_ptr(qdz),
-                                seq=rc_seq + 1, **rc_common)))
+                                seq=rc_seq + 1, **rc_common, **rc_f8b())))
                         else:
                             bwd.append(('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=_ptr(g_out), t=_ptr(t2), partial=_ptr(part),
                                                                                   N=N, HW=H * W, C=F)))

@@ -290,7 +290,45 @@ def test_edsr_baseline_fp8_training_step_against_the_fp32_oracle():
     assert torch.equal(h.run_eval(x=xe)[0], h2.run_eval(x=xe)[0])
 
 
-@pytest.mark.parametrize('name,kw', [('edsr', dict(scale=2, num_blocks=4, res_scale=0.1))])
+def test_rcan_fp8_training_step_against_the_fp32_oracle():
+    """RCAN 10 x 20 - the generator of BASELINE config 5 - one run_train step with precision='fp8' (every RCAB in one launch forward and one
+    backward, both sweeps on the fp8 MFMA: conv_rcab_fp8.hip) against OracleHandler, in the tolerance class of this precision."""
+    h, oh = _pair('rcan', 2025, scale=4)
+    x, y = O.synthetic_batch(79, 2, lr_hw=48, scale=4)
+    loss, out = h.run_train(x=x, y=y)
+    oloss, oout = oh.run_train(x, y)
+    eng = h.net.engine
+    plan = eng.plan_for(2, 48, 48, True)
+    assert eng.fp8 and plan.f8_f_n == 200 and plan.f8_b_n == 200
+    assert all(a.w1_f8 for n_, a in plan.fwd + plan.bwd if n_ in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd'))
+    assert eng.exchange_status() == 0
+    assert abs(float(loss) - float(oloss)) < 5e-3 * float(oloss)
+    whole, cos, worst = _grad_stats(h, oh)
+    print('RCAN fp8: whole-gradient rel %.3e, cosine %.5f, worst 3x3 tensor %.3e (%s)' % (whole, cos, worst[0], worst[1]))
+    assert whole <= 5e-2 and cos >= 0.998 and worst[0] <= 1.5e-1, (whole, cos, worst)
+
+
+def test_blind_qrcan_fp8_step_runs_next_to_the_bf16_step():
+    """BASELINE config 5 as named: contrastive degradation encoder + QRCAN with q-layers, precision='fp8' (the encoder and the q-layer MLPs are
+    not matrix-pipe work and stay as they are).  Three steps next to the bf16 handler from the same weights: losses within 1 %."""
+    kw = dict(scale=4, n_resgroups=2, n_resblocks=3, style='standard', include_q_layer=True, block_encoder_loading=True,
+              selective_meta_blocks=[True, False], num_q_layers_inner_residual=1, lr=1e-4)
+    torch.manual_seed(8)
+    h8 = _handler('contrastiveblindqrcan', precision='fp8', **kw)
+    torch.manual_seed(8)
+    h16 = _handler('contrastiveblindqrcan', **kw)
+    h16.net.load_state_dict(h8.net.state_dict())
+    for step in range(3):
+        x, y = O.synthetic_batch(90 + step, 4, lr_hw=48, scale=4)
+        l8, _ = h8.run_train(x=x, y=y)
+        l16, _ = h16.run_train(x=x, y=y)
+        assert np.isfinite(float(l8)) and abs(float(l8) - float(l16)) < 1e-2 * float(l16), (step, float(l8), float(l16))
+    gen = h8.net.hip_generator
+    plan = gen.engine.plan_for(4, 48, 48, True)
+    assert gen.engine.fp8 and plan.f8_f_n == 6 and plan.f8_b_n == 6 and gen.engine.exchange_status() == 0
+
+
+@pytest.mark.parametrize('name,kw', [('edsr', dict(scale=2, num_blocks=4, res_scale=0.1)), ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=3, reduction=16))])
 def test_fp8_training_trajectory_stays_within_one_percent_of_the_oracle(name, kw):
     """the learnable task of tests/test_network_gpu.py::test_training_trajectory_follows_the_oracle_on_a_learnable_task (HR = smooth images,
     LR = their 2x average pooling, default-initialised weights, 40 Adam steps) with precision='fp8': the loss stays within 1 % of the fp32
