@@ -16,19 +16,25 @@ constexpr int BREGS = (BPIECES + BTHREADS - 1) / BTHREADS;   // 8
 // images (the round-1/2 geometry = BlockGeo<3, false>).  CT = true: the image is cut into column tiles of OW = 16 NC output columns; the
 // second conv then needs T on one REAL halo column per side, so the input image carries two halo columns per side and every wave computes
 // one more (half-filled) MFMA tile in the first phase: its 4 T rows x the 2 halo columns (block_common.hpp::halo_sweep).
-template <int NC_, bool CT_> struct BlockGeo {
+// SH = rows of a strip (round 4): 6 everywhere until round 3.  With 32-column tiles (NC = 2) a strip may also be 4 or 8 rows high, so that the
+// number of workgroups of a launch lands on a multiple of the CUs: 16 crops of 64 x 64 are 16 x 11 x 2 = 352 workgroups of 6 rows (1.4 rounds on
+// 256 CUs) and 16 x 8 x 2 = 256 of 8 rows (one round).  A row half owns OR = SH / 2 output rows and TR = OR + 1 rows of the intermediate image.
+template <int NC_, bool CT_, int SH_ = BSH> struct BlockGeo {
   static constexpr int NC = NC_, OW = 16 * NC_;
   static constexpr bool CT = CT_;
+  static constexpr int SH = SH_, OR = SH_ / 2, TR = SH_ / 2 + 1;
+  static constexpr int XROWS = SH_ + 4, TROWS = SH_ + 2;
   static constexpr int XH = CT_ ? 2 : 1;                 // halo columns per side of the input image
   static constexpr int XC = OW + 2 * XH;                 // columns of the input image in LDS
   static constexpr int TC = OW + 2;                      // columns of the T image in LDS
-  static constexpr int XBYTES = BXROWS * XC * 128, TBYTES = BTROWS * TC * 128;
-  static constexpr int XPIECES = BXROWS * XC * 8;        // 16-byte pieces of the input tile
+  static constexpr int XBYTES = XROWS * XC * 128, TBYTES = TROWS * TC * 128;
+  static constexpr int XPIECES = XROWS * XC * 8;         // 16-byte pieces of the input tile
   static constexpr int XREGS = (XPIECES + BTHREADS - 1) / BTHREADS;
-  static constexpr int GPIECES = 3 * OW * 8;             // a row half's 3 strip rows as 16-byte pieces
+  static constexpr int GPIECES = OR * OW * 8;            // a row half's strip rows as 16-byte pieces
   static constexpr int GREGS = (GPIECES + 255) / 256;
-  static constexpr int SPIECES = BSH * OW * 8;           // the whole strip
+  static constexpr int SPIECES = SH_ * OW * 8;           // the whole strip
   static constexpr int SREGS = (SPIECES + BTHREADS - 1) / BTHREADS;
+  static_assert(SH_ == BSH || (NC_ == 2 && CT_), "strips of 4 or 8 rows are built for 32-column tiles");
 };
 typedef BlockGeo<3, false> GeoL;       // W <= 48: BXBYTES / BTBYTES / BCOLS above
 
@@ -189,7 +195,7 @@ __device__ __forceinline__ void strip_stage(uint4 (&S)[G::SREGS], const unsigned
 // element offset of piece i in an [N,H,W,64] tensor, or 0xffffffff when the pixel lies outside the image (x0 = image column of strip column 0)
 template <class G = GeoL>
 __device__ __forceinline__ unsigned strip_piece_off(int i, int tid, int n, int sy, int H, int W, int x0 = 0) {
-  const int p = tid + BTHREADS * i, pix = p >> 3, r = pix / G::OW, col = pix - r * G::OW, y = sy * BSH + r;
+  const int p = tid + BTHREADS * i, pix = p >> 3, r = pix / G::OW, col = pix - r * G::OW, y = sy * G::SH + r;
   return (p < G::SPIECES && y < H && x0 + col < W) ? (unsigned)(((n * H + y) * W + x0 + col) * 64 + (p & 7) * 8) : 0xffffffffu;
 }
 
@@ -214,11 +220,11 @@ __device__ __forceinline__ void group_stage(uint4 (&S)[G::GREGS], const unsigned
 #pragma unroll
   for (int i = 0; i < G::GREGS; ++i) {
     const int p = tg + 256 * i, pix = (p < G::GPIECES ? p : 0) >> 3, r = pix / G::OW, col = pix - r * G::OW;
-    S[i] = *reinterpret_cast<const uint4*>(img + swz((3 * rh + r + ROW0) * COLS + col + CO, p & 7));
+    S[i] = *reinterpret_cast<const uint4*>(img + swz((G::OR * rh + r + ROW0) * COLS + col + CO, p & 7));
   }
 }
 template <class G = GeoL>
 __device__ __forceinline__ unsigned group_piece_off(int i, int tg, int rh, int n, int sy, int H, int W, int x0 = 0) {
-  const int p = tg + 256 * i, pix = p >> 3, r = pix / G::OW, col = pix - r * G::OW, y = sy * BSH + 3 * rh + r;
+  const int p = tg + 256 * i, pix = p >> 3, r = pix / G::OW, col = pix - r * G::OW, y = sy * G::SH + G::OR * rh + r;
   return (p < G::GPIECES && y < H && x0 + col < W) ? (unsigned)(((n * H + y) * W + x0 + col) * 64 + (p & 7) * 8) : 0xffffffffu;
 }

@@ -27,6 +27,7 @@
 // sweeps, row-half gates, whole-line stores - is the W <= 48 kernel with the geometry as a template parameter; per accumulator the MFMA
 // order is unchanged, so the results are bitwise those of the two-launch path (test_conv_block_column_tiles_*).
 #include "block_common.hpp"
+#include <cstdlib>
 
 // (The timing-experiment builds of rounds 1-3 - phase stamps, pieces compiled out, alternative prologue orders - live as a patch under
 // tests/tools/patches/abl_r03.patch; this file holds the product kernel only.)
@@ -41,8 +42,9 @@
 template <bool GEN, int FORM = 0, int FMT = RUMPY_FMT_BF16, class G = GeoL>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   constexpr int NC = G::NC, XC = G::XC, TC = G::TC, XH = G::XH;
-  constexpr int NP1 = NC == 3 ? 6 : 4;     // paired tiles of the first phase (4 rows x NC column tiles)
-  constexpr int NP2 = NC == 3 ? 4 : 3;     // ... of the second phase (3 rows x NC; NC = 3 leaves one single tile)
+  constexpr int SH = G::SH, OR = G::OR, TR = G::TR;       // strip rows, output rows / T rows per row half
+  constexpr int NP1 = NC == 3 ? 6 : TR;    // paired tiles of the first phase (TR rows x NC column tiles; NC = 2: one pair per row)
+  constexpr int NP2 = NC == 3 ? 4 : OR;    // ... of the second phase (OR rows x NC; NC = 3 leaves one single tile)
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::XBYTES + G::TBYTES];
   __shared__ unsigned gate[8];             // waves of row half 0 / 1 that have written their T rows [0, 1], their OUT rows [2, 3] (block_common.hpp::gate_*);
                                            // [4] waves that have written the early part of the input tile, [5] row half 1's waves: the late part
@@ -64,7 +66,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   // the rest is loaded by row half 1's threads (row half 0 issues as many loads of one cached line instead: every wave runs the same,
   // unconditional load sequence, so the compiler's waits stay counted).  Row half 0 starts its first sweep when rows 0 .. 5 are in LDS, row half
   // 1 when everything is; the first conv's filter is requested before the tile, so its (L2-hit) latency lies under the tile's.
-  constexpr int R0 = (6 * XC * 8 + BTHREADS - 1) / BTHREADS;                               // rounds that cover input rows 0 .. 5
+  constexpr int R0 = ((TR + 2) * XC * 8 + BTHREADS - 1) / BTHREADS;                        // rounds that cover input rows 0 .. TR + 1 (row half 0's window)
   constexpr int LATE = G::XPIECES - R0 * BTHREADS > 0 ? G::XPIECES - R0 * BTHREADS : 0;
   constexpr int R1 = (LATE + 255) / 256;                                                     // rounds of row half 1's 256 threads for the rest
   if (tid < 8) gate[tid] = 0u;
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   };
   {
     uint4 R[R0], Rl[R1 > 0 ? R1 : 1];
-    const int y0 = sy * BSH - 2;
+    const int y0 = sy * SH - 2;
     auto fetch = [&](int p, bool live) -> uint4 {
       const int pix = p >> 3, part = p & 7;
       const int lr = pix / XC, lc = pix - lr * XC;
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     for (int i = 0; i < R1; ++i) Rl[i] = fetch(R0 * BTHREADS + tg + 256 * i, rh == 1);
     fetch_filter();                          // behind the tile's requests (returns in order): under the tile's latency, not in front of it
     // border columns of the T image: convB's zero padding, never written by the epilogue (column tiles: real T values, written by the halo tile)
-    if (!G::CT && tid < BTROWS * 2 * 8) {
+    if (!G::CT && tid < G::TROWS * 2 * 8) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
@@ -126,8 +128,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
   unsigned MB[FORM == 3 ? NP1 : 1];
 #pragma unroll
   for (int k = 0; k < NP1; ++k) {
-    const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
-    const int y = sy * BSH - 1 + 4 * rh + jr, xx = x0 + 16 * c + px;
+    const int jr = (k < TR) ? k : (2 * (k - TR) + (g & 1)), c = (k < TR) ? (g & 1) : 2;
+    const int y = sy * SH - 1 + TR * rh + jr, xx = x0 + 16 * c + px;
     const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
     moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
     if (FORM == 0 || FORM == 2) {
@@ -137,22 +139,22 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     if (FORM == 3) MB[FORM == 3 ? k : 0] = a.mbits[(in ? moff[k] : 0u) >> 3];
   }
   // column tiles: this lane's pixel of the halo tile = T row hj, halo side px & 1 (lanes px >= 8 repeat lanes px - 8 and store nothing)
-  const int hj = 4 * rh + ((px >> 1) & 3), htc = (px & 1) ? TC - 1 : 0;
+  const int hj = TR * rh + ((px >> 1) < TR ? (px >> 1) : TR - 1), htc = (px & 1) ? TC - 1 : 0;      // (lanes px >= 2 TR repeat the last row and store nothing)
   unsigned hoffe = 0xffffffffu;            // element offset of (that pixel, channel c0) in an [N,H,W,64] tensor, or outside the image
   uint2 HM = make_uint2(0, 0);
   unsigned HB = 0;
   if (G::CT) {
-    const int y = sy * BSH - 1 + hj, xx = x0 - 1 + htc;
+    const int y = sy * SH - 1 + hj, xx = x0 - 1 + htc;
     if (((unsigned)y < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W)) hoffe = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
     if (FORM == 2 || (FORM == 0 && a.mask)) HM = *reinterpret_cast<const uint2*>(a.mask + (hoffe != 0xffffffffu ? hoffe : 0u));
     if (FORM == 3) HB = a.mbits[(hoffe != 0xffffffffu ? hoffe : 0u) >> 3];
   }
   {
-    f32x4 acc[4][NC];
+    f32x4 acc[TR][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.b1) { const float4 t = *reinterpret_cast<const float4*>(a.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < TR; ++r)
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     unsigned off[8][2];
@@ -168,12 +170,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       return t;
     };
     auto t_pair = [&](int k) {          // k is a constant after unrolling
-      const f32x4 tx = post1((k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][NC - 1]);
-      const f32x4 ty = post1((k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][NC - 1]);
+      const f32x4 tx = post1((k < TR) ? acc[k < TR ? k : 0][0] : acc[2 * (k < TR ? 0 : k - TR)][NC - 1]);
+      const f32x4 ty = post1((k < TR) ? acc[k < TR ? k : 0][1] : acc[2 * (k < TR ? 0 : k - TR) + 1][NC - 1]);
       float v[8];
       pair_up(tx, ty, g, v);
-      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
-      const int j = 4 * rh + jr, xx = 16 * c + px;
+      const int jr = (k < TR) ? k : (2 * (k - TR) + (g & 1)), c = (k < TR) ? (g & 1) : 2;
+      const int j = TR * rh + jr, xx = 16 * c + px;
       uint4 o = make_uint4(0, 0, 0, 0);                      // outside the image: convB's zero padding
       if (moff[k] != 0xffffffffu) {
         const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
@@ -197,10 +199,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
           o = make_uint2(m4.x, m4.y);
         }
       }
-      if (px < 8) *reinterpret_cast<uint2*>(ldt + swz(hj * TC + htc, 2 * q + (g >> 1)) + (g & 1) * 8) = o;
+      if (px < 2 * TR) *reinterpret_cast<uint2*>(ldt + swz(hj * TC + htc, 2 * q + (g >> 1)) + (g & 1) * 8) = o;
     }
-    sweep_bases<XC>(off, 0u, 4 * rh, px, g, G::CT ? 1 : 0);
-    block_sweep<4, FMT, NoHook, NC, XC>(acc, F, lds, off);
+    sweep_bases<XC>(off, 0u, TR * rh, px, g, G::CT ? 1 : 0);
+    block_sweep<TR, FMT, NoHook, NC, XC>(acc, F, lds, off);
     // second filter: L2 hits that land under the epilogue
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
@@ -236,11 +238,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
 
   // ---- phase 2: output rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ; OUT = X + scale2 * (convB(T) + b2) [+ res2] ----
   {
-    f32x4 acc[3][NC];
+    f32x4 acc[OR][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.b2) { const float4 t = *reinterpret_cast<const float4*>(a.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < OR; ++r)
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     // GEN, res_mode 2: the residual vectors are requested before the sweep and land under it
@@ -250,14 +252,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     if (GEN) {
 #pragma unroll
       for (int k = 0; k < NP2; ++k) {
-        const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-        const int y = sy * BSH + 3 * rh + r, xx = x0 + 16 * c + px;
+        const int r = (k < OR) ? k : (g & 1), c = (k < OR) ? (g & 1) : 2;
+        const int y = sy * SH + OR * rh + r, xx = x0 + 16 * c + px;
         roff[k] = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
         P1p[k] = make_uint4(0, 0, 0, 0);
         if (a.res_mode == 2) P1p[k] = *reinterpret_cast<const uint4*>(a.res1 + (roff[k] != 0xffffffffu ? roff[k] : 0u));
       }
       if (NC == 3) {
-        const int y = sy * BSH + 3 * rh + 2, xx = x0 + 32 + px;
+        const int y = sy * SH + OR * rh + 2, xx = x0 + 32 + px;
         rsoff = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0) : 0xffffffffu;
         if (a.res_mode == 2) P1s = *reinterpret_cast<const uint2*>(a.res1 + (rsoff != 0xffffffffu ? rsoff : 0u));
       }
@@ -265,25 +267,25 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
     unsigned off[8][2];
     if (rh == 0) {
       sweep_bases<TC>(off, (unsigned)G::XBYTES, 0, px, g);
-      block_sweep<2, FMT, decltype(t_store), NC, TC>(*reinterpret_cast<f32x4(*)[2][NC]>(&acc[0]), F, lds, off, t_store);   // output rows 0, 1 <- T rows 0 .. 3
+      block_sweep<OR - 1, FMT, decltype(t_store), NC, TC>(*reinterpret_cast<f32x4(*)[OR - 1][NC]>(&acc[0]), F, lds, off, t_store);   // output rows 0 .. OR-2 <- T rows 0 .. OR (this half's own)
       gate_wait(&gate[1], 4u);
-      sweep_bases<TC>(off, (unsigned)G::XBYTES, 2, px, g);
-      block_sweep<1, FMT, NoHook, NC, TC>(*reinterpret_cast<f32x4(*)[1][NC]>(&acc[2]), F, lds, off);                        // output row 2 <- T rows 2 .. 4
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, OR - 1, px, g);
+      block_sweep<1, FMT, NoHook, NC, TC>(*reinterpret_cast<f32x4(*)[1][NC]>(&acc[OR - 1]), F, lds, off);                              // output row OR-1 <- T rows OR-1 .. OR+1
     } else {
-      sweep_bases<TC>(off, (unsigned)G::XBYTES, 3, px, g);
-      block_sweep<3, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                           // output rows 3 .. 5 <- T rows 3 .. 7
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, OR, px, g);
+      block_sweep<OR, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                                     // output rows OR .. SH-1 <- T rows OR .. SH+1
     }
     float ps[4] = {0.f, 0.f, 0.f, 0.f};                         // GEN pool sums: single tile, channels 4g .. 4g+3 of the wave's 16
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    //                paired tiles, channels 4(g&~1) .. +7
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
 #pragma unroll
     for (int k = 0; k < NP2; ++k) {
-      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][NC - 1];
-      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][NC - 1];
+      const f32x4 tx = (k < OR) ? acc[k < OR ? k : 0][0] : acc[0][NC - 1];
+      const f32x4 ty = (k < OR) ? acc[k < OR ? k : 0][1] : acc[1][NC - 1];
       float v[8], m[8];
       pair_up(tx, ty, g, v);
-      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-      const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
+      const int r = (k < OR) ? k : (g & 1), c = (k < OR) ? (g & 1) : 2;
+      const int srow = OR * rh + r, y = sy * SH + srow, xx = 16 * c + px;
       if (y < a.H && x0 + xx < a.W) {
         if (!GEN) {
           unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * XC + xx + XH, chunk8)), m);   // residual = the input tile
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_kernel(BlockDev a) {
       }
     }
     if (NC == 3) {
-      const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px;
+      const int srow = OR * rh + 2, y = sy * SH + srow, xx = 32 + px;
       if (y < a.H && x0 + xx < a.W) {
         float v[4] = {acc[2][NC - 1][0], acc[2][NC - 1][1], acc[2][NC - 1][2], acc[2][NC - 1][3]};
         float m[4];
@@ -393,6 +395,40 @@ static void block_launch(const rumpy_block_args* p, const BlockDev& d, hipStream
   }
 }
 
+// Round 4: strips of 4 / 8 rows x 32-column tiles, for the ResBlock forms the engine launches (forward bf16 / fp16, mask-byte data gradient)
+template <int SH>
+static void block_launch_rows(const rumpy_block_args* p, const BlockDev& d, hipStream_t s) {
+  typedef BlockGeo<2, true, SH> G;
+  const dim3 grid(d.N * d.sy_n * d.ct_n);
+  if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1, RUMPY_FMT_F16, G>), grid, dim3(BTHREADS), s, d);
+  else if (p->relu1) RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 1, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+  else RUMPY_LAUNCH_PROBED(5, (conv_block_kernel<false, 3, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+}
+
+// Geometry of a ResBlock-form launch on [N, H, W] (W > 48): strip rows SH in {4, 6, 8} x column tiles of 16 NC columns.  A workgroup is alone on
+// its CU, so a launch costs (rounds of workgroups on the CUs) x (time of one workgroup); one workgroup = (2 SH + 2 rows of MFMA work: the first
+// conv also on the two halo rows; + about 6 rows' worth of what is paid once: prologue, gates, epilogue tails) x (NC column tiles + 1: the halo
+// tile and the two extra input columns per side).  The count lands on or just under a multiple of the CUs where it can: 16 x 64 x 64 ->
+// 8 rows x 32 columns = 256 workgroups (one round; 6 rows: 352 = two rounds), 339 x 510 -> 8 x 32 (688 workgroups, three rounds of less).
+// RUMPY_BLOCK_GEO="SH,NC" forces one (A/B runs).
+static void block_geometry(int N, int H, int W, bool rows_ok, int* sh, int* nc, int* ct_n) {
+  block_col_tiles(W, nc, ct_n);
+  *sh = BSH;
+  if (!rows_ok || W <= BSW) return;
+  const char* force = getenv("RUMPY_BLOCK_GEO");          // (read per call: the tests toggle it)
+  const int cus = rumpy_device_cus();
+  long best = -1;
+  const int cand[4][2] = {{BSH, *nc}, {BSH, 2}, {8, 2}, {4, 2}};
+  for (int i = 0; i < 4; ++i) {
+    const int h = cand[i][0], c = cand[i][1];
+    if (force && (force[0] - '0' != h || force[2] - '0' != c)) continue;
+    const int ct = (W + 16 * c - 1) / (16 * c);
+    const long wgs = (long)N * ((H + h - 1) / h) * ct;
+    const long cost = ((wgs + cus - 1) / cus) * (2 * h + 2 + 6) * (c + 1);
+    if (best < 0 || cost < best) { best = cost; *sh = h; *nc = c; *ct_n = ct; }
+  }
+}
+
 // rows of per-image pool partial sums a rumpy_conv_block launch with `pool` writes: 2 per (strip row, column tile)
 extern "C" int rumpy_block_pool_tiles(int32_t H, int32_t W) {
   int nc, ct_n;
@@ -415,10 +451,14 @@ extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
   BlockDev d;
   d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
   d.mask = (const uint16_t*)p->mask; d.res2 = (const uint16_t*)p->res2; d.t = (uint16_t*)p->t; d.out = (uint16_t*)p->out;
-  d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = (p->H + BSH - 1) / BSH; d.relu1 = p->relu1; d.scale1 = p->scale1; d.scale2 = p->scale2;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.relu1 = p->relu1; d.scale1 = p->scale1; d.scale2 = p->scale2;
   d.res_mode = p->res_mode; d.res1 = (const uint16_t*)p->res1; d.pool = p->pool; d.mbits = (unsigned char*)p->maskbits;
-  int nc;
-  block_col_tiles(p->W, &nc, &d.ct_n);
+  // the forms with kernels at every strip height: ResBlock forward (bf16 / fp16) and its mask-byte data gradient
+  const bool rows_ok = p->res_mode == 0 && !p->pool && !p->col_tile &&
+                       ((p->relu1 && p->scale1 == 1.0f && !p->mask) || (!p->relu1 && p->maskbits && p->fmt == RUMPY_FMT_BF16));
+  int nc, sh;
+  block_geometry(p->N, p->H, p->W, rows_ok, &sh, &nc, &d.ct_n);
+  d.sy_n = (p->H + sh - 1) / sh;
   bool tiled = p->W > BSW;
   if (p->col_tile) {
     if ((p->col_tile != 2 && p->col_tile != 3) || p->pool) { rumpy_set_error("rumpy_conv_block: col_tile is 0, 2 or 3 (and not with pool)"); return RUMPY_E_ARG; }
@@ -432,6 +472,8 @@ extern "C" int rumpy_conv_block(const rumpy_block_args* p, void* stream) {
     rumpy_set_error("rumpy_conv_block: fmt %d goes with the forward forms only", p->fmt); return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   if (!tiled) block_launch<GeoL>(p, d, s);
+  else if (sh == 8) block_launch_rows<8>(p, d, s);
+  else if (sh == 4) block_launch_rows<4>(p, d, s);
   else if (nc == 3) block_launch<BlockGeo<3, true> >(p, d, s);
   else block_launch<BlockGeo<2, true> >(p, d, s);
   return rumpy_check_launch("rumpy_conv_block");

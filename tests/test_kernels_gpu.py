@@ -653,6 +653,45 @@ def test_conv_block_geometries_agree_bitwise(N, H, W):
     assert L.lib().rumpy_conv_block(a, None) == -1 and b'col_tile' in L.lib().rumpy_last_error()
 
 
+@pytest.mark.parametrize('N,H,W', [(2, 13, 64), (1, 20, 100), (16, 64, 64), (1, 7, 49), (3, 33, 130)])
+def test_conv_block_strip_heights_agree_bitwise(N, H, W, monkeypatch):
+    """round 4: strips of 4 / 6 / 8 rows x column tiles of 32 / 48 columns (the geometry rumpy_conv_block picks by itself so that the
+    workgroup count fits the CUs; RUMPY_BLOCK_GEO forces one) compute every output element with the same MFMA sequence: activation, output
+    and mask bytes of the forward launch (bf16 and fp16) and both tensors of the mask-byte data-gradient launch are bitwise equal."""
+    gen = np.random.default_rng(900 + H + W)
+    pa, pb = PackedConv(*_wb(gen, 64, 64)), PackedConv(*_wb(gen, 64, 64))
+    rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    x, g, extra = rnd(), rnd(), rnd()
+    xh = x.float().to(torch.float16)
+    wh = lambda pc: pc.w_fwd.float().to(torch.float16)      # (any fp16 bit patterns do for a bitwise comparison between geometries)
+    pah, pbh = wh(pa), wh(pb)
+    res = []
+    for geo in ('6,3', '6,2', '8,2', '4,2', None):
+        if geo is None:
+            monkeypatch.delenv('RUMPY_BLOCK_GEO', raising=False)
+        else:
+            monkeypatch.setenv('RUMPY_BLOCK_GEO', geo)
+        t, y, dt, dx = (torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV) for _ in range(4))
+        yh = torch.full((N, H, W, 64), float('nan'), dtype=torch.float16, device=DEV)
+        mb = torch.full((N, H, W, 8), 0xAA, dtype=torch.uint8, device=DEV)
+        L.call('rumpy_conv_block', L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
+                                               b2=pb.b_packed.data_ptr(), t=t.data_ptr(), out=y.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0,
+                                               scale2=0.1, maskbits=mb.data_ptr()), stream())
+        L.call('rumpy_conv_block', L.BlockArgs(x=xh.data_ptr(), w1=pah.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pbh.data_ptr(),
+                                               b2=pb.b_packed.data_ptr(), out=yh.data_ptr(), N=N, H=H, W=W, relu1=1, scale1=1.0, scale2=0.1,
+                                               fmt=L.FMT_F16), stream())
+        L.call('rumpy_conv_block', L.BlockArgs(x=g.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), res2=extra.data_ptr(),
+                                               t=dt.data_ptr(), out=dx.data_ptr(), N=N, H=H, W=W, relu1=0, scale1=0.1, scale2=1.0,
+                                               maskbits=mb.data_ptr()), stream())
+        torch.cuda.synchronize()
+        outs = [t, y, mb, yh, dt, dx]
+        assert all(torch.isfinite(o.float()).all() for o in outs if o.dtype != torch.uint8), geo
+        res.append(outs)
+    for gi, other in enumerate(res[1:]):
+        for i, (a, b) in enumerate(zip(res[0], other)):
+            assert torch.equal(a.view(torch.int16) if a.dtype != torch.uint8 else a, b.view(torch.int16) if b.dtype != torch.uint8 else b), (gi, i)
+
+
 @pytest.mark.parametrize('N,H,W', [(2, 13, 48), (3, 20, 37), (8, 48, 48), (2, 13, 64), (1, 20, 100)])
 def test_conv_block_rcab_form_matches_two_layer_launches(N, H, W):
     """general form of the block kernel (RCAB): no residual + pool partial sums forward; external residual operand backward"""
