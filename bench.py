@@ -587,6 +587,8 @@ def main():
                     kname = 'conv_block_fp8_kernel (residual block per launch, both sweeps on the block-scaled fp8 MFMA; fwd + data-gradient launches)'
                 if rcabs:
                     kname = 'rcab_kernel (residual channel-attention block per launch: two 3x3 convs 64->64 + attention gate; fwd + bwd launches)'
+                    if fp8 and all(a.w1_f8 for a in rcabs):
+                        kname = 'rcab_fp8_kernel (residual channel-attention block per launch, both sweeps on the block-scaled fp8 MFMA; fwd + bwd launches)'
             else:
                 flop = layer_flop
                 tensors = [2 + sum(1 for f in ('mask', 'res1', 'res2') if getattr(a, f))

@@ -22,14 +22,16 @@
 // exchange is then a (column tile, strip row) pair, ns = ceil(H/6) * column tiles of them per image, all of which must be resident
 // together (ns <= CUs; the reference's 64 x 64 training crops are 22).
 #include "rcab_common.hpp"
+#include <cstdlib>
 
 // MB (backward only): the ReLU mask comes as bytes (written by the forward launch) instead of the bf16 activation
 // FMT: element format (RUMPY_FMT_F16 is instantiated for the forward launch only: evaluation plans)
 template <bool BWD, bool MB = false, int FMT = RUMPY_FMT_BF16, class G = GeoL>
 __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   constexpr int NC = G::NC, XC = G::XC, TC = G::TC, XH = G::XH, OW = G::OW;
-  constexpr int NP1 = NC == 3 ? 6 : 4;     // paired tiles of the first phase (4 rows x NC column tiles)
-  constexpr int NP2 = NC == 3 ? 4 : 3;     // ... of the second phase (3 rows x NC; NC = 3 leaves one single tile)
+  constexpr int SH = G::SH, OR = G::OR, TR = G::TR;       // strip rows, output rows / T rows per row half (block_common.hpp::BlockGeo)
+  constexpr int NP1 = NC == 3 ? 6 : TR;    // paired tiles of the first phase (TR rows x NC column tiles; NC = 2: one pair per row)
+  constexpr int NP2 = NC == 3 ? 4 : OR;    // ... of the second phase (OR rows x NC; NC = 3 leaves one single tile)
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::XBYTES + G::TBYTES];
   __shared__ float sx[8 * 64];
   __shared__ float spool[2 * 64];
@@ -83,7 +85,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   }
   {
     uint4 R[G::XREGS];
-    const int y0 = sy * BSH - 2;
+    const int y0 = sy * SH - 2;
 #pragma unroll
     for (int i = 0; i < G::XREGS; ++i) {
       const int p = tid + BTHREADS * i;
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       for (int i = 0; i < G::SREGS; ++i) {
         const int p = tid + BTHREADS * i;
         const int pix = p >> 3, r = pix / OW, col = pix - r * OW;
-        const int y = sy * BSH + r;
+        const int y = sy * SH + r;
         const bool ok = (p < G::SPIECES) & (y < a.H) & (x0 + col < a.W);
         const int e = ok ? ((n * a.H + y) * a.W + x0 + col) * 64 + (p & 7) * 8 : 0;
         uint4 v = *reinterpret_cast<const uint4*>(a.t2_in + (unsigned)e);
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         T2[i] = v;
       }
     }
-    if (!G::CT && tid < BTROWS * 2 * 8) {       // (column tiles: the halo tile of the first phase writes these columns)
+    if (!G::CT && tid < G::TROWS * 2 * 8) {       // (column tiles: the halo tile of the first phase writes these columns)
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     float mine = 0.f;
     if (tid < 64) mine = (red[64 * 64 + tid] + red[64 * 64 + 64 + tid]) + (red[64 * 64 + 128 + tid] + red[64 * 64 + 192 + tid]);
     __syncthreads();                                        // red is dead: the border columns of the T image are rewritten below
-    if (!G::CT && tid < BTROWS * 2 * 8) {
+    if (!G::CT && tid < G::TROWS * 2 * 8) {
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     // d_t2 = dy * gate + dp / HW on every pixel of the tile that lies inside the image (outside stays the zero padding);
     // the strip's own rows also go to HBM: conv2's weight gradient reads them
     {
-      const int y0 = sy * BSH - 2;
+      const int y0 = sy * SH - 2;
       const float4 ga = *reinterpret_cast<const float4*>(sgate + (tid & 7) * 8), gb = *reinterpret_cast<const float4*>(sgate + (tid & 7) * 8 + 4);
       const float4 pa = *reinterpret_cast<const float4*>(sdp + (tid & 7) * 8), pb = *reinterpret_cast<const float4*>(sdp + (tid & 7) * 8 + 4);
 #pragma unroll
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           const uint2 hi = pack4<FMT>(fmaf(d[4], gb.x, pb.x), fmaf(d[5], gb.y, pb.y), fmaf(d[6], gb.z, pb.z), fmaf(d[7], gb.w, pb.w));
           const uint4 o = make_uint4(lo.x, lo.y, hi.x, hi.y);
           *cell = o;
-          if (lr >= 2 && lr < 2 + BSH && (!G::CT || (lc >= XH && lc < XH + OW)))      // the strip's own pixels (halo columns belong to the neighbours)
+          if (lr >= 2 && lr < 2 + SH && (!G::CT || (lc >= XH && lc < XH + OW)))      // the strip's own pixels (halo columns belong to the neighbours)
             st16_nt(a.t2 + (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8), o);     // 8 lanes per pixel: whole lines
         }
       }
@@ -249,30 +251,30 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
   unsigned MBY[(BWD && MB) ? NP1 : 1];
 #pragma unroll
   for (int k = 0; k < NP1; ++k) {
-    const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
-    const int y = sy * BSH - 1 + 4 * rh + jr, xx = x0 + 16 * c + px;
+    const int jr = (k < TR) ? k : (2 * (k - TR) + (g & 1)), c = (k < TR) ? (g & 1) : 2;
+    const int y = sy * SH - 1 + TR * rh + jr, xx = x0 + 16 * c + px;
     const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
     moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
     if (BWD && !MB) M[(BWD && !MB) ? k : 0] = *reinterpret_cast<const uint4*>(a.mask + (in ? moff[k] : 0u));
     if (BWD && MB) MBY[(BWD && MB) ? k : 0] = a.mbits[(in ? moff[k] : 0u) >> 3];
   }
   // column tiles: this lane's pixel of the halo tile = T row hj, halo side px & 1 (conv_block.hip)
-  const int hj = 4 * rh + ((px >> 1) & 3), htc = (px & 1) ? TC - 1 : 0;
+  const int hj = TR * rh + ((px >> 1) < TR ? (px >> 1) : TR - 1), htc = (px & 1) ? TC - 1 : 0;
   unsigned hoffe = 0xffffffffu;
   uint2 HM = make_uint2(0, 0);
   unsigned HB = 0;
   if (G::CT) {
-    const int y = sy * BSH - 1 + hj, xx = x0 - 1 + htc;
+    const int y = sy * SH - 1 + hj, xx = x0 - 1 + htc;
     if (((unsigned)y < (unsigned)a.H) & ((unsigned)xx < (unsigned)a.W)) hoffe = (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0);
     if (BWD && !MB) HM = *reinterpret_cast<const uint2*>(a.mask + (hoffe != 0xffffffffu ? hoffe : 0u));
     if (BWD && MB) HB = a.mbits[(hoffe != 0xffffffffu ? hoffe : 0u) >> 3];
   }
   {
-    f32x4 acc[4][NC];
+    f32x4 acc[TR][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!BWD) { const float4 t = *reinterpret_cast<const float4*>(a.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < TR; ++r)
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     unsigned off[8][2];
@@ -292,10 +294,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           o = make_uint2(m4.x, m4.y);
         }
       }
-      if (px < 8) *reinterpret_cast<uint2*>(ldt + swz(hj * TC + htc, 2 * q + (g >> 1)) + (g & 1) * 8) = o;
+      if (px < 2 * TR) *reinterpret_cast<uint2*>(ldt + swz(hj * TC + htc, 2 * q + (g >> 1)) + (g & 1) * 8) = o;
     }
-    sweep_bases<XC>(off, 0u, 4 * rh, px, g, G::CT ? 1 : 0);
-    block_sweep<4, FMT, NoHook, NC, XC>(acc, F, lds, off);
+    sweep_bases<XC>(off, 0u, TR * rh, px, g, G::CT ? 1 : 0);
+    block_sweep<TR, FMT, NoHook, NC, XC>(acc, F, lds, off);
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
@@ -303,16 +305,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     }
 #pragma unroll
     for (int k = 0; k < NP1; ++k) {
-      const f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][NC - 1];
-      const f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][NC - 1];
+      const f32x4 tx = (k < TR) ? acc[k < TR ? k : 0][0] : acc[2 * (k < TR ? 0 : k - TR)][NC - 1];
+      const f32x4 ty = (k < TR) ? acc[k < TR ? k : 0][1] : acc[2 * (k < TR ? 0 : k - 4) + 1][NC - 1];
       float v[8];
       pair_up(tx, ty, g, v);
       if (!BWD) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = relu_f32(v[j]);
       }
-      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
-      const int j = 4 * rh + jr, xx = 16 * c + px;
+      const int jr = (k < TR) ? k : (2 * (k - TR) + (g & 1)), c = (k < TR) ? (g & 1) : 2;
+      const int j = TR * rh + jr, xx = 16 * c + px;
       uint4 o = make_uint4(0, 0, 0, 0);
       if (moff[k] != 0xffffffffu) {
         const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
@@ -349,11 +351,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 
   // ---- phase 2: rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ----
   {
-    f32x4 acc[3][NC];
+    f32x4 acc[OR][NC];
     f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!BWD) { const float4 t = *reinterpret_cast<const float4*>(a.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < OR; ++r)
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     // backward: the residual operand dy (its tile in LDS now holds d_t2) is requested before the sweep and lands under it.  (Taking it
@@ -363,37 +365,37 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     uint2 P1s = make_uint2(0, 0);
 #pragma unroll
     for (int k = 0; k < NP2; ++k) {
-      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-      const int y = sy * BSH + 3 * rh + r, xx = x0 + 16 * c + px;
+      const int r = (k < OR) ? k : (g & 1), c = (k < OR) ? (g & 1) : 2;
+      const int y = sy * SH + OR * rh + r, xx = x0 + 16 * c + px;
       ooff[k] = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
       if (BWD) P1p[k] = *reinterpret_cast<const uint4*>(a.x + (ooff[k] != 0xffffffffu ? ooff[k] : 0u));
     }
     if (NC == 3) {
-      const int y = sy * BSH + 3 * rh + 2, xx = x0 + 32 + px;
+      const int y = sy * SH + OR * rh + 2, xx = x0 + 32 + px;
       osoff = (y < a.H && xx < a.W) ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0) : 0xffffffffu;
       if (BWD) P1s = *reinterpret_cast<const uint2*>(a.x + (osoff != 0xffffffffu ? osoff : 0u));
     }
     unsigned off[8][2];
     if (rh == 0) {
       sweep_bases<TC>(off, (unsigned)G::XBYTES, 0, px, g);
-      block_sweep<2, FMT, decltype(t_store), NC, TC>(*reinterpret_cast<f32x4(*)[2][NC]>(&acc[0]), F, lds, off, t_store);   // rows 0, 1 <- T rows 0 .. 3 (this half's own)
+      block_sweep<OR - 1, FMT, decltype(t_store), NC, TC>(*reinterpret_cast<f32x4(*)[OR - 1][NC]>(&acc[0]), F, lds, off, t_store);   // rows 0, 1 <- T rows 0 .. 3 (this half's own)
       gate_wait(&gate[1], 4u);
-      sweep_bases<TC>(off, (unsigned)G::XBYTES, 2, px, g);
-      block_sweep<1, FMT, NoHook, NC, TC>(*reinterpret_cast<f32x4(*)[1][NC]>(&acc[2]), F, lds, off);                        // row 2 <- T rows 2 .. 4
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, OR - 1, px, g);
+      block_sweep<1, FMT, NoHook, NC, TC>(*reinterpret_cast<f32x4(*)[1][NC]>(&acc[OR - 1]), F, lds, off);                        // row 2 <- T rows 2 .. 4
     } else {
-      sweep_bases<TC>(off, (unsigned)G::XBYTES, 3, px, g);
-      block_sweep<3, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                           // rows 3 .. 5 <- T rows 3 .. 7
+      sweep_bases<TC>(off, (unsigned)G::XBYTES, OR, px, g);
+      block_sweep<OR, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);                                           // rows 3 .. 5 <- T rows 3 .. 7
     }
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
     float V[NP2][8], vs[4];
 #pragma unroll
     for (int k = 0; k < NP2; ++k) {
-      const f32x4 tx = (k < 3) ? acc[k < 3 ? k : 0][0] : acc[0][NC - 1];
-      const f32x4 ty = (k < 3) ? acc[k < 3 ? k : 0][1] : acc[1][NC - 1];
+      const f32x4 tx = (k < OR) ? acc[k < OR ? k : 0][0] : acc[0][NC - 1];
+      const f32x4 ty = (k < OR) ? acc[k < OR ? k : 0][1] : acc[1][NC - 1];
       pair_up(tx, ty, g, V[k]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vs[j] = acc[2][NC - 1][j];      // (NC = 3 only: the single tile; osoff stays "outside" otherwise)
+    for (int j = 0; j < 4; ++j) vs[j] = acc[NC == 3 ? 2 : 0][NC - 1][j];      // (NC = 3 only: the single tile; osoff stays "outside" otherwise)
 
     if (BWD) {
       // dx = dy + conv1^T(gt1)
@@ -410,8 +412,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
           }
           const uint2 lo = pack4<FMT>(V[k][0] + m[0], V[k][1] + m[1], V[k][2] + m[2], V[k][3] + m[3]);
           const uint2 hi = pack4<FMT>(V[k][4] + m[4], V[k][5] + m[5], V[k][6] + m[6], V[k][7] + m[7]);
-          const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-          *reinterpret_cast<uint4*>(ldx + swz((3 * rh + r + 2) * XC + 16 * c + px + XH, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // dx image in place of the
+          const int r = (k < OR) ? k : (g & 1), c = (k < OR) ? (g & 1) : 2;
+          *reinterpret_cast<uint4*>(ldx + swz((OR * rh + r + 2) * XC + 16 * c + px + XH, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);   // dx image in place of the
         }                                                                                                                                // d_t2 tile (dead in phase 2)
       }
       if (osoff != 0xffffffffu) {
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) m[j] += e[j];
         }
-        *reinterpret_cast<uint2*>(ldx + swz((3 * rh + 2 + 2) * XC + 32 + px + XH, 2 * q + (g >> 1)) + (g & 1) * 8) =
+        *reinterpret_cast<uint2*>(ldx + swz((OR * rh + 2 + 2) * XC + 32 + px + XH, 2 * q + (g >> 1)) + (g & 1) * 8) =
             pack4<FMT>(vs[0] + m[0], vs[1] + m[1], vs[2] + m[2], vs[3] + m[3]);
       }
     } else {
@@ -465,13 +467,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 #pragma unroll
         for (int k = 0; k < NP2; ++k) {
           if (ooff[k] != 0xffffffffu) {
-            const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+            const int r = (k < OR) ? k : (g & 1), c = (k < OR) ? (g & 1) : 2;
             const uint2 lo = pack4<FMT>(V[k][0], V[k][1], V[k][2], V[k][3]), hi = pack4<FMT>(V[k][4], V[k][5], V[k][6], V[k][7]);
-            *reinterpret_cast<uint4*>(ldt + swz((3 * rh + r + 1) * TC + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            *reinterpret_cast<uint4*>(ldt + swz((OR * rh + r + 1) * TC + 16 * c + px + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
         }
         if (osoff != 0xffffffffu)
-          *reinterpret_cast<uint2*>(ldt + swz((3 * rh + 2 + 1) * TC + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
+          *reinterpret_cast<uint2*>(ldt + swz((OR * rh + 2 + 1) * TC + 32 + px + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(vs[0], vs[1], vs[2], vs[3]);
       }
       const float mine = (tid < 64) ? spool[tid] + spool[64 + tid] : 0.f;
       const float tot = strip_allsum(a, mine, n, si, tid, tag, sx);      // (its barriers also complete the t2 image)
@@ -513,8 +515,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
 #pragma unroll
       for (int k = 0; k < NP2; ++k) {
         if (ooff[k] != 0xffffffffu) {
-          const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-          const int srow = 3 * rh + r, xx = 16 * c + px;
+          const int r = (k < OR) ? k : (g & 1), c = (k < OR) ? (g & 1) : 2;
+          const int srow = OR * rh + r, xx = 16 * c + px;
           float m[8];
           unpack8<FMT>(*reinterpret_cast<const uint4*>(ldx + swz((srow + 2) * XC + xx + XH, chunk8)), m);
           const uint2 lo = pack4<FMT>(fmaf(V[k][0], ga.x, m[0]), fmaf(V[k][1], ga.y, m[1]), fmaf(V[k][2], ga.z, m[2]), fmaf(V[k][3], ga.w, m[3]));
@@ -523,7 +525,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         }
       }
       if (osoff != 0xffffffffu) {
-        const int srow = 3 * rh + 2, xx = 32 + px;
+        const int srow = OR * rh + 2, xx = 32 + px;
         float m[4];
         unpack4<FMT>(*reinterpret_cast<const uint2*>(ldx + swz((srow + 2) * XC + xx + XH, 2 * q + (g >> 1)) + (g & 1) * 8), m);
         const float4 gs = *reinterpret_cast<const float4*>(sgate + c0);
@@ -560,11 +562,48 @@ static void rcab_dispatch(const rumpy_rcab_args* p, const RcabDev& d, hipStream_
   else RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
 }
 
-// strips (workgroups) of one image: strip rows x column tiles; all of them exchange their pool sums, so all must be resident together
+// Geometry of a launch on [N, H, W] (round 4; conv_block.hip::block_geometry): strips of 4 / 6 / 8 rows x column tiles, chosen so that the
+// workgroup count fits the CUs - 8 crops of 64 x 64 (the reference's div2k/rcan.toml batch) are 8 x 16 x 2 = 256 workgroups of 4 rows, where
+// 6-row strips leave 80 CUs idle.  A workgroup's fixed part (exchange, MLP, gate, two more barriers) is priced at 12 rows' worth of MFMA work.
+static void rcab_geometry(int N, int H, int W, bool rows_ok, int* sh, int* nc, int* ct_n) {
+  block_col_tiles(W, nc, ct_n);
+  *sh = BSH;
+  if (!rows_ok || W <= BSW) return;
+  const char* force = getenv("RUMPY_BLOCK_GEO");          // (read per call: the tests toggle it)
+  const int cus = rumpy_device_cus();
+  long best = -1;
+  const int cand[4][2] = {{BSH, *nc}, {BSH, 2}, {8, 2}, {4, 2}};
+  for (int i = 0; i < 4; ++i) {
+    const int h = cand[i][0], c = cand[i][1];
+    if (force && (force[0] - '0' != h || force[2] - '0' != c)) continue;
+    const int ct = (W + 16 * c - 1) / (16 * c);
+    if (((H + h - 1) / h) * ct > cus) continue;           // every strip of an image has to be resident
+    const long wgs = (long)N * ((H + h - 1) / h) * ct;
+    const long cost = ((wgs + cus - 1) / cus) * (2 * h + 2 + 12) * (c + 1);
+    if (best < 0 || cost < best) { best = cost; *sh = h; *nc = c; *ct_n = ct; }
+  }
+}
+
+template <int SH>
+static void rcab_dispatch_rows(const rumpy_rcab_args* p, const RcabDev& d, hipStream_t s, bool bwd) {
+  typedef BlockGeo<2, true, SH> G;
+  const dim3 grid(d.N * d.ns);
+  if (bwd) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<true, true, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+  else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false, RUMPY_FMT_F16, G>), grid, dim3(BTHREADS), s, d);
+  else RUMPY_LAUNCH_PROBED(5, (rcab_kernel<false, false, RUMPY_FMT_BF16, G>), grid, dim3(BTHREADS), s, d);
+}
+
+// upper bound of the strips (workgroups) of one image over the geometries a launch may take: strip rows x column tiles; all of them exchange
+// their pool sums, so all must be resident together (the host sizes the exchange buffer and checks residency with it)
 extern "C" int rumpy_rcab_strips(int32_t H, int32_t W) {
   int nc, ct_n;
   block_col_tiles(W, &nc, &ct_n);
-  return ((H + BSH - 1) / BSH) * ct_n;
+  int n = ((H + BSH - 1) / BSH) * ct_n;
+  if (W > BSW) {
+    const int ct2 = (W + 31) / 32;
+    n = max(n, ((H + BSH - 1) / BSH) * ct2);
+  }
+  return n;
 }
 
 int rumpy_rcab_fp8_launch(const rumpy_rcab_args* p, const RcabDev& d0, hipStream_t s, bool bwd, const char* what);      // conv_rcab_fp8.hip
@@ -576,14 +615,18 @@ static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const c
   if (bwd && (!p->t2_in || (!p->mask && !p->maskbits) || !p->t2 || !p->dz)) { rumpy_set_error("%s: backward needs t2_in, mask, t2 (d_t2 out), dz", what); return RUMPY_E_ARG; }
   if (bwd && p->dzq && !p->qgate) { rumpy_set_error("%s: dzq without qgate", what); return RUMPY_E_ARG; }
   if (p->N <= 0 || p->H <= 0 || p->W <= 0) { rumpy_set_error("%s: bad shape", what); return RUMPY_E_ARG; }
-  const int sy_n = (p->H + BSH - 1) / BSH;
-  int nc, ct_n;
-  block_col_tiles(p->W, &nc, &ct_n);
+  // strips of 4 / 8 rows: forward (bf16 / fp16) and the mask-byte backward form, when the 4-row strips of an image still fit the CUs and the
+  // exchange buffer (sized for rumpy_rcab_strips) holds them
+  int nc, ct_n, sh;
+  const int ns4 = ((p->H + 3) / 4) * ((p->W + 31) / 32);
+  const bool rows_ok = !p->w1_f8 && (!bwd || p->maskbits) && ns4 <= rumpy_device_cus() && (int64_t)p->N * ns4 * 64 * 8 <= p->xchg_bytes;
+  rcab_geometry(p->N, p->H, p->W, rows_ok, &sh, &nc, &ct_n);
+  const int sy_n = (p->H + sh - 1) / sh;
   const int ns = sy_n * ct_n;
   if (p->cr <= 0 || p->cr > RC_MAXR || ns > rumpy_device_cus() || p->seq >= 4096u || (int64_t)p->N * p->H * p->W * 64 >= (int64_t)0xffffffffu) {
     rumpy_set_error("%s: needs strips per image = ceil(H/6) * column tiles <= CUs, 0 < Cr <= 16, seq < 4096 (W=%d H=%d strips=%d Cr=%d seq=%u)", what, p->W, p->H, ns, p->cr, p->seq); return RUMPY_E_ARG; }
   if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !bwd)) { rumpy_set_error("%s: fmt %d is a forward-only format", what, p->fmt); return RUMPY_E_ARG; }
-  const int64_t need = rumpy_rcab_xchg_bytes(p->N, p->H, p->W);
+  const int64_t need = (int64_t)p->N * ns * 64 * 8;
   if (p->xchg_bytes < need) { rumpy_set_error("%s: exchange buffer too small (%lld < %lld)", what, (long long)p->xchg_bytes, (long long)need); return RUMPY_E_ARG; }
   RcabDev d;
   d.x = (const uint16_t*)p->x; d.w1 = (const uint4*)p->w1; d.b1 = p->b1; d.w2 = (const uint4*)p->w2; d.b2 = p->b2;
@@ -597,13 +640,18 @@ static int rcab_launch(const rumpy_rcab_args* p, void* stream, bool bwd, const c
     const int rc = rumpy_rcab_fp8_launch(p, d, s, bwd, what);
     return rc ? rc : rumpy_check_launch(what);
   }
-  if (p->W <= BSW) rcab_dispatch<GeoL>(p, d, s, bwd);
+  if (sh == 8) rcab_dispatch_rows<8>(p, d, s, bwd);
+  else if (sh == 4) rcab_dispatch_rows<4>(p, d, s, bwd);
+  else if (p->W <= BSW) rcab_dispatch<GeoL>(p, d, s, bwd);
   else if (nc == 3) rcab_dispatch<BlockGeo<3, true> >(p, d, s, bwd);
   else rcab_dispatch<BlockGeo<2, true> >(p, d, s, bwd);
   return rumpy_check_launch(what);
 }
 
-extern "C" int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H, int32_t W) { return (int64_t)N * rumpy_rcab_strips(H, W) * 64 * 8; }
+extern "C" int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H, int32_t W) {
+  const int64_t ns4 = W > BSW ? (int64_t)((H + 3) / 4) * ((W + 31) / 32) : 0;          // room for the 4-row geometry as well
+  return (int64_t)N * max((int64_t)rumpy_rcab_strips(H, W), ns4) * 64 * 8;
+}
 extern "C" int rumpy_rcab_fwd(const rumpy_rcab_args* p, void* stream) { return rcab_launch(p, stream, false, "rumpy_rcab_fwd"); }
 extern "C" int rumpy_rcab_bwd(const rumpy_rcab_args* p, void* stream) { return rcab_launch(p, stream, true, "rumpy_rcab_bwd"); }
 extern "C" int rumpy_rcab_epoch_advance(void* epoch, void* stream) {

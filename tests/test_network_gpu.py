@@ -700,6 +700,36 @@ def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, m
             assert float((a - b).norm() / b.norm()) < 2e-2, k
 
 
+@pytest.mark.parametrize('geo', ['4,2', '6,2', '8,2', '6,3'])
+def test_one_launch_rcab_strip_heights_agree(geo, monkeypatch):
+    """round 4: the one-launch RCAB kernels on strips of 4 / 6 / 8 rows (rcab_geometry picks the height whose workgroup count fits the CUs;
+    RUMPY_BLOCK_GEO forces one).  The convolutions are bitwise those of every other geometry (test_conv_block_strip_heights_agree_bitwise);
+    the pool sums are added in strip order, so the gates - and everything behind them - agree to fp32 rounding, not bit for bit: checked
+    against the separate attention launches like the other geometries."""
+    kw = dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16)
+    x, y = O.synthetic_batch(661, 3, lr_hw=(33, 70), scale=2)
+    res = []
+    for no_rcab in ('0', '1'):
+        monkeypatch.setenv('RUMPY_NO_RCAB', no_rcab)
+        if no_rcab == '0':
+            monkeypatch.setenv('RUMPY_BLOCK_GEO', geo)
+        else:
+            monkeypatch.delenv('RUMPY_BLOCK_GEO', raising=False)
+        h = _handler('rcan', lr=1e-3, **kw)
+        h.net.load_state_dict(O.seeded_state_dict(O.build_oracle('rcan', **kw), 827))
+        ev, evl, _ = h.run_eval(x=x, y=y, request_loss=True)
+        loss, out = h.run_train(x=x, y=y)
+        plan = h.net.engine.plan_for(3, 33, 70, True)
+        assert ('rumpy_rcab_fwd' in [op for op, _ in plan.fwd]) == (no_rcab == '0')
+        assert h.net.engine.exchange_status() == 0
+        res.append((float(loss), out, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}, ev, float(evl)))
+    assert abs(res[0][0] - res[1][0]) < 2e-4 * abs(res[1][0]) and abs(res[0][4] - res[1][4]) < 2e-4 * abs(res[1][4])
+    assert self_psnr(res[0][1], res[1][1]) > 58.0 and self_psnr(res[0][3], res[1][3]) > 58.0
+    for k in res[0][2]:
+        a, b = res[0][2][k], res[1][2][k]
+        assert float((a - b).norm()) <= 2e-2 * float(b.norm()), k
+
+
 def test_one_launch_rcab_is_deterministic_at_the_headline_shape():
     """32 x 48 x 48: 256 strips, one per CU, every image's 8 strips exchange sums.  (a) 16 repeated forward + backward passes on frozen
     weights give bit-identical outputs AND gradient buffers (this is the check that caught compiler-formed packed-fp32 adds dropping an
