@@ -69,11 +69,16 @@ def bench_moco(args):
     # dominant launch: conv 64 -> 64 on [N, 48, 48], with the plan's own buffers and filter image
     enc = h.net.encoder_q
     plan = enc._train_plans[(N, 48, 48, 0)]
-    wf, _, bp = enc._training_images(dev)[0]
-    from rumpy_amd.regression.models.contrastive_learning.encoding_models import _conv_plain
+    im0 = enc._training_images(dev)[0]
+    wf, bp = im0[0], im0[2]
+    from rumpy_amd.regression.models.contrastive_learning.encoding_models import _conv_plain, TRAIN_FMT, TRAIN_Z32
+    from rumpy_amd import _lib as L
     s = torch.cuda.current_stream(dev).cuda_stream
-    from rumpy_amd.regression.models.contrastive_learning.encoding_models import TRAIN_FMT
-    launch = lambda: _conv_plain(plan['a'][0].data_ptr(), wf.data_ptr(), bp.data_ptr(), plan['z'][1].data_ptr(), N, 48, 48, 64, 64, s, fmt=TRAIN_FMT)   # as the step launches it
+    if TRAIN_Z32:      # as the step launches it since round 4: filter + rounding-residual image, fp32 conv output (twice the MFMAs per algorithmic FLOP)
+        launch = lambda: L.call('rumpy_enc_conv', L.EncConvArgs(x=plan['a'][0].data_ptr(), w=wf.data_ptr(), bias=bp.data_ptr(), out=plan['z'][1].data_ptr(), N=N, H=48, W=48,
+                                                                cin=64, cout=64, stride=1, neg_slope=1.0, fmt=TRAIN_FMT, w_lo=im0[3].data_ptr(), out_fmt=L.FMT_F32), s)
+    else:
+        launch = lambda: _conv_plain(plan['a'][0].data_ptr(), wf.data_ptr(), bp.data_ptr(), plan['z'][1].data_ptr(), N, 48, 48, 64, 64, s, fmt=TRAIN_FMT)
     for _ in range(5):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -84,10 +89,11 @@ def bench_moco(args):
     torch.cuda.synchronize(dev)
     avg_s = e0.elapsed_time(e1) * 1e-3 / 50
     flop = 2.0 * N * 48 * 48 * 64 * 64 * 9
-    alg_bytes = 2.0 * N * 48 * 48 * 64 * 2
+    alg_bytes = N * 48 * 48 * 64 * (2.0 + (4.0 if TRAIN_Z32 else 2.0))
     tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
     roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4),
-                'traffic': None, 'kernel': 'conv3x3_strip_kernel via rumpy_conv3x3 (3x3 conv 64 -> 64 of the encoder trunk, the largest launch of the step)',
+                'traffic': None, 'kernel': ('enc_conv_kernel via rumpy_enc_conv (3x3 conv 64 -> 64 of the encoder trunk on the filter + its rounding-residual image, fp32 output; the largest launch of the step)'
+                                            if TRAIN_Z32 else 'conv3x3_strip_kernel via rumpy_conv3x3 (3x3 conv 64 -> 64 of the encoder trunk, the largest launch of the step)'),
                 'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': 50, 'algorithmic_gflop_per_launch': round(flop / 1e9, 3),
                 'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
                 'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}

@@ -33,6 +33,8 @@ extern "C" {
 #define RUMPY_FMT_BF16 0
 #define RUMPY_FMT_F16 1
 #define RUMPY_FMT_F16_RESIDUAL 2   /* rumpy_pack_weights, kind 0 only: the fp16 image of w - fp16(w), the rounding residual of the RUMPY_FMT_F16 image */
+#define RUMPY_FMT_F32 3            /* fp32 elements: the conv outputs z of the degradation encoder's TRAINING forward pass only (rumpy_head_fwd /
+                                      rumpy_enc_conv out, rumpy_enc_bn_train_keep x, rumpy_enc_bn_bwd z; round 4) */
 
 #define RUMPY_TILE_H 8
 #define RUMPY_TILE_W 16
@@ -193,7 +195,7 @@ typedef struct {
   int32_t N, C, H, W, cout;
   float neg_slope_m1;  /* negative-side slope MINUS ONE of the activation applied to the output: 0 = none (SR head),
                           -0.9f = LeakyReLU(0.1) (first conv of the degradation encoder), -1 = ReLU */
-  int32_t fmt;         /* RUMPY_FMT_* of `out` */
+  int32_t fmt;         /* RUMPY_FMT_* of `out` (incl. RUMPY_FMT_F32: fp32 [N,H,W,cout]) */
   int32_t pad_;
   const float* const* x_ind;   /* NULL, or a device word holding the address to read instead of `x` (rumpy_set_pointers): a captured
                                   hipGraph of the training step then follows the caller's batch without a copy into a fixed buffer */
@@ -508,6 +510,10 @@ typedef struct {
   int32_t fmt;     /* RUMPY_FMT_BF16 | RUMPY_FMT_F16: element format of x, w and out (ABI 3: the TRAINING forward pass of the encoder stores its
                       filters, conv outputs and stage outputs as fp16 - the gradient of this BatchNorm + LeakyReLU network is 3-4 x closer to the
                       fp32 reference's than with 8-bit mantissas; gradients and the data-gradient convs stay bf16) */
+  const void* w_lo;    /* ABI 4: NULL, or (fmt F16) the filter's rounding-residual image (rumpy_pack_weights fmt F16_RESIDUAL): swept into the same
+                          accumulators, i.e. the conv runs on the unrounded filter (22 significant bits) */
+  int32_t out_fmt;     /* 0: `out` has format `fmt`; RUMPY_FMT_F32: `out` is fp32 [N,Ho,Wo,cout] (the accumulators as they are) */
+  int32_t pad_;
 } rumpy_enc_conv_args;
 int rumpy_enc_conv(const rumpy_enc_conv_args* a, void* stream);
 int rumpy_enc_pool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, int32_t fmt, void* stream);
@@ -524,6 +530,7 @@ typedef struct {
   int32_t P, C;
   float eps, momentum, neg_slope;
   int32_t fmt;                   /* RUMPY_FMT_*: format of x and of the output */
+  int32_t x_fmt;                 /* ABI 4: 0 = x has format `fmt`; RUMPY_FMT_F32: x is fp32 [P, C] (rumpy_enc_bn_train_keep only: out of place) */
 } rumpy_enc_bn_args;
 int rumpy_enc_bn_train(const rumpy_enc_bn_args* a, void* stream);
 int64_t rumpy_enc_bn_partial_floats(int32_t P, int32_t C);
@@ -551,7 +558,7 @@ typedef struct {
   float* coef;               /* scratch [3, C] */
   int32_t N, Ho, Wo, C, up, Hz, Wz;
   float neg_slope, scale;
-  int32_t fmt;               /* RUMPY_FMT_*: format of z (da and dz are bf16) */
+  int32_t fmt;               /* RUMPY_FMT_* (incl. RUMPY_FMT_F32): format of z (da and dz are bf16) */
 } rumpy_enc_bn_bwd_args;
 int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* a, void* stream);
 /* key-encoder momentum update over flat fp32 buffers: k = k * m + q * one_minus_m (two rounded products, then the sum: moco.py:71) */

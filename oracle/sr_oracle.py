@@ -339,14 +339,24 @@ class OracleEncoder(nn.Module):
         self.mlp = nn.Sequential(nn.Linear(256, 256), nn.LeakyReLU(0.1), nn.Linear(256, 256))
         self.bf16_storage = False
         self.storage_dtype = torch.float16
+        self.z_fp32 = True          # round 4: conv outputs fp32, filters as image + rounding-residual image (False: the round-3 all-fp16 pass)
 
     def _trunk_bf16_storage(self, x):
         a = x
         for i in range(6):
             conv, bn = self.E[3 * i], self.E[3 * i + 1]
             sd = self.storage_dtype
-            w = conv.weight if i == 0 else _Bf16Point.apply(conv.weight, sd, False)       # the first conv reads fp32 filters on the HIP path too
-            z = _Bf16Point.apply(F.conv2d(a, w, conv.bias, stride=conv.stride, padding=1), sd, True)
+            if i == 0:
+                w = conv.weight                                            # the first conv reads fp32 filters on the HIP path too
+            elif self.z_fp32:
+                # round 4: the filter enters as its fp16 image + the fp16 image of its rounding residual (22 significant bits) ...
+                hi = conv.weight.detach().to(sd).float()
+                w = conv.weight + ((hi + (conv.weight.detach() - hi).to(sd).float()) - conv.weight.detach())
+            else:
+                w = _Bf16Point.apply(conv.weight, sd, False)
+            z = F.conv2d(a, w, conv.bias, stride=conv.stride, padding=1)
+            # ... and the conv output stays fp32 (its gradient is still stored as bf16)
+            z = _Bf16Point.apply(z, None if self.z_fp32 else sd, True)
             a = _Bf16Point.apply(F.leaky_relu(bn(z), 0.1), sd, i < 5)      # the pool's gradient reaches the last stage in fp32
         return a.mean((2, 3))
 

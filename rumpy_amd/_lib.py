@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get('RUMPY_AMD_LIB') or os.path.join(_HERE, 'librumpy_amd.
 c_void_p, c_int32, c_int64, c_float = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 TILE_H, TILE_W = 8, 16
-FMT_BF16, FMT_F16, FMT_F16_RESIDUAL = 0, 1, 2          # include/rumpy_amd.h RUMPY_FMT_*
+FMT_BF16, FMT_F16, FMT_F16_RESIDUAL, FMT_F32 = 0, 1, 2, 3          # include/rumpy_amd.h RUMPY_FMT_*
 
 
 class _S(C.Structure):
@@ -44,7 +44,7 @@ class HeadFwdArgs(_S):
 class EncConvArgs(_S):
     _fields_ = [('x', c_void_p), ('w', c_void_p), ('bias', c_void_p), ('out', c_void_p),
                 ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cin', c_int32), ('cout', c_int32), ('stride', c_int32),
-                ('neg_slope', c_float), ('fmt', c_int32)]
+                ('neg_slope', c_float), ('fmt', c_int32), ('w_lo', c_void_p), ('out_fmt', c_int32), ('pad_', c_int32)]
 
 
 class RcabArgs(_S):
@@ -65,7 +65,8 @@ class Op(_S):
 class EncBnArgs(_S):
     _fields_ = [('x', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('running_mean', c_void_p), ('running_var', c_void_p),
                 ('num_batches_tracked', c_void_p), ('partial', c_void_p), ('scale_shift', c_void_p),
-                ('P', c_int32), ('C', c_int32), ('eps', c_float), ('momentum', c_float), ('neg_slope', c_float), ('fmt', c_int32)]
+                ('P', c_int32), ('C', c_int32), ('eps', c_float), ('momentum', c_float), ('neg_slope', c_float), ('fmt', c_int32),
+                ('x_fmt', c_int32)]
 
 
 class EncBnBwdArgs(_S):

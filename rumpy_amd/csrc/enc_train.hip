@@ -15,7 +15,7 @@
 
 
 struct BnBwd {
-  const uint4* z; const uint4* da; const float* dpool; const float* scale_shift; const float* saved;
+  const void* z; const uint4* da; const float* dpool; const float* scale_shift; const float* saved;
   int P, C, HW; float inv_hw, neg_slope;
 };
 
@@ -28,10 +28,12 @@ __device__ __forceinline__ BnbCh bnb_channels(const BnBwd& a, int c0) {
   return k;
 }
 // raw operands of pixel p, channels 8 cv..: the conv output and (unless the pool's gradient stands in) the stage-output gradient
-struct BnbRaw { uint4 z, d; };
+struct BnbRaw { uint4 z, z2, d; };      // (z2: the second half of an fp32 z vector)
+template <int FMT>
 __device__ __forceinline__ BnbRaw bnb_fetch(const BnBwd& a, int p, int cv, int cvec) {
   BnbRaw r;
-  r.z = a.z[(size_t)p * cvec + cv];
+  if (FMT == RUMPY_FMT_F32) { const uint4* q = reinterpret_cast<const uint4*>(a.z) + 2 * ((size_t)p * cvec + cv); r.z = q[0]; r.z2 = q[1]; }
+  else { r.z = reinterpret_cast<const uint4*>(a.z)[(size_t)p * cvec + cv]; r.z2 = make_uint4(0, 0, 0, 0); }
   r.d = a.da ? a.da[(size_t)p * cvec + cv] : make_uint4(0, 0, 0, 0);
   return r;
 }
@@ -39,9 +41,15 @@ __device__ __forceinline__ BnbRaw bnb_fetch(const BnBwd& a, int p, int cv, int c
 template <int FMT>
 __device__ __forceinline__ void bnb_decode(const BnBwd& a, const BnbCh& k, const BnbRaw& r, int p, int c0, float (&dy)[8], float (&xh)[8]) {
   float z[8], d[8];
-  { float lo[4], hi[4]; unpack4<FMT>(make_uint2(r.z.x, r.z.y), lo); unpack4<FMT>(make_uint2(r.z.z, r.z.w), hi);
+  if (FMT == RUMPY_FMT_F32) {
+    z[0] = __uint_as_float(r.z.x); z[1] = __uint_as_float(r.z.y); z[2] = __uint_as_float(r.z.z); z[3] = __uint_as_float(r.z.w);
+    z[4] = __uint_as_float(r.z2.x); z[5] = __uint_as_float(r.z2.y); z[6] = __uint_as_float(r.z2.z); z[7] = __uint_as_float(r.z2.w);
+  } else {
+    constexpr int ZF = FMT == RUMPY_FMT_F32 ? RUMPY_FMT_BF16 : FMT;
+    float lo[4], hi[4]; unpack4<ZF>(make_uint2(r.z.x, r.z.y), lo); unpack4<ZF>(make_uint2(r.z.z, r.z.w), hi);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { z[i] = lo[i]; z[4 + i] = hi[i]; } }
+    for (int i = 0; i < 4; ++i) { z[i] = lo[i]; z[4 + i] = hi[i]; }
+  }
   if (a.da) {
     float lo[4], hi[4]; unpack4_bf16(make_uint2(r.d.x, r.d.y), lo); unpack4_bf16(make_uint2(r.d.z, r.d.w), hi);
 #pragma unroll
@@ -79,11 +87,11 @@ __global__ void __launch_bounds__(256) enc_bnb_stats_kernel(BnBwd a, float* __re
   for (; p + 3 * 32 < p1; p += 4 * 32) {               // four pixels (eight loads) in flight per thread; summed in pixel order all the same
     BnbRaw r[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = bnb_fetch(a, p + 32 * j, cv, cvec);
+    for (int j = 0; j < 4; ++j) r[j] = bnb_fetch<FMT>(a, p + 32 * j, cv, cvec);
 #pragma unroll
     for (int j = 0; j < 4; ++j) add(r[j], p + 32 * j);
   }
-  for (; p < p1; p += 32) add(bnb_fetch(a, p, cv, cvec), p);
+  for (; p < p1; p += 32) add(bnb_fetch<FMT>(a, p, cv, cvec), p);
 #pragma unroll
   for (int i = 0; i < 8; ++i) { red[pr][c8 * 8 + i] = s[i]; red[pr][64 + c8 * 8 + i] = q[i]; }
   __syncthreads();
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__(256) enc_bnb_apply_kernel(BnBwd a, const float
   for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (size_t)gridDim.x * 256) {
     const int cv = (int)(v % cvec), p = (int)(v / cvec), c0 = cv * 8;
     float dy[8], xh[8], r[8];
-    bnb_decode<FMT>(a, bnb_channels(a, c0), bnb_fetch(a, p, cv, cvec), p, c0, dy, xh);
+    bnb_decode<FMT>(a, bnb_channels(a, c0), bnb_fetch<FMT>(a, p, cv, cvec), p, c0, dy, xh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = coef[c0 + i] * (dy[i] - coef[a.C + c0 + i] - xh[i] * coef[2 * a.C + c0 + i]);
     const uint2 lo = pack4_bf16(r[0], r[1], r[2], r[3]), hi = pack4_bf16(r[4], r[5], r[6], r[7]);
@@ -142,18 +150,19 @@ extern "C" int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* p, void* stream) {
   if (!p || !p->z || (!p->da && !p->dpool) || !p->scale_shift || !p->saved || !p->gamma || !p->dz || !p->partial || !p->coef) {
     rumpy_set_error("rumpy_enc_bn_bwd: null pointer"); return RUMPY_E_ARG; }
   const long long P = (long long)p->N * p->Ho * p->Wo;
-  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("rumpy_enc_bn_bwd: fmt %d", p->fmt); return RUMPY_E_ARG; }
-  const bool h16 = p->fmt == RUMPY_FMT_F16;
+  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16 && p->fmt != RUMPY_FMT_F32) { rumpy_set_error("rumpy_enc_bn_bwd: fmt %d", p->fmt); return RUMPY_E_ARG; }
+  const bool h16 = p->fmt == RUMPY_FMT_F16, z32 = p->fmt == RUMPY_FMT_F32;
   if (p->N <= 0 || p->Ho <= 0 || p->Wo <= 0 || P < 2 || P > 0x7fffffffLL || p->C <= 0 || p->C % 64 || (p->up != 1 && p->up != 2) ||
       p->Hz < p->up * (p->Ho - 1) + 1 || p->Wz < p->up * (p->Wo - 1) + 1) {
     rumpy_set_error("rumpy_enc_bn_bwd: unsupported shape (N=%d Ho=%d Wo=%d C=%d up=%d Hz=%d Wz=%d)", p->N, p->Ho, p->Wo, p->C, p->up, p->Hz, p->Wz);
     return RUMPY_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   BnBwd a;
-  a.z = (const uint4*)p->z; a.da = (const uint4*)p->da; a.dpool = p->dpool; a.scale_shift = p->scale_shift; a.saved = p->saved;
+  a.z = p->z; a.da = (const uint4*)p->da; a.dpool = p->dpool; a.scale_shift = p->scale_shift; a.saved = p->saved;
   a.P = (int)P; a.C = p->C; a.HW = p->Ho * p->Wo; a.inv_hw = 1.f / (float)a.HW; a.neg_slope = p->neg_slope;
   const int nblk = rumpy_bn_blocks(a.P, a.C), chunk = (a.P + nblk - 1) / nblk;
-  if (h16) hipLaunchKernelGGL(enc_bnb_stats_kernel<RUMPY_FMT_F16>, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
+  if (z32) hipLaunchKernelGGL(enc_bnb_stats_kernel<RUMPY_FMT_F32>, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
+  else if (h16) hipLaunchKernelGGL(enc_bnb_stats_kernel<RUMPY_FMT_F16>, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
   else hipLaunchKernelGGL(enc_bnb_stats_kernel<RUMPY_FMT_BF16>, dim3(nblk, a.C / 64), dim3(256), 0, s, a, p->partial, chunk);
   hipLaunchKernelGGL(enc_bnb_finalize_kernel, dim3(a.C / 64), dim3(256), 0, s, p->partial, nblk, a.P, a.C, p->gamma, p->saved, p->dgamma, p->dbeta,
                      p->coef, p->scale);
@@ -161,7 +170,8 @@ extern "C" int rumpy_enc_bn_bwd(const rumpy_enc_bn_bwd_args* p, void* stream) {
   size_t blocks = (tv + 255) / 256;
   const size_t cap = (size_t)rumpy_device_cus() * 8;
   if (blocks > cap) blocks = cap;
-  if (h16) hipLaunchKernelGGL(enc_bnb_apply_kernel<RUMPY_FMT_F16>, dim3((unsigned)blocks), dim3(256), 0, s, a, p->coef, (uint4*)p->dz, p->Wo, p->up, p->Hz, p->Wz);
+  if (z32) hipLaunchKernelGGL(enc_bnb_apply_kernel<RUMPY_FMT_F32>, dim3((unsigned)blocks), dim3(256), 0, s, a, p->coef, (uint4*)p->dz, p->Wo, p->up, p->Hz, p->Wz);
+  else if (h16) hipLaunchKernelGGL(enc_bnb_apply_kernel<RUMPY_FMT_F16>, dim3((unsigned)blocks), dim3(256), 0, s, a, p->coef, (uint4*)p->dz, p->Wo, p->up, p->Hz, p->Wz);
   else hipLaunchKernelGGL(enc_bnb_apply_kernel<RUMPY_FMT_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, a, p->coef, (uint4*)p->dz, p->Wo, p->up, p->Hz, p->Wz);
   return rumpy_check_launch("rumpy_enc_bn_bwd");
 }

@@ -59,9 +59,16 @@ __global__ void __launch_bounds__(HEAD_FWD_THREADS) head_fwd_kernel(const float*
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = fmaf(slope_m1, fminf(acc[j], 0.f), acc[j]);
     }
-    const uint2 lo = pack4<FMT>(acc[0], acc[1], acc[2], acc[3]);
-    const uint2 hi = pack4<FMT>(acc[4], acc[5], acc[6], acc[7]);
-    *reinterpret_cast<uint4*>(op + cb) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    if (FMT == RUMPY_FMT_F32) {       // the encoder's training forward pass: its first conv output as it is (this kernel is exact fp32)
+      float* of = reinterpret_cast<float*>(out) + p * cout + ct * 64 + cb;
+      *reinterpret_cast<float4*>(of) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(of + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+      constexpr int PF = FMT == RUMPY_FMT_F32 ? RUMPY_FMT_BF16 : FMT;
+      const uint2 lo = pack4<PF>(acc[0], acc[1], acc[2], acc[3]);
+      const uint2 hi = pack4<PF>(acc[4], acc[5], acc[6], acc[7]);
+      *reinterpret_cast<uint4*>(op + cb) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
   }
 }
 
@@ -293,9 +300,16 @@ extern "C" int rumpy_head_fwd(const rumpy_head_fwd_args* p, void* stream) {
   dim3 grid((unsigned)((total + HEAD_FWD_THREADS - 1) / HEAD_FWD_THREADS), p->cout / 64);
   hipStream_t s = (hipStream_t)stream;
   uint16_t* o = (uint16_t*)p->out;
-  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16) { rumpy_set_error("rumpy_head_fwd: bad fmt %d", p->fmt); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && p->fmt != RUMPY_FMT_F16 && p->fmt != RUMPY_FMT_F32) { rumpy_set_error("rumpy_head_fwd: bad fmt %d", p->fmt); return RUMPY_E_ARG; }
 #define HEAD_LAUNCH(C_, F_) hipLaunchKernelGGL((head_fwd_kernel<C_, F_>), grid, dim3(HEAD_FWD_THREADS), 0, s, p->x, p->x_ind, p->w, p->b, o, p->N, p->H, p->W, p->cout, p->neg_slope_m1)
-  if (p->fmt == RUMPY_FMT_F16) {
+  if (p->fmt == RUMPY_FMT_F32) {
+    switch (p->C) {
+      case 1: HEAD_LAUNCH(1, RUMPY_FMT_F32); break;
+      case 2: HEAD_LAUNCH(2, RUMPY_FMT_F32); break;
+      case 3: HEAD_LAUNCH(3, RUMPY_FMT_F32); break;
+      default: HEAD_LAUNCH(4, RUMPY_FMT_F32); break;
+    }
+  } else if (p->fmt == RUMPY_FMT_F16) {
     switch (p->C) {
       case 1: HEAD_LAUNCH(1, RUMPY_FMT_F16); break;
       case 2: HEAD_LAUNCH(2, RUMPY_FMT_F16); break;

@@ -69,6 +69,13 @@ class _LaunchGraph:
 # RUMPY_ENC_TRAIN_BF16=1: the round-2 all-bf16 forward pass (A/B).
 TRAIN_FMT = L.FMT_BF16 if os.environ.get('RUMPY_ENC_TRAIN_BF16') == '1' else L.FMT_F16
 TRAIN_DT = torch.float16 if TRAIN_FMT == L.FMT_F16 else BF16
+# Round 4: of the three 11-bit roundings of that fp16 pass (filter, conv output z, stage output a) the filter's and z's carry most of what is
+# left - a CPU simulation of the rounding points on five seeded cases (tests/tools/enc_storage_sim.py): all fp16 -> worst parameter tensor
+# 5.4-7.7e-2 from the fp32 graph; fp32 z alone 3.0-7.6e-2 (not robust); unrounded filter alone: no gain; BOTH: 3.1-3.9e-2.  So the training
+# forward pass keeps every conv output z as fp32 (read by the BatchNorm statistics / apply passes and once more by the backward pass: +2 bytes
+# per element on three streaming reads) and runs its convs on the filter AND its rounding-residual image (w = fp16(w) + fp16(w - fp16(w)):
+# twice the forward MFMAs of a network whose step is launch- and bandwidth-bound).  RUMPY_ENC_TRAIN_Z16=1: the round-3 all-fp16 pass (A/B).
+TRAIN_Z32 = TRAIN_FMT == L.FMT_F16 and os.environ.get('RUMPY_ENC_TRAIN_Z16') != '1'
 
 _SR_CONVS = os.environ.get('RUMPY_ENC_OWN_CONV') != '1'      # A/B: the encoder's own kernel for every launch
 
@@ -236,15 +243,20 @@ class Encoder(nn.Module):
                 wf = torch.empty(cout * cin * 9, dtype=torch.float16 if fwd_fmt == L.FMT_F16 else BF16, device=dev)
                 wd = torch.empty(cout * cin * 9, dtype=BF16, device=dev) if dgrad else None
                 bp = torch.empty(cout, dtype=torch.float32, device=dev)
-                out.append((wf, wd, bp) if dgrad else (wf, bp))
+                if dgrad and fwd_fmt == L.FMT_F16 and TRAIN_Z32:      # + the fp16 filter's rounding-residual image (rumpy_enc_conv.w_lo)
+                    out.append((wf, wd, bp, torch.empty(cout * cin * 9, dtype=torch.float16, device=dev)))
+                else:
+                    out.append((wf, wd, bp) if dgrad else (wf, bp))
             st = self._img_store[slot] = dict(dev=dev, imgs=out, src=None, tab=None)
         src = tuple(_ptr(t) for t in list(weights) + list(biases))
         if st['src'] != src:
             if fwd_fmt and dgrad:      # forward image in fp16, data-gradient image in bf16: two items per conv
-                items = [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[0]), w_dgrad=None, b_packed=_ptr(im[-1]), cout=w.shape[0], cin=w.shape[1], kind=0,
+                items = [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[0]), w_dgrad=None, b_packed=_ptr(im[2]), cout=w.shape[0], cin=w.shape[1], kind=0,
                                     shuffle=0, fmt=fwd_fmt) for w, b, im in zip(weights, biases, st['imgs'])] + \
                         [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=None, w_dgrad=_ptr(im[1]), b_packed=None, cout=w.shape[0], cin=w.shape[1], kind=0,
-                                    shuffle=0) for w, b, im in zip(weights, biases, st['imgs'])]
+                                    shuffle=0) for w, b, im in zip(weights, biases, st['imgs'])] + \
+                        [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[3]), w_dgrad=None, b_packed=None, cout=w.shape[0], cin=w.shape[1], kind=0,
+                                    shuffle=0, fmt=L.FMT_F16_RESIDUAL) for w, b, im in zip(weights, biases, st['imgs']) if len(im) > 3]
             else:
                 items = [L.PackItem(w=_ptr(w), b=_ptr(b), w_fwd=_ptr(im[0]), w_dgrad=_ptr(im[1]) if dgrad else None, b_packed=_ptr(im[-1]),
                                     cout=w.shape[0], cin=w.shape[1], kind=0, shuffle=0, fmt=fwd_fmt) for w, b, im in zip(weights, biases, st['imgs'])]
@@ -387,7 +399,7 @@ class Encoder(nn.Module):
             hi, wi = h, w                                   # this conv's input size = the grid its gradients live on
             h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
             dims.append((hi, wi, h, w))
-            z.append(new(N, h, w, cout, dtype=TRAIN_DT))       # forward storage: fp16 (TRAIN_FMT)
+            z.append(new(N, h, w, cout, dtype=torch.float32 if TRAIN_Z32 else TRAIN_DT))       # conv outputs: fp32 (round 4) / fp16 (TRAIN_FMT)
             a.append(new(N, h, w, cout, dtype=TRAIN_DT))
             abf.append(new(N, h, w, cout) if (TRAIN_FMT and len(abf) < 5) else None)     # bf16 copy of a stage output: the next conv's weight-gradient operand
             # gradient at the conv output on the stride-1 grid of the conv's input (stride 2: every second pixel, the rest stays zero)
@@ -450,12 +462,16 @@ class Encoder(nn.Module):
         def launches():
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.call('rumpy_head_fwd', L.HeadFwdArgs(x=_ptr(xs), w=_ptr(convs[0].weight), b=_ptr(convs[0].bias), out=_ptr(z[0]), N=N, C=3, H=H, W=W,
-                                                   cout=64, neg_slope_m1=0.0, fmt=TRAIN_FMT), stream)
+                                                   cout=64, neg_slope_m1=0.0, fmt=L.FMT_F32 if TRAIN_Z32 else TRAIN_FMT), stream)
             for i, (cin, cout, stride) in enumerate(LAYERS):
                 hi, wi, ho, wo = plan['dims'][i]
                 if i > 0:
-                    wf, _, bp = imgs[i - 1]
-                    if stride == 1:
+                    wf, _, bp = imgs[i - 1][:3]
+                    if TRAIN_Z32:      # unrounded filter (image + residual image), fp32 conv output
+                        L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
+                                                               cout=cout, stride=stride, neg_slope=1.0, fmt=TRAIN_FMT, w_lo=_ptr(imgs[i - 1][3]),
+                                                               out_fmt=L.FMT_F32), stream)
+                    elif stride == 1:
                         _conv_plain(_ptr(a[i - 1]), _ptr(wf), _ptr(bp), _ptr(z[i]), N, hi, wi, cin, cout, stream, fmt=TRAIN_FMT)
                     else:
                         L.call('rumpy_enc_conv', L.EncConvArgs(x=_ptr(a[i - 1]), w=_ptr(wf), bias=_ptr(bp), out=_ptr(z[i]), N=N, H=hi, W=wi, cin=cin,
@@ -465,7 +481,7 @@ class Encoder(nn.Module):
                 args = L.EncBnArgs(x=_ptr(z[i]), gamma=_ptr(bn.weight), beta=_ptr(bn.bias), running_mean=_ptr(bn.running_mean),
                                    running_var=_ptr(bn.running_var), num_batches_tracked=_ptr(bn.num_batches_tracked),
                                    partial=_ptr(plan['partial']), scale_shift=_ptr(plan['ss'][i]), P=N * ho * wo, C=cout, eps=bn.eps, momentum=mom,
-                                   neg_slope=SLOPE, fmt=TRAIN_FMT)
+                                   neg_slope=SLOPE, fmt=TRAIN_FMT, x_fmt=L.FMT_F32 if TRAIN_Z32 else 0)
                 L.check(L.lib().rumpy_enc_bn_train_keep(C.byref(args), _ptr(a[i]), _ptr(plan['abf'][i]), _ptr(plan['saved'][i]), stream), 'rumpy_enc_bn_train_keep')
             ho, wo = plan['dims'][5][2:]
             L.check(L.lib().rumpy_enc_pool(_ptr(a[5]), _ptr(fea), N, ho * wo, 256, TRAIN_FMT, stream), 'rumpy_enc_pool')
@@ -511,9 +527,9 @@ class Encoder(nn.Module):
                                                           dgamma=_ptr(gv(bn.weight)), dbeta=_ptr(gv(bn.bias)), dz=_ptr(dz[i]),
                                                           partial=_ptr(plan['partial']), coef=_ptr(plan['coef']), N=N, Ho=ho, Wo=wo, C=cout,
                                                           up=stride, Hz=hi if stride == 2 else ho, Wz=wi if stride == 2 else wo,
-                                                          neg_slope=SLOPE, scale=1.0, fmt=TRAIN_FMT), stream)
+                                                          neg_slope=SLOPE, scale=1.0, fmt=L.FMT_F32 if TRAIN_Z32 else TRAIN_FMT), stream)
                 if i > 0:      # data gradient: the stride-1 convolution of dz (on the input's grid) with the transposed, flipped filter
-                    _, wd, _ = imgs[i - 1]
+                    wd = imgs[i - 1][1]
                     _conv_plain(_ptr(dz[i]), _ptr(wd), _ptr(plan['zero_bias']), _ptr(da[i - 1]),
                                 N, hi, wi, cout, cin, stream)
             L.check(lib.rumpy_wgrad_grouped(_ptr(plan['jobs']), plan['njobs'], 4, 0, stream), 'rumpy_wgrad_grouped')

@@ -221,7 +221,7 @@ def test_blind_qrcan_joint_contrastive_losses_against_oracle(mode, crops, freeze
                     if k.split('.', 1)[1] in ('E.0.bias', 'E.3.bias', 'E.6.bias', 'E.9.bias', 'E.12.bias', 'E.15.bias'):      # through d metadata)
                         continue                                                      # zero gradient in front of a training BatchNorm
                     trunk_worst = max(trunk_worst, _rel(p.grad.cpu(), po.grad))
-                    assert _rel(p.grad.cpu(), po.grad) < 1.0e-1, (k, _rel(p.grad.cpu(), po.grad))   # fp32 oracle; fp16 forward storage (tests/test_contrastive_gpu.py)
+                    assert _rel(p.grad.cpu(), po.grad) < 6e-2, (k, _rel(p.grad.cpu(), po.grad))   # fp32 oracle; fp32 conv outputs + unrounded filters, fp16 stage outputs (tests/test_contrastive_gpu.py)
                 else:
                     assert p.grad is None, k
             print('joint losses %s / %s: worst trunk gradient tensor against the fp32 oracle %.3e' % (mode, freeze, trunk_worst))

@@ -3,7 +3,8 @@ update against plain torch, the encoder trunk's gradients and whole MoCo / SupMo
 'supmoco') against the CPU oracle (oracle/contrastive_oracle.py, pinned on the real reference handlers by golden G20).
 
 Tolerances (round 3): the TRAINING forward pass stores filters, conv outputs and stage outputs as IEEE fp16 (their gradients as bf16), with fp32
-accumulation.  The acceptance criterion is the fp32 oracle - what the reference computes:
+accumulation.  Round 4: the conv outputs stay fp32 and the convs run on the filter + its rounding-residual image (encoding_models.py::TRAIN_Z32);
+only the stage outputs are still fp16: per tensor <= 6e-2 (was 1.2e-1).  The acceptance criterion is the fp32 oracle - what the reference computes:
 * fp32 oracle: whole gradient <= FP32_WHOLE, every tensor <= FP32_TENSOR (constants below; round 2, with bf16 storage: 1.5e-1 / 3e-1, measured
   5-10 %).  What remains is a property of 16-bit storage on THIS network, not of the kernels: a LeakyReLU(0.1) input whose sign changes under
   the storage rounding changes its gradient tenfold; fp16's 2^-12 flips 8 x fewer of them than bf16's 2^-9 (CPU simulation of the rounding
@@ -28,7 +29,8 @@ from rumpy_amd.shared_framework.models import define_model
 
 DEV = torch.device('cuda:0')
 BF16 = torch.bfloat16
-FP32_WHOLE, FP32_TENSOR = 3.5e-2, 1.2e-1     # against the fp32 oracle (acceptance): measured 0.5-2.9e-2 / 3.4-9.6e-2 over the ten cases of this file
+FP32_WHOLE, FP32_TENSOR = 3.5e-2, 6e-2       # against the fp32 oracle (acceptance); round 3 (all-fp16 forward pass): 3.5e-2 / 1.2e-1, measured 0.5-2.9e-2 / 3.4-9.6e-2;
+                                             # round 4 (fp32 conv outputs, unrounded filters): see profiles/r04_encoder_parity.txt
                                              # (round 2, bf16 forward storage: bounds 1.5e-1 / 3e-1, measured 5-10e-2 / 14-21e-2)
 EMU_WHOLE, EMU_TENSOR = 3e-2, 6e-2           # against the oracle with the HIP path's storage points (diagnostic): measured 0.3-2.1e-2 / 1.6-4.9e-2
 ZERO_GRAD_BIASES = ('E.0.bias', 'E.3.bias', 'E.6.bias', 'E.9.bias', 'E.12.bias', 'E.15.bias')
