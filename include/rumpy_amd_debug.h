@@ -27,7 +27,7 @@ int rumpy_debug_occupy(int32_t blocks, float microseconds, void* stream);
 
 /* out[2 i] / out[2 i + 1] = the OCP e4m3 / e5m2 byte the hardware conversion gives for in[i] / scale (tests/test_fp8_gpu.py pins rounding and
  * saturation, which the delayed scaling of precision 'fp8' relies on) */
-int rumpy_fp8_convert(const float* in, float scale, void* out, int32_t n, void* stream);
+int rumpy_fp8_convert(const float* in, float scale, void* out, int32_t n, int32_t ovfl, void* stream);   /* ovfl: with MODE.FP16_OVFL set */
 
 #ifdef __cplusplus
 }

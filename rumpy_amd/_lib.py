@@ -295,7 +295,7 @@ SYMBOLS = {
     'rumpy_fp8_pack': (C.c_int, [c_void_p, c_int32, c_void_p]),
     'rumpy_fp8_rotate': (C.c_int, [c_void_p, c_int32, c_int32, c_void_p]),
     'rumpy_fp8_site_entries': (C.c_int, [c_int32, c_int32, c_int32]),
-    'rumpy_fp8_convert': (C.c_int, [c_void_p, C.c_float, c_void_p, c_int32, c_void_p]),
+    'rumpy_fp8_convert': (C.c_int, [c_void_p, C.c_float, c_void_p, c_int32, c_int32, c_void_p]),
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
     'rumpy_sgemm': (C.c_int, [_P(SgemmArgs), c_void_p]),
     'rumpy_sgemm_partial_floats': (c_int64, [c_int32, c_int32, c_int32]),

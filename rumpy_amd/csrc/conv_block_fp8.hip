@@ -44,6 +44,7 @@ struct BlockF8Dev {
 template <int FORM>
 __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev a) {
   constexpr bool E5M2 = FORM == 3;
+  f8_saturating_mode();                   // fp8 conversions clamp what outgrew its scale (fp8_common.hpp)
   __shared__ __attribute__((aligned(16))) unsigned char lds[F8_LDS];
   __shared__ unsigned gate[4];
   __shared__ unsigned amax_s[2];
@@ -428,8 +429,11 @@ extern "C" int rumpy_fp8_site_entries(int32_t N, int32_t H, int32_t W) {
   return 2 * N * ((H + BSH - 1) / BSH);
 }
 
-// test hook of the conversions' overflow behaviour (tests/test_fp8_gpu.py): out[2 i], out[2 i + 1] = the e4m3 / e5m2 byte of in[i] / scale
-__global__ void fp8_convert_kernel(const float* in, float scale, unsigned char* out, int n) {
+// test hook of the conversions' overflow behaviour (tests/test_fp8_gpu.py): out[2 i], out[2 i + 1] = the e4m3 / e5m2 byte of in[i] / scale.
+// ovfl != 0: with MODE.FP16_OVFL set for the wave, as the fp8 kernels run (f8_saturating_mode): out-of-range values then convert to the largest
+// finite number instead of NaN / inf.
+__global__ void fp8_convert_kernel(const float* in, float scale, unsigned char* out, int n, int ovfl) {
+  if (ovfl) f8_saturating_mode();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   f8_v2s a = {0, 0}, b = {0, 0};
@@ -438,8 +442,8 @@ __global__ void fp8_convert_kernel(const float* in, float scale, unsigned char* 
   out[2 * i] = (unsigned char)(__builtin_bit_cast(unsigned, a) & 255u);
   out[2 * i + 1] = (unsigned char)(__builtin_bit_cast(unsigned, b) & 255u);
 }
-extern "C" int rumpy_fp8_convert(const float* in, float scale, void* out, int32_t n, void* stream) {
+extern "C" int rumpy_fp8_convert(const float* in, float scale, void* out, int32_t n, int32_t ovfl, void* stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(fp8_convert_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, scale, (unsigned char*)out, n);
+  hipLaunchKernelGGL(fp8_convert_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, scale, (unsigned char*)out, n, ovfl);
   return rumpy_check_launch("rumpy_fp8_convert");
 }

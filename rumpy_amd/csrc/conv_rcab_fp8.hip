@@ -21,6 +21,7 @@ constexpr int R8_REGS = (R8_PIECES + BTHREADS - 1) / BTHREADS;          // 5
 template <bool BWD>
 __global__ void __launch_bounds__(BTHREADS, 2) rcab_fp8_kernel(RcabDev a) {
   constexpr bool E5M2 = BWD;
+  f8_saturating_mode();                   // fp8 conversions clamp what outgrew its scale (fp8_common.hpp)
   __shared__ __attribute__((aligned(16))) unsigned char lds[F8_LDS];
   __shared__ float sx[8 * 64];
   __shared__ float spool[2 * 64];

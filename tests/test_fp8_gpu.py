@@ -62,7 +62,7 @@ def test_fp8_conversions_round_to_nearest_even_and_what_they_do_beyond_the_range
     vals = torch.tensor([0.0, 1.0, -1.0, 17.0, 19.0, 448.0, 449.0, 2.0 ** -9, 2.0 ** -10 * 0.49, 0.3, 100.0, -3.3, 5e-3], device=DEV)
     out = torch.zeros(2 * vals.numel(), dtype=torch.uint8, device=DEV)
     for scale in (1.0, 4.0, 0.25):
-        L.check(L.lib().rumpy_fp8_convert(vals.data_ptr(), scale, out.data_ptr(), vals.numel(), stream()), 'rumpy_fp8_convert')
+        L.check(L.lib().rumpy_fp8_convert(vals.data_ptr(), scale, out.data_ptr(), vals.numel(), 0, stream()), 'rumpy_fp8_convert')
         torch.cuda.synchronize()
         got4 = out[0::2].cpu().view(F8).float()
         got5 = out[1::2].cpu().view(F8E5).float()
@@ -70,9 +70,16 @@ def test_fp8_conversions_round_to_nearest_even_and_what_they_do_beyond_the_range
         assert torch.equal(got4[ok4], q8(vals.cpu(), scale, F8)[ok4]), (scale, got4, q8(vals.cpu(), scale, F8))
         assert torch.equal(got5, q8(vals.cpu(), scale, F8E5)), (scale, got5, q8(vals.cpu(), scale, F8E5))
     big = torch.tensor([1e6, -1e6, 6e4], device=DEV)
-    L.check(L.lib().rumpy_fp8_convert(big.data_ptr(), 1.0, out.data_ptr(), 3, stream()), 'rumpy_fp8_convert')
+    L.check(L.lib().rumpy_fp8_convert(big.data_ptr(), 1.0, out.data_ptr(), 3, 0, stream()), 'rumpy_fp8_convert')
     torch.cuda.synchronize()
-    assert not torch.isfinite(out[0:6:2].cpu().view(F8).float()).any()       # e4m3: NaN, not 448 - hence the clamp in the kernels
+    assert not torch.isfinite(out[0:6:2].cpu().view(F8).float()).any()       # e4m3: NaN, not 448 ...
+    # ... unless the wave runs with MODE.FP16_OVFL set, as the fp8 kernels do (f8_saturating_mode): then the largest finite value, both formats
+    big = torch.tensor([1e6, -1e6, 6e4, 500.0, 3e38, -7e7], device=DEV)
+    L.check(L.lib().rumpy_fp8_convert(big.data_ptr(), 1.0, out.data_ptr(), 6, 1, stream()), 'rumpy_fp8_convert')
+    torch.cuda.synchronize()
+    print('FP16_OVFL conversions:', out[0:12:2].cpu().view(F8).float().tolist(), out[1:12:2].cpu().view(F8E5).float().tolist())
+    assert torch.equal(out[0:12:2].cpu().view(F8).float(), torch.tensor([448., -448., 448., 448., 448., -448.]))
+    assert torch.equal(out[1:12:2].cpu().view(F8E5).float(), torch.tensor([57344., -57344., 57344., 512., 57344., -57344.]))
 
 
 def _mk(gen, lo=0.06):
