@@ -29,7 +29,7 @@ for d in sorted(glob.glob('gpurun_out/pmcs_%s_*' % M)):
 forms = {k: (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024 for k, c in means.items() if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c}
 if forms:
     kind = 'rcab_kernel' if M != 'edsr' else 'conv_block_kernel'
-    srcs = ['rumpy_amd/csrc/block_common.hpp', 'rumpy_amd/csrc/conv_rcab.hip' if kind == 'rcab_kernel' else 'rumpy_amd/csrc/conv_block.hip']
+    srcs = ['rumpy_amd/csrc/block_common.hpp'] + (['rumpy_amd/csrc/rcab_common.hpp', 'rumpy_amd/csrc/conv_rcab.hip'] if kind == 'rcab_kernel' else ['rumpy_amd/csrc/conv_block.hip'])
     entry = {'bytes_per_launch': sum(forms.values()) / len(forms), 'per_form_bytes': forms, 'sources': srcs, 'sha16': bench.source_sha16(srcs),
              'source': 'profiles/pmc_traffic.json <- tests/tools/pmc_step.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --model %s '
                        '(32 x 48 x 48), 2 x FETCH_SIZE + WRITE_SIZE, mean over the forward and data-gradient launches' % (M, M)}
