@@ -314,45 +314,47 @@ int rumpy_conv_block_fp8_launch(const rumpy_block_args* p, hipStream_t s) {
 // (A rows = output channels) and data-gradient image (the transposed, flipped filter: A rows = input channels), e4m3 of w / 2^(e - 127) with ONE
 // exponent e per conv chosen so that amax / scale lies in [128, 256); e goes to *exponent.  One workgroup per conv, after every optimizer step.
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// two launches: (1) one workgroup of 1024 threads per conv takes its amax (nine 16-byte loads per thread in flight) and writes the exponent;
-// (2) F8_PACK_PARTS workgroups per conv convert 1 / F8_PACK_PARTS of both images each.  (One launch in which every part took the amax for itself
-// read every filter sixteen times: 166 us per RCAN step for 400 convs.)
-constexpr int F8_PACK_PARTS = 8;
-__global__ void __launch_bounds__(1024) fp8_amax_kernel(const rumpy_fp8_pack_item* items) {
+// One workgroup of 1024 threads per conv: the filter is read ONCE, coalesced, into LDS (36864 floats, rows of 64 x 9 padded to 577 so that the
+// gathers below spread over the banks), its amax falls out of the same pass, and both images are gathered from LDS.  (Earlier forms of this
+// round: 16 parts per conv that each took the amax for themselves - 166 us per RCAN step for 400 convs; an amax launch + 8 converting parts
+// per conv gathering from global memory - 102 us.)
+constexpr int F8_WROW = 577;
+__global__ void __launch_bounds__(1024) fp8_pack_kernel(const rumpy_fp8_pack_item* items) {
   const rumpy_fp8_pack_item it = items[blockIdx.x];
+  __shared__ float wl[64 * F8_WROW];
   __shared__ float red[16];
   const int tid = threadIdx.x;
-  const float4* w4 = reinterpret_cast<const float4*>(it.w);
-  float4 v[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) v[i] = w4[tid + 1024 * i];              // 64 * 64 * 9 / 4 = 9216 vectors
   float am = 0.f;
+  {
+    const float4* w4 = reinterpret_cast<const float4*>(it.w);
+    float4 v[9];
 #pragma unroll
-  for (int i = 0; i < 9; ++i) am = fmaxf(fmaxf(am, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    for (int i = 0; i < 9; ++i) v[i] = w4[tid + 1024 * i];              // 64 * 64 * 9 / 4 = 9216 vectors
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+      const int e = 4 * (tid + 1024 * i), row = e / 576, c = e - row * 576;      // 576 % 4 == 0: a vector never straddles two rows
+      float* d = wl + row * F8_WROW + c;
+      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+    }
+  }
   am = f8_wave_max(am, tid & 63);
   if ((tid & 63) == 0) red[tid >> 6] = am;
   __syncthreads();
-  if (tid == 0) {
 #pragma unroll
-    for (int i = 1; i < 16; ++i) am = fmaxf(am, red[i]);
-    int e = (int)((__float_as_uint(am) >> 23) & 255u) - 7;      // amax in [2^(E-127), 2^(E-126)) -> amax / 2^(E-134) in [128, 256)
-    if (am == 0.f || !(am < 3e38f)) e = 127;
-    *it.exponent = (unsigned)(e < 1 ? 1 : (e > 254 ? 254 : e));
-  }
-}
-
-__global__ void __launch_bounds__(256) fp8_pack_kernel(const rumpy_fp8_pack_item* items) {
-  const rumpy_fp8_pack_item it = items[blockIdx.x / F8_PACK_PARTS];
-  const int part = blockIdx.x % F8_PACK_PARTS;
-  const int tid = threadIdx.x;
-  const float scale = __uint_as_float((*it.exponent & 255u) << 23);
+  for (int i = 0; i < 16; ++i) am = fmaxf(am, red[i]);
+  int e8 = (int)((__float_as_uint(am) >> 23) & 255u) - 7;       // amax in [2^(E-127), 2^(E-126)) -> amax / 2^(E-134) in [128, 256)
+  if (am == 0.f || !(am < 3e38f)) e8 = 127;
+  e8 = e8 < 1 ? 1 : (e8 > 254 ? 254 : e8);
+  if (tid == 0) *it.exponent = (unsigned)e8;
+  const float scale = __uint_as_float((unsigned)e8 << 23);
   // word i of an image = bytes 4 (i & 7) .. + 3 of (lane, mfma, q); fwd: row = output channel co, k = input channel ci, tap (ky, kx);
   // dgrad: row = input channel, k = output channel, tap flipped
-  constexpr int WORDS = 4 * 5 * 64 * 8, PER = WORDS / F8_PACK_PARTS;       // 10240 words per image
+  constexpr int WORDS = 4 * 5 * 64 * 8;       // 10240 words per image
   for (int img = 0; img < 2; ++img) {
     unsigned* dst = reinterpret_cast<unsigned*>(img ? it.img_dgrad : it.img_fwd);
     if (!dst) continue;
-    for (int i = part * PER + tid; i < (part + 1) * PER; i += 256) {
+    for (int i = tid; i < WORDS; i += 1024) {
       const int w4 = i & 7, lane = (i >> 3) & 63, m = (i >> 9) % 5, q = i / (5 * 64 * 8);
       const int r = lane & 15, g = lane >> 4, row = 16 * q + r;
       float f[4];
@@ -365,7 +367,7 @@ __global__ void __launch_bounds__(256) fp8_pack_kernel(const rumpy_fp8_pack_item
         else if (m == 3) { ky = g >> 1; kx = 2; k = 32 * (g & 1) + b; }
         else { ky = 2; kx = 2; k = 16 * g + (b & 15); zero = b >= 16; }
         float v = 0.f;
-        if (!zero) v = img ? it.w[((k * 64 + row) * 3 + (2 - ky)) * 3 + (2 - kx)] : it.w[((row * 64 + k) * 3 + ky) * 3 + kx];
+        if (!zero) v = img ? wl[k * F8_WROW + (row * 3 + (2 - ky)) * 3 + (2 - kx)] : wl[row * F8_WROW + (k * 3 + ky) * 3 + kx];
         f[b4] = v;
       }
       f8_v2s o = {0, 0};
@@ -379,8 +381,7 @@ __global__ void __launch_bounds__(256) fp8_pack_kernel(const rumpy_fp8_pack_item
 extern "C" int rumpy_fp8_pack(const rumpy_fp8_pack_item* items, int32_t n, void* stream) {
   if (n <= 0) return 0;
   if (!items) { rumpy_set_error("rumpy_fp8_pack: null table"); return RUMPY_E_ARG; }
-  hipLaunchKernelGGL(fp8_amax_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, items);
-  hipLaunchKernelGGL(fp8_pack_kernel, dim3(n * F8_PACK_PARTS), dim3(256), 0, (hipStream_t)stream, items);
+  hipLaunchKernelGGL(fp8_pack_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, items);
   return rumpy_check_launch("rumpy_fp8_pack");
 }
 
