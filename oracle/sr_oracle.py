@@ -729,24 +729,24 @@ def vignetted_pair(hr_u8, lr_hw, scale=4, margin=24):
 
 
 def forward_chop(run, x, scale, max_combined_im_size, shave=10):
-    """Tiled whole-image evaluation as the reference restates it twice, word for word: SANHandler.forward_chop
-    (rumpy/SISR/models/advanced/handlers.py:85-123) and ContrastiveBlindQEDSRHandler.forward_chop
-    (rumpy/SISR/models/blur_kernel_blind_sr/handlers.py:907-945).  `run(chunk)` super-resolves one chunk (the handlers' run_eval(...)[0])."""
-    b, c, h, w = x.size()
-    h_half, w_half = h // 2, w // 2
-    h_size, w_size = h_half + shave, w_half + shave
-    lr_list = [x[:, :, 0:h_size, 0:w_size], x[:, :, 0:h_size, (w - w_size):w],
-               x[:, :, (h - h_size):h, 0:w_size], x[:, :, (h - h_size):h, (w - w_size):w]]
-    if w_size * h_size < max_combined_im_size:
-        sr_list = [run(chunk) for chunk in lr_list]
-    else:
-        sr_list = [forward_chop(run, patch, scale, max_combined_im_size, shave=shave) for patch in lr_list]
-    h, w = scale * h, scale * w
-    h_half, w_half = scale * h_half, scale * w_half
-    h_size, w_size = scale * h_size, scale * w_size
-    output = x.new(b, c, h, w)
-    output[:, :, 0:h_half, 0:w_half] = sr_list[0][:, :, 0:h_half, 0:w_half]
-    output[:, :, 0:h_half, w_half:w] = sr_list[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
-    output[:, :, h_half:h, 0:w_half] = sr_list[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
-    output[:, :, h_half:h, w_half:w] = sr_list[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
-    return output
+    """Tiled whole-image evaluation as the reference has it twice: SANHandler.forward_chop (rumpy/SISR/models/advanced/handlers.py:85-123) and
+    ContrastiveBlindQEDSRHandler.forward_chop (rumpy/SISR/models/blur_kernel_blind_sr/handlers.py:907-945).  Restated from what that code does:
+    the image is covered by four corner-anchored windows of (H // 2 + shave) x (W // 2 + shave) pixels; each is super-resolved by
+    `run(chunk)` (the handlers' run_eval(...)[0]) - or, while a window still has max_combined_im_size pixels or more, by this function again -
+    and contributes the output pixels of its own quadrant (rows / columns below or from H // 2 / W // 2).  Pinned on the reference's own
+    method by fixture G23 (tests/golden/make_golden_chop.py)."""
+    n, c, height, width = x.shape
+    win_h, win_w = height // 2 + shave, width // 2 + shave
+    deeper = win_h * win_w >= max_combined_im_size
+    out = x.new_empty(n, c, scale * height, scale * width)
+    for top in (True, False):
+        y0 = 0 if top else height - win_h                       # window rows [y0, y0 + win_h)
+        ys = (0, height // 2) if top else (height // 2, height)   # output rows this window owns (LR units)
+        for left in (True, False):
+            x0 = 0 if left else width - win_w
+            xs = (0, width // 2) if left else (width // 2, width)
+            chunk = x[:, :, y0:y0 + win_h, x0:x0 + win_w]
+            sr = forward_chop(run, chunk, scale, max_combined_im_size, shave=shave) if deeper else run(chunk)
+            out[:, :, scale * ys[0]:scale * ys[1], scale * xs[0]:scale * xs[1]] = \
+                sr[:, :, scale * (ys[0] - y0):scale * (ys[1] - y0), scale * (xs[0] - x0):scale * (xs[1] - x0)]
+    return out
