@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev 
   // ---- phase 0: input tile -> fp8 image (matrix operand); its centre 6 x 48 pixels also as they are (residual operand) ----
   {
     uint4 R[BREGS];
+    unsigned am_xb = 0u;
     const int y0 = sy * BSH - 2;
 #pragma unroll
     for (int i = 0; i < BREGS; ++i) {
@@ -93,13 +94,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev 
       if (p < BPIECES) {
         const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
         if (lr >= 2 && lr < 2 + BSH && lc >= 1 && lc <= BSW) *reinterpret_cast<uint4*>(lc16 + swz((lr - 2) * BSW + lc - 1, part)) = R[i];
-        float f[8];
-        unpack8(R[i], f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) am_x = fmaxf(am_x, fabsf(f[j]));
-        *reinterpret_cast<uint2*>(lx8 + f8_swz(pix, part >> 1) + (part & 1) * 8) = f8_pack8<E5M2>(f, x_scale);
+        am_xb = f8_amax_bf16(am_xb, R[i]);
+        *reinterpret_cast<uint2*>(lx8 + f8_swz(pix, part >> 1) + (part & 1) * 8) = f8_pack8_bf16<E5M2>(R[i], x_scale);
       }
     }
+    am_x = f8_amax_bf16_value(am_xb);
   }
   f8_v8i A[5];
   {

@@ -40,6 +40,39 @@ __device__ __forceinline__ uint2 f8_pack8(const float (&f)[8], float scale) {
   return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
 }
 
+// the same from 8 bf16 values as they come out of HBM (a 16-byte piece of a tile): v_cvt_scalef32_pk_{fp8,bf8}_bf16 converts the packed pairs
+// directly - no unpacking to fp32 (the staging pass of a tile is VALU time in front of the first MFMA)
+typedef __bf16 f8_v2bf __attribute__((ext_vector_type(2)));
+template <bool E5M2>
+__device__ __forceinline__ uint2 f8_pack8_bf16(uint4 v, float scale) {
+  f8_v2s a = {0, 0}, b = {0, 0};
+  if (E5M2) {
+    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(a, __builtin_bit_cast(f8_v2bf, v.x), scale, false);
+    a = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(a, __builtin_bit_cast(f8_v2bf, v.y), scale, true);
+    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(b, __builtin_bit_cast(f8_v2bf, v.z), scale, false);
+    b = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(b, __builtin_bit_cast(f8_v2bf, v.w), scale, true);
+  } else {
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(a, __builtin_bit_cast(f8_v2bf, v.x), scale, false);
+    a = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(a, __builtin_bit_cast(f8_v2bf, v.y), scale, true);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(b, __builtin_bit_cast(f8_v2bf, v.z), scale, false);
+    b = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(b, __builtin_bit_cast(f8_v2bf, v.w), scale, true);
+  }
+  return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+}
+// running amax of packed bf16 pairs as integers: |x| = bits & 0x7fff, and non-negative floats order like their bit patterns (v_pk_max_u16);
+// f8_amax_bf16_value turns the two halves into the fp32 amax
+typedef unsigned short f8_v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned f8_amax_bf16(unsigned m, uint4 v) {
+  auto mx = [](unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f8_v2u16, a), __builtin_bit_cast(f8_v2u16, b & 0x7fff7fffu)));
+  };
+  return mx(mx(mx(mx(m, v.x), v.y), v.z), v.w);
+}
+__device__ __forceinline__ float f8_amax_bf16_value(unsigned m) {
+  const unsigned h = (m >> 16) > (m & 0xffffu) ? (m >> 16) : (m & 0xffffu);
+  return __uint_as_float(h << 16);
+}
+
 // A = filter fragment (always e4m3), B = image fragment (e4m3 or e5m2); sa / sb = e8m0 exponents, uniform over the lanes
 template <bool E5M2>
 __device__ __forceinline__ f32x4 f8_mfma(f8_v8i a, f8_v8i b, f32x4 c, int sa, int sb) {
