@@ -24,13 +24,11 @@
 //    (conflict-free ds_read_b128 of chunk g of 16 consecutive pixels); a bf16 image of the strip's own 6 x 48 pixels of X (residual operand; OUT
 //    is written over it and leaves from there) and one of T (leaves for HBM from there; training).  131 KB.  X is converted while its tile is
 //    staged, T in the first phase's epilogue (v_cvt_scalef32_pk_{fp8,bf8}_f32) - never inside a sweep.
-//  * One MFMA has K = 128 = two taps x 64 channels; lane (pixel px, group g) supplies 32 bytes.  The 9 taps of an output tile are 5 MFMAs:
-//      P[ky]  (3x): taps (ky, kx 0 | kx 1): lane bytes 0-15 = channels 16 g .. of the pixel at kx 0, bytes 16-31 = the same channels at kx 1 - a
-//                   fragment is an image ROW property, shared by the three output rows it feeds (as in the bf16 sweep);
-//      Q01        : taps (ky 0 | ky 1, kx 2): lanes g < 2 read the pixel of row r, lanes g >= 2 the pixel of row r + 1, channels 32 (g & 1) ..;
-//      Q2         : tap (ky 2, kx 2) | nothing: bytes 0-15 = channels 16 g .., bytes 16-31 meet zeros in the filter image.
-//    (tests/tools/fp8/fp8_probe.hip: any lane / byte -> k assignment works as long as both operands use the same one.)  5 MFMAs of 32 cycles
-//    against 18 of 16: 0.56 of the matrix-pipe time, and 0.6 of the LDS fragment bytes.
+//  * One MFMA has K = 128 = two taps x 64 channels; lane (pixel px, group g) supplies 32 bytes.  The 9 taps of an output tile are 5 MFMAs - three
+//    "taps (ky, kx 0 | kx 1)" on row fragments shared by the output rows they feed, "taps (ky 0 | ky 1, kx 2)" and "(nothing | ky 2, kx 2)" on
+//    windows of one register run of column-2 pieces (fp8_common.hpp::f8_sweep).  (tests/tools/fp8/fp8_probe.hip: any lane / byte -> k assignment
+//    works as long as both operands use the same one.)  5 MFMAs of 32 cycles against 18 of 16: 0.56 of the matrix-pipe time, and half of the
+//    LDS fragment bytes.
 #include "fp8_common.hpp"
 
 struct BlockF8Dev {
@@ -131,9 +129,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev 
         MB[FORM == 3 ? k : 0] = a.mbits[in ? (unsigned)(((n * a.H + y) * a.W + xx) * 8 + chunk8) : 0u];
       }
     }
-    unsigned fb[8], hb[8];
-    f8_bases(fb, hb, (unsigned)F8_OFF_X8, 4 * rh, px, g);
-    f8_sweep<4, E5M2>(acc, A, lds, fb, hb, sa1, sbx);
+    unsigned fb[8];
+    f8_bases(fb, (unsigned)F8_OFF_X8, 4 * rh, px, g);
+    f8_sweep<4, E5M2>(acc, A, lds, fb, sa1, sbx);
     {
       const f8_v8i* wp = a.w2 + (size_t)q * 5 * 64 + lane;
 #pragma unroll
@@ -217,16 +215,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev 
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[r][c] = b4;
-    unsigned fb[8], hb[8];
+    unsigned fb[8];
     if (rh == 0) {
-      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 0, px2, g2);
-      f8_sweep<2, E5M2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, hb, sa2, sbt);   // output rows 0, 1 <- T rows 0 .. 3
+      f8_bases(fb, (unsigned)F8_OFF_T8, 0, px2, g2);
+      f8_sweep<2, E5M2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, sa2, sbt);   // output rows 0, 1 <- T rows 0 .. 3
       gate_wait(&gate[1], 4u);
-      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 2, px2, g2);
-      f8_sweep<1, E5M2>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), A, lds, fb, hb, sa2, sbt);                                // output row 2 <- T rows 2 .. 4
+      f8_bases(fb, (unsigned)F8_OFF_T8, 2, px2, g2);
+      f8_sweep<1, E5M2>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), A, lds, fb, sa2, sbt);                                // output row 2 <- T rows 2 .. 4
     } else {
-      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 3, px2, g2);
-      f8_sweep<3, E5M2>(acc, A, lds, fb, hb, sa2, sbt);                                           // output rows 3 .. 5 <- T rows 3 .. 7
+      f8_bases(fb, (unsigned)F8_OFF_T8, 3, px2, g2);
+      f8_sweep<3, E5M2>(acc, A, lds, fb, sa2, sbt);                                           // output rows 3 .. 5 <- T rows 3 .. 7
     }
     int px3 = px2, g3 = g2;
     asm volatile("" : "+v"(px3), "+v"(g3) : "v"(acc[2][2]));
@@ -362,9 +360,10 @@ __global__ void __launch_bounds__(1024) fp8_pack_kernel(const rumpy_fp8_pack_ite
         const int b = 4 * w4 + b4;
         int k, ky, kx;
         bool zero = false;
-        if (m < 3) { ky = m; kx = b >> 4; k = 16 * g + (b & 15); }
-        else if (m == 3) { ky = g >> 1; kx = 2; k = 32 * (g & 1) + b; }
-        else { ky = 2; kx = 2; k = 16 * g + (b & 15); zero = b >= 16; }
+        if (m < 3) { ky = m; kx = b >> 4; }                    // P[ky]: bytes 0-15 tap (ky, 0), 16-31 tap (ky, 1)
+        else if (m == 3) { ky = b >> 4; kx = 2; }              // Q01: bytes 0-15 tap (0, 2), 16-31 tap (1, 2)
+        else { ky = 2; kx = 2; zero = b < 16; }                // Q2: bytes 0-15 zero, 16-31 tap (2, 2)
+        k = 16 * g + (b & 15);
         float v = 0.f;
         if (!zero) v = img ? wl[k * F8_WROW + (row * 3 + (2 - ky)) * 3 + (2 - kx)] : wl[row * F8_WROW + (k * 3 + ky) * 3 + kx];
         f[b4] = v;

@@ -259,9 +259,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_fp8_kernel(RcabDev a) {
         MB[BWD ? k : 0] = a.mbits[in ? (unsigned)(((n * a.H + y) * a.W + xx) * 8 + chunk8) : 0u];
       }
     }
-    unsigned fb[8], hb[8];
-    f8_bases(fb, hb, (unsigned)F8_OFF_X8, 4 * rh, px, g);
-    f8_sweep<4, E5M2>(acc, A, lds, fb, hb, sa1, sbx);
+    unsigned fb[8];
+    f8_bases(fb, (unsigned)F8_OFF_X8, 4 * rh, px, g);
+    f8_sweep<4, E5M2>(acc, A, lds, fb, sa1, sbx);
     {
       const f8_v8i* wp = reinterpret_cast<const f8_v8i*>(a.w2) + (size_t)q * 5 * 64 + lane;
 #pragma unroll
@@ -333,16 +333,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_fp8_kernel(RcabDev a) {
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int c = 0; c < 3; ++c) acc[r][c] = b4;
-    unsigned fb[8], hb[8];
+    unsigned fb[8];
     if (rh == 0) {
-      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 0, px2, g2);
-      f8_sweep<2, E5M2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, hb, sa2, sbt);
+      f8_bases(fb, (unsigned)F8_OFF_T8, 0, px2, g2);
+      f8_sweep<2, E5M2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, sa2, sbt);
       gate_wait(&gate[1], 4u);
-      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 2, px2, g2);
-      f8_sweep<1, E5M2>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), A, lds, fb, hb, sa2, sbt);
+      f8_bases(fb, (unsigned)F8_OFF_T8, 2, px2, g2);
+      f8_sweep<1, E5M2>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), A, lds, fb, sa2, sbt);
     } else {
-      f8_bases(fb, hb, (unsigned)F8_OFF_T8, 3, px2, g2);
-      f8_sweep<3, E5M2>(acc, A, lds, fb, hb, sa2, sbt);
+      f8_bases(fb, (unsigned)F8_OFF_T8, 3, px2, g2);
+      f8_sweep<3, E5M2>(acc, A, lds, fb, sa2, sbt);
     }
     int px3 = px2, g3 = g2;
     asm volatile("" : "+v"(px3), "+v"(g3) : "v"(acc[2][2]));

@@ -87,67 +87,71 @@ __device__ __forceinline__ float f8_wave_max(float t, int lane) {
   return t;
 }
 
-// bases of the three fragment kinds for window row 0 = image row `row0` of the fp8 image at byte `buffer`:
-//   fb[d]: chunk g of pixel (row0, px) for XOR class d ; hb[d]: chunk 2 (g & 1) of pixel (row0 + (g >> 1), px + 2)
-__device__ __forceinline__ void f8_bases(unsigned (&fb)[8], unsigned (&hb)[8], unsigned buffer, int row0, int px, int g) {
-  const int p0 = row0 * BCOLS + px, ph = (row0 + (g >> 1)) * BCOLS + px + 2;
+// per-lane read bases for window row 0 = image row `row0` of the fp8 image at byte `buffer`: fb[d] = chunk g of pixel (row0, px) for XOR class d
+__device__ __forceinline__ void f8_bases(unsigned (&fb)[8], unsigned buffer, int row0, int px, int g) {
+  const int p0 = row0 * BCOLS + px;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    fb[d] = buffer + (unsigned)(p0 * 64 + ((g ^ ((((p0 + d) >> 2) & 1) << 1)) << 4));
-    hb[d] = buffer + (unsigned)(ph * 64 + (((2 * (g & 1)) ^ ((((ph + d) >> 2) & 1) << 1)) << 4));
-  }
+  for (int d = 0; d < 8; ++d) fb[d] = buffer + (unsigned)(p0 * 64 + ((g ^ ((((p0 + d) >> 2) & 1) << 1)) << 4));
 }
 
-// hook(i), i = 0 .. 8, runs after the MFMAs of step i have been issued (the HBM stores of the previous phase's tile travel there)
+// The sweep.  Operands of the five MFMAs of an output tile (window rows r .. r + 2 of the image, lane = (pixel px, channel group g)):
+//   P[ky] (3x): taps (ky, kx 0 | kx 1): bytes 0-15 = channels 16 g .. of the pixel at column px, bytes 16-31 = the same channels at px + 1 - one
+//               row fragment R[r + ky] (two 16-byte reads), shared by the three output rows it feeds;
+//   Q01       : taps (ky 0 | ky 1, kx 2): bytes 0-15 = channels 16 g .. of the pixel at (row r, px + 2), bytes 16-31 = at (row r + 1, px + 2);
+//   Q2        : taps (nothing | ky 2, kx 2): bytes 0-15 meet zeros in the filter image, bytes 16-31 = channels 16 g .. at (row r + 2, px + 2).
+// Round 4, second form: the column-2 pieces C[r] = (row r, px + 2) of ALL window rows sit in ONE run of registers, so that Q01's operand is the
+// window C[r .. r + 1] and Q2's C[r + 1 .. r + 2] - sub-tuples of the run, no moves, no zero registers - and every 16-byte piece of the image is
+// read from LDS once per column tile: 18 reads where the first form (its Q01 mixed two rows ACROSS lane groups and needed its own reads) took
+// 24, and 72 fragment registers instead of 112.  With 24 reads the fp8 sweep was LDS-bound (8 waves x 72 KB per first phase = 4608 clocks of
+// the CU's 128 B / clk against 3840 of matrix pipe per SIMD); with 18 it is 3456.
+// hook(i), i = 0 .. 8, runs after the MFMAs of step i have been issued.
+typedef int f8_v32i __attribute__((ext_vector_type(32)));
 template <int ROWS, bool E5M2, class Hook = NoHook>
 __device__ __forceinline__ void f8_sweep(f32x4 (&acc)[ROWS][3], const f8_v8i (&A)[5], const unsigned char* lds, const unsigned (&fb)[8],
-                                         const unsigned (&hb)[8], int sa, int sb, Hook hook = Hook()) {
-  f8_v8i F[ROWS + 2], Hh[ROWS], G[ROWS];
+                                         int sa, int sb, Hook hook = Hook()) {
+  f8_v8i R[ROWS + 2];
+  f8_v32i C;                              // pieces C[r] at elements 4 r .. 4 r + 3 (r < ROWS + 2 <= 6)
+#pragma unroll
+  for (int i = 0; i < 32; ++i) C[i] = 0;
   auto ld16 = [&](unsigned addr) { return *reinterpret_cast<const f8_v4i*>(lds + addr); };
-  auto load_f = [&](int c) {
+  auto load_r = [&](int c) {
 #pragma unroll
     for (int r = 0; r < ROWS + 2; ++r) {
       const int k0 = r * BCOLS + 16 * c, k1 = k0 + 1;
       const f8_v4i lo = ld16(fb[k0 & 7] + k0 * 64), hi = ld16(fb[k1 & 7] + k1 * 64);
-      F[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      R[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     }
   };
-  auto load_h = [&](int c) {
+  auto load_c = [&](int c) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int k = r * BCOLS + 16 * c;                    // (the + 2 columns and the lane's row are in hb)
-      const f8_v4i lo = ld16(hb[k & 7] + k * 64), hi = ld16(hb[k & 7] + k * 64 + 16);
-      Hh[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    for (int r = 0; r < ROWS + 2; ++r) {
+      const int k = r * BCOLS + 16 * c + 2;
+      const f8_v4i v = ld16(fb[k & 7] + k * 64);
+      C[4 * r] = v.x; C[4 * r + 1] = v.y; C[4 * r + 2] = v.z; C[4 * r + 3] = v.w;
     }
   };
-  auto load_g = [&](int c) {
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const int k = (r + 2) * BCOLS + 16 * c + 2;
-      const f8_v4i lo = ld16(fb[k & 7] + k * 64);
-      G[r] = (f8_v8i){lo.x, lo.y, lo.z, lo.w, 0, 0, 0, 0};     // the filter image's second half is zero for this MFMA
-    }
+  auto win = [&](int r) {                 // C[r .. r + 1] as one operand
+    return (f8_v8i){C[4 * r], C[4 * r + 1], C[4 * r + 2], C[4 * r + 3], C[4 * r + 4], C[4 * r + 5], C[4 * r + 6], C[4 * r + 7]};
   };
-  load_f(0);
+  load_r(0);
+  load_c(0);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    load_h(c);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[ky], F[r + ky], acc[r][c], sa, sb);
+      for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[ky], R[r + ky], acc[r][c], sa, sb);
     hook(3 * c);
-    load_g(c);
+    if (c + 1 < 3) load_r(c + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[3], Hh[r], acc[r][c], sa, sb);
+    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[3], win(r), acc[r][c], sa, sb);
     hook(3 * c + 1);
-    if (c + 1 < 3) load_f(c + 1);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[4], G[r], acc[r][c], sa, sb);
+    for (int r = 0; r < ROWS; ++r) acc[r][c] = f8_mfma<E5M2>(A[4], win(r + 1), acc[r][c], sa, sb);
     hook(3 * c + 2);
+    if (c + 1 < 3) load_c(c + 1);
   }
 }
 

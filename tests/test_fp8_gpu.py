@@ -40,7 +40,7 @@ def exponent_for(amax):
 
 def pack_filter_fp8(w, scale):
     """w [64, 64, 3, 3] fp32 (row = MFMA row, i.e. output channel of the conv being evaluated) -> [q 4][mfma 5][lane 64][32 bytes]
-    (conv_block_fp8.hip: P[ky], Q01, Q2)"""
+    (fp8_common.hpp::f8_sweep: P[ky] = taps (ky, 0 | 1); Q01 = taps (0 | 1, 2); Q2 = (zeros | tap (2, 2)))"""
     w8 = q8(w, scale).to(F8).view(torch.uint8).numpy()
     img = np.zeros((4, 5, 64, 32), dtype=np.uint8)
     for q in range(4):
@@ -50,8 +50,9 @@ def pack_filter_fp8(w, scale):
             for ky in range(3):
                 img[q, ky, lane, :16] = w8[co, 16 * g:16 * g + 16, ky, 0]
                 img[q, ky, lane, 16:] = w8[co, 16 * g:16 * g + 16, ky, 1]
-            img[q, 3, lane, :] = w8[co, 32 * (g & 1):32 * (g & 1) + 32, g >> 1, 2]
-            img[q, 4, lane, :16] = w8[co, 16 * g:16 * g + 16, 2, 2]
+            img[q, 3, lane, :16] = w8[co, 16 * g:16 * g + 16, 0, 2]
+            img[q, 3, lane, 16:] = w8[co, 16 * g:16 * g + 16, 1, 2]
+            img[q, 4, lane, 16:] = w8[co, 16 * g:16 * g + 16, 2, 2]
     return img.reshape(-1)
 
 
