@@ -192,19 +192,21 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev 
   for (int i = 0; i < GROUP_REGS; ++i) soff[i] = group_piece_off(i, tg2, rh, n, sy, a.H, a.W);
   // the row half's own strip rows of T (and, forward, their ReLU mask bytes) leave for HBM from the finished bf16 image: whole lines, non-temporal,
   // one piece after every other step of the second sweep
-  // ... issued HERE, in front of the second sweep (they drain under it): staged up front and stored one by one between the sweep's steps, as
-  // conv_block.hip does, the five pieces do not fit next to this sweep's fragments (scratch round trips), and stores inside the sweep are
-  // branches, which let LLVM sink MFMAs past them.
-  if (a.t) {
-    uint4 S[GROUP_REGS];
-    f8_stage48(S, lt16, tg2, rh);
-#pragma unroll
-    for (int i = 0; i < GROUP_REGS; ++i)
-      if (soff[i] != 0xffffffffu) {
+  // ... one 16-byte piece per thread after every other step of the second sweep (conv_block.hip), staged from the finished bf16 image first.
+  // (With the first form of the sweep - 112 fragment registers - the five staged pieces did not fit and went to scratch; the stores then sat in front
+  // of the sweep.  Under it they are worth 0.8 % of the step.)
+  uint4 S[GROUP_REGS];
+  const bool t_out = a.t != nullptr;
+  if (t_out) f8_stage48(S, lt16, tg2, rh);
+  auto t_store = [&](int step) {          // step is a constant after unrolling
+    if (step % 2 == 0 && step / 2 < GROUP_REGS) {
+      const int i = step / 2 < GROUP_REGS ? step / 2 : 0;
+      if (t_out && soff[i] != 0xffffffffu) {
         st16_nt(a.t + soff[i], S[i]);
         if (FORM == 1 && a.mbits) a.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
       }
-  }
+    }
+  };
 
   // ---- phase 2: output rows 3rh .. 3rh+2 ; OUT = X + scale2 * (convB(T) + b2) [+ res2] ----
   {
@@ -218,13 +220,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) conv_block_fp8_kernel(BlockF8Dev 
     unsigned fb[8];
     if (rh == 0) {
       f8_bases(fb, (unsigned)F8_OFF_T8, 0, px2, g2);
-      f8_sweep<2, E5M2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, sa2, sbt);   // output rows 0, 1 <- T rows 0 .. 3
+      f8_sweep<2, E5M2, decltype(t_store)>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, sa2, sbt, t_store);   // output rows 0, 1 <- T rows 0 .. 3
       gate_wait(&gate[1], 4u);
       f8_bases(fb, (unsigned)F8_OFF_T8, 2, px2, g2);
       f8_sweep<1, E5M2>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), A, lds, fb, sa2, sbt);                                // output row 2 <- T rows 2 .. 4
     } else {
       f8_bases(fb, (unsigned)F8_OFF_T8, 3, px2, g2);
-      f8_sweep<3, E5M2>(acc, A, lds, fb, sa2, sbt);                                           // output rows 3 .. 5 <- T rows 3 .. 7
+      f8_sweep<3, E5M2, decltype(t_store)>(acc, A, lds, fb, sa2, sbt, t_store);                                           // output rows 3 .. 5 <- T rows 3 .. 7
     }
     int px3 = px2, g3 = g2;
     asm volatile("" : "+v"(px3), "+v"(g3) : "v"(acc[2][2]));

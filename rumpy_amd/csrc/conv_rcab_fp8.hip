@@ -312,17 +312,20 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_fp8_kernel(RcabDev a) {
   unsigned soffg[GROUP_REGS];
 #pragma unroll
   for (int i = 0; i < GROUP_REGS; ++i) soffg[i] = group_piece_off(i, tg2, rh, n, sy, a.H, a.W);
-  // the row half's own strip rows of t1 / gt1 (forward: + the ReLU mask bytes) leave for HBM in front of the second sweep (conv_block_fp8.hip)
-  if (a.t) {
-    uint4 S[GROUP_REGS];
-    f8_stage48(S, lt16, tg2, rh);
-#pragma unroll
-    for (int i = 0; i < GROUP_REGS; ++i)
-      if (soffg[i] != 0xffffffffu) {
-        st16_nt(a.t + soffg[i], S[i]);
-        if (!BWD && a.mbits) a.mbits[soffg[i] >> 3] = (unsigned char)relu_bits(S[i]);
+  // the row half's own strip rows of t1 / gt1 (forward: + the ReLU mask bytes) leave for HBM under the second sweep, one 16-byte piece per thread
+  // after every other step (conv_block_fp8.hip), staged from the finished bf16 image first
+  uint4 St[GROUP_REGS];
+  const bool t_out = a.t != nullptr;
+  if (t_out) f8_stage48(St, lt16, tg2, rh);
+  auto t_store = [&](int step) {          // step is a constant after unrolling
+    if (step % 2 == 0 && step / 2 < GROUP_REGS) {
+      const int i = step / 2 < GROUP_REGS ? step / 2 : 0;
+      if (t_out && soffg[i] != 0xffffffffu) {
+        st16_nt(a.t + soffg[i], St[i]);
+        if (!BWD && a.mbits) a.mbits[soffg[i] >> 3] = (unsigned char)relu_bits(St[i]);
       }
-  }
+    }
+  };
 
   // ---- phase 2: rows 3rh .. 3rh+2 of the strip from T rows r .. r+2 ----
   {
@@ -336,13 +339,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_fp8_kernel(RcabDev a) {
     unsigned fb[8];
     if (rh == 0) {
       f8_bases(fb, (unsigned)F8_OFF_T8, 0, px2, g2);
-      f8_sweep<2, E5M2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, sa2, sbt);
+      f8_sweep<2, E5M2, decltype(t_store)>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), A, lds, fb, sa2, sbt, t_store);
       gate_wait(&gate[1], 4u);
       f8_bases(fb, (unsigned)F8_OFF_T8, 2, px2, g2);
       f8_sweep<1, E5M2>(*reinterpret_cast<f32x4(*)[1][3]>(&acc[2]), A, lds, fb, sa2, sbt);
     } else {
       f8_bases(fb, (unsigned)F8_OFF_T8, 3, px2, g2);
-      f8_sweep<3, E5M2>(acc, A, lds, fb, sa2, sbt);
+      f8_sweep<3, E5M2, decltype(t_store)>(acc, A, lds, fb, sa2, sbt, t_store);
     }
     int px3 = px2, g3 = g2;
     asm volatile("" : "+v"(px3), "+v"(g3) : "v"(acc[2][2]));
