@@ -389,6 +389,11 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='LR patches per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--probe-steps', type=int, default=5)
+    ap.add_argument('--settle-ms', type=float, default=120.0,
+                    help='hold the GPU under load (the same training steps) for this long before the W warm-up steps: a fresh process starts with '
+                         'the core clock at its idle level and the SMU needs 30-50 ms of load to raise it (profiles/r04_clock_ramp.txt: every '
+                         'MFMA-bound kernel 15-27 %% slower over the first 25 steps, the HBM-bound ones unchanged).  On one GPU the region of a '
+                         'fresh process (W warm-up + K steps, no settling) is timed first and reported as `cold_start`.  0 = off')
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan', 'blindqrcan', 'edsr256', 'moco'), default='edsr',
@@ -522,6 +527,23 @@ def main():
     # process group - one inline collective behind the backward pass, then the early half on the side stream under the remaining weight
     # gradients - reports the faster as `value` and both under `distributed.forms`; every rank prints its own time to stderr.
     forms_ms = forms_loss = None
+    cold_start = settle = None
+    if args.settle_ms > 0:
+        t_load = time.perf_counter()
+        n_settle = 0
+        if not dp:
+            e, _, _ = timed_region()        # a fresh process, exactly as the contract reads: the like-for-like figure of BENCH_r01..r03
+            cold_start = {'value': round(N * args.steps / e, 2), 'ms_per_step': round(1e3 * e / args.steps, 4), 'steps': args.steps, 'warmup': args.warmup}
+            n_settle = args.steps + args.warmup
+        if not dp:
+            while time.perf_counter() - t_load < 1e-3 * args.settle_ms:
+                step(n_settle)
+                n_settle += 1
+        else:
+            for n_settle in range(1, 1 + max(1, int(args.settle_ms / 1.2))):      # the same count on every rank: the step contains the all-reduce
+                step(n_settle)
+        settle = {'steps_before_warmup': n_settle, 'ms': round(1e3 * (time.perf_counter() - t_load), 1),
+                  'what': 'training steps that keep the GPU loaded until its core clock has left the idle level; then W warm-up steps, then the K timed ones'}
     hipnet0 = getattr(h.net, 'hip_generator', h.net)
     if dp and args.allreduce_form == 'auto' and hasattr(hipnet0, 'engine_forward') and not getattr(hipnet0, 'use_graph', False) \
             and not any(os.environ.get(k) for k in ('RUMPY_DP_EARLY', 'RUMPY_DP_LATE')):
@@ -694,7 +716,7 @@ def main():
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),
                            'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4),      # (whole step, against the bf16 peak)
                            'precision': args.precision},
-                'roofline': roofline, 'cpu_baseline': cpu, 'as_called': as_called,
+                'roofline': roofline, 'cpu_baseline': cpu, 'as_called': as_called, 'cold_start': cold_start, 'clock_settle': settle,
                 # what the collectives really ran on (the driver's scaling run can check that RCCL saw N ranks on N devices)
                 'distributed': {'world_size': dist.get_world_size() if dp else 1, 'backend': dist.get_backend() if dp else None,
                                 'device_count': torch.cuda.device_count(), 'ranks_on_one_device': bool(one_device),

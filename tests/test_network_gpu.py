@@ -811,7 +811,7 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     env = dict(os.environ, RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29571', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
-           '--no-cpu-baseline']
+           '--no-cpu-baseline', '--settle-ms', '0']
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-3000:]
@@ -834,7 +834,7 @@ def test_bench_starts_its_own_ranks_when_called_plainly():
     env.update(RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     for form, want in (('auto', None), ('early', 'early')):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
-               '--no-cpu-baseline', '--allreduce-form', form]
+               '--no-cpu-baseline', '--settle-ms', '0', '--allreduce-form', form]
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
         out = p.stdout.decode()
         assert p.returncode == 0, (out + p.stderr.decode())[-3000:]
@@ -897,7 +897,7 @@ def test_bench_runs_over_rccl_with_one_rank(model, early):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tail = ['--model', model, '--steps', '6', '--warmup', '2', '--probe-steps', '2', '--no-cpu-baseline']
+    tail = ['--model', model, '--steps', '6', '--warmup', '2', '--probe-steps', '2', '--no-cpu-baseline', '--settle-ms', '0']
     env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', **({'RUMPY_DP_EARLY': '1'} if early else {}))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', '29573', os.path.join(root, 'bench.py'), '--gpus', '1'] + tail
@@ -964,12 +964,33 @@ def test_bench_line_reports_what_the_collectives_ran_on():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29574',
-           os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--probe-steps', '1', '--no-cpu-baseline']
+           os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--probe-steps', '1', '--no-cpu-baseline', '--settle-ms', '0']
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
     assert p.returncode == 0, p.stdout.decode()[-3000:]
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')][0])['distributed']
     assert d['world_size'] == 1 and d['backend'] == 'nccl' and d['device_count'] >= 1 and d['ranks_on_one_device'] is False
     assert abs(d['grad_allreduce_mb'] - 6.07) < 0.01
+
+
+def test_bench_line_separates_the_cold_start_from_the_settled_clock():
+    """bench.py's default run: the region of a fresh process (W warm-up + K steps) is timed first and reported as `cold_start`, then the GPU
+    is kept under load until --settle-ms have passed, then W warm-up + K timed steps give `value`; --settle-ms 0 reports the cold region as
+    `value` (the form of rounds 1-3) and leaves both fields null."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, 'bench.py'), '--steps', '10', '--warmup', '3', '--probe-steps', '1', '--no-cpu-baseline']
+    lines = []
+    for extra in ([], ['--settle-ms', '0']):
+        p = subprocess.run(base + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+        assert p.returncode == 0, p.stdout.decode()[-3000:]
+        lines.append(json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')][0]))
+    d, e = lines
+    assert d['steps'] == 10 and d['warmup'] == 3 and d['cold_start']['steps'] == 10 and d['cold_start']['warmup'] == 3
+    assert d['clock_settle']['steps_before_warmup'] >= 13 and d['clock_settle']['ms'] >= 120.0
+    assert d['cold_start']['value'] > 0 and d['value'] > 0.97 * d['cold_start']['value']      # (the settled clock is never the slower one)
+    assert e['cold_start'] is None and e['clock_settle'] is None and e['value'] > 0
 
 
 def test_rcab_launches_next_to_a_foreign_kernel_that_holds_cus():
