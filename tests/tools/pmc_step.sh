@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 M=${1:-edsr}
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmcs_${M}_$c -o p --output-format csv -- python3 $R/bench.py --model $M --steps 3 --warmup 1 --probe-steps 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmcs_${M}_$c -o p --output-format csv -- python3 $R/bench.py --model $M --steps 3 --warmup 1 --probe-steps 1 --no-cpu-baseline --settle-ms 0 > /dev/null 2>&1
 done
 cd $R
 python3 - <<PY

@@ -19,12 +19,12 @@ python3 bench.py --mode eval --steps 60 --warmup 6 > $OUT/eval_edsr_bench_line.j
 python3 bench.py --mode eval --model rcan --steps 20 --warmup 3 > $OUT/eval_rcan_bench_line.json 2>> $OUT/bench_err.log
 python3 bench.py --model moco --steps 300 --warmup 30 > $OUT/moco_bench_line.json 2>> $OUT/bench_err.log
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr -o p -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $OUT/prof_edsr.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan -o p -- python3 $R/bench.py --model rcan --steps 40 --warmup 10 --no-cpu-baseline > $OUT/prof_rcan.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr64 -o p -- python3 $R/bench.py --lr-size 64 --batch 16 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/prof_edsr64.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eval -o p -- python3 $R/bench.py --mode eval --steps 40 --warmup 5 --no-cpu-baseline > $OUT/prof_eval.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr_fp8 -o p -- python3 $R/bench.py --precision fp8 --steps 100 --warmup 20 --no-cpu-baseline > $OUT/prof_edsr_fp8.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan_fp8 -o p -- python3 $R/bench.py --model rcan --precision fp8 --steps 40 --warmup 10 --no-cpu-baseline > $OUT/prof_rcan_fp8.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr -o p -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --settle-ms 0 > $OUT/prof_edsr.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan -o p -- python3 $R/bench.py --model rcan --steps 40 --warmup 10 --no-cpu-baseline --settle-ms 0 > $OUT/prof_rcan.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr64 -o p -- python3 $R/bench.py --lr-size 64 --batch 16 --steps 60 --warmup 10 --no-cpu-baseline --settle-ms 0 > $OUT/prof_edsr64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eval -o p -- python3 $R/bench.py --mode eval --steps 40 --warmup 5 --no-cpu-baseline --settle-ms 0 > $OUT/prof_eval.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr_fp8 -o p -- python3 $R/bench.py --precision fp8 --steps 100 --warmup 20 --no-cpu-baseline --settle-ms 0 > $OUT/prof_edsr_fp8.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan_fp8 -o p -- python3 $R/bench.py --model rcan --precision fp8 --steps 40 --warmup 10 --no-cpu-baseline --settle-ms 0 > $OUT/prof_rcan_fp8.log 2>&1
 cd $R
 for m in edsr rcan edsr64 eval edsr_fp8 rcan_fp8; do cp $(find $OUT/prof_$m -name '*kernel_stats.csv' | head -1) $OUT/${m}_kernel_stats.csv; rm -rf $OUT/prof_$m; done
 bash tests/tools/pmc_step.sh edsr > $OUT/pmc_step_edsr.txt 2>&1
