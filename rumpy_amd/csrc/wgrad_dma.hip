@@ -155,9 +155,9 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
   for (int ct = 0; ct < MT; ++ct)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[ct][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 bacc[MT];
-#pragma unroll
-  for (int ct = 0; ct < MT; ++ct) bacc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient = dy against a ones fragment: output-channel tile w4 on the waves (w4, *) - one MFMA per k-step on every wave (round 4; all four
+  // on the w4 = 0 waves until then: 40 MFMAs per k-step there against 36 elsewhere, and the tile barrier made everybody wait for them)
+  f32x4 bacc = (f32x4){0.f, 0.f, 0.f, 0.f};
   bf16x8 ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
@@ -200,9 +200,13 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
           A[ct] = join8b(tr_read2(pa), tr_read2(pa + ((p4 == 0) ? 8 * 8 : 0)));
         }
       }
-      if (w4 == 0) {
-#pragma unroll
-        for (int ct = 0; ct < MT; ++ct) bacc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], ones, bacc[ct], 0, 0, 0);
+      if (MT == 4) {                     // (wave-uniform branches: A[w4] without indexing the register file)
+        if (w4 == 0) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], ones, bacc, 0, 0, 0);
+        else if (w4 == 1) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1 % MT], ones, bacc, 0, 0, 0);
+        else if (w4 == 2) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 % MT], ones, bacc, 0, 0, 0);
+        else bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[3 % MT], ones, bacc, 0, 0, 0);
+      } else if (w4 == 0) {
+        bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], ones, bacc, 0, 0, 0);
       }
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -236,21 +240,19 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
         for (int e = 0; e < 4; ++e) slab[((16 * ct + 4 * g + e) * 9 + tap) * 64 + ci] = o[e];
       }
   }
-  // bias sums: waves (w4 = 0, kh = 0/1) hold D[co][*] (all 16 columns equal); add the halves through LDS too
+  // bias sums: waves (w4, kh = 0/1) hold D[co of tile w4][*] (all 16 columns equal; MT = 1: the w4 = 0 waves only); add the halves through LDS too
   __syncthreads();
   float* bx = reinterpret_cast<float*>(lds);
-  if (w4 == 0 && kh == 1 && (lane & 15) == 0) {
+  const bool bias_wave = (MT == 4) || w4 == 0;
+  const int bct = (MT == 4) ? w4 : 0;
+  if (bias_wave && kh == 1 && (lane & 15) == 0) {
 #pragma unroll
-    for (int ct = 0; ct < MT; ++ct)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bx[16 * ct + 4 * g + e] = bacc[ct][e];
+    for (int e = 0; e < 4; ++e) bx[16 * bct + 4 * g + e] = bacc[e];
   }
   __syncthreads();
-  if (w4 == 0 && kh == 0 && (lane & 15) == 0) {
+  if (bias_wave && kh == 0 && (lane & 15) == 0) {
 #pragma unroll
-    for (int ct = 0; ct < MT; ++ct)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) slab[16 * MT * 576 + 16 * ct + 4 * g + e] = bacc[ct][e] + bx[16 * ct + 4 * g + e];
+    for (int e = 0; e < 4; ++e) slab[16 * MT * 576 + 16 * bct + 4 * g + e] = bacc[e] + bx[16 * bct + 4 * g + e];
   }
 }
 
