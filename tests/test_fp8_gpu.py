@@ -8,6 +8,7 @@ Two layers of checks:
         every 3x3-conv tensor <= 1.5e-1 (bf16 path: 3e-2), loss trajectory over 40 Adam steps within 1 % of the oracle's at every step,
         evaluation untouched (fp16 evaluation plans run on the fp32 master weights whatever the training precision).
 """
+import os
 import tempfile
 
 import numpy as np
@@ -371,3 +372,29 @@ def test_fp8_needs_the_eager_step_and_the_narrow_net():
         h.run_train(x=x, y=y)
     with pytest.raises(RuntimeError, match='precision'):
         _handler('edsr', lr=1e-3, scale=2, num_blocks=1, precision='int4')
+
+
+@pytest.mark.parametrize('model,early', [('edsr', False), ('rcan', True)])
+def test_fp8_step_under_the_data_parallel_path(model, early):
+    """precision='fp8' needs nothing from the data-parallel path (scales and site records are per rank, the all-reduce sees the same flat fp32
+    gradient): bench.py --precision fp8 over RCCL with one rank (RUMPY_DP_FORCE=1) in both all-reduce forms - a sum over one rank is the
+    identity, so the loss after W + K steps equals the plain fp8 run's (with the same weight-gradient plan form, as in the bf16 test)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = ['--model', model, '--precision', 'fp8', '--steps', '5', '--warmup', '2', '--probe-steps', '1', '--no-cpu-baseline', '--settle-ms', '0']
+    env = dict(os.environ, RUMPY_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', **({'RUMPY_DP_EARLY': '1'} if early else {'RUMPY_DP_LATE': '1'}))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29577', os.path.join(root, 'bench.py'), '--gpus', '1'] + tail
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
+    q = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + tail, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=600, cwd=root, env=dict(os.environ, **({'RUMPY_WGRAD_AB': '1'} if early else {})))
+    assert q.returncode == 0, q.stdout.decode()[-3000:]
+    e = json.loads([l for l in q.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
+    assert d['config']['precision'] == 'fp8' and d['distributed']['backend'] == 'nccl'
+    assert d['distributed']['allreduce_form'] == ('early' if early else 'inline')
+    assert d['roofline']['peak'] == 5000.0 and 'fp8' in d['roofline']['kernel']
+    assert d['config']['loss'] == e['config']['loss'], (d['config']['loss'], e['config']['loss'])
