@@ -21,9 +21,20 @@
 //     with the stage whose slot the next DMA overwrites); no K split, so no partial-sum exchange either: same MFMA order per accumulator as
 //     conv3x3_kernel<4> (chunks 0 .. 3 in turn): bitwise that kernel (tests/test_kernels_gpu.py).
 #include "block_common.hpp"
+#include <cstdlib>
+static inline int d4_cdiv(int a, int b) { return (a + b - 1) / b; }
 
-constexpr int D4_PIECES = 23;                         // 184 pixel slots >= 180 halo pixels
-constexpr int D4_STAGE = D4_PIECES * 1024;
+// Tile height as a parameter (round 4): 8 rows, or 6 where that fills the chip better - the 32 x 48 x 48 stage of the x4 upsampler is 576 tiles of
+// 8 rows = three rounds of 192 workgroups for 2.25 rounds of work, and exactly three rounds of 256 six-row tiles (35.1 -> 27-28 us).  Every output
+// element sees the same MFMA sequence either way (chunk, tap column, channel half, tap row): bitwise equal.
+template <int TH_> struct D4Geo {
+  static constexpr int TR = TH_;                         // output rows per tile
+  static constexpr int HR = TH_ / 2;                     // rows per pass
+  static constexpr int HPIX = (TH_ + 2) * HALO_W;        // halo pixels: 180 / 144
+  static constexpr int PIECES = (HPIX + 7) / 8;          // DMA pieces of 8 pixels: 23 / 18
+  static constexpr int STAGE = PIECES * 1024;
+  static constexpr int PW = (PIECES + 3) / 4;            // DMA pieces per wave and stage (the surplus repeats the last piece): 6 / 5
+};
 constexpr int D4_NST = 6;                             // ring slots: the stage in use, four in flight, one being refilled
 #ifndef D4_AHEAD
 #define D4_AHEAD 4
@@ -35,10 +46,8 @@ constexpr int D4_NST = 6;                             // ring slots: the stage i
                         // channels evenly at every moment; in runs, each XCD streams one compact region and the halo lines it saves were L2 hits of the
                         // Infinity Cache anyway (profiles/r03_conv4_xcd_ab.txt)
 #ifndef D4_RD
-#define D4_RD 2         // fragment sets read ahead of the MFMAs (units of 6 reads / 12 MFMAs)
+#define D4_RD 2         // fragment sets read ahead of the MFMAs (units of HR + 2 reads / 3 HR MFMAs)
 #endif
-constexpr int D4_RING = D4_NST * D4_STAGE;            // 141,312 B
-constexpr int D4_PW = 6;                              // DMA pieces per wave and stage (4 waves x 6 >= 23; the surplus repeats piece 22)
 
 __device__ __attribute__((aligned(256))) uint4 g_zero_page4[16];
 typedef __attribute__((address_space(3))) unsigned char* d4_lds_u8;
@@ -51,9 +60,11 @@ __device__ __forceinline__ void d4_dma16(const void* gsrc, unsigned lds_dst) {  
 template <int N> __device__ __forceinline__ void d4_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 
-template <int FMT>      // element format of activations and filters (RUMPY_FMT_F16: evaluation plans of the wide nets)
+template <int FMT, int TH_ = TH>      // element format of activations and filters (RUMPY_FMT_F16: evaluation plans of the wide nets); tile rows
 __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[D4_RING];
+  typedef D4Geo<TH_> G;
+  constexpr int D4_PIECES = G::PIECES, D4_STAGE = G::STAGE, D4_PW = G::PW, HR = G::HR;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[D4_NST * D4_STAGE];      // 141,312 / 110,592 B
   __shared__ unsigned landed;            // stages landed: 4 arrivals each
   const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, g = lane >> 4;
@@ -91,7 +102,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     const int piece = (q + 4 * k < D4_PIECES) ? q + 4 * k : D4_PIECES - 1;
     const int pix = piece * 8 + (lane >> 3);
     const int r = pix / HALO_W, c = pix - r * HALO_W;
-    pr[k] = (pix < HALO_PIX) ? r - 1 : -100000;                     // a pixel slot past the halo is out of the image for every tile
+    pr[k] = (pix < G::HPIX) ? r - 1 : -100000;                     // a pixel slot past the halo is out of the image for every tile
     pc[k] = ((c - 1) << 8) | (((lane & 7) ^ (pix & 7)) * 8);         // column (may be -1: arithmetic shift) and source chunk offset in elements
   }
   // piece k of stage u (tile tile0 + (u / 4) * tstride, input chunk u & 3): ~12 VALU + the DMA; called one piece at a time from inside the
@@ -102,7 +113,7 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
     const int ch = u & 3;
     const unsigned dst = ring + (unsigned)(u % D4_NST) * D4_STAGE;
     const int piece = (q + 4 * k < D4_PIECES) ? q + 4 * k : D4_PIECES - 1;
-    const int y = tc.ty * TH + pr[k], x = tc.tx * TW + (pc[k] >> 8);
+    const int y = tc.ty * TH_ + pr[k], x = tc.tx * TW + (pc[k] >> 8);
     const int sch = pc[k] & 255;
     const bool ok = ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
     unsigned e;
@@ -136,9 +147,9 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
   for (int it = 0; it < nt; ++it) {
     const TileCoord tc = decode_tile(tile_of(it), a.tiles_x, a.tiles_y);
     const int xx = tc.tx * TW + px;
-    f32x4 acc[TH];
+    f32x4 acc[TH_];
 #pragma unroll
-    for (int r = 0; r < TH; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < TH_; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
       const int u = 4 * it + ch;
@@ -150,12 +161,12 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
       if (u + D4_AHEAD < nstage) issue(u + D4_AHEAD);   // into a slot every wave is past (stage u - 2's)
       const unsigned char* cur = lds + (u % D4_NST) * D4_STAGE;
       // 12 units (tap column, channel half, row half) of 6 fragment reads + 12 MFMAs; the reads of unit j + 1 travel under the MFMAs of unit j
-      bf16x8 I[D4_RD + 1][6];
-      auto load_unit = [&](int j, bf16x8 (&dst)[6]) {
+      bf16x8 I[D4_RD + 1][HR + 2];
+      auto load_unit = [&](int j, bf16x8 (&dst)[HR + 2]) {
         const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
-          dst[r] = *reinterpret_cast<const bf16x8*>(cur + off[(2 * r + kx) & 7][half] + ((4 * pass + r) * HALO_W + kx) * 128);
+        for (int r = 0; r < HR + 2; ++r)
+          dst[r] = *reinterpret_cast<const bf16x8*>(cur + off[(2 * (HR * pass + r) + kx) & 7][half] + ((HR * pass + r) * HALO_W + kx) * 128);
       };
 #pragma unroll
       for (int j = 0; j < D4_RD; ++j) load_unit(j, I[j]);
@@ -167,15 +178,15 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[4 * pass + r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[4 * pass + r]);
+          for (int r = 0; r < HR; ++r)
+            acc[HR * pass + r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[HR * pass + r]);
       }
     }
     // ---- epilogue: lane holds channels c0 .. c0+3 of pixel (row r, column px); the residual operand is read here (plain loads: the
     // compiler's wait for them drains the DMA queue - everything older - which costs one stage's slack once per tile) ----
 #pragma unroll
-    for (int r = 0; r < TH; ++r) {
-      const int y = tc.ty * TH + r;
+    for (int r = 0; r < TH_; ++r) {
+      const int y = tc.ty * TH_ + r;
       if (y < a.H && xx < a.W) {
         const size_t e = ((size_t)(tc.n * a.H + y) * a.W + xx) * cstr + ct * 64 + c0;
         float v[4];
@@ -209,8 +220,25 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
   }
 }
 
-int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s, int fmt) {
-  if (fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(conv4d_kernel<RUMPY_FMT_F16>, dim3(grid, d.cout_tiles), dim3(256), 0, s, d);
-  else hipLaunchKernelGGL(conv4d_kernel<RUMPY_FMT_BF16>, dim3(grid, d.cout_tiles), dim3(256), 0, s, d);
+// grid_x <= 0: choose tile height and grid for `cap` resident workgroups per output tile (a workgroup is alone on its CU): fewest
+// rounds x (rows + 2) - a tile costs its output rows plus the two halo rows it also fetches
+int rumpy_conv4d_launch(ConvDev d, int grid_x, int cap, hipStream_t s, int fmt) {
+  int th = TH;
+  if (fmt != RUMPY_FMT_F16 && !getenv("RUMPY_CONV4_TH8")) {
+    const long long t8 = (long long)d.N * d.tiles_x * d4_cdiv(d.H, 8), t6 = (long long)d.N * d.tiles_x * d4_cdiv(d.H, 6);
+    if (d4_cdiv((int)t6, cap) * 8 < d4_cdiv((int)t8, cap) * 10) th = 6;
+  }
+  d.tiles_y = d4_cdiv(d.H, th);
+  const int ntiles = d.N * d.tiles_x * d.tiles_y;
+  int g2 = grid_x > 0 ? grid_x : cap;
+  const int rounds = d4_cdiv(ntiles, g2);
+  g2 = d4_cdiv(ntiles, rounds);
+  // several output tiles: workgroup (x, ct) has linear id ct * g2 + x and lands on XCD id % 8 - with g2 a multiple of 8 the cout_tiles
+  // workgroups that read the same input tiles share an XCD, i.e. an L2 (PMC: 118 MB fetched per 256 -> 256 launch at 16 x 48 x 48 with
+  // g2 = 58, four times the input; profiles/r02_pmc_wide.md)
+  if (grid_x <= 0 && d.cout_tiles > 1 && g2 >= 8) g2 = ((g2 + 7) & ~7) <= cap ? ((g2 + 7) & ~7) : (g2 & ~7);
+  if (fmt == RUMPY_FMT_F16) hipLaunchKernelGGL(conv4d_kernel<RUMPY_FMT_F16>, dim3(g2, d.cout_tiles), dim3(256), 0, s, d);
+  else if (th == 6) hipLaunchKernelGGL((conv4d_kernel<RUMPY_FMT_BF16, 6>), dim3(g2, d.cout_tiles), dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(conv4d_kernel<RUMPY_FMT_BF16>, dim3(g2, d.cout_tiles), dim3(256), 0, s, d);
   return 0;
 }

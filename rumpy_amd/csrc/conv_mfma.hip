@@ -477,7 +477,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 int rumpy_conv3x3_strip_launch(const rumpy_conv_args* p, hipStream_t s);   // conv_strip.hip
 int rumpy_conv_up_launch(const rumpy_conv_args* p, hipStream_t s);          // conv_up.hip
 
-int rumpy_conv4d_launch(const ConvDev& d, int grid, hipStream_t s, int fmt);      // conv_dgrad4.hip
+int rumpy_conv4d_launch(ConvDev d, int grid_x, int cap, hipStream_t s, int fmt);      // conv_dgrad4.hip
 extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   if (!p || !p->x || !p->w || !p->out) { rumpy_set_error("rumpy_conv3x3: null pointer"); return RUMPY_E_ARG; }
   if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->cout_tiles <= 0) { rumpy_set_error("rumpy_conv3x3: bad shape"); return RUMPY_E_ARG; }
@@ -540,14 +540,7 @@ extern "C" int rumpy_conv3x3(const rumpy_conv_args* p, void* stream) {
   // and the body convs of the wide EDSR; RUMPY_CONV4_OLD=1 keeps the register-staged kernel below (A/B, tests)
   const bool plain = p->out_mode == 0 && !p->pool;
   if (plain && !old4 && p->cin_chunks == 4) {
-    int g2 = p->grid_x > 0 ? p->grid_x : (rumpy_device_cus() / p->cout_tiles > 0 ? rumpy_device_cus() / p->cout_tiles : 1);
-    const int rounds = cdiv(ntiles, g2);
-    g2 = cdiv(ntiles, rounds);
-    // several output tiles: workgroup (x, ct) has linear id ct * g2 + x and lands on XCD id % 8 - with g2 a multiple of 8 the cout_tiles
-    // workgroups that read the same input tiles share an XCD, i.e. an L2 (PMC: 118 MB fetched per 256 -> 256 launch at 16 x 48 x 48 with
-    // g2 = 58, four times the input; profiles/r02_pmc_wide.md)
-    if (p->grid_x <= 0 && p->cout_tiles > 1 && g2 >= 8) g2 = ((g2 + 7) & ~7) <= rumpy_device_cus() / p->cout_tiles ? ((g2 + 7) & ~7) : (g2 & ~7);
-    rumpy_conv4d_launch(d, g2, s, p->fmt);
+    rumpy_conv4d_launch(d, p->grid_x, rumpy_device_cus() / p->cout_tiles > 0 ? rumpy_device_cus() / p->cout_tiles : 1, s, p->fmt);
   } else if (p->fmt == RUMPY_FMT_F16) {      // evaluation plans of the wide nets
     if (p->cin_chunks == 4) hipLaunchKernelGGL((conv3x3_kernel<4, RUMPY_FMT_F16>), grid, dim3(256), 0, s, d);
     else if (p->cin_chunks == 3) hipLaunchKernelGGL((conv3x3_kernel<3, RUMPY_FMT_F16>), grid, dim3(256), 0, s, d);

@@ -207,20 +207,24 @@ def test_streaming_cin256_kernel_is_bitwise_the_register_staged_kernel(monkeypat
     gen = np.random.default_rng(41)
     w, b = _wb(gen, 256, 64)
     pc = PackedConv(w, b, 0, True)
-    for (N, H, W, gx) in ((2, 13, 17, 0), (3, 40, 50, 7), (1, 8, 16, 0), (2, 24, 33, 2), (1, 5, 3, 1), (2, 96, 96, 0)):
+    for (N, H, W, gx) in ((2, 13, 17, 0), (3, 40, 50, 7), (1, 8, 16, 0), (2, 24, 33, 2), (1, 5, 3, 1), (2, 96, 96, 0), (4, 48, 48, 0)):
         gy = nhwc(_rand(gen, N, 64, 2 * H, 2 * W))
         gp = nhwc(_rand(gen, N, 256, H, W))
         r1 = nhwc(_rand(gen, N, 64, H, W))
         outs = []
-        for env in ('RUMPY_CONV4_OLD', None):
+        for env in ('RUMPY_CONV4_OLD', 'RUMPY_CONV4_TH8', None):      # register-staged kernel | streaming, 8-row tiles forced | streaming, tile height chosen (6 here)
             monkeypatch.delenv('RUMPY_CONV4_OLD', raising=False)
+            monkeypatch.delenv('RUMPY_CONV4_TH8', raising=False)
             if env:
                 monkeypatch.setenv(env, '1')
             outs.append((hip_conv(gy, pc, N, H, W, dgrad=True, in_mode=1, grid_x=gx)[0],
                          hip_conv(gy, pc, N, H, W, dgrad=True, in_mode=1, scale=0.7, res1=r1, grid_x=gx)[0],
                          hip_conv(gp, pc, N, H, W, dgrad=True, in_mode=0, res1=r1, grid_x=gx)[0]))
+        monkeypatch.delenv('RUMPY_CONV4_TH8', raising=False)
         for k in range(3):
             assert torch.equal(outs[0][k].view(torch.int16), outs[1][k].view(torch.int16)), (N, H, W, gx, k)
+            assert torch.equal(outs[0][k].view(torch.int16), outs[2][k].view(torch.int16)), (N, H, W, gx, k, 'six-row tiles')
+        outs = [outs[0], outs[2]]
         x = torch.zeros(N, 64, H, W, requires_grad=True)
         F.pixel_shuffle(F.conv2d(x, bf16r(w), None, padding=1), 2).backward(nchw(gy).float())
         assert_bf16_close(nchw(outs[1][0]), x.grad, 'streaming dgrad upsampler')
