@@ -6,8 +6,8 @@
 // SIMD (round 2, removed) 96 us; a streaming K-split form with LDS-DMA rings and gates instead of barriers 97 us; this kernel 93-98 us.
 // Four structures, one time - because what they share is what costs: in-kernel cycle counters of this kernel (a round-2 probe build) say sweeping
 // 56 % (the MFMA loop itself runs at 84 % of the matrix pipe), ISSUING the DMA 26 % (213 cycles per global_load_lds: address arithmetic plus
-// the wait for a slot in a vector-memory queue that a bandwidth-bound gather keeps full - the gather alone, MFMAs compiled out, takes 60 us
-// = 3.5 TB/s of 128-byte pieces, whatever the prefetch depth), waiting for a stage 10 %, epilogue 8 %.  A wave that feeds the memory pipe
+// the wait for a slot in the vector-memory queue - the kernel with its MFMAs compiled out still takes 60 us, whatever the prefetch depth; the DMA
+// issue, waits and hand-over ALONE run the gather in 31 us = 4.9 TB/s, tests/tools/overlap/gather_probe.hip, round 4: it is issue time, not bandwidth), waiting for a stage 10 %, epilogue 8 %.  A wave that feeds the memory pipe
 // cannot feed the matrix pipe meanwhile, and every wave here must do both (the filter fills its registers: no spare wave).  Interleaving
 // the DMA issue with the MFMAs made it worse (110 us).  Kept because it is the simplest of the four and 0.5 % faster on the step.
 // Structure: ONE wave per SIMD (512 registers: the whole filter AND three fragment sets), but a wave that does not wait for itself:
