@@ -1,17 +1,19 @@
 # SQ / LDS counters of the block kernels (conv_block_kernel / rcab_kernel) INSIDE the training step: one rocprofv3 --pmc pass over a short bench run
-# usage (GPU box): bash tests/tools/pmc_step_sq.sh edsr|rcan
+# usage (GPU box): bash tests/tools/pmc_step_sq.sh edsr|rcan [fp8]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 M=${1:-edsr}
+PREC=${2:-bf16}
 rm -rf $R/gpurun_out/pmcq_${M}
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $R/gpurun_out/pmcq_${M} -o p --output-format csv -- python3 $R/bench.py --model $M --steps 3 --warmup 1 --probe-steps 1 --no-cpu-baseline --settle-ms 0 > /dev/null 2>&1
+# (the fp8 kernels are conv_block_fp8_kernel / rcab_fp8_kernel: matched by the same substrings below)
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $R/gpurun_out/pmcq_${M} -o p --output-format csv -- python3 $R/bench.py --model $M --precision $PREC --steps 3 --warmup 1 --probe-steps 1 --no-cpu-baseline --settle-ms 0 > /dev/null 2>&1
 cd $R
 python3 - <<PY
 import csv,glob,collections
 for f in glob.glob('gpurun_out/pmcq_${M}/*counter_collection.csv'):
     by=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'rcab_kernel' in r['Kernel_Name'] or 'conv_block_kernel' in r['Kernel_Name']:
+        if any(t in r['Kernel_Name'] for t in ('rcab_kernel', 'conv_block_kernel', 'rcab_fp8_kernel', 'conv_block_fp8_kernel')):
             by[(r['Kernel_Name'][:48], r['Counter_Name'])].append(float(r['Counter_Value']))
     for k,v in sorted(by.items()):
         v=v[len(v)//2:]
@@ -19,7 +21,7 @@ for f in glob.glob('gpurun_out/pmcq_${M}/*counter_collection.csv'):
 for f in glob.glob('gpurun_out/pmcq_${M}/*kernel_trace.csv'):
     by=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'rcab_kernel' in r['Kernel_Name'] or 'conv_block_kernel' in r['Kernel_Name']:
+        if any(t in r['Kernel_Name'] for t in ('rcab_kernel', 'conv_block_kernel', 'rcab_fp8_kernel', 'conv_block_fp8_kernel')):
             by[r['Kernel_Name'][:48]].append(float(r['End_Timestamp'])-float(r['Start_Timestamp']))
     for k,v in sorted(by.items()):
         v=v[len(v)//2:]
