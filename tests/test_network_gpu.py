@@ -811,7 +811,7 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     env = dict(os.environ, RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29571', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
-           '--no-cpu-baseline', '--settle-ms', '0']
+           '--no-cpu-baseline', '--settle-ms', '12']      # (the data-parallel settling phase: the same 10 steps on both ranks, no cold region)
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-3000:]
@@ -820,6 +820,8 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 64 and d['value'] > 0 and d['scaling'] == 'weak'
     assert d['roofline'] is not None and d['roofline']['launches_timed'] > 0
+    assert d['cold_start'] is None and d['clock_settle']['steps_before_warmup'] == 10
+    assert set(d['distributed']['forms']) == {'inline', 'early'}
 
 
 def test_bench_starts_its_own_ranks_when_called_plainly():
