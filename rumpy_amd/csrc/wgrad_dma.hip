@@ -12,6 +12,9 @@
 //     lane-linear - which makes every transposed read (8 consecutive pixels x 32 B per 32-lane half) conflict free.
 //   * out-of-image pixels are fetched from a zero page; the bias gradient is one extra MFMA against a ones fragment.
 #include "common.hpp"
+#ifndef WGRAD_PIPE
+#define WGRAD_PIPE 1    // 0: A/B - leave the order of fragment reads and MFMAs inside a tile to the compiler (rounds 1-3)
+#endif
 #ifndef WGRAD_STAGGER
 #define WGRAD_STAGGER 1 // 0: A/B - every wave issues its DMA pieces right behind the tile's barrier (rounds 1-2)
 #endif
@@ -186,36 +189,52 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
     if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
     const unsigned sb = lds0 + slot * DSTAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (WGRAD_STAGGER && ks == 1 && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
-      bf16x8 A[MT];
+    // 18 units (k-step ks, tap) of one B fragment (two transposed reads) and MT MFMAs.  Round 4: the fragment of unit u + 2 is requested BEFORE the
+    // MFMAs of unit u are issued (three fragments in rotation, the second k-step's A fragments in registers of their own from unit 5 on): left to
+    // itself the compiler put every tap's two reads right behind the previous tap's MFMAs and an lgkmcnt(0) behind them - a full LDS round trip
+    // per four MFMAs, hidden only as far as the sibling wave's MFMAs reach (WGRAD_PIPE=0 restores that order; same MFMA sequence either way)
+    auto load_a = [&](int ks, bf16x8 (&dst)[MT]) {
 #pragma unroll
       for (int ct = 0; ct < MT; ++ct) {
         if (MT == 4) {
           const unsigned pa = sb + offA[ct] + ks * (32 * 128);
-          A[ct] = join8b(tr_read2(pa), tr_read2(pa + 8 * 128));
+          dst[ct] = join8b(tr_read2(pa), tr_read2(pa + 8 * 128));
         } else {   // dy4: 8 B per pixel; lanes p4 > 0 read the zero piece (same address for both reads)
           const unsigned pa = sb + offA[ct] + ((p4 == 0) ? ks * (32 * 8) : 0);
-          A[ct] = join8b(tr_read2(pa), tr_read2(pa + ((p4 == 0) ? 8 * 8 : 0)));
+          dst[ct] = join8b(tr_read2(pa), tr_read2(pa + ((p4 == 0) ? 8 * 8 : 0)));
         }
       }
-      if (MT == 4) {                     // (wave-uniform branches: A[w4] without indexing the register file)
-        if (w4 == 0) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], ones, bacc, 0, 0, 0);
-        else if (w4 == 1) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[1 % MT], ones, bacc, 0, 0, 0);
-        else if (w4 == 2) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[2 % MT], ones, bacc, 0, 0, 0);
-        else bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[3 % MT], ones, bacc, 0, 0, 0);
-      } else if (w4 == 0) {
-        bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[0], ones, bacc, 0, 0, 0);
+    };
+    auto load_b = [&](int u) {
+      const int ks = u / 9, tap = u - 9 * ks;
+      const unsigned pb = sb + (ks ? (offB[tap] ^ 64u) + 36 * 128 : offB[tap]);
+      return join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
+    };
+    bf16x8 A[2][MT], Bq[3];
+    load_a(0, A[0]);
+    Bq[0] = load_b(0);
+    Bq[1] = load_b(1);
+#pragma unroll
+    for (int u = 0; u < 18; ++u) {
+      const int ks = u / 9, tap = u - 9 * ks;
+      if (u == 9 && WGRAD_STAGGER && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
+      if (u + 2 < 18) Bq[(u + 2) % 3] = load_b(u + 2);
+      if (u == 5) load_a(1, A[1]);
+      if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
+      if (tap == 0) {
+        if (MT == 4) {                     // (wave-uniform branches: A[w4] without indexing the register file)
+          if (w4 == 0) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][0], ones, bacc, 0, 0, 0);
+          else if (w4 == 1) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][1 % MT], ones, bacc, 0, 0, 0);
+          else if (w4 == 2) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][2 % MT], ones, bacc, 0, 0, 0);
+          else bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][3 % MT], ones, bacc, 0, 0, 0);
+        } else if (w4 == 0) {
+          bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][0], ones, bacc, 0, 0, 0);
+        }
       }
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const unsigned pb = sb + (ks ? (offB[tap] ^ 64u) + 36 * 128 : offB[tap]);
-        const bf16x8 B = join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
-#pragma unroll
-        for (int ct = 0; ct < MT; ++ct)
-          acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ct], B, acc[ct][tap], 0, 0, 0);
-      }
+      for (int ct = 0; ct < MT; ++ct)
+        acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][ct], Bq[u % 3], acc[ct][tap], 0, 0, 0);
+      if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
     }
     slot = (slot + 1 >= NST) ? 0 : slot + 1;
   }
