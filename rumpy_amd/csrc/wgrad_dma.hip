@@ -15,6 +15,9 @@
 #ifndef WGRAD_PIPE
 #define WGRAD_PIPE 1    // 0: A/B - leave the order of fragment reads and MFMAs inside a tile to the compiler (rounds 1-3)
 #endif
+#ifndef WGRAD_RD
+#define WGRAD_RD 4      // B fragments requested ahead of their MFMAs
+#endif
 #ifndef WGRAD_STAGGER
 #define WGRAD_STAGGER 1 // 0: A/B - every wave issues its DMA pieces right behind the tile's barrier (rounds 1-2)
 #endif
@@ -187,7 +190,6 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     // tile t + AHEAD are still its youngest at the top of step t + 1), and so is every accumulation order.
     const bool more = t + AHEAD < ntiles;
     const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
-    if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
     const unsigned sb = lds0 + slot * DSTAGE;
     // 18 units (k-step ks, tap) of one B fragment (two transposed reads) and MT MFMAs.  Round 4: the fragment of unit u + 2 is requested BEFORE the
     // MFMAs of unit u are issued (three fragments in rotation, the second k-step's A fragments in registers of their own from unit 5 on): left to
@@ -210,30 +212,31 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
       const unsigned pb = sb + (ks ? (offB[tap] ^ 64u) + 36 * 128 : offB[tap]);
       return join8b(tr_read2(pb), tr_read2(pb + 8 * 128));
     };
-    bf16x8 A[2][MT], Bq[3];
+    constexpr int RD = WGRAD_RD;
+    bf16x8 A[2][MT], Bq[RD + 1];
     load_a(0, A[0]);
-    Bq[0] = load_b(0);
-    Bq[1] = load_b(1);
+#pragma unroll
+    for (int u = 0; u < RD; ++u) Bq[u] = load_b(u);
+    // the kh = 0 waves' DMA pieces of tile t + AHEAD go out BEHIND the first fragment requests (their round trip runs under the DMA issue;
+    // WGRAD_DMA_FIRST=1: in front, as before), the kh = 1 waves' at unit 9
+    if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
+    if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
       const int ks = u / 9, tap = u - 9 * ks;
       if (u == 9 && WGRAD_STAGGER && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
-      if (u + 2 < 18) Bq[(u + 2) % 3] = load_b(u + 2);
+      if (u + RD < 18) Bq[(u + RD) % (RD + 1)] = load_b(u + RD);
       if (u == 5) load_a(1, A[1]);
       if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
-      if (tap == 0) {
-        if (MT == 4) {                     // (wave-uniform branches: A[w4] without indexing the register file)
-          if (w4 == 0) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][0], ones, bacc, 0, 0, 0);
-          else if (w4 == 1) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][1 % MT], ones, bacc, 0, 0, 0);
-          else if (w4 == 2) bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][2 % MT], ones, bacc, 0, 0, 0);
-          else bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][3 % MT], ones, bacc, 0, 0, 0);
-        } else if (w4 == 0) {
-          bacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][0], ones, bacc, 0, 0, 0);
-        }
+      if (tap == 0) {                      // bias: dy tile w4 (selects on a wave-uniform condition: a branch here costs a full lgkmcnt(0) in each arm)
+        bf16x8 Ab = A[ks][0];
+        if (MT == 4) Ab = (w4 == 0) ? A[ks][0] : (w4 == 1) ? A[ks][1 % MT] : (w4 == 2) ? A[ks][2 % MT] : A[ks][3 % MT];
+        const f32x4 b2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ab, ones, bacc, 0, 0, 0);
+        bacc = (MT == 4 || w4 == 0) ? b2 : bacc;
       }
 #pragma unroll
       for (int ct = 0; ct < MT; ++ct)
-        acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][ct], Bq[u % 3], acc[ct][tap], 0, 0, 0);
+        acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][ct], Bq[u % (RD + 1)], acc[ct][tap], 0, 0, 0);
       if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
     }
     slot = (slot + 1 >= NST) ? 0 : slot + 1;
