@@ -15,6 +15,9 @@
 #ifndef WGRAD_PIPE
 #define WGRAD_PIPE 1    // 0: A/B - leave the order of fragment reads and MFMAs inside a tile to the compiler (rounds 1-3)
 #endif
+#ifndef WGRAD_A1_SPREAD
+#define WGRAD_A1_SPREAD 1    // 0: A/B - the second k-step's A fragments requested in one go at unit 5 (+0.2-0.4 % spread out, same box)
+#endif
 #ifndef WGRAD_RD
 #define WGRAD_RD 4      // B fragments requested ahead of their MFMAs
 #endif
@@ -226,7 +229,15 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
       const int ks = u / 9, tap = u - 9 * ks;
       if (u == 9 && WGRAD_STAGGER && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
       if (u + RD < 18) Bq[(u + RD) % (RD + 1)] = load_b(u + RD);
+#if WGRAD_A1_SPREAD
+      if (u >= 2 && u < 2 + MT) {        // the second k-step's A fragments one dy tile per unit (with RD = 3: never more than 15 reads outstanding)
+        const int ct = u - 2;
+        if (MT == 4) { const unsigned pa = sb + offA[ct] + (32 * 128); A[1][ct] = join8b(tr_read2(pa), tr_read2(pa + 8 * 128)); }
+        else { const unsigned pa = sb + offA[ct] + ((p4 == 0) ? (32 * 8) : 0); A[1][ct] = join8b(tr_read2(pa), tr_read2(pa + ((p4 == 0) ? 8 * 8 : 0))); }
+      }
+#else
       if (u == 5) load_a(1, A[1]);
+#endif
       if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
       if (tap == 0) {                      // bias: dy tile w4 (selects on a wave-uniform condition: a branch here costs a full lgkmcnt(0) in each arm)
         bf16x8 Ab = A[ks][0];
