@@ -194,10 +194,13 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     const bool more = t + AHEAD < ntiles;
     const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
     const unsigned sb = lds0 + slot * DSTAGE;
-    // 18 units (k-step ks, tap) of one B fragment (two transposed reads) and MT MFMAs.  Round 4: the fragment of unit u + 2 is requested BEFORE the
-    // MFMAs of unit u are issued (three fragments in rotation, the second k-step's A fragments in registers of their own from unit 5 on): left to
-    // itself the compiler put every tap's two reads right behind the previous tap's MFMAs and an lgkmcnt(0) behind them - a full LDS round trip
-    // per four MFMAs, hidden only as far as the sibling wave's MFMAs reach (WGRAD_PIPE=0 restores that order; same MFMA sequence either way)
+    // 18 units (k-step ks, tap) of one B fragment (two transposed reads) and MT MFMAs.  Round 4: the fragment of unit u + RD is requested BEFORE the
+    // MFMAs of unit u are issued (RD + 1 fragments in rotation, the second k-step's A fragments in registers of their own, requested from unit 2
+    // on): left to itself the compiler put every tap's two reads right behind the previous tap's MFMAs and an lgkmcnt(0) behind them - a full LDS
+    // round trip per four MFMAs, hidden only as far as the sibling wave's MFMAs reach (WGRAD_PIPE=0 restores that order; same MFMA sequence
+    // either way).  261 -> 233 us in the EDSR step.  Measured around it (same box): 2 / 3 / 4 / 5 / 6 fragments ahead - 4 is where it stops paying;
+    // requests behind the unit's MFMAs instead of in front: -1 %; lgkmcnt counts 15 reads at most - with 16 outstanding (unit 5 when the four A
+    // fragments are requested in one go) the compiler falls back to a full wait
     auto load_a = [&](int ks, bf16x8 (&dst)[MT]) {
 #pragma unroll
       for (int ct = 0; ct < MT; ++ct) {
@@ -220,8 +223,8 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     load_a(0, A[0]);
 #pragma unroll
     for (int u = 0; u < RD; ++u) Bq[u] = load_b(u);
-    // the kh = 0 waves' DMA pieces of tile t + AHEAD go out BEHIND the first fragment requests (their round trip runs under the DMA issue;
-    // WGRAD_DMA_FIRST=1: in front, as before), the kh = 1 waves' at unit 9
+    // the kh = 0 waves' DMA pieces of tile t + AHEAD go out BEHIND the first fragment requests (their round trip runs under the DMA issue:
+    // measured neutral against "in front"), the kh = 1 waves' at unit 9
     if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
     if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
 #pragma unroll
@@ -230,7 +233,7 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
       if (u == 9 && WGRAD_STAGGER && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
       if (u + RD < 18) Bq[(u + RD) % (RD + 1)] = load_b(u + RD);
 #if WGRAD_A1_SPREAD
-      if (u >= 2 && u < 2 + MT) {        // the second k-step's A fragments one dy tile per unit (with RD = 3: never more than 15 reads outstanding)
+      if (u >= 2 && u < 2 + MT) {        // the second k-step's A fragments, one dy tile per unit
         const int ct = u - 2;
         if (MT == 4) { const unsigned pa = sb + offA[ct] + (32 * 128); A[1][ct] = join8b(tr_read2(pa), tr_read2(pa + 8 * 128)); }
         else { const unsigned pa = sb + offA[ct] + ((p4 == 0) ? (32 * 8) : 0); A[1][ct] = join8b(tr_read2(pa), tr_read2(pa + ((p4 == 0) ? 8 * 8 : 0))); }
@@ -239,7 +242,8 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
       if (u == 5) load_a(1, A[1]);
 #endif
       if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
-      if (tap == 0) {                      // bias: dy tile w4 (selects on a wave-uniform condition: a branch here costs a full lgkmcnt(0) in each arm)
+      if (tap == 0) {                      // bias: dy tile w4 (the compiler turns these wave-uniform selects into branches with an lgkmcnt(0) in each arm - twice
+                                           // per tile, at units that wait for (nearly) everything anyway; picking the operand with masks instead cost more than it saved)
         bf16x8 Ab = A[ks][0];
         if (MT == 4) Ab = (w4 == 0) ? A[ks][0] : (w4 == 1) ? A[ks][1 % MT] : (w4 == 2) ? A[ks][2 % MT] : A[ks][3 % MT];
         const f32x4 b2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ab, ones, bacc, 0, 0, 0);
