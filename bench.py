@@ -642,6 +642,8 @@ def main():
             roofline.update(common)
             # HBM bytes per launch from the PMC passes committed under profiles/ (not re-measured here; null when the kernel changed since)
             kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else 'rcab_kernel' if rcabs else 'conv_block_kernel'
+            if use_block and kname.startswith(('conv_block_fp8_kernel', 'rcab_fp8_kernel')):      # the fp8 kernels have PMC entries of their own
+                kind = 'rcab_fp8_kernel' if rcabs else 'conv_block_fp8_kernel'
             roofline['traffic'], roofline['traffic_source'] = pmc_traffic('%s:N%d:P%d' % (kind, N, P))
 
     # ---- informational: the step exactly as the reference's caller makes it (SISRInterface.train_batch, interface.py:97-101): batch on the HOST,

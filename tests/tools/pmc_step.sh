@@ -1,11 +1,13 @@
 # HBM traffic of the block kernels (conv_block_kernel / rcab_kernel) from PMC counters, measured INSIDE the training step: separate
 # rocprofv3 --pmc passes (MI355X_MICROARCH.md: one counter group per pass, --kernel-trace only) over a short bench run.
-# usage (GPU box): bash tests/tools/pmc_step.sh edsr|rcan
+# usage (GPU box): bash tests/tools/pmc_step.sh edsr|rcan [fp8]      (fp8: the conv_block_fp8_kernel / rcab_fp8_kernel entries)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 M=${1:-edsr}
+PREC=${2:-bf16}
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmcs_${M}_$c -o p --output-format csv -- python3 $R/bench.py --model $M --steps 3 --warmup 1 --probe-steps 1 --no-cpu-baseline --settle-ms 0 > /dev/null 2>&1
+  rm -rf $R/gpurun_out/pmcs_${M}_$c
+  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmcs_${M}_$c -o p --output-format csv -- python3 $R/bench.py --model $M --precision $PREC --steps 3 --warmup 1 --probe-steps 1 --no-cpu-baseline --settle-ms 0 > /dev/null 2>&1
 done
 cd $R
 python3 - <<PY
@@ -13,12 +15,13 @@ import csv, glob, collections, json, os, sys
 sys.path.insert(0, '$R')
 import bench
 M = '${M}'
+FP8 = '${PREC}' == 'fp8'
 means = collections.defaultdict(dict)
 for d in sorted(glob.glob('gpurun_out/pmcs_%s_*' % M)):
     for f in glob.glob(d + '/*counter_collection.csv'):
         by = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if 'rcab_kernel' in r['Kernel_Name'] or 'conv_block_kernel' in r['Kernel_Name']:
+            if any(t in r['Kernel_Name'] for t in (('rcab_fp8_kernel', 'conv_block_fp8_kernel') if FP8 else ('rcab_kernel', 'conv_block_kernel'))):
                 by[(r['Kernel_Name'][:64], r['Counter_Name'])].append(float(r['Counter_Value']))
         for k, v in sorted(by.items()):
             v = v[len(v) // 2:]
@@ -28,12 +31,16 @@ for d in sorted(glob.glob('gpurun_out/pmcs_%s_*' % M)):
 # launches the forward and the data-gradient form equally often)
 forms = {k: (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024 for k, c in means.items() if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c}
 if forms:
-    kind = 'rcab_kernel' if M != 'edsr' else 'conv_block_kernel'
-    srcs = ['rumpy_amd/csrc/block_common.hpp'] + (['rumpy_amd/csrc/rcab_common.hpp', 'rumpy_amd/csrc/conv_rcab.hip'] if kind == 'rcab_kernel' else ['rumpy_amd/csrc/conv_block.hip'])
+    kind = ('rcab_fp8_kernel' if FP8 else 'rcab_kernel') if M != 'edsr' else ('conv_block_fp8_kernel' if FP8 else 'conv_block_kernel')
+    srcs = ['rumpy_amd/csrc/block_common.hpp'] + (['rumpy_amd/csrc/fp8_common.hpp'] if FP8 else [])
+    if M != 'edsr':
+        srcs += ['rumpy_amd/csrc/rcab_common.hpp', 'rumpy_amd/csrc/conv_rcab_fp8.hip' if FP8 else 'rumpy_amd/csrc/conv_rcab.hip']
+    else:
+        srcs += ['rumpy_amd/csrc/conv_block_fp8.hip' if FP8 else 'rumpy_amd/csrc/conv_block.hip']
     entry = {'bytes_per_launch': sum(forms.values()) / len(forms), 'per_form_bytes': forms, 'sources': srcs, 'sha16': bench.source_sha16(srcs),
              'source': 'profiles/pmc_traffic.json <- tests/tools/pmc_step.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --model %s '
-                       '(32 x 48 x 48), 2 x FETCH_SIZE + WRITE_SIZE, mean over the forward and data-gradient launches' % (M, M)}
-    out = 'gpurun_out/pmc_traffic_%s.json' % M
+                       '(32 x 48 x 48)%s, 2 x FETCH_SIZE + WRITE_SIZE, mean over the forward and data-gradient launches' % (M, M, ' --precision fp8' if FP8 else '')}
+    out = 'gpurun_out/pmc_traffic_%s%s.json' % (M, '_fp8' if FP8 else '')
     json.dump({'%s:N32:P48' % kind: entry}, open(out, 'w'), indent=1)
     print('wrote', out, '(merge into profiles/pmc_traffic.json)')
 PY
