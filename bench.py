@@ -705,7 +705,7 @@ def main():
                's_per_step': round(best, 3), 'warmup_s': round(warm, 3)}
 
     if rank == 0:
-        line = {'metric': '%dpx LR patches/sec (train step) %s x4 bf16' % (P, args.model.upper()), 'value': round(value, 2), 'unit': 'LR patches/s',
+        line = {'metric': '%dpx LR patches/sec (train step) %s x4 %s' % (P, args.model.upper(), 'fp8 opt-in' if fp8 else 'bf16'), 'value': round(value, 2), 'unit': 'LR patches/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                 'dtype': 'fp8 (e4m3 forward / e5m2 gradient MFMA operands of the residual-block launches, fp32 accumulation; bf16 storage and bf16 MFMA elsewhere)' if fp8 else 'bf16',
