@@ -396,5 +396,7 @@ def test_fp8_step_under_the_data_parallel_path(model, early):
     e = json.loads([l for l in q.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
     assert d['config']['precision'] == 'fp8' and d['distributed']['backend'] == 'nccl'
     assert d['distributed']['allreduce_form'] == ('early' if early else 'inline')
-    assert d['roofline']['peak'] == 5000.0 and 'fp8' in d['roofline']['kernel']
+    assert d['roofline']['peak'] == 5000.0 and 'fp8' in d['roofline']['kernel'] and d['metric'].endswith('fp8 opt-in') and e['metric'].endswith('fp8 opt-in')
+    # the fp8 kernels' own PMC entry (profiles/pmc_traffic.json), not the bf16 kernels': null only if their sources changed since it was taken
+    assert d['roofline']['traffic'] is None or 'fp8' in d['roofline']['traffic_source']
     assert d['config']['loss'] == e['config']['loss'], (d['config']['loss'], e['config']['loss'])
