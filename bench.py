@@ -226,7 +226,7 @@ def bench_eval(args):
     eng.check_eval()
     plan = eng.plan_for(1, H, W, False, eng.eval_fmt)
     ops = [op for op, _ in plan.fwd]
-    blocks = [a for op, a in plan.fwd if op in ('rumpy_conv_block', 'rumpy_rcab_fwd')]
+    blocks = [a for op, a in plan.fwd if op in ('rumpy_conv_block', 'rumpy_rcab_fwd', 'rumpy_rcab2_fwd')]
     roofline = None
     if blocks:
         lib = L.lib()
@@ -244,7 +244,7 @@ def bench_eval(args):
             tflops, gbps = flop / avg_s / 1e12, alg_bytes / avg_s / 1e9
             roofline = {'bound': 'mfma', 'achieved': round(tflops, 2), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
-                        'kernel': ('rcab_kernel' if 'rumpy_rcab_fwd' in ops else 'conv_block_kernel') + ' forward form, fp16, column tiles (one residual block per launch)',
+                        'kernel': ('rcab2_kernel' if 'rumpy_rcab2_fwd' in ops else 'rcab_kernel' if 'rumpy_rcab_fwd' in ops else 'conv_block_kernel') + ' forward form, fp16, column tiles (one residual block per launch)',
                         'avg_launch_us': round(avg_s * 1e6, 3), 'launches_timed': n_launch, 'launches_per_image': len(blocks),
                         'algorithmic_gflop_per_launch': round(flop / 1e9, 3), 'algorithmic_mb_per_launch': round(alg_bytes / 1e6, 3),
                         'hbm': {'achieved': round(gbps, 1), 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': round(gbps / HBM_PEAK_GBPS, 4)}}
@@ -584,7 +584,8 @@ def main():
         plan = hipnet.engine.plan_for(N, P, P, True)
         ops = plan.fwd + plan.bwd
         blocks = [a for name, a in ops if name == 'rumpy_conv_block']
-        rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd')]      # share probe id 5 with the block kernel
+        rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd', 'rumpy_rcab2_fwd', 'rumpy_rcab2_bwd')]      # share probe id 5 with the block kernel
+        rcab2 = any(name == 'rumpy_rcab2_fwd' for name, _ in ops)
         use_block = len(blocks) + len(rcabs) > 0
         wide_convs = [a for name, a in ops if name == 'rumpy_conv3x3' and a.cin_chunks == 4] if getattr(hipnet.engine, 'wide', False) else []
         hipnet.use_graph = False          # the probe records events around eager launches (a graph replay has none)
@@ -609,12 +610,15 @@ def main():
                 flop = 2 * layer_flop                      # the halo-row recompute of the first conv is overhead, not counted
                 # (a mask that travels as bytes - maskbits - is 1/16 of a tensor and not counted)
                 tensors = [2 + sum(1 for f in ('t', 'res2') if getattr(a, f)) + (1 if (a.mask and not a.maskbits) else 0) for a in blocks] + \
-                          [2 + sum(1 for f in ('t', 't2', 't2_in', 'res2') if getattr(a, f)) + (1 if (a.mask and not a.maskbits) else 0) for a in rcabs]
+                          [2 + sum(1 for f in (('u_in', 'x_out', 't', 'res2') if rcab2 else ('t', 't2', 't2_in', 'res2')) if getattr(a, f)) +
+                           (1 if (not rcab2 and a.mask and not a.maskbits) else 0) for a in rcabs]
                 kname = 'conv_block_kernel (residual block: two 3x3 convs 64->64 per launch, fwd + data-gradient launches)'
                 if fp8 and blocks and all(a.w1_f8 for a in blocks):
                     kname = 'conv_block_fp8_kernel (residual block per launch, both sweeps on the block-scaled fp8 MFMA; fwd + data-gradient launches)'
                 if rcabs:
                     kname = 'rcab_kernel (residual channel-attention block per launch: two 3x3 convs 64->64 + attention gate; fwd + bwd launches)'
+                    if rcab2:
+                        kname = 'rcab2_kernel (residual channel-attention block per launch, gate applied by the consuming launch: two 3x3 convs 64->64; fwd + bwd launches)'
                     if fp8 and all(a.w1_f8 for a in rcabs):
                         kname = 'rcab_fp8_kernel (residual channel-attention block per launch, both sweeps on the block-scaled fp8 MFMA; fwd + bwd launches)'
             else:
@@ -641,7 +645,7 @@ def main():
                             'frac': round(tflops / mfma_peak, 4), 'traffic': None}
             roofline.update(common)
             # HBM bytes per launch from the PMC passes committed under profiles/ (not re-measured here; null when the kernel changed since)
-            kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else 'rcab_kernel' if rcabs else 'conv_block_kernel'
+            kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else ('rcab2_kernel' if rcab2 else 'rcab_kernel') if rcabs else 'conv_block_kernel'
             if use_block and kname.startswith(('conv_block_fp8_kernel', 'rcab_fp8_kernel')):      # the fp8 kernels have PMC entries of their own
                 kind = 'rcab_fp8_kernel' if rcabs else 'conv_block_fp8_kernel'
             roofline['traffic'], roofline['traffic_source'] = pmc_traffic('%s:N%d:P%d' % (kind, N, P))

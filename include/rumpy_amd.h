@@ -185,6 +185,34 @@ int64_t rumpy_rcab_xchg_bytes(int32_t N, int32_t H, int32_t W);
 int rumpy_rcab_strips(int32_t H, int32_t W);      /* workgroups per image = ceil(H/6) * column tiles: must be <= the device's CUs */
 int rumpy_rcab_epoch_advance(void* epoch, void* stream);
 
+/* ---- ABI 5: the same blocks per launch WITHOUT any exchange between workgroups (conv_rcab2.hip) - the attention gate is applied by the launch
+ * that CONSUMES a block's output, from partial sums the producing launch stored; no residency requirement, no epoch / status words, any image size.
+ *   rumpy_rcab2_fwd:  [u_in: x' = x + gate(part_in) * [qgate *] u_in, own rows -> x_out; mean / hidden / gate of THAT block: out]
+ *                     t = relu(conv1(x') + b1) (stored when t is set; + maskbits) ; u_out = conv2(t) + b2, UNGATED ;
+ *                     part_out[n][2 strip + row half][64] = its channel sums (rumpy_rcab2_partials(N, H, W) rows per image).
+ *                     The attention MLP arguments (ca_*, cr, qgate, mean, hidden, gate) describe the block that produced u_in.
+ *   rumpy_rcab2_bwd:  x = G = dL/d(block output) ; part_in = rows of sum_hw(G * U) of THIS block (written by the launch that produced G, or by
+ *                     rumpy_ca_bwd_reduce) -> dz [, dzq] ; x_out = dU = G * gate [* qgate] + dp / HW ; t = [mask bits] . conv2^T(dU) ;
+ *                     u_out = G + conv1^T(t) [+ res2] ; with u_in (the forward pass's U of the PREVIOUS block): part_out = rows of sum_hw(u_out * u_in).
+ *                     w1 / w2 = DATA-GRADIENT filter images of conv2 / conv1; the attention MLP arguments describe this block (hidden, gate: in).
+ * np_in > 64 (whole-image evaluation): the launch first folds the rows into one with a small kernel and needs part_scratch ([N][64] floats).
+ * x + gate * u of a chain's LAST block: rumpy_ca_fwd_fused on part_out. */
+typedef struct {
+  const void* x; const void* u_in; const float* part_in; float* part_out; float* part_scratch;
+  const void* w1; const float* b1; const void* w2; const float* b2;
+  void* x_out; void* t; void* u_out;
+  const void* res2;    /* backward only */
+  void* maskbits;      /* [N,H,W,8] bytes: written by the forward launch (training), read by the backward launch */
+  const float* ca_w1; const float* ca_b1; const float* ca_w2; const float* ca_b2;   /* conv_du.0 [cr,64],[cr] ; conv_du.2 [64,cr],[64] */
+  float* mean; float* hidden; float* gate;       /* [N,64], [N,cr], [N,64] */
+  const float* qgate; float* dz; float* dzq;     /* [N,64] each */
+  int32_t N, H, W, cr, np_in;
+  int32_t fmt;         /* RUMPY_FMT_*; F16: rumpy_rcab2_fwd only */
+} rumpy_rcab2_args;
+int rumpy_rcab2_fwd(const rumpy_rcab2_args* a, void* stream);
+int rumpy_rcab2_bwd(const rumpy_rcab2_args* a, void* stream);
+int rumpy_rcab2_partials(int32_t N, int32_t H, int32_t W);      /* rows of part_out per image */
+
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
  * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */
 typedef struct {

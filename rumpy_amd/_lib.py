@@ -58,6 +58,15 @@ class RcabArgs(_S):
                 ('w1_f8', c_void_p), ('w2_f8', c_void_p), ('f8_sw1', c_void_p), ('f8_sw2', c_void_p), ('f8_site', c_void_p), ('f8_entries', c_int32)]
 
 
+class Rcab2Args(_S):
+    _fields_ = [('x', c_void_p), ('u_in', c_void_p), ('part_in', c_void_p), ('part_out', c_void_p), ('part_scratch', c_void_p),
+                ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p),
+                ('x_out', c_void_p), ('t', c_void_p), ('u_out', c_void_p), ('res2', c_void_p), ('maskbits', c_void_p),
+                ('ca_w1', c_void_p), ('ca_b1', c_void_p), ('ca_w2', c_void_p), ('ca_b2', c_void_p),
+                ('mean', c_void_p), ('hidden', c_void_p), ('gate', c_void_p), ('qgate', c_void_p), ('dz', c_void_p), ('dzq', c_void_p),
+                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cr', c_int32), ('np_in', c_int32), ('fmt', c_int32)]
+
+
 class Op(_S):
     _fields_ = [('fn', c_void_p), ('args', c_void_p)]
 
@@ -297,6 +306,9 @@ SYMBOLS = {
     'rumpy_fp8_site_entries': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_fp8_convert': (C.c_int, [c_void_p, C.c_float, c_void_p, c_int32, c_int32, c_void_p]),
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
+    'rumpy_rcab2_fwd': (C.c_int, [_P(Rcab2Args), c_void_p]),
+    'rumpy_rcab2_bwd': (C.c_int, [_P(Rcab2Args), c_void_p]),
+    'rumpy_rcab2_partials': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_sgemm': (C.c_int, [_P(SgemmArgs), c_void_p]),
     'rumpy_sgemm_partial_floats': (c_int64, [c_int32, c_int32, c_int32]),
     'rumpy_l2norm_rows': (C.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),

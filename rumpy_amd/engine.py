@@ -137,6 +137,11 @@ class SREngine:
         self.batch_by_pointer = os.environ.get('RUMPY_BATCH_COPY') != '1'  # captured training step reads the caller's x / target through a pointer table; =1: A/B, copies into fixed buffers
         self.block_any_width = os.environ.get('RUMPY_BLOCK_W48') != '1'    # ... also for images wider than one strip (column tiles); =1: A/B, two launches per block there
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
+        # ... and which one-launch form (round 5): 'lazy' = conv_rcab2.hip, the gate applied by the launch that consumes a block's output - no exchange
+        # between workgroups, any image size; 'xchg' = conv_rcab.hip, pool sums exchanged inside the launch (A/B; precision 'fp8' runs this form)
+        self.rcab_form = os.environ.get('RUMPY_RCAB_FORM', 'lazy')
+        if self.rcab_form not in ('lazy', 'xchg'):
+            raise RuntimeError("rumpy_amd: RUMPY_RCAB_FORM is 'lazy' or 'xchg' (got %r)" % self.rcab_form)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
         # Evaluation plans store activations and filters as IEEE fp16 (same MFMA rate and bytes as bf16, 11 instead of 8 significant bits):
         # bf16 storage alone costs a >= 30 dB model 0.02-0.03 dB of Y-PSNR against the fp32 reference (fixtures G17 / G18).
@@ -258,11 +263,18 @@ class SREngine:
         n = getattr(plan, 'f8_' + which + '_n')
         if not n:
             return
-        if not getattr(plan, 'f8_' + which + '_cal'):
-            setattr(plan, 'f8_' + which + '_cal', True)
-            self._run(ops, stream)
-            self._advance_epoch(plan, stream)
         buf = getattr(plan, 'f8_' + which)
+        if not getattr(plan, 'f8_' + which + '_cal'):
+            # TWO measuring passes: with every exponent at 127 the first one converts at scale 1 - gradients that arrive mean-reduced
+            # (1e-7: the generic loss path) flush to zero in e5m2, the intermediate image of a block is then exactly 0 and its amax with it.  The
+            # skip connection carries the block's input through unconverted, so pass one leaves every site's INPUT amax right; with those exponents
+            # rotated in, pass two measures the intermediate images from values that were converted at their proper scale.
+            setattr(plan, 'f8_' + which + '_cal', True)
+            for rep in range(2):
+                self._run(ops, stream)
+                self._advance_epoch(plan, stream)
+                if rep == 0:
+                    L.check(self.lib.rumpy_fp8_rotate(buf.data_ptr(), n, buf.shape[1], stream), 'rumpy_fp8_rotate')
         L.check(self.lib.rumpy_fp8_rotate(buf.data_ptr(), n, buf.shape[1], stream), 'rumpy_fp8_rotate')
 
     # ------------------------------------------------------------------ packed filters
@@ -448,7 +460,25 @@ class SREngine:
             A backward node is a callable(g_out, extra) -> g_in for a residual unit, or
             ('group', conv, inner_out, sub_nodes) for a ResidualGroup."""
             nodes = []
+            pending = None        # conv_rcab2.hip chain: the last block's (x, ungated branch u, pool partial rows, its attention MLP) - x + gate * u not formed yet
+
+            def flush(pd):
+                """x + gate * u of a chain's last block (streaming launch; the MLP is evaluated per workgroup from the partial rows)"""
+                y = act()
+                fwd.append(('rumpy_ca_fwd_fused', L.CaFwdFusedArgs(
+                    pool=_ptr(pd['part']), w1=_ptr(pd['ca'].w1), b1=_ptr(pd['ca'].b1), w2=_ptr(pd['ca'].w2), b2=_ptr(pd['ca'].b2), mean=_ptr(pd['mean']),
+                    hidden=_ptr(pd['hid']), gate=_ptr(pd['gate']), t=_ptr(pd['u']), res=_ptr(pd['x']), out=_ptr(y), N=N, HW=H * W, C=F, Cr=pd['ca'].Cr,
+                    ntiles=pd['np'], inv_hw=1.0 / (H * W), qgate=_ptr(pd['qg']), fmt=fmt)))
+                release(pd['u'])
+                release(pd['x'])
+                return y
+
             for it in items:
+                lazy = (it[0] == 'rcab' and not getattr(it[3], 'gen', False) and self.rcab_form == 'lazy' and self.use_rcab_kernel and self.use_block_kernel
+                        and (W <= 48 or self.block_any_width) and not (train and (self.fp8 or not self.use_mask_bytes)))
+                if pending is not None and not lazy:
+                    cur = flush(pending)
+                    pending = None
                 if it[0] == 'resblock':
                     _, c1, c2, rs = it
                     # one launch per block (conv_block.hip; images wider than 48 pixels as column tiles since round 3): the activation
@@ -509,6 +539,69 @@ class SREngine:
                         plan.q_shape = (q.M, q.Hq)
                     if getattr(ca, 'gen', False):
                         cur = self._emit_styled_rcab(plan, fwd, bwd, wjobs, nodes, c1, c2, ca, cur, N, H, W, tiles, train, act, release)
+                        continue
+                    if lazy:
+                        # ---- one launch per block, no exchange inside it (conv_rcab2.hip): this launch stores the UNGATED branch u = conv2(t1) + b2 and its
+                        # pool partial rows; the NEXT launch (or flush() at the chain's end) evaluates the gate and forms x + gate * u on its way in ----
+                        np_out = int(lib.rumpy_rcab2_partials(N, H, W))
+                        t1 = act() if train else None
+                        u = act()
+                        part = self._new(plan, N, np_out, F, dtype=torch.float32)
+                        mean = self._new(plan, N, F, dtype=torch.float32)
+                        hid = self._new(plan, N, ca.Cr, dtype=torch.float32)
+                        gate = self._new(plan, N, F, dtype=torch.float32)
+                        mbr = self._new(plan, N, H, W, 8, dtype=torch.uint8) if train else None
+                        if not hasattr(plan, 'part_scratch'):
+                            plan.part_scratch = self._new(plan, N, F, dtype=torch.float32)
+                        common = dict(w1=_ptr(wf(c1)), b1=_ptr(c1.b_packed), w2=_ptr(wf(c2)), b2=_ptr(c2.b_packed), t=_ptr(t1), u_out=_ptr(u),
+                                      part_out=_ptr(part), part_scratch=_ptr(plan.part_scratch), maskbits=_ptr(mbr), N=N, H=H, W=W, fmt=fmt)
+                        if pending is None:
+                            x_k = cur
+                            fwd.append(('rumpy_rcab2_fwd', L.Rcab2Args(x=_ptr(cur), u_in=None, part_in=None, np_in=0, x_out=None, cr=ca.Cr, **common)))
+                        else:
+                            pd = pending
+                            x_k = act()
+                            fwd.append(('rumpy_rcab2_fwd', L.Rcab2Args(
+                                x=_ptr(pd['x']), u_in=_ptr(pd['u']), part_in=_ptr(pd['part']), np_in=pd['np'], x_out=_ptr(x_k), cr=pd['ca'].Cr,
+                                ca_w1=_ptr(pd['ca'].w1), ca_b1=_ptr(pd['ca'].b1), ca_w2=_ptr(pd['ca'].w2), ca_b2=_ptr(pd['ca'].b2),
+                                mean=_ptr(pd['mean']), hidden=_ptr(pd['hid']), gate=_ptr(pd['gate']), qgate=_ptr(pd['qg']), **common)))
+                            release(pd['u'])
+                            release(pd['x'])
+                        me = dict(x=x_k, u=u, part=part, np=np_out, ca=ca, qg=qg, mean=mean, hid=hid, gate=gate, link={})
+
+                        def node(g_out, extra, me=me, prev=pending, t1=t1, c1=c1, c2=c2, ca=ca, qdz=qdz, mbr=mbr, np_out=np_out):
+                            # G = g_out = dL/d(x + gate * u).  sum_hw(G * u) comes as partial rows from the launch that produced G (the next block's
+                            # backward launch, which ran before this node) or, at the chain's end, from rumpy_ca_bwd_reduce
+                            dz = self._new(plan, N, F, dtype=torch.float32)
+                            dt2, dt1, dx = (self._new(plan, N, H, W, F) for _ in range(3))
+                            lp = me['link'].get('part')
+                            if lp is None:
+                                nchunks = (H * W + 127) // 128
+                                pb = self._new(plan, N, nchunks, F, dtype=torch.float32)
+                                bwd.append(('rumpy_ca_bwd_reduce', L.CaBwdReduceArgs(dy=_ptr(g_out), t=_ptr(me['u']), partial=_ptr(pb), N=N, HW=H * W, C=F)))
+                                lp = (pb, nchunks)
+                            u_prev = part_out = None
+                            if prev is not None:
+                                u_prev = prev['u']
+                                part_out = self._new(plan, N, np_out, F, dtype=torch.float32)
+                                prev['link']['part'] = (part_out, np_out)
+                            bwd.append(('rumpy_rcab2_bwd', L.Rcab2Args(
+                                x=_ptr(g_out), u_in=_ptr(u_prev), part_in=_ptr(lp[0]), np_in=lp[1], part_out=_ptr(part_out), part_scratch=_ptr(plan.part_scratch),
+                                w1=_ptr(c2.w_dgrad), b1=None, w2=_ptr(c1.w_dgrad), b2=None, x_out=_ptr(dt2), t=_ptr(dt1), u_out=_ptr(dx), res2=_ptr(extra),
+                                maskbits=_ptr(mbr), ca_w1=_ptr(ca.w1), ca_b1=_ptr(ca.b1), ca_w2=_ptr(ca.w2), ca_b2=_ptr(ca.b2), mean=None,
+                                hidden=_ptr(me['hid']), gate=_ptr(me['gate']), qgate=_ptr(me['qg']), dz=_ptr(dz), dzq=_ptr(qdz), N=N, H=H, W=W, cr=ca.Cr, fmt=0)))
+                            plan.ca_param_items.append(L.CaMlpBwdArgs(
+                                partial=_ptr(dz), mean=_ptr(me['mean']), hidden=_ptr(me['hid']), gate=_ptr(me['gate']), w1=_ptr(ca.w1), w2=_ptr(ca.w2),
+                                dpool=_ptr(dz), gw1=_ptr(ca.gw1), gb1=_ptr(ca.gb1), gw2=_ptr(ca.gw2), gb2=_ptr(ca.gb2), N=N, C=F, Cr=ca.Cr,
+                                nchunks=1, inv_hw=1.0 / (H * W), scale=1.0))
+                            wjobs.append((c2, t1, dt2, H, W, 0, 1.0, 4))
+                            wjobs.append((c1, me['x'], dt1, H, W, 0, 1.0, 4))
+                            return dx
+                        nodes.append(node)
+                        if t1 is not None:
+                            release(t1)
+                        pending = me
+                        cur = None
                         continue
                     t1, t2, y = act(), act(), act()
                     fused = self.use_block_kernel and (W <= 48 or self.block_any_width)
@@ -612,9 +705,16 @@ class SREngine:
                         release(inner)
                     release(x_in)
                     cur = y
+            if pending is not None:
+                cur = flush(pending)
             return cur, nodes
 
         last, tree = emit_items(spec.body, a0)
+        if train and self.fp8 and plan.f8_f_n == 0:
+            #  the fp8 kernels are the W <= 48, mask-byte, one-launch forms: a plan that has none of them trains in bf16 - say so
+            import warnings
+            warnings.warn("rumpy_amd: precision='fp8' has no fp8 launch for %d x %d x %d training batches (the fp8 residual-block kernels are built for "
+                          "patches up to 48 pixels wide, mask bytes on, one-launch forms on); this plan trains in bf16" % (N, H, W))
         r = act()
         self._conv(fwd, last, spec.body_conv, N, H, W, r, res1=a0, fmt=fmt)
         # ---- upsampler ----

@@ -337,6 +337,131 @@ def test_blind_qrcan_fp8_step_runs_next_to_the_bf16_step():
     assert gen.engine.fp8 and plan.f8_f_n == 6 and plan.f8_b_n == 6 and gen.engine.exchange_status() == 0
 
 
+# ---- BASELINE config 5 AS NAMED: contrastive degradation encoder + QRCAN 10 x 20 with q-layers, precision='fp8', against the
+# fp32 ORACLE (not against the bf16 handler) in the tolerance class of this precision.  Reference: rumpy/SISR/models/blur_kernel_blind_sr/
+# handlers.py:454-609 (run_train, joint losses), contrastive_blind_sr.py:241-329 (pipeline forward).
+BLIND_FULL = dict(scale=4, n_feats=64, n_resgroups=10, n_resblocks=20, reduction=16, style='standard', include_q_layer=True,
+                  selective_meta_blocks=[True] + [False] * 9, num_q_layers_inner_residual=1)
+
+
+def _fp8_class_check(named_h, named_o, tag, q_bound=1e-1):
+    """whole gradient <= 5e-2, cosine >= 0.998, every 3x3 tensor <= 1.5e-1, q-layer tensors <= the bf16 joint test's bound (1e-1, cosine 0.99)"""
+    num = den = dot = gg = 0.0
+    worst3, worstq = (0.0, None), (0.0, None)
+    for (k, p), (k2, q) in zip(named_h, named_o):
+        assert k == k2
+        g, r = p.grad.detach().float().cpu().double().reshape(-1), q.grad.double().reshape(-1)
+        assert torch.isfinite(g).all(), k
+        num += float((g - r).pow(2).sum()); den += float(r.pow(2).sum()); dot += float(g @ r); gg += float(g.pow(2).sum())
+        if float(r.norm()) == 0.0:
+            continue
+        rel = float((g - r).norm() / r.norm())
+        if p.dim() == 4 and p.shape[-1] == 3 and rel > worst3[0]:
+            worst3 = (rel, k)
+        if 'q_node' in k:
+            cos = float((g @ r) / (g.norm() * r.norm() + 1e-30))
+            assert cos > 0.99, (k, cos)
+            if rel > worstq[0]:
+                worstq = (rel, k)
+    whole, cos = (num / den) ** 0.5, dot / (gg * den) ** 0.5
+    print('%s: whole-gradient rel %.3e, cosine %.5f, worst 3x3 tensor %.3e (%s), worst q-layer tensor %.3e (%s)'
+          % (tag, whole, cos, worst3[0], worst3[1], worstq[0], worstq[1]))
+    assert whole <= 5e-2 and cos >= 0.998 and worst3[0] <= 1.5e-1 and worstq[0] <= q_bound, (whole, cos, worst3, worstq)
+
+
+def test_config5_blind_qrcan_full_depth_fp8_step_against_the_fp32_oracle():
+    """frozen encoder (block_encoder_loading: seeded weights) + QRCAN 10 x 20, q-layer in group 0 block 0 as in the reference's test config,
+    one run_train step at N = 2, 48 x 48: every RCAB launch on the fp8 MFMA, gradients of the generator against OracleHandler"""
+    h = _handler('contrastiveblindqrcan', precision='fp8', metadata_list=None, block_encoder_loading=True, lr=1e-4, **BLIND_FULL)
+    onet = O.build_oracle('contrastiveblindqrcan', **BLIND_FULL)
+    assert list(onet.state_dict().keys()) == list(h.net.state_dict().keys())
+    sd = O.seeded_pipeline_state(onet, 4105)
+    onet.load_state_dict(sd)
+    h.net.load_state_dict(sd)
+    oh = O.OracleHandler(onet, lr=1e-4)
+    x, y = O.synthetic_batch(4106, 2, lr_hw=48, scale=4)
+    loss, out = h.run_train(x=x, y=y)
+    oloss, oout = oh.run_train(x, y)
+    gen = h.net.hip_generator
+    plan = gen.engine.plan_for(2, 48, 48, True)
+    assert gen.engine.fp8 and plan.f8_f_n == 200 and plan.f8_b_n == 200 and gen.engine.exchange_status() == 0
+    assert all(a.w1_f8 for n_, a in plan.fwd + plan.bwd if n_ in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd'))
+    assert abs(float(loss) - float(oloss)) < 5e-3 * float(oloss), (float(loss), float(oloss))
+    assert all(p.grad is None for p in h.net.E.parameters())
+    _fp8_class_check(h.net.G.named_parameters(), oh.net.G.named_parameters(), 'config 5, frozen encoder, fp8')
+
+
+@pytest.mark.parametrize('mode,crops,freeze', [('supmoco', 3, 'pre_q'), ('moco', 2, 'none')])
+def test_config5_blind_qrcan_full_depth_fp8_joint_losses_against_the_fp32_oracle(mode, crops, freeze):
+    """the same generator under the joint SR + contrastive losses with the encoder TRAINING (handlers.py:513-586): 'supmoco' with the mlp heads
+    trainable (the form G21 pins), 'moco' with the whole query encoder trainable - the gradient reaches the generator through the generic
+    loss path (mean-reduced, 1e-7: the case the two-pass scale measurement exists for) and the encoder through d loss / d metadata."""
+    from oracle import contrastive_oracle as CO
+    from tests.test_oracle_golden import G21_KEYS, G21_META, _g20_seed, g21_supmoco_pretrained_state
+    extra, labels = dict(block_encoder_loading=True), None
+    if mode == 'supmoco':
+        sd, labels, total = g21_supmoco_pretrained_state()
+        ckpt = os.path.join(tempfile.mkdtemp(), 'enc_0')
+        torch.save({'network': sd, 'model_name': 'supmoco', 'model_epoch': 0}, ckpt)
+        extra = dict(pre_trained_encoder_weights=ckpt, data_type='noise', labelling_strategy='double_precision')
+    h = _handler('contrastiveblindqrcan', precision='fp8', metadata_list=None, lr=1e-4, combined_loss_mode=mode, crop_count=crops,
+                 encoder_train_eval='train', encoder_freeze_mode=freeze, **extra, **BLIND_FULL)
+    oh = CO.OracleJointHandler(O.build_oracle('qrcan', num_metadata=256, **BLIND_FULL), mode, crops, freeze, lr=1e-4)
+    gsd = O.seeded_state_dict(oh.net.G, 4200)
+    oh.net.G.load_state_dict(gsd)
+    h.net.G.load_state_dict(gsd)
+    if mode == 'moco':
+        _g20_seed(oh.net.E, 4210)
+        h.net.E.load_state_dict(oh.net.E.state_dict())
+    else:
+        oh.net.E.register_classes(total)
+        oh.net.E.load_state_dict(sd)
+    kw = dict(metadata=torch.from_numpy(G21_META), metadata_keys=[(k,) for k in G21_KEYS]) if mode == 'supmoco' else {}
+    x = CO.contrastive_batch(4220, 4, crops, hw=48)
+    rng = np.random.default_rng(4227)
+    y = torch.nn.functional.interpolate(x.view(-1, 3, 48, 48), scale_factor=4, mode='bilinear', align_corners=False).view(4, crops, 3, 192, 192)
+    y = (y + torch.from_numpy(rng.uniform(-0.05, 0.05, tuple(y.shape)).astype(np.float32))).clamp(0, 1)
+    opkg, ologits = oh.run_train(x, y, labels)
+    pkg, logits = h.run_train(x=x, y=y, **kw)
+    gen = h.net.hip_generator
+    plan = gen.engine.plan_for(4, 48, 48, True)
+    assert gen.engine.fp8 and plan.f8_f_n == 200 and plan.f8_b_n == 200 and gen.engine.exchange_status() == 0
+    for k in pkg:
+        assert abs(float(pkg[k]) - float(opkg[k])) <= 2e-2 * max(1.0, float(opkg[k])), (k, float(pkg[k]), float(opkg[k]))
+    _fp8_class_check(h.net.G.named_parameters(), oh.net.G.named_parameters(), 'config 5, joint %s / %s, fp8' % (mode, freeze))
+    # the encoder's own gradients: bounds of the bf16 joint test (tests/test_blind_gpu.py) - the fp8 launches enter them only through d metadata
+    for (k, p), (_, po) in zip(h.net.E.named_parameters(), oh.net.E.named_parameters()):
+        if po.requires_grad and 'mlp' in k:
+            r = float((p.grad.cpu().double() - po.grad.double()).norm() / (po.grad.double().norm() + 1e-30))
+            assert r < 5e-2, (k, r)
+        elif po.requires_grad:
+            if k.split('.', 1)[1] in ('E.0.bias', 'E.3.bias', 'E.6.bias', 'E.9.bias', 'E.12.bias', 'E.15.bias'):
+                continue
+            r = float((p.grad.cpu().double() - po.grad.double()).norm() / (po.grad.double().norm() + 1e-30))
+            assert r < 6e-2, (k, r)
+        else:
+            assert p.grad is None, k
+
+
+def test_fp8_scales_are_measured_right_for_mean_reduced_gradients():
+    """ an upstream gradient of 2^-23 per element (the generic loss path hands over 1 / numel) must give 2^-23 x the weight
+    gradients of the same pass with a unit upstream gradient: every scale is a power of two, so the arithmetic is scale-invariant unless a
+    conversion flushed - which the single measuring pass at scale 1 did to the intermediate image of every block on a plan's first pass."""
+    grads = []
+    for scale in (1.0, 2.0 ** -23):
+        h, _ = _pair('edsr', 31, scale=2, num_blocks=3, res_scale=0.1)
+        x, y = O.synthetic_batch(32, 2, lr_hw=24, scale=2)
+        out, _, plan = h.net.engine_forward(x.to(DEV), train=True)
+        g = torch.sign(out - y.to(DEV)).contiguous() * scale
+        h.net.engine.backward(plan, 1.0, gout=g)
+        h.net.attach_grads()
+        torch.cuda.synchronize()
+        grads.append(torch.cat([p.grad.detach().float().reshape(-1) for p in h.net.parameters()]).cpu().double() / scale)
+    rel = float((grads[0] - grads[1]).norm() / grads[0].norm())
+    print('fp8 first-pass gradients, unit vs 2^-23 upstream gradient: rel %.3e' % rel)
+    assert rel < 1e-3, rel
+
+
 @pytest.mark.parametrize('name,kw', [('edsr', dict(scale=2, num_blocks=4, res_scale=0.1)), ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=3, reduction=16))])
 def test_fp8_training_trajectory_stays_within_one_percent_of_the_oracle(name, kw):
     """the learnable task of tests/test_network_gpu.py::test_training_trajectory_follows_the_oracle_on_a_learnable_task (HR = smooth images,

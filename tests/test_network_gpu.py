@@ -15,6 +15,15 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# the one-launch RCAB forms (engine.rcab_form / RUMPY_RCAB_FORM): 'lazy' = conv_rcab2.hip (round 5, the default: the gate is applied by the launch
+# that consumes a block's output), 'xchg' = conv_rcab.hip (pool sums exchanged between the strips of an image inside the launch)
+RCAB_OPS = {'lazy': ('rumpy_rcab2_fwd', 'rumpy_rcab2_bwd'), 'xchg': ('rumpy_rcab_fwd', 'rumpy_rcab_bwd')}
+
+
+def rcab_ops():
+    return RCAB_OPS[os.environ.get('RUMPY_RCAB_FORM', 'lazy')]
+
+
 from oracle import sr_oracle as O
 from rumpy_amd.shared_framework.models.base_architecture import BaseModel
 from rumpy_amd.shared_framework.models import define_model
@@ -177,7 +186,7 @@ def test_rcan_full_depth_gradient_parity_at_the_shipped_crop_size():
     h = _handler('rcan', scale=4)
     h.net._ensure_engine()
     plan = h.net.engine.plan_for(1, 64, 64, True)
-    assert sum(1 for op, _ in plan.fwd if op == 'rumpy_rcab_fwd') == 200 and sum(1 for op, _ in plan.bwd if op == 'rumpy_rcab_bwd') == 200
+    assert sum(1 for op, _ in plan.fwd if op == rcab_ops()[0]) == 200 and sum(1 for op, _ in plan.bwd if op == rcab_ops()[1]) == 200
     _full_depth_step('rcan', 524, 1, {}, 3e-2, 0.999, lr_hw=64)
 
 
@@ -413,7 +422,7 @@ def test_wide_image_eval_and_training_against_oracle_and_against_the_two_launch_
         x, y = O.synthetic_batch(632, 2, lr_hw=(64, 80), scale=2)
         loss, tout = h.run_train(x=x, y=y)
         eng = h.net.engine
-        fused_op = {'edsr': 'rumpy_conv_block', 'rcan': 'rumpy_rcab_fwd'}[name]
+        fused_op = {'edsr': 'rumpy_conv_block', 'rcan': rcab_ops()[0]}[name]
         assert (fused_op in {op for op, _ in eng.plan_for(1, 150, 211, False, eng.eval_fmt).fwd}) == (w48 == '0')
         assert (fused_op in {op for op, _ in eng.plan_for(2, 64, 80, True).fwd}) == (w48 == '0')
         assert eng.exchange_status() == 0
@@ -643,7 +652,7 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
         loss, out = h.run_train(x=x, y=y)
         assert h.net.engine.use_block_kernel == (no_block == '0')
         names = {op for op, _ in h.net.engine.plan_for(2, 20, 20, True).fwd}
-        assert (({'edsr': 'rumpy_conv_block', 'rcan': 'rumpy_rcab_fwd'}[name]) in names) == (no_block == '0')
+        assert (({'edsr': 'rumpy_conv_block', 'rcan': rcab_ops()[0]}[name]) in names) == (no_block == '0')
         res.append((float(loss), out, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}))
     assert abs(res[0][0] - res[1][0]) < 1e-4 * abs(res[1][0])
     assert self_psnr(res[0][1], res[1][1]) > 60.0
@@ -665,10 +674,13 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
     ('rcan', dict(scale=2, n_resgroups=2, n_resblocks=1, reduction=16), (20, 100)),       # 3 column tiles of 48 (ragged last one), 12 strips per image
     ('qrcan', dict(scale=2, n_resgroups=1, n_resblocks=1, reduction=16, style='standard', include_q_layer=True, metadata=['a', 'b', 'c']), (13, 130)),   # 3 tiles of 48
 ])
-def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, monkeypatch):
-    """conv_rcab.hip (RCAB forward / backward in ONE launch, pool sums exchanged between the strips of an image) against the
-    conv_block + ca_fwd_fused / ca_bwd_reduce + ca_bwd_fused + conv_block launches (RUMPY_NO_RCAB=1).  Same operands; the fused
-    kernel applies the gate to the fp32 accumulators instead of the bf16-stored conv output, so outputs agree to bf16 rounding."""
+@pytest.mark.parametrize('form', ['lazy', 'xchg'])
+def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, form, monkeypatch):
+    """the one-launch RCAB forms - conv_rcab2.hip ('lazy': the gate applied by the consuming launch, partial sums through HBM, no exchange inside
+    a launch) and conv_rcab.hip ('xchg': pool sums exchanged between the strips of an image) - against the conv_block + ca_fwd_fused /
+    ca_bwd_reduce + ca_bwd_fused + conv_block launches (RUMPY_NO_RCAB=1).  Same operands; 'xchg' applies the gate to the fp32 accumulators
+    instead of the stored conv output, 'lazy' sums the partial rows in another order: outputs agree to bf16 rounding."""
+    monkeypatch.setenv('RUMPY_RCAB_FORM', form)
     sc = kw['scale']
     x, y = O.synthetic_batch(660, 3, lr_hw=hw, scale=sc)
     meta = torch.rand(3, 3, 1, 1, generator=torch.Generator().manual_seed(4)) if name == 'qrcan' else None
@@ -684,8 +696,10 @@ def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, m
         H, W = (hw, hw) if isinstance(hw, int) else hw
         plan = h.net.engine.plan_for(3, H, W, True)
         fnames, bnames = [op for op, _ in plan.fwd], [op for op, _ in plan.bwd]
-        assert ('rumpy_rcab_fwd' in fnames) == (no_rcab == '0') and ('rumpy_rcab_bwd' in bnames) == (no_rcab == '0')
-        assert ('rumpy_ca_fwd_fused' in fnames) == (no_rcab == '1') and ('rumpy_ca_bwd_reduce' in bnames) == (no_rcab == '1')
+        assert (rcab_ops()[0] in fnames) == (no_rcab == '0') and (rcab_ops()[1] in bnames) == (no_rcab == '0')
+        chains = kw['n_resgroups']      # 'lazy': one streaming x + gate * u / one sum(G * u) launch per chain of blocks (= per group), not per block
+        assert fnames.count('rumpy_ca_fwd_fused') == (chains if (no_rcab == '0' and form == 'lazy') else 0 if no_rcab == '0' else chains * kw['n_resblocks'])
+        assert bnames.count('rumpy_ca_bwd_reduce') == (chains if (no_rcab == '0' and form == 'lazy') else 0 if no_rcab == '0' else chains * kw['n_resblocks'])
         grads = {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}
         assert h.net.engine.exchange_status() == 0
         res.append((float(loss), out, grads, ev, float(evl)))
@@ -701,11 +715,13 @@ def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, m
 
 
 @pytest.mark.parametrize('geo', ['4,2', '6,2', '8,2', '6,3'])
-def test_one_launch_rcab_strip_heights_agree(geo, monkeypatch):
+@pytest.mark.parametrize('form', ['lazy', 'xchg'])
+def test_one_launch_rcab_strip_heights_agree(geo, form, monkeypatch):
     """round 4: the one-launch RCAB kernels on strips of 4 / 6 / 8 rows (rcab_geometry picks the height whose workgroup count fits the CUs;
     RUMPY_BLOCK_GEO forces one).  The convolutions are bitwise those of every other geometry (test_conv_block_strip_heights_agree_bitwise);
     the pool sums are added in strip order, so the gates - and everything behind them - agree to fp32 rounding, not bit for bit: checked
     against the separate attention launches like the other geometries."""
+    monkeypatch.setenv('RUMPY_RCAB_FORM', form)
     kw = dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16)
     x, y = O.synthetic_batch(661, 3, lr_hw=(33, 70), scale=2)
     res = []
@@ -720,7 +736,7 @@ def test_one_launch_rcab_strip_heights_agree(geo, monkeypatch):
         ev, evl, _ = h.run_eval(x=x, y=y, request_loss=True)
         loss, out = h.run_train(x=x, y=y)
         plan = h.net.engine.plan_for(3, 33, 70, True)
-        assert ('rumpy_rcab_fwd' in [op for op, _ in plan.fwd]) == (no_rcab == '0')
+        assert (rcab_ops()[0] in [op for op, _ in plan.fwd]) == (no_rcab == '0')
         assert h.net.engine.exchange_status() == 0
         res.append((float(loss), out, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}, ev, float(evl)))
     assert abs(res[0][0] - res[1][0]) < 2e-4 * abs(res[1][0]) and abs(res[0][4] - res[1][4]) < 2e-4 * abs(res[1][4])
@@ -730,11 +746,13 @@ def test_one_launch_rcab_strip_heights_agree(geo, monkeypatch):
         assert float((a - b).norm()) <= 2e-2 * float(b.norm()), k
 
 
-def test_one_launch_rcab_is_deterministic_at_the_headline_shape():
+@pytest.mark.parametrize('form', ['lazy', 'xchg'])
+def test_one_launch_rcab_is_deterministic_at_the_headline_shape(form, monkeypatch):
     """32 x 48 x 48: 256 strips, one per CU, every image's 8 strips exchange sums.  (a) 16 repeated forward + backward passes on frozen
     weights give bit-identical outputs AND gradient buffers (this is the check that caught compiler-formed packed-fp32 adds dropping an
     addend in a few workgroups per launch - csrc/Makefile); (b) two handlers trained from the same state follow bit-identical
     trajectories."""
+    monkeypatch.setenv('RUMPY_RCAB_FORM', form)
     kw = dict(scale=4, n_resgroups=2, n_resblocks=3, reduction=16)
     x, y = O.synthetic_batch(670, 32, lr_hw=48, scale=4)
     h = _handler('rcan', lr=1e-3, **kw)
@@ -995,13 +1013,15 @@ def test_bench_line_separates_the_cold_start_from_the_settled_clock():
     assert e['cold_start'] is None and e['clock_settle'] is None and e['value'] > 0
 
 
-def test_rcab_launches_next_to_a_foreign_kernel_that_holds_cus():
+@pytest.mark.parametrize('form', ['lazy', 'xchg'])
+def test_rcab_launches_next_to_a_foreign_kernel_that_holds_cus(form, monkeypatch):
     """the one-launch RCAB kernels spin on their sibling strips - can they wedge behind a collective that occupies CUs on
     the side stream?  A stand-in (rumpy_debug_occupy: 48 workgroups x 80 KiB LDS, i.e. 24-48 CUs unavailable to the 115-KiB RCAB workgroups,
     for 30 ms at a time) runs on a side stream for the WHOLE of three RCAN training steps at the headline strip count (256 workgroups per
     launch).  Strips are dispatched in order and the foreign kernel waits for nobody, so the oldest unfinished image always completes:
     no exchange may time out and every number must equal the undisturbed run's, bit for bit."""
     from rumpy_amd import _lib as L
+    monkeypatch.setenv('RUMPY_RCAB_FORM', form)      # ('lazy': no launch waits for another workgroup - nothing to wedge; the numbers must still not move)
     kw = dict(scale=2, n_resgroups=2, n_resblocks=3, reduction=16)
     x, y = O.synthetic_batch(671, 32, lr_hw=48, scale=2)
     res = []
@@ -1022,10 +1042,12 @@ def test_rcab_launches_next_to_a_foreign_kernel_that_holds_cus():
 
 
 @pytest.mark.parametrize('N', [67, 160])
-def test_one_launch_rcab_with_more_strips_than_cus(N, monkeypatch):
+@pytest.mark.parametrize('form', ['lazy', 'xchg'])
+def test_one_launch_rcab_with_more_strips_than_cus(N, form, monkeypatch):
     """N * 8 workgroups per launch >> 256 CUs (536 / 1280), images straddling the residency boundary: workgroup ids are dispatched in
     order, so the oldest unfinished image always has all of its strips on the chip - no exchange may time out, and the result equals
     the separate-launch path."""
+    monkeypatch.setenv('RUMPY_RCAB_FORM', form)
     kw = dict(scale=2, n_resgroups=1, n_resblocks=3, reduction=16)
     x, y = O.synthetic_batch(671, N, lr_hw=48, scale=2)
     res = {}

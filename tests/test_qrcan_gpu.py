@@ -257,7 +257,7 @@ def test_qrcan_wide_images_one_launch_rcab_and_the_separate_launches(style, no_r
     oloss, oout = oh.run_train(x, y, extra_channels=a)
     plan = h.net.engine.plan_for(2, 20, 60, True)
     ops = [op for op, _ in plan.fwd]
-    assert ('rumpy_rcab_fwd' in ops) == (no_rcab == '0') and ('rumpy_ca_fwd_fused' in ops and 'rumpy_conv_block' in ops) == (no_rcab == '1')
+    assert ('rumpy_rcab2_fwd' in ops) == (no_rcab == '0') and ('rumpy_conv_block' in ops) == (no_rcab == '1')
     assert self_psnr(out, oout) >= 50.0 and abs(float(loss) - float(oloss)) < 2e-3 * float(oloss)
     print('worst grad rel err', _grad_check(h, oh))
     xe, ye = O.synthetic_batch(962, 1, lr_hw=(33, 70), scale=2)

@@ -451,3 +451,37 @@ def tail_bench(N=32, H=192, W=192):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'tail':
     tail_bench()
+
+
+def rcab2_bench(N=32, H=48, W=48, reps=40):
+    """conv_rcab2.hip (gate applied by the consuming launch) as the dependent chains a network runs: forward launch k reads (x, u) of launch k - 1
+    and writes its own; backward launch k reads the gradient and the product rows launch k + 1 wrote.  Same shapes and stores as `rcab`."""
+    gen = np.random.default_rng(0)
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.04, 0.04, (64, 64, 3, 3)).astype(np.float32)), torch.zeros(64))
+    pa, pb = mk(), mk()
+    f32 = lambda *s: torch.from_numpy(gen.uniform(-0.3, 0.3, s).astype(np.float32)).to(DEV)
+    cw1, cb1, cw2, cb2 = f32(4, 64), f32(4), f32(64, 4), f32(64)
+    act = lambda: (torch.randn(N, H, W, 64, device=DEV) * 0.1).to(BF16)
+    X, U, G = [act(), act()], [act(), act()], [act(), act()]
+    t1, dt1, dt2, uprev = act(), act(), act(), act()
+    mb = torch.zeros(N, H, W, 8, dtype=torch.uint8, device=DEV)
+    npr = int(L.lib().rumpy_rcab2_partials(N, H, W))
+    P = [torch.zeros(N, npr, 64, device=DEV), torch.zeros(N, npr, 64, device=DEV)]
+    mean, hid, gate, dz, scratch = torch.zeros(N, 64, device=DEV), torch.ones(N, 4, device=DEV), torch.full((N, 64), 0.5, device=DEV), torch.zeros(N, 64, device=DEV), torch.zeros(N, 64, device=DEV)
+    ca = dict(ca_w1=cw1.data_ptr(), ca_b1=cb1.data_ptr(), ca_w2=cw2.data_ptr(), ca_b2=cb2.data_ptr(), cr=4, N=N, H=H, W=W, part_scratch=scratch.data_ptr())
+    fwd = [L.Rcab2Args(x=X[k].data_ptr(), u_in=U[k].data_ptr(), part_in=P[k].data_ptr(), np_in=npr, part_out=P[1 - k].data_ptr(), w1=pa.w_fwd.data_ptr(),
+                       b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(), b2=pb.b_packed.data_ptr(), x_out=X[1 - k].data_ptr(), t=t1.data_ptr(), u_out=U[1 - k].data_ptr(),
+                       maskbits=mb.data_ptr(), mean=mean.data_ptr(), hidden=hid.data_ptr(), gate=gate.data_ptr(), **ca) for k in (0, 1)]
+    bwd = [L.Rcab2Args(x=G[k].data_ptr(), u_in=uprev.data_ptr(), part_in=P[k].data_ptr(), np_in=npr, part_out=P[1 - k].data_ptr(), w1=pb.w_dgrad.data_ptr(),
+                       w2=pa.w_dgrad.data_ptr(), x_out=dt2.data_ptr(), t=dt1.data_ptr(), u_out=G[1 - k].data_ptr(), maskbits=mb.data_ptr(),
+                       hidden=hid.data_ptr(), gate=gate.data_ptr(), dz=dz.data_ptr(), **ca) for k in (0, 1)]
+    for name, fn, pair in (('fwd', 'rumpy_rcab2_fwd', fwd), ('bwd', 'rumpy_rcab2_bwd', bwd)):
+        def run():
+            for i in range(reps):
+                L.call(fn, pair[i & 1], stream())
+        us = time_fn(run, iters=5, warm=2) / reps
+        print('rcab2 %s %dx%dx%d: %.2f us per launch (chain of dependent launches)' % (name, N, H, W, us))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'rcab2':
+    rcab2_bench()

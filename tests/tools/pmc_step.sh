@@ -21,7 +21,7 @@ for d in sorted(glob.glob('gpurun_out/pmcs_%s_*' % M)):
     for f in glob.glob(d + '/*counter_collection.csv'):
         by = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if any(t in r['Kernel_Name'] for t in (('rcab_fp8_kernel', 'conv_block_fp8_kernel') if FP8 else ('rcab_kernel', 'conv_block_kernel'))):
+            if any(t in r['Kernel_Name'] for t in (('rcab_fp8_kernel', 'conv_block_fp8_kernel') if FP8 else ('rcab_kernel', 'rcab2_kernel', 'conv_block_kernel'))):
                 by[(r['Kernel_Name'][:64], r['Counter_Name'])].append(float(r['Counter_Value']))
         for k, v in sorted(by.items()):
             v = v[len(v) // 2:]
@@ -31,10 +31,11 @@ for d in sorted(glob.glob('gpurun_out/pmcs_%s_*' % M)):
 # launches the forward and the data-gradient form equally often)
 forms = {k: (2 * c['FETCH_SIZE'] + c['WRITE_SIZE']) * 1024 for k, c in means.items() if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c}
 if forms:
-    kind = ('rcab_fp8_kernel' if FP8 else 'rcab_kernel') if M != 'edsr' else ('conv_block_fp8_kernel' if FP8 else 'conv_block_kernel')
+    lazy = any('rcab2_kernel' in k for k in forms)        # the default RCAB form since round 5 (conv_rcab2.hip); RUMPY_RCAB_FORM=xchg: conv_rcab.hip
+    kind = ('rcab_fp8_kernel' if FP8 else 'rcab2_kernel' if lazy else 'rcab_kernel') if M != 'edsr' else ('conv_block_fp8_kernel' if FP8 else 'conv_block_kernel')
     srcs = ['rumpy_amd/csrc/block_common.hpp'] + (['rumpy_amd/csrc/fp8_common.hpp'] if FP8 else [])
     if M != 'edsr':
-        srcs += ['rumpy_amd/csrc/rcab_common.hpp', 'rumpy_amd/csrc/conv_rcab_fp8.hip' if FP8 else 'rumpy_amd/csrc/conv_rcab.hip']
+        srcs += ['rumpy_amd/csrc/rcab_common.hpp', 'rumpy_amd/csrc/conv_rcab_fp8.hip' if FP8 else 'rumpy_amd/csrc/conv_rcab2.hip' if lazy else 'rumpy_amd/csrc/conv_rcab.hip']
     else:
         srcs += ['rumpy_amd/csrc/conv_block_fp8.hip' if FP8 else 'rumpy_amd/csrc/conv_block.hip']
     entry = {'bytes_per_launch': sum(forms.values()) / len(forms), 'per_form_bytes': forms, 'sources': srcs, 'sha16': bench.source_sha16(srcs),
