@@ -389,11 +389,14 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='LR patches per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--probe-steps', type=int, default=5)
-    ap.add_argument('--settle-ms', type=float, default=120.0,
-                    help='hold the GPU under load (the same training steps) for this long before the W warm-up steps: a fresh process starts with '
-                         'the core clock at its idle level and the SMU needs 30-50 ms of load to raise it (profiles/r04_clock_ramp.txt: every '
-                         'MFMA-bound kernel 15-27 %% slower over the first 25 steps, the HBM-bound ones unchanged).  On one GPU the region of a '
-                         'fresh process (W warm-up + K steps, no settling) is timed first and reported as `cold_start`.  0 = off')
+    ap.add_argument('--settle-ms', type=float, default=0.0,
+                    help='A/B tooling only (default 0 = off): hold the GPU under load for this long BEFORE the W warm-up steps.  `value` is always the '
+                         'contract\'s region of the process as the flags describe it; with the default flags that is a fresh process (ADVICE r4).')
+    ap.add_argument('--settled-probe-ms', type=float, default=120.0,
+                    help='AFTER the contract\'s timed region (one GPU): keep the GPU under load for this long, then time the same W + K steps again and '
+                         'report them as the extra field `settled` - a fresh process starts with the core clock at its idle level and the SMU needs '
+                         '30-50 ms of load to raise it (profiles/r04_clock_ramp.txt: MFMA-bound kernels 15-27 %% slower over the first 25 steps).  '
+                         'Information beside `value`, never `value`.  0 = off')
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--model', choices=('edsr', 'rcan', 'qrcan', 'blindqrcan', 'edsr256', 'moco'), default='edsr',
@@ -467,7 +470,8 @@ def main():
     fp8 = args.precision == 'fp8'
     if fp8:
         extra = dict(extra, precision='fp8')
-    mfma_peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS      # the dominant kernel's matrix instruction
+    mfma_peak = MFMA_FP8_PEAK_TFLOPS if fp8 else MFMA_BF16_PEAK_TFLOPS      # the dominant kernel's matrix instruction (re-derived below from what the plan really launches)
+    fp8_live = fp8
     h = define_model({'blindqrcan': 'contrastiveblindqrcan', 'edsr256': 'edsr'}.get(args.model, args.model), model_save_dir=tempfile.mkdtemp(), device=local_rank,
                      eval_mode=False, checkpoint_load=False, loss_masking=False, scale=4, lr=1e-4, scheduler='cosine_annealing_warm_restarts',
                      scheduler_params=SCHED, **extra)
@@ -523,18 +527,16 @@ def main():
             worst = float(t.item())
         return worst, own, loss
 
-    # The driver runs ONE plain command per N: when no all-reduce form is forced, a data-parallel run times the region twice inside the same
-    # process group - one inline collective behind the backward pass, then the early half on the side stream under the remaining weight
-    # gradients - reports the faster as `value` and both under `distributed.forms`; every rank prints its own time to stderr.
+    # The driver runs ONE plain command per N.  When no all-reduce form is forced, a data-parallel run first tries both forms as part of its
+    # WARM-UP (a short region each, inside one process group: one inline collective behind the backward pass / the early half on the side stream
+    # under the remaining weight gradients), keeps the faster one, and then runs the contract's region - W warm-up steps, exactly K
+    # timed steps - ONCE, in that form.  `value` is that region; the trial figures are reported under `distributed.forms` (`value`
+    # is never the better of two timed regions).  Every rank prints its own time to stderr.
     forms_ms = forms_loss = None
-    cold_start = settle = None
+    settle = settled = None
     if args.settle_ms > 0:
         t_load = time.perf_counter()
         n_settle = 0
-        if not dp:
-            e, _, _ = timed_region()        # a fresh process, exactly as the contract reads: the like-for-like figure of BENCH_r01..r03
-            cold_start = {'value': round(N * args.steps / e, 2), 'ms_per_step': round(1e3 * e / args.steps, 4), 'steps': args.steps, 'warmup': args.warmup}
-            n_settle = args.steps + args.warmup
         if not dp:
             while time.perf_counter() - t_load < 1e-3 * args.settle_ms:
                 step(n_settle)
@@ -543,26 +545,39 @@ def main():
             for n_settle in range(1, 1 + max(1, int(args.settle_ms / 1.2))):      # the same count on every rank: the step contains the all-reduce
                 step(n_settle)
         settle = {'steps_before_warmup': n_settle, 'ms': round(1e3 * (time.perf_counter() - t_load), 1),
-                  'what': 'training steps that keep the GPU loaded until its core clock has left the idle level; then W warm-up steps, then the K timed ones'}
+                  'what': '--settle-ms (A/B tooling): training steps that kept the GPU loaded in front of the W warm-up steps'}
     hipnet0 = getattr(h.net, 'hip_generator', h.net)
     if dp and args.allreduce_form == 'auto' and hasattr(hipnet0, 'engine_forward') and not getattr(hipnet0, 'use_graph', False) \
             and not any(os.environ.get(k) for k in ('RUMPY_DP_EARLY', 'RUMPY_DP_LATE')):
         forms_ms, forms_loss, best = {}, {}, None
+        k_try, w_try = min(args.steps, 20), min(args.warmup, 5)
+        keep = (args.steps, args.warmup)
+        args.steps, args.warmup = k_try, w_try
         for form in ('inline', 'early'):
             h.set_allreduce_form(form)
             e, own, l = timed_region()
-            forms_ms[h.data_parallel.form] = round(1e3 * e / args.steps, 4)
+            forms_ms[h.data_parallel.form] = round(1e3 * e / k_try, 4)
             forms_loss[h.data_parallel.form] = float(l)
-            sys.stderr.write('bench.py: rank %d, all-reduce form %s: %.4f ms per step (max over ranks %.4f)\n'
-                             % (rank, h.data_parallel.form, 1e3 * own / args.steps, 1e3 * e / args.steps))
+            sys.stderr.write('bench.py: rank %d, warm-up trial of all-reduce form %s: %.4f ms per step over %d steps (max over ranks %.4f)\n'
+                             % (rank, h.data_parallel.form, 1e3 * own / k_try, k_try, 1e3 * e / k_try))
             if best is None or e < best[0]:
-                best = (e, l, form)
-        elapsed, loss, chosen = best
-        h.set_allreduce_form(chosen)        # (the probe steps below run the reported form)
-    else:
-        elapsed, own, loss = timed_region()
-        if dp:
-            sys.stderr.write('bench.py: rank %d: %.4f ms per step (max over ranks %.4f)\n' % (rank, 1e3 * own / args.steps, 1e3 * elapsed / args.steps))
+                best = (e, form)
+        args.steps, args.warmup = keep
+        h.set_allreduce_form(best[1])       # (max over ranks, all-reduced: every rank picks the same form)
+    elapsed, own, loss = timed_region()
+    if dp:
+        sys.stderr.write('bench.py: rank %d: %.4f ms per step (max over ranks %.4f)\n' % (rank, 1e3 * own / args.steps, 1e3 * elapsed / args.steps))
+    if not dp and args.settled_probe_ms > 0:
+        t_load = time.perf_counter()
+        n_more = 0
+        while time.perf_counter() - t_load < 1e-3 * args.settled_probe_ms:
+            step(n_more)
+            n_more += 1
+        e2, _, _ = timed_region()
+        settled = {'value': round(N * args.steps / e2, 2), 'ms_per_step': round(1e3 * e2 / args.steps, 4), 'steps': args.steps, 'warmup': args.warmup,
+                   'steps_before': args.warmup + args.steps + n_more,
+                   'what': 'the same W + K region timed again behind the contract\'s region and %d more steps (%.0f ms under load): the core clock has '
+                           'left its idle level by then (profiles/r04_clock_ramp.txt).  Information; `value` is the first region.' % (n_more, args.settled_probe_ms)}
     ms_per_step = 1e3 * elapsed / args.steps
     value = N * world * args.steps / elapsed
 
@@ -587,6 +602,10 @@ def main():
         rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd', 'rumpy_rcab2_fwd', 'rumpy_rcab2_bwd')]      # share probe id 5 with the block kernel
         rcab2 = any(name == 'rumpy_rcab2_fwd' for name, _ in ops)
         use_block = len(blocks) + len(rcabs) > 0
+        #  an fp8 line only if every one-launch block of the plan really runs the fp8 kernels (patches wider than 48 pixels do not)
+        fp8_live = fp8 and use_block and all(getattr(a, 'w1_f8', None) for a in blocks + rcabs)
+        if fp8 and not fp8_live:
+            mfma_peak = MFMA_BF16_PEAK_TFLOPS
         wide_convs = [a for name, a in ops if name == 'rumpy_conv3x3' and a.cin_chunks == 4] if getattr(hipnet.engine, 'wide', False) else []
         hipnet.use_graph = False          # the probe records events around eager launches (a graph replay has none)
         lib.rumpy_probe_begin(5 if use_block else (3 if wide_convs else 1), max(80, len(blocks) + len(rcabs), len(wide_convs) + 8) * args.probe_steps + 8)
@@ -709,10 +728,12 @@ def main():
                's_per_step': round(best, 3), 'warmup_s': round(warm, 3)}
 
     if rank == 0:
-        line = {'metric': '%dpx LR patches/sec (train step) %s x4 %s' % (P, args.model.upper(), 'fp8 opt-in' if fp8 else 'bf16'), 'value': round(value, 2), 'unit': 'LR patches/s',
+        if fp8 and not fp8_live:
+            sys.stderr.write('bench.py: --precision fp8, but this plan has no fp8 launch (patches wider than 48 pixels?): the line is labelled bf16\n')
+        line = {'metric': '%dpx LR patches/sec (train step) %s x4 %s' % (P, args.model.upper(), 'fp8 opt-in' if fp8_live else 'bf16'), 'value': round(value, 2), 'unit': 'LR patches/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-                'dtype': 'fp8 (e4m3 forward / e5m2 gradient MFMA operands of the residual-block launches, fp32 accumulation; bf16 storage and bf16 MFMA elsewhere)' if fp8 else 'bf16',
+                'dtype': 'fp8 (e4m3 forward / e5m2 gradient MFMA operands of the residual-block launches, fp32 accumulation; bf16 storage and bf16 MFMA elsewhere)' if fp8_live else 'bf16',
                 'data': ('synthetic uint8 images in HBM, patches cropped/flipped/converted on the GPU every step (device patch pipeline), '
                          'random-init weights (seed 8)') if args.device_patches else
                         'synthetic uniform[0,1) DIV2K-shaped patches, random-init weights (seed 8)',
@@ -720,9 +741,10 @@ def main():
                                        ' train step, %dx%d LR patches, batch %d per GPU' % (P, P, N),
                            'global_batch': N * world, 'parallelism': 'dp%d' % world, 'optimizer': 'Adam lr 1e-4 + cosine warm restarts per batch',
                            'loss': float(loss), 'train_tflops': round(value * flop_per_patch / 1e12, 2),
-                           'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4),      # (whole step, against the bf16 peak)
+                           'train_mfma_frac': round(value * flop_per_patch / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4),      # (whole step, against the bf16 peak: most of a step's launches are bf16 in either precision)
+                           'train_mfma_frac_peak_tflops': MFMA_BF16_PEAK_TFLOPS,
                            'precision': args.precision},
-                'roofline': roofline, 'cpu_baseline': cpu, 'as_called': as_called, 'cold_start': cold_start, 'clock_settle': settle,
+                'roofline': roofline, 'cpu_baseline': cpu, 'as_called': as_called, 'settled': settled, 'clock_settle': settle,
                 # what the collectives really ran on (the driver's scaling run can check that RCCL saw N ranks on N devices)
                 'distributed': {'world_size': dist.get_world_size() if dp else 1, 'backend': dist.get_backend() if dp else None,
                                 'device_count': torch.cuda.device_count(), 'ranks_on_one_device': bool(one_device),

@@ -313,9 +313,11 @@ class HipSRNet(nn.Module):
         out, _, _ = self.engine_forward(x, train=False, meta=metadata)
         return out
 
-    def fused_l1_forward_backward(self, x, y, metadata=None):
+    def fused_l1_forward_backward(self, x, y, metadata=None, out_to_host=False):
         """forward + nn.L1Loss + full backward in one pass (base_architecture.py:474-480 minus the optimizer).
-        Returns (loss device scalar, out).  Gradients land in flat_g / p.grad."""
+        Returns (loss device scalar, out).  Gradients land in flat_g / p.grad.
+        out_to_host ('inline' | 'side'; run_train(keep_on_device=False), the reference's default call): the output image is final behind the
+        forward pass - its copy into pinned host memory is queued there (_stage_out); take_staged_out() hands it over."""
         if self.use_graph:
             self._ensure_engine()
             out, loss, plan = self.engine.train_pass_graphed(x.float().contiguous(), y.float().contiguous(), meta=self._meta_matrix(metadata, x))
@@ -330,8 +332,37 @@ class HipSRNet(nn.Module):
         # base_architecture.py:482-485) waits for the forward pass only and the host can queue the next step while the GPU
         # still runs this step's backward pass and optimizer.
         self._stage_loss(loss, plan.rcab_status)
+        if out_to_host:
+            self._stage_out(out, side=(out_to_host == 'side'))
         self.engine.backward(plan, 1.0 / out.numel(), on_ready=getattr(self, 'grad_ready_hook', None))
         return loss, out
+
+    def _stage_out(self, out, side=False):
+        """queue `out` -> a pinned host tensor behind what the current stream has queued so far (the forward pass); the caller waits for that copy's
+        event only, i.e. run_train returns while the backward pass and the optimizer still run.  Default: the copy goes to the step's OWN stream
+        (0.3 ms of PCIe in front of the backward pass; no second queue in the process).  side=True: on a copy stream, under the backward pass."""
+        host = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)       # (caching host allocator: the block of an earlier step comes back)
+        ev = torch.cuda.Event()
+        if side:
+            if getattr(self, '_copy_stream', None) is None:
+                self._copy_stream = torch.cuda.Stream(out.device)
+            self._copy_stream.wait_stream(torch.cuda.current_stream(out.device))
+            with torch.cuda.stream(self._copy_stream):
+                host.copy_(out, non_blocking=True)
+                ev.record(self._copy_stream)
+            out.record_stream(self._copy_stream)
+        else:
+            host.copy_(out, non_blocking=True)
+            ev.record()
+        self._staged_out = (host, ev)
+
+    def take_staged_out(self):
+        """-> the host copy of the last step's output queued by fused_l1_forward_backward(out_to_host=True) (waits for that copy only), or None"""
+        st, self._staged_out = getattr(self, '_staged_out', None), None
+        if st is None:
+            return None
+        st[1].synchronize()
+        return st[0]
 
     def _stage_loss(self, loss, status=None):
         """Queue the read-back of a step's loss (and the strip-exchange watchdog word) into pinned memory, fenced by an event."""

@@ -53,6 +53,15 @@ __device__ __forceinline__ void unpack4_bf16(uint2 v, float (&o)[4]) {
   o[2] = bf16_bits_to_f32(v.y & 0xffffu); o[3] = bf16_bits_to_f32(v.y >> 16);
 }
 
+// A loaded 16-byte vector, zeroed unless `ok` - as four ANDs with an all-ones / zero mask.  Written as `if (!ok) v = make_uint4(0, 0, 0, 0)` the
+// compiler is free to build an exec-masked block that holds an s_waitcnt vmcnt(0) right behind the load; in the tile loaders of the one-launch RCAB
+// kernels it did (round 5, found in the ISA: eight to eighteen loads per wave, each followed by a full wait - and the block is entered by every
+// strip of a W <= 48 image, whose halo columns always lie outside it): the tile then arrives one load latency at a time.
+__device__ __forceinline__ uint4 keep_if(uint4 v, bool ok) {
+  const unsigned m = 0u - (unsigned)ok;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+
 // ---- element format of the stored activations / packed filters (rumpy_amd.h: RUMPY_FMT_*) ----
 // bf16 (training, the default) or IEEE fp16 (evaluation plans: same MFMA rate and bytes, 11 instead of 8 significant bits - the
 // forward pass of a trained SR network stays far inside fp16's range, and rumpy_tail_fwd reports a non-finite output).  The kernels

@@ -28,6 +28,7 @@
 // order is unchanged, so the results are bitwise those of the two-launch path (test_conv_block_column_tiles_*).
 #include "block_common.hpp"
 #include <cstdlib>
+#include <cstdio>
 
 // (The timing-experiment builds of rounds 1-3 - phase stamps, pieces compiled out, alternative prologue orders - live as a patch under
 // tests/tools/patches/abl_r03.patch; this file holds the product kernel only.)
@@ -416,12 +417,18 @@ static void block_geometry(int N, int H, int W, bool rows_ok, int* sh, int* nc, 
   *sh = BSH;
   if (!rows_ok || W <= BSW) return;
   const char* force = getenv("RUMPY_BLOCK_GEO");          // (read per call: the tests toggle it)
+  int fh = 0, fc = 0;                                      // "SH,NC": one of the candidates below, or it is ignored with a message (it used to be read as two characters)
+  if (force && (sscanf(force, "%d,%d", &fh, &fc) != 2 || !((fh == BSH && (fc == 2 || fc == 3)) || ((fh == 4 || fh == 8) && fc == 2)))) {
+    static bool told = false;
+    if (!told) { fprintf(stderr, "rumpy_amd: RUMPY_BLOCK_GEO=\"%s\" is not one of 6,3 6,2 8,2 4,2 - ignored\n", force); told = true; }
+    fh = fc = 0;
+  }
   const int cus = rumpy_device_cus();
   long best = -1;
   const int cand[4][2] = {{BSH, *nc}, {BSH, 2}, {8, 2}, {4, 2}};
   for (int i = 0; i < 4; ++i) {
     const int h = cand[i][0], c = cand[i][1];
-    if (force && (force[0] - '0' != h || force[2] - '0' != c)) continue;
+    if (fh && (fh != h || fc != c)) continue;
     const int ct = (W + 16 * c - 1) / (16 * c);
     const long wgs = (long)N * ((H + h - 1) / h) * ct;
     const long cost = ((wgs + cus - 1) / cus) * (2 * h + 2 + 6) * (c + 1);

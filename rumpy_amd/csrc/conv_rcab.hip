@@ -23,6 +23,7 @@
 // together (ns <= CUs; the reference's 64 x 64 training crops are 22).
 #include "rcab_common.hpp"
 #include <cstdlib>
+#include <cstdio>
 
 // MB (backward only): the ReLU mask comes as bytes (written by the forward launch) instead of the bf16 activation
 // FMT: element format (RUMPY_FMT_F16 is instantiated for the forward launch only: evaluation plans)
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
     mv = src[idx];
     if (which == 2 && !a.qgate) mv = 1.f;
   }
+  bf16x8 F[18];
   {
     uint4 R[G::XREGS];
     const int y0 = sy * SH - 2;
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       const bool ok = (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
       uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
-      if (!ok) v = make_uint4(0, 0, 0, 0);
+      v = keep_if(v, ok);
       R[i] = v;
     }
     if (BWD) {   // the strip's own rows of the forward conv2 output: piece p = tid + 512 i -> (pixel p >> 3 of 6 x OW, chunk tid & 7)
@@ -107,9 +109,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
         const bool ok = (p < G::SPIECES) & (y < a.H) & (x0 + col < a.W);
         const int e = ok ? ((n * a.H + y) * a.W + x0 + col) * 64 + (p & 7) * 8 : 0;
         uint4 v = *reinterpret_cast<const uint4*>(a.t2_in + (unsigned)e);
-        if (!ok) v = make_uint4(0, 0, 0, 0);
+        v = keep_if(v, ok);
         T2[i] = v;
       }
+    }
+    // the first conv's filter: requested behind the tile (loads return in order) and in front of the tile's waits - its L2-hit latency lies
+    // under the tile's (round 5: it used to be requested behind the LDS writes, i.e. after the whole tile had arrived)
+    {
+      const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
     if (!G::CT && tid < G::TROWS * 2 * 8) {       // (column tiles: the halo tile of the first phase writes these columns)
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
@@ -136,12 +145,6 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_kernel(RcabDev a) {
       else if (which < 4) svec[which * 64 + c] = mv;
       else if (which == 4 && c < RC_MAXR) svec[32 + c] = mv;      // hidden[n][r] behind the (<= 16) bias entries of row 0
     }
-  }
-  bf16x8 F[18];
-  {
-    const uint4* wp = a.w1 + (size_t)q * 18 * 64 + lane;
-#pragma unroll
-    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
   }
   const int c0 = 16 * q + 4 * g;
   const int gpair = 4 * (g & ~1);
@@ -570,12 +573,18 @@ static void rcab_geometry(int N, int H, int W, bool rows_ok, int* sh, int* nc, i
   *sh = BSH;
   if (!rows_ok || W <= BSW) return;
   const char* force = getenv("RUMPY_BLOCK_GEO");          // (read per call: the tests toggle it)
+  int fh = 0, fc = 0;                                      // "SH,NC": one of the candidates below, or it is ignored with a message (it used to be read as two characters)
+  if (force && (sscanf(force, "%d,%d", &fh, &fc) != 2 || !((fh == BSH && (fc == 2 || fc == 3)) || ((fh == 4 || fh == 8) && fc == 2)))) {
+    static bool told = false;
+    if (!told) { fprintf(stderr, "rumpy_amd: RUMPY_BLOCK_GEO=\"%s\" is not one of 6,3 6,2 8,2 4,2 - ignored\n", force); told = true; }
+    fh = fc = 0;
+  }
   const int cus = rumpy_device_cus();
   long best = -1;
   const int cand[4][2] = {{BSH, *nc}, {BSH, 2}, {8, 2}, {4, 2}};
   for (int i = 0; i < 4; ++i) {
     const int h = cand[i][0], c = cand[i][1];
-    if (force && (force[0] - '0' != h || force[2] - '0' != c)) continue;
+    if (fh && (fh != h || fc != c)) continue;
     const int ct = (W + 16 * c - 1) / (16 * c);
     if (((H + h - 1) / h) * ct > cus) continue;           // every strip of an image has to be resident
     const long wgs = (long)N * ((H + h - 1) / h) * ct;

@@ -23,6 +23,7 @@
 // One more rounding than conv_rcab.hip: the residual branch is gated from the STORED (bf16 / fp16) U, not from the fp32 accumulators.
 #include "rcab_common.hpp"
 #include <cstdlib>
+#include <cstdio>
 
 struct Rcab2Dev {
   const uint16_t* x;         // fwd: x_{k-1} (or the block input itself when u_in is NULL); bwd: G
@@ -47,6 +48,16 @@ __device__ __forceinline__ void r2_dma16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// -DRCAB2_STAMPS (measurement builds only, tests/tools/r05_stamps.sh): phase time stamps of every wave (s_memrealtime, 100 MHz) into a buffer
+// handed over by rumpy_debug_rcab2_stamps; the results of the launch are unchanged
+#ifdef RCAB2_STAMPS
+__device__ unsigned long long* g_r2_stamps;
+#define R2_STAMP(k) do { if ((threadIdx.x & 63) == 0 && g_r2_stamps) g_r2_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int rumpy_debug_rcab2_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_r2_stamps), &buf, sizeof(buf)); }
+#else
+#define R2_STAMP(k) do { } while (0)
+#endif
+
 template <bool BWD, int FMT = RUMPY_FMT_BF16, class G = GeoL>
 __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
   constexpr int NC = G::NC, XC = G::XC, TC = G::TC, XH = G::XH, OW = G::OW;
@@ -57,7 +68,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[G::XBYTES + G::TBYTES];
   __shared__ __attribute__((aligned(16))) unsigned char ldu[UBYTES];
   __shared__ float red[8 * 64];            // prologue: the waves' shares of the partial rows; bwd tail: [rh][q][64] product sums
-  __shared__ unsigned gate[8];             // [0, 1] T rows of row half 0 / 1 written, [2, 3] OUT rows written, [4, 5] product sums written
+  __shared__ unsigned gate[12];            // waves that have written: [0, 1] T rows of row half 0 / 1, [2, 3] OUT rows, [4] the early part of the input tile, [5] row half
+                                           // 1: the late part, [6] their share of the partial rows, [8, 9] their product sums (bwd)
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + G::XBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,7 +83,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
   const int np_out = 2 * a.sy_n * a.ct_n;
   const int x0 = ct * OW;
   const bool pend = BWD || a.u_in != nullptr;      // a gate is evaluated and applied in this launch
-  if (tid < 8) gate[tid] = 0u;
+  if (tid < 12) gate[tid] = 0u;
+  __syncthreads();                         // (nothing is in flight yet: a bare s_barrier) the counters are zero before anybody arrives
+  R2_STAMP(0);
 
   // ---- phase 0a: the oldest requests of the launch - this wave's share of the partial rows, the MLP's operands of channel `lane` ----
   float pv[8], mw1[4], mw2[4], mu[4] = {0.f, 0.f, 0.f, 0.f}, mb2 = 0.f, mgq = 1.f, msg = 0.f;
@@ -81,13 +95,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
   for (int i = 0; i < 4; ++i) { mw1[i] = 0.f; mw2[i] = 0.f; }
   if (pend) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {          // rows wave, wave + 8, ... (np_in <= 64, checked by the host)
+    for (int k = 0; k < 8; ++k) {          // rows wave, wave + 8, ... (np_in <= 64, checked by the host); rows beyond np_in are masked where they are added
       const int j = wave + 8 * k;
-      const float v = a.part_in[((size_t)n * a.np_in + (j < a.np_in ? j : 0)) * 64 + lane];
-      pv[k] = j < a.np_in ? v : 0.f;
+      pv[k] = a.part_in[((size_t)n * a.np_in + (j < a.np_in ? j : 0)) * 64 + lane];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {          // hidden units 0 .. 3 (the reference's reduction 16: all of them); further ones are fetched in their round
+    for (int i = 0; i < 4; ++i) {          // hidden units 0 .. cr - 1 (cr <= 4)
       const int r = i < a.cr ? i : 0;
       mw1[i] = a.cw1[r * 64 + lane];
       mw2[i] = a.cw2[lane * a.cr + r];
@@ -99,29 +112,40 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
     for (int i = 0; i < 4; ++i) mu[i] = BWD ? a.hidden[n * a.cr + (i < a.cr ? i : 0)] : a.cb1[i < a.cr ? i : 0];      // (uniform: bias of conv_du.0 | its hidden unit)
   }
   // ---- phase 0b: tile requests: input rows SH sy - 2 .. SH sy + SH + 1, columns x0 - XH .. x0 + OW + XH - 1 (zero outside the image) ----
-  uint4 R[G::XREGS], R2[(!BWD) ? G::XREGS : 1];
+  // conv_block.hip's split: the pieces of input rows 0 .. TR + 1 (row half 0's window; R0 rounds of 512) are requested by all threads first and
+  // announced on their own LDS counter, the rest by row half 1's threads (row half 0 issues as many loads of one cached line instead: every wave
+  // runs the same, unconditional load sequence, so the compiler's waits stay counted).  Row half 0 starts its first sweep when rows 0 .. TR + 1 are
+  // in LDS, row half 1 when everything is.  With a pending branch every piece is two loads (x and u).
+  constexpr int R0 = ((TR + 2) * XC * 8 + BTHREADS - 1) / BTHREADS;
+  constexpr int LATE = G::XPIECES - R0 * BTHREADS > 0 ? G::XPIECES - R0 * BTHREADS : 0;
+  constexpr int R1 = (LATE + 255) / 256;
+  constexpr int RA = R0 + (R1 > 0 ? R1 : 0);
+  uint4 R[RA], R2[(!BWD) ? RA : 1];      // (R2: requested and read with a pending branch only)
   const int y0 = sy * SH - 2;
-  auto piece_elem = [&](int p, bool& ok) -> unsigned {
+  auto piece_of = [&](int i) -> int { return i < R0 ? tid + BTHREADS * i : R0 * BTHREADS + tg + 256 * (i - R0); };
+  // (masks, not selects or branches: with `if (!ok) v = 0` the compiler built an exec-masked block holding an s_waitcnt vmcnt(0) behind EVERY load -
+  // taken by every strip, because the halo columns of a W <= 48 image always lie outside it - and the tile arrived one load latency at a time)
+  auto piece_elem = [&](int p, bool live, unsigned& m) -> unsigned {
     const int pix = p >> 3, part = p & 7;
     const int lr = pix / XC, lc = pix - lr * XC;
     const int y = y0 + lr, x = x0 - XH + lc;
-    ok = (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
-    return ok ? (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8) : 0u;
+    const bool ok = live & (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+    m = 0u - (unsigned)ok;
+    return (unsigned)(((n * a.H + y) * a.W + x) * 64 + part * 8) & m;
   };
+  unsigned RM[RA];                         // all ones where the piece lies inside the image
+  if (!BWD && pend) {
 #pragma unroll
-  for (int i = 0; i < G::XREGS; ++i) {
-    bool ok;
-    const unsigned e = piece_elem(tid + BTHREADS * i, ok);
-    uint4 v = *reinterpret_cast<const uint4*>(a.x + e);
-    if (!ok) v = make_uint4(0, 0, 0, 0);
-    R[i] = v;
-    if (!BWD) {
-      uint4 u = make_uint4(0, 0, 0, 0);
-      if (pend) {
-        u = *reinterpret_cast<const uint4*>(a.u_in + e);
-        if (!ok) u = make_uint4(0, 0, 0, 0);
-      }
-      R2[(!BWD) ? i : 0] = u;
+    for (int i = 0; i < RA; ++i) {
+      const unsigned e = piece_elem(piece_of(i), i < R0 || rh == 1, RM[i]);
+      R[i] = *reinterpret_cast<const uint4*>(a.x + e);
+      R2[(!BWD) ? i : 0] = *reinterpret_cast<const uint4*>(a.u_in + e);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const unsigned e = piece_elem(piece_of(i), i < R0 || rh == 1, RM[i]);
+      R[i] = *reinterpret_cast<const uint4*>(a.x + e);
     }
   }
   bf16x8 F[18];
@@ -130,49 +154,41 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
 #pragma unroll
     for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
   }
-  unsigned soff[G::GREGS];                 // element offsets of this thread's pieces of its row half's strip rows (T, OUT stores; bwd: the U_{k-1} pieces)
-#pragma unroll
-  for (int i = 0; i < G::GREGS; ++i) soff[i] = group_piece_off<G>(i, tg, rh, n, sy, a.H, a.W, x0);
-  const bool prod = BWD && a.u_in != nullptr && a.part_out != nullptr;
-  if (BWD && prod) {                       // the forward pass's U_{k-1}, own rows: needed behind the last sweep - by LDS-DMA, no registers
-    const unsigned ubase = (unsigned)(size_t)(r2_lds_u8)ldu;
-#pragma unroll
-    for (int i = 0; i < G::GREGS; ++i)
-      r2_dma16((const void*)(a.u_in + (soff[i] != 0xffffffffu ? soff[i] : 0u)), __builtin_amdgcn_readfirstlane(ubase + ((rh * G::GREGS + i) * 256 + 64 * q) * 16));
-  }
 
-  // ---- phase 0c: the gate (every wave by itself, lane = channel; all in registers) ----
+  // ---- phase 0c: the gate (every wave by itself, lane = channel; all in registers).  The waves' shares of the partial rows meet through LDS and a
+  // counter, not through __syncthreads: that is a full s_waitcnt vmcnt(0) - it would hold the gate back until the whole tile has arrived ----
   float sA[8], pA[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { sA[j] = 0.f; pA[j] = 0.f; }
+  __builtin_amdgcn_sched_barrier(0);       // every request above is issued before the first wait below (left alone the scheduler put the partial rows' adds - a wait - in front of the tile)
   if (pend) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pv[k] = (wave + 8 * k < a.np_in) ? pv[k] : 0.f;
     red[wave * 64 + lane] = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
-    __syncthreads();
+    gate_arrive(&gate[6], lane);
+    gate_wait(&gate[6], 8u);
     float tot = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) tot += red[k * 64 + lane];
     const bool wr = (si == 0) && (wave == 0);
     float sg, dpv = 0.f;
+    // straight-line over the (at most 4) hidden units, operands requested at kernel start.  Cr <= 4 (the reference's reduction 16 of 64 features) is
+    // all this kernel takes: a loop over further units with loads in it made the compiler drain EVERY outstanding load in front of the gate (a full
+    // wait at the loop head; and a register that such a load may still target costs the straight-line path an s_waitcnt vmcnt(0) where it is
+    // reused).  Wider attention MLPs run conv_rcab.hip (the engine picks the form per block).
     if (!BWD) {
       const float mean = tot * a.inv_hw;
       float z = mb2;
-      for (int r0 = 0; r0 < a.cr; r0 += 4) {
-        float hs[4], w2[4];
+      {
+        float hs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hs[i] = wave_sum(mw1[i] * mean);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = (r0 + i < a.cr) ? r0 + i : r0;
-          const float w1 = r0 ? a.cw1[r * 64 + lane] : mw1[i];
-          w2[i] = r0 ? a.cw2[lane * a.cr + r] : mw2[i];
-          hs[i] = w1 * mean;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hs[i] = wave_sum(hs[i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (r0 + i < a.cr) {
-            const float h = fmaxf(hs[i] + (r0 ? a.cb1[r0 + i] : mu[i]), 0.f);
-            z = fmaf(w2[i], h, z);
-            if (wr && lane == 0) a.hidden[n * a.cr + r0 + i] = h;
+          if (i < a.cr) {
+            const float h = fmaxf(hs[i] + mu[i], 0.f);
+            z = fmaf(mw2[i], h, z);
+            if (wr && lane == 0) a.hidden[n * a.cr + i] = h;
           }
         }
       }
@@ -183,22 +199,15 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
       const float ds = tot, s = msg, gq = mgq;
       const float dz = (ds * gq) * s * (1.f - s);
       float dp = 0.f;
-      for (int r0 = 0; r0 < a.cr; r0 += 4) {
-        float dhs[4], w1[4];
+      {
+        float dhs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dhs[i] = wave_sum(mw2[i] * dz);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int r = (r0 + i < a.cr) ? r0 + i : r0;
-          w1[i] = r0 ? a.cw1[r * 64 + lane] : mw1[i];
-          const float w2 = r0 ? a.cw2[lane * a.cr + r] : mw2[i];
-          dhs[i] = w2 * dz;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dhs[i] = wave_sum(dhs[i]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (r0 + i < a.cr) {
-            const float dh = ((r0 ? a.hidden[n * a.cr + r0 + i] : mu[i]) > 0.f) ? dhs[i] : 0.f;
-            dp = fmaf(w1[i], dh, dp);
+          if (i < a.cr) {
+            const float dh = (mu[i] > 0.f) ? dhs[i] : 0.f;
+            dp = fmaf(mw1[i], dh, dp);
           }
         }
       }
@@ -216,20 +225,21 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
       if (BWD) pA[j] = __shfl(dpv, 8 * (tid & 7) + j);
     }
   }
+  R2_STAMP(1);
   // ---- phase 0d: the tile -> LDS, gated on the way; its own pixels -> HBM (whole lines: 8 lanes per pixel) ----
   if (!G::CT && tid < G::TROWS * 2 * 8) {
     const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
     *reinterpret_cast<uint4*>(ldt + swz(row * TC + side * (TC - 1), chunk)) = make_uint4(0, 0, 0, 0);
   }
-#pragma unroll
-  for (int i = 0; i < G::XREGS; ++i) {
-    const int p = tid + BTHREADS * i;
+  auto stage_piece = [&](int i) {           // i is a constant after unrolling
+    const int p = piece_of(i);
     const int pix = p >> 3, part = p & 7;
-    uint4 o = R[i];
+    const unsigned m = RM[i];
+    uint4 o = make_uint4(R[i].x & m, R[i].y & m, R[i].z & m, R[i].w & m);
     if (pend) {
-      bool ok;
-      const unsigned e = piece_elem(p, ok);
-      if (ok) {
+      unsigned m2;
+      const unsigned e = piece_elem(p, true, m2);
+      if (m) {
         float d[8];
         unpack8<FMT>(R[i], d);
         if (!BWD) {
@@ -248,11 +258,34 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
       }
     }
     if (p < G::XPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = o;
+  };
+#pragma unroll
+  for (int i = 0; i < R0; ++i) stage_piece(i);
+  gate_arrive(&gate[4], lane);             // this wave's pieces of input rows 0 .. TR + 1 (and a bit) are in LDS
+  if (R1 > 0 && rh == 1) {
+#pragma unroll
+    for (int i = R0; i < RA; ++i) stage_piece(i);
+    gate_arrive(&gate[5], lane);
   }
   const int c0 = 16 * q + 4 * g;
   const int gpair = 4 * (g & ~1);
   const int chunk8 = 2 * q + (gpair >> 3);
-  __syncthreads();
+  unsigned soff[G::GREGS];                 // element offsets of this thread's pieces of its row half's strip rows (T, OUT stores; bwd: the U_{k-1} pieces)
+#pragma unroll
+  for (int i = 0; i < G::GREGS; ++i) soff[i] = group_piece_off<G>(i, tg, rh, n, sy, a.H, a.W, x0);
+  const bool prod = BWD && a.u_in != nullptr && a.part_out != nullptr;
+  R2_STAMP(2);
+  gate_wait(&gate[4], 8u);                 // input rows 0 .. TR + 1: all eight waves' early pieces
+  if (R1 > 0 && rh == 1) gate_wait(&gate[5], 4u);   // the rest: row half 1's own late pieces
+  R2_STAMP(3);
+  if (BWD && prod) {
+    // the forward pass's U_{k-1}, own rows: needed behind the last sweep - by LDS-DMA, no registers; requested here (not in front of the tile: it
+    // would delay it) and complete at the start of phase 2 (the wait for the second filter, which is younger, covers it)
+    const unsigned ubase = (unsigned)(size_t)(r2_lds_u8)ldu;
+#pragma unroll
+    for (int i = 0; i < G::GREGS; ++i)
+      r2_dma16((const void*)(a.u_in + (soff[i] != 0xffffffffu ? soff[i] : 0u)), __builtin_amdgcn_readfirstlane(ubase + ((rh * G::GREGS + i) * 256 + 64 * q) * 16));
+  }
 
   // ---- phase 1: T rows TR rh .. TR rh + TR - 1 (image rows SH sy - 1 + j) from input rows j .. j + 2 ----
   unsigned moff[NP1];
@@ -301,6 +334,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
     }
     sweep_bases<XC>(off, 0u, TR * rh, px, g, G::CT ? 1 : 0);
     block_sweep<TR, FMT, NoHook, NC, XC>(acc, F, lds, off);
+    R2_STAMP(4);
     {
       const uint4* wp = a.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
@@ -328,8 +362,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
     }
     gate_arrive(&gate[rh], lane);
   }
+  R2_STAMP(5);
   gate_wait(&gate[rh], 4u);
   if (rh == 1) gate_wait(&gate[0], 4u);
+  if (BWD && prod) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the U_{k-1} pieces are in LDS (only the second filter is younger, and it is needed now)
   uint4 S[G::GREGS];
   const bool t_out = a.t != nullptr;
   if (t_out) group_stage<1, G>(S, ldt, tg, rh);
@@ -379,6 +415,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
       sweep_bases<TC>(off, (unsigned)G::XBYTES, OR, px, g);
       block_sweep<OR, FMT, decltype(t_store), NC, TC>(acc, F, lds, off, t_store);
     }
+    R2_STAMP(6);
     float ps[4] = {0.f, 0.f, 0.f, 0.f};
     float ps8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -449,15 +486,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
   }
   // ---- OUT: the row half's rows sit in LDS in place of the input tile's centre rows -> whole lines, non-temporal ----
   gate_arrive(&gate[2 + rh], lane);
+  R2_STAMP(7);
   gate_wait(&gate[2 + rh], 4u);
   group_stage<2, G>(S, ldx, tg, rh);
 #pragma unroll
   for (int i = 0; i < G::GREGS; ++i)
     if (soff[i] != 0xffffffffu) st16_nt(a.u_out + soff[i], S[i]);
+  R2_STAMP(8);
   if (BWD && prod) {
     // partial rows of sum_hw dx * U_{k-1} for the backward launch of block k - 1: this thread's dx pieces against the U pieces its own wave
     // fetched at kernel start; lanes with the same chunk hold the same 8 channels
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < G::GREGS; ++i) {
@@ -482,12 +520,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab2_kernel(Rcab2Dev a) {
       *reinterpret_cast<float4*>(rp) = make_float4(a8[0], a8[1], a8[2], a8[3]);
       *reinterpret_cast<float4*>(rp + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
     }
-    gate_arrive(&gate[4 + rh], lane);
+    gate_arrive(&gate[8 + rh], lane);
     if (q == 0) {
-      gate_wait(&gate[4 + rh], 4u);
+      gate_wait(&gate[8 + rh], 4u);
       const float* rp = red + rh * 4 * 64 + lane;
       a.part_out[((size_t)n * np_out + 2 * si + rh) * 64 + lane] = (rp[0] + rp[64]) + (rp[128] + rp[192]);
     }
+    R2_STAMP(9);
   }
 }
 
@@ -531,7 +570,7 @@ static void rcab2_geometry(int N, int H, int W, int* sh, int* nc, int* ct_n) {
   if (W <= BSW) return;
   const char* force = getenv("RUMPY_BLOCK_GEO");
   int fh = 0, fc = 0;
-  if (force && sscanf(force, "%d,%d", &fh, &fc) != 2) { fh = 0; fc = 0; }
+  if (force && (sscanf(force, "%d,%d", &fh, &fc) != 2 || !((fh == BSH && (fc == 2 || fc == 3)) || ((fh == 4 || fh == 8) && fc == 2)))) { fh = 0; fc = 0; }   // (conv_block.hip says so once)
   const int cus = rumpy_device_cus();
   long best = -1;
   const int cand[4][2] = {{BSH, *nc}, {BSH, 2}, {8, 2}, {4, 2}};
@@ -562,8 +601,8 @@ static int rcab2_launch(const rumpy_rcab2_args* p, void* stream, bool bwd, const
   if (bwd && p->u_in && !p->part_out) { rumpy_set_error("%s: backward with u_in needs part_out", what); return RUMPY_E_ARG; }
   if (gated && p->np_in > 64 && !p->part_scratch) { rumpy_set_error("%s: %d partial rows per image need part_scratch", what, p->np_in); return RUMPY_E_ARG; }
   if (gated && (!p->part_in || p->np_in <= 0 || !p->ca_w1 || !p->ca_b1 || !p->ca_w2 || !p->ca_b2 || !p->hidden || !p->gate ||
-                p->cr <= 0 || p->cr > RC_MAXR || (!bwd && !p->mean))) {
-    rumpy_set_error("%s: a gate needs part_in (%d rows), the attention MLP, hidden, gate%s, 0 < Cr <= 16", what, p->np_in, bwd ? "" : ", mean"); return RUMPY_E_ARG; }
+                p->cr <= 0 || p->cr > 4 || (!bwd && !p->mean))) {
+    rumpy_set_error("%s: a gate needs part_in (%d rows), the attention MLP, hidden, gate%s, 0 < Cr <= 4", what, p->np_in, bwd ? "" : ", mean"); return RUMPY_E_ARG; }
   if (bwd && p->dzq && !p->qgate) { rumpy_set_error("%s: dzq without qgate", what); return RUMPY_E_ARG; }
   if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !bwd)) { rumpy_set_error("%s: fmt %d is a forward-only format", what, p->fmt); return RUMPY_E_ARG; }
   int sh, nc, ct_n;

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_fp8_kernel(RcabDev a) {
       const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
       uint4 v = *reinterpret_cast<const uint4*>(a.x + (unsigned)e);
-      if (!ok) v = make_uint4(0, 0, 0, 0);
+      v = keep_if(v, ok);
       R[i] = v;
     }
     if (BWD) {   // the strip's own rows of the forward conv2 output
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_fp8_kernel(RcabDev a) {
         const bool ok = (p < R8_PIECES) & (y < a.H) & (col < a.W);
         const int e = ok ? ((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8 : 0;
         uint4 v = *reinterpret_cast<const uint4*>(a.t2_in + (unsigned)e);
-        if (!ok) v = make_uint4(0, 0, 0, 0);
+        v = keep_if(v, ok);
         T2[BWD ? i : 0] = v;
       }
     }

@@ -139,9 +139,13 @@ class SREngine:
         self.use_rcab_kernel = os.environ.get('RUMPY_NO_RCAB') != '1'      # channel-attention blocks in one launch (conv_rcab.hip)
         # ... and which one-launch form (round 5): 'lazy' = conv_rcab2.hip, the gate applied by the launch that consumes a block's output - no exchange
         # between workgroups, any image size; 'xchg' = conv_rcab.hip, pool sums exchanged inside the launch (A/B; precision 'fp8' runs this form)
-        self.rcab_form = os.environ.get('RUMPY_RCAB_FORM', 'lazy')
-        if self.rcab_form not in ('lazy', 'xchg'):
-            raise RuntimeError("rumpy_amd: RUMPY_RCAB_FORM is 'lazy' or 'xchg' (got %r)" % self.rcab_form)
+        # Default 'auto' = what measured faster per shape (profiles/r05_rcab_forms.txt): 'xchg' while a strip spans the image (W <= 48) and all strips of an
+        # image are resident (32 x 48 x 48: 3.02 k against 2.83 k patches/s - the lazy forward launch reads two halo tiles), 'lazy' for every wider image
+        # (8 crops of 64 x 64, div2k/rcan.toml: +6.4 %; 96 x 96: +2.6 %; whole-image evaluation: one launch per block instead of two, +2.8 %) and wherever
+        # the exchange's residency condition does not hold.
+        self.rcab_form = os.environ.get('RUMPY_RCAB_FORM', 'auto')
+        if self.rcab_form not in ('auto', 'lazy', 'xchg'):
+            raise RuntimeError("rumpy_amd: RUMPY_RCAB_FORM is 'auto', 'lazy' or 'xchg' (got %r)" % self.rcab_form)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
         # Evaluation plans store activations and filters as IEEE fp16 (same MFMA rate and bytes as bf16, 11 instead of 8 significant bits):
         # bf16 storage alone costs a >= 30 dB model 0.02-0.03 dB of Y-PSNR against the fp32 reference (fixtures G17 / G18).
@@ -474,8 +478,10 @@ class SREngine:
                 return y
 
             for it in items:
-                lazy = (it[0] == 'rcab' and not getattr(it[3], 'gen', False) and self.rcab_form == 'lazy' and self.use_rcab_kernel and self.use_block_kernel
+                lazy = (it[0] == 'rcab' and not getattr(it[3], 'gen', False) and it[3].Cr <= 4 and self.rcab_form != 'xchg' and self.use_rcab_kernel and self.use_block_kernel
                         and (W <= 48 or self.block_any_width) and not (train and (self.fp8 or not self.use_mask_bytes)))
+                if lazy and self.rcab_form == 'auto':
+                    lazy = W > 48 or int(self.lib.rumpy_rcab_strips(H, W)) > self.cus
                 if pending is not None and not lazy:
                     cur = flush(pending)
                     pending = None

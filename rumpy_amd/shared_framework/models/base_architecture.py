@@ -289,9 +289,19 @@ class BaseModel(nn.Module):
             raise RuntimeError('Model initialized in eval mode, training not possible.')
         self.net.train()
         dev = self._torch_device()
-        x, y = x.to(device=dev, non_blocking=True), y.to(device=dev, non_blocking=True)
+        x, y = self._to_device(x, dev, 'x'), self._to_device(y, dev, 'y')
+        host_out = False
         if self._fused_l1():
-            loss, out = self.net.fused_l1_forward_backward(x, y, metadata=kwargs.get('extra_channels'))
+            # the reference's caller (SISRInterface.train_batch, interface.py:97-101) hands over host tensors and takes the image back on the host:
+            # its device-to-host copy is queued behind the forward pass and runs under the backward pass (HipSRNet._stage_out)
+            # 2 (default): copy on a copy stream, under the backward pass (1.51 ms per call); 1: on the step's own stream (2.10); 0: out.cpu() behind the
+            # whole step (1.76) - same box, EDSR 32 x 48 x 48, profiles/r05_as_called.txt.  Only this mode ever creates the second stream.
+            mode = os.environ.get('RUMPY_HOST_STAGING', '2')
+            host_out = (not keep_on_device) and isinstance(self.net, HipSRNet) and not getattr(self.net, 'use_graph', False) and mode in ('1', '2')
+            if host_out:
+                loss, out = self.net.fused_l1_forward_backward(x, y, metadata=kwargs.get('extra_channels'), out_to_host='side' if mode == '2' else 'inline')
+            else:
+                loss, out = self.net.fused_l1_forward_backward(x, y, metadata=kwargs.get('extra_channels'))
             self._apply_update(scheduler_skip)
         elif self._fused_mse():
             loss, out = self.net.fused_mse_forward_backward(x, y)
@@ -310,7 +320,17 @@ class BaseModel(nn.Module):
             # in graph mode `out` is the plan's static buffer (rewritten by the next step): hand out a copy
             keep = out.detach().clone() if getattr(self.net, 'use_graph', False) else out.detach()
             return loss_np, keep
+        if host_out:
+            staged = self.net.take_staged_out()
+            if staged is not None:
+                return loss_np, staged
         return loss_np, out.detach().cpu()
+
+    def _to_device(self, t, dev, slot):
+        """a batch tensor onto the device.  Pageable host tensors (what the reference's data loader hands over) take torch's own path: measured on
+        this platform (tests/tools/as_called_prof.py, profiles/r05_as_called.txt) a pageable .to(device, non_blocking=True) of the 14 MB target costs
+        the host 0.15 ms, while a ring of pinned staging buffers costs 2-4 ms of cold host memcpy per step - tried and dropped."""
+        return t.to(device=dev, non_blocking=True)
 
     @_on_own_device
     def run_eval(self, x, y=None, request_loss=False, tag=None, timing=False, keep_on_device=False, *args, **kwargs):

@@ -739,3 +739,23 @@ if __name__ == '__main__':
     child.write_text(child.read_text().replace("sys.exit(7)", "time.sleep(3600)"))
     p = subprocess.run([sys.executable, str(child)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 124
+
+
+def test_ablation_patch_applies_to_its_base():
+    """tests/tools/patches/abl_r03.patch (the *_ABL timing branches of rounds 1-3) is applied by tests/tools/build_abl.sh to the kernel sources of
+    the commit it was cut from (ABL_BASE in that script): patch and base must keep matching (the tool had rotted unnoticed)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.isdir(os.path.join(root, '.git')) or shutil.which('git') is None:
+        pytest.skip('no git history here (a snapshot of the tree): build_abl.sh runs where the history is')
+    base = re.search(r'^ABL_BASE=(\w+)', open(os.path.join(root, 'tests', 'tools', 'build_abl.sh')).read(), re.M).group(1)
+    with tempfile.TemporaryDirectory() as d:
+        ar = subprocess.run(['git', '-C', root, 'archive', base, 'rumpy_amd/csrc', 'include'], stdout=subprocess.PIPE, check=True).stdout
+        subprocess.run(['tar', '-x', '-C', d], input=ar, check=True)
+        subprocess.run(['git', 'init', '-q', d], check=True)
+        p = subprocess.run(['git', '-C', d, 'apply', '--check', os.path.join(root, 'tests', 'tools', 'patches', 'abl_r03.patch')],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]

@@ -19,7 +19,7 @@
 #include "rumpy_experimental.h"
 
 #ifndef CHAIN_ABL
-#define CHAIN_ABL 0   // timing only (WRONG results): 1 = no flag wait / halo rows, 2 = 1 + OUT stored non-temporal, 3 = 1 + no T stores, 4 = all three; 9 = phase stamps of the middle block, per wave, behind the flag words (tests/tools/chain_stamps.py)
+#define CHAIN_ABL 0   // timing only (WRONG results): 1 = no flag wait / halo rows, 2 = 1 + OUT stored non-temporal, 3 = 1 + no T stores, 4 = all three; 5 = XCD-local hand-off (sc0 stores: right only while an image's strips share an XCD); 9 = phase stamps of the middle block, per wave, behind the flag words (tests/tools/chain_stamps.py)
 #endif
 #define CHAIN_STAMPS (CHAIN_ABL >= 9)   // 9 = stamps; 10 + v = stamps with ablation v
 #define CHAIN_CUT (CHAIN_ABL >= 10 ? CHAIN_ABL - 10 : CHAIN_ABL)
@@ -34,6 +34,18 @@ typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ch_store16_sc1(uint16_t* p, uint4 v) {
   const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");   // s_nop: the >64-bit store data hazard is ours inside asm
+}
+// CHAIN_ABL 5 (round 5, VERDICT r4 item 3: the XCD-local hand-off): OUT rows and flag words stored with sc0 only - they stay in the writer's XCD's L2, no
+// write-through to the memory side - and read by the neighbour with sc1 loads, which that L2 serves when the line is there (tests/tools/overlap/
+// xcd_probe.hip: 0.29 us per hand-off instead of 0.45).  Correct only while the strips of an image sit on ONE XCD: xcd_strip() gives every XCD a
+// contiguous run of strips (32 = four whole images at 32 x 48 x 48) IF workgroup b runs on XCD b % 8 - what the dispatcher does on an idle GPU,
+// not what it promises.  A timing form: what the chain could gain at most from a hand-off that never leaves the XCD.
+__device__ __forceinline__ void ch_store16_sc0(uint16_t* p, uint4 v) {
+  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void ch_store_flag_sc0(unsigned* p, unsigned v) {
+  asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
   ch_u32x4 w;
@@ -161,7 +173,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) body_chain_kernel(ChainDev a) {
       gate_arrive(&gate[6 + rh], lane);
       if (q == 0) {
         gate_wait(&gate[6 + rh], done);
-        if (lane == 0) __hip_atomic_store(a.flags + 2 * strip + rh, (epoch << 8) + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) { if (CHAIN_CUT == 5) ch_store_flag_sc0(a.flags + 2 * strip + rh, (epoch << 8) + (unsigned)b); else __hip_atomic_store(a.flags + 2 * strip + rh, (epoch << 8) + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       }
       // (c) the neighbour's two rows: poll its flag, fetch, write to the halo rows of the input image
       if (has_nb && !(CHAIN_CUT >= 1 && CHAIN_CUT <= 4)) {
@@ -311,7 +323,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) body_chain_kernel(ChainDev a) {
       group_stage<2>(S, ldx, tg, rh);
 #pragma unroll
       for (int i = 0; i < GROUP_REGS; ++i)
-        if (soff[i] != 0xffffffffu) { if (CHAIN_CUT == 2 || CHAIN_CUT == 4) st16_nt(blk.out + soff[i], S[i]); else ch_store16_sc1(blk.out + soff[i], S[i]); }
+        if (soff[i] != 0xffffffffu) { if (CHAIN_CUT == 2 || CHAIN_CUT == 4) st16_nt(blk.out + soff[i], S[i]); else if (CHAIN_CUT == 5) ch_store16_sc0(blk.out + soff[i], S[i]); else ch_store16_sc1(blk.out + soff[i], S[i]); }
     }
     CH_STAMP();                                          // 11: stores issued
     if (CHAIN_STAMPS && b == a.nblk / 2) stamps[13] = __builtin_amdgcn_s_memtime();

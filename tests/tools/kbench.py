@@ -476,6 +476,9 @@ def rcab2_bench(N=32, H=48, W=48, reps=40):
                        w2=pa.w_dgrad.data_ptr(), x_out=dt2.data_ptr(), t=dt1.data_ptr(), u_out=G[1 - k].data_ptr(), maskbits=mb.data_ptr(),
                        hidden=hid.data_ptr(), gate=gate.data_ptr(), dz=dz.data_ptr(), **ca) for k in (0, 1)]
     for name, fn, pair in (('fwd', 'rumpy_rcab2_fwd', fwd), ('bwd', 'rumpy_rcab2_bwd', bwd)):
+        if globals().get('_R2_ONLY') not in (None, name):
+            continue
+
         def run():
             for i in range(reps):
                 L.call(fn, pair[i & 1], stream())
@@ -485,3 +488,43 @@ def rcab2_bench(N=32, H=48, W=48, reps=40):
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'rcab2':
     rcab2_bench()
+
+
+def rcab2_stamps(N=32, H=48, W=48):
+    """phase stamps of the conv_rcab2.hip launches (a -DRCAB2_STAMPS build: RUMPY_AMD_LIB=build_abl/R2_STAMPS/librumpy_amd.so)"""
+    import ctypes
+    lib = L.lib()
+    fn = getattr(ctypes.CDLL(os.environ['RUMPY_AMD_LIB']), 'rumpy_debug_rcab2_stamps')
+    fn.argtypes = [ctypes.c_void_p]
+    nwg = N * ((H + 5) // 6)
+    buf = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device=DEV)
+    assert fn(buf.data_ptr()) == 0
+    rcab2_bench(N, H, W, reps=3)
+    names = ['start', 'gate ready', 'tile merged', 'barrier', 'sweep 1', 'T in LDS', 'sweep 2', 'OUT in LDS', 'stores issued', 'product rows']
+    # the buffer holds the LAST launch of the bench: a backward launch; run one forward chain again for its stamps
+    for which in ('bwd', 'fwd'):
+        if which == 'fwd':
+            buf.zero_()
+            rcab2_bench_one(N, H, W, 'fwd')
+        torch.cuda.synchronize()
+        raw = buf.cpu().numpy().reshape(nwg, 8, 16).astype(np.float64)
+        k = int((raw[0, 0] > 0).sum())
+        rel = (raw[:, :, :k] - raw[:, :, :1]) * 0.01
+        print('rcab2 %s stamps, us from each wave\'s start (%s):' % (which, ', '.join(names[:k])))
+        print('   rh=0: ' + ' '.join('%.2f' % v for v in rel[:, :4].mean((0, 1))) + ' | rh=1: ' + ' '.join('%.2f' % v for v in rel[:, 4:].mean((0, 1))))
+        print('   wave start spread %.2f us; last end - first start %.2f us' % ((raw[:, :, 0].max() - raw[:, :, 0].min()) * 0.01, (raw[:, :, k - 1].max() - raw[:, :, 0].min()) * 0.01))
+
+
+def rcab2_bench_one(N, H, W, which):
+    global _R2_ONLY
+    _R2_ONLY = which
+    try:
+        rcab2_bench(N, H, W, reps=4)
+    finally:
+        _R2_ONLY = None
+
+
+_R2_ONLY = None
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'rcab2stamps':
+    rcab2_stamps()
