@@ -213,6 +213,30 @@ int rumpy_rcab2_fwd(const rumpy_rcab2_args* a, void* stream);
 int rumpy_rcab2_bwd(const rumpy_rcab2_args* a, void* stream);
 int rumpy_rcab2_partials(int32_t N, int32_t H, int32_t W);      /* rows of part_out per image */
 
+/* ---- ABI 5: a CHAIN of residual blocks in one persistent launch (conv_chain.hip): the ResBlock forms of rumpy_conv_block - backward = 0:
+ * t = relu(conv1(x) + b1) [mask bytes -> maskbits], out = x + scale2 * (conv2(t) + b2) [+ res2]; backward = 1: t = maskbits . scale1 * convA(x),
+ * out = x + scale2 * convB(t) [+ res2] - for `nblocks` blocks, block b's x BEING block b - 1's out.  A workgroup keeps its strip in LDS from block to block;
+ * the halo rows travel between vertical neighbours through the XCD's L2 (strips are claimed per XCD: all strips of an image run behind one L2) or, for a
+ * strip that had to be claimed from another XCD, through the memory side.  Bitwise the per-block launches.  Needs N * ceil(H/6) <= CUs, W <= 48, and
+ * `work` = rumpy_res_chain_work_bytes(N, H) bytes, zeroed once.  *status (device word, zero it once) becomes 0x4ff / 0x500 + block after a hand-off that
+ * timed out: the results of that launch are invalid.  fake_xcc / force_sc1: test hooks (0 in production). */
+typedef struct {
+  const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
+  const void* res2; void* t; void* out; void* maskbits;
+  float scale1, scale2;
+} rumpy_res_chain_block;
+typedef struct {
+  const void* blocks;      /* DEVICE array of rumpy_res_chain_block */
+  int32_t nblocks, N, H, W;
+  int32_t backward, fmt;   /* fmt: RUMPY_FMT_*; F16 with backward = 0 only */
+  void* work; int64_t work_bytes; void* status;
+  int32_t fake_xcc;        /* test hook: > 0 = pretend workgroup b runs on XCD b % fake_xcc (claim bookkeeping under oversubscription); needs force_sc1 */
+  int32_t force_sc1;       /* test hook / A-B: every hand-off through the memory side */
+} rumpy_res_chain_args;
+int rumpy_res_chain(const rumpy_res_chain_args* a, void* stream);
+int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H);
+int rumpy_device_xcds(void);   /* accelerator dies (XCDs, each with its own L2) of the current device: 8 on MI355X */
+
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
  * Replaces nn.Conv2d(in_features, n_feats, 3, p=1): architectures.py:216,232 (EDSR head), :153,167 (RCAN head). */
 typedef struct {

@@ -67,6 +67,16 @@ class Rcab2Args(_S):
                 ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cr', c_int32), ('np_in', c_int32), ('fmt', c_int32)]
 
 
+class ResChainBlock(_S):
+    _fields_ = [('x', c_void_p), ('w1', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('res2', c_void_p), ('t', c_void_p), ('out', c_void_p),
+                ('maskbits', c_void_p), ('scale1', c_float), ('scale2', c_float)]
+
+
+class ResChainArgs(_S):
+    _fields_ = [('blocks', c_void_p), ('nblocks', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('backward', c_int32), ('fmt', c_int32),
+                ('work', c_void_p), ('work_bytes', c_int64), ('status', c_void_p), ('fake_xcc', c_int32), ('force_sc1', c_int32)]
+
+
 class Op(_S):
     _fields_ = [('fn', c_void_p), ('args', c_void_p)]
 
@@ -306,6 +316,9 @@ SYMBOLS = {
     'rumpy_fp8_site_entries': (C.c_int, [c_int32, c_int32, c_int32]),
     'rumpy_fp8_convert': (C.c_int, [c_void_p, C.c_float, c_void_p, c_int32, c_int32, c_void_p]),
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
+    'rumpy_res_chain': (C.c_int, [_P(ResChainArgs), c_void_p]),
+    'rumpy_res_chain_work_bytes': (c_int64, [c_int32, c_int32]),
+    'rumpy_device_xcds': (C.c_int, []),
     'rumpy_rcab2_fwd': (C.c_int, [_P(Rcab2Args), c_void_p]),
     'rumpy_rcab2_bwd': (C.c_int, [_P(Rcab2Args), c_void_p]),
     'rumpy_rcab2_partials': (C.c_int, [c_int32, c_int32, c_int32]),

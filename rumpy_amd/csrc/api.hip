@@ -1,5 +1,6 @@
 // Error reporting, device query and the timing probe of the C ABI.
 #include "common.hpp"
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <vector>
@@ -59,6 +60,17 @@ extern "C" int rumpy_device_cus(void) {
     else cus = 256;  // MI355X
   }
   return cus;
+}
+
+// XCDs of the current device (conv_chain.hip assigns whole images to XCDs): MI355X = 8 dies of 32 CUs; RUMPY_XCDS overrides
+extern "C" int rumpy_device_xcds(void) {
+  static int n = 0;
+  if (n == 0) {
+    const char* e = getenv("RUMPY_XCDS");
+    n = e ? atoi(e) : 0;
+    if (n <= 0 || n > 16) { const int cus = rumpy_device_cus(); n = cus >= 64 ? 8 : 1; }
+  }
+  return n;
 }
 
 // ---- timing probe ---------------------------------------------------------------------------------------

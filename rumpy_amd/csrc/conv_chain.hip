@@ -1,0 +1,380 @@
+// A chain of residual blocks (the EDSR body, forward or data-gradient direction) in ONE persistent launch - conv_block.hip's block with the strip
+// resident in LDS from block to block, the two halo rows above and below handed over by the vertical neighbours THROUGH THE XCD'S L2 (round 5).
+//
+// History (DESIGN_HISTORY.md 4.2 items 5, 10, 12): two earlier chains lost to per-block launches because a hand-off between workgroups went through
+// the memory side - on this 8-XCD part a write that another XCD must see is a write-through to HBM, 0.45 us per hop plus the acknowledgement in the
+// chain.  tests/tools/overlap/xcd_probe.hip (round 4) showed the way out: an sc1 LOAD is served by the XCD's own L2 when the line is there, so a
+// record stored with sc0 ONLY (stays dirty in the writer's L2) reaches a reader on the SAME XCD in 0.29 us and never leaves the die.  Round 5 measured
+// what that buys the chain (profiles/r05_chain_xcd_local.txt: 16 blocks 32 x 48 x 48, training form): 225 / 231 us forward / data gradient against
+// 268 / 265 us for one launch per block (-16 % / -13 %; memory-side hand-off: 289 / 285; no hand-off at all - wrong results - 219 / 220).
+//
+// Made correct by construction, not by dispatch order: a workgroup does not run strip blockIdx.x - it reads the XCD it is on (s_getreg XCC_ID) and
+// CLAIMS a strip from that XCD's counter.  XCD x owns the images x, x + 8, ...: all strips of an image are claimed by workgroups behind one L2,
+// whatever order or placement the dispatcher chose.  A workgroup whose XCD is oversubscribed (its counter is past its share: another queue holds CUs
+// elsewhere) claims a leftover strip of another XCD.  Every strip publishes where it physically runs; a row half hands its rows over with sc0 stores
+// only if the neighbour that reads them sits on the same XCD, and with write-through (sc1) stores otherwise.  Loads are sc1 everywhere: they see a
+// dirty line of the own L2 and, failing that, the memory side - never a stale copy (the probe's cross-XCD sc1 / sc1 ping-pong relies on the same).
+// OUT rows stored sc0 are ordinary dirty L2 lines: written back at the end of the kernel like any store, for the launches that follow.
+//
+// Needs every strip co-resident (N * ceil(H/6) <= CUs, one 512-thread workgroup per CU): a poll that does not complete within ~0.1 s stores a code in
+// *status (read back with the loss; the handler raises).  W <= 48.  Everything inside a block - sweeps, epilogues, row-half gates, whole-line stores -
+// is conv_block.hip (forms 1 and 3): the results are bitwise those of one launch per block (tests/test_chain_gpu.py).
+#include "block_common.hpp"
+
+struct ChainBlk {
+  const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
+  const uint16_t* res2; uint16_t* t; uint16_t* out; unsigned char* mbits; float scale1, scale2;
+};
+static_assert(sizeof(ChainBlk) == sizeof(rumpy_res_chain_block), "rumpy_res_chain_block is the device-side block record");
+// work buffer (unsigned words): [0] launch epoch, [CH_W_COUNT + x] strips claimed on XCD x, [CH_W_WHERE + s] (epoch << 8) + XCD strip s runs on,
+// then per (strip, row half) ONE 128-BYTE LINE whose first word is the flag: (epoch << 8) + last block whose rows of that half are visible.  A line
+// per flag, because flags may be stored sc0: a line that is dirty in an XCD's L2 for ONE word would serve that XCD's polls of its other words stale
+constexpr int CH_W_COUNT = 8, CH_W_WHERE = 32, CH_MAX_XCD = 16, CH_FLAG_STRIDE = 32;
+struct ChainDev { const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* work; const unsigned* epoch; unsigned* status; int nxcd, fake_xcc, force_sc1; };
+constexpr unsigned CH_SPIN = 1u << 20;
+typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ch_store16_sc1(uint16_t* p, uint4 v) {
+  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");   // s_nop: the >64-bit store data hazard is ours inside asm
+}
+__device__ __forceinline__ void ch_store16_sc0(uint16_t* p, uint4 v) {
+  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void ch_store_flag_sc0(unsigned* p, unsigned v) {
+  asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
+  ch_u32x4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory");
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
+
+// FORM 1: forward (ReLU, mask bytes written if given); FORM 3: data gradient (* scale1, mask bytes read)
+template <int FORM, int FMT = RUMPY_FMT_BF16>
+__global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  __shared__ unsigned gate[8];             // per row half: T rows written [0,1], OUT rows written [2,3], halo rows in LDS [4,5], stores acknowledged [6,7]
+  unsigned char* const ldx = lds;
+  unsigned char* const ldt = lds + BXBYTES;
+  const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = wave & 3, rh = wave >> 2;
+  const unsigned epoch = *a.epoch;
+  // ---- which strip this workgroup runs: CLAIMED, per XCD (top of this file) ----
+  __shared__ int claim[2];
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    if (a.fake_xcc > 0) xcc = blockIdx.x % (unsigned)a.fake_xcc;      // (test hook: the claims' bookkeeping under heavy oversubscription; the host forces sc1 hand-offs with it)
+    const int nx = a.nxcd, me = (int)(xcc % (unsigned)nx);
+    int slot = -1;
+    for (int d = 0; slot < 0; d = (d + 1) % nx) {        // own XCD first, then the others in turn: workgroups = slots, so a free one exists while this one has none
+      const int x = (me + d) % nx;
+      const int quota = (a.N / nx + (x < a.N % nx ? 1 : 0)) * a.sy_n;      // XCD x runs the images x, x + nx, x + 2 nx, ...: whole images, all their strips behind ONE L2
+      if ((int)__hip_atomic_load(a.work + CH_W_COUNT + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= quota) continue;
+      const int t = (int)__hip_atomic_fetch_add(a.work + CH_W_COUNT + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t < quota) slot = (x + nx * (t / a.sy_n)) * a.sy_n + t % a.sy_n;
+    }
+    claim[0] = slot;
+    claim[1] = (int)xcc;
+    // where this strip physically runs, for its two neighbours (memory side: they may sit on any XCD)
+    __hip_atomic_store(a.work + CH_W_WHERE + slot, (epoch << 8) + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int strip = claim[0];
+  const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
+  const bool has_nb = (rh == 0) ? (sy > 0) : (sy + 1 < a.sy_n);
+  const int nb_strip = (rh == 0) ? strip - 1 : strip + 1;
+  unsigned* const flags = a.work + CH_W_WHERE + ((gridDim.x + 31u) & ~31u);
+  // this row half's hand-off: through the XCD's L2 (sc0 stores) when the neighbour that reads its rows runs on the same XCD, write-through otherwise
+  bool local = false;
+  if (has_nb && !a.force_sc1) {
+    unsigned w, spins = 0;
+    for (;;) {
+      w = __hip_atomic_load(a.work + CH_W_WHERE + nb_strip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((w >> 8) == epoch) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > CH_SPIN) { if (lane0 == 0) atomicExch(a.status, 0x4ffu); break; }
+    }
+    local = ((w >> 8) == epoch) && ((w & 255u) == (unsigned)claim[1]);
+  }
+  const ChainBlk b0 = a.blk[0];
+
+  // ---- block 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (conv_block.hip) ----
+  {
+    uint4 R[BREGS];
+    const int y0 = sy * BSH - 2;
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+      const int y = y0 + lr, x = lc - 1;
+      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
+      uint4 v = *reinterpret_cast<const uint4*>(b0.x + (unsigned)e);
+      if (!ok) v = make_uint4(0, 0, 0, 0);
+      R[i] = v;
+    }
+    if (tid < 8) gate[tid] = 0u;
+    if (tid < BTROWS * 2 * 8) {            // border columns of the T image: convB's zero padding, never written by the epilogues
+      const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
+      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BREGS; ++i) {
+      const int p = tid + BTHREADS * i;
+      const int pix = p >> 3, part = p & 7;
+      if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+    }
+  }
+  bf16x8 F[18];
+  {
+    const uint4* wp = b0.w1 + (size_t)q * 18 * 64 + lane0;
+#pragma unroll
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+  }
+  __syncthreads();
+
+  for (int b = 0; b < a.nblk; ++b) {
+    const ChainBlk blk = a.blk[b];
+    // Lane geometry is recomputed per block from an opaque copy of the lane id: hoisted out of the loop it would hold ~100 VGPRs for the
+    // whole chain (the sweeps' read bases alone are 5 x 16) and spill; per block it is ~150 VALU instructions.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int px = lane & 15, g = lane >> 4, tg = 64 * q + lane;
+    const int c0 = 16 * q + 4 * g;
+    const int gpair = 4 * (g & ~1);
+    const int chunk8 = 2 * q + (gpair >> 3);
+    // lane geometry that does not change from block to block: offsets of the T pairs and of this thread's store pieces in a [N,H,W,64] tensor
+    unsigned moff[6], soff[GROUP_REGS];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+      const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+      const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
+      moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int i = 0; i < GROUP_REGS; ++i) soff[i] = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+    // halo pieces of this row half: 2 rows x 48 columns x 8 chunks = 768 = 3 per thread; rows 6sy-2, 6sy-1 (half 0) or 6sy+6, 6sy+7 (half 1)
+    unsigned hoff[3], hlds[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+      const int y = (rh == 0) ? sy * BSH - 2 + r : sy * BSH + BSH + r;
+      hoff[i] = (has_nb && (unsigned)y < (unsigned)a.H && col < a.W) ? (unsigned)(((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+      hlds[i] = swz(((rh == 0) ? r : BSH + 2 + r) * BCOLS + col + 1, p & 7);
+    }
+    const unsigned done = 4u * (unsigned)b;              // gate counts at the end of block b - 1
+    unsigned MB[FORM == 3 ? 6 : 1];
+    if (FORM == 3) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) MB[FORM == 3 ? k : 0] = blk.mbits[(moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3];
+    }
+    f32x4 acc[4][3];                                     // wave row jr (T row 4rh + jr)
+    {
+      f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (blk.b1) { const float4 t = *reinterpret_cast<const float4*>(blk.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+    }
+    unsigned off[8][2];
+    if (b == 0) {
+      sweep_bases(off, 0u, 4 * rh, px, g);
+      block_sweep<4, FMT>(acc, F, lds, off);
+    } else {
+      // (a) the two T rows that need no halo row: row half 0 -> T rows 2, 3 (wave rows 2, 3); row half 1 -> T rows 4, 5 (wave rows 0, 1)
+      gate_wait(&gate[2], done);
+      gate_wait(&gate[3], done);                         // both halves' OUT rows of block b - 1 are in LDS (and nobody reads the old T image)
+      sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
+      // (b) publish block b - 1: this wave's OUT stores are acknowledged -> count in -> one lane stores the flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      gate_arrive(&gate[6 + rh], lane);
+      if (q == 0) {
+        gate_wait(&gate[6 + rh], done);
+        if (lane == 0) { if (local) ch_store_flag_sc0(flags + (2 * strip + rh) * CH_FLAG_STRIDE, (epoch << 8) + (unsigned)b); else __hip_atomic_store(flags + (2 * strip + rh) * CH_FLAG_STRIDE, (epoch << 8) + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+      // (c) the neighbour's two rows: poll its flag, fetch, write to the halo rows of the input image
+      if (has_nb) {
+        const unsigned want = (epoch << 8) + (unsigned)b;
+        unsigned spins = 0;
+        for (;;) {
+          const unsigned f = __hip_atomic_load(flags + (2 * nb_strip + (1 - rh)) * CH_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f >> 8) == epoch && (f & 0xffu) >= (want & 0xffu)) break;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + (unsigned)b); break; }
+        }
+      }
+      uint4 Hr[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        Hr[i] = ch_load16_sc1(blk.x + (hoff[i] != 0xffffffffu ? hoff[i] : 0u));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (hoff[i] != 0xffffffffu) *reinterpret_cast<uint4*>(ldx + hlds[i]) = Hr[i];
+      gate_arrive(&gate[4 + rh], lane);
+      gate_wait(&gate[4 + rh], done);
+      // (d) the two T rows that do: row half 0 -> T rows 0, 1 (input rows 0 .. 3); row half 1 -> T rows 6, 7 (input rows 6 .. 9)
+      sweep_bases(off, 0u, (rh == 0) ? 0 : 6, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 0 : 2]), F, lds, off);
+    }
+    // second filter: L2 hits that land under the epilogue
+    {
+      const uint4* wp = blk.w2 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    }
+    // ---- epilogue 1 (conv_block.hip): pairs k < 4: (row k, col tile 0 | 1); k = 4: rows 0 | 1 of col tile 2; k = 5: rows 2 | 3 ----
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2];
+      f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2];
+      if (FORM == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { tx[j] = relu_f32(tx[j]); ty[j] = relu_f32(ty[j]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { tx[j] *= blk.scale1; ty[j] *= blk.scale1; }
+      }
+      float v[8];
+      pair_up(tx, ty, g, v);
+      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+      uint4 o = make_uint4(0, 0, 0, 0);                  // outside the image: convB's zero padding
+      if (moff[k] != 0xffffffffu) {
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+        o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
+      }
+      *reinterpret_cast<uint4*>(ldt + swz((4 * rh + jr) * BCOLS + 16 * c + px + 1, chunk8)) = o;
+    }
+    gate_arrive(&gate[rh], lane);
+    gate_wait(&gate[rh], done + 4u);
+    if (rh == 1) gate_wait(&gate[0], done + 4u);
+    // the row half's own strip rows of T (+ mask bytes) -> HBM from the LDS image: whole lines, non-temporal, under the second sweep
+    uint4 S[GROUP_REGS];
+    const bool t_out = blk.t != nullptr;
+    if (t_out) group_stage<1>(S, ldt, tg, rh);
+    auto t_store = [&](int grp) {
+      if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
+        const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
+        if (t_out && soff[i] != 0xffffffffu) {
+          st16_nt(blk.t + soff[i], S[i]);
+          if (FORM == 1 && blk.mbits) blk.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+        }
+      }
+    };
+    // ---- phase 2: OUT = X + scale2 * (convB(T) + b2) [+ res2], in place over the input image's centre rows ----
+    f32x4 acc2[3][3];
+    {
+      f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (blk.b2) { const float4 t = *reinterpret_cast<const float4*>(blk.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc2[r][c] = b4;
+    }
+    if (rh == 0) {
+      sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
+      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[0]), F, lds, off, t_store);
+      gate_wait(&gate[1], done + 4u);
+      sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
+      block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc2[2]), F, lds, off);
+    } else {
+      sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
+      block_sweep<3, FMT>(acc2, F, lds, off, t_store);
+    }
+    if (b + 1 < a.nblk) {                                // the next block's first filter lands under the epilogue and the halo step
+      const uint4* wp = a.blk[b + 1].w1 + (size_t)q * 18 * 64 + lane;
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = (k < 3) ? acc2[k < 3 ? k : 0][0] : acc2[0][2];
+      const f32x4 ty = (k < 3) ? acc2[k < 3 ? k : 0][1] : acc2[1][2];
+      float v[8], m[8];
+      pair_up(tx, ty, g, v);
+      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+      const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
+      if (y < a.H && xx < a.W) {
+        unsigned char* cell = ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8);
+        unpack8<FMT>(*reinterpret_cast<const uint4*>(cell), m);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
+        if (blk.res2) {
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair)), m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += m[j];
+        }
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<uint4*>(cell) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
+    {
+      const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px;
+      if (y < a.H && xx < a.W) {
+        unsigned char* cell = ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8;
+        float v[4] = {acc2[2][2][0], acc2[2][2][1], acc2[2][2][2], acc2[2][2][3]};
+        float m[4];
+        unpack4<FMT>(*reinterpret_cast<const uint2*>(cell), m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
+        if (blk.res2) {
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0)), m);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += m[j];
+        }
+        *reinterpret_cast<uint2*>(cell) = pack4<FMT>(v[0], v[1], v[2], v[3]);
+      }
+    }
+    gate_arrive(&gate[2 + rh], lane);
+    gate_wait(&gate[2 + rh], done + 4u);
+    {                                                    // this row half's 3 OUT rows -> HBM: whole lines, write-through (the neighbours read them back)
+      group_stage<2>(S, ldx, tg, rh);
+#pragma unroll
+      for (int i = 0; i < GROUP_REGS; ++i)
+        if (soff[i] != 0xffffffffu) { if (local) ch_store16_sc0(blk.out + soff[i], S[i]); else ch_store16_sc1(blk.out + soff[i], S[i]); }
+    }
+  }
+}
+
+// one thread in front of every chain launch: new epoch (tags of flags and placement words), claim counters back to zero
+__global__ void block_chain_begin_kernel(unsigned* work) {
+  work[0] = (work[0] + 1u) & 0xffffffu;
+  for (int x = 0; x < CH_MAX_XCD; ++x) work[CH_W_COUNT + x] = 0u;
+}
+
+extern "C" int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H) {
+  const int64_t strips = (int64_t)N * ((H + BSH - 1) / BSH);
+  return (CH_W_WHERE + ((strips + 31) & ~(int64_t)31) + 2 * strips * CH_FLAG_STRIDE) * 4;
+}
+
+extern "C" int rumpy_res_chain(const rumpy_res_chain_args* p, void* stream) {
+  if (!p || !p->blocks || !p->work || !p->status || p->nblocks <= 0 || p->nblocks > 255) { rumpy_set_error("rumpy_res_chain: bad argument"); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW) { rumpy_set_error("rumpy_res_chain: needs 0 < W <= 48 (got %d)", p->W); return RUMPY_E_ARG; }
+  if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !p->backward)) { rumpy_set_error("rumpy_res_chain: fmt %d is a forward-only format", p->fmt); return RUMPY_E_ARG; }
+  const int sy_n = (p->H + BSH - 1) / BSH;
+  if (p->N * sy_n > rumpy_device_cus()) { rumpy_set_error("rumpy_res_chain: %d strips do not fit %d CUs (all must be co-resident)", p->N * sy_n, rumpy_device_cus()); return RUMPY_E_ARG; }
+  if (p->work_bytes < rumpy_res_chain_work_bytes(p->N, p->H)) { rumpy_set_error("rumpy_res_chain: work buffer too small"); return RUMPY_E_ARG; }
+  if (p->fake_xcc < 0 || (p->fake_xcc > 0 && !p->force_sc1)) { rumpy_set_error("rumpy_res_chain: fake_xcc (a test hook) goes with force_sc1"); return RUMPY_E_ARG; }
+  ChainDev d;
+  d.blk = reinterpret_cast<const ChainBlk*>(p->blocks); d.nblk = p->nblocks; d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;
+  d.work = (unsigned*)p->work; d.epoch = (const unsigned*)p->work; d.status = (unsigned*)p->status;
+  d.nxcd = rumpy_device_xcds(); d.fake_xcc = p->fake_xcc; d.force_sc1 = p->force_sc1;
+  if (d.fake_xcc > 0) d.nxcd = d.fake_xcc < CH_MAX_XCD ? d.fake_xcc : CH_MAX_XCD;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(block_chain_begin_kernel, dim3(1), dim3(1), 0, s, (unsigned*)p->work);
+  const dim3 grid(p->N * sy_n);
+  if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3>), grid, dim3(BTHREADS), s, d);
+  else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);
+  else RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1>), grid, dim3(BTHREADS), s, d);
+  return rumpy_check_launch("rumpy_res_chain");
+}

@@ -147,6 +147,10 @@ class SREngine:
         if self.rcab_form not in ('auto', 'lazy', 'xchg'):
             raise RuntimeError("rumpy_amd: RUMPY_RCAB_FORM is 'auto', 'lazy' or 'xchg' (got %r)" % self.rcab_form)
         self.use_mask_bytes = os.environ.get('RUMPY_NO_MASKBITS') != '1'   # ReLU mask of the block kernels as one byte per 8 channels
+        # runs of consecutive residual-block launches as ONE persistent launch with the halo rows handed over through the XCD's L2 (conv_chain.hip, round 5;
+        # bitwise the per-block launches; needs every strip co-resident: N * ceil(H/6) <= CUs, W <= 48); RUMPY_NO_CHAIN=1: one launch per block (A/B)
+        self.use_chain = os.environ.get('RUMPY_NO_CHAIN') != '1'
+        self.chain_force_sc1 = os.environ.get('RUMPY_CHAIN_SC1') == '1'       # A/B: every hand-off of the chain through the memory side
         # Evaluation plans store activations and filters as IEEE fp16 (same MFMA rate and bytes as bf16, 11 instead of 8 significant bits):
         # bf16 storage alone costs a >= 30 dB model 0.02-0.03 dB of Y-PSNR against the fp32 reference (fixtures G17 / G18).
         # Training stays bf16 (gradient range).  An output that is not finite (fp16 overflow) switches the engine back to bf16 for good.
@@ -788,6 +792,7 @@ class SREngine:
                                            loss=_ptr(plan.loss), N=N, C=Cout, H=h, W=w, grid_x=tail_grid, wslab=_ptr(plan.tail_wslab),
                                            nonfinite=_ptr(plan.nonfinite), fmt=fmt)
         if not train:
+            self._chain_runs(plan, fwd, 0)
             return plan
 
         # =============================== backward ===============================
@@ -860,7 +865,45 @@ class SREngine:
 
         # ---- grouped weight gradients ----
         self._emit_wgrad(plan, wjobs, N)
+        self._chain_runs(plan, fwd, 0)
+        self._chain_runs(plan, bwd, 1)
         return plan
+
+    def _chain_runs(self, plan, ops, backward):
+        """replace every maximal run (>= 2) of consecutive ResBlock-form rumpy_conv_block launches, each reading the previous one's output, by ONE
+        rumpy_res_chain launch (conv_chain.hip).  In place: `ops` is the plan's launch list."""
+        N, H, W = plan.N, plan.H, plan.W
+        if not self.use_chain or self.wide or W > 48 or N * ((H + 5) // 6) > self.cus:
+            return
+
+        def chainable(a):
+            if a.res_mode != 0 or a.pool or a.w1_f8 or a.col_tile or a.N != N or a.H != H or a.W != W:
+                return False
+            if backward:
+                return (not a.relu1) and bool(a.maskbits) and a.fmt == 0
+            return bool(a.relu1) and a.scale1 == 1.0 and not a.mask
+        i = 0
+        while i < len(ops):
+            j = i
+            if ops[i][0] == 'rumpy_conv_block' and chainable(ops[i][1]):
+                j = i + 1
+                while j < len(ops) and ops[j][0] == 'rumpy_conv_block' and chainable(ops[j][1]) and ops[j][1].x == ops[j - 1][1].out and ops[j][1].fmt == ops[i][1].fmt:
+                    j += 1
+            if j - i >= 2:
+                blocks = [a for _, a in ops[i:j]]
+                tab = (L.ResChainBlock * len(blocks))(*[L.ResChainBlock(x=a.x, w1=a.w1, b1=a.b1, w2=a.w2, b2=a.b2, res2=a.res2, t=a.t, out=a.out,
+                                                                          maskbits=a.maskbits, scale1=a.scale1, scale2=a.scale2) for a in blocks])
+                dev = self._to_device_bytes(tab)
+                if getattr(plan, 'chain_work', None) is None:
+                    plan.chain_work = torch.zeros(int(self.lib.rumpy_res_chain_work_bytes(N, H)), dtype=torch.uint8, device=self.device)
+                    plan.rcab_status = plan.flags[1:2]          # the hand-off watchdog shares the strip-exchange status word (read back with the loss)
+                plan.keep += [dev, plan.chain_work]
+                args = L.ResChainArgs(blocks=_ptr(dev), nblocks=len(blocks), N=N, H=H, W=W, backward=backward, fmt=blocks[0].fmt, work=_ptr(plan.chain_work),
+                                      work_bytes=plan.chain_work.numel(), status=_ptr(plan.flags[1:2]), fake_xcc=0, force_sc1=1 if self.chain_force_sc1 else 0)
+                args._blocks_host = tab            # (kept alive with the argument block)
+                ops[i:j] = [('rumpy_res_chain', args)]
+                j = i + 1
+            i = max(j, i + 1)
 
     def _emit_styled_rcab(self, plan, fwd, bwd, wjobs, nodes, c1, c2, ca, cur, N, H, W, tiles, train, act, release):
         """A QRCAB whose channel-attention gate also reads the attribute vector (StyledCAParams): the residual block in one launch with pool

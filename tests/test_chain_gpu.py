@@ -1,0 +1,149 @@
+"""-m gpu parity of conv_chain.hip (round 5): a run of residual blocks (the EDSR body, forward or data-gradient direction) as ONE persistent launch -
+strips claimed per XCD, halo rows handed over through the XCD's L2 (sc0 stores / sc1 loads) or, where a strip had to be claimed from another XCD,
+through the memory side.  Reference: rumpy/SISR/models/advanced/common.py ResBlock, architectures.py:198-241 (EDSR.forward).
+
+The chain must be BITWISE the per-block launches (rumpy_conv_block, itself checked against torch fp32 in tests/test_kernels_gpu.py): in every hand-off
+form (XCD-local, memory side forced, claim bookkeeping under a faked heavy oversubscription), next to a foreign kernel that really holds CUs, and as the
+engine uses it (EDSR training and evaluation plans against RUMPY_NO_CHAIN=1)."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_utils import BF16, DEV, PackedConv, stream, to_dev_bytes
+from oracle import sr_oracle as O
+from rumpy_amd import _lib as L
+from tests.test_network_gpu import _handler, _pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False):
+    gen = np.random.default_rng(seed)
+    convs = [(PackedConv(torch.from_numpy(gen.uniform(-0.05, 0.05, (64, 64, 3, 3)).astype(np.float32)), torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32))),
+              PackedConv(torch.from_numpy(gen.uniform(-0.05, 0.05, (64, 64, 3, 3)).astype(np.float32)), torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32))))
+             for _ in range(nblk)]
+    dt = torch.float16 if fmt else BF16
+    rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(dt)
+    x0, extra = rnd(), rnd()
+    masks = [torch.from_numpy(gen.integers(0, 256, (N, H, W, 8), dtype=np.uint8)).to(DEV) for _ in range(nblk)]
+    if fmt:
+        items = []
+        for pa, pb in convs:
+            for pc in (pa, pb):
+                pc.w_h = torch.zeros(64 * 64 * 9, dtype=torch.float16, device=DEV)
+                items.append(L.PackItem(w=pc.w.data_ptr(), b=pc.b.data_ptr(), w_fwd=pc.w_h.data_ptr(), w_dgrad=None, b_packed=None, cout=64, cin=64, kind=0, shuffle=0, fmt=L.FMT_F16))
+        tab = to_dev_bytes((L.PackItem * len(items))(*items))
+        L.check(L.lib().rumpy_pack_weights(tab.data_ptr(), len(items), stream()), 'pack')
+    outs = {}
+    for form in ('blocks', 'chain'):
+        ts = [torch.full((N, H, W, 64), float('nan'), dtype=dt, device=DEV) for _ in range(nblk)] if (backward or not fmt) else [None] * nblk
+        ys = [torch.full((N, H, W, 64), float('nan'), dtype=dt, device=DEV) for _ in range(nblk)]
+        mbs = masks if backward else [torch.zeros(N, H, W, 8, dtype=torch.uint8, device=DEV) for _ in range(nblk)]
+        recs = []
+        for b, (pa, pb) in enumerate(convs):
+            x = x0 if b == 0 else ys[b - 1]
+            if backward:
+                recs.append(dict(x=x.data_ptr(), w1=pb.w_dgrad.data_ptr(), b1=None, w2=pa.w_dgrad.data_ptr(), b2=None, res2=extra.data_ptr() if b == nblk - 1 else None,
+                                 t=ts[b].data_ptr(), out=ys[b].data_ptr(), maskbits=mbs[b].data_ptr(), scale1=0.1, scale2=1.0))
+            else:
+                w1, w2 = (pa.w_h, pb.w_h) if fmt else (pa.w_fwd, pb.w_fwd)
+                recs.append(dict(x=x.data_ptr(), w1=w1.data_ptr(), b1=pa.b_packed.data_ptr(), w2=w2.data_ptr(), b2=pb.b_packed.data_ptr(), res2=None,
+                                 t=ts[b].data_ptr() if ts[b] is not None else None, out=ys[b].data_ptr(), maskbits=None if fmt else mbs[b].data_ptr(), scale1=1.0, scale2=0.1))
+        if form == 'blocks':
+            for r in recs:
+                L.call('rumpy_conv_block', L.BlockArgs(N=N, H=H, W=W, relu1=0 if backward else 1, fmt=fmt, **r), stream())
+        else:
+            tab = to_dev_bytes((L.ResChainBlock * nblk)(*[L.ResChainBlock(**r) for r in recs]))
+            work = torch.zeros(int(L.lib().rumpy_res_chain_work_bytes(N, H)), dtype=torch.uint8, device=DEV)
+            status = torch.zeros(1, dtype=torch.int32, device=DEV)
+            a = L.ResChainArgs(blocks=tab.data_ptr(), nblocks=nblk, N=N, H=H, W=W, backward=1 if backward else 0, fmt=fmt, work=work.data_ptr(),
+                               work_bytes=work.numel(), status=status.data_ptr(), **hooks)
+            side = torch.cuda.Stream()
+            for rep in range(3):           # (launch epochs: the same work buffer serves launch after launch)
+                if disturb:
+                    L.check(L.lib().rumpy_debug_occupy(48, 20000.0, side.cuda_stream), 'occupy')
+                L.call('rumpy_res_chain', a, stream())
+            torch.cuda.synchronize()
+            assert int(status.item()) == 0
+        torch.cuda.synchronize()
+        outs[form] = [t for t in ts if t is not None] + ys + ([] if backward or fmt else mbs)
+    for i, (p, q) in enumerate(zip(outs['blocks'], outs['chain'])):
+        assert torch.isfinite(p.float()).all() or p.dtype == torch.uint8
+        assert torch.equal(p.view(torch.uint8), q.view(torch.uint8)), (i, hooks)
+
+
+HOOKS = [dict(fake_xcc=0, force_sc1=0), dict(fake_xcc=0, force_sc1=1), dict(fake_xcc=3, force_sc1=1), dict(fake_xcc=1, force_sc1=1), dict(fake_xcc=16, force_sc1=1)]
+
+
+@pytest.mark.parametrize('hooks', HOOKS)
+@pytest.mark.parametrize('N,H,W,nblk,backward,fmt', [(32, 48, 48, 6, 0, 0), (32, 48, 48, 6, 1, 0), (5, 20, 37, 3, 0, 0), (5, 20, 37, 3, 1, 0), (3, 13, 48, 4, 0, 1),
+                                                     (1, 5, 9, 2, 0, 0), (7, 31, 24, 5, 1, 0)])
+def test_chain_is_bitwise_the_per_block_launches(N, H, W, nblk, backward, fmt, hooks):
+    _chain_case(N, H, W, nblk, backward, fmt, hooks, 900 + N + H)
+
+
+@pytest.mark.parametrize('backward', [0, 1])
+def test_chain_next_to_a_foreign_kernel_that_holds_cus(backward):
+    """256 strips on 256 CUs while another queue holds 24-48 of them (rumpy_debug_occupy, 48 workgroups x 80 KiB of LDS, 20 ms at a time): the
+    chain's workgroups arrive late and on whatever XCD has room - strips are claimed, oversubscribed XCDs hand their surplus to others (memory-side
+    hand-off there), nothing may time out and every buffer must equal the per-block launches'."""
+    _chain_case(32, 48, 48, 8, backward, 0, dict(fake_xcc=0, force_sc1=0), 77, disturb=True)
+
+
+def test_chain_refuses_what_it_cannot_run():
+    work = torch.zeros(int(L.lib().rumpy_res_chain_work_bytes(40, 48)), dtype=torch.uint8, device=DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    a = L.ResChainArgs(blocks=work.data_ptr(), nblocks=2, N=40, H=48, W=48, work=work.data_ptr(), work_bytes=work.numel(), status=st.data_ptr())
+    assert L.lib().rumpy_res_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()      # 320 strips > 256 CUs
+    a.N, a.W = 2, 64
+    assert L.lib().rumpy_res_chain(a, None) == -1 and b'W <= 48' in L.lib().rumpy_last_error()
+    a.W, a.fake_xcc = 48, 3
+    assert L.lib().rumpy_res_chain(a, None) == -1 and b'force_sc1' in L.lib().rumpy_last_error()
+    assert L.lib().rumpy_device_xcds() == 8
+
+
+@pytest.mark.parametrize('mode', ['local', 'sc1'])
+def test_edsr_training_and_evaluation_on_the_chain_equal_the_per_block_launches(mode, monkeypatch):
+    """EDSR x4, 6 blocks, three training steps at 32 x 48 x 48 and an evaluation image: with the chain (forward + data gradient, one launch each) and with
+    RUMPY_NO_CHAIN=1 - losses, outputs, weights and the evaluation image bit for bit; the plans really differ."""
+    kw = dict(scale=4, num_blocks=6, res_scale=0.1)
+    res = []
+    for no_chain in ('0', '1'):
+        monkeypatch.setenv('RUMPY_NO_CHAIN', no_chain)
+        monkeypatch.setenv('RUMPY_CHAIN_SC1', '1' if mode == 'sc1' else '0')
+        h, _ = _pair('edsr', 511, sched=False, **kw)
+        losses = []
+        for step in range(3):
+            x, y = O.synthetic_batch(690 + step, 32, lr_hw=48, scale=4)
+            loss, out = h.run_train(x=x, y=y)
+            losses.append(float(loss))
+        xe, _ = O.synthetic_batch(699, 1, lr_hw=(40, 44), scale=4)
+        ev, _, _ = h.run_eval(x=xe)
+        eng = h.net.engine
+        tp, ep = eng.plan_for(32, 48, 48, True), eng.plan_for(1, 40, 44, False, eng.eval_fmt)
+        for ops in (tp.fwd, tp.bwd, ep.fwd):
+            names = [op for op, _ in ops]
+            assert (names.count('rumpy_res_chain') == 1 and 'rumpy_conv_block' not in names) == (no_chain == '0'), names
+        assert eng.exchange_status() == 0
+        res.append((losses, out.clone(), ev.clone(), h.net.flat_p.detach().cpu().clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+
+
+def test_chain_is_deterministic_at_the_headline_shape():
+    kw = dict(scale=4, num_blocks=16, res_scale=0.1)
+    x, y = O.synthetic_batch(671, 32, lr_hw=48, scale=4)
+    h = _handler('edsr', lr=1e-3, **kw)
+    h.net.load_state_dict(O.seeded_state_dict(O.build_oracle('edsr', **kw), 826))
+    xd, yd = x.cuda(), y.cuda()
+    ref = None
+    for rep in range(12):
+        _, out = h.net.fused_l1_forward_backward(xd, yd)
+        torch.cuda.synchronize()
+        cur = (out.detach().clone(), h.net.flat_g.detach().clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(ref[0], cur[0]) and torch.equal(ref[1].view(torch.int32), cur[1].view(torch.int32)), rep
+    h.net.take_early_loss()
+    plan = h.net.engine.plan_for(32, 48, 48, True)
+    assert [op for op, _ in plan.fwd].count('rumpy_res_chain') == 1 and h.net.engine.exchange_status() == 0

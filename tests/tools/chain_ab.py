@@ -4,6 +4,7 @@ The forward and backward runs of consecutive rumpy_conv_block launches of an EDS
 every buffer the launches write must be bitwise the same; then both forms are timed.  Timing variants of the kernel: make -C tests/tools/csrc
 clean all EXTRA=-DCHAIN_ABL=<v> (1 = no hand-off at all, 3 = also no T stores; >= 9 adds phase stamps, printed here)."""
 import ctypes as C, os, sys, tempfile, numpy as np, torch
+os.environ['RUMPY_NO_CHAIN'] = '1'      # the plan's per-block launches are what this tool re-issues as a chain
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
