@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r05_suite; rm -rf $O; mkdir -p $O
+python3 -m pytest tests -m gpu -q -x > $O/gpu_suite.log 2>&1; tail -12 $O/gpu_suite.log
+python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
