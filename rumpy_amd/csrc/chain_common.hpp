@@ -1,0 +1,76 @@
+// Shared by conv_chain.hip (a run of residual blocks per persistent launch) and conv_rcab_chain.hip (a run of RCABs): where a workgroup's strip comes
+// from (claimed per XCD), which of its hand-offs may stay inside the XCD's L2, and the store / load forms of the two hand-offs.  Design: conv_chain.hip.
+#pragma once
+#include "block_common.hpp"
+
+// work buffer (unsigned words): [0] launch epoch, [CH_W_COUNT + x] strips claimed on XCD x, [CH_W_WHERE + s] (epoch << 8) + XCD strip s runs on,
+// then per (strip, row half) ONE 128-BYTE LINE whose first word is the flag: (epoch << 8) + last block whose rows of that half are visible.  A line
+// per flag, because flags may be stored sc0: a line that is dirty in an XCD's L2 for ONE word would serve that XCD's polls of its other words stale
+constexpr int CH_W_COUNT = 8, CH_W_WHERE = 32, CH_MAX_XCD = 16, CH_FLAG_STRIDE = 32;
+constexpr unsigned CH_SPIN = 1u << 20;
+typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void ch_store16_sc1(uint16_t* p, uint4 v) {
+  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");   // s_nop: the >64-bit store data hazard is ours inside asm
+}
+__device__ __forceinline__ void ch_store16_sc0(uint16_t* p, uint4 v) {
+  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ void ch_store_flag_sc0(unsigned* p, unsigned v) {
+  asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
+  ch_u32x4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory");
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
+
+struct ChainPlace { int strip; unsigned xcc; };
+// Thread 0 of the workgroup claims a strip (own XCD first, then the others in turn: workgroups = slots, so a free one exists while this one has none),
+// publishes where it physically runs, and hands both to the workgroup through `claim` (LDS, two ints); ends with a workgroup barrier.
+// XCD x runs the images x, x + nx, x + 2 nx, ...: whole images, all their strips behind ONE L2.
+__device__ __forceinline__ ChainPlace chain_claim(unsigned* work, unsigned epoch, int N, int sy_n, int nx, int fake_xcc, int* claim) {
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15u;
+    if (fake_xcc > 0) xcc = blockIdx.x % (unsigned)fake_xcc;      // (test hook: the claims' bookkeeping under heavy oversubscription; the host forces sc1 hand-offs with it)
+    const int me = (int)(xcc % (unsigned)nx);
+    int slot = -1;
+    for (int d = 0; slot < 0; d = (d + 1) % nx) {
+      const int x = (me + d) % nx;
+      const int quota = (N / nx + (x < N % nx ? 1 : 0)) * sy_n;
+      if ((int)__hip_atomic_load(work + CH_W_COUNT + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= quota) continue;
+      const int t = (int)__hip_atomic_fetch_add(work + CH_W_COUNT + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t < quota) slot = (x + nx * (t / sy_n)) * sy_n + t % sy_n;
+    }
+    claim[0] = slot;
+    claim[1] = (int)xcc;
+    __hip_atomic_store(work + CH_W_WHERE + slot, (epoch << 8) + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // memory side: the neighbours may sit on any XCD
+  }
+  __syncthreads();
+  ChainPlace p;
+  p.strip = claim[0];
+  p.xcc = (unsigned)claim[1];
+  return p;
+}
+// does strip `nb` run on this workgroup's XCD?  (polls the word its workgroup publishes at claim time)
+__device__ __forceinline__ bool chain_same_xcd(unsigned* work, unsigned epoch, int nb, unsigned my_xcc, unsigned* status) {
+  unsigned w, spins = 0;
+  for (;;) {
+    w = __hip_atomic_load(work + CH_W_WHERE + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((w >> 8) == epoch) break;
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > CH_SPIN) { if ((threadIdx.x & 63) == 0) atomicExch(status, 0x4ffu); break; }
+  }
+  return ((w >> 8) == epoch) && ((w & 255u) == my_xcc);
+}
+__device__ __forceinline__ unsigned* chain_flags(unsigned* work, unsigned nstrips) { return work + CH_W_WHERE + ((nstrips + 31u) & ~31u); }
+// one thread in front of every chain launch: new epoch (tags of flags and placement words), claim counters back to zero
+static __global__ void chain_begin_kernel(unsigned* work) {
+  work[0] = (work[0] + 1u) & 0xffffffu;
+  for (int x = 0; x < CH_MAX_XCD; ++x) work[CH_W_COUNT + x] = 0u;
+}
+static inline int64_t chain_work_bytes(int64_t strips) { return (CH_W_WHERE + ((strips + 31) & ~(int64_t)31) + 2 * strips * CH_FLAG_STRIDE) * 4; }

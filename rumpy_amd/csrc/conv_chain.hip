@@ -19,37 +19,14 @@
 // Needs every strip co-resident (N * ceil(H/6) <= CUs, one 512-thread workgroup per CU): a poll that does not complete within ~0.1 s stores a code in
 // *status (read back with the loss; the handler raises).  W <= 48.  Everything inside a block - sweeps, epilogues, row-half gates, whole-line stores -
 // is conv_block.hip (forms 1 and 3): the results are bitwise those of one launch per block (tests/test_chain_gpu.py).
-#include "block_common.hpp"
+#include "chain_common.hpp"
 
 struct ChainBlk {
   const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
   const uint16_t* res2; uint16_t* t; uint16_t* out; unsigned char* mbits; float scale1, scale2;
 };
 static_assert(sizeof(ChainBlk) == sizeof(rumpy_res_chain_block), "rumpy_res_chain_block is the device-side block record");
-// work buffer (unsigned words): [0] launch epoch, [CH_W_COUNT + x] strips claimed on XCD x, [CH_W_WHERE + s] (epoch << 8) + XCD strip s runs on,
-// then per (strip, row half) ONE 128-BYTE LINE whose first word is the flag: (epoch << 8) + last block whose rows of that half are visible.  A line
-// per flag, because flags may be stored sc0: a line that is dirty in an XCD's L2 for ONE word would serve that XCD's polls of its other words stale
-constexpr int CH_W_COUNT = 8, CH_W_WHERE = 32, CH_MAX_XCD = 16, CH_FLAG_STRIDE = 32;
 struct ChainDev { const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* work; const unsigned* epoch; unsigned* status; int nxcd, fake_xcc, force_sc1; };
-constexpr unsigned CH_SPIN = 1u << 20;
-typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void ch_store16_sc1(uint16_t* p, uint4 v) {
-  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");   // s_nop: the >64-bit store data hazard is ours inside asm
-}
-__device__ __forceinline__ void ch_store16_sc0(uint16_t* p, uint4 v) {
-  const ch_u32x4 w = (ch_u32x4){v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 0" :: "v"(p), "v"(w) : "memory");
-}
-__device__ __forceinline__ void ch_store_flag_sc0(unsigned* p, unsigned v) {
-  asm volatile("global_store_dword %0, %1, off sc0" :: "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
-  ch_u32x4 w;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(p) : "memory");
-  return make_uint4(w.x, w.y, w.z, w.w);
-}
 
 // FORM 1: forward (ReLU, mask bytes written if given); FORM 3: data gradient (* scale1, mask bytes read)
 template <int FORM, int FMT = RUMPY_FMT_BF16>
@@ -61,45 +38,16 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = wave & 3, rh = wave >> 2;
   const unsigned epoch = *a.epoch;
-  // ---- which strip this workgroup runs: CLAIMED, per XCD (top of this file) ----
+  // ---- which strip this workgroup runs: CLAIMED, per XCD (top of this file; chain_common.hpp) ----
   __shared__ int claim[2];
-  if (tid == 0) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 15u;
-    if (a.fake_xcc > 0) xcc = blockIdx.x % (unsigned)a.fake_xcc;      // (test hook: the claims' bookkeeping under heavy oversubscription; the host forces sc1 hand-offs with it)
-    const int nx = a.nxcd, me = (int)(xcc % (unsigned)nx);
-    int slot = -1;
-    for (int d = 0; slot < 0; d = (d + 1) % nx) {        // own XCD first, then the others in turn: workgroups = slots, so a free one exists while this one has none
-      const int x = (me + d) % nx;
-      const int quota = (a.N / nx + (x < a.N % nx ? 1 : 0)) * a.sy_n;      // XCD x runs the images x, x + nx, x + 2 nx, ...: whole images, all their strips behind ONE L2
-      if ((int)__hip_atomic_load(a.work + CH_W_COUNT + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= quota) continue;
-      const int t = (int)__hip_atomic_fetch_add(a.work + CH_W_COUNT + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t < quota) slot = (x + nx * (t / a.sy_n)) * a.sy_n + t % a.sy_n;
-    }
-    claim[0] = slot;
-    claim[1] = (int)xcc;
-    // where this strip physically runs, for its two neighbours (memory side: they may sit on any XCD)
-    __hip_atomic_store(a.work + CH_W_WHERE + slot, (epoch << 8) + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  const int strip = claim[0];
+  const ChainPlace place = chain_claim(a.work, epoch, a.N, a.sy_n, a.nxcd, a.fake_xcc, claim);
+  const int strip = place.strip;
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
   const bool has_nb = (rh == 0) ? (sy > 0) : (sy + 1 < a.sy_n);
   const int nb_strip = (rh == 0) ? strip - 1 : strip + 1;
-  unsigned* const flags = a.work + CH_W_WHERE + ((gridDim.x + 31u) & ~31u);
+  unsigned* const flags = chain_flags(a.work, gridDim.x);
   // this row half's hand-off: through the XCD's L2 (sc0 stores) when the neighbour that reads its rows runs on the same XCD, write-through otherwise
-  bool local = false;
-  if (has_nb && !a.force_sc1) {
-    unsigned w, spins = 0;
-    for (;;) {
-      w = __hip_atomic_load(a.work + CH_W_WHERE + nb_strip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((w >> 8) == epoch) break;
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > CH_SPIN) { if (lane0 == 0) atomicExch(a.status, 0x4ffu); break; }
-    }
-    local = ((w >> 8) == epoch) && ((w & 255u) == (unsigned)claim[1]);
-  }
+  const bool local = has_nb && !a.force_sc1 && chain_same_xcd(a.work, epoch, nb_strip, place.xcc, a.status);
   const ChainBlk b0 = a.blk[0];
 
   // ---- block 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (conv_block.hip) ----
@@ -115,8 +63,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
       uint4 v = *reinterpret_cast<const uint4*>(b0.x + (unsigned)e);
-      if (!ok) v = make_uint4(0, 0, 0, 0);
-      R[i] = v;
+      R[i] = keep_if(v, ok);
     }
     if (tid < 8) gate[tid] = 0u;
     if (tid < BTROWS * 2 * 8) {            // border columns of the T image: convB's zero padding, never written by the epilogues
@@ -188,7 +135,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       sweep_bases(off, 0u, 4 * rh, px, g);
       block_sweep<4, FMT>(acc, F, lds, off);
     } else {
-      // (a) the two T rows that need no halo row: row half 0 -> T rows 2, 3 (wave rows 2, 3); row half 1 -> T rows 4, 5 (wave rows 0, 1)
+      // (a) the two T rows that need no halo row: row half 0 -> T rows 2, 3 (wave rows 2, 3); row half 1 -> T rows 4, 5 (wave rows 0, 1).
+      // (Round 5 also tried NOT to bring the halves into step here - a half waits for its own OUT rows only, computes the three T rows that need nothing
+      // from the other half, and the fourth behind the other half's gate - so that one half's epilogue could run beside the other's sweep as inside a
+      // per-block launch: bitwise equal, 28.5 k against 28.9 k patches/s on one box, profiles/r05_negative_results.txt item 6.  Not kept.)
       gate_wait(&gate[2], done);
       gate_wait(&gate[3], done);                         // both halves' OUT rows of block b - 1 are in LDS (and nobody reads the old T image)
       sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
@@ -346,15 +296,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   }
 }
 
-// one thread in front of every chain launch: new epoch (tags of flags and placement words), claim counters back to zero
-__global__ void block_chain_begin_kernel(unsigned* work) {
-  work[0] = (work[0] + 1u) & 0xffffffu;
-  for (int x = 0; x < CH_MAX_XCD; ++x) work[CH_W_COUNT + x] = 0u;
-}
-
 extern "C" int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H) {
-  const int64_t strips = (int64_t)N * ((H + BSH - 1) / BSH);
-  return (CH_W_WHERE + ((strips + 31) & ~(int64_t)31) + 2 * strips * CH_FLAG_STRIDE) * 4;
+  return chain_work_bytes((int64_t)N * ((H + BSH - 1) / BSH));
 }
 
 extern "C" int rumpy_res_chain(const rumpy_res_chain_args* p, void* stream) {
@@ -371,7 +314,7 @@ extern "C" int rumpy_res_chain(const rumpy_res_chain_args* p, void* stream) {
   d.nxcd = rumpy_device_xcds(); d.fake_xcc = p->fake_xcc; d.force_sc1 = p->force_sc1;
   if (d.fake_xcc > 0) d.nxcd = d.fake_xcc < CH_MAX_XCD ? d.fake_xcc : CH_MAX_XCD;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(block_chain_begin_kernel, dim3(1), dim3(1), 0, s, (unsigned*)p->work);
+  hipLaunchKernelGGL(chain_begin_kernel, dim3(1), dim3(1), 0, s, (unsigned*)p->work);
   const dim3 grid(p->N * sy_n);
   if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3>), grid, dim3(BTHREADS), s, d);
   else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);

@@ -793,6 +793,7 @@ class SREngine:
                                            nonfinite=_ptr(plan.nonfinite), fmt=fmt)
         if not train:
             self._chain_runs(plan, fwd, 0)
+            self._rcab_chain_runs(plan, fwd, 0)
             return plan
 
         # =============================== backward ===============================
@@ -867,7 +868,47 @@ class SREngine:
         self._emit_wgrad(plan, wjobs, N)
         self._chain_runs(plan, fwd, 0)
         self._chain_runs(plan, bwd, 1)
+        self._rcab_chain_runs(plan, fwd, 0)
+        self._rcab_chain_runs(plan, bwd, 1)
         return plan
+
+    def _rcab_chain_runs(self, plan, ops, backward):
+        """the same for the RCABs of a ResidualGroup in the 'xchg' form (rumpy_rcab_fwd / rumpy_rcab_bwd -> ONE rumpy_rcab_chain launch per group and
+        direction, conv_rcab_chain.hip: strip resident in LDS, pool sums exchanged inside the launch, bitwise the per-block launches)"""
+        N, H, W = plan.N, plan.H, plan.W
+        if not self.use_chain or W > 48 or N * ((H + 5) // 6) > self.cus:
+            return
+        name = 'rumpy_rcab_bwd' if backward else 'rumpy_rcab_fwd'
+
+        def chainable(a):
+            if a.w1_f8 or a.fmt != 0 or a.cr > 4 or a.N != N or a.H != H or a.W != W:
+                return False
+            return bool(a.maskbits and a.t2_in) if backward else True
+        i = 0
+        while i < len(ops):
+            j = i
+            if ops[i][0] == name and chainable(ops[i][1]):
+                j = i + 1
+                while j < len(ops) and ops[j][0] == name and chainable(ops[j][1]) and ops[j][1].x == ops[j - 1][1].out and ops[j][1].cr == ops[i][1].cr:
+                    j += 1
+            if j - i >= 2:
+                blocks = [a for _, a in ops[i:j]]
+                keys = ('x', 'w1', 'b1', 'w2', 'b2', 't', 't2', 't2_in', 'res2', 'out', 'maskbits', 'ca_w1', 'ca_b1', 'ca_w2', 'ca_b2', 'mean', 'hidden', 'gate', 'qgate', 'dz', 'dzq')
+                tab = (L.RcabChainBlock * len(blocks))(*[L.RcabChainBlock(**{k: getattr(a, k) for k in keys}) for a in blocks])
+                dev = self._to_device_bytes(tab)
+                if getattr(plan, 'chain_work', None) is None:
+                    plan.chain_work = torch.zeros(int(self.lib.rumpy_rcab_chain_work_bytes(N, H)), dtype=torch.uint8, device=self.device)
+                if getattr(plan, 'chain_xchg', None) is None:
+                    plan.chain_xchg = torch.zeros(N * ((H + 5) // 6) * 512, dtype=torch.uint8, device=self.device)
+                plan.rcab_status = plan.flags[1:2]
+                plan.keep += [dev, plan.chain_work, plan.chain_xchg]
+                args = L.RcabChainArgs(blocks=_ptr(dev), nblocks=len(blocks), N=N, H=H, W=W, cr=blocks[0].cr, backward=backward, work=_ptr(plan.chain_work),
+                                       work_bytes=plan.chain_work.numel(), xchg=_ptr(plan.chain_xchg), xchg_bytes=plan.chain_xchg.numel(),
+                                       status=_ptr(plan.flags[1:2]), fake_xcc=0, force_sc1=1 if self.chain_force_sc1 else 0)
+                args._blocks_host = tab
+                ops[i:j] = [('rumpy_rcab_chain', args)]
+                j = i + 1
+            i = max(j, i + 1)
 
     def _chain_runs(self, plan, ops, backward):
         """replace every maximal run (>= 2) of consecutive ResBlock-form rumpy_conv_block launches, each reading the previous one's output, by ONE

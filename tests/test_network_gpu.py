@@ -685,7 +685,7 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
         loss, out = h.run_train(x=x, y=y)
         assert h.net.engine.use_block_kernel == (no_block == '0')
         names = {op for op, _ in h.net.engine.plan_for(2, 20, 20, True).fwd}
-        fused = {'edsr': 'rumpy_res_chain', 'rcan': rcab_ops()[0]}[name]      # (EDSR: the run of block launches is one chain launch, conv_chain.hip)
+        fused = {'edsr': 'rumpy_res_chain', 'rcan': 'rumpy_rcab_chain'}[name]      # (the run of block / RCAB launches is one chain launch: conv_chain.hip, conv_rcab_chain.hip)
         assert (fused in names) == (no_block == '0')
         res.append((float(loss), out, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}))
     assert abs(res[0][0] - res[1][0]) < 1e-4 * abs(res[1][0])
@@ -715,6 +715,7 @@ def test_one_launch_rcab_matches_the_separate_attention_launches(name, kw, hw, f
     ca_bwd_reduce + ca_bwd_fused + conv_block launches (RUMPY_NO_RCAB=1).  Same operands; 'xchg' applies the gate to the fp32 accumulators
     instead of the stored conv output, 'lazy' sums the partial rows in another order: outputs agree to bf16 rounding."""
     monkeypatch.setenv('RUMPY_RCAB_FORM', form)
+    monkeypatch.setenv('RUMPY_NO_CHAIN', '1')      # (the per-block launches are what this test compares; their chain: tests/test_chain_gpu.py)
     sc = kw['scale']
     x, y = O.synthetic_batch(660, 3, lr_hw=hw, scale=sc)
     meta = torch.rand(3, 3, 1, 1, generator=torch.Generator().manual_seed(4)) if name == 'qrcan' else None
@@ -756,6 +757,7 @@ def test_one_launch_rcab_strip_heights_agree(geo, form, monkeypatch):
     the pool sums are added in strip order, so the gates - and everything behind them - agree to fp32 rounding, not bit for bit: checked
     against the separate attention launches like the other geometries."""
     monkeypatch.setenv('RUMPY_RCAB_FORM', form)
+    monkeypatch.setenv('RUMPY_NO_CHAIN', '1')
     kw = dict(scale=2, n_resgroups=2, n_resblocks=2, reduction=16)
     x, y = O.synthetic_batch(661, 3, lr_hw=(33, 70), scale=2)
     res = []

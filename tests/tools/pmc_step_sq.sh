@@ -13,7 +13,7 @@ import csv,glob,collections
 for f in glob.glob('gpurun_out/pmcq_${M}/*counter_collection.csv'):
     by=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if any(t in r['Kernel_Name'] for t in ('rcab_kernel', 'conv_block_kernel', 'rcab_fp8_kernel', 'conv_block_fp8_kernel')):
+        if any(t in r['Kernel_Name'] for t in ('rcab_kernel', 'rcab2_kernel', 'conv_block_kernel', 'block_chain_kernel', 'rcab_fp8_kernel', 'conv_block_fp8_kernel')):
             by[(r['Kernel_Name'][:48], r['Counter_Name'])].append(float(r['Counter_Value']))
     for k,v in sorted(by.items()):
         v=v[len(v)//2:]
@@ -21,7 +21,7 @@ for f in glob.glob('gpurun_out/pmcq_${M}/*counter_collection.csv'):
 for f in glob.glob('gpurun_out/pmcq_${M}/*kernel_trace.csv'):
     by=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if any(t in r['Kernel_Name'] for t in ('rcab_kernel', 'conv_block_kernel', 'rcab_fp8_kernel', 'conv_block_fp8_kernel')):
+        if any(t in r['Kernel_Name'] for t in ('rcab_kernel', 'rcab2_kernel', 'conv_block_kernel', 'block_chain_kernel', 'rcab_fp8_kernel', 'conv_block_fp8_kernel')):
             by[r['Kernel_Name'][:48]].append(float(r['End_Timestamp'])-float(r['Start_Timestamp']))
     for k,v in sorted(by.items()):
         v=v[len(v)//2:]
