@@ -28,6 +28,15 @@ struct ChainBlk {
 static_assert(sizeof(ChainBlk) == sizeof(rumpy_res_chain_block), "rumpy_res_chain_block is the device-side block record");
 struct ChainDev { const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* work; const unsigned* epoch; unsigned* status; int nxcd, fake_xcc, force_sc1; };
 
+// -DCHAIN_STAMPS (measurement builds only, tests/tools/r05_chain_stamps.sh): phase time stamps (s_memrealtime, 100 MHz) of every wave in the MIDDLE block
+#ifdef CHAIN_STAMPS
+__device__ unsigned long long* g_chain_stamps;
+#define CH_STAMP(k) do { if (b == a.nblk / 2 && (threadIdx.x & 63) == 0 && g_chain_stamps) g_chain_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int rumpy_debug_chain_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps), &buf, sizeof(buf)); }
+#else
+#define CH_STAMP(k) do { } while (0)
+#endif
+
 // FORM 1: forward (ReLU, mask bytes written if given); FORM 3: data gradient (* scale1, mask bytes read)
 template <int FORM, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
@@ -87,6 +96,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
 
   for (int b = 0; b < a.nblk; ++b) {
     const ChainBlk blk = a.blk[b];
+    CH_STAMP(0);
     // Lane geometry is recomputed per block from an opaque copy of the lane id: hoisted out of the loop it would hold ~100 VGPRs for the
     // whole chain (the sweeps' read bases alone are 5 x 16) and spill; per block it is ~150 VALU instructions.
     int lane = lane0;
@@ -141,10 +151,15 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       // per-block launch: bitwise equal, 28.5 k against 28.9 k patches/s on one box, profiles/r05_negative_results.txt item 6.  Not kept.)
       gate_wait(&gate[2], done);
       gate_wait(&gate[3], done);                         // both halves' OUT rows of block b - 1 are in LDS (and nobody reads the old T image)
+      CH_STAMP(1);
       sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
       block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
-      // (b) publish block b - 1: this wave's OUT stores are acknowledged -> count in -> one lane stores the flag
+      CH_STAMP(2);
+      // (b) publish block b - 1: this wave's OUT stores are acknowledged (under the sweep above) -> count in -> one lane stores the flag.  (Publishing IN
+      // FRONT of the sweep - the neighbours see the flag a sweep earlier, this wave stalls 0.4 us for the rest of its acknowledgements - measured the
+      // same within noise: 28.67 k against 28.78 k patches/s, profiles/r05_negative_results.txt item 8.)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      CH_STAMP(3);
       gate_arrive(&gate[6 + rh], lane);
       if (q == 0) {
         gate_wait(&gate[6 + rh], done);
@@ -161,6 +176,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
           if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + (unsigned)b); break; }
         }
       }
+      CH_STAMP(4);
       uint4 Hr[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -172,10 +188,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
         if (hoff[i] != 0xffffffffu) *reinterpret_cast<uint4*>(ldx + hlds[i]) = Hr[i];
       gate_arrive(&gate[4 + rh], lane);
       gate_wait(&gate[4 + rh], done);
+      CH_STAMP(5);
       // (d) the two T rows that do: row half 0 -> T rows 0, 1 (input rows 0 .. 3); row half 1 -> T rows 6, 7 (input rows 6 .. 9)
       sweep_bases(off, 0u, (rh == 0) ? 0 : 6, px, g);
       block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 0 : 2]), F, lds, off);
     }
+    CH_STAMP(6);
     // second filter: L2 hits that land under the epilogue
     {
       const uint4* wp = blk.w2 + (size_t)q * 18 * 64 + lane;
@@ -205,6 +223,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       }
       *reinterpret_cast<uint4*>(ldt + swz((4 * rh + jr) * BCOLS + 16 * c + px + 1, chunk8)) = o;
     }
+    CH_STAMP(7);
     gate_arrive(&gate[rh], lane);
     gate_wait(&gate[rh], done + 4u);
     if (rh == 1) gate_wait(&gate[0], done + 4u);
@@ -241,6 +260,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
       block_sweep<3, FMT>(acc2, F, lds, off, t_store);
     }
+    CH_STAMP(8);
     if (b + 1 < a.nblk) {                                // the next block's first filter lands under the epilogue and the halo step
       const uint4* wp = a.blk[b + 1].w1 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
@@ -285,6 +305,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
         *reinterpret_cast<uint2*>(cell) = pack4<FMT>(v[0], v[1], v[2], v[3]);
       }
     }
+    CH_STAMP(9);
     gate_arrive(&gate[2 + rh], lane);
     gate_wait(&gate[2 + rh], done + 4u);
     {                                                    // this row half's 3 OUT rows -> HBM: whole lines, write-through (the neighbours read them back)
@@ -293,6 +314,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       for (int i = 0; i < GROUP_REGS; ++i)
         if (soff[i] != 0xffffffffu) { if (local) ch_store16_sc0(blk.out + soff[i], S[i]); else ch_store16_sc1(blk.out + soff[i], S[i]); }
     }
+    CH_STAMP(10);
   }
 }
 

@@ -26,7 +26,7 @@ struct RcBlk {
 static_assert(sizeof(RcBlk) == sizeof(rumpy_rcab_chain_block), "rumpy_rcab_chain_block is the device-side block record");
 struct RcChainDev {
   const RcBlk* blk; int nblk, N, H, W, sy_n, cr; float inv_hw;
-  unsigned* work; unsigned long long* xchg; unsigned xchg_bytes; unsigned* status; int nxcd, fake_xcc, force_sc1, abl;
+  unsigned* work; unsigned long long* xchg; unsigned xchg_bytes; unsigned* status; int nxcd, fake_xcc, force_sc1;
 };
 constexpr int RCC_R = 4;               // hidden units of the attention MLP this kernel holds in LDS
 
@@ -47,7 +47,7 @@ __device__ __forceinline__ float rcc_gather(const RcChainDev& a, int n, int tid,
       const unsigned byte = (unsigned)(((n * a.sy_n + s) * 64 + c) * 8);
       rc_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rr, byte, 0, RC_SC1);
       unsigned spins = 0;
-      while (!(a.abl & 1) && !__all(r.y == tag)) {
+      while (!__all(r.y == tag)) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > RC_SPIN) { if (c == 0) atomicExch(a.status, 0x600u + (tag & 255u)); break; }
         r = __builtin_amdgcn_raw_buffer_load_b64(rr, byte, 0, RC_SC1);
@@ -71,6 +71,15 @@ __device__ __forceinline__ void rcc_dma16(const void* gsrc, unsigned lds_dst) { 
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+
+// -DRCC_STAMPS (measurement builds only): phase time stamps (s_memrealtime, 100 MHz) of every wave in the chain's MIDDLE block
+#ifdef RCC_STAMPS
+__device__ unsigned long long* g_rcc_stamps;
+#define RCC_STAMP(k) do { if (b == a.nblk / 2 && (threadIdx.x & 63) == 0 && g_rcc_stamps) g_rcc_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int rumpy_debug_rcc_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rcc_stamps), &buf, sizeof(buf)); }
+#else
+#define RCC_STAMP(k) do { } while (0)
+#endif
 
 template <bool BWD>
 __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
@@ -147,6 +156,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
     const RcBlk blk = a.blk[b];
     const unsigned tag = (epoch << 8) + (unsigned)b;
     const unsigned done = 4u * (unsigned)b;              // gate counts at the end of block b - 1
+    RCC_STAMP(0);
     int lane = lane0, tidb = tid;
     asm volatile("" : "+v"(lane), "+v"(tidb));           // (per-lane geometry is recomputed per block from opaque copies: hoisted out of the loop it spills, conv_chain.hip)
     const int px = lane & 15, g = lane >> 4, tg = 64 * q + lane;
@@ -258,7 +268,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
         gate_wait(&gate[3], done);
         sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
         block_sweep<2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
-        if (!(a.abl & 2)) hand_off();
+        hand_off();
+        RCC_STAMP(2);
         sweep_bases(off, 0u, (rh == 0) ? 0 : 6, px, g);
         block_sweep<2>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 0 : 2]), F, lds, off);
       }
@@ -306,8 +317,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       }
       // fetch the neighbours' rows, then - the t2 rows of this block have been consumed by every wave: two barriers ago - request the NEXT block's by
       // LDS-DMA: they have the rest of this block to land
+      RCC_STAMP(1);
       rcc_post(a, mine, n, sy, tidb, tag);               // this strip's sums are on their way while ...
-      if (b > 0 && !(a.abl & 2)) hand_off();             // ... the neighbours' rows are fetched
+      if (b > 0) hand_off();             // ... the neighbours' rows are fetched
+      RCC_STAMP(2);
       if (b + 1 < a.nblk) t2_dma(a.blk[b + 1].t2_in, tidb);
       {                                                  // the first sweep's filter: lands under the exchange, the MLP and the tile's transform
         const uint4* wp = blk.w1 + (size_t)q * 18 * 64 + lane;
@@ -315,6 +328,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
         for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
       }
       const float ds = rcc_gather(a, n, tidb, tag, sx);
+      RCC_STAMP(3);
       if (tidb < 64) {
         const int c = tidb;
         const float s = svec[3 * 64 + c];
@@ -371,6 +385,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       }
       __syncthreads();
       geometry();
+      RCC_STAMP(4);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -378,6 +393,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       sweep_bases(off, 0u, 4 * rh, px, g);
       block_sweep<4>(acc, F, lds, off);
     }
+    RCC_STAMP(5);
     // second filter: L2 hits that land under the epilogue
     {
       const uint4* wp = blk.w2 + (size_t)q * 18 * 64 + lane;
@@ -404,11 +420,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       }
       *reinterpret_cast<uint4*>(ldt + swz((4 * rh + jr) * BCOLS + 16 * c + px + 1, chunk8)) = o;
     }
+    RCC_STAMP(6);
     gate_arrive(&gate[rh], lane);
     gate_wait(&gate[rh], done + 4u);
     if (rh == 1) gate_wait(&gate[0], done + 4u);
     uint4 S[GROUP_REGS];
-    const bool t_out = blk.t != nullptr && !(a.abl & 8);
+    const bool t_out = blk.t != nullptr;
     if (t_out) group_stage<1>(S, ldt, tg, rh);
     // the row half's own T rows (+ mask bytes) -> HBM from the LDS image, whole lines, non-temporal - all of them in front of the second sweep (conv_block.hip
     // spreads them under it, one piece per third MFMA group: here the 20 staged registers beside the sweep's spilled, and a spill reload between MFMAs is
@@ -460,6 +477,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
       block_sweep<3>(acc2, F, lds, off);
     }
+    RCC_STAMP(7);
     // pairs k < 3: X = (row k, col 0), Y = (row k, col 1); k = 3: X = (0, 2), Y = (1, 2); single: (2, 2)
     float V[4][8], vs[4];
 #pragma unroll
@@ -550,7 +568,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       const float mine = (tidb < 64) ? spool[tidb] + spool[64 + tidb] : 0.f;
       rcc_post(a, mine, n, sy, tidb, tag);
       const float tot = rcc_gather(a, n, tidb, tag, sx);      // (its barriers also complete the t2 image)
-      if (blk.t2 && !(a.abl & 4)) {                        // t2 leaves right here (it does not wait for the gate): whole lines, non-temporal
+      RCC_STAMP(8);
+      if (blk.t2) {                        // t2 leaves right here (it does not wait for the gate): whole lines, non-temporal
         uint4 S5[STRIP_REGS];
         strip_stage<1>(S5, ldt, tidb);
 #pragma unroll
@@ -585,6 +604,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
         sgate[c] = gt * svec[2 * 64 + c];
         if (sy == 0) { blk.mean[n * 64 + c] = mean; blk.gate[n * 64 + c] = gt; }
       }
+      RCC_STAMP(9);
       __syncthreads();
       // out = x + gate * t2, the residual operand from the input tile in LDS; the result replaces it there
       const float4 ga = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair), gb = *reinterpret_cast<const float4*>(sgate + 16 * q + gpair + 4);
@@ -617,12 +637,14 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
     // ---- OUT (forward: x + gate * t2; backward: dx): per row half, whole lines, handed to the neighbours (conv_chain.hip) ----
+    RCC_STAMP(10);
     gate_arrive(&gate[2 + rh], lane);
     gate_wait(&gate[2 + rh], done + 4u);
     group_stage<2>(S, ldx, tg, rh);
 #pragma unroll
     for (int i = 0; i < GROUP_REGS; ++i)
       if (soff[i] != 0xffffffffu) { if (local) ch_store16_sc0(blk.out + soff[i], S[i]); else ch_store16_sc1(blk.out + soff[i], S[i]); }
+    RCC_STAMP(11);
   }
 }
 
@@ -643,7 +665,6 @@ extern "C" int rumpy_rcab_chain(const rumpy_rcab_chain_args* p, void* stream) {
   d.inv_hw = 1.0f / ((float)p->H * (float)p->W);
   d.work = (unsigned*)p->work; d.xchg = (unsigned long long*)p->xchg; d.xchg_bytes = (unsigned)need; d.status = (unsigned*)p->status;
   d.nxcd = rumpy_device_xcds(); d.fake_xcc = p->fake_xcc; d.force_sc1 = p->force_sc1;
-  { const char* e = getenv("RUMPY_RCC_ABL"); d.abl = e ? atoi(e) : 0; }      // TIMING EXPERIMENTS ONLY (wrong results): 1 no pool polls, 2 no hand-off, 4 no t2 stores, 8 no T stores
   if (d.fake_xcc > 0) d.nxcd = d.fake_xcc < CH_MAX_XCD ? d.fake_xcc : CH_MAX_XCD;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(chain_begin_kernel, dim3(1), dim3(1), 0, s, (unsigned*)p->work);

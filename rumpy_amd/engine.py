@@ -151,6 +151,10 @@ class SREngine:
         # bitwise the per-block launches; needs every strip co-resident: N * ceil(H/6) <= CUs, W <= 48); RUMPY_NO_CHAIN=1: one launch per block (A/B)
         self.use_chain = os.environ.get('RUMPY_NO_CHAIN') != '1'
         self.chain_force_sc1 = os.environ.get('RUMPY_CHAIN_SC1') == '1'       # A/B: every hand-off of the chain through the memory side
+        # the RCABs of a residual group as one persistent launch (conv_rcab_chain.hip; bitwise the per-block launches): OPT-IN - measured at parity forward
+        # (19.7 against 19.8 us per RCAB) and slower backward (21.6 against 19.0): every block ends in an image-wide exchange AND a neighbour hand-off, and the
+        # strips of an image drift by microseconds between them (profiles/r05_rcab_chain.txt)
+        self.use_rcab_chain = os.environ.get('RUMPY_RCAB_CHAIN') == '1'
         # Evaluation plans store activations and filters as IEEE fp16 (same MFMA rate and bytes as bf16, 11 instead of 8 significant bits):
         # bf16 storage alone costs a >= 30 dB model 0.02-0.03 dB of Y-PSNR against the fp32 reference (fixtures G17 / G18).
         # Training stays bf16 (gradient range).  An output that is not finite (fp16 overflow) switches the engine back to bf16 for good.
@@ -876,7 +880,7 @@ class SREngine:
         """the same for the RCABs of a ResidualGroup in the 'xchg' form (rumpy_rcab_fwd / rumpy_rcab_bwd -> ONE rumpy_rcab_chain launch per group and
         direction, conv_rcab_chain.hip: strip resident in LDS, pool sums exchanged inside the launch, bitwise the per-block launches)"""
         N, H, W = plan.N, plan.H, plan.W
-        if not self.use_chain or W > 48 or N * ((H + 5) // 6) > self.cus:
+        if not self.use_chain or not self.use_rcab_chain or W > 48 or N * ((H + 5) // 6) > self.cus:
             return
         name = 'rumpy_rcab_bwd' if backward else 'rumpy_rcab_fwd'
 

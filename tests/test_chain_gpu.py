@@ -229,6 +229,7 @@ def test_rcan_training_on_the_rcab_chain_equals_the_per_block_launches(name, kw,
     meta = torch.rand(8, 3, 1, 1, generator=torch.Generator().manual_seed(4)) if name == 'qrcan' else None
     extra = dict(extra_channels=meta) if meta is not None else {}
     res = []
+    monkeypatch.setenv('RUMPY_RCAB_CHAIN', '1')      # (opt-in: measured not to pay, engine.use_rcab_chain)
     for no_chain in ('0', '1'):
         monkeypatch.setenv('RUMPY_NO_CHAIN', no_chain)
         h = _handler(name, lr=1e-3, **kw)

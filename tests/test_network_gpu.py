@@ -685,7 +685,7 @@ def test_two_launch_path_matches_the_block_kernel_path(name, kw, monkeypatch):
         loss, out = h.run_train(x=x, y=y)
         assert h.net.engine.use_block_kernel == (no_block == '0')
         names = {op for op, _ in h.net.engine.plan_for(2, 20, 20, True).fwd}
-        fused = {'edsr': 'rumpy_res_chain', 'rcan': 'rumpy_rcab_chain'}[name]      # (the run of block / RCAB launches is one chain launch: conv_chain.hip, conv_rcab_chain.hip)
+        fused = {'edsr': 'rumpy_res_chain', 'rcan': rcab_ops()[0]}[name]      # (EDSR: the run of block launches is one chain launch, conv_chain.hip)
         assert (fused in names) == (no_block == '0')
         res.append((float(loss), out, {k: p.grad.detach().float().cpu().clone() for k, p in h.net.named_parameters()}))
     assert abs(res[0][0] - res[1][0]) < 1e-4 * abs(res[1][0])

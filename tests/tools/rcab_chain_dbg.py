@@ -44,3 +44,19 @@ for _ in range(reps):
 e1.record()
 torch.cuda.synchronize()
 print('%s chain: %.1f us per launch = %.2f us per block' % (which, e0.elapsed_time(e1) / reps * 1e3, e0.elapsed_time(e1) / reps * 1e3 / nblk), flush=True)
+if 'RCC_STAMPS' in os.environ.get('RUMPY_AMD_LIB', ''):
+    import ctypes
+    fn = getattr(ctypes.CDLL(os.environ['RUMPY_AMD_LIB']), 'rumpy_debug_rcc_stamps')
+    fn.argtypes = [ctypes.c_void_p]
+    nwg = N * ((H + 5) // 6)
+    buf = torch.zeros(nwg * 8 * 16, dtype=torch.int64, device=DEV)
+    assert fn(buf.data_ptr()) == 0
+    L.call('rumpy_rcab_chain', a, stream())
+    torch.cuda.synchronize()
+    raw = buf.cpu().numpy().reshape(nwg, 8, 16).astype(np.float64)
+    names = {'fwd': ['start', '-', 'sweep a', '-', '-', 'conv1 swept', 'T written', 'conv2 swept', 'pool gathered', 'gate ready', 'OUT written', 'stored'],
+             'bwd': ['start', 'ds reduced', 'halo in', 'ds gathered', 'd_t2 tile', 'conv2^T swept', 'T written', 'conv1^T swept', '-', '-', 'dx written', 'stored']}[which]
+    rel = (raw - raw[:, :, :1]) * 0.01
+    for rh in (0, 1):
+        print('   row half %d, us from the start of block %d: ' % (rh, nblk // 2) + '  '.join('%s %.2f' % (nm, rel[:, 4 * rh:4 * rh + 4, i].mean()) for i, nm in enumerate(names) if nm != '-'))
+    print('   block starts spread over %.1f us' % ((raw[:, :, 0].max() - raw[:, :, 0].min()) * 0.01))
