@@ -38,7 +38,7 @@ if forms:
     if M != 'edsr':
         srcs += ['rumpy_amd/csrc/rcab_common.hpp', 'rumpy_amd/csrc/conv_rcab_fp8.hip' if FP8 else 'rumpy_amd/csrc/conv_rcab2.hip' if lazy else 'rumpy_amd/csrc/conv_rcab.hip']
     else:
-        srcs += ['rumpy_amd/csrc/conv_block_fp8.hip' if FP8 else 'rumpy_amd/csrc/conv_chain.hip' if chain else 'rumpy_amd/csrc/conv_block.hip']
+        srcs += ['rumpy_amd/csrc/conv_block_fp8.hip'] if FP8 else ['rumpy_amd/csrc/chain_common.hpp', 'rumpy_amd/csrc/conv_chain.hip'] if chain else ['rumpy_amd/csrc/conv_block.hip']
     entry = {'bytes_per_launch': sum(forms.values()) / len(forms), 'per_form_bytes': forms, 'sources': srcs, 'sha16': bench.source_sha16(srcs),
              'source': 'profiles/pmc_traffic.json <- tests/tools/pmc_step.sh %s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py --model %s '
                        '(32 x 48 x 48)%s, 2 x FETCH_SIZE + WRITE_SIZE, mean over the forward and data-gradient launches (block_chain_kernel: per launch of 16 blocks)' % (M, M, ' --precision fp8' if FP8 else '')}
