@@ -389,6 +389,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='LR patches per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--probe-steps', type=int, default=5)
+    ap.add_argument('--no-as-called', action='store_true', help='skip the informational host-tensor leg (profiles: its copies run beside the kernels of 23 more steps)')
     ap.add_argument('--settle-ms', type=float, default=0.0,
                     help='A/B tooling only (default 0 = off): hold the GPU under load for this long BEFORE the W warm-up steps.  `value` is always the '
                          'contract\'s region of the process as the flags describe it; with the default flags that is a fresh process (ADVICE r4).')
@@ -687,7 +688,7 @@ def main():
     # ---- informational: the step exactly as the reference's caller makes it (SISRInterface.train_batch, interface.py:97-101): batch on the HOST,
     # output returned to the HOST (keep_on_device=False): 15 MB up + 14 MB down over PCIe per step.  Never `value`. ----
     as_called = None
-    if rank == 0 and world == 1 and src is None and meta_pool is None:
+    if rank == 0 and world == 1 and src is None and meta_pool is None and not args.no_as_called:
         host_pool = [(x.cpu(), y.cpu()) for x, y in pool[:4]]
         for i in range(3):
             h.run_train(x=host_pool[i % 4][0], y=host_pool[i % 4][1])

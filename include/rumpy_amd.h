@@ -196,7 +196,10 @@ int rumpy_rcab_epoch_advance(void* epoch, void* stream);
  *                     u_out = G + conv1^T(t) [+ res2] ; with u_in (the forward pass's U of the PREVIOUS block): part_out = rows of sum_hw(u_out * u_in).
  *                     w1 / w2 = DATA-GRADIENT filter images of conv2 / conv1; the attention MLP arguments describe this block (hidden, gate: in).
  * np_in > 64 (whole-image evaluation): the launch first folds the rows into one with a small kernel and needs part_scratch ([N][64] floats).
- * x + gate * u of a chain's LAST block: rumpy_ca_fwd_fused on part_out. */
+ * x + gate * u of a chain's LAST block: rumpy_ca_fwd_fused on part_out.
+ * Replaces: RCAB.forward (rumpy/SISR/models/advanced/architectures.py:60-84: body = conv, ReLU, conv, CALayer; res += x) with CALayer
+ * (architectures.py:24-44: AdaptiveAvgPool2d(1), conv_du = 1x1 conv, ReLU, 1x1 conv, Sigmoid; x * y) and its autograd backward; QRCAB's 'standard' /
+ * 'modulate' styles (attention_manipulators/architectures.py:154-228) through qgate. */
 typedef struct {
   const void* x; const void* u_in; const float* part_in; float* part_out; float* part_scratch;
   const void* w1; const float* b1; const void* w2; const float* b2;
@@ -219,7 +222,9 @@ int rumpy_rcab2_partials(int32_t N, int32_t H, int32_t W);      /* rows of part_
  * the halo rows travel between vertical neighbours through the XCD's L2 (strips are claimed per XCD: all strips of an image run behind one L2) or, for a
  * strip that had to be claimed from another XCD, through the memory side.  Bitwise the per-block launches.  Needs N * ceil(H/6) <= CUs, W <= 48, and
  * `work` = rumpy_res_chain_work_bytes(N, H) bytes, zeroed once.  *status (device word, zero it once) becomes 0x4ff / 0x500 + block after a hand-off that
- * timed out: the results of that launch are invalid.  fake_xcc / force_sc1: test hooks (0 in production). */
+ * timed out: the results of that launch are invalid.  fake_xcc / force_sc1: test hooks (0 in production).
+ * Replaces: the ResBlocks of EDSR.body (rumpy/SISR/models/advanced/architectures.py:218-224, 233: nn.Sequential of n_resblocks common.ResBlock;
+ * common.py:62-73: conv, ReLU, conv, .mul(res_scale), res += x) run back to back by EDSR.forward (architectures.py:236-241), and their autograd data gradients. */
 typedef struct {
   const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
   const void* res2; void* t; void* out; void* maskbits;
@@ -239,7 +244,9 @@ int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H);
  * BEING block b - 1's out; the strips of an image exchange their pool sums inside the launch through `xchg` (N * ceil(H/6) * 512 bytes, zeroed once; its own
  * buffer, not one shared with rumpy_rcab_fwd).  backward = 0: t = t1, t2 = conv2's output (both stored when set), mean / hidden / gate: out.
  * backward = 1: x = dy, w1 / w2 = DATA-GRADIENT images of conv2 / conv1, t = gt1 out, t2 = d_t2 out, t2_in = the forward pass's t2, maskbits, hidden / gate: in,
- * dz [, dzq]: out.  W <= 48, N * ceil(H/6) <= CUs, Cr <= 4, bf16.  *status: 0x4ff / 0x500 + block (hand-off) or 0x600 + block (pool exchange) after a time-out. */
+ * dz [, dzq]: out.  W <= 48, N * ceil(H/6) <= CUs, Cr <= 4, bf16.  *status: 0x4ff / 0x500 + block (hand-off) or 0x600 + block (pool exchange) after a time-out.
+ * Replaces: the RCABs of ResidualGroup.body (rumpy/SISR/models/advanced/architectures.py:107-119: n_resblocks RCAB + conv; forward :121-124) run back to
+ * back, and their autograd backward.  Opt-in in the engine (RUMPY_RCAB_CHAIN=1): measured slower than the per-block launches in the backward pass. */
 typedef struct {
   const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
   void* t; void* t2; const void* t2_in; const void* res2; void* out; void* maskbits;
@@ -332,6 +339,23 @@ typedef struct {
   int32_t N, H, W;
 } rumpy_tail_dgrad_args;
 int rumpy_tail_dgrad(const rumpy_tail_dgrad_args* a, void* stream);
+
+/* ABI 5: the tail conv's data gradient and the data gradient of the LAST upsampler stage (conv 64 -> 256 + PixelShuffle(2)) in one launch:
+ *   dx [N,2H,2W,64] bf16 = rumpy_tail_dgrad(dy4 [N,2H,2W,4], w_tail)    (still written: the upsampler conv's weight gradient reads it)
+ *   out [N,H,W,64]  bf16 = rumpy_conv3x3(x = dx, w, cin_chunks 4, in_mode 1, no bias / ReLU / residuals)
+ * without reading dx back: every workgroup makes its input tiles from its window of dy4.  Bitwise the two launches.  H, W = the conv's grid
+ * (half the tail's).  Replaces: autograd's backward of `x = self.tail(res)` (rumpy/SISR/models/advanced/architectures.py:226-230, 240: the last
+ * Upsampler stage, common.py:30-33 (conv(n_feat, 4 n_feat) + PixelShuffle(2)), followed by default_conv(n_feats, out_features)) from the loss gradient down to the stage's input. */
+typedef struct {
+  const void* dy4;      /* [N,2H,2W,4] bf16 */
+  const void* w_tail;   /* packed tail filter, dgrad image (rumpy_tail_dgrad_args.w) */
+  void* dx;             /* [N,2H,2W,64] bf16, out */
+  const void* w;        /* packed upsampler filter, dgrad image (rumpy_conv_args.w of the data-gradient launch) */
+  void* out;            /* [N,H,W,64] bf16 */
+  int32_t N, H, W;
+  int32_t grid_x;       /* persistent workgroups; 0 = one per CU */
+} rumpy_conv4d_tail_args;
+int rumpy_conv4d_tail(const rumpy_conv4d_tail_args* a, void* stream);
 
 /* fp32 NCHW [N,C<=4,H,W] -> bf16 [N,H,W,4] (zero padded): an upstream gradient entering the backward pass */
 typedef struct {

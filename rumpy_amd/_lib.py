@@ -123,6 +123,11 @@ class TailDgradArgs(_S):
     _fields_ = [('dy4', c_void_p), ('w', c_void_p), ('dx', c_void_p), ('N', c_int32), ('H', c_int32), ('W', c_int32)]
 
 
+class Conv4dTailArgs(_S):       # = rumpy_conv4d_tail_args
+    _fields_ = [('dy4', c_void_p), ('w_tail', c_void_p), ('dx', c_void_p), ('w', c_void_p), ('out', c_void_p),
+                ('N', c_int32), ('H', c_int32), ('W', c_int32), ('grid_x', c_int32)]
+
+
 class NchwToNhwc4Args(_S):
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('N', c_int32), ('C', c_int32), ('H', c_int32), ('W', c_int32)]
 
@@ -361,6 +366,7 @@ SYMBOLS = {
     'rumpy_tail_fwd_grid': (C.c_int, [c_int32, c_int32, c_int32, c_int32]),
     'rumpy_tail_wgrad_reduce': (C.c_int, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     'rumpy_tail_dgrad': (C.c_int, [_P(TailDgradArgs), c_void_p]),
+    'rumpy_conv4d_tail': (C.c_int, [_P(Conv4dTailArgs), c_void_p]),
     'rumpy_nchw_to_nhwc4': (C.c_int, [_P(NchwToNhwc4Args), c_void_p]),
     'rumpy_pixel_shuffle': (C.c_int, [_P(PixelShuffleArgs), c_void_p]),
     'rumpy_tail_fwd_wide': (C.c_int, [_P(TailWideArgs), c_void_p]),

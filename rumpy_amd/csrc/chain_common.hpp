@@ -3,10 +3,10 @@
 #pragma once
 #include "block_common.hpp"
 
-// work buffer (unsigned words): [0] launch epoch, [CH_W_COUNT + x] strips claimed on XCD x, [CH_W_WHERE + s] (epoch << 8) + XCD strip s runs on,
+// work buffer (unsigned words): [0] epoch of the LAST launch, [CH_W_DONE] workgroups of this launch that hold a strip, [CH_W_COUNT + x] strips claimed on XCD x, [CH_W_WHERE + s] (epoch << 8) + XCD strip s runs on,
 // then per (strip, row half) ONE 128-BYTE LINE whose first word is the flag: (epoch << 8) + last block whose rows of that half are visible.  A line
 // per flag, because flags may be stored sc0: a line that is dirty in an XCD's L2 for ONE word would serve that XCD's polls of its other words stale
-constexpr int CH_W_COUNT = 8, CH_W_WHERE = 32, CH_MAX_XCD = 16, CH_FLAG_STRIDE = 32;
+constexpr int CH_W_DONE = 1, CH_W_COUNT = 8, CH_W_WHERE = 32, CH_MAX_XCD = 16, CH_FLAG_STRIDE = 32;
 constexpr unsigned CH_SPIN = 1u << 20;
 typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -27,12 +27,16 @@ __device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
   return make_uint4(w.x, w.y, w.z, w.w);
 }
 
-struct ChainPlace { int strip; unsigned xcc; };
-// Thread 0 of the workgroup claims a strip (own XCD first, then the others in turn: workgroups = slots, so a free one exists while this one has none),
-// publishes where it physically runs, and hands both to the workgroup through `claim` (LDS, two ints); ends with a workgroup barrier.
-// XCD x runs the images x, x + nx, x + 2 nx, ...: whole images, all their strips behind ONE L2.
-__device__ __forceinline__ ChainPlace chain_claim(unsigned* work, unsigned epoch, int N, int sy_n, int nx, int fake_xcc, int* claim) {
+struct ChainPlace { int strip; unsigned xcc, epoch; };
+// Thread 0 of the workgroup reads the launch's epoch (the last launch's + 1: tags of flags and placement words), claims a strip (own XCD first, then
+// the others in turn: workgroups = slots, so a free one exists while this one has none), publishes where it physically runs, and hands all three
+// to the workgroup through `claim` (LDS, three ints); ends with a workgroup barrier.  XCD x runs the images x, x + nx, x + 2 nx, ...: whole
+// images, all their strips behind ONE L2.  The workgroup whose claim is the launch's last puts the counters back to zero and stores the epoch for
+// the next launch - every workgroup has read the old one by then (one thread per workgroup reads it, BEFORE its claim is counted) - so a chain needs
+// no launch in front of it (a one-thread kernel there cost 4.6 us per chain: the launch boundary, not the work).
+__device__ __forceinline__ ChainPlace chain_claim(unsigned* work, int N, int sy_n, int nx, int fake_xcc, int* claim) {
   if (threadIdx.x == 0) {
+    const unsigned epoch = (__hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u) & 0xffffffu;
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 15u;
@@ -48,12 +52,20 @@ __device__ __forceinline__ ChainPlace chain_claim(unsigned* work, unsigned epoch
     }
     claim[0] = slot;
     claim[1] = (int)xcc;
+    claim[2] = (int)epoch;
     __hip_atomic_store(work + CH_W_WHERE + slot, (epoch << 8) + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // memory side: the neighbours may sit on any XCD
+    // this claim is complete (its fetch_add has returned) and the epoch is read: count it; the last one re-arms the buffer for the next launch
+    if (__hip_atomic_fetch_add(work + CH_W_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+      for (int x = 0; x < CH_MAX_XCD; ++x) __hip_atomic_store(work + CH_W_COUNT + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(work + CH_W_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(work, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
   ChainPlace p;
   p.strip = claim[0];
   p.xcc = (unsigned)claim[1];
+  p.epoch = (unsigned)__builtin_amdgcn_readfirstlane(claim[2]);
   return p;
 }
 // does strip `nb` run on this workgroup's XCD?  (polls the word its workgroup publishes at claim time)
@@ -68,9 +80,4 @@ __device__ __forceinline__ bool chain_same_xcd(unsigned* work, unsigned epoch, i
   return ((w >> 8) == epoch) && ((w & 255u) == my_xcc);
 }
 __device__ __forceinline__ unsigned* chain_flags(unsigned* work, unsigned nstrips) { return work + CH_W_WHERE + ((nstrips + 31u) & ~31u); }
-// one thread in front of every chain launch: new epoch (tags of flags and placement words), claim counters back to zero
-static __global__ void chain_begin_kernel(unsigned* work) {
-  work[0] = (work[0] + 1u) & 0xffffffu;
-  for (int x = 0; x < CH_MAX_XCD; ++x) work[CH_W_COUNT + x] = 0u;
-}
 static inline int64_t chain_work_bytes(int64_t strips) { return (CH_W_WHERE + ((strips + 31) & ~(int64_t)31) + 2 * strips * CH_FLAG_STRIDE) * 4; }

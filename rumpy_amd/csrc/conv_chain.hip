@@ -26,7 +26,7 @@ struct ChainBlk {
   const uint16_t* res2; uint16_t* t; uint16_t* out; unsigned char* mbits; float scale1, scale2;
 };
 static_assert(sizeof(ChainBlk) == sizeof(rumpy_res_chain_block), "rumpy_res_chain_block is the device-side block record");
-struct ChainDev { const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* work; const unsigned* epoch; unsigned* status; int nxcd, fake_xcc, force_sc1; };
+struct ChainDev { const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* work; unsigned* status; int nxcd, fake_xcc, force_sc1; };
 
 // -DCHAIN_STAMPS (measurement builds only, tests/tools/r05_chain_stamps.sh): phase time stamps (s_memrealtime, 100 MHz) of every wave in the MIDDLE block
 #ifdef CHAIN_STAMPS
@@ -46,10 +46,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   unsigned char* const ldt = lds + BXBYTES;
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = wave & 3, rh = wave >> 2;
-  const unsigned epoch = *a.epoch;
   // ---- which strip this workgroup runs: CLAIMED, per XCD (top of this file; chain_common.hpp) ----
-  __shared__ int claim[2];
-  const ChainPlace place = chain_claim(a.work, epoch, a.N, a.sy_n, a.nxcd, a.fake_xcc, claim);
+  __shared__ int claim[3];
+  const ChainPlace place = chain_claim(a.work, a.N, a.sy_n, a.nxcd, a.fake_xcc, claim);
+  const unsigned epoch = place.epoch;
   const int strip = place.strip;
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
   const bool has_nb = (rh == 0) ? (sy > 0) : (sy + 1 < a.sy_n);
@@ -332,11 +332,10 @@ extern "C" int rumpy_res_chain(const rumpy_res_chain_args* p, void* stream) {
   if (p->fake_xcc < 0 || (p->fake_xcc > 0 && !p->force_sc1)) { rumpy_set_error("rumpy_res_chain: fake_xcc (a test hook) goes with force_sc1"); return RUMPY_E_ARG; }
   ChainDev d;
   d.blk = reinterpret_cast<const ChainBlk*>(p->blocks); d.nblk = p->nblocks; d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;
-  d.work = (unsigned*)p->work; d.epoch = (const unsigned*)p->work; d.status = (unsigned*)p->status;
+  d.work = (unsigned*)p->work; d.status = (unsigned*)p->status;
   d.nxcd = rumpy_device_xcds(); d.fake_xcc = p->fake_xcc; d.force_sc1 = p->force_sc1;
   if (d.fake_xcc > 0) d.nxcd = d.fake_xcc < CH_MAX_XCD ? d.fake_xcc : CH_MAX_XCD;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(chain_begin_kernel, dim3(1), dim3(1), 0, s, (unsigned*)p->work);
   const dim3 grid(p->N * sy_n);
   if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3>), grid, dim3(BTHREADS), s, d);
   else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);

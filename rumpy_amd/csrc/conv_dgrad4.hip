@@ -22,6 +22,7 @@
 //     conv3x3_kernel<4> (chunks 0 .. 3 in turn): bitwise that kernel (tests/test_kernels_gpu.py).
 #include "block_common.hpp"
 #include <cstdlib>
+#include <type_traits>
 static inline int d4_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // Tile height as a parameter (round 4): 8 rows, or 6 where that fills the chip better - the 32 x 48 x 48 stage of the x4 upsampler is 576 tiles of
@@ -241,4 +242,276 @@ int rumpy_conv4d_launch(ConvDev d, int grid_x, int cap, hipStream_t s, int fmt) 
   else if (th == 6) hipLaunchKernelGGL((conv4d_kernel<RUMPY_FMT_BF16, 6>), dim3(g2, d.cout_tiles), dim3(256), 0, s, d);
   else hipLaunchKernelGGL(conv4d_kernel<RUMPY_FMT_BF16>, dim3(g2, d.cout_tiles), dim3(256), 0, s, d);
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Round 5: the tail conv's data gradient INSIDE this kernel (rumpy_conv4d_tail).  The last upsampler stage's data gradient used to read the
+// 151 MB tensor dx = conv^T_tail(dy4) that rumpy_tail_dgrad had just written (64 us, write-bound, + this kernel's 26 % of DMA issue time for
+// reading it back).  dx is a 3x3 conv over FOUR channels: a workgroup that holds the (2 TH + 6) x 40 pixel window of dy4 (7 KB by LDS-DMA,
+// one tile ahead) makes each stage image - the 64 channels of one PixelShuffle phase over its 10 x 18 halo pixels - with 24 MFMAs per wave
+// (tail_dgrad_kernel's two per 16 pixels x 16 channels, same operands, same order: the bf16 values are bitwise that kernel's) and writes them
+// into the ring in the DMA's layout; the stage sweep below is conv4d_kernel's.  dx still goes to HBM - the weight gradient of the upsampler
+// conv reads it - as whole 128-byte lines from the stage image, each pixel by the one tile that owns it.  No input DMA ring: a stage is
+// produced one sweep ahead (4 slots), the waves meet on an LDS counter per stage as above.
+// ------------------------------------------------------------------------------------------------------
+typedef unsigned int tail_u32x4_d4 __attribute__((ext_vector_type(4)));
+typedef unsigned int d4_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) d4_u32x2* d4_lds_u32x2;
+struct Conv4TDev { const uint16_t* dy4; const uint4* wt; uint16_t* dx; const uint4* w; uint16_t* out; int N, H, W, tiles_x, tiles_y; };
+
+template <int TH_>
+__global__ void __launch_bounds__(256, 1) conv4dt_kernel(Conv4TDev a) {
+  typedef D4Geo<TH_> G;
+  constexpr int HR = G::HR;
+  constexpr int STG = ((G::HPIX + 15) / 16) * 16 * 128;     // 24,576 / 18,432 B
+  constexpr int DYR = 2 * (TH_ + 2) + 2, DYW = 40;          // dy4 window: rows 2 (ty TH - 1) - 1 .. , columns 32 tx - 4 .. (16-byte aligned pairs)
+  constexpr int DYP = (DYR * (DYW / 2) + 63) / 64;          // DMA pieces of 64 x 16 bytes: 7 / 5
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * STG];
+  __shared__ __attribute__((aligned(1024))) unsigned char sdy[2][DYP * 1024];
+  __shared__ unsigned landed, dyl;
+  const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 15, g = lane >> 4;
+  const int ntiles = a.N * a.tiles_y * a.tiles_x;
+  const int tile0 = blockIdx.x, tstride = (int)gridDim.x;
+  if (tile0 >= ntiles) return;
+  const int nt = (ntiles - tile0 + tstride - 1) / tstride;
+  const int nstage = 4 * nt;
+  if (tid == 0) { landed = 0u; dyl = 0u; }
+
+  bf16x8 F[4][18];
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+    for (int s = 0; s < 18; ++s) F[ch][s] = as_bf16x8(a.w[((ch * 4 + q) * 18 + s) * 64 + lane]);
+  const bf16x8 T0 = as_bf16x8(a.wt[(q * 2 + 0) * 64 + lane]), T1 = as_bf16x8(a.wt[(q * 2 + 1) * 64 + lane]);
+
+  const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_page4;
+  const unsigned dybase = (unsigned)(size_t)(d4_lds_u8)&sdy[0][0];
+  // the dy4 window of tile t -> sdy[t & 1]: wave q moves pieces q and q + 4; lane = 16-byte unit (row, column pair) in row-major order
+  auto dy_issue = [&](int t) {
+    const TileCoord tc = decode_tile(tile0 + t * tstride, a.tiles_x, a.tiles_y);
+    const int Y0 = 2 * (tc.ty * TH_ - 1) - 1, X0 = 32 * tc.tx - 4;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int piece = q + 4 * k;
+      if (piece < DYP) {                                      // wave-uniform
+        const int i = piece * 64 + lane, row = i / (DYW / 2), cp = i - row * (DYW / 2);
+        const int Y = Y0 + row, X = X0 + 2 * cp;
+        const bool ok = (row < DYR) & ((unsigned)Y < (unsigned)(2 * a.H)) & ((unsigned)X < (unsigned)(2 * a.W));
+        const unsigned long long src = ok ? (unsigned long long)(uintptr_t)a.dy4 + 8ull * (unsigned)((tc.n * 2 * a.H + Y) * (2 * a.W) + X) : zero;
+        d4_dma16((const void*)(uintptr_t)src, __builtin_amdgcn_readfirstlane(dybase + (unsigned)((t & 1) * DYP + piece) * 1024u));
+      }
+    }
+  };
+  // taps of this lane group in the tail filter's K order (tail_dgrad_kernel): MFMA 1 = taps 2 g, 2 g + 1; MFMA 2 = tap 8 (g = 0 only)
+  const int ta = 2 * g, tb = 2 * g + 1;
+  const int offa = ((ta / 3) * DYW + ta % 3) * 8, offb = ((tb / 3) * DYW + tb % 3) * 8, offc = (2 * DYW + 2) * 8;
+  // Stage image of phase PH (= input chunk of the sweep: pixels (2 y + PH / 2, 2 x + PH % 2)) of tile t into ring slot PH, one group of 16 pixels at a
+  // time and in three pieces - operand reads, the two MFMAs, the write - so that the sweep below can carry a group per unit: done in one go
+  // (reads -> wait -> MFMA -> MFMA -> result -> write, twelve times) a stage image took longer than the sweep it feeds.
+  // Groups: one per halo row (columns 0 .. 15: row and column known at compile time / per lane, so every LDS address is a lane constant
+  // plus an immediate - groups cut out of the flattened pixel index cost 45 VALU instructions each in divisions and swizzles), then the two
+  // columns 16, 17 of all rows in NEDGE more.
+  constexpr int NROW = TH_ + 2, NEDGE = (2 * NROW + 15) / 16, NGRP = NROW + NEDGE;        // 10 + 2 / 8 + 1
+  const unsigned sdy0 = (unsigned)(size_t)(d4_lds_u8)&sdy[0][0], ring0 = (unsigned)(size_t)(d4_lds_u8)lds;
+  const unsigned chunkq = (unsigned)(2 * q + (g >> 1));
+  const unsigned rd0 = sdy0 + (unsigned)((2 * px + 1) * 8);
+  unsigned W4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) W4[k] = ring0 + (unsigned)(px * 128 + ((chunkq ^ (unsigned)((2 * k + px) & 7)) << 4) + (g & 1) * 8);
+  unsigned erd[NEDGE], ewr[NEDGE];
+  int er[NEDGE], ec[NEDGE];
+#pragma unroll
+  for (int e = 0; e < NEDGE; ++e) {
+    const int pe = 16 * e + px;
+    er[e] = pe >> 1; ec[e] = 16 + (pe & 1);
+    // lanes past the last row (the second edge group's upper 12 pixel slots): operands from any valid address, result (zeros) into the image's spare
+    // pixel slots behind the halo tile - NOT onto a real pixel, which a lane of the same write instruction fills
+    const int rc = er[e] < NROW ? er[e] : NROW - 1, pE = er[e] < NROW ? rc * HALO_W + ec[e] : G::HPIX + (pe & 7);
+    erd[e] = sdy0 + (unsigned)((2 * rc * DYW + 2 * ec[e] + 1) * 8);
+    ewr[e] = ring0 + (unsigned)(pE * 128 + ((chunkq ^ (unsigned)(pE & 7)) << 4) + (g & 1) * 8);
+  }
+  struct PGroup { uint2 b0a, b0b, b1; };
+  struct PTile { unsigned dyoff; int ty, tx; bool colok; bool eok[NEDGE]; };       // per produced tile: window slot, masks
+  auto p_tile = [&](int t, PTile& T_) {
+    const TileCoord tn = decode_tile(tile0 + t * tstride, a.tiles_x, a.tiles_y);
+    T_.dyoff = (unsigned)((t & 1) * DYP * 1024); T_.ty = tn.ty; T_.tx = tn.tx;
+    T_.colok = (unsigned)(tn.tx * TW + px - 1) < (unsigned)a.W;
+#pragma unroll
+    for (int e = 0; e < NEDGE; ++e)
+      T_.eok[e] = (er[e] < NROW) & ((unsigned)(tn.ty * TH_ + er[e] - 1) < (unsigned)a.H) & ((unsigned)(tn.tx * TW + ec[e] - 1) < (unsigned)a.W);
+  };
+  auto lds_rd8 = [&](unsigned addr) { const d4_u32x2 v = *(d4_lds_u32x2)(size_t)addr; return make_uint2(v.x, v.y); };
+  auto p_read = [&](const PTile& T_, auto PHc, auto Jc, PGroup& G_) {
+    constexpr int PH = decltype(PHc)::value, j = decltype(Jc)::value;
+    constexpr int rowimm = (j < NROW) ? ((2 * j + (PH >> 1)) * DYW + (PH & 1)) * 8 : ((PH >> 1) * DYW + (PH & 1)) * 8;
+    const unsigned b = ((j < NROW) ? rd0 : erd[j < NROW ? 0 : j - NROW]) + T_.dyoff + rowimm;
+    G_.b0a = lds_rd8(b + offa);
+    G_.b0b = lds_rd8(b + offb);
+    G_.b1 = lds_rd8(b + offc);          // every lane reads (no exec-masked read in the stream); lanes g > 0 drop it below
+  };
+  auto p_mfma = [&](const PGroup& G_, f32x4& acc) {
+    union { uint2 u[2]; bf16x8 v; } B0, B1;
+    B0.u[0] = G_.b0a; B0.u[1] = G_.b0b;
+    B1.u[0] = (g == 0) ? G_.b1 : make_uint2(0, 0);
+    B1.u[1] = make_uint2(0, 0);
+    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T0, B0.v, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T1, B1.v, acc, 0, 0, 0);
+  };
+  auto p_write = [&](const PTile& T_, auto PHc, auto Jc, const f32x4& acc) {
+    constexpr int PH = decltype(PHc)::value, j = decltype(Jc)::value;
+    bool inside;
+    unsigned dst;
+    if (j < NROW) {
+      inside = T_.colok & ((unsigned)(T_.ty * TH_ + j - 1) < (unsigned)a.H);
+      dst = W4[j & 3] + (unsigned)(PH * STG + j * HALO_W * 128);
+    } else {
+      inside = T_.eok[j < NROW ? 0 : j - NROW];
+      dst = ewr[j < NROW ? 0 : j - NROW] + (unsigned)(PH * STG);
+    }
+    uint2 v = pack4_bf16(acc[0], acc[1], acc[2], acc[3]);
+    v.x = inside ? v.x : 0u; v.y = inside ? v.y : 0u;      // the conv's zero padding (NOT the tail gradient of a pixel outside the image)
+    *(d4_lds_u32x2)(size_t)dst = (d4_u32x2){v.x, v.y};
+  };
+  auto produce = [&](int t, auto PHc) {      // a whole stage image in one go: the first one of the kernel only
+    PTile T_;
+    p_tile(t, T_);
+    PGroup G_; f32x4 pa;
+#define D4T_ONE(J) if (J < NGRP) { p_read(T_, PHc, std::integral_constant<int, (J < NGRP ? J : 0)>(), G_); p_mfma(G_, pa); p_write(T_, PHc, std::integral_constant<int, (J < NGRP ? J : 0)>(), pa); }
+    D4T_ONE(0) D4T_ONE(1) D4T_ONE(2) D4T_ONE(3) D4T_ONE(4) D4T_ONE(5) D4T_ONE(6) D4T_ONE(7) D4T_ONE(8) D4T_ONE(9) D4T_ONE(10) D4T_ONE(11)
+#undef D4T_ONE
+  };
+  // dx of the pixels this tile owns, phase PH: whole 128-byte lines out of the stage image, TH_ / 2 pieces of 16 bytes per thread - piece i is read in
+  // unit i of the sweep and leaves in unit i + 1
+  constexpr int NDX = TH_ * TW * 8 / 256;
+  auto dx_read = [&](auto PHc, int i, uint4& v) {
+    constexpr int PH = decltype(PHc)::value;
+    int tido = tid;
+    asm volatile("" : "+v"(tido));
+    const int e = tido + 256 * i, pl = e >> 3, c = e & 7, rr = pl >> 4, cc = pl & 15;
+    const int p = (rr + 1) * HALO_W + cc + 1;
+    v = *reinterpret_cast<const uint4*>(lds + PH * STG + p * 128 + ((c ^ (p & 7)) << 4));
+  };
+  auto dx_store = [&](const TileCoord& tc, auto PHc, int i, const uint4& v) {
+    constexpr int PH = decltype(PHc)::value;
+    int tido = tid;
+    asm volatile("" : "+v"(tido));
+    const int e = tido + 256 * i, pl = e >> 3, c = e & 7, rr = pl >> 4, cc = pl & 15;
+    const int y = tc.ty * TH_ + rr, x = tc.tx * TW + cc;
+    if (y < a.H && x < a.W)      // (plain instead of non-temporal stores: the same time; without the stores at all: -5 us of 118)
+      __builtin_nontemporal_store((tail_u32x4_d4){v.x, v.y, v.z, v.w},
+          reinterpret_cast<tail_u32x4_d4*>(a.dx + ((size_t)((tc.n * 2 * a.H + 2 * y + (PH >> 1)) * (2 * a.W) + 2 * x + (PH & 1))) * 64 + c * 8));
+  };
+  unsigned off[8][2];
+#pragma unroll
+  for (int d = 0; d < 8; ++d)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) off[d][h] = (unsigned)(px * 128 + (((4 * h + g) ^ ((px + d) & 7)) << 4));
+
+  __syncthreads();                        // counters zeroed
+  dy_issue(0);
+  d4_wait<0>();
+  gate_arrive(&dyl, lane);
+  gate_wait(&dyl, 4u);
+  produce(0, std::integral_constant<int, 0>());
+  gate_arrive(&landed, lane);
+
+  const int c0 = 16 * q + 4 * g;
+  for (int it = 0; it < nt; ++it) {
+    const TileCoord tc = decode_tile(tile0 + it * tstride, a.tiles_x, a.tiles_y);
+    const int xx = tc.tx * TW + px;
+    if (it + 1 < nt) dy_issue(it + 1);    // into the window of tile it - 1: every wave is past its last stage image (it arrived for it)
+    f32x4 acc[TH_];
+#pragma unroll
+    for (int r = 0; r < TH_; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](auto CHc) {
+      constexpr int ch = decltype(CHc)::value;
+      typedef std::integral_constant<int, (ch + 1) & 3> NPc;      // the phase whose stage image this sweep carries along
+      const int u = 4 * it + ch;
+      const bool more = ch < 3 || it + 1 < nt;               // wave-uniform
+      PTile PT;
+      p_tile(more && ch == 3 ? it + 1 : it, PT);
+      if (ch == 3 && more) {
+        d4_wait<0>();                     // the next tile's dy4 window (issued four sweeps ago); the dx stores in flight are a sweep old
+        gate_arrive(&dyl, lane);
+        gate_wait(&dyl, 4u * (unsigned)(it + 2));
+      }
+      gate_wait(&landed, 4u * (unsigned)(u + 1));
+      const unsigned char* cur = lds + ch * STG;
+      bf16x8 I[D4_RD + 1][HR + 2];
+      auto load_unit = [&](int j, bf16x8 (&dst)[HR + 2]) {
+        const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
+#pragma unroll
+        for (int r = 0; r < HR + 2; ++r)
+          dst[r] = *reinterpret_cast<const bf16x8*>(cur + off[(2 * (HR * pass + r) + kx) & 7][half] + ((HR * pass + r) * HALO_W + kx) * 128);
+      };
+      PGroup PG[2];
+      f32x4 pacc[2];
+      uint4 dxv;
+#pragma unroll
+      for (int j = 0; j < D4_RD; ++j) load_unit(j, I[j]);
+      // unit j: the fragment reads of unit j + 2, the operand reads of group j of the next stage image, the write of group j - 1 and piece j of this
+      // image's dx rows travel under the 12 MFMAs of unit j; the group's own two MFMAs follow them (their operands have landed by then)
+      auto unit = [&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        if (j + D4_RD < 12) load_unit(j + D4_RD, I[(j + D4_RD) % (D4_RD + 1)]);
+        if (more && j < NGRP) p_read(PT, NPc(), std::integral_constant<int, (j < NGRP ? j : 0)>(), PG[j & 1]);
+        if (more && j >= 1 && j - 1 < NGRP) p_write(PT, NPc(), std::integral_constant<int, (j >= 1 && j - 1 < NGRP ? j - 1 : 0)>(), pacc[(j - 1) & 1]);
+        if (j >= 1 && j - 1 < NDX) dx_store(tc, CHc, j - 1, dxv);
+        if (j < NDX) dx_read(CHc, j, dxv);
+        __builtin_amdgcn_sched_barrier(0);
+        const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int r = 0; r < HR; ++r)
+            acc[HR * pass + r] = mfma16<RUMPY_FMT_BF16>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[HR * pass + r]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && j < NGRP) p_mfma(PG[j & 1], pacc[j & 1]);
+      };
+      unit(std::integral_constant<int, 0>()); unit(std::integral_constant<int, 1>()); unit(std::integral_constant<int, 2>());
+      unit(std::integral_constant<int, 3>()); unit(std::integral_constant<int, 4>()); unit(std::integral_constant<int, 5>());
+      unit(std::integral_constant<int, 6>()); unit(std::integral_constant<int, 7>()); unit(std::integral_constant<int, 8>());
+      unit(std::integral_constant<int, 9>()); unit(std::integral_constant<int, 10>()); unit(std::integral_constant<int, 11>());
+      if (more) {
+        if (NGRP == 12) p_write(PT, NPc(), std::integral_constant<int, NGRP - 1>(), pacc[1]);
+        gate_arrive(&landed, lane);
+      }
+    };
+    stage(std::integral_constant<int, 0>());
+    stage(std::integral_constant<int, 1>());
+    stage(std::integral_constant<int, 2>());
+    stage(std::integral_constant<int, 3>());
+#pragma unroll
+    for (int r = 0; r < TH_; ++r) {
+      const int y = tc.ty * TH_ + r;
+      if (y < a.H && xx < a.W)
+        *reinterpret_cast<uint2*>(a.out + ((size_t)(tc.n * a.H + y) * a.W + xx) * 64 + c0) = pack4<RUMPY_FMT_BF16>(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+    }
+  }
+}
+
+extern "C" int rumpy_conv4d_tail(const rumpy_conv4d_tail_args* p, void* stream) {
+  if (!p || !p->dy4 || !p->w_tail || !p->dx || !p->w || !p->out || p->N <= 0 || p->H <= 0 || p->W <= 0) {
+    rumpy_set_error("rumpy_conv4d_tail: bad argument");
+    return RUMPY_E_ARG;
+  }
+  if ((long long)p->N * 2 * p->H * 2 * p->W * 64 >= (1ll << 31)) { rumpy_set_error("rumpy_conv4d_tail: tensor beyond 2^31 elements"); return RUMPY_E_ARG; }
+  Conv4TDev d;
+  d.dy4 = (const uint16_t*)p->dy4; d.wt = (const uint4*)p->w_tail; d.dx = (uint16_t*)p->dx; d.w = (const uint4*)p->w; d.out = (uint16_t*)p->out;
+  d.N = p->N; d.H = p->H; d.W = p->W; d.tiles_x = d4_cdiv(p->W, TW);
+  const int cap = rumpy_device_cus() > 0 ? rumpy_device_cus() : 1;
+  int th = 8;
+  {
+    const long long t8 = (long long)d.N * d.tiles_x * d4_cdiv(d.H, 8), t6 = (long long)d.N * d.tiles_x * d4_cdiv(d.H, 6);
+    if (d4_cdiv((int)t6, cap) * 8 < d4_cdiv((int)t8, cap) * 10) th = 6;
+  }
+  d.tiles_y = d4_cdiv(d.H, th);
+  const int ntiles = d.N * d.tiles_x * d.tiles_y;
+  int g2 = p->grid_x > 0 ? p->grid_x : cap;
+  g2 = d4_cdiv(ntiles, d4_cdiv(ntiles, g2));
+  if (th == 6) hipLaunchKernelGGL(conv4dt_kernel<6>, dim3(g2), dim3(256), 0, (hipStream_t)stream, d);
+  else hipLaunchKernelGGL(conv4dt_kernel<8>, dim3(g2), dim3(256), 0, (hipStream_t)stream, d);
+  return rumpy_check_launch("rumpy_conv4d_tail");
 }

@@ -94,13 +94,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
   __shared__ float sw2t[RCC_R * 64];       // [r][c] = conv_du.2.weight[c][r]
   __shared__ float svec[4 * 64];           // [0] conv_du.0.bias (cr) | [1] conv_du.2.bias | [2] q gate | [3] bwd: forward gate ; hidden at [0][32..]
   __shared__ unsigned gate[8];             // per row half: T rows written [0,1], OUT rows written [2,3], halo rows in LDS [4,5], stores acknowledged [6,7]
-  __shared__ int claim[2];
+  __shared__ int claim[3];
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + BXBYTES;
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = wave & 3, rh = wave >> 2;
-  const unsigned epoch = *a.work;
-  const ChainPlace place = chain_claim(a.work, epoch, a.N, a.sy_n, a.nxcd, a.fake_xcc, claim);
+  const ChainPlace place = chain_claim(a.work, a.N, a.sy_n, a.nxcd, a.fake_xcc, claim);
+  const unsigned epoch = place.epoch;
   const int strip = place.strip;
   const int n = strip / a.sy_n, sy = strip - n * a.sy_n;
   const bool has_nb = (rh == 0) ? (sy > 0) : (sy + 1 < a.sy_n);
@@ -667,7 +667,6 @@ extern "C" int rumpy_rcab_chain(const rumpy_rcab_chain_args* p, void* stream) {
   d.nxcd = rumpy_device_xcds(); d.fake_xcc = p->fake_xcc; d.force_sc1 = p->force_sc1;
   if (d.fake_xcc > 0) d.nxcd = d.fake_xcc < CH_MAX_XCD ? d.fake_xcc : CH_MAX_XCD;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(chain_begin_kernel, dim3(1), dim3(1), 0, s, (unsigned*)p->work);
   const dim3 grid(p->N * sy_n);
   if (p->backward) RUMPY_LAUNCH_PROBED(5, (rcab_chain_kernel<true>), grid, dim3(BTHREADS), s, d);
   else RUMPY_LAUNCH_PROBED(5, (rcab_chain_kernel<false>), grid, dim3(BTHREADS), s, d);

@@ -150,6 +150,8 @@ class SREngine:
         # runs of consecutive residual-block launches as ONE persistent launch with the halo rows handed over through the XCD's L2 (conv_chain.hip, round 5;
         # bitwise the per-block launches; needs every strip co-resident: N * ceil(H/6) <= CUs, W <= 48); RUMPY_NO_CHAIN=1: one launch per block (A/B)
         self.use_chain = os.environ.get('RUMPY_NO_CHAIN') != '1'
+        # the tail conv's data gradient inside the last upsampler stage's data-gradient launch (rumpy_conv4d_tail; RUMPY_NO_TAIL_FUSE=1: two launches, A/B)
+        self.fuse_tail_dgrad = os.environ.get('RUMPY_NO_TAIL_FUSE') != '1'
         self.chain_force_sc1 = os.environ.get('RUMPY_CHAIN_SC1') == '1'       # A/B: every hand-off of the chain through the memory side
         # the RCABs of a residual group as one persistent launch (conv_rcab_chain.hip; bitwise the per-block launches): OPT-IN - measured at parity forward
         # (19.7 against 19.8 us per RCAB) and slower backward (21.6 against 19.0): every block ends in an image-wide exchange AND a neighbour hand-off, and the
@@ -809,8 +811,19 @@ class SREngine:
         else:
             bwd.append(('rumpy_tail_dgrad', L.TailDgradArgs(dy4=_ptr(plan.dy4), w=_ptr(spec.tail.w_dgrad), dx=_ptr(g), N=N, H=h, W=w)))
         wjobs.append((spec.tail, u, plan.dy4, h, w, 2, 1.0, 1))
+        fuse_tail = (self.fuse_tail_dgrad and not self.wide and not self.generic_up and F == 64 and bool(ups_in)
+                     and ups_in[-1][4] == 2 and N * h * w * F < 2 ** 31)
         for cv, uin, uh, uw, rr in reversed(ups_in):
             gin = self._new(plan, N, uh, uw, F)
+            if fuse_tail:
+                # the last stage: its input gradient g = conv^T_tail(dy4) is made tile by tile inside the launch (and written for the weight gradient)
+                fuse_tail = False
+                assert bwd[-1][0] == 'rumpy_tail_dgrad'
+                bwd[-1] = ('rumpy_conv4d_tail', L.Conv4dTailArgs(dy4=_ptr(plan.dy4), w_tail=_ptr(spec.tail.w_dgrad), dx=_ptr(g), w=_ptr(cv.w_dgrad),
+                                                                  out=_ptr(gin), N=N, H=uh, W=uw, grid_x=0))
+                wjobs.append((cv, uin, g, uh, uw, 1, 1.0, 4))
+                g = gin
+                continue
             if self.generic_up:
                 # the gradient un-permuted into the conv's natural channel order: data and weight gradient are a plain conv's then.  The data
                 # gradient has Cin = r^2 F input channels - beyond rumpy_conv3x3's 64 / 256 - and runs the encoder's general conv kernel.

@@ -358,6 +358,52 @@ def test_tail_forward_l1_and_dgrad(C):
     assert_bf16_close(nchw(dx), xin.grad, 'tail dgrad')
 
 
+@pytest.mark.parametrize('N,H,W,gx', [(2, 13, 17, 0), (3, 40, 50, 7), (1, 8, 16, 0), (2, 24, 33, 2), (1, 5, 3, 1), (2, 96, 96, 0), (4, 48, 48, 0), (1, 6, 16, 0),
+                                      (32, 96, 96, 0), (40, 12, 16, 0)])
+def test_tail_dgrad_inside_the_last_upsampler_dgrad_is_bitwise_the_two_launches(N, H, W, gx):
+    """rumpy_conv4d_tail (round 5): dx = conv^T_tail(dy4) made tile by tile INSIDE the PixelShuffle^T data-gradient launch of the last upsampler
+    stage, against rumpy_tail_dgrad followed by rumpy_conv3x3(in_mode 1): dx and the stage's input gradient bit for bit - ragged sizes (edge tiles
+    whose halo pixels lie outside the image must see ZERO there, not the tail gradient of an outside pixel), one and several tiles per
+    workgroup, both tile heights, more tiles than workgroups; and the result against torch autograd through conv + PixelShuffle + tail conv"""
+    gen = np.random.default_rng(77 + H + W)
+    C = 3
+    b_ = 1.0 / np.sqrt(64 * 9)
+    wt = torch.from_numpy(gen.uniform(-b_, b_, (C, 64, 3, 3)).astype(np.float32))
+    bt = torch.from_numpy(gen.uniform(-b_, b_, (C,)).astype(np.float32))
+    pt = PackedConv(wt, bt, 2)
+    wu, bu = _wb(gen, 256, 64)
+    pu = PackedConv(wu, bu, 0, True)
+    gy = _rand(gen, N, C, 2 * H, 2 * W)
+    g4 = torch.zeros(N, 2 * H, 2 * W, 4, dtype=BF16, device=DEV)
+    gyd = gy.to(DEV)
+    L.call('rumpy_nchw_to_nhwc4', L.NchwToNhwc4Args(src=gyd.data_ptr(), dst=g4.data_ptr(), N=N, C=C, H=2 * H, W=2 * W), stream())
+    dx_ref = torch.full((N, 2 * H, 2 * W, 64), float('nan'), dtype=BF16, device=DEV)
+    L.call('rumpy_tail_dgrad', L.TailDgradArgs(dy4=g4.data_ptr(), w=pt.w_dgrad.data_ptr(), dx=dx_ref.data_ptr(), N=N, H=2 * H, W=2 * W), stream())
+    o_ref, _ = hip_conv(dx_ref, pu, N, H, W, dgrad=True, in_mode=1, grid_x=gx)
+    dx = torch.full((N, 2 * H, 2 * W, 64), float('nan'), dtype=BF16, device=DEV)
+    out = torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    L.call('rumpy_conv4d_tail', L.Conv4dTailArgs(dy4=g4.data_ptr(), w_tail=pt.w_dgrad.data_ptr(), dx=dx.data_ptr(), w=pu.w_dgrad.data_ptr(),
+                                                 out=out.data_ptr(), N=N, H=H, W=W, grid_x=gx), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16)), 'dx'
+    assert torch.equal(out.view(torch.int16), o_ref.view(torch.int16)), 'stage input gradient'
+    if N * H * W <= 4 * 48 * 48:
+        x = torch.zeros(N, 64, H, W, requires_grad=True)
+        mid = F.pixel_shuffle(F.conv2d(x, bf16r(wu), None, padding=1), 2)
+        mid.retain_grad()
+        F.conv2d(mid, bf16r(wt), None, padding=1).backward(bf16r(gy))
+        assert_bf16_close(nchw(dx), mid.grad, 'tail dgrad inside the upsampler dgrad')
+        # the stage gradient from the bf16-ROUNDED dx, as both HIP paths compute it
+        x2 = torch.zeros(N, 64, H, W, requires_grad=True)
+        F.pixel_shuffle(F.conv2d(x2, bf16r(wu), None, padding=1), 2).backward(nchw(dx).float())
+        assert_bf16_close(nchw(out), x2.grad, 'upsampler dgrad from the in-kernel tail gradient')
+
+
+def test_conv4d_tail_refuses_bad_arguments():
+    with pytest.raises(RuntimeError, match='rumpy_conv4d_tail'):
+        L.call('rumpy_conv4d_tail', L.Conv4dTailArgs(dy4=None, w_tail=None, dx=None, w=None, out=None, N=1, H=8, W=8, grid_x=0), stream())
+
+
 def _wgrad_ref(x, gy, co, scale=1.0):
     w = torch.zeros(co, 64, 3, 3, requires_grad=True)
     b = torch.zeros(co, requires_grad=True)

@@ -528,3 +528,37 @@ _R2_ONLY = None
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'rcab2stamps':
     rcab2_stamps()
+
+
+def tailfuse_bench(N=32, H=96, W=96):
+    """rumpy_tail_dgrad + rumpy_conv3x3(in_mode 1) against rumpy_conv4d_tail (round 5) on the last upsampler stage of the x4 step"""
+    gen = np.random.default_rng(0)
+    wt = torch.from_numpy(gen.uniform(-0.04, 0.04, (3, 64, 3, 3)).astype(np.float32))
+    pt = PackedConv(wt, torch.zeros(3), 2)
+    wu = torch.from_numpy(gen.uniform(-0.04, 0.04, (256, 64, 3, 3)).astype(np.float32))
+    pu = PackedConv(wu, torch.zeros(256), 0, True)
+    g4 = torch.sign(torch.randn(N, 2 * H, 2 * W, 4, device=DEV)).to(BF16)
+    g4[..., 3] = 0
+    dx = torch.empty(N, 2 * H, 2 * W, 64, dtype=BF16, device=DEV)
+    out = torch.empty(N, H, W, 64, dtype=BF16, device=DEV)
+    a_t = L.TailDgradArgs(dy4=g4.data_ptr(), w=pt.w_dgrad.data_ptr(), dx=dx.data_ptr(), N=N, H=2 * H, W=2 * W)
+    a_c = L.ConvArgs(x=dx.data_ptr(), w=pu.w_dgrad.data_ptr(), bias=None, out=out.data_ptr(), N=N, H=H, W=W, cin_chunks=4, cout_tiles=1,
+                     in_mode=1, out_mode=0, relu=0, scale=1.0, grid_x=0)
+    a_f = L.Conv4dTailArgs(dy4=g4.data_ptr(), w_tail=pt.w_dgrad.data_ptr(), dx=dx.data_ptr(), w=pu.w_dgrad.data_ptr(), out=out.data_ptr(),
+                           N=N, H=H, W=W, grid_x=0)
+    for rep in range(3):
+        t1 = time_fn(lambda: L.call('rumpy_tail_dgrad', a_t, stream()), iters=100)
+        t2 = time_fn(lambda: L.call('rumpy_conv3x3', a_c, stream()), iters=100)
+
+        def both():
+            L.call('rumpy_tail_dgrad', a_t, stream())
+            L.call('rumpy_conv3x3', a_c, stream())
+        t12 = time_fn(both, iters=100)
+        t3 = time_fn(lambda: L.call('rumpy_conv4d_tail', a_f, stream()), iters=100)
+        print('%dx%dx%d: tail_dgrad %6.1f us + conv4d %6.1f us (back to back %6.1f) | conv4d_tail %6.1f us' % (N, H, W, t1, t2, t12, t3))
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'tailfuse':
+    tailfuse_bench()
+    tailfuse_bench(8, 128, 128)
+    tailfuse_bench(32, 48, 48)

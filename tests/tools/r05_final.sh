@@ -21,11 +21,11 @@ python3 bench.py --mode eval --steps 60 --warmup 6 > $OUT/eval_edsr_bench_line.j
 python3 bench.py --mode eval --model rcan --steps 20 --warmup 3 > $OUT/eval_rcan_bench_line.json 2>> $OUT/bench_err.log
 python3 bench.py --model moco --steps 300 --warmup 30 > $OUT/moco_bench_line.json 2>> $OUT/bench_err.log
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr -o p -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --settled-probe-ms 0 > $OUT/prof_edsr.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan -o p -- python3 $R/bench.py --model rcan --steps 40 --warmup 10 --no-cpu-baseline --settled-probe-ms 0 > $OUT/prof_rcan.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan64 -o p -- python3 $R/bench.py --model rcan --lr-size 64 --batch 8 --steps 40 --warmup 8 --no-cpu-baseline --settled-probe-ms 0 > $OUT/prof_rcan64.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_edsr -o p -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-as-called --settled-probe-ms 0 > $OUT/prof_edsr.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan -o p -- python3 $R/bench.py --model rcan --steps 40 --warmup 10 --no-cpu-baseline --no-as-called --settled-probe-ms 0 > $OUT/prof_rcan.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan64 -o p -- python3 $R/bench.py --model rcan --lr-size 64 --batch 8 --steps 40 --warmup 8 --no-cpu-baseline --no-as-called --settled-probe-ms 0 > $OUT/prof_rcan64.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_eval_rcan -o p -- python3 $R/bench.py --mode eval --model rcan --steps 20 --warmup 3 --no-cpu-baseline > $OUT/prof_eval_rcan.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan_fp8 -o p -- python3 $R/bench.py --model rcan --precision fp8 --steps 40 --warmup 10 --no-cpu-baseline --settled-probe-ms 0 > $OUT/prof_rcan_fp8.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_rcan_fp8 -o p -- python3 $R/bench.py --model rcan --precision fp8 --steps 40 --warmup 10 --no-cpu-baseline --no-as-called --settled-probe-ms 0 > $OUT/prof_rcan_fp8.log 2>&1
 cd $R
 for m in edsr rcan rcan64 eval_rcan rcan_fp8; do cp $(find $OUT/prof_$m -name '*kernel_stats.csv' | head -1) $OUT/${m}_kernel_stats.csv; rm -rf $OUT/prof_$m; done
 bash tests/tools/pmc_step.sh edsr > $OUT/pmc_step_edsr.txt 2>&1
@@ -43,7 +43,7 @@ for f in sorted(glob.glob('$OUT/*bench_line.json')):
     r = d.get('roofline') or {}
     print('%-34s %10.2f %-13s %8.3f ms  kernel %s us frac %s traffic %s settled %s as_called %s' % (os.path.basename(f), d['value'], d['unit'], d['ms_per_step'], r.get('avg_launch_us'), r.get('frac'), r.get('traffic'), (d.get('settled') or {}).get('value'), (d.get('as_called') or {}).get('value')))
 PY
-for m in edsr rcan; do echo "== $m"; python3 tests/tools/prof_summary.py $OUT/${m}_kernel_stats.csv $( [ $m = edsr ] && echo 148 || echo 78 ) | head -16; done
+for m in edsr rcan; do echo "== $m"; python3 tests/tools/prof_summary.py $OUT/${m}_kernel_stats.csv $( [ $m = edsr ] && echo 125 || echo 55 ) | head -16; done
 tail -4 $OUT/pmc_step_edsr.txt $OUT/pmc_step_rcan.txt
 tail -14 $OUT/pmc_sq_edsr.txt
 tail -14 $OUT/pmc_sq_rcan.txt
