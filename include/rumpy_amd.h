@@ -563,6 +563,26 @@ int rumpy_q_mlp_bwd_params(const rumpy_q_mlp_item* items_device, int32_t nitems,
  * produced the metadata (the degradation encoder of the blind pipeline when its trunk trains jointly: contrastive_blind_sr.py:337) */
 int rumpy_q_mlp_bwd_meta(const rumpy_q_mlp_item* items_device, int32_t nitems, int32_t N, int32_t M, int32_t Hq, int32_t C, float* dmeta, void* stream);
 
+/* ABI 5: the same q-layer with ParaCALayer's `num_layers` (q_layer.py:13,22-41) other than 2: layer l = [n[l+1], n[l]] weights + bias, ReLU behind every
+ * layer but the last (nonlinearity=True, as QRCAB builds it: architectures.py:182-183), sigmoid behind the last.  n[0] = M (metadata), n[nlayers] = C;
+ * every q-layer of a network has the same shape, stated by the caller (n, nlayers: HOST values).  acts: the post-ReLU outputs of layers 0 .. L-2 per
+ * image, concatenated ([N, n[1] + .. + n[L-1]]).  N <= 64, every n <= 256, n[1] + .. + n[L] <= 448. */
+#define RUMPY_QN_MAX_LAYERS 4
+typedef struct {
+  const float* w[RUMPY_QN_MAX_LAYERS]; const float* b[RUMPY_QN_MAX_LAYERS];
+  float* gw[RUMPY_QN_MAX_LAYERS]; float* gb[RUMPY_QN_MAX_LAYERS];
+  float* acts;                          /* out of the forward launch */
+  float* gate;                          /* [N,C] out of the forward launch */
+  const float* dzq;                     /* [N,C] in of the backward launches (gradient before the sigmoid) */
+  int32_t n[RUMPY_QN_MAX_LAYERS + 1];
+  int32_t nlayers;
+  float scale;
+  int32_t pad_;
+} rumpy_q_mlpn_item;
+int rumpy_q_mlpn_fwd(const rumpy_q_mlpn_item* items_device, int32_t nitems, const float* meta, int32_t N, const int32_t* n, int32_t nlayers, void* stream);
+int rumpy_q_mlpn_bwd_params(const rumpy_q_mlpn_item* items_device, int32_t nitems, const float* meta, int32_t N, const int32_t* n, int32_t nlayers, void* stream);
+int rumpy_q_mlpn_bwd_meta(const rumpy_q_mlpn_item* items_device, int32_t nitems, int32_t N, const int32_t* n, int32_t nlayers, float* dmeta, void* stream);
+
 /* ---- the other QCALayer styles (rumpy/SISR/models/attention_manipulators/architectures.py:41-136: 'max_concat', 'mini_concat',
  * 'extended_attention', 'softmax'): the gate of a block is an MLP of at most four layers over the block's channel means and the image's
  * attribute vector (qca_style.hip).  Layer l: v = [previous output (n_prev) ; attr (M) if cat]; v = relu(v) if relu_in; out = act(W v + b),

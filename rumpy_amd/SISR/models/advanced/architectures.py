@@ -16,7 +16,7 @@ import os
 import torch
 from torch import nn
 
-from rumpy_amd.engine import CALayerParams, ConvLayer, NetSpec, QLayerParams, SREngine
+from rumpy_amd.engine import CALayerParams, ConvLayer, NetSpec, QLayerNParams, QLayerParams, SREngine
 
 
 def _ceil64(f):
@@ -255,10 +255,14 @@ class HipSRNet(nn.Module):
         return lp
 
     def _q_layer(self, name, qn):
-        c0, c2 = qn.attribute_integrator[0], qn.attribute_integrator[2]
+        convs = [m for m in qn.attribute_integrator if isinstance(m, nn.Conv2d)]
+        idx = {id(p): i for i, p in enumerate(self.param_list)}
+        if len(convs) != 2:       # ParaCALayer's num_layers other than the default: the general-depth launches (rumpy_q_mlpn_*)
+            return QLayerNParams(name, [dict(w=c.weight.data.reshape(c.weight.shape[0], -1), b=c.bias.data, gw=self.grad_views[idx[id(c.weight)]],
+                                             gb=self.grad_views[idx[id(c.bias)]]) for c in convs])
+        c0, c2 = convs
         lp = QLayerParams(name, c0.weight.data.reshape(c0.weight.shape[0], -1), c0.bias.data,
                           c2.weight.data.reshape(c2.weight.shape[0], -1), c2.bias.data)
-        idx = {id(p): i for i, p in enumerate(self.param_list)}
         lp.gw1, lp.gb1 = self.grad_views[idx[id(c0.weight)]], self.grad_views[idx[id(c0.bias)]]
         lp.gw2, lp.gb2 = self.grad_views[idx[id(c2.weight)]], self.grad_views[idx[id(c2.bias)]]
         return lp

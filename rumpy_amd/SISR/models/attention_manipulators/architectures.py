@@ -23,14 +23,22 @@ from rumpy_amd.SISR.models.advanced.architectures import HipSRNet, _CAParams, _c
 
 
 class _QLayerParams(nn.Module):
-    # q_layer.py:22-45 with nonlinearity=True, num_layers=2: attribute_integrator = [conv1x1, ReLU, conv1x1, Sigmoid]
+    # q_layer.py:22-45 with nonlinearity=True (as QRCAB builds it, architectures.py:182-183): attribute_integrator = [conv1x1, ReLU] x (num_layers - 1),
+    # conv1x1, Sigmoid; layer i maps to feats // (num_layers - i) units, or (feats - M) // (num_layers - i) + M when M > 15
     def __init__(self, feats, num_metadata, num_layers=2):
         super().__init__()
-        if num_layers != 2:
-            raise RuntimeError('rumpy_amd: q-layers with %d FC layers are not implemented on the HIP path (2 only)' % num_layers)
-        hidden = (feats - num_metadata) // 2 + num_metadata if num_metadata > 15 else feats // 2
-        self.attribute_integrator = nn.Sequential(nn.Conv2d(num_metadata, hidden, 1, padding=0, bias=True), nn.ReLU(inplace=True),
-                                                  nn.Conv2d(hidden, feats, 1, padding=0, bias=True), nn.Sigmoid())
+        if not 1 <= num_layers <= 4:
+            raise RuntimeError('rumpy_amd: q-layers with %d FC layers are not implemented on the HIP path (1 .. 4)' % num_layers)
+        layers, sizes, mult = [], [num_metadata], num_layers
+        for i in range(num_layers):
+            sizes.append((feats - num_metadata) // mult + num_metadata if num_metadata > 15 else feats // mult)
+            layers.append(nn.Conv2d(sizes[i], sizes[i + 1], 1, padding=0, bias=True))
+            if mult != 1:
+                layers.append(nn.ReLU(inplace=True))
+            mult -= 1
+        layers.append(nn.Sigmoid())
+        self.attribute_integrator = nn.Sequential(*layers)
+        self.num_layers = num_layers
 
 
 STYLED = ('max_concat', 'mini_concat', 'extended_attention', 'softmax')      # QCALayer styles whose gate MLP also reads the attribute vector

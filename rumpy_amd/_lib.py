@@ -233,6 +233,11 @@ class QMlpItem(_S):
                 ('pad_', c_int32)]
 
 
+class QMlpNItem(_S):         # = rumpy_q_mlpn_item
+    _fields_ = [('w', c_void_p * 4), ('b', c_void_p * 4), ('gw', c_void_p * 4), ('gb', c_void_p * 4), ('acts', c_void_p), ('gate', c_void_p),
+                ('dzq', c_void_p), ('n', c_int32 * 5), ('nlayers', c_int32), ('scale', c_float), ('pad_', c_int32)]
+
+
 class AdamHyper(_S):
     _fields_ = [('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float), ('bias_c1', c_float),
                 ('sqrt_bias_c2', c_float), ('grad_mult', c_float), ('max_norm', c_float)]
@@ -388,6 +393,9 @@ SYMBOLS = {
     'rumpy_q_mlp_fwd': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_q_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_q_mlp_bwd_meta': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'rumpy_q_mlpn_fwd': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, C.POINTER(c_int32), c_int32, c_void_p]),
+    'rumpy_q_mlpn_bwd_params': (C.c_int, [c_void_p, c_int32, c_void_p, c_int32, C.POINTER(c_int32), c_int32, c_void_p]),
+    'rumpy_q_mlpn_bwd_meta': (C.c_int, [c_void_p, c_int32, c_int32, C.POINTER(c_int32), c_int32, c_void_p, c_void_p]),
     'rumpy_ca_mlp_bwd_params': (C.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'rumpy_ca_bwd_apply': (C.c_int, [_P(CaBwdApplyArgs), c_void_p]),
     'rumpy_adam_step': (C.c_int, [_P(AdamArgs), c_void_p]),

@@ -609,6 +609,155 @@ __global__ void __launch_bounds__(256) q_mlp_bwd_meta_kernel(const rumpy_q_mlp_i
   if (tid < M) dmeta[(size_t)n * M + tid] = acc;
 }
 
+// ---- the same q-layer with any number of FC layers (ParaCALayer's num_layers, q_layer.py:22-41: 1 .. RUMPY_QN_MAX_LAYERS; the two-layer kernels above
+// are what the reference's default builds and stay the hot path).  Layer l: [n[l+1], n[l]] weights, ReLU behind every layer but the last, sigmoid
+// behind the last.  Same launch structure and the same accumulation order per output (bias first, inputs ascending): with two layers the gates are
+// bitwise those of q_mlp_fwd_kernel. ----
+constexpr int QN_MAXW = 256;                     // widest layer (input included)
+constexpr int QN_MAXSUM = 448;                   // sum of the layer outputs n[1 .. L]: the backward kernel keeps every layer's delta for 64 images in LDS
+__global__ void __launch_bounds__(256) q_mlpn_fwd_kernel(const rumpy_q_mlpn_item* __restrict__ items, const float* __restrict__ meta, int N) {
+  __shared__ float buf[2][Q_NB * QN_MAXW];
+  const rumpy_q_mlpn_item it = items[blockIdx.x];
+  const int n0 = blockIdx.y * Q_NB, t = threadIdx.x, M = it.n[0];
+  const int nb = min(Q_NB, N - n0);
+  for (int i = t; i < Q_NB * M; i += 256) buf[0][i] = (i < nb * M) ? meta[(size_t)n0 * M + i] : 0.f;
+  __syncthreads();
+  int hoff = 0, hsum = 0;
+  for (int l = 0; l + 1 < it.nlayers; ++l) hsum += it.n[l + 1];
+  for (int l = 0; l < it.nlayers; ++l) {
+    const int ni = it.n[l], no = it.n[l + 1];
+    const float* in = buf[l & 1];
+    float* out = buf[(l + 1) & 1];
+    const bool last = l + 1 == it.nlayers;
+    if (t < no) {
+      float acc[Q_NB];
+      const float b = it.b[l][t];
+#pragma unroll
+      for (int k = 0; k < Q_NB; ++k) acc[k] = b;
+      const float* wr = it.w[l] + (size_t)t * ni;
+      for (int m = 0; m < ni; ++m) {
+        const float w = wr[m];
+#pragma unroll
+        for (int k = 0; k < Q_NB; ++k) acc[k] = fmaf(w, in[k * ni + m], acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < Q_NB; ++k) {
+        if (last) {
+          if (k < nb) it.gate[(size_t)(n0 + k) * no + t] = 1.f / (1.f + expf(-acc[k]));
+        } else {
+          const float h = fmaxf(acc[k], 0.f);
+          out[k * no + t] = h;
+          if (k < nb) it.acts[(size_t)(n0 + k) * hsum + hoff + t] = h;
+        }
+      }
+    }
+    hoff += no;
+    __syncthreads();
+  }
+}
+
+// grid (layers of the network, Q_PARTS): every workgroup rebuilds the deltas of its q-layer for all images in LDS, then writes its share of the
+// gradient entries; sums over images in image order
+__global__ void __launch_bounds__(256) q_mlpn_bwd_params_kernel(const rumpy_q_mlpn_item* __restrict__ items, const float* __restrict__ meta, int N) {
+  extern __shared__ float sdl[];                 // [N][dsum]: image n's deltas of layer l at n * dsum + doff[l]
+  const rumpy_q_mlpn_item it = items[blockIdx.x];
+  const int tid = threadIdx.x, part = blockIdx.y, L = it.nlayers, C = it.n[L];
+  int doff[RUMPY_QN_MAX_LAYERS + 1], dsum = 0, hsum = 0;
+  for (int l = 0; l < L; ++l) { doff[l] = dsum; dsum += it.n[l + 1]; }
+  for (int l = 0; l + 1 < L; ++l) hsum += it.n[l + 1];
+  for (int i = tid; i < N * C; i += 256) { const int n = i / C, c = i - n * C; sdl[n * dsum + doff[L - 1] + c] = it.dzq[i]; }
+  __syncthreads();
+  for (int l = L - 2; l >= 0; --l) {             // delta of layer l's output = relu'(act) * W_{l+1}^T delta_{l+1}
+    const int nh = it.n[l + 1], no = it.n[l + 2];
+    for (int i = tid; i < N * nh; i += 256) {
+      const int n = i / nh, h = i - n * nh;
+      float d = 0.f;
+      for (int o = 0; o < no; ++o) d = fmaf(it.w[l + 1][(size_t)o * nh + h], sdl[n * dsum + doff[l + 1] + o], d);
+      sdl[n * dsum + doff[l] + h] = (it.acts[(size_t)n * hsum + doff[l] + h] > 0.f) ? d : 0.f;
+    }
+    __syncthreads();
+  }
+  const int gt = part * 256 + tid, gstride = Q_PARTS * 256;
+  for (int l = L - 1; l >= 0; --l) {
+    const int ni = it.n[l], no = it.n[l + 1];
+    for (int i = gt; i < no * ni; i += gstride) {  // gW_l[o][m] = sum_n delta_l[n][o] in_l[n][m]
+      const int o = i / ni, m = i - o * ni;
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) {
+        const float x = (l == 0) ? meta[(size_t)n * ni + m] : it.acts[(size_t)n * hsum + doff[l - 1] + m];
+        s = fmaf(sdl[n * dsum + doff[l] + o], x, s);
+      }
+      it.gw[l][i] = s * it.scale;
+    }
+    for (int o = gt; o < no; o += gstride) {
+      float s = 0.f;
+      for (int n = 0; n < N; ++n) s += sdl[n * dsum + doff[l] + o];
+      it.gb[l][o] = s * it.scale;
+    }
+  }
+}
+
+// d loss / d metadata: grid (N), 256 threads, the q-layers of the network in table order
+__global__ void __launch_bounds__(256) q_mlpn_bwd_meta_kernel(const rumpy_q_mlpn_item* __restrict__ items, int nitems, int N, float* __restrict__ dmeta) {
+  __shared__ float sd[2][QN_MAXW];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int M = items[0].n[0];
+  float acc = 0.f;                                 // M <= 256: one output per thread
+  for (int q = 0; q < nitems; ++q) {
+    const rumpy_q_mlpn_item it = items[q];
+    const int L = it.nlayers, C = it.n[L];
+    int hoff[RUMPY_QN_MAX_LAYERS + 1], hsum = 0;
+    for (int l = 0; l + 1 < L; ++l) { hoff[l] = hsum; hsum += it.n[l + 1]; }
+    for (int c = tid; c < C; c += 256) sd[(L - 1) & 1][c] = it.dzq[(size_t)n * C + c];
+    __syncthreads();
+    for (int l = L - 2; l >= 0; --l) {
+      const int nh = it.n[l + 1], no = it.n[l + 2];
+      for (int h = tid; h < nh; h += 256) {
+        float d = 0.f;
+        for (int o = 0; o < no; ++o) d = fmaf(it.w[l + 1][(size_t)o * nh + h], sd[(l + 1) & 1][o], d);
+        sd[l & 1][h] = (it.acts[(size_t)n * hsum + hoff[l] + h] > 0.f) ? d : 0.f;
+      }
+      __syncthreads();
+    }
+    if (tid < M) {
+      float s = 0.f;
+      const int n1 = it.n[1];
+      for (int h = 0; h < n1; ++h) s = fmaf(sd[0][h], it.w[0][(size_t)h * M + tid], s);
+      acc += s * it.scale;
+    }
+    __syncthreads();
+  }
+  if (tid < M) dmeta[(size_t)n * M + tid] = acc;
+}
+
+// host-side shape check of the q-layers of a network (the items live in device memory: the caller states the shape they share)
+static bool qn_shape_ok(int N, const int32_t* n, int L) {
+  if (N <= 0 || N > Q_MAXN || !n || L < 1 || L > RUMPY_QN_MAX_LAYERS) return false;
+  int sum = 0;
+  for (int l = 0; l <= L; ++l) { if (n[l] <= 0 || n[l] > QN_MAXW) return false; if (l) sum += n[l]; }
+  return sum <= QN_MAXSUM;
+}
+extern "C" int rumpy_q_mlpn_fwd(const rumpy_q_mlpn_item* items_device, int32_t nitems, const float* meta, int32_t N, const int32_t* n, int32_t nlayers, void* stream) {
+  if (!items_device || !meta || nitems <= 0 || !qn_shape_ok(N, n, nlayers)) { rumpy_set_error("rumpy_q_mlpn_fwd: bad argument (N=%d layers=%d)", N, nlayers); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(q_mlpn_fwd_kernel, dim3(nitems, (N + Q_NB - 1) / Q_NB), dim3(256), 0, (hipStream_t)stream, items_device, meta, N);
+  return rumpy_check_launch("rumpy_q_mlpn_fwd");
+}
+extern "C" int rumpy_q_mlpn_bwd_params(const rumpy_q_mlpn_item* items_device, int32_t nitems, const float* meta, int32_t N, const int32_t* n, int32_t nlayers, void* stream) {
+  if (!items_device || !meta || nitems <= 0 || !qn_shape_ok(N, n, nlayers)) { rumpy_set_error("rumpy_q_mlpn_bwd_params: bad argument (N=%d layers=%d)", N, nlayers); return RUMPY_E_ARG; }
+  int dsum = 0;
+  for (int l = 1; l <= nlayers; ++l) dsum += n[l];
+  const size_t lds = (size_t)N * dsum * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)q_mlpn_bwd_params_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_MAXN * QN_MAXSUM * (int)sizeof(float)); attr_set = true; }
+  hipLaunchKernelGGL(q_mlpn_bwd_params_kernel, dim3(nitems, Q_PARTS), dim3(256), lds, (hipStream_t)stream, items_device, meta, N);
+  return rumpy_check_launch("rumpy_q_mlpn_bwd_params");
+}
+extern "C" int rumpy_q_mlpn_bwd_meta(const rumpy_q_mlpn_item* items_device, int32_t nitems, int32_t N, const int32_t* n, int32_t nlayers, float* dmeta, void* stream) {
+  if (!items_device || !dmeta || nitems <= 0 || !qn_shape_ok(N, n, nlayers)) { rumpy_set_error("rumpy_q_mlpn_bwd_meta: bad argument (N=%d layers=%d)", N, nlayers); return RUMPY_E_ARG; }
+  hipLaunchKernelGGL(q_mlpn_bwd_meta_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, items_device, nitems, N, dmeta);
+  return rumpy_check_launch("rumpy_q_mlpn_bwd_meta");
+}
+
 static bool q_shape_ok(int N, int M, int Hq, int C) { return N > 0 && N <= Q_MAXN && M > 0 && M <= Q_MAXM && Hq > 0 && Hq <= Q_MAXH && C > 0 && C <= Q_MAXC; }
 extern "C" int rumpy_q_mlp_fwd(const rumpy_q_mlp_item* items_device, int32_t nitems, const float* meta, int32_t N, int32_t M, int32_t Hq, int32_t C, void* stream) {
   if (!items_device || !meta || nitems <= 0 || !q_shape_ok(N, M, Hq, C)) { rumpy_set_error("rumpy_q_mlp_fwd: bad argument (N=%d M=%d Hq=%d C=%d)", N, M, Hq, C); return RUMPY_E_ARG; }

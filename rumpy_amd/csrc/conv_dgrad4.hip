@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(256, 1) conv4dt_kernel(Conv4TDev a) {
   const int tile0 = blockIdx.x, tstride = (int)gridDim.x;
   if (tile0 >= ntiles) return;
   const int nt = (ntiles - tile0 + tstride - 1) / tstride;
-  const int nstage = 4 * nt;
   if (tid == 0) { landed = 0u; dyl = 0u; }
 
   bf16x8 F[4][18];

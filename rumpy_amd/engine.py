@@ -65,6 +65,19 @@ class QLayerParams(CALayerParams):
         self.Hq, self.M = w1.shape[0], w1.shape[1]
 
 
+class QLayerNParams:
+    """The same q-layer with ParaCALayer's `num_layers` other than 2 (q_layer.py:13,22-41): layers = [dict(w [n_out, n_in], b, gw, gb)], ReLU behind
+    every layer but the last - run by the general-depth launches rumpy_q_mlpn_* (csrc/ca.hip)."""
+
+    def __init__(self, name, layers):
+        self.name, self.layers = name, layers
+        self.M, self.C = layers[0]['w'].shape[1], layers[-1]['w'].shape[0]
+        self.widths = [self.M] + [l['w'].shape[0] for l in layers]
+        self.hsum = sum(self.widths[1:-1])
+        if len(layers) > 4 or max(self.widths) > 256 or sum(self.widths[1:]) > 448:
+            raise RuntimeError('rumpy_amd: q-layer %s (widths %s) is beyond the HIP path (<= 4 layers of <= 256 units, <= 448 in all)' % (name, self.widths))
+
+
 class NetSpec:
     """Topology handed over by the architecture module.
 
@@ -445,6 +458,7 @@ class SREngine:
         plan.ca_param_items = []
         plan.qca_items, plan.qca_dev = [], None      # gate MLPs of the styled QCALayers: parameter gradients in one launch
         plan.q_items, plan.q_shape, plan.q_dev = [], None, None
+        plan.qn_items, plan.qn_shape, plan.qn_dev = [], None, None      # q-layers of another depth than 2 (rumpy_q_mlpn_*)
         plan.rcab_n, plan.rcab_xchg, plan.rcab_epoch, plan.rcab_status = 0, None, None, None
         plan.f8_f = plan.f8_b = None              # fp8 site records of the forward / backward launches (precision 'fp8')
         plan.f8_f_n = plan.f8_b_n = 0
@@ -545,7 +559,18 @@ class SREngine:
                         if q is not None or spec.num_metadata != F:
                             raise RuntimeError('rumpy_amd: style "modulate" takes one attribute per feature channel and no q-layers')
                         qg = plan.meta
-                    if q is not None:      # meta-attention gate of this QRCAB: evaluated for all layers by one launch before the forward ops
+                    if q is not None and isinstance(q, QLayerNParams):      # ... with num_layers other than 2: the general-depth launches
+                        qa = self._new(plan, N, max(q.hsum, 1), dtype=torch.float32)
+                        qg = self._new(plan, N, F, dtype=torch.float32)
+                        qdz = self._new(plan, N, F, dtype=torch.float32) if train else None
+                        item = L.QMlpNItem(acts=_ptr(qa), gate=_ptr(qg), dzq=_ptr(qdz), nlayers=len(q.layers), scale=1.0)
+                        for li, lay in enumerate(q.layers):
+                            item.w[li], item.b[li], item.gw[li], item.gb[li] = _ptr(lay['w']), _ptr(lay['b']), _ptr(lay['gw']), _ptr(lay['gb'])
+                        for li, wd in enumerate(q.widths):
+                            item.n[li] = wd
+                        plan.qn_items.append(item)
+                        plan.qn_shape = tuple(q.widths)
+                    elif q is not None:      # meta-attention gate of this QRCAB: evaluated for all layers by one launch before the forward ops
                         qh = self._new(plan, N, q.Hq, dtype=torch.float32)
                         qg = self._new(plan, N, F, dtype=torch.float32)
                         qdz = self._new(plan, N, F, dtype=torch.float32) if train else None
@@ -1222,8 +1247,8 @@ class SREngine:
             if getattr(plan, 'ca_params_dev', None) is None:
                 plan.ca_params_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
             plan.ca_params_dev.copy_(torch.from_numpy(raw), non_blocking=False)
-        if plan.q_items:
-            for a in plan.q_items:
+        if plan.q_items or plan.qn_items:
+            for a in plan.q_items + plan.qn_items:
                 a.scale = gs
             self._upload_q_items(plan)
         if plan.qca_items:
@@ -1246,11 +1271,22 @@ class SREngine:
         return worst
 
     def _upload_q_items(self, plan):
-        arr = (L.QMlpItem * len(plan.q_items))(*plan.q_items)
-        raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-        if plan.q_dev is None:
-            plan.q_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
-        plan.q_dev.copy_(torch.from_numpy(raw), non_blocking=False)
+        if plan.q_items:
+            arr = (L.QMlpItem * len(plan.q_items))(*plan.q_items)
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            if plan.q_dev is None:
+                plan.q_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
+            plan.q_dev.copy_(torch.from_numpy(raw), non_blocking=False)
+        if plan.qn_items:
+            arr = (L.QMlpNItem * len(plan.qn_items))(*plan.qn_items)
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            if plan.qn_dev is None:
+                plan.qn_dev = torch.empty(raw.size, dtype=torch.uint8, device=self.device)
+            plan.qn_dev.copy_(torch.from_numpy(raw), non_blocking=False)
+
+    @staticmethod
+    def _qn_widths(plan):
+        return (C.c_int32 * len(plan.qn_shape))(*plan.qn_shape), len(plan.qn_shape) - 1
 
     def _q_gates(self, plan, meta, stream, launch=True):
         """metadata [N,M] -> the plan's static metadata buffer, then (launch) the meta-attention gates of every q-layer in one launch"""
@@ -1264,29 +1300,41 @@ class SREngine:
             self._q_gates_launch(plan, stream)
 
     def _q_gates_launch(self, plan, stream):
-        if not plan.q_items:
+        if not plan.q_items and not plan.qn_items:
             return
-        if plan.q_dev is None:
+        if (plan.q_items and plan.q_dev is None) or (plan.qn_items and plan.qn_dev is None):
             self._upload_q_items(plan)
-        M, Hq = plan.q_shape
-        L.check(self.lib.rumpy_q_mlp_fwd(_ptr(plan.q_dev), len(plan.q_items), _ptr(plan.meta), plan.N, M, Hq, self.feats, stream), 'rumpy_q_mlp_fwd')
+        if plan.q_items:
+            M, Hq = plan.q_shape
+            L.check(self.lib.rumpy_q_mlp_fwd(_ptr(plan.q_dev), len(plan.q_items), _ptr(plan.meta), plan.N, M, Hq, self.feats, stream), 'rumpy_q_mlp_fwd')
+        if plan.qn_items:
+            n, nl = self._qn_widths(plan)
+            L.check(self.lib.rumpy_q_mlpn_fwd(_ptr(plan.qn_dev), len(plan.qn_items), _ptr(plan.meta), plan.N, n, nl, stream), 'rumpy_q_mlpn_fwd')
 
     def _q_param_grads(self, plan, stream):
         if plan.q_items:
             M, Hq = plan.q_shape
             L.check(self.lib.rumpy_q_mlp_bwd_params(_ptr(plan.q_dev), len(plan.q_items), _ptr(plan.meta), plan.N, M, Hq, self.feats, stream),
                     'rumpy_q_mlp_bwd_params')
+        if plan.qn_items:
+            n, nl = self._qn_widths(plan)
+            L.check(self.lib.rumpy_q_mlpn_bwd_params(_ptr(plan.qn_dev), len(plan.qn_items), _ptr(plan.meta), plan.N, n, nl, stream), 'rumpy_q_mlpn_bwd_params')
 
     def meta_grad(self, plan):
         """d loss / d metadata [N, M] of the backward pass that has just run on `plan` (q-layer networks: the metadata enters through the
         ParaCALayer MLPs only).  Asked for by the autograd node when the metadata itself has a gradient path (a jointly trained encoder)."""
-        if not plan.q_items or plan.qca_items:
+        if not (plan.q_items or plan.qn_items) or plan.qca_items:
             raise RuntimeError('rumpy_amd: the gradient of the metadata input is built for q-layer networks (style "standard" + '
                                'include_q_layer) only')
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if plan.qn_items:
+            n, nl = self._qn_widths(plan)
+            dmeta = torch.empty(plan.N, plan.qn_shape[0], dtype=torch.float32, device=self.device)
+            L.check(self.lib.rumpy_q_mlpn_bwd_meta(_ptr(plan.qn_dev), len(plan.qn_items), plan.N, n, nl, _ptr(dmeta), stream), 'rumpy_q_mlpn_bwd_meta')
+            return dmeta
         M, Hq = plan.q_shape
         dmeta = torch.empty(plan.N, M, dtype=torch.float32, device=self.device)
-        L.check(self.lib.rumpy_q_mlp_bwd_meta(_ptr(plan.q_dev), len(plan.q_items), plan.N, M, Hq, self.feats, _ptr(dmeta),
-                                              torch.cuda.current_stream(self.device).cuda_stream), 'rumpy_q_mlp_bwd_meta')
+        L.check(self.lib.rumpy_q_mlp_bwd_meta(_ptr(plan.q_dev), len(plan.q_items), plan.N, M, Hq, self.feats, _ptr(dmeta), stream), 'rumpy_q_mlp_bwd_meta')
         return dmeta
 
     # ------------------------------------------------------------------ execution
@@ -1530,7 +1578,7 @@ class SREngine:
             self._bind_batch(plan, x, target, cur)
             self._q_gates(plan, meta, None, launch=False)
 
-            if plan.q_items and plan.q_dev is None:
+            if (plan.q_items and plan.q_dev is None) or (plan.qn_items and plan.qn_dev is None):
                 self._upload_q_items(plan)          # not inside the capture
 
             def body(stream):

@@ -1,4 +1,5 @@
-"""Golden fixture G12 (meta-attention QRCAN) from the REAL reference handler.
+"""Golden fixtures G12 (meta-attention QRCAN) and G24 (the same with ParaCALayer's num_layers = 1 and 3: `num_layers_in_q_layer`,
+attention_manipulators/architectures.py:162,182-183) from the REAL reference handler.
 
 Runs ONLY in the build container (needs /root/reference):   python tests/golden/make_golden_qrcan.py
 The reference's define_model('qrcan', style='standard', include_q_layer=True, metadata=[...]) is built on the CPU (reduced: 16
@@ -28,19 +29,21 @@ def meta_batch(seed, n):
     return torch.from_numpy(gen.uniform(0, 1, (n, len(META))).astype(np.float32))
 
 
-def main():
+def main(depth=2, out='g12_qrcan_small_train.npz'):
     import tempfile
     torch.manual_seed(0)
     kw = dict(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True, lr=1e-3,
               scheduler='cosine_annealing_warm_restarts', scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+    extra = {} if depth == 2 else {'num_layers_in_q_layer': depth}
+    kw.update(extra)
     h = define_model('qrcan', model_save_dir=tempfile.mkdtemp(), device=torch.device('cpu'), eval_mode=False, checkpoint_load=False,
                      loss_masking=False, metadata_list=None, metadata=list(META), **kw)
     # default initialisation under torch.manual_seed(8): pins the layer CREATION order (one checksum pair per tensor)
     torch.manual_seed(8)
     from rumpy.SISR.models.attention_manipulators.architectures import QRCAN as RefQRCAN
-    r8 = RefQRCAN(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True, num_metadata=len(META))
+    r8 = RefQRCAN(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True, num_metadata=len(META), **extra)
     init8 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in r8.state_dict().values()])
-    h.net.load_state_dict(O.seeded_state_dict(h.net, 811))
+    h.net.load_state_dict(O.seeded_state_dict(h.net, 811 + (0 if depth == 2 else 10 * depth)))
     keys = [(m,) for m in META]                          # the dataset delivers (name, ...) tuples; QModel reads key[0]
     d = {'keys': np.array(list(h.net.state_dict().keys())), 'init8': init8}
     for step in range(3):
@@ -63,9 +66,11 @@ def main():
     d['eval_out'] = ev.detach().numpy()
     d['eval_loss'] = np.asarray(evl)
     d['num_metadata'] = np.asarray(h.num_metadata)
-    np.savez_compressed(os.path.join(HERE, 'g12_qrcan_small_train.npz'), **d)
-    print('wrote g12_qrcan_small_train.npz; params', sum(p.numel() for p in h.net.parameters()), 'num_metadata', h.num_metadata)
+    np.savez_compressed(os.path.join(HERE, out), **d)
+    print('wrote', out, '; params', sum(p.numel() for p in h.net.parameters()), 'num_metadata', h.num_metadata)
 
 
 if __name__ == '__main__':
     main()
+    main(1, 'g24_qrcan_qdepth1_small_train.npz')
+    main(3, 'g24_qrcan_qdepth3_small_train.npz')

@@ -62,7 +62,7 @@ def test_ctypes_structs_match_the_header_layout():
              'rumpy_ca_bwd_apply_args': _lib.CaBwdApplyArgs, 'rumpy_adam_hyper': _lib.AdamHyper, 'rumpy_adam_args': _lib.AdamArgs,
              'rumpy_sumsq_args': _lib.SumsqArgs, 'rumpy_eval_post_args': _lib.EvalPostArgs, 'rumpy_block_args': _lib.BlockArgs,
              'rumpy_ca_fwd_fused_args': _lib.CaFwdFusedArgs, 'rumpy_ca_bwd_fused_args': _lib.CaBwdFusedArgs,
-             'rumpy_q_mlp_item': _lib.QMlpItem, 'rumpy_ssim_args': _lib.SsimArgs, 'rumpy_patch_item': _lib.PatchItem, 'rumpy_patch_args': _lib.PatchArgs,
+             'rumpy_q_mlp_item': _lib.QMlpItem, 'rumpy_q_mlpn_item': _lib.QMlpNItem, 'rumpy_ssim_args': _lib.SsimArgs, 'rumpy_patch_item': _lib.PatchItem, 'rumpy_patch_args': _lib.PatchArgs,
              'rumpy_finish_reduce_args': _lib.FinishReduceArgs, 'rumpy_update_item': _lib.UpdateItem, 'rumpy_adam_pack_args': _lib.AdamPackArgs,
              'rumpy_qca_layer': _lib.QcaLayer, 'rumpy_qca_args': _lib.QcaArgs,
              'rumpy_dconv_args': _lib.DconvArgs, 'rumpy_dconv_wgrad_args': _lib.DconvWgradArgs, 'rumpy_mse_args': _lib.MseArgs, 'rumpy_op': _lib.Op,
@@ -393,6 +393,18 @@ def test_qrcan_module_tree_has_the_reference_key_and_creation_order(golden_dir):
     assert qk and all(k.startswith('body.1.body.0.q_node') for k in qk)
     with pytest.raises(RuntimeError):
         QRCAN(style='modulate', **kw)
+    # ParaCALayer's num_layers other than 2: the REAL reference's keys (golden G24) and the oracle's seed-8 weights
+    for depth in (1, 3):
+        g24 = np.load(os.path.join(golden_dir, 'g24_qrcan_qdepth%d_small_train.npz' % depth))
+        torch.manual_seed(8)
+        netd = QRCAN(style='standard', include_q_layer=True, num_metadata=5, num_layers_in_q_layer=depth, **kw)
+        assert list(netd.state_dict().keys()) == [str(k) for k in g24['keys']]
+        torch.manual_seed(8)
+        od = O.build_oracle('qrcan', style='standard', include_q_layer=True, num_metadata=5, num_layers_in_q_layer=depth, **kw)
+        for (k, a), (k2, b) in zip(netd.state_dict().items(), od.state_dict().items()):
+            assert k == k2 and torch.equal(a, b), k
+    with pytest.raises(RuntimeError, match='FC layers'):
+        QRCAN(style='standard', include_q_layer=True, num_metadata=5, num_layers_in_q_layer=5, **kw)
 
 
 @pytest.mark.parametrize('style', ['max_concat', 'mini_concat', 'extended_attention', 'softmax'])

@@ -247,6 +247,40 @@ def test_g12_qrcan_meta_attention_oracle_matches_reference_handler(golden_dir):
     assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
 
 
+@pytest.mark.parametrize('depth', [1, 3])
+def test_g24_qrcan_q_layer_depths_oracle_matches_reference_handler(golden_dir, depth):
+    """the same with ParaCALayer's num_layers = 1 and 3 (`num_layers_in_q_layer`): key order, seed-8 initialisation, three training steps and one
+    evaluation of the REAL reference QRCANHandler (tests/golden/make_golden_qrcan.py)"""
+    g = np.load(os.path.join(golden_dir, 'g24_qrcan_qdepth%d_small_train.npz' % depth))
+    M = int(g['num_metadata'])
+    kw = dict(scale=2, n_feats=16, n_resgroups=2, n_resblocks=2, reduction=16, style='standard', include_q_layer=True, num_metadata=M, num_layers_in_q_layer=depth)
+    net = O.build_oracle('qrcan', **kw)
+    assert list(net.state_dict().keys()) == [str(k) for k in g['keys']]
+    torch.manual_seed(8)
+    net8 = O.build_oracle('qrcan', **kw)
+    init8 = np.array([[float(v.double().sum()), float(v.double().abs().sum())] for v in net8.state_dict().values()])
+    assert np.allclose(init8, g['init8'], rtol=0, atol=1e-12)
+    net.load_state_dict(O.seeded_state_dict(net, 811 + 10 * depth))
+    h = O.OracleHandler(net, lr=1e-3, scheduler='cosine_annealing_warm_restarts', scheduler_params={'t_mult': 1, 'restart_period': 5, 'lr_min': 1e-7})
+
+    def meta(seed, n):
+        m = np.random.default_rng(seed).uniform(0, 1, (n, M)).astype(np.float32)
+        return torch.from_numpy(m).unsqueeze(2).unsqueeze(3)
+    for step in range(3):
+        xb, yb = O.synthetic_batch(700 + step, 2, lr_hw=12, scale=2)
+        loss, out = h.run_train(xb, yb, extra_channels=meta(750 + step, 2))
+        assert abs(float(loss) - float(g['loss%d' % step])) < 1e-6
+        if step == 0:
+            assert np.allclose(out.numpy(), g['out0'], atol=1e-6)
+            for k, p in net.named_parameters():
+                assert np.allclose(p.grad.numpy(), g['grad0.' + k], atol=1e-6, rtol=1e-4), k
+    for k, v in net.state_dict().items():
+        assert np.allclose(v.numpy(), g['w3.' + k], atol=2e-6), k
+    xe, ye = O.synthetic_batch(790, 1, lr_hw=10, scale=2)
+    ev, evl, _ = h.run_eval(xe, ye, request_loss=True, extra_channels=meta(791, 1))
+    assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
+
+
 @pytest.mark.parametrize('si,style', list(enumerate(('max_concat', 'mini_concat', 'extended_attention', 'softmax'))))
 def test_g19_qcalayer_styles_oracle_matches_reference_handler(golden_dir, si, style):
     """oracle QRCAN with the QCALayer styles whose gate MLP also reads the attribute vector, against three training steps and one evaluation

