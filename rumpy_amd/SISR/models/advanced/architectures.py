@@ -435,7 +435,8 @@ class RCAN(HipSRNet):
                  res_scale=1.0, **kwargs):
         super().__init__()
         f = n_feats
-        P = _ceil64(f) if f % 64 else None       # fewer than 64 features: embedded in the 64-feature kernels (_embed)
+        P = _ceil64(f) if f % 64 else None       # a width between the kernel widths runs embedded in the next one (_embed)
+        self.supports_fused_l1 = (P or f) == 64   # (wide nets: the handlers take the generic loss path, as for EDSR at 128 .. 256 features)
         self.scale = scale
         self.head = nn.Sequential(_conv(in_feats, f, pout=P))
         self.body = nn.Sequential(*([_GroupParams(f, reduction, res_scale, n_resblocks, P) for _ in range(n_resgroups)]

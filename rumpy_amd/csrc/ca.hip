@@ -413,8 +413,15 @@ extern "C" int rumpy_ca_bwd_reduce(const rumpy_ca_bwd_reduce_args* p, void* stre
                      (const uint4*)p->t, p->partial, p->HW, p->C, nchunks);
   return rumpy_check_launch("rumpy_ca_bwd_reduce");
 }
+constexpr size_t CA_PARAMS_LDS_MAX = 150 * 1024;      // 256 channels x 16 hidden units (RCAN at 256 features, round 5) need 135 KB: opted in below
 static size_t ca_params_lds(int N, int C, int Cr, int* Cp) {
   *Cp = (C + 63) / 64 * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ca_mlp_bwd_params_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CA_PARAMS_LDS_MAX);
+    (void)hipFuncSetAttribute((const void*)ca_mlp_bwd_params_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CA_PARAMS_LDS_MAX);
+    attr_set = true;
+  }
   return ((size_t)N * Cr + (size_t)CA_PGROUPS * *Cp * (2 * Cr + 1) + (size_t)CA_PGROUPS * Cr) * sizeof(float);
 }
 extern "C" int rumpy_ca_mlp_bwd(const rumpy_ca_mlp_bwd_args* p, void* stream) {
@@ -425,7 +432,7 @@ extern "C" int rumpy_ca_mlp_bwd(const rumpy_ca_mlp_bwd_args* p, void* stream) {
   if (!ca_shape_ok(p->C, p->Cr) || p->N <= 0 || p->nchunks <= 0) { rumpy_set_error("rumpy_ca_mlp_bwd: unsupported shape"); return RUMPY_E_ARG; }
   int Cp;
   const size_t dyn = ca_params_lds(p->N, p->C, p->Cr, &Cp);
-  if (p->Cr > CA_PR || dyn > 60 * 1024) { rumpy_set_error("rumpy_ca_mlp_bwd: shape too large for the parameter kernel (N=%d C=%d Cr=%d)", p->N, p->C, p->Cr); return RUMPY_E_ARG; }
+  if (p->Cr > CA_PR || dyn > CA_PARAMS_LDS_MAX) { rumpy_set_error("rumpy_ca_mlp_bwd: shape too large for the parameter kernel (N=%d C=%d Cr=%d)", p->N, p->C, p->Cr); return RUMPY_E_ARG; }
   hipLaunchKernelGGL(ca_mlp_bwd_image_kernel, dim3(p->N), dim3(CA_MAXC), 0, (hipStream_t)stream, *p);
   if (with_params) hipLaunchKernelGGL(ca_mlp_bwd_params_kernel, dim3(1), dim3(CA_PGROUPS * Cp), dyn, (hipStream_t)stream, *p, Cp);
   return rumpy_check_launch("rumpy_ca_mlp_bwd");
@@ -434,7 +441,7 @@ extern "C" int rumpy_ca_mlp_bwd_params(const rumpy_ca_mlp_bwd_args* items_device
   if (!items_device || nitems <= 0 || N <= 0 || !ca_shape_ok(C, Cr)) { rumpy_set_error("rumpy_ca_mlp_bwd_params: bad argument"); return RUMPY_E_ARG; }
   int Cp;
   const size_t dyn = ca_params_lds(N, C, Cr, &Cp);
-  if (Cr > CA_PR || dyn > 60 * 1024) { rumpy_set_error("rumpy_ca_mlp_bwd_params: shape too large (N=%d C=%d Cr=%d)", N, C, Cr); return RUMPY_E_ARG; }
+  if (Cr > CA_PR || dyn > CA_PARAMS_LDS_MAX) { rumpy_set_error("rumpy_ca_mlp_bwd_params: shape too large (N=%d C=%d Cr=%d)", N, C, Cr); return RUMPY_E_ARG; }
   hipLaunchKernelGGL(ca_mlp_bwd_params_batch_kernel, dim3(nitems), dim3(CA_PGROUPS * Cp), dyn, (hipStream_t)stream, items_device, Cp);
   return rumpy_check_launch("rumpy_ca_mlp_bwd_params");
 }

@@ -208,8 +208,14 @@ class SREngine:
             raise RuntimeError('rumpy_amd: image channels must be <= 4')
         if spec.tail.cin != self.feats:
             raise RuntimeError('rumpy_amd: tail conv needs %d input features (got %d)' % (self.feats, spec.tail.cin))
-        if self.wide and (spec.cas() or spec.num_metadata or any(it[0] != 'resblock' for it in spec.body)):
-            raise RuntimeError('rumpy_amd: n_feats > 64 is built for EDSR (residual blocks); the channel-attention kernels are 64-feature kernels')
+        if self.wide and (spec.cas() or any(it[0] != 'resblock' for it in spec.body)):
+            # RCAN wider than 64 features (round 5): every conv on the Cin = 128 / 256 form of rumpy_conv3x3, the channel attention as its separate
+            # launches (pool sums from the conv's epilogue, rumpy_ca_fwd_fused, rumpy_ca_bwd_reduce / _fused: C <= 256 with C / 8 dividing 256). The
+            # one-launch RCAB kernels and the q-layer launches are 64-feature kernels.
+            plain_ca = all(not getattr(ca, 'gen', False) and not isinstance(ca, QLayerParams) for ca in spec.cas())
+            if self.feats not in (128, 256) or spec.num_metadata or not plain_ca:
+                raise RuntimeError('rumpy_amd: n_feats > 64 is built for EDSR and for plain RCAN at 128 / 256 features; meta-attention / styled channel '
+                                   'attention and 192-feature channel attention are 64-feature kernels')
         for cv in spec.convs():
             if cv.kind == 'main' and (cv.cin not in (64, 128, 192, 256) or cv.cout % 64):
                 raise RuntimeError('rumpy_amd: conv %s %d->%d unsupported (Cin must be 64, 128, 192 or 256, Cout a multiple of 64)'
@@ -447,7 +453,7 @@ class SREngine:
         Cin, Cout = spec.head.cin, spec.tail.cout
         plan.x_in = self._new(plan, N, Cin, H, W, dtype=torch.float32)
         fwd, bwd = plan.fwd, plan.bwd
-        tiles = int(lib.rumpy_conv_pool_tiles(H, W, 1))     # per-image pool partial rows written by the 64->64 conv
+        tiles = int(lib.rumpy_conv_pool_tiles(H, W, F // 64))     # per-image pool partial rows written by the F->F conv (its kernel's tiling)
         # ... and by the one-launch residual block (column tiles when W > 48: another count of partial rows)
         btiles = int(lib.rumpy_block_pool_tiles(H, W))
         wjobs = []      # (layer, x, dy, H, W, dy_mode, scale, mt)
@@ -503,7 +509,7 @@ class SREngine:
 
             for it in items:
                 lazy = (it[0] == 'rcab' and not getattr(it[3], 'gen', False) and it[3].Cr <= 4 and self.rcab_form != 'xchg' and self.use_rcab_kernel and self.use_block_kernel
-                        and (W <= 48 or self.block_any_width) and not (train and (self.fp8 or not self.use_mask_bytes)))
+                        and not self.wide and (W <= 48 or self.block_any_width) and not (train and (self.fp8 or not self.use_mask_bytes)))
                 if lazy and self.rcab_form == 'auto':
                     lazy = W > 48 or int(self.lib.rumpy_rcab_strips(H, W)) > self.cus
                 if pending is not None and not lazy:
@@ -645,7 +651,7 @@ class SREngine:
                         cur = None
                         continue
                     t1, t2, y = act(), act(), act()
-                    fused = self.use_block_kernel and (W <= 48 or self.block_any_width)
+                    fused = self.use_block_kernel and (W <= 48 or self.block_any_width) and not self.wide
                     # the whole RCAB in one launch (conv_rcab.hip): the strips of an image exchange their pool sums, the gate is applied on chip
                     # (every strip of an image - strip rows x column tiles - has to be resident at the same time)
                     rc = fused and self.use_rcab_kernel and int(self.lib.rumpy_rcab_strips(H, W)) <= self.cus and 2 * plan.rcab_n + 2 <= 4096

@@ -467,9 +467,10 @@ def test_wgrad_tail_dy4(W, variant):
     assert_f32_close(gb, rb, 'tail bgrad', rel=1e-4)
 
 
-def test_channel_attention_forward_backward():
+@pytest.mark.parametrize('Cc,Cr', [(64, 4), (128, 8), (256, 16), (128, 6)])
+def test_channel_attention_forward_backward(Cc, Cr):
     gen = np.random.default_rng(20)
-    N, H, W, Cc, Cr = 3, 10, 23, 64, 4
+    N, H, W = 3, 10, 23
     t2, xres, gy = _rand(gen, N, Cc, H, W), _rand(gen, N, Cc, H, W), _rand(gen, N, Cc, H, W)
     w1 = torch.from_numpy(gen.uniform(-0.3, 0.3, (Cr, Cc, 1, 1)).astype(np.float32)).requires_grad_(True)
     b1 = torch.from_numpy(gen.uniform(-0.3, 0.3, (Cr,)).astype(np.float32)).requires_grad_(True)
