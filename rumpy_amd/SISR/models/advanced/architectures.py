@@ -257,7 +257,7 @@ class HipSRNet(nn.Module):
     def _q_layer(self, name, qn):
         convs = [m for m in qn.attribute_integrator if isinstance(m, nn.Conv2d)]
         idx = {id(p): i for i, p in enumerate(self.param_list)}
-        if len(convs) != 2:       # ParaCALayer's num_layers other than the default: the general-depth launches (rumpy_q_mlpn_*)
+        if len(convs) != 2 or convs[-1].weight.shape[0] > 64:       # ParaCALayer's num_layers other than the default, or more than 64 features: the general-depth launches (rumpy_q_mlpn_*)
             return QLayerNParams(name, [dict(w=c.weight.data.reshape(c.weight.shape[0], -1), b=c.bias.data, gw=self.grad_views[idx[id(c.weight)]],
                                              gb=self.grad_views[idx[id(c.bias)]]) for c in convs])
         c0, c2 = convs

@@ -118,6 +118,7 @@ class QRCAN(HipSRNet):
             raise RuntimeError('rumpy_amd: QRCAN option(s) %s are not implemented on the HIP path (every QCALayer style, with or without '
                                'q-layers - "modulate" without); there is no fallback' % ', '.join(unsupported))
         f = n_feats
+        self.supports_fused_l1 = f == 64          # (wider nets: the handlers take the generic loss path)
         self.scale, self.num_metadata, self.style = scale, num_metadata, style
         self.metadata_reduction = nn.Sequential(nn.Identity())
         head = _conv(in_feats, f)

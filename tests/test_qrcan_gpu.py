@@ -189,6 +189,30 @@ def test_qrcan_with_other_q_layer_depths_against_oracle(depth, names):
     assert plan.qn_items and not plan.q_items
 
 
+def test_qrcan_at_128_features_against_oracle():
+    """QRCAN 'standard' + q-layers wider than 64 features (round 5): convs on the Cin = 128 kernels, channel attention as its separate launches with the
+    meta-attention gate multiplied in, q-layers (5 -> 64 -> 128) on the general-depth launches.  Weight seed 837: every squeeze-excite hidden unit
+    >= 7e-3 away from its ReLU threshold on these inputs (conditioning note of test_qrcan_train_steps_against_oracle)."""
+    names = ['blur_sigma', 'noise_level', 'jpeg_q', 'extra_a', 'extra_b']
+    kw = dict(scale=2, n_feats=128, n_resgroups=2, n_resblocks=2, reduction=16)
+    h, oh = _pair(names, 837, **kw)
+    keys = [(n, 'numeric') for n in names]
+    for step in range(2):
+        x, y = O.synthetic_batch(860 + step, 3, lr_hw=16, scale=2)
+        m = _meta(870 + step, 3, 5)
+        loss, out = h.run_train(x=x, y=y, metadata=m, metadata_keys=keys)
+        oloss, oout = oh.run_train(x, y, extra_channels=m.unsqueeze(2).unsqueeze(3))
+        assert abs(float(loss) - float(oloss)) < (2e-3 if step == 0 else 1e-2) * float(oloss)
+        if step == 0:
+            assert self_psnr(out, oout) >= 50.0
+            _grad_check(h, oh)
+            for k, p in h.net.named_parameters():
+                if 'q_node' in k:
+                    assert float(p.grad.abs().max()) > 0, k
+    plan = h.net.engine.plan_for(3, 16, 16, True)
+    assert plan.qn_items and not plan.q_items and 'rumpy_rcab_fwd' not in [op for op, _ in plan.fwd]
+
+
 def test_qrcan_three_layer_q_nodes_return_the_gradient_of_their_metadata_input():
     kw = dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16, num_layers_in_q_layer=3)
     h, oh = _pair(['e%03d' % i for i in range(256)], 77, **kw)

@@ -192,3 +192,13 @@ def test_wide_channel_attention_nets_outside_the_built_shapes_are_refused():
                          n_feats=192, n_resgroups=1, n_resblocks=1, reduction=16, lr=1e-4, **SCHED)
         x, y = O.synthetic_batch(1900, 1, lr_hw=16, scale=2)
         h.run_train(x=x, y=y)
+
+
+def test_wide_rcan_evaluates_a_larger_image_like_the_oracle():
+    """RCAN at 128 features on a 96 x 140 image: 108 pool partial rows per image, i.e. the folded form of the channel attention's pool step"""
+    kw = dict(scale=2, n_feats=128, n_resgroups=1, n_resblocks=2, reduction=16)
+    h, oh = _pair('rcan', 1519, eval_mode=True, **kw)
+    xe, ye = O.synthetic_batch(1710, 1, lr_hw=(96, 140), scale=2)
+    ev, evl, _ = h.run_eval(x=xe, y=ye, request_loss=True)
+    oev, oevl, _ = oh.run_eval(xe, ye, request_loss=True)
+    assert self_psnr(ev, oev) >= 45.0 and abs(float(evl) - float(oevl)) < 1e-2 * float(oevl)
