@@ -237,6 +237,11 @@ typedef struct {
   void* work; int64_t work_bytes; void* status;
   int32_t fake_xcc;        /* test hook: > 0 = pretend workgroup b runs on XCD b % fake_xcc (claim bookkeeping under oversubscription); needs force_sc1 */
   int32_t force_sc1;       /* test hook / A-B: every hand-off through the memory side */
+  /* optional single 3x3 conv at the chain's OUTER end (edge_w != NULL): the body-end conv of EDSR (architectures.py:224: m_body.append(default_conv)).
+   * backward = 0: after the last block, edge_out = conv(out_last, edge_w) + edge_b [+ edge_res] - `res = self.body(x); res += x` (architectures.py:238-239);
+   * backward = 1: in front of the first block, blocks[0].x (a tensor the launch WRITES then) = conv(edge_x, edge_w), edge_w = the conv's data-gradient
+   * filter image.  Bitwise rumpy_conv3x3 in front of / behind the chain.  nblocks <= 254 with it. */
+  const void* edge_w; const float* edge_b; const void* edge_x; const void* edge_res; void* edge_out;
 } rumpy_res_chain_args;
 int rumpy_res_chain(const rumpy_res_chain_args* a, void* stream);
 int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H);

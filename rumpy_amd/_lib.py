@@ -74,7 +74,8 @@ class ResChainBlock(_S):
 
 class ResChainArgs(_S):
     _fields_ = [('blocks', c_void_p), ('nblocks', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('backward', c_int32), ('fmt', c_int32),
-                ('work', c_void_p), ('work_bytes', c_int64), ('status', c_void_p), ('fake_xcc', c_int32), ('force_sc1', c_int32)]
+                ('work', c_void_p), ('work_bytes', c_int64), ('status', c_void_p), ('fake_xcc', c_int32), ('force_sc1', c_int32),
+                ('edge_w', c_void_p), ('edge_b', c_void_p), ('edge_x', c_void_p), ('edge_res', c_void_p), ('edge_out', c_void_p)]
 
 
 class RcabChainBlock(_S):

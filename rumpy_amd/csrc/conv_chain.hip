@@ -26,7 +26,11 @@ struct ChainBlk {
   const uint16_t* res2; uint16_t* t; uint16_t* out; unsigned char* mbits; float scale1, scale2;
 };
 static_assert(sizeof(ChainBlk) == sizeof(rumpy_res_chain_block), "rumpy_res_chain_block is the device-side block record");
-struct ChainDev { const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* work; unsigned* status; int nxcd, fake_xcc, force_sc1; };
+struct ChainDev {
+  const ChainBlk* blk; int nblk, N, H, W, sy_n; unsigned* work; unsigned* status; int nxcd, fake_xcc, force_sc1;
+  // the single conv at the chain's outer end (rumpy_res_chain_args.edge_*; edge_w = NULL: none): FORM 1 behind the last block, FORM 3 in front of the first
+  const uint4* edge_w; const float* edge_b; const uint16_t* edge_x; const uint16_t* edge_res; uint16_t* edge_out;
+};
 
 // -DCHAIN_STAMPS (measurement builds only, tests/tools/r05_chain_stamps.sh): phase time stamps (s_memrealtime, 100 MHz) of every wave in the MIDDLE block
 #ifdef CHAIN_STAMPS
@@ -38,10 +42,11 @@ extern "C" int rumpy_debug_chain_stamps(void* buf) { return (int)hipMemcpyToSymb
 #endif
 
 // FORM 1: forward (ReLU, mask bytes written if given); FORM 3: data gradient (* scale1, mask bytes read)
-template <int FORM, int FMT = RUMPY_FMT_BF16>
+// EDGE: with the single conv at the chain's outer end (its own instantiations: the plain chain keeps its register budget)
+template <int FORM, int FMT = RUMPY_FMT_BF16, bool EDGE = false>
 __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
-  __shared__ unsigned gate[8];             // per row half: T rows written [0,1], OUT rows written [2,3], halo rows in LDS [4,5], stores acknowledged [6,7]
+  __shared__ unsigned gate[10];            // per row half: T rows written [0,1], OUT rows written [2,3], halo rows in LDS [4,5], stores acknowledged [6,7], edge conv's rows staged [8,9]
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + BXBYTES;
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,9 +63,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   // this row half's hand-off: through the XCD's L2 (sc0 stores) when the neighbour that reads its rows runs on the same XCD, write-through otherwise
   const bool local = has_nb && !a.force_sc1 && chain_same_xcd(a.work, epoch, nb_strip, place.xcc, a.status);
   const ChainBlk b0 = a.blk[0];
+  constexpr bool pre = FORM == 3 && EDGE;        // the edge conv in front of block 0: the tile loaded here is ITS input
+  constexpr bool post = FORM == 1 && EDGE;
 
   // ---- block 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (conv_block.hip) ----
   {
+    const uint16_t* const src0 = pre ? a.edge_x : b0.x;
     uint4 R[BREGS];
     const int y0 = sy * BSH - 2;
 #pragma unroll
@@ -71,10 +79,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       const int y = y0 + lr, x = lc - 1;
       const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(b0.x + (unsigned)e);
+      uint4 v = *reinterpret_cast<const uint4*>(src0 + (unsigned)e);
       R[i] = keep_if(v, ok);
     }
-    if (tid < 8) gate[tid] = 0u;
+    if (tid < 10) gate[tid] = 0u;
     if (tid < BTROWS * 2 * 8) {            // border columns of the T image: convB's zero padding, never written by the epilogues
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
@@ -88,11 +96,86 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   }
   bf16x8 F[18];
   {
-    const uint4* wp = b0.w1 + (size_t)q * 18 * 64 + lane0;
+    const uint4* wp = (pre ? a.edge_w : b0.w1) + (size_t)q * 18 * 64 + lane0;
 #pragma unroll
     for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
   }
   __syncthreads();
+
+  // The edge conv's three rows of this row half, accumulated in acc3 (bias included) -> [+ res] -> rows 3rh+1 .. 3rh+3 of the T image (scratch here: no
+  // sweep reads it), from where they leave as whole lines.  Pairs as in the blocks' second epilogue.
+  auto edge_rows_to_t = [&](f32x4 (&acc3)[3][3], const uint16_t* res) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int px = lane & 15, g = lane >> 4, c0 = 16 * q + 4 * g, gpair = 4 * (g & ~1), chunk8 = 2 * q + (gpair >> 3);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 tx = (k < 3) ? acc3[k < 3 ? k : 0][0] : acc3[0][2];
+      const f32x4 ty = (k < 3) ? acc3[k < 3 ? k : 0][1] : acc3[1][2];
+      float v[8];
+      pair_up(tx, ty, g, v);
+      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
+      const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
+      if (y < a.H && xx < a.W) {
+        if (res) {
+          float m[8];
+          unpack8<FMT>(*reinterpret_cast<const uint4*>(res + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair)), m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += m[j];
+        }
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<uint4*>(ldt + swz((srow + 1) * BCOLS + xx + 1, chunk8)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+    }
+    {
+      const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px;
+      if (y < a.H && xx < a.W) {
+        float v[4] = {acc3[2][2][0], acc3[2][2][1], acc3[2][2][2], acc3[2][2][3]};
+        if (res) {
+          float m[4];
+          unpack4<FMT>(*reinterpret_cast<const uint2*>(res + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0)), m);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += m[j];
+        }
+        *reinterpret_cast<uint2*>(ldt + swz((srow + 1) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8) = pack4<FMT>(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+  if (pre) {
+    // ---- the conv in front of the chain (data gradient of the body-end conv): this half's three rows from input rows 3rh .. 3rh+4 of the tile ----
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    f32x4 acc3[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc3[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned off[8][2];
+    sweep_bases(off, 0u, 3 * rh + 1, lane & 15, lane >> 4);
+    block_sweep<3, FMT>(acc3, F, lds, off);
+    {
+      const uint4* wp = b0.w1 + (size_t)q * 18 * 64 + lane0;      // block 0's first filter, under the epilogue
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    }
+    edge_rows_to_t(acc3, nullptr);
+    gate_arrive(&gate[8 + rh], lane);
+    gate_wait(&gate[8], 4u);
+    gate_wait(&gate[9], 4u);                 // both halves are through their sweeps (they read each other's rows of the tile) and have staged their rows
+    // the rows become the resident strip (input image rows 3rh+2 .. 3rh+4) and go to HBM for the neighbours and the weight gradient: whole lines
+    const int tg = 64 * q + lane;
+    uint4 S[GROUP_REGS];
+    group_stage<1>(S, ldt, tg, rh);
+#pragma unroll
+    for (int i = 0; i < GROUP_REGS; ++i) {
+      const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+      const unsigned so = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+      if (p < GROUP_PIECES) *reinterpret_cast<uint4*>(ldx + swz((3 * rh + r + 2) * BCOLS + col + 1, p & 7)) = (so != 0xffffffffu) ? S[i] : make_uint4(0, 0, 0, 0);
+      if (so != 0xffffffffu) { if (local) ch_store16_sc0(const_cast<uint16_t*>(b0.x) + so, S[i]); else ch_store16_sc1(const_cast<uint16_t*>(b0.x) + so, S[i]); }
+    }
+    gate_arrive(&gate[2 + rh], lane);
+  }
+  constexpr unsigned pre4 = pre ? 4u : 0u;       // the gates of the block boundary (OUT rows written, halo rows in, stores acknowledged) have seen one more round
 
   for (int b = 0; b < a.nblk; ++b) {
     const ChainBlk blk = a.blk[b];
@@ -125,7 +208,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       hoff[i] = (has_nb && (unsigned)y < (unsigned)a.H && col < a.W) ? (unsigned)(((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
       hlds[i] = swz(((rh == 0) ? r : BSH + 2 + r) * BCOLS + col + 1, p & 7);
     }
-    const unsigned done = 4u * (unsigned)b;              // gate counts at the end of block b - 1
+    const unsigned done = 4u * (unsigned)b + pre4;       // boundary-gate counts at the end of block b - 1
+    const unsigned tdone = 4u * (unsigned)b;             // T-gate counts
     unsigned MB[FORM == 3 ? 6 : 1];
     if (FORM == 3) {
 #pragma unroll
@@ -141,7 +225,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
         for (int c = 0; c < 3; ++c) acc[r][c] = b4;
     }
     unsigned off[8][2];
-    if (b == 0) {
+    if (b == 0 && !pre) {
       sweep_bases(off, 0u, 4 * rh, px, g);
       block_sweep<4, FMT>(acc, F, lds, off);
     } else {
@@ -225,8 +309,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     }
     CH_STAMP(7);
     gate_arrive(&gate[rh], lane);
-    gate_wait(&gate[rh], done + 4u);
-    if (rh == 1) gate_wait(&gate[0], done + 4u);
+    gate_wait(&gate[rh], tdone + 4u);
+    if (rh == 1) gate_wait(&gate[0], tdone + 4u);
     // the row half's own strip rows of T (+ mask bytes) -> HBM from the LDS image: whole lines, non-temporal, under the second sweep
     uint4 S[GROUP_REGS];
     const bool t_out = blk.t != nullptr;
@@ -253,7 +337,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     if (rh == 0) {
       sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
       block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[0]), F, lds, off, t_store);
-      gate_wait(&gate[1], done + 4u);
+      gate_wait(&gate[1], tdone + 4u);
       sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
       block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc2[2]), F, lds, off);
     } else {
@@ -261,8 +345,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       block_sweep<3, FMT>(acc2, F, lds, off, t_store);
     }
     CH_STAMP(8);
-    if (b + 1 < a.nblk) {                                // the next block's first filter lands under the epilogue and the halo step
-      const uint4* wp = a.blk[b + 1].w1 + (size_t)q * 18 * 64 + lane;
+    if (b + 1 < a.nblk || post) {                        // the next block's first filter (or the edge conv's) lands under the epilogue and the halo step
+      const uint4* wp = (b + 1 < a.nblk ? a.blk[b + 1].w1 : a.edge_w) + (size_t)q * 18 * 64 + lane;
 #pragma unroll
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
@@ -316,6 +400,76 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     }
     CH_STAMP(10);
   }
+  if (post) {
+    // ---- the conv behind the chain (EDSR's body-end conv + the global skip): block-start steps once more, then ONE sweep and its rows out through the T image ----
+    const unsigned b = (unsigned)a.nblk, done = 4u * b;
+    const ChainBlk last = a.blk[a.nblk - 1];
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int px = lane & 15, g = lane >> 4, tg = 64 * q + lane;
+    f32x4 acc3[3][3];
+    {
+      f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (a.edge_b) { const float4 t = *reinterpret_cast<const float4*>(a.edge_b + 16 * q + 4 * g); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc3[r][c] = b4;
+    }
+    unsigned hoff[3], hlds[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
+      const int y = (rh == 0) ? sy * BSH - 2 + r : sy * BSH + BSH + r;
+      hoff[i] = (has_nb && (unsigned)y < (unsigned)a.H && col < a.W) ? (unsigned)(((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+      hlds[i] = swz(((rh == 0) ? r : BSH + 2 + r) * BCOLS + col + 1, p & 7);
+    }
+    gate_wait(&gate[2], done);
+    gate_wait(&gate[3], done);
+    unsigned off[8][2];
+    // the two rows that need no halo row (strip rows 1, 2 | 3, 4: input image rows 2 .. 5 | 4 .. 7)
+    sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
+    block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc3[(rh == 0) ? 1 : 0]), F, lds, off);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gate_arrive(&gate[6 + rh], lane);
+    if (q == 0) {
+      gate_wait(&gate[6 + rh], done);
+      if (lane == 0) { if (local) ch_store_flag_sc0(flags + (2 * strip + rh) * CH_FLAG_STRIDE, (epoch << 8) + b); else __hip_atomic_store(flags + (2 * strip + rh) * CH_FLAG_STRIDE, (epoch << 8) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    if (has_nb) {
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned f = __hip_atomic_load(flags + (2 * nb_strip + (1 - rh)) * CH_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((f >> 8) == epoch && (f & 0xffu) >= (b & 0xffu)) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + b); break; }
+      }
+    }
+    {
+      uint4 Hr[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Hr[i] = ch_load16_sc1(last.out + (hoff[i] != 0xffffffffu ? hoff[i] : 0u));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (hoff[i] != 0xffffffffu) *reinterpret_cast<uint4*>(ldx + hlds[i]) = Hr[i];
+    }
+    gate_arrive(&gate[4 + rh], lane);
+    gate_wait(&gate[4 + rh], done);
+    // the row that does (strip row 0 | 5)
+    sweep_bases(off, 0u, (rh == 0) ? 1 : 6, px, g);
+    block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc3[(rh == 0) ? 0 : 2]), F, lds, off);
+    edge_rows_to_t(acc3, a.edge_res);
+    gate_arrive(&gate[8 + rh], lane);
+    gate_wait(&gate[8 + rh], 4u);
+    uint4 S[GROUP_REGS];
+    group_stage<1>(S, ldt, tg, rh);
+#pragma unroll
+    for (int i = 0; i < GROUP_REGS; ++i) {
+      const unsigned so = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
+      if (so != 0xffffffffu) st16_nt(a.edge_out + so, S[i]);
+    }
+  }
 }
 
 extern "C" int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H) {
@@ -334,10 +488,17 @@ extern "C" int rumpy_res_chain(const rumpy_res_chain_args* p, void* stream) {
   d.blk = reinterpret_cast<const ChainBlk*>(p->blocks); d.nblk = p->nblocks; d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;
   d.work = (unsigned*)p->work; d.status = (unsigned*)p->status;
   d.nxcd = rumpy_device_xcds(); d.fake_xcc = p->fake_xcc; d.force_sc1 = p->force_sc1;
+  d.edge_w = (const uint4*)p->edge_w; d.edge_b = p->edge_b; d.edge_x = (const uint16_t*)p->edge_x; d.edge_res = (const uint16_t*)p->edge_res; d.edge_out = (uint16_t*)p->edge_out;
+  if (p->edge_w && (p->nblocks > 254 || (p->backward ? !p->edge_x : !p->edge_out))) {
+    rumpy_set_error("rumpy_res_chain: the edge conv needs edge_x (backward) / edge_out (forward) and at most 254 blocks"); return RUMPY_E_ARG; }
   if (d.fake_xcc > 0) d.nxcd = d.fake_xcc < CH_MAX_XCD ? d.fake_xcc : CH_MAX_XCD;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(p->N * sy_n);
-  if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3>), grid, dim3(BTHREADS), s, d);
+  if (p->edge_w) {
+    if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3, RUMPY_FMT_BF16, true>), grid, dim3(BTHREADS), s, d);
+    else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_F16, true>), grid, dim3(BTHREADS), s, d);
+    else RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_BF16, true>), grid, dim3(BTHREADS), s, d);
+  } else if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3>), grid, dim3(BTHREADS), s, d);
   else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_F16>), grid, dim3(BTHREADS), s, d);
   else RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1>), grid, dim3(BTHREADS), s, d);
   return rumpy_check_launch("rumpy_res_chain");

@@ -165,6 +165,7 @@ class SREngine:
         self.use_chain = os.environ.get('RUMPY_NO_CHAIN') != '1'
         # the tail conv's data gradient inside the last upsampler stage's data-gradient launch (rumpy_conv4d_tail; RUMPY_NO_TAIL_FUSE=1: two launches, A/B)
         self.fuse_tail_dgrad = os.environ.get('RUMPY_NO_TAIL_FUSE') != '1'
+        self.chain_edge = os.environ.get('RUMPY_NO_CHAIN_EDGE') != '1'     # the body-end conv (and its data gradient) inside the chain launch; =1: its own launch (A/B)
         self.chain_force_sc1 = os.environ.get('RUMPY_CHAIN_SC1') == '1'       # A/B: every hand-off of the chain through the memory side
         # the RCABs of a residual group as one persistent launch (conv_rcab_chain.hip; bitwise the per-block launches): OPT-IN - measured at parity forward
         # (19.7 against 19.8 us per RCAB) and slower backward (21.6 against 19.0): every block ends in an image-wide exchange AND a neighbour hand-off, and the
@@ -992,6 +993,22 @@ class SREngine:
                 args._blocks_host = tab            # (kept alive with the argument block)
                 ops[i:j] = [('rumpy_res_chain', args)]
                 j = i + 1
+                # the single conv at the run's outer end - EDSR's body-end conv behind the last block, its data gradient in front of the first - joins
+                # the launch (rumpy_res_chain_args.edge_*; bitwise the separate launch)
+                def plain_conv(c):
+                    return (c.cin_chunks == 1 and c.cout_tiles == 1 and c.in_mode == 0 and c.out_mode == 0 and not c.relu and c.scale == 1.0 and not c.mask
+                            and not c.pool and not c.res2 and not c.w_lo and c.N == N and c.H == H and c.W == W and c.fmt == args.fmt)
+                if self.chain_edge and len(blocks) <= 254:
+                    if not backward and j < len(ops) and ops[j][0] == 'rumpy_conv3x3' and plain_conv(ops[j][1]) and ops[j][1].x == blocks[-1].out:
+                        c = ops[j][1]
+                        args.edge_w, args.edge_b, args.edge_res, args.edge_out = c.w, c.bias, c.res1, c.out
+                        del ops[j]
+                    elif (backward and i > 0 and ops[i - 1][0] == 'rumpy_conv3x3' and plain_conv(ops[i - 1][1]) and ops[i - 1][1].out == blocks[0].x
+                          and not ops[i - 1][1].bias and not ops[i - 1][1].res1):
+                        c = ops[i - 1][1]
+                        args.edge_w, args.edge_x = c.w, c.x
+                        del ops[i - 1]
+                        j -= 1
             i = max(j, i + 1)
 
     def _emit_styled_rcab(self, plan, fwd, bwd, wjobs, nodes, c1, c2, ca, cur, N, H, W, tiles, train, act, release):

@@ -17,21 +17,22 @@ from tests.test_network_gpu import _handler, _pair
 pytestmark = pytest.mark.gpu
 
 
-def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False):
+def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False, edge=False):
+    """edge: with the single conv at the chain's outer end (rumpy_res_chain_args.edge_*) - forward: rumpy_conv3x3 (+ bias + residual) behind the last block;
+    backward: rumpy_conv3x3 with the data-gradient filter in front of the first, whose output tensor the chain launch then WRITES"""
     gen = np.random.default_rng(seed)
-    convs = [(PackedConv(torch.from_numpy(gen.uniform(-0.05, 0.05, (64, 64, 3, 3)).astype(np.float32)), torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32))),
-              PackedConv(torch.from_numpy(gen.uniform(-0.05, 0.05, (64, 64, 3, 3)).astype(np.float32)), torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32))))
-             for _ in range(nblk)]
+    mk = lambda: PackedConv(torch.from_numpy(gen.uniform(-0.05, 0.05, (64, 64, 3, 3)).astype(np.float32)), torch.from_numpy(gen.uniform(-0.1, 0.1, 64).astype(np.float32)))
+    convs = [(mk(), mk()) for _ in range(nblk)]
+    pe = mk() if edge else None
     dt = torch.float16 if fmt else BF16
     rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(dt)
-    x0, extra = rnd(), rnd()
+    x0, extra, eres = rnd(), rnd(), rnd()
     masks = [torch.from_numpy(gen.integers(0, 256, (N, H, W, 8), dtype=np.uint8)).to(DEV) for _ in range(nblk)]
     if fmt:
         items = []
-        for pa, pb in convs:
-            for pc in (pa, pb):
-                pc.w_h = torch.zeros(64 * 64 * 9, dtype=torch.float16, device=DEV)
-                items.append(L.PackItem(w=pc.w.data_ptr(), b=pc.b.data_ptr(), w_fwd=pc.w_h.data_ptr(), w_dgrad=None, b_packed=None, cout=64, cin=64, kind=0, shuffle=0, fmt=L.FMT_F16))
+        for pc in [c for pair in convs for c in pair] + ([pe] if edge else []):
+            pc.w_h = torch.zeros(64 * 64 * 9, dtype=torch.float16, device=DEV)
+            items.append(L.PackItem(w=pc.w.data_ptr(), b=pc.b.data_ptr(), w_fwd=pc.w_h.data_ptr(), w_dgrad=None, b_packed=None, cout=64, cin=64, kind=0, shuffle=0, fmt=L.FMT_F16))
         tab = to_dev_bytes((L.PackItem * len(items))(*items))
         L.check(L.lib().rumpy_pack_weights(tab.data_ptr(), len(items), stream()), 'pack')
     outs = {}
@@ -39,9 +40,11 @@ def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False):
         ts = [torch.full((N, H, W, 64), float('nan'), dtype=dt, device=DEV) for _ in range(nblk)] if (backward or not fmt) else [None] * nblk
         ys = [torch.full((N, H, W, 64), float('nan'), dtype=dt, device=DEV) for _ in range(nblk)]
         mbs = masks if backward else [torch.zeros(N, H, W, 8, dtype=torch.uint8, device=DEV) for _ in range(nblk)]
+        eo = torch.full((N, H, W, 64), float('nan'), dtype=dt, device=DEV)      # the edge conv's output (backward: = the first block's input)
+        first_in = eo if (edge and backward) else x0
         recs = []
         for b, (pa, pb) in enumerate(convs):
-            x = x0 if b == 0 else ys[b - 1]
+            x = first_in if b == 0 else ys[b - 1]
             if backward:
                 recs.append(dict(x=x.data_ptr(), w1=pb.w_dgrad.data_ptr(), b1=None, w2=pa.w_dgrad.data_ptr(), b2=None, res2=extra.data_ptr() if b == nblk - 1 else None,
                                  t=ts[b].data_ptr(), out=ys[b].data_ptr(), maskbits=mbs[b].data_ptr(), scale1=0.1, scale2=1.0))
@@ -49,15 +52,27 @@ def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False):
                 w1, w2 = (pa.w_h, pb.w_h) if fmt else (pa.w_fwd, pb.w_fwd)
                 recs.append(dict(x=x.data_ptr(), w1=w1.data_ptr(), b1=pa.b_packed.data_ptr(), w2=w2.data_ptr(), b2=pb.b_packed.data_ptr(), res2=None,
                                  t=ts[b].data_ptr() if ts[b] is not None else None, out=ys[b].data_ptr(), maskbits=None if fmt else mbs[b].data_ptr(), scale1=1.0, scale2=0.1))
+        ekw = {}
+        if edge and backward:
+            ekw = dict(edge_w=pe.w_dgrad.data_ptr(), edge_x=x0.data_ptr())
+        elif edge:
+            ekw = dict(edge_w=(pe.w_h if fmt else pe.w_fwd).data_ptr(), edge_b=pe.b_packed.data_ptr(), edge_res=eres.data_ptr(), edge_out=eo.data_ptr())
         if form == 'blocks':
+            if edge and backward:
+                L.call('rumpy_conv3x3', L.ConvArgs(x=x0.data_ptr(), w=pe.w_dgrad.data_ptr(), bias=None, out=eo.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1,
+                                                   in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0, fmt=fmt), stream())
             for r in recs:
                 L.call('rumpy_conv_block', L.BlockArgs(N=N, H=H, W=W, relu1=0 if backward else 1, fmt=fmt, **r), stream())
+            if edge and not backward:
+                L.call('rumpy_conv3x3', L.ConvArgs(x=ys[-1].data_ptr(), w=(pe.w_h if fmt else pe.w_fwd).data_ptr(), bias=pe.b_packed.data_ptr(), out=eo.data_ptr(),
+                                                   res1=eres.data_ptr(), N=N, H=H, W=W, cin_chunks=1, cout_tiles=1, in_mode=0, out_mode=0, relu=0, scale=1.0, grid_x=0,
+                                                   fmt=fmt), stream())
         else:
             tab = to_dev_bytes((L.ResChainBlock * nblk)(*[L.ResChainBlock(**r) for r in recs]))
             work = torch.zeros(int(L.lib().rumpy_res_chain_work_bytes(N, H)), dtype=torch.uint8, device=DEV)
             status = torch.zeros(1, dtype=torch.int32, device=DEV)
             a = L.ResChainArgs(blocks=tab.data_ptr(), nblocks=nblk, N=N, H=H, W=W, backward=1 if backward else 0, fmt=fmt, work=work.data_ptr(),
-                               work_bytes=work.numel(), status=status.data_ptr(), **hooks)
+                               work_bytes=work.numel(), status=status.data_ptr(), **hooks, **ekw)
             side = torch.cuda.Stream()
             for rep in range(3):           # (launch epochs: the same work buffer serves launch after launch)
                 if disturb:
@@ -66,7 +81,7 @@ def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False):
             torch.cuda.synchronize()
             assert int(status.item()) == 0
         torch.cuda.synchronize()
-        outs[form] = [t for t in ts if t is not None] + ys + ([] if backward or fmt else mbs)
+        outs[form] = [t for t in ts if t is not None] + ys + ([] if backward or fmt else mbs) + ([eo] if edge else [])
     for i, (p, q) in enumerate(zip(outs['blocks'], outs['chain'])):
         assert torch.isfinite(p.float()).all() or p.dtype == torch.uint8
         assert torch.equal(p.view(torch.uint8), q.view(torch.uint8)), (i, hooks)
@@ -80,6 +95,15 @@ HOOKS = [dict(fake_xcc=0, force_sc1=0), dict(fake_xcc=0, force_sc1=1), dict(fake
                                                      (1, 5, 9, 2, 0, 0), (7, 31, 24, 5, 1, 0)])
 def test_chain_is_bitwise_the_per_block_launches(N, H, W, nblk, backward, fmt, hooks):
     _chain_case(N, H, W, nblk, backward, fmt, hooks, 900 + N + H)
+
+
+@pytest.mark.parametrize('hooks', HOOKS[:3])
+@pytest.mark.parametrize('N,H,W,nblk,backward,fmt', [(32, 48, 48, 6, 0, 0), (32, 48, 48, 6, 1, 0), (5, 20, 37, 3, 0, 0), (5, 20, 37, 3, 1, 0), (3, 13, 48, 4, 0, 1),
+                                                     (1, 5, 9, 2, 0, 0), (7, 31, 24, 2, 1, 0), (2, 6, 16, 2, 0, 0), (2, 6, 16, 2, 1, 0)])
+def test_chain_with_the_conv_at_its_outer_end_is_bitwise_the_separate_launches(N, H, W, nblk, backward, fmt, hooks):
+    """EDSR's body-end conv (+ bias + global skip) behind the last block of the forward chain, its data gradient in front of the first block of the backward
+    chain - inside the chain launch (rumpy_res_chain_args.edge_*), against rumpy_conv3x3 in front of / behind per-block launches: every buffer bit for bit"""
+    _chain_case(N, H, W, nblk, backward, fmt, hooks, 940 + N + H, edge=True)
 
 
 @pytest.mark.parametrize('backward', [0, 1])
@@ -124,6 +148,8 @@ def test_edsr_training_and_evaluation_on_the_chain_equal_the_per_block_launches(
         for ops in (tp.fwd, tp.bwd, ep.fwd):
             names = [op for op, _ in ops]
             assert (names.count('rumpy_res_chain') == 1 and 'rumpy_conv_block' not in names) == (no_chain == '0'), names
+            if no_chain == '0':      # ... and the body-end conv (its data gradient) rides in the chain launch
+                assert all(bool(a.edge_w) for op, a in ops if op == 'rumpy_res_chain')
         assert eng.exchange_status() == 0
         res.append((losses, out.clone(), ev.clone(), h.net.flat_p.detach().cpu().clone()))
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
