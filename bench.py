@@ -639,9 +639,14 @@ def main():
                     # one launch = a whole run of blocks: flops and algorithmic tensors of all of them (per block: x | g read once at the chain's head
                     # only - the strip stays in LDS - so a block touches its T store, its OUT store, + res2 where given; the first block also its input)
                     nb = [a.nblocks for a in chains]
-                    flop = 2 * layer_flop * sum(nb) / len(nb)
-                    tensors = [1 + sum(1 + (1 if b.t else 0) + (1 if b.res2 else 0) for b in a._blocks_host) for a in chains]
-                    kname = 'block_chain_kernel (a run of %d residual blocks per persistent launch, halo rows handed over through the XCD L2; fwd + data-gradient launches)' % nb[0]
+                    # ... + the single conv at the chain's outer end where the launch carries it (EDSR's body-end conv: forward it stores its output and
+                    # reads the skip operand; backward it stores the chain's first input, which the launch then does NOT read)
+                    ne = sum(1 for a in chains if a.edge_w)
+                    flop = (2 * layer_flop * sum(nb) + layer_flop * ne) / len(nb)
+                    tensors = [1 + sum(1 + (1 if b.t else 0) + (1 if b.res2 else 0) for b in a._blocks_host) + (0 if not a.edge_w else (2 if a.edge_res else 1))
+                               for a in chains]
+                    kname = ('block_chain_kernel (a run of %d residual blocks%s per persistent launch, halo rows handed over through the XCD L2; fwd + data-gradient '
+                             'launches)' % (nb[0], ' + the body-end conv' if ne else ''))
                 if rchains and not rcabs:
                     nb = [a.nblocks for a in rchains]
                     flop = 2 * layer_flop * sum(nb) / len(nb)
