@@ -64,28 +64,31 @@ __device__ __forceinline__ unsigned swz(int p, int chunk) { return (unsigned)(p 
 struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
 // hook(grp) runs after the MFMAs of group grp have been issued: the place for work that should travel under the matrix pipe
 // (the HBM stores of the previous phase's tile, block_common.hpp::strip_store_piece)
-template <int ROWS, int FMT = RUMPY_FMT_BF16, class Hook = NoHook, int NC = 3, int COLS = BCOLS>
+// AHEAD: groups whose fragment reads are in flight in front of the MFMAs (1: the next group's travel under this group's MFMAs; 2 costs ROWS + 2 more
+// fragment registers - measured in the chain kernel, round 5)
+template <int ROWS, int FMT = RUMPY_FMT_BF16, class Hook = NoHook, int NC = 3, int COLS = BCOLS, int AHEAD = 1>
 __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2],
                                             Hook hook = Hook()) {
   constexpr int NG = 6 * NC;            // (channel half, tap column, column tile) groups
-  bf16x8 I[2][ROWS + 2];
+  bf16x8 I[AHEAD + 1][ROWS + 2];
   auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
     const int half = grp / (3 * NC), kx = (grp % (3 * NC)) / NC, c = grp % NC;
 #pragma unroll
     for (int r = 0; r < ROWS + 2; ++r)
       dst[r] = *reinterpret_cast<const bf16x8*>(lds + off[(r * COLS + kx) & 7][half] + (r * COLS + 16 * c + kx) * 128);
   };
-  load_group(0, I[0]);
+#pragma unroll
+  for (int g0 = 0; g0 < AHEAD; ++g0) load_group(g0, I[g0]);
 #pragma unroll
   for (int grp = 0; grp < NG; ++grp) {
-    if (grp + 1 < NG) load_group(grp + 1, I[(grp + 1) & 1]);
+    if (grp + AHEAD < NG) load_group(grp + AHEAD, I[(grp + AHEAD) % (AHEAD + 1)]);
     __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs
     const int half = grp / (3 * NC), kx = (grp % (3 * NC)) / NC, c = grp % NC;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
-        acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp & 1][r + ky], acc[r][c]);
+        acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp % (AHEAD + 1)][r + ky], acc[r][c]);
       }
     hook(grp);
   }

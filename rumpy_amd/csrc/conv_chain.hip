@@ -20,6 +20,9 @@
 // *status (read back with the loss; the handler raises).  W <= 48.  Everything inside a block - sweeps, epilogues, row-half gates, whole-line stores -
 // is conv_block.hip (forms 1 and 3): the results are bitwise those of one launch per block (tests/test_chain_gpu.py).
 #include "chain_common.hpp"
+#ifndef CHAIN_AHEAD
+#define CHAIN_AHEAD 2      // fragment reads two groups ahead in the one- and two-row sweeps (round 5: 228.3 -> 226.4 us per launch, no spills; three-row sweeps: spills)
+#endif
 
 struct ChainBlk {
   const uint16_t* x; const uint4* w1; const float* b1; const uint4* w2; const float* b2;
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       gate_wait(&gate[3], done);                         // both halves' OUT rows of block b - 1 are in LDS (and nobody reads the old T image)
       CH_STAMP(1);
       sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
-      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
+      block_sweep<2, FMT, NoHook, 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
       CH_STAMP(2);
       // (b) publish block b - 1: this wave's OUT stores are acknowledged (under the sweep above) -> count in -> one lane stores the flag.  (Publishing IN
       // FRONT of the sweep - the neighbours see the flag a sweep earlier, this wave stalls 0.4 us for the rest of its acknowledgements - measured the
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       CH_STAMP(5);
       // (d) the two T rows that do: row half 0 -> T rows 0, 1 (input rows 0 .. 3); row half 1 -> T rows 6, 7 (input rows 6 .. 9)
       sweep_bases(off, 0u, (rh == 0) ? 0 : 6, px, g);
-      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 0 : 2]), F, lds, off);
+      block_sweep<2, FMT, NoHook, 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 0 : 2]), F, lds, off);
     }
     CH_STAMP(6);
     // second filter: L2 hits that land under the epilogue
@@ -336,10 +339,10 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     }
     if (rh == 0) {
       sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
-      block_sweep<2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[0]), F, lds, off, t_store);
+      block_sweep<2, FMT, decltype(t_store), 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[0]), F, lds, off, t_store);
       gate_wait(&gate[1], tdone + 4u);
       sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
-      block_sweep<1, FMT>(*reinterpret_cast<f32x4(*)[1][3]>(&acc2[2]), F, lds, off);
+      block_sweep<1, FMT, NoHook, 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[1][3]>(&acc2[2]), F, lds, off);
     } else {
       sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
       block_sweep<3, FMT>(acc2, F, lds, off, t_store);
