@@ -1008,7 +1008,7 @@ class SREngine:
                         c = ops[i - 1][1]
                         args.edge_w, args.edge_x = c.w, c.x
                         del ops[i - 1]
-                        j -= 1
+                        i, j = i - 1, j - 1            # (the chain op moved one place down)
             i = max(j, i + 1)
 
     def _emit_styled_rcab(self, plan, fwd, bwd, wjobs, nodes, c1, c2, ca, cur, N, H, W, tiles, train, act, release):
