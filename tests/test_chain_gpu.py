@@ -155,6 +155,30 @@ def test_edsr_training_and_evaluation_on_the_chain_equal_the_per_block_launches(
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
 
 
+@pytest.mark.parametrize('blocks,N', [(2, 32), (32, 8), (3, 1)])
+def test_edsr_chains_of_other_lengths_equal_the_per_block_launches(blocks, N, monkeypatch):
+    """the shortest run that chains (2 blocks + the body-end conv), the depth of the reference's shipped config (32), a single image: two training steps and an
+    evaluation, chain against RUMPY_NO_CHAIN=1, bit for bit"""
+    kw = dict(scale=2, num_blocks=blocks, res_scale=0.1)
+    res = []
+    for no_chain in ('0', '1'):
+        monkeypatch.setenv('RUMPY_NO_CHAIN', no_chain)
+        h, _ = _pair('edsr', 512, sched=False, **kw)
+        losses = []
+        for step in range(2):
+            x, y = O.synthetic_batch(730 + step, N, lr_hw=48, scale=2)
+            loss, out = h.run_train(x=x, y=y)
+            losses.append(float(loss))
+        xe, _ = O.synthetic_batch(739, 1, lr_hw=(30, 48), scale=2)
+        ev, _, _ = h.run_eval(x=xe)
+        tp = h.net.engine.plan_for(N, 48, 48, True)
+        chains = [a for op, a in tp.fwd + tp.bwd if op == 'rumpy_res_chain']
+        assert (len(chains) == 2 and all(a.nblocks == blocks and a.edge_w for a in chains)) == (no_chain == '0')
+        assert h.net.engine.exchange_status() == 0
+        res.append((losses, out.clone(), ev.clone(), h.net.flat_p.detach().cpu().clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+
+
 def test_chain_is_deterministic_at_the_headline_shape():
     kw = dict(scale=4, num_blocks=16, res_scale=0.1)
     x, y = O.synthetic_batch(671, 32, lr_hw=48, scale=4)
