@@ -1046,6 +1046,16 @@ def test_bench_line_value_is_the_fresh_process_region_and_the_settled_clock_is_e
     assert d['settled']['value'] > 0.97 * d['value']      # (the settled clock is never the slower one)
     assert e['settled'] is None and e['clock_settle'] is None and e['value'] > 0
     assert abs(e['value'] - d['value']) < 0.1 * d['value']
+    # the informational host-tensor leg is there by default and gone with --no-as-called (what the profile commands pass: its copies run beside kernels)
+    assert d['as_called'] and d['as_called']['value'] > 0
+    p = subprocess.run(base + ['--settled-probe-ms', '0', '--no-as-called'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+    f = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
+    assert f['as_called'] is None and f['value'] > 0
+    # the dominant kernel of the default plan is the chain (16 blocks + the body-end conv per launch); its PMC entry must belong to the committed sources
+    r = d['roofline']
+    assert 'block_chain_kernel' in r['kernel'] and 'body-end conv' in r['kernel'] and r['launches_per_step'] == 2
+    assert r['traffic'] and 1.0 < r['traffic'] / (r['algorithmic_mb_per_launch'] * 1e6) < 1.6, r.get('traffic_source')
 
 
 @pytest.mark.parametrize('form', ['lazy', 'xchg'])
