@@ -601,12 +601,11 @@ def main():
         ops = plan.fwd + plan.bwd
         blocks = [a for name, a in ops if name == 'rumpy_conv_block']
         chains = [a for name, a in ops if name == 'rumpy_res_chain']      # runs of residual blocks as one persistent launch (conv_chain.hip); probe id 5 too
-        rchains = [a for name, a in ops if name == 'rumpy_rcab_chain']    # ... of RCABs (conv_rcab_chain.hip)
         rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd', 'rumpy_rcab2_fwd', 'rumpy_rcab2_bwd')]      # share probe id 5 with the block kernel
         rcab2 = any(name == 'rumpy_rcab2_fwd' for name, _ in ops)
-        use_block = len(blocks) + len(rcabs) + len(chains) + len(rchains) > 0
+        use_block = len(blocks) + len(rcabs) + len(chains) > 0
         #  an fp8 line only if every one-launch block of the plan really runs the fp8 kernels (patches wider than 48 pixels do not)
-        fp8_live = fp8 and use_block and not chains and not rchains and all(getattr(a, 'w1_f8', None) for a in blocks + rcabs)
+        fp8_live = fp8 and use_block and not chains and all(getattr(a, 'w1_f8', None) for a in blocks + rcabs)
         if fp8 and not fp8_live:
             mfma_peak = MFMA_BF16_PEAK_TFLOPS
         wide_convs = [a for name, a in ops if name == 'rumpy_conv3x3' and a.cin_chunks == 4] if getattr(hipnet.engine, 'wide', False) else []
@@ -647,12 +646,6 @@ def main():
                                for a in chains]
                     kname = ('block_chain_kernel (a run of %d residual blocks%s per persistent launch, halo rows handed over through the XCD L2; fwd + data-gradient '
                              'launches)' % (nb[0], ' + the body-end conv' if ne else ''))
-                if rchains and not rcabs:
-                    nb = [a.nblocks for a in rchains]
-                    flop = 2 * layer_flop * sum(nb) / len(nb)
-                    # per block: its stores (forward t1, t2, out; backward d_t2, gt1, dx) + the forward pass's t2 (backward) + res2; the chain's first block also reads its input
-                    tensors = [1 + sum(1 + sum(1 for f in ('t', 't2', 't2_in', 'res2') if getattr(b, f)) for b in a._blocks_host) for a in rchains]
-                    kname = 'rcab_chain_kernel (the %d RCABs of a residual group per persistent launch: pool sums exchanged inside, halo rows between neighbours; fwd + bwd launches)' % nb[0]
                 if fp8 and blocks and all(a.w1_f8 for a in blocks):
                     kname = 'conv_block_fp8_kernel (residual block per launch, both sweeps on the block-scaled fp8 MFMA; fwd + data-gradient launches)'
                 if rcabs:
@@ -685,7 +678,7 @@ def main():
                             'frac': round(tflops / mfma_peak, 4), 'traffic': None}
             roofline.update(common)
             # HBM bytes per launch from the PMC passes committed under profiles/ (not re-measured here; null when the kernel changed since)
-            kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else ('rcab2_kernel' if rcab2 else 'rcab_kernel') if rcabs else 'rcab_chain_kernel' if rchains else 'block_chain_kernel' if (chains and not blocks) else 'conv_block_kernel'
+            kind = 'conv3x3_cin256' if wide_convs else 'conv3x3_strip' if not use_block else ('rcab2_kernel' if rcab2 else 'rcab_kernel') if rcabs else 'block_chain_kernel' if (chains and not blocks) else 'conv_block_kernel'
             if use_block and kname.startswith(('conv_block_fp8_kernel', 'rcab_fp8_kernel')):      # the fp8 kernels have PMC entries of their own
                 kind = 'rcab_fp8_kernel' if rcabs else 'conv_block_fp8_kernel'
             roofline['traffic'], roofline['traffic_source'] = pmc_traffic('%s:N%d:P%d' % (kind, N, P))

@@ -245,28 +245,6 @@ typedef struct {
 } rumpy_res_chain_args;
 int rumpy_res_chain(const rumpy_res_chain_args* a, void* stream);
 int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H);
-/* ... and a chain of RCABs (conv_rcab_chain.hip): the blocks of rumpy_rcab_fwd / rumpy_rcab_bwd (same arithmetic, bitwise the per-block launches), block b's x
- * BEING block b - 1's out; the strips of an image exchange their pool sums inside the launch through `xchg` (N * ceil(H/6) * 512 bytes, zeroed once; its own
- * buffer, not one shared with rumpy_rcab_fwd).  backward = 0: t = t1, t2 = conv2's output (both stored when set), mean / hidden / gate: out.
- * backward = 1: x = dy, w1 / w2 = DATA-GRADIENT images of conv2 / conv1, t = gt1 out, t2 = d_t2 out, t2_in = the forward pass's t2, maskbits, hidden / gate: in,
- * dz [, dzq]: out.  W <= 48, N * ceil(H/6) <= CUs, Cr <= 4, bf16.  *status: 0x4ff / 0x500 + block (hand-off) or 0x600 + block (pool exchange) after a time-out.
- * Replaces: the RCABs of ResidualGroup.body (rumpy/SISR/models/advanced/architectures.py:107-119: n_resblocks RCAB + conv; forward :121-124) run back to
- * back, and their autograd backward.  Opt-in in the engine (RUMPY_RCAB_CHAIN=1): measured slower than the per-block launches in the backward pass. */
-typedef struct {
-  const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
-  void* t; void* t2; const void* t2_in; const void* res2; void* out; void* maskbits;
-  const float* ca_w1; const float* ca_b1; const float* ca_w2; const float* ca_b2;
-  float* mean; float* hidden; float* gate; const float* qgate; float* dz; float* dzq;
-} rumpy_rcab_chain_block;
-typedef struct {
-  const void* blocks;      /* DEVICE array of rumpy_rcab_chain_block */
-  int32_t nblocks, N, H, W, cr, backward;
-  void* work; int64_t work_bytes;      /* rumpy_rcab_chain_work_bytes(N, H), zeroed once */
-  void* xchg; int64_t xchg_bytes; void* status;
-  int32_t fake_xcc, force_sc1;         /* test hooks, as in rumpy_res_chain_args */
-} rumpy_rcab_chain_args;
-int rumpy_rcab_chain(const rumpy_rcab_chain_args* a, void* stream);
-int64_t rumpy_rcab_chain_work_bytes(int32_t N, int32_t H);
 int rumpy_device_xcds(void);   /* accelerator dies (XCDs, each with its own L2) of the current device: 8 on MI355X */
 
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----
@@ -743,6 +721,8 @@ typedef struct {
   const rumpy_adam_hyper* hyper;  /* DEVICE pointer: lets a captured graph replay with new hyper-parameters */
   const float* sumsq;             /* device scalar (sum of g^2) when hyper->max_norm > 0, else NULL */
   rumpy_adam_hyper hyper_value;   /* hyper == NULL: the hyper-parameters travel BY VALUE with the launch (eager steps: no staging copy) */
+  const uint32_t* skip_if;        /* ABI 6: NULL, or a device word; when it is non-zero the launch leaves p, m and v untouched - the watchdog word of the step's
+                                     persistent launches (rumpy_res_chain / rumpy_rcab_fwd status): a step whose hand-off timed out never reaches the weights */
 } rumpy_adam_args;
 int rumpy_adam_step(const rumpy_adam_args* a, void* stream);
 
@@ -775,6 +755,7 @@ typedef struct {
   const rumpy_adam_hyper* hyper;  /* DEVICE pointer or NULL (then hyper_value), as rumpy_adam_args */
   const float* sumsq;
   rumpy_adam_hyper hyper_value;
+  const uint32_t* skip_if;        /* ABI 6: as rumpy_adam_args.skip_if (the packed images stay as they are too) */
 } rumpy_adam_pack_args;
 int rumpy_adam_pack(const rumpy_adam_pack_args* a, void* stream);
 

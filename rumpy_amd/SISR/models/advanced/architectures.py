@@ -110,6 +110,7 @@ class _NetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, train, meta, *params):
+        net.check_step_status()          # the previous step's watchdog word, if nobody has looked at it yet
         out, _, plan = net.engine_forward(x, train=train, meta=meta)
         ctx.net, ctx.plan, ctx.gen = net, plan, plan.gen
         # a metadata tensor with a gradient path of its own (the embedding of a jointly trained degradation encoder) gets its gradient too
@@ -125,6 +126,7 @@ class _NetFn(torch.autograd.Function):
             raise RuntimeError('rumpy_amd: backward() of an output whose saved activations were overwritten by a later training forward '
                                'pass of the same shape; run forward and backward of one batch before the next forward pass')
         net.engine.backward(ctx.plan, 1.0, gout=gout.contiguous().float(), on_ready=getattr(net, 'grad_ready_hook', None))
+        net.stage_step_status()          # read back behind the backward pass; examined behind the step's loss read-back (BaseModel.run_train) or by the next pass
         net.attach_grads()
         dmeta = net.engine.meta_grad(ctx.plan).reshape(ctx.meta_shape) if ctx.meta_shape is not None else None
         return (None, None, None, dmeta) + tuple(None for _ in net.param_list)
@@ -389,9 +391,56 @@ class HipSRNet(nn.Module):
         self._loss_event.synchronize()
         st = getattr(self, '_status_host', None)
         if st is not None and int(st[0]) != 0:
-            raise RuntimeError('rumpy_amd: a strip exchange of the RCAB kernels timed out (code 0x%x): the results of this and the previous '
-                               'step are invalid (GPU shared with another job? set RUMPY_NO_RCAB=1 to use the separate launches)' % int(st[0]))
+            self._watchdog_fired(int(st[0]))
         return self._loss_host.numpy().copy().reshape(())
+
+    # ---- watchdog of the launches that wait for other workgroups (persistent block chain, in-launch pool exchange) ----
+    def _watchdog_fired(self, code):
+        """A step's status word came back non-zero: a workgroup gave up waiting for another one, its results are garbage.  The optimizer launch of
+        such a step reads the same word on the device and changes nothing (rumpy_adam_pack_args.skip_if), so the weights are intact.  A single
+        process then switches its engine to launches that wait for nobody and goes on (the affected steps were skipped, says the warning);
+        a data-parallel rank or a captured graph cannot (the replicas would diverge / the graph is fixed): it raises, as before round 6."""
+        eng = self.engine
+        text = eng.watchdog_text(code)
+        st = getattr(self, '_status_host', None)
+        if st is not None:
+            st.zero_()
+        plan_like = next((p for p in list(eng.plans.values())[::-1] if getattr(p, 'rcab_status', None) is not None), None)
+        may = (os.environ.get('RUMPY_WATCHDOG_STRICT') != '1' and not getattr(self, 'use_graph', False)
+               and not getattr(self, 'data_parallel_rank', False) and getattr(self, 'grad_ready_hook', None) is None)
+        what = eng.degrade(plan_like) if (may and plan_like is not None) else None
+        if what is None:
+            if plan_like is not None:
+                plan_like.flags.zero_()
+            raise RuntimeError('rumpy_amd: %s.  The optimizer steps of the affected passes were skipped on the device (weights intact); their '
+                               'losses and outputs are invalid (GPU shared with another job?)' % text)
+        import warnings
+        warnings.warn('rumpy_amd: %s (GPU shared with another job?).  The optimizer steps of the affected passes were skipped on the device (weights '
+                      'intact, their losses / outputs are invalid); training continues with: %s' % (text, what), RuntimeWarning)
+
+    def stage_step_status(self):
+        """generic-loss path: queue the read-back of the step's watchdog word behind what has been launched so far (the fused-L1 path read
+        it with the loss, this path never did)"""
+        st = getattr(self.engine, 'step_status', None) if self.engine is not None else None
+        if st is None:
+            return
+        if getattr(self, '_status_host', None) is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if getattr(self, '_status_event', None) is None:
+            self._status_event = torch.cuda.Event()
+        self._status_host.copy_(st, non_blocking=True)
+        self._status_event.record()
+        self._status_pending = True
+
+    def check_step_status(self):
+        """examine the word staged by stage_step_status (waits for the launches in front of it); called by the handlers behind their loss read-back
+        and by the next training pass"""
+        if not getattr(self, '_status_pending', False):
+            return
+        self._status_pending = False
+        self._status_event.synchronize()
+        if int(self._status_host[0]) != 0:
+            self._watchdog_fired(int(self._status_host[0]))
 
     def l1_eval(self, x, y, metadata=None):
         out, loss, _ = self.engine_forward(x, train=False, target=y.float().contiguous(), meta=metadata)

@@ -80,6 +80,7 @@ class ContrastiveBlindQRCANHandler(BaseContrastive):
         loss = loss_contrast + loss_SR
         self.standard_update(loss)
         package = {name: v.detach().cpu().numpy() for v, name in zip((loss, loss_SR, loss_contrast), ('train-loss', 'l1-loss', 'contrast-loss'))}
+        self._check_watchdog()          # (the read-back above has waited for the step)
         return package, output.detach().cpu()
 
     def run_model(self, x, *args, **kwargs):

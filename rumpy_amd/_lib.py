@@ -78,17 +78,6 @@ class ResChainArgs(_S):
                 ('edge_w', c_void_p), ('edge_b', c_void_p), ('edge_x', c_void_p), ('edge_res', c_void_p), ('edge_out', c_void_p)]
 
 
-class RcabChainBlock(_S):
-    _fields_ = [(k, c_void_p) for k in ('x', 'w1', 'b1', 'w2', 'b2', 't', 't2', 't2_in', 'res2', 'out', 'maskbits', 'ca_w1', 'ca_b1', 'ca_w2', 'ca_b2',
-                                        'mean', 'hidden', 'gate', 'qgate', 'dz', 'dzq')]
-
-
-class RcabChainArgs(_S):
-    _fields_ = [('blocks', c_void_p), ('nblocks', c_int32), ('N', c_int32), ('H', c_int32), ('W', c_int32), ('cr', c_int32), ('backward', c_int32),
-                ('work', c_void_p), ('work_bytes', c_int64), ('xchg', c_void_p), ('xchg_bytes', c_int64), ('status', c_void_p),
-                ('fake_xcc', c_int32), ('force_sc1', c_int32)]
-
-
 class Op(_S):
     _fields_ = [('fn', c_void_p), ('args', c_void_p)]
 
@@ -246,12 +235,12 @@ class AdamHyper(_S):
 
 class AdamArgs(_S):
     _fields_ = [('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p), ('n', c_int64),
-                ('hyper', c_void_p), ('sumsq', c_void_p), ('hyper_value', AdamHyper)]
+                ('hyper', c_void_p), ('sumsq', c_void_p), ('hyper_value', AdamHyper), ('skip_if', c_void_p)]
 
 
 class AdamPackArgs(_S):
     _fields_ = [('items', c_void_p), ('nitems', c_int32), ('pad_', c_int32), ('p', c_void_p), ('g', c_void_p), ('m', c_void_p), ('v', c_void_p),
-                ('hyper', c_void_p), ('sumsq', c_void_p), ('hyper_value', AdamHyper)]
+                ('hyper', c_void_p), ('sumsq', c_void_p), ('hyper_value', AdamHyper), ('skip_if', c_void_p)]
 
 
 class SumsqArgs(_S):
@@ -339,8 +328,6 @@ SYMBOLS = {
     'rumpy_fp8_convert': (C.c_int, [c_void_p, C.c_float, c_void_p, c_int32, c_int32, c_void_p]),
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
     'rumpy_res_chain': (C.c_int, [_P(ResChainArgs), c_void_p]),
-    'rumpy_rcab_chain': (C.c_int, [_P(RcabChainArgs), c_void_p]),
-    'rumpy_rcab_chain_work_bytes': (c_int64, [c_int32, c_int32]),
     'rumpy_res_chain_work_bytes': (c_int64, [c_int32, c_int32]),
     'rumpy_device_xcds': (C.c_int, []),
     'rumpy_rcab2_fwd': (C.c_int, [_P(Rcab2Args), c_void_p]),

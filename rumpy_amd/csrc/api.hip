@@ -36,7 +36,7 @@ extern "C" int rumpy_run_list(const rumpy_op* ops, int32_t n, void* stream) {
   }
   return RUMPY_OK;
 }
-extern "C" int rumpy_abi_version(void) { return 5; }
+extern "C" int rumpy_abi_version(void) { return 6; }
 
 // diagnostic (tests only): `blocks` workgroups that each hold 80 KiB of LDS (at most two per CU) and spin for about `microseconds` -
 // a stand-in for a foreign kernel (an RCCL collective on the side stream) that occupies CUs while the product kernels run

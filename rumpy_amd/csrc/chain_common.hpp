@@ -27,6 +27,12 @@ __device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
   return make_uint4(w.x, w.y, w.z, w.w);
 }
 
+// every 1024th round of a poll looks at the launch's status word: once ANY poll of the launch has timed out (co-residency did not hold) the results are
+// lost anyway - the others stop waiting, so that the launch ends within milliseconds of the first time-out instead of one time-out per block
+__device__ __forceinline__ bool ch_give_up(unsigned spins, const unsigned* status) {
+  return (spins & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+}
+
 struct ChainPlace { int strip; unsigned xcc, epoch; };
 // Thread 0 of the workgroup reads the launch's epoch (the last launch's + 1: tags of flags and placement words), claims a strip (own XCD first, then
 // the others in turn: workgroups = slots, so a free one exists while this one has none), publishes where it physically runs, and hands all three
@@ -76,6 +82,7 @@ __device__ __forceinline__ bool chain_same_xcd(unsigned* work, unsigned epoch, i
     if ((w >> 8) == epoch) break;
     __builtin_amdgcn_s_sleep(2);
     if (++spins > CH_SPIN) { if ((threadIdx.x & 63) == 0) atomicExch(status, 0x4ffu); break; }
+    if (ch_give_up(spins, status)) break;
   }
   return ((w >> 8) == epoch) && ((w & 255u) == my_xcc);
 }

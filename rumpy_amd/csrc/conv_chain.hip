@@ -16,8 +16,10 @@
 // dirty line of the own L2 and, failing that, the memory side - never a stale copy (the probe's cross-XCD sc1 / sc1 ping-pong relies on the same).
 // OUT rows stored sc0 are ordinary dirty L2 lines: written back at the end of the kernel like any store, for the launches that follow.
 //
-// Needs every strip co-resident (N * ceil(H/6) <= CUs, one 512-thread workgroup per CU): a poll that does not complete within ~0.1 s stores a code in
-// *status (read back with the loss; the handler raises).  W <= 48.  Everything inside a block - sweeps, epilogues, row-half gates, whole-line stores -
+// Needs every strip co-resident (N * ceil(H/6) <= CUs, one 512-thread workgroup per CU): a poll that does not complete within CH_SPIN rounds (about a
+// second) stores a code in *status; every other poll of the launch then gives up at its next look at that word (chain_common.hpp::ch_give_up), the
+// launch drains in milliseconds with garbage results, the optimizer launch of the step reads the same word and changes nothing, and the host - which
+// reads it back with the loss - switches the engine to one launch per block (engine.py::degrade; data-parallel ranks raise).  W <= 48.  Everything inside a block - sweeps, epilogues, row-half gates, whole-line stores -
 // is conv_block.hip (forms 1 and 3): the results are bitwise those of one launch per block (tests/test_chain_gpu.py).
 #include "chain_common.hpp"
 #ifndef CHAIN_AHEAD
@@ -261,6 +263,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
           if ((f >> 8) == epoch && (f & 0xffu) >= (want & 0xffu)) break;
           __builtin_amdgcn_s_sleep(2);
           if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + (unsigned)b); break; }
+          if (ch_give_up(spins, a.status)) break;
         }
       }
       CH_STAMP(4);
@@ -446,6 +449,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
         if ((f >> 8) == epoch && (f & 0xffu) >= (b & 0xffu)) break;
         __builtin_amdgcn_s_sleep(2);
         if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + b); break; }
+        if (ch_give_up(spins, a.status)) break;
       }
     }
     {

@@ -152,6 +152,7 @@ __device__ __forceinline__ float adam_one(const AdamCoef& c, float* __restrict__
 constexpr int AP_ROW = 288;                   // 32 input channels x 9 taps: contiguous in the OIHW master copy
 __global__ void __launch_bounds__(256) adam_pack_kernel(rumpy_adam_pack_args a) {
   __shared__ __attribute__((aligned(16))) float P[16 * AP_ROW];          // 18 KB: the updated values of this workgroup's set
+  if (a.skip_if && *a.skip_if) return;      // (uniform over the grid) the step's watchdog word is set: weights, moments and images stay as they are
   const rumpy_update_item it = a.items[blockIdx.x];
   const rumpy_adam_hyper h = a.hyper ? *a.hyper : a.hyper_value;
   const AdamCoef c = adam_coef(h, a.sumsq);

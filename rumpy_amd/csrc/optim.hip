@@ -4,7 +4,9 @@
 // torch.optim.Adam (no amsgrad, no weight decay) in torch's operation order:
 //   m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g*g; denom = sqrt(v)/sqrt(bias_c2) + eps; p -= (lr/bias_c1) * m/denom
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, const rumpy_adam_hyper* __restrict__ hp, rumpy_adam_hyper hv, const float* __restrict__ sumsq) {
+                            size_t n, const rumpy_adam_hyper* __restrict__ hp, rumpy_adam_hyper hv, const float* __restrict__ sumsq,
+                            const uint32_t* __restrict__ skip_if) {
+  if (skip_if && *skip_if) return;      // the step's watchdog word is set (a hand-off of its persistent launches timed out): its gradients never reach the weights
   const rumpy_adam_hyper h = hp ? *hp : hv;
   float gm = h.grad_mult;
   if (h.max_norm > 0.f && sumsq) {
@@ -206,7 +208,7 @@ extern "C" int rumpy_adam_step(const rumpy_adam_args* a, void* stream) {
   size_t blocks = ((size_t)a->n + 255) / 256;
   const size_t cap = (size_t)rumpy_device_cus() * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (size_t)a->n, a->hyper, a->hyper_value, a->sumsq);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a->p, a->g, a->m, a->v, (size_t)a->n, a->hyper, a->hyper_value, a->sumsq, a->skip_if);
   return rumpy_check_launch("rumpy_adam_step");
 }
 extern "C" int rumpy_sumsq(const rumpy_sumsq_args* a, void* stream) {

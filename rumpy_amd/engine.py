@@ -167,10 +167,6 @@ class SREngine:
         self.fuse_tail_dgrad = os.environ.get('RUMPY_NO_TAIL_FUSE') != '1'
         self.chain_edge = os.environ.get('RUMPY_NO_CHAIN_EDGE') != '1'     # the body-end conv (and its data gradient) inside the chain launch; =1: its own launch (A/B)
         self.chain_force_sc1 = os.environ.get('RUMPY_CHAIN_SC1') == '1'       # A/B: every hand-off of the chain through the memory side
-        # the RCABs of a residual group as one persistent launch (conv_rcab_chain.hip; bitwise the per-block launches): OPT-IN - measured at parity forward
-        # (19.7 against 19.8 us per RCAB) and slower backward (21.6 against 19.0): every block ends in an image-wide exchange AND a neighbour hand-off, and the
-        # strips of an image drift by microseconds between them (profiles/r05_rcab_chain.txt)
-        self.use_rcab_chain = os.environ.get('RUMPY_RCAB_CHAIN') == '1'
         # Evaluation plans store activations and filters as IEEE fp16 (same MFMA rate and bytes as bf16, 11 instead of 8 significant bits):
         # bf16 storage alone costs a >= 30 dB model 0.02-0.03 dB of Y-PSNR against the fp32 reference (fixtures G17 / G18).
         # Training stays bf16 (gradient range).  An output that is not finite (fp16 overflow) switches the engine back to bf16 for good.
@@ -235,6 +231,9 @@ class SREngine:
         self.fp8 = False
         self.f8_gen = -1
         self._f8_items = None
+        # the watchdog word of the LAST training pass's plan (or None: no launch of it waits for another workgroup); the fused optimizer launch
+        # reads it on the device (rumpy_adam_pack_args.skip_if): a step whose hand-off timed out never reaches the weights (round 6)
+        self.step_status = None
 
     # ------------------------------------------------------------------ precision 'fp8'
     def enable_fp8(self):
@@ -257,6 +256,10 @@ class SREngine:
                 elif it[0] == 'group':
                     walk(it[1])
         walk(self.spec.body)
+        # mixed-precision policy (round 6): blocks that stay on the bf16 kernels (no fp8 filter images -> the plan emits their bf16 launches)
+        nblk = len(convs) // 2
+        self.f8_bf16_blocks = self._fp8_bf16_blocks(nblk)
+        convs = [cv for i, cv in enumerate(convs) if (i // 2) not in self.f8_bf16_blocks]
         self.f8_wscale = torch.full((max(1, len(convs)),), 127, dtype=torch.int32, device=self.device)
         items = []
         for i, cv in enumerate(convs):
@@ -268,6 +271,33 @@ class SREngine:
         if items:
             self._f8_items_host = (L.Fp8PackItem * len(items))(*items)
             self._f8_items = (self._to_device_bytes(self._f8_items_host), len(items))
+
+    # default mixed-precision policy of precision='fp8' (round 6, profiles/r06_fp8_block_ablation.txt): see _fp8_bf16_blocks
+    FP8_POLICY_DEFAULT = 'none'
+
+    def _fp8_bf16_blocks(self, nblk):
+        """ordinals (walk order of the body) of the residual blocks / RCABs that precision='fp8' keeps on the bf16 kernels.
+        RUMPY_FP8_BF16_BLOCKS overrides the default policy: 'none', a comma list of ordinals ('0,20,199'), 'first:K' / 'last:K' (the first / last K
+        blocks of the body) or 'every:K' (every K-th block: with K = n_resblocks each group's first RCAB)."""
+        pol = os.environ.get('RUMPY_FP8_BF16_BLOCKS', self.FP8_POLICY_DEFAULT).strip()
+        if pol in ('', 'none'):
+            return frozenset()
+        try:
+            if ':' in pol:
+                kind, k = pol.split(':', 1)
+                k = int(k)
+                if k <= 0:
+                    raise ValueError
+                if kind == 'first':
+                    return frozenset(range(min(k, nblk)))
+                if kind == 'last':
+                    return frozenset(range(max(0, nblk - k), nblk))
+                if kind == 'every':
+                    return frozenset(range(0, nblk, k))
+                raise ValueError
+            return frozenset(b for b in (int(t) for t in pol.split(',')) if 0 <= b < nblk)
+        except ValueError:
+            raise RuntimeError("rumpy_amd: RUMPY_FP8_BF16_BLOCKS is 'none', 'first:K', 'last:K', 'every:K' or a comma list of block ordinals (got %r)" % pol)
 
     def _repack_f8(self, stream):
         """bring the fp8 filter images (and their per-conv scale exponents) up to date with the master weights; no-op when nothing changed"""
@@ -831,7 +861,6 @@ class SREngine:
                                            nonfinite=_ptr(plan.nonfinite), fmt=fmt)
         if not train:
             self._chain_runs(plan, fwd, 0)
-            self._rcab_chain_runs(plan, fwd, 0)
             return plan
 
         # =============================== backward ===============================
@@ -917,47 +946,7 @@ class SREngine:
         self._emit_wgrad(plan, wjobs, N)
         self._chain_runs(plan, fwd, 0)
         self._chain_runs(plan, bwd, 1)
-        self._rcab_chain_runs(plan, fwd, 0)
-        self._rcab_chain_runs(plan, bwd, 1)
         return plan
-
-    def _rcab_chain_runs(self, plan, ops, backward):
-        """the same for the RCABs of a ResidualGroup in the 'xchg' form (rumpy_rcab_fwd / rumpy_rcab_bwd -> ONE rumpy_rcab_chain launch per group and
-        direction, conv_rcab_chain.hip: strip resident in LDS, pool sums exchanged inside the launch, bitwise the per-block launches)"""
-        N, H, W = plan.N, plan.H, plan.W
-        if not self.use_chain or not self.use_rcab_chain or W > 48 or N * ((H + 5) // 6) > self.cus:
-            return
-        name = 'rumpy_rcab_bwd' if backward else 'rumpy_rcab_fwd'
-
-        def chainable(a):
-            if a.w1_f8 or a.fmt != 0 or a.cr > 4 or a.N != N or a.H != H or a.W != W:
-                return False
-            return bool(a.maskbits and a.t2_in) if backward else True
-        i = 0
-        while i < len(ops):
-            j = i
-            if ops[i][0] == name and chainable(ops[i][1]):
-                j = i + 1
-                while j < len(ops) and ops[j][0] == name and chainable(ops[j][1]) and ops[j][1].x == ops[j - 1][1].out and ops[j][1].cr == ops[i][1].cr:
-                    j += 1
-            if j - i >= 2:
-                blocks = [a for _, a in ops[i:j]]
-                keys = ('x', 'w1', 'b1', 'w2', 'b2', 't', 't2', 't2_in', 'res2', 'out', 'maskbits', 'ca_w1', 'ca_b1', 'ca_w2', 'ca_b2', 'mean', 'hidden', 'gate', 'qgate', 'dz', 'dzq')
-                tab = (L.RcabChainBlock * len(blocks))(*[L.RcabChainBlock(**{k: getattr(a, k) for k in keys}) for a in blocks])
-                dev = self._to_device_bytes(tab)
-                if getattr(plan, 'chain_work', None) is None:
-                    plan.chain_work = torch.zeros(int(self.lib.rumpy_rcab_chain_work_bytes(N, H)), dtype=torch.uint8, device=self.device)
-                if getattr(plan, 'chain_xchg', None) is None:
-                    plan.chain_xchg = torch.zeros(N * ((H + 5) // 6) * 512, dtype=torch.uint8, device=self.device)
-                plan.rcab_status = plan.flags[1:2]
-                plan.keep += [dev, plan.chain_work, plan.chain_xchg]
-                args = L.RcabChainArgs(blocks=_ptr(dev), nblocks=len(blocks), N=N, H=H, W=W, cr=blocks[0].cr, backward=backward, work=_ptr(plan.chain_work),
-                                       work_bytes=plan.chain_work.numel(), xchg=_ptr(plan.chain_xchg), xchg_bytes=plan.chain_xchg.numel(),
-                                       status=_ptr(plan.flags[1:2]), fake_xcc=0, force_sc1=1 if self.chain_force_sc1 else 0)
-                args._blocks_host = tab
-                ops[i:j] = [('rumpy_rcab_chain', args)]
-                j = i + 1
-            i = max(j, i + 1)
 
     def _chain_runs(self, plan, ops, backward):
         """replace every maximal run (>= 2) of consecutive ResBlock-form rumpy_conv_block launches, each reading the previous one's output, by ONE
@@ -1293,6 +1282,56 @@ class SREngine:
                 worst = max(worst, int(p.rcab_status.item()))
         return worst
 
+    # ------------------------------------------------------------------ watchdog of the launches that wait for other workgroups (round 6)
+    @staticmethod
+    def _waiting_kinds(plan):
+        """which kinds of launches of `plan` poll for another workgroup: 'chain' (rumpy_res_chain hand-offs), 'xchg' (the pool exchange of
+        rumpy_rcab_fwd / _bwd)"""
+        kinds = set()
+        for name, _ in list(plan.fwd) + list(getattr(plan, 'bwd', None) or []):
+            if name == 'rumpy_res_chain':
+                kinds.add('chain')
+            if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd'):
+                kinds.add('xchg')
+        return kinds
+
+    @staticmethod
+    def watchdog_text(code):
+        """what a non-zero status word says (csrc: 0x4ff / 0x500 + b = a hand-off of the persistent block chain, 0x300 + seq = the pool exchange of a
+        one-launch RCAB) and which switch selects launches that wait for nobody"""
+        if code == 0x4ff or 0x500 <= code < 0x600:
+            return ('a halo hand-off of the persistent residual-block chain timed out (code 0x%x: %s); RUMPY_NO_CHAIN=1 selects one launch per block'
+                    % (code, 'a neighbour strip never published where it runs' if code == 0x4ff else 'block %d' % (code - 0x500)))
+        return ('a strip exchange of the one-launch RCAB kernels timed out (code 0x%x); RUMPY_RCAB_FORM=lazy selects the exchange-free launches, '
+                'RUMPY_NO_RCAB=1 the separate ones' % code)
+
+    def degrade(self, plan):
+        """A watchdog word of `plan` came back non-zero: the co-residency its waiting launches need did not hold (GPU shared with another job, a CU
+        mask).  Switch THIS engine to the launch forms that wait for nobody - the chain -> one launch per block (bitwise the same results), the
+        in-launch pool exchange -> the exchange-free RCAB form (or the separate launches where that form does not exist) - and drop the plans built
+        with the old forms.  -> text of what was switched, or None when nothing is left to switch (the caller raises)."""
+        kinds = self._waiting_kinds(plan)
+        done = []
+        if 'chain' in kinds and self.use_chain:
+            self.use_chain = False
+            done.append('persistent block chain -> one launch per block')
+        if 'xchg' in kinds and self.use_rcab_kernel:
+            if self.rcab_form != 'lazy' and not self.fp8:
+                self.rcab_form = 'lazy'
+                done.append("RCAB pool exchange -> the exchange-free form ('lazy')")
+            else:
+                self.use_rcab_kernel = False
+                done.append('one-launch RCAB kernels -> separate launches')
+        if not done:
+            return None
+        for k in list(self.plans):
+            old = self.plans.pop(k)
+            for ops in (old.fwd, getattr(old, 'bwd', None)):
+                if ops is not None:
+                    self._tables.pop(id(ops), None)
+        self.step_status = None
+        return '; '.join(done)
+
     def _upload_q_items(self, plan):
         if plan.q_items:
             arr = (L.QMlpItem * len(plan.q_items))(*plan.q_items)
@@ -1406,6 +1445,8 @@ class SREngine:
         if fmt:
             self._repack_h(stream)
         plan.gen += 1
+        if train:
+            self.step_status = plan.rcab_status
         self._q_gates(plan, meta, stream)
         self._advance_epoch(plan, stream)
         # the head / tail kernels read the caller's fp32 NCHW tensors in place and write a fresh output tensor: no copies
@@ -1461,9 +1502,15 @@ class SREngine:
             # anyway), so that neither problem can go unnoticed on any return path of the handlers
             bad, xch = plan.flags.tolist()
             if xch:
+                # an evaluation pass has no side effects: switch to the launches that wait for nobody and run it again
                 plan.flags.zero_()
-                raise RuntimeError('rumpy_amd: a strip exchange of the RCAB kernels timed out (code 0x%x); the evaluation output is invalid '
-                                   '(GPU shared with another job? RUMPY_NO_RCAB=1 selects the separate launches)' % xch)
+                what = self.degrade(plan)
+                if what is None:
+                    raise RuntimeError('rumpy_amd: %s; the evaluation output is invalid (GPU shared with another job?)' % self.watchdog_text(xch))
+                import warnings
+                warnings.warn('rumpy_amd: %s (GPU shared with another job?) - this engine continues with: %s; the pass is run again'
+                              % (self.watchdog_text(xch), what), RuntimeWarning)
+                return self.forward(x, train=False, target=target, meta=meta)
             if bad and fmt:             # fp16 overflowed somewhere in this network: bf16 has fp32's range
                 import warnings
                 warnings.warn('rumpy_amd: an fp16 evaluation pass produced a non-finite output; evaluation of this network continues in bf16')
@@ -1484,8 +1531,8 @@ class SREngine:
         ev.synchronize()
         bad, xch = self._flag_host.tolist()
         if xch:
-            raise RuntimeError('rumpy_amd: a strip exchange of the RCAB kernels timed out (code 0x%x); the output of the previous evaluation '
-                               'pass is invalid (GPU shared with another job? RUMPY_NO_RCAB=1 selects the separate launches)' % xch)
+            raise RuntimeError('rumpy_amd: %s; the output of the previous evaluation pass (kept on the device, unchecked) is invalid '
+                               '(GPU shared with another job?)' % self.watchdog_text(xch))
         if bad and fmt and self.eval_fmt != L.FMT_BF16:
             import warnings
             warnings.warn('rumpy_amd: the previous fp16 evaluation pass produced a non-finite output (it was kept on the device, unchecked); '

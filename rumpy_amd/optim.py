@@ -113,6 +113,10 @@ class FlatAdam(torch.optim.Adam):
         dev = net.flat_p.device
         n = net.flat_p.numel()
 
+        # the watchdog word of the step's persistent launches (engine.step_status): non-zero -> this launch changes nothing (rumpy_adam_args.skip_if)
+        st = getattr(getattr(net, 'engine', None), 'step_status', None)
+        skip = st.data_ptr() if (st is not None and not graphed) else None
+
         def launches(stream):
             sumsq = None
             if max_norm:
@@ -124,11 +128,12 @@ class FlatAdam(torch.optim.Adam):
                 # Adam AND the re-packing of the bf16 filter images in one launch (csrc/finish.hip): every parameter is an item of the table
                 L.call('rumpy_adam_pack', L.AdamPackArgs(items=upd[0].data_ptr(), nitems=upd[1], p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(),
                                                          m=self.flat_m.data_ptr(), v=self.flat_v.data_ptr(),
-                                                         hyper=self._hyper_dev.data_ptr() if graphed else None, sumsq=sumsq, hyper_value=hv), stream)
+                                                         hyper=self._hyper_dev.data_ptr() if graphed else None, sumsq=sumsq, hyper_value=hv,
+                                                         skip_if=skip), stream)
                 return
             L.call('rumpy_adam_step', L.AdamArgs(p=net.flat_p.data_ptr(), g=net.flat_g.data_ptr(), m=self.flat_m.data_ptr(),
                                                  v=self.flat_v.data_ptr(), n=n, hyper=self._hyper_dev.data_ptr() if graphed else None,
-                                                 sumsq=sumsq, hyper_value=hv), stream)      # eager: by value with the launch
+                                                 sumsq=sumsq, hyper_value=hv, skip_if=skip), stream)      # eager: by value with the launch
             net.engine.repack(stream)
 
         net._ensure_engine()

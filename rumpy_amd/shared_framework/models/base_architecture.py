@@ -96,6 +96,8 @@ class BaseModel(nn.Module):
             hip.grad_ready_hook = self.data_parallel.begin      # all-reduce of the upper half starts under the remaining weight gradients
             self.data_parallel.form = 'early'
         if self.data_parallel.active:
+            if hip is not None:
+                hip.data_parallel_rank = True       # a watchdog time-out raises instead of switching launch forms on one rank only (HipSRNet._watchdog_fired)
             print('Model replicated over %d GPU processes (RCCL gradient all-reduce)' % self.data_parallel.world_size)
 
     def set_allreduce_form(self, form):
@@ -274,6 +276,13 @@ class BaseModel(nn.Module):
         gen = getattr(self.net, 'hip_generator', None)
         return gen if isinstance(gen, HipSRNet) else None
 
+    def _check_watchdog(self):
+        """generic-loss steps: the watchdog word of the step's persistent launches was staged behind the backward pass (HipSRNet.stage_step_status);
+        the loss read-back above has waited for the step, so looking at it costs nothing (the fused-L1 path reads it with the loss)"""
+        hip = self._hip_net()
+        if hip is not None and hasattr(hip, 'check_step_status'):
+            hip.check_step_status()
+
     def _fused_l1(self):
         hip = self._hip_net()
         return hip is not None and getattr(hip, 'supports_fused_l1', True) and type(self.criterion) is nn.L1Loss and not self.loss_masking
@@ -316,6 +325,7 @@ class BaseModel(nn.Module):
             self.standard_update(loss, scheduler_skip=scheduler_skip)
         early = self.net.take_early_loss() if hasattr(self.net, 'take_early_loss') else None   # read back after the forward pass
         loss_np = early if early is not None else loss.detach().reshape(()).cpu().numpy()
+        self._check_watchdog()
         if keep_on_device:
             # in graph mode `out` is the plan's static buffer (rewritten by the next step): hand out a copy
             keep = out.detach().clone() if getattr(self.net, 'use_graph', False) else out.detach()

@@ -27,6 +27,17 @@ class BlockChainArgs(L._S):
                 ('xchg', C.c_void_p), ('status', C.c_void_p)]
 
 
+class RcabChainBlock(L._S):
+    _fields_ = [(k, C.c_void_p) for k in ('x', 'w1', 'b1', 'w2', 'b2', 't', 't2', 't2_in', 'res2', 'out', 'maskbits', 'ca_w1', 'ca_b1', 'ca_w2', 'ca_b2',
+                                          'mean', 'hidden', 'gate', 'qgate', 'dz', 'dzq')]
+
+
+class RcabChainArgs(L._S):
+    _fields_ = [('blocks', C.c_void_p), ('nblocks', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('cr', C.c_int32), ('backward', C.c_int32),
+                ('work', C.c_void_p), ('work_bytes', C.c_int64), ('xchg', C.c_void_p), ('xchg_bytes', C.c_int64), ('status', C.c_void_p),
+                ('fake_xcc', C.c_int32), ('force_sc1', C.c_int32)]
+
+
 _exp = None
 
 
@@ -64,6 +75,7 @@ def exp_lib():
                                 ('rumpy_body_chain', C.c_int, [C.POINTER(BodyChainArgs), C.c_void_p]),
                                 ('rumpy_body_chain_flag_bytes', C.c_int64, [C.c_int32, C.c_int32]),
                                 ('rumpy_conv_block_split', C.c_int, [C.POINTER(BlockSplitArgs), C.c_void_p]),
+                                ('rumpy_rcab_chain', C.c_int, [C.POINTER(RcabChainArgs), C.c_void_p]), ('rumpy_rcab_chain_work_bytes', C.c_int64, [C.c_int32, C.c_int32]),
                                 ('rumpy_last_error', C.c_char_p, [])):
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args

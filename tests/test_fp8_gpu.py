@@ -391,6 +391,57 @@ def test_config5_blind_qrcan_full_depth_fp8_step_against_the_fp32_oracle():
     _fp8_class_check(h.net.G.named_parameters(), oh.net.G.named_parameters(), 'config 5, frozen encoder, fp8')
 
 
+def joint_case(mode, crops, freeze):
+    """inputs, seeded weights and handler arguments of one joint-loss case (shared with tests/tools/fp8_block_ablation.py)"""
+    from oracle import contrastive_oracle as CO
+    from tests.test_oracle_golden import G21_KEYS, G21_META, g21_supmoco_pretrained_state
+    case = dict(mode=mode, crops=crops, freeze=freeze, extra=dict(block_encoder_loading=True), labels=None, sd=None, total=None)
+    if mode == 'supmoco':
+        sd, labels, total = g21_supmoco_pretrained_state()
+        ckpt = os.path.join(tempfile.mkdtemp(), 'enc_0')
+        torch.save({'network': sd, 'model_name': 'supmoco', 'model_epoch': 0}, ckpt)
+        case.update(sd=sd, labels=labels, total=total,
+                    extra=dict(pre_trained_encoder_weights=ckpt, data_type='noise', labelling_strategy='double_precision'))
+    case['kw'] = dict(metadata=torch.from_numpy(G21_META), metadata_keys=[(k,) for k in G21_KEYS]) if mode == 'supmoco' else {}
+    x = CO.contrastive_batch(4220, 4, crops, hw=48)
+    rng = np.random.default_rng(4227)
+    y = torch.nn.functional.interpolate(x.view(-1, 3, 48, 48), scale_factor=4, mode='bilinear', align_corners=False).view(4, crops, 3, 192, 192)
+    case['x'] = x
+    case['y'] = (y + torch.from_numpy(rng.uniform(-0.05, 0.05, tuple(y.shape)).astype(np.float32))).clamp(0, 1)
+    return case
+
+
+def joint_oracle(case):
+    """the fp32 oracle handler of a joint-loss case after ONE run_train step (its gradients are the reference of the class check)"""
+    from oracle import contrastive_oracle as CO
+    from tests.test_oracle_golden import _g20_seed
+    oh = CO.OracleJointHandler(O.build_oracle('qrcan', num_metadata=256, **BLIND_FULL), case['mode'], case['crops'], case['freeze'], lr=1e-4)
+    gsd = O.seeded_state_dict(oh.net.G, 4200)
+    if case.get('state_hook') is not None:      # (tests/tools/fp8_block_ablation.py --wq)
+        gsd = case['state_hook'](gsd)
+    oh.net.G.load_state_dict(gsd)
+    if case['mode'] == 'moco':
+        _g20_seed(oh.net.E, 4210)
+    else:
+        oh.net.E.register_classes(case['total'])
+        oh.net.E.load_state_dict(case['sd'])
+    case['G_state'] = {k: v.clone() for k, v in oh.net.G.state_dict().items()}
+    case['E_state'] = {k: v.clone() for k, v in oh.net.E.state_dict().items()}
+    case['opkg'], case['ologits'] = oh.run_train(case['x'], case['y'], case['labels'])
+    return oh
+
+
+def joint_handler(case, precision='fp8'):
+    """the HIP handler of a joint-loss case with the oracle's starting weights (joint_oracle first)"""
+    h = _handler('contrastiveblindqrcan', precision=precision, metadata_list=None, lr=1e-4, combined_loss_mode=case['mode'], crop_count=case['crops'],
+                 encoder_train_eval='train', encoder_freeze_mode=case['freeze'], **case['extra'], **BLIND_FULL)
+    h.net.G.load_state_dict(case['G_state'])
+    if case['mode'] == 'moco':
+        h.net.E.load_state_dict(case['E_state'])
+    return h
+
+
+
 _JOINT_XFAIL = ("MEASURED ABOVE THE CLASS BOUND, bound kept (VERDICT r4 item 1: 'report the numbers, do not loosen the class'): whole gradient 5.26e-2 "
                 "(supmoco / pre_q) and 5.08e-2 (moco / none) against <= 5e-2; cosine 0.99886 / 0.99893 (>= 0.998 holds), worst 3x3 tensor 1.37e-1 / "
                 "1.22e-1 (<= 1.5e-1 holds), worst q-layer tensor 8.0e-2 / 7.6e-2 (<= 1e-1 holds).  The same generator through the fused-L1 path on the "
@@ -404,33 +455,11 @@ def test_config5_blind_qrcan_full_depth_fp8_joint_losses_against_the_fp32_oracle
     """the same generator under the joint SR + contrastive losses with the encoder TRAINING (handlers.py:513-586): 'supmoco' with the mlp heads
     trainable (the form G21 pins), 'moco' with the whole query encoder trainable - the gradient reaches the generator through the generic
     loss path (mean-reduced, 1e-7: the case the two-pass scale measurement exists for) and the encoder through d loss / d metadata."""
-    from oracle import contrastive_oracle as CO
-    from tests.test_oracle_golden import G21_KEYS, G21_META, _g20_seed, g21_supmoco_pretrained_state
-    extra, labels = dict(block_encoder_loading=True), None
-    if mode == 'supmoco':
-        sd, labels, total = g21_supmoco_pretrained_state()
-        ckpt = os.path.join(tempfile.mkdtemp(), 'enc_0')
-        torch.save({'network': sd, 'model_name': 'supmoco', 'model_epoch': 0}, ckpt)
-        extra = dict(pre_trained_encoder_weights=ckpt, data_type='noise', labelling_strategy='double_precision')
-    h = _handler('contrastiveblindqrcan', precision='fp8', metadata_list=None, lr=1e-4, combined_loss_mode=mode, crop_count=crops,
-                 encoder_train_eval='train', encoder_freeze_mode=freeze, **extra, **BLIND_FULL)
-    oh = CO.OracleJointHandler(O.build_oracle('qrcan', num_metadata=256, **BLIND_FULL), mode, crops, freeze, lr=1e-4)
-    gsd = O.seeded_state_dict(oh.net.G, 4200)
-    oh.net.G.load_state_dict(gsd)
-    h.net.G.load_state_dict(gsd)
-    if mode == 'moco':
-        _g20_seed(oh.net.E, 4210)
-        h.net.E.load_state_dict(oh.net.E.state_dict())
-    else:
-        oh.net.E.register_classes(total)
-        oh.net.E.load_state_dict(sd)
-    kw = dict(metadata=torch.from_numpy(G21_META), metadata_keys=[(k,) for k in G21_KEYS]) if mode == 'supmoco' else {}
-    x = CO.contrastive_batch(4220, 4, crops, hw=48)
-    rng = np.random.default_rng(4227)
-    y = torch.nn.functional.interpolate(x.view(-1, 3, 48, 48), scale_factor=4, mode='bilinear', align_corners=False).view(4, crops, 3, 192, 192)
-    y = (y + torch.from_numpy(rng.uniform(-0.05, 0.05, tuple(y.shape)).astype(np.float32))).clamp(0, 1)
-    opkg, ologits = oh.run_train(x, y, labels)
-    pkg, logits = h.run_train(x=x, y=y, **kw)
+    case = joint_case(mode, crops, freeze)
+    oh = joint_oracle(case)
+    opkg, ologits = case['opkg'], case['ologits']
+    h = joint_handler(case)
+    pkg, logits = h.run_train(x=case['x'], y=case['y'], **case['kw'])
     gen = h.net.hip_generator
     plan = gen.engine.plan_for(4, 48, 48, True)
     assert gen.engine.fp8 and plan.f8_f_n == 200 and plan.f8_b_n == 200 and gen.engine.exchange_status() == 0

@@ -47,14 +47,14 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(h, s), s
     lib = _lib.lib()
-    assert lib.rumpy_abi_version() == 5
+    assert lib.rumpy_abi_version() == 6
     assert lib.rumpy_wgrad_slab_floats(4) == 64 * 576 + 64 and lib.rumpy_wgrad_slab_floats(1) == 16 * 576 + 16
 
 
 def test_ctypes_structs_match_the_header_layout():
     """compile a C probe against include/rumpy_amd.h and compare sizeof / offsetof with the ctypes mirrors"""
     _lib = _lib_or_skip()
-    pairs = {'rumpy_conv_args': _lib.ConvArgs, 'rumpy_head_fwd_args': _lib.HeadFwdArgs, 'rumpy_enc_conv_args': _lib.EncConvArgs, 'rumpy_rcab_args': _lib.RcabArgs, 'rumpy_rcab2_args': _lib.Rcab2Args, 'rumpy_res_chain_block': _lib.ResChainBlock, 'rumpy_res_chain_args': _lib.ResChainArgs, 'rumpy_rcab_chain_block': _lib.RcabChainBlock, 'rumpy_rcab_chain_args': _lib.RcabChainArgs, 'rumpy_enc_bn_args': _lib.EncBnArgs, 'rumpy_enc_bn_bwd_args': _lib.EncBnBwdArgs, 'rumpy_pixel_shuffle_args': _lib.PixelShuffleArgs, 'rumpy_tail_wide_args': _lib.TailWideArgs, 'rumpy_head_wgrad_args': _lib.HeadWgradArgs,
+    pairs = {'rumpy_conv_args': _lib.ConvArgs, 'rumpy_head_fwd_args': _lib.HeadFwdArgs, 'rumpy_enc_conv_args': _lib.EncConvArgs, 'rumpy_rcab_args': _lib.RcabArgs, 'rumpy_rcab2_args': _lib.Rcab2Args, 'rumpy_res_chain_block': _lib.ResChainBlock, 'rumpy_res_chain_args': _lib.ResChainArgs, 'rumpy_enc_bn_args': _lib.EncBnArgs, 'rumpy_enc_bn_bwd_args': _lib.EncBnBwdArgs, 'rumpy_pixel_shuffle_args': _lib.PixelShuffleArgs, 'rumpy_tail_wide_args': _lib.TailWideArgs, 'rumpy_head_wgrad_args': _lib.HeadWgradArgs,
              'rumpy_tail_fwd_args': _lib.TailFwdArgs, 'rumpy_tail_dgrad_args': _lib.TailDgradArgs, 'rumpy_conv4d_tail_args': _lib.Conv4dTailArgs,
              'rumpy_nchw_to_nhwc4_args': _lib.NchwToNhwc4Args, 'rumpy_wgrad_job': _lib.WgradJob, 'rumpy_reduce_item': _lib.ReduceItem,
              'rumpy_pack_item': _lib.PackItem, 'rumpy_ca_mlp_fwd_args': _lib.CaMlpFwdArgs, 'rumpy_ca_scale_args': _lib.CaScaleArgs,

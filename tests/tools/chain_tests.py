@@ -13,7 +13,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C                  # noqa: E402
-from gpu_utils import (BF16, DEV, SPLIT_FORK, SPLIT_JOIN, SPLIT_ONE_STREAM, BlockChainArgs, BlockSplitArgs, ChainArgs, ChainLayer, PackedConv, assert_bf16_close, exp_call, exp_lib, hip_conv, nhwc,   # noqa: E402
+from gpu_utils import (BF16, DEV, SPLIT_FORK, SPLIT_JOIN, SPLIT_ONE_STREAM, BlockChainArgs, BlockSplitArgs, ChainArgs, ChainLayer, PackedConv, RcabChainArgs, RcabChainBlock, assert_bf16_close, exp_call, exp_lib, hip_conv, nhwc,   # noqa: E402
                        stream, to_dev_bytes)
 from rumpy_amd import _lib as L          # noqa: E402
 
@@ -219,3 +219,75 @@ def test_half_strip_block_launches_are_bitwise_the_whole_strip_launches(N, H, W)
     assert torch.equal(cur_w.view(torch.int16), cur_s.view(torch.int16))
     bad = BlockSplitArgs(block=L.BlockArgs(x=x.data_ptr(), w1=pa.w_fwd.data_ptr(), w2=pb.w_fwd.data_ptr(), out=x.data_ptr(), N=1, H=8, W=64, relu1=1, scale1=1.0, scale2=1.0), flags=0)
     assert exp_lib().rumpy_conv_block_split(C.byref(bad), None) == -1 and b'W <= 48' in exp_lib().rumpy_last_error()
+
+
+# ---- a run of RCABs as one persistent launch (conv_rcab_chain.hip; product library until round 6: measured slower than the per-block launches, profiles/r05_rcab_chain.txt)
+def _rcab_chain_case(N, H, W, nblk, cr, hooks, seed, with_q=False):
+    gen = np.random.default_rng(seed)
+    f32 = lambda lo, hi, *s: torch.from_numpy(gen.uniform(lo, hi, s).astype(np.float32)).to(DEV)
+    convs = [(PackedConv(f32(-0.05, 0.05, 64, 64, 3, 3).cpu(), f32(-0.1, 0.1, 64).cpu()), PackedConv(f32(-0.05, 0.05, 64, 64, 3, 3).cpu(), f32(-0.1, 0.1, 64).cpu()))
+             for _ in range(nblk)]
+    mlps = [(f32(-0.3, 0.3, cr, 64), f32(-0.3, 0.3, cr), f32(-0.3, 0.3, 64, cr), f32(-0.3, 0.3, 64)) for _ in range(nblk)]
+    qgs = [f32(0.2, 1.0, N, 64) if with_q else None for _ in range(nblk)]
+    rnd = lambda: torch.from_numpy(gen.standard_normal((N, H, W, 64)).astype(np.float32)).to(DEV).to(BF16)
+    nan = lambda: torch.full((N, H, W, 64), float('nan'), dtype=BF16, device=DEV)
+    x0, dy0, extra = rnd(), rnd(), rnd()
+    lib = L.lib()
+    res = {}
+    for form in ('blocks', 'chain'):
+        t1s, t2s, ys = [nan() for _ in range(nblk)], [nan() for _ in range(nblk)], [nan() for _ in range(nblk)]
+        mbs = [torch.zeros(N, H, W, 8, dtype=torch.uint8, device=DEV) for _ in range(nblk)]
+        means, hids, gates = ([torch.full(s, float('nan'), device=DEV) for _ in range(nblk)] for s in ((N, 64), (N, cr), (N, 64)))
+        dt2s, dt1s, dxs = [nan() for _ in range(nblk)], [nan() for _ in range(nblk)], [nan() for _ in range(nblk)]
+        dzs, dzqs = [torch.zeros(N, 64, device=DEV) for _ in range(nblk)], [torch.zeros(N, 64, device=DEV) for _ in range(nblk)]
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        if form == 'blocks':
+            xchg = torch.zeros(int(lib.rumpy_rcab_xchg_bytes(N, H, W)), dtype=torch.uint8, device=DEV)
+            epoch = torch.zeros(1, dtype=torch.int32, device=DEV)
+            common = lambda b: dict(N=N, H=H, W=W, cr=cr, ca_w1=mlps[b][0].data_ptr(), ca_b1=mlps[b][1].data_ptr(), ca_w2=mlps[b][2].data_ptr(), ca_b2=mlps[b][3].data_ptr(),
+                                    hidden=hids[b].data_ptr(), gate=gates[b].data_ptr(), qgate=qgs[b].data_ptr() if with_q else None, xchg=xchg.data_ptr(),
+                                    xchg_bytes=xchg.numel(), epoch=epoch.data_ptr(), status=status.data_ptr(), maskbits=mbs[b].data_ptr())
+            L.check(lib.rumpy_rcab_epoch_advance(epoch.data_ptr(), stream()), 'epoch')
+            for b, (pa, pb) in enumerate(convs):
+                L.call('rumpy_rcab_fwd', L.RcabArgs(x=(x0 if b == 0 else ys[b - 1]).data_ptr(), w1=pa.w_fwd.data_ptr(), b1=pa.b_packed.data_ptr(), w2=pb.w_fwd.data_ptr(),
+                                                    b2=pb.b_packed.data_ptr(), t=t1s[b].data_ptr(), t2=t2s[b].data_ptr(), out=ys[b].data_ptr(), mean=means[b].data_ptr(),
+                                                    seq=2 * b, **common(b)), stream())
+            for k, b in enumerate(reversed(range(nblk))):
+                pa, pb = convs[b]
+                g_in = dy0 if k == 0 else dxs[b + 1]
+                L.call('rumpy_rcab_bwd', L.RcabArgs(x=g_in.data_ptr(), w1=pb.w_dgrad.data_ptr(), w2=pa.w_dgrad.data_ptr(), t=dt1s[b].data_ptr(), t2=dt2s[b].data_ptr(),
+                                                    t2_in=t2s[b].data_ptr(), mask=t1s[b].data_ptr(), res2=extra.data_ptr() if b == 0 else None, out=dxs[b].data_ptr(),
+                                                    dz=dzs[b].data_ptr(), dzq=dzqs[b].data_ptr() if with_q else None, seq=2 * b + 1, **common(b)), stream())
+        else:
+            work = torch.zeros(int(exp_lib().rumpy_rcab_chain_work_bytes(N, H)), dtype=torch.uint8, device=DEV)
+            xchg = torch.zeros(N * ((H + 5) // 6) * 512, dtype=torch.uint8, device=DEV)
+            rec = lambda **kw: RcabChainBlock(**{k: (v.data_ptr() if torch.is_tensor(v) else v) for k, v in kw.items()})
+            fwd = [rec(x=x0 if b == 0 else ys[b - 1], w1=pa.w_fwd, b1=pa.b_packed, w2=pb.w_fwd, b2=pb.b_packed, t=t1s[b], t2=t2s[b], out=ys[b], maskbits=mbs[b],
+                       ca_w1=mlps[b][0], ca_b1=mlps[b][1], ca_w2=mlps[b][2], ca_b2=mlps[b][3], mean=means[b], hidden=hids[b], gate=gates[b],
+                       qgate=qgs[b] if with_q else None) for b, (pa, pb) in enumerate(convs)]
+            bwd = []
+            for k, b in enumerate(reversed(range(nblk))):
+                pa, pb = convs[b]
+                bwd.append(rec(x=dy0 if k == 0 else dxs[b + 1], w1=pb.w_dgrad, w2=pa.w_dgrad, t=dt1s[b], t2=dt2s[b], t2_in=t2s[b], res2=extra if b == 0 else None, out=dxs[b],
+                               maskbits=mbs[b], ca_w1=mlps[b][0], ca_b1=mlps[b][1], ca_w2=mlps[b][2], ca_b2=mlps[b][3], hidden=hids[b], gate=gates[b],
+                               qgate=qgs[b] if with_q else None, dz=dzs[b], dzq=dzqs[b] if with_q else None))
+            for recs, backward in ((fwd, 0), (bwd, 1)):
+                tab = to_dev_bytes((RcabChainBlock * nblk)(*recs))
+                a = RcabChainArgs(blocks=tab.data_ptr(), nblocks=nblk, N=N, H=H, W=W, cr=cr, backward=backward, work=work.data_ptr(), work_bytes=work.numel(),
+                                    xchg=xchg.data_ptr(), xchg_bytes=xchg.numel(), status=status.data_ptr(), **hooks)
+                for rep in range(2):
+                    exp_call('rumpy_rcab_chain', a, stream())
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        assert int(status.item()) == 0, hex(int(status.item()))
+        res[form] = t1s + t2s + ys + mbs + means + hids + gates + dt2s + dt1s + dxs + dzs + dzqs
+    names = ['t1', 't2', 'y', 'mb', 'mean', 'hid', 'gate', 'dt2', 'dt1', 'dx', 'dz', 'dzq']
+    for i, (p, q) in enumerate(zip(res['blocks'], res['chain'])):
+        assert p.dtype == torch.uint8 or torch.isfinite(p.float()).all(), (names[i // nblk], i % nblk)
+        assert torch.equal(p.view(torch.uint8), q.view(torch.uint8)), (names[i // nblk], i % nblk, hooks)
+
+
+@pytest.mark.parametrize('hooks', [dict(fake_xcc=0, force_sc1=0), dict(fake_xcc=0, force_sc1=1), dict(fake_xcc=3, force_sc1=1)])
+@pytest.mark.parametrize('N,H,W,nblk,cr,with_q', [(32, 48, 48, 5, 4, False), (3, 20, 37, 3, 4, True), (2, 5, 9, 2, 1, False), (6, 31, 24, 4, 3, True)])
+def test_rcab_chain_is_bitwise_the_per_block_launches(N, H, W, nblk, cr, with_q, hooks):
+    _rcab_chain_case(N, H, W, nblk, cr, hooks, 1200 + N + H, with_q)

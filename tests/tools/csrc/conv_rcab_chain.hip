@@ -15,6 +15,7 @@
 // the two images: 152 KB + the attention MLP's operands), bf16.
 #include "chain_common.hpp"
 #include "rcab_common.hpp"
+#include "rumpy_experimental.h"
 #include <cstdlib>
 
 struct RcBlk {

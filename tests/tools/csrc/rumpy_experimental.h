@@ -95,6 +95,31 @@ typedef struct {
 } rumpy_block_split_args;
 int rumpy_conv_block_split(const rumpy_block_split_args* a, void* stream);
 
+/* ---- round 5, moved here in round 6 (measured slower than the per-block launches; never launched by the engine): a chain of RCABs in one persistent launch
+ * (conv_rcab_chain.hip; work buffer, claims and hand-offs as rumpy_res_chain of the product library): the blocks of rumpy_rcab_fwd / rumpy_rcab_bwd (same arithmetic, bitwise the per-block launches), block b's x
+ * BEING block b - 1's out; the strips of an image exchange their pool sums inside the launch through `xchg` (N * ceil(H/6) * 512 bytes, zeroed once; its own
+ * buffer, not one shared with rumpy_rcab_fwd).  backward = 0: t = t1, t2 = conv2's output (both stored when set), mean / hidden / gate: out.
+ * backward = 1: x = dy, w1 / w2 = DATA-GRADIENT images of conv2 / conv1, t = gt1 out, t2 = d_t2 out, t2_in = the forward pass's t2, maskbits, hidden / gate: in,
+ * dz [, dzq]: out.  W <= 48, N * ceil(H/6) <= CUs, Cr <= 4, bf16.  *status: 0x4ff / 0x500 + block (hand-off) or 0x600 + block (pool exchange) after a time-out.
+ * Replaces: the RCABs of ResidualGroup.body (rumpy/SISR/models/advanced/architectures.py:107-119: n_resblocks RCAB + conv; forward :121-124) run back to
+ * back, and their autograd backward.  Measured at parity forward (19.7 against 19.8 us per RCAB) and slower backward (21.6 against 19.0): profiles/r05_rcab_chain.txt. */
+typedef struct {
+  const void* x; const void* w1; const float* b1; const void* w2; const float* b2;
+  void* t; void* t2; const void* t2_in; const void* res2; void* out; void* maskbits;
+  const float* ca_w1; const float* ca_b1; const float* ca_w2; const float* ca_b2;
+  float* mean; float* hidden; float* gate; const float* qgate; float* dz; float* dzq;
+} rumpy_rcab_chain_block;
+typedef struct {
+  const void* blocks;      /* DEVICE array of rumpy_rcab_chain_block */
+  int32_t nblocks, N, H, W, cr, backward;
+  void* work; int64_t work_bytes;      /* rumpy_rcab_chain_work_bytes(N, H), zeroed once */
+  void* xchg; int64_t xchg_bytes; void* status;
+  int32_t fake_xcc, force_sc1;         /* test hooks, as in rumpy_res_chain_args */
+} rumpy_rcab_chain_args;
+int rumpy_rcab_chain(const rumpy_rcab_chain_args* a, void* stream);
+int64_t rumpy_rcab_chain_work_bytes(int32_t N, int32_t H);
+int rumpy_debug_rcc_stamps(void* buf);   /* -DRCC_STAMPS builds only */
+
 #ifdef __cplusplus
 }
 #endif
