@@ -344,8 +344,10 @@ BLIND_FULL = dict(scale=4, n_feats=64, n_resgroups=10, n_resblocks=20, reduction
                   selective_meta_blocks=[True] + [False] * 9, num_q_layers_inner_residual=1)
 
 
-def _fp8_class_check(named_h, named_o, tag, q_bound=1e-1):
-    """whole gradient <= 5e-2, cosine >= 0.998, every 3x3 tensor <= 1.5e-1, q-layer tensors <= the bf16 joint test's bound (1e-1, cosine 0.99)"""
+def _fp8_class_check(named_h, named_o, tag, q_bound=1e-1, whole_ceiling=None, xfail_reason=None):
+    """whole gradient <= 5e-2, cosine >= 0.998, every 3x3 tensor <= 1.5e-1, q-layer tensors <= the bf16 joint test's bound (1e-1, cosine 0.99).
+    whole_ceiling: a case whose ONLY miss is a whole-gradient error in (5e-2, whole_ceiling] is reported as an expected failure with its
+    numbers; anything beyond the recorded ceiling, or any other bound missed, fails hard - drift does not hide behind an xfail mark."""
     num = den = dot = gg = 0.0
     worst3, worstq = (0.0, None), (0.0, None)
     for (k, p), (k2, q) in zip(named_h, named_o):
@@ -366,7 +368,10 @@ def _fp8_class_check(named_h, named_o, tag, q_bound=1e-1):
     whole, cos = (num / den) ** 0.5, dot / (gg * den) ** 0.5
     print('%s: whole-gradient rel %.3e, cosine %.5f, worst 3x3 tensor %.3e (%s), worst q-layer tensor %.3e (%s)'
           % (tag, whole, cos, worst3[0], worst3[1], worstq[0], worstq[1]))
-    assert whole <= 5e-2 and cos >= 0.998 and worst3[0] <= 1.5e-1 and worstq[0] <= q_bound, (whole, cos, worst3, worstq)
+    assert cos >= 0.998 and worst3[0] <= 1.5e-1 and worstq[0] <= q_bound, (whole, cos, worst3, worstq)
+    if whole_ceiling is not None and 5e-2 < whole <= whole_ceiling:
+        pytest.xfail('%s  [this run: whole gradient %.3e, cosine %.5f, worst 3x3 %.3e, worst q-layer %.3e]' % (xfail_reason, whole, cos, worst3[0], worstq[0]))
+    assert whole <= 5e-2, (whole, cos, worst3, worstq)
 
 
 def test_config5_blind_qrcan_full_depth_fp8_step_against_the_fp32_oracle():
@@ -442,15 +447,14 @@ def joint_handler(case, precision='fp8'):
 
 
 
-_JOINT_XFAIL = ("MEASURED ABOVE THE CLASS BOUND, bound kept (VERDICT r4 item 1: 'report the numbers, do not loosen the class'): whole gradient 5.26e-2 "
-                "(supmoco / pre_q) and 5.08e-2 (moco / none) against <= 5e-2; cosine 0.99886 / 0.99893 (>= 0.998 holds), worst 3x3 tensor 1.37e-1 / "
-                "1.22e-1 (<= 1.5e-1 holds), worst q-layer tensor 8.0e-2 / 7.6e-2 (<= 1e-1 holds).  The same generator through the fused-L1 path on the "
-                "same four images: 4.37e-2 (profiles/r05_fp8_joint_diag.txt) - the whole-gradient error of full-depth fp8 moves between 4.0e-2 and "
-                "5.3e-2 with weights and data; the class bound was set from the 4.0e-2 cases")
+_JOINT_XFAIL = ("MEASURED ABOVE THE CLASS BOUND, bound kept (VERDICT r4 item 1 / r5 item 1): whole gradient 5.26e-2 (supmoco / pre_q) and 5.08e-2 (moco / none) "
+                "against <= 5e-2; every other bound of the class holds.  Round 6 found the cause and measured the policies (profiles/r06_fp8_block_ablation.txt): "
+                "the error is the e4m3 rounding of the WEIGHTS (filters pre-rounded to the e4m3 grid in both nets: 6.2e-3, the bf16 level), it is not additive in "
+                "the blocks, and no mixed-precision policy with m <= 20 bf16 blocks reaches 4.5e-2 (random 20-block subsets: 4.46e-2 .. 5.29e-2; <= 4.5e-2 needs "
+                "m >= 54).  The bound is kept, the class is closed as it is; a whole-gradient error beyond 5.5e-2 or any other bound missed FAILS")
 
 
-@pytest.mark.parametrize('mode,crops,freeze', [pytest.param('supmoco', 3, 'pre_q', marks=pytest.mark.xfail(strict=False, reason=_JOINT_XFAIL)),
-                                               pytest.param('moco', 2, 'none', marks=pytest.mark.xfail(strict=False, reason=_JOINT_XFAIL))])
+@pytest.mark.parametrize('mode,crops,freeze', [('supmoco', 3, 'pre_q'), ('moco', 2, 'none')])
 def test_config5_blind_qrcan_full_depth_fp8_joint_losses_against_the_fp32_oracle(mode, crops, freeze):
     """the same generator under the joint SR + contrastive losses with the encoder TRAINING (handlers.py:513-586): 'supmoco' with the mlp heads
     trainable (the form G21 pins), 'moco' with the whole query encoder trainable - the gradient reaches the generator through the generic
@@ -465,7 +469,6 @@ def test_config5_blind_qrcan_full_depth_fp8_joint_losses_against_the_fp32_oracle
     assert gen.engine.fp8 and plan.f8_f_n == 200 and plan.f8_b_n == 200 and gen.engine.exchange_status() == 0
     for k in pkg:
         assert abs(float(pkg[k]) - float(opkg[k])) <= 2e-2 * max(1.0, float(opkg[k])), (k, float(pkg[k]), float(opkg[k]))
-    _fp8_class_check(h.net.G.named_parameters(), oh.net.G.named_parameters(), 'config 5, joint %s / %s, fp8' % (mode, freeze))
     # the encoder's own gradients: bounds of the bf16 joint test (tests/test_blind_gpu.py) - the fp8 launches enter them only through d metadata
     for (k, p), (_, po) in zip(h.net.E.named_parameters(), oh.net.E.named_parameters()):
         if po.requires_grad and 'mlp' in k:
@@ -478,6 +481,9 @@ def test_config5_blind_qrcan_full_depth_fp8_joint_losses_against_the_fp32_oracle
             assert r < 6e-2, (k, r)
         else:
             assert p.grad is None, k
+    # LAST (an expected failure ends the test): the generator's gradients in the class of this precision; ceiling of the recorded miss: 5.5e-2
+    _fp8_class_check(h.net.G.named_parameters(), oh.net.G.named_parameters(), 'config 5, joint %s / %s, fp8' % (mode, freeze),
+                     whole_ceiling=5.5e-2, xfail_reason=_JOINT_XFAIL)
 
 
 def test_fp8_scales_are_measured_right_for_mean_reduced_gradients():
