@@ -7,7 +7,6 @@
 // then per (strip, row half) ONE 128-BYTE LINE whose first word is the flag: (epoch << 8) + last block whose rows of that half are visible.  A line
 // per flag, because flags may be stored sc0: a line that is dirty in an XCD's L2 for ONE word would serve that XCD's polls of its other words stale
 constexpr int CH_W_DONE = 1, CH_W_COUNT = 8, CH_W_WHERE = 32, CH_MAX_XCD = 16, CH_FLAG_STRIDE = 32;
-constexpr unsigned CH_SPIN = 1u << 20;
 typedef unsigned int ch_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void ch_store16_sc1(uint16_t* p, uint4 v) {
@@ -27,10 +26,18 @@ __device__ __forceinline__ uint4 ch_load16_sc1(const uint16_t* p) {
   return make_uint4(w.x, w.y, w.z, w.w);
 }
 
-// every 1024th round of a poll looks at the launch's status word: once ANY poll of the launch has timed out (co-residency did not hold) the results are
-// lost anyway - the others stop waiting, so that the launch ends within milliseconds of the first time-out instead of one time-out per block
-__device__ __forceinline__ bool ch_give_up(unsigned spins, const unsigned* status) {
-  return (spins & 1023u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+// One round of a poll that has not seen its value yet: sleep, and every 256th round look at the clock and at the launch's status word.
+//   -> 0: poll again; 1: this poll has waited CH_TIMEOUT (0.5 s of the 100 MHz s_memrealtime clock - round 6: a watchdog in TIME; the 2^20 rounds of round 5 were
+//   meant as 0.1 s and took more than 3 s) - the caller stores its code in *status and goes on; 2: ANOTHER poll of the launch has timed out (co-residency did
+//   not hold: the results are lost anyway) - stop waiting, so that the launch drains within milliseconds of the first time-out instead of one time-out per block.
+// The clock is started at the first look (round 256): a hand-off that completes in microseconds never executes the s_memrealtime.
+constexpr unsigned long long CH_TIMEOUT = 50000000ull;
+__device__ __forceinline__ int ch_poll_round(unsigned& spins, unsigned long long& t0, const unsigned* status) {
+  __builtin_amdgcn_s_sleep(2);
+  if ((++spins & 255u) != 0u) return 0;
+  if (spins == 256u) { t0 = __builtin_amdgcn_s_memrealtime(); return 0; }
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return 2;
+  return (__builtin_amdgcn_s_memrealtime() - t0 > CH_TIMEOUT) ? 1 : 0;
 }
 
 struct ChainPlace { int strip; unsigned xcc, epoch; };
@@ -77,12 +84,13 @@ __device__ __forceinline__ ChainPlace chain_claim(unsigned* work, int N, int sy_
 // does strip `nb` run on this workgroup's XCD?  (polls the word its workgroup publishes at claim time)
 __device__ __forceinline__ bool chain_same_xcd(unsigned* work, unsigned epoch, int nb, unsigned my_xcc, unsigned* status) {
   unsigned w, spins = 0;
+  unsigned long long t0 = 0;
   for (;;) {
     w = __hip_atomic_load(work + CH_W_WHERE + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((w >> 8) == epoch) break;
-    __builtin_amdgcn_s_sleep(2);
-    if (++spins > CH_SPIN) { if ((threadIdx.x & 63) == 0) atomicExch(status, 0x4ffu); break; }
-    if (ch_give_up(spins, status)) break;
+    const int r = ch_poll_round(spins, t0, status);
+    if (r == 1 && (threadIdx.x & 63) == 0) atomicExch(status, 0x4ffu);
+    if (r) break;
   }
   return ((w >> 8) == epoch) && ((w & 255u) == my_xcc);
 }

@@ -16,8 +16,8 @@
 // dirty line of the own L2 and, failing that, the memory side - never a stale copy (the probe's cross-XCD sc1 / sc1 ping-pong relies on the same).
 // OUT rows stored sc0 are ordinary dirty L2 lines: written back at the end of the kernel like any store, for the launches that follow.
 //
-// Needs every strip co-resident (N * ceil(H/6) <= CUs, one 512-thread workgroup per CU): a poll that does not complete within CH_SPIN rounds (about a
-// second) stores a code in *status; every other poll of the launch then gives up at its next look at that word (chain_common.hpp::ch_give_up), the
+// Needs every strip co-resident (N * ceil(H/6) <= CUs, one 512-thread workgroup per CU): a poll that does not complete within CH_TIMEOUT (0.5 s)
+// stores a code in *status; every other poll of the launch then gives up at its next look at that word (chain_common.hpp::ch_poll_round), the
 // launch drains in milliseconds with garbage results, the optimizer launch of the step reads the same word and changes nothing, and the host - which
 // reads it back with the loss - switches the engine to one launch per block (engine.py::degrade; data-parallel ranks raise).  W <= 48.  Everything inside a block - sweeps, epilogues, row-half gates, whole-line stores -
 // is conv_block.hip (forms 1 and 3): the results are bitwise those of one launch per block (tests/test_chain_gpu.py).
@@ -258,12 +258,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       if (has_nb) {
         const unsigned want = (epoch << 8) + (unsigned)b;
         unsigned spins = 0;
+        unsigned long long t0 = 0;
         for (;;) {
           const unsigned f = __hip_atomic_load(flags + (2 * nb_strip + (1 - rh)) * CH_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((f >> 8) == epoch && (f & 0xffu) >= (want & 0xffu)) break;
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + (unsigned)b); break; }
-          if (ch_give_up(spins, a.status)) break;
+          const int tr = ch_poll_round(spins, t0, a.status);
+          if (tr == 1 && lane == 0) atomicExch(a.status, 0x500u + (unsigned)b);
+          if (tr) break;
         }
       }
       CH_STAMP(4);
@@ -444,12 +445,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     }
     if (has_nb) {
       unsigned spins = 0;
+      unsigned long long t0 = 0;
       for (;;) {
         const unsigned f = __hip_atomic_load(flags + (2 * nb_strip + (1 - rh)) * CH_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((f >> 8) == epoch && (f & 0xffu) >= (b & 0xffu)) break;
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + b); break; }
-        if (ch_give_up(spins, a.status)) break;
+        const int tr = ch_poll_round(spins, t0, a.status);
+        if (tr == 1 && lane == 0) atomicExch(a.status, 0x500u + b);
+        if (tr) break;
       }
     }
     {

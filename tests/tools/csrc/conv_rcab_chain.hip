@@ -220,11 +220,13 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
       if (has_nb) {
         const unsigned want = (unsigned)b;
         unsigned spins = 0;
+        unsigned long long t0 = 0;
         for (;;) {
           const unsigned f = __hip_atomic_load(flags + (2 * nb_strip + (1 - rh)) * CH_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((f >> 8) == epoch && (f & 0xffu) >= want) break;
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > CH_SPIN) { if (lane == 0) atomicExch(a.status, 0x500u + (unsigned)b); break; }
+          const int tr = ch_poll_round(spins, t0, a.status);
+          if (tr == 1 && lane == 0) atomicExch(a.status, 0x500u + (unsigned)b);
+          if (tr) break;
         }
       }
       uint4 Hr[3];
