@@ -22,6 +22,15 @@
 #ifndef C1_AHEAD
 #define C1_AHEAD 1      // fragment reads this many groups ahead of the MFMAs
 #endif
+#ifndef C1_HV
+#define C1_HV 2          // vector instructions of a hosted epilogue slice pinned per MFMA of the hosting sweep (0: the slice trails the group's MFMAs)
+#endif
+#ifndef C1_E1A
+#define C1_E1A 2         // where the epilogue of the four halo-free T rows runs: 0 = behind the halo sweeps with the rest, 1 = under the halo sweeps' MFMAs, 2 = in the waits of the hand-off
+#endif
+#ifndef C1_MERGE_D
+#define C1_MERGE_D 1     // the two two-row halo windows in one loop
+#endif
 #ifndef C1_INTERLEAVE
 #define C1_INTERLEAVE 1  // the next group's fragment reads pinned BETWEEN this group's MFMAs (0: in front of them, A/B)
 #endif
@@ -49,7 +58,7 @@ extern "C" int rumpy_debug_c1_stamps(void* buf) { return (int)hipMemcpyToSymbol(
 
 // block_common.hpp::block_sweep for a window that starts at row R0 of the image the bases were prepared for (sweep_bases with row0 = 0): the XOR class of
 // a read is ((R0 + r) * 50 + kx) & 7 - a compile-time index into the SAME 16 base registers - and the rest of the address is an immediate
-template <int ROWS, int R0, int FMT, class Hook = NoHook, int AHEAD = C1_AHEAD>
+template <int ROWS, int R0, int FMT, class Hook = NoHook, int HV = 0, int AHEAD = C1_AHEAD>
 __device__ __forceinline__ void sweep_at(f32x4 (&acc)[ROWS][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2], Hook hook = Hook()) {
   constexpr int NG = 18;
   bf16x8 I[AHEAD + 1][ROWS + 2];
@@ -77,16 +86,78 @@ __device__ __forceinline__ void sweep_at(f32x4 (&acc)[ROWS][3], const bf16x8 (&F
     // ROWS + 2 reads of the next group cost the pipe ~80 idle cycles per group (stamps: the six-row sweep at 64 % of its MFMA time); issued BETWEEN the MFMAs
     // they are nearly free (MI355X_MICROARCH.md, LDS: 2 ds_read_b128 per MFMA gap cost at most 3 cycles).  The group's region is pinned to
     // (1 read, PER MFMAs) x (ROWS + 2); what is left (MFMAs, the hook's instructions) follows.
+    // HV > 0: the hook's vector instructions (a slice of an epilogue that does not depend on this sweep) are pinned between the MFMAs too, HV per MFMA:
+    // an MFMA 16x16x32 holds the SIMD's vector issue for 8 of its 16 cycles - two 4-cycle instructions fit into every gap
+    constexpr int M = 3 * ROWS, PER = M / (ROWS + 2) > 0 ? M / (ROWS + 2) : 1;
     if (grp + AHEAD < NG) {
-      constexpr int PER = (3 * ROWS) / (ROWS + 2) > 0 ? (3 * ROWS) / (ROWS + 2) : 1;
 #pragma unroll
       for (int i = 0; i < ROWS + 2; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (HV > 0) __builtin_amdgcn_sched_group_barrier(0x002, HV * PER, 0);
+      }
+      if (HV > 0) {
+#pragma unroll
+        for (int i = 0; i < M - PER * (ROWS + 2); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, HV, 0);
+        }
+      }
+    } else if (HV > 0) {
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, HV, 0);
       }
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);   // a group's instructions stay inside the group
+  }
+}
+
+// two two-row windows (rows RA .. RA + 3 and RB .. RB + 3 of the image) in ONE loop: a group = 8 fragment reads and 12 MFMAs - alone, a two-row window's
+// group is 6 MFMAs = 96 cycles, shorter than the latency of the reads it has to cover.  Per accumulator the order is sweep_at's.
+template <int RA, int RB, int FMT, int AHEAD = C1_AHEAD>
+__device__ __forceinline__ void sweep_two(f32x4 (&accA)[2][3], f32x4 (&accB)[2][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2]) {
+  constexpr int NG = 18;
+  bf16x8 I[AHEAD + 1][8];
+  auto load_group = [&](int grp, bf16x8 (&dst)[8]) {
+    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int row = (r < 4 ? RA : RB - 4) + r;
+      dst[r] = *reinterpret_cast<const bf16x8*>(lds + off[(row * BCOLS + kx) & 7][half] + (row * BCOLS + 16 * c + kx) * 128);
+    }
+  };
+#pragma unroll
+  for (int g0 = 0; g0 < AHEAD; ++g0) load_group(g0, I[g0]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int grp = 0; grp < NG; ++grp) {
+    if (grp + AHEAD < NG) load_group(grp + AHEAD, I[(grp + AHEAD) % (AHEAD + 1)]);
+    const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        accA[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp % (AHEAD + 1)][r + ky], accA[r][c]);
+        accB[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp % (AHEAD + 1)][4 + r + ky], accB[r][c]);
+      }
+#if C1_INTERLEAVE
+    if (grp + AHEAD < NG) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -210,6 +281,39 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
     // (a) the four T rows that need no halo row (input rows 2 .. 7 = the strip's own rows: block b - 1's OUT, complete behind the gate at its end)
     sweep_at<4, 2, FMT>(*reinterpret_cast<f32x4(*)[4][3]>(&acc[2]), F, lds, offX);
     C1_STAMP(1);
+    // ---- epilogue 1 of ONE pair of T tiles, T = post1(acc) -> the T image in LDS, cut into slices j = 0 .. 3 (k, j are constants after unrolling; the
+    // slices of a pair run in order, one pair at a time) ----
+    f32x4 etx, ety;
+    float ev[8];
+    auto e1_slice = [&](int k, int j) {
+      if (j == 0) {
+        etx = (k < 8) ? acc[k < 8 ? k : 0][0] : acc[2 * (k < 8 ? 0 : k - 8)][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) etx[i] = (FORM == 1) ? relu_f32(etx[i]) : etx[i] * blk.scale1;
+      } else if (j == 1) {
+        ety = (k < 8) ? acc[k < 8 ? k : 0][1] : acc[2 * (k < 8 ? 0 : k - 8) + 1][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ety[i] = (FORM == 1) ? relu_f32(ety[i]) : ety[i] * blk.scale1;
+      } else if (j == 2) {
+        pair_up(etx, ety, g, ev);
+      } else if (j == 3) {
+        uint4 o = make_uint4(0, 0, 0, 0);                // outside the image: convB's zero padding
+        if (moff[k] != 0xffffffffu) {
+          const uint2 lo = pack4<FMT>(ev[0], ev[1], ev[2], ev[3]), hi = pack4<FMT>(ev[4], ev[5], ev[6], ev[7]);
+          o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
+        }
+        *reinterpret_cast<uint4*>(lds + tcell[k]) = o;
+      }
+    };
+    auto e1_pairs = [&](const int (&ks)[3]) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e1_slice(ks[i], j);
+    };
+    // the pairs of the four finished rows (2 .. 5 x column tiles 0 | 1: pairs 2 .. 5; rows 2 | 3 and 4 | 5 of column tile 2: pairs 9, 10)
+    const int ka0[3] = {2, 3, 4}, ka1[3] = {5, 9, 10};
     if (b > 0) {
       // (b) publish block b - 1: this wave's OUT stores are acknowledged (under the sweep above) -> count in -> one lane stores the strip's flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -219,6 +323,9 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
         if (lane == 0) __hip_atomic_store(my_flag, (epoch << 8) + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       C1_STAMP(2);
+      // C1_E1A = 2: the epilogue of the finished rows fills the two waits of the hand-off - the neighbours' flags travel while its first half runs,
+      // their rows while the second half does (one wave per SIMD: nobody else would use the time)
+      if (C1_E1A == 2) e1_pairs(ka0);
       // (c) the neighbours' rows: poll their flags, fetch, write to the halo rows of the input image
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -239,6 +346,7 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
       uint4 Hr[2 * C1_HREGS];
 #pragma unroll
       for (int i = 0; i < 2 * C1_HREGS; ++i) Hr[i] = ch_load16_sc1(blk.x + (hoff[i] != 0xffffffffu ? hoff[i] : 0u));
+      if (C1_E1A == 2) e1_pairs(ka1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < 2 * C1_HREGS; ++i)
@@ -246,10 +354,21 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
       gate_arrive(&gate[1], lane);
       gate_wait(&gate[1], 4u * (unsigned)b);
       C1_STAMP(4);
+    } else if (C1_E1A == 2) {
+      e1_pairs(ka0);
+      e1_pairs(ka1);
     }
-    // (d) the four T rows that do: rows 0, 1 (input rows 0 .. 3) and 6, 7 (input rows 6 .. 9)
-    sweep_at<2, 0, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), F, lds, offX);
-    sweep_at<2, 6, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[6]), F, lds, offX);
+    // (d) the four T rows that need the halo rows: rows 0, 1 (input rows 0 .. 3) and 6, 7 (input rows 6 .. 9)
+    auto e1a_d0 = [&](int grp) { if (C1_E1A == 1) e1_slice(ka0[grp / 6], grp % 6); };     // C1_E1A = 1: ... under these sweeps' MFMAs, one pair per six groups
+    auto e1a_d1 = [&](int grp) { if (C1_E1A == 1) e1_slice(ka1[grp / 6], grp % 6); };
+    if (C1_MERGE_D) {
+      sweep_two<0, 6, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), *reinterpret_cast<f32x4(*)[2][3]>(&acc[6]), F, lds, offX);
+      if (C1_E1A == 1) { e1_pairs(ka0); e1_pairs(ka1); }
+    } else {
+      sweep_at<2, 0, FMT, decltype(e1a_d0), (C1_E1A == 1 ? C1_HV : 0)>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), F, lds, offX, e1a_d0);
+      sweep_at<2, 6, FMT, decltype(e1a_d1), (C1_E1A == 1 ? C1_HV : 0)>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[6]), F, lds, offX, e1a_d1);
+    }
+    if (C1_E1A == 0) { e1_pairs(ka0); e1_pairs(ka1); }
     C1_STAMP(5);
     // second filter: L2 hits that land under the epilogue
     {
@@ -257,27 +376,11 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
 #pragma unroll
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
     }
-    // ---- epilogue 1: T = post1(acc) -> the T image in LDS ----
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      f32x4 tx = (k < 8) ? acc[k < 8 ? k : 0][0] : acc[2 * (k < 8 ? 0 : k - 8)][2];
-      f32x4 ty = (k < 8) ? acc[k < 8 ? k : 0][1] : acc[2 * (k < 8 ? 0 : k - 8) + 1][2];
-      if (FORM == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { tx[j] = relu_f32(tx[j]); ty[j] = relu_f32(ty[j]); }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { tx[j] *= blk.scale1; ty[j] *= blk.scale1; }
-      }
-      float v[8];
-      pair_up(tx, ty, g, v);
-      uint4 o = make_uint4(0, 0, 0, 0);                  // outside the image: convB's zero padding
-      if (moff[k] != 0xffffffffu) {
-        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
-        o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
-      }
-      *reinterpret_cast<uint4*>(lds + tcell[k]) = o;
+    // ---- the rest of epilogue 1: T rows 0, 1, 6, 7 ----
+    {
+      const int kb0[3] = {0, 1, 8}, kb1[3] = {6, 7, 11};
+      e1_pairs(kb0);
+      e1_pairs(kb1);
     }
     C1_STAMP(6);
     gate_arrive(&gate[2], lane);
