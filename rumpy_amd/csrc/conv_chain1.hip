@@ -31,6 +31,9 @@
 #ifndef C1_MERGE_D
 #define C1_MERGE_D 1     // the two two-row halo windows in one loop
 #endif
+#ifndef C1_ABL
+#define C1_ABL 0          // measurement builds only (results WRONG): 1 = the sweeps' fragment reads compiled out, 2 = their MFMAs
+#endif
 #ifndef C1_INTERLEAVE
 #define C1_INTERLEAVE 1  // the next group's fragment reads pinned BETWEEN this group's MFMAs (0: in front of them, A/B)
 #endif
@@ -42,6 +45,23 @@ struct C1Blk {
 static_assert(sizeof(C1Blk) == sizeof(rumpy_res_chain_block), "rumpy_res_chain_block is the device-side block record");
 struct C1Dev { const C1Blk* blk; int nblk, N, H, W, sy_n; unsigned* work; unsigned* status; int nxcd, fake_xcc; };
 
+
+// Every pointer of a block record comes out of device memory and is therefore a GENERIC pointer to the compiler: loads and stores through it are flat_*
+// instructions, which count on BOTH wait counters and complete out of order - every s_waitcnt lgkmcnt(N) of the fragment reads around a T store degrades to
+// a full drain (common.hpp::load_global_ptr: the same finding for the tail kernel, round 3).  These helpers go through the global address space.
+#define C1_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(unsigned long long)(p))
+__device__ __forceinline__ uint4 gld16(const void* p) { const u32x4v v = *C1_GLOBAL(const u32x4v, p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void gst16_nt(void* p, uint4 v) { __builtin_nontemporal_store((u32x4v){v.x, v.y, v.z, v.w}, C1_GLOBAL(u32x4v, p)); }
+__device__ __forceinline__ unsigned gld8(const unsigned char* p) { return *C1_GLOBAL(const unsigned char, p); }
+__device__ __forceinline__ void gst8(unsigned char* p, unsigned v) { *C1_GLOBAL(unsigned char, p) = (unsigned char)v; }
+__device__ __forceinline__ f32x4 gldf4(const float* p) { return *C1_GLOBAL(const f32x4, p); }
+// 16 bytes another workgroup has published (write-through stores behind a flag): two 8-byte agent-scope atomic loads - sc1, never served from a stale line
+__device__ __forceinline__ uint4 gld16_agent(const void* p) {
+  const unsigned long long lo = __hip_atomic_load(C1_GLOBAL(const unsigned long long, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(C1_GLOBAL(const unsigned long long, p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint4((unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32));
+}
+
 constexpr int C1T = 256;
 constexpr int C1_SREGS = BSH * BSW * 8 / C1T;        // 9: the strip's 6 x 48 pixels as 16-byte pieces per thread
 constexpr int C1_HREGS = 2 * BSW * 8 / C1T;          // 3: two halo rows per side
@@ -50,7 +70,9 @@ static_assert(C1_SREGS * C1T == BSH * BSW * 8 && C1_HREGS * C1T == 2 * BSW * 8, 
 // -DC1_STAMPS (measurement builds only): phase time stamps (s_memrealtime, 100 MHz) of every wave in the MIDDLE block
 #ifdef C1_STAMPS
 __device__ unsigned long long* g_c1_stamps;
-#define C1_STAMP(k) do { if (b == a.nblk / 2 && (threadIdx.x & 63) == 0 && g_c1_stamps) g_c1_stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// (second half of the buffer: the same stamps in shader-clock cycles, s_memtime - their ratio is the clock the kernel really ran at)
+#define C1_STAMP(k) do { if (b == a.nblk / 2 && (threadIdx.x & 63) == 0 && g_c1_stamps) { const size_t si_ = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k); \
+    g_c1_stamps[si_] = __builtin_amdgcn_s_memrealtime(); g_c1_stamps[(size_t)gridDim.x * 64 + si_] = __builtin_amdgcn_s_memtime(); } } while (0)
 extern "C" int rumpy_debug_c1_stamps(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_c1_stamps), &buf, sizeof(buf)); }
 #else
 #define C1_STAMP(k) do { } while (0)
@@ -73,13 +95,18 @@ __device__ __forceinline__ void sweep_at(f32x4 (&acc)[ROWS][3], const bf16x8 (&F
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int grp = 0; grp < NG; ++grp) {
-    if (grp + AHEAD < NG) load_group(grp + AHEAD, I[(grp + AHEAD) % (AHEAD + 1)]);
+    if (grp + AHEAD < NG && !(C1_ABL & 1)) load_group(grp + AHEAD, I[(grp + AHEAD) % (AHEAD + 1)]);
     const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+    if (!(C1_ABL & 2)) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int r = 0; r < ROWS; ++r)
-        acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp % (AHEAD + 1)][r + ky], acc[r][c]);
+        acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[(C1_ABL & 1) ? 0 : grp % (AHEAD + 1)][r + ky], acc[r][c]);
+    } else if (grp + AHEAD >= NG) {
+#pragma unroll
+      for (int r = 0; r < ROWS + 2; ++r) acc[r % ROWS][c] = mfma16<FMT>(F[0], I[grp % (AHEAD + 1)][r], acc[r % ROWS][c]);      // (keeps the reads alive)
+    }
     hook(grp);
 #if C1_INTERLEAVE
     // ONE wave per SIMD: nobody else fills the matrix pipe while this wave issues its fragment reads.  In front of the group's MFMAs (round-5 order) the
@@ -117,8 +144,8 @@ __device__ __forceinline__ void sweep_at(f32x4 (&acc)[ROWS][3], const bf16x8 (&F
 
 // two two-row windows (rows RA .. RA + 3 and RB .. RB + 3 of the image) in ONE loop: a group = 8 fragment reads and 12 MFMAs - alone, a two-row window's
 // group is 6 MFMAs = 96 cycles, shorter than the latency of the reads it has to cover.  Per accumulator the order is sweep_at's.
-template <int RA, int RB, int FMT, int AHEAD = C1_AHEAD>
-__device__ __forceinline__ void sweep_two(f32x4 (&accA)[2][3], f32x4 (&accB)[2][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2]) {
+template <int RA, int RB, int FMT, class Hook = NoHook, int AHEAD = C1_AHEAD>
+__device__ __forceinline__ void sweep_two(f32x4 (&accA)[2][3], f32x4 (&accB)[2][3], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2], Hook hook = Hook()) {
   constexpr int NG = 18;
   bf16x8 I[AHEAD + 1][8];
   auto load_group = [&](int grp, bf16x8 (&dst)[8]) {
@@ -134,15 +161,21 @@ __device__ __forceinline__ void sweep_two(f32x4 (&accA)[2][3], f32x4 (&accB)[2][
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int grp = 0; grp < NG; ++grp) {
-    if (grp + AHEAD < NG) load_group(grp + AHEAD, I[(grp + AHEAD) % (AHEAD + 1)]);
+    if (grp + AHEAD < NG && !(C1_ABL & 1)) load_group(grp + AHEAD, I[(grp + AHEAD) % (AHEAD + 1)]);
     const int half = grp / 9, kx = (grp % 9) / 3, c = grp % 3;
+    if (!(C1_ABL & 2)) {
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        accA[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp % (AHEAD + 1)][r + ky], accA[r][c]);
-        accB[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp % (AHEAD + 1)][4 + r + ky], accB[r][c]);
+        accA[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[(C1_ABL & 1) ? 0 : grp % (AHEAD + 1)][r + ky], accA[r][c]);
+        accB[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[(C1_ABL & 1) ? 0 : grp % (AHEAD + 1)][4 + r + ky], accB[r][c]);
       }
+    } else if (grp + AHEAD >= NG) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) accA[r % 2][c] = mfma16<FMT>(F[0], I[grp % (AHEAD + 1)][r], accA[r % 2][c]);
+    }
+    hook(grp);
 #if C1_INTERLEAVE
     if (grp + AHEAD < NG) {
 #pragma unroll
@@ -165,7 +198,7 @@ __device__ __forceinline__ void sweep_two(f32x4 (&accA)[2][3], f32x4 (&accB)[2][
 template <int FORM, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
-  __shared__ unsigned gate[4];             // waves that have: written their OUT channels [0], written the halo rows [1], written their T channels [2], seen their OUT stores acknowledged [3]
+  __shared__ unsigned gate[5];             // waves that have: written their OUT channels [0], written the halo rows [1], written their T channels [2], seen their OUT stores acknowledged [3]
   __shared__ int claim[3];
   const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, g = lane >> 4;
@@ -192,9 +225,9 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
       const int y = y0 + lr, x = lc - 1;
       const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
-      R[i] = keep_if(*reinterpret_cast<const uint4*>(b0.x + (unsigned)e), ok);
+      R[i] = keep_if(gld16(b0.x + (unsigned)e), ok);
     }
-    if (tid < 4) gate[tid] = 0u;
+    if (tid < 5) gate[tid] = 0u;
     if (tid < BTROWS * 2 * 8) {            // border columns of the T image: convB's zero padding, never written by the epilogues
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
       *reinterpret_cast<uint4*>(lds + BXBYTES + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
@@ -209,7 +242,7 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
   {
     const uint4* wp = b0.w1 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(gld16(wp + t * 64));
   }
 
   // ---- lane geometry, ONCE for the whole chain ----
@@ -261,72 +294,100 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
   sweep_bases(offT, (unsigned)BXBYTES, 0, px, g);
   __syncthreads();
 
+  // Order of a block (round 6, third form): everything that needs NO halo row first - T rows 2 .. 5, their epilogue, and from them OUT rows 2, 3 with theirs -
+  // then the four T rows that do, the rest of the second conv, the stores.  The hand-off of block b - 1 (stores acknowledged -> flag -> the neighbours' flags ->
+  // their rows) runs beside ~5 us of this strip's own work instead of in front of the halo sweep (stamps of the first form: 2.2 us of waiting per block).
+  // Both filters of a block are resident (144 of the 256 AGPRs).
+  bf16x8 F2[18];
   for (int b = 0; b < a.nblk; ++b) {
     const C1Blk blk = a.blk[b];
     C1_STAMP(0);
+    {
+      const uint4* wp = blk.w2 + (size_t)q * 18 * 64 + lane;      // the second filter: L2 hits that land under the first sweep
+#pragma unroll
+      for (int t = 0; t < 18; ++t) F2[t] = as_bf16x8(gld16(wp + t * 64));
+    }
     unsigned MB[FORM == 3 ? 12 : 1];
     if (FORM == 3) {
 #pragma unroll
-      for (int k = 0; k < 12; ++k) MB[FORM == 3 ? k : 0] = blk.mbits[(moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3];
+      for (int k = 0; k < 12; ++k) MB[FORM == 3 ? k : 0] = gld8(blk.mbits + ((moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3));
     }
     f32x4 acc[8][3];                                     // T row j = image row 6sy - 1 + j
+    f32x4 acc2[6][3];                                    // OUT row r = image row 6sy + r
     {
       f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (blk.b1) { const float4 t = *reinterpret_cast<const float4*>(blk.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+      if (blk.b1) b4 = gldf4(blk.b1 + c0);
 #pragma unroll
       for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+      b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (blk.b2) b4 = gldf4(blk.b2 + c0);
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc2[r][c] = b4;
     }
-    // (a) the four T rows that need no halo row (input rows 2 .. 7 = the strip's own rows: block b - 1's OUT, complete behind the gate at its end)
-    sweep_at<4, 2, FMT>(*reinterpret_cast<f32x4(*)[4][3]>(&acc[2]), F, lds, offX);
-    C1_STAMP(1);
-    // ---- epilogue 1 of ONE pair of T tiles, T = post1(acc) -> the T image in LDS, cut into slices j = 0 .. 3 (k, j are constants after unrolling; the
-    // slices of a pair run in order, one pair at a time) ----
-    f32x4 etx, ety;
-    float ev[8];
-    auto e1_slice = [&](int k, int j) {
-      if (j == 0) {
-        etx = (k < 8) ? acc[k < 8 ? k : 0][0] : acc[2 * (k < 8 ? 0 : k - 8)][2];
+    // ---- epilogue 1 of one pair of T tiles: T = post1(acc) -> the T image in LDS (k is a constant after unrolling) ----
+    auto e1_pair = [&](int k) {
+      f32x4 tx = (k < 8) ? acc[k < 8 ? k : 0][0] : acc[2 * (k < 8 ? 0 : k - 8)][2];
+      f32x4 ty = (k < 8) ? acc[k < 8 ? k : 0][1] : acc[2 * (k < 8 ? 0 : k - 8) + 1][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) etx[i] = (FORM == 1) ? relu_f32(etx[i]) : etx[i] * blk.scale1;
-      } else if (j == 1) {
-        ety = (k < 8) ? acc[k < 8 ? k : 0][1] : acc[2 * (k < 8 ? 0 : k - 8) + 1][2];
+      for (int i = 0; i < 4; ++i) {
+        tx[i] = (FORM == 1) ? relu_f32(tx[i]) : tx[i] * blk.scale1;
+        ty[i] = (FORM == 1) ? relu_f32(ty[i]) : ty[i] * blk.scale1;
+      }
+      float v[8];
+      pair_up(tx, ty, g, v);
+      uint4 o = make_uint4(0, 0, 0, 0);                  // outside the image: convB's zero padding
+      if (moff[k] != 0xffffffffu) {
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+        o = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
+      }
+      *reinterpret_cast<uint4*>(lds + tcell[k]) = o;
+    };
+    // ---- epilogue 2 of one pair of OUT tiles: OUT = X + scale2 * acc2 [+ res2], in place over the input image's centre rows ----
+    auto e2_pair = [&](int k) {
+      const f32x4 tx = (k < 6) ? acc2[k < 6 ? k : 0][0] : acc2[2 * (k < 6 ? 0 : k - 6)][2];
+      const f32x4 ty = (k < 6) ? acc2[k < 6 ? k : 0][1] : acc2[2 * (k < 6 ? 0 : k - 6) + 1][2];
+      float v[8], m[8];
+      pair_up(tx, ty, g, v);
+      if (ooff[k] != 0xffffffffu) {
+        unsigned char* cell = lds + xcell[k];
+        unpack8<FMT>(*reinterpret_cast<const uint4*>(cell), m);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ety[i] = (FORM == 1) ? relu_f32(ety[i]) : ety[i] * blk.scale1;
-      } else if (j == 2) {
-        pair_up(etx, ety, g, ev);
-      } else if (j == 3) {
-        uint4 o = make_uint4(0, 0, 0, 0);                // outside the image: convB's zero padding
-        if (moff[k] != 0xffffffffu) {
-          const uint2 lo = pack4<FMT>(ev[0], ev[1], ev[2], ev[3]), hi = pack4<FMT>(ev[4], ev[5], ev[6], ev[7]);
-          o = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
+        if (blk.res2) {
+          unpack8<FMT>(gld16(blk.res2 + ooff[k]), m);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
-        *reinterpret_cast<uint4*>(lds + tcell[k]) = o;
+        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
+        *reinterpret_cast<uint4*>(cell) = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     };
-    auto e1_pairs = [&](const int (&ks)[3]) {
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) e1_slice(ks[i], j);
-    };
-    // the pairs of the four finished rows (2 .. 5 x column tiles 0 | 1: pairs 2 .. 5; rows 2 | 3 and 4 | 5 of column tile 2: pairs 9, 10)
-    const int ka0[3] = {2, 3, 4}, ka1[3] = {5, 9, 10};
+
+    // (1) T rows 2 .. 5: input rows 2 .. 7 = the strip's own rows (block b - 1's OUT, complete behind the gate at its end)
+    sweep_at<4, 2, FMT>(*reinterpret_cast<f32x4(*)[4][3]>(&acc[2]), F, lds, offX);
+    C1_STAMP(1);
     if (b > 0) {
-      // (b) publish block b - 1: this wave's OUT stores are acknowledged (under the sweep above) -> count in -> one lane stores the strip's flag
+      // (2) publish block b - 1: this wave's OUT stores are acknowledged (under the sweep above) -> count in -> one lane stores the strip's flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       gate_arrive(&gate[3], lane);
       if (q == 0) {
         gate_wait(&gate[3], 4u * (unsigned)b);
         if (lane == 0) __hip_atomic_store(my_flag, (epoch << 8) + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      C1_STAMP(2);
-      // C1_E1A = 2: the epilogue of the finished rows fills the two waits of the hand-off - the neighbours' flags travel while its first half runs,
-      // their rows while the second half does (one wave per SIMD: nobody else would use the time)
-      if (C1_E1A == 2) e1_pairs(ka0);
-      // (c) the neighbours' rows: poll their flags, fetch, write to the halo rows of the input image
+    }
+    C1_STAMP(2);
+    // (3) their epilogue: pairs 2 .. 5 (rows 2 .. 5 x column tiles 0 | 1), 9 and 10 (rows 2 | 3 and 4 | 5 of column tile 2)
+    e1_pair(2); e1_pair(3); e1_pair(4); e1_pair(5); e1_pair(9); e1_pair(10);
+    gate_arrive(&gate[4], lane);
+    C1_STAMP(3);
+    uint4 Hr[2 * C1_HREGS];
+    if (b > 0) {
+      // (4) the neighbours' flags (published a sweep and an epilogue ago if the strips run in step), then their rows: requested here, used behind (5) and (6)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if ((s == 0) ? has_top : has_bot) {
@@ -342,51 +403,36 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
           }
         }
       }
-      C1_STAMP(3);
-      uint4 Hr[2 * C1_HREGS];
+      // (agent-scope atomic loads = global_load ... sc1 that the COMPILER tracks: the rows are used two phases later, and an inline-asm load's
+      // destination registers look ready to the register allocator - it moved them to AGPRs before the data had arrived, found the hard way)
 #pragma unroll
-      for (int i = 0; i < 2 * C1_HREGS; ++i) Hr[i] = ch_load16_sc1(blk.x + (hoff[i] != 0xffffffffu ? hoff[i] : 0u));
-      if (C1_E1A == 2) e1_pairs(ka1);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int i = 0; i < 2 * C1_HREGS; ++i) Hr[i] = gld16_agent(blk.x + (hoff[i] != 0xffffffffu ? hoff[i] : 0u));
+    }
+    C1_STAMP(4);
+    // (5) OUT rows 2, 3 from T rows 2 .. 5 (every wave's channels of them: the gate also says that nobody sweeps over input rows 4, 5 any more)
+    gate_wait(&gate[4], 4u * (unsigned)(b + 1));
+    sweep_at<2, 2, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[2]), F2, lds, offT);
+    C1_STAMP(5);
+    // (6) their epilogue: pairs 2, 3 (rows 2, 3 x column tiles 0 | 1) and 7 (rows 2 | 3 of column tile 2) - in place over input rows 4, 5, which the halo
+    // sweeps do not read
+    e2_pair(2); e2_pair(3); e2_pair(7);
+    C1_STAMP(6);
+    if (b > 0) {
 #pragma unroll
       for (int i = 0; i < 2 * C1_HREGS; ++i)
         if (hoff[i] != 0xffffffffu) *reinterpret_cast<uint4*>(lds + hlds[i]) = Hr[i];
       gate_arrive(&gate[1], lane);
       gate_wait(&gate[1], 4u * (unsigned)b);
-      C1_STAMP(4);
-    } else if (C1_E1A == 2) {
-      e1_pairs(ka0);
-      e1_pairs(ka1);
     }
-    // (d) the four T rows that need the halo rows: rows 0, 1 (input rows 0 .. 3) and 6, 7 (input rows 6 .. 9)
-    auto e1a_d0 = [&](int grp) { if (C1_E1A == 1) e1_slice(ka0[grp / 6], grp % 6); };     // C1_E1A = 1: ... under these sweeps' MFMAs, one pair per six groups
-    auto e1a_d1 = [&](int grp) { if (C1_E1A == 1) e1_slice(ka1[grp / 6], grp % 6); };
-    if (C1_MERGE_D) {
-      sweep_two<0, 6, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), *reinterpret_cast<f32x4(*)[2][3]>(&acc[6]), F, lds, offX);
-      if (C1_E1A == 1) { e1_pairs(ka0); e1_pairs(ka1); }
-    } else {
-      sweep_at<2, 0, FMT, decltype(e1a_d0), (C1_E1A == 1 ? C1_HV : 0)>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), F, lds, offX, e1a_d0);
-      sweep_at<2, 6, FMT, decltype(e1a_d1), (C1_E1A == 1 ? C1_HV : 0)>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[6]), F, lds, offX, e1a_d1);
-    }
-    if (C1_E1A == 0) { e1_pairs(ka0); e1_pairs(ka1); }
-    C1_STAMP(5);
-    // second filter: L2 hits that land under the epilogue
-    {
-      const uint4* wp = blk.w2 + (size_t)q * 18 * 64 + lane;
-#pragma unroll
-      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
-    }
-    // ---- the rest of epilogue 1: T rows 0, 1, 6, 7 ----
-    {
-      const int kb0[3] = {0, 1, 8}, kb1[3] = {6, 7, 11};
-      e1_pairs(kb0);
-      e1_pairs(kb1);
-    }
-    C1_STAMP(6);
-    gate_arrive(&gate[2], lane);
-    gate_wait(&gate[2], 4u * (unsigned)(b + 1));
     C1_STAMP(7);
-    // the strip's own rows of T (+ mask bytes) -> HBM from the LDS image: whole lines, non-temporal, one piece after every second group of the second sweep
+    // (7) the four T rows that need the halo rows: rows 0, 1 (input rows 0 .. 3) and 6, 7 (input rows 6 .. 9), and their epilogue
+    sweep_two<0, 6, FMT>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[0]), *reinterpret_cast<f32x4(*)[2][3]>(&acc[6]), F, lds, offX);
+    C1_STAMP(8);
+    e1_pair(0); e1_pair(1); e1_pair(8); e1_pair(6); e1_pair(7); e1_pair(11);
+    gate_arrive(&gate[2], lane);
+    gate_wait(&gate[2], 4u * (unsigned)(b + 1));         // the T image is complete - and nobody sweeps over the input image any more
+    C1_STAMP(9);
+    // the strip's own rows of T (+ mask bytes) -> HBM from the LDS image: whole lines, non-temporal, one piece after every second group of the sweep below
     uint4 S[C1_SREGS];
     const bool t_out = blk.t != nullptr;
     if (t_out) {
@@ -397,49 +443,21 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
       if (grp % 2 == 0 && grp / 2 < C1_SREGS) {
         const int i = grp / 2 < C1_SREGS ? grp / 2 : 0;
         if (t_out && soff[i] != 0xffffffffu) {
-          st16_nt(blk.t + soff[i], S[i]);
-          if (FORM == 1 && blk.mbits) blk.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+          gst16_nt(blk.t + soff[i], S[i]);
+          if (FORM == 1 && blk.mbits) gst8(blk.mbits + (soff[i] >> 3), relu_bits(S[i]));
         }
       }
     };
-    // ---- phase 2: OUT = X + scale2 * (convB(T) + b2) [+ res2], in place over the input image's centre rows ----
-    f32x4 acc2[6][3];
-    {
-      f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (blk.b2) { const float4 t = *reinterpret_cast<const float4*>(blk.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc2[r][c] = b4;
-    }
-    sweep_at<6, 0, FMT, decltype(t_store)>(acc2, F, lds, offT, t_store);
-    C1_STAMP(8);
-    if (b + 1 < a.nblk) {                                // the next block's first filter lands under the epilogue and the halo step
+    // (8) OUT rows 0, 1 (T rows 0 .. 3) and 4, 5 (T rows 4 .. 7)
+    sweep_two<0, 4, FMT, decltype(t_store)>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[0]), *reinterpret_cast<f32x4(*)[2][3]>(&acc2[4]), F2, lds, offT, t_store);
+    C1_STAMP(10);
+    if (b + 1 < a.nblk) {                                // the next block's first filter lands under the epilogue
       const uint4* wp = a.blk[b + 1].w1 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(gld16(wp + t * 64));
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const f32x4 tx = (k < 6) ? acc2[k < 6 ? k : 0][0] : acc2[2 * (k < 6 ? 0 : k - 6)][2];
-      const f32x4 ty = (k < 6) ? acc2[k < 6 ? k : 0][1] : acc2[2 * (k < 6 ? 0 : k - 6) + 1][2];
-      float v[8], m[8];
-      pair_up(tx, ty, g, v);
-      if (ooff[k] != 0xffffffffu) {
-        unsigned char* cell = lds + xcell[k];
-        unpack8<FMT>(*reinterpret_cast<const uint4*>(cell), m);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
-        if (blk.res2) {
-          unpack8<FMT>(*reinterpret_cast<const uint4*>(blk.res2 + ooff[k]), m);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += m[j];
-        }
-        const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
-        *reinterpret_cast<uint4*>(cell) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-      }
-    }
-    C1_STAMP(9);
+    e2_pair(0); e2_pair(1); e2_pair(6); e2_pair(4); e2_pair(5); e2_pair(8);
+    C1_STAMP(11);
     gate_arrive(&gate[0], lane);
     gate_wait(&gate[0], 4u * (unsigned)(b + 1));
     // the strip's 6 OUT rows -> HBM: whole lines, write-through (the neighbours read rows 0, 1 / 4, 5 back)
@@ -448,7 +466,7 @@ __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
 #pragma unroll
     for (int i = 0; i < C1_SREGS; ++i)
       if (soff[i] != 0xffffffffu) ch_store16_sc1(blk.out + soff[i], S[i]);
-    C1_STAMP(10);
+    C1_STAMP(12);
   }
 }
 

@@ -58,8 +58,17 @@ for backward in (0, 1):
         if ref is None:
             ref = cur
         else:
-            bad = sum(0 if torch.equal(p.view(torch.int16), q.view(torch.int16)) else 1 for p, q in zip(ref, cur))
+            diff = [i for i, (p, q) in enumerate(zip(ref, cur)) if not torch.equal(p.view(torch.int16), q.view(torch.int16))]
+            bad = len(diff)
             print('%s %s: %d of %d buffers differ from the per-block launches; status 0x%x' % ('backward' if backward else 'forward', form, bad, len(cur), int(status.item())), flush=True)
+            if diff and os.environ.get('C1_DEBUG'):
+                for i in diff[:4]:
+                    d = (ref[i].view(torch.int16) != cur[i].view(torch.int16))
+                    rows = d.any(dim=3).any(dim=2).any(dim=0).nonzero().flatten().tolist()      # image rows with a difference
+                    cols = d.any(dim=3).any(dim=1).any(dim=0).nonzero().flatten().tolist()
+                    chans = d.any(dim=2).any(dim=1).any(dim=0).nonzero().flatten().tolist()
+                    imgs = d.any(dim=3).any(dim=2).any(dim=1).nonzero().flatten().tolist()
+                    print('   %s[%d]: rows %s cols %s channels %s images %s' % ('t' if i < nblk else 'y', i % nblk, rows, cols[:6] + ['..'] + cols[-3:], chans[:6] + ['..'] + chans[-3:], imgs[:8]), flush=True)
     times = {f: [] for f in forms}
     for rnd_ in range(3):
         for form in forms:
@@ -80,15 +89,21 @@ for backward in (0, 1):
         fn = getattr(ctypes.CDLL(L.LIB_PATH), 'rumpy_debug_c1_stamps')
         fn.argtypes = [ctypes.c_void_p]
         nwg = N * ((H + 5) // 6)
-        buf = torch.zeros(nwg * 4 * 16, dtype=torch.int64, device=DEV)
+        buf = torch.zeros(2 * nwg * 4 * 16, dtype=torch.int64, device=DEV)
         assert fn(buf.data_ptr()) == 0
         run('rumpy_res_chain1')
         torch.cuda.synchronize()
-        raw = buf.cpu().numpy().reshape(nwg, 4, 16).astype(np.float64)
-        names = ['block start', 'sweep a (T rows 2-5)', 'published', 'neighbours seen', 'halo rows in', 'sweep d (T rows 0,1,6,7)', 'epilogue 1', 'T gate', 'sweep 2 (6 rows)',
-                 'epilogue 2', 'OUT gate + stores']
-        rel = (raw[:, :, 1:11] - raw[:, :, 0:10]) * 0.01
+        both = buf.cpu().numpy().reshape(2, nwg, 4, 16).astype(np.float64)
+        raw, cyc = both[0], both[1]
+        names = ['block start', '(1) sweep T rows 2-5', '(2) acks + publish', '(3) epilogue of T rows 2-5', '(4) flags seen, rows requested', '(5) sweep OUT rows 2,3',
+                 '(6) epilogue of OUT rows 2,3', 'halo rows in LDS + gate', '(7) sweep T rows 0,1,6,7', 'epilogue of them + T gate', '(8) sweep OUT rows 0,1,4,5', 'epilogue of them',
+                 'OUT gate + stores']
+        nst = len(names) - 1
+        rel = (raw[:, :, 1:nst + 1] - raw[:, :, 0:nst]) * 0.01
         print('   phase durations in the middle block, us (mean over all waves | max):')
-        for k in range(10):
-            print('   %-28s %6.2f | %6.2f' % (names[k + 1], rel[:, :, k].mean(), rel[:, :, k].max()))
-        print('   %-28s %6.2f' % ('block (start -> stores issued)', ((raw[:, :, 10] - raw[:, :, 0]) * 0.01).mean()))
+        crel = cyc[:, :, 1:nst + 1] - cyc[:, :, 0:nst]
+        for k in range(nst):
+            print('   %-34s %6.2f | %6.2f   %7.0f shader cycles' % (names[k + 1], rel[:, :, k].mean(), rel[:, :, k].max(), crel[:, :, k].mean()))
+        tot_us, tot_cyc = ((raw[:, :, nst] - raw[:, :, 0]) * 0.01).mean(), (cyc[:, :, nst] - cyc[:, :, 0]).mean()
+        print('   shader clock over the block: %.0f cycles / %.2f us = %.2f GHz' % (tot_cyc, tot_us, tot_cyc / tot_us / 1e3))
+        print('   %-28s %6.2f' % ('block (start -> stores issued)', ((raw[:, :, nst] - raw[:, :, 0]) * 0.01).mean()))
