@@ -600,7 +600,7 @@ def main():
         plan = hipnet.engine.plan_for(N, P, P, True)
         ops = plan.fwd + plan.bwd
         blocks = [a for name, a in ops if name == 'rumpy_conv_block']
-        chains = [a for name, a in ops if name in ('rumpy_res_chain', 'rumpy_res_chain1')]      # runs of residual blocks as one persistent launch (conv_chain.hip); probe id 5 too
+        chains = [a for name, a in ops if name == 'rumpy_res_chain']      # runs of residual blocks as one persistent launch (conv_chain.hip); probe id 5 too
         rcabs = [a for name, a in ops if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd', 'rumpy_rcab2_fwd', 'rumpy_rcab2_bwd')]      # share probe id 5 with the block kernel
         rcab2 = any(name == 'rumpy_rcab2_fwd' for name, _ in ops)
         use_block = len(blocks) + len(rcabs) + len(chains) > 0

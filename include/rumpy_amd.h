@@ -245,10 +245,6 @@ typedef struct {
 } rumpy_res_chain_args;
 int rumpy_res_chain(const rumpy_res_chain_args* a, void* stream);
 int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H);
-/* ABI 6 (round 6): the same chain with ONE wave per SIMD (conv_chain1.hip: 256-thread workgroups, 512 registers per wave, every per-lane address computed once in
- * front of the block loop, four- and six-row sweeps).  Same arguments, work buffer and results (bitwise); hand-offs always through the memory side (force_sc1 is
- * ignored); edge_w must be NULL. */
-int rumpy_res_chain1(const rumpy_res_chain_args* a, void* stream);
 int rumpy_device_xcds(void);   /* accelerator dies (XCDs, each with its own L2) of the current device: 8 on MI355X */
 
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----

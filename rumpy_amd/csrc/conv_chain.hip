@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = wave & 3, rh = wave >> 2;
   // ---- which strip this workgroup runs: CLAIMED, per XCD (top of this file; chain_common.hpp) ----
-  __shared__ int claim[3];
+  __shared__ int claim[4];
   const ChainPlace place = chain_claim(a.work, a.N, a.sy_n, a.nxcd, a.fake_xcc, claim);
   const unsigned epoch = place.epoch;
   const int strip = place.strip;
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       const int y = y0 + lr, x = lc - 1;
       const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
-      uint4 v = *reinterpret_cast<const uint4*>(src0 + (unsigned)e);
+      uint4 v = ch_gld16(src0 + (unsigned)e);
       R[i] = keep_if(v, ok);
     }
     if (tid < 10) gate[tid] = 0u;
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   {
     const uint4* wp = (pre ? a.edge_w : b0.w1) + (size_t)q * 18 * 64 + lane0;
 #pragma unroll
-    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+    for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(ch_gld16(wp + t * 64));
   }
   __syncthreads();
 
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       if (y < a.H && xx < a.W) {
         if (res) {
           float m[8];
-          unpack8<FMT>(*reinterpret_cast<const uint4*>(res + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair)), m);
+          unpack8<FMT>(ch_gld16(res + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair)), m);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
         float v[4] = {acc3[2][2][0], acc3[2][2][1], acc3[2][2][2], acc3[2][2][3]};
         if (res) {
           float m[4];
-          unpack4<FMT>(*reinterpret_cast<const uint2*>(res + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0)), m);
+          unpack4<FMT>(ch_gld8b(res + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0)), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     {
       const uint4* wp = b0.w1 + (size_t)q * 18 * 64 + lane0;      // block 0's first filter, under the epilogue
 #pragma unroll
-      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(ch_gld16(wp + t * 64));
     }
     edge_rows_to_t(acc3, nullptr);
     gate_arrive(&gate[8 + rh], lane);
@@ -218,12 +218,12 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     unsigned MB[FORM == 3 ? 6 : 1];
     if (FORM == 3) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) MB[FORM == 3 ? k : 0] = blk.mbits[(moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3];
+      for (int k = 0; k < 6; ++k) MB[FORM == 3 ? k : 0] = ch_gld8(blk.mbits + ((moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3));
     }
     f32x4 acc[4][3];                                     // wave row jr (T row 4rh + jr)
     {
       f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (blk.b1) { const float4 t = *reinterpret_cast<const float4*>(blk.b1 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+      if (blk.b1) b4 = ch_gldf4(blk.b1 + c0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -252,6 +252,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       gate_arrive(&gate[6 + rh], lane);
       if (q == 0) {
         gate_wait(&gate[6 + rh], done);
+        if (place.stall && b == 1) ch_stall();           // (test hook, chain_common.hpp::CH_W_STALL)
         if (lane == 0) { if (local) ch_store_flag_sc0(flags + (2 * strip + rh) * CH_FLAG_STRIDE, (epoch << 8) + (unsigned)b); else __hip_atomic_store(flags + (2 * strip + rh) * CH_FLAG_STRIDE, (epoch << 8) + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       }
       // (c) the neighbour's two rows: poll its flag, fetch, write to the halo rows of the input image
@@ -289,7 +290,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     {
       const uint4* wp = blk.w2 + (size_t)q * 18 * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(ch_gld16(wp + t * 64));
     }
     // ---- epilogue 1 (conv_block.hip): pairs k < 4: (row k, col tile 0 | 1); k = 4: rows 0 | 1 of col tile 2; k = 5: rows 2 | 3 ----
 #pragma unroll
@@ -326,8 +327,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
         const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
         if (t_out && soff[i] != 0xffffffffu) {
-          st16_nt(blk.t + soff[i], S[i]);
-          if (FORM == 1 && blk.mbits) blk.mbits[soff[i] >> 3] = (unsigned char)relu_bits(S[i]);
+          ch_gst16_nt(blk.t + soff[i], S[i]);
+          if (FORM == 1 && blk.mbits) ch_gst8(blk.mbits + (soff[i] >> 3), relu_bits(S[i]));
         }
       }
     };
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     f32x4 acc2[3][3];
     {
       f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (blk.b2) { const float4 t = *reinterpret_cast<const float4*>(blk.b2 + c0); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+      if (blk.b2) b4 = ch_gldf4(blk.b2 + c0);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -355,7 +356,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     if (b + 1 < a.nblk || post) {                        // the next block's first filter (or the edge conv's) lands under the epilogue and the halo step
       const uint4* wp = (b + 1 < a.nblk ? a.blk[b + 1].w1 : a.edge_w) + (size_t)q * 18 * 64 + lane;
 #pragma unroll
-      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(wp[t * 64]);
+      for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(ch_gld16(wp + t * 64));
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
         if (blk.res2) {
-          unpack8<FMT>(*reinterpret_cast<const uint4*>(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair)), m);
+          unpack8<FMT>(ch_gld16(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair)), m);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += m[j];
         }
@@ -389,7 +390,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
         if (blk.res2) {
-          unpack4<FMT>(*reinterpret_cast<const uint2*>(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0)), m);
+          unpack4<FMT>(ch_gld8b(blk.res2 + (unsigned)(((n * a.H + y) * a.W + xx) * 64 + c0)), m);
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += m[j];
         }
@@ -417,7 +418,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     f32x4 acc3[3][3];
     {
       f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (a.edge_b) { const float4 t = *reinterpret_cast<const float4*>(a.edge_b + 16 * q + 4 * g); b4 = (f32x4){t.x, t.y, t.z, t.w}; }
+      if (a.edge_b) b4 = ch_gldf4(a.edge_b + 16 * q + 4 * g);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
 #pragma unroll
     for (int i = 0; i < GROUP_REGS; ++i) {
       const unsigned so = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
-      if (so != 0xffffffffu) st16_nt(a.edge_out + so, S[i]);
+      if (so != 0xffffffffu) ch_gst16_nt(a.edge_out + so, S[i]);
     }
   }
 }

@@ -163,11 +163,6 @@ class SREngine:
         # runs of consecutive residual-block launches as ONE persistent launch with the halo rows handed over through the XCD's L2 (conv_chain.hip, round 5;
         # bitwise the per-block launches; needs every strip co-resident: N * ceil(H/6) <= CUs, W <= 48); RUMPY_NO_CHAIN=1: one launch per block (A/B)
         self.use_chain = os.environ.get('RUMPY_NO_CHAIN') != '1'
-        # which kernel runs a chain (round 6): '2' = conv_chain.hip (512-thread workgroups, two waves per SIMD = the two row halves of a strip), '1' = conv_chain1.hip
-        # (256-thread workgroups, one wave per SIMD with 512 registers: lane geometry hoisted out of the block loop, taller sweeps; no edge conv inside)
-        self.chain_form = os.environ.get('RUMPY_CHAIN_FORM', '2')
-        if self.chain_form not in ('1', '2'):
-            raise RuntimeError("rumpy_amd: RUMPY_CHAIN_FORM is '1' or '2' (got %r)" % self.chain_form)
         # the tail conv's data gradient inside the last upsampler stage's data-gradient launch (rumpy_conv4d_tail; RUMPY_NO_TAIL_FUSE=1: two launches, A/B)
         self.fuse_tail_dgrad = os.environ.get('RUMPY_NO_TAIL_FUSE') != '1'
         self.chain_edge = os.environ.get('RUMPY_NO_CHAIN_EDGE') != '1'     # the body-end conv (and its data gradient) inside the chain launch; =1: its own launch (A/B)
@@ -985,14 +980,14 @@ class SREngine:
                 args = L.ResChainArgs(blocks=_ptr(dev), nblocks=len(blocks), N=N, H=H, W=W, backward=backward, fmt=blocks[0].fmt, work=_ptr(plan.chain_work),
                                       work_bytes=plan.chain_work.numel(), status=_ptr(plan.flags[1:2]), fake_xcc=0, force_sc1=1 if self.chain_force_sc1 else 0)
                 args._blocks_host = tab            # (kept alive with the argument block)
-                ops[i:j] = [('rumpy_res_chain1' if self.chain_form == '1' else 'rumpy_res_chain', args)]
+                ops[i:j] = [('rumpy_res_chain', args)]
                 j = i + 1
                 # the single conv at the run's outer end - EDSR's body-end conv behind the last block, its data gradient in front of the first - joins
                 # the launch (rumpy_res_chain_args.edge_*; bitwise the separate launch)
                 def plain_conv(c):
                     return (c.cin_chunks == 1 and c.cout_tiles == 1 and c.in_mode == 0 and c.out_mode == 0 and not c.relu and c.scale == 1.0 and not c.mask
                             and not c.pool and not c.res2 and not c.w_lo and c.N == N and c.H == H and c.W == W and c.fmt == args.fmt)
-                if self.chain_edge and len(blocks) <= 254 and self.chain_form != '1':
+                if self.chain_edge and len(blocks) <= 254:
                     if not backward and j < len(ops) and ops[j][0] == 'rumpy_conv3x3' and plain_conv(ops[j][1]) and ops[j][1].x == blocks[-1].out:
                         c = ops[j][1]
                         args.edge_w, args.edge_b, args.edge_res, args.edge_out = c.w, c.bias, c.res1, c.out
@@ -1294,7 +1289,7 @@ class SREngine:
         rumpy_rcab_fwd / _bwd)"""
         kinds = set()
         for name, _ in list(plan.fwd) + list(getattr(plan, 'bwd', None) or []):
-            if name in ('rumpy_res_chain', 'rumpy_res_chain1'):
+            if name == 'rumpy_res_chain':
                 kinds.add('chain')
             if name in ('rumpy_rcab_fwd', 'rumpy_rcab_bwd'):
                 kinds.add('xchg')

@@ -75,6 +75,7 @@ def exp_lib():
                                 ('rumpy_body_chain', C.c_int, [C.POINTER(BodyChainArgs), C.c_void_p]),
                                 ('rumpy_body_chain_flag_bytes', C.c_int64, [C.c_int32, C.c_int32]),
                                 ('rumpy_conv_block_split', C.c_int, [C.POINTER(BlockSplitArgs), C.c_void_p]),
+                                ('rumpy_res_chain1', C.c_int, [C.POINTER(L.ResChainArgs), C.c_void_p]),
                                 ('rumpy_rcab_chain', C.c_int, [C.POINTER(RcabChainArgs), C.c_void_p]), ('rumpy_rcab_chain_work_bytes', C.c_int64, [C.c_int32, C.c_int32]),
                                 ('rumpy_last_error', C.c_char_p, [])):
             fn = getattr(h, name)

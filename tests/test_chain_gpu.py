@@ -17,7 +17,7 @@ from tests.test_network_gpu import _handler, _pair
 pytestmark = pytest.mark.gpu
 
 
-def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False, edge=False, entry='rumpy_res_chain'):
+def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False, edge=False, entry='rumpy_res_chain', call=L.call):
     """edge: with the single conv at the chain's outer end (rumpy_res_chain_args.edge_*) - forward: rumpy_conv3x3 (+ bias + residual) behind the last block;
     backward: rumpy_conv3x3 with the data-gradient filter in front of the first, whose output tensor the chain launch then WRITES"""
     gen = np.random.default_rng(seed)
@@ -76,8 +76,8 @@ def _chain_case(N, H, W, nblk, backward, fmt, hooks, seed, disturb=False, edge=F
             side = torch.cuda.Stream()
             for rep in range(3):           # (launch epochs: the same work buffer serves launch after launch)
                 if disturb:
-                    L.check(L.lib().rumpy_debug_occupy(48, 20000.0, side.cuda_stream), 'occupy')
-                L.call(entry, a, stream())
+                    L.check(L.lib().rumpy_debug_occupy(160, 20000.0, side.cuda_stream), 'occupy')
+                call(entry, a, stream())
             torch.cuda.synchronize()
             assert int(status.item()) == 0
         torch.cuda.synchronize()
@@ -106,22 +106,10 @@ def test_chain_with_the_conv_at_its_outer_end_is_bitwise_the_separate_launches(N
     _chain_case(N, H, W, nblk, backward, fmt, hooks, 940 + N + H, edge=True)
 
 
-# ---- round 6: the same chain with ONE wave per SIMD (conv_chain1.hip, rumpy_res_chain1): same cases, same bitwise bar ----
-@pytest.mark.parametrize('hooks', [dict(fake_xcc=0, force_sc1=0), dict(fake_xcc=3, force_sc1=1), dict(fake_xcc=16, force_sc1=1)])
-@pytest.mark.parametrize('N,H,W,nblk,backward,fmt', [(32, 48, 48, 6, 0, 0), (32, 48, 48, 6, 1, 0), (5, 20, 37, 3, 0, 0), (5, 20, 37, 3, 1, 0), (3, 13, 48, 4, 0, 1),
-                                                     (1, 5, 9, 2, 0, 0), (7, 31, 24, 5, 1, 0), (2, 6, 16, 2, 0, 0), (2, 6, 16, 2, 1, 0), (42, 36, 48, 16, 0, 0)])
-def test_one_wave_per_simd_chain_is_bitwise_the_per_block_launches(N, H, W, nblk, backward, fmt, hooks):
-    _chain_case(N, H, W, nblk, backward, fmt, hooks, 1900 + N + H, entry='rumpy_res_chain1')
-
-
-@pytest.mark.parametrize('backward', [0, 1])
-def test_one_wave_per_simd_chain_next_to_a_foreign_kernel_that_holds_cus(backward):
-    _chain_case(32, 48, 48, 8, backward, 0, dict(fake_xcc=0, force_sc1=0), 78, disturb=True, entry='rumpy_res_chain1')
-
-
 @pytest.mark.parametrize('backward', [0, 1])
 def test_chain_next_to_a_foreign_kernel_that_holds_cus(backward):
-    """256 strips on 256 CUs while another queue holds 24-48 of them (rumpy_debug_occupy, 48 workgroups x 80 KiB of LDS, 20 ms at a time): the
+    """256 strips on 256 CUs while another queue holds part of the chip (rumpy_debug_occupy, 160 workgroups x 80 KiB of LDS, 20 ms at a time - round 6: the 48
+    workgroups of round 5 disturbed nothing, tests/tools/watchdog_probe.py; 160 leave chain workgroups without a CU for up to 20 ms, far below the watchdog): the
     chain's workgroups arrive late and on whatever XCD has room - strips are claimed, oversubscribed XCDs hand their surplus to others (memory-side
     hand-off there), nothing may time out and every buffer must equal the per-block launches'."""
     _chain_case(32, 48, 48, 8, backward, 0, dict(fake_xcc=0, force_sc1=0), 77, disturb=True)
@@ -139,7 +127,7 @@ def test_chain_refuses_what_it_cannot_run():
     assert L.lib().rumpy_device_xcds() == 8
 
 
-@pytest.mark.parametrize('mode', ['local', 'sc1', 'form1'])
+@pytest.mark.parametrize('mode', ['local', 'sc1'])
 def test_edsr_training_and_evaluation_on_the_chain_equal_the_per_block_launches(mode, monkeypatch):
     """EDSR x4, 6 blocks, three training steps at 32 x 48 x 48 and an evaluation image: with the chain (forward + data gradient, one launch each) and with
     RUMPY_NO_CHAIN=1 - losses, outputs, weights and the evaluation image bit for bit; the plans really differ."""
@@ -148,7 +136,6 @@ def test_edsr_training_and_evaluation_on_the_chain_equal_the_per_block_launches(
     for no_chain in ('0', '1'):
         monkeypatch.setenv('RUMPY_NO_CHAIN', no_chain)
         monkeypatch.setenv('RUMPY_CHAIN_SC1', '1' if mode == 'sc1' else '0')
-        monkeypatch.setenv('RUMPY_CHAIN_FORM', '1' if mode == 'form1' else '2')      # (form1: conv_chain1.hip, one wave per SIMD; the body-end conv stays a launch of its own)
         h, _ = _pair('edsr', 511, sched=False, **kw)
         losses = []
         for step in range(3):
@@ -161,9 +148,8 @@ def test_edsr_training_and_evaluation_on_the_chain_equal_the_per_block_launches(
         tp, ep = eng.plan_for(32, 48, 48, True), eng.plan_for(1, 40, 44, False, eng.eval_fmt)
         for ops in (tp.fwd, tp.bwd, ep.fwd):
             names = [op for op, _ in ops]
-            cname = 'rumpy_res_chain1' if mode == 'form1' else 'rumpy_res_chain'
-            assert (names.count(cname) == 1 and 'rumpy_conv_block' not in names) == (no_chain == '0'), names
-            if no_chain == '0' and mode != 'form1':      # ... and the body-end conv (its data gradient) rides in the chain launch
+            assert (names.count('rumpy_res_chain') == 1 and 'rumpy_conv_block' not in names) == (no_chain == '0'), names
+            if no_chain == '0':      # ... and the body-end conv (its data gradient) rides in the chain launch
                 assert all(bool(a.edge_w) for op, a in ops if op == 'rumpy_res_chain')
         assert eng.exchange_status() == 0
         res.append((losses, out.clone(), ev.clone(), h.net.flat_p.detach().cpu().clone()))
@@ -215,14 +201,14 @@ def test_chain_is_deterministic_at_the_headline_shape():
 
 
 # ---- round 6: a hand-off that times out.  The chain needs all 256 strips co-resident; a foreign kernel that holds CUs for longer than the
-# watchdog (0.5 s, chain_common.hpp::CH_TIMEOUT) breaks that.  What must happen: the launch gives up within milliseconds of the first time-out, the optimizer launch of the
+# watchdog (0.5 s, chain_common.hpp::CH_TIMEOUT) breaks that; the tests provoke the same time-out through the work buffer's test hook (_stall_strip_zero).  What must happen: the launch gives up within milliseconds of the first time-out, the optimizer launch of the
 # step reads the status word on the device and changes NOTHING, the host warns, switches the engine to one launch per block and training goes on.
-def _occupy(seconds):
-    side = torch.cuda.Stream()
-    L.check(L.lib().rumpy_debug_occupy(48, seconds * 1e6, side.cuda_stream), 'occupy')
-    import time
-    time.sleep(0.05)                   # (the occupier is on the chip before the step is queued)
-    return side
+def _stall_strip_zero(plan, on=True):
+    """the test hook of the chain's work buffer (chain_common.hpp::CH_W_STALL): the workgroup of strip 0 publishes its first hand-off 0.7 s late - its neighbour's
+    poll runs into the watchdog (CH_TIMEOUT = 0.5 s).  Deterministic; a foreign kernel that takes CUs breaks the co-residency only when the dispatcher places it
+    just so (tests/tools/watchdog_probe.py: up to 96 workgroups of 80 KiB LDS disturb nothing, 160 sometimes, 256 keep the whole launch waiting)."""
+    plan.chain_work.view(torch.int32)[2] = 1 if on else 0
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize('generic', [False, True])
@@ -240,14 +226,13 @@ def test_a_chain_hand_off_that_times_out_skips_the_step_and_falls_back_to_per_bl
     assert eng.use_chain and 'rumpy_res_chain' in [op for op, _ in eng.plan_for(32, 48, 48, True).fwd]
     before = h.net.flat_p.detach().clone()
     m_before = h.optimizer.flat_m.detach().clone()
-    side = _occupy(2.0)
+    _stall_strip_zero(eng.plan_for(32, 48, 48, True))
     with pytest.warns(RuntimeWarning, match='one launch per block'):
         h.run_train(x=x, y=y)
     torch.cuda.synchronize()
     assert torch.equal(before.view(torch.int32), h.net.flat_p.view(torch.int32)), 'the step whose hand-off timed out reached the weights'
     assert torch.equal(m_before.view(torch.int32), h.optimizer.flat_m.view(torch.int32))
     assert not eng.use_chain
-    side.synchronize()
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter('error')
@@ -276,11 +261,10 @@ def test_strict_watchdog_raises_with_the_right_switch_named(monkeypatch):
     x, y = O.synthetic_batch(761, 32, lr_hw=48, scale=2)
     h.run_train(x=x, y=y)
     before = h.net.flat_p.detach().clone()
-    side = _occupy(2.0)
+    _stall_strip_zero(h.net.engine.plan_for(32, 48, 48, True))
     with pytest.raises(RuntimeError, match='RUMPY_NO_CHAIN=1'):
         h.run_train(x=x, y=y)
     torch.cuda.synchronize()
-    side.synchronize()
     assert torch.equal(before.view(torch.int32), h.net.flat_p.view(torch.int32))
 
 
@@ -290,8 +274,7 @@ def test_an_evaluation_pass_whose_chain_timed_out_is_run_again_with_per_block_la
     x, _ = O.synthetic_batch(762, 32, lr_hw=48, scale=2)
     good, _, _ = h.run_eval(x=x)
     assert 'rumpy_res_chain' in [op for op, _ in h.net.engine.plan_for(32, 48, 48, False, h.net.engine.eval_fmt).fwd]
-    side = _occupy(2.0)
+    _stall_strip_zero(h.net.engine.plan_for(32, 48, 48, False, h.net.engine.eval_fmt))
     with pytest.warns(RuntimeWarning, match='run again'):
         again, _, _ = h.run_eval(x=x)
-    side.synchronize()
     assert torch.equal(good, again) and not h.net.engine.use_chain

@@ -1,7 +1,8 @@
 """Isolated time of a run of residual blocks (32 x 48 x 48, training forms) per launch form: one launch per block, the persistent chain with two waves per
 SIMD (rumpy_res_chain, conv_chain.hip) and with one wave per SIMD (rumpy_res_chain1, conv_chain1.hip) - alternating, same buffers, HIP events.
 
-  python tests/tools/chain_forms_time.py [nblk] [N] [reps]       (RUMPY_AMD_LIB selects another build of the library: stamps / ablations)"""
+  python tests/tools/chain_forms_time.py [nblk] [N] [reps]       (conv_chain1.hip lives in the experimental library: make -C tests/tools/csrc EXTRA=-DC1_STAMPS clean all builds its stamps form, C1_STAMPS=1 prints them;
+   RUMPY_EXP_LIB selects another build)"""
 import os
 import sys
 
@@ -11,7 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
-from gpu_utils import BF16, DEV, PackedConv, stream, to_dev_bytes  # noqa: E402
+from gpu_utils import BF16, DEV, PackedConv, exp_call, exp_lib, stream, to_dev_bytes  # noqa: E402
 from rumpy_amd import _lib as L  # noqa: E402
 
 nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -49,7 +50,7 @@ for backward in (0, 1):
             for ba in blocks:
                 L.call('rumpy_conv_block', ba, stream())
         else:
-            L.call(form, a, stream())
+            (exp_call if form == 'rumpy_res_chain1' else L.call)(form, a, stream())
     ref = None
     for form in forms:
         run(form)
@@ -86,7 +87,7 @@ for backward in (0, 1):
                                                                          min(times[form]) / nblk), flush=True)
     if os.environ.get('C1_STAMPS'):
         import ctypes
-        fn = getattr(ctypes.CDLL(L.LIB_PATH), 'rumpy_debug_c1_stamps')
+        fn = getattr(exp_lib(), 'rumpy_debug_c1_stamps')
         fn.argtypes = [ctypes.c_void_p]
         nwg = N * ((H + 5) // 6)
         buf = torch.zeros(2 * nwg * 4 * 16, dtype=torch.int64, device=DEV)

@@ -291,3 +291,19 @@ def _rcab_chain_case(N, H, W, nblk, cr, hooks, seed, with_q=False):
 @pytest.mark.parametrize('N,H,W,nblk,cr,with_q', [(32, 48, 48, 5, 4, False), (3, 20, 37, 3, 4, True), (2, 5, 9, 2, 1, False), (6, 31, 24, 4, 3, True)])
 def test_rcab_chain_is_bitwise_the_per_block_launches(N, H, W, nblk, cr, with_q, hooks):
     _rcab_chain_case(N, H, W, nblk, cr, hooks, 1200 + N + H, with_q)
+
+
+# ---- round 6: the block chain with ONE wave per SIMD (conv_chain1.hip, rumpy_res_chain1; measured, not shipped: profiles/r06_block_body.txt): the product chain's
+# cases, the same bitwise bar against one launch per block ----
+from test_chain_gpu import _chain_case  # noqa: E402
+
+@pytest.mark.parametrize('hooks', [dict(fake_xcc=0, force_sc1=0), dict(fake_xcc=3, force_sc1=1), dict(fake_xcc=16, force_sc1=1)])
+@pytest.mark.parametrize('N,H,W,nblk,backward,fmt', [(32, 48, 48, 6, 0, 0), (32, 48, 48, 6, 1, 0), (5, 20, 37, 3, 0, 0), (5, 20, 37, 3, 1, 0), (3, 13, 48, 4, 0, 1),
+                                                     (1, 5, 9, 2, 0, 0), (7, 31, 24, 5, 1, 0), (2, 6, 16, 2, 0, 0), (2, 6, 16, 2, 1, 0), (42, 36, 48, 16, 0, 0)])
+def test_one_wave_per_simd_chain_is_bitwise_the_per_block_launches(N, H, W, nblk, backward, fmt, hooks):
+    _chain_case(N, H, W, nblk, backward, fmt, hooks, 1900 + N + H, entry='rumpy_res_chain1', call=exp_call)
+
+
+@pytest.mark.parametrize('backward', [0, 1])
+def test_one_wave_per_simd_chain_next_to_a_foreign_kernel_that_holds_cus(backward):
+    _chain_case(32, 48, 48, 8, backward, 0, dict(fake_xcc=0, force_sc1=0), 78, disturb=True, entry='rumpy_res_chain1', call=exp_call)

@@ -1,4 +1,5 @@
-// The chain of residual blocks (conv_chain.hip) with ONE wave per SIMD - round 6, VERDICT r5 item 2 ("the block body, not the hand-off").
+// EXPERIMENT (tests/tools/csrc, never launched by the engine; outcome: profiles/r06_block_body.txt - isolated 3 % faster than conv_chain.hip, the training step
+// 1.7 % SLOWER: not shipped).  The chain of residual blocks (conv_chain.hip) with ONE wave per SIMD - round 6, VERDICT r5 item 2 ("the block body, not the hand-off").
 //
 // What round 5 measured: with no hand-off at all a block of the 512-thread chain costs 12.2 us against 6.9 us of MFMA issue.  The ISA of its block loop says
 // why (profiles/r06_block_body.txt): per SIMD and block 756 MFMAs (12,096 cycles of the matrix pipe) AND ~2,000 vector instructions of the two waves that
@@ -19,6 +20,7 @@
 // Per accumulator the MFMA order is conv_block.hip's ((channel half, tap column) groups, tap row innermost): the results are BITWISE those of one launch per
 // block and of conv_chain.hip (tests/test_chain_gpu.py runs the same cases through both forms).
 #include "chain_common.hpp"
+#include "rumpy_experimental.h"
 #ifndef C1_AHEAD
 #define C1_AHEAD 1      // fragment reads this many groups ahead of the MFMAs
 #endif
@@ -46,16 +48,15 @@ static_assert(sizeof(C1Blk) == sizeof(rumpy_res_chain_block), "rumpy_res_chain_b
 struct C1Dev { const C1Blk* blk; int nblk, N, H, W, sy_n; unsigned* work; unsigned* status; int nxcd, fake_xcc; };
 
 
-// Every pointer of a block record comes out of device memory and is therefore a GENERIC pointer to the compiler: loads and stores through it are flat_*
-// instructions, which count on BOTH wait counters and complete out of order - every s_waitcnt lgkmcnt(N) of the fragment reads around a T store degrades to
-// a full drain (common.hpp::load_global_ptr: the same finding for the tail kernel, round 3).  These helpers go through the global address space.
-#define C1_GLOBAL(T, p) ((T __attribute__((address_space(1)))*)(unsigned long long)(p))
-__device__ __forceinline__ uint4 gld16(const void* p) { const u32x4v v = *C1_GLOBAL(const u32x4v, p); return make_uint4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ void gst16_nt(void* p, uint4 v) { __builtin_nontemporal_store((u32x4v){v.x, v.y, v.z, v.w}, C1_GLOBAL(u32x4v, p)); }
-__device__ __forceinline__ unsigned gld8(const unsigned char* p) { return *C1_GLOBAL(const unsigned char, p); }
-__device__ __forceinline__ void gst8(unsigned char* p, unsigned v) { *C1_GLOBAL(unsigned char, p) = (unsigned char)v; }
-__device__ __forceinline__ f32x4 gldf4(const float* p) { return *C1_GLOBAL(const f32x4, p); }
-// 16 bytes another workgroup has published (write-through stores behind a flag): two 8-byte agent-scope atomic loads - sc1, never served from a stale line
+// (block pointers go through the global address space and the neighbour's rows through agent-scope atomic loads: chain_common.hpp::CH_GLOBAL)
+#define C1_GLOBAL CH_GLOBAL
+#define gld16 ch_gld16
+#define gst16_nt ch_gst16_nt
+#define gld8 ch_gld8
+#define gst8 ch_gst8
+#define gldf4 ch_gldf4
+// 16 bytes another workgroup has published (write-through stores behind a flag): two 8-byte agent-scope atomic loads - sc1, never served from a stale line,
+// and tracked by the compiler's wait counters (an inline-asm load's destination registers look ready to the register allocator)
 __device__ __forceinline__ uint4 gld16_agent(const void* p) {
   const unsigned long long lo = __hip_atomic_load(C1_GLOBAL(const unsigned long long, p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const unsigned long long hi = __hip_atomic_load(C1_GLOBAL(const unsigned long long, p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -199,7 +200,7 @@ template <int FORM, int FMT = RUMPY_FMT_BF16>
 __global__ void __launch_bounds__(C1T, 1) block_chain1_kernel(C1Dev a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
   __shared__ unsigned gate[5];             // waves that have: written their OUT channels [0], written the halo rows [1], written their T channels [2], seen their OUT stores acknowledged [3]
-  __shared__ int claim[3];
+  __shared__ int claim[4];
   const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 15, g = lane >> 4;
   // ---- which strip this workgroup runs: CLAIMED, per XCD (chain_common.hpp) ----
@@ -477,7 +478,7 @@ extern "C" int rumpy_res_chain1(const rumpy_res_chain_args* p, void* stream) {
   if (p->edge_w) { rumpy_set_error("rumpy_res_chain1: the conv at the chain's outer end is not built into this form"); return RUMPY_E_ARG; }
   const int sy_n = (p->H + BSH - 1) / BSH;
   if (p->N * sy_n > rumpy_device_cus()) { rumpy_set_error("rumpy_res_chain1: %d strips do not fit %d CUs (all must be co-resident)", p->N * sy_n, rumpy_device_cus()); return RUMPY_E_ARG; }
-  if (p->work_bytes < rumpy_res_chain_work_bytes(p->N, p->H)) { rumpy_set_error("rumpy_res_chain1: work buffer too small"); return RUMPY_E_ARG; }
+  if (p->work_bytes < chain_work_bytes((int64_t)p->N * ((p->H + BSH - 1) / BSH))) { rumpy_set_error("rumpy_res_chain1: work buffer too small"); return RUMPY_E_ARG; }
   if (p->fake_xcc < 0) { rumpy_set_error("rumpy_res_chain1: fake_xcc"); return RUMPY_E_ARG; }
   C1Dev d;
   d.blk = reinterpret_cast<const C1Blk*>(p->blocks); d.nblk = p->nblocks; d.N = p->N; d.H = p->H; d.W = p->W; d.sy_n = sy_n;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(BTHREADS, 2) rcab_chain_kernel(RcChainDev a) {
   __shared__ float sw2t[RCC_R * 64];       // [r][c] = conv_du.2.weight[c][r]
   __shared__ float svec[4 * 64];           // [0] conv_du.0.bias (cr) | [1] conv_du.2.bias | [2] q gate | [3] bwd: forward gate ; hidden at [0][32..]
   __shared__ unsigned gate[8];             // per row half: T rows written [0,1], OUT rows written [2,3], halo rows in LDS [4,5], stores acknowledged [6,7]
-  __shared__ int claim[3];
+  __shared__ int claim[4];
   unsigned char* const ldx = lds;
   unsigned char* const ldt = lds + BXBYTES;
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -120,6 +120,11 @@ int rumpy_rcab_chain(const rumpy_rcab_chain_args* a, void* stream);
 int64_t rumpy_rcab_chain_work_bytes(int32_t N, int32_t H);
 int rumpy_debug_rcc_stamps(void* buf);   /* -DRCC_STAMPS builds only */
 
+/* ---- round 6 (measured, not shipped - profiles/r06_block_body.txt): rumpy_res_chain of the product library with ONE wave per SIMD (conv_chain1.hip: 256-thread workgroups, 512 registers per wave, every per-lane address computed once in
+ * front of the block loop, four- and six-row sweeps).  Same arguments, work buffer and results (bitwise); hand-offs always through the memory side (force_sc1 is
+ * ignored); edge_w must be NULL. */
+int rumpy_res_chain1(const rumpy_res_chain_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
