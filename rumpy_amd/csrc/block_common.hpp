@@ -3,6 +3,10 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef BLOCK_PIN
+#define BLOCK_PIN 1        // (round 6) block_sweep's fragment reads pinned BETWEEN the MFMAs of the group before (0: in front of them, rounds 1-5; A/B same box:
+                           // EDSR step 29.60 -> 29.75 k patches/s, conv_up 53.2 -> 51.7 us, forward chain 235.2 -> 232.7 us, RCAN +0.3 %; bitwise)
+#endif
 constexpr int BSH = 6, BSW = 48, BCOLS = BSW + 2;
 constexpr int BXROWS = BSH + 4, BTROWS = BSH + 2;
 constexpr int BXBYTES = BXROWS * BCOLS * 128;       // 64000
@@ -82,7 +86,9 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8
 #pragma unroll
   for (int grp = 0; grp < NG; ++grp) {
     if (grp + AHEAD < NG) load_group(grp + AHEAD, I[(grp + AHEAD) % (AHEAD + 1)]);
+#if !BLOCK_PIN
     __builtin_amdgcn_sched_barrier(0);   // keep the next group's reads ahead of this group's MFMAs
+#endif
     const int half = grp / (3 * NC), kx = (grp % (3 * NC)) / NC, c = grp % NC;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -91,6 +97,18 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8
         acc[r][c] = mfma16<FMT>(F[(ky * 3 + kx) * 2 + half], I[grp % (AHEAD + 1)][r + ky], acc[r][c]);
       }
     hook(grp);
+#if BLOCK_PIN
+    // round 6: the next group's ROWS + 2 fragment reads pinned BETWEEN this group's 3 ROWS MFMAs (sched_group_barrier) instead of in front of them
+    if (grp + AHEAD < NG) {
+      constexpr int PER = (3 * ROWS) / (ROWS + 2) > 0 ? (3 * ROWS) / (ROWS + 2) : 1;
+#pragma unroll
+      for (int i = 0; i < ROWS + 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // a group's instructions stay inside the group
+#endif
   }
 }
 

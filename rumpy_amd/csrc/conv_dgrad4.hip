@@ -46,6 +46,9 @@ constexpr int D4_NST = 6;                             // ring slots: the stage i
                         // 101.7-102.5 us, 32x48x48 39.3-40.2 against 36.9-37.7): dealt round-robin, a round's 256 tiles load all eight L2s and their memory
                         // channels evenly at every moment; in runs, each XCD streams one compact region and the halo lines it saves were L2 hits of the
                         // Infinity Cache anyway (profiles/r03_conv4_xcd_ab.txt)
+#ifndef D4_PIN
+#define D4_PIN 1        // (round 6) a unit's LDS reads pinned BETWEEN its MFMAs (0: in front of them; same box: conv4dt 121.5 -> 117.5 us, conv4d unchanged; bitwise)
+#endif
 #ifndef D4_RD
 #define D4_RD 2         // fragment sets read ahead of the MFMAs (units of HR + 2 reads / 3 HR MFMAs)
 #endif
@@ -174,13 +177,28 @@ __global__ void __launch_bounds__(256, 1) conv4d_kernel(ConvDev a) {
 #pragma unroll
       for (int j = 0; j < 12; ++j) {
         if (j + D4_RD < 12) load_unit(j + D4_RD, I[(j + D4_RD) % (D4_RD + 1)]);
+#if !D4_PIN
         __builtin_amdgcn_sched_barrier(0);
+#endif
         const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < HR; ++r)
             acc[HR * pass + r] = mfma16<FMT>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[HR * pass + r]);
+#if D4_PIN
+        // round 6: one wave per SIMD - nobody else feeds the matrix pipe while this wave issues the HR + 2 fragment reads of a later unit in front of its MFMAs;
+        // pinned between them (MFMA x PER, read) they cost next to nothing (block_common.hpp::BLOCK_PIN)
+        if (j + D4_RD < 12) {
+          constexpr int PER = (3 * HR) / (HR + 2) > 0 ? (3 * HR) / (HR + 2) : 1;
+#pragma unroll
+          for (int i = 0; i < HR + 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
     // ---- epilogue: lane holds channels c0 .. c0+3 of pixel (row r, column px); the residual operand is read here (plain loads: the
@@ -459,13 +477,24 @@ __global__ void __launch_bounds__(256, 1) conv4dt_kernel(Conv4TDev a) {
         if (more && j >= 1 && j - 1 < NGRP) p_write(PT, NPc(), std::integral_constant<int, (j >= 1 && j - 1 < NGRP ? j - 1 : 0)>(), pacc[(j - 1) & 1]);
         if (j >= 1 && j - 1 < NDX) dx_store(tc, CHc, j - 1, dxv);
         if (j < NDX) dx_read(CHc, j, dxv);
+#if !D4_PIN
         __builtin_amdgcn_sched_barrier(0);
+#endif
         const int kx = j >> 2, half = (j >> 1) & 1, pass = j & 1;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int r = 0; r < HR; ++r)
             acc[HR * pass + r] = mfma16<RUMPY_FMT_BF16>(F[ch][(ky * 3 + kx) * 2 + half], I[j % (D4_RD + 1)][r + ky], acc[HR * pass + r]);
+#if D4_PIN
+        {      // (the unit's LDS reads - fragments of unit j + 2, the stage image's operands, a dx piece - between its 3 HR MFMAs: MFMA x 2, read, ...)
+#pragma unroll
+          for (int i = 0; i < (3 * HR) / 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (more && j < NGRP) p_mfma(PG[j & 1], pacc[j & 1]);
       };

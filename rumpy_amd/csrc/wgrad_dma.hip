@@ -21,6 +21,10 @@
 #ifndef WGRAD_RD
 #define WGRAD_RD 4      // B fragments requested ahead of their MFMAs
 #endif
+#ifndef WGRAD_PIN
+#define WGRAD_PIN 1     // (round 6) a unit's fragment reads pinned BETWEEN its MFMAs (sched_group_barrier: MFMA, read, MFMA, read ...) instead of in front of them:
+                        // 245-249 -> 232-234 us per EDSR step on one box (0: A/B; 2: two MFMAs per read 239; 3: two reads per MFMA 234; read-ahead 3 / 5 / 6 under it: 232-233)
+#endif
 #ifndef WGRAD_STAGGER
 #define WGRAD_STAGGER 1 // 0: A/B - every wave issues its DMA pieces right behind the tile's barrier (rounds 1-2)
 #endif
@@ -241,7 +245,7 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
 #else
       if (u == 5) load_a(1, A[1]);
 #endif
-      if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
+      if (WGRAD_PIPE && !WGRAD_PIN) __builtin_amdgcn_sched_barrier(0);
       if (tap == 0) {                      // bias: dy tile w4 (the compiler turns these wave-uniform selects into branches with an lgkmcnt(0) in each arm - twice
                                            // per tile, at units that wait for (nearly) everything anyway; picking the operand with masks instead cost more than it saved)
         bf16x8 Ab = A[ks][0];
@@ -252,6 +256,15 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
 #pragma unroll
       for (int ct = 0; ct < MT; ++ct)
         acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][ct], Bq[u % (RD + 1)], acc[ct][tap], 0, 0, 0);
+#if WGRAD_PIN
+      if (MT == 4) {      // (1 MFMA, 1 transposed read) x 4: the unit's two to four reads travel between its four or five MFMAs
+#pragma unroll
+        for (int i = 0; i < (WGRAD_PIN == 2 ? 2 : 4); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, WGRAD_PIN == 2 ? 2 : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, WGRAD_PIN == 3 ? 2 : 1, 0);
+        }
+      }
+#endif
       if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
     }
     slot = (slot + 1 >= NST) ? 0 : slot + 1;
