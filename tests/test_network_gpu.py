@@ -906,6 +906,33 @@ def test_bench_starts_its_own_ranks_when_called_plainly():
             assert d['distributed']['allreduce_form'] == want and d['distributed']['forms'] is None
 
 
+def test_bench_runs_with_eight_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 8` at the REAL world size of the driver's scaling run, on a 1-GPU box: eight processes on cuda:0 over gloo
+    (RUMPY_BENCH_ONE_DEVICE=1).  What this exercises: the launcher at eight children, the broadcast of the replicas, the bucket slicing of
+    the flat gradient buffer for eight ranks, the max-over-ranks timing, the all-reduce form trial - and eight processes' persistent block chains (256 strips
+    each) contending for one GPU's 256 CUs: strips are claimed, a launch waits for the CUs the others hold, nothing may run into the watchdog (a data-parallel
+    rank raises on a time-out).  It says NOTHING about scaling: eight ranks time-share one device, `value` is not a throughput of eight GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update(RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--probe-steps', '1', '--no-cpu-baseline', '--settle-ms', '0']
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, cwd=root)
+    out = p.stdout.decode()
+    assert p.returncode == 0, (out + p.stderr.decode())[-4000:]
+    lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out[-3000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 256 and d['config']['parallelism'] == 'dp8' and d['scaling'] == 'weak' and d['value'] > 0
+    dd = d['distributed']
+    assert dd['world_size'] == 8 and dd['backend'] == 'gloo' and dd['ranks_on_one_device'] is True and dd['device_count'] >= 1
+    assert set(dd['forms']) == {'inline', 'early'} and dd['allreduce_form'] == min(dd['forms'], key=dd['forms'].get)
+    assert abs(dd['grad_allreduce_mb'] - 6.07) < 0.1          # EDSR-baseline's flat gradient buffer, one mean all-reduce per step
+    assert np.isfinite(d['config']['loss']) and all(np.isfinite(v) for v in dd['forms_loss'].values())
+
+
 @pytest.mark.parametrize('name,kw,N', [
     ('edsr', dict(scale=4), 32),
     ('edsr', dict(scale=4, _graph=True), 32),      # hipGraph replay: the hyper-parameters go through device memory (fenced pinned staging)
