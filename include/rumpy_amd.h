@@ -220,7 +220,7 @@ int rumpy_rcab2_partials(int32_t N, int32_t H, int32_t W);      /* rows of part_
  * t = relu(conv1(x) + b1) [mask bytes -> maskbits], out = x + scale2 * (conv2(t) + b2) [+ res2]; backward = 1: t = maskbits . scale1 * convA(x),
  * out = x + scale2 * convB(t) [+ res2] - for `nblocks` blocks, block b's x BEING block b - 1's out.  A workgroup keeps its strip in LDS from block to block;
  * the halo rows travel between vertical neighbours through the XCD's L2 (strips are claimed per XCD: all strips of an image run behind one L2) or, for a
- * strip that had to be claimed from another XCD, through the memory side.  Bitwise the per-block launches.  Needs N * ceil(H/6) <= CUs, W <= 48, and
+ * strip that had to be claimed from another XCD, through the memory side.  Bitwise the per-block launches.  Needs rumpy_res_chain_strips(N, H, W) <= CUs, W <= 64 (round 6; W <= 48 before), and
  * `work` = rumpy_res_chain_work_bytes(N, H) bytes, zeroed once.  *status (device word, zero it once) becomes 0x4ff / 0x500 + block after a hand-off that
  * timed out: the results of that launch are invalid.  fake_xcc / force_sc1: test hooks (0 in production).
  * Replaces: the ResBlocks of EDSR.body (rumpy/SISR/models/advanced/architectures.py:218-224, 233: nn.Sequential of n_resblocks common.ResBlock;
@@ -245,6 +245,9 @@ typedef struct {
 } rumpy_res_chain_args;
 int rumpy_res_chain(const rumpy_res_chain_args* a, void* stream);
 int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H);
+/* ABI 6 (round 6): strips of an [N, H, W] launch - all of them must be co-resident (<= rumpy_device_cus()): 6 rows x 48 columns for W <= 48, 4 rows x 64 columns for
+ * 48 < W <= 64 (the reference's shipped 64-pixel training crops: 16 crops = 256 strips; no edge conv at this geometry); 0: W is beyond the kernel */
+int32_t rumpy_res_chain_strips(int32_t N, int32_t H, int32_t W);
 int rumpy_device_xcds(void);   /* accelerator dies (XCDs, each with its own L2) of the current device: 8 on MI355X */
 
 /* ---- head conv: Cin = C (<=4) fp32 NCHW image -> 64*cout_tiles ch NHWC bf16 (exact fp32 arithmetic) ----

@@ -329,6 +329,7 @@ SYMBOLS = {
     'rumpy_rcab_epoch_advance': (C.c_int, [c_void_p, c_void_p]),
     'rumpy_res_chain': (C.c_int, [_P(ResChainArgs), c_void_p]),
     'rumpy_res_chain_work_bytes': (c_int64, [c_int32, c_int32]),
+    'rumpy_res_chain_strips': (c_int32, [c_int32, c_int32, c_int32]),
     'rumpy_device_xcds': (C.c_int, []),
     'rumpy_rcab2_fwd': (C.c_int, [_P(Rcab2Args), c_void_p]),
     'rumpy_rcab2_bwd': (C.c_int, [_P(Rcab2Args), c_void_p]),

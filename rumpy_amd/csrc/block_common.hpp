@@ -38,7 +38,7 @@ template <int NC_, bool CT_, int SH_ = BSH> struct BlockGeo {
   static constexpr int GREGS = (GPIECES + 255) / 256;
   static constexpr int SPIECES = SH_ * OW * 8;           // the whole strip
   static constexpr int SREGS = (SPIECES + BTHREADS - 1) / BTHREADS;
-  static_assert(SH_ == BSH || (NC_ == 2 && CT_), "strips of 4 or 8 rows are built for 32-column tiles");
+  static_assert(SH_ == BSH || (NC_ == 2 && CT_) || (NC_ == 4 && !CT_ && SH_ == 4), "strips of 4 or 8 rows are built for 32-column tiles (and 4 rows x 64 columns for the chain)");
 };
 typedef BlockGeo<3, false> GeoL;       // W <= 48: BXBYTES / BTBYTES / BCOLS above
 

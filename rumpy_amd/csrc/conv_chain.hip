@@ -46,14 +46,27 @@ extern "C" int rumpy_debug_chain_stamps(void* buf) { return (int)hipMemcpyToSymb
 #define CH_STAMP(k) do { } while (0)
 #endif
 
+// Geometry (round 6): G6 = strips of 6 rows x 48 columns (W <= 48; BlockGeo<3, false, 6>, the kernel of round 5) and G4 = strips of 4 rows x 64 columns
+// (48 < W <= 64: the reference's shipped training crops, div2k/edsr.toml:16 - 16 crops of 64 x 64 are 256 strips).  G4 has the registers and the LDS of G6: a
+// row half owns 3 T rows x 4 column tiles = the 12 accumulator tiles of G6's 4 x 3, the images are 8 x 66 and 6 x 66 pixels = 118 KB (G6: 115 KB).  Per
+// accumulator the MFMA order is conv_block.hip's in both: bitwise the per-block launches (which cut a 64-pixel image into two 32-column tiles).
+typedef BlockGeo<3, false, 6> ChainG6;
+typedef BlockGeo<4, false, 4> ChainG4;
+
 // FORM 1: forward (ReLU, mask bytes written if given); FORM 3: data gradient (* scale1, mask bytes read)
-// EDGE: with the single conv at the chain's outer end (its own instantiations: the plain chain keeps its register budget)
-template <int FORM, int FMT = RUMPY_FMT_BF16, bool EDGE = false>
+// EDGE: with the single conv at the chain's outer end (its own instantiations: the plain chain keeps its register budget; G6 only)
+template <int FORM, int FMT = RUMPY_FMT_BF16, bool EDGE = false, class G = ChainG6>
 __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[BXBYTES + BTBYTES];
+  constexpr int NC = G::NC, SH = G::SH, OR = G::OR, TR = G::TR, COLS = G::XC, OW = G::OW;       // (XC = TC = OW + 2 columns in both LDS images)
+  constexpr int NP1 = TR * NC / 2;                     // paired tiles of the first epilogue (G6: 4 rows x 3 = 6 pairs; G4: 3 rows x 4 = 6 pairs)
+  constexpr int NP2 = OR * NC / 2;                     // ... of the second (G6: 4 pairs + one single tile; G4: 4 pairs)
+  constexpr int HREGS = (2 * OW * 8 + 255) / 256;      // a row half's two halo rows as 16-byte pieces per thread
+  static_assert(!EDGE || SH == 6, "the edge conv is built into the 6-row geometry");
+  static_assert(G::XC == G::TC && (NC == 3 || NC == 4) && (TR * NC) % 2 == 0, "geometries of this kernel");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[G::XBYTES + G::TBYTES];
   __shared__ unsigned gate[10];            // per row half: T rows written [0,1], OUT rows written [2,3], halo rows in LDS [4,5], stores acknowledged [6,7], edge conv's rows staged [8,9]
   unsigned char* const ldx = lds;
-  unsigned char* const ldt = lds + BXBYTES;
+  unsigned char* const ldt = lds + G::XBYTES;
   const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = wave & 3, rh = wave >> 2;
   // ---- which strip this workgroup runs: CLAIMED, per XCD (top of this file; chain_common.hpp) ----
@@ -74,29 +87,29 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   // ---- block 0: input rows 6sy-2 .. 6sy+7, columns -1 .. 48 -> LDS (conv_block.hip) ----
   {
     const uint16_t* const src0 = pre ? a.edge_x : b0.x;
-    uint4 R[BREGS];
-    const int y0 = sy * BSH - 2;
+    uint4 R[G::XREGS];
+    const int y0 = sy * SH - 2;
 #pragma unroll
-    for (int i = 0; i < BREGS; ++i) {
+    for (int i = 0; i < G::XREGS; ++i) {
       const int p = tid + BTHREADS * i;
       const int pix = p >> 3, part = p & 7;
-      const int lr = pix / BCOLS, lc = pix - lr * BCOLS;
+      const int lr = pix / COLS, lc = pix - lr * COLS;
       const int y = y0 + lr, x = lc - 1;
-      const bool ok = (p < BPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
+      const bool ok = (p < G::XPIECES) & ((unsigned)y < (unsigned)a.H) & ((unsigned)x < (unsigned)a.W);
       const int e = ok ? ((n * a.H + y) * a.W + x) * 64 + part * 8 : 0;
       uint4 v = ch_gld16(src0 + (unsigned)e);
       R[i] = keep_if(v, ok);
     }
     if (tid < 10) gate[tid] = 0u;
-    if (tid < BTROWS * 2 * 8) {            // border columns of the T image: convB's zero padding, never written by the epilogues
+    if (tid < G::TROWS * 2 * 8) {          // border columns of the T image: convB's zero padding, never written by the epilogues
       const int row = tid >> 4, side = (tid >> 3) & 1, chunk = tid & 7;
-      *reinterpret_cast<uint4*>(ldt + swz(row * BCOLS + side * (BCOLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(ldt + swz(row * COLS + side * (COLS - 1), chunk)) = make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < BREGS; ++i) {
+    for (int i = 0; i < G::XREGS; ++i) {
       const int p = tid + BTHREADS * i;
       const int pix = p >> 3, part = p & 7;
-      if (p < BPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
+      if (p < G::XPIECES) *reinterpret_cast<uint4*>(ldx + swz(pix, part)) = R[i];
     }
   }
   bf16x8 F[18];
@@ -194,45 +207,50 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     const int gpair = 4 * (g & ~1);
     const int chunk8 = 2 * q + (gpair >> 3);
     // lane geometry that does not change from block to block: offsets of the T pairs and of this thread's store pieces in a [N,H,W,64] tensor
-    unsigned moff[6], soff[GROUP_REGS];
+    // pairs of the first epilogue: three column tiles (G6): k < TR: (wave row k, column tile 0 | 1), k >= TR: (rows 2(k-TR) | 2(k-TR)+1, column tile 2);
+    // four (G4): (wave row k / 2, column tiles 2(k%2) | 2(k%2)+1)
+    auto p1_row = [&](int k) -> int { return NC == 3 ? ((k < TR) ? k : (2 * (k - TR) + (g & 1))) : k / 2; };
+    auto p1_col = [&](int k) -> int { return NC == 3 ? ((k < TR) ? (g & 1) : 2) : 2 * (k % 2) + (g & 1); };
+    unsigned moff[NP1], soff[G::GREGS];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
-      const int y = sy * BSH - 1 + 4 * rh + jr, xx = 16 * c + px;
+    for (int k = 0; k < NP1; ++k) {
+      const int jr = p1_row(k), c = p1_col(k);
+      const int y = sy * SH - 1 + TR * rh + jr, xx = 16 * c + px;
       const bool in = ((unsigned)y < (unsigned)a.H) & (xx < a.W);
       moff[k] = in ? (unsigned)(((n * a.H + y) * a.W + xx) * 64 + 16 * q + gpair) : 0xffffffffu;
     }
 #pragma unroll
-    for (int i = 0; i < GROUP_REGS; ++i) soff[i] = group_piece_off(i, tg, rh, n, sy, a.H, a.W);
-    // halo pieces of this row half: 2 rows x 48 columns x 8 chunks = 768 = 3 per thread; rows 6sy-2, 6sy-1 (half 0) or 6sy+6, 6sy+7 (half 1)
-    unsigned hoff[3], hlds[3];
+    for (int i = 0; i < G::GREGS; ++i) soff[i] = group_piece_off<G>(i, tg, rh, n, sy, a.H, a.W);
+    // halo pieces of this row half: 2 rows x OW columns x 8 chunks (768 = 3 per thread | 1024 = 4); rows SH sy - 2, - 1 (half 0) or SH sy + SH, + 1 (half 1)
+    unsigned hoff[HREGS], hlds[HREGS];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int p = tg + 256 * i, pix = p >> 3, r = pix / BSW, col = pix - r * BSW;
-      const int y = (rh == 0) ? sy * BSH - 2 + r : sy * BSH + BSH + r;
-      hoff[i] = (has_nb && (unsigned)y < (unsigned)a.H && col < a.W) ? (unsigned)(((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
-      hlds[i] = swz(((rh == 0) ? r : BSH + 2 + r) * BCOLS + col + 1, p & 7);
+    for (int i = 0; i < HREGS; ++i) {
+      const int p = tg + 256 * i, pix = p >> 3, r = pix / OW, col = pix - r * OW;
+      const int y = (rh == 0) ? sy * SH - 2 + r : sy * SH + SH + r;
+      hoff[i] = (p < 2 * OW * 8 && has_nb && (unsigned)y < (unsigned)a.H && col < a.W) ? (unsigned)(((n * a.H + y) * a.W + col) * 64 + (p & 7) * 8) : 0xffffffffu;
+      hlds[i] = swz(((rh == 0) ? r : SH + 2 + r) * COLS + col + 1, p & 7);
     }
     const unsigned done = 4u * (unsigned)b + pre4;       // boundary-gate counts at the end of block b - 1
     const unsigned tdone = 4u * (unsigned)b;             // T-gate counts
-    unsigned MB[FORM == 3 ? 6 : 1];
+    unsigned MB[FORM == 3 ? NP1 : 1];
     if (FORM == 3) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) MB[FORM == 3 ? k : 0] = ch_gld8(blk.mbits + ((moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3));
+      for (int k = 0; k < NP1; ++k) MB[FORM == 3 ? k : 0] = ch_gld8(blk.mbits + ((moff[k] != 0xffffffffu ? moff[k] : 0u) >> 3));
     }
-    f32x4 acc[4][3];                                     // wave row jr (T row 4rh + jr)
+    f32x4 acc[TR][NC];                                   // wave row jr (T row TR rh + jr)
     {
       f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (blk.b1) b4 = ch_gldf4(blk.b1 + c0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < TR; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[r][c] = b4;
+        for (int c = 0; c < NC; ++c) acc[r][c] = b4;
     }
     unsigned off[8][2];
+    constexpr int NA = TR - 2;                           // T rows of a row half that need no halo row (G6: 2, G4: 1); the other two do
     if (b == 0 && !pre) {
-      sweep_bases(off, 0u, 4 * rh, px, g);
-      block_sweep<4, FMT>(acc, F, lds, off);
+      sweep_bases<COLS>(off, 0u, TR * rh, px, g);
+      block_sweep<TR, FMT, NoHook, NC, COLS>(acc, F, lds, off);
     } else {
       // (a) the two T rows that need no halo row: row half 0 -> T rows 2, 3 (wave rows 2, 3); row half 1 -> T rows 4, 5 (wave rows 0, 1).
       // (Round 5 also tried NOT to bring the halves into step here - a half waits for its own OUT rows only, computes the three T rows that need nothing
@@ -241,8 +259,8 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       gate_wait(&gate[2], done);
       gate_wait(&gate[3], done);                         // both halves' OUT rows of block b - 1 are in LDS (and nobody reads the old T image)
       CH_STAMP(1);
-      sweep_bases(off, 0u, (rh == 0) ? 2 : 4, px, g);
-      block_sweep<2, FMT, NoHook, 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
+      sweep_bases<COLS>(off, 0u, (rh == 0) ? 2 : TR, px, g);      // (G6: T rows 2, 3 | 4, 5; G4: T row 2 | 3)
+      block_sweep<NA, FMT, NoHook, NC, COLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[NA][NC]>(&acc[(rh == 0) ? 2 : 0]), F, lds, off);
       CH_STAMP(2);
       // (b) publish block b - 1: this wave's OUT stores are acknowledged (under the sweep above) -> count in -> one lane stores the flag.  (Publishing IN
       // FRONT of the sweep - the neighbours see the flag a sweep earlier, this wave stalls 0.4 us for the rest of its acknowledgements - measured the
@@ -269,21 +287,21 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
         }
       }
       CH_STAMP(4);
-      uint4 Hr[3];
+      uint4 Hr[HREGS];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < HREGS; ++i) {
         Hr[i] = ch_load16_sc1(blk.x + (hoff[i] != 0xffffffffu ? hoff[i] : 0u));
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < HREGS; ++i)
         if (hoff[i] != 0xffffffffu) *reinterpret_cast<uint4*>(ldx + hlds[i]) = Hr[i];
       gate_arrive(&gate[4 + rh], lane);
       gate_wait(&gate[4 + rh], done);
       CH_STAMP(5);
       // (d) the two T rows that do: row half 0 -> T rows 0, 1 (input rows 0 .. 3); row half 1 -> T rows 6, 7 (input rows 6 .. 9)
-      sweep_bases(off, 0u, (rh == 0) ? 0 : 6, px, g);
-      block_sweep<2, FMT, NoHook, 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[2][3]>(&acc[(rh == 0) ? 0 : 2]), F, lds, off);
+      sweep_bases<COLS>(off, 0u, (rh == 0) ? 0 : 2 * TR - 2, px, g);      // (G6: input rows 0 .. 3 | 6 .. 9; G4: 0 .. 3 | 4 .. 7)
+      block_sweep<2, FMT, NoHook, NC, COLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[2][NC]>(&acc[(rh == 0) ? 0 : TR - 2]), F, lds, off);
     }
     CH_STAMP(6);
     // second filter: L2 hits that land under the epilogue
@@ -294,9 +312,15 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     }
     // ---- epilogue 1 (conv_block.hip): pairs k < 4: (row k, col tile 0 | 1); k = 4: rows 0 | 1 of col tile 2; k = 5: rows 2 | 3 ----
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      f32x4 tx = (k < 4) ? acc[k < 4 ? k : 0][0] : acc[2 * (k < 4 ? 0 : k - 4)][2];
-      f32x4 ty = (k < 4) ? acc[k < 4 ? k : 0][1] : acc[2 * (k < 4 ? 0 : k - 4) + 1][2];
+    for (int k = 0; k < NP1; ++k) {
+      f32x4 tx, ty;
+      if (NC == 3) {
+        tx = (k < TR) ? acc[k < TR ? k : 0][0] : acc[2 * (k < TR ? 0 : k - TR)][NC - 1];
+        ty = (k < TR) ? acc[k < TR ? k : 0][1] : acc[2 * (k < TR ? 0 : k - TR) + 1][NC - 1];
+      } else {
+        tx = acc[(k / 2) % TR][(2 * (k % 2)) % NC];
+        ty = acc[(k / 2) % TR][(2 * (k % 2) + 1) % NC];
+      }
       if (FORM == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { tx[j] = relu_f32(tx[j]); ty[j] = relu_f32(ty[j]); }
@@ -306,26 +330,26 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       }
       float v[8];
       pair_up(tx, ty, g, v);
-      const int jr = (k < 4) ? k : (2 * (k - 4) + (g & 1)), c = (k < 4) ? (g & 1) : 2;
+      const int jr = p1_row(k), c = p1_col(k);
       uint4 o = make_uint4(0, 0, 0, 0);                  // outside the image: convB's zero padding
       if (moff[k] != 0xffffffffu) {
         const uint2 lo = pack4<FMT>(v[0], v[1], v[2], v[3]), hi = pack4<FMT>(v[4], v[5], v[6], v[7]);
         o = make_uint4(lo.x, lo.y, hi.x, hi.y);
         if (FORM == 3) o = relu_mask_bits(o, MB[FORM == 3 ? k : 0]);
       }
-      *reinterpret_cast<uint4*>(ldt + swz((4 * rh + jr) * BCOLS + 16 * c + px + 1, chunk8)) = o;
+      *reinterpret_cast<uint4*>(ldt + swz((TR * rh + jr) * COLS + 16 * c + px + 1, chunk8)) = o;
     }
     CH_STAMP(7);
     gate_arrive(&gate[rh], lane);
     gate_wait(&gate[rh], tdone + 4u);
     if (rh == 1) gate_wait(&gate[0], tdone + 4u);
     // the row half's own strip rows of T (+ mask bytes) -> HBM from the LDS image: whole lines, non-temporal, under the second sweep
-    uint4 S[GROUP_REGS];
+    uint4 S[G::GREGS];
     const bool t_out = blk.t != nullptr;
-    if (t_out) group_stage<1>(S, ldt, tg, rh);
+    if (t_out) group_stage<1, G>(S, ldt, tg, rh);
     auto t_store = [&](int grp) {
-      if (grp % 3 == 0 && grp / 3 < GROUP_REGS) {
-        const int i = grp / 3 < GROUP_REGS ? grp / 3 : 0;
+      if (grp % 3 == 0 && grp / 3 < G::GREGS) {
+        const int i = grp / 3 < G::GREGS ? grp / 3 : 0;
         if (t_out && soff[i] != 0xffffffffu) {
           ch_gst16_nt(blk.t + soff[i], S[i]);
           if (FORM == 1 && blk.mbits) ch_gst8(blk.mbits + (soff[i] >> 3), relu_bits(S[i]));
@@ -333,24 +357,24 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
       }
     };
     // ---- phase 2: OUT = X + scale2 * (convB(T) + b2) [+ res2], in place over the input image's centre rows ----
-    f32x4 acc2[3][3];
+    f32x4 acc2[OR][NC];
     {
       f32x4 b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (blk.b2) b4 = ch_gldf4(blk.b2 + c0);
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < OR; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc2[r][c] = b4;
+        for (int c = 0; c < NC; ++c) acc2[r][c] = b4;
     }
-    if (rh == 0) {
-      sweep_bases(off, (unsigned)BXBYTES, 0, px, g);
-      block_sweep<2, FMT, decltype(t_store), 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[2][3]>(&acc2[0]), F, lds, off, t_store);
+    if (rh == 0) {      // output rows 0 .. OR-2 from this half's own T rows 0 .. OR; row OR-1 also needs the other half's first T row
+      sweep_bases<COLS>(off, (unsigned)G::XBYTES, 0, px, g);
+      block_sweep<OR - 1, FMT, decltype(t_store), NC, COLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[OR - 1][NC]>(&acc2[0]), F, lds, off, t_store);
       gate_wait(&gate[1], tdone + 4u);
-      sweep_bases(off, (unsigned)BXBYTES, 2, px, g);
-      block_sweep<1, FMT, NoHook, 3, BCOLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[1][3]>(&acc2[2]), F, lds, off);
+      sweep_bases<COLS>(off, (unsigned)G::XBYTES, OR - 1, px, g);
+      block_sweep<1, FMT, NoHook, NC, COLS, CHAIN_AHEAD>(*reinterpret_cast<f32x4(*)[1][NC]>(&acc2[OR - 1]), F, lds, off);
     } else {
-      sweep_bases(off, (unsigned)BXBYTES, 3, px, g);
-      block_sweep<3, FMT>(acc2, F, lds, off, t_store);
+      sweep_bases<COLS>(off, (unsigned)G::XBYTES, OR, px, g);
+      block_sweep<OR, FMT, decltype(t_store), NC, COLS>(acc2, F, lds, off, t_store);
     }
     CH_STAMP(8);
     if (b + 1 < a.nblk || post) {                        // the next block's first filter (or the edge conv's) lands under the epilogue and the halo step
@@ -358,16 +382,19 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
 #pragma unroll
       for (int t = 0; t < 18; ++t) F[t] = as_bf16x8(ch_gld16(wp + t * 64));
     }
+    // pairs of the second epilogue: G6: k < 3: (row k, column tile 0 | 1), k = 3: (rows 0 | 1, column tile 2) + the single tile (row 2, column tile 2) below;
+    // G4: (row k / 2, column tiles 2(k%2) | 2(k%2)+1)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const f32x4 tx = (k < 3) ? acc2[k < 3 ? k : 0][0] : acc2[0][2];
-      const f32x4 ty = (k < 3) ? acc2[k < 3 ? k : 0][1] : acc2[1][2];
+    for (int k = 0; k < NP2; ++k) {
+      f32x4 tx, ty;
+      if (NC == 3) { tx = (k < OR) ? acc2[k < OR ? k : 0][0] : acc2[0][NC - 1]; ty = (k < OR) ? acc2[k < OR ? k : 0][1] : acc2[1 % OR][NC - 1]; }
+      else { tx = acc2[(k / 2) % OR][(2 * (k % 2)) % NC]; ty = acc2[(k / 2) % OR][(2 * (k % 2) + 1) % NC]; }
       float v[8], m[8];
       pair_up(tx, ty, g, v);
-      const int r = (k < 3) ? k : (g & 1), c = (k < 3) ? (g & 1) : 2;
-      const int srow = 3 * rh + r, y = sy * BSH + srow, xx = 16 * c + px;
+      const int r = NC == 3 ? ((k < OR) ? k : (g & 1)) : k / 2, c = NC == 3 ? ((k < OR) ? (g & 1) : 2) : 2 * (k % 2) + (g & 1);
+      const int srow = OR * rh + r, y = sy * SH + srow, xx = 16 * c + px;
       if (y < a.H && xx < a.W) {
-        unsigned char* cell = ldx + swz((srow + 2) * BCOLS + xx + 1, chunk8);
+        unsigned char* cell = ldx + swz((srow + 2) * COLS + xx + 1, chunk8);
         unpack8<FMT>(*reinterpret_cast<const uint4*>(cell), m);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], blk.scale2, m[j]);
@@ -380,11 +407,11 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
         *reinterpret_cast<uint4*>(cell) = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     }
-    {
-      const int srow = 3 * rh + 2, y = sy * BSH + srow, xx = 32 + px;
+    if (NC == 3) {                                       // (three column tiles: the ninth tile of a row half has no partner)
+      const int srow = OR * rh + 2, y = sy * SH + srow, xx = 32 + px;
       if (y < a.H && xx < a.W) {
-        unsigned char* cell = ldx + swz((srow + 2) * BCOLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8;
-        float v[4] = {acc2[2][2][0], acc2[2][2][1], acc2[2][2][2], acc2[2][2][3]};
+        unsigned char* cell = ldx + swz((srow + 2) * COLS + xx + 1, 2 * q + (g >> 1)) + (g & 1) * 8;
+        float v[4] = {acc2[2 % OR][NC - 1][0], acc2[2 % OR][NC - 1][1], acc2[2 % OR][NC - 1][2], acc2[2 % OR][NC - 1][3]};
         float m[4];
         unpack4<FMT>(*reinterpret_cast<const uint2*>(cell), m);
 #pragma unroll
@@ -401,9 +428,9 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
     gate_arrive(&gate[2 + rh], lane);
     gate_wait(&gate[2 + rh], done + 4u);
     {                                                    // this row half's 3 OUT rows -> HBM: whole lines, write-through (the neighbours read them back)
-      group_stage<2>(S, ldx, tg, rh);
+      group_stage<2, G>(S, ldx, tg, rh);
 #pragma unroll
-      for (int i = 0; i < GROUP_REGS; ++i)
+      for (int i = 0; i < G::GREGS; ++i)
         if (soff[i] != 0xffffffffu) { if (local) ch_store16_sc0(blk.out + soff[i], S[i]); else ch_store16_sc1(blk.out + soff[i], S[i]); }
     }
     CH_STAMP(10);
@@ -482,15 +509,24 @@ __global__ void __launch_bounds__(BTHREADS, 2) block_chain_kernel(ChainDev a) {
   }
 }
 
+// (sized for the 4-row geometry, which has the more strips: one work buffer serves a plan's launches at either geometry)
 extern "C" int64_t rumpy_res_chain_work_bytes(int32_t N, int32_t H) {
-  return chain_work_bytes((int64_t)N * ((H + BSH - 1) / BSH));
+  return chain_work_bytes((int64_t)N * ((H + ChainG4::SH - 1) / ChainG4::SH));
+}
+// strips of an [N, H, W] launch (all of them must be co-resident): rows per strip 6 (W <= 48) or 4 (48 < W <= 64); 0: W is beyond the kernel
+extern "C" int32_t rumpy_res_chain_strips(int32_t N, int32_t H, int32_t W) {
+  if (W <= 0 || W > ChainG4::OW) return 0;
+  const int sh = W <= ChainG6::OW ? ChainG6::SH : ChainG4::SH;
+  return N * ((H + sh - 1) / sh);
 }
 
 extern "C" int rumpy_res_chain(const rumpy_res_chain_args* p, void* stream) {
   if (!p || !p->blocks || !p->work || !p->status || p->nblocks <= 0 || p->nblocks > 255) { rumpy_set_error("rumpy_res_chain: bad argument"); return RUMPY_E_ARG; }
-  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > BSW) { rumpy_set_error("rumpy_res_chain: needs 0 < W <= 48 (got %d)", p->W); return RUMPY_E_ARG; }
+  if (p->N <= 0 || p->H <= 0 || p->W <= 0 || p->W > ChainG4::OW) { rumpy_set_error("rumpy_res_chain: needs 0 < W <= 64 (got %d)", p->W); return RUMPY_E_ARG; }
+  const bool wide = p->W > ChainG6::OW;        // 48 < W <= 64: strips of 4 rows x 64 columns
+  if (wide && p->edge_w) { rumpy_set_error("rumpy_res_chain: the conv at the chain's outer end is built into the 6-row geometry (W <= 48)"); return RUMPY_E_ARG; }
   if (p->fmt != RUMPY_FMT_BF16 && !(p->fmt == RUMPY_FMT_F16 && !p->backward)) { rumpy_set_error("rumpy_res_chain: fmt %d is a forward-only format", p->fmt); return RUMPY_E_ARG; }
-  const int sy_n = (p->H + BSH - 1) / BSH;
+  const int sy_n = (p->H + (wide ? ChainG4::SH : ChainG6::SH) - 1) / (wide ? ChainG4::SH : ChainG6::SH);
   if (p->N * sy_n > rumpy_device_cus()) { rumpy_set_error("rumpy_res_chain: %d strips do not fit %d CUs (all must be co-resident)", p->N * sy_n, rumpy_device_cus()); return RUMPY_E_ARG; }
   if (p->work_bytes < rumpy_res_chain_work_bytes(p->N, p->H)) { rumpy_set_error("rumpy_res_chain: work buffer too small"); return RUMPY_E_ARG; }
   if (p->fake_xcc < 0 || (p->fake_xcc > 0 && !p->force_sc1)) { rumpy_set_error("rumpy_res_chain: fake_xcc (a test hook) goes with force_sc1"); return RUMPY_E_ARG; }
@@ -504,7 +540,11 @@ extern "C" int rumpy_res_chain(const rumpy_res_chain_args* p, void* stream) {
   if (d.fake_xcc > 0) d.nxcd = d.fake_xcc < CH_MAX_XCD ? d.fake_xcc : CH_MAX_XCD;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(p->N * sy_n);
-  if (p->edge_w) {
+  if (wide) {
+    if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3, RUMPY_FMT_BF16, false, ChainG4>), grid, dim3(BTHREADS), s, d);
+    else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_F16, false, ChainG4>), grid, dim3(BTHREADS), s, d);
+    else RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_BF16, false, ChainG4>), grid, dim3(BTHREADS), s, d);
+  } else if (p->edge_w) {
     if (p->backward) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<3, RUMPY_FMT_BF16, true>), grid, dim3(BTHREADS), s, d);
     else if (p->fmt == RUMPY_FMT_F16) RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_F16, true>), grid, dim3(BTHREADS), s, d);
     else RUMPY_LAUNCH_PROBED(5, (block_chain_kernel<1, RUMPY_FMT_BF16, true>), grid, dim3(BTHREADS), s, d);

@@ -952,7 +952,8 @@ class SREngine:
         """replace every maximal run (>= 2) of consecutive ResBlock-form rumpy_conv_block launches, each reading the previous one's output, by ONE
         rumpy_res_chain launch (conv_chain.hip).  In place: `ops` is the plan's launch list."""
         N, H, W = plan.N, plan.H, plan.W
-        if not self.use_chain or self.wide or W > 48 or N * ((H + 5) // 6) > self.cus:
+        strips = int(self.lib.rumpy_res_chain_strips(N, H, W))      # 6-row x 48-column strips for W <= 48, 4-row x 64-column strips for 48 < W <= 64 (round 6); 0: wider
+        if not self.use_chain or self.wide or strips == 0 or strips > self.cus:
             return
 
         def chainable(a):
@@ -987,7 +988,7 @@ class SREngine:
                 def plain_conv(c):
                     return (c.cin_chunks == 1 and c.cout_tiles == 1 and c.in_mode == 0 and c.out_mode == 0 and not c.relu and c.scale == 1.0 and not c.mask
                             and not c.pool and not c.res2 and not c.w_lo and c.N == N and c.H == H and c.W == W and c.fmt == args.fmt)
-                if self.chain_edge and len(blocks) <= 254:
+                if self.chain_edge and len(blocks) <= 254 and W <= 48:       # (the edge conv is built into the 6-row geometry)
                     if not backward and j < len(ops) and ops[j][0] == 'rumpy_conv3x3' and plain_conv(ops[j][1]) and ops[j][1].x == blocks[-1].out:
                         c = ops[j][1]
                         args.edge_w, args.edge_b, args.edge_res, args.edge_out = c.w, c.bias, c.res1, c.out

@@ -106,6 +106,44 @@ def test_chain_with_the_conv_at_its_outer_end_is_bitwise_the_separate_launches(N
     _chain_case(N, H, W, nblk, backward, fmt, hooks, 940 + N + H, edge=True)
 
 
+# ---- round 6: strips of 4 rows x 64 columns (48 < W <= 64: the reference's shipped 64-pixel crops) - the same kernel, geometry G4; the per-block launches it is
+# compared with cut such an image into two column tiles of 32 ----
+@pytest.mark.parametrize('hooks', HOOKS[:3])
+@pytest.mark.parametrize('N,H,W,nblk,backward,fmt', [(16, 64, 64, 6, 0, 0), (16, 64, 64, 6, 1, 0), (5, 20, 53, 3, 0, 0), (5, 20, 53, 3, 1, 0), (3, 13, 64, 4, 0, 1),
+                                                     (1, 5, 49, 2, 0, 0), (7, 30, 60, 5, 1, 0), (2, 4, 64, 2, 0, 0), (2, 4, 64, 2, 1, 0), (9, 23, 57, 16, 0, 0)])
+def test_chain_on_four_row_strips_of_64_columns_is_bitwise_the_per_block_launches(N, H, W, nblk, backward, fmt, hooks):
+    _chain_case(N, H, W, nblk, backward, fmt, hooks, 2100 + N + H + W)
+
+
+def test_chain_on_64_column_strips_next_to_a_foreign_kernel(monkeypatch):
+    _chain_case(16, 64, 64, 8, 1, 0, dict(fake_xcc=0, force_sc1=0), 79, disturb=True)
+
+
+@pytest.mark.parametrize('N,hw', [(16, 64), (4, (40, 56))])
+def test_edsr_training_at_the_shipped_crop_size_on_the_chain_equals_the_per_block_launches(N, hw, monkeypatch):
+    """EDSR x2, 5 blocks, two training steps on 64-pixel crops (16 crops = 256 strips of 4 x 64) and an evaluation image 60 pixels wide: the chain launches against
+    RUMPY_NO_CHAIN=1 (column-tiled per-block launches) - losses, outputs, weights and the evaluation image bit for bit; the body-end conv stays its own launch"""
+    kw = dict(scale=2, num_blocks=5, res_scale=0.1)
+    res = []
+    for no_chain in ('0', '1'):
+        monkeypatch.setenv('RUMPY_NO_CHAIN', no_chain)
+        h, _ = _pair('edsr', 516, sched=False, **kw)
+        losses = []
+        for step in range(2):
+            x, y = O.synthetic_batch(770 + step, N, lr_hw=hw, scale=2)
+            loss, out = h.run_train(x=x, y=y)
+            losses.append(float(loss))
+        xe, _ = O.synthetic_batch(779, 1, lr_hw=(37, 60), scale=2)
+        ev, _, _ = h.run_eval(x=xe)
+        H, W = (hw, hw) if isinstance(hw, int) else hw
+        tp = h.net.engine.plan_for(N, H, W, True)
+        chains = [a for op, a in tp.fwd + tp.bwd if op == 'rumpy_res_chain']
+        assert (len(chains) == 2 and all(a.nblocks == 5 and not a.edge_w for a in chains)) == (no_chain == '0')
+        assert h.net.engine.exchange_status() == 0
+        res.append((losses, out.clone(), ev.clone(), h.net.flat_p.detach().cpu().clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+
+
 @pytest.mark.parametrize('backward', [0, 1])
 def test_chain_next_to_a_foreign_kernel_that_holds_cus(backward):
     """256 strips on 256 CUs while another queue holds part of the chip (rumpy_debug_occupy, 160 workgroups x 80 KiB of LDS, 20 ms at a time - round 6: the 48
@@ -120,8 +158,9 @@ def test_chain_refuses_what_it_cannot_run():
     st = torch.zeros(1, dtype=torch.int32, device=DEV)
     a = L.ResChainArgs(blocks=work.data_ptr(), nblocks=2, N=40, H=48, W=48, work=work.data_ptr(), work_bytes=work.numel(), status=st.data_ptr())
     assert L.lib().rumpy_res_chain(a, None) == -1 and b'co-resident' in L.lib().rumpy_last_error()      # 320 strips > 256 CUs
-    a.N, a.W = 2, 64
-    assert L.lib().rumpy_res_chain(a, None) == -1 and b'W <= 48' in L.lib().rumpy_last_error()
+    a.N, a.W = 2, 65
+    assert L.lib().rumpy_res_chain(a, None) == -1 and b'W <= 64' in L.lib().rumpy_last_error()
+    assert L.lib().rumpy_res_chain_strips(16, 64, 64) == 256 and L.lib().rumpy_res_chain_strips(32, 48, 48) == 256 and L.lib().rumpy_res_chain_strips(1, 8, 65) == 0
     a.W, a.fake_xcc = 48, 3
     assert L.lib().rumpy_res_chain(a, None) == -1 and b'force_sc1' in L.lib().rumpy_last_error()
     assert L.lib().rumpy_device_xcds() == 8

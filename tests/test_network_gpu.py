@@ -173,8 +173,20 @@ def test_rcan_full_depth_gradient_parity():
 
 
 def test_edsr_baseline_full_depth_gradient_parity_at_the_shipped_crop_size():
-    """64 x 64 LR crops (Documentation/sample_config_files/div2k/edsr.toml:16,26 of the reference): wider than one strip - every residual
-    block runs the column-tiled one-launch kernel (two tiles of 32 columns), forward and data gradient"""
+    """64 x 64 LR crops (Documentation/sample_config_files/div2k/edsr.toml:16,26 of the reference): wider than a 48-column strip.  Round 6: the 16 residual
+    blocks run as ONE persistent chain launch per direction on strips of 4 rows x 64 columns (conv_chain.hip, geometry G4); with RUMPY_NO_CHAIN=1 every block
+    runs the column-tiled one-launch kernel (two tiles of 32 columns) as before - both against the fp32 oracle"""
+    h = _handler('edsr', scale=4)
+    h.net._ensure_engine()
+    plan = h.net.engine.plan_for(4, 64, 64, True)
+    for ops in (plan.fwd, plan.bwd):
+        chains = [a for op, a in ops if op == 'rumpy_res_chain']
+        assert len(chains) == 1 and chains[0].nblocks == 16 and chains[0].W == 64 and not chains[0].edge_w and 'rumpy_conv_block' not in [op for op, _ in ops]
+    _full_depth_step('edsr', 523, 4, {}, 3e-2, 0.999, lr_hw=64)
+
+
+def test_edsr_baseline_full_depth_gradient_parity_at_the_shipped_crop_size_per_block(monkeypatch):
+    monkeypatch.setenv('RUMPY_NO_CHAIN', '1')
     h = _handler('edsr', scale=4)
     h.net._ensure_engine()
     plan = h.net.engine.plan_for(4, 64, 64, True)
