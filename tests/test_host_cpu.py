@@ -771,3 +771,39 @@ def test_ablation_patch_applies_to_its_base():
         p = subprocess.run(['git', '-C', d, 'apply', '--check', os.path.join(root, 'tests', 'tools', 'patches', 'abl_r03.patch')],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         assert p.returncode == 0, p.stdout.decode()[-2000:]
+
+
+# ------------------------------------------------------------------ round 6: host logic of the watchdog fall-back, the fp8 block policy, the chain geometries
+def test_watchdog_codes_name_the_switch_that_applies():
+    """codes 0x4ff / 0x500 + b come from the residual-block chain (RUMPY_NO_CHAIN), 0x300 + seq from the RCAB pool exchange (RUMPY_RCAB_FORM / RUMPY_NO_RCAB)"""
+    from rumpy_amd.engine import SREngine
+    assert 'RUMPY_NO_CHAIN=1' in SREngine.watchdog_text(0x4ff) and 'never published' in SREngine.watchdog_text(0x4ff)
+    assert 'RUMPY_NO_CHAIN=1' in SREngine.watchdog_text(0x503) and 'block 3' in SREngine.watchdog_text(0x503)
+    t = SREngine.watchdog_text(0x305)
+    assert 'RUMPY_RCAB_FORM=lazy' in t and 'RUMPY_NO_RCAB=1' in t and 'RUMPY_NO_CHAIN' not in t
+
+
+def test_fp8_block_policy_parsing(monkeypatch):
+    import types
+    from rumpy_amd.engine import SREngine
+    me = types.SimpleNamespace(FP8_POLICY_DEFAULT='none')
+    pol = lambda: SREngine._fp8_bf16_blocks(me, 200)
+    monkeypatch.delenv('RUMPY_FP8_BF16_BLOCKS', raising=False)
+    assert pol() == frozenset()
+    for spec, want in (('none', set()), ('first:3', {0, 1, 2}), ('last:2', {198, 199}), ('every:50', {0, 50, 100, 150}), ('7,9,500,-1', {7, 9}), ('first:500', set(range(200)))):
+        monkeypatch.setenv('RUMPY_FP8_BF16_BLOCKS', spec)
+        assert pol() == frozenset(want), spec
+    for bad in ('some', 'first:0', 'every:x', 'middle:3', '1;2'):
+        monkeypatch.setenv('RUMPY_FP8_BF16_BLOCKS', bad)
+        with pytest.raises(RuntimeError, match='RUMPY_FP8_BF16_BLOCKS'):
+            pol()
+
+
+def test_chain_geometries_by_image_width():
+    """rumpy_res_chain_strips (host-side, no GPU): 6-row strips up to 48 columns, 4-row strips up to 64 (the reference's shipped crops: 16 x 64 x 64 = 256 strips), 0 beyond;
+    the work buffer is sized for the geometry with the more strips"""
+    lib = _lib_or_skip().lib()
+    assert lib.rumpy_res_chain_strips(32, 48, 48) == 256 and lib.rumpy_res_chain_strips(32, 48, 9) == 256 and lib.rumpy_res_chain_strips(1, 5, 48) == 1
+    assert lib.rumpy_res_chain_strips(16, 64, 64) == 256 and lib.rumpy_res_chain_strips(16, 64, 49) == 256 and lib.rumpy_res_chain_strips(3, 13, 60) == 12
+    assert lib.rumpy_res_chain_strips(1, 64, 65) == 0 and lib.rumpy_res_chain_strips(1, 64, 0) == 0
+    assert lib.rumpy_res_chain_work_bytes(16, 64) >= (32 + 256 + 2 * 256 * 32) * 4      # placement words + one 128-byte flag line per (strip, row half)
