@@ -18,6 +18,13 @@
 #ifndef WGRAD_A1_SPREAD
 #define WGRAD_A1_SPREAD 1    // 0: A/B - the second k-step's A fragments requested in one go at unit 5 (+0.2-0.4 % spread out, same box)
 #endif
+#ifndef WGRAD_ABL
+#define WGRAD_ABL 0     // timing-only builds, results wrong by design (tests/tools/wgrad_time.py): 1 no DMA behind the prologue (MFMAs + fragment reads alone), 2 no MFMAs (the stream alone)
+#endif
+#ifndef WGRAD_NST
+#define WGRAD_NST 3     // ring slots of the 64-channel kernel: 3 x 40 KB, two tiles in flight (round 6: 4 slots = all 160 KB of a CU's LDS, three in flight - the stream alone
+                        // 168.6 against 167.9 us, the kernel in the step 228.9 against 226.1: depth is not what it waits for)
+#endif
 #ifndef WGRAD_RD
 #define WGRAD_RD 4      // B fragments requested ahead of their MFMAs
 #endif
@@ -44,8 +51,8 @@ template <int MT> struct DmaCfg {
   static constexpr int STAGE = PIECES * 1024;
   // ring depth: MT = 4 has room for 3 slots of 40 KB (two tiles in flight); the tail conv's 32 KB slots fit 4 (three tiles in
   // flight per CU) - that kernel only streams the largest activation of the network, bytes in flight are its throughput
-  static constexpr int NSTAGE = (MT == 4) ? 3 : 4;
-  static constexpr int LDS = (MT == 4) ? 4 * 36 * 1024 : NSTAGE * STAGE;   // >= the ring and >= the final K-half exchange
+  static constexpr int NSTAGE = (MT == 4) ? WGRAD_NST : 4;
+  static constexpr int LDS = (NSTAGE * STAGE > 4 * 36 * 1024) ? NSTAGE * STAGE : 4 * 36 * 1024;   // >= the ring and >= the final K-half exchange
 };
 
 __device__ __forceinline__ short4v tr_read2(unsigned addr) {
@@ -66,59 +73,55 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 
 struct DmaJob { const uint16_t* x; const uint16_t* dy; int n0, H, W, x_cstride, x_coff, dy_mode, dy_cstride, dy_coff, tiles_x, tiles_y; };
 
-// Per-lane geometry of this wave's DMA pieces, computed once per job: piece k of the wave = piece index wave + 8k; k < 3 are x
-// halo pieces (8 pixels x 128 B of the 10x18 halo), k >= 3 dy pieces.  Per tile only the tile origin changes, so the source
-// address is a handful of 32-bit operations instead of the div/mod + 64-bit chain it replaces (the address generation of
-// 5 pieces used to cost as many issue cycles as the tile's MFMAs).
-struct PieceGeom { int r, c, coff; bool valid; };
-template <int MT>
-__device__ __forceinline__ void piece_geometry(PieceGeom (&pg)[DmaCfg<MT>::PER_WAVE], const DmaJob& j, int wave, int lane) {
-  const int sub = lane >> 3, slot = lane & 7;
-#pragma unroll
-  for (int k = 0; k < DmaCfg<MT>::PER_WAVE; ++k) {
-    const int piece = wave + 8 * k;
-    if (k < 3) {                                          // x halo: pixels 8*piece .. 8*piece+7 of the 10x18 tile
-      const int pix = piece * 8 + sub;
-      const int r = pix / HALO_W;
-      pg[k].r = r - 1; pg[k].c = pix - r * HALO_W - 1;
-      pg[k].coff = j.x_coff + (slot ^ (pix & 7)) * 8;
-      pg[k].valid = pix < HALO_PIX;
-    } else if (MT == 1) {                                 // dy4: lane l carries pixels 2l, 2l+1 (8 B each) of piece 24; others: zeros
-      const int pix = 2 * lane;
-      pg[k].r = pix >> 4; pg[k].c = pix & 15; pg[k].coff = 0; pg[k].valid = piece == 24;
-    } else {                                              // dy: pixels 8*(piece-24) .. of the 8x16 tile
-      const int pix = (piece - 24) * 8 + sub;
-      pg[k].r = pix >> 4; pg[k].c = pix & 15;
-      pg[k].coff = (slot ^ (pix & 7)) * 8 + (j.dy_mode == 0 ? j.dy_coff : 0);
-      pg[k].valid = true;
-    }
-  }
-}
+// Per-lane geometry of this wave's DMA pieces: piece k of the wave = piece index wave + 8k; k < 3 are x halo pieces (8 pixels x 128 B of the 10x18 halo),
+// k >= 3 dy pieces.  A lane's pixel inside a piece is sub = lane / 8 and its swizzled 16-byte chunk (lane & 7) ^ (pixel & 7) = (lane & 7) ^ sub for every
+// piece (a piece starts at a multiple of 8 pixels) - the rest is a handful of 32-bit operations per piece and tile.  Round 6: recomputed per tile from
+// an OPAQUE copy of `sub` instead of kept in registers per piece (5 pieces x row, column, offset, valid = 20 registers across the tile loop - the
+// compiler hoists whatever is loop-invariant - that the cross-tile fragment pipeline needs for its sixth fragment and does not have).
+struct LaneGeom { int sub, swz8; };
 
 // issue this wave's pieces of one tile into ring slot `stage_addr` (LDS byte address, wave-uniform)
 template <int MT>
-__device__ __forceinline__ void tile_issue(const DmaJob& j, const PieceGeom (&pg)[DmaCfg<MT>::PER_WAVE], int tile, unsigned stage_addr, int wave) {
+__device__ __forceinline__ void tile_issue(const DmaJob& j, const LaneGeom& lg, int tile, unsigned stage_addr, int wave, int lane) {
   const TileCoord tc = decode_tile(tile, j.tiles_x, j.tiles_y);
   const int n = j.n0 + tc.n;
   const int y0 = tc.ty * TH, x0 = tc.tx * TW;
   const unsigned long long zero = (unsigned long long)(uintptr_t)g_zero_page;
+  int sub = lg.sub;
+  asm volatile("" : "+v"(sub));
 #pragma unroll
   for (int k = 0; k < DmaCfg<MT>::PER_WAVE; ++k) {
     const int piece = wave + 8 * k;                       // wave-uniform
-    const int y = y0 + pg[k].r, x = x0 + pg[k].c;
-    const bool ok = pg[k].valid & ((unsigned)y < (unsigned)j.H) & ((unsigned)x < (unsigned)j.W);
+    int r, c, coff;
+    bool valid = true;
+    if (k < 3) {                                          // x halo: pixels 8*piece .. 8*piece+7 of the 10x18 tile
+      const int pix = piece * 8 + sub;
+      const int hr = (pix * 3641) >> 16;                  // pix / HALO_W for pix < 192
+      r = hr - 1; c = pix - hr * HALO_W - 1;
+      coff = j.x_coff + lg.swz8;
+      valid = pix < HALO_PIX;
+    } else if (MT == 1) {                                 // dy4: lane l carries pixels 2l, 2l+1 (8 B each) of piece 24; others: zeros
+      const int pix = 2 * lane;
+      r = pix >> 4; c = pix & 15; coff = 0; valid = piece == 24;
+    } else {                                              // dy: pixels 8*(piece-24) .. of the 8x16 tile
+      const int pix = (piece - 24) * 8 + sub;
+      r = pix >> 4; c = pix & 15;
+      coff = lg.swz8 + (j.dy_mode == 0 ? j.dy_coff : 0);
+    }
+    const int y = y0 + r, x = x0 + c;
+    const bool ok = valid & ((unsigned)y < (unsigned)j.H) & ((unsigned)x < (unsigned)j.W);
     unsigned long long base;
     unsigned e;                                           // element offset (every tensor of the path has < 2^31 elements)
     if (k < 3) {
       base = (unsigned long long)(uintptr_t)j.x;
-      e = (unsigned)(((n * j.H + y) * j.W + x) * j.x_cstride + pg[k].coff);
+      e = (unsigned)(((n * j.H + y) * j.W + x) * j.x_cstride + coff);
     } else if (MT == 1) {
       base = (unsigned long long)(uintptr_t)j.dy;
       e = (unsigned)(((n * j.H + y) * j.W + x) * 4);      // W is even: x+1 is in the image too
     } else {
       base = (unsigned long long)(uintptr_t)j.dy;
-      if (j.dy_mode == 0) e = (unsigned)(((n * j.H + y) * j.W + x) * j.dy_cstride + pg[k].coff);
-      else e = (unsigned)(((n * 2 * j.H + 2 * y + (j.dy_coff >> 1)) * (2 * j.W) + 2 * x + (j.dy_coff & 1)) * 64 + pg[k].coff);
+      if (j.dy_mode == 0) e = (unsigned)(((n * j.H + y) * j.W + x) * j.dy_cstride + coff);
+      else e = (unsigned)(((n * 2 * j.H + 2 * y + (j.dy_coff >> 1)) * (2 * j.W) + 2 * x + (j.dy_coff & 1)) * 64 + coff);
     }
     const unsigned long long src = ok ? base + 2ull * e : zero;
     dma16((const void*)(uintptr_t)src, __builtin_amdgcn_readfirstlane(stage_addr + piece * 1024));
@@ -176,17 +179,18 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   constexpr int NST = DmaCfg<MT>::NSTAGE, AHEAD = NST - 1, PW = DmaCfg<MT>::PER_WAVE;
-  PieceGeom pg[PW];
-  piece_geometry<MT>(pg, j, wave, lane);
+  const LaneGeom pg = {lane >> 3, ((lane & 7) ^ (lane >> 3)) * 8};
 #pragma unroll
   for (int k = 0; k < AHEAD; ++k)
-    if (k < ntiles) tile_issue<MT>(j, pg, t0 + k, lds0 + k * DSTAGE, wave);
+    if (k < ntiles) tile_issue<MT>(j, pg, t0 + k, lds0 + k * DSTAGE, wave, lane);
   int slot = 0;
   for (int t = 0; t < ntiles; ++t) {
     // tile t has landed once at most the pieces of the tiles issued after it are still in flight (per wave; counted
     // s_waitcnt immediates), then all waves meet
-    const int younger = (ntiles - 1 - t < AHEAD - 1) ? ntiles - 1 - t : AHEAD - 1;
-    if (younger >= 2) { if (PW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+    const int younger = (WGRAD_ABL == 1) ? 0 : (ntiles - 1 - t < AHEAD - 1) ? ntiles - 1 - t : AHEAD - 1;
+    static_assert(AHEAD - 1 <= 3, "counted waits below: up to three younger tiles");
+    if (younger >= 3) { if (PW == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); }
+    else if (younger == 2) { if (PW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
     else if (younger == 1) { if (PW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -195,7 +199,7 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     // vector-memory queue (5 pieces, 100-185 issue cycles each next to LDS reads: MI355X_MICROARCH.md) cannot feed the matrix pipe meanwhile;
     // staggered, one wave of every SIMD issues MFMAs while its sibling issues DMA.  The counted waits are unchanged (a wave's pieces of
     // tile t + AHEAD are still its youngest at the top of step t + 1), and so is every accumulation order.
-    const bool more = t + AHEAD < ntiles;
+    const bool more = WGRAD_ABL != 1 && t + AHEAD < ntiles;
     const int s2 = (slot + AHEAD >= NST) ? slot + AHEAD - NST : slot + AHEAD;
     const unsigned sb = lds0 + slot * DSTAGE;
     // 18 units (k-step ks, tap) of one B fragment (two transposed reads) and MT MFMAs.  Round 4: the fragment of unit u + RD is requested BEFORE the
@@ -230,11 +234,11 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
     // the kh = 0 waves' DMA pieces of tile t + AHEAD go out BEHIND the first fragment requests (their round trip runs under the DMA issue:
     // measured neutral against "in front"), the kh = 1 waves' at unit 9
     if (WGRAD_PIPE) __builtin_amdgcn_sched_barrier(0);
-    if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
+    if (more && (!WGRAD_STAGGER || kh == 0)) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave, lane);
 #pragma unroll
     for (int u = 0; u < 18; ++u) {
       const int ks = u / 9, tap = u - 9 * ks;
-      if (u == 9 && WGRAD_STAGGER && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave);
+      if (u == 9 && WGRAD_STAGGER && more && kh == 1) tile_issue<MT>(j, pg, t0 + t + AHEAD, lds0 + s2 * DSTAGE, wave, lane);
       if (u + RD < 18) Bq[(u + RD) % (RD + 1)] = load_b(u + RD);
 #if WGRAD_A1_SPREAD
       if (u >= 2 && u < 2 + MT) {        // the second k-step's A fragments, one dy tile per unit
@@ -253,9 +257,15 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
         const f32x4 b2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ab, ones, bacc, 0, 0, 0);
         bacc = (MT == 4 || w4 == 0) ? b2 : bacc;
       }
+      if (WGRAD_ABL != 2) {
 #pragma unroll
-      for (int ct = 0; ct < MT; ++ct)
-        acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][ct], Bq[u % (RD + 1)], acc[ct][tap], 0, 0, 0);
+        for (int ct = 0; ct < MT; ++ct)
+          acc[ct][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks][ct], Bq[u % (RD + 1)], acc[ct][tap], 0, 0, 0);
+      } else {                             // the stream alone: the fragment stays requested, nothing multiplies it
+        asm volatile("" :: "v"(Bq[u % (RD + 1)]));
+#pragma unroll
+        for (int ct = 0; ct < MT; ++ct) asm volatile("" :: "v"(A[ks][ct]));
+      }
 #if WGRAD_PIN
       if (MT == 4) {      // (1 MFMA, 1 transposed read) x 4: the unit's two to four reads travel between its four or five MFMAs
 #pragma unroll

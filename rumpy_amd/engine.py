@@ -8,6 +8,7 @@ reproduced (paths relative to /root/reference/rumpy):
   :107-124 (ResidualGroup), :24-44 (CALayer); SISR/models/advanced/common.py:23-75 (Upsampler, ResBlock);
   shared_framework/models/base_architecture.py:425-485 (loss.backward + Adam step).
 """
+import bisect
 import collections
 import ctypes as C
 import math
@@ -129,6 +130,113 @@ class _Plan:
         self.gout_stage = None
 
 
+def cut_wgrad_shares(units, nsh, job_cost=4.0):
+    """Cut the weight-gradient work of one launch into `nsh` shares, one per workgroup (= CU).  units: [(tiles, quad_key or None, q)] in layer order; returns per
+    unit its tile ranges [(t0, t1, share, prio)] (prio 0 jobs run first inside a share).  A range is a JOB of the kernel: tiles streamed through the ring, then
+    a K-half exchange and a 147 KB slab - a fixed cost of `job_cost` tiles (round 6, measured: a second job per workgroup = +8 us = 4 tiles of 1.9 us,
+    profiles/r06_wgrad.txt).
+
+    Plain units (quad_key None) form ONE tile sequence; a share may end one layer and begin the next.  The shares are cut to equal COST, tiles + job_cost per
+    job (round 6; equal tile counts until then: the launch ended with the workgroups that crossed a layer boundary, 8 us behind the others).
+
+    (round 6) ALIGNED units: the four output-channel tiles q = 0 .. 3 of an upsampler conv (64 -> 256 + pixel shuffle; same quad_key) read the SAME x tiles.  Cut
+    as part of the one sequence they ran on workgroups of different XCDs a third of a launch apart and x came out of HBM four times (170 MB of the 1,020 MB the
+    launch of a x4 net reads).  Here nq QUADS of workgroups - four of ONE XCD each (workgroup w runs on XCD w % 8) - take the aligned convs' tile sequence cut
+    into nq chunks, output-channel tile q on the q-th workgroup of the quad: the four start together, run in step, and x is read once into that XCD's L2.  The
+    other workgroups share the plain units; nothing is cut finer than before."""
+    T_all = sum(u[0] for u in units)
+    by_key = {}
+    for i, (nt, key, q) in enumerate(units):
+        if key is not None:
+            by_key.setdefault(key, []).append(i)
+    quads = [sorted(v, key=lambda i: units[i][2]) for v in by_key.values()
+             if len(v) == 4 and sorted(units[i][2] for i in v) == [0, 1, 2, 3] and len(set(units[i][0] for i in v)) == 1]
+    TA = sum(units[quad[0]][0] for quad in quads)                     # aligned tiles per output-channel tile
+    avg = T_all / nsh + job_cost
+    quad_share = lambda j, q: (j % 8) + 8 * ((j // 8) * 4 + q)
+    MIN_JOB = max(1, min(int(job_cost), T_all // (4 * nsh)))         # no job shorter than its own fixed cost - unless the launch is that small
+
+    def layout(nq):
+        """the cut with nq quads of workgroups on the aligned units (0: none aligned) -> (ranges per unit, cost of the most loaded share)"""
+        out = [None] * len(units)
+        use = quads if nq else []
+        aligned = set(i for quad in use for i in quad)
+        a_cost = {}
+        if use:
+            def chunks(CA):                                # the aligned sequence in chunks of cost <= CA (tiles + job_cost per conv a chunk touches)
+                res, c, cap = [[] for _ in use], 0, CA
+                for n, quad in enumerate(use):
+                    nt, t = units[quad[0]][0], 0
+                    while t < nt:
+                        if cap < job_cost + min(MIN_JOB, nt - t):
+                            c, cap = c + 1, CA
+                        take = min(nt - t, max(1, int(cap - job_cost)))
+                        if nt - t - take < MIN_JOB:
+                            take = nt - t
+                        res[n].append((t, t + take, c))
+                        cap -= job_cost + take
+                        t += take
+                return res, c + 1
+            lo, hi = 0.0, float(TA + job_cost * len(use) + 1)
+            for _ in range(40):
+                mid = 0.5 * (lo + hi)
+                lo, hi = (lo, mid) if chunks(mid)[1] <= nq else (mid, hi)
+            for quad, rs in zip(use, chunks(hi)[0]):
+                for q, i in enumerate(quad):
+                    out[i] = [(t, t1, quad_share(c, q), 0) for t, t1, c in rs]
+                    for t, t1, c in rs:
+                        a_cost[quad_share(c, q)] = a_cost.get(quad_share(c, q), 0.0) + t1 - t + job_cost
+        # the plain units: every share is filled up to the cost C - the smallest C all the work fits under (bisection over a greedy fill).  A share with
+        # aligned work takes plain work only if a quarter of the average is missing; no job of less than MIN_JOB tiles unless that is all a layer has left
+        rest = [i for i in range(len(units)) if i not in aligned]
+
+        def fill(C, commit):
+            it, t = 0, 0                                   # next plain tile: unit rest[it], tile t
+            res = [[] for _ in rest]
+            for k in range(nsh):
+                cap = C - a_cost.get(k, 0.0)
+                if k in a_cost and cap < 0.25 * avg:
+                    continue
+                while it < len(rest) and cap >= job_cost + min(MIN_JOB, units[rest[it]][0] - t):
+                    left = units[rest[it]][0] - t
+                    take = min(left, int(cap - job_cost))
+                    if left - take < MIN_JOB:
+                        take = left                        # (a rest of a layer too small for a job of its own goes along)
+                    res[it].append((t, t + take, k, 1))
+                    cap -= job_cost + take
+                    t += take
+                    if t >= units[rest[it]][0]:
+                        it, t = it + 1, 0
+            if it < len(rest):
+                return False
+            if commit:
+                for i, rs in zip(rest, res):
+                    out[i] = rs
+            return True
+        C = 0.0
+        if rest:
+            lo, hi = 0.0, 2.0 * (avg + job_cost) + max(units[i][0] for i in rest)
+            while not fill(hi, False):
+                hi *= 2.0
+            for _ in range(40):
+                mid = 0.5 * (lo + hi)
+                lo, hi = (lo, mid) if fill(mid, False) else (mid, hi)
+            fill(hi, True)
+            C = hi
+        cost = [0.0] * nsh
+        for rs in out:
+            for t, t1, k, prio in rs:
+                cost[k] += t1 - t + job_cost
+        return out, max(cost)
+    cands = [0]
+    if quads and nsh % 32 == 0:
+        ideal = (TA + job_cost * len(quads)) / avg                    # quads that would carry exactly the average cost
+        top = min(nsh // 4 - (1 if len(units) > 4 * len(quads) else 0), TA)      # (a quad of workgroups less when there is plain work as well)
+        cands = sorted(set(min(top, n) for n in list(range(int(ideal) - 1, int(ideal) + 3)) + [int(ideal * f) for f in (1.25, 1.5, 2.0)] if n >= 1)) if top >= 1 else [0]
+    best = min((layout(nq) for nq in cands), key=lambda oc: oc[1])     # the launch ends with its most loaded workgroup
+    return best[0]
+
+
 class SREngine:
     def __init__(self, spec, device, wgrad_pixels_per_job=8192):
         self.spec, self.device = spec, device
@@ -145,6 +253,7 @@ class SREngine:
         # data-parallel form (upper part first, its all-reduce under the rest) and the one-launch form run the SAME jobs: bitwise equal
         # gradients.  Set by the first backward pass with a gradient-ready hook / RUMPY_WGRAD_AB=1.
         self.wgrad_shares = os.environ.get('RUMPY_WGRAD_JOBS') != '1'
+        self.wgrad_align = os.environ.get('RUMPY_WGRAD_ALIGN', '1') != '0'       # the output-channel tiles of an upsampler conv on one XCD, in step (_emit_wgrad)
         self.wgrad_two_phase = os.environ.get('RUMPY_WGRAD_AB') == '1'
         self.use_block_kernel = os.environ.get('RUMPY_NO_BLOCK') != '1'    # residual blocks in one launch (conv_block.hip)
         self.batch_by_pointer = os.environ.get('RUMPY_BATCH_COPY') != '1'  # captured training step reads the caller's x / target through a pointer table; =1: A/B, copies into fixed buffers
@@ -1101,18 +1210,13 @@ class SREngine:
             share_ranges, share_counts, base_share = [None] * len(units4), {}, 0
             for grp in sorted(set(group_of)):
                 idx = [i for i in range(len(units4)) if group_of[i] == grp]
-                T = sum(units4[i][3] for i in idx)
-                nsh = max(1, min(int(os.environ.get('RUMPY_WGRAD_NSH', self.cus)), T))      # env: A/B runs of the share count
-                pos = 0
-                for i in idx:
-                    nt, rs, t = units4[i][3], [], 0
-                    while t < nt:                      # share k covers tiles [k T / nsh, (k+1) T / nsh) of the group's sequence
-                        k = min(nsh - 1, ((pos + t + 1) * nsh - 1) // T)
-                        t1 = min(nt, max(t + 1, ((k + 1) * T + nsh - 1) // nsh - pos))
-                        rs.append((t, t1, base_share + k))
-                        t = t1
-                    share_ranges[i] = rs
-                    pos += nt
+                T_all = sum(units4[i][3] for i in idx)
+                nsh = max(1, min(int(os.environ.get('RUMPY_WGRAD_NSH', self.cus)), T_all))      # env: A/B runs of the share count
+                # the four output-channel tiles of an upsampler conv (64 -> 256 + pixel shuffle) read the same x tiles: aligned units of cut_wgrad_shares
+                quad_of = lambda u: (id(u[0]), u[1]) if (self.wgrad_align and u[0].shuffle and u[0].cout == 256) else None
+                cut = cut_wgrad_shares([(units4[i][3], quad_of(units4[i]), units4[i][2]) for i in idx], nsh, float(os.environ.get('RUMPY_WGRAD_JOB_COST', 4.0)))
+                for i, rs in zip(idx, cut):
+                    share_ranges[i] = [(t, t1, base_share + k, prio) for t, t1, k, prio in rs]
                 share_counts[grp] = (base_share, nsh)
                 base_share += nsh
         u4 = 0
@@ -1123,7 +1227,7 @@ class SREngine:
             per = max(1, self.wgrad_pixels_per_job // (L.TILE_H * L.TILE_W))
             njob = max(1, (ntile + per - 1) // per)
             per = (ntile + njob - 1) // njob
-            fixed = [(t0, min(ntile, t0 + per), -1) for t0 in range(0, ntile, per)]
+            fixed = [(t0, min(ntile, t0 + per), -1, 1) for t0 in range(0, ntile, per)]
             cin_chunks = cv.cin // 64
             cout_tiles = cv.cout // 64 if mt == 4 else 1
             for ch in range(cin_chunks):
@@ -1140,7 +1244,7 @@ class SREngine:
         keyed = {4: [], 1: []}
         for li, (cv, x, dy, H, W, dy_mode, scale, mt, ch, ct, ranges, off) in enumerate(layout):
             sf = slab_floats[mt]
-            for k, (t0, t1, share) in enumerate(ranges):
+            for k, (t0, t1, share, prio) in enumerate(ranges):
                 if dy_mode == 0:
                     dcs, dco = cv.cout, ct * 64
                 elif dy_mode == 1:
@@ -1149,7 +1253,7 @@ class SREngine:
                     dcs, dco = 4, 0
                 # launch order: jobs that read the same x tiles (the cout tiles of one tile range) sit next to each other,
                 # so the x halo re-reads of an upsampler conv hit L2; slab addresses do not depend on the order
-                keyed[mt].append(((id(x), k, li, share), L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=0, n1=N,
+                keyed[mt].append(((id(x), k, li, share, prio), L.WgradJob(x=_ptr(x), dy=_ptr(dy), slab=base + 4 * (off + k * sf), n0=0, n1=N,
                                                               t0=t0, t1=t1, H=H, W=W, x_cstride=cv.cin, x_coff=ch * 64, dy_mode=dy_mode,
                                                               dy_cstride=dcs, dy_coff=dco, mt=mt)))
             items.append(L.ReduceItem(slab=base + 4 * off, slab_stride=sf, njobs=len(ranges), mt=mt,
@@ -1163,8 +1267,8 @@ class SREngine:
             jobs[mt] = [jb for _, jb in sorted(keyed[mt], key=lambda kj: (first_seen[kj[0][0]], kj[0][1], kj[0][2]))]
         plan.shares = None
         if share_ranges is not None:
-            # jobs in share order (within a share: layer order); first[s] = index of share s's first job
-            order = sorted(keyed[4], key=lambda kj: (kj[0][3], kj[0][2]))
+            # jobs in share order (within a share: the aligned jobs, then layer order); first[s] = index of share s's first job
+            order = sorted(keyed[4], key=lambda kj: (kj[0][3], kj[0][4], kj[0][2]))
             jobs[4] = [jb for _, jb in order]
             nshares = sum(n for _, n in share_counts.values())
             first = [0] * (nshares + 1)

@@ -807,3 +807,46 @@ def test_chain_geometries_by_image_width():
     assert lib.rumpy_res_chain_strips(16, 64, 64) == 256 and lib.rumpy_res_chain_strips(16, 64, 49) == 256 and lib.rumpy_res_chain_strips(3, 13, 60) == 12
     assert lib.rumpy_res_chain_strips(1, 64, 65) == 0 and lib.rumpy_res_chain_strips(1, 64, 0) == 0
     assert lib.rumpy_res_chain_work_bytes(16, 64) >= (32 + 256 + 2 * 256 * 32) * 4      # placement words + one 128-byte flag line per (strip, row half)
+
+
+def test_weight_gradient_share_cut_covers_balances_and_aligns():
+    """rumpy_amd.engine.cut_wgrad_shares (round 6): every unit's ranges cover its tiles once; the most loaded share (tiles + 4 tiles per job) is within 3 % of the
+    mean - the launch ends with it; the four output-channel tiles of an upsampler conv get the same ranges on four shares of one XCD (share % 8), before any
+    other job; the number of jobs does not grow."""
+    from rumpy_amd.engine import cut_wgrad_shares
+    JC = 4.0
+
+    def run(units, nsh, jc=JC):
+        out = cut_wgrad_shares(units, nsh, jc)
+        cost, jobs = [0.0] * nsh, 0
+        for (nt, key, q), rs in zip(units, out):
+            assert rs[0][0] == 0 and rs[-1][1] == nt and all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:])) and all(r[1] > r[0] for r in rs)
+            for t, t1, k, prio in rs:
+                assert 0 <= k < nsh
+                cost[k] += t1 - t + JC
+                jobs += 1
+        return out, cost, jobs
+
+    for plain, up1, up2 in [((576, 33), 576, 2304), ((288, 403), 288, 1152), ((576, 9), 576, 2304), ((576, 3), 576, 2304), ((18, 9), 18, 72)]:
+        units = [(plain[0], None, 0)] * plain[1] + [(up1, 'a', q) for q in range(4)] + [(up2, 'b', q) for q in range(4)]
+        out, cost, jobs = run(units, 256)
+        _, cost0, jobs0 = run([(nt, None, q) for nt, key, q in units], 256, 0.0)       # the cut of rounds 3-5: one sequence, equal tile counts
+        mean = sum(cost) / 256
+        assert max(cost) <= (1.03 * mean + JC if mean > 40 else mean + 2 * JC + 1), (max(cost), mean)      # (a few tiles per share: no job under 4 tiles)
+        assert max(cost) <= max(cost0) and (jobs <= jobs0 + 8 or mean <= 40), (max(cost), max(cost0), jobs, jobs0)
+        for key in ('a', 'b'):
+            quad = [rs for (nt, k, q), rs in zip(units, out) if k == key]
+            for r0, r1, r2, r3 in zip(*quad):
+                assert r0[:2] == r1[:2] == r2[:2] == r3[:2] and all(r[3] == 0 for r in (r0, r1, r2, r3))
+                assert len(set(r[2] % 8 for r in (r0, r1, r2, r3))) == 1 and len(set(r[2] for r in (r0, r1, r2, r3))) == 4
+        for (nt, k, q), rs in zip(units, out):
+            if k is None:
+                assert all(r[3] == 1 for r in rs)
+    # share counts a quad layout does not fit, a conv with other than four output-channel tiles: the plain cut
+    units = [(18, None, 0)] * 9 + [(18, 'a', q) for q in range(4)] + [(72, 'b', q) for q in range(3)]
+    out, cost, jobs = run(units, 7)
+    assert max(cost) <= 1.05 * sum(cost) / 7 + JC and all(r[3] == 1 for rs in out for r in rs)
+    out, cost, jobs = run([(2304, 'b', q) for q in range(4)], 256)      # a launch of aligned work only (the upper group of a two-phase plan): all 64 quads
+    assert max(cost) == 36 + JC and min(cost) == 36 + JC
+    out, cost, jobs = run([(5, None, 0)], 256)       # fewer tiles than shares: a tile per share beats one share with five
+    assert jobs == 5 and max(cost) == 1 + JC

@@ -866,6 +866,63 @@ def test_two_phase_weight_gradient_is_bitwise_the_single_launch_one(name, kw):
     assert torch.equal(net.flat_g.view(torch.int32), ref.view(torch.int32))
 
 
+@pytest.mark.parametrize('two_phase', [False, True])
+def test_weight_gradient_shares_cover_every_tile_once_and_align_the_upsampler_tiles(two_phase):
+    """The job table of the shared weight-gradient launch (SREngine._emit_wgrad): every (layer, output-channel tile) unit's jobs cover its tiles exactly
+    once; the four output-channel tiles of an upsampler conv (dy_mode 1: the same x tiles) get the SAME tile ranges, on four workgroups of one XCD
+    (workgroup index % 8), as the first jobs of their shares - x is read once per XCD instead of once per output-channel tile."""
+    from rumpy_amd import _lib as L
+    h = _handler('edsr', lr=1e-3, scale=4, num_blocks=4, res_scale=0.1)
+    net = h.net
+    net._ensure_engine()
+    eng = net.engine
+    if two_phase:
+        eng.set_two_phase()
+    N, hw = 32, 48
+    plan = eng.plan_for(N, hw, hw, True)
+    assert plan.shares is not None and plan.shares['n'] % 32 == 0
+    dev, n = plan.job_dev[4]
+    raw = dev.cpu().numpy().tobytes()
+    jobs = (L.WgradJob * n).from_buffer_copy(raw)
+    first = plan.shares['first'].cpu().tolist()
+    share_of = {}
+    for s_ in range(plan.shares['n']):
+        for k in range(first[s_], first[s_ + 1]):
+            share_of[k] = (s_, k - first[s_])
+    assert len(share_of) == n
+    units, slabs = {}, set()
+    for k in range(n):
+        j = jobs[k]
+        units.setdefault((j.x, j.dy, j.dy_mode, j.dy_coff, j.x_coff), []).append((j.t0, j.t1, k))
+        assert j.slab not in slabs
+        slabs.add(j.slab)
+    quads = {}
+    for (x, dy, mode, coff, xoff), rs in units.items():
+        j = jobs[rs[0][2]]
+        tiles = N * ((j.H + 7) // 8) * ((j.W + 15) // 16)
+        rs.sort()
+        assert rs[0][0] == 0 and rs[-1][1] == tiles and all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:])), (mode, coff, rs[:4])
+        if mode == 1:
+            quads.setdefault((x, dy), {})[coff] = rs
+    assert len(quads) == 2                                   # the two stages of the x4 upsampler
+    base = {g: lo for g, (lo, cnt) in plan.shares['groups'].items()}
+    for q in quads.values():
+        assert sorted(q) == [0, 1, 2, 3]
+        for r0, r1, r2, r3 in zip(q[0], q[1], q[2], q[3]):
+            assert r0[:2] == r1[:2] == r2[:2] == r3[:2]
+            where = [share_of[r[2]] for r in (r0, r1, r2, r3)]
+            lo = max(b for b in base.values() if b <= where[0][0])
+            assert len(set((w[0] - lo) % 8 for w in where)) == 1 and len(set(w[0] for w in where)) == 4, where
+            assert all(w[1] <= 1 for w in where), where      # first jobs of their shares (two convs: position 0 or 1)
+    # the work of the shares is even (the launch ends with its most loaded workgroup)
+    work = [0] * plan.shares['n']
+    for k in range(n):
+        work[share_of[k][0]] += jobs[k].t1 - jobs[k].t0
+    for g, (lo, cnt) in plan.shares['groups'].items():
+        w = work[lo:lo + cnt]
+        assert max(w) <= 1.05 * sum(w) / cnt + 1, (g, min(w), max(w), sum(w) / cnt)      # no workgroup more than 5 % over the average
+
+
 def test_bench_runs_with_two_ranks_sharing_the_gpu():
     """The N > 1 path of bench.py end to end on a 1-GPU box: two processes on cuda:0 over gloo (RUMPY_BENCH_ONE_DEVICE=1; RCCL refuses
     two ranks on one device).  Covers broadcast of the replicas, the two-phase weight gradient with the early all-reduce on the side
