@@ -19,7 +19,7 @@
 #define WGRAD_A1_SPREAD 1    // 0: A/B - the second k-step's A fragments requested in one go at unit 5 (+0.2-0.4 % spread out, same box)
 #endif
 #ifndef WGRAD_ABL
-#define WGRAD_ABL 0     // timing-only builds, results wrong by design (tests/tools/wgrad_time.py): 1 no DMA behind the prologue (MFMAs + fragment reads alone), 2 no MFMAs (the stream alone)
+#define WGRAD_ABL 0     // timing-only builds, results wrong by design (tests/tools/wgrad_time.py): 1 no DMA behind the prologue (MFMAs + fragment reads alone), 2 no MFMAs (the stream alone), 4 no slab stores
 #endif
 #ifndef WGRAD_NST
 #define WGRAD_NST 3     // ring slots of the 64-channel kernel: 3 x 40 KB, two tiles in flight (round 6: 4 slots = all 160 KB of a CU's LDS, three in flight - the stream alone
@@ -296,6 +296,7 @@ __device__ __forceinline__ void wgrad_dma_job(const rumpy_wgrad_job* __restrict_
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const f32x4 o = acc[ct][tap] + xch[(ct * 9 + tap) * 64];
+        if (WGRAD_ABL == 4) { bacc += o; continue; }
 #pragma unroll
         for (int e = 0; e < 4; ++e) slab[((16 * ct + 4 * g + e) * 9 + tap) * 64 + ci] = o[e];
       }
