@@ -444,13 +444,16 @@ def test_backward_of_a_stale_forward_pass_raises():
 
 
 def test_arbitrary_image_size_eval():
+    """odd image sizes: 37 x 53 (round 6: up to 64 columns the residual blocks run as ONE persistent launch, strips of 4 rows x 64 columns) and 37 x 70 (wider:
+    one launch per block over column tiles)"""
     h, oh = _pair('edsr', 504, eval_mode=True, scale=4, num_blocks=2)
-    x, _ = O.synthetic_batch(630, 1, lr_hw=(37, 53), scale=4)
-    out, _, _ = h.run_eval(x=x)
-    oout, _, _ = oh.run_eval(x)
-    assert out.shape == (1, 3, 148, 212)
-    assert self_psnr(out, oout) >= 60.0
-    assert 'rumpy_conv_block' in {op for op, _ in h.net.engine.plan_for(1, 37, 53, False, h.net.engine.eval_fmt).fwd}      # column tiles
+    for hw, op in (((37, 53), 'rumpy_res_chain'), ((37, 70), 'rumpy_conv_block')):
+        x, _ = O.synthetic_batch(630, 1, lr_hw=hw, scale=4)
+        out, _, _ = h.run_eval(x=x)
+        oout, _, _ = oh.run_eval(x)
+        assert out.shape == (1, 3, 4 * hw[0], 4 * hw[1])
+        assert self_psnr(out, oout) >= 60.0
+        assert op in {o for o, _ in h.net.engine.plan_for(1, hw[0], hw[1], False, h.net.engine.eval_fmt).fwd}, hw
 
 
 @pytest.mark.parametrize('name,kw', [('edsr', dict(scale=2, num_blocks=3, res_scale=0.1)), ('rcan', dict(scale=2, n_resgroups=1, n_resblocks=2, reduction=16))])
