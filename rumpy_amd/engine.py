@@ -1064,6 +1064,11 @@ class SREngine:
         strips = int(self.lib.rumpy_res_chain_strips(N, H, W))      # 6-row x 48-column strips for W <= 48, 4-row x 64-column strips for 48 < W <= 64 (round 6); 0: wider
         if not self.use_chain or self.wide or strips == 0 or strips > self.cus:
             return
+        # The 4-row strips of the 64-column geometry carry 1.5 x their MFMAs in halo rows (the 6-row strips 1.33 x) and have no conv at the outer end: against one
+        # launch per block over column tiles they win only where the chip is (nearly) full - EDSR x4, 64-px crops, same box: 192 strips +3.6 %, 256 +1 %, but
+        # 128 strips -7 %, 64 -9 % (profiles/r06_negative_results.txt).  The 48-column geometry wins at every batch measured (64 strips +8 %, 128 +7 %, 192 +7 %).
+        if W > 48 and 4 * strips < 3 * self.cus and os.environ.get('RUMPY_CHAIN_ANY_FILL') != '1':
+            return
 
         def chainable(a):
             if a.res_mode != 0 or a.pool or a.w1_f8 or a.col_tile or a.N != N or a.H != H or a.W != W:

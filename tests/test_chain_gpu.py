@@ -125,6 +125,7 @@ def test_edsr_training_at_the_shipped_crop_size_on_the_chain_equals_the_per_bloc
     RUMPY_NO_CHAIN=1 (column-tiled per-block launches) - losses, outputs, weights and the evaluation image bit for bit; the body-end conv stays its own launch"""
     kw = dict(scale=2, num_blocks=5, res_scale=0.1)
     res = []
+    monkeypatch.setenv('RUMPY_CHAIN_ANY_FILL', '1')        # 40 strips (the 4-crop case) and the 10 of the evaluation image are below the fill the engine asks for
     for no_chain in ('0', '1'):
         monkeypatch.setenv('RUMPY_NO_CHAIN', no_chain)
         h, _ = _pair('edsr', 516, sched=False, **kw)

@@ -172,10 +172,18 @@ def test_rcan_full_depth_gradient_parity():
     _full_depth_step('rcan', 522, 2, {}, 3e-2, 0.999)
 
 
-def test_edsr_baseline_full_depth_gradient_parity_at_the_shipped_crop_size():
+def test_edsr_baseline_full_depth_gradient_parity_at_the_shipped_crop_size(monkeypatch):
     """64 x 64 LR crops (Documentation/sample_config_files/div2k/edsr.toml:16,26 of the reference): wider than a 48-column strip.  Round 6: the 16 residual
-    blocks run as ONE persistent chain launch per direction on strips of 4 rows x 64 columns (conv_chain.hip, geometry G4); with RUMPY_NO_CHAIN=1 every block
-    runs the column-tiled one-launch kernel (two tiles of 32 columns) as before - both against the fp32 oracle"""
+    blocks run as ONE persistent chain launch per direction on strips of 4 rows x 64 columns (conv_chain.hip, geometry G4) where those fill at least three
+    quarters of the CUs (12 crops and more; below that the column-tiled per-block launches are faster: -7 % at 8 crops) - forced here for 4 crops
+    (RUMPY_CHAIN_ANY_FILL=1) so that the oracle step stays small; with RUMPY_NO_CHAIN=1 every block runs the column-tiled one-launch kernel (two tiles of 32
+    columns) as before - both against the fp32 oracle"""
+    h = _handler('edsr', scale=4)
+    h.net._ensure_engine()
+    eng = h.net.engine
+    assert 'rumpy_res_chain' not in [op for op, _ in eng.plan_for(4, 64, 64, True).fwd]            # 64 strips of 256 CUs: one launch per block
+    assert 'rumpy_res_chain' in [op for op, _ in eng.plan_for(3 * eng.cus // 64, 64, 64, True).fwd]      # three quarters of the CUs: the chain
+    monkeypatch.setenv('RUMPY_CHAIN_ANY_FILL', '1')
     h = _handler('edsr', scale=4)
     h.net._ensure_engine()
     plan = h.net.engine.plan_for(4, 64, 64, True)
@@ -443,11 +451,13 @@ def test_backward_of_a_stale_forward_pass_raises():
     assert not h.net(x1.cuda()).requires_grad          # eval mode: the evaluation plan, no autograd node
 
 
-def test_arbitrary_image_size_eval():
-    """odd image sizes: 37 x 53 (round 6: up to 64 columns the residual blocks run as ONE persistent launch, strips of 4 rows x 64 columns) and 37 x 70 (wider:
-    one launch per block over column tiles)"""
-    h, oh = _pair('edsr', 504, eval_mode=True, scale=4, num_blocks=2)
-    for hw, op in (((37, 53), 'rumpy_res_chain'), ((37, 70), 'rumpy_conv_block')):
+def test_arbitrary_image_size_eval(monkeypatch):
+    """odd image sizes: 37 x 53 and 37 x 70 - one launch per block over column tiles; 37 x 53 again with the 64-column chain forced (RUMPY_CHAIN_ANY_FILL=1:
+    one image is ten strips, far below the fill at which the engine picks that chain by itself)"""
+    for hw, op, force in (((37, 53), 'rumpy_conv_block', False), ((37, 70), 'rumpy_conv_block', False), ((37, 53), 'rumpy_res_chain', True)):
+        if force:
+            monkeypatch.setenv('RUMPY_CHAIN_ANY_FILL', '1')
+        h, oh = _pair('edsr', 504, eval_mode=True, scale=4, num_blocks=2)
         x, _ = O.synthetic_batch(630, 1, lr_hw=hw, scale=4)
         out, _, _ = h.run_eval(x=x)
         oout, _, _ = oh.run_eval(x)
