@@ -391,7 +391,8 @@ static int stream_blocks(size_t total_vec) {
   const size_t cap = (size_t)rumpy_device_cus() * 8;
   return (int)(b > cap ? cap : (b ? b : 1));
 }
-static bool ca_shape_ok(int C, int Cr) { return C > 0 && C <= CA_MAXC && C % 8 == 0 && 256 % (C / 8) == 0 && Cr > 0 && Cr <= 16; }
+// (round 6: C / 8 need not divide the 256 threads any more - 192 features: ca_bwd_reduce_kernel leaves the surplus threads idle, every other kernel indexes by vector)
+static bool ca_shape_ok(int C, int Cr) { return C > 0 && C <= CA_MAXC && C % 8 == 0 && Cr > 0 && Cr <= 16; }
 
 extern "C" int rumpy_ca_mlp_fwd(const rumpy_ca_mlp_fwd_args* p, void* stream) {
   if (!p || !p->pool || !p->w1 || !p->b1 || !p->w2 || !p->b2 || !p->mean || !p->hidden || !p->gate) { rumpy_set_error("rumpy_ca_mlp_fwd: null pointer"); return RUMPY_E_ARG; }

@@ -316,12 +316,12 @@ class SREngine:
             raise RuntimeError('rumpy_amd: tail conv needs %d input features (got %d)' % (self.feats, spec.tail.cin))
         if self.wide and (spec.cas() or any(it[0] != 'resblock' for it in spec.body)):
             # RCAN wider than 64 features (round 5): every conv on the Cin = 128 / 256 form of rumpy_conv3x3, the channel attention as its separate
-            # launches (pool sums from the conv's epilogue, rumpy_ca_fwd_fused, rumpy_ca_bwd_reduce / _fused: C <= 256 with C / 8 dividing 256). The
+            # launches (pool sums from the conv's epilogue, rumpy_ca_fwd_fused, rumpy_ca_bwd_reduce / _fused: C <= 256, a multiple of 8; 192 since round 6). The
             # one-launch RCAB kernels and the q-layer launches are 64-feature kernels.
             plain_ca = all(not getattr(ca, 'gen', False) for ca in spec.cas())
-            if self.feats not in (128, 256) or not plain_ca:
-                raise RuntimeError('rumpy_amd: n_feats > 64 is built for EDSR and for RCAN / QRCAN (styles "standard", "modulate") at 128 / 256 features; '
-                                   'styled channel attention and 192-feature channel attention are 64-feature kernels')
+            if not plain_ca:
+                raise RuntimeError('rumpy_amd: n_feats > 64 is built for EDSR and for RCAN / QRCAN (styles "standard", "modulate") at 128 / 192 / 256 '
+                                   'features; styled channel attention is a 64-feature kernel')
         for cv in spec.convs():
             if cv.kind == 'main' and (cv.cin not in (64, 128, 192, 256) or cv.cout % 64):
                 raise RuntimeError('rumpy_amd: conv %s %d->%d unsupported (Cin must be 64, 128, 192 or 256, Cout a multiple of 64)'

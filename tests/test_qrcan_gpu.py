@@ -189,13 +189,15 @@ def test_qrcan_with_other_q_layer_depths_against_oracle(depth, names):
     assert plan.qn_items and not plan.q_items
 
 
-def test_qrcan_at_128_features_against_oracle():
-    """QRCAN 'standard' + q-layers wider than 64 features (round 5): convs on the Cin = 128 kernels, channel attention as its separate launches with the
-    meta-attention gate multiplied in, q-layers (5 -> 64 -> 128) on the general-depth launches.  Weight seed 837: every squeeze-excite hidden unit
-    >= 7e-3 away from its ReLU threshold on these inputs (conditioning note of test_qrcan_train_steps_against_oracle)."""
+@pytest.mark.parametrize('feats,wseed', [(128, 837), (192, 837)])
+def test_qrcan_wider_than_64_features_against_oracle(feats, wseed):
+    """QRCAN 'standard' + q-layers wider than 64 features (round 5: 128; round 6: 192 = three input chunks, 24 channel vectors per pixel): convs on the wide
+    kernels, channel attention as its separate launches with the meta-attention gate multiplied in, q-layers (5 -> 64 -> F) on the general-depth launches.
+    Weight seed 837: every squeeze-excite hidden unit >= 7e-3 away from its ReLU threshold on these inputs at 128 features (conditioning note of
+    test_qrcan_train_steps_against_oracle)."""
     names = ['blur_sigma', 'noise_level', 'jpeg_q', 'extra_a', 'extra_b']
-    kw = dict(scale=2, n_feats=128, n_resgroups=2, n_resblocks=2, reduction=16)
-    h, oh = _pair(names, 837, **kw)
+    kw = dict(scale=2, n_feats=feats, n_resgroups=2, n_resblocks=2, reduction=16)
+    h, oh = _pair(names, wseed, **kw)
     keys = [(n, 'numeric') for n in names]
     for step in range(2):
         x, y = O.synthetic_batch(860 + step, 3, lr_hw=16, scale=2)
