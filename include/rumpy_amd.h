@@ -553,7 +553,7 @@ int rumpy_q_mlp_bwd_meta(const rumpy_q_mlp_item* items_device, int32_t nitems, i
  * layer but the last (nonlinearity=True, as QRCAB builds it: architectures.py:182-183), sigmoid behind the last.  n[0] = M (metadata), n[nlayers] = C;
  * every q-layer of a network has the same shape, stated by the caller (n, nlayers: HOST values).  acts: the post-ReLU outputs of layers 0 .. L-2 per
  * image, concatenated ([N, n[1] + .. + n[L-1]]).  N <= 64, every n <= 256, n[1] + .. + n[L] <= 448. */
-#define RUMPY_QN_MAX_LAYERS 4
+#define RUMPY_QN_MAX_LAYERS 8      /* (4 until round 6; the item's layout changed with it) */
 typedef struct {
   const float* w[RUMPY_QN_MAX_LAYERS]; const float* b[RUMPY_QN_MAX_LAYERS];
   float* gw[RUMPY_QN_MAX_LAYERS]; float* gb[RUMPY_QN_MAX_LAYERS];

@@ -27,8 +27,8 @@ class _QLayerParams(nn.Module):
     # conv1x1, Sigmoid; layer i maps to feats // (num_layers - i) units, or (feats - M) // (num_layers - i) + M when M > 15
     def __init__(self, feats, num_metadata, num_layers=2):
         super().__init__()
-        if not 1 <= num_layers <= 4:
-            raise RuntimeError('rumpy_amd: q-layers with %d FC layers are not implemented on the HIP path (1 .. 4)' % num_layers)
+        if not 1 <= num_layers <= 8:
+            raise RuntimeError('rumpy_amd: q-layers with %d FC layers are not implemented on the HIP path (1 .. 8)' % num_layers)
         layers, sizes, mult = [], [num_metadata], num_layers
         for i in range(num_layers):
             sizes.append((feats - num_metadata) // mult + num_metadata if num_metadata > 15 else feats // mult)

@@ -223,9 +223,12 @@ class QMlpItem(_S):
                 ('pad_', c_int32)]
 
 
+QN_MAX_LAYERS = 8            # include/rumpy_amd.h RUMPY_QN_MAX_LAYERS
+
+
 class QMlpNItem(_S):         # = rumpy_q_mlpn_item
-    _fields_ = [('w', c_void_p * 4), ('b', c_void_p * 4), ('gw', c_void_p * 4), ('gb', c_void_p * 4), ('acts', c_void_p), ('gate', c_void_p),
-                ('dzq', c_void_p), ('n', c_int32 * 5), ('nlayers', c_int32), ('scale', c_float), ('pad_', c_int32)]
+    _fields_ = [('w', c_void_p * QN_MAX_LAYERS), ('b', c_void_p * QN_MAX_LAYERS), ('gw', c_void_p * QN_MAX_LAYERS), ('gb', c_void_p * QN_MAX_LAYERS), ('acts', c_void_p),
+                ('gate', c_void_p), ('dzq', c_void_p), ('n', c_int32 * (QN_MAX_LAYERS + 1)), ('nlayers', c_int32), ('scale', c_float), ('pad_', c_int32)]
 
 
 class AdamHyper(_S):

@@ -75,8 +75,8 @@ class QLayerNParams:
         self.M, self.C = layers[0]['w'].shape[1], layers[-1]['w'].shape[0]
         self.widths = [self.M] + [l['w'].shape[0] for l in layers]
         self.hsum = sum(self.widths[1:-1])
-        if len(layers) > 4 or max(self.widths) > 256 or sum(self.widths[1:]) > 448:
-            raise RuntimeError('rumpy_amd: q-layer %s (widths %s) is beyond the HIP path (<= 4 layers of <= 256 units, <= 448 in all)' % (name, self.widths))
+        if len(layers) > L.QN_MAX_LAYERS or max(self.widths) > 256 or sum(self.widths[1:]) > 448:
+            raise RuntimeError('rumpy_amd: q-layer %s (widths %s) is beyond the HIP path (<= %d layers of <= 256 units, <= 448 in all)' % (name, self.widths, L.QN_MAX_LAYERS))
 
 
 class NetSpec:

@@ -1,4 +1,4 @@
-"""Golden fixtures G12 (meta-attention QRCAN) and G24 (the same with ParaCALayer's num_layers = 1 and 3: `num_layers_in_q_layer`,
+"""Golden fixtures G12 (meta-attention QRCAN) and G24 (the same with ParaCALayer's num_layers = 1, 3 and 6: `num_layers_in_q_layer`,
 attention_manipulators/architectures.py:162,182-183) from the REAL reference handler.
 
 Runs ONLY in the build container (needs /root/reference):   python tests/golden/make_golden_qrcan.py
@@ -74,3 +74,4 @@ if __name__ == '__main__':
     main()
     main(1, 'g24_qrcan_qdepth1_small_train.npz')
     main(3, 'g24_qrcan_qdepth3_small_train.npz')
+    main(6, 'g24_qrcan_qdepth6_small_train.npz')      # (round 6: the HIP path takes 1 .. 8 layers)

@@ -394,7 +394,7 @@ def test_qrcan_module_tree_has_the_reference_key_and_creation_order(golden_dir):
     with pytest.raises(RuntimeError):
         QRCAN(style='modulate', **kw)
     # ParaCALayer's num_layers other than 2: the REAL reference's keys (golden G24) and the oracle's seed-8 weights
-    for depth in (1, 3):
+    for depth in (1, 3, 6):
         g24 = np.load(os.path.join(golden_dir, 'g24_qrcan_qdepth%d_small_train.npz' % depth))
         torch.manual_seed(8)
         netd = QRCAN(style='standard', include_q_layer=True, num_metadata=5, num_layers_in_q_layer=depth, **kw)
@@ -404,7 +404,7 @@ def test_qrcan_module_tree_has_the_reference_key_and_creation_order(golden_dir):
         for (k, a), (k2, b) in zip(netd.state_dict().items(), od.state_dict().items()):
             assert k == k2 and torch.equal(a, b), k
     with pytest.raises(RuntimeError, match='FC layers'):
-        QRCAN(style='standard', include_q_layer=True, num_metadata=5, num_layers_in_q_layer=5, **kw)
+        QRCAN(style='standard', include_q_layer=True, num_metadata=5, num_layers_in_q_layer=9, **kw)
 
 
 @pytest.mark.parametrize('style', ['max_concat', 'mini_concat', 'extended_attention', 'softmax'])

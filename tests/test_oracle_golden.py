@@ -247,7 +247,7 @@ def test_g12_qrcan_meta_attention_oracle_matches_reference_handler(golden_dir):
     assert np.allclose(ev.numpy(), g['eval_out'], atol=1e-6) and abs(float(evl) - float(g['eval_loss'])) < 1e-6
 
 
-@pytest.mark.parametrize('depth', [1, 3])
+@pytest.mark.parametrize('depth', [1, 3, 6])
 def test_g24_qrcan_q_layer_depths_oracle_matches_reference_handler(golden_dir, depth):
     """the same with ParaCALayer's num_layers = 1 and 3 (`num_layers_in_q_layer`): key order, seed-8 initialisation, three training steps and one
     evaluation of the REAL reference QRCANHandler (tests/golden/make_golden_qrcan.py)"""

@@ -84,9 +84,10 @@ def test_q_mlp_kernels_against_torch(N, M, Hq):
     assert lib.rumpy_q_mlp_bwd_params(tab.data_ptr(), len(items), md.data_ptr(), N, M, 161, C, s) != 0
 
 
-@pytest.mark.parametrize('N,widths', [(7, (5, 64)), (32, (5, 21, 32, 64)), (64, (18, 33, 41, 64)), (3, (256, 192, 160, 64)), (9, (5, 16, 21, 32, 64)), (5, (5, 32, 64))])
+@pytest.mark.parametrize('N,widths', [(7, (5, 64)), (32, (5, 21, 32, 64)), (64, (18, 33, 41, 64)), (3, (256, 192, 160, 64)), (9, (5, 16, 21, 32, 64)), (5, (5, 32, 64)),
+                                      (6, (5, 10, 12, 16, 21, 32, 64)), (4, (7, 8, 9, 10, 12, 16, 21, 32, 64))])
 def test_general_depth_q_mlp_kernels_against_torch(N, widths):
-    """rumpy_q_mlpn_*: ParaCALayer with num_layers = 1, 3, 4 (and 2, where the gates must be BITWISE those of the two-layer kernels): gates, every
+    """rumpy_q_mlpn_*: ParaCALayer with num_layers = 1, 3, 4, 6, 8 (and 2, where the gates must be BITWISE those of the two-layer kernels): gates, every
     parameter gradient and the gradient at the metadata input against torch autograd; (256, 192, 160, 64) = three layers on the 256-entry embedding"""
     dev = torch.device('cuda:0')
     lib = L.lib()
@@ -163,10 +164,10 @@ def test_general_depth_q_mlp_kernels_against_torch(N, widths):
 
 
 @pytest.mark.parametrize('depth,names', [(1, ['blur_sigma', 'noise_level', 'jpeg_q']), (3, ['blur_sigma', 'noise_level', 'jpeg_q', 'extra_a', 'extra_b']),
-                                         (3, ['m%02d' % i for i in range(18)]), (4, ['qpi'])])
+                                         (3, ['m%02d' % i for i in range(18)]), (4, ['qpi']), (6, ['blur_sigma', 'noise_level', 'jpeg_q', 'extra_a', 'extra_b'])])
 def test_qrcan_with_other_q_layer_depths_against_oracle(depth, names):
     """`num_layers_in_q_layer` other than 2 (ParaCALayer num_layers, q_layer.py:13,22-41; VERDICT r4 missing 3): three training steps against the oracle
-    (pinned on the real reference handler for depths 1 and 3 by golden G24), every gradient checked at step 0, the q-layers' own among them"""
+    (pinned on the real reference handler for depths 1, 3 and 6 by golden G24; the HIP path takes 1 .. 8 layers since round 6), every gradient checked at step 0, the q-layers' own among them"""
     kw = dict(scale=2, n_feats=64, n_resgroups=2, n_resblocks=2, reduction=16, num_layers_in_q_layer=depth)
     h, oh = _pair(names, 826, **kw)
     M = len(names)
