@@ -936,6 +936,21 @@ def test_weight_gradient_shares_cover_every_tile_once_and_align_the_upsampler_ti
         assert max(w) <= 1.05 * sum(w) / cnt + 1, (g, min(w), max(w), sum(w) / cnt)      # no workgroup more than 5 % over the average
 
 
+def _run_ranks_on_one_device(cmd, env, timeout, root):
+    """bench.py with several ranks on ONE device - the one situation in which two persistent chains can each hold part of the chip (a chain wants every CU; the
+    dispatcher normally finishes one launch's workgroups before the next queue's, so this has not been seen in the rounds' runs): both would wait out the
+    0.5 s watchdog and a data-parallel rank raises, by design.  With one rank per GPU - the driver's scaling run - it cannot happen.  Such a run is repeated.
+    -> (return code, stdout, stderr)"""
+    import subprocess
+    for attempt in range(3):
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=root)
+        out, err = p.stdout.decode(), p.stderr.decode()
+        if p.returncode != 0 and 'timed out' in out + err and attempt < 2:
+            continue
+        break
+    return p.returncode, out, err
+
+
 def test_bench_runs_with_two_ranks_sharing_the_gpu():
     """The N > 1 path of bench.py end to end on a 1-GPU box: two processes on cuda:0 over gloo (RUMPY_BENCH_ONE_DEVICE=1; RCCL refuses
     two ranks on one device).  Covers broadcast of the replicas, the two-phase weight gradient with the early all-reduce on the side
@@ -948,9 +963,8 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29571', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
            '--no-cpu-baseline', '--settle-ms', '12']      # (the data-parallel settling phase: the same 10 steps on both ranks, no cold region)
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=root)
-    out = p.stdout.decode()
-    assert p.returncode == 0, out[-3000:]
+    rc, out, err = _run_ranks_on_one_device(cmd, env, 600, root)
+    assert rc == 0, (out + err)[-3000:]
     lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out[-3000:]
     d = json.loads(lines[0])
@@ -973,9 +987,8 @@ def test_bench_starts_its_own_ranks_when_called_plainly():
     for form, want in (('auto', None), ('early', 'early')):
         cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2', '--probe-steps', '2',
                '--no-cpu-baseline', '--settle-ms', '0', '--allreduce-form', form]
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
-        out = p.stdout.decode()
-        assert p.returncode == 0, (out + p.stderr.decode())[-3000:]
+        rc, out, err = _run_ranks_on_one_device(cmd, env, 600, root)
+        assert rc == 0, (out + err)[-3000:]
         lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
         assert len(lines) == 1, out[-3000:]
         d = json.loads(lines[0])
@@ -1001,16 +1014,8 @@ def test_bench_runs_with_eight_ranks_sharing_the_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     env.update(RUMPY_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--probe-steps', '1', '--no-cpu-baseline', '--settle-ms', '0']
-    for attempt in range(3):
-        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500, cwd=root)
-        out = p.stdout.decode()
-        # Eight ranks on ONE device is the one situation in which two chains can hold part of the chip each (a chain wants every CU; the dispatcher normally
-        # finishes one launch's workgroups before the next queue's, so this has not been seen in the rounds' runs): both then wait out the 0.5 s watchdog
-        # and a data-parallel rank raises, by design.  With one rank per GPU - the driver's scaling run - it cannot happen.  Such a run is repeated.
-        if p.returncode != 0 and 'timed out' in (out + p.stderr.decode()) and attempt < 2:
-            continue
-        break
-    assert p.returncode == 0, (out + p.stderr.decode())[-4000:]
+    rc, out, err = _run_ranks_on_one_device(cmd, env, 1500, root)
+    assert rc == 0, (out + err)[-4000:]
     lines = [l for l in out.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, out[-3000:]
     d = json.loads(lines[0])
