@@ -3,6 +3,11 @@
 #pragma once
 #include "common.hpp"
 
+#ifndef BLOCK_PRIO
+#define BLOCK_PRIO 1       // (round 6) a wave raises its issue priority (s_setprio) for the length of a sweep: when its sibling on the SIMD is in an epilogue or a
+                           // hand-off, the sweep's MFMAs and fragment reads win the arbitration.  0: A/B.  Same box: forward chain 224.6 -> 217.6 us, data-gradient
+                           // chain 234.9 -> 232.2, EDSR step +0.6 %; priority 3 = priority 1.  No arithmetic changes.
+#endif
 #ifndef BLOCK_PIN
 #define BLOCK_PIN 1        // (round 6) block_sweep's fragment reads pinned BETWEEN the MFMAs of the group before (0: in front of them, rounds 1-5; A/B same box:
                            // EDSR step 29.60 -> 29.75 k patches/s, conv_up 53.2 -> 51.7 us, forward chain 235.2 -> 232.7 us, RCAN +0.3 %; bitwise)
@@ -74,6 +79,7 @@ template <int ROWS, int FMT = RUMPY_FMT_BF16, class Hook = NoHook, int NC = 3, i
 __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8 (&F)[18], const unsigned char* lds, const unsigned (&off)[8][2],
                                             Hook hook = Hook()) {
   constexpr int NG = 6 * NC;            // (channel half, tap column, column tile) groups
+  if (BLOCK_PRIO) __builtin_amdgcn_s_setprio(BLOCK_PRIO);
   bf16x8 I[AHEAD + 1][ROWS + 2];
   auto load_group = [&](int grp, bf16x8 (&dst)[ROWS + 2]) {
     const int half = grp / (3 * NC), kx = (grp % (3 * NC)) / NC, c = grp % NC;
@@ -110,6 +116,7 @@ __device__ __forceinline__ void block_sweep(f32x4 (&acc)[ROWS][NC], const bf16x8
     __builtin_amdgcn_sched_barrier(0);   // a group's instructions stay inside the group
 #endif
   }
+  if (BLOCK_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // per-lane read bases of a phase: window row 0 = row `row0` of the image (COLS columns) at byte `buffer` of the LDS allocation, window

@@ -5,6 +5,7 @@
 // its packed values there and the strip leaves as whole 128-byte lines with non-temporal stores, one piece after every third MFMA group of
 // the NEXT strip's sweep (block_common.hpp::strip_stage; conv_block.hip).  The MFMA epilogue's own layout would store 32-byte pieces of 32
 // lines per wave-instruction: 1.3 TB/s on the 151 MB of the second upsampler conv (tests/tools/kbench.py up), with or without the shuffle.
+#define BLOCK_PRIO 0       // no raised priority for this kernel's sweeps (block_common.hpp, round 6): the stores of the previous strip ride inside them - 54.6 against 51.4 us with it
 #include "block_common.hpp"
 
 struct UpDev {
