@@ -105,6 +105,9 @@ __device__ __forceinline__ void f8_bases(unsigned (&fb)[8], unsigned buffer, int
 // 24, and 72 fragment registers instead of 112.  With 24 reads the fp8 sweep was LDS-bound (8 waves x 72 KB per first phase = 4608 clocks of
 // the CU's 128 B / clk against 3840 of matrix pipe per SIMD); with 18 it is 3456.
 // hook(i), i = 0 .. 8, runs after the MFMAs of step i have been issued.
+#ifndef F8_PRIO
+#define F8_PRIO 1          // (round 6) 0: A/B
+#endif
 typedef int f8_v32i __attribute__((ext_vector_type(32)));
 template <int ROWS, bool E5M2, class Hook = NoHook>
 __device__ __forceinline__ void f8_sweep(f32x4 (&acc)[ROWS][3], const f8_v8i (&A)[5], const unsigned char* lds, const unsigned (&fb)[8],
@@ -133,6 +136,7 @@ __device__ __forceinline__ void f8_sweep(f32x4 (&acc)[ROWS][3], const f8_v8i (&A
   auto win = [&](int r) {                 // C[r .. r + 1] as one operand
     return (f8_v8i){C[4 * r], C[4 * r + 1], C[4 * r + 2], C[4 * r + 3], C[4 * r + 4], C[4 * r + 5], C[4 * r + 6], C[4 * r + 7]};
   };
+  if (F8_PRIO) __builtin_amdgcn_s_setprio(F8_PRIO);      // the sweeping wave wins the SIMD's arbitration against its sibling's epilogue (block_common.hpp BLOCK_PRIO)
   load_r(0);
   load_c(0);
 #pragma unroll
@@ -153,6 +157,7 @@ __device__ __forceinline__ void f8_sweep(f32x4 (&acc)[ROWS][3], const f8_v8i (&A
     hook(3 * c + 2);
     if (c + 1 < 3) load_c(c + 1);
   }
+  if (F8_PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 // a row half's 3 strip rows of a 6 x 48-pixel bf16 image as 16-byte pieces (block_common.hpp::group_stage for an image without halo)
